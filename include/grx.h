@@ -1,0 +1,346 @@
+/*
+ * grx.h -- C ABI of the MI355X-native GRx legged-locomotion environment step.
+ *
+ * This library replaces, for ONE path, the closed Isaac Gym / PhysX tensor API that
+ * FFTAI/Wiki-GRx-Gym drives from Python.  The reference crosses its native boundary ~7 times
+ * per physics sub-step (70x per policy step):
+ *
+ *   gym.set_dof_actuation_force_tensor   legged_robot_fftai.py:67   (legged_robot.py:258)
+ *   gym.simulate                         legged_robot_fftai.py:68   (legged_robot.py:259)
+ *   gym.fetch_results                    legged_robot_fftai.py:70-71
+ *   gym.refresh_dof_state_tensor         legged_robot_fftai.py:73
+ *   gym.refresh_actor_root_state_tensor  legged_robot_fftai.py:74
+ *   gym.refresh_net_contact_force_tensor legged_robot_fftai.py:75
+ *   gym.refresh_rigid_body_state_tensor  legged_robot_fftai.py:76
+ *   gym.set_dof_state_tensor_indexed     legged_robot.py:737
+ *   gym.set_actor_root_state_tensor_indexed  legged_robot.py:782
+ *   gym.set_actor_root_state_tensor      legged_robot.py:796
+ *   gym.acquire_*_tensor + gymtorch.wrap_tensor   legged_robot.py:110-135, gymtorch.py:61-73,
+ *                                                 gymtorch.cpp:33-158
+ *
+ * and runs the whole of LeggedRobot.step() (legged_robot.py:222-246) as O(400) small torch
+ * kernels.  Here the boundary is coarser: ONE call per policy step (grx_step) runs clip-actions,
+ * the 10 PD+dynamics+contact sub-steps, state update, termination, the reward terms, masked
+ * in-kernel reset and the observation build as hand-written HIP kernels for gfx950.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative grx_status otherwise; the message is
+ *     available from grx_last_error() (thread-local).
+ *   - the library owns every device buffer for the life of the handle; grx_tensor() hands out
+ *     NON-OWNING device pointers (the gymtorch.wrap_tensor model, gymtorch.py:61-73).
+ *   - caller-provided device pointers (actions, injected noise) are borrowed for the call.
+ *   - all work is enqueued on the caller's stream (void* = hipStream_t); no internal threads.
+ *   - one handle per process/GPU; a handle is not thread-safe.
+ *   - no torch types, no C++ types: plain pointers, sizes and PODs only.
+ */
+#ifndef GRX_H_
+#define GRX_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRX_ABI_VERSION 1
+
+#define GRX_MAX_BODIES 36   /* moving bodies after merging fixed joints (base + DOFs) */
+#define GRX_MAX_DOFS 32
+#define GRX_MAX_SPHERES 48  /* collision spheres (primitive URDF shapes -> sphere sets) */
+#define GRX_NUM_FEET 2
+#define GRX_NUM_CMD 3
+#define GRX_MAX_HEIGHT_POINTS 128
+
+typedef enum grx_status {
+    GRX_OK = 0,
+    GRX_ERR_INVALID_ARGUMENT = -1,
+    GRX_ERR_UNSUPPORTED_MODEL = -2, /* tree topology the HIP kernels are not specialised for */
+    GRX_ERR_HIP = -3,               /* a HIP runtime call or kernel launch failed */
+    GRX_ERR_NO_DEVICE = -4,
+    GRX_ERR_OUT_OF_MEMORY = -5,
+    GRX_ERR_ABI_MISMATCH = -6
+} grx_status;
+
+/* Reward terms, in ALPHABETICAL order: the reference iterates class_to_dict(cfg.rewards.scales)
+ * (helpers.py:42-57, dir() order) in legged_robot.py:845-866, so rew_buf is accumulated in
+ * this order (legged_robot.py:362-366).  Formulas: legged_robot_fftai.py:180-352, gr1t1.py:338-589. */
+typedef enum grx_reward_term {
+    GRX_REW_ACTION_DIFF = 0,
+    GRX_REW_ACTION_DIFF_DIFF,
+    GRX_REW_ACTION_DIFF_KNEE,
+    GRX_REW_CMD_DIFF_ANG_VEL_PITCH,
+    GRX_REW_CMD_DIFF_ANG_VEL_ROLL,
+    GRX_REW_CMD_DIFF_ANG_VEL_YAW,
+    GRX_REW_CMD_DIFF_BASE_HEIGHT,
+    GRX_REW_CMD_DIFF_BASE_ORIENT,
+    GRX_REW_CMD_DIFF_FOREHEAD_ORIENT,
+    GRX_REW_CMD_DIFF_LIN_VEL_X,
+    GRX_REW_CMD_DIFF_LIN_VEL_Y,
+    GRX_REW_CMD_DIFF_LIN_VEL_Z,
+    GRX_REW_CMD_DIFF_TORSO_ORIENT,
+    GRX_REW_COLLISION,
+    GRX_REW_DOF_ACC_NEW,
+    GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP,
+    GRX_REW_DOF_TOR_NEW,
+    GRX_REW_DOF_TOR_NEW_HIP_ROLL,
+    GRX_REW_DOF_VEL_NEW,
+    GRX_REW_DOF_VEL_NEW_KNEE,
+    GRX_REW_FEET_AIR_FORCE,
+    GRX_REW_FEET_AIR_HEIGHT,
+    GRX_REW_FEET_AIR_TIME,
+    GRX_REW_FEET_LAND_TIME,
+    GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND,
+    GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET,
+    GRX_REW_FEET_STUMBLE,
+    GRX_REW_LIMITS_ACTIONS,
+    GRX_REW_LIMITS_DOF_POS,
+    GRX_REW_LIMITS_DOF_TOR,
+    GRX_REW_LIMITS_DOF_VEL,
+    GRX_REW_ON_THE_AIR,
+    GRX_REW_POSE_OFFSET,
+    GRX_REW_POSE_OFFSET_HIP_YAW,
+    GRX_REW_STAND_STILL,
+    GRX_REW_TERMINATION,
+    GRX_NUM_REWARD_TERMS
+} grx_reward_term;
+
+/* sphere flags */
+#define GRX_SPH_FOOT_LEFT 0x1u   /* belongs to feet_indices[0] (first body whose name contains foot_name) */
+#define GRX_SPH_FOOT_RIGHT 0x2u
+#define GRX_SPH_TERMINATE 0x4u   /* body is in termination_contact_indices (legged_robot.py:1145-1161) */
+#define GRX_SPH_PENALISE 0x8u    /* body is in penalised_contact_indices  (legged_robot.py:1127-1143) */
+
+typedef enum grx_terrain_type { GRX_TERRAIN_PLANE = 0, GRX_TERRAIN_HEIGHTFIELD = 1 } grx_terrain_type;
+
+/* Robot model after merging fixed-joint subtrees into their moving ancestor.  Body 0 is the
+ * free-floating base (fix_base_link=False, legged_robot_config.py:119); body i>0 hangs from
+ * parent[i] < i by ONE revolute joint; DOF index of body i is i-1.  Replaces gym.load_asset +
+ * create_actor (legged_robot.py:966, 1022-1028). */
+typedef struct grx_model {
+    int32_t num_bodies;                      /* nb = 1 + num_dofs */
+    int32_t parent[GRX_MAX_BODIES];          /* parent[0] = -1 */
+    float joint_axis[GRX_MAX_BODIES][3];     /* unit axis in the child frame */
+    float joint_rot0[GRX_MAX_BODIES][9];     /* row-major R0: child(q=0)->parent rotation (URDF rpy) */
+    float joint_pos[GRX_MAX_BODIES][3];      /* child origin in parent frame (URDF xyz) */
+    float mass[GRX_MAX_BODIES];
+    float com[GRX_MAX_BODIES][3];            /* centre of mass, body frame */
+    float inertia[GRX_MAX_BODIES][6];        /* about COM, body axes: xx xy xz yy yz zz */
+    /* base_link alone (props[0] in legged_robot.py:618-648) for mass / COM randomisation:
+     * base lump = base_rest + base_link(randomised) */
+    float base_link_mass, base_link_com[3], base_link_inertia[6];
+    float base_rest_mass, base_rest_com[3], base_rest_inertia[6];
+    /* per-DOF properties (URDF <limit>, legged_robot.py:582-616) */
+    float dof_lower[GRX_MAX_DOFS], dof_upper[GRX_MAX_DOFS];
+    float dof_vel_limit[GRX_MAX_DOFS], dof_effort[GRX_MAX_DOFS];
+    /* collision spheres (URDF primitives -> spheres, DESIGN.md "contact geometry") */
+    int32_t num_spheres;
+    int32_t sph_body[GRX_MAX_SPHERES];
+    float sph_pos[GRX_MAX_SPHERES][3];       /* centre, body frame */
+    float sph_radius[GRX_MAX_SPHERES];
+    uint32_t sph_flags[GRX_MAX_SPHERES];
+    int32_t sph_link[GRX_MAX_SPHERES];       /* index of the URDF link (0..36) the shape belongs to: contact
+                                                forces are netted per LINK (contact_forces (N, nb, 3)) */
+    float sph_damp_max[GRX_MAX_SPHERES];     /* cap of the normal damping coefficient [N s/m]: alpha * m_eff / dt,
+                                                m_eff = effective mass of the carrying body at the sphere along
+                                                its z axis; keeps the explicit contact damping stable */
+    /* named frames the env pipeline reads from rigid_body_states */
+    int32_t foot_body[GRX_NUM_FEET];         /* moving body carrying *_foot_roll_link */
+    float foot_pos[GRX_NUM_FEET][3];         /* link-frame origin in that body's frame */
+    int32_t torso_body;                      /* -1: no body name contains torso_name */
+    float torso_rot[9];                      /* torso link -> body rotation, row-major */
+    int32_t forehead_body;
+    float forehead_rot[9];
+} grx_model;
+
+typedef struct grx_contact_params {
+    float kn;        /* normal stiffness per sphere [N/m] */
+    float dn;        /* Hunt-Crossley damping factor [s/m]: fn = kn*d*(1 + dn*ddot) */
+    float kt;        /* tangential (anchor spring) stiffness, foot spheres [N/m] */
+    float ct;        /* tangential damping [N s/m] */
+    float cv;        /* viscous friction coefficient of non-foot spheres [N s/m] */
+    float k_limit;   /* joint-limit spring: torque = k_limit*effort*(violation) [1/rad] */
+    float c_limit;   /* joint-limit damper, relative to the spring [s] */
+    float damp_alpha; /* sph_damp_max = damp_alpha * m_eff / sim_dt */
+    float terrain_friction;      /* legged_robot_config.py:77-78 */
+} grx_contact_params;
+
+typedef struct grx_config {
+    int32_t abi_version;         /* must be GRX_ABI_VERSION */
+    int32_t struct_size;         /* sizeof(grx_config) */
+    int32_t num_envs;            /* envs owned by THIS handle (one rank) */
+    int32_t env_offset;          /* global index of local env 0 (rank * num_envs) */
+    int32_t total_envs;          /* global env count (terrain_types uses the global index, legged_robot.py:1177-1180) */
+    uint64_t seed;
+
+    grx_model model;
+    grx_contact_params contact;
+
+    /* sim (legged_robot_config.py:35-52, gr1t1_config.py:11-12,185) */
+    float sim_dt;                /* 0.002 */
+    int32_t decimation;          /* 10 */
+    float gravity[3];
+
+    /* control (legged_robot.py:679-715, gr1t1_lower_limb_config.py:20-35) */
+    float kp[GRX_MAX_DOFS], kd[GRX_MAX_DOFS];
+    float default_dof_pos[GRX_MAX_DOFS];
+    float action_scale;
+    float clip_actions_min[GRX_MAX_DOFS], clip_actions_max[GRX_MAX_DOFS]; /* legged_robot_fftai.py:171-177 */
+
+    /* episode / commands (legged_robot.py:91-104, 650-677) */
+    float max_episode_length;    /* ceil(episode_length_s / dt) */
+    float max_episode_length_s;
+    int32_t resample_command_interval;
+    float cmd_lin_vel_x[2], cmd_lin_vel_y[2], cmd_ang_vel_yaw[2];
+
+    /* initial state (gr1t1_config.py:88-92) */
+    float init_pos[3], init_rot[4], init_lin_vel[3], init_ang_vel[3];
+
+    /* domain randomisation (legged_robot_config.py:177-206) */
+    int32_t randomize_friction;      float friction_range[2];
+    int32_t randomize_restitution;   float restitution_range[2];   /* stored; contact model has e=0 */
+    int32_t randomize_base_mass;     float base_mass_range[2];
+    int32_t randomize_base_com;      float base_com_range[3][2];
+    int32_t randomize_motor_strength; float motor_strength_range[2];
+    int32_t push_robots;             int32_t push_interval; float max_push_vel_xy;
+    int32_t randomize_init_dof_pos;
+    int32_t randomize_init_base_velocity;
+
+    /* rewards (gr1t1_config.py:187-259, gr1t1_lower_limb_config.py:40-80) */
+    float reward_scale[GRX_NUM_REWARD_TERMS];   /* raw cfg scale; the library multiplies by dt (legged_robot.py:850) */
+    float reward_sigma[GRX_NUM_REWARD_TERMS];
+    int32_t only_positive_rewards;
+    float base_height_target, swing_feet_height_target, feet_stumble_ratio;
+    float feet_air_time_target, feet_land_time_max;
+    float soft_dof_pos_limit, soft_dof_vel_limit, soft_torque_limit;
+    uint32_t knee_mask, hip_roll_mask, hip_yaw_mask, ankle_left_mask, ankle_right_mask; /* DOF bitmasks, gr1t1.py:127-279 */
+
+    /* observations (gr1t1.py:281-336, gr1t1_config.py:261-283) */
+    int32_t num_obs, num_pri_obs;
+    float obs_scale_action, obs_scale_lin_vel, obs_scale_ang_vel, obs_scale_gravity;
+    float obs_scale_dof_pos, obs_scale_dof_vel, obs_scale_height;
+    int32_t add_noise; float noise_level;
+    float noise_action, noise_lin_vel, noise_ang_vel, noise_gravity, noise_dof_pos, noise_dof_vel, noise_height;
+    float clip_observations;
+
+    /* termination (legged_robot.py:336-353) */
+    float termination_force;     /* 1.0 N */
+    float termination_gravity_z; /* 0.33 */
+
+    /* terrain (legged_robot_config.py:65-110, terrain.py:38-164, legged_robot.py:1163-1274) */
+    int32_t terrain_type;        /* grx_terrain_type */
+    int32_t measure_heights;
+    int32_t num_height_points;   /* 121 */
+    float height_points[GRX_MAX_HEIGHT_POINTS][2]; /* base-frame xy, meshgrid(x,y) order (legged_robot.py:1219-1233) */
+    const int16_t* height_samples; /* HOST pointer, (hf_rows, hf_cols) row-major; copied at create */
+    int32_t hf_rows, hf_cols;
+    float horizontal_scale, vertical_scale, border_size;
+    int32_t curriculum;
+    int32_t num_terrain_rows, num_terrain_cols; /* levels, types */
+    int32_t max_init_terrain_level;
+    const float* terrain_origins;  /* HOST pointer, (rows, cols, 3); copied at create */
+    float terrain_length;          /* env_length: curriculum move-up threshold */
+    float env_spacing;             /* plane grid (legged_robot.py:1187-1195) */
+} grx_config;
+
+typedef enum grx_tensor_id {
+    /* step outputs, row-major (N, k) */
+    GRX_T_OBS = 0,            /* f32 (N, num_obs) */
+    GRX_T_PRI_OBS,            /* f32 (N, num_pri_obs) */
+    GRX_T_REW,                /* f32 (N) */
+    GRX_T_RESET,              /* u8  (N)  bool */
+    GRX_T_TIME_OUT,           /* u8  (N)  bool */
+    GRX_T_EPISODE_LENGTH,     /* i64 (N)  caller-writable (on_policy_runner.py:126) */
+    /* simulation state; (N, k) views with strides (1, N) over SoA storage */
+    GRX_T_DOF_POS,            /* f32 (N, nd) */
+    GRX_T_DOF_VEL,            /* f32 (N, nd) */
+    GRX_T_TORQUES,            /* f32 (N, nd)  torque of the LAST sub-step */
+    GRX_T_ACTIONS,            /* f32 (N, nd)  clipped */
+    GRX_T_LAST_ACTIONS,       /* f32 (N, nd) */
+    GRX_T_LAST_DOF_VEL,       /* f32 (N, nd) */
+    GRX_T_COMMANDS,           /* f32 (N, 3) */
+    GRX_T_ROOT_STATES,        /* f32 (N, 13)  p3 q4(xyzw) v3 w3, world frame */
+    GRX_T_BASE_LIN_VEL,       /* f32 (N, 3)   base frame */
+    GRX_T_BASE_ANG_VEL,       /* f32 (N, 3) */
+    GRX_T_PROJECTED_GRAVITY,  /* f32 (N, 3) */
+    GRX_T_FEET_CONTACT_FORCE, /* f32 (N, 2, 3) net contact force on the foot links, last sub-step */
+    GRX_T_FEET_POS,           /* f32 (N, 2, 3) world position of the foot link origins */
+    GRX_T_FEET_HEIGHT,        /* f32 (N, 2) */
+    GRX_T_FEET_AIR_TIME,      /* f32 (N, 2) */
+    GRX_T_FEET_LAND_TIME,     /* f32 (N, 2) */
+    GRX_T_FEET_CONTACT,       /* u8  (N, 2) */
+    GRX_T_AVG_FEET_FORCE,     /* f32 (N, 2)   sub-step averaged |F| (legged_robot_fftai.py:79,86) */
+    GRX_T_AVG_FEET_SPEED,     /* f32 (N, 2, 3) sub-step averaged |v| */
+    GRX_T_MEASURED_HEIGHTS,   /* f32 (N, nh) */
+    GRX_T_BASE_HEIGHTS_OFFSET,/* f32 (N) */
+    GRX_T_EPISODE_SUMS,       /* f32 (GRX_NUM_REWARD_TERMS, N) */
+    GRX_T_REWARD_TERMS,       /* f32 (GRX_NUM_REWARD_TERMS, N) last step's r_i*scale_i*dt */
+    GRX_T_TERRAIN_LEVELS,     /* i32 (N) */
+    GRX_T_TERRAIN_TYPES,      /* i32 (N) */
+    GRX_T_ENV_ORIGINS,        /* f32 (N, 3) */
+    GRX_T_MOTOR_STRENGTH,     /* f32 (N, nd) */
+    GRX_T_FRICTION,           /* f32 (N) */
+    GRX_T_BASE_MASS_COM,      /* f32 (N, 4)  randomised base_link mass, com xyz */
+    GRX_T_TERM_CONTACT,       /* u8  (N) any terminating body touched the ground, last sub-step */
+    GRX_T_EPISODE_STATS,      /* f32 (GRX_NUM_REWARD_TERMS + 1): mean episode sums of the envs reset
+                                 by the last step that reset any (legged_robot.py:420-424), [NT] = count */
+    GRX_T_ANCHORS,            /* f32 (N, 8, 3) foot-sphere friction anchors xy + active flag */
+    GRX_NUM_TENSORS
+} grx_tensor_id;
+
+typedef enum grx_dtype { GRX_F32 = 0, GRX_U8 = 1, GRX_I32 = 2, GRX_I64 = 3 } grx_dtype;
+
+typedef struct grx_tensor_desc {
+    void* data;           /* device pointer (host pointer for the CPU oracle build) */
+    int32_t dtype;        /* grx_dtype */
+    int32_t ndim;
+    int64_t shape[4];
+    int64_t stride[4];    /* in elements */
+} grx_tensor_desc;
+
+typedef struct grx_sim* grx_handle;
+
+/* Optional per-step inputs; all pointers may be NULL. */
+typedef struct grx_step_args {
+    const float* actions;      /* device, (N, nd) row-major contiguous -- legged_robot.py:222 */
+    float delay_substeps;      /* sub-steps (real valued) that still use last_actions: "deci < delay"
+                                  (legged_robot_fftai.py:53-61); the host draws max(0, N(5,2)) */
+    int64_t common_step_counter; /* value AFTER increment (legged_robot.py:281); pushes fire when
+                                  counter % push_interval == 0 (legged_robot.py:333) */
+    const float* noise_uniform;/* device (N, num_obs) uniforms in [0,1) replacing the internal
+                                  Philox stream for obs noise (parity tests); NULL = internal */
+} grx_step_args;
+
+/* create / destroy.  device_id: HIP device ordinal. */
+int grx_create(const grx_config* cfg, int device_id, grx_handle* out);
+int grx_destroy(grx_handle h);
+
+/* reset every env (BaseTask.reset() first half, base_task.py:117-119) without stepping */
+int grx_reset_all(grx_handle h, void* stream);
+
+/* one policy step = LeggedRobot.step() (legged_robot.py:222-246) */
+int grx_step(grx_handle h, const grx_step_args* args, void* stream);
+
+/* non-owning view of a library buffer */
+int grx_tensor(grx_handle h, int tensor_id, grx_tensor_desc* out);
+
+/* overwrite simulation state of ALL envs from device buffers (any may be NULL = keep):
+ * the set_dof_state_tensor / set_actor_root_state_tensor role (legged_robot.py:737, 796).
+ * Layouts: root (N,13) row-major, dof_pos/dof_vel (N,nd) row-major. */
+int grx_set_state(grx_handle h, const float* root_states, const float* dof_pos,
+                  const float* dof_vel, void* stream);
+
+/* copy GRX_T_EPISODE_STATS to host (synchronises the stream) */
+int grx_episode_stats(grx_handle h, float* host_out, void* stream);
+
+/* average duration [ms] of the fused step kernel over the launches since the last call, measured
+ * with HIP events recorded on the launch stream (bench.py roofline leg); resets the window. */
+int grx_kernel_time_ms(grx_handle h, int enable, float* avg_ms, int64_t* launches);
+
+const char* grx_last_error(void);
+int grx_abi_version(void);
+const char* grx_reward_term_name(int term);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRX_H_ */

@@ -1,0 +1,173 @@
+"""ctypes mirror of include/grx.h (the C ABI of libgrx_hip.so).
+
+Field order and sizes must match the header exactly; ``grx_create`` rejects a mismatching
+``struct_size`` (GRX_ERR_ABI_MISMATCH) so drift fails loudly instead of corrupting memory.
+"""
+import ctypes as C
+
+GRX_ABI_VERSION = 1
+MAX_BODIES = 36
+MAX_DOFS = 32
+MAX_SPHERES = 48
+NUM_FEET = 2
+MAX_HEIGHT_POINTS = 128
+
+REWARD_TERMS = (
+    "action_diff", "action_diff_diff", "action_diff_knee", "cmd_diff_ang_vel_pitch",
+    "cmd_diff_ang_vel_roll", "cmd_diff_ang_vel_yaw", "cmd_diff_base_height", "cmd_diff_base_orient",
+    "cmd_diff_forehead_orient", "cmd_diff_lin_vel_x", "cmd_diff_lin_vel_y", "cmd_diff_lin_vel_z",
+    "cmd_diff_torso_orient", "collision", "dof_acc_new", "dof_tor_ankle_feet_lift_up", "dof_tor_new",
+    "dof_tor_new_hip_roll", "dof_vel_new", "dof_vel_new_knee", "feet_air_force", "feet_air_height",
+    "feet_air_time", "feet_land_time", "feet_speed_xy_close_to_ground",
+    "feet_speed_z_close_to_height_target", "feet_stumble", "limits_actions", "limits_dof_pos",
+    "limits_dof_tor", "limits_dof_vel", "on_the_air", "pose_offset", "pose_offset_hip_yaw",
+    "stand_still", "termination",
+)
+NUM_REWARD_TERMS = len(REWARD_TERMS)
+assert list(REWARD_TERMS) == sorted(REWARD_TERMS)  # alphabetical == the reference's dir() order
+
+SPH_FOOT_LEFT, SPH_FOOT_RIGHT, SPH_TERMINATE, SPH_PENALISE = 1, 2, 4, 8
+TERRAIN_PLANE, TERRAIN_HEIGHTFIELD = 0, 1
+
+TENSOR_IDS = (
+    "OBS", "PRI_OBS", "REW", "RESET", "TIME_OUT", "EPISODE_LENGTH", "DOF_POS", "DOF_VEL", "TORQUES",
+    "ACTIONS", "LAST_ACTIONS", "LAST_DOF_VEL", "COMMANDS", "ROOT_STATES", "BASE_LIN_VEL",
+    "BASE_ANG_VEL", "PROJECTED_GRAVITY", "FEET_CONTACT_FORCE", "FEET_POS", "FEET_HEIGHT",
+    "FEET_AIR_TIME", "FEET_LAND_TIME", "FEET_CONTACT", "AVG_FEET_FORCE", "AVG_FEET_SPEED",
+    "MEASURED_HEIGHTS", "BASE_HEIGHTS_OFFSET", "EPISODE_SUMS", "REWARD_TERMS", "TERRAIN_LEVELS",
+    "TERRAIN_TYPES", "ENV_ORIGINS", "MOTOR_STRENGTH", "FRICTION", "BASE_MASS_COM", "TERM_CONTACT",
+    "EPISODE_STATS", "ANCHORS",
+)
+T = {name: i for i, name in enumerate(TENSOR_IDS)}
+DTYPE_F32, DTYPE_U8, DTYPE_I32, DTYPE_I64 = 0, 1, 2, 3
+
+f32, i32, u32, u64, i64 = C.c_float, C.c_int32, C.c_uint32, C.c_uint64, C.c_int64
+
+
+class Model(C.Structure):
+    _fields_ = [
+        ("num_bodies", i32),
+        ("parent", i32 * MAX_BODIES),
+        ("joint_axis", (f32 * 3) * MAX_BODIES),
+        ("joint_rot0", (f32 * 9) * MAX_BODIES),
+        ("joint_pos", (f32 * 3) * MAX_BODIES),
+        ("mass", f32 * MAX_BODIES),
+        ("com", (f32 * 3) * MAX_BODIES),
+        ("inertia", (f32 * 6) * MAX_BODIES),
+        ("base_link_mass", f32), ("base_link_com", f32 * 3), ("base_link_inertia", f32 * 6),
+        ("base_rest_mass", f32), ("base_rest_com", f32 * 3), ("base_rest_inertia", f32 * 6),
+        ("dof_lower", f32 * MAX_DOFS), ("dof_upper", f32 * MAX_DOFS),
+        ("dof_vel_limit", f32 * MAX_DOFS), ("dof_effort", f32 * MAX_DOFS),
+        ("num_spheres", i32),
+        ("sph_body", i32 * MAX_SPHERES),
+        ("sph_pos", (f32 * 3) * MAX_SPHERES),
+        ("sph_radius", f32 * MAX_SPHERES),
+        ("sph_flags", u32 * MAX_SPHERES),
+        ("sph_link", i32 * MAX_SPHERES),
+        ("sph_damp_max", f32 * MAX_SPHERES),
+        ("foot_body", i32 * NUM_FEET),
+        ("foot_pos", (f32 * 3) * NUM_FEET),
+        ("torso_body", i32),
+        ("torso_rot", f32 * 9),
+        ("forehead_body", i32),
+        ("forehead_rot", f32 * 9),
+    ]
+
+
+class ContactParams(C.Structure):
+    _fields_ = [("kn", f32), ("dn", f32), ("kt", f32), ("ct", f32), ("cv", f32),
+                ("k_limit", f32), ("c_limit", f32), ("damp_alpha", f32), ("terrain_friction", f32)]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", i32), ("struct_size", i32),
+        ("num_envs", i32), ("env_offset", i32), ("total_envs", i32),
+        ("seed", u64),
+        ("model", Model),
+        ("contact", ContactParams),
+        ("sim_dt", f32), ("decimation", i32), ("gravity", f32 * 3),
+        ("kp", f32 * MAX_DOFS), ("kd", f32 * MAX_DOFS), ("default_dof_pos", f32 * MAX_DOFS),
+        ("action_scale", f32),
+        ("clip_actions_min", f32 * MAX_DOFS), ("clip_actions_max", f32 * MAX_DOFS),
+        ("max_episode_length", f32), ("max_episode_length_s", f32),
+        ("resample_command_interval", i32),
+        ("cmd_lin_vel_x", f32 * 2), ("cmd_lin_vel_y", f32 * 2), ("cmd_ang_vel_yaw", f32 * 2),
+        ("init_pos", f32 * 3), ("init_rot", f32 * 4), ("init_lin_vel", f32 * 3), ("init_ang_vel", f32 * 3),
+        ("randomize_friction", i32), ("friction_range", f32 * 2),
+        ("randomize_restitution", i32), ("restitution_range", f32 * 2),
+        ("randomize_base_mass", i32), ("base_mass_range", f32 * 2),
+        ("randomize_base_com", i32), ("base_com_range", (f32 * 2) * 3),
+        ("randomize_motor_strength", i32), ("motor_strength_range", f32 * 2),
+        ("push_robots", i32), ("push_interval", i32), ("max_push_vel_xy", f32),
+        ("randomize_init_dof_pos", i32), ("randomize_init_base_velocity", i32),
+        ("reward_scale", f32 * NUM_REWARD_TERMS), ("reward_sigma", f32 * NUM_REWARD_TERMS),
+        ("only_positive_rewards", i32),
+        ("base_height_target", f32), ("swing_feet_height_target", f32), ("feet_stumble_ratio", f32),
+        ("feet_air_time_target", f32), ("feet_land_time_max", f32),
+        ("soft_dof_pos_limit", f32), ("soft_dof_vel_limit", f32), ("soft_torque_limit", f32),
+        ("knee_mask", u32), ("hip_roll_mask", u32), ("hip_yaw_mask", u32),
+        ("ankle_left_mask", u32), ("ankle_right_mask", u32),
+        ("num_obs", i32), ("num_pri_obs", i32),
+        ("obs_scale_action", f32), ("obs_scale_lin_vel", f32), ("obs_scale_ang_vel", f32),
+        ("obs_scale_gravity", f32), ("obs_scale_dof_pos", f32), ("obs_scale_dof_vel", f32),
+        ("obs_scale_height", f32),
+        ("add_noise", i32), ("noise_level", f32),
+        ("noise_action", f32), ("noise_lin_vel", f32), ("noise_ang_vel", f32), ("noise_gravity", f32),
+        ("noise_dof_pos", f32), ("noise_dof_vel", f32), ("noise_height", f32),
+        ("clip_observations", f32),
+        ("termination_force", f32), ("termination_gravity_z", f32),
+        ("terrain_type", i32), ("measure_heights", i32), ("num_height_points", i32),
+        ("height_points", (f32 * 2) * MAX_HEIGHT_POINTS),
+        ("height_samples", C.c_void_p),
+        ("hf_rows", i32), ("hf_cols", i32),
+        ("horizontal_scale", f32), ("vertical_scale", f32), ("border_size", f32),
+        ("curriculum", i32), ("num_terrain_rows", i32), ("num_terrain_cols", i32),
+        ("max_init_terrain_level", i32),
+        ("terrain_origins", C.c_void_p),
+        ("terrain_length", f32), ("env_spacing", f32),
+    ]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("dtype", i32), ("ndim", i32),
+                ("shape", i64 * 4), ("stride", i64 * 4)]
+
+
+class StepArgs(C.Structure):
+    _fields_ = [("actions", C.c_void_p), ("delay_substeps", f32),
+                ("common_step_counter", i64), ("noise_uniform", C.c_void_p)]
+
+
+def bind(lib, prefix="grx_"):
+    """Declare argtypes/restypes of every entry point of include/grx.h on a loaded CDLL."""
+    H = C.c_void_p
+
+    def fn(name, restype, *argtypes):
+        f = getattr(lib, prefix + name)
+        f.restype = restype
+        f.argtypes = list(argtypes)
+        return f
+
+    api = {
+        "create": fn("create", C.c_int, C.POINTER(Config), C.c_int, C.POINTER(H)),
+        "destroy": fn("destroy", C.c_int, H),
+        "reset_all": fn("reset_all", C.c_int, H, C.c_void_p),
+        "step": fn("step", C.c_int, H, C.POINTER(StepArgs), C.c_void_p),
+        "tensor": fn("tensor", C.c_int, H, C.c_int, C.POINTER(TensorDesc)),
+        "set_state": fn("set_state", C.c_int, H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p),
+        "episode_stats": fn("episode_stats", C.c_int, H, C.POINTER(C.c_float), C.c_void_p),
+        "last_error": fn("last_error", C.c_char_p),
+        "abi_version": fn("abi_version", C.c_int),
+        "reward_term_name": fn("reward_term_name", C.c_char_p, C.c_int),
+    }
+    if hasattr(lib, prefix + "kernel_time_ms"):
+        api["kernel_time_ms"] = fn("kernel_time_ms", C.c_int, H, C.c_int, C.POINTER(C.c_float), C.POINTER(i64))
+    return api
+
+
+EXPORTED_SYMBOLS = (
+    "grx_create", "grx_destroy", "grx_reset_all", "grx_step", "grx_tensor", "grx_set_state",
+    "grx_episode_stats", "grx_kernel_time_ms", "grx_last_error", "grx_abi_version",
+    "grx_reward_term_name",
+)

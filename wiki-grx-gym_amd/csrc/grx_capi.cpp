@@ -1,0 +1,526 @@
+// grx_capi.cpp -- host side of the C ABI declared in include/grx.h (compiled with hipcc into
+// libgrx_hip.so together with grx_kernels.hip).  No torch, no Python: plain C entry points.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/grx.h"
+#include "grx_device.h"
+#include "grx_rng.h"
+
+extern "C" {
+void grx_launch_step(const KParams* dP, int N, int heightfield, const float* actions, float delay, long long common_step,
+                     const float* noise, hipStream_t stream);
+void grx_launch_finalize(const KParams* dP, int N, hipStream_t stream);
+void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream);
+void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, hipStream_t stream);
+int grx_envs_per_block(void);
+}
+
+namespace {
+constexpr int NT = GRX_NUM_REWARD_TERMS;
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(GRX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct Timing {
+    bool enabled = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+};
+}  // namespace
+
+struct grx_sim {
+    grx_config cfg;
+    int device = 0;
+    int N = 0;
+    KParams hp;            // host copy (device pointers inside)
+    KParams* dp = nullptr; // device copy
+    std::vector<void*> allocs;
+    uint32_t reset_count = 0;
+    Timing timing;
+    // tensor table
+    grx_tensor_desc desc[GRX_NUM_TENSORS];
+};
+
+namespace {
+
+template <typename T>
+int dalloc(grx_sim* s, T** out, size_t count) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+    if (e != hipSuccess) return fail(GRX_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemset(p, 0, (count ? count : 1) * sizeof(T));
+    if (e != hipSuccess) return fail(GRX_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    s->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return GRX_OK;
+}
+
+void set_desc(grx_tensor_desc* d, void* p, int dtype, int ndim, const int64_t* shape, const int64_t* stride) {
+    d->data = p;
+    d->dtype = dtype;
+    d->ndim = ndim;
+    for (int i = 0; i < 4; ++i) { d->shape[i] = i < ndim ? shape[i] : 1; d->stride[i] = i < ndim ? stride[i] : 1; }
+}
+// SoA [k][N] exposed as (N, k) with strides (1, N)
+void desc_soa(grx_sim* s, int id, void* p, int dtype, int64_t k) {
+    int64_t shape[2] = {s->N, k}, stride[2] = {1, s->N};
+    set_desc(&s->desc[id], p, dtype, 2, shape, stride);
+}
+void desc_soa3(grx_sim* s, int id, void* p, int64_t a, int64_t b) {  // [a*b][N] as (N, a, b)
+    int64_t shape[3] = {s->N, a, b}, stride[3] = {1, b * (int64_t)s->N, s->N};
+    set_desc(&s->desc[id], p, GRX_F32, 3, shape, stride);
+}
+void desc_vec(grx_sim* s, int id, void* p, int dtype, int64_t n) {
+    int64_t shape[1] = {n}, stride[1] = {1};
+    set_desc(&s->desc[id], p, dtype, 1, shape, stride);
+}
+void desc_rows(grx_sim* s, int id, void* p, int64_t rows, int64_t cols) {  // row-major
+    int64_t shape[2] = {rows, cols}, stride[2] = {cols, 1};
+    set_desc(&s->desc[id], p, GRX_F32, 2, shape, stride);
+}
+
+// the fused kernel is specialised for the GR1 lower-limb tree: base + two 5-joint chains with
+// axes x, z, y, y, y and unrotated joint frames (GR1T1_lower_limb.urdf / GR1T2_lower_limb.urdf)
+int check_topology(const grx_model& m) {
+    if (m.num_bodies != 1 + GRX_ND) return fail(GRX_ERR_UNSUPPORTED_MODEL, "HIP path supports 10-DOF lower-limb models (2 chains x 5 joints); got num_bodies=" + std::to_string(m.num_bodies));
+    static const int axes[GRX_LEG] = {0, 2, 1, 1, 1};
+    for (int side = 0; side < 2; ++side)
+        for (int k = 0; k < GRX_LEG; ++k) {
+            int b = 1 + side * GRX_LEG + k;
+            int want_parent = k == 0 ? 0 : b - 1;
+            if (m.parent[b] != want_parent) return fail(GRX_ERR_UNSUPPORTED_MODEL, "unsupported tree: body " + std::to_string(b) + " parent " + std::to_string(m.parent[b]));
+            for (int a = 0; a < 3; ++a) {
+                float want = a == axes[k] ? 1.f : 0.f;
+                if (fabsf(m.joint_axis[b][a] - want) > 1e-6f) return fail(GRX_ERR_UNSUPPORTED_MODEL, "unsupported joint axis on body " + std::to_string(b));
+            }
+            static const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            for (int a = 0; a < 9; ++a)
+                if (fabsf(m.joint_rot0[b][a] - I9[a]) > 1e-6f) return fail(GRX_ERR_UNSUPPORTED_MODEL, "rotated joint frame on body " + std::to_string(b));
+        }
+    for (int f = 0; f < 2; ++f)
+        if (m.foot_body[f] != (f + 1) * GRX_LEG) return fail(GRX_ERR_UNSUPPORTED_MODEL, "feet must be the chain leaves");
+    if (m.torso_body > 0 || m.forehead_body > 0) return fail(GRX_ERR_UNSUPPORTED_MODEL, "torso/forehead must ride on the base lump");
+    return GRX_OK;
+}
+
+int build_side_tables(const grx_config& c, KParams& P) {
+    const grx_model& m = c.model;
+    memset(P.side, 0, sizeof P.side);
+    for (int side = 0; side < 2; ++side) {
+        SideConst& S = P.side[side];
+        for (int k = 0; k < GRX_LEG; ++k) {
+            int b = 1 + side * GRX_LEG + k, j = b - 1;
+            for (int a = 0; a < 3; ++a) { S.r[k][a] = m.joint_pos[b][a]; S.com[k][a] = m.com[b][a]; }
+            for (int a = 0; a < 6; ++a) S.Ic[k][a] = m.inertia[b][a];
+            S.mass[k] = m.mass[b];
+            S.kp[k] = c.kp[j]; S.kd[k] = c.kd[j]; S.q0[k] = c.default_dof_pos[j];
+            S.effort[k] = m.dof_effort[j]; S.vlim[k] = m.dof_vel_limit[j];
+            S.qlo[k] = m.dof_lower[j]; S.qhi[k] = m.dof_upper[j];
+            S.Klim[k] = c.contact.k_limit * m.dof_effort[j];
+            S.Clim[k] = c.contact.c_limit * S.Klim[k];
+            S.amin[k] = c.clip_actions_min[j]; S.amax[k] = c.clip_actions_max[j];
+            float mid = (m.dof_lower[j] + m.dof_upper[j]) / 2, rng = m.dof_upper[j] - m.dof_lower[j];
+            S.slo[k] = mid - 0.5f * rng * c.soft_dof_pos_limit;
+            S.shi[k] = mid + 0.5f * rng * c.soft_dof_pos_limit;
+        }
+        for (int a = 0; a < 3; ++a) S.foot_pos[a] = m.foot_pos[side][a];
+    }
+    // spheres: chain spheres go to their side; base-lump spheres are split between the two lanes
+    // at a LINK boundary (per-link force netting must see a whole link on one lane)
+    std::vector<int> base_idx;
+    for (int i = 0; i < m.num_spheres; ++i) {
+        int b = m.sph_body[i];
+        if (b < 0 || b >= m.num_bodies) return fail(GRX_ERR_INVALID_ARGUMENT, "sphere body out of range");
+        if (b == 0) base_idx.push_back(i);
+        else if (m.sph_flags[i] & (GRX_SPH_TERMINATE | GRX_SPH_PENALISE))
+            return fail(GRX_ERR_UNSUPPORTED_MODEL, "terminating/penalised shapes must ride on the base lump");
+    }
+    // base_idx is sorted by link (model.py emits spheres sorted by (body, link)); cut near the middle
+    size_t cut = base_idx.size() / 2;
+    while (cut > 0 && cut < base_idx.size() && m.sph_link[base_idx[cut]] == m.sph_link[base_idx[cut - 1]]) ++cut;
+    int fill[2] = {0, 0};
+    auto push = [&](int side, int i, int slot) -> int {
+        SideConst& S = P.side[side];
+        if (fill[side] >= GRX_MAXSPH_SIDE) return fail(GRX_ERR_UNSUPPORTED_MODEL, "too many collision spheres per lane");
+        SphC& o = S.sph[fill[side]++];
+        o.x = m.sph_pos[i][0]; o.y = m.sph_pos[i][1]; o.z = m.sph_pos[i][2]; o.r = m.sph_radius[i];
+        o.flags = m.sph_flags[i]; o.slot = slot; o.link_last = 0; o.dmax = m.sph_damp_max[i];
+        return GRX_OK;
+    };
+    for (int side = 0; side < 2; ++side) {
+        SideConst& S = P.side[side];
+        S.sph_begin[0] = 0;
+        size_t lo = side == 0 ? 0 : cut, hi = side == 0 ? cut : base_idx.size();
+        for (size_t n = lo; n < hi; ++n) {
+            int rc = push(side, base_idx[n], -1);
+            if (rc) return rc;
+            bool last = (n + 1 == hi) || m.sph_link[base_idx[n + 1]] != m.sph_link[base_idx[n]];
+            S.sph[fill[side] - 1].link_last = last ? 1 : 0;
+        }
+        for (int k = 0; k < GRX_LEG; ++k) {
+            S.sph_begin[1 + k] = fill[side];
+            int b = 1 + side * GRX_LEG + k, slot = 0;
+            for (int i = 0; i < m.num_spheres; ++i) {
+                if (m.sph_body[i] != b) continue;
+                bool foot = m.sph_flags[i] & (side == 0 ? GRX_SPH_FOOT_LEFT : GRX_SPH_FOOT_RIGHT);
+                if (m.sph_flags[i] & (side == 0 ? GRX_SPH_FOOT_RIGHT : GRX_SPH_FOOT_LEFT))
+                    return fail(GRX_ERR_UNSUPPORTED_MODEL, "foot shape on the wrong chain");
+                if (foot && slot >= 4) return fail(GRX_ERR_UNSUPPORTED_MODEL, "more than 4 anchored spheres per foot");
+                int rc = push(side, i, foot ? slot++ : -1);
+                if (rc) return rc;
+            }
+        }
+        S.sph_begin[GRX_LEG + 1] = fill[side];
+    }
+    return GRX_OK;
+}
+
+// randomised base lump (oracle base_lump(); legged_robot.py:618-648)
+void base_lump(const grx_model& m, float link_mass, const float link_com[3], float* M_out, float c_out[3], float I_out[6]) {
+    float m1 = m.base_rest_mass, m2 = link_mass;
+    float scale = m.base_link_mass > 0 ? m2 / m.base_link_mass : 1.f;
+    float M = m1 + m2, c[3], I[6];
+    for (int i = 0; i < 3; ++i) c[i] = (m1 * m.base_rest_com[i] + m2 * link_com[i]) / M;
+    for (int i = 0; i < 6; ++i) I[i] = m.base_rest_inertia[i] + scale * m.base_link_inertia[i];
+    const float* cs[2] = {m.base_rest_com, link_com};
+    float ms[2] = {m1, m2};
+    for (int k = 0; k < 2; ++k) {
+        float d[3] = {cs[k][0] - c[0], cs[k][1] - c[1], cs[k][2] - c[2]};
+        float dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        I[0] += ms[k] * (dd - d[0] * d[0]); I[1] -= ms[k] * d[0] * d[1]; I[2] -= ms[k] * d[0] * d[2];
+        I[3] += ms[k] * (dd - d[1] * d[1]); I[4] -= ms[k] * d[1] * d[2];
+        I[5] += ms[k] * (dd - d[2] * d[2]);
+    }
+    *M_out = M;
+    for (int i = 0; i < 3; ++i) c_out[i] = c[i];
+    for (int i = 0; i < 6; ++i) I_out[i] = I[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
+    if (!cfg || !out) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: null argument");
+    if (cfg->abi_version != GRX_ABI_VERSION || cfg->struct_size != (int)sizeof(grx_config))
+        return fail(GRX_ERR_ABI_MISMATCH, "grx_create: grx_config ABI mismatch (header " + std::to_string(sizeof(grx_config)) + " B, caller " + std::to_string(cfg->struct_size) + " B)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GRX_ERR_NO_DEVICE, "grx_create: no HIP device visible (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: bad device id");
+    HIP_TRY(hipSetDevice(device_id));
+    const grx_config& c = *cfg;
+    const grx_model& m = c.model;
+    if (c.num_envs < 1) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: num_envs < 1");
+    int rc = check_topology(m);
+    if (rc) return rc;
+    const int nh = c.measure_heights ? c.num_height_points : 0;
+    if (c.num_obs != GRX_NUM_OBS) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: num_obs must be 39");
+    if (c.num_pri_obs != c.num_obs + 8 + nh || c.num_pri_obs > GRX_MAX_PRI) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: num_pri_obs mismatch");
+    if (nh > GRX_MAX_HEIGHT_POINTS) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: too many height points");
+    if ((c.ankle_left_mask >> GRX_LEG) || (c.ankle_right_mask & 31u)) return fail(GRX_ERR_UNSUPPORTED_MODEL, "ankle masks must be split left/right");
+    if (c.terrain_type == GRX_TERRAIN_HEIGHTFIELD && (!c.height_samples || !c.terrain_origins))
+        return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: heightfield terrain needs height_samples and terrain_origins");
+
+    grx_sim* s = new grx_sim();
+    s->cfg = c;
+    s->cfg.height_samples = nullptr;
+    s->cfg.terrain_origins = nullptr;
+    s->device = device_id;
+    s->N = c.num_envs;
+    const size_t N = (size_t)c.num_envs;
+    KParams& P = s->hp;
+    memset(&P, 0, sizeof P);
+    P.N = c.num_envs; P.env_offset = c.env_offset; P.total_envs = c.total_envs;
+    const char* dbg = getenv("GRX_PUBLISH_DEBUG");
+    P.publish_debug = dbg ? atoi(dbg) : 1;
+    P.seed = c.seed;
+    P.sim_dt = c.sim_dt; P.decimation = c.decimation;
+    for (int i = 0; i < 3; ++i) { P.gravity[i] = c.gravity[i]; P.init_pos[i] = c.init_pos[i]; }
+    P.action_scale = c.action_scale;
+    P.kn = c.contact.kn; P.dn = c.contact.dn; P.kt = c.contact.kt; P.ct = c.contact.ct; P.cv = c.contact.cv;
+    P.terrain_friction = c.contact.terrain_friction;
+    P.termination_force = c.termination_force; P.termination_gravity_z = c.termination_gravity_z;
+    P.max_episode_length = c.max_episode_length; P.max_episode_length_s = c.max_episode_length_s;
+    P.resample_command_interval = c.resample_command_interval;
+    for (int i = 0; i < 2; ++i) { P.cmd_lin_vel_x[i] = c.cmd_lin_vel_x[i]; P.cmd_lin_vel_y[i] = c.cmd_lin_vel_y[i]; P.cmd_ang_vel_yaw[i] = c.cmd_ang_vel_yaw[i]; }
+    P.randomize_init_dof_pos = c.randomize_init_dof_pos; P.randomize_init_base_velocity = c.randomize_init_base_velocity;
+    P.push_robots = c.push_robots; P.push_interval = c.push_interval; P.max_push_vel_xy = c.max_push_vel_xy;
+    const float dtp = c.sim_dt * (float)c.decimation;
+    for (int t = 0; t < NT; ++t) { P.reward_scale_dt[t] = c.reward_scale[t] * dtp; P.reward_sigma[t] = c.reward_sigma[t]; }
+    P.only_positive_rewards = c.only_positive_rewards;
+    P.base_height_target = c.base_height_target; P.swing_feet_height_target = c.swing_feet_height_target;
+    P.feet_stumble_ratio = c.feet_stumble_ratio; P.feet_air_time_target = c.feet_air_time_target; P.feet_land_time_max = c.feet_land_time_max;
+    P.soft_dof_vel_limit = c.soft_dof_vel_limit; P.soft_torque_limit = c.soft_torque_limit;
+    P.knee_mask = c.knee_mask; P.hip_roll_mask = c.hip_roll_mask; P.hip_yaw_mask = c.hip_yaw_mask;
+    P.ankle_left_mask = c.ankle_left_mask; P.ankle_right_mask = c.ankle_right_mask;
+    P.num_pri_obs = c.num_pri_obs;
+    P.obs_scale_action = c.obs_scale_action; P.obs_scale_lin_vel = c.obs_scale_lin_vel; P.obs_scale_ang_vel = c.obs_scale_ang_vel;
+    P.obs_scale_gravity = c.obs_scale_gravity; P.obs_scale_dof_pos = c.obs_scale_dof_pos; P.obs_scale_dof_vel = c.obs_scale_dof_vel;
+    P.obs_scale_height = c.obs_scale_height;
+    P.add_noise = c.add_noise; P.noise_level = c.noise_level; P.noise_action = c.noise_action; P.noise_ang_vel = c.noise_ang_vel;
+    P.noise_gravity = c.noise_gravity; P.noise_dof_pos = c.noise_dof_pos; P.noise_dof_vel = c.noise_dof_vel;
+    P.clip_observations = c.clip_observations;
+    P.terrain_type = c.terrain_type; P.measure_heights = c.measure_heights; P.nh = nh;
+    memcpy(P.height_points, c.height_points, sizeof P.height_points);
+    P.hf_rows = c.hf_rows; P.hf_cols = c.hf_cols;
+    P.horizontal_scale = c.horizontal_scale; P.vertical_scale = c.vertical_scale; P.border_size = c.border_size;
+    P.curriculum = c.curriculum; P.num_terrain_rows = c.num_terrain_rows; P.num_terrain_cols = c.num_terrain_cols;
+    P.terrain_length = c.terrain_length;
+    memcpy(P.torso_rot, m.torso_rot, sizeof P.torso_rot);
+    memcpy(P.forehead_rot, m.forehead_rot, sizeof P.forehead_rot);
+    P.has_torso = m.torso_body >= 0; P.has_forehead = m.forehead_body >= 0;
+    rc = build_side_tables(c, P);
+    if (rc) { delete s; return rc; }
+
+#define DA(field, count) do { rc = dalloc(s, &P.field, (count)); if (rc) { grx_destroy(s); return rc; } } while (0)
+    DA(q, GRX_ND * N); DA(qd, GRX_ND * N); DA(root, 13 * N); DA(anchors, 24 * N);
+    DA(last_actions, GRX_ND * N); DA(last_dof_vel, GRX_ND * N); DA(actions, GRX_ND * N); DA(torques, GRX_ND * N);
+    DA(motor_strength, GRX_ND * N); DA(base_m, N); DA(base_c, 3 * N); DA(base_I, 6 * N); DA(friction, N);
+    DA(commands, 3 * N); DA(origins, 3 * N); DA(levels, N); DA(types, N);
+    DA(air_time, 2 * N); DA(land_time, 2 * N); DA(contact_last, 2 * N); DA(feet_contact, 2 * N);
+    DA(feet_height, 2 * N); DA(avg_force, 2 * N); DA(feet_force, 6 * N); DA(feet_pos, 6 * N); DA(avg_speed, 6 * N);
+    DA(base_heights_offset, N); DA(ep_len, N); DA(rew, N); DA(reset, N); DA(time_out, N); DA(term_contact, N);
+    DA(base_lin_vel, 3 * N); DA(base_ang_vel, 3 * N); DA(proj_grav, 3 * N);
+    DA(episode_sums, NT * N); DA(reward_terms, NT * N); DA(heights, (size_t)(nh > 0 ? nh : 1) * N);
+    DA(obs, GRX_NUM_OBS * N + 64); DA(pri_obs, (size_t)c.num_pri_obs * N + 64);
+    const int nblocks = (c.num_envs + grx_envs_per_block() - 1) / grx_envs_per_block();
+    DA(stat_partial, (size_t)nblocks * (NT + 1)); DA(stats, NT + 1);
+    float* base_mass_com = nullptr;
+    rc = dalloc(s, &base_mass_com, 4 * N);
+    if (rc) { grx_destroy(s); return rc; }
+    if (c.terrain_type == GRX_TERRAIN_HEIGHTFIELD) {
+        int16_t* dhf = nullptr;
+        size_t n = (size_t)c.hf_rows * c.hf_cols;
+        rc = dalloc(s, &dhf, n);
+        if (rc) { grx_destroy(s); return rc; }
+        HIP_TRY(hipMemcpy(dhf, c.height_samples, n * sizeof(int16_t), hipMemcpyHostToDevice));
+        P.hf = dhf;
+        float* dor = nullptr;
+        size_t no = (size_t)c.num_terrain_rows * c.num_terrain_cols * 3;
+        rc = dalloc(s, &dor, no);
+        if (rc) { grx_destroy(s); return rc; }
+        HIP_TRY(hipMemcpy(dor, c.terrain_origins, no * sizeof(float), hipMemcpyHostToDevice));
+        P.terrain_origins = dor;
+    }
+    // ---- per-env constants on the host (same arithmetic as the oracle's gro_create)
+    {
+        const int nd = GRX_ND;
+        std::vector<float> h_strength(nd * N), h_bm(N), h_bc(3 * N), h_bI(6 * N), h_fr(N), h_or(3 * N), h_q(nd * N), h_root(13 * N, 0.f), h_bmc(4 * N);
+        std::vector<int32_t> h_lv(N, 0), h_ty(N, 0);
+        std::vector<uint8_t> h_reset(N, 1);
+        for (size_t i = 0; i < N; ++i) {
+            uint32_t ge = (uint32_t)(c.env_offset + (int)i);
+            float origin[3] = {0, 0, 0};
+            if (c.terrain_type == GRX_TERRAIN_HEIGHTFIELD) {
+                int max_init = c.curriculum ? c.max_init_terrain_level : c.num_terrain_rows - 1;
+                float u = grx_rand(c.seed, ge, 0, GRX_RNG_INIT_LEVEL, 0);
+                int lv = (int)(u * (float)(max_init + 1));
+                if (lv > max_init) lv = max_init;
+                double per = (double)c.total_envs / c.num_terrain_cols;
+                int ty = (int)floor((double)ge / per);
+                if (ty > c.num_terrain_cols - 1) ty = c.num_terrain_cols - 1;
+                h_lv[i] = lv; h_ty[i] = ty;
+                const float* o = c.terrain_origins + ((size_t)lv * c.num_terrain_cols + ty) * 3;
+                origin[0] = o[0]; origin[1] = o[1]; origin[2] = o[2];
+            } else {
+                int ncols = (int)floor(sqrt((double)c.total_envs));
+                if (ncols < 1) ncols = 1;
+                origin[0] = c.env_spacing * (float)(ge / (uint32_t)ncols);
+                origin[1] = c.env_spacing * (float)(ge % (uint32_t)ncols);
+            }
+            for (int k = 0; k < 3; ++k) h_or[k * N + i] = origin[k];
+            float fr = 1.f;
+            if (c.randomize_friction) {
+                uint32_t b = (uint32_t)(grx_rand(c.seed, ge, 0, GRX_RNG_INIT_DR, 0) * 64);
+                if (b > 63) b = 63;
+                fr = c.friction_range[0] + (c.friction_range[1] - c.friction_range[0]) * grx_rand(c.seed, b, 1, GRX_RNG_INIT_DR, 0);
+            }
+            h_fr[i] = fr;
+            float lm = m.base_link_mass, lc[3] = {m.base_link_com[0], m.base_link_com[1], m.base_link_com[2]};
+            if (c.randomize_base_mass) lm *= c.base_mass_range[0] + (c.base_mass_range[1] - c.base_mass_range[0]) * grx_rand(c.seed, ge, 0, GRX_RNG_INIT_DR, 2);
+            if (c.randomize_base_com)
+                for (int k = 0; k < 3; ++k) lc[k] += c.base_com_range[k][0] + (c.base_com_range[k][1] - c.base_com_range[k][0]) * grx_rand(c.seed, ge, 0, GRX_RNG_INIT_DR, 3 + k);
+            float M, cc[3], I6[6];
+            base_lump(m, lm, lc, &M, cc, I6);
+            h_bm[i] = M;
+            for (int k = 0; k < 3; ++k) h_bc[k * N + i] = cc[k];
+            for (int k = 0; k < 6; ++k) h_bI[k * N + i] = I6[k];
+            h_bmc[4 * i] = lm;
+            for (int k = 0; k < 3; ++k) h_bmc[4 * i + 1 + k] = lc[k];
+            for (int j = 0; j < nd; ++j) {
+                float st = 1.f;
+                if (c.randomize_motor_strength) st = c.motor_strength_range[0] + (c.motor_strength_range[1] - c.motor_strength_range[0]) * grx_rand(c.seed, ge, 0, GRX_RNG_INIT_DR, 8 + j);
+                h_strength[j * N + i] = st;
+                h_q[j * N + i] = c.default_dof_pos[j];
+            }
+            for (int k = 0; k < 3; ++k) h_root[k * N + i] = c.init_pos[k] + origin[k];
+            h_root[6 * N + i] = 1.f;
+        }
+#define UP(dst, vec) HIP_TRY(hipMemcpy(P.dst, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice))
+        UP(motor_strength, h_strength); UP(base_m, h_bm); UP(base_c, h_bc); UP(base_I, h_bI); UP(friction, h_fr);
+        UP(origins, h_or); UP(levels, h_lv); UP(types, h_ty); UP(q, h_q); UP(root, h_root); UP(reset, h_reset);
+        HIP_TRY(hipMemcpy(base_mass_com, h_bmc.data(), h_bmc.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc((void**)&s->dp, sizeof(KParams)));
+    HIP_TRY(hipMemcpy(s->dp, &P, sizeof(KParams), hipMemcpyHostToDevice));
+
+    // ---- tensor table
+    const int64_t Ni = c.num_envs;
+    desc_rows(s, GRX_T_OBS, P.obs, Ni, GRX_NUM_OBS);
+    desc_rows(s, GRX_T_PRI_OBS, P.pri_obs, Ni, c.num_pri_obs);
+    desc_vec(s, GRX_T_REW, P.rew, GRX_F32, Ni);
+    desc_vec(s, GRX_T_RESET, P.reset, GRX_U8, Ni);
+    desc_vec(s, GRX_T_TIME_OUT, P.time_out, GRX_U8, Ni);
+    desc_vec(s, GRX_T_EPISODE_LENGTH, P.ep_len, GRX_I64, Ni);
+    desc_soa(s, GRX_T_DOF_POS, P.q, GRX_F32, GRX_ND);
+    desc_soa(s, GRX_T_DOF_VEL, P.qd, GRX_F32, GRX_ND);
+    desc_soa(s, GRX_T_TORQUES, P.torques, GRX_F32, GRX_ND);
+    desc_soa(s, GRX_T_ACTIONS, P.actions, GRX_F32, GRX_ND);
+    desc_soa(s, GRX_T_LAST_ACTIONS, P.last_actions, GRX_F32, GRX_ND);
+    desc_soa(s, GRX_T_LAST_DOF_VEL, P.last_dof_vel, GRX_F32, GRX_ND);
+    desc_soa(s, GRX_T_COMMANDS, P.commands, GRX_F32, 3);
+    desc_soa(s, GRX_T_ROOT_STATES, P.root, GRX_F32, 13);
+    desc_soa(s, GRX_T_BASE_LIN_VEL, P.base_lin_vel, GRX_F32, 3);
+    desc_soa(s, GRX_T_BASE_ANG_VEL, P.base_ang_vel, GRX_F32, 3);
+    desc_soa(s, GRX_T_PROJECTED_GRAVITY, P.proj_grav, GRX_F32, 3);
+    desc_soa3(s, GRX_T_FEET_CONTACT_FORCE, P.feet_force, 2, 3);
+    desc_soa3(s, GRX_T_FEET_POS, P.feet_pos, 2, 3);
+    desc_soa(s, GRX_T_FEET_HEIGHT, P.feet_height, GRX_F32, 2);
+    desc_soa(s, GRX_T_FEET_AIR_TIME, P.air_time, GRX_F32, 2);
+    desc_soa(s, GRX_T_FEET_LAND_TIME, P.land_time, GRX_F32, 2);
+    desc_soa(s, GRX_T_FEET_CONTACT, P.feet_contact, GRX_U8, 2);
+    desc_soa(s, GRX_T_AVG_FEET_FORCE, P.avg_force, GRX_F32, 2);
+    desc_soa3(s, GRX_T_AVG_FEET_SPEED, P.avg_speed, 2, 3);
+    desc_soa(s, GRX_T_MEASURED_HEIGHTS, P.heights, GRX_F32, nh);
+    desc_vec(s, GRX_T_BASE_HEIGHTS_OFFSET, P.base_heights_offset, GRX_F32, Ni);
+    desc_rows(s, GRX_T_EPISODE_SUMS, P.episode_sums, NT, Ni);
+    desc_rows(s, GRX_T_REWARD_TERMS, P.reward_terms, NT, Ni);
+    desc_vec(s, GRX_T_TERRAIN_LEVELS, P.levels, GRX_I32, Ni);
+    desc_vec(s, GRX_T_TERRAIN_TYPES, P.types, GRX_I32, Ni);
+    desc_soa(s, GRX_T_ENV_ORIGINS, P.origins, GRX_F32, 3);
+    desc_soa(s, GRX_T_MOTOR_STRENGTH, P.motor_strength, GRX_F32, GRX_ND);
+    desc_vec(s, GRX_T_FRICTION, P.friction, GRX_F32, Ni);
+    desc_rows(s, GRX_T_BASE_MASS_COM, base_mass_com, Ni, 4);
+    desc_vec(s, GRX_T_TERM_CONTACT, P.term_contact, GRX_U8, Ni);
+    desc_vec(s, GRX_T_EPISODE_STATS, P.stats, GRX_F32, NT + 1);
+    desc_soa3(s, GRX_T_ANCHORS, P.anchors, 8, 3);
+    *out = s;
+    return GRX_OK;
+}
+
+int grx_destroy(grx_handle s) {
+    if (!s) return GRX_OK;
+    hipSetDevice(s->device);
+    for (void* p : s->allocs) hipFree(p);
+    if (s->dp) hipFree(s->dp);
+    for (auto& pr : s->timing.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& pr : s->timing.pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    delete s;
+    return GRX_OK;
+}
+
+int grx_reset_all(grx_handle s, void* stream) {
+    if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_reset_all: null handle");
+    hipStream_t st = (hipStream_t)stream;
+    // extras["episode"] of a full reset: mean of the running episode sums over all envs
+    // (legged_robot.py:420-424); computed by the stats path with every env flagged.
+    uint32_t step = 0x80000000u + (s->reset_count++);
+    grx_launch_reset_all(s->dp, s->N, step, st);
+    grx_launch_finalize(s->dp, s->N, st);
+    HIP_TRY(hipGetLastError());
+    return GRX_OK;
+}
+
+int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
+    if (!s || !a) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_step: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (s->timing.enabled) {
+        if (!s->timing.pool.empty()) { ev = s->timing.pool.back(); s->timing.pool.pop_back(); }
+        else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
+        HIP_TRY(hipEventRecord(ev.first, st));
+    }
+    grx_launch_step(s->dp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
+                    (long long)a->common_step_counter, a->noise_uniform, st);
+    if (s->timing.enabled) {
+        HIP_TRY(hipEventRecord(ev.second, st));
+        s->timing.pending.push_back(ev);
+    }
+    grx_launch_finalize(s->dp, s->N, st);
+    HIP_TRY(hipGetLastError());
+    return GRX_OK;
+}
+
+int grx_tensor(grx_handle s, int id, grx_tensor_desc* out) {
+    if (!s || !out) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_tensor: null argument");
+    if (id < 0 || id >= GRX_NUM_TENSORS) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_tensor: unknown tensor id");
+    *out = s->desc[id];
+    return GRX_OK;
+}
+
+int grx_set_state(grx_handle s, const float* root, const float* q, const float* qd, void* stream) {
+    if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_set_state: null handle");
+    grx_launch_set_state(s->dp, s->N, root, q, qd, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return GRX_OK;
+}
+
+int grx_episode_stats(grx_handle s, float* host_out, void* stream) {
+    if (!s || !host_out) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_episode_stats: null argument");
+    HIP_TRY(hipMemcpyAsync(host_out, s->hp.stats, (NT + 1) * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GRX_OK;
+}
+
+int grx_kernel_time_ms(grx_handle s, int enable, float* avg_ms, int64_t* launches) {
+    if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_kernel_time_ms: null handle");
+    double tot = 0;
+    int64_t n = 0;
+    for (auto& pr : s->timing.pending) {
+        HIP_TRY(hipEventSynchronize(pr.second));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        tot += ms;
+        ++n;
+        s->timing.pool.push_back(pr);
+    }
+    s->timing.pending.clear();
+    s->timing.enabled = enable != 0;
+    if (avg_ms) *avg_ms = n ? (float)(tot / n) : 0.f;
+    if (launches) *launches = n;
+    return GRX_OK;
+}
+
+const char* grx_last_error(void) { return g_err.c_str(); }
+int grx_abi_version(void) { return GRX_ABI_VERSION; }
+
+const char* grx_reward_term_name(int t) {
+    static const char* names[NT] = {
+        "action_diff", "action_diff_diff", "action_diff_knee", "cmd_diff_ang_vel_pitch", "cmd_diff_ang_vel_roll",
+        "cmd_diff_ang_vel_yaw", "cmd_diff_base_height", "cmd_diff_base_orient", "cmd_diff_forehead_orient",
+        "cmd_diff_lin_vel_x", "cmd_diff_lin_vel_y", "cmd_diff_lin_vel_z", "cmd_diff_torso_orient", "collision",
+        "dof_acc_new", "dof_tor_ankle_feet_lift_up", "dof_tor_new", "dof_tor_new_hip_roll", "dof_vel_new",
+        "dof_vel_new_knee", "feet_air_force", "feet_air_height", "feet_air_time", "feet_land_time",
+        "feet_speed_xy_close_to_ground", "feet_speed_z_close_to_height_target", "feet_stumble", "limits_actions",
+        "limits_dof_pos", "limits_dof_tor", "limits_dof_vel", "on_the_air", "pose_offset", "pose_offset_hip_yaw",
+        "stand_still", "termination"};
+    return (t >= 0 && t < NT) ? names[t] : "";
+}
+
+}  // extern "C"

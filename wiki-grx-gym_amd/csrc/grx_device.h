@@ -1,0 +1,79 @@
+// grx_device.h -- device-side parameter blocks shared by the kernels and the C-ABI host code.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/grx.h"
+
+#define GRX_LEG 5        // joints per leg chain
+#define GRX_ND 10        // DOFs of the supported (lower-limb) topology
+#define GRX_NUM_OBS 39   // 9 + 3*GRX_ND (gr1t1.py:281-295)
+#define GRX_MAX_PRI 168  // 39 + 3 + 1 + 2 + 2 + 121 (gr1t1.py:297-313)
+#define GRX_MAXSPH_SIDE 16
+
+struct SphC {
+    float x, y, z, r;    // centre (body frame), radius
+    uint32_t flags;      // GRX_SPH_*
+    int32_t slot;        // 0..3: anchored foot sphere index within this lane's foot, -1 otherwise
+    int32_t link_last;   // 1: last sphere of its URDF link in this lane's list (per-link force netting)
+    float dmax;          // cap of the normal damping coefficient (grx_model.sph_damp_max)
+};
+
+// Per-side (left leg / right leg lane) robot constants; staged into LDS by every block.
+struct SideConst {
+    float r[GRX_LEG][3];     // joint origin in the parent body frame
+    float com[GRX_LEG][3];
+    float Ic[GRX_LEG][6];    // inertia about COM: xx xy xz yy yz zz
+    float mass[GRX_LEG];
+    float kp[GRX_LEG], kd[GRX_LEG], q0[GRX_LEG], effort[GRX_LEG], vlim[GRX_LEG];
+    float qlo[GRX_LEG], qhi[GRX_LEG], Klim[GRX_LEG], Clim[GRX_LEG];
+    float amin[GRX_LEG], amax[GRX_LEG];  // clip_actions
+    float slo[GRX_LEG], shi[GRX_LEG];    // soft dof position limits (legged_robot.py:606-610)
+    float foot_pos[3];
+    int32_t sph_begin[GRX_LEG + 2];      // [0]=0: base-lump share, [1+k]: chain body k, [GRX_LEG+1]: end
+    SphC sph[GRX_MAXSPH_SIDE];
+};
+
+struct KParams {
+    int32_t N, env_offset, total_envs, publish_debug;
+    uint64_t seed;
+    float sim_dt; int32_t decimation; float gravity[3];
+    float action_scale;
+    float kn, dn, kt, ct, cv, terrain_friction;
+    float termination_force, termination_gravity_z;
+    float max_episode_length, max_episode_length_s;
+    int32_t resample_command_interval;
+    float cmd_lin_vel_x[2], cmd_lin_vel_y[2], cmd_ang_vel_yaw[2];
+    float init_pos[3];
+    int32_t randomize_init_dof_pos, randomize_init_base_velocity;
+    int32_t push_robots, push_interval; float max_push_vel_xy;
+    float reward_scale_dt[GRX_NUM_REWARD_TERMS], reward_sigma[GRX_NUM_REWARD_TERMS];
+    int32_t only_positive_rewards;
+    float base_height_target, swing_feet_height_target, feet_stumble_ratio, feet_air_time_target, feet_land_time_max;
+    float soft_dof_vel_limit, soft_torque_limit;
+    uint32_t knee_mask, hip_roll_mask, hip_yaw_mask, ankle_left_mask, ankle_right_mask;
+    int32_t num_pri_obs;
+    float obs_scale_action, obs_scale_lin_vel, obs_scale_ang_vel, obs_scale_gravity, obs_scale_dof_pos, obs_scale_dof_vel, obs_scale_height;
+    int32_t add_noise; float noise_level, noise_action, noise_ang_vel, noise_gravity, noise_dof_pos, noise_dof_vel;
+    float clip_observations;
+    int32_t terrain_type, measure_heights, nh;
+    float height_points[GRX_MAX_HEIGHT_POINTS][2];
+    const int16_t* hf; int32_t hf_rows, hf_cols;
+    float horizontal_scale, vertical_scale, border_size;
+    int32_t curriculum, num_terrain_rows, num_terrain_cols;
+    const float* terrain_origins; float terrain_length;
+    float torso_rot[9], forehead_rot[9];
+    int32_t has_torso, has_forehead;
+    SideConst side[2];
+    // state (SoA [k][N])
+    float *q, *qd, *root, *anchors, *last_actions, *last_dof_vel, *actions, *torques, *motor_strength;
+    float *base_m, *base_c, *base_I, *friction, *commands, *origins;
+    int32_t *levels, *types;
+    float *air_time, *land_time;
+    uint8_t *contact_last, *feet_contact;
+    float *feet_height, *avg_force, *feet_force, *feet_pos, *avg_speed, *base_heights_offset;
+    long long* ep_len;
+    float* rew;
+    uint8_t *reset, *time_out, *term_contact;
+    float *base_lin_vel, *base_ang_vel, *proj_grav, *episode_sums, *reward_terms, *heights;
+    float *obs, *pri_obs, *stat_partial, *stats;
+};

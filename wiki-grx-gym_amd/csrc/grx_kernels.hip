@@ -1,0 +1,943 @@
+// grx_kernels.hip -- the fused GRx environment-step kernel for MI355X (gfx950, wave64).
+//
+// One launch = one LeggedRobot.step() (reference legged_robot.py:222-246) for every env:
+//   clip_actions -> 10 x [PD torque -> articulated-body dynamics + contact -> integrate]
+//   -> state update -> termination -> 36 reward terms -> masked in-kernel reset
+//   -> observations (+noise) -> history.
+//
+// MI355X mapping:
+//   * ONE ENV PER LANE PAIR: lane 2e holds the left leg chain (5 joints), lane 2e+1 the right
+//     leg.  The two chains only meet in the floating base, so the articulated inertia / bias of
+//     each chain is combined with ONE DPP quad_perm exchange (27 values) per sub-step; no LDS,
+//     no barrier.  A 64-lane wave advances 32 envs; all state stays in VGPRs across the fused
+//     decimation loop (no per-sub-step tensor refresh: the reference moves >= 25 KB/env-step
+//     through gym.refresh_*_tensor).
+//   * dynamics in WORLD axes about the base origin: all spatial quantities share one frame, so
+//     the articulated-body recursion needs no 6x6 frame transforms (the CPU oracle uses the
+//     textbook body-frame form: the two implementations are independent).
+//   * SoA state in HBM ([k][N]): a wave's loads are 128-B contiguous segments; AoS outputs
+//     (obs (N,39), pri_obs (N,168), consumed row-major by the PPO GEMMs) are staged through LDS
+//     and written as 16-B-per-lane coalesced rows.
+//   * per-side robot constants (joint tree, inertias, gains, sphere tables) staged once per
+//     block into LDS; per-launch scalars come through the scalar cache (s_load) from KParams.
+//   * resets are masked in-kernel (counter-based Philox): no nonzero()/host sync
+//     (legged_robot.py:292, 317 each force one in the reference).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/grx.h"
+#include "grx_device.h"
+#include "grx_math.h"
+#include "grx_rng.h"
+
+namespace {
+
+constexpr int NT = GRX_NUM_REWARD_TERMS;
+constexpr int LEG = GRX_LEG;
+constexpr int EPB = 32;  // envs per block (one wave64 = 32 lane pairs)
+
+// joint axes of a GR1 leg chain: hip_roll(x) hip_yaw(z) hip_pitch(y) knee_pitch(y) ankle_pitch(y)
+__device__ constexpr int kAxis[LEG] = {0, 2, 1, 1, 1};
+
+GRX_DEV R3 joint_rot_k(const R3& P, float c, float s, int ax) {
+    if (ax == 0) return joint_rot<0>(P, c, s);
+    if (ax == 1) return joint_rot<1>(P, c, s);
+    return joint_rot<2>(P, c, s);
+}
+GRX_DEV V3 axis_k(const R3& R, int ax) { return ax == 0 ? R.cx : (ax == 1 ? R.cy : R.cz); }
+
+// physics terrain query: bilinear interpolation of the int16 heightfield (oracle: terrain_height)
+template <bool HF>
+GRX_DEV float terrain_height(const KParams& P, float x, float y) {
+    if (!HF) return 0.0f;
+    float fx = (x + P.border_size) / P.horizontal_scale;
+    float fy = (y + P.border_size) / P.horizontal_scale;
+    fx = fminf(fmaxf(fx, 0.0f), (float)(P.hf_rows - 1));
+    fy = fminf(fmaxf(fy, 0.0f), (float)(P.hf_cols - 1));
+    int ix = min((int)fx, P.hf_rows - 2), iy = min((int)fy, P.hf_cols - 2);
+    float tx = fx - (float)ix, ty = fy - (float)iy;
+    const int16_t* H = P.hf + (size_t)ix * P.hf_cols + iy;
+    float h00 = (float)H[0], h01 = (float)H[1], h10 = (float)H[P.hf_cols], h11 = (float)H[P.hf_cols + 1];
+    float h = (h00 * (1.0f - tx) + h10 * tx) * (1.0f - ty) + (h01 * (1.0f - tx) + h11 * tx) * ty;
+    return h * P.vertical_scale;
+}
+
+// per-lane persistent simulation state
+struct LaneState {
+    float q[LEG], qd[LEG];
+    V3 pos, vel, ang;
+    float qx, qy, qz, qw;
+    float ax[4], ay[4];  // friction anchors of the 4 spheres of this lane's foot
+    uint32_t anchor_on;  // bit i: anchor i active
+};
+
+struct LaneConst {  // per-env constants held in registers
+    float strength[LEG];
+    float base_m;
+    V3 base_c;
+    S3 base_I;
+    float mu;
+};
+
+struct SubstepOut {
+    V3 foot_force;   // net contact force on this lane's foot link (world)
+    bool term;       // a terminating link handled by this lane carries |F| > threshold
+    bool pen;        // a penalised link carries |F| > 0.1 (count in pen_count)
+    float pen_count;
+};
+
+struct FootKin { V3 pos, vel, ang; };  // foot link origin (world), its velocity, body angular velocity
+
+// One sphere against the terrain.  R/rho/w/v: rotation, origin (relative to the base origin O),
+// angular velocity and O-referenced linear velocity of the carrying body.
+template <bool HF>
+GRX_DEV V3 sphere_force(const KParams& P, const SphC& S, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu,
+                        LaneState& st, bool enabled, V3& xr_out) {
+    V3 xr = rho + rot(R, v3(S.x, S.y, S.z));
+    xr_out = xr;
+    V3 F = v3(0.f, 0.f, 0.f);
+    float wx = O.x + xr.x, wy = O.y + xr.y, wz = O.z + xr.z;
+    float h = terrain_height<HF>(P, wx, wy);
+    float d = h + S.r - wz;
+    int slot = S.slot;
+    if (!enabled) return F;
+    if (d <= 0.0f) {
+        if (slot >= 0) st.anchor_on &= ~(1u << slot);
+        return F;
+    }
+    V3 u = v + cross(w, xr);
+    float cd = fminf(P.kn * d * P.dn, S.dmax);  // Hunt-Crossley damping, mass-aware cap (oracle contact_forces())
+    float fn = fmaxf(P.kn * d - cd * u.z, 0.0f);
+    F.z = fn;
+    float fmax = mu * fn;
+    if (slot >= 0) {
+        float axx = st.ax[0], ayy = st.ay[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) if (slot == i) { axx = st.ax[i]; ayy = st.ay[i]; }
+        if (!(st.anchor_on & (1u << slot))) { axx = wx; ayy = wy; st.anchor_on |= (1u << slot); }
+        float ftx = -P.kt * (wx - axx) - P.ct * u.x;
+        float fty = -P.kt * (wy - ayy) - P.ct * u.y;
+        float ft = sqrtf(ftx * ftx + fty * fty);
+        if (ft > fmax) {
+            float sc = fmax / ft;
+            ftx *= sc; fty *= sc;
+            axx = wx + ftx / P.kt;
+            ayy = wy + fty / P.kt;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (slot == i) { st.ax[i] = axx; st.ay[i] = ayy; }
+        F.x = ftx; F.y = fty;
+    } else {
+        float sp = sqrtf(u.x * u.x + u.y * u.y);
+        float ft = fminf(P.cv * sp, fmax);
+        if (sp > 1e-9f) { F.x = -ft * u.x / sp; F.y = -ft * u.y / sp; }
+    }
+    return F;
+}
+
+// One physics sub-step (gym.simulate(dt), legged_robot_fftai.py:68) for this lane's half of the env.
+// tau: motor torques of this lane's 5 joints.  fk_only: just the kinematics pass (foot frames).
+template <bool HF>
+GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
+                     SubstepOut& out, FootKin& fk_before) {
+    const float dt = P.sim_dt;
+    R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
+    V3 O = st.pos;
+    // ---- pass 1: kinematics, rigid inertias, bias forces, contacts (root -> leaf)
+    V3 Sa[LEG], Ss[LEG];       // joint motion subspace S = (a; rho x a)
+    S3 IAk[LEG]; V3 Ih[LEG];   // rigid inertia about O: A and h = m*kappa
+    V3 pA[LEG], pL[LEG];       // bias force
+    R3 Rp = R0;
+    V3 rho_p = v3(0.f, 0.f, 0.f);
+    V3 w = st.ang, v = st.vel;
+    out.foot_force = v3(0.f, 0.f, 0.f);
+    out.term = false;
+    out.pen_count = 0.f;
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        V3 rho = rho_p + rot(Rp, v3(C.r[k][0], C.r[k][1], C.r[k][2]));
+        float sn, cs;
+        sincosf(st.q[k], &sn, &cs);
+        R3 R = joint_rot_k(Rp, cs, sn, kAxis[k]);
+        V3 a = axis_k(R, kAxis[k]);
+        V3 s = cross(rho, a);
+        V3 wk = fma3(a, st.qd[k], w), vk = fma3(s, st.qd[k], v);
+        float m = C.mass[k];
+        V3 kap = rho + rot(R, v3(C.com[k][0], C.com[k][1], C.com[k][2]));
+        S3 Ic = {C.Ic[k][0], C.Ic[k][1], C.Ic[k][2], C.Ic[k][3], C.Ic[k][4], C.Ic[k][5]};
+        S3 A = rot_sym(R, Ic);
+        float kk = dot(kap, kap);
+        A.xx += m * (kk - kap.x * kap.x); A.xy -= m * kap.x * kap.y; A.xz -= m * kap.x * kap.z;
+        A.yy += m * (kk - kap.y * kap.y); A.yz -= m * kap.y * kap.z; A.zz += m * (kk - kap.z * kap.z);
+        V3 h = kap * m;
+        V3 hl = fma3(vk, m, cross(wk, h));
+        V3 ha = mul(A, wk) + cross(h, vk);
+        V3 pa = cross(wk, ha) + cross(vk, hl);
+        V3 pl = cross(wk, hl);
+        // contacts of the spheres carried by chain body k (thigh_pitch, shank, foot)
+        int sb = C.sph_begin[1 + k], se = C.sph_begin[2 + k];
+        int cnt = max(se - sb, __builtin_bit_cast(int, pair_swap(__builtin_bit_cast(float, se - sb))));
+        for (int i = 0; i < cnt; ++i) {
+            bool en = (sb + i) < se;
+            const SphC& S = C.sph[min(sb + i, GRX_MAXSPH_SIDE - 1)];
+            V3 xr;
+            V3 F = sphere_force<HF>(P, S, R, rho, wk, vk, O, LC.mu, st, en, xr);
+            pa = pa - cross(xr, F);
+            pl = pl - F;
+            if (en && (S.flags & (GRX_SPH_FOOT_LEFT | GRX_SPH_FOOT_RIGHT))) out.foot_force = out.foot_force + F;
+        }
+        if (k == LEG - 1) {  // foot link frame BEFORE this sub-step's integration
+            V3 fr = rho + rot(R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
+            fk_before.pos = O + fr;
+            fk_before.vel = vk + cross(wk, fr);
+            fk_before.ang = wk;
+        }
+        Sa[k] = a; Ss[k] = s; IAk[k] = A; Ih[k] = h; pA[k] = pa; pL[k] = pl;
+        Rp = R; rho_p = rho; w = wk; v = vk;
+    }
+    // ---- base-lump spheres handled by this lane (per-link netting for termination / collision)
+    V3 f0a = v3(0.f, 0.f, 0.f), f0l = v3(0.f, 0.f, 0.f);
+    {
+        int sb = C.sph_begin[0], se = C.sph_begin[1];
+        int cnt = max(se - sb, __builtin_bit_cast(int, pair_swap(__builtin_bit_cast(float, se - sb))));
+        V3 Flink = v3(0.f, 0.f, 0.f);
+        V3 zero = v3(0.f, 0.f, 0.f);
+        for (int i = 0; i < cnt; ++i) {
+            bool en = (sb + i) < se;
+            const SphC& S = C.sph[min(sb + i, GRX_MAXSPH_SIDE - 1)];
+            V3 xr;
+            V3 F = sphere_force<HF>(P, S, R0, zero, st.ang, st.vel, O, LC.mu, st, en, xr);
+            f0a = f0a + cross(xr, F);
+            f0l = f0l + F;
+            if (en) {
+                Flink = Flink + F;
+                if (S.link_last) {
+                    float n2 = dot(Flink, Flink);
+                    if ((S.flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) out.term = true;
+                    if ((S.flags & GRX_SPH_PENALISE) && n2 > 0.01f) out.pen_count += 1.0f;
+                    Flink = zero;
+                }
+            }
+        }
+    }
+    // ---- pass 2: articulated inertias (leaf -> root).  w, v currently = velocity of body LEG-1.
+    S3 A = IAk[LEG - 1];
+    V3 h4 = Ih[LEG - 1];
+    float m4 = C.mass[LEG - 1];
+    M3 B = {0.f, -h4.z, h4.y, h4.z, 0.f, -h4.x, -h4.y, h4.x, 0.f};
+    S3 D = {m4, 0.f, 0.f, m4, 0.f, m4};
+    V3 pa = pA[LEG - 1], pl = pL[LEG - 1];
+    V3 Ua[LEG], Ul[LEG], ca[LEG], cl[LEG];
+    float dinv[LEG], uu[LEG];
+#pragma unroll
+    for (int k = LEG - 1; k >= 0; --k) {
+        V3 a = Sa[k], s = Ss[k];
+        float qdk = st.qd[k];
+        w = fma3(a, -qdk, w); v = fma3(s, -qdk, v);  // parent velocity
+        V3 cak = cross(w, a) * qdk;
+        V3 clk = (cross(v, a) + cross(w, s)) * qdk;
+        V3 ua = mul(A, a) + mul(B, s);
+        V3 ul = mulT(B, a) + mul(D, s);
+        float d = dot(a, ua) + dot(s, ul);
+        float di = 1.0f / d;
+        // joint-limit spring/damper (oracle substep()): added to the motor torque
+        float t = tau_m[k];
+        if (st.q[k] < C.qlo[k]) t += C.Klim[k] * (C.qlo[k] - st.q[k]) - C.Clim[k] * qdk;
+        else if (st.q[k] > C.qhi[k]) t += C.Klim[k] * (C.qhi[k] - st.q[k]) - C.Clim[k] * qdk;
+        float u = t - (dot(a, pa) + dot(s, pl));
+        syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
+        float ud = u * di;
+        V3 npa = pa + mul(A, cak) + mul(B, clk) + ua * ud;
+        V3 npl = pl + mulT(B, cak) + mul(D, clk) + ul * ud;
+        Ua[k] = ua; Ul[k] = ul; dinv[k] = di; uu[k] = u; ca[k] = cak; cl[k] = clk;
+        pa = npa; pl = npl;
+        if (k > 0) {  // add the parent's rigid inertia: [A B; B^T D] += rigid(k-1)
+            V3 hp = Ih[k - 1];
+            float mp = C.mass[k - 1];
+            A = A + IAk[k - 1];
+            B.a01 -= hp.z; B.a02 += hp.y; B.a10 += hp.z; B.a12 -= hp.x; B.a20 -= hp.y; B.a21 += hp.x;
+            D.xx += mp; D.yy += mp; D.zz += mp;
+            pa = pa + pA[k - 1]; pl = pl + pL[k - 1];
+        }
+    }
+    // ---- base: combine both chains (DPP pair exchange), add the base lump, solve the 6x6
+    pa = pa - f0a; pl = pl - f0l;
+    A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
+    pa = pair_sum(pa); pl = pair_sum(pl);
+    {
+        V3 kap = rot(R0, LC.base_c);
+        float m = LC.base_m;
+        S3 A0 = rot_sym(R0, LC.base_I);
+        float kk = dot(kap, kap);
+        A0.xx += m * (kk - kap.x * kap.x); A0.xy -= m * kap.x * kap.y; A0.xz -= m * kap.x * kap.z;
+        A0.yy += m * (kk - kap.y * kap.y); A0.yz -= m * kap.y * kap.z; A0.zz += m * (kk - kap.z * kap.z);
+        V3 h = kap * m;
+        V3 w0 = st.ang, v0 = st.vel;
+        V3 hl = fma3(v0, m, cross(w0, h));
+        V3 ha = mul(A0, w0) + cross(h, v0);
+        pa = pa + cross(w0, ha) + cross(v0, hl);
+        pl = pl + cross(w0, hl);
+        A = A + A0;
+        B.a01 -= h.z; B.a02 += h.y; B.a10 += h.z; B.a12 -= h.x; B.a20 -= h.y; B.a21 += h.x;
+        D.xx += m; D.yy += m; D.zz += m;
+    }
+    // [A B; B^T D][alpha; acc] = -[pa; pl]:  acc = -Dinv (pl + B^T alpha);  (A - B Dinv B^T) alpha = -pa + B Dinv pl
+    S3 Di = inv(D);
+    V3 Dipl = mul(Di, pl);
+    V3 rhs = mul(B, Dipl) - pa;
+    // Schur complement S = A - B Dinv B^T (symmetric)
+    V3 b0 = v3(B.a00, B.a01, B.a02), b1 = v3(B.a10, B.a11, B.a12), b2 = v3(B.a20, B.a21, B.a22);
+    V3 d0 = mul(Di, b0), d1 = mul(Di, b1), d2 = mul(Di, b2);
+    S3 Sc = {A.xx - dot(b0, d0), A.xy - dot(b0, d1), A.xz - dot(b0, d2), A.yy - dot(b1, d1), A.yz - dot(b1, d2), A.zz - dot(b2, d2)};
+    V3 alpha = mul(inv(Sc), rhs);
+    V3 acc = neg(mul(Di, pl + mulT(B, alpha)));
+    // ---- pass 3: accelerations (root -> leaf)
+    float qdd[LEG];
+    V3 aa = alpha, al = acc;
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        V3 pa_ = aa + ca[k], pl_ = al + cl[k];
+        float qd2 = (uu[k] - (dot(Ua[k], pa_) + dot(Ul[k], pl_))) * dinv[k];
+        qdd[k] = qd2;
+        aa = fma3(Sa[k], qd2, pa_);
+        al = fma3(Ss[k], qd2, pl_);
+    }
+    // ---- integrate (semi-implicit Euler)
+    V3 lin = acc + cross(st.ang, st.vel);  // classical acceleration of the base origin
+    st.vel = v3(st.vel.x + (lin.x + P.gravity[0]) * dt, st.vel.y + (lin.y + P.gravity[1]) * dt, st.vel.z + (lin.z + P.gravity[2]) * dt);
+    st.ang = fma3(alpha, dt, st.ang);
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        float vq = fmaf(qdd[k], dt, st.qd[k]);
+        vq = fminf(fmaxf(vq, -C.vlim[k]), C.vlim[k]);
+        st.qd[k] = vq;
+        st.q[k] = fmaf(vq, dt, st.q[k]);
+    }
+    st.pos = fma3(st.vel, dt, st.pos);
+    float hx = 0.5f * dt * st.ang.x, hy = 0.5f * dt * st.ang.y, hz = 0.5f * dt * st.ang.z;
+    float x = st.qx, y = st.qy, z = st.qz, ww = st.qw;
+    float nx = x + hx * ww + hy * z - hz * y;
+    float ny = y - hx * z + hy * ww + hz * x;
+    float nz = z + hx * y - hy * x + hz * ww;
+    float nw = ww - hx * x - hy * y - hz * z;
+    float n = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+    st.qx = nx * n; st.qy = ny * n; st.qz = nz * n; st.qw = nw * n;
+}
+
+// kinematics only: this lane's foot link frame in the current state
+GRX_DEV FootKin foot_kinematics(const SideConst& C, const LaneState& st) {
+    R3 Rp = quat_to_R(st.qx, st.qy, st.qz, st.qw);
+    V3 rho = v3(0.f, 0.f, 0.f), w = st.ang, v = st.vel;
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        rho = rho + rot(Rp, v3(C.r[k][0], C.r[k][1], C.r[k][2]));
+        float sn, cs;
+        sincosf(st.q[k], &sn, &cs);
+        R3 R = joint_rot_k(Rp, cs, sn, kAxis[k]);
+        V3 a = axis_k(R, kAxis[k]);
+        V3 s = cross(rho, a);
+        w = fma3(a, st.qd[k], w);
+        v = fma3(s, st.qd[k], v);
+        Rp = R;
+    }
+    V3 fr = rho + rot(Rp, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
+    FootKin f;
+    f.pos = st.pos + fr;
+    f.vel = v + cross(w, fr);
+    f.ang = w;
+    return f;
+}
+
+GRX_DEV float urand(const KParams& P, uint32_t genv, uint32_t step, uint32_t stream, uint32_t i, float lo, float hi) {
+    return (hi - lo) * grx_rand(P.seed, genv, step, stream, i) + lo;
+}
+
+// legged_robot.py:650-677
+GRX_DEV void resample_commands(const KParams& P, uint32_t genv, uint32_t step, uint32_t stream, float cmd[3]) {
+    float c0 = urand(P, genv, step, stream, 0, P.cmd_lin_vel_x[0], P.cmd_lin_vel_x[1]);
+    float c1 = urand(P, genv, step, stream, 1, P.cmd_lin_vel_y[0], P.cmd_lin_vel_y[1]);
+    float keep = sqrtf(c0 * c0 + c1 * c1) > 0.1f ? 1.0f : 0.0f;
+    cmd[0] = c0 * keep;
+    cmd[1] = c1 * keep;
+    cmd[2] = urand(P, genv, step, stream, 2, P.cmd_ang_vel_yaw[0], P.cmd_ang_vel_yaw[1]);
+}
+
+struct EnvAux {  // per-env (replicated in both lanes) pipeline state touched by reset
+    float cmd[3];
+    float origin[3];
+    int level, type;
+};
+
+// reset_idx for one env (legged_robot.py:377-440, 717-826; legged_robot_fftai.py:137-146):
+// each lane resets its own leg, the root state is computed redundantly (same counters -> same values)
+GRX_DEV void reset_env(const KParams& P, const SideConst& C, int side, uint32_t genv, uint32_t step, bool init_done,
+                       LaneState& st, EnvAux& ea) {
+    if (P.curriculum && P.terrain_type != GRX_TERRAIN_PLANE && init_done) {  // legged_robot.py:799-826
+        float dx = st.pos.x - ea.origin[0], dy = st.pos.y - ea.origin[1];
+        float dist = sqrtf(dx * dx + dy * dy);
+        int up = dist > P.terrain_length * 0.5f;
+        float cn = sqrtf(ea.cmd[0] * ea.cmd[0] + ea.cmd[1] * ea.cmd[1]);
+        int down = (dist < cn * P.max_episode_length_s * 0.5f) && !up;
+        ea.level += up - down;
+        if (ea.level >= P.num_terrain_rows) {
+            float u = grx_rand(P.seed, genv, step, GRX_RNG_CURRICULUM, 0);
+            ea.level = min((int)(u * (float)P.num_terrain_rows), P.num_terrain_rows - 1);
+        } else if (ea.level < 0)
+            ea.level = 0;
+        const float* o = P.terrain_origins + ((size_t)ea.level * P.num_terrain_cols + ea.type) * 3;
+        ea.origin[0] = o[0]; ea.origin[1] = o[1]; ea.origin[2] = o[2];
+    }
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {  // _reset_dofs
+        float f = P.randomize_init_dof_pos ? urand(P, genv, step, GRX_RNG_RESET_DOF, (uint32_t)(side * LEG + k), 0.5f, 1.5f) : 1.0f;
+        st.q[k] = f * C.q0[k];
+        st.qd[k] = 0.0f;
+    }
+    st.pos = v3(P.init_pos[0] + ea.origin[0], P.init_pos[1] + ea.origin[1], P.init_pos[2] + ea.origin[2]);
+    if (P.terrain_type != GRX_TERRAIN_PLANE) {
+        st.pos.x += urand(P, genv, step, GRX_RNG_RESET_ROOT, 0, -1.0f, 1.0f);
+        st.pos.y += urand(P, genv, step, GRX_RNG_RESET_ROOT, 1, -1.0f, 1.0f);
+    }
+    float yaw = urand(P, genv, step, GRX_RNG_RESET_ROOT, 2, -6.283185307179586f, 6.283185307179586f);
+    float sy, cy;
+    sincosf(yaw * 0.5f, &sy, &cy);
+    st.qx = 0.f; st.qy = 0.f; st.qz = sy; st.qw = cy;  // quat_from_euler_xyz(0,0,yaw)
+    if (P.randomize_init_base_velocity) {
+        st.vel = v3(urand(P, genv, step, GRX_RNG_RESET_ROOT, 3, -0.5f, 0.5f), urand(P, genv, step, GRX_RNG_RESET_ROOT, 4, -0.5f, 0.5f),
+                    urand(P, genv, step, GRX_RNG_RESET_ROOT, 5, -0.5f, 0.5f));
+        st.ang = v3(urand(P, genv, step, GRX_RNG_RESET_ROOT, 6, -0.5f, 0.5f), urand(P, genv, step, GRX_RNG_RESET_ROOT, 7, -0.5f, 0.5f),
+                    urand(P, genv, step, GRX_RNG_RESET_ROOT, 8, -0.5f, 0.5f));
+    } else {
+        st.vel = v3(0.f, 0.f, 0.f);
+        st.ang = v3(0.f, 0.f, 0.f);
+    }
+    resample_commands(P, genv, step, GRX_RNG_CMD_RESET, ea.cmd);
+    st.anchor_on = 0;
+}
+
+// legged_robot.py:1235-1274 _get_heights, one point
+GRX_DEV float height_sample(const KParams& P, float qz, float qw, V3 pos, int k) {
+    float n = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
+    V3 p = quat_apply(v3(0.f, 0.f, qz / n), qw / n, v3(P.height_points[k][0], P.height_points[k][1], 0.f));
+    float px = (p.x + pos.x + P.border_size) / P.horizontal_scale;
+    float py = (p.y + pos.y + P.border_size) / P.horizontal_scale;
+    int ix = min(max((int)px, 0), P.hf_rows - 2), iy = min(max((int)py, 0), P.hf_cols - 2);
+    const int16_t* H = P.hf + (size_t)ix * P.hf_cols + iy;
+    int16_t h1 = H[0], h2 = H[P.hf_cols], h3 = H[1];
+    int16_t h = min(min(h1, h2), h3);
+    return (float)h * P.vertical_scale;
+}
+
+GRX_DEV float sum_abs_mask(const float a[LEG], uint32_t mask) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) if (mask & (1u << k)) s += fabsf(a[k]);
+    return s;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+template <bool HF>
+__global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict__ Pp, const float* __restrict__ actions_in,
+                                                      float delay, long long common_step, const float* __restrict__ noise_in) {
+    const KParams& P = *Pp;
+    __shared__ SideConst sc[2];
+    __shared__ __attribute__((aligned(16))) float s_obs[EPB * GRX_NUM_OBS];
+    __shared__ __attribute__((aligned(16))) float s_pri[EPB * GRX_MAX_PRI];
+    __shared__ float s_stat[NT + 1];
+    {   // stage the per-side robot tables (joint tree, inertias, gains, spheres) into LDS
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.side);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(sc);
+        for (int i = threadIdx.x; i < (int)(2 * sizeof(SideConst) / 4); i += 64) dst[i] = src[i];
+        if (threadIdx.x <= NT) s_stat[threadIdx.x] = 0.f;
+    }
+    __syncthreads();
+    const int N = P.N;
+    const int lane = threadIdx.x, el = lane >> 1, side = lane & 1;
+    const int e_raw = blockIdx.x * EPB + el;
+    const bool act = e_raw < N;
+    const int e = act ? e_raw : N - 1;
+    const SideConst& C = sc[side];
+    const uint32_t genv = (uint32_t)(P.env_offset + e);
+    const uint32_t step = (uint32_t)common_step;
+    const int nh = P.nh, npri = P.num_pri_obs;
+    const float dtp = P.sim_dt * (float)P.decimation;
+    const int j0 = side * LEG;
+
+    // ---- load state (SoA, coalesced)
+    LaneState st;
+    LaneConst LC;
+    float a_cur[LEG], a_last[LEG], qd_last[LEG];
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        size_t o = (size_t)(j0 + k) * N + e;
+        st.q[k] = P.q[o]; st.qd[k] = P.qd[o];
+        a_last[k] = P.last_actions[o]; qd_last[k] = P.last_dof_vel[o];
+        LC.strength[k] = P.motor_strength[o];
+        float a = actions_in ? actions_in[(size_t)e * GRX_ND + j0 + k] : 0.0f;
+        a_cur[k] = fminf(fmaxf(a, C.amin[k]), C.amax[k]);  // clip_actions legged_robot_fftai.py:171-177
+    }
+    st.pos = v3(P.root[0 * (size_t)N + e], P.root[1 * (size_t)N + e], P.root[2 * (size_t)N + e]);
+    st.qx = P.root[3 * (size_t)N + e]; st.qy = P.root[4 * (size_t)N + e]; st.qz = P.root[5 * (size_t)N + e]; st.qw = P.root[6 * (size_t)N + e];
+    st.vel = v3(P.root[7 * (size_t)N + e], P.root[8 * (size_t)N + e], P.root[9 * (size_t)N + e]);
+    st.ang = v3(P.root[10 * (size_t)N + e], P.root[11 * (size_t)N + e], P.root[12 * (size_t)N + e]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        st.ax[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 0) * N + e];
+        st.ay[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e];
+    }
+    st.anchor_on = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] != 0.0f) st.anchor_on |= (1u << i);
+    LC.base_m = P.base_m[e];
+    LC.base_c = v3(P.base_c[e], P.base_c[(size_t)N + e], P.base_c[2 * (size_t)N + e]);
+    LC.base_I.xx = P.base_I[e]; LC.base_I.xy = P.base_I[(size_t)N + e]; LC.base_I.xz = P.base_I[2 * (size_t)N + e];
+    LC.base_I.yy = P.base_I[3 * (size_t)N + e]; LC.base_I.yz = P.base_I[4 * (size_t)N + e]; LC.base_I.zz = P.base_I[5 * (size_t)N + e];
+    LC.mu = 0.5f * (P.terrain_friction + P.friction[e]);
+    EnvAux ea;
+    ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[(size_t)N + e]; ea.cmd[2] = P.commands[2 * (size_t)N + e];
+    ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[(size_t)N + e]; ea.origin[2] = P.origins[2 * (size_t)N + e];
+    ea.level = P.levels[e]; ea.type = P.types[e];
+    float air_time = P.air_time[(size_t)side * N + e], land_time = P.land_time[(size_t)side * N + e];
+    bool contact_last = P.contact_last[(size_t)side * N + e] != 0;
+    float bho_stale = P.base_heights_offset[e];
+    long long ep_len = P.ep_len[e];
+
+    // ---- during_physics_step (legged_robot_fftai.py:51-88), fused decimation loop
+    float avg_force = 0.f;
+    V3 avg_speed = v3(0.f, 0.f, 0.f);
+    float torque[LEG];
+    SubstepOut so;
+    FootKin fk;
+    for (int deci = 0; deci < P.decimation; ++deci) {
+        // keep the LDS-resident robot tables in LDS: without this barrier LICM hoists ~240 loop-invariant
+        // ds_reads into VGPRs and the kernel spills to scratch (measured: 604 B/lane -> 0)
+        asm volatile("" ::: "memory");
+        const bool use_last = (float)deci < delay;
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) {  // _compute_torques legged_robot.py:679-715
+            float a = use_last ? a_last[k] : a_cur[k];
+            float t = C.kp[k] * (a * P.action_scale + C.q0[k] - st.q[k]) - C.kd[k] * st.qd[k];
+            t *= LC.strength[k];
+            torque[k] = fminf(fmaxf(t, -C.effort[k]), C.effort[k]);
+        }
+        substep<HF>(P, C, LC, st, torque, so, fk);
+        if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
+            avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
+        }
+        avg_force += sqrtf(dot(so.foot_force, so.foot_force));
+    }
+    fk = foot_kinematics(C, st);  // refresh_rigid_body_state_tensor after the last sub-step
+    avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
+    avg_force = avg_force / (float)P.decimation;  // legged_robot_fftai.py:86-88
+    avg_speed = v3(avg_speed.x / (float)P.decimation, avg_speed.y / (float)P.decimation, avg_speed.z / (float)P.decimation);
+    const bool term_contact = __builtin_bit_cast(int, pair_swap(__builtin_bit_cast(float, (int)so.term))) | (int)so.term;
+    const float pen_count = pair_sum(so.pen_count);
+
+    // ---- post_physics_step (legged_robot.py:269-305)
+    ep_len += 1;
+    V3 qv = v3(st.qx, st.qy, st.qz);
+    V3 blv = quat_rotate_inverse(qv, st.qw, st.vel);
+    V3 bav = quat_rotate_inverse(qv, st.qw, st.ang);
+    V3 pg = quat_rotate_inverse(qv, st.qw, v3(0.f, 0.f, -1.f));
+    if (P.resample_command_interval > 0 && (ep_len % P.resample_command_interval) == 0)
+        resample_commands(P, genv, step, GRX_RNG_CMD_TIME, ea.cmd);
+    // measured heights: this lane samples points k = 2*i + side; raw heights parked in the pri_obs staging row
+    float* prow = s_pri + el * GRX_MAX_PRI;
+    float hsum = 0.f;
+    if (HF && P.measure_heights) {
+        for (int k = side; k < nh; k += 2) {
+            float h = height_sample(P, st.qz, st.qw, st.pos, k);
+            prow[GRX_NUM_OBS + 8 + k] = h;
+            hsum += h;
+        }
+        hsum = pair_sum(hsum);
+    } else {
+        for (int k = side; k < nh; k += 2) prow[GRX_NUM_OBS + 8 + k] = 0.f;
+    }
+    if (P.push_robots && P.push_interval > 0 && (common_step % P.push_interval) == 0) {  // legged_robot.py:786-797
+        st.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
+        st.vel.y = urand(P, genv, step, GRX_RNG_PUSH, 1, -P.max_push_vel_xy, P.max_push_vel_xy);
+    }
+    // feet timers (legged_robot_fftai.py:108-133) -- this lane's foot
+    const bool contact = so.foot_force.z > 1.0f;
+    const bool contact_filt = contact || contact_last;
+    contact_last = contact;
+    const bool first_contact = (air_time > 0.f) && contact_filt;
+    air_time += dtp;
+    const float feet_height = nh > 0 ? (fk.pos.z * (float)nh - hsum) / (float)nh : fk.pos.z;
+    land_time = (land_time + dtp) * (contact ? 1.0f : 0.0f);
+    // check_termination (legged_robot.py:336-353)
+    bool reset = term_contact || (fabsf(pg.z) < P.termination_gravity_z);
+    const bool time_out = (float)ep_len > P.max_episode_length;
+    reset = reset || time_out;
+
+    // ---- compute_reward (legged_robot.py:355-375): per-lane partial sums, pair-combined
+    float r[NT];
+    {
+        const float as = P.action_scale, H = P.swing_feet_height_target, T = P.feet_air_time_target;
+        const float* sg = P.reward_sigma;
+        const uint32_t knee = (P.knee_mask >> j0) & 31u, hiproll = (P.hip_roll_mask >> j0) & 31u, hipyaw = (P.hip_yaw_mask >> j0) & 31u;
+        const uint32_t ankle = ((side ? P.ankle_right_mask : P.ankle_left_mask) >> j0) & 31u;
+        float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) {
+            float d1 = (a_last[k] - a_cur[k]) * as;
+            s1 += fabsf(d1);  // last_last_actions == last_actions (legged_robot_fftai.py:94 copies after legged_robot.py:299)
+            if (knee & (1u << k)) s3 += fabsf((a_cur[k] - a_last[k]) * as);
+            sacc += fabsf((st.qd[k] - qd_last[k]) / dtp);
+            stor += fabsf(torque[k]);
+            svel += fabsf(st.qd[k]);
+            float po = fabsf(st.q[k] - C.q0[k]);
+            spose += po;
+            if (hipyaw & (1u << k)) shy += po;
+            float a = a_cur[k] * as, oa = 0.f, op = 0.f;
+            if (a - C.slo[k] < 0.f) oa += -(a - C.slo[k]);
+            if (a - C.shi[k] > 0.f) oa += (a - C.shi[k]);
+            sla += oa * oa;
+            if (st.q[k] - C.slo[k] < 0.f) op += -(st.q[k] - C.slo[k]);
+            if (st.q[k] - C.shi[k] > 0.f) op += (st.q[k] - C.shi[k]);
+            slp += fabsf(op);
+            slv += fminf(fmaxf(fabsf(st.qd[k]) - C.vlim[k] * P.soft_dof_vel_limit, 0.f), 1.f);
+            slt += fmaxf(fabsf(torque[k]) - C.effort[k] * P.soft_torque_limit, 0.f);
+        }
+        float tor_hr = sum_abs_mask(torque, hiproll), vel_kn = sum_abs_mask(st.qd, knee);
+        float h = feet_height;
+        float lift = sum_abs_mask(torque, ankle) * fabsf(h) * (h > H * 0.5f ? 1.f : 0.f);
+        float hmin = fminf(h, pair_swap(h));
+        float mid = fabsf(air_time - T * 0.5f);
+        float af = mid * avg_force;
+        float ah = mid * fabsf(h - hmin - H);
+        float at = expf(sg[GRX_REW_FEET_AIR_TIME] * fabsf(air_time - T)) * (first_contact ? 1.f : 0.f);
+        float le = (land_time - P.feet_land_time_max) * (land_time > P.feet_land_time_max ? 1.f : 0.f);
+        float lt = 1.f - expf(sg[GRX_REW_FEET_LAND_TIME] * le);
+        float close = fabsf(h - H * 0.25f) * (h < H * 0.25f ? 1.f : 0.f) / (H * 0.25f);
+        float exy = sqrtf(avg_speed.x * avg_speed.x + avg_speed.y * avg_speed.y) * close;
+        float far = fabsf(h - H * 3.f / 4.f) * (h > H * 3.f / 4.f ? 1.f : 0.f) / (H * 1.f / 4.f);
+        float ez = fabsf(avg_speed.z) * far;
+        V3 F = so.foot_force;
+        float serr = sqrtf(F.x * F.x + F.y * F.y) - P.feet_stumble_ratio * fabsf(F.z);
+        serr = serr * (serr > 0.f ? 1.f : 0.f);
+        float stum = 1.f - expf(sg[GRX_REW_FEET_STUMBLE] * serr);
+        float ncontact = contact ? 1.f : 0.f;
+        s1 = pair_sum(s1); s3 = pair_sum(s3); sacc = pair_sum(sacc); stor = pair_sum(stor); svel = pair_sum(svel);
+        spose = pair_sum(spose); sla = pair_sum(sla); slp = pair_sum(slp); slt = pair_sum(slt); slv = pair_sum(slv);
+        shy = pair_sum(shy); tor_hr = pair_sum(tor_hr); vel_kn = pair_sum(vel_kn); lift = pair_sum(lift);
+        af = pair_sum(af); ah = pair_sum(ah); at = pair_sum(at); lt = pair_sum(lt); exy = pair_sum(exy); ez = pair_sum(ez);
+        stum = pair_sum(stum); ncontact = pair_sum(ncontact);
+        const float cmd_n = sqrtf(ea.cmd[0] * ea.cmd[0] + ea.cmd[1] * ea.cmd[1]);
+        const float moving = cmd_n > 0.1f ? 1.f : 0.f;
+        r[GRX_REW_ACTION_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF] * s1);
+        r[GRX_REW_ACTION_DIFF_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_DIFF] * s1);
+        r[GRX_REW_ACTION_DIFF_KNEE] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_KNEE] * s3);
+        r[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] * fabsf(0.f - bav.y));
+        r[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] * fabsf(0.f - bav.x));
+        r[GRX_REW_CMD_DIFF_ANG_VEL_YAW] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_YAW] * fabsf(ea.cmd[2] - bav.z));
+        r[GRX_REW_CMD_DIFF_BASE_HEIGHT] = expf(sg[GRX_REW_CMD_DIFF_BASE_HEIGHT] * (fabsf(bho_stale) * (bho_stale < 0.f ? 1.f : 0.f)));
+        r[GRX_REW_CMD_DIFF_BASE_ORIENT] = expf(sg[GRX_REW_CMD_DIFF_BASE_ORIENT] * (fabsf(pg.x) + fabsf(pg.y)));
+        R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
+        {   // torso / forehead links ride on the base lump: R_link = R0 * rot; R^T(0,0,-1) = -(third row)
+            float tx = -(R0.cx.z * P.torso_rot[0] + R0.cy.z * P.torso_rot[3] + R0.cz.z * P.torso_rot[6]);
+            float ty = -(R0.cx.z * P.torso_rot[1] + R0.cy.z * P.torso_rot[4] + R0.cz.z * P.torso_rot[7]);
+            r[GRX_REW_CMD_DIFF_TORSO_ORIENT] = P.has_torso ? expf(sg[GRX_REW_CMD_DIFF_TORSO_ORIENT] * (fabsf(tx) + fabsf(ty))) : 0.f;
+            float fx = -(R0.cx.z * P.forehead_rot[0] + R0.cy.z * P.forehead_rot[3] + R0.cz.z * P.forehead_rot[6]);
+            float fy = -(R0.cx.z * P.forehead_rot[1] + R0.cy.z * P.forehead_rot[4] + R0.cz.z * P.forehead_rot[7]);
+            r[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] = P.has_forehead ? expf(sg[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] * (fabsf(fx) + fabsf(fy))) : 0.f;
+        }
+        r[GRX_REW_CMD_DIFF_LIN_VEL_X] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_X] * fabsf(ea.cmd[0] - blv.x));
+        r[GRX_REW_CMD_DIFF_LIN_VEL_Y] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Y] * fabsf(ea.cmd[1] - blv.y));
+        r[GRX_REW_CMD_DIFF_LIN_VEL_Z] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Z] * fabsf(0.f - blv.z));
+        r[GRX_REW_COLLISION] = 1.f - expf(sg[GRX_REW_COLLISION] * pen_count);
+        r[GRX_REW_DOF_ACC_NEW] = 1.f - expf(sg[GRX_REW_DOF_ACC_NEW] * sacc);
+        r[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] = 1.f - expf(sg[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] * lift);
+        r[GRX_REW_DOF_TOR_NEW] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW] * stor);
+        r[GRX_REW_DOF_TOR_NEW_HIP_ROLL] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW_HIP_ROLL] * tor_hr);
+        r[GRX_REW_DOF_VEL_NEW] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW] * svel);
+        r[GRX_REW_DOF_VEL_NEW_KNEE] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW_KNEE] * vel_kn);
+        r[GRX_REW_FEET_AIR_FORCE] = expf(sg[GRX_REW_FEET_AIR_FORCE] * af) * moving;
+        r[GRX_REW_FEET_AIR_HEIGHT] = expf(sg[GRX_REW_FEET_AIR_HEIGHT] * ah) * moving;
+        r[GRX_REW_FEET_AIR_TIME] = at * moving;
+        r[GRX_REW_FEET_LAND_TIME] = lt * moving;
+        r[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] = expf(sg[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] * exy);
+        r[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] = expf(sg[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] * ez);
+        r[GRX_REW_FEET_STUMBLE] = stum;
+        r[GRX_REW_LIMITS_ACTIONS] = 1.f - expf(sg[GRX_REW_LIMITS_ACTIONS] * sla);
+        r[GRX_REW_LIMITS_DOF_POS] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_POS] * slp);
+        r[GRX_REW_LIMITS_DOF_TOR] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_TOR] * slt);
+        r[GRX_REW_LIMITS_DOF_VEL] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_VEL] * slv);
+        r[GRX_REW_ON_THE_AIR] = ncontact == 0.f ? 1.f : 0.f;
+        r[GRX_REW_POSE_OFFSET] = expf(sg[GRX_REW_POSE_OFFSET] * spose);
+        r[GRX_REW_POSE_OFFSET_HIP_YAW] = 1.f - expf(sg[GRX_REW_POSE_OFFSET_HIP_YAW] * shy);
+        r[GRX_REW_STAND_STILL] = expf(sg[GRX_REW_STAND_STILL] * spose) * (cmd_n < 0.1f ? 1.f : 0.f);
+        r[GRX_REW_TERMINATION] = (reset && !time_out) ? 1.f : 0.f;
+    }
+    float rew = 0.f;
+    const bool writer = act && side == 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float sc_t = P.reward_scale_dt[t];
+        float rt = 0.f;
+        if (t != GRX_REW_TERMINATION && sc_t != 0.f) { rt = r[t] * sc_t; rew += rt; }
+        r[t] = rt;
+    }
+    if (P.only_positive_rewards) rew = fmaxf(rew, 0.f);
+    if (P.reward_scale_dt[GRX_REW_TERMINATION] != 0.f) {
+        float rt = r[GRX_REW_TERMINATION] = ((reset && !time_out) ? 1.f : 0.f) * P.reward_scale_dt[GRX_REW_TERMINATION];
+        rew += rt;
+    }
+    // episode sums; reset envs contribute to the block's episode statistics (legged_robot.py:420-424)
+    const unsigned long long reset_mask = __ballot(reset && writer);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (P.reward_scale_dt[t] == 0.f) continue;  // uniform
+        float es = P.episode_sums[(size_t)t * N + e] + r[t];
+        if (reset_mask) {  // wave-uniform: reduce the finished episodes' sums over the wave
+            float contrib = (reset && writer) ? es : 0.f;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off);
+            if (lane == 0) s_stat[t] = contrib;
+        }
+        if (writer) {
+            P.episode_sums[(size_t)t * N + e] = reset ? 0.f : es;
+            if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
+        }
+    }
+    if (lane == 0) s_stat[NT] = (float)__popcll(reset_mask);
+
+    // ---- reset_idx (masked, in-kernel)
+    if (reset) {
+        reset_env(P, C, side, genv, step, true, st, ea);
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) { a_last[k] = 0.f; qd_last[k] = 0.f; }
+        air_time = 0.f; land_time = 0.f;
+        contact_last = false;
+        ep_len = 0;
+    }
+    const bool feet_contact_obs = reset ? false : contact;  // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
+
+    // ---- compute_observations (legged_robot.py:442-452, legged_robot_fftai.py:148-167, gr1t1.py:281-336)
+    float bho;
+    {
+        float sum = 0.f;
+        for (int k = side; k < nh; k += 2) {
+            float d = st.pos.z - P.base_height_target - prow[GRX_NUM_OBS + 8 + k];
+            d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
+            if (P.publish_debug && act) P.heights[(size_t)k * N + e] = prow[GRX_NUM_OBS + 8 + k];
+            prow[GRX_NUM_OBS + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -P.clip_observations), P.clip_observations);
+            sum += d;
+        }
+        sum = pair_sum(sum);
+        bho = nh > 0 ? sum / (float)nh : 0.f;
+    }
+    float* orow = s_obs + el * GRX_NUM_OBS;
+    const float clipo = P.clip_observations;
+    auto put = [&](int idx, float val, float nscale) {
+        float pv = fminf(fmaxf(val, -clipo), clipo);
+        prow[idx] = pv;  // pri_obs copies obs BEFORE noise
+        float ov = val;
+        if (P.add_noise && nscale != 0.f) {
+            float u = noise_in ? noise_in[(size_t)e * GRX_NUM_OBS + idx] : grx_rand(P.seed, genv, step, GRX_RNG_NOISE, (uint32_t)idx);
+            ov += (2.f * u - 1.f) * nscale;
+        }
+        orow[idx] = fminf(fmaxf(ov, -clipo), clipo);
+    };
+    if (side == 0) {
+        put(0, ea.cmd[0], 0.f); put(1, ea.cmd[1], 0.f); put(2, ea.cmd[2], 0.f);
+        const float na = P.noise_ang_vel * P.noise_level * P.obs_scale_ang_vel;
+        put(3, bav.x * P.obs_scale_ang_vel, na); put(4, bav.y * P.obs_scale_ang_vel, na); put(5, bav.z * P.obs_scale_ang_vel, na);
+        const float ng = P.noise_gravity * P.noise_level * P.obs_scale_gravity;
+        put(6, pg.x * P.obs_scale_gravity, ng); put(7, pg.y * P.obs_scale_gravity, ng); put(8, pg.z * P.obs_scale_gravity, ng);
+        prow[GRX_NUM_OBS + 0] = fminf(fmaxf(blv.x * P.obs_scale_lin_vel, -clipo), clipo);
+        prow[GRX_NUM_OBS + 1] = fminf(fmaxf(blv.y * P.obs_scale_lin_vel, -clipo), clipo);
+        prow[GRX_NUM_OBS + 2] = fminf(fmaxf(blv.z * P.obs_scale_lin_vel, -clipo), clipo);
+        prow[GRX_NUM_OBS + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
+    }
+    {
+        const float np_ = P.noise_dof_pos * P.noise_level * P.obs_scale_dof_pos;
+        const float nv = P.noise_dof_vel * P.noise_level * P.obs_scale_dof_vel;
+        const float nac = P.noise_action * P.noise_level * P.obs_scale_action;
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) {
+            put(9 + j0 + k, (st.q[k] - C.q0[k]) * P.obs_scale_dof_pos, np_);
+            put(9 + GRX_ND + j0 + k, st.qd[k] * P.obs_scale_dof_vel, nv);
+            put(9 + 2 * GRX_ND + j0 + k, a_cur[k] * P.obs_scale_action, nac);
+        }
+        prow[GRX_NUM_OBS + 4 + side] = feet_contact_obs ? 1.f : 0.f;
+        prow[GRX_NUM_OBS + 6 + side] = fminf(fmaxf(feet_height * P.obs_scale_height, -clipo), clipo);
+    }
+
+    // ---- store state (SoA) -- history: last_actions = actions, last_dof_vel = dof_vel (legged_robot.py:299-300)
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) {
+            size_t o = (size_t)(j0 + k) * N + e;
+            P.q[o] = st.q[k]; P.qd[o] = st.qd[k];
+            P.last_actions[o] = a_cur[k]; P.last_dof_vel[o] = st.qd[k];
+            P.actions[o] = a_cur[k]; P.torques[o] = torque[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            P.anchors[(size_t)((side * 4 + i) * 3 + 0) * N + e] = st.ax[i];
+            P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e] = st.ay[i];
+            P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] = (st.anchor_on >> i) & 1u ? 1.f : 0.f;
+        }
+        P.air_time[(size_t)side * N + e] = air_time * (contact_filt ? 0.f : 1.f);  // legged_robot_fftai.py:97
+        P.land_time[(size_t)side * N + e] = land_time;
+        P.contact_last[(size_t)side * N + e] = contact_last ? 1 : 0;
+        P.feet_contact[(size_t)side * N + e] = feet_contact_obs ? 1 : 0;
+        P.feet_height[(size_t)side * N + e] = feet_height;
+        P.avg_force[(size_t)side * N + e] = avg_force;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float ff = i == 0 ? so.foot_force.x : (i == 1 ? so.foot_force.y : so.foot_force.z);
+            float fp = i == 0 ? fk.pos.x : (i == 1 ? fk.pos.y : fk.pos.z);
+            float as_ = i == 0 ? avg_speed.x : (i == 1 ? avg_speed.y : avg_speed.z);
+            P.feet_force[(size_t)(side * 3 + i) * N + e] = ff;
+            P.feet_pos[(size_t)(side * 3 + i) * N + e] = fp;
+            P.avg_speed[(size_t)(side * 3 + i) * N + e] = as_;
+        }
+    }
+    if (writer) {
+        float rs[13] = {st.pos.x, st.pos.y, st.pos.z, st.qx, st.qy, st.qz, st.qw, st.vel.x, st.vel.y, st.vel.z, st.ang.x, st.ang.y, st.ang.z};
+#pragma unroll
+        for (int i = 0; i < 13; ++i) P.root[(size_t)i * N + e] = rs[i];
+        P.commands[e] = ea.cmd[0]; P.commands[(size_t)N + e] = ea.cmd[1]; P.commands[2 * (size_t)N + e] = ea.cmd[2];
+        P.base_lin_vel[e] = blv.x; P.base_lin_vel[(size_t)N + e] = blv.y; P.base_lin_vel[2 * (size_t)N + e] = blv.z;
+        P.base_ang_vel[e] = bav.x; P.base_ang_vel[(size_t)N + e] = bav.y; P.base_ang_vel[2 * (size_t)N + e] = bav.z;
+        P.proj_grav[e] = pg.x; P.proj_grav[(size_t)N + e] = pg.y; P.proj_grav[2 * (size_t)N + e] = pg.z;
+        P.origins[e] = ea.origin[0]; P.origins[(size_t)N + e] = ea.origin[1]; P.origins[2 * (size_t)N + e] = ea.origin[2];
+        P.levels[e] = ea.level;
+        P.base_heights_offset[e] = bho;
+        P.ep_len[e] = ep_len;
+        P.rew[e] = rew;
+        P.reset[e] = reset ? 1 : 0;
+        P.time_out[e] = time_out ? 1 : 0;
+        P.term_contact[e] = term_contact ? 1 : 0;
+    }
+    // ---- coalesced AoS output rows: the wave's 32 obs / pri_obs rows are contiguous in HBM
+    __syncthreads();
+    {
+        const int e0 = blockIdx.x * EPB;
+        const int nenv = min(EPB, N - e0);
+        float* gobs = P.obs + (size_t)e0 * GRX_NUM_OBS;
+        const int tot = nenv * GRX_NUM_OBS;
+        if (nenv == EPB) {
+            const float4* s4 = reinterpret_cast<const float4*>(s_obs);
+            float4* g4 = reinterpret_cast<float4*>(gobs);
+            for (int i = lane; i < EPB * GRX_NUM_OBS / 4; i += 64) g4[i] = s4[i];
+        } else
+            for (int i = lane; i < tot; i += 64) gobs[i] = s_obs[i];
+        float* gpri = P.pri_obs + (size_t)e0 * npri;
+        if (npri == GRX_MAX_PRI && nenv == EPB) {
+            const float4* s4 = reinterpret_cast<const float4*>(s_pri);
+            float4* g4 = reinterpret_cast<float4*>(gpri);
+            for (int i = lane; i < EPB * GRX_MAX_PRI / 4; i += 64) g4[i] = s4[i];
+        } else
+            for (int i = lane; i < nenv * npri; i += 64) gpri[i] = s_pri[(i / npri) * GRX_MAX_PRI + (i % npri)];
+        if (lane <= NT) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + lane] = s_stat[lane];
+    }
+}
+
+// extras["episode"] (legged_robot.py:420-424): mean episode sums of the envs reset by this step;
+// kept from the previous resetting step when nobody reset (the reference only rewrites the dict
+// inside reset_idx, which returns early for an empty id list, legged_robot.py:387-388).
+__global__ void grx_finalize_stats(const KParams* __restrict__ Pp, int nblocks) {
+    const KParams& P = *Pp;
+    int t = threadIdx.x;
+    if (t > NT) return;
+    float cnt = 0.f, s = 0.f;
+    for (int b = 0; b < nblocks; ++b) {
+        cnt += P.stat_partial[(size_t)b * (NT + 1) + NT];
+        s += P.stat_partial[(size_t)b * (NT + 1) + t];
+    }
+    if (cnt > 0.f) P.stats[t] = (t == NT) ? cnt : s / cnt / P.max_episode_length_s;
+}
+
+// BaseTask.reset() first half (base_task.py:117-119): reset_idx(all envs), no step
+__global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __restrict__ Pp, uint32_t step) {
+    const KParams& P = *Pp;
+    __shared__ SideConst sc[2];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.side);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(sc);
+        for (int i = threadIdx.x; i < (int)(2 * sizeof(SideConst) / 4); i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int N = P.N;
+    const int lane = threadIdx.x, el = lane >> 1, side = lane & 1;
+    const int e_raw = blockIdx.x * EPB + el;
+    const bool act = e_raw < N;
+    const int e = act ? e_raw : N - 1;
+    const bool writer = act && side == 0;
+    const SideConst& C = sc[side];
+    const uint32_t genv = (uint32_t)(P.env_offset + e);
+    const int j0 = side * LEG;
+    // extras["episode"]: every env is "finished" (legged_robot.py:420-424)
+    for (int t = 0; t < NT; ++t) {
+        float contrib = writer ? P.episode_sums[(size_t)t * N + e] : 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off);
+        if (lane == 0) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + t] = contrib;
+    }
+    if (lane == 0) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + NT] = (float)min(EPB, N - blockIdx.x * EPB);
+    LaneState st;
+    EnvAux ea;
+    st.pos = v3(P.root[e], P.root[(size_t)N + e], P.root[2 * (size_t)N + e]);
+    ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[(size_t)N + e]; ea.cmd[2] = P.commands[2 * (size_t)N + e];
+    ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[(size_t)N + e]; ea.origin[2] = P.origins[2 * (size_t)N + e];
+    ea.level = P.levels[e]; ea.type = P.types[e];
+    reset_env(P, C, side, genv, step, false, st, ea);
+    if (!act) return;
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        size_t o = (size_t)(j0 + k) * N + e;
+        P.q[o] = st.q[k]; P.qd[o] = 0.f; P.last_actions[o] = 0.f; P.last_dof_vel[o] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] = 0.f;
+    P.air_time[(size_t)side * N + e] = 0.f; P.land_time[(size_t)side * N + e] = 0.f;
+    P.contact_last[(size_t)side * N + e] = 0; P.feet_contact[(size_t)side * N + e] = 0;
+    if (side == 0) {
+        float rs[13] = {st.pos.x, st.pos.y, st.pos.z, st.qx, st.qy, st.qz, st.qw, st.vel.x, st.vel.y, st.vel.z, st.ang.x, st.ang.y, st.ang.z};
+#pragma unroll
+        for (int i = 0; i < 13; ++i) P.root[(size_t)i * N + e] = rs[i];
+        P.commands[e] = ea.cmd[0]; P.commands[(size_t)N + e] = ea.cmd[1]; P.commands[2 * (size_t)N + e] = ea.cmd[2];
+        P.ep_len[e] = 0;
+        P.reset[e] = 1;
+        for (int t = 0; t < NT; ++t) P.episode_sums[(size_t)t * N + e] = 0.f;
+    }
+}
+
+// set_dof_state_tensor / set_actor_root_state_tensor (legged_robot.py:737, 796): AoS rows -> SoA state
+__global__ void grx_set_state_kernel(const KParams* __restrict__ Pp, const float* __restrict__ root, const float* __restrict__ q,
+                                     const float* __restrict__ qd) {
+    const KParams& P = *Pp;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.N) return;
+    size_t N = P.N;
+    if (root) for (int i = 0; i < 13; ++i) P.root[i * N + e] = root[(size_t)e * 13 + i];
+    if (q) for (int j = 0; j < GRX_ND; ++j) P.q[j * N + e] = q[(size_t)e * GRX_ND + j];
+    if (qd) for (int j = 0; j < GRX_ND; ++j) P.qd[j * N + e] = qd[(size_t)e * GRX_ND + j];
+    for (int i = 0; i < 8; ++i) P.anchors[(size_t)(i * 3 + 2) * N + e] = 0.f;
+}
+
+// host-callable launchers (grx_capi.cpp is compiled by hipcc too; kept separate for readability)
+extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, const float* actions, float delay, long long common_step,
+                                const float* noise, hipStream_t stream) {
+    int nblocks = (N + EPB - 1) / EPB;
+    if (heightfield) hipLaunchKernelGGL(grx_step_kernel<true>, dim3(nblocks), dim3(64), 0, stream, dP, actions, delay, common_step, noise);
+    else hipLaunchKernelGGL(grx_step_kernel<false>, dim3(nblocks), dim3(64), 0, stream, dP, actions, delay, common_step, noise);
+}
+extern "C" void grx_launch_finalize(const KParams* dP, int N, hipStream_t stream) {
+    int nblocks = (N + EPB - 1) / EPB;
+    hipLaunchKernelGGL(grx_finalize_stats, dim3(1), dim3(64), 0, stream, dP, nblocks);
+}
+extern "C" void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream) {
+    int nblocks = (N + EPB - 1) / EPB;
+    hipLaunchKernelGGL(grx_reset_all_kernel, dim3(nblocks), dim3(64), 0, stream, dP, step);
+}
+extern "C" void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, hipStream_t stream) {
+    hipLaunchKernelGGL(grx_set_state_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dP, root, q, qd);
+}
+extern "C" int grx_envs_per_block(void) { return EPB; }

@@ -1,0 +1,345 @@
+"""Configuration tree of the GRx tasks.
+
+Same *surface* as the reference (attribute paths such as ``cfg.env.num_envs``,
+``cfg.rewards.scales.<term>``, ``train_cfg.runner.max_iterations``; nested classes that user
+code may subclass; ``BaseConfig()`` instantiates every nested class), same resolved values:
+
+    legged_robot_config.py:33-294   LeggedRobotCfg / LeggedRobotCfgPPO
+    legged_robot_fftai_config.py    LeggedRobotFFTAICfg / ...PPO
+    gr1t1_config.py:10-345          GR1T1Cfg (full body, 32 DOF)     -> here GR1T1FullCfg
+    gr1t1_lower_limb_config.py      GR1T1LowerLimbCfg (registered as task "GR1T1")
+    gr1t2_config.py / gr1t2_lower_limb_config.py
+
+The only additions are ``sim.grx`` (contact-model parameters of this build's own physics; the
+reference's PhysX block ``sim.physx`` is kept for CLI/``class_to_dict`` compatibility but the
+TGS-specific entries have no effect here) and ``asset.model`` (key of the model table under
+assets/).  Sections are built with ``section()`` (type() under the hood) instead of nested class
+statements; the result is ordinary classes, so ``class env(GR1T1Cfg.env): ...`` keeps working.
+"""
+import inspect
+import math
+
+import numpy as np
+
+E = math.e  # the reference writes torch.e
+
+
+class BaseConfig:
+    """Instantiating a config turns every nested class attribute into an instance, recursively
+    (reference: base_config.py:33-55)."""
+
+    def __init__(self):
+        _instantiate_sections(self)
+
+
+def _instantiate_sections(obj):
+    for name in dir(obj):
+        if name == "__class__":
+            continue
+        val = getattr(obj, name)
+        if inspect.isclass(val):
+            inst = val()
+            setattr(obj, name, inst)
+            _instantiate_sections(inst)
+
+
+def section(_section_name, *bases, **fields):
+    """A config section = a plain class whose attributes are the fields."""
+    return type(_section_name, bases, dict(fields))
+
+
+def _deg(x):
+    return float(np.deg2rad(x))
+
+
+# --------------------------------------------------------------------------------------------
+# generic legged robot (legged_robot_config.py:33-294)
+class LeggedRobotCfg(BaseConfig):
+    sim = section(
+        "sim", dt=0.005, substeps=1, gravity=[0.0, 0.0, -9.81], up_axis=1,
+        physx=section("physx", num_threads=10, solver_type=1, num_position_iterations=4,
+                      num_velocity_iterations=0, contact_offset=0.01, rest_offset=0.0,
+                      bounce_threshold_velocity=0.5, max_depenetration_velocity=1.0,
+                      max_gpu_contact_pairs=2 ** 23, default_buffer_size_multiplier=5,
+                      contact_collection=2),
+        # this build's compliant contact model; units in include/grx.h
+        grx=section("grx", kn=2.5e4, dn=4.0, kt=1.5e4, ct=60.0, cv=300.0, k_limit=30.0, c_limit=0.005, damp_alpha=0.5),
+    )
+    env = section("env", num_envs=4096, episode_length_s=20, num_obs=235, num_pri_obs=None,
+                  num_actions=12, env_spacing=3.0, send_timeouts=True)
+    terrain = section(
+        "terrain", mesh_type="trimesh", horizontal_scale=0.1, vertical_scale=0.005, border_size=25,
+        curriculum=True, num_rows=10, num_cols=20, max_init_terrain_level=9,
+        static_friction=1.0, dynamic_friction=1.0, restitution=0.0, measure_heights=True,
+        measured_points_x=[-0.5, -0.4, -0.3, -0.2, -0.1, 0.0, 0.1, 0.2, 0.3, 0.4, 0.5],
+        measured_points_y=[-0.5, -0.4, -0.3, -0.2, -0.1, 0.0, 0.1, 0.2, 0.3, 0.4, 0.5],
+        selected=False, terrain_kwargs=None, terrain_proportions=[0.1, 0.1, 0.35, 0.25, 0.2],
+        slope_treshold=0.75, terrain_length=8.0, terrain_width=8.0)
+    asset = section(
+        "asset", file="", name="legged_robot", torso_name="torso", foot_name="None",
+        penalize_contacts_on=[], terminate_after_contacts_on=["base"], disable_gravity=False,
+        collapse_fixed_joints=False, fix_base_link=False, default_dof_drive_mode=3, self_collisions=0,
+        replace_cylinder_with_capsule=False, flip_visual_attachments=False, density=0.001,
+        angular_damping=0.0, linear_damping=0.0, max_angular_velocity=1000.0,
+        max_linear_velocity=1000.0, armature=0.0, thickness=0.01)
+    init_state = section("init_state", pos=[0.0, 0.0, 1.0], rot=[0.0, 0.0, 0.0, 1.0],
+                         lin_vel=[0.0, 0.0, 0.0], ang_vel=[0.0, 0.0, 0.0],
+                         default_joint_angles={"joint_a": 0.0, "joint_b": 0.0})
+    commands = section(
+        "commands", curriculum=False, max_curriculum=1.0, num_commands=4,
+        resampling_command_interval_s=10.0, heading_command=True,
+        ranges=section("ranges", lin_vel_x=[-1.0, 1.0], lin_vel_y=[-1.0, 1.0], ang_vel_yaw=[-1, 1],
+                       heading=[-3.14, 3.14]))
+    control = section("control", control_type="P", stiffness={"joint_a": 10.0, "joint_b": 15.0},
+                      damping={"joint_a": 1.0, "joint_b": 1.5}, action_scale=0.5, decimation=4)
+    domain_rand = section(
+        "domain_rand", randomize_friction=True, friction_range=[0.1, 1.0],
+        randomize_restitution=True, restitution_range=[0.0, 0.5],
+        randomize_base_mass=True, multiply_base_mass_range=[0.9, 1.1],
+        randomize_base_com=True, add_base_com_range_x=[-0.1, 0.1], add_base_com_range_y=[-0.1, 0.1],
+        add_base_com_range_z=[-0.1, 0.1],
+        randomize_motor_strength=True, multiply_motor_strength=[0.9, 1.1],
+        push_robots=True, push_interval_s=10.0, max_push_vel_xy=0.5,
+        randomize_init_dof_pos=True, randomize_init_base_velocity=True)
+    rewards = section(
+        "rewards", scales=section("scales", termination=-0.0), only_positive_rewards=True,
+        tracking_sigma=0.25, soft_dof_pos_limit=1.0, soft_dof_vel_limit=1.0, soft_torque_limit=1.0,
+        base_height_target=1.0, max_contact_force=100.0)
+    noise = section(
+        "noise", add_noise=True, noise_level=1.0,
+        noise_scales=section("noise_scales", action=0.0, dof_pos=0.01, dof_vel=1.5, lin_vel=0.1,
+                             ang_vel=0.2, gravity=0.05, height_measurements=0.1))
+    normalization = section(
+        "normalization",
+        obs_scales=section("obs_scales", action=1.0, lin_vel=2.0, ang_vel=0.25, gravity=1.0,
+                           dof_pos=1.0, dof_vel=0.05, height_measurements=5.0),
+        clip_observations=100.0, clip_actions=100.0)
+    viewer = section("viewer", ref_env=0, pos=[10, 0, 6], lookat=[11.0, 5, 3.0])
+
+
+class LeggedRobotCfgPPO(BaseConfig):
+    seed = 1
+    runner_class_name = "OnPolicyRunner"
+    runner = section("runner", algorithm_class_name="PPO", policy_class_name="ActorCritic",
+                     num_steps_per_env=24, max_iterations=1500, save_interval=50,
+                     experiment_name="test", run_name="", resume=False, load_run=-1, checkpoint=-1,
+                     resume_path=None)
+    algorithm = section("algorithm", value_loss_coef=1.0, use_clipped_value_loss=True, clip_param=0.2,
+                        entropy_coef=0.01, num_learning_epochs=5, num_mini_batches=4,
+                        learning_rate=1.0e-3, schedule="adaptive", gamma=0.99, lam=0.95,
+                        desired_kl=0.01, max_grad_norm=1.0)
+    policy = section("policy", init_noise_std=1.0, actor_hidden_dims=[512, 256, 128],
+                     critic_hidden_dims=[512, 256, 128], activation="elu")
+
+
+# --------------------------------------------------------------------------------------------
+# Fourier layer (legged_robot_fftai_config.py)
+class LeggedRobotFFTAICfg(LeggedRobotCfg):
+    sim = section("sim", LeggedRobotCfg.sim, dt=0.001,
+                  physx=section("physx", LeggedRobotCfg.sim.physx, num_position_iterations=4,
+                                num_velocity_iterations=0))
+    env = section("env", LeggedRobotCfg.env, num_obs=1, num_actions=1)
+    rewards = section("rewards", LeggedRobotCfg.rewards, sigma_action_diff=-0.1, sigma_action_diff_diff=-1.0)
+
+
+class LeggedRobotFFTAICfgPPO(LeggedRobotCfgPPO):
+    pass
+
+
+# --------------------------------------------------------------------------------------------
+# GR1T1 full body (gr1t1_config.py:10-345).  Joint order of the 32-entry arrays:
+# left leg (6), right leg (6), waist (3), head (3), left arm (7), right arm (7).
+_LEG_JOINTS = ("hip_roll", "hip_yaw", "hip_pitch", "knee_pitch", "ankle_pitch", "ankle_roll")
+_FULL_DEFAULT_ANGLES = {}
+for _side in ("left", "right"):
+    for _j, _a in zip(_LEG_JOINTS, (0.0, 0.0, -_deg(15), _deg(30), -_deg(15), 0.0)):
+        _FULL_DEFAULT_ANGLES[f"{_side}_{_j}_joint"] = _a
+for _j in ("waist_yaw", "waist_pitch", "waist_roll", "head_yaw", "head_pitch", "head_roll"):
+    _FULL_DEFAULT_ANGLES[_j + "_joint"] = 0.0
+for _side, _sgn in (("left", 1.0), ("right", -1.0)):
+    for _j, _a in (("shoulder_pitch", 0.0), ("shoulder_roll", 0.2 * _sgn), ("shoulder_yaw", 0.0),
+                   ("elbow_pitch", -0.3), ("wrist_yaw", 0.0), ("wrist_roll", 0.0), ("wrist_pitch", 0.0)):
+        _FULL_DEFAULT_ANGLES[f"{_side}_{_j}_joint"] = _a
+
+_FULL_ACT_MAX = np.array([0.79, 0.7, 0.7, 1.92, 0.52, 0.44, 0.09, 0.7, 0.7, 1.92, 0.52, 0.44,
+                          1.05, 1.22, 0.7, 2.71, 0.35, 0.35,
+                          1.92, 3.27, 2.97, 2.27, 2.97, 0.61, 0.61,
+                          1.92, 0.57, 2.97, 2.27, 2.97, 0.61, 0.61])
+_FULL_ACT_MIN = np.array([-0.09, -0.7, -1.75, -0.09, -1.05, -0.44, -0.79, -0.7, -1.75, -0.09, -1.05, -0.44,
+                          -1.05, -0.52, -0.7, -2.71, -0.35, -0.52,
+                          -2.79, -0.57, -2.97, -2.27, -2.97, -0.61, -0.61,
+                          -2.79, -3.27, -2.97, -2.27, -2.97, -0.61, -0.61])
+_FULL_SPAN = np.abs(_FULL_ACT_MAX) + np.abs(_FULL_ACT_MIN)
+
+_SIGMAS = dict(
+    sigma_collision=-1.0 * E, sigma_stand_still=-1.0 * E,
+    sigma_cmd_diff_lin_vel_x=-1.0 * E * (1.0 / 0.50), sigma_cmd_diff_lin_vel_y=-1.0 * E * (1.0 / 1.00),
+    sigma_cmd_diff_lin_vel_z=-1.0 * E, sigma_cmd_diff_ang_vel_roll=-1.0 * E,
+    sigma_cmd_diff_ang_vel_pitch=-1.0 * E, sigma_cmd_diff_ang_vel_yaw=-1.0 * E * (1.0 / 3.00),
+    sigma_cmd_diff_base_height=-10.0 * E, sigma_cmd_diff_base_orient=-20.0,
+    sigma_cmd_diff_torso_orient=-20.0, sigma_cmd_diff_forehead_orient=-20.0,
+    sigma_action_diff=-0.1, sigma_action_diff_knee=-1.0, sigma_dof_vel_new=-0.01,
+    sigma_dof_vel_new_knee=-0.05, sigma_dof_acc_new=-0.001 * E, sigma_dof_tor_new=-0.01 * E,
+    sigma_dof_tor_new_hip_roll=-0.002, sigma_dof_tor_ankle_feet_lift_up=-1.0, sigma_pose_offset=-0.1,
+    sigma_pose_offset_hip_yaw=-0.1, sigma_limits_dof_pos=-1.0, sigma_limits_dof_vel=-10.0,
+    sigma_limits_dof_tor=-0.1, sigma_feet_speed_xy_close_to_ground=-10.0,
+    sigma_feet_speed_z_close_to_height_target=-10.0, sigma_feet_air_time=-1.0,
+    sigma_feet_air_time_mid=-10.0, sigma_feet_air_height=-200.0, sigma_feet_air_force=-0.05,
+    sigma_feet_land_time=-1.0, sigma_on_the_air=-1.0, sigma_feet_stumble=-1.0)
+
+_ASSET_NAMES = dict(
+    torso_name="torso", forehead_name="head_pitch", imu_name="imu", waist_name="waist",
+    waist_yaw_name="waist_yaw", waist_roll_name="waist_roll", waist_pitch_name="waist_pitch",
+    head_name="head", head_roll_name="head_roll", head_pitch_name="head_pitch", thigh_name="thigh",
+    shank_name="shank", foot_name="foot_roll", sole_name="sole", upper_arm_name="upper_arm",
+    lower_arm_name="lower_arm", hand_name="hand", hip_name="hip", hip_roll_name="hip_roll",
+    hip_yaw_name="hip_yaw", hip_pitch_name="hip_pitch", knee_name="knee", ankle_name="ankle",
+    ankle_pitch_name="ankle_pitch", ankle_roll_name="ankle_roll", shoulder_name="shoulder",
+    shoulder_pitch_name="shoulder_pitch", shoulder_roll_name="shoulder_roll",
+    shoulder_yaw_name="shoulder_yaw", elbow_name="elbow", wrist_name="wrist", wrist_yaw_name="wrist_yaw",
+    wrist_roll_name="wrist_roll", wrist_pitch_name="wrist_pitch", arm_base_name="arm_base",
+    arm_end_name="arm_end")
+
+
+class GR1T1FullCfg(LeggedRobotFFTAICfg):
+    sim = section("sim", LeggedRobotFFTAICfg.sim, dt=0.002)
+    env = section("env", LeggedRobotFFTAICfg.env, num_envs=8192, episode_length_s=20, num_obs=121, num_actions=32)
+    terrain = section("terrain", LeggedRobotFFTAICfg.terrain, mesh_type="plane")
+    asset = section(
+        "asset", LeggedRobotFFTAICfg.asset,
+        file="{LEGGED_GYM_ROOT_DIR}/resources/robots/GR1T1/urdf/GR1T1.urdf", name="GR1T1",
+        penalize_contacts_on=[],
+        terminate_after_contacts_on=["imu", "torso", "head_pitch", "waist", "upper_arm", "lower_arm", "hand"],
+        **_ASSET_NAMES)
+    init_state = section("init_state", LeggedRobotFFTAICfg.init_state, pos=[0.0, 0.0, 0.95],
+                         rot=[0.0, 0.0, 0.0, 1.0], lin_vel=[0.0, 0.0, 0.0], ang_vel=[0.0, 0.0, 0.0],
+                         default_joint_angles=dict(_FULL_DEFAULT_ANGLES))
+    commands = section(
+        "commands", LeggedRobotFFTAICfg.commands, curriculum=False, curriculum_chg_lin_vel_x=0.25,
+        curriculum_chg_lin_vel_y=0.25, curriculum_chg_ang_vel_yaw=0.25, curriculum_max_lin_vel_x=1.00,
+        curriculum_max_lin_vel_y=0.50, curriculum_max_ang_vel_yaw=1.00, num_commands=3,
+        resampling_command_interval_s=10.0, heading_command=False,
+        ranges=section("ranges", LeggedRobotFFTAICfg.commands.ranges, lin_vel_x=[-1.00, 1.00],
+                       lin_vel_y=[-0.50, 0.50], ang_vel_yaw=[-1.00, 1.00]))
+    control = section(
+        "control", LeggedRobotFFTAICfg.control,
+        stiffness={"hip_roll": 251.625, "hip_yaw": 362.5214, "hip_pitch": 200, "knee_pitch": 200,
+                   "ankle_pitch": 10.9805, "ankle_roll": 0.25, "waist_yaw": 362.5214,
+                   "waist_pitch": 362.5214, "waist_roll": 362.5214, "head_yaw": 10.0, "head_pitch": 10.0,
+                   "head_roll": 10.0, "shoulder_pitch": 92.85, "shoulder_roll": 92.85,
+                   "shoulder_yaw": 112.06, "elbow_pitch": 112.06, "wrist_yaw": 10.0, "wrist_roll": 10.0,
+                   "wrist_pitch": 10.0},
+        damping={"hip_roll": 14.72, "hip_yaw": 10.0833, "hip_pitch": 11, "knee_pitch": 11,
+                 "ankle_pitch": 0.5991, "ankle_roll": 0.01, "waist_yaw": 10.0833, "waist_pitch": 10.0833,
+                 "waist_roll": 10.0833, "head_yaw": 1.0, "head_pitch": 1.0, "head_roll": 1.0,
+                 "shoulder_pitch": 2.575, "shoulder_roll": 2.575, "shoulder_yaw": 3.1, "elbow_pitch": 3.1,
+                 "wrist_yaw": 1.0, "wrist_roll": 1.0, "wrist_pitch": 1.0},
+        action_scale=1.0, decimation=10)
+    rewards = section(
+        "rewards", LeggedRobotFFTAICfg.rewards, only_positive_rewards=False, base_height_target=0.85,
+        swing_feet_height_target=0.10, feet_stumble_ratio=5.0, feet_air_time_target=0.5,
+        feet_land_time_max=1.0, tracking_sigma=1.0, soft_dof_pos_limit=0.95, soft_dof_vel_limit=0.95,
+        soft_torque_limit=0.95, max_contact_force=500.0,
+        scales=section("scales", LeggedRobotFFTAICfg.rewards.scales, termination=0.0), **_SIGMAS)
+    noise = section(
+        "noise", LeggedRobotFFTAICfg.noise, add_noise=True, noise_level=1.0,
+        noise_scales=section("noise_scales", LeggedRobotFFTAICfg.noise.noise_scales, action=0.00,
+                             lin_vel=0.10, ang_vel=0.05, gravity=0.03, dof_pos=0.04, dof_vel=0.20,
+                             height_measurements=0.05))
+    normalization = section(
+        "normalization", LeggedRobotFFTAICfg.normalization,
+        obs_scales=section("obs_scales", LeggedRobotFFTAICfg.normalization.obs_scales, action=1.0,
+                           lin_vel=1.0, ang_vel=1.0, gravity=1.0, dof_pos=1.0, dof_vel=1.0,
+                           height_measurements=5.0),
+        actions_max=_FULL_ACT_MAX, actions_min=_FULL_ACT_MIN, clip_observations=100.0,
+        clip_actions_max=_FULL_ACT_MAX + _FULL_SPAN * 0.01, clip_actions_min=_FULL_ACT_MIN - _FULL_SPAN * 0.01)
+
+
+class GR1T1FullCfgPPO(LeggedRobotFFTAICfgPPO, GR1T1FullCfg):
+    runner_class_name = "OnPolicyRunner"
+    runner = section("runner", LeggedRobotFFTAICfgPPO.runner, algorithm_class_name="PPO",
+                     policy_class_name="ActorCriticMLP", experiment_name="GR1T1", num_steps_per_env=64,
+                     run_name="gr1t1", max_iterations=2000, save_interval=100)
+    algorithm = section("algorithm", LeggedRobotFFTAICfgPPO.algorithm, num_learning_epochs=8,
+                        num_mini_batches=25, learning_rate=1.0e-4, learning_rate_min=1.0e-5,
+                        learning_rate_max=1.0e-3, schedule="adaptive", desired_kl=0.01,
+                        storage_class="RolloutStorage")
+    policy = section("policy", LeggedRobotFFTAICfgPPO.policy, actor_hidden_dims=[512, 256, 128],
+                     critic_hidden_dims=[512, 256, 128], activation="elu", actor_output_activation=None,
+                     critic_output_activation=None, fixed_std=False, init_noise_std=0.2)
+
+
+# --------------------------------------------------------------------------------------------
+# GR1T1 lower limb = the registered task "GR1T1" (gr1t1_lower_limb_config.py, envs/__init__.py:41-55)
+_LL_STIFF = {"hip_roll": 48 / _deg(30), "hip_yaw": 66 / _deg(30), "hip_pitch": 130 / _deg(30),
+             "knee_pitch": 130 / _deg(30), "ankle_pitch": 15 / _deg(30)}
+_LL_ACT_MAX = np.array([0.79, 0.7, 0.7, 1.92, 0.52, 0.09, 0.7, 0.7, 1.92, 0.52])
+_LL_ACT_MIN = np.array([-0.09, -0.7, -1.75, -0.09, -1.05, -0.79, -0.7, -1.75, -0.09, -1.05])
+
+_LL_SCALES = dict(
+    termination=-0.0, collision=-0.0, stand_still=1.0, cmd_diff_lin_vel_x=1.00, cmd_diff_lin_vel_y=0.50,
+    cmd_diff_ang_vel_yaw=0.75, cmd_diff_lin_vel_z=0.25, cmd_diff_base_height=0.50,
+    cmd_diff_base_orient=0.25, cmd_diff_torso_orient=0.5, action_diff=-5.0, action_diff_diff=-1.0,
+    dof_acc_new=-0.25, dof_tor_new=-0.05, dof_tor_ankle_feet_lift_up=-0.5, pose_offset=1.0,
+    limits_dof_pos=-10.00, limits_dof_vel=-5.00, limits_dof_tor=-1.00,
+    feet_speed_xy_close_to_ground=0.50, feet_speed_z_close_to_height_target=0.0, feet_air_time=2.0,
+    feet_air_height=1.5, feet_air_force=1.0, feet_land_time=-1.0, on_the_air=-10.0, feet_stumble=-0.2)
+
+
+class GR1T1LowerLimbCfg(GR1T1FullCfg):
+    env = section("env", GR1T1FullCfg.env, num_envs=8192, num_obs=39, num_pri_obs=168, num_actions=10)
+    terrain = section("terrain", GR1T1FullCfg.terrain, mesh_type="plane")
+    control = section("control", GR1T1FullCfg.control, stiffness=dict(_LL_STIFF),
+                      damping={k: v / 10 * 0.5 for k, v in _LL_STIFF.items()})
+    asset = section("asset", GR1T1FullCfg.asset,
+                    file="{LEGGED_GYM_ROOT_DIR}/resources/robots/GR1T1/urdf/GR1T1_lower_limb.urdf")
+    rewards = section("rewards", GR1T1FullCfg.rewards,
+                      scales=section("scales", GR1T1FullCfg.rewards.scales, **_LL_SCALES))
+    normalization = section(
+        "normalization", GR1T1FullCfg.normalization, actions_max=_LL_ACT_MAX, actions_min=_LL_ACT_MIN,
+        clip_observations=100.0, clip_actions_max=_LL_ACT_MAX + np.deg2rad(np.full(10, 30.0)),
+        clip_actions_min=_LL_ACT_MIN - np.deg2rad(np.full(10, 30.0)))
+
+
+class GR1T1LowerLimbCfgPPO(GR1T1FullCfgPPO, GR1T1LowerLimbCfg):
+    runner = section("runner", GR1T1FullCfgPPO.runner, run_name="gr1t1_lower_limb", max_iterations=1000)
+    algorithm = section("algorithm", GR1T1FullCfgPPO.algorithm, desired_kl=0.03)
+    policy = section("policy", GR1T1FullCfgPPO.policy)
+
+
+# --------------------------------------------------------------------------------------------
+# GR1T2: same task class, different asset (gr1t2_config.py, gr1t2_lower_limb_config.py)
+class GR1T2FullCfg(GR1T1FullCfg):
+    asset = section("asset", GR1T1FullCfg.asset, file="{LEGGED_GYM_ROOT_DIR}/resources/robots/GR1T2/urdf/GR1T2.urdf")
+
+
+class GR1T2FullCfgPPO(GR1T1FullCfgPPO, GR1T2FullCfg):
+    runner = section("runner", GR1T1FullCfgPPO.runner, run_name="gr1t2")
+
+
+class GR1T2LowerLimbCfg(GR1T1LowerLimbCfg):
+    asset = section("asset", GR1T1LowerLimbCfg.asset,
+                    file="{LEGGED_GYM_ROOT_DIR}/resources/robots/GR1T2/urdf/GR1T2_lower_limb.urdf")
+
+
+class GR1T2LowerLimbCfgPPO(GR1T1LowerLimbCfgPPO, GR1T2LowerLimbCfg):
+    runner = section("runner", GR1T1LowerLimbCfgPPO.runner, run_name="gr1t2_lower_limb")
+
+
+# names under which the reference registers/imports them (envs/__init__.py:41-50)
+GR1T1Cfg, GR1T1CfgPPO = GR1T1LowerLimbCfg, GR1T1LowerLimbCfgPPO
+GR1T2Cfg, GR1T2CfgPPO = GR1T2LowerLimbCfg, GR1T2LowerLimbCfgPPO
+
+
+def class_to_dict(obj):
+    """Config (instance or class) -> nested dict of its public attributes, keys in dir() order
+    (reference helpers.py:42-57; the alphabetical order fixes the reward summation order)."""
+    if not hasattr(obj, "__dict__"):
+        return obj
+    out = {}
+    for key in dir(obj):
+        if key.startswith("_"):
+            continue
+        val = getattr(obj, key)
+        out[key] = [class_to_dict(v) for v in val] if isinstance(val, list) else class_to_dict(val)
+    return out

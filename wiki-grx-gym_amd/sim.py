@@ -1,0 +1,205 @@
+"""ctypes binding of the C ABI (include/grx.h) + zero-copy tensor views.
+
+``HipSim`` loads ``csrc/libgrx_hip.so`` -- the ONLY simulation backend of the product.  There is
+no CPU fallback: if the library is missing, or no HIP device is visible, construction raises
+(the reference equally raises when its binding is missing, gymapi.py:100-101).
+
+``SimHandle`` is backend-agnostic over a bound entry-point table so that the test-suite can drive
+the CPU oracle (oracle/binding.py) through the very same code path.
+
+Tensor views follow the gymtorch.wrap_tensor model (gymtorch.py:61-73, gymtorch.cpp:33-158):
+non-owning, zero-copy, possibly strided.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libgrx_hip.so")
+
+_TORCH_DTYPE = {_capi.DTYPE_F32: torch.float32, _capi.DTYPE_U8: torch.uint8,
+                _capi.DTYPE_I32: torch.int32, _capi.DTYPE_I64: torch.int64}
+_NP_DTYPE = {_capi.DTYPE_F32: np.float32, _capi.DTYPE_U8: np.uint8, _capi.DTYPE_I32: np.int32,
+             _capi.DTYPE_I64: np.int64}
+_TYPESTR = {_capi.DTYPE_F32: "<f4", _capi.DTYPE_U8: "|u1", _capi.DTYPE_I32: "<i4", _capi.DTYPE_I64: "<i8"}
+
+
+class GrxError(RuntimeError):
+    pass
+
+
+class _DeviceArray:
+    """Minimal __cuda_array_interface__ carrier (works for HIP device memory in ROCm torch)."""
+
+    def __init__(self, ptr, shape, strides_bytes, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False),
+                                         "strides": tuple(strides_bytes), "version": 3}
+
+
+def _wrap_device(ptr, dtype, shape, stride, device_index):
+    ext = _load_torch_ext()
+    if ext is not None:
+        return ext.wrap(int(ptr), int(dtype), list(shape), list(stride), int(device_index))
+    item = np.dtype(_NP_DTYPE[dtype]).itemsize
+    arr = _DeviceArray(ptr, shape, [s * item for s in stride], _TYPESTR[dtype])
+    return torch.as_tensor(arr, device=torch.device("cuda", device_index))
+
+
+def _wrap_host(ptr, dtype, shape, stride):
+    npdt = np.dtype(_NP_DTYPE[dtype])
+    span = 1 + sum((n - 1) * s for n, s in zip(shape, stride)) if all(n > 0 for n in shape) else 0
+    if span == 0:
+        return torch.zeros(tuple(shape), dtype=_TORCH_DTYPE[dtype])
+    buf = (C.c_char * (span * npdt.itemsize)).from_address(ptr)
+    flat = np.frombuffer(buf, dtype=npdt)
+    view = np.lib.stride_tricks.as_strided(flat, shape=tuple(shape), strides=tuple(s * npdt.itemsize for s in stride))
+    return torch.from_numpy(view)
+
+
+_ext_cache = [False, None]
+
+
+def _load_torch_ext():
+    """The native gymtorch successor (csrc/grx_torch.cpp -> _grxtorch*.so), if it was built."""
+    if _ext_cache[0]:
+        return _ext_cache[1]
+    _ext_cache[0] = True
+    try:
+        import importlib.util
+        import glob
+        cands = glob.glob(os.path.join(_HERE, "csrc", "_grxtorch*.so"))
+        if cands:
+            spec = importlib.util.spec_from_file_location("_grxtorch", cands[0])
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            _ext_cache[1] = mod
+    except Exception:  # pragma: no cover - fall back to __cuda_array_interface__
+        _ext_cache[1] = None
+    return _ext_cache[1]
+
+
+class SimHandle:
+    """One simulation handle behind the C ABI.  ``device``: torch.device the buffers live on."""
+
+    def __init__(self, api, cfg_struct, device, device_id=0, keepalive=()):
+        self._api = api
+        self._keep = list(keepalive) + [cfg_struct]
+        self.device = torch.device(device)
+        self.num_envs = int(cfg_struct.num_envs)
+        self.num_dofs = int(cfg_struct.model.num_bodies) - 1
+        self._h = C.c_void_p()
+        self._check(api["create"](C.byref(cfg_struct), int(device_id), C.byref(self._h)), "create")
+        self._views = {}
+
+    # -- errors
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._api["last_error"]()
+            raise GrxError(f"grx {what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def _stream(self):
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(0)
+
+    # -- API
+    def tensor(self, name):
+        """Zero-copy torch view of a library buffer (cached)."""
+        if name in self._views:
+            return self._views[name]
+        d = _capi.TensorDesc()
+        self._check(self._api["tensor"](self._h, _capi.T[name], C.byref(d)), f"tensor({name})")
+        shape = [int(d.shape[i]) for i in range(d.ndim)]
+        stride = [int(d.stride[i]) for i in range(d.ndim)]
+        if self.device.type == "cuda":
+            t = _wrap_device(d.data, d.dtype, shape, stride, self.device.index or 0)
+        else:
+            t = _wrap_host(d.data, d.dtype, shape, stride)
+        self._views[name] = t
+        return t
+
+    def reset_all(self):
+        self._check(self._api["reset_all"](self._h, self._stream()), "reset_all")
+
+    def step(self, actions, delay_substeps, common_step_counter, noise_uniform=None):
+        """actions: contiguous float32 (N, nd) tensor on self.device (borrowed for the call)."""
+        if actions is not None:
+            if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device.type != self.device.type:
+                raise GrxError("actions must be a contiguous float32 tensor on the simulation device")  # gymtorch.py:98-99
+            if tuple(actions.shape) != (self.num_envs, self.num_dofs):
+                raise GrxError(f"actions shape {tuple(actions.shape)} != ({self.num_envs}, {self.num_dofs})")
+        a = _capi.StepArgs()
+        a.actions = actions.data_ptr() if actions is not None else None
+        a.delay_substeps = float(delay_substeps)
+        a.common_step_counter = int(common_step_counter)
+        if noise_uniform is not None:
+            if noise_uniform.dtype != torch.float32 or not noise_uniform.is_contiguous():
+                raise GrxError("noise_uniform must be contiguous float32")
+            a.noise_uniform = noise_uniform.data_ptr()
+        self._check(self._api["step"](self._h, C.byref(a), self._stream()), "step")
+
+    def set_state(self, root_states=None, dof_pos=None, dof_vel=None):
+        def ptr(t, cols):
+            if t is None:
+                return None
+            if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (self.num_envs, cols):
+                raise GrxError("set_state tensors must be contiguous float32 (N, k)")
+            return t.data_ptr()
+        self._check(self._api["set_state"](self._h, ptr(root_states, 13), ptr(dof_pos, self.num_dofs),
+                                           ptr(dof_vel, self.num_dofs), self._stream()), "set_state")
+
+    def episode_stats(self):
+        out = (C.c_float * (_capi.NUM_REWARD_TERMS + 1))()
+        self._check(self._api["episode_stats"](self._h, out, self._stream()), "episode_stats")
+        return np.array(out[:], dtype=np.float32)
+
+    def kernel_time_ms(self, enable=True):
+        if "kernel_time_ms" not in self._api:
+            return 0.0, 0
+        ms, n = C.c_float(0), C.c_int64(0)
+        self._check(self._api["kernel_time_ms"](self._h, int(bool(enable)), C.byref(ms), C.byref(n)), "kernel_time_ms")
+        return float(ms.value), int(n.value)
+
+    def close(self):
+        if self._h:
+            self._views.clear()
+            self._api["destroy"](self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_hip_api = None
+
+
+def load_hip_library():
+    """dlopen csrc/libgrx_hip.so and bind every include/grx.h entry point; raises if absent."""
+    global _hip_api
+    if _hip_api is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise GrxError(f"{HIP_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(HIP_LIB_PATH)
+        _hip_api = _capi.bind(lib, "grx_")
+        if _hip_api["abi_version"]() != _capi.GRX_ABI_VERSION:
+            raise GrxError("libgrx_hip.so ABI version mismatch")
+    return _hip_api
+
+
+class HipSim(SimHandle):
+    def __init__(self, cfg_struct, device="cuda:0", keepalive=()):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise GrxError(f"the GRx simulation runs on an MI355X (HIP) device only; got sim device '{device}'. "
+                           "No CPU pipeline is shipped (the reference's CPU pipeline is PhysX-CPU, which this build does not emulate).")
+        if not torch.cuda.is_available():
+            raise GrxError("no HIP device visible (torch.cuda.is_available() is False); the GRx step has no CPU fallback")
+        super().__init__(load_hip_library(), cfg_struct, dev, device_id=dev.index or 0, keepalive=keepalive)
