@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the GRx environment step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 500 --warmup 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 500 --warmup 50
+
+One "step" = one ``env.step()`` of the hot path (clip actions, 10 fused physics sub-steps,
+termination, 24 reward terms, masked reset, observations) over one batch of synthetic actions
+already resident in HBM.  Workload (named in ``config.workload``): GR1T1 lower-limb on the
+ROUGH-TERRAIN curriculum heightfield (10x20 tiles, 1300x2100 int16, seed 1) with the 121-point
+height scan, 4096 envs per GPU, all domain randomisation / observation noise / pushes on,
+action latency fixed at 5 sub-steps.  Multi-GPU: envs are sharded by global index,
+4096 per rank (weak scaling); the step needs NO collective -- the barrier + max-over-ranks below
+is measurement only.
+
+Extra objects on the JSON line:
+  roofline      HBM roofline of the fused step kernel: algorithmic bytes per env-step
+                (2476 B rough / 1750 B flat) x envs per launch / average kernel
+                duration measured with HIP events on the launch stream (grx_kernel_time_ms).
+  cpu_baseline  the CPU oracle ("port": oracle/grx_oracle.c, fp32, OpenMP over envs) timed on
+                this box's host cores on a bounded sample of the same workload.  It is NOT
+                Isaac Gym's CPU pipeline (unobtainable).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_FLAT, B_ROUGH = 1750.0, 2476.0   # algorithmic bytes per env-step
+HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def make_cfg(terrain):
+    from wiki_grx_gym_amd.envs import config
+    cfg = config.GR1T1Cfg()                       # registered task "GR1T1" = lower-limb config
+    cfg.terrain.mesh_type = "heightfield" if terrain == "rough" else "plane"
+    cfg.terrain.curriculum = True
+    return cfg
+
+
+def cpu_baseline(cfg, terrain_obj, envs, steps, seed):
+    """Oracle (fp32, OpenMP) on the host cores: bounded sample of the same workload."""
+    import torch
+    from oracle.binding import OracleSim
+    from wiki_grx_gym_amd.envs import build_config
+    from tests.helpers import random_actions
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    c, keep, _ = build_config.build(cfg, cfg.sim.dt, envs, 0, envs, seed, terrain_obj)
+    sim = OracleSim(c, "f32", keep)
+    sim.reset_all()
+    gen = torch.Generator().manual_seed(0)
+    acts = [random_actions(cfg, envs, gen, 1.0) for _ in range(4)]
+    sim.step(acts[0], 5.0, 1)
+    t0 = time.time()
+    for i in range(steps):
+        sim.step(acts[i % 4], 5.0, 2 + i)
+    dt = time.time() - t0
+    sim.close()
+    return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{envs} envs x {steps} steps of the same workload, oracle/grx_oracle.c fp32 + OpenMP ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--terrain", choices=["rough", "flat"], default="rough")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=512)
+    ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the GRx step has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from wiki_grx_gym_amd.envs import build_config
+    from wiki_grx_gym_amd.sim import HipSim
+    from wiki_grx_gym_amd.utils.terrain import Terrain
+    from tests.helpers import random_actions
+
+    seed = 1
+    n_local = args.envs_per_gpu
+    n_total = n_local * world
+    cfg = make_cfg(args.terrain)
+    terrain_obj = Terrain(cfg.terrain, n_total, seed=seed) if args.terrain == "rough" else None
+    c, keep, _ = build_config.build(cfg, cfg.sim.dt, n_local, rank * n_local, n_total, seed, terrain_obj)
+    os.environ.setdefault("GRX_PUBLISH_DEBUG", "0")   # production path: no per-term debug tensors
+    sim = HipSim(c, dev, keep)
+    sim.reset_all()
+    gen = torch.Generator().manual_seed(rank)
+    pool = [random_actions(cfg, n_local, gen, 1.0).to(dev) for _ in range(16)]   # U[clip_min, clip_max]
+    delay = 5.0
+    counter = 0
+    for _ in range(args.warmup):
+        counter += 1
+        sim.step(pool[counter % 16], delay, counter)
+    sim.kernel_time_ms(enable=True)               # start the HIP-event window
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counter += 1
+        sim.step(pool[counter % 16], delay, counter)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = sim.kernel_time_ms(enable=False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(sim.tensor("OBS")).all().item()) and bool(torch.isfinite(sim.tensor("REW")).all().item())
+
+    if rank == 0:
+        bytes_per = B_ROUGH if args.terrain == "rough" else B_FLAT
+        achieved = bytes_per * n_local / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec GR1T1 rough-terrain @4096 envs" if args.terrain == "rough" else "env-steps/sec GR1T1 flat-terrain @4096 envs",
+            "value": n_total * args.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"GR1T1 lower-limb (10 DOF), {'rough-terrain curriculum heightfield 10x20 tiles + 121-pt height scan' if args.terrain == 'rough' else 'flat plane'}, "
+                                   f"{n_local} envs/GPU, decimation 10 @ dt 0.002, DR+noise+push on, action latency 5 sub-steps, random actions U[clip_min,clip_max]",
+                       "envs_per_gpu": n_local, "global_envs": n_total, "parallelism": f"env-sharded x{world} (no data-path collective)",
+                       "finite_outputs": finite},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "grx_step_kernel", "kernel_ms": kern_ms, "launches": launches,
+                         "algorithmic_bytes_per_env_step": bytes_per,
+                         "note": "latency/VALU-issue bound at this batch size (DESIGN.md section 5); HBM is the contractual roofline"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            steps = args.cpu_steps
+            if steps <= 0:
+                probe = cpu_baseline(cfg, terrain_obj, args.cpu_envs, 3, seed)
+                steps = max(5, int(15.0 * probe["value"] / args.cpu_envs))
+            out["cpu_baseline"] = cpu_baseline(cfg, terrain_obj, args.cpu_envs, steps, seed)
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
