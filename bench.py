@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--terrain", choices=["rough", "flat"], default="rough")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=512)
+    ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
     args = ap.parse_args()
 
@@ -163,9 +163,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             steps = args.cpu_steps
-            if steps <= 0:
-                probe = cpu_baseline(cfg, terrain_obj, args.cpu_envs, 3, seed)
-                steps = max(5, int(15.0 * probe["value"] / args.cpu_envs))
+            if steps <= 0:   # calibrate on a short probe, then aim at ~15 s (bounded to [3, 400] steps)
+                probe = cpu_baseline(cfg, terrain_obj, args.cpu_envs, 4, seed)
+                steps = min(400, max(3, int(15.0 * probe["value"] / args.cpu_envs)))
             out["cpu_baseline"] = cpu_baseline(cfg, terrain_obj, args.cpu_envs, steps, seed)
         print(json.dumps(out), flush=True)
     sim.close()

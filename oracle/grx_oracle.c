@@ -1434,6 +1434,10 @@ int gro_debug_post_physics(grx_handle s, int le, const gro_pipeline_state* ps, i
         e->reward_terms[t] = rew; e->rew += rew; e->episode_sums[t] += rew;
     }
     if (c->only_positive_rewards && e->rew < 0) e->rew = 0;
+    if (c->reward_scale[GRX_REW_TERMINATION] != 0) {
+        real rew = r[GRX_REW_TERMINATION] * (c->reward_scale[GRX_REW_TERMINATION] * dt);
+        e->reward_terms[GRX_REW_TERMINATION] = rew; e->rew += rew; e->episode_sums[GRX_REW_TERMINATION] += rew;
+    }
     if (e->reset && apply_reset) reset_env(s, e, le, step, 1);
     build_observations(s, e, le, args, step);
     for (int j = 0; j < nd; ++j) { e->last_actions[j] = e->actions[j]; e->last_dof_vel[j] = e->qd[j]; e->last_last_actions[j] = e->last_actions[j]; }

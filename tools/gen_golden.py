@@ -1,0 +1,458 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by IMPORTING THE REFERENCE PYTHON in the build container.
+
+    python tools/gen_golden.py        # writes tests/golden/*.npz  (+ config dump json)
+
+The reference (/root/reference) never travels to the GPU box; only the vectors produced here are
+committed.  Physics (Isaac Gym / PhysX) is a closed, absent binary, so ``isaacgym``
+is replaced by a stub: ``gymapi/gymtorch/gymutil`` are MagicMocks, ``torch_utils`` and
+``terrain_utils`` are the real files.  The reference's own functions are then called on synthetic
+state tensors: quaternion helpers, clip_actions/_compute_torques, the whole
+``post_physics_step`` (state update, timers, termination, the 24 active reward terms,
+observations incl. injected noise), ``_get_heights``, ``Terrain`` and the rsl_rl PPO pieces.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def install_stub():
+    np.float = float  # torch_utils.py:135 default argument
+    pkg = types.ModuleType("isaacgym")
+    pkg.__path__ = []
+    sys.modules["isaacgym"] = pkg
+    for name in ("gymapi", "gymtorch", "gymutil"):
+        m = MagicMock(name=name)
+        sys.modules["isaacgym." + name] = m
+        setattr(pkg, name, m)
+    base = os.path.join(REF, "IsaacGym_Preview_4_Package/isaacgym/python/isaacgym")
+    for name in ("torch_utils", "terrain_utils"):
+        spec = importlib.util.spec_from_file_location("isaacgym." + name, os.path.join(base, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["isaacgym." + name] = mod
+        spec.loader.exec_module(mod)
+        setattr(pkg, name, mod)
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = MagicMock()
+    sys.modules["torch.utils.tensorboard"] = tb
+    # scipy.interpolate.interp2d was removed (scipy >= 1.14): bilinear shim with the same call shape
+    from scipy import interpolate
+
+    class interp2d:  # noqa: N801
+        def __init__(self, x, y, z, kind="linear"):
+            self.f = interpolate.RegularGridInterpolator((np.asarray(y), np.asarray(x)), np.asarray(z, dtype=float))
+
+        def __call__(self, xn, yn):
+            yy, xx = np.meshgrid(yn, xn, indexing="ij")
+            return self.f(np.stack([yy, xx], -1))
+    interpolate.interp2d = interp2d
+    sys.path.insert(0, os.path.join(REF, "legged_gym"))
+    sys.path.insert(0, os.path.join(REF, "rsl_rl"))
+    import legged_gym.envs  # noqa: F401  -- must precede legged_gym.utils (circular import, task_registry.py:42)
+
+
+def make_ref_env(N, seed, terrain_obj=None):
+    """A reference GR1T1 instance without Isaac Gym: attributes set by hand on a bare object."""
+    import legged_gym.envs as E  # noqa: F401  (must be imported before legged_gym.utils)
+    from legged_gym.envs import GR1T1
+    from legged_gym.envs.gr1t1.gr1t1_lower_limb_config import GR1T1LowerLimbCfg
+    from isaacgym.torch_utils import quat_rotate_inverse
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed)
+    cfg = GR1T1LowerLimbCfg()
+    env = object.__new__(GR1T1)
+    env.cfg = cfg
+    env.device = "cpu"
+    env.num_envs, env.num_obs, env.num_pri_obs, env.num_actions = N, 39, 168, 10
+    env.num_dof = env.num_dofs = 10
+    env.gym = MagicMock()
+    env.sim = MagicMock()
+    env.viewer = None
+    env.sim_params = types.SimpleNamespace(dt=cfg.sim.dt)
+    env.headless = True
+    env.init_done = True
+    env.up_axis_idx = 2
+    env.height_samples = None
+    env.debug_viz = False
+    env._parse_cfg()
+    nb = 37
+    names = json.load(open(os.path.join(os.path.dirname(OUT), "..", "wiki-grx-gym_amd", "assets", "gr1t1_lower_limb.model.json")))
+    body_names, dof_names = names["body_names"], names["dof_names"]
+    env.dof_names = dof_names
+    idx = lambda sub: torch.tensor([i for i, n in enumerate(body_names) if sub in n], dtype=torch.long)
+    env.feet_indices = idx("foot_roll")
+    env.torso_indices = idx("torso")
+    env.forehead_indices = idx("head_pitch")
+    term = []
+    for n in cfg.asset.terminate_after_contacts_on:
+        term.extend([i for i, b in enumerate(body_names) if n in b])
+    env.termination_contact_indices = torch.tensor(term, dtype=torch.long)
+    env.penalised_contact_indices = torch.zeros(0, dtype=torch.long)
+    # buffers (BaseTask.__init__ / _init_buffers)
+    env.obs_buf = torch.zeros(N, 39)
+    env.pri_obs_buf = torch.zeros(N, 168)
+    env.rew_buf = torch.zeros(N)
+    env.reset_buf = torch.ones(N, dtype=torch.long)
+    env.episode_length_buf = torch.zeros(N, dtype=torch.long)
+    env.time_out_buf = torch.zeros(N, dtype=torch.bool)
+    env.extras = {}
+    env.common_step_counter = 0
+    env.root_states = torch.zeros(N, 13)
+    env.root_states[:, 6] = 1
+    env.dof_state = torch.zeros(N * 10, 2)
+    env.dof_pos = env.dof_state.view(N, 10, 2)[..., 0]
+    env.dof_vel = env.dof_state.view(N, 10, 2)[..., 1]
+    env.dof_acc = torch.zeros(N, 10)
+    env.dof_pos_offset = torch.zeros(N, 10)
+    env.base_pos = env.root_states[:, 0:3]
+    env.base_quat = env.root_states[:, 3:7]
+    env.contact_forces = torch.zeros(N, nb, 3)
+    env.rigid_body_states = torch.zeros(N, nb, 13)
+    env.rigid_body_states[:, :, 6] = 1
+    env.gravity_vec = torch.tensor([0., 0., -1.]).repeat(N, 1)
+    env.forward_vec = torch.tensor([1., 0., 0.]).repeat(N, 1)
+    env.torques = torch.zeros(N, 10)
+    env.p_gains = torch.zeros(10)
+    env.d_gains = torch.zeros(10)
+    env.default_dof_pos = torch.zeros(10)
+    for i, name in enumerate(dof_names):
+        env.default_dof_pos[i] = cfg.init_state.default_joint_angles[name]
+        for k in cfg.control.stiffness:
+            if k in name:
+                env.p_gains[i] = cfg.control.stiffness[k]
+                env.d_gains[i] = cfg.control.damping[k]
+    env.default_dof_pos = env.default_dof_pos.unsqueeze(0)
+    env.default_dof_pos_tenors = torch.ones(N, 10) * env.default_dof_pos
+    env.last_dof_vel = torch.zeros(N, 10)
+    env.actions = torch.zeros(N, 10)
+    env.last_actions = torch.zeros(N, 10)
+    env.last_last_actions = torch.zeros(N, 10)
+    env.commands = torch.zeros(N, 3)
+    env.commands_heading = torch.zeros(N)
+    env.commands_scale = torch.ones(N, 3)
+    env.base_lin_vel = torch.zeros(N, 3)
+    env.base_ang_vel = torch.zeros(N, 3)
+    env.base_projected_gravity = torch.zeros(N, 3)
+    env.base_heights_offset = torch.zeros(N)
+    env.surround_heights_offset = torch.zeros(N, 121)
+    for nm in ("feet_air_time", "last_feet_air_time", "feet_land_time", "last_feet_land_time", "avg_feet_contact_force", "feet_height"):
+        setattr(env, nm, torch.zeros(N, 2))
+    env.avg_feet_speed_xyz = torch.zeros(N, 2, 3)
+    env.avg_feet_speed_rpy = torch.zeros(N, 2, 3)
+    for nm in ("feet_contact", "feet_contact_last", "feet_contact_filt"):
+        setattr(env, nm, torch.zeros(N, 2, dtype=torch.bool))
+    env.motor_strength_scales = torch.ones(N, 10)
+    # URDF limits (legged_robot.py:582-616)
+    links = {l["joint_name"]: l for l in names["links"] if l["joint_name"]}
+    env.dof_pos_limits = torch.zeros(10, 2)
+    env.dof_vel_limits = torch.zeros(10)
+    env.torque_limits = torch.zeros(10)
+    for i, dn in enumerate(dof_names):
+        lim = links[dn]["limit"]
+        env.dof_pos_limits[i, 0], env.dof_pos_limits[i, 1] = lim["lower"], lim["upper"]
+        env.dof_vel_limits[i], env.torque_limits[i] = lim["velocity"], lim["effort"]
+        m = (env.dof_pos_limits[i, 0] + env.dof_pos_limits[i, 1]) / 2
+        r = env.dof_pos_limits[i, 1] - env.dof_pos_limits[i, 0]
+        env.dof_pos_limits[i, 0] = m - 0.5 * r * cfg.rewards.soft_dof_pos_limit
+        env.dof_pos_limits[i, 1] = m + 0.5 * r * cfg.rewards.soft_dof_pos_limit
+    env.swing_feet_height_target = torch.ones(N, 1) * cfg.rewards.swing_feet_height_target
+    env._init_buffers_joint_indices()
+    env.height_points = env._init_height_points()
+    env.measured_heights = 0
+    env.noise_scale_vec = env.compute_noise_scale_vec()
+    env._prepare_reward_function()
+    env.env_origins = torch.zeros(N, 3)
+    env.custom_origins = False
+    env.base_init_state = torch.tensor(cfg.init_state.pos + cfg.init_state.rot + cfg.init_state.lin_vel + cfg.init_state.ang_vel)
+    if terrain_obj is not None:
+        env.cfg.terrain.mesh_type = "heightfield"
+        env.terrain = terrain_obj
+        env.height_samples = torch.tensor(terrain_obj.heightsamples).view(terrain_obj.tot_rows, terrain_obj.tot_cols)
+    return env, g, body_names
+
+
+def rand_quat(n, g, tilt=0.6):
+    e = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([tilt, tilt, 3.14])
+    from isaacgym.torch_utils import quat_from_euler_xyz
+    return quat_from_euler_xyz(e[:, 0], e[:, 1], e[:, 2])
+
+
+def gen_quat(out):
+    from isaacgym.torch_utils import quat_rotate_inverse, quat_apply, quat_from_euler_xyz, quat_rotate
+    from legged_gym.utils.math import quat_apply_yaw, wrap_to_pi
+    g = torch.Generator().manual_seed(11)
+    q = rand_quat(256, g, tilt=3.0)
+    v = torch.randn(256, 3, generator=g)
+    e = (torch.rand(256, 3, generator=g) * 2 - 1) * 6.28
+    ang = (torch.rand(256, generator=g) * 2 - 1) * 20
+    np.savez(os.path.join(out, "quat.npz"), q=q.numpy(), v=v.numpy(), rotate_inverse=quat_rotate_inverse(q, v).numpy(),
+             rotate=quat_rotate(q, v).numpy(), apply=quat_apply(q, v).numpy(), apply_yaw=quat_apply_yaw(q.clone(), v.clone()).numpy(),
+             euler=e.numpy(), from_euler=quat_from_euler_xyz(e[:, 0], e[:, 1], e[:, 2]).numpy(),
+             ang=ang.numpy(), wrap_to_pi=wrap_to_pi(ang.clone()).numpy())
+
+
+def gen_torques(out):
+    env, g, _ = make_ref_env(64, 3)
+    env.dof_pos[:] = env.default_dof_pos + (torch.rand(64, 10, generator=g) - 0.5)
+    env.dof_vel[:] = (torch.rand(64, 10, generator=g) - 0.5) * 20
+    env.motor_strength_scales = 0.9 + 0.2 * torch.rand(64, 10, generator=g)
+    a = (torch.rand(64, 10, generator=g) - 0.5) * 6
+    clipped = env.clip_actions(a)
+    tq = env._compute_torques(clipped)
+    np.savez(os.path.join(out, "torques.npz"), dof_pos=env.dof_pos.numpy().copy(), dof_vel=env.dof_vel.numpy().copy(),
+             strength=env.motor_strength_scales.numpy(), actions=a.numpy(), clipped=clipped.numpy(), torques=tq.numpy(),
+             p_gains=env.p_gains.numpy(), d_gains=env.d_gains.numpy(), default_dof_pos=env.default_dof_pos.numpy(),
+             torque_limits=env.torque_limits.numpy(), dof_pos_limits=env.dof_pos_limits.numpy(),
+             dof_vel_limits=env.dof_vel_limits.numpy(), noise_vec=env.noise_scale_vec.numpy(),
+             reward_names=np.array(env.reward_names), reward_scales=np.array([env.reward_scales[n] for n in env.reward_names]),
+             clip_min=np.asarray(env.cfg.normalization.clip_actions_min), clip_max=np.asarray(env.cfg.normalization.clip_actions_max))
+
+
+def randomize_state(env, g, body_names, N, step):
+    """Synthetic post-physics state incl. edge rows (thresholds, timers at zero, near limits)."""
+    feet = env.feet_indices
+    torso = int(env.torso_indices[0])
+    env.root_states[:, 0:2] = (torch.rand(N, 2, generator=g) - 0.5) * 4
+    env.root_states[:, 2] = 0.6 + 0.5 * torch.rand(N, generator=g)
+    env.root_states[:, 3:7] = rand_quat(N, g, tilt=0.5)
+    env.root_states[:, 7:13] = torch.randn(N, 6, generator=g)
+    env.dof_pos[:] = env.default_dof_pos + (torch.rand(N, 10, generator=g) - 0.5) * 1.5
+    env.dof_vel[:] = torch.randn(N, 10, generator=g) * 8
+    env.dof_vel[::7] *= 4                                   # some rows beyond the soft velocity limit
+    env.torques = torch.randn(N, 10, generator=g) * 40
+    env.torques[::5] *= 3                                   # some rows beyond the soft torque limit
+    env.actions = env.clip_actions(torch.randn(N, 10, generator=g))
+    env.commands[:] = (torch.rand(N, 3, generator=g) * 2 - 1) * torch.tensor([1.0, 0.5, 1.0])
+    env.commands[::4, :2] = 0.0                             # standing commands
+    env.contact_forces[:] = 0
+    fz = torch.rand(N, 2, generator=g) * 400 * (torch.rand(N, 2, generator=g) > 0.4)
+    env.contact_forces[:, feet, 2] = fz
+    env.contact_forces[:, feet, 0:2] = torch.randn(N, 2, 2, generator=g) * 30 * (fz > 0).unsqueeze(-1)
+    env.contact_forces[3, feet[0], 2] = 1.0                 # exactly at the contact threshold (not > 1)
+    env.contact_forces[4, feet[1], 2] = 1.0 + 1e-3
+    env.rigid_body_states[:, :, 0:3] = env.root_states[:, None, 0:3]
+    env.rigid_body_states[:, feet, 2] = torch.rand(N, 2, generator=g) * 0.25
+    env.rigid_body_states[:, feet, 7:10] = torch.randn(N, 2, 3, generator=g)
+    env.rigid_body_states[:, torso, 3:7] = env.root_states[:, 3:7]
+    env.avg_feet_contact_force = torch.rand(N, 2, generator=g) * 300
+    env.avg_feet_speed_xyz = torch.rand(N, 2, 3, generator=g) * 2
+    if step == 0:
+        env.feet_air_time = torch.rand(N, 2, generator=g) * 0.8 * (torch.rand(N, 2, generator=g) > 0.3)
+        env.feet_land_time = torch.rand(N, 2, generator=g) * 2.0
+        env.feet_contact_last = torch.rand(N, 2, generator=g) > 0.5
+        env.episode_length_buf[:] = torch.randint(0, 990, (N,), generator=g)
+        env.episode_length_buf[5] = 499                     # resample-by-time row
+        env.episode_length_buf[6] = 999                     # becomes 1000: not yet a time-out
+        env.episode_length_buf[7] = 1000                    # becomes 1001: time-out
+        env.last_actions = torch.randn(N, 10, generator=g) * 0.5
+        env.last_last_actions = torch.randn(N, 10, generator=g) * 0.5
+        env.last_dof_vel = torch.randn(N, 10, generator=g) * 8
+        env.base_heights_offset = (torch.rand(N, generator=g) - 0.5) * 2   # stale value used by the reward (Q4)
+    # termination rows
+    tilt = rand_quat(N, g, tilt=0.0)
+    env.root_states[8, 3:7] = torch.tensor([0.0, 0.62, 0.0, 0.7846])   # |g_z| just below 0.33 -> reset
+    env.root_states[9, 3:7] = torch.tensor([0.0, 0.575, 0.0, 0.8182])  # |g_z| just above 0.33
+    env.contact_forces[10, torso, 2] = 5.0                             # terminating body contact
+
+
+def snapshot_inputs(env):
+    feet = env.feet_indices
+    torso = int(env.torso_indices[0])
+    return dict(root=env.root_states.numpy().copy(), dof_pos=env.dof_pos.numpy().copy(), dof_vel=env.dof_vel.numpy().copy(),
+                torques=env.torques.numpy().copy(), actions=env.actions.numpy().copy(), commands=env.commands.numpy().copy(),
+                feet_force=env.contact_forces[:, feet].numpy().copy(), feet_pos=env.rigid_body_states[:, feet, 0:3].numpy().copy(),
+                torso_quat=env.rigid_body_states[:, torso, 3:7].numpy().copy(),
+                term_contact=(torch.norm(env.contact_forces[:, env.termination_contact_indices], dim=-1) > 1.0).any(1).numpy().copy(),
+                avg_force=env.avg_feet_contact_force.numpy().copy(), avg_speed=env.avg_feet_speed_xyz.numpy().copy(),
+                air_time=env.feet_air_time.numpy().copy(), land_time=env.feet_land_time.numpy().copy(),
+                contact_last=env.feet_contact_last.numpy().copy(), episode_length=env.episode_length_buf.numpy().copy(),
+                last_actions=env.last_actions.numpy().copy(), last_last_actions=env.last_last_actions.numpy().copy(),
+                last_dof_vel=env.last_dof_vel.numpy().copy(), base_heights_offset=env.base_heights_offset.numpy().copy())
+
+
+def gen_pipeline(out):
+    """Two consecutive reference post_physics_step() calls on synthetic state, resets disabled
+    (reset_idx is replaced by a recorder: its RNG stream cannot be reproduced)."""
+    N = 64
+    env, g, body_names = make_ref_env(N, 5)
+    env.cfg.domain_rand.push_robots = False
+    noise_u = torch.rand(2, N, 39, generator=g)
+    data = {}
+    for step in range(2):
+        randomize_state(env, g, body_names, N, step)
+        inp = snapshot_inputs(env)
+        env.reset_idx = lambda ids: None          # keep rows un-reset; reset_buf/time_out still recorded
+        # the time-based command resample draws from torch's RNG: record commands after the step instead
+        orig_rand_like = torch.rand_like
+        torch.rand_like = lambda t, _u=noise_u[step]: _u.clone()   # inject the observation-noise uniforms
+        try:
+            env.post_physics_step()
+        finally:
+            torch.rand_like = orig_rand_like
+        obs = torch.clip(env.obs_buf, -100, 100)
+        pri = torch.clip(env.pri_obs_buf, -100, 100)
+        terms = {}
+        for name, fn in zip(env.reward_names, env.reward_functions):
+            terms[name] = None
+        outd = dict(obs=obs.numpy().copy(), pri_obs=pri.numpy().copy(), rew=env.rew_buf.numpy().copy(),
+                    reset=env.reset_buf.numpy().copy(), time_out=env.time_out_buf.numpy().copy(),
+                    base_lin_vel=env.base_lin_vel.numpy().copy(), base_ang_vel=env.base_ang_vel.numpy().copy(),
+                    projected_gravity=env.base_projected_gravity.numpy().copy(), commands_after=env.commands.numpy().copy(),
+                    feet_contact=env.feet_contact.numpy().copy(), air_time_after=env.feet_air_time.numpy().copy(),
+                    land_time_after=env.feet_land_time.numpy().copy(), feet_height=env.feet_height.numpy().copy(),
+                    first_contact=env.feet_first_contact.numpy().copy(), base_heights_offset_after=env.base_heights_offset.numpy().copy(),
+                    episode_sums=np.stack([env.episode_sums[n].numpy().copy() for n in env.reward_names]),
+                    episode_length_after=env.episode_length_buf.numpy().copy(),
+                    last_actions_after=env.last_actions.numpy().copy(), last_last_actions_after=env.last_last_actions.numpy().copy())
+        for k, v in inp.items():
+            data[f"s{step}_in_{k}"] = v
+        for k, v in outd.items():
+            data[f"s{step}_out_{k}"] = v
+        data[f"s{step}_noise_u"] = noise_u[step].numpy()
+    # per-term unscaled rewards of the second state (recomputed; read-only functions)
+    data["reward_names"] = np.array(env.reward_names)
+    data["reward_scales_dt"] = np.array([env.reward_scales[n] for n in env.reward_names])
+    np.savez(os.path.join(out, "pipeline.npz"), **data)
+
+
+def gen_reward_terms(out):
+    """Every implemented FF/G1 reward term (active or not) evaluated by the reference on one state."""
+    N = 64
+    env, g, body_names = make_ref_env(N, 9)
+    randomize_state(env, g, body_names, N, 0)
+    inp = snapshot_inputs(env)   # BEFORE the timers are advanced
+    from isaacgym.torch_utils import quat_rotate_inverse
+    env.base_lin_vel[:] = quat_rotate_inverse(env.base_quat, env.root_states[:, 7:10])
+    env.base_ang_vel[:] = quat_rotate_inverse(env.base_quat, env.root_states[:, 10:13])
+    env.base_projected_gravity[:] = quat_rotate_inverse(env.base_quat, env.gravity_vec)
+    env.measured_heights = env._get_heights()
+    env._calculate_air_time(); env._calculate_feet_height(); env._calculate_land_time()
+    env.check_termination()
+    names = ["action_diff", "action_diff_diff", "action_diff_knee", "cmd_diff_ang_vel_pitch", "cmd_diff_ang_vel_roll",
+             "cmd_diff_ang_vel_yaw", "cmd_diff_base_height", "cmd_diff_base_orient", "cmd_diff_lin_vel_x", "cmd_diff_lin_vel_y",
+             "cmd_diff_lin_vel_z", "cmd_diff_torso_orient", "collision", "dof_acc_new", "dof_tor_ankle_feet_lift_up", "dof_tor_new",
+             "dof_tor_new_hip_roll", "dof_vel_new", "dof_vel_new_knee", "feet_air_force", "feet_air_height", "feet_air_time",
+             "feet_land_time", "feet_speed_xy_close_to_ground", "feet_speed_z_close_to_height_target", "feet_stumble",
+             "limits_dof_pos",   # limits_actions: the reference has no sigma_limits_actions -> AttributeError if enabled "limits_dof_tor", "limits_dof_vel", "on_the_air", "pose_offset",
+             "pose_offset_hip_yaw", "stand_still", "termination"]
+    vals = {}
+    for n in names:
+        v = getattr(env, "_reward_" + n)()
+        vals[n] = (v.float() if torch.is_tensor(v) else torch.full((N,), float(v))).numpy().copy()
+    np.savez(os.path.join(out, "reward_terms.npz"), names=np.array(names), values=np.stack([vals[n] for n in names]),
+             **{"in_" + k: v for k, v in inp.items()})
+
+
+def gen_terrain_and_heights(out):
+    from legged_gym.utils.terrain import Terrain
+    from legged_gym.envs.base.legged_robot_config import LeggedRobotCfg
+    tcfg = LeggedRobotCfg.terrain()
+    tcfg.mesh_type = "heightfield"
+    np.random.seed(1)
+    ter = Terrain(tcfg, 64)
+    N = 64
+    env, g, _ = make_ref_env(N, 21, terrain_obj=ter)
+    env.root_states[:, 0] = torch.rand(N, generator=g) * 90 - 5      # incl. negative coords and beyond-map rows
+    env.root_states[:, 1] = torch.rand(N, generator=g) * 170 - 5
+    env.root_states[0, 0:2] = torch.tensor([-30.0, -30.0])           # clamps to index 0
+    env.root_states[1, 0:2] = torch.tensor([200.0, 300.0])           # clamps to dim-2
+    env.root_states[:, 3:7] = rand_quat(N, g, tilt=0.4)
+    h = env._get_heights()
+    # sparse fingerprint of the raster + the deterministic tiles in full
+    hs = ter.heightsamples
+    np.savez_compressed(os.path.join(out, "terrain.npz"), heightsamples=hs, env_origins=ter.env_origins,
+                        root=env.root_states.numpy().copy(), heights=h.numpy().copy())
+
+
+def gen_config(out):
+    from legged_gym.envs import GR1T1Cfg, GR1T1CfgPPO, GR1T2Cfg, GR1T2CfgPPO
+    from legged_gym.utils.helpers import class_to_dict
+
+    def clean(o):
+        if isinstance(o, dict):
+            return {k: clean(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        if isinstance(o, np.ndarray):
+            return o.tolist()
+        if isinstance(o, (np.floating, np.integer)):
+            return o.item()
+        return o
+    dump = {"GR1T1": clean(class_to_dict(GR1T1Cfg())), "GR1T1PPO": clean(class_to_dict(GR1T1CfgPPO())),
+            "GR1T2": clean(class_to_dict(GR1T2Cfg())), "GR1T2PPO": clean(class_to_dict(GR1T2CfgPPO()))}
+    with open(os.path.join(out, "config_dump.json"), "w") as f:
+        json.dump(dump, f, indent=0, sort_keys=True)
+
+
+def gen_ppo(out):
+    """rsl_rl: GAE returns, minibatch index stream, one PPO.update() on fixed weights/batch."""
+    from rsl_rl.modules import ActorCriticMLP
+    from rsl_rl.algorithms import PPO
+    torch.manual_seed(0)
+    N, T, no, npri, na = 16, 8, 39, 168, 10
+    ac = ActorCriticMLP(no, npri, na, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu", init_noise_std=0.2)
+    sd0 = {k: v.clone() for k, v in ac.state_dict().items()}
+    alg = PPO(actor_critic=ac, num_learning_epochs=2, num_mini_batches=4, clip_param=0.2, gamma=0.99, lam=0.95,
+              value_loss_coef=1.0, entropy_coef=0.01, learning_rate=1e-4, learning_rate_min=1e-5, learning_rate_max=1e-3,
+              max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.03, device="cpu",
+              storage_class="RolloutStorage")
+    alg.init_storage(N, T)
+    g = torch.Generator().manual_seed(1)
+    obs_seq = torch.randn(T + 1, N, no, generator=g)
+    pri_seq = torch.randn(T + 1, N, npri, generator=g)
+    rew_seq = torch.randn(T, N, generator=g)
+    done_seq = torch.rand(T, N, generator=g) < 0.1
+    to_seq = done_seq & (torch.rand(T, N, generator=g) < 0.5)
+    eps = torch.randn(T, N, na, generator=g)
+    acts = []
+    with torch.inference_mode():
+        for t in range(T):
+            orig = torch.distributions.Normal.sample
+            torch.distributions.Normal.sample = lambda self, _e=eps[t]: self.mean + self.stddev * _e
+            try:
+                a = alg.act(obs_seq[t], pri_seq[t])
+            finally:
+                torch.distributions.Normal.sample = orig
+            acts.append(a.clone())
+            alg.process_env_step(rew_seq[t].clone(), done_seq[t], {"time_outs": to_seq[t]})
+        alg.compute_returns(pri_seq[T])
+    st = alg.storage
+    golden = dict(returns=st.returns.numpy().copy(), advantages=st.advantages.numpy().copy(), values=st.values.numpy().copy(),
+                  rewards=st.rewards.numpy().copy(), actions=torch.stack(acts).numpy(), log_prob=st.actions_log_prob.numpy().copy(),
+                  mu=st.mu.numpy().copy(), sigma=st.sigma.numpy().copy())
+    torch.manual_seed(123)
+    perm_probe = torch.randperm(4 * (N * T // 4))
+    torch.manual_seed(123)
+    vl, sl = alg.update()
+    sd1 = {k: v.clone() for k, v in ac.state_dict().items()}
+    np.savez(os.path.join(out, "ppo.npz"), obs=obs_seq.numpy(), pri=pri_seq.numpy(), rew=rew_seq.numpy(), done=done_seq.numpy(),
+             time_outs=to_seq.numpy(), eps=eps.numpy(), perm=perm_probe.numpy(), value_loss=vl, surrogate_loss=sl,
+             lr_after=alg.learning_rate, **golden,
+             **{"w0_" + k: v.numpy() for k, v in sd0.items()}, **{"w1_" + k: v.detach().numpy() for k, v in sd1.items()})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    install_stub()
+    gen_quat(OUT)
+    gen_torques(OUT)
+    gen_pipeline(OUT)
+    gen_reward_terms(OUT)
+    gen_terrain_and_heights(OUT)
+    gen_config(OUT)
+    gen_ppo(OUT)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
