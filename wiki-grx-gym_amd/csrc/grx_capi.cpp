@@ -293,7 +293,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(last_actions, GRX_ND * N); DA(last_dof_vel, GRX_ND * N); DA(actions, GRX_ND * N); DA(torques, GRX_ND * N);
     DA(motor_strength, GRX_ND * N); DA(base_m, N); DA(base_c, 3 * N); DA(base_I, 6 * N); DA(friction, N);
     DA(commands, 3 * N); DA(origins, 3 * N); DA(levels, N); DA(types, N);
-    DA(air_time, 2 * N); DA(land_time, 2 * N); DA(contact_last, 2 * N); DA(feet_contact, 2 * N);
+    DA(air_time, 2 * N); DA(land_time, 2 * N); DA(feet_contact, 2 * N);
     DA(feet_height, 2 * N); DA(avg_force, 2 * N); DA(feet_force, 6 * N); DA(feet_pos, 6 * N); DA(avg_speed, 6 * N);
     DA(base_heights_offset, N); DA(ep_len, N); DA(rew, N); DA(reset, N); DA(time_out, N); DA(term_contact, N);
     DA(base_lin_vel, 3 * N); DA(base_ang_vel, 3 * N); DA(proj_grav, 3 * N);

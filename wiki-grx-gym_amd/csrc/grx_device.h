@@ -69,7 +69,7 @@ struct KParams {
     float *base_m, *base_c, *base_I, *friction, *commands, *origins;
     int32_t *levels, *types;
     float *air_time, *land_time;
-    uint8_t *contact_last, *feet_contact;
+    uint8_t* feet_contact;   // also the "contact_last" state of the next step (legged_robot_fftai.py:113,131)
     float *feet_height, *avg_force, *feet_force, *feet_pos, *avg_speed, *base_heights_offset;
     long long* ep_len;
     float* rew;

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
     ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[(size_t)N + e]; ea.origin[2] = P.origins[2 * (size_t)N + e];
     ea.level = P.levels[e]; ea.type = P.types[e];
     float air_time = P.air_time[(size_t)side * N + e], land_time = P.land_time[(size_t)side * N + e];
-    bool contact_last = P.contact_last[(size_t)side * N + e] != 0;
+    bool contact_last = P.feet_contact[(size_t)side * N + e] != 0;
     float bho_stale = P.base_heights_offset[e];
     long long ep_len = P.ep_len[e];
 
@@ -784,7 +784,6 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
         }
         P.air_time[(size_t)side * N + e] = air_time * (contact_filt ? 0.f : 1.f);  // legged_robot_fftai.py:97
         P.land_time[(size_t)side * N + e] = land_time;
-        P.contact_last[(size_t)side * N + e] = contact_last ? 1 : 0;
         P.feet_contact[(size_t)side * N + e] = feet_contact_obs ? 1 : 0;
         P.feet_height[(size_t)side * N + e] = feet_height;
         P.avg_force[(size_t)side * N + e] = avg_force;
@@ -897,7 +896,7 @@ __global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __rest
 #pragma unroll
     for (int i = 0; i < 4; ++i) P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] = 0.f;
     P.air_time[(size_t)side * N + e] = 0.f; P.land_time[(size_t)side * N + e] = 0.f;
-    P.contact_last[(size_t)side * N + e] = 0; P.feet_contact[(size_t)side * N + e] = 0;
+    P.feet_contact[(size_t)side * N + e] = 0;
     if (side == 0) {
         float rs[13] = {st.pos.x, st.pos.y, st.pos.z, st.qx, st.qy, st.qz, st.qw, st.vel.x, st.vel.y, st.vel.z, st.ang.x, st.ang.y, st.ang.z};
 #pragma unroll
@@ -916,7 +915,12 @@ __global__ void grx_set_state_kernel(const KParams* __restrict__ Pp, const float
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.N) return;
     size_t N = P.N;
-    if (root) for (int i = 0; i < 13; ++i) P.root[i * N + e] = root[(size_t)e * 13 + i];
+    if (root) {
+        for (int i = 0; i < 13; ++i) P.root[i * N + e] = root[(size_t)e * 13 + i];
+        const float* qp = root + (size_t)e * 13 + 3;
+        float n = sqrtf(qp[0] * qp[0] + qp[1] * qp[1] + qp[2] * qp[2] + qp[3] * qp[3]);
+        for (int i = 0; i < 4; ++i) P.root[(3 + i) * N + e] = qp[i] / n;
+    }
     if (q) for (int j = 0; j < GRX_ND; ++j) P.q[j * N + e] = q[(size_t)e * GRX_ND + j];
     if (qd) for (int j = 0; j < GRX_ND; ++j) P.qd[j * N + e] = qd[(size_t)e * GRX_ND + j];
     for (int i = 0; i < 8; ++i) P.anchors[(size_t)(i * 3 + 2) * N + e] = 0.f;
