@@ -841,16 +841,17 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
 // extras["episode"] (legged_robot.py:420-424): mean episode sums of the envs reset by this step;
 // kept from the previous resetting step when nobody reset (the reference only rewrites the dict
 // inside reset_idx, which returns early for an empty id list, legged_robot.py:387-388).
-__global__ void grx_finalize_stats(const KParams* __restrict__ Pp, int nblocks) {
+__global__ __launch_bounds__(64) void grx_finalize_stats(const KParams* __restrict__ Pp, int nblocks) {
     const KParams& P = *Pp;
-    int t = threadIdx.x;
-    if (t > NT) return;
+    const int t = blockIdx.x, lane = threadIdx.x;   // one wave per reward term: lanes stride over the step kernel's blocks
     float cnt = 0.f, s = 0.f;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = lane; b < nblocks; b += 64) {
         cnt += P.stat_partial[(size_t)b * (NT + 1) + NT];
         s += P.stat_partial[(size_t)b * (NT + 1) + t];
     }
-    if (cnt > 0.f) P.stats[t] = (t == NT) ? cnt : s / cnt / P.max_episode_length_s;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { cnt += __shfl_xor(cnt, off); s += __shfl_xor(s, off); }
+    if (lane == 0 && cnt > 0.f) P.stats[t] = (t == NT) ? cnt : s / cnt / P.max_episode_length_s;
 }
 
 // BaseTask.reset() first half (base_task.py:117-119): reset_idx(all envs), no step
@@ -935,7 +936,7 @@ extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, const
 }
 extern "C" void grx_launch_finalize(const KParams* dP, int N, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    hipLaunchKernelGGL(grx_finalize_stats, dim3(1), dim3(64), 0, stream, dP, nblocks);
+    hipLaunchKernelGGL(grx_finalize_stats, dim3(NT + 1), dim3(64), 0, stream, dP, nblocks);
 }
 extern "C" void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
