@@ -1,0 +1,94 @@
+"""BASELINE config 1 (plumbing, no GPU): GR1T1 flat terrain, 64 envs, PPO 10 iterations through
+task_registry.make_env / make_alg_runner, the VecEnv surface of the reference, checkpoint files.
+
+The product has no CPU simulation backend; here -- in tests only -- the env class is pointed at the
+CPU oracle through its backend hook, which exercises exactly the host-side code that runs on the
+GPU box (config -> grx_config, views, extras, runner, PPO)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from wiki_grx_gym_amd.envs import GR1T1, GR1T1Cfg, GR1T1CfgPPO, GRxEnv
+from wiki_grx_gym_amd.utils import get_args, task_registry
+
+
+@pytest.fixture()
+def oracle_backend():
+    from oracle.binding import OracleSim
+    GRxEnv._backend_factory = staticmethod(lambda c, dev, keep: OracleSim(c, "f32", keep))
+    yield
+    GRxEnv._backend_factory = None
+
+
+def _args(extra=()):
+    return get_args(["--task", "GR1T1", "--headless", "--num_envs", "64", "--sim_device", "cpu", "--rl_device", "cpu",
+                     "--pipeline", "cpu", "--max_iterations", "10", "--seed", "3", *extra])
+
+
+def test_vec_env_surface(oracle_backend):
+    args = _args()
+    env, cfg = task_registry.make_env("GR1T1", args=args, env_cfg=GR1T1Cfg())
+    assert isinstance(env, GR1T1) and (env.num_envs, env.num_obs, env.num_pri_obs, env.num_actions) == (64, 39, 168, 10)
+    assert env.dt == pytest.approx(0.02) and env.max_episode_length == 1000 and isinstance(env.max_episode_length, float)
+    assert cfg.commands.resample_command_interval == 500 and cfg.domain_rand.push_interval == 500
+    assert len(env.reward_names) == 24 and env.reward_scales["action_diff"] == pytest.approx(-5.0 * 0.02)
+    assert env.feet_indices.tolist() == [7, 13] and len(env.termination_contact_indices) == 19
+    assert env.dof_names[3] == "left_knee_pitch_joint" and env.knee_indices == [3, 8] and env.ankle_indices == [4, 9]
+    obs, pri = env.reset()
+    assert obs.shape == (64, 39) and pri.shape == (64, 168) and obs is env.get_observations() and pri is env.get_privileged_observations()
+    assert env.reset_buf.dtype == torch.bool and env.episode_length_buf.dtype == torch.int64
+    o2, p2, rew, dones, extras = env.step(torch.zeros(64, 10))
+    assert rew.shape == (64,) and dones.dtype == torch.bool and extras["time_outs"].dtype == torch.bool
+    assert set(extras["episode"]) == {"rew_" + n for n in env.reward_names}
+    assert all(v.ndim == 0 for v in extras["episode"].values())
+    # the runner rebinds episode_length_buf (on_policy_runner.py:126): must land in the library buffer
+    env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=1000)
+    before = env.episode_length_buf.clone()
+    env.step(torch.zeros(64, 10))
+    alive = ~env.reset_buf
+    assert torch.equal(env.episode_length_buf[alive], before[alive] + 1)
+    # play.py reads these (play.py:86-137)
+    assert env.dof_pos.shape == (64, 10) and env.commands.shape == (64, 3) and env.base_lin_vel.shape == (64, 3)
+    assert env.contact_forces[0, env.feet_indices, 2].shape == (2,)
+    assert env.cfg.control.action_scale == 1.0
+    with pytest.raises(Exception):
+        env.step(torch.zeros(64, 9))
+
+
+def test_unregistered_task_and_cpu_device_fail_loudly():
+    with pytest.raises(ValueError, match="not registered"):
+        task_registry.make_env("anymal_c_flat", args=_args())
+    from wiki_grx_gym_amd.sim import GrxError
+    GRxEnv._backend_factory = None
+    with pytest.raises(GrxError):                     # sim_device=cpu: no CPU pipeline in the product
+        task_registry.make_env("GR1T1", args=_args(), env_cfg=GR1T1Cfg())
+
+
+def test_train_ten_iterations_and_resume(oracle_backend, tmp_path):
+    args = _args()
+    env, _ = task_registry.make_env("GR1T1", args=args, env_cfg=GR1T1Cfg())
+    tcfg = GR1T1CfgPPO()
+    tcfg.runner.num_steps_per_env = 8            # keep the CPU test short; everything else as registered
+    tcfg.runner.save_interval = 5
+    runner, tcfg = task_registry.make_alg_runner(env, name="GR1T1", args=args, train_cfg=tcfg, log_root=str(tmp_path))
+    w0 = runner.algorithm.actor_critic.actor.model[0].weight.clone()
+    runner.learn(num_learning_iterations=tcfg.runner.max_iterations, init_at_random_ep_len=True)
+    assert runner.current_learning_iteration == 10
+    assert not torch.equal(w0, runner.algorithm.actor_critic.actor.model[0].weight)
+    run_dir = glob.glob(os.path.join(str(tmp_path), "*gr1t1_lower_limb"))[0]
+    assert {"model_0.pt", "model_5.pt", "model_10.pt"} <= set(os.listdir(run_dir))
+    tags = {line.split('"tag": "')[1].split('"')[0] for line in open(os.path.join(run_dir, "scalars.jsonl"))}
+    assert {"Loss/value_function", "Loss/surrogate", "Loss/learning_rate", "Loss/kl", "Perf/total_fps", "Policy/mean_noise_std",
+            "Episode/rew_action_diff"} <= tags
+    # resume (task_registry.py:150-155, helpers.py:108-130)
+    tcfg.runner.resume = True
+    r2, _ = task_registry.make_alg_runner(env, name="GR1T1", args=args, train_cfg=tcfg, log_root=str(tmp_path))
+    assert r2.current_learning_iteration == 10
+    pol = r2.get_inference_policy(device="cpu")
+    assert pol(env.get_observations()).shape == (64, 10)
+    from wiki_grx_gym_amd.utils import export_policy_as_jit
+    p = export_policy_as_jit(r2.algorithm.actor_critic, str(tmp_path / "exported"))
+    assert torch.jit.load(p)(torch.zeros(1, 39)).shape == (1, 10)

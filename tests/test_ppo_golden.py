@@ -1,0 +1,81 @@
+"""PPO side (stays PyTorch): this build's rl/ package against the reference rsl_rl run on the same
+seeded inputs (tests/golden/ppo.npz, SURVEY G-10): GAE returns, advantage normalisation,
+time-out bootstrap, log-probs, the minibatch index stream, and one full update() (8 optimizer
+steps incl. adaptive-KL learning rate) ending in the same weights."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from wiki_grx_gym_amd.rl import PPO, ActorCriticMLP, OnPolicyRunner
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _build(d):
+    N, T, no, npri, na = 16, 8, 39, 168, 10
+    ac = ActorCriticMLP(no, npri, na, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu", init_noise_std=0.2)
+    with torch.no_grad():
+        for k, v in ac.state_dict().items():
+            v.copy_(torch.tensor(d["w0_" + k]))
+    alg = PPO(actor_critic=ac, num_learning_epochs=2, num_mini_batches=4, clip_param=0.2, gamma=0.99, lam=0.95,
+              value_loss_coef=1.0, entropy_coef=0.01, learning_rate=1e-4, learning_rate_min=1e-5, learning_rate_max=1e-3,
+              max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.03, device="cpu")
+    alg.init_storage(N, T)
+    return ac, alg, N, T
+
+
+def test_rollout_returns_and_update_match_reference():
+    d = np.load(os.path.join(G, "ppo.npz"))
+    ac, alg, N, T = _build(d)
+    assert sorted(ac.state_dict()) == sorted(k[3:] for k in d.files if k.startswith("w0_"))   # checkpoint key layout
+    obs, pri, rew = torch.tensor(d["obs"]), torch.tensor(d["pri"]), torch.tensor(d["rew"])
+    done, tos, eps = torch.tensor(d["done"]), torch.tensor(d["time_outs"]), torch.tensor(d["eps"])
+    with torch.inference_mode():
+        for t in range(T):
+            orig = torch.distributions.Normal.sample
+            torch.distributions.Normal.sample = lambda self, _e=eps[t]: self.mean + self.stddev * _e
+            try:
+                a = alg.act(obs[t], pri[t])
+            finally:
+                torch.distributions.Normal.sample = orig
+            np.testing.assert_allclose(a.numpy(), d["actions"][t], rtol=1e-5, atol=1e-6)
+            alg.process_env_step(rew[t].clone(), done[t], {"time_outs": tos[t]})
+        alg.compute_returns(pri[T])
+    st = alg.storage
+    for name, got in (("values", st.values), ("rewards", st.rewards), ("returns", st.returns), ("advantages", st.advantages),
+                      ("log_prob", st.actions_log_prob), ("mu", st.mu), ("sigma", st.sigma)):
+        np.testing.assert_allclose(got.numpy(), d[name], rtol=2e-5, atol=2e-6, err_msg=name)
+    torch.manual_seed(123)
+    np.testing.assert_array_equal(torch.randperm(4 * (N * T // 4)).numpy(), d["perm"])
+    torch.manual_seed(123)
+    vl, sl = alg.update()
+    assert vl == pytest.approx(float(d["value_loss"]), rel=1e-4)
+    assert sl == pytest.approx(float(d["surrogate_loss"]), rel=1e-4, abs=1e-6)
+    assert alg.learning_rate == pytest.approx(float(d["lr_after"]), rel=1e-9)
+    for k, v in ac.state_dict().items():
+        np.testing.assert_allclose(v.detach().numpy(), d["w1_" + k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+def test_checkpoint_roundtrip_and_std_quirk(tmp_path):
+    """model_<it>.pt keys as the reference (on_policy_runner.py:297-331); loading overwrites std with
+    set_noise_std = 1.0 unless set_std=False (actor_critic_mlp.py:116-134)."""
+    d = np.load(os.path.join(G, "ppo.npz"))
+    ac, alg, _, _ = _build(d)
+    path = tmp_path / "model_0.pt"
+    torch.save({"model_state_dict": ac.state_dict(), "optimizer_state_dict": alg.optimizer.state_dict(), "iter": 7, "infos": None}, path)
+    loaded = torch.load(path, weights_only=False)
+    assert set(loaded) == {"model_state_dict", "optimizer_state_dict", "iter", "infos"}
+    ac2 = ActorCriticMLP(39, 168, 10, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], init_noise_std=0.2)
+    ac2.load_state_dict(loaded["model_state_dict"])
+    assert torch.allclose(ac2.std.data, torch.ones(10))                  # the quirk
+    assert torch.equal(ac2.actor.model[0].weight, ac.actor.model[0].weight)
+    ac3 = ActorCriticMLP(39, 168, 10, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], init_noise_std=0.5, set_std=False)
+    ac3.load_state_dict(loaded["model_state_dict"])
+    assert torch.allclose(ac3.std.data, torch.full((10,), 0.2))
+
+
+def test_parameter_count_of_the_registered_policy():
+    ac = ActorCriticMLP(39, 168, 10, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], init_noise_std=0.2)
+    assert sum(p.numel() for p in ac.parameters()) == 436885          # 1 747 540 B fp32

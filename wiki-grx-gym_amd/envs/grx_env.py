@@ -1,0 +1,257 @@
+"""GRx vectorised environments: the reference's VecEnv surface over the fused HIP step.
+
+Mirrors, for the registered tasks, the class chain
+``BaseTask -> LeggedRobot -> LeggedRobotFFTAI -> GR1T1 (-> GR1T2)`` of the reference
+(base_task.py:39-150, legged_robot.py:53-305, legged_robot_fftai.py:12-177, gr1t1.py:7-16):
+same constructor signature ``cls(cfg, sim_params, physics_engine, sim_device, headless)``
+(task_registry.py:98-102), same attributes (``num_envs, num_obs, num_pri_obs, num_actions,
+max_episode_length, dt, device, obs_buf, pri_obs_buf, rew_buf, reset_buf, episode_length_buf,
+extras, dof_pos, dof_vel, torques, commands, base_lin_vel, base_ang_vel, root_states,
+feet_indices, ...``), same methods (``step, reset, get_observations,
+get_privileged_observations``).  What differs is *where the work happens*: ``step`` is one C-ABI
+call (one kernel launch) instead of ~70 gym calls and ~400 torch kernels, and there is no host
+synchronisation in it.
+
+Every buffer attribute is a zero-copy view of library-owned device memory (the
+``gymtorch.wrap_tensor`` model, legged_robot.py:110-135); SoA-backed ones are (N, k) views with
+strides (1, N).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import _capi
+from ..sim import HipSim
+from . import build_config
+from .config import class_to_dict
+
+
+class GRxEnv:
+    """VecEnv (rsl_rl/env/vec_env.py:7-40) implemented on libgrx_hip.so."""
+
+    # tests inject the CPU oracle here (tests/ only; the product has no CPU backend)
+    _backend_factory = None
+
+    def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True,
+                 env_offset=0, total_envs=None):
+        self.cfg = cfg
+        self.sim_params = sim_params
+        self.physics_engine = physics_engine
+        self.sim_device = sim_device
+        self.headless = headless
+        self.viewer = None
+        self.init_done = False
+        self.debug_viz = False
+        self.height_samples = None
+        sim_dt = float(_get(sim_params, "dt", cfg.sim.dt))
+        # _parse_cfg (legged_robot.py:91-104)
+        if cfg.terrain.mesh_type not in ("heightfield", "trimesh"):
+            cfg.terrain.curriculum = False
+        self.dt = cfg.control.decimation * sim_dt
+        self.obs_scales = cfg.normalization.obs_scales
+        self.reward_scales = class_to_dict(cfg.rewards.scales)
+        self.command_ranges = class_to_dict(cfg.commands.ranges)
+        self.max_episode_length_s = cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
+        cfg.domain_rand.push_interval = np.ceil(cfg.domain_rand.push_interval_s / self.dt)
+        cfg.commands.resample_command_interval = int(cfg.commands.resampling_command_interval_s / self.dt)
+        self.num_envs = cfg.env.num_envs
+        self.num_obs = cfg.env.num_obs
+        self.num_pri_obs = cfg.env.num_pri_obs
+        self.num_actions = cfg.env.num_actions
+        seed = getattr(cfg, "seed", 1)
+        # create_sim (legged_robot.py:507-528): terrain + simulation handle
+        self.terrain = None
+        if cfg.terrain.mesh_type in ("heightfield", "trimesh"):
+            from ..utils.terrain import Terrain
+            self.terrain = Terrain(cfg.terrain, total_envs or self.num_envs, seed=seed)
+        elif cfg.terrain.mesh_type != "plane":
+            raise ValueError("Terrain mesh type not recognised. Allowed types are [plane, heightfield, trimesh]")
+        c, keep, meta = build_config.build(cfg, sim_dt, self.num_envs, env_offset, total_envs, seed, self.terrain)
+        factory = type(self)._backend_factory
+        self._sim = factory(c, sim_device, keep) if factory else HipSim(c, sim_device, keep)
+        self.device = str(self._sim.device) if self._sim.device.type == "cpu" else f"cuda:{self._sim.device.index or 0}"
+        self._meta = meta
+        rm = meta["model"]
+        # asset facts the reference reads back from gym (legged_robot.py:966-977, 1092-1161)
+        self.num_dof = self.num_dofs = rm.num_dofs
+        self.num_bodies = rm.num_links
+        self.body_names = list(rm.body_names)
+        self.dof_names = list(rm.dof_names)
+        dev = self._sim.device
+        self.feet_indices = torch.tensor(meta["feet_links"], dtype=torch.long, device=dev)
+        self.termination_contact_indices = torch.tensor(meta["termination_links"], dtype=torch.long, device=dev)
+        self.penalised_contact_indices = torch.tensor(meta["penalised_links"], dtype=torch.long, device=dev)
+        self.torso_indices = torch.tensor(rm.links_containing(cfg.asset.torso_name), dtype=torch.long, device=dev)
+        kp, kd, q0 = build_config.resolve_gains(cfg, rm.dof_names)
+        self.p_gains = torch.tensor(kp, dtype=torch.float, device=dev)
+        self.d_gains = torch.tensor(kd, dtype=torch.float, device=dev)
+        self.default_dof_pos = torch.tensor(q0, dtype=torch.float, device=dev).unsqueeze(0)
+        self.dof_pos_limits = torch.tensor(build_config.soft_dof_pos_limits(rm, cfg.rewards.soft_dof_pos_limit), dtype=torch.float, device=dev)
+        self.dof_vel_limits = torch.tensor(rm.dof_vel_limit, dtype=torch.float, device=dev)
+        self.torque_limits = torch.tensor(rm.dof_effort, dtype=torch.float, device=dev)
+        for name in ("knee", "hip_roll", "hip_yaw", "hip_pitch", "ankle", "ankle_pitch"):
+            setattr(self, name + "_indices", rm.dofs_containing(getattr(cfg.asset, name + "_name", name)))
+        # reward bookkeeping as _prepare_reward_function leaves it (legged_robot.py:840-866)
+        for k in list(self.reward_scales.keys()):
+            if self.reward_scales[k] == 0:
+                self.reward_scales.pop(k)
+            else:
+                self.reward_scales[k] *= self.dt
+        self.reward_names = [n for n in self.reward_scales if n != "termination"]
+        self._term_index = {n: _capi.REWARD_TERMS.index(n) for n in self.reward_scales}
+        # buffers (base_task.py:69-76, legged_robot.py:106-203): zero-copy views
+        t = self._sim.tensor
+        self.obs_buf = t("OBS")
+        self.pri_obs_buf = t("PRI_OBS") if self.num_pri_obs is not None else None
+        self.rew_buf = t("REW")
+        self._reset_u8 = t("RESET")
+        self._timeout_u8 = t("TIME_OUT")
+        self.reset_buf = self._reset_u8.view(torch.bool)
+        self.time_out_buf = self._timeout_u8.view(torch.bool)
+        self._episode_length = t("EPISODE_LENGTH")
+        self.root_states = t("ROOT_STATES")
+        self.base_pos = self.root_states[:, 0:3]
+        self.base_quat = self.root_states[:, 3:7]
+        self.dof_pos, self.dof_vel = t("DOF_POS"), t("DOF_VEL")
+        self.torques, self.actions = t("TORQUES"), t("ACTIONS")
+        self.last_actions, self.last_dof_vel = t("LAST_ACTIONS"), t("LAST_DOF_VEL")
+        self.last_last_actions = self.last_actions        # identical by construction (FF:94 after LR:299)
+        self.commands = t("COMMANDS")
+        self.base_lin_vel, self.base_ang_vel = t("BASE_LIN_VEL"), t("BASE_ANG_VEL")
+        self.base_projected_gravity = t("PROJECTED_GRAVITY")
+        self.feet_contact_forces = t("FEET_CONTACT_FORCE")
+        self.feet_contact = t("FEET_CONTACT").view(torch.bool)
+        self.feet_air_time, self.feet_land_time, self.feet_height = t("FEET_AIR_TIME"), t("FEET_LAND_TIME"), t("FEET_HEIGHT")
+        self.avg_feet_contact_force, self.avg_feet_speed_xyz = t("AVG_FEET_FORCE"), t("AVG_FEET_SPEED")
+        self.measured_heights = t("MEASURED_HEIGHTS")
+        self.base_heights_offset = t("BASE_HEIGHTS_OFFSET")
+        self.env_origins = t("ENV_ORIGINS")
+        self.terrain_levels, self.terrain_types = t("TERRAIN_LEVELS"), t("TERRAIN_TYPES")
+        self.motor_strength_scales = t("MOTOR_STRENGTH")
+        self._episode_sums = t("EPISODE_SUMS")
+        self._episode_stats = t("EPISODE_STATS")
+        self.episode_sums = {n: self._episode_sums[i] for n, i in self._term_index.items()}
+        self.contact_forces = _FeetOnlyContactForces(self)
+        self.noise_scale_vec = self._noise_scale_vec()
+        self.common_step_counter = 0
+        self.extras = {}
+        self.custom_origins = cfg.terrain.mesh_type in ("heightfield", "trimesh")
+        # action latency N(5, 2) sub-steps, one draw per step shared by all envs (FF:53-54);
+        # numpy's global generator like the reference, so set_seed() governs it
+        self._delay_rng = np.random
+        self.fixed_action_delay = None
+        self.init_done = True
+
+    # ------------------------------------------------------------------ VecEnv surface
+    @property
+    def episode_length_buf(self):
+        return self._episode_length
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):
+        # the runner REBINDS this attribute (on_policy_runner.py:126): copy into the library buffer
+        self._episode_length.copy_(value.to(self._episode_length.dtype))
+
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_privileged_observations(self):
+        return self.pri_obs_buf
+
+    def step(self, actions):
+        """legged_robot.py:222-246 -- one fused kernel launch."""
+        a = actions.to(device=self._sim.device, dtype=torch.float32)
+        if not a.is_contiguous():
+            a = a.contiguous()
+        delay = self.fixed_action_delay
+        if delay is None:
+            delay = max(0.0, float(self._delay_rng.normal(loc=5, scale=2, size=1)[0]))   # FF:53-54
+        self.common_step_counter += 1
+        self._sim.step(a, delay, self.common_step_counter)
+        self._fill_extras()
+        return self.obs_buf, self.pri_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def reset(self):
+        """base_task.py:117-121: reset every env, then one zero-action step."""
+        self._sim.reset_all()
+        obs, pri, _, _, _ = self.step(torch.zeros(self.num_envs, self.num_actions, device=self._sim.device))
+        return obs, pri
+
+    def reset_idx(self, env_ids):
+        raise NotImplementedError("resets happen inside the fused step kernel (masked, no host sync); "
+                                  "use reset() for a full reset")
+
+    def render(self, sync_frame_time=True):
+        pass  # headless only (viewer is out of scope)
+
+    def set_camera(self, position, lookat):
+        pass
+
+    def close(self):
+        self._sim.close()
+
+    # ------------------------------------------------------------------ helpers
+    def _fill_extras(self):
+        """extras['episode'] / extras['time_outs'] (legged_robot.py:419-440) without a host sync:
+        the means live in a device buffer that the finalize kernel rewrites only on steps where some
+        env reset -- the dict semantics of the reference (it keeps the last dict otherwise)."""
+        stats = self._episode_stats.clone()           # the runner keeps one entry per step
+        ep = {"rew_" + n: stats[i] for n, i in self._term_index.items()}
+        if self.cfg.terrain.curriculum:
+            ep["terrain_level"] = self.terrain_levels.float().mean()
+        self.extras["episode"] = ep
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = self.time_out_buf
+
+    def _noise_scale_vec(self):
+        """gr1t1.py:315-336"""
+        n, s, lv = self.cfg.noise.noise_scales, self.obs_scales, self.cfg.noise.noise_level
+        nd = self.num_dof
+        v = torch.zeros(self.num_obs, device=self._sim.device)
+        v[3:6] = n.ang_vel * lv * s.ang_vel
+        v[6:9] = n.gravity * lv * s.gravity
+        v[9:9 + nd] = n.dof_pos * lv * s.dof_pos
+        v[9 + nd:9 + 2 * nd] = n.dof_vel * lv * s.dof_vel
+        v[9 + 2 * nd:9 + 3 * nd] = n.action * lv * s.action
+        return v
+
+
+class _FeetOnlyContactForces:
+    """``env.contact_forces[i, env.feet_indices, 2]`` as play.py:124 reads it.  Only the foot links are
+    materialised per step (the full 37-link tensor is 'next')."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def __getitem__(self, key):
+        env = self._env
+        full = torch.zeros(env.num_envs, env.num_bodies, 3, device=env.feet_contact_forces.device)
+        full[:, env.feet_indices] = env.feet_contact_forces
+        return full[key]
+
+
+def _get(obj, name, default):
+    if obj is None:
+        return default
+    if isinstance(obj, dict):
+        return obj.get("sim", obj).get(name, default) if isinstance(obj.get("sim", obj), dict) else default
+    return getattr(obj, name, default)
+
+
+# class names of the reference (envs/__init__.py:30-50)
+class LeggedRobot(GRxEnv):
+    pass
+
+
+class LeggedRobotFFTAI(LeggedRobot):
+    pass
+
+
+class GR1T1(LeggedRobotFFTAI):
+    pass
+
+
+class GR1T2(GR1T1):
+    pass

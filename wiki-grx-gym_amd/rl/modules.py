@@ -1,0 +1,105 @@
+"""Actor-critic MLP policy with the semantics of rsl_rl's ActorCriticMLP (reference:
+rsl_rl/modules/actor_critic_mlp.py:10-231, mlp.py:7-42): separate actor / critic MLPs with ELU
+(or the named activation) between hidden layers and a linear output, one learnable std per action,
+``Normal(mean, mean*0 + std)``, log-prob / entropy summed over actions, default PyTorch init.
+
+State-dict layout (``actor.model.<i>.weight`` ..., ``critic.model.<i>...``, ``std``) equals the
+reference's so checkpoints (``model_<it>.pt``) interchange; ``load_state_dict`` reproduces the
+reference quirk of overwriting ``std`` with ``set_noise_std`` unless ``set_std=False``
+(actor_critic_mlp.py:116-134)."""
+import torch
+import torch.nn as nn
+from torch.distributions import Normal
+
+_ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "crelu": nn.ReLU, "lrelu": nn.LeakyReLU,
+                "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
+
+
+def get_activation(name):
+    """rsl_rl/utils/utils.py:231-254"""
+    if name not in _ACTIVATIONS:
+        print("invalid activation function!")
+        return None
+    return _ACTIVATIONS[name]()
+
+
+class MLP(nn.Module):
+    def __init__(self, input_size, output_size, hidden_dims=(256, 256, 256), activation="relu", **_):
+        super().__init__()
+        self.input_size, self.output_size, self.hidden_dims = input_size, output_size, list(hidden_dims)
+        dims = [input_size] + list(hidden_dims)
+        layers = []
+        for a, b in zip(dims[:-1], dims[1:]):
+            layers += [nn.Linear(a, b), get_activation(activation)]
+        layers.append(nn.Linear(dims[-1], output_size))
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class ActorCriticMLP(nn.Module):
+    def __init__(self, actor_num_input, critic_num_input, actor_num_output, actor_hidden_dims=(256, 256, 256),
+                 critic_hidden_dims=(256, 256, 256), activation="elu", fixed_std=False, init_noise_std=1.0,
+                 set_std=True, set_noise_std=1.0, actor_output_activation=None, critic_output_activation=None, **kwargs):
+        if kwargs:
+            print("ActorCritic.__init__ got unexpected arguments, which will be ignored: " + str(list(kwargs)))
+        super().__init__()
+        self.num_actor_input, self.num_actor_output = actor_num_input, actor_num_output
+        self.num_critic_input, self.num_critic_output = critic_num_input, 1
+        self.actor = MLP(actor_num_input, actor_num_output, actor_hidden_dims, activation)
+        self.critic = MLP(critic_num_input, 1, critic_hidden_dims, activation)
+        self.fixed_std, self.init_noise_std = fixed_std, init_noise_std
+        self.std = nn.Parameter(init_noise_std * torch.ones(actor_num_output))
+        self.set_std, self.set_noise_std = set_std, set_noise_std
+        self.distribution = None
+        Normal.set_default_validate_args = False
+
+    is_recurrent = False
+
+    def load_state_dict(self, state_dict, strict=True):
+        state_dict = dict(state_dict)
+        if self.set_std:
+            state_dict["std"] = torch.ones_like(state_dict["std"]) * self.set_noise_std
+        else:
+            self.std.data = state_dict["std"]
+        if self.fixed_std:
+            self.std.data = self.init_noise_std * torch.ones_like(self.std.data)
+            self.std.requires_grad = False
+        return super().load_state_dict(state_dict, strict)
+
+    def reset(self, dones=None):
+        pass
+
+    def forward(self, *a, **k):
+        raise NotImplementedError
+
+    @property
+    def action_mean(self):
+        return self.distribution.mean
+
+    @property
+    def action_std(self):
+        return self.distribution.stddev
+
+    @property
+    def entropy(self):
+        return self.distribution.entropy().sum(dim=-1)
+
+    def update_distribution(self, observations):
+        mean = self.actor(observations)
+        std = self.init_noise_std if self.fixed_std else self.std.to(mean.device)
+        self.distribution = Normal(mean, mean * 0.0 + std)
+
+    def act(self, observations, **_):
+        self.update_distribution(observations)
+        return self.distribution.sample()
+
+    def get_actions_log_prob(self, actions):
+        return self.distribution.log_prob(actions).sum(dim=-1)
+
+    def act_inference(self, observations):
+        return self.actor(observations)
+
+    def evaluate(self, critic_observations=None, **_):
+        return self.critic(critic_observations)

@@ -1,0 +1,159 @@
+"""PPO with rsl_rl semantics (reference: rsl_rl/algorithms/ppo.py:10-333): clipped surrogate, clipped
+value loss, entropy bonus, adaptive-KL learning rate (x / 1.5 outside [kl/2, 2 kl], clamped),
+NaN-skip, grad-norm clip 1.0, one Adam step per minibatch, time-out bootstrap.
+
+Multi-GPU (the one addition): envs are sharded over ranks, every rank holds a replica of
+the 436 885-parameter model.  Per optimizer step ONE flat fp32 bucket (gradients + the minibatch KL
+appended as the last element) is all-reduced over RCCL/xGMI and averaged, so every rank takes the
+same adaptive-LR decision and the same Adam step: replicas stay bit-identical without broadcasting.
+At 1.75 MB the collective is latency-bound; a single fused bucket keeps it at one launch."""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.optim as optim
+
+from .modules import ActorCriticMLP  # noqa: F401
+from .storage import RolloutStorage
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class PPO:
+    def __init__(self, actor_critic=None, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
+                 value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, learning_rate_min=1e-5, learning_rate_max=1e-2,
+                 weight_decay=0.0, max_grad_norm=1.0, use_clipped_value_loss=True, schedule="fixed", desired_kl=0.01,
+                 device="cpu", storage_class="RolloutStorage", **kwargs):
+        if kwargs:
+            print("PPO.__init__ got unexpected arguments, which will be ignored: " + str(list(kwargs)))
+        self.device = device
+        self.desired_kl, self.schedule, self.mean_kl = desired_kl, schedule, 0.0
+        self.learning_rate, self.learning_rate_min, self.learning_rate_max = learning_rate, learning_rate_min, learning_rate_max
+        self.actor_critic = actor_critic.to(device)
+        self.storage_class = storage_class
+        self.storage, self.transition = None, None
+        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate, weight_decay=weight_decay)
+        self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
+        self.value_loss_coef, self.entropy_coef, self.gamma, self.lam = value_loss_coef, entropy_coef, gamma, lam
+        self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
+        self.symmetry_coef = 0
+        self.num_updates = 0
+        self._params = [p for p in self.actor_critic.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self._params)
+        self._bucket = torch.zeros(n + 1, device=device) if _world() > 1 else None   # grads + KL
+
+    def init_storage(self, num_envs, num_transitions_per_env, **_):
+        ac = self.actor_critic
+        self.transition = RolloutStorage.Transition()
+        self.storage = RolloutStorage(num_envs, num_transitions_per_env, [ac.num_actor_input], [ac.num_critic_input],
+                                      [ac.num_actor_output], self.device)
+
+    def test_mode(self):
+        self.actor_critic.eval()
+
+    def train_mode(self):
+        self.actor_critic.train()
+
+    def act(self, actor_observations, critic_observations):
+        t, ac = self.transition, self.actor_critic
+        t.actions = ac.act(actor_observations).detach()
+        t.values = ac.evaluate(critic_observations).detach()
+        t.actions_log_prob = ac.get_actions_log_prob(t.actions).detach()
+        t.action_mean, t.action_sigma = ac.action_mean.detach(), ac.action_std.detach()
+        t.observations, t.critic_observations = actor_observations, critic_observations
+        return t.actions
+
+    def act_inference(self, obs):
+        return self.actor_critic.act_inference(obs)
+
+    def process_env_step(self, rewards, dones, infos):
+        t = self.transition
+        t.rewards = rewards.clone()
+        t.dones = dones
+        if "time_outs" in infos:   # bootstrap on time-outs (ppo.py:190-191)
+            t.rewards += self.gamma * torch.squeeze(t.values * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+        self.storage.add_transitions(t)
+        t.clear()
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs):
+        last_values = self.actor_critic.evaluate(last_critic_obs).detach()
+        self.storage.compute_returns(last_values, self.gamma, self.lam)
+
+    def update_learning_rate(self, kl_mean):
+        if kl_mean > self.desired_kl * 2.0:
+            self.learning_rate = max(self.learning_rate_min, self.learning_rate / 1.5)
+        elif self.desired_kl / 2.0 > kl_mean > 0.0:
+            self.learning_rate = min(self.learning_rate_max, self.learning_rate * 1.5)
+
+    def _sync_gradients(self, kl_mean):
+        """ONE collective per optimizer step: [flat grads | KL] summed over ranks, averaged."""
+        b, o = self._bucket, 0
+        for p in self._params:
+            n = p.numel()
+            b[o:o + n].copy_(p.grad.reshape(-1) if p.grad is not None else torch.zeros(n, device=b.device))
+            o += n
+        b[o] = kl_mean
+        dist.all_reduce(b)
+        b /= _world()
+        o = 0
+        for p in self._params:
+            n = p.numel()
+            if p.grad is not None:
+                p.grad.copy_(b[o:o + n].view_as(p.grad))
+            o += n
+        return b[o]
+
+    def update(self):
+        mean_value_loss, mean_surrogate_loss = 0.0, 0.0
+        ac, multi = self.actor_critic, _world() > 1
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        for (obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _, _) in \
+                self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            ac.act(obs)
+            logp = ac.get_actions_log_prob(actions)
+            value = ac.evaluate(cobs)
+            mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+            kl_mean = None
+            if adaptive:
+                with torch.inference_mode():
+                    kl = torch.sum(torch.log(sigma / old_sigma + 1.e-5) + (old_sigma.square() + (old_mu - mu).square())
+                                   / (2.0 * sigma.square()) - 0.5, axis=-1)
+                    kl_mean = kl.mean()
+                if not multi:
+                    self._apply_kl(kl_mean.item())
+            ratio = torch.exp(logp - torch.squeeze(old_logp))
+            adv = torch.squeeze(advantages)
+            surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+            if self.use_clipped_value_loss:
+                clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
+                value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
+            else:
+                value_loss = (returns - value).pow(2).mean()
+            loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
+            if not multi and torch.isnan(loss):
+                continue
+            self.optimizer.zero_grad()
+            loss.backward()
+            if multi:
+                kl_avg = self._sync_gradients(kl_mean if kl_mean is not None else torch.zeros((), device=self.device))
+                if adaptive:
+                    self._apply_kl(kl_avg.item())
+                if not all(torch.isfinite(p.grad).all() for p in self._params if p.grad is not None):
+                    continue   # NaN-skip must be a collective decision: the averaged bucket is identical on every rank
+            nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+            mean_value_loss += value_loss.item()
+            mean_surrogate_loss += surrogate_loss.item()
+        self.num_updates = self.num_learning_epochs * self.num_mini_batches
+        return mean_value_loss / self.num_updates, mean_surrogate_loss / self.num_updates
+
+    def _apply_kl(self, kl_value):
+        self.mean_kl = kl_value
+        self.update_learning_rate(kl_value)
+        for g in self.optimizer.param_groups:
+            g["lr"] = self.learning_rate
+
+    def clear_storage(self):
+        self.storage.clear()
