@@ -1094,6 +1094,17 @@ int gro_reset_all(grx_handle s, void* stream) {
     return GRX_OK;
 }
 
+/* c10::div_floor_floating (what torch.div(..., rounding_mode='floor') evaluates in float32) */
+static float torch_div_floor(float a, float b) {
+    float mod = fmodf(a, b);
+    float div = (a - mod) / b;
+    if (mod != 0.0f && ((b < 0.0f) != (mod < 0.0f))) div -= 1.0f;
+    if (div == 0.0f) return copysignf(0.0f, a / b);
+    float fl = floorf(div);
+    if (div - fl > 0.5f) fl += 1.0f;
+    return fl;
+}
+
 /* ------------------------------------------------------------------ create / tensors */
 static void* zalloc(size_t n) { return calloc(n ? n : 1, 1); }
 
@@ -1156,8 +1167,9 @@ int gro_create(const grx_config* cfg, int device_id, grx_handle* out) {
             float u = gro_rand(cfg->seed, ge, 0, GRO_RNG_INIT_LEVEL, 0);
             e->level = (int)(u * (max_init + 1));
             if (e->level > max_init) e->level = max_init;
-            double per = (double)cfg->total_envs / cfg->num_terrain_cols;
-            e->type = (int)floor((double)ge / per);
+            /* torch.div(arange(N), N / num_cols, rounding_mode='floor') evaluates in float32 (legged_robot.py:1177-1180) */
+            float per = (float)((double)cfg->total_envs / cfg->num_terrain_cols);
+            e->type = (int)torch_div_floor((float)ge, per);
             if (e->type > cfg->num_terrain_cols - 1) e->type = cfg->num_terrain_cols - 1;
             env_origin_from_terrain(s, e);
         } else {

@@ -1,0 +1,147 @@
+"""Multi-process path on CPU (gloo, world_size 2): env sharding by global index, global advantage
+normalisation, ONE flat-bucket all-reduce per optimizer step that keeps the replicas bit-identical
+and equals a single-process update on the union batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T, n, NO, NP, NA = 6, 8, 39, 168, 10
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_alg():
+    from wiki_grx_gym_amd.rl import PPO, ActorCriticMLP
+    torch.manual_seed(0)
+    ac = ActorCriticMLP(NO, NP, NA, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], init_noise_std=0.2)
+    return PPO(actor_critic=ac, num_learning_epochs=2, num_mini_batches=3, learning_rate=1e-4, learning_rate_min=1e-5,
+               learning_rate_max=1e-3, schedule="adaptive", desired_kl=0.03, entropy_coef=0.01, gamma=0.99, lam=0.95, device="cpu")
+
+
+def _data(world):
+    g = torch.Generator().manual_seed(5)
+    N = n * world
+    return dict(obs=torch.randn(T + 1, N, NO, generator=g), pri=torch.randn(T + 1, N, NP, generator=g),
+                rew=torch.randn(T, N, generator=g), done=torch.rand(T, N, generator=g) < 0.15,
+                eps=torch.randn(T, N, NA, generator=g))
+
+
+def _rollout(alg, d, cols):
+    with torch.inference_mode():
+        for t in range(T):
+            orig = torch.distributions.Normal.sample
+            torch.distributions.Normal.sample = lambda self, _e=d["eps"][t][cols]: self.mean + self.stddev * _e
+            try:
+                alg.act(d["obs"][t][cols], d["pri"][t][cols])
+            finally:
+                torch.distributions.Normal.sample = orig
+            alg.process_env_step(d["rew"][t][cols].clone(), d["done"][t][cols], {})
+        alg.compute_returns(d["pri"][T][cols])
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    alg = _make_alg()
+    alg.init_storage(n, T)
+    d = _data(world)
+    cols = slice(rank * n, (rank + 1) * n)
+    _rollout(alg, d, cols)
+    adv = alg.storage.advantages.clone()
+    perm = torch.randperm(3 * (T * n // 3), generator=torch.Generator().manual_seed(9))
+    orig = torch.randperm
+    torch.randperm = lambda *a, **k: perm.clone()
+    try:
+        vl, sl = alg.update()
+    finally:
+        torch.randperm = orig
+    flat = torch.cat([p.detach().reshape(-1) for p in alg.actor_critic.parameters()])
+    torch.save(dict(adv=adv, flat=flat, lr=alg.learning_rate, kl=alg.mean_kl, vl=vl, sl=sl), os.path.join(out, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_update_equals_union_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{k}.pt") for k in range(world)]
+    assert torch.equal(r[0]["flat"], r[1]["flat"]), "replicas diverged"
+    assert r[0]["lr"] == r[1]["lr"] and r[0]["kl"] == pytest.approx(r[1]["kl"])
+    # single process on the union batch, minibatches = union of the two ranks' minibatches
+    alg = _make_alg()
+    N = n * world
+    alg.init_storage(N, T)
+    d = _data(world)
+    _rollout(alg, d, slice(0, N))
+    adv = alg.storage.advantages
+    np.testing.assert_allclose(torch.cat([r[0]["adv"], r[1]["adv"]], dim=1).numpy(), adv.numpy(), rtol=1e-5, atol=1e-6)
+    perm = torch.randperm(3 * (T * n // 3), generator=torch.Generator().manual_seed(9))
+    t_idx, j_idx = perm // n, perm % n
+    union = torch.stack([t_idx * N + rk * n + j_idx for rk in range(world)], dim=1)        # (len, world)
+    mb = (T * n) // 3
+    st = alg.storage
+    flat = lambda x: x.flatten(0, 1)
+
+    def gen(num_mini_batches, num_epochs=8):
+        cols = [flat(x) for x in (st.observations, st.pri_observations, st.actions, st.values, st.advantages, st.returns,
+                                  st.actions_log_prob, st.mu, st.sigma)]
+        for _ in range(num_epochs):
+            for i in range(num_mini_batches):
+                idx = union[i * mb:(i + 1) * mb].reshape(-1)
+                yield (*[c[idx] for c in cols], (None, None), None)
+    st.mini_batch_generator = gen
+    alg.update()
+    single = torch.cat([p.detach().reshape(-1) for p in alg.actor_critic.parameters()])
+    np.testing.assert_allclose(r[0]["flat"].numpy(), single.numpy(), rtol=2e-4, atol=2e-6)
+    assert alg.learning_rate == pytest.approx(r[0]["lr"])
+
+
+def _env_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from oracle.binding import OracleSim
+    from wiki_grx_gym_amd.envs import GR1T1Cfg, GR1T1CfgPPO, GRxEnv
+    from wiki_grx_gym_amd.utils import get_args, task_registry
+    GRxEnv._backend_factory = staticmethod(lambda c, dev, keep: OracleSim(c, "f32", keep))
+    args = get_args(["--task", "GR1T1", "--headless", "--num_envs", "16", "--sim_device", "cpu", "--rl_device", "cpu", "--seed", "2"])
+    cfg = GR1T1Cfg()
+    cfg.terrain.mesh_type = "heightfield"
+    env, _ = task_registry.make_env("GR1T1", args=args, env_cfg=cfg)
+    tcfg = GR1T1CfgPPO()
+    tcfg.runner.num_steps_per_env = 4
+    runner, _ = task_registry.make_alg_runner(env, name="GR1T1", args=args, train_cfg=tcfg, log_root=out)
+    runner.learn(num_learning_iterations=2)
+    flat = torch.cat([p.detach().reshape(-1) for p in runner.algorithm.actor_critic.parameters()])
+    torch.save(dict(flat=flat, types=env.terrain_types.clone(), origins=env.env_origins.clone(), friction=env._sim.tensor("FRICTION").clone(),
+                    files=sorted(os.listdir(out))), os.path.join(out, f"env{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_envs_train_two_ranks(tmp_path):
+    """make_env shards by global index; only rank 0 writes logs/checkpoints; replicas stay identical."""
+    world = 2
+    mp.spawn(_env_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"env{k}.pt") for k in range(world)]
+    assert torch.equal(r[0]["flat"], r[1]["flat"])
+    # terrain types follow the GLOBAL env index (legged_robot.py:1177-1180): 32 envs over 20 columns
+    want = torch.div(torch.arange(32), 32 / 20, rounding_mode="floor").to(torch.int32)
+    assert torch.equal(torch.cat([r[0]["types"], r[1]["types"]]), want)
+    assert not torch.equal(r[0]["friction"], r[1]["friction"])
+    runs = [f for f in os.listdir(tmp_path) if f.endswith("gr1t1_lower_limb")]
+    assert len(runs) == 1 and "model_2.pt" in os.listdir(tmp_path / runs[0])

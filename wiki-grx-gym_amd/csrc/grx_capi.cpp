@@ -191,6 +191,17 @@ int build_side_tables(const grx_config& c, KParams& P) {
     return GRX_OK;
 }
 
+/* c10::div_floor_floating (what torch.div(..., rounding_mode='floor') evaluates in float32) */
+float torch_div_floor(float a, float b) {
+    float mod = fmodf(a, b);
+    float div = (a - mod) / b;
+    if (mod != 0.0f && ((b < 0.0f) != (mod < 0.0f))) div -= 1.0f;
+    if (div == 0.0f) return copysignf(0.0f, a / b);
+    float fl = floorf(div);
+    if (div - fl > 0.5f) fl += 1.0f;
+    return fl;
+}
+
 // randomised base lump (oracle base_lump(); legged_robot.py:618-648)
 void base_lump(const grx_model& m, float link_mass, const float link_com[3], float* M_out, float c_out[3], float I_out[6]) {
     float m1 = m.base_rest_mass, m2 = link_mass;
@@ -332,8 +343,9 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
                 float u = grx_rand(c.seed, ge, 0, GRX_RNG_INIT_LEVEL, 0);
                 int lv = (int)(u * (float)(max_init + 1));
                 if (lv > max_init) lv = max_init;
-                double per = (double)c.total_envs / c.num_terrain_cols;
-                int ty = (int)floor((double)ge / per);
+                // torch.div(arange(N), N / num_cols, rounding_mode='floor') evaluates in float32 (legged_robot.py:1177-1180)
+                float per = (float)((double)c.total_envs / c.num_terrain_cols);
+                int ty = (int)torch_div_floor((float)ge, per);
                 if (ty > c.num_terrain_cols - 1) ty = c.num_terrain_cols - 1;
                 h_lv[i] = lv; h_ty[i] = ty;
                 const float* o = c.terrain_origins + ((size_t)lv * c.num_terrain_cols + ty) * 3;
