@@ -896,8 +896,14 @@ static void build_observations(struct grx_sim* s, env_t* e, int le, const grx_st
             else if (i >= 9 + nd && i < 9 + 2 * nd) sc = c->noise_dof_vel * c->noise_level * c->obs_scale_dof_vel;
             else if (i >= 9 + 2 * nd) sc = c->noise_action * c->noise_level * c->obs_scale_action;
             if (sc == 0) continue;
-            float u = (args && args->noise_uniform) ? args->noise_uniform[(size_t)le * c->num_obs + i]
-                                                    : gro_rand(c->seed, (uint32_t)(c->env_offset + le), step, GRO_RNG_NOISE, (uint32_t)i);
+            float u;
+            if (args && args->noise_uniform) u = args->noise_uniform[(size_t)le * c->num_obs + i];
+            else if (i < 9) u = gro_rand(c->seed, (uint32_t)(c->env_offset + le), step, GRO_RNG_NOISE, (uint32_t)(i - 3));
+            else { /* dof terms: one stream per leg half so that both GPU lanes of an env index their blocks statically */
+                int g = (i - 9) / nd, j = (i - 9) % nd, half = nd / 2;
+                int right = j >= half, k = right ? j - half : j;
+                u = gro_rand(c->seed, (uint32_t)(c->env_offset + le), step, right ? GRO_RNG_NOISE_DOF_R : GRO_RNG_NOISE_DOF_L, (uint32_t)(g * half + k));
+            }
             o[i] += (2 * (real)u - 1) * sc;
         }
     }

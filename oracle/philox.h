@@ -40,7 +40,9 @@ enum {
     GRO_RNG_NOISE = 6,
     GRO_RNG_CURRICULUM = 7,
     GRO_RNG_INIT_DR = 8,
-    GRO_RNG_INIT_LEVEL = 9
+    GRO_RNG_INIT_LEVEL = 9,
+    GRO_RNG_NOISE_DOF_L = 10, /* obs noise of the left-leg dof terms: item = group*5 + k (0 pos, 1 vel, 2 action) */
+    GRO_RNG_NOISE_DOF_R = 11
 };
 
 /* i-th uniform of stream `stream` for (global env, step) */

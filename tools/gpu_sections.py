@@ -1,0 +1,30 @@
+"""Section-level cycle profile of grx_step_kernel (build with -DGRX_PROFILE_SECTIONS)."""
+import sys, ctypes as C, subprocess, os; sys.path.insert(0,'.')
+import numpy as np, torch
+csrc="wiki-grx-gym_amd/csrc"
+flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-hip-fp32-correctly-rounded-divide-sqrt -DGRX_PROFILE_SECTIONS"
+subprocess.run(f"cd {csrc} && hipcc {flags} -shared -o libgrx_hip.so grx_kernels.hip grx_capi.cpp 2>/dev/null", shell=True, check=True)
+from tests.helpers import *
+from wiki_grx_gym_amd.sim import HipSim, load_hip_library
+from wiki_grx_gym_amd.envs import build_config
+os.environ["GRX_PUBLISH_DEBUG"]="0"
+names=["load","substeps","footkin","update+heights","timers","reward","reset","obs","store","rows->HBM"]
+for terrain in ("plane","heightfield"):
+    cfg = make_cfg(noise=True, dr=True, push=True, terrain=terrain); N=4096
+    ter = make_terrain(cfg, N, 1)
+    c,keep,_ = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
+    s = HipSim(c, "cuda:0", keep); s.reset_all()
+    gen = torch.Generator().manual_seed(0)
+    acts=[random_actions(cfg,N,gen,1.0).cuda() for _ in range(4)]
+    for i in range(40): s.step(acts[i%4],5.0,i+1)
+    torch.cuda.synchronize()
+    lib=C.CDLL(csrc+"/libgrx_hip.so"); buf=(C.c_longlong*(128*32))()
+    lib.grx_debug_profile.argtypes=[C.c_void_p, C.c_void_p, C.c_int]
+    nb=lib.grx_debug_profile(s._h, buf, 128)
+    full=np.array(buf[:],dtype=np.int64).reshape(128,32)[:nb]
+    a=full[:,:11]
+    print('   substep sections (sum over 10 substeps):', dict(zip(['pass1+chain contacts','base spheres','pass2','base solve','pass3','integrate'], np.median(full[:,16:22],axis=0).astype(int).tolist())))
+    d=np.diff(a,axis=1)
+    print(terrain, "total cycles median", np.median(a[:,10]-a[:,0]))
+    for n,v in zip(names, np.median(d,axis=0)): print(f"   {n:16s} {v:9.0f} ticks")
+    s.close()

@@ -48,13 +48,14 @@ struct grx_sim {
     grx_config cfg;
     int device = 0;
     int N = 0;
-    KParams hp;            // host copy (device pointers inside)
-    KParams* dp = nullptr; // device copy
+    KParams hp;            // launch parameters (passed by value to every kernel)
+    KTables tab;           // host image of the device tables
     std::vector<void*> allocs;
     uint32_t reset_count = 0;
     Timing timing;
     // tensor table
     grx_tensor_desc desc[GRX_NUM_TENSORS];
+    long long* prof_host = nullptr; int prof_blocks = 0;
 };
 
 namespace {
@@ -119,7 +120,7 @@ int check_topology(const grx_model& m) {
     return GRX_OK;
 }
 
-int build_side_tables(const grx_config& c, KParams& P) {
+int build_side_tables(const grx_config& c, KTables& P) {
     const grx_model& m = c.model;
     memset(P.side, 0, sizeof P.side);
     for (int side = 0; side < 2; ++side) {
@@ -154,39 +155,37 @@ int build_side_tables(const grx_config& c, KParams& P) {
     // base_idx is sorted by link (model.py emits spheres sorted by (body, link)); cut near the middle
     size_t cut = base_idx.size() / 2;
     while (cut > 0 && cut < base_idx.size() && m.sph_link[base_idx[cut]] == m.sph_link[base_idx[cut - 1]]) ++cut;
-    int fill[2] = {0, 0};
-    auto push = [&](int side, int i, int slot) -> int {
-        SideConst& S = P.side[side];
-        if (fill[side] >= GRX_MAXSPH_SIDE) return fail(GRX_ERR_UNSUPPORTED_MODEL, "too many collision spheres per lane");
-        SphC& o = S.sph[fill[side]++];
+    // fixed table layout per lane: [0..7] base-lump share, [8,9] chain body 2 (thigh_pitch), [10,11] body 3 (shank),
+    // [12..15] body 4 (foot, anchored).  Unused slots are parked far above any terrain (r = -1e30).
+    static const int cnt[GRX_LEG] = {0, 0, 2, 2, 4}, off[GRX_LEG] = {8, 8, 8, 10, 12};
+    auto put = [&](SphC& o, int i, int slot) {
         o.x = m.sph_pos[i][0]; o.y = m.sph_pos[i][1]; o.z = m.sph_pos[i][2]; o.r = m.sph_radius[i];
         o.flags = m.sph_flags[i]; o.slot = slot; o.link_last = 0; o.dmax = m.sph_damp_max[i];
-        return GRX_OK;
     };
     for (int side = 0; side < 2; ++side) {
         SideConst& S = P.side[side];
-        S.sph_begin[0] = 0;
+        for (int i = 0; i < GRX_MAXSPH_SIDE; ++i) { S.sph[i] = SphC{0.f, 0.f, 0.f, -1e30f, 0u, -1, 0, 0.f}; }
         size_t lo = side == 0 ? 0 : cut, hi = side == 0 ? cut : base_idx.size();
+        if (hi - lo > 8) return fail(GRX_ERR_UNSUPPORTED_MODEL, "more than 8 base-lump collision spheres per lane");
         for (size_t n = lo; n < hi; ++n) {
-            int rc = push(side, base_idx[n], -1);
-            if (rc) return rc;
+            SphC& o = S.sph[n - lo];
+            put(o, base_idx[n], -1);
             bool last = (n + 1 == hi) || m.sph_link[base_idx[n + 1]] != m.sph_link[base_idx[n]];
-            S.sph[fill[side] - 1].link_last = last ? 1 : 0;
+            o.link_last = last ? 1 : 0;
         }
         for (int k = 0; k < GRX_LEG; ++k) {
-            S.sph_begin[1 + k] = fill[side];
-            int b = 1 + side * GRX_LEG + k, slot = 0;
+            int b = 1 + side * GRX_LEG + k, n = 0;
             for (int i = 0; i < m.num_spheres; ++i) {
                 if (m.sph_body[i] != b) continue;
                 bool foot = m.sph_flags[i] & (side == 0 ? GRX_SPH_FOOT_LEFT : GRX_SPH_FOOT_RIGHT);
                 if (m.sph_flags[i] & (side == 0 ? GRX_SPH_FOOT_RIGHT : GRX_SPH_FOOT_LEFT))
                     return fail(GRX_ERR_UNSUPPORTED_MODEL, "foot shape on the wrong chain");
-                if (foot && slot >= 4) return fail(GRX_ERR_UNSUPPORTED_MODEL, "more than 4 anchored spheres per foot");
-                int rc = push(side, i, foot ? slot++ : -1);
-                if (rc) return rc;
+                if (n >= cnt[k]) return fail(GRX_ERR_UNSUPPORTED_MODEL, "collision shapes on chain body " + std::to_string(k) + " exceed the kernel's table (0,0,2,2,4)");
+                if (foot != (k == GRX_LEG - 1)) return fail(GRX_ERR_UNSUPPORTED_MODEL, "anchored foot shapes must sit on the chain leaf");
+                put(S.sph[off[k] + n], i, foot ? n : -1);
+                ++n;
             }
         }
-        S.sph_begin[GRX_LEG + 1] = fill[side];
     }
     return GRX_OK;
 }
@@ -266,6 +265,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     P.action_scale = c.action_scale;
     P.kn = c.contact.kn; P.dn = c.contact.dn; P.kt = c.contact.kt; P.ct = c.contact.ct; P.cv = c.contact.cv;
     P.terrain_friction = c.contact.terrain_friction;
+    P.inv_kt = 1.0f / c.contact.kt;
     P.termination_force = c.termination_force; P.termination_gravity_z = c.termination_gravity_z;
     P.max_episode_length = c.max_episode_length; P.max_episode_length_s = c.max_episode_length_s;
     P.resample_command_interval = c.resample_command_interval;
@@ -288,7 +288,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     P.noise_gravity = c.noise_gravity; P.noise_dof_pos = c.noise_dof_pos; P.noise_dof_vel = c.noise_dof_vel;
     P.clip_observations = c.clip_observations;
     P.terrain_type = c.terrain_type; P.measure_heights = c.measure_heights; P.nh = nh;
-    memcpy(P.height_points, c.height_points, sizeof P.height_points);
+    memcpy(s->tab.height_points, c.height_points, sizeof s->tab.height_points);
     P.hf_rows = c.hf_rows; P.hf_cols = c.hf_cols;
     P.horizontal_scale = c.horizontal_scale; P.vertical_scale = c.vertical_scale; P.border_size = c.border_size;
     P.curriculum = c.curriculum; P.num_terrain_rows = c.num_terrain_rows; P.num_terrain_cols = c.num_terrain_cols;
@@ -296,7 +296,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     memcpy(P.torso_rot, m.torso_rot, sizeof P.torso_rot);
     memcpy(P.forehead_rot, m.forehead_rot, sizeof P.forehead_rot);
     P.has_torso = m.torso_body >= 0; P.has_forehead = m.forehead_body >= 0;
-    rc = build_side_tables(c, P);
+    rc = build_side_tables(c, s->tab);
     if (rc) { delete s; return rc; }
 
 #define DA(field, count) do { rc = dalloc(s, &P.field, (count)); if (rc) { grx_destroy(s); return rc; } } while (0)
@@ -311,7 +311,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(episode_sums, NT * N); DA(reward_terms, NT * N); DA(heights, (size_t)(nh > 0 ? nh : 1) * N);
     DA(obs, GRX_NUM_OBS * N + 64); DA(pri_obs, (size_t)c.num_pri_obs * N + 64);
     const int nblocks = (c.num_envs + grx_envs_per_block() - 1) / grx_envs_per_block();
-    DA(stat_partial, (size_t)nblocks * (NT + 1)); DA(stats, NT + 1);
+    DA(stat_partial, (size_t)nblocks * (NT + 1)); DA(stats, NT + 1); DA(prof, (size_t)nblocks * 32);
     float* base_mass_com = nullptr;
     rc = dalloc(s, &base_mass_com, 4 * N);
     if (rc) { grx_destroy(s); return rc; }
@@ -322,6 +322,34 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
         if (rc) { grx_destroy(s); return rc; }
         HIP_TRY(hipMemcpy(dhf, c.height_samples, n * sizeof(int16_t), hipMemcpyHostToDevice));
         P.hf = dhf;
+        {   // coarse max map: max height over each 8x8-cell block dilated by 3 blocks (>= 2.4 m: robot reach 1.1 m
+            // + travel within a policy step + bilinear support), used only to cull spheres that cannot touch
+            int cr = (c.hf_rows + GRX_COARSE - 1) / GRX_COARSE, cc = (c.hf_cols + GRX_COARSE - 1) / GRX_COARSE;
+            std::vector<int16_t> blk((size_t)cr * cc, INT16_MIN);
+            for (int i = 0; i < c.hf_rows; ++i)
+                for (int j = 0; j < c.hf_cols; ++j) {
+                    int16_t& b = blk[(size_t)(i / GRX_COARSE) * cc + j / GRX_COARSE];
+                    int16_t v = c.height_samples[(size_t)i * c.hf_cols + j];
+                    if (v > b) b = v;
+                }
+            std::vector<float> cm((size_t)cr * cc);
+            for (int i = 0; i < cr; ++i)
+                for (int j = 0; j < cc; ++j) {
+                    int16_t m = INT16_MIN;
+                    for (int di = -3; di <= 3; ++di)
+                        for (int dj = -3; dj <= 3; ++dj) {
+                            int ii = i + di, jj = j + dj;
+                            if (ii < 0 || jj < 0 || ii >= cr || jj >= cc) continue;
+                            if (blk[(size_t)ii * cc + jj] > m) m = blk[(size_t)ii * cc + jj];
+                        }
+                    cm[(size_t)i * cc + j] = (float)m * c.vertical_scale;
+                }
+            float* dcm = nullptr;
+            rc = dalloc(s, &dcm, cm.size());
+            if (rc) { grx_destroy(s); return rc; }
+            HIP_TRY(hipMemcpy(dcm, cm.data(), cm.size() * sizeof(float), hipMemcpyHostToDevice));
+            P.coarse_max = dcm; P.coarse_rows = cr; P.coarse_cols = cc;
+        }
         float* dor = nullptr;
         size_t no = (size_t)c.num_terrain_rows * c.num_terrain_cols * 3;
         rc = dalloc(s, &dor, no);
@@ -389,8 +417,14 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
         UP(origins, h_or); UP(levels, h_lv); UP(types, h_ty); UP(q, h_q); UP(root, h_root); UP(reset, h_reset);
         HIP_TRY(hipMemcpy(base_mass_com, h_bmc.data(), h_bmc.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc((void**)&s->dp, sizeof(KParams)));
-    HIP_TRY(hipMemcpy(s->dp, &P, sizeof(KParams), hipMemcpyHostToDevice));
+    {
+        KTables* dt = nullptr;
+        rc = dalloc(s, &dt, 1);
+        if (rc) { grx_destroy(s); return rc; }
+        HIP_TRY(hipMemcpy(dt, &s->tab, sizeof(KTables), hipMemcpyHostToDevice));
+        P.tables = dt;
+    }
+    static_assert(sizeof(KParams) <= 4096, "KParams must fit the kernarg segment");
 
     // ---- tensor table
     const int64_t Ni = c.num_envs;
@@ -432,6 +466,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     desc_vec(s, GRX_T_TERM_CONTACT, P.term_contact, GRX_U8, Ni);
     desc_vec(s, GRX_T_EPISODE_STATS, P.stats, GRX_F32, NT + 1);
     desc_soa3(s, GRX_T_ANCHORS, P.anchors, 8, 3);
+    s->prof_host = P.prof; s->prof_blocks = nblocks;
     *out = s;
     return GRX_OK;
 }
@@ -440,7 +475,6 @@ int grx_destroy(grx_handle s) {
     if (!s) return GRX_OK;
     hipSetDevice(s->device);
     for (void* p : s->allocs) hipFree(p);
-    if (s->dp) hipFree(s->dp);
     for (auto& pr : s->timing.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto& pr : s->timing.pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     delete s;
@@ -453,8 +487,8 @@ int grx_reset_all(grx_handle s, void* stream) {
     // extras["episode"] of a full reset: mean of the running episode sums over all envs
     // (legged_robot.py:420-424); computed by the stats path with every env flagged.
     uint32_t step = 0x80000000u + (s->reset_count++);
-    grx_launch_reset_all(s->dp, s->N, step, st);
-    grx_launch_finalize(s->dp, s->N, st);
+    grx_launch_reset_all(&s->hp, s->N, step, st);
+    grx_launch_finalize(&s->hp, s->N, st);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
@@ -468,13 +502,13 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
     }
-    grx_launch_step(s->dp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
+    grx_launch_step(&s->hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
                     (long long)a->common_step_counter, a->noise_uniform, st);
     if (s->timing.enabled) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->timing.pending.push_back(ev);
     }
-    grx_launch_finalize(s->dp, s->N, st);
+    grx_launch_finalize(&s->hp, s->N, st);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
@@ -488,7 +522,7 @@ int grx_tensor(grx_handle s, int id, grx_tensor_desc* out) {
 
 int grx_set_state(grx_handle s, const float* root, const float* q, const float* qd, void* stream) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_set_state: null handle");
-    grx_launch_set_state(s->dp, s->N, root, q, qd, (hipStream_t)stream);
+    grx_launch_set_state(&s->hp, s->N, root, q, qd, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
@@ -517,6 +551,14 @@ int grx_kernel_time_ms(grx_handle s, int enable, float* avg_ms, int64_t* launche
     if (avg_ms) *avg_ms = n ? (float)(tot / n) : 0.f;
     if (launches) *launches = n;
     return GRX_OK;
+}
+
+// tools only (GRX_PROFILE_SECTIONS builds): copy the per-block section stamps to the host
+int grx_debug_profile(grx_handle s, long long* out, int max_blocks) {
+    if (!s || !out) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_profile: null argument");
+    int nb = s->prof_blocks < max_blocks ? s->prof_blocks : max_blocks;
+    HIP_TRY(hipMemcpy(out, s->prof_host, (size_t)nb * 32 * sizeof(long long), hipMemcpyDeviceToHost));
+    return nb;
 }
 
 const char* grx_last_error(void) { return g_err.c_str(); }

@@ -9,6 +9,7 @@
 #define GRX_NUM_OBS 39   // 9 + 3*GRX_ND (gr1t1.py:281-295)
 #define GRX_MAX_PRI 168  // 39 + 3 + 1 + 2 + 2 + 121 (gr1t1.py:297-313)
 #define GRX_MAXSPH_SIDE 16
+#define GRX_COARSE 8     // raster cells per coarse max-map cell (0.8 m)
 
 struct SphC {
     float x, y, z, r;    // centre (body frame), radius
@@ -29,16 +30,24 @@ struct SideConst {
     float amin[GRX_LEG], amax[GRX_LEG];  // clip_actions
     float slo[GRX_LEG], shi[GRX_LEG];    // soft dof position limits (legged_robot.py:606-610)
     float foot_pos[3];
-    int32_t sph_begin[GRX_LEG + 2];      // [0]=0: base-lump share, [1+k]: chain body k, [GRX_LEG+1]: end
     SphC sph[GRX_MAXSPH_SIDE];
 };
 
+// Large read-only tables, in device memory.
+struct KTables {
+    SideConst side[2];
+    float height_points[GRX_MAX_HEIGHT_POINTS][2];
+};
+
+// Launch parameters.  Passed BY VALUE: the kernarg segment is constant address space, so the compiler may
+// hoist / merge the scalar loads across the kernel's global stores (as a device-memory struct every store forced
+// a reload + s_waitcnt: 421 waits in the post-physics section, measured).
 struct KParams {
     int32_t N, env_offset, total_envs, publish_debug;
     uint64_t seed;
     float sim_dt; int32_t decimation; float gravity[3];
     float action_scale;
-    float kn, dn, kt, ct, cv, terrain_friction;
+    float kn, dn, kt, ct, cv, terrain_friction, inv_kt;
     float termination_force, termination_gravity_z;
     float max_episode_length, max_episode_length_s;
     int32_t resample_command_interval;
@@ -56,14 +65,14 @@ struct KParams {
     int32_t add_noise; float noise_level, noise_action, noise_ang_vel, noise_gravity, noise_dof_pos, noise_dof_vel;
     float clip_observations;
     int32_t terrain_type, measure_heights, nh;
-    float height_points[GRX_MAX_HEIGHT_POINTS][2];
     const int16_t* hf; int32_t hf_rows, hf_cols;
+    const float* coarse_max; int32_t coarse_rows, coarse_cols;   // dilated block-max of the raster [m]: sphere culling
     float horizontal_scale, vertical_scale, border_size;
     int32_t curriculum, num_terrain_rows, num_terrain_cols;
     const float* terrain_origins; float terrain_length;
     float torso_rot[9], forehead_rot[9];
     int32_t has_torso, has_forehead;
-    SideConst side[2];
+    const struct KTables* tables;   // per-side robot tables + height-scan points (staged into LDS by every block)
     // state (SoA [k][N])
     float *q, *qd, *root, *anchors, *last_actions, *last_dof_vel, *actions, *torques, *motor_strength;
     float *base_m, *base_c, *base_I, *friction, *commands, *origins;
@@ -76,4 +85,5 @@ struct KParams {
     uint8_t *reset, *time_out, *term_contact;
     float *base_lin_vel, *base_ang_vel, *proj_grav, *episode_sums, *reward_terms, *heights;
     float *obs, *pri_obs, *stat_partial, *stats;
+    long long* prof;   // GRX_PROFILE_SECTIONS builds only: [nblocks][16] s_memtime stamps
 };

@@ -30,6 +30,14 @@
 #include "grx_math.h"
 #include "grx_rng.h"
 
+#ifdef GRX_PROFILE_SECTIONS
+#define GRX_TICK(i) do { if (threadIdx.x == 0) P.prof[(size_t)blockIdx.x * 32 + (i)] = clock64(); } while (0)
+#define GRX_TICK2(i) do { if (threadIdx.x == 0) P.prof[(size_t)blockIdx.x * 32 + (i)] += clock64() - tprev; tprev = clock64(); } while (0)
+#else
+#define GRX_TICK2(i) do {} while (0)
+#define GRX_TICK(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int NT = GRX_NUM_REWARD_TERMS;
@@ -45,6 +53,12 @@ GRX_DEV R3 joint_rot_k(const R3& P, float c, float s, int ax) {
     return joint_rot<2>(P, c, s);
 }
 GRX_DEV V3 axis_k(const R3& R, int ax) { return ax == 0 ? R.cx : (ax == 1 ? R.cy : R.cz); }
+
+// sin/cos of a joint angle: hardware v_sin/v_cos (|q| < pi: abs error < 1e-6, far below the contact noise)
+GRX_DEV void grx_sincos(float x, float& s, float& c) {
+    s = __sinf(x);
+    c = __cosf(x);
+}
 
 // physics terrain query: bilinear interpolation of the int16 heightfield (oracle: terrain_height)
 template <bool HF>
@@ -77,6 +91,7 @@ struct LaneConst {  // per-env constants held in registers
     V3 base_c;
     S3 base_I;
     float mu;
+    float hmax;   // upper bound of the terrain height within reach during this policy step
 };
 
 struct SubstepOut {
@@ -88,51 +103,74 @@ struct SubstepOut {
 
 struct FootKin { V3 pos, vel, ang; };  // foot link origin (world), its velocity, body angular velocity
 
-// One sphere against the terrain.  R/rho/w/v: rotation, origin (relative to the base origin O),
-// angular velocity and O-referenced linear velocity of the carrying body.
-template <bool HF>
-GRX_DEV V3 sphere_force(const KParams& P, const SphC& S, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu,
-                        LaneState& st, bool enabled, V3& xr_out) {
-    V3 xr = rho + rot(R, v3(S.x, S.y, S.z));
-    xr_out = xr;
+// Fixed per-lane sphere table layout (grx_capi.cpp build_side_tables): slots 0..7 = this lane's share of the
+// base-lump shapes, then the chain bodies' shapes.  Unused slots carry r = -1e30 (never within reach).
+__device__ constexpr int kSphCnt[LEG] = {0, 0, 2, 2, 4};
+__device__ constexpr int kSphOff[LEG] = {8, 8, 8, 10, 12};
+
+// One sphere against the terrain.  R/rho/w/v: rotation, origin (relative to the base origin O), angular
+// velocity and O-referenced linear velocity of the carrying body.  SLOT: friction-anchor slot of a foot
+// sphere (compile time), -1 for the other shapes.  Returns the world-frame force; xr = centre relative to O.
+template <bool HF, int SLOT>
+GRX_DEV V3 sphere_contact(const KParams& P, const SphC& S, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu, float hmax,
+                          LaneState& st, V3& xr) {
+    xr = rho + rot(R, v3(S.x, S.y, S.z));
     V3 F = v3(0.f, 0.f, 0.f);
-    float wx = O.x + xr.x, wy = O.y + xr.y, wz = O.z + xr.z;
-    float h = terrain_height<HF>(P, wx, wy);
-    float d = h + S.r - wz;
-    int slot = S.slot;
-    if (!enabled) return F;
-    if (d <= 0.0f) {
-        if (slot >= 0) st.anchor_on &= ~(1u << slot);
-        return F;
-    }
-    V3 u = v + cross(w, xr);
-    float cd = fminf(P.kn * d * P.dn, S.dmax);  // Hunt-Crossley damping, mass-aware cap (oracle contact_forces())
-    float fn = fmaxf(P.kn * d - cd * u.z, 0.0f);
-    F.z = fn;
-    float fmax = mu * fn;
-    if (slot >= 0) {
-        float axx = st.ax[0], ayy = st.ay[0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) if (slot == i) { axx = st.ax[i]; ayy = st.ay[i]; }
-        if (!(st.anchor_on & (1u << slot))) { axx = wx; ayy = wy; st.anchor_on |= (1u << slot); }
-        float ftx = -P.kt * (wx - axx) - P.ct * u.x;
-        float fty = -P.kt * (wy - ayy) - P.ct * u.y;
-        float ft = sqrtf(ftx * ftx + fty * fty);
-        if (ft > fmax) {
-            float sc = fmax / ft;
-            ftx *= sc; fty *= sc;
-            axx = wx + ftx / P.kt;
-            ayy = wy + fty / P.kt;
+    const float wz = O.z + xr.z;
+    // cull: hmax bounds the terrain height anywhere the robot can reach during this policy step
+    // (plane: 0; heightfield: dilated coarse max map): above it the sphere cannot touch (exactly d <= 0)
+    bool touching = false;
+    if (wz - S.r <= hmax) {
+        const float wx = O.x + xr.x, wy = O.y + xr.y;
+        const float d = terrain_height<HF>(P, wx, wy) + S.r - wz;
+        if (d > 0.0f) {
+            touching = true;
+            V3 u = v + cross(w, xr);
+            float cd = fminf(P.kn * d * P.dn, S.dmax);  // Hunt-Crossley damping, mass-aware cap (oracle contact_forces())
+            float fn = fmaxf(P.kn * d - cd * u.z, 0.0f);
+            F.z = fn;
+            float fmax = mu * fn;
+            if (SLOT >= 0) {
+                float axx = st.ax[SLOT < 0 ? 0 : SLOT], ayy = st.ay[SLOT < 0 ? 0 : SLOT];
+                if (!(st.anchor_on & (1u << (SLOT < 0 ? 0 : SLOT)))) { axx = wx; ayy = wy; }
+                float ftx = -P.kt * (wx - axx) - P.ct * u.x;
+                float fty = -P.kt * (wy - ayy) - P.ct * u.y;
+                float ft = sqrtf(ftx * ftx + fty * fty);
+                if (ft > fmax) {  // slip: clamp to the cone, drag the anchor along
+                    float sc = fmax / ft;
+                    ftx *= sc; fty *= sc;
+                    axx = wx + ftx * P.inv_kt;
+                    ayy = wy + fty * P.inv_kt;
+                }
+                st.ax[SLOT < 0 ? 0 : SLOT] = axx; st.ay[SLOT < 0 ? 0 : SLOT] = ayy;
+                F.x = ftx; F.y = fty;
+            } else {
+                float sp = sqrtf(u.x * u.x + u.y * u.y);
+                float ft = fminf(P.cv * sp, fmax);
+                if (sp > 1e-9f) { float k = -ft / sp; F.x = k * u.x; F.y = k * u.y; }
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) if (slot == i) { st.ax[i] = axx; st.ay[i] = ayy; }
-        F.x = ftx; F.y = fty;
-    } else {
-        float sp = sqrtf(u.x * u.x + u.y * u.y);
-        float ft = fminf(P.cv * sp, fmax);
-        if (sp > 1e-9f) { F.x = -ft * u.x / sp; F.y = -ft * u.y / sp; }
+    }
+    if (SLOT >= 0) {
+        const uint32_t bit = 1u << (SLOT < 0 ? 0 : SLOT);
+        st.anchor_on = touching ? (st.anchor_on | bit) : (st.anchor_on & ~bit);
     }
     return F;
+}
+
+// Wave-uniform pre-check of a group of CNT spheres on one body: can ANY lane's sphere be within reach of the
+// terrain?  All LDS reads of the group are issued together (one exposed latency instead of one per sphere);
+// when no lane of the wave qualifies the whole contact block is skipped (upright robot: every group but the feet).
+template <int CNT>
+GRX_DEV bool group_within_reach(const SphC* S, const R3& R, V3 rho, V3 O, float hmax) {
+    bool cand = false;
+    const float base_z = O.z + rho.z;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        float z = base_z + fmaf(R.cx.z, S[i].x, fmaf(R.cy.z, S[i].y, R.cz.z * S[i].z));
+        cand = cand || (z - S[i].r <= hmax);
+    }
+    return __any(cand);
 }
 
 // One physics sub-step (gym.simulate(dt), legged_robot_fftai.py:68) for this lane's half of the env.
@@ -143,6 +181,9 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     const float dt = P.sim_dt;
     R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
     V3 O = st.pos;
+#ifdef GRX_PROFILE_SECTIONS
+    long long tprev = clock64();
+#endif
     // ---- pass 1: kinematics, rigid inertias, bias forces, contacts (root -> leaf)
     V3 Sa[LEG], Ss[LEG];       // joint motion subspace S = (a; rho x a)
     S3 IAk[LEG]; V3 Ih[LEG];   // rigid inertia about O: A and h = m*kappa
@@ -157,7 +198,7 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     for (int k = 0; k < LEG; ++k) {
         V3 rho = rho_p + rot(Rp, v3(C.r[k][0], C.r[k][1], C.r[k][2]));
         float sn, cs;
-        sincosf(st.q[k], &sn, &cs);
+        grx_sincos(st.q[k], sn, cs);
         R3 R = joint_rot_k(Rp, cs, sn, kAxis[k]);
         V3 a = axis_k(R, kAxis[k]);
         V3 s = cross(rho, a);
@@ -174,17 +215,26 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
         V3 ha = mul(A, wk) + cross(h, vk);
         V3 pa = cross(wk, ha) + cross(vk, hl);
         V3 pl = cross(wk, hl);
-        // contacts of the spheres carried by chain body k (thigh_pitch, shank, foot)
-        int sb = C.sph_begin[1 + k], se = C.sph_begin[2 + k];
-        int cnt = max(se - sb, __builtin_bit_cast(int, pair_swap(__builtin_bit_cast(float, se - sb))));
-        for (int i = 0; i < cnt; ++i) {
-            bool en = (sb + i) < se;
-            const SphC& S = C.sph[min(sb + i, GRX_MAXSPH_SIDE - 1)];
-            V3 xr;
-            V3 F = sphere_force<HF>(P, S, R, rho, wk, vk, O, LC.mu, st, en, xr);
-            pa = pa - cross(xr, F);
-            pl = pl - F;
-            if (en && (S.flags & (GRX_SPH_FOOT_LEFT | GRX_SPH_FOOT_RIGHT))) out.foot_force = out.foot_force + F;
+        // contacts of the shapes carried by chain body k (thigh_pitch: 2, shank: 2, foot: 4 anchored spheres)
+        if (kSphCnt[k] == 2 && group_within_reach<2>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                V3 xr;
+                V3 F = sphere_contact<HF, -1>(P, C.sph[kSphOff[k] + i], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
+                pa = pa - cross(xr, F); pl = pl - F;
+            }
+        } else if (kSphCnt[k] == 4) {
+          if (group_within_reach<4>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
+            V3 xr, F;
+            F = sphere_contact<HF, 0>(P, C.sph[kSphOff[k] + 0], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
+            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
+            F = sphere_contact<HF, 1>(P, C.sph[kSphOff[k] + 1], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
+            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
+            F = sphere_contact<HF, 2>(P, C.sph[kSphOff[k] + 2], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
+            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
+            F = sphere_contact<HF, 3>(P, C.sph[kSphOff[k] + 3], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
+            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
+          } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
         }
         if (k == LEG - 1) {  // foot link frame BEFORE this sub-step's integration
             V3 fr = rho + rot(R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
@@ -195,31 +245,29 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
         Sa[k] = a; Ss[k] = s; IAk[k] = A; Ih[k] = h; pA[k] = pa; pL[k] = pl;
         Rp = R; rho_p = rho; w = wk; v = vk;
     }
+    GRX_TICK2(16);
     // ---- base-lump spheres handled by this lane (per-link netting for termination / collision)
     V3 f0a = v3(0.f, 0.f, 0.f), f0l = v3(0.f, 0.f, 0.f);
-    {
-        int sb = C.sph_begin[0], se = C.sph_begin[1];
-        int cnt = max(se - sb, __builtin_bit_cast(int, pair_swap(__builtin_bit_cast(float, se - sb))));
+    if (group_within_reach<8>(&C.sph[0], R0, v3(0.f, 0.f, 0.f), O, LC.hmax)) {
         V3 Flink = v3(0.f, 0.f, 0.f);
-        V3 zero = v3(0.f, 0.f, 0.f);
-        for (int i = 0; i < cnt; ++i) {
-            bool en = (sb + i) < se;
-            const SphC& S = C.sph[min(sb + i, GRX_MAXSPH_SIDE - 1)];
+        const V3 zero = v3(0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const SphC& S = C.sph[i];
             V3 xr;
-            V3 F = sphere_force<HF>(P, S, R0, zero, st.ang, st.vel, O, LC.mu, st, en, xr);
+            V3 F = sphere_contact<HF, -1>(P, S, R0, zero, st.ang, st.vel, O, LC.mu, LC.hmax, st, xr);
             f0a = f0a + cross(xr, F);
             f0l = f0l + F;
-            if (en) {
-                Flink = Flink + F;
-                if (S.link_last) {
-                    float n2 = dot(Flink, Flink);
-                    if ((S.flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) out.term = true;
-                    if ((S.flags & GRX_SPH_PENALISE) && n2 > 0.01f) out.pen_count += 1.0f;
-                    Flink = zero;
-                }
+            Flink = Flink + F;
+            if (S.link_last) {   // uniform per side: net force of one URDF link complete
+                float n2 = dot(Flink, Flink);
+                if ((S.flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) out.term = true;
+                if ((S.flags & GRX_SPH_PENALISE) && n2 > 0.01f) out.pen_count += 1.0f;
+                Flink = zero;
             }
         }
     }
+    GRX_TICK2(17);
     // ---- pass 2: articulated inertias (leaf -> root).  w, v currently = velocity of body LEG-1.
     S3 A = IAk[LEG - 1];
     V3 h4 = Ih[LEG - 1];
@@ -260,6 +308,7 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
             pa = pa + pA[k - 1]; pl = pl + pL[k - 1];
         }
     }
+    GRX_TICK2(18);
     // ---- base: combine both chains (DPP pair exchange), add the base lump, solve the 6x6
     pa = pa - f0a; pl = pl - f0l;
     A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
@@ -291,6 +340,7 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     S3 Sc = {A.xx - dot(b0, d0), A.xy - dot(b0, d1), A.xz - dot(b0, d2), A.yy - dot(b1, d1), A.yz - dot(b1, d2), A.zz - dot(b2, d2)};
     V3 alpha = mul(inv(Sc), rhs);
     V3 acc = neg(mul(Di, pl + mulT(B, alpha)));
+    GRX_TICK2(19);
     // ---- pass 3: accelerations (root -> leaf)
     float qdd[LEG];
     V3 aa = alpha, al = acc;
@@ -302,6 +352,7 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
         aa = fma3(Sa[k], qd2, pa_);
         al = fma3(Ss[k], qd2, pl_);
     }
+    GRX_TICK2(20);
     // ---- integrate (semi-implicit Euler)
     V3 lin = acc + cross(st.ang, st.vel);  // classical acceleration of the base origin
     st.vel = v3(st.vel.x + (lin.x + P.gravity[0]) * dt, st.vel.y + (lin.y + P.gravity[1]) * dt, st.vel.z + (lin.z + P.gravity[2]) * dt);
@@ -322,6 +373,7 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     float nw = ww - hx * x - hy * y - hz * z;
     float n = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
     st.qx = nx * n; st.qy = ny * n; st.qz = nz * n; st.qw = nw * n;
+    GRX_TICK2(21);
 }
 
 // kinematics only: this lane's foot link frame in the current state
@@ -332,7 +384,7 @@ GRX_DEV FootKin foot_kinematics(const SideConst& C, const LaneState& st) {
     for (int k = 0; k < LEG; ++k) {
         rho = rho + rot(Rp, v3(C.r[k][0], C.r[k][1], C.r[k][2]));
         float sn, cs;
-        sincosf(st.q[k], &sn, &cs);
+        grx_sincos(st.q[k], sn, cs);
         R3 R = joint_rot_k(Rp, cs, sn, kAxis[k]);
         V3 a = axis_k(R, kAxis[k]);
         V3 s = cross(rho, a);
@@ -416,9 +468,9 @@ GRX_DEV void reset_env(const KParams& P, const SideConst& C, int side, uint32_t 
 }
 
 // legged_robot.py:1235-1274 _get_heights, one point
-GRX_DEV float height_sample(const KParams& P, float qz, float qw, V3 pos, int k) {
+GRX_DEV float height_sample(const KParams& P, const KTables& T, float qz, float qw, V3 pos, int k) {
     float n = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
-    V3 p = quat_apply(v3(0.f, 0.f, qz / n), qw / n, v3(P.height_points[k][0], P.height_points[k][1], 0.f));
+    V3 p = quat_apply(v3(0.f, 0.f, qz / n), qw / n, v3(T.height_points[k][0], T.height_points[k][1], 0.f));
     float px = (p.x + pos.x + P.border_size) / P.horizontal_scale;
     float py = (p.y + pos.y + P.border_size) / P.horizontal_scale;
     int ix = min(max((int)px, 0), P.hf_rows - 2), iy = min(max((int)py, 0), P.hf_cols - 2);
@@ -439,17 +491,16 @@ GRX_DEV float sum_abs_mask(const float a[LEG], uint32_t mask) {
 
 // ------------------------------------------------------------------------------------------
 template <bool HF>
-__global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict__ Pp, const float* __restrict__ actions_in,
+__global__ __launch_bounds__(64) void grx_step_kernel(const KParams P, const float* __restrict__ actions_in,
                                                       float delay, long long common_step, const float* __restrict__ noise_in) {
-    const KParams& P = *Pp;
-    __shared__ SideConst sc[2];
+    __shared__ KTables s_tab;
     __shared__ __attribute__((aligned(16))) float s_obs[EPB * GRX_NUM_OBS];
     __shared__ __attribute__((aligned(16))) float s_pri[EPB * GRX_MAX_PRI];
     __shared__ float s_stat[NT + 1];
     {   // stage the per-side robot tables (joint tree, inertias, gains, spheres) into LDS
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.side);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(sc);
-        for (int i = threadIdx.x; i < (int)(2 * sizeof(SideConst) / 4); i += 64) dst[i] = src[i];
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab);
+        for (int i = threadIdx.x; i < (int)(sizeof(KTables) / 4); i += 64) dst[i] = src[i];
         if (threadIdx.x <= NT) s_stat[threadIdx.x] = 0.f;
     }
     __syncthreads();
@@ -458,13 +509,17 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
     const int e_raw = blockIdx.x * EPB + el;
     const bool act = e_raw < N;
     const int e = act ? e_raw : N - 1;
-    const SideConst& C = sc[side];
+    const SideConst& C = s_tab.side[side];
     const uint32_t genv = (uint32_t)(P.env_offset + e);
     const uint32_t step = (uint32_t)common_step;
     const int nh = P.nh, npri = P.num_pri_obs;
     const float dtp = P.sim_dt * (float)P.decimation;
     const int j0 = side * LEG;
 
+#ifdef GRX_PROFILE_SECTIONS
+    if (threadIdx.x == 0) for (int i = 16; i < 22; ++i) P.prof[(size_t)blockIdx.x * 32 + i] = 0;
+#endif
+    GRX_TICK(0);
     // ---- load state (SoA, coalesced)
     LaneState st;
     LaneConst LC;
@@ -495,6 +550,12 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
     LC.base_I.xx = P.base_I[e]; LC.base_I.xy = P.base_I[(size_t)N + e]; LC.base_I.xz = P.base_I[2 * (size_t)N + e];
     LC.base_I.yy = P.base_I[3 * (size_t)N + e]; LC.base_I.yz = P.base_I[4 * (size_t)N + e]; LC.base_I.zz = P.base_I[5 * (size_t)N + e];
     LC.mu = 0.5f * (P.terrain_friction + P.friction[e]);
+    LC.hmax = 0.0f;
+    if (HF) {
+        int ci = min(max((int)((st.pos.x + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_rows - 1);
+        int cj = min(max((int)((st.pos.y + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
+        LC.hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
+    }
     EnvAux ea;
     ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[(size_t)N + e]; ea.cmd[2] = P.commands[2 * (size_t)N + e];
     ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[(size_t)N + e]; ea.origin[2] = P.origins[2 * (size_t)N + e];
@@ -504,6 +565,7 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
     float bho_stale = P.base_heights_offset[e];
     long long ep_len = P.ep_len[e];
 
+    GRX_TICK(1);
     // ---- during_physics_step (legged_robot_fftai.py:51-88), fused decimation loop
     float avg_force = 0.f;
     V3 avg_speed = v3(0.f, 0.f, 0.f);
@@ -528,6 +590,7 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
         }
         avg_force += sqrtf(dot(so.foot_force, so.foot_force));
     }
+    GRX_TICK(2);
     fk = foot_kinematics(C, st);  // refresh_rigid_body_state_tensor after the last sub-step
     avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
     avg_force = avg_force / (float)P.decimation;  // legged_robot_fftai.py:86-88
@@ -535,7 +598,11 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
     const bool term_contact = __builtin_bit_cast(int, pair_swap(__builtin_bit_cast(float, (int)so.term))) | (int)so.term;
     const float pen_count = pair_sum(so.pen_count);
 
+    GRX_TICK(3);
     // ---- post_physics_step (legged_robot.py:269-305)
+    float es_raw[NT];   // running episode sums: loads issued here so their HBM latency overlaps the state update
+#pragma unroll
+    for (int t = 0; t < NT; ++t) es_raw[t] = (P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
     ep_len += 1;
     V3 qv = v3(st.qx, st.qy, st.qz);
     V3 blv = quat_rotate_inverse(qv, st.qw, st.vel);
@@ -547,10 +614,18 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
     float* prow = s_pri + el * GRX_MAX_PRI;
     float hsum = 0.f;
     if (HF && P.measure_heights) {
-        for (int k = side; k < nh; k += 2) {
-            float h = height_sample(P, st.qz, st.qw, st.pos, k);
-            prow[GRX_NUM_OBS + 8 + k] = h;
-            hsum += h;
+        for (int k0 = side; k0 < nh; k0 += 16) {
+            float hb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {   // independent gathers: all 24 loads of the batch are in flight together
+                int k = k0 + 2 * j;
+                hb[j] = height_sample(P, s_tab, st.qz, st.qw, st.pos, min(k, nh - 1));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int k = k0 + 2 * j;
+                if (k < nh) { prow[GRX_NUM_OBS + 8 + k] = hb[j]; hsum += hb[j]; }
+            }
         }
         hsum = pair_sum(hsum);
     } else {
@@ -560,6 +635,7 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
         st.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
         st.vel.y = urand(P, genv, step, GRX_RNG_PUSH, 1, -P.max_push_vel_xy, P.max_push_vel_xy);
     }
+    GRX_TICK(4);
     // feet timers (legged_robot_fftai.py:108-133) -- this lane's foot
     const bool contact = so.foot_force.z > 1.0f;
     const bool contact_filt = contact || contact_last;
@@ -573,6 +649,7 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
     const bool time_out = (float)ep_len > P.max_episode_length;
     reset = reset || time_out;
 
+    GRX_TICK(5);
     // ---- compute_reward (legged_robot.py:355-375): per-lane partial sums, pair-combined
     float r[NT];
     {
@@ -688,23 +765,38 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
     }
     // episode sums; reset envs contribute to the block's episode statistics (legged_robot.py:420-424)
     const unsigned long long reset_mask = __ballot(reset && writer);
+    float es_all[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (P.reward_scale_dt[t] == 0.f) continue;  // uniform
-        float es = P.episode_sums[(size_t)t * N + e] + r[t];
-        if (reset_mask) {  // wave-uniform: reduce the finished episodes' sums over the wave
-            float contrib = (reset && writer) ? es : 0.f;
+    for (int t = 0; t < NT; ++t) es_all[t] = es_raw[t] + r[t];
+    if (reset_mask) {
+        // finished episodes: a wave holds 0-2 of them per step, so walk the set bits (uniform loop) and pull the
+        // lane's sums through v_readlane instead of 36 six-step shuffle reductions (216 ds_bpermute + waits, measured)
+        float acc[NT];
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off);
-            if (lane == 0) s_stat[t] = contrib;
+        for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+        unsigned long long m = reset_mask;
+        while (m) {
+            const int L = __ffsll((long long)m) - 1;
+            m &= m - 1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] += __shfl(es_all[t], L);
         }
-        if (writer) {
-            P.episode_sums[(size_t)t * N + e] = reset ? 0.f : es;
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) s_stat[t] = acc[t];
+        }
+    }
+    if (writer) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (P.reward_scale_dt[t] == 0.f) continue;  // uniform
+            P.episode_sums[(size_t)t * N + e] = reset ? 0.f : es_all[t];
             if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
         }
     }
     if (lane == 0) s_stat[NT] = (float)__popcll(reset_mask);
 
+    GRX_TICK(6);
     // ---- reset_idx (masked, in-kernel)
     if (reset) {
         reset_env(P, C, side, genv, step, true, st, ea);
@@ -716,6 +808,7 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
     }
     const bool feet_contact_obs = reset ? false : contact;  // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
 
+    GRX_TICK(7);
     // ---- compute_observations (legged_robot.py:442-452, legged_robot_fftai.py:148-167, gr1t1.py:281-336)
     float bho;
     {
@@ -732,22 +825,57 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
     }
     float* orow = s_obs + el * GRX_NUM_OBS;
     const float clipo = P.clip_observations;
-    auto put = [&](int idx, float val, float nscale) {
+    // observation noise.  Streams are keyed so that every lane indexes its blocks statically: base terms
+    // (ang vel, gravity; obs 3..8) = stream NOISE item i-3; dof terms = stream NOISE_DOF_L/R item group*5 + k
+    // (group 0 pos, 1 vel, 2 action).  The six 10-round chains are advanced together, round by round, so the
+    // 64-bit multiplies of independent chains interleave (a serial chain per value cost ~18k cycles/step, measured).
+    constexpr int NZB = 6;   // slots 0..3: dof stream blocks 0..3; slots 4,5: base stream blocks 0,1 (left lane)
+    U4 nzb[NZB];
+    if (P.add_noise && !noise_in) {
+        uint32_t c0[NZB], c1[NZB], c2[NZB], c3[NZB];
+#pragma unroll
+        for (int b = 0; b < NZB; ++b) {
+            c0[b] = genv; c1[b] = step;
+            c2[b] = b < 4 ? (uint32_t)(side == 0 ? GRX_RNG_NOISE_DOF_L : GRX_RNG_NOISE_DOF_R) : (uint32_t)GRX_RNG_NOISE;
+            c3[b] = b < 4 ? b : b - 4;
+        }
+        uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
+#pragma unroll
+        for (int rnd = 0; rnd < 10; ++rnd) {
+#pragma unroll
+            for (int b = 0; b < NZB; ++b) {
+                uint64_t p0 = (uint64_t)0xD2511F53u * c0[b], p1 = (uint64_t)0xCD9E8D57u * c2[b];
+                uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1[b] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3[b] ^ k1;
+                c1[b] = (uint32_t)p1; c3[b] = (uint32_t)p0; c0[b] = n0; c2[b] = n2;
+            }
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+#pragma unroll
+        for (int b = 0; b < NZB; ++b) { nzb[b].x = c0[b]; nzb[b].y = c1[b]; nzb[b].z = c2[b]; nzb[b].w = c3[b]; }
+    }
+    // item: index within the lane's stream (compile-time); slot0: first block slot of that stream
+    auto put = [&](int idx, float val, float nscale, int item, int slot0) {
         float pv = fminf(fmaxf(val, -clipo), clipo);
         prow[idx] = pv;  // pri_obs copies obs BEFORE noise
         float ov = val;
         if (P.add_noise && nscale != 0.f) {
-            float u = noise_in ? noise_in[(size_t)e * GRX_NUM_OBS + idx] : grx_rand(P.seed, genv, step, GRX_RNG_NOISE, (uint32_t)idx);
+            float u;
+            if (noise_in) u = noise_in[(size_t)e * GRX_NUM_OBS + idx];
+            else {
+                const U4 o = nzb[slot0 + (item >> 2)];
+                const int wsel = item & 3;
+                u = grx_u01(wsel == 0 ? o.x : (wsel == 1 ? o.y : (wsel == 2 ? o.z : o.w)));
+            }
             ov += (2.f * u - 1.f) * nscale;
         }
         orow[idx] = fminf(fmaxf(ov, -clipo), clipo);
     };
     if (side == 0) {
-        put(0, ea.cmd[0], 0.f); put(1, ea.cmd[1], 0.f); put(2, ea.cmd[2], 0.f);
+        put(0, ea.cmd[0], 0.f, 0, 4); put(1, ea.cmd[1], 0.f, 0, 4); put(2, ea.cmd[2], 0.f, 0, 4);
         const float na = P.noise_ang_vel * P.noise_level * P.obs_scale_ang_vel;
-        put(3, bav.x * P.obs_scale_ang_vel, na); put(4, bav.y * P.obs_scale_ang_vel, na); put(5, bav.z * P.obs_scale_ang_vel, na);
+        put(3, bav.x * P.obs_scale_ang_vel, na, 0, 4); put(4, bav.y * P.obs_scale_ang_vel, na, 1, 4); put(5, bav.z * P.obs_scale_ang_vel, na, 2, 4);
         const float ng = P.noise_gravity * P.noise_level * P.obs_scale_gravity;
-        put(6, pg.x * P.obs_scale_gravity, ng); put(7, pg.y * P.obs_scale_gravity, ng); put(8, pg.z * P.obs_scale_gravity, ng);
+        put(6, pg.x * P.obs_scale_gravity, ng, 3, 4); put(7, pg.y * P.obs_scale_gravity, ng, 4, 4); put(8, pg.z * P.obs_scale_gravity, ng, 5, 4);
         prow[GRX_NUM_OBS + 0] = fminf(fmaxf(blv.x * P.obs_scale_lin_vel, -clipo), clipo);
         prow[GRX_NUM_OBS + 1] = fminf(fmaxf(blv.y * P.obs_scale_lin_vel, -clipo), clipo);
         prow[GRX_NUM_OBS + 2] = fminf(fmaxf(blv.z * P.obs_scale_lin_vel, -clipo), clipo);
@@ -759,14 +887,15 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
         const float nac = P.noise_action * P.noise_level * P.obs_scale_action;
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {
-            put(9 + j0 + k, (st.q[k] - C.q0[k]) * P.obs_scale_dof_pos, np_);
-            put(9 + GRX_ND + j0 + k, st.qd[k] * P.obs_scale_dof_vel, nv);
-            put(9 + 2 * GRX_ND + j0 + k, a_cur[k] * P.obs_scale_action, nac);
+            put(9 + j0 + k, (st.q[k] - C.q0[k]) * P.obs_scale_dof_pos, np_, k, 0);
+            put(9 + GRX_ND + j0 + k, st.qd[k] * P.obs_scale_dof_vel, nv, 5 + k, 0);
+            put(9 + 2 * GRX_ND + j0 + k, a_cur[k] * P.obs_scale_action, nac, 10 + k, 0);
         }
         prow[GRX_NUM_OBS + 4 + side] = feet_contact_obs ? 1.f : 0.f;
         prow[GRX_NUM_OBS + 6 + side] = fminf(fmaxf(feet_height * P.obs_scale_height, -clipo), clipo);
     }
 
+    GRX_TICK(8);
     // ---- store state (SoA) -- history: last_actions = actions, last_dof_vel = dof_vel (legged_robot.py:299-300)
     if (act) {
 #pragma unroll
@@ -814,6 +943,7 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
         P.time_out[e] = time_out ? 1 : 0;
         P.term_contact[e] = term_contact ? 1 : 0;
     }
+    GRX_TICK(9);
     // ---- coalesced AoS output rows: the wave's 32 obs / pri_obs rows are contiguous in HBM
     __syncthreads();
     {
@@ -836,13 +966,13 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams* __restrict_
             for (int i = lane; i < nenv * npri; i += 64) gpri[i] = s_pri[(i / npri) * GRX_MAX_PRI + (i % npri)];
         if (lane <= NT) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + lane] = s_stat[lane];
     }
+    GRX_TICK(10);
 }
 
 // extras["episode"] (legged_robot.py:420-424): mean episode sums of the envs reset by this step;
 // kept from the previous resetting step when nobody reset (the reference only rewrites the dict
 // inside reset_idx, which returns early for an empty id list, legged_robot.py:387-388).
-__global__ __launch_bounds__(64) void grx_finalize_stats(const KParams* __restrict__ Pp, int nblocks) {
-    const KParams& P = *Pp;
+__global__ __launch_bounds__(64) void grx_finalize_stats(const KParams P, int nblocks) {
     const int t = blockIdx.x, lane = threadIdx.x;   // one wave per reward term: lanes stride over the step kernel's blocks
     float cnt = 0.f, s = 0.f;
     for (int b = lane; b < nblocks; b += 64) {
@@ -855,11 +985,10 @@ __global__ __launch_bounds__(64) void grx_finalize_stats(const KParams* __restri
 }
 
 // BaseTask.reset() first half (base_task.py:117-119): reset_idx(all envs), no step
-__global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __restrict__ Pp, uint32_t step) {
-    const KParams& P = *Pp;
+__global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams P, uint32_t step) {
     __shared__ SideConst sc[2];
     {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.side);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables->side);
         uint32_t* dst = reinterpret_cast<uint32_t*>(sc);
         for (int i = threadIdx.x; i < (int)(2 * sizeof(SideConst) / 4); i += 64) dst[i] = src[i];
     }
@@ -910,9 +1039,8 @@ __global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __rest
 }
 
 // set_dof_state_tensor / set_actor_root_state_tensor (legged_robot.py:737, 796): AoS rows -> SoA state
-__global__ void grx_set_state_kernel(const KParams* __restrict__ Pp, const float* __restrict__ root, const float* __restrict__ q,
+__global__ void grx_set_state_kernel(const KParams P, const float* __restrict__ root, const float* __restrict__ q,
                                      const float* __restrict__ qd) {
-    const KParams& P = *Pp;
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.N) return;
     size_t N = P.N;
@@ -928,21 +1056,21 @@ __global__ void grx_set_state_kernel(const KParams* __restrict__ Pp, const float
 }
 
 // host-callable launchers (grx_capi.cpp is compiled by hipcc too; kept separate for readability)
-extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, const float* actions, float delay, long long common_step,
+extern "C" void grx_launch_step(const KParams* hP, int N, int heightfield, const float* actions, float delay, long long common_step,
                                 const float* noise, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    if (heightfield) hipLaunchKernelGGL(grx_step_kernel<true>, dim3(nblocks), dim3(64), 0, stream, dP, actions, delay, common_step, noise);
-    else hipLaunchKernelGGL(grx_step_kernel<false>, dim3(nblocks), dim3(64), 0, stream, dP, actions, delay, common_step, noise);
+    if (heightfield) hipLaunchKernelGGL(grx_step_kernel<true>, dim3(nblocks), dim3(64), 0, stream, *hP, actions, delay, common_step, noise);
+    else hipLaunchKernelGGL(grx_step_kernel<false>, dim3(nblocks), dim3(64), 0, stream, *hP, actions, delay, common_step, noise);
 }
-extern "C" void grx_launch_finalize(const KParams* dP, int N, hipStream_t stream) {
+extern "C" void grx_launch_finalize(const KParams* hP, int N, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    hipLaunchKernelGGL(grx_finalize_stats, dim3(NT + 1), dim3(64), 0, stream, dP, nblocks);
+    hipLaunchKernelGGL(grx_finalize_stats, dim3(NT + 1), dim3(64), 0, stream, *hP, nblocks);
 }
-extern "C" void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream) {
+extern "C" void grx_launch_reset_all(const KParams* hP, int N, uint32_t step, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    hipLaunchKernelGGL(grx_reset_all_kernel, dim3(nblocks), dim3(64), 0, stream, dP, step);
+    hipLaunchKernelGGL(grx_reset_all_kernel, dim3(nblocks), dim3(64), 0, stream, *hP, step);
 }
-extern "C" void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, hipStream_t stream) {
-    hipLaunchKernelGGL(grx_set_state_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dP, root, q, qd);
+extern "C" void grx_launch_set_state(const KParams* hP, int N, const float* root, const float* q, const float* qd, hipStream_t stream) {
+    hipLaunchKernelGGL(grx_set_state_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, *hP, root, q, qd);
 }
 extern "C" int grx_envs_per_block(void) { return EPB; }

@@ -15,7 +15,9 @@ enum {
     GRX_RNG_NOISE = 6,
     GRX_RNG_CURRICULUM = 7,
     GRX_RNG_INIT_DR = 8,
-    GRX_RNG_INIT_LEVEL = 9
+    GRX_RNG_INIT_LEVEL = 9,
+    GRX_RNG_NOISE_DOF_L = 10,   // obs noise of the left-leg dof terms: item = group*5 + k (group 0 pos, 1 vel, 2 action)
+    GRX_RNG_NOISE_DOF_R = 11
 };
 
 struct U4 { uint32_t x, y, z, w; };
