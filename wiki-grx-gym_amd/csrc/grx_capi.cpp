@@ -127,18 +127,18 @@ int build_side_tables(const grx_config& c, KTables& P) {
         SideConst& S = P.side[side];
         for (int k = 0; k < GRX_LEG; ++k) {
             int b = 1 + side * GRX_LEG + k, j = b - 1;
-            for (int a = 0; a < 3; ++a) { S.r[k][a] = m.joint_pos[b][a]; S.com[k][a] = m.com[b][a]; }
-            for (int a = 0; a < 6; ++a) S.Ic[k][a] = m.inertia[b][a];
-            S.mass[k] = m.mass[b];
-            S.kp[k] = c.kp[j]; S.kd[k] = c.kd[j]; S.q0[k] = c.default_dof_pos[j];
-            S.effort[k] = m.dof_effort[j]; S.vlim[k] = m.dof_vel_limit[j];
-            S.qlo[k] = m.dof_lower[j]; S.qhi[k] = m.dof_upper[j];
-            S.Klim[k] = c.contact.k_limit * m.dof_effort[j];
-            S.Clim[k] = c.contact.c_limit * S.Klim[k];
-            S.amin[k] = c.clip_actions_min[j]; S.amax[k] = c.clip_actions_max[j];
+            for (int a = 0; a < 3; ++a) { S.body[k].r[a] = m.joint_pos[b][a]; S.body[k].com[a] = m.com[b][a]; }
+            for (int a = 0; a < 6; ++a) S.body[k].Ic[a] = m.inertia[b][a];
+            S.body[k].mass = m.mass[b];
+            S.body[k].kp = c.kp[j]; S.body[k].kd = c.kd[j]; S.body[k].q0 = c.default_dof_pos[j];
+            S.body[k].effort = m.dof_effort[j]; S.body[k].vlim = m.dof_vel_limit[j];
+            S.body[k].qlo = m.dof_lower[j]; S.body[k].qhi = m.dof_upper[j];
+            S.body[k].Klim = c.contact.k_limit * m.dof_effort[j];
+            S.body[k].Clim = c.contact.c_limit * S.body[k].Klim;
+            S.body[k].amin = c.clip_actions_min[j]; S.body[k].amax = c.clip_actions_max[j];
             float mid = (m.dof_lower[j] + m.dof_upper[j]) / 2, rng = m.dof_upper[j] - m.dof_lower[j];
-            S.slo[k] = mid - 0.5f * rng * c.soft_dof_pos_limit;
-            S.shi[k] = mid + 0.5f * rng * c.soft_dof_pos_limit;
+            S.body[k].slo = mid - 0.5f * rng * c.soft_dof_pos_limit;
+            S.body[k].shi = mid + 0.5f * rng * c.soft_dof_pos_limit;
         }
         for (int a = 0; a < 3; ++a) S.foot_pos[a] = m.foot_pos[side][a];
     }
@@ -291,6 +291,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     memcpy(s->tab.height_points, c.height_points, sizeof s->tab.height_points);
     P.hf_rows = c.hf_rows; P.hf_cols = c.hf_cols;
     P.horizontal_scale = c.horizontal_scale; P.vertical_scale = c.vertical_scale; P.border_size = c.border_size;
+    P.inv_hscale = 1.0f / c.horizontal_scale;
     P.curriculum = c.curriculum; P.num_terrain_rows = c.num_terrain_rows; P.num_terrain_cols = c.num_terrain_cols;
     P.terrain_length = c.terrain_length;
     memcpy(P.torso_rot, m.torso_rot, sizeof P.torso_rot);

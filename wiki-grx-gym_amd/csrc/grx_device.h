@@ -19,16 +19,20 @@ struct SphC {
     float dmax;          // cap of the normal damping coefficient (grx_model.sph_damp_max)
 };
 
+// Constants of one chain body + its joint, packed so that a body's dynamics constants are four adjacent
+// 16-byte LDS words (ds_read_b128: one exposed LDS latency per body instead of ~13 narrow reads).
+struct alignas(16) BodyC {
+    float r[3]; float mass;        // joint origin in the parent body frame | mass
+    float com[3]; float Ic[6];     // centre of mass | inertia about COM: xx xy xz yy yz zz
+    float kp, kd, q0;              // PD gains, default angle
+    float effort, vlim, qlo, qhi;  // URDF limits
+    float Klim, Clim, amin, amax;  // joint-limit spring/damper | clip_actions
+    float slo, shi, pad0, pad1;    // soft dof position limits (legged_robot.py:606-610)
+};
+
 // Per-side (left leg / right leg lane) robot constants; staged into LDS by every block.
-struct SideConst {
-    float r[GRX_LEG][3];     // joint origin in the parent body frame
-    float com[GRX_LEG][3];
-    float Ic[GRX_LEG][6];    // inertia about COM: xx xy xz yy yz zz
-    float mass[GRX_LEG];
-    float kp[GRX_LEG], kd[GRX_LEG], q0[GRX_LEG], effort[GRX_LEG], vlim[GRX_LEG];
-    float qlo[GRX_LEG], qhi[GRX_LEG], Klim[GRX_LEG], Clim[GRX_LEG];
-    float amin[GRX_LEG], amax[GRX_LEG];  // clip_actions
-    float slo[GRX_LEG], shi[GRX_LEG];    // soft dof position limits (legged_robot.py:606-610)
+struct alignas(16) SideConst {
+    BodyC body[GRX_LEG];
     float foot_pos[3];
     SphC sph[GRX_MAXSPH_SIDE];
 };
@@ -67,7 +71,7 @@ struct KParams {
     int32_t terrain_type, measure_heights, nh;
     const int16_t* hf; int32_t hf_rows, hf_cols;
     const float* coarse_max; int32_t coarse_rows, coarse_cols;   // dilated block-max of the raster [m]: sphere culling
-    float horizontal_scale, vertical_scale, border_size;
+    float horizontal_scale, vertical_scale, border_size, inv_hscale;
     int32_t curriculum, num_terrain_rows, num_terrain_cols;
     const float* terrain_origins; float terrain_length;
     float torso_rot[9], forehead_rot[9];

@@ -64,8 +64,8 @@ GRX_DEV void grx_sincos(float x, float& s, float& c) {
 template <bool HF>
 GRX_DEV float terrain_height(const KParams& P, float x, float y) {
     if (!HF) return 0.0f;
-    float fx = (x + P.border_size) / P.horizontal_scale;
-    float fy = (y + P.border_size) / P.horizontal_scale;
+    float fx = (x + P.border_size) * P.inv_hscale;
+    float fy = (y + P.border_size) * P.inv_hscale;
     fx = fminf(fmaxf(fx, 0.0f), (float)(P.hf_rows - 1));
     fy = fminf(fmaxf(fy, 0.0f), (float)(P.hf_cols - 1));
     int ix = min((int)fx, P.hf_rows - 2), iy = min((int)fy, P.hf_cols - 2);
@@ -135,9 +135,9 @@ GRX_DEV V3 sphere_contact(const KParams& P, const SphC& S, const R3& R, V3 rho, 
                 if (!(st.anchor_on & (1u << (SLOT < 0 ? 0 : SLOT)))) { axx = wx; ayy = wy; }
                 float ftx = -P.kt * (wx - axx) - P.ct * u.x;
                 float fty = -P.kt * (wy - ayy) - P.ct * u.y;
-                float ft = sqrtf(ftx * ftx + fty * fty);
+                float ft = grx_sqrt(ftx * ftx + fty * fty);
                 if (ft > fmax) {  // slip: clamp to the cone, drag the anchor along
-                    float sc = fmax / ft;
+                    float sc = fmax * grx_rcp(ft);
                     ftx *= sc; fty *= sc;
                     axx = wx + ftx * P.inv_kt;
                     ayy = wy + fty * P.inv_kt;
@@ -145,9 +145,9 @@ GRX_DEV V3 sphere_contact(const KParams& P, const SphC& S, const R3& R, V3 rho, 
                 st.ax[SLOT < 0 ? 0 : SLOT] = axx; st.ay[SLOT < 0 ? 0 : SLOT] = ayy;
                 F.x = ftx; F.y = fty;
             } else {
-                float sp = sqrtf(u.x * u.x + u.y * u.y);
+                float sp = grx_sqrt(u.x * u.x + u.y * u.y);
                 float ft = fminf(P.cv * sp, fmax);
-                if (sp > 1e-9f) { float k = -ft / sp; F.x = k * u.x; F.y = k * u.y; }
+                if (sp > 1e-9f) { float k = -ft * grx_rcp(sp); F.x = k * u.x; F.y = k * u.y; }
             }
         }
     }
@@ -196,16 +196,16 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     out.pen_count = 0.f;
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
-        V3 rho = rho_p + rot(Rp, v3(C.r[k][0], C.r[k][1], C.r[k][2]));
+        V3 rho = rho_p + rot(Rp, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
         float sn, cs;
         grx_sincos(st.q[k], sn, cs);
         R3 R = joint_rot_k(Rp, cs, sn, kAxis[k]);
         V3 a = axis_k(R, kAxis[k]);
         V3 s = cross(rho, a);
         V3 wk = fma3(a, st.qd[k], w), vk = fma3(s, st.qd[k], v);
-        float m = C.mass[k];
-        V3 kap = rho + rot(R, v3(C.com[k][0], C.com[k][1], C.com[k][2]));
-        S3 Ic = {C.Ic[k][0], C.Ic[k][1], C.Ic[k][2], C.Ic[k][3], C.Ic[k][4], C.Ic[k][5]};
+        float m = C.body[k].mass;
+        V3 kap = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+        S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
         S3 A = rot_sym(R, Ic);
         float kk = dot(kap, kap);
         A.xx += m * (kk - kap.x * kap.x); A.xy -= m * kap.x * kap.y; A.xz -= m * kap.x * kap.z;
@@ -271,7 +271,7 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     // ---- pass 2: articulated inertias (leaf -> root).  w, v currently = velocity of body LEG-1.
     S3 A = IAk[LEG - 1];
     V3 h4 = Ih[LEG - 1];
-    float m4 = C.mass[LEG - 1];
+    float m4 = C.body[LEG - 1].mass;
     M3 B = {0.f, -h4.z, h4.y, h4.z, 0.f, -h4.x, -h4.y, h4.x, 0.f};
     S3 D = {m4, 0.f, 0.f, m4, 0.f, m4};
     V3 pa = pA[LEG - 1], pl = pL[LEG - 1];
@@ -287,11 +287,11 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
         V3 ua = mul(A, a) + mul(B, s);
         V3 ul = mulT(B, a) + mul(D, s);
         float d = dot(a, ua) + dot(s, ul);
-        float di = 1.0f / d;
+        float di = grx_rcp(d);
         // joint-limit spring/damper (oracle substep()): added to the motor torque
         float t = tau_m[k];
-        if (st.q[k] < C.qlo[k]) t += C.Klim[k] * (C.qlo[k] - st.q[k]) - C.Clim[k] * qdk;
-        else if (st.q[k] > C.qhi[k]) t += C.Klim[k] * (C.qhi[k] - st.q[k]) - C.Clim[k] * qdk;
+        if (st.q[k] < C.body[k].qlo) t += C.body[k].Klim * (C.body[k].qlo - st.q[k]) - C.body[k].Clim * qdk;
+        else if (st.q[k] > C.body[k].qhi) t += C.body[k].Klim * (C.body[k].qhi - st.q[k]) - C.body[k].Clim * qdk;
         float u = t - (dot(a, pa) + dot(s, pl));
         syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
         float ud = u * di;
@@ -301,7 +301,7 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
         pa = npa; pl = npl;
         if (k > 0) {  // add the parent's rigid inertia: [A B; B^T D] += rigid(k-1)
             V3 hp = Ih[k - 1];
-            float mp = C.mass[k - 1];
+            float mp = C.body[k - 1].mass;
             A = A + IAk[k - 1];
             B.a01 -= hp.z; B.a02 += hp.y; B.a10 += hp.z; B.a12 -= hp.x; B.a20 -= hp.y; B.a21 += hp.x;
             D.xx += mp; D.yy += mp; D.zz += mp;
@@ -360,7 +360,7 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
         float vq = fmaf(qdd[k], dt, st.qd[k]);
-        vq = fminf(fmaxf(vq, -C.vlim[k]), C.vlim[k]);
+        vq = fminf(fmaxf(vq, -C.body[k].vlim), C.body[k].vlim);
         st.qd[k] = vq;
         st.q[k] = fmaf(vq, dt, st.q[k]);
     }
@@ -371,7 +371,7 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     float ny = y - hx * z + hy * ww + hz * x;
     float nz = z + hx * y - hy * x + hz * ww;
     float nw = ww - hx * x - hy * y - hz * z;
-    float n = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz + nw * nw);
+    float n = grx_rsq(nx * nx + ny * ny + nz * nz + nw * nw);
     st.qx = nx * n; st.qy = ny * n; st.qz = nz * n; st.qw = nw * n;
     GRX_TICK2(21);
 }
@@ -382,7 +382,7 @@ GRX_DEV FootKin foot_kinematics(const SideConst& C, const LaneState& st) {
     V3 rho = v3(0.f, 0.f, 0.f), w = st.ang, v = st.vel;
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
-        rho = rho + rot(Rp, v3(C.r[k][0], C.r[k][1], C.r[k][2]));
+        rho = rho + rot(Rp, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
         float sn, cs;
         grx_sincos(st.q[k], sn, cs);
         R3 R = joint_rot_k(Rp, cs, sn, kAxis[k]);
@@ -442,7 +442,7 @@ GRX_DEV void reset_env(const KParams& P, const SideConst& C, int side, uint32_t 
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {  // _reset_dofs
         float f = P.randomize_init_dof_pos ? urand(P, genv, step, GRX_RNG_RESET_DOF, (uint32_t)(side * LEG + k), 0.5f, 1.5f) : 1.0f;
-        st.q[k] = f * C.q0[k];
+        st.q[k] = f * C.body[k].q0;
         st.qd[k] = 0.0f;
     }
     st.pos = v3(P.init_pos[0] + ea.origin[0], P.init_pos[1] + ea.origin[1], P.init_pos[2] + ea.origin[2]);
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams P, const flo
         a_last[k] = P.last_actions[o]; qd_last[k] = P.last_dof_vel[o];
         LC.strength[k] = P.motor_strength[o];
         float a = actions_in ? actions_in[(size_t)e * GRX_ND + j0 + k] : 0.0f;
-        a_cur[k] = fminf(fmaxf(a, C.amin[k]), C.amax[k]);  // clip_actions legged_robot_fftai.py:171-177
+        a_cur[k] = fminf(fmaxf(a, C.body[k].amin), C.body[k].amax);  // clip_actions legged_robot_fftai.py:171-177
     }
     st.pos = v3(P.root[0 * (size_t)N + e], P.root[1 * (size_t)N + e], P.root[2 * (size_t)N + e]);
     st.qx = P.root[3 * (size_t)N + e]; st.qy = P.root[4 * (size_t)N + e]; st.qz = P.root[5 * (size_t)N + e]; st.qw = P.root[6 * (size_t)N + e];
@@ -580,15 +580,15 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams P, const flo
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {  // _compute_torques legged_robot.py:679-715
             float a = use_last ? a_last[k] : a_cur[k];
-            float t = C.kp[k] * (a * P.action_scale + C.q0[k] - st.q[k]) - C.kd[k] * st.qd[k];
+            float t = C.body[k].kp * (a * P.action_scale + C.body[k].q0 - st.q[k]) - C.body[k].kd * st.qd[k];
             t *= LC.strength[k];
-            torque[k] = fminf(fmaxf(t, -C.effort[k]), C.effort[k]);
+            torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
         substep<HF>(P, C, LC, st, torque, so, fk);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
             avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
         }
-        avg_force += sqrtf(dot(so.foot_force, so.foot_force));
+        avg_force += grx_sqrt(dot(so.foot_force, so.foot_force));
     }
     GRX_TICK(2);
     fk = foot_kinematics(C, st);  // refresh_rigid_body_state_tensor after the last sub-step
@@ -666,18 +666,18 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams P, const flo
             sacc += fabsf((st.qd[k] - qd_last[k]) / dtp);
             stor += fabsf(torque[k]);
             svel += fabsf(st.qd[k]);
-            float po = fabsf(st.q[k] - C.q0[k]);
+            float po = fabsf(st.q[k] - C.body[k].q0);
             spose += po;
             if (hipyaw & (1u << k)) shy += po;
             float a = a_cur[k] * as, oa = 0.f, op = 0.f;
-            if (a - C.slo[k] < 0.f) oa += -(a - C.slo[k]);
-            if (a - C.shi[k] > 0.f) oa += (a - C.shi[k]);
+            if (a - C.body[k].slo < 0.f) oa += -(a - C.body[k].slo);
+            if (a - C.body[k].shi > 0.f) oa += (a - C.body[k].shi);
             sla += oa * oa;
-            if (st.q[k] - C.slo[k] < 0.f) op += -(st.q[k] - C.slo[k]);
-            if (st.q[k] - C.shi[k] > 0.f) op += (st.q[k] - C.shi[k]);
+            if (st.q[k] - C.body[k].slo < 0.f) op += -(st.q[k] - C.body[k].slo);
+            if (st.q[k] - C.body[k].shi > 0.f) op += (st.q[k] - C.body[k].shi);
             slp += fabsf(op);
-            slv += fminf(fmaxf(fabsf(st.qd[k]) - C.vlim[k] * P.soft_dof_vel_limit, 0.f), 1.f);
-            slt += fmaxf(fabsf(torque[k]) - C.effort[k] * P.soft_torque_limit, 0.f);
+            slv += fminf(fmaxf(fabsf(st.qd[k]) - C.body[k].vlim * P.soft_dof_vel_limit, 0.f), 1.f);
+            slt += fmaxf(fabsf(torque[k]) - C.body[k].effort * P.soft_torque_limit, 0.f);
         }
         float tor_hr = sum_abs_mask(torque, hiproll), vel_kn = sum_abs_mask(st.qd, knee);
         float h = feet_height;
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(64) void grx_step_kernel(const KParams P, const flo
         const float nac = P.noise_action * P.noise_level * P.obs_scale_action;
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {
-            put(9 + j0 + k, (st.q[k] - C.q0[k]) * P.obs_scale_dof_pos, np_, k, 0);
+            put(9 + j0 + k, (st.q[k] - C.body[k].q0) * P.obs_scale_dof_pos, np_, k, 0);
             put(9 + GRX_ND + j0 + k, st.qd[k] * P.obs_scale_dof_vel, nv, 5 + k, 0);
             put(9 + 2 * GRX_ND + j0 + k, a_cur[k] * P.obs_scale_action, nac, 10 + k, 0);
         }

@@ -5,6 +5,11 @@
 
 #define GRX_DEV __device__ __forceinline__
 
+// hardware reciprocal / sqrt (1 ulp): no denormal pre-scaling sequences in the issue-bound inner loop
+GRX_DEV float grx_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+GRX_DEV float grx_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+GRX_DEV float grx_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
 struct V3 { float x, y, z; };
 struct S3 { float xx, xy, xz, yy, yz, zz; };          // symmetric 3x3
 struct M3 { float a00, a01, a02, a10, a11, a12, a20, a21, a22; };  // full 3x3, row-major
@@ -65,7 +70,7 @@ GRX_DEV S3 inv(const S3& A) {
     float c01 = fmaf(A.xz, A.yz, -A.xy * A.zz);
     float c02 = fmaf(A.xy, A.yz, -A.xz * A.yy);
     float det = fmaf(A.xx, c00, fmaf(A.xy, c01, A.xz * c02));
-    float id = 1.0f / det;
+    float id = grx_rcp(det);
     S3 r;
     r.xx = c00 * id; r.xy = c01 * id; r.xz = c02 * id;
     r.yy = fmaf(A.xx, A.zz, -A.xz * A.xz) * id;
