@@ -41,6 +41,9 @@ def test_vec_env_surface(oracle_backend):
     assert obs.shape == (64, 39) and pri.shape == (64, 168) and obs is env.get_observations() and pri is env.get_privileged_observations()
     assert env.reset_buf.dtype == torch.bool and env.episode_length_buf.dtype == torch.int64
     o2, p2, rew, dones, extras = env.step(torch.zeros(64, 10))
+    # fresh tensors every step (rsl_rl keeps the observation it acted on across env.step, ppo.py:160-161,194)
+    kept = obs.clone()
+    assert o2 is not obs and o2.data_ptr() != obs.data_ptr() and torch.equal(obs, kept) and env.get_observations() is o2
     assert rew.shape == (64,) and dones.dtype == torch.bool and extras["time_outs"].dtype == torch.bool
     assert set(extras["episode"]) == {"rew_" + n for n in env.reward_names}
     assert all(v.ndim == 0 for v in extras["episode"].values())

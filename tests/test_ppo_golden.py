@@ -13,7 +13,7 @@ from wiki_grx_gym_amd.rl import PPO, ActorCriticMLP, OnPolicyRunner
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _build(d):
+def _build(d, device="cpu"):
     N, T, no, npri, na = 16, 8, 39, 168, 10
     ac = ActorCriticMLP(no, npri, na, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu", init_noise_std=0.2)
     with torch.no_grad():
@@ -21,17 +21,27 @@ def _build(d):
             v.copy_(torch.tensor(d["w0_" + k]))
     alg = PPO(actor_critic=ac, num_learning_epochs=2, num_mini_batches=4, clip_param=0.2, gamma=0.99, lam=0.95,
               value_loss_coef=1.0, entropy_coef=0.01, learning_rate=1e-4, learning_rate_min=1e-5, learning_rate_max=1e-3,
-              max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.03, device="cpu")
+              max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.03, device=device)
     alg.init_storage(N, T)
     return ac, alg, N, T
 
 
+@pytest.mark.gpu
+def test_device_update_path_matches_reference():
+    """The sync-free HIP update path (device-side adaptive LR, fused Adam, found_inf NaN-skip)."""
+    _check_against_reference("cuda")
+
+
 def test_rollout_returns_and_update_match_reference():
+    _check_against_reference("cpu")
+
+
+def _check_against_reference(device):
     d = np.load(os.path.join(G, "ppo.npz"))
-    ac, alg, N, T = _build(d)
+    ac, alg, N, T = _build(d, device)
     assert sorted(ac.state_dict()) == sorted(k[3:] for k in d.files if k.startswith("w0_"))   # checkpoint key layout
-    obs, pri, rew = torch.tensor(d["obs"]), torch.tensor(d["pri"]), torch.tensor(d["rew"])
-    done, tos, eps = torch.tensor(d["done"]), torch.tensor(d["time_outs"]), torch.tensor(d["eps"])
+    dv = lambda k: torch.tensor(d[k]).to(device)
+    obs, pri, rew, done, tos, eps = dv("obs"), dv("pri"), dv("rew"), dv("done"), dv("time_outs"), dv("eps")
     with torch.inference_mode():
         for t in range(T):
             orig = torch.distributions.Normal.sample
@@ -40,22 +50,27 @@ def test_rollout_returns_and_update_match_reference():
                 a = alg.act(obs[t], pri[t])
             finally:
                 torch.distributions.Normal.sample = orig
-            np.testing.assert_allclose(a.numpy(), d["actions"][t], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(a.cpu().numpy(), d["actions"][t], rtol=1e-5, atol=1e-6)
             alg.process_env_step(rew[t].clone(), done[t], {"time_outs": tos[t]})
         alg.compute_returns(pri[T])
     st = alg.storage
     for name, got in (("values", st.values), ("rewards", st.rewards), ("returns", st.returns), ("advantages", st.advantages),
                       ("log_prob", st.actions_log_prob), ("mu", st.mu), ("sigma", st.sigma)):
-        np.testing.assert_allclose(got.numpy(), d[name], rtol=2e-5, atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(got.cpu().numpy(), d[name], rtol=2e-5, atol=2e-6, err_msg=name)
     torch.manual_seed(123)
     np.testing.assert_array_equal(torch.randperm(4 * (N * T // 4)).numpy(), d["perm"])
-    torch.manual_seed(123)
-    vl, sl = alg.update()
+    perm = torch.tensor(d["perm"]).to(device)
+    orig_rp = torch.randperm
+    torch.randperm = lambda *a, **k: perm.clone()      # same minibatch stream on any device
+    try:
+        vl, sl = alg.update()
+    finally:
+        torch.randperm = orig_rp
     assert vl == pytest.approx(float(d["value_loss"]), rel=1e-4)
     assert sl == pytest.approx(float(d["surrogate_loss"]), rel=1e-4, abs=1e-6)
     assert alg.learning_rate == pytest.approx(float(d["lr_after"]), rel=1e-9)
     for k, v in ac.state_dict().items():
-        np.testing.assert_allclose(v.detach().numpy(), d["w1_" + k], rtol=1e-4, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(v.detach().cpu().numpy(), d["w1_" + k], rtol=2e-4 if device == "cuda" else 1e-4, atol=2e-6, err_msg=k)
 
 
 def test_checkpoint_roundtrip_and_std_quirk(tmp_path):

@@ -103,8 +103,13 @@ class GRxEnv:
         self._term_index = {n: _capi.REWARD_TERMS.index(n) for n in self.reward_scales}
         # buffers (base_task.py:69-76, legged_robot.py:106-203): zero-copy views
         t = self._sim.tensor
-        self.obs_buf = t("OBS")
-        self.pri_obs_buf = t("PRI_OBS") if self.num_pri_obs is not None else None
+        # obs_buf / pri_obs_buf are REBOUND to fresh tensors every step, as in the reference (torch.cat / torch.clip
+        # create new tensors, gr1t1.py:282, legged_robot.py:241): rsl_rl keeps a reference to the observation it
+        # acted on until after env.step() (ppo.py:160-161, 194), so handing out the live library view would alias.
+        self._obs_view = t("OBS")
+        self._pri_view = t("PRI_OBS") if self.num_pri_obs is not None else None
+        self.obs_buf = self._obs_view.clone()
+        self.pri_obs_buf = self._pri_view.clone() if self._pri_view is not None else None
         self.rew_buf = t("REW")
         self._reset_u8 = t("RESET")
         self._timeout_u8 = t("TIME_OUT")
@@ -170,6 +175,9 @@ class GRxEnv:
             delay = max(0.0, float(self._delay_rng.normal(loc=5, scale=2, size=1)[0]))   # FF:53-54
         self.common_step_counter += 1
         self._sim.step(a, delay, self.common_step_counter)
+        self.obs_buf = self._obs_view.clone()
+        if self._pri_view is not None:
+            self.pri_obs_buf = self._pri_view.clone()
         self._fill_extras()
         return self.obs_buf, self.pri_obs_buf, self.rew_buf, self.reset_buf, self.extras
 

@@ -33,7 +33,15 @@ class PPO:
         self.actor_critic = actor_critic.to(device)
         self.storage_class = storage_class
         self.storage, self.transition = None, None
-        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate, weight_decay=weight_decay)
+        # On a HIP device the whole update runs without host synchronisation: the adaptive learning rate lives in a
+        # device scalar consumed by the fused Adam kernel, the NaN-skip uses Adam's found_inf hook, and the loss
+        # statistics are read back once per update().  (The reference does three .item() per minibatch, ppo.py:264,308-309.)
+        self._device_lr = torch.device(device).type == "cuda"
+        if self._device_lr:
+            self._lr_t = torch.tensor(float(learning_rate), device=device)
+            self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=self._lr_t, weight_decay=weight_decay, fused=True)
+        else:
+            self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate, weight_decay=weight_decay)
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
         self.value_loss_coef, self.entropy_coef, self.gamma, self.lam = value_loss_coef, entropy_coef, gamma, lam
         self.max_grad_norm, self.use_clipped_value_loss = max_grad_norm, use_clipped_value_loss
@@ -105,7 +113,18 @@ class PPO:
             o += n
         return b[o]
 
+    def _device_lr_update(self, kl_mean):
+        """update_learning_rate() on the device (same branches as ppo.py:205-213)."""
+        lr = self._lr_t
+        down = torch.clamp(lr / 1.5, min=self.learning_rate_min)
+        up = torch.clamp(lr * 1.5, max=self.learning_rate_max)
+        new = torch.where(kl_mean > self.desired_kl * 2.0, down,
+                          torch.where((kl_mean < self.desired_kl / 2.0) & (kl_mean > 0.0), up, lr))
+        lr.copy_(new)
+
     def update(self):
+        if self._device_lr:
+            return self._update_device()
         mean_value_loss, mean_surrogate_loss = 0.0, 0.0
         ac, multi = self.actor_critic, _world() > 1
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
@@ -148,6 +167,58 @@ class PPO:
             mean_surrogate_loss += surrogate_loss.item()
         self.num_updates = self.num_learning_epochs * self.num_mini_batches
         return mean_value_loss / self.num_updates, mean_surrogate_loss / self.num_updates
+
+    def _update_device(self):
+        """Same arithmetic as update(), no host round-trips inside the minibatch loop."""
+        ac, multi = self.actor_critic, _world() > 1
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        sums = torch.zeros(3, device=self.device)        # value loss, surrogate loss, last KL
+        for (obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _, _) in \
+                self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            ac.act(obs)
+            logp = ac.get_actions_log_prob(actions)
+            value = ac.evaluate(cobs)
+            mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+            kl_mean = torch.zeros((), device=self.device)
+            if adaptive:
+                with torch.no_grad():
+                    kl_mean = torch.sum(torch.log(sigma / old_sigma + 1.e-5) + (old_sigma.square() + (old_mu - mu).square())
+                                        / (2.0 * sigma.square()) - 0.5, axis=-1).mean()
+            ratio = torch.exp(logp - torch.squeeze(old_logp))
+            adv = torch.squeeze(advantages)
+            surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+            if self.use_clipped_value_loss:
+                clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
+                value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
+            else:
+                value_loss = (returns - value).pow(2).mean()
+            loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
+            self.optimizer.zero_grad(set_to_none=False)
+            loss.backward()
+            if multi:
+                kl_mean = self._sync_gradients(kl_mean)
+            if adaptive:
+                self._device_lr_update(kl_mean)
+            with torch.no_grad():
+                bad = ~torch.isfinite(loss)
+                if multi:
+                    bad = bad | ~torch.isfinite(self._bucket[:-1]).all()
+                # NaN-skip (ppo.py:297-299) without a sync: the fused Adam kernel leaves parameters and moments
+                # untouched when found_inf is set (the GradScaler hook)
+                self.optimizer.found_inf = bad.float().reshape(1)
+                self.optimizer.grad_scale = None
+            nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm, foreach=True)
+            self.optimizer.step()
+            with torch.no_grad():
+                ok = (~bad).float()
+                sums[0] += value_loss.detach() * ok
+                sums[1] += surrogate_loss.detach() * ok
+                sums[2] = kl_mean
+        self.num_updates = self.num_learning_epochs * self.num_mini_batches
+        host = sums.tolist()                           # the only device->host transfer of the update
+        self.mean_kl = host[2]
+        self.learning_rate = float(self._lr_t.item())
+        return host[0] / self.num_updates, host[1] / self.num_updates
 
     def _apply_kl(self, kl_value):
         self.mean_kl = kl_value
