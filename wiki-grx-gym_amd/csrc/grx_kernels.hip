@@ -173,77 +173,83 @@ GRX_DEV bool group_within_reach(const SphC* S, const R3& R, V3 rho, V3 O, float 
     return __any(cand);
 }
 
+// parent rotation from the child rotation: inverse of joint_rot_k (R_parent = R_child * Rot_axis(-q))
+GRX_DEV R3 joint_unrot_k(const R3& R, float c, float s, int ax) {
+    R3 P;
+    if (ax == 0) { P.cx = R.cx; P.cy = fma3(R.cy, c, R.cz * (-s)); P.cz = fma3(R.cz, c, R.cy * s); }
+    else if (ax == 1) { P.cy = R.cy; P.cx = fma3(R.cx, c, R.cz * s); P.cz = fma3(R.cz, c, R.cx * (-s)); }
+    else { P.cz = R.cz; P.cx = fma3(R.cx, c, R.cy * (-s)); P.cy = fma3(R.cy, c, R.cx * s); }
+    return P;
+}
+
 // One physics sub-step (gym.simulate(dt), legged_robot_fftai.py:68) for this lane's half of the env.
-// tau: motor torques of this lane's 5 joints.  fk_only: just the kinematics pass (foot frames).
+// tau_m: motor torques of this lane's 5 joints.
+//
+// Register discipline (the kernel runs one wave per SIMD, so the 256-VGPR file is the scarce resource and a
+// register-starved schedule degenerates into a dependent chain at ~7 cycles/instruction, measured): the outward
+// pass keeps only sin/cos per joint and the contact wrenches; the inward pass walks the frames back by
+// UN-rotating (12 FMAs per joint) and builds each body's rigid inertia / bias force right where the
+// articulated recursion consumes it; the final outward pass recomputes the velocity-product terms from the
+// running parent velocity.
 template <bool HF>
 GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                      SubstepOut& out, FootKin& fk_before) {
     const float dt = P.sim_dt;
-    R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
-    V3 O = st.pos;
+    const R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
+    const V3 O = st.pos;
 #ifdef GRX_PROFILE_SECTIONS
     long long tprev = clock64();
 #endif
-    // ---- pass 1: kinematics, rigid inertias, bias forces, contacts (root -> leaf)
-    V3 Sa[LEG], Ss[LEG];       // joint motion subspace S = (a; rho x a)
-    S3 IAk[LEG]; V3 Ih[LEG];   // rigid inertia about O: A and h = m*kappa
-    V3 pA[LEG], pL[LEG];       // bias force
-    R3 Rp = R0;
-    V3 rho_p = v3(0.f, 0.f, 0.f);
+    // ---- pass 1 (root -> leaf): kinematics + contacts
+    float cs[LEG], sn[LEG];
+    V3 fca[3], fcl[3];           // contact wrench about O on chain bodies 2 (thigh_pitch), 3 (shank), 4 (foot)
+    R3 R = R0;
+    V3 rho = v3(0.f, 0.f, 0.f);
     V3 w = st.ang, v = st.vel;
     out.foot_force = v3(0.f, 0.f, 0.f);
     out.term = false;
     out.pen_count = 0.f;
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
-        V3 rho = rho_p + rot(Rp, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
-        float sn, cs;
-        grx_sincos(st.q[k], sn, cs);
-        R3 R = joint_rot_k(Rp, cs, sn, kAxis[k]);
+        rho = rho + rot(R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+        grx_sincos(st.q[k], sn[k], cs[k]);
+        R = joint_rot_k(R, cs[k], sn[k], kAxis[k]);
         V3 a = axis_k(R, kAxis[k]);
         V3 s = cross(rho, a);
-        V3 wk = fma3(a, st.qd[k], w), vk = fma3(s, st.qd[k], v);
-        float m = C.body[k].mass;
-        V3 kap = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
-        S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
-        S3 A = rot_sym(R, Ic);
-        float kk = dot(kap, kap);
-        A.xx += m * (kk - kap.x * kap.x); A.xy -= m * kap.x * kap.y; A.xz -= m * kap.x * kap.z;
-        A.yy += m * (kk - kap.y * kap.y); A.yz -= m * kap.y * kap.z; A.zz += m * (kk - kap.z * kap.z);
-        V3 h = kap * m;
-        V3 hl = fma3(vk, m, cross(wk, h));
-        V3 ha = mul(A, wk) + cross(h, vk);
-        V3 pa = cross(wk, ha) + cross(vk, hl);
-        V3 pl = cross(wk, hl);
-        // contacts of the shapes carried by chain body k (thigh_pitch: 2, shank: 2, foot: 4 anchored spheres)
-        if (kSphCnt[k] == 2 && group_within_reach<2>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
+        w = fma3(a, st.qd[k], w); v = fma3(s, st.qd[k], v);
+        if (kSphCnt[k] > 0) {
+            V3 fa = v3(0.f, 0.f, 0.f), fl = v3(0.f, 0.f, 0.f);
+            if (kSphCnt[k] == 2) {
+                if (group_within_reach<2>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                V3 xr;
-                V3 F = sphere_contact<HF, -1>(P, C.sph[kSphOff[k] + i], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
-                pa = pa - cross(xr, F); pl = pl - F;
+                    for (int i = 0; i < 2; ++i) {
+                        V3 xr;
+                        V3 F = sphere_contact<HF, -1>(P, C.sph[kSphOff[k] + i], R, rho, w, v, O, LC.mu, LC.hmax, st, xr);
+                        fa = fa + cross(xr, F); fl = fl + F;
+                    }
+                }
+            } else {
+                if (group_within_reach<4>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
+                    V3 xr, F;
+                    F = sphere_contact<HF, 0>(P, C.sph[kSphOff[k] + 0], R, rho, w, v, O, LC.mu, LC.hmax, st, xr);
+                    fa = fa + cross(xr, F); fl = fl + F;
+                    F = sphere_contact<HF, 1>(P, C.sph[kSphOff[k] + 1], R, rho, w, v, O, LC.mu, LC.hmax, st, xr);
+                    fa = fa + cross(xr, F); fl = fl + F;
+                    F = sphere_contact<HF, 2>(P, C.sph[kSphOff[k] + 2], R, rho, w, v, O, LC.mu, LC.hmax, st, xr);
+                    fa = fa + cross(xr, F); fl = fl + F;
+                    F = sphere_contact<HF, 3>(P, C.sph[kSphOff[k] + 3], R, rho, w, v, O, LC.mu, LC.hmax, st, xr);
+                    fa = fa + cross(xr, F); fl = fl + F;
+                    out.foot_force = fl;
+                } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
             }
-        } else if (kSphCnt[k] == 4) {
-          if (group_within_reach<4>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
-            V3 xr, F;
-            F = sphere_contact<HF, 0>(P, C.sph[kSphOff[k] + 0], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
-            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
-            F = sphere_contact<HF, 1>(P, C.sph[kSphOff[k] + 1], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
-            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
-            F = sphere_contact<HF, 2>(P, C.sph[kSphOff[k] + 2], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
-            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
-            F = sphere_contact<HF, 3>(P, C.sph[kSphOff[k] + 3], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
-            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
-          } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
+            fca[k - 2] = fa; fcl[k - 2] = fl;
         }
         if (k == LEG - 1) {  // foot link frame BEFORE this sub-step's integration
             V3 fr = rho + rot(R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
             fk_before.pos = O + fr;
-            fk_before.vel = vk + cross(wk, fr);
-            fk_before.ang = wk;
+            fk_before.vel = v + cross(w, fr);
+            fk_before.ang = w;
         }
-        Sa[k] = a; Ss[k] = s; IAk[k] = A; Ih[k] = h; pA[k] = pa; pL[k] = pl;
-        Rp = R; rho_p = rho; w = wk; v = vk;
     }
     GRX_TICK2(16);
     // ---- base-lump spheres handled by this lane (per-link netting for termination / collision)
@@ -268,45 +274,56 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
         }
     }
     GRX_TICK2(17);
-    // ---- pass 2: articulated inertias (leaf -> root).  w, v currently = velocity of body LEG-1.
-    S3 A = IAk[LEG - 1];
-    V3 h4 = Ih[LEG - 1];
-    float m4 = C.body[LEG - 1].mass;
-    M3 B = {0.f, -h4.z, h4.y, h4.z, 0.f, -h4.x, -h4.y, h4.x, 0.f};
-    S3 D = {m4, 0.f, 0.f, m4, 0.f, m4};
-    V3 pa = pA[LEG - 1], pl = pL[LEG - 1];
-    V3 Ua[LEG], Ul[LEG], ca[LEG], cl[LEG];
+    // ---- pass 2 (leaf -> root): rigid inertia + bias of body k, articulated recursion, frame walk-back.
+    // R, rho, w, v enter as those of body LEG-1.
+    S3 A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    M3 B = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    V3 pa = v3(0.f, 0.f, 0.f), pl = v3(0.f, 0.f, 0.f);
+    V3 Sa[LEG], Ss[LEG], Ua[LEG], Ul[LEG];
     float dinv[LEG], uu[LEG];
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
-        V3 a = Sa[k], s = Ss[k];
-        float qdk = st.qd[k];
+        const V3 a = axis_k(R, kAxis[k]);
+        const V3 s = cross(rho, a);
+        {   // [A B; B^T D] += rigid inertia of body k about O (world axes); (pa, pl) += its bias force - contacts
+            const float m = C.body[k].mass;
+            const V3 kap = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+            const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
+            S3 Ak = rot_sym(R, Ic);
+            const float kk = dot(kap, kap);
+            Ak.xx += m * (kk - kap.x * kap.x); Ak.xy -= m * kap.x * kap.y; Ak.xz -= m * kap.x * kap.z;
+            Ak.yy += m * (kk - kap.y * kap.y); Ak.yz -= m * kap.y * kap.z; Ak.zz += m * (kk - kap.z * kap.z);
+            const V3 h = kap * m;
+            const V3 hl = fma3(v, m, cross(w, h));
+            const V3 ha = mul(Ak, w) + cross(h, v);
+            pa = pa + cross(w, ha) + cross(v, hl);
+            pl = pl + cross(w, hl);
+            if (kSphCnt[k] > 0) { pa = pa - fca[k - 2]; pl = pl - fcl[k - 2]; }
+            A = A + Ak;
+            B.a01 -= h.z; B.a02 += h.y; B.a10 += h.z; B.a12 -= h.x; B.a20 -= h.y; B.a21 += h.x;
+            D.xx += m; D.yy += m; D.zz += m;
+        }
+        const float qdk = st.qd[k];
         w = fma3(a, -qdk, w); v = fma3(s, -qdk, v);  // parent velocity
-        V3 cak = cross(w, a) * qdk;
-        V3 clk = (cross(v, a) + cross(w, s)) * qdk;
-        V3 ua = mul(A, a) + mul(B, s);
-        V3 ul = mulT(B, a) + mul(D, s);
-        float d = dot(a, ua) + dot(s, ul);
-        float di = grx_rcp(d);
+        const V3 cak = cross(w, a) * qdk;
+        const V3 clk = (cross(v, a) + cross(w, s)) * qdk;
+        const V3 ua = mul(A, a) + mul(B, s);
+        const V3 ul = mulT(B, a) + mul(D, s);
+        const float di = grx_rcp(dot(a, ua) + dot(s, ul));
         // joint-limit spring/damper (oracle substep()): added to the motor torque
         float t = tau_m[k];
         if (st.q[k] < C.body[k].qlo) t += C.body[k].Klim * (C.body[k].qlo - st.q[k]) - C.body[k].Clim * qdk;
         else if (st.q[k] > C.body[k].qhi) t += C.body[k].Klim * (C.body[k].qhi - st.q[k]) - C.body[k].Clim * qdk;
-        float u = t - (dot(a, pa) + dot(s, pl));
+        const float u = t - (dot(a, pa) + dot(s, pl));
         syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
-        float ud = u * di;
-        V3 npa = pa + mul(A, cak) + mul(B, clk) + ua * ud;
-        V3 npl = pl + mulT(B, cak) + mul(D, clk) + ul * ud;
-        Ua[k] = ua; Ul[k] = ul; dinv[k] = di; uu[k] = u; ca[k] = cak; cl[k] = clk;
+        const float ud = u * di;
+        const V3 npa = pa + mul(A, cak) + mul(B, clk) + ua * ud;
+        const V3 npl = pl + mulT(B, cak) + mul(D, clk) + ul * ud;
         pa = npa; pl = npl;
-        if (k > 0) {  // add the parent's rigid inertia: [A B; B^T D] += rigid(k-1)
-            V3 hp = Ih[k - 1];
-            float mp = C.body[k - 1].mass;
-            A = A + IAk[k - 1];
-            B.a01 -= hp.z; B.a02 += hp.y; B.a10 += hp.z; B.a12 -= hp.x; B.a20 -= hp.y; B.a21 += hp.x;
-            D.xx += mp; D.yy += mp; D.zz += mp;
-            pa = pa + pA[k - 1]; pl = pl + pL[k - 1];
-        }
+        Sa[k] = a; Ss[k] = s; Ua[k] = ua; Ul[k] = ul; dinv[k] = di; uu[k] = u;
+        // walk the frame back to the parent body
+        R = joint_unrot_k(R, cs[k], sn[k], kAxis[k]);
+        rho = rho - rot(R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
     }
     GRX_TICK2(18);
     // ---- base: combine both chains (DPP pair exchange), add the base lump, solve the 6x6
@@ -334,23 +351,27 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     S3 Di = inv(D);
     V3 Dipl = mul(Di, pl);
     V3 rhs = mul(B, Dipl) - pa;
-    // Schur complement S = A - B Dinv B^T (symmetric)
     V3 b0 = v3(B.a00, B.a01, B.a02), b1 = v3(B.a10, B.a11, B.a12), b2 = v3(B.a20, B.a21, B.a22);
     V3 d0 = mul(Di, b0), d1 = mul(Di, b1), d2 = mul(Di, b2);
     S3 Sc = {A.xx - dot(b0, d0), A.xy - dot(b0, d1), A.xz - dot(b0, d2), A.yy - dot(b1, d1), A.yz - dot(b1, d2), A.zz - dot(b2, d2)};
     V3 alpha = mul(inv(Sc), rhs);
     V3 acc = neg(mul(Di, pl + mulT(B, alpha)));
     GRX_TICK2(19);
-    // ---- pass 3: accelerations (root -> leaf)
+    // ---- pass 3 (root -> leaf): accelerations; the velocity-product terms come from the running parent velocity
     float qdd[LEG];
     V3 aa = alpha, al = acc;
+    w = st.ang; v = st.vel;
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
-        V3 pa_ = aa + ca[k], pl_ = al + cl[k];
-        float qd2 = (uu[k] - (dot(Ua[k], pa_) + dot(Ul[k], pl_))) * dinv[k];
+        const float qdk = st.qd[k];
+        const V3 cak = cross(w, Sa[k]) * qdk;
+        const V3 clk = (cross(v, Sa[k]) + cross(w, Ss[k])) * qdk;
+        const V3 pa_ = aa + cak, pl_ = al + clk;
+        const float qd2 = (uu[k] - (dot(Ua[k], pa_) + dot(Ul[k], pl_))) * dinv[k];
         qdd[k] = qd2;
         aa = fma3(Sa[k], qd2, pa_);
         al = fma3(Ss[k], qd2, pl_);
+        w = fma3(Sa[k], qdk, w); v = fma3(Ss[k], qdk, v);
     }
     GRX_TICK2(20);
     // ---- integrate (semi-implicit Euler)
@@ -491,7 +512,7 @@ GRX_DEV float sum_abs_mask(const float a[LEG], uint32_t mask) {
 
 // ------------------------------------------------------------------------------------------
 template <bool HF>
-__global__ __launch_bounds__(64) void grx_step_kernel(const KParams P, const float* __restrict__ actions_in,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_kernel(const KParams P, const float* __restrict__ actions_in,
                                                       float delay, long long common_step, const float* __restrict__ noise_in) {
     __shared__ KTables s_tab;
     __shared__ __attribute__((aligned(16))) float s_obs[EPB * GRX_NUM_OBS];

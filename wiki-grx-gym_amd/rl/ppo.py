@@ -205,7 +205,7 @@ class PPO:
                     bad = bad | ~torch.isfinite(self._bucket[:-1]).all()
                 # NaN-skip (ppo.py:297-299) without a sync: the fused Adam kernel leaves parameters and moments
                 # untouched when found_inf is set (the GradScaler hook)
-                self.optimizer.found_inf = bad.float().reshape(1)
+                self.optimizer.found_inf = bad.float().reshape(())
                 self.optimizer.grad_scale = None
             nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm, foreach=True)
             self.optimizer.step()
