@@ -68,7 +68,7 @@ def _check_against_reference(device):
         torch.randperm = orig_rp
     assert vl == pytest.approx(float(d["value_loss"]), rel=1e-4)
     assert sl == pytest.approx(float(d["surrogate_loss"]), rel=1e-4, abs=1e-6)
-    assert alg.learning_rate == pytest.approx(float(d["lr_after"]), rel=1e-9)
+    assert alg.learning_rate == pytest.approx(float(d["lr_after"]), rel=1e-6)   # the device path keeps the LR in fp32
     for k, v in ac.state_dict().items():
         np.testing.assert_allclose(v.detach().cpu().numpy(), d["w1_" + k], rtol=2e-4 if device == "cuda" else 1e-4, atol=2e-6, err_msg=k)
 

@@ -1,0 +1,41 @@
+#!/bin/bash
+# usage (on the GPU box, through gpurun): tools/collect_profiles.sh <tag> [skip-tests]
+# Regenerates every measurement artefact the docs quote, for the kernel as built in the tree:
+#   gpurun_out/<tag>/pytest_gpu.log         python -m pytest tests -m gpu
+#   gpurun_out/<tag>/bench_rough.json       python bench.py                       (the headline line)
+#   gpurun_out/<tag>/bench_flat.json        python bench.py --terrain flat
+#   gpurun_out/<tag>/sweep.jsonl            rough terrain, envs/GPU in {8192, 16384, 32768, 65536, 131072}
+#   gpurun_out/<tag>/stats/                 rocprofv3 --kernel-trace --stats of a 100-step bench run
+#   gpurun_out/<tag>/pmc_fetch|pmc_write/   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes
+# Copy what is to be judged into profiles/ afterwards (tools/summarise_profiles.py does that).
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+tag=${1:-r01}
+out=gpurun_out/$tag
+mkdir -p $out
+if [ "$2" != "skip-tests" ]; then
+    timeout 1500 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1
+    tail -3 $out/pytest_gpu.log
+fi
+timeout 600 python bench.py 2> $out/bench_rough.err | tail -1 > $out/bench_rough.json
+timeout 300 python bench.py --terrain flat --no-cpu-baseline 2> $out/bench_flat.err | tail -1 > $out/bench_flat.json
+: > $out/sweep.jsonl
+for n in 8192 16384 32768 65536 131072; do
+    timeout 300 python bench.py --envs-per-gpu $n --steps 200 --warmup 20 --no-cpu-baseline 2>> $out/sweep.err | tail -1 >> $out/sweep.jsonl
+done
+BENCH="python bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats -o b -- bash -c "cd $OLDPWD && $BENCH" > $OLDPWD/$out/stats.log 2>&1)
+for c in FETCH_SIZE WRITE_SIZE; do
+    d=$out/pmc_$(echo $c | tr 'A-Z' 'a-z' | cut -d_ -f1)
+    (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OLDPWD/$d -o b -- bash -c "cd $OLDPWD && $BENCH" > $OLDPWD/$d.log 2>&1)
+done
+cut -c1-400 $out/bench_rough.json; cut -c1-200 $out/bench_flat.json
+python - <<EOF
+import json
+for l in open("$out/sweep.jsonl"):
+    try:
+        j = json.loads(l); print(j["config"]["envs_per_gpu"], round(j["value"] / 1e6, 2), "M env-steps/s", round(j["roofline"]["kernel_ms"] * 1e3, 1), "us/launch")
+    except Exception as e:
+        print("bad sweep line", e)
+EOF
+find $out -name "*stats*.csv" | head; find $out -name "*counter_collection.csv" | head

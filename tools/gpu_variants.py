@@ -1,8 +1,14 @@
 """Compile libgrx_hip.so with different flag sets on the GPU box and time the step kernel."""
 import subprocess, sys, os
 sys.path.insert(0, ".")
-base = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-hip-fp32-correctly-rounded-divide-sqrt"
+base = "-I../../include --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-hip-fp32-correctly-rounded-divide-sqrt"
 variants = {
+    "default(noslp)": "-fno-slp-vectorize",
+    "no-licm-barrier": "-fno-slp-vectorize -DGRX_NO_LICM_BARRIER",
+}
+if len(sys.argv) > 1:   # name=flags ... on the command line
+    variants = {a.split("=", 1)[0]: "-fno-slp-vectorize " + a.split("=", 1)[1] for a in sys.argv[1:]}
+_unused = {
     "default(noslp)": "-fno-slp-vectorize",
     "slp": "",
     "noslp max-ilp": "-fno-slp-vectorize -mllvm -amdgpu-sched-strategy=max-ilp",

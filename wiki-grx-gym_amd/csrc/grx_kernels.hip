@@ -32,7 +32,8 @@
 
 #ifdef GRX_PROFILE_SECTIONS
 #define GRX_TICK(i) do { if (threadIdx.x == 0) P.prof[(size_t)blockIdx.x * 32 + (i)] = clock64(); } while (0)
-#define GRX_TICK2(i) do { if (threadIdx.x == 0) P.prof[(size_t)blockIdx.x * 32 + (i)] += clock64() - tprev; tprev = clock64(); } while (0)
+// sub-step sections accumulate in registers (g_tacc is a kernel-scope local); sched_barrier pins the code motion
+#define GRX_TICK2(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); tacc[(i) - 16] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define GRX_TICK2(i) do {} while (0)
 #define GRX_TICK(i) do {} while (0)
@@ -182,6 +183,8 @@ GRX_DEV R3 joint_unrot_k(const R3& R, float c, float s, int ax) {
     return P;
 }
 
+#ifdef GRX_SUBSTEP_LEAN
+// (register-lean variant: recomputes frames on the way back; measured 3-4 % slower than the default below)
 // One physics sub-step (gym.simulate(dt), legged_robot_fftai.py:68) for this lane's half of the env.
 // tau_m: motor torques of this lane's 5 joints.
 //
@@ -193,7 +196,7 @@ GRX_DEV R3 joint_unrot_k(const R3& R, float c, float s, int ax) {
 // running parent velocity.
 template <bool HF>
 GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
-                     SubstepOut& out, FootKin& fk_before) {
+                     SubstepOut& out, FootKin& fk_before, long long* tacc) {
     const float dt = P.sim_dt;
     const R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
     const V3 O = st.pos;
@@ -397,6 +400,211 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     GRX_TICK2(21);
 }
 
+#else
+// One physics sub-step (gym.simulate(dt), legged_robot_fftai.py:68) for this lane's half of the env.
+// tau: motor torques of this lane's 5 joints.  fk_only: just the kinematics pass (foot frames).
+template <bool HF>
+GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
+                     SubstepOut& out, FootKin& fk_before, long long* tacc) {
+    const float dt = P.sim_dt;
+    R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
+    V3 O = st.pos;
+#ifdef GRX_PROFILE_SECTIONS
+    long long tprev = clock64();
+#endif
+    // ---- pass 1: kinematics, rigid inertias, bias forces, contacts (root -> leaf)
+    V3 Sa[LEG], Ss[LEG];       // joint motion subspace S = (a; rho x a)
+    S3 IAk[LEG]; V3 Ih[LEG];   // rigid inertia about O: A and h = m*kappa
+    V3 pA[LEG], pL[LEG];       // bias force
+    R3 Rp = R0;
+    V3 rho_p = v3(0.f, 0.f, 0.f);
+    V3 w = st.ang, v = st.vel;
+    out.foot_force = v3(0.f, 0.f, 0.f);
+    out.term = false;
+    out.pen_count = 0.f;
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        V3 rho = rho_p + rot(Rp, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+        float sn, cs;
+        grx_sincos(st.q[k], sn, cs);
+        R3 R = joint_rot_k(Rp, cs, sn, kAxis[k]);
+        V3 a = axis_k(R, kAxis[k]);
+        V3 s = cross(rho, a);
+        V3 wk = fma3(a, st.qd[k], w), vk = fma3(s, st.qd[k], v);
+        float m = C.body[k].mass;
+        V3 kap = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+        S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
+        S3 A = rot_sym(R, Ic);
+        float kk = dot(kap, kap);
+        A.xx += m * (kk - kap.x * kap.x); A.xy -= m * kap.x * kap.y; A.xz -= m * kap.x * kap.z;
+        A.yy += m * (kk - kap.y * kap.y); A.yz -= m * kap.y * kap.z; A.zz += m * (kk - kap.z * kap.z);
+        V3 h = kap * m;
+        V3 hl = fma3(vk, m, cross(wk, h));
+        V3 ha = mul(A, wk) + cross(h, vk);
+        V3 pa = cross(wk, ha) + cross(vk, hl);
+        V3 pl = cross(wk, hl);
+        // contacts of the shapes carried by chain body k (thigh_pitch: 2, shank: 2, foot: 4 anchored spheres)
+        if (kSphCnt[k] == 2 && group_within_reach<2>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                V3 xr;
+                V3 F = sphere_contact<HF, -1>(P, C.sph[kSphOff[k] + i], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
+                pa = pa - cross(xr, F); pl = pl - F;
+            }
+        } else if (kSphCnt[k] == 4) {
+          if (group_within_reach<4>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
+            V3 xr, F;
+            F = sphere_contact<HF, 0>(P, C.sph[kSphOff[k] + 0], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
+            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
+            F = sphere_contact<HF, 1>(P, C.sph[kSphOff[k] + 1], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
+            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
+            F = sphere_contact<HF, 2>(P, C.sph[kSphOff[k] + 2], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
+            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
+            F = sphere_contact<HF, 3>(P, C.sph[kSphOff[k] + 3], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
+            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
+          } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
+        }
+        if (k == LEG - 1) {  // foot link frame BEFORE this sub-step's integration
+            V3 fr = rho + rot(R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
+            fk_before.pos = O + fr;
+            fk_before.vel = vk + cross(wk, fr);
+            fk_before.ang = wk;
+        }
+        Sa[k] = a; Ss[k] = s; IAk[k] = A; Ih[k] = h; pA[k] = pa; pL[k] = pl;
+        Rp = R; rho_p = rho; w = wk; v = vk;
+    }
+    GRX_TICK2(16);
+    // ---- base-lump spheres handled by this lane (per-link netting for termination / collision)
+    V3 f0a = v3(0.f, 0.f, 0.f), f0l = v3(0.f, 0.f, 0.f);
+    if (group_within_reach<8>(&C.sph[0], R0, v3(0.f, 0.f, 0.f), O, LC.hmax)) {
+        V3 Flink = v3(0.f, 0.f, 0.f);
+        const V3 zero = v3(0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const SphC& S = C.sph[i];
+            V3 xr;
+            V3 F = sphere_contact<HF, -1>(P, S, R0, zero, st.ang, st.vel, O, LC.mu, LC.hmax, st, xr);
+            f0a = f0a + cross(xr, F);
+            f0l = f0l + F;
+            Flink = Flink + F;
+            if (S.link_last) {   // uniform per side: net force of one URDF link complete
+                float n2 = dot(Flink, Flink);
+                if ((S.flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) out.term = true;
+                if ((S.flags & GRX_SPH_PENALISE) && n2 > 0.01f) out.pen_count += 1.0f;
+                Flink = zero;
+            }
+        }
+    }
+    GRX_TICK2(17);
+    // ---- pass 2: articulated inertias (leaf -> root).  w, v currently = velocity of body LEG-1.
+    S3 A = IAk[LEG - 1];
+    V3 h4 = Ih[LEG - 1];
+    float m4 = C.body[LEG - 1].mass;
+    M3 B = {0.f, -h4.z, h4.y, h4.z, 0.f, -h4.x, -h4.y, h4.x, 0.f};
+    S3 D = {m4, 0.f, 0.f, m4, 0.f, m4};
+    V3 pa = pA[LEG - 1], pl = pL[LEG - 1];
+    V3 Ua[LEG], Ul[LEG], ca[LEG], cl[LEG];
+    float dinv[LEG], uu[LEG];
+#pragma unroll
+    for (int k = LEG - 1; k >= 0; --k) {
+        V3 a = Sa[k], s = Ss[k];
+        float qdk = st.qd[k];
+        w = fma3(a, -qdk, w); v = fma3(s, -qdk, v);  // parent velocity
+        V3 cak = cross(w, a) * qdk;
+        V3 clk = (cross(v, a) + cross(w, s)) * qdk;
+        V3 ua = mul(A, a) + mul(B, s);
+        V3 ul = mulT(B, a) + mul(D, s);
+        float d = dot(a, ua) + dot(s, ul);
+        float di = grx_rcp(d);
+        // joint-limit spring/damper (oracle substep()): added to the motor torque
+        float t = tau_m[k];
+        if (st.q[k] < C.body[k].qlo) t += C.body[k].Klim * (C.body[k].qlo - st.q[k]) - C.body[k].Clim * qdk;
+        else if (st.q[k] > C.body[k].qhi) t += C.body[k].Klim * (C.body[k].qhi - st.q[k]) - C.body[k].Clim * qdk;
+        float u = t - (dot(a, pa) + dot(s, pl));
+        syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
+        float ud = u * di;
+        V3 npa = pa + mul(A, cak) + mul(B, clk) + ua * ud;
+        V3 npl = pl + mulT(B, cak) + mul(D, clk) + ul * ud;
+        Ua[k] = ua; Ul[k] = ul; dinv[k] = di; uu[k] = u; ca[k] = cak; cl[k] = clk;
+        pa = npa; pl = npl;
+        if (k > 0) {  // add the parent's rigid inertia: [A B; B^T D] += rigid(k-1)
+            V3 hp = Ih[k - 1];
+            float mp = C.body[k - 1].mass;
+            A = A + IAk[k - 1];
+            B.a01 -= hp.z; B.a02 += hp.y; B.a10 += hp.z; B.a12 -= hp.x; B.a20 -= hp.y; B.a21 += hp.x;
+            D.xx += mp; D.yy += mp; D.zz += mp;
+            pa = pa + pA[k - 1]; pl = pl + pL[k - 1];
+        }
+    }
+    GRX_TICK2(18);
+    // ---- base: combine both chains (DPP pair exchange), add the base lump, solve the 6x6
+    pa = pa - f0a; pl = pl - f0l;
+    A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
+    pa = pair_sum(pa); pl = pair_sum(pl);
+    {
+        V3 kap = rot(R0, LC.base_c);
+        float m = LC.base_m;
+        S3 A0 = rot_sym(R0, LC.base_I);
+        float kk = dot(kap, kap);
+        A0.xx += m * (kk - kap.x * kap.x); A0.xy -= m * kap.x * kap.y; A0.xz -= m * kap.x * kap.z;
+        A0.yy += m * (kk - kap.y * kap.y); A0.yz -= m * kap.y * kap.z; A0.zz += m * (kk - kap.z * kap.z);
+        V3 h = kap * m;
+        V3 w0 = st.ang, v0 = st.vel;
+        V3 hl = fma3(v0, m, cross(w0, h));
+        V3 ha = mul(A0, w0) + cross(h, v0);
+        pa = pa + cross(w0, ha) + cross(v0, hl);
+        pl = pl + cross(w0, hl);
+        A = A + A0;
+        B.a01 -= h.z; B.a02 += h.y; B.a10 += h.z; B.a12 -= h.x; B.a20 -= h.y; B.a21 += h.x;
+        D.xx += m; D.yy += m; D.zz += m;
+    }
+    // [A B; B^T D][alpha; acc] = -[pa; pl]:  acc = -Dinv (pl + B^T alpha);  (A - B Dinv B^T) alpha = -pa + B Dinv pl
+    S3 Di = inv(D);
+    V3 Dipl = mul(Di, pl);
+    V3 rhs = mul(B, Dipl) - pa;
+    // Schur complement S = A - B Dinv B^T (symmetric)
+    V3 b0 = v3(B.a00, B.a01, B.a02), b1 = v3(B.a10, B.a11, B.a12), b2 = v3(B.a20, B.a21, B.a22);
+    V3 d0 = mul(Di, b0), d1 = mul(Di, b1), d2 = mul(Di, b2);
+    S3 Sc = {A.xx - dot(b0, d0), A.xy - dot(b0, d1), A.xz - dot(b0, d2), A.yy - dot(b1, d1), A.yz - dot(b1, d2), A.zz - dot(b2, d2)};
+    V3 alpha = mul(inv(Sc), rhs);
+    V3 acc = neg(mul(Di, pl + mulT(B, alpha)));
+    GRX_TICK2(19);
+    // ---- pass 3: accelerations (root -> leaf)
+    float qdd[LEG];
+    V3 aa = alpha, al = acc;
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        V3 pa_ = aa + ca[k], pl_ = al + cl[k];
+        float qd2 = (uu[k] - (dot(Ua[k], pa_) + dot(Ul[k], pl_))) * dinv[k];
+        qdd[k] = qd2;
+        aa = fma3(Sa[k], qd2, pa_);
+        al = fma3(Ss[k], qd2, pl_);
+    }
+    GRX_TICK2(20);
+    // ---- integrate (semi-implicit Euler)
+    V3 lin = acc + cross(st.ang, st.vel);  // classical acceleration of the base origin
+    st.vel = v3(st.vel.x + (lin.x + P.gravity[0]) * dt, st.vel.y + (lin.y + P.gravity[1]) * dt, st.vel.z + (lin.z + P.gravity[2]) * dt);
+    st.ang = fma3(alpha, dt, st.ang);
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        float vq = fmaf(qdd[k], dt, st.qd[k]);
+        vq = fminf(fmaxf(vq, -C.body[k].vlim), C.body[k].vlim);
+        st.qd[k] = vq;
+        st.q[k] = fmaf(vq, dt, st.q[k]);
+    }
+    st.pos = fma3(st.vel, dt, st.pos);
+    float hx = 0.5f * dt * st.ang.x, hy = 0.5f * dt * st.ang.y, hz = 0.5f * dt * st.ang.z;
+    float x = st.qx, y = st.qy, z = st.qz, ww = st.qw;
+    float nx = x + hx * ww + hy * z - hz * y;
+    float ny = y - hx * z + hy * ww + hz * x;
+    float nz = z + hx * y - hy * x + hz * ww;
+    float nw = ww - hx * x - hy * y - hz * z;
+    float n = grx_rsq(nx * nx + ny * ny + nz * nz + nw * nw);
+    st.qx = nx * n; st.qy = ny * n; st.qz = nz * n; st.qw = nw * n;
+    GRX_TICK2(21);
+}
+#endif
+
 // kinematics only: this lane's foot link frame in the current state
 GRX_DEV FootKin foot_kinematics(const SideConst& C, const LaneState& st) {
     R3 Rp = quat_to_R(st.qx, st.qy, st.qz, st.qw);
@@ -488,12 +696,18 @@ GRX_DEV void reset_env(const KParams& P, const SideConst& C, int side, uint32_t 
     st.anchor_on = 0;
 }
 
-// legged_robot.py:1235-1274 _get_heights, one point
-GRX_DEV float height_sample(const KParams& P, const KTables& T, float qz, float qw, V3 pos, int k) {
-    float n = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);
-    V3 p = quat_apply(v3(0.f, 0.f, qz / n), qw / n, v3(T.height_points[k][0], T.height_points[k][1], 0.f));
-    float px = (p.x + pos.x + P.border_size) / P.horizontal_scale;
-    float py = (p.y + pos.y + P.border_size) / P.horizontal_scale;
+// legged_robot.py:1235-1274 _get_heights, one point.  The cell index is a discrete decision (truncation, then the
+// min of three raster corners), so this function is compiled with reassociation OFF and spells out
+// quat_apply_yaw (math.py:38-42 -> torch_utils.py:48-55) in the reference's operation order; zn/wn are the
+// yaw-only quaternion's z and w (the x, y terms of the two cross products are exact zeros and are dropped).
+GRX_DEV float height_sample(const KParams& P, const KTables& T, float zn, float wn, V3 pos, int k) {
+#pragma clang fp reassociate(off)
+    const float bx = T.height_points[k][0], by = T.height_points[k][1];
+    const float tx = -(zn * by) * 2.0f, ty = (zn * bx) * 2.0f;   // t = 2 * cross(qv, b)
+    const float ux = -(zn * ty), uy = zn * tx;                   // cross(qv, t)
+    const float qx_ = bx + wn * tx + ux, qy_ = by + wn * ty + uy;
+    float px = (qx_ + pos.x + P.border_size) / P.horizontal_scale;
+    float py = (qy_ + pos.y + P.border_size) / P.horizontal_scale;
     int ix = min(max((int)px, 0), P.hf_rows - 2), iy = min(max((int)py, 0), P.hf_cols - 2);
     const int16_t* H = P.hf + (size_t)ix * P.hf_cols + iy;
     int16_t h1 = H[0], h2 = H[P.hf_cols], h3 = H[1];
@@ -538,7 +752,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int j0 = side * LEG;
 
 #ifdef GRX_PROFILE_SECTIONS
-    if (threadIdx.x == 0) for (int i = 16; i < 22; ++i) P.prof[(size_t)blockIdx.x * 32 + i] = 0;
+    long long tacc[6] = {0, 0, 0, 0, 0, 0};
+#else
+    long long* tacc = nullptr;
 #endif
     GRX_TICK(0);
     // ---- load state (SoA, coalesced)
@@ -596,7 +812,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int deci = 0; deci < P.decimation; ++deci) {
         // keep the LDS-resident robot tables in LDS: without this barrier LICM hoists ~240 loop-invariant
         // ds_reads into VGPRs and the kernel spills to scratch (measured: 604 B/lane -> 0)
+#ifndef GRX_NO_LICM_BARRIER
         asm volatile("" ::: "memory");
+#endif
         const bool use_last = (float)deci < delay;
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {  // _compute_torques legged_robot.py:679-715
@@ -605,13 +823,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             t *= LC.strength[k];
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
-        substep<HF>(P, C, LC, st, torque, so, fk);
+        substep<HF>(P, C, LC, st, torque, so, fk, tacc);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
             avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
         }
         avg_force += grx_sqrt(dot(so.foot_force, so.foot_force));
     }
     GRX_TICK(2);
+#ifdef GRX_PROFILE_SECTIONS
+    if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) P.prof[(size_t)blockIdx.x * 32 + 16 + i] = tacc[i];
+#endif
     fk = foot_kinematics(C, st);  // refresh_rigid_body_state_tensor after the last sub-step
     avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
     avg_force = avg_force / (float)P.decimation;  // legged_robot_fftai.py:86-88
@@ -635,12 +856,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     float* prow = s_pri + el * GRX_MAX_PRI;
     float hsum = 0.f;
     if (HF && P.measure_heights) {
+        const float yaw_n = fmaxf(sqrtf(st.qz * st.qz + st.qw * st.qw), 1e-9f);   // normalize(): torch_utils.py:43-45
+        const float yaw_z = st.qz / yaw_n, yaw_w = st.qw / yaw_n;
         for (int k0 = side; k0 < nh; k0 += 16) {
             float hb[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {   // independent gathers: all 24 loads of the batch are in flight together
                 int k = k0 + 2 * j;
-                hb[j] = height_sample(P, s_tab, st.qz, st.qw, st.pos, min(k, nh - 1));
+                hb[j] = height_sample(P, s_tab, yaw_z, yaw_w, st.pos, min(k, nh - 1));
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
