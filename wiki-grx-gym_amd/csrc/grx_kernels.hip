@@ -183,229 +183,43 @@ GRX_DEV R3 joint_unrot_k(const R3& R, float c, float s, int ax) {
     return P;
 }
 
-#ifdef GRX_SUBSTEP_LEAN
-// (register-lean variant: recomputes frames on the way back; measured 3-4 % slower than the default below)
-// One physics sub-step (gym.simulate(dt), legged_robot_fftai.py:68) for this lane's half of the env.
-// tau_m: motor torques of this lane's 5 joints.
-//
-// Register discipline (the kernel runs one wave per SIMD, so the 256-VGPR file is the scarce resource and a
-// register-starved schedule degenerates into a dependent chain at ~7 cycles/instruction, measured): the outward
-// pass keeps only sin/cos per joint and the contact wrenches; the inward pass walks the frames back by
-// UN-rotating (12 FMAs per joint) and builds each body's rigid inertia / bias force right where the
-// articulated recursion consumes it; the final outward pass recomputes the velocity-product terms from the
-// running parent velocity.
+// Contacts of the base-lump shapes (torso, head, arms, ... rigidly attached to the floating base) handled by this
+// lane's side, with per-link netting for termination / collision (legged_robot.py:336-353).  They depend only on
+// the base state at the start of the sub-step, so the block's HELPER WAVE evaluates them while the dynamics wave
+// runs the kinematics / articulated-inertia passes; the wrench enters at the base solve.
 template <bool HF>
-GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
-                     SubstepOut& out, FootKin& fk_before, long long* tacc) {
-    const float dt = P.sim_dt;
-    const R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
-    const V3 O = st.pos;
-#ifdef GRX_PROFILE_SECTIONS
-    long long tprev = clock64();
-#endif
-    // ---- pass 1 (root -> leaf): kinematics + contacts
-    float cs[LEG], sn[LEG];
-    V3 fca[3], fcl[3];           // contact wrench about O on chain bodies 2 (thigh_pitch), 3 (shank), 4 (foot)
-    R3 R = R0;
-    V3 rho = v3(0.f, 0.f, 0.f);
-    V3 w = st.ang, v = st.vel;
-    out.foot_force = v3(0.f, 0.f, 0.f);
-    out.term = false;
-    out.pen_count = 0.f;
-#pragma unroll
-    for (int k = 0; k < LEG; ++k) {
-        rho = rho + rot(R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
-        grx_sincos(st.q[k], sn[k], cs[k]);
-        R = joint_rot_k(R, cs[k], sn[k], kAxis[k]);
-        V3 a = axis_k(R, kAxis[k]);
-        V3 s = cross(rho, a);
-        w = fma3(a, st.qd[k], w); v = fma3(s, st.qd[k], v);
-        if (kSphCnt[k] > 0) {
-            V3 fa = v3(0.f, 0.f, 0.f), fl = v3(0.f, 0.f, 0.f);
-            if (kSphCnt[k] == 2) {
-                if (group_within_reach<2>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        V3 xr;
-                        V3 F = sphere_contact<HF, -1>(P, C.sph[kSphOff[k] + i], R, rho, w, v, O, LC.mu, LC.hmax, st, xr);
-                        fa = fa + cross(xr, F); fl = fl + F;
-                    }
-                }
-            } else {
-                if (group_within_reach<4>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
-                    V3 xr, F;
-                    F = sphere_contact<HF, 0>(P, C.sph[kSphOff[k] + 0], R, rho, w, v, O, LC.mu, LC.hmax, st, xr);
-                    fa = fa + cross(xr, F); fl = fl + F;
-                    F = sphere_contact<HF, 1>(P, C.sph[kSphOff[k] + 1], R, rho, w, v, O, LC.mu, LC.hmax, st, xr);
-                    fa = fa + cross(xr, F); fl = fl + F;
-                    F = sphere_contact<HF, 2>(P, C.sph[kSphOff[k] + 2], R, rho, w, v, O, LC.mu, LC.hmax, st, xr);
-                    fa = fa + cross(xr, F); fl = fl + F;
-                    F = sphere_contact<HF, 3>(P, C.sph[kSphOff[k] + 3], R, rho, w, v, O, LC.mu, LC.hmax, st, xr);
-                    fa = fa + cross(xr, F); fl = fl + F;
-                    out.foot_force = fl;
-                } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
-            }
-            fca[k - 2] = fa; fcl[k - 2] = fl;
-        }
-        if (k == LEG - 1) {  // foot link frame BEFORE this sub-step's integration
-            V3 fr = rho + rot(R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
-            fk_before.pos = O + fr;
-            fk_before.vel = v + cross(w, fr);
-            fk_before.ang = w;
-        }
-    }
-    GRX_TICK2(16);
-    // ---- base-lump spheres handled by this lane (per-link netting for termination / collision)
-    V3 f0a = v3(0.f, 0.f, 0.f), f0l = v3(0.f, 0.f, 0.f);
-    if (group_within_reach<8>(&C.sph[0], R0, v3(0.f, 0.f, 0.f), O, LC.hmax)) {
+GRX_DEV void base_lump_contacts(const KParams& P, const SideConst& C, const R3& R0, V3 O, V3 ang, V3 vel, float mu, float hmax,
+                                V3& f0a, V3& f0l, bool& term, float& pen_count) {
+    f0a = v3(0.f, 0.f, 0.f); f0l = v3(0.f, 0.f, 0.f);
+    term = false; pen_count = 0.f;
+    LaneState dummy;   // anchors are only touched by foot spheres (SLOT >= 0)
+    dummy.anchor_on = 0;
+    if (group_within_reach<8>(&C.sph[0], R0, v3(0.f, 0.f, 0.f), O, hmax)) {
         V3 Flink = v3(0.f, 0.f, 0.f);
         const V3 zero = v3(0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const SphC& S = C.sph[i];
             V3 xr;
-            V3 F = sphere_contact<HF, -1>(P, S, R0, zero, st.ang, st.vel, O, LC.mu, LC.hmax, st, xr);
+            V3 F = sphere_contact<HF, -1>(P, S, R0, zero, ang, vel, O, mu, hmax, dummy, xr);
             f0a = f0a + cross(xr, F);
             f0l = f0l + F;
             Flink = Flink + F;
             if (S.link_last) {   // uniform per side: net force of one URDF link complete
                 float n2 = dot(Flink, Flink);
-                if ((S.flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) out.term = true;
-                if ((S.flags & GRX_SPH_PENALISE) && n2 > 0.01f) out.pen_count += 1.0f;
+                if ((S.flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term = true;
+                if ((S.flags & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.0f;
                 Flink = zero;
             }
         }
     }
-    GRX_TICK2(17);
-    // ---- pass 2 (leaf -> root): rigid inertia + bias of body k, articulated recursion, frame walk-back.
-    // R, rho, w, v enter as those of body LEG-1.
-    S3 A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    M3 B = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    V3 pa = v3(0.f, 0.f, 0.f), pl = v3(0.f, 0.f, 0.f);
-    V3 Sa[LEG], Ss[LEG], Ua[LEG], Ul[LEG];
-    float dinv[LEG], uu[LEG];
-#pragma unroll
-    for (int k = LEG - 1; k >= 0; --k) {
-        const V3 a = axis_k(R, kAxis[k]);
-        const V3 s = cross(rho, a);
-        {   // [A B; B^T D] += rigid inertia of body k about O (world axes); (pa, pl) += its bias force - contacts
-            const float m = C.body[k].mass;
-            const V3 kap = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
-            const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
-            S3 Ak = rot_sym(R, Ic);
-            const float kk = dot(kap, kap);
-            Ak.xx += m * (kk - kap.x * kap.x); Ak.xy -= m * kap.x * kap.y; Ak.xz -= m * kap.x * kap.z;
-            Ak.yy += m * (kk - kap.y * kap.y); Ak.yz -= m * kap.y * kap.z; Ak.zz += m * (kk - kap.z * kap.z);
-            const V3 h = kap * m;
-            const V3 hl = fma3(v, m, cross(w, h));
-            const V3 ha = mul(Ak, w) + cross(h, v);
-            pa = pa + cross(w, ha) + cross(v, hl);
-            pl = pl + cross(w, hl);
-            if (kSphCnt[k] > 0) { pa = pa - fca[k - 2]; pl = pl - fcl[k - 2]; }
-            A = A + Ak;
-            B.a01 -= h.z; B.a02 += h.y; B.a10 += h.z; B.a12 -= h.x; B.a20 -= h.y; B.a21 += h.x;
-            D.xx += m; D.yy += m; D.zz += m;
-        }
-        const float qdk = st.qd[k];
-        w = fma3(a, -qdk, w); v = fma3(s, -qdk, v);  // parent velocity
-        const V3 cak = cross(w, a) * qdk;
-        const V3 clk = (cross(v, a) + cross(w, s)) * qdk;
-        const V3 ua = mul(A, a) + mul(B, s);
-        const V3 ul = mulT(B, a) + mul(D, s);
-        const float di = grx_rcp(dot(a, ua) + dot(s, ul));
-        // joint-limit spring/damper (oracle substep()): added to the motor torque
-        float t = tau_m[k];
-        if (st.q[k] < C.body[k].qlo) t += C.body[k].Klim * (C.body[k].qlo - st.q[k]) - C.body[k].Clim * qdk;
-        else if (st.q[k] > C.body[k].qhi) t += C.body[k].Klim * (C.body[k].qhi - st.q[k]) - C.body[k].Clim * qdk;
-        const float u = t - (dot(a, pa) + dot(s, pl));
-        syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
-        const float ud = u * di;
-        const V3 npa = pa + mul(A, cak) + mul(B, clk) + ua * ud;
-        const V3 npl = pl + mulT(B, cak) + mul(D, clk) + ul * ud;
-        pa = npa; pl = npl;
-        Sa[k] = a; Ss[k] = s; Ua[k] = ua; Ul[k] = ul; dinv[k] = di; uu[k] = u;
-        // walk the frame back to the parent body
-        R = joint_unrot_k(R, cs[k], sn[k], kAxis[k]);
-        rho = rho - rot(R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
-    }
-    GRX_TICK2(18);
-    // ---- base: combine both chains (DPP pair exchange), add the base lump, solve the 6x6
-    pa = pa - f0a; pl = pl - f0l;
-    A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
-    pa = pair_sum(pa); pl = pair_sum(pl);
-    {
-        V3 kap = rot(R0, LC.base_c);
-        float m = LC.base_m;
-        S3 A0 = rot_sym(R0, LC.base_I);
-        float kk = dot(kap, kap);
-        A0.xx += m * (kk - kap.x * kap.x); A0.xy -= m * kap.x * kap.y; A0.xz -= m * kap.x * kap.z;
-        A0.yy += m * (kk - kap.y * kap.y); A0.yz -= m * kap.y * kap.z; A0.zz += m * (kk - kap.z * kap.z);
-        V3 h = kap * m;
-        V3 w0 = st.ang, v0 = st.vel;
-        V3 hl = fma3(v0, m, cross(w0, h));
-        V3 ha = mul(A0, w0) + cross(h, v0);
-        pa = pa + cross(w0, ha) + cross(v0, hl);
-        pl = pl + cross(w0, hl);
-        A = A + A0;
-        B.a01 -= h.z; B.a02 += h.y; B.a10 += h.z; B.a12 -= h.x; B.a20 -= h.y; B.a21 += h.x;
-        D.xx += m; D.yy += m; D.zz += m;
-    }
-    // [A B; B^T D][alpha; acc] = -[pa; pl]:  acc = -Dinv (pl + B^T alpha);  (A - B Dinv B^T) alpha = -pa + B Dinv pl
-    S3 Di = inv(D);
-    V3 Dipl = mul(Di, pl);
-    V3 rhs = mul(B, Dipl) - pa;
-    V3 b0 = v3(B.a00, B.a01, B.a02), b1 = v3(B.a10, B.a11, B.a12), b2 = v3(B.a20, B.a21, B.a22);
-    V3 d0 = mul(Di, b0), d1 = mul(Di, b1), d2 = mul(Di, b2);
-    S3 Sc = {A.xx - dot(b0, d0), A.xy - dot(b0, d1), A.xz - dot(b0, d2), A.yy - dot(b1, d1), A.yz - dot(b1, d2), A.zz - dot(b2, d2)};
-    V3 alpha = mul(inv(Sc), rhs);
-    V3 acc = neg(mul(Di, pl + mulT(B, alpha)));
-    GRX_TICK2(19);
-    // ---- pass 3 (root -> leaf): accelerations; the velocity-product terms come from the running parent velocity
-    float qdd[LEG];
-    V3 aa = alpha, al = acc;
-    w = st.ang; v = st.vel;
-#pragma unroll
-    for (int k = 0; k < LEG; ++k) {
-        const float qdk = st.qd[k];
-        const V3 cak = cross(w, Sa[k]) * qdk;
-        const V3 clk = (cross(v, Sa[k]) + cross(w, Ss[k])) * qdk;
-        const V3 pa_ = aa + cak, pl_ = al + clk;
-        const float qd2 = (uu[k] - (dot(Ua[k], pa_) + dot(Ul[k], pl_))) * dinv[k];
-        qdd[k] = qd2;
-        aa = fma3(Sa[k], qd2, pa_);
-        al = fma3(Ss[k], qd2, pl_);
-        w = fma3(Sa[k], qdk, w); v = fma3(Ss[k], qdk, v);
-    }
-    GRX_TICK2(20);
-    // ---- integrate (semi-implicit Euler)
-    V3 lin = acc + cross(st.ang, st.vel);  // classical acceleration of the base origin
-    st.vel = v3(st.vel.x + (lin.x + P.gravity[0]) * dt, st.vel.y + (lin.y + P.gravity[1]) * dt, st.vel.z + (lin.z + P.gravity[2]) * dt);
-    st.ang = fma3(alpha, dt, st.ang);
-#pragma unroll
-    for (int k = 0; k < LEG; ++k) {
-        float vq = fmaf(qdd[k], dt, st.qd[k]);
-        vq = fminf(fmaxf(vq, -C.body[k].vlim), C.body[k].vlim);
-        st.qd[k] = vq;
-        st.q[k] = fmaf(vq, dt, st.q[k]);
-    }
-    st.pos = fma3(st.vel, dt, st.pos);
-    float hx = 0.5f * dt * st.ang.x, hy = 0.5f * dt * st.ang.y, hz = 0.5f * dt * st.ang.z;
-    float x = st.qx, y = st.qy, z = st.qz, ww = st.qw;
-    float nx = x + hx * ww + hy * z - hz * y;
-    float ny = y - hx * z + hy * ww + hz * x;
-    float nz = z + hx * y - hy * x + hz * ww;
-    float nw = ww - hx * x - hy * y - hz * z;
-    float n = grx_rsq(nx * nx + ny * ny + nz * nz + nw * nw);
-    st.qx = nx * n; st.qy = ny * n; st.qz = nz * n; st.qw = nw * n;
-    GRX_TICK2(21);
 }
 
-#else
 // One physics sub-step (gym.simulate(dt), legged_robot_fftai.py:68) for this lane's half of the env.
 // tau: motor torques of this lane's 5 joints.  fk_only: just the kinematics pass (foot frames).
 template <bool HF>
 GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
-                     SubstepOut& out, FootKin& fk_before, long long* tacc) {
+                     SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc) {
     const float dt = P.sim_dt;
     R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
     V3 O = st.pos;
@@ -474,27 +288,7 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
         Rp = R; rho_p = rho; w = wk; v = vk;
     }
     GRX_TICK2(16);
-    // ---- base-lump spheres handled by this lane (per-link netting for termination / collision)
-    V3 f0a = v3(0.f, 0.f, 0.f), f0l = v3(0.f, 0.f, 0.f);
-    if (group_within_reach<8>(&C.sph[0], R0, v3(0.f, 0.f, 0.f), O, LC.hmax)) {
-        V3 Flink = v3(0.f, 0.f, 0.f);
-        const V3 zero = v3(0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const SphC& S = C.sph[i];
-            V3 xr;
-            V3 F = sphere_contact<HF, -1>(P, S, R0, zero, st.ang, st.vel, O, LC.mu, LC.hmax, st, xr);
-            f0a = f0a + cross(xr, F);
-            f0l = f0l + F;
-            Flink = Flink + F;
-            if (S.link_last) {   // uniform per side: net force of one URDF link complete
-                float n2 = dot(Flink, Flink);
-                if ((S.flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) out.term = true;
-                if ((S.flags & GRX_SPH_PENALISE) && n2 > 0.01f) out.pen_count += 1.0f;
-                Flink = zero;
-            }
-        }
-    }
+    // ---- base-lump spheres: computed concurrently by the block's helper wave (base_lump_contacts), fetched below
     GRX_TICK2(17);
     // ---- pass 2: articulated inertias (leaf -> root).  w, v currently = velocity of body LEG-1.
     S3 A = IAk[LEG - 1];
@@ -538,7 +332,13 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     }
     GRX_TICK2(18);
     // ---- base: combine both chains (DPP pair exchange), add the base lump, solve the 6x6
-    pa = pa - f0a; pl = pl - f0l;
+    __syncthreads();   // helper wave: this sub-step's base-lump contact wrench is in LDS (wr: this lane's column)
+    {
+        const V3 f0a = v3(wr[0 * 64], wr[1 * 64], wr[2 * 64]), f0l = v3(wr[3 * 64], wr[4 * 64], wr[5 * 64]);
+        out.term = wr[6 * 64] != 0.f;
+        out.pen_count = wr[7 * 64];
+        pa = pa - f0a; pl = pl - f0l;
+    }
     A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
     pa = pair_sum(pa); pl = pair_sum(pl);
     {
@@ -603,8 +403,6 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     st.qx = nx * n; st.qy = ny * n; st.qz = nz * n; st.qw = nw * n;
     GRX_TICK2(21);
 }
-#endif
-
 // kinematics only: this lane's foot link frame in the current state
 GRX_DEV FootKin foot_kinematics(const SideConst& C, const LaneState& st) {
     R3 Rp = quat_to_R(st.qx, st.qy, st.qz, st.qw);
@@ -725,22 +523,32 @@ GRX_DEV float sum_abs_mask(const float a[LEG], uint32_t mask) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+// Block = 2 waves for the same 32 envs (one env per lane PAIR in each wave):
+//   wave 0 (dynamics wave): the whole env.step() below;
+//   wave 1 (helper wave):   per sub-step, the base-lump contact wrench (base_lump_contacts) from the base state
+//                           wave 0 publishes in LDS -- off the dynamics wave's critical path (the kernel runs one wave
+//                           per SIMD, i.e. at one instruction per 4 cycles, so per-wave instruction count is time).
+// Two s_barriers per sub-step keep the hand-over race-free: #1 state published, #2 wrench published.
 template <bool HF>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_kernel(const KParams P, const float* __restrict__ actions_in,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_kernel(const KParams P, const float* __restrict__ actions_in,
                                                       float delay, long long common_step, const float* __restrict__ noise_in) {
     __shared__ KTables s_tab;
     __shared__ __attribute__((aligned(16))) float s_obs[EPB * GRX_NUM_OBS];
     __shared__ __attribute__((aligned(16))) float s_pri[EPB * GRX_MAX_PRI];
     __shared__ float s_stat[NT + 1];
+    __shared__ float s_base[13 * EPB];   // base state at the start of the current sub-step (dynamics -> helper)
+    __shared__ float s_wr[8 * 64];       // base-lump wrench + termination / collision flags (helper -> dynamics)
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     {   // stage the per-side robot tables (joint tree, inertias, gains, spheres) into LDS
         const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab);
-        for (int i = threadIdx.x; i < (int)(sizeof(KTables) / 4); i += 64) dst[i] = src[i];
-        if (threadIdx.x <= NT) s_stat[threadIdx.x] = 0.f;
+        for (int i = tid; i < (int)(sizeof(KTables) / 4); i += 128) dst[i] = src[i];
+        if (tid <= NT) s_stat[tid] = 0.f;
     }
     __syncthreads();
     const int N = P.N;
-    const int lane = threadIdx.x, el = lane >> 1, side = lane & 1;
+    const int lane = tid & 63, el = lane >> 1, side = lane & 1;
     const int e_raw = blockIdx.x * EPB + el;
     const bool act = e_raw < N;
     const int e = act ? e_raw : N - 1;
@@ -750,6 +558,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int nh = P.nh, npri = P.num_pri_obs;
     const float dtp = P.sim_dt * (float)P.decimation;
     const int j0 = side * LEG;
+
+    if (wv == 1) {
+        // ---- helper wave: base-lump contacts of every sub-step (see base_lump_contacts)
+        const float mu = 0.5f * (P.terrain_friction + P.friction[e]);
+        float hmax = 0.0f;
+        if (HF) {
+            const float x0 = P.root[0 * (size_t)N + e], y0 = P.root[1 * (size_t)N + e];
+            int ci = min(max((int)((x0 + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_rows - 1);
+            int cj = min(max((int)((y0 + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
+            hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
+        }
+        for (int deci = 0; deci < P.decimation; ++deci) {
+            __syncthreads();   // #1
+            const float* b = s_base + el;
+            const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
+            const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
+            const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+            V3 f0a, f0l; bool term; float pen;
+            base_lump_contacts<HF>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen);
+            float* w_ = s_wr + lane;
+            w_[0 * 64] = f0a.x; w_[1 * 64] = f0a.y; w_[2 * 64] = f0a.z;
+            w_[3 * 64] = f0l.x; w_[4 * 64] = f0l.y; w_[5 * 64] = f0l.z;
+            w_[6 * 64] = term ? 1.f : 0.f; w_[7 * 64] = pen;
+            __syncthreads();   // #2
+        }
+    } else {
 
 #ifdef GRX_PROFILE_SECTIONS
     long long tacc[6] = {0, 0, 0, 0, 0, 0};
@@ -815,6 +649,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #ifndef GRX_NO_LICM_BARRIER
         asm volatile("" ::: "memory");
 #endif
+        if (side == 0) {   // publish the base state of this sub-step for the helper wave
+            float* b = s_base + el;
+            b[0 * EPB] = st.pos.x; b[1 * EPB] = st.pos.y; b[2 * EPB] = st.pos.z;
+            b[3 * EPB] = st.qx; b[4 * EPB] = st.qy; b[5 * EPB] = st.qz; b[6 * EPB] = st.qw;
+            b[7 * EPB] = st.vel.x; b[8 * EPB] = st.vel.y; b[9 * EPB] = st.vel.z;
+            b[10 * EPB] = st.ang.x; b[11 * EPB] = st.ang.y; b[12 * EPB] = st.ang.z;
+        }
+        __syncthreads();   // #1
         const bool use_last = (float)deci < delay;
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {  // _compute_torques legged_robot.py:679-715
@@ -823,7 +665,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             t *= LC.strength[k];
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
-        substep<HF>(P, C, LC, st, torque, so, fk, tacc);
+        substep<HF>(P, C, LC, st, torque, so, fk, s_wr + lane, tacc);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
             avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
         }
@@ -1188,7 +1030,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         P.term_contact[e] = term_contact ? 1 : 0;
     }
     GRX_TICK(9);
-    // ---- coalesced AoS output rows: the wave's 32 obs / pri_obs rows are contiguous in HBM
+    }   // dynamics wave
+    // ---- coalesced AoS output rows (both waves): the block's 32 obs / pri_obs rows are contiguous in HBM
     __syncthreads();
     {
         const int e0 = blockIdx.x * EPB;
@@ -1198,17 +1041,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (nenv == EPB) {
             const float4* s4 = reinterpret_cast<const float4*>(s_obs);
             float4* g4 = reinterpret_cast<float4*>(gobs);
-            for (int i = lane; i < EPB * GRX_NUM_OBS / 4; i += 64) g4[i] = s4[i];
+            for (int i = tid; i < EPB * GRX_NUM_OBS / 4; i += 128) g4[i] = s4[i];
         } else
-            for (int i = lane; i < tot; i += 64) gobs[i] = s_obs[i];
+            for (int i = tid; i < tot; i += 128) gobs[i] = s_obs[i];
         float* gpri = P.pri_obs + (size_t)e0 * npri;
         if (npri == GRX_MAX_PRI && nenv == EPB) {
             const float4* s4 = reinterpret_cast<const float4*>(s_pri);
             float4* g4 = reinterpret_cast<float4*>(gpri);
-            for (int i = lane; i < EPB * GRX_MAX_PRI / 4; i += 64) g4[i] = s4[i];
+            for (int i = tid; i < EPB * GRX_MAX_PRI / 4; i += 128) g4[i] = s4[i];
         } else
-            for (int i = lane; i < nenv * npri; i += 64) gpri[i] = s_pri[(i / npri) * GRX_MAX_PRI + (i % npri)];
-        if (lane <= NT) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + lane] = s_stat[lane];
+            for (int i = tid; i < nenv * npri; i += 128) gpri[i] = s_pri[(i / npri) * GRX_MAX_PRI + (i % npri)];
+        if (tid <= NT) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + tid] = s_stat[tid];
     }
     GRX_TICK(10);
 }
@@ -1303,8 +1146,8 @@ __global__ void grx_set_state_kernel(const KParams P, const float* __restrict__ 
 extern "C" void grx_launch_step(const KParams* hP, int N, int heightfield, const float* actions, float delay, long long common_step,
                                 const float* noise, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    if (heightfield) hipLaunchKernelGGL(grx_step_kernel<true>, dim3(nblocks), dim3(64), 0, stream, *hP, actions, delay, common_step, noise);
-    else hipLaunchKernelGGL(grx_step_kernel<false>, dim3(nblocks), dim3(64), 0, stream, *hP, actions, delay, common_step, noise);
+    if (heightfield) hipLaunchKernelGGL(grx_step_kernel<true>, dim3(nblocks), dim3(128), 0, stream, *hP, actions, delay, common_step, noise);
+    else hipLaunchKernelGGL(grx_step_kernel<false>, dim3(nblocks), dim3(128), 0, stream, *hP, actions, delay, common_step, noise);
 }
 extern "C" void grx_launch_finalize(const KParams* hP, int N, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
