@@ -2,7 +2,7 @@
 import sys, ctypes as C, subprocess, os; sys.path.insert(0,'.')
 import numpy as np, torch
 csrc="wiki-grx-gym_amd/csrc"
-flags="-I../../include --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-hip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize -DGRX_PROFILE_SECTIONS"
+flags="-I../../include --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-hip-fp32-correctly-rounded-divide-sqrt -ffinite-math-only -fno-signed-zeros -fno-trapping-math -fassociative-math -fno-slp-vectorize -DGRX_PROFILE_SECTIONS"
 subprocess.run(f"cd {csrc} && hipcc {flags} -shared -o libgrx_hip.so grx_kernels.hip grx_capi.cpp 2>/dev/null", shell=True, check=True)
 from tests.helpers import *
 from wiki_grx_gym_amd.sim import HipSim, load_hip_library

@@ -15,7 +15,7 @@
 #include "grx_rng.h"
 
 extern "C" {
-void grx_launch_step(const KParams* dP, int N, int heightfield, const float* actions, float delay, long long common_step,
+void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                      const float* noise, hipStream_t stream);
 void grx_launch_finalize(const KParams* dP, int N, hipStream_t stream);
 void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream);
@@ -48,6 +48,7 @@ struct grx_sim {
     grx_config cfg;
     int device = 0;
     int N = 0;
+    int waves = 1;         // waves per 32-env block of the step kernel (1, 2 or 4)
     KParams hp;            // launch parameters (passed by value to every kernel)
     KTables tab;           // host image of the device tables
     std::vector<void*> allocs;
@@ -257,6 +258,18 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     KParams& P = s->hp;
     memset(&P, 0, sizeof P);
     P.N = c.num_envs; P.env_offset = c.env_offset; P.total_envs = c.total_envs;
+    {   // waves per block: the step kernel needs a SIMD per wave (512 registers/lane), so use the helper waves only
+        // while blocks x waves still fits the device's SIMDs in one round; GRX_WAVES_PER_BLOCK overrides (tests)
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+        const int simds = prop.multiProcessorCount * 4;
+        const int nblocks = (c.num_envs + grx_envs_per_block() - 1) / grx_envs_per_block();
+        s->waves = nblocks * 4 <= simds ? 4 : (nblocks * 2 <= simds ? 2 : 1);
+        if (const char* w = getenv("GRX_WAVES_PER_BLOCK")) {
+            const int v = atoi(w);
+            if (v == 1 || v == 2 || v == 4) s->waves = v;
+        }
+    }
     const char* dbg = getenv("GRX_PUBLISH_DEBUG");
     P.publish_debug = dbg ? atoi(dbg) : 1;
     P.seed = c.seed;
@@ -503,7 +516,7 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
     }
-    grx_launch_step(&s->hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
+    grx_launch_step(&s->hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
                     (long long)a->common_step_counter, a->noise_uniform, st);
     if (s->timing.enabled) {
         HIP_TRY(hipEventRecord(ev.second, st));

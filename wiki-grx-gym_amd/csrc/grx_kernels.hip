@@ -185,41 +185,94 @@ GRX_DEV R3 joint_unrot_k(const R3& R, float c, float s, int ax) {
 
 // Contacts of the base-lump shapes (torso, head, arms, ... rigidly attached to the floating base) handled by this
 // lane's side, with per-link netting for termination / collision (legged_robot.py:336-353).  They depend only on
-// the base state at the start of the sub-step, so the block's HELPER WAVE evaluates them while the dynamics wave
-// runs the kinematics / articulated-inertia passes; the wrench enters at the base solve.
-template <bool HF>
+// the base state at the start of the sub-step, so with W >= 2 waves per block a HELPER WAVE evaluates them while
+// the dynamics wave runs the kinematics / articulated-inertia passes; the wrench enters at the base solve.
+// MIDBAR: the 4-wave block layout has a barrier (#2) in the middle of the sub-step; the helper passes it half-way.
+template <bool HF, bool MIDBAR>
 GRX_DEV void base_lump_contacts(const KParams& P, const SideConst& C, const R3& R0, V3 O, V3 ang, V3 vel, float mu, float hmax,
                                 V3& f0a, V3& f0l, bool& term, float& pen_count) {
     f0a = v3(0.f, 0.f, 0.f); f0l = v3(0.f, 0.f, 0.f);
     term = false; pen_count = 0.f;
     LaneState dummy;   // anchors are only touched by foot spheres (SLOT >= 0)
     dummy.anchor_on = 0;
-    if (group_within_reach<8>(&C.sph[0], R0, v3(0.f, 0.f, 0.f), O, hmax)) {
-        V3 Flink = v3(0.f, 0.f, 0.f);
-        const V3 zero = v3(0.f, 0.f, 0.f);
+    const bool reach = group_within_reach<8>(&C.sph[0], R0, v3(0.f, 0.f, 0.f), O, hmax);
+    V3 Flink = v3(0.f, 0.f, 0.f);
+    const V3 zero = v3(0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const SphC& S = C.sph[i];
-            V3 xr;
-            V3 F = sphere_contact<HF, -1>(P, S, R0, zero, ang, vel, O, mu, hmax, dummy, xr);
-            f0a = f0a + cross(xr, F);
-            f0l = f0l + F;
-            Flink = Flink + F;
-            if (S.link_last) {   // uniform per side: net force of one URDF link complete
-                float n2 = dot(Flink, Flink);
-                if ((S.flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term = true;
-                if ((S.flags & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.0f;
-                Flink = zero;
+    for (int half = 0; half < 2; ++half) {
+        if (reach) {
+#pragma unroll
+            for (int i = half * 4; i < half * 4 + 4; ++i) {
+                const SphC& S = C.sph[i];
+                V3 xr;
+                V3 F = sphere_contact<HF, -1>(P, S, R0, zero, ang, vel, O, mu, hmax, dummy, xr);
+                f0a = f0a + cross(xr, F);
+                f0l = f0l + F;
+                Flink = Flink + F;
+                if (S.link_last) {   // uniform per side: net force of one URDF link complete
+                    float n2 = dot(Flink, Flink);
+                    if ((S.flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term = true;
+                    if ((S.flags & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.0f;
+                    Flink = zero;
+                }
             }
+        }
+        if (MIDBAR && half == 0) __syncthreads();   // #2
+    }
+}
+
+// running frame of a chain body during an outward walk: rotation, origin relative to the base origin O,
+// angular velocity, O-referenced linear velocity (world axes)
+struct ChainKin { R3 R; V3 rho, w, v; };
+
+GRX_DEV void chain_step(const SideConst& C, int k, float q, float qd, ChainKin& K) {
+    K.rho = K.rho + rot(K.R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+    float sn, cs;
+    grx_sincos(q, sn, cs);
+    K.R = joint_rot_k(K.R, cs, sn, kAxis[k]);
+    const V3 a = axis_k(K.R, kAxis[k]);
+    const V3 s = cross(K.rho, a);
+    K.w = fma3(a, qd, K.w); K.v = fma3(s, qd, K.v);
+}
+
+// the four anchored spheres of this lane's foot (chain body LEG-1): wrench about O + anchor update
+template <bool HF>
+GRX_DEV void foot_contacts(const KParams& P, const SideConst& C, const ChainKin& K, V3 O, float mu, float hmax, LaneState& st,
+                           V3& fa, V3& fl) {
+    fa = v3(0.f, 0.f, 0.f); fl = v3(0.f, 0.f, 0.f);
+    constexpr int o = kSphOff[LEG - 1];
+    if (group_within_reach<4>(&C.sph[o], K.R, K.rho, O, hmax)) {
+        V3 xr, F;
+        F = sphere_contact<HF, 0>(P, C.sph[o + 0], K.R, K.rho, K.w, K.v, O, mu, hmax, st, xr); fa = fa + cross(xr, F); fl = fl + F;
+        F = sphere_contact<HF, 1>(P, C.sph[o + 1], K.R, K.rho, K.w, K.v, O, mu, hmax, st, xr); fa = fa + cross(xr, F); fl = fl + F;
+        F = sphere_contact<HF, 2>(P, C.sph[o + 2], K.R, K.rho, K.w, K.v, O, mu, hmax, st, xr); fa = fa + cross(xr, F); fl = fl + F;
+        F = sphere_contact<HF, 3>(P, C.sph[o + 3], K.R, K.rho, K.w, K.v, O, mu, hmax, st, xr); fa = fa + cross(xr, F); fl = fl + F;
+    } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
+}
+
+// the two (unanchored) spheres of chain body k (thigh_pitch / shank)
+template <bool HF>
+GRX_DEV void link_contacts(const KParams& P, const SideConst& C, int k, const ChainKin& K, V3 O, float mu, float hmax, V3& fa, V3& fl) {
+    fa = v3(0.f, 0.f, 0.f); fl = v3(0.f, 0.f, 0.f);
+    LaneState dummy;
+    dummy.anchor_on = 0;
+    if (group_within_reach<2>(&C.sph[kSphOff[k]], K.R, K.rho, O, hmax)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            V3 xr;
+            V3 F = sphere_contact<HF, -1>(P, C.sph[kSphOff[k] + i], K.R, K.rho, K.w, K.v, O, mu, hmax, dummy, xr);
+            fa = fa + cross(xr, F); fl = fl + F;
         }
     }
 }
 
 // One physics sub-step (gym.simulate(dt), legged_robot_fftai.py:68) for this lane's half of the env.
 // tau: motor torques of this lane's 5 joints.  fk_only: just the kinematics pass (foot frames).
-template <bool HF>
+// W = waves per block: 1 = everything inline; 2 = base-lump contacts come from the helper wave through `wr`;
+// 4 = additionally the chain-body contacts (feet: wave 2, thigh/shank: wave 3) come through `wc`.
+template <bool HF, int W>
 GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
-                     SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc) {
+                     SubstepOut& out, FootKin& fk_before, const float* wr, const float* wc, long long* tacc) {
     const float dt = P.sim_dt;
     R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
     V3 O = st.pos;
@@ -258,25 +311,12 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
         V3 pa = cross(wk, ha) + cross(vk, hl);
         V3 pl = cross(wk, hl);
         // contacts of the shapes carried by chain body k (thigh_pitch: 2, shank: 2, foot: 4 anchored spheres)
-        if (kSphCnt[k] == 2 && group_within_reach<2>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                V3 xr;
-                V3 F = sphere_contact<HF, -1>(P, C.sph[kSphOff[k] + i], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
-                pa = pa - cross(xr, F); pl = pl - F;
-            }
-        } else if (kSphCnt[k] == 4) {
-          if (group_within_reach<4>(&C.sph[kSphOff[k]], R, rho, O, LC.hmax)) {
-            V3 xr, F;
-            F = sphere_contact<HF, 0>(P, C.sph[kSphOff[k] + 0], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
-            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
-            F = sphere_contact<HF, 1>(P, C.sph[kSphOff[k] + 1], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
-            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
-            F = sphere_contact<HF, 2>(P, C.sph[kSphOff[k] + 2], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
-            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
-            F = sphere_contact<HF, 3>(P, C.sph[kSphOff[k] + 3], R, rho, wk, vk, O, LC.mu, LC.hmax, st, xr);
-            pa = pa - cross(xr, F); pl = pl - F; out.foot_force = out.foot_force + F;
-          } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
+        if (W < 4 && kSphCnt[k] > 0) {
+            ChainKin K = {R, rho, wk, vk};
+            V3 fa, fl;
+            if (kSphCnt[k] == 2) link_contacts<HF>(P, C, k, K, O, LC.mu, LC.hmax, fa, fl);
+            else { foot_contacts<HF>(P, C, K, O, LC.mu, LC.hmax, st, fa, fl); out.foot_force = fl; }
+            pa = pa - fa; pl = pl - fl;
         }
         if (k == LEG - 1) {  // foot link frame BEFORE this sub-step's integration
             V3 fr = rho + rot(R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
@@ -287,8 +327,17 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
         Sa[k] = a; Ss[k] = s; IAk[k] = A; Ih[k] = h; pA[k] = pa; pL[k] = pl;
         Rp = R; rho_p = rho; w = wk; v = vk;
     }
+    if (W >= 4) {   // chain-body contact wrenches of this sub-step from the helper waves
+        __syncthreads();   // #2
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float* c = wc + b * 6 * 64;
+            const V3 fa = v3(c[0 * 64], c[1 * 64], c[2 * 64]), fl = v3(c[3 * 64], c[4 * 64], c[5 * 64]);
+            pA[2 + b] = pA[2 + b] - fa; pL[2 + b] = pL[2 + b] - fl;
+            if (b == 2) out.foot_force = fl;
+        }
+    }
     GRX_TICK2(16);
-    // ---- base-lump spheres: computed concurrently by the block's helper wave (base_lump_contacts), fetched below
     GRX_TICK2(17);
     // ---- pass 2: articulated inertias (leaf -> root).  w, v currently = velocity of body LEG-1.
     S3 A = IAk[LEG - 1];
@@ -332,11 +381,15 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     }
     GRX_TICK2(18);
     // ---- base: combine both chains (DPP pair exchange), add the base lump, solve the 6x6
-    __syncthreads();   // helper wave: this sub-step's base-lump contact wrench is in LDS (wr: this lane's column)
-    {
+    if (W >= 2) {
+        __syncthreads();   // #3: the helper wave's base-lump contact wrench of this sub-step is in LDS (wr: this lane's column)
         const V3 f0a = v3(wr[0 * 64], wr[1 * 64], wr[2 * 64]), f0l = v3(wr[3 * 64], wr[4 * 64], wr[5 * 64]);
         out.term = wr[6 * 64] != 0.f;
         out.pen_count = wr[7 * 64];
+        pa = pa - f0a; pl = pl - f0l;
+    } else {
+        V3 f0a, f0l;
+        base_lump_contacts<HF, false>(P, C, R0, O, st.ang, st.vel, LC.mu, LC.hmax, f0a, f0l, out.term, out.pen_count);
         pa = pa - f0a; pl = pl - f0l;
     }
     A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
@@ -523,27 +576,34 @@ GRX_DEV float sum_abs_mask(const float a[LEG], uint32_t mask) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
-// Block = 2 waves for the same 32 envs (one env per lane PAIR in each wave):
-//   wave 0 (dynamics wave): the whole env.step() below;
-//   wave 1 (helper wave):   per sub-step, the base-lump contact wrench (base_lump_contacts) from the base state
-//                           wave 0 publishes in LDS -- off the dynamics wave's critical path (the kernel runs one wave
-//                           per SIMD, i.e. at one instruction per 4 cycles, so per-wave instruction count is time).
-// Two s_barriers per sub-step keep the hand-over race-free: #1 state published, #2 wrench published.
-template <bool HF>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_kernel(const KParams P, const float* __restrict__ actions_in,
+// Block = W waves (W = 1, 2 or 4, chosen at launch so that every wave gets a SIMD to itself) for the same 32 envs,
+// one env per lane PAIR in each wave.  The kernel runs one wave per SIMD, i.e. at one instruction per 4 cycles, so
+// a wave's instruction count IS its time; the helper waves take the contact work off the dynamics wave:
+//   wave 0 (dynamics): the whole env.step() below;
+//   wave 1 (W >= 2):   per sub-step, the base-lump contact wrench (base_lump_contacts);
+//   wave 2 (W == 4):   per sub-step, own outward walk to the foot + the 4 anchored foot spheres (owns the anchors);
+//   wave 3 (W == 4):   per sub-step, own outward walk to the shank + thigh / shank spheres.
+// Hand-over through LDS with block barriers per sub-step: #1 state published, #2 chain-body wrenches published
+// (W == 4), #3 base-lump wrench published; #4 after the loop: final friction anchors published (W == 4).
+template <bool HF, int W>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_kernel(const KParams P, const float* __restrict__ actions_in,
                                                       float delay, long long common_step, const float* __restrict__ noise_in) {
+    constexpr int NTHR = 64 * W;
     __shared__ KTables s_tab;
     __shared__ __attribute__((aligned(16))) float s_obs[EPB * GRX_NUM_OBS];
     __shared__ __attribute__((aligned(16))) float s_pri[EPB * GRX_MAX_PRI];
     __shared__ float s_stat[NT + 1];
-    __shared__ float s_base[13 * EPB];   // base state at the start of the current sub-step (dynamics -> helper)
-    __shared__ float s_wr[8 * 64];       // base-lump wrench + termination / collision flags (helper -> dynamics)
+    __shared__ float s_base[13 * EPB];   // base state at the start of the current sub-step (dynamics -> helpers)
+    __shared__ float s_q[2 * LEG * 64];  // q, qd of every lane's leg at the start of the current sub-step (W == 4)
+    __shared__ float s_wr[8 * 64];       // base-lump wrench + termination / collision flags (wave 1 -> dynamics)
+    __shared__ float s_wc[18 * 64];      // wrenches on chain bodies 2, 3 (wave 3) and 4 (wave 2) -> dynamics
+    __shared__ float s_anch[9 * 64];     // final friction anchors of the step (wave 2 -> dynamics)
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     {   // stage the per-side robot tables (joint tree, inertias, gains, spheres) into LDS
         const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab);
-        for (int i = tid; i < (int)(sizeof(KTables) / 4); i += 128) dst[i] = src[i];
+        for (int i = tid; i < (int)(sizeof(KTables) / 4); i += NTHR) dst[i] = src[i];
         if (tid <= NT) s_stat[tid] = 0.f;
     }
     __syncthreads();
@@ -559,8 +619,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float dtp = P.sim_dt * (float)P.decimation;
     const int j0 = side * LEG;
 
-    if (wv == 1) {
-        // ---- helper wave: base-lump contacts of every sub-step (see base_lump_contacts)
+    if (W >= 2 && wv != 0) {
+        // ---- helper waves
         const float mu = 0.5f * (P.terrain_friction + P.friction[e]);
         float hmax = 0.0f;
         if (HF) {
@@ -569,19 +629,64 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             int cj = min(max((int)((y0 + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
             hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
         }
+        LaneState hs;   // wave 2: the friction anchors of this lane's foot
+        hs.anchor_on = 0;
+        if (W == 4 && wv == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hs.ax[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 0) * N + e];
+                hs.ay[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e];
+                if (P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] != 0.0f) hs.anchor_on |= (1u << i);
+            }
+        }
         for (int deci = 0; deci < P.decimation; ++deci) {
             __syncthreads();   // #1
             const float* b = s_base + el;
             const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
             const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
             const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
-            V3 f0a, f0l; bool term; float pen;
-            base_lump_contacts<HF>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen);
-            float* w_ = s_wr + lane;
-            w_[0 * 64] = f0a.x; w_[1 * 64] = f0a.y; w_[2 * 64] = f0a.z;
-            w_[3 * 64] = f0l.x; w_[4 * 64] = f0l.y; w_[5 * 64] = f0l.z;
-            w_[6 * 64] = term ? 1.f : 0.f; w_[7 * 64] = pen;
-            __syncthreads();   // #2
+            if (wv == 1) {
+                V3 f0a, f0l; bool term; float pen;
+                base_lump_contacts<HF, W == 4>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen);   // passes #2 when W == 4
+                float* w_ = s_wr + lane;
+                w_[0 * 64] = f0a.x; w_[1 * 64] = f0a.y; w_[2 * 64] = f0a.z;
+                w_[3 * 64] = f0l.x; w_[4 * 64] = f0l.y; w_[5 * 64] = f0l.z;
+                w_[6 * 64] = term ? 1.f : 0.f; w_[7 * 64] = pen;
+            } else {   // W == 4: waves 2 and 3 walk the chain themselves and evaluate the chain-body spheres
+                ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
+                const float* qs = s_q + lane;
+                float* c_ = s_wc + lane;
+                if (wv == 2) {
+#pragma unroll
+                    for (int k = 0; k < LEG; ++k) chain_step(C, k, qs[k * 64], qs[(LEG + k) * 64], K);
+                    V3 fa, fl;
+                    foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl);
+                    c_[12 * 64] = fa.x; c_[13 * 64] = fa.y; c_[14 * 64] = fa.z; c_[15 * 64] = fl.x; c_[16 * 64] = fl.y; c_[17 * 64] = fl.z;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < LEG - 1; ++k) {
+                        chain_step(C, k, qs[k * 64], qs[(LEG + k) * 64], K);
+                        if (kSphCnt[k] == 2) {
+                            V3 fa, fl;
+                            link_contacts<HF>(P, C, k, K, O, mu, hmax, fa, fl);
+                            const int o = (k - 2) * 6;
+                            c_[(o + 0) * 64] = fa.x; c_[(o + 1) * 64] = fa.y; c_[(o + 2) * 64] = fa.z;
+                            c_[(o + 3) * 64] = fl.x; c_[(o + 4) * 64] = fl.y; c_[(o + 5) * 64] = fl.z;
+                        }
+                    }
+                }
+                __syncthreads();   // #2
+            }
+            __syncthreads();   // #3
+        }
+        if (W == 4) {
+            if (wv == 2) {
+                float* a_ = s_anch + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a_[i * 64] = hs.ax[i]; a_[(4 + i) * 64] = hs.ay[i]; }
+                a_[8 * 64] = __uint_as_float(hs.anchor_on);
+            }
+            __syncthreads();   // #4
         }
     } else {
 
@@ -649,14 +754,18 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifndef GRX_NO_LICM_BARRIER
         asm volatile("" ::: "memory");
 #endif
-        if (side == 0) {   // publish the base state of this sub-step for the helper wave
+        if (W >= 2 && side == 0) {   // publish the base state of this sub-step for the helper waves
             float* b = s_base + el;
             b[0 * EPB] = st.pos.x; b[1 * EPB] = st.pos.y; b[2 * EPB] = st.pos.z;
             b[3 * EPB] = st.qx; b[4 * EPB] = st.qy; b[5 * EPB] = st.qz; b[6 * EPB] = st.qw;
             b[7 * EPB] = st.vel.x; b[8 * EPB] = st.vel.y; b[9 * EPB] = st.vel.z;
             b[10 * EPB] = st.ang.x; b[11 * EPB] = st.ang.y; b[12 * EPB] = st.ang.z;
         }
-        __syncthreads();   // #1
+        if (W == 4) {
+#pragma unroll
+            for (int k = 0; k < LEG; ++k) { s_q[k * 64 + lane] = st.q[k]; s_q[(LEG + k) * 64 + lane] = st.qd[k]; }
+        }
+        if (W >= 2) __syncthreads();   // #1
         const bool use_last = (float)deci < delay;
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {  // _compute_torques legged_robot.py:679-715
@@ -665,11 +774,18 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             t *= LC.strength[k];
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
-        substep<HF>(P, C, LC, st, torque, so, fk, s_wr + lane, tacc);
+        substep<HF, W>(P, C, LC, st, torque, so, fk, s_wr + lane, s_wc + lane, tacc);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
             avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
         }
         avg_force += grx_sqrt(dot(so.foot_force, so.foot_force));
+    }
+    if (W == 4) {   // the foot wave owned the friction anchors during the sub-steps
+        __syncthreads();   // #4
+        const float* a_ = s_anch + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { st.ax[i] = a_[i * 64]; st.ay[i] = a_[(4 + i) * 64]; }
+        st.anchor_on = __float_as_uint(a_[8 * 64]);
     }
     GRX_TICK(2);
 #ifdef GRX_PROFILE_SECTIONS
@@ -1031,7 +1147,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     GRX_TICK(9);
     }   // dynamics wave
-    // ---- coalesced AoS output rows (both waves): the block's 32 obs / pri_obs rows are contiguous in HBM
+    // ---- coalesced AoS output rows (all waves): the block's 32 obs / pri_obs rows are contiguous in HBM
     __syncthreads();
     {
         const int e0 = blockIdx.x * EPB;
@@ -1041,16 +1157,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (nenv == EPB) {
             const float4* s4 = reinterpret_cast<const float4*>(s_obs);
             float4* g4 = reinterpret_cast<float4*>(gobs);
-            for (int i = tid; i < EPB * GRX_NUM_OBS / 4; i += 128) g4[i] = s4[i];
+            for (int i = tid; i < EPB * GRX_NUM_OBS / 4; i += NTHR) g4[i] = s4[i];
         } else
-            for (int i = tid; i < tot; i += 128) gobs[i] = s_obs[i];
+            for (int i = tid; i < tot; i += NTHR) gobs[i] = s_obs[i];
         float* gpri = P.pri_obs + (size_t)e0 * npri;
         if (npri == GRX_MAX_PRI && nenv == EPB) {
             const float4* s4 = reinterpret_cast<const float4*>(s_pri);
             float4* g4 = reinterpret_cast<float4*>(gpri);
-            for (int i = tid; i < EPB * GRX_MAX_PRI / 4; i += 128) g4[i] = s4[i];
+            for (int i = tid; i < EPB * GRX_MAX_PRI / 4; i += NTHR) g4[i] = s4[i];
         } else
-            for (int i = tid; i < nenv * npri; i += 128) gpri[i] = s_pri[(i / npri) * GRX_MAX_PRI + (i % npri)];
+            for (int i = tid; i < nenv * npri; i += NTHR) gpri[i] = s_pri[(i / npri) * GRX_MAX_PRI + (i % npri)];
         if (tid <= NT) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + tid] = s_stat[tid];
     }
     GRX_TICK(10);
@@ -1143,11 +1259,14 @@ __global__ void grx_set_state_kernel(const KParams P, const float* __restrict__ 
 }
 
 // host-callable launchers (grx_capi.cpp is compiled by hipcc too; kept separate for readability)
-extern "C" void grx_launch_step(const KParams* hP, int N, int heightfield, const float* actions, float delay, long long common_step,
+// waves: waves per 32-env block (1, 2 or 4; grx_capi.cpp picks the largest that still gives every wave its own SIMD)
+extern "C" void grx_launch_step(const KParams* hP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                                 const float* noise, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    if (heightfield) hipLaunchKernelGGL(grx_step_kernel<true>, dim3(nblocks), dim3(128), 0, stream, *hP, actions, delay, common_step, noise);
-    else hipLaunchKernelGGL(grx_step_kernel<false>, dim3(nblocks), dim3(128), 0, stream, *hP, actions, delay, common_step, noise);
+#define GRX_LAUNCH_STEP(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, *hP, actions, delay, common_step, noise)
+    if (heightfield) { if (waves == 4) GRX_LAUNCH_STEP(true, 4); else if (waves == 2) GRX_LAUNCH_STEP(true, 2); else GRX_LAUNCH_STEP(true, 1); }
+    else { if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
+#undef GRX_LAUNCH_STEP
 }
 extern "C" void grx_launch_finalize(const KParams* hP, int N, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
