@@ -24,6 +24,7 @@ for terrain in ("plane","heightfield"):
     full=np.array(buf[:],dtype=np.int64).reshape(128,32)[:nb]
     a=full[:,:11]
     print('   substep sections (sum over 10 substeps):', dict(zip(['pass1+chain contacts','base spheres','pass2','base solve','pass3','integrate'], np.median(full[:,16:22],axis=0).astype(int).tolist())))
+    print('   helper waves (idle waiting for state, total) cycles:', {f"wave{w}": np.median(full[:,22+2*w:24+2*w],axis=0).astype(int).tolist() for w in (1,2,3)})
     d=np.diff(a,axis=1)
     print(terrain, "total cycles median", np.median(a[:,10]-a[:,0]))
     for n,v in zip(names, np.median(d,axis=0)): print(f"   {n:16s} {v:9.0f} ticks")

@@ -268,11 +268,11 @@ GRX_DEV void link_contacts(const KParams& P, const SideConst& C, int k, const Ch
 
 // One physics sub-step (gym.simulate(dt), legged_robot_fftai.py:68) for this lane's half of the env.
 // tau: motor torques of this lane's 5 joints.  fk_only: just the kinematics pass (foot frames).
-// W = waves per block: 1 = everything inline; 2 = base-lump contacts come from the helper wave through `wr`;
-// 4 = additionally the chain-body contacts (feet: wave 2, thigh/shank: wave 3) come through `wc`.
+// W = waves per block: 1 = everything inline; 2 = the base-lump contacts come from the helper wave through `wr`
+// (W == 4 uses the producer/consumer pipeline of grx_wavepipe.h instead of this function).
 template <bool HF, int W>
 GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
-                     SubstepOut& out, FootKin& fk_before, const float* wr, const float* wc, long long* tacc) {
+                     SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc) {
     const float dt = P.sim_dt;
     R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
     V3 O = st.pos;
@@ -311,7 +311,7 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
         V3 pa = cross(wk, ha) + cross(vk, hl);
         V3 pl = cross(wk, hl);
         // contacts of the shapes carried by chain body k (thigh_pitch: 2, shank: 2, foot: 4 anchored spheres)
-        if (W < 4 && kSphCnt[k] > 0) {
+        if (kSphCnt[k] > 0) {
             ChainKin K = {R, rho, wk, vk};
             V3 fa, fl;
             if (kSphCnt[k] == 2) link_contacts<HF>(P, C, k, K, O, LC.mu, LC.hmax, fa, fl);
@@ -326,16 +326,6 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
         }
         Sa[k] = a; Ss[k] = s; IAk[k] = A; Ih[k] = h; pA[k] = pa; pL[k] = pl;
         Rp = R; rho_p = rho; w = wk; v = vk;
-    }
-    if (W >= 4) {   // chain-body contact wrenches of this sub-step from the helper waves
-        __syncthreads();   // #2
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const float* c = wc + b * 6 * 64;
-            const V3 fa = v3(c[0 * 64], c[1 * 64], c[2 * 64]), fl = v3(c[3 * 64], c[4 * 64], c[5 * 64]);
-            pA[2 + b] = pA[2 + b] - fa; pL[2 + b] = pL[2 + b] - fl;
-            if (b == 2) out.foot_force = fl;
-        }
     }
     GRX_TICK2(16);
     GRX_TICK2(17);
@@ -456,6 +446,8 @@ GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, 
     st.qx = nx * n; st.qy = ny * n; st.qz = nz * n; st.qw = nw * n;
     GRX_TICK2(21);
 }
+#include "grx_wavepipe.h"
+
 // kinematics only: this lane's foot link frame in the current state
 GRX_DEV FootKin foot_kinematics(const SideConst& C, const LaneState& st) {
     R3 Rp = quat_to_R(st.qx, st.qy, st.qz, st.qw);
@@ -578,13 +570,10 @@ GRX_DEV float sum_abs_mask(const float a[LEG], uint32_t mask) {
 // ------------------------------------------------------------------------------------------
 // Block = W waves (W = 1, 2 or 4, chosen at launch so that every wave gets a SIMD to itself) for the same 32 envs,
 // one env per lane PAIR in each wave.  The kernel runs one wave per SIMD, i.e. at one instruction per 4 cycles, so
-// a wave's instruction count IS its time; the helper waves take the contact work off the dynamics wave:
-//   wave 0 (dynamics): the whole env.step() below;
-//   wave 1 (W >= 2):   per sub-step, the base-lump contact wrench (base_lump_contacts);
-//   wave 2 (W == 4):   per sub-step, own outward walk to the foot + the 4 anchored foot spheres (owns the anchors);
-//   wave 3 (W == 4):   per sub-step, own outward walk to the shank + thigh / shank spheres.
-// Hand-over through LDS with block barriers per sub-step: #1 state published, #2 chain-body wrenches published
-// (W == 4), #3 base-lump wrench published; #4 after the loop: final friction anchors published (W == 4).
+// a wave's instruction count IS its time:
+//   W == 1: one wave does everything (large batches: every SIMD is busy with its own envs anyway);
+//   W == 2: wave 1 computes the base-lump contact wrench of every sub-step (two block barriers per sub-step);
+//   W == 4: the four-wave producer/consumer pipeline of grx_wavepipe.h (sequence counters in LDS).
 template <bool HF, int W>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_kernel(const KParams P, const float* __restrict__ actions_in,
                                                       float delay, long long common_step, const float* __restrict__ noise_in) {
@@ -594,10 +583,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __shared__ __attribute__((aligned(16))) float s_pri[EPB * GRX_MAX_PRI];
     __shared__ float s_stat[NT + 1];
     __shared__ float s_base[13 * EPB];   // base state at the start of the current sub-step (dynamics -> helpers)
-    __shared__ float s_q[2 * LEG * 64];  // q, qd of every lane's leg at the start of the current sub-step (W == 4)
-    __shared__ float s_wr[8 * 64];       // base-lump wrench + termination / collision flags (wave 1 -> dynamics)
-    __shared__ float s_wc[18 * 64];      // wrenches on chain bodies 2, 3 (wave 3) and 4 (wave 2) -> dynamics
-    __shared__ float s_anch[9 * 64];     // final friction anchors of the step (wave 2 -> dynamics)
+    __shared__ float s_wr[8 * 64];       // base-lump wrench + termination / collision flags (helper -> dynamics)
+    // W == 4 pipeline buffers (grx_wavepipe.h)
+    __shared__ float s_q[W == 4 ? 2 * LEG * 64 : 1];
+    __shared__ float s_rec[W == 4 ? LEG * REC * 64 : 1];
+    __shared__ float s_rec0[W == 4 ? 21 * 64 : 1];
+    __shared__ float s_wc[W == 4 ? 21 * 64 : 1];
+    __shared__ float s_pb[W == 4 ? (LEG * PBR + 6) * 64 : 1];
+    __shared__ float s_anch[W == 4 ? 9 * 64 : 1];     // final friction anchors of the step (wave 2 -> wave 0)
+    __shared__ int s_flag[FL_COUNT];
+    const PipeLds L = {s_base, s_q, s_rec, s_rec0, s_wc, s_pb, s_wr, s_flag};
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     {   // stage the per-side robot tables (joint tree, inertias, gains, spheres) into LDS
@@ -605,6 +600,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab);
         for (int i = tid; i < (int)(sizeof(KTables) / 4); i += NTHR) dst[i] = src[i];
         if (tid <= NT) s_stat[tid] = 0.f;
+        if (tid < FL_COUNT) s_flag[tid] = 0;
     }
     __syncthreads();
     const int N = P.N;
@@ -629,64 +625,46 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             int cj = min(max((int)((y0 + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
             hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
         }
-        LaneState hs;   // wave 2: the friction anchors of this lane's foot
+        LaneState hs;   // W == 4, wave 2: the friction anchors of this lane's foot
         hs.anchor_on = 0;
-        if (W == 4 && wv == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                hs.ax[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 0) * N + e];
-                hs.ay[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e];
-                if (P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] != 0.0f) hs.anchor_on |= (1u << i);
-            }
-        }
-        for (int deci = 0; deci < P.decimation; ++deci) {
-            __syncthreads();   // #1
-            const float* b = s_base + el;
-            const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
-            const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
-            const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
-            if (wv == 1) {
-                V3 f0a, f0l; bool term; float pen;
-                base_lump_contacts<HF, W == 4>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen);   // passes #2 when W == 4
-                float* w_ = s_wr + lane;
-                w_[0 * 64] = f0a.x; w_[1 * 64] = f0a.y; w_[2 * 64] = f0a.z;
-                w_[3 * 64] = f0l.x; w_[4 * 64] = f0l.y; w_[5 * 64] = f0l.z;
-                w_[6 * 64] = term ? 1.f : 0.f; w_[7 * 64] = pen;
-            } else {   // W == 4: waves 2 and 3 walk the chain themselves and evaluate the chain-body spheres
-                ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
-                const float* qs = s_q + lane;
-                float* c_ = s_wc + lane;
-                if (wv == 2) {
-#pragma unroll
-                    for (int k = 0; k < LEG; ++k) chain_step(C, k, qs[k * 64], qs[(LEG + k) * 64], K);
-                    V3 fa, fl;
-                    foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl);
-                    c_[12 * 64] = fa.x; c_[13 * 64] = fa.y; c_[14 * 64] = fa.z; c_[15 * 64] = fl.x; c_[16 * 64] = fl.y; c_[17 * 64] = fl.z;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < LEG - 1; ++k) {
-                        chain_step(C, k, qs[k * 64], qs[(LEG + k) * 64], K);
-                        if (kSphCnt[k] == 2) {
-                            V3 fa, fl;
-                            link_contacts<HF>(P, C, k, K, O, mu, hmax, fa, fl);
-                            const int o = (k - 2) * 6;
-                            c_[(o + 0) * 64] = fa.x; c_[(o + 1) * 64] = fa.y; c_[(o + 2) * 64] = fa.z;
-                            c_[(o + 3) * 64] = fl.x; c_[(o + 4) * 64] = fl.y; c_[(o + 5) * 64] = fl.z;
-                        }
-                    }
-                }
-                __syncthreads();   // #2
-            }
-            __syncthreads();   // #3
-        }
         if (W == 4) {
-            if (wv == 2) {
+            const float bm = P.base_m[e];
+            const V3 bc = v3(P.base_c[e], P.base_c[(size_t)N + e], P.base_c[2 * (size_t)N + e]);
+            const S3 bI = {P.base_I[e], P.base_I[(size_t)N + e], P.base_I[2 * (size_t)N + e],
+                           P.base_I[3 * (size_t)N + e], P.base_I[4 * (size_t)N + e], P.base_I[5 * (size_t)N + e]};
+            if (wv == 1) {
+                iwave_loop(P, C, bm, bc, bI, L, lane, el);
+            } else if (wv == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    hs.ax[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 0) * N + e];
+                    hs.ay[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e];
+                    if (P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] != 0.0f) hs.anchor_on |= (1u << i);
+                }
+                chain_contact_loop<HF>(P, C, mu, hmax, hs, L, lane, el);
                 float* a_ = s_anch + lane;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { a_[i * 64] = hs.ax[i]; a_[(4 + i) * 64] = hs.ay[i]; }
                 a_[8 * 64] = __uint_as_float(hs.anchor_on);
+            } else {
+                base_contact_loop<HF>(P, C, mu, hmax, bm, bc, bI, L, lane, el);
             }
-            __syncthreads();   // #4
+            __syncthreads();   // final friction anchors published
+        } else {
+            for (int deci = 0; deci < P.decimation; ++deci) {
+                __syncthreads();   // #1: base state published
+                const float* b = s_base + el;
+                const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
+                const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
+                const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+                V3 f0a, f0l; bool term; float pen;
+                base_lump_contacts<HF, false>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen);
+                float* w_ = s_wr + lane;
+                w_[0 * 64] = f0a.x; w_[1 * 64] = f0a.y; w_[2 * 64] = f0a.z;
+                w_[3 * 64] = f0l.x; w_[4 * 64] = f0l.y; w_[5 * 64] = f0l.z;
+                w_[6 * 64] = term ? 1.f : 0.f; w_[7 * 64] = pen;
+                __syncthreads();   // #3: wrench published
+            }
         }
     } else {
 
@@ -765,7 +743,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #pragma unroll
             for (int k = 0; k < LEG; ++k) { s_q[k * 64 + lane] = st.q[k]; s_q[(LEG + k) * 64 + lane] = st.qd[k]; }
         }
-        if (W >= 2) __syncthreads();   // #1
+        if (W == 4) flag_set(s_flag + FL_STATE, deci + 1, lane);
+        else if (W == 2) __syncthreads();   // #1
         const bool use_last = (float)deci < delay;
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {  // _compute_torques legged_robot.py:679-715
@@ -774,14 +753,15 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             t *= LC.strength[k];
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
-        substep<HF, W>(P, C, LC, st, torque, so, fk, s_wr + lane, s_wc + lane, tacc);
+        if (W == 4) substep_p<HF>(P, C, LC, st, torque, so, fk, L, lane, deci, tacc);
+        else substep<HF, W>(P, C, LC, st, torque, so, fk, s_wr + lane, tacc);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
             avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
         }
         avg_force += grx_sqrt(dot(so.foot_force, so.foot_force));
     }
     if (W == 4) {   // the foot wave owned the friction anchors during the sub-steps
-        __syncthreads();   // #4
+        __syncthreads();   // final friction anchors published
         const float* a_ = s_anch + lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { st.ax[i] = a_[i * 64]; st.ay[i] = a_[(4 + i) * 64]; }
