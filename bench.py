@@ -137,6 +137,18 @@ def main():
 
     if rank == 0:
         bytes_per = B_ROUGH if args.terrain == "rough" else B_FLAT
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this very workload (separate FETCH_SIZE /
+        # WRITE_SIZE runs, tools/collect_profiles.sh); bench.py cannot host the profiler itself.  Raw counter sum:
+        # FETCH_SIZE is a lower bound on gfx950 (MI355X_MICROARCH.md), see the note inside the file.
+        traffic, traffic_src = None, None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_rough4096.json")
+        if args.terrain == "rough" and n_local == 4096 and os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                traffic = (j["FETCH_SIZE"]["mean_KB"] + j["WRITE_SIZE"]["mean_KB"]) * 1024.0
+                traffic_src = "profiles/r01_pmc_hbm_rough4096.json (FETCH_SIZE + WRITE_SIZE, bytes per launch, uncorrected)"
+            except Exception:
+                traffic = None
         achieved = bytes_per * n_local / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec GR1T1 rough-terrain @4096 envs" if args.terrain == "rough" else "env-steps/sec GR1T1 flat-terrain @4096 envs",
@@ -156,10 +168,11 @@ def main():
                        "envs_per_gpu": n_local, "global_envs": n_total, "parallelism": f"env-sharded x{world} (no data-path collective)",
                        "finite_outputs": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": bytes_per * n_local,
                          "kernel": "grx_step_kernel", "kernel_ms": kern_ms, "launches": launches,
                          "algorithmic_bytes_per_env_step": bytes_per,
-                         "note": "latency/VALU-issue bound at this batch size (DESIGN.md section 5); HBM is the contractual roofline"},
+                         "note": "instruction-issue bound at this batch size (one wave per SIMD, DESIGN.md sections 4.1 and 5); HBM is the contractual roofline"},
         }
         if world == 1 and not args.no_cpu_baseline:
             steps = args.cpu_steps

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -39,8 +40,11 @@ int fail(int code, const std::string& msg) {
 
 struct Timing {
     bool enabled = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::deque<std::pair<hipEvent_t, hipEvent_t>> pending;   // at most kMaxPending launches in flight
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double total_ms = 0;   // launches already drained from `pending`
+    int64_t count = 0;
+    static constexpr size_t kMaxPending = 64;
 };
 }  // namespace
 
@@ -512,6 +516,15 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (s->timing.enabled) {
+        if (s->timing.pending.size() >= Timing::kMaxPending) {   // bound the event population (and the host's run-ahead)
+            auto pr = s->timing.pending.front();
+            s->timing.pending.pop_front();
+            HIP_TRY(hipEventSynchronize(pr.second));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+            s->timing.total_ms += ms; ++s->timing.count;
+            s->timing.pool.push_back(pr);
+        }
         if (!s->timing.pool.empty()) { ev = s->timing.pool.back(); s->timing.pool.pop_back(); }
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
@@ -550,8 +563,9 @@ int grx_episode_stats(grx_handle s, float* host_out, void* stream) {
 
 int grx_kernel_time_ms(grx_handle s, int enable, float* avg_ms, int64_t* launches) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_kernel_time_ms: null handle");
-    double tot = 0;
-    int64_t n = 0;
+    double tot = s->timing.total_ms;
+    int64_t n = s->timing.count;
+    s->timing.total_ms = 0; s->timing.count = 0;
     for (auto& pr : s->timing.pending) {
         HIP_TRY(hipEventSynchronize(pr.second));
         float ms = 0;

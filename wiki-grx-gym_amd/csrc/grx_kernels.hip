@@ -31,7 +31,7 @@
 #include "grx_rng.h"
 
 #ifdef GRX_PROFILE_SECTIONS
-#define GRX_TICK(i) do { if (threadIdx.x == 0) P.prof[(size_t)blockIdx.x * 32 + (i)] = clock64(); } while (0)
+#define GRX_TICK(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); if (threadIdx.x == 0) P.prof[(size_t)blockIdx.x * 32 + (i)] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 // sub-step sections accumulate in registers (g_tacc is a kernel-scope local); sched_barrier pins the code motion
 #define GRX_TICK2(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); tacc[(i) - 16] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -558,11 +558,58 @@ GRX_DEV float height_sample(const KParams& P, const KTables& T, float zn, float 
     return (float)h * P.vertical_scale;
 }
 
+// One lane's share of the height scan: points k = first, first + 2*NW, ... (NW waves x 2 lanes per env); raw heights
+// parked in the env's pri_obs staging row; returns the lane's partial sum.  Batches of 8 independent gathers.
+template <int NW>
+GRX_DEV float height_scan_share(const KParams& P, const KTables& T, float zn, float wn, V3 pos, int first, int nh, float* prow) {
+    float hsum = 0.f;
+    for (int k0 = first; k0 < nh; k0 += 16 * NW) {
+        float hb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hb[j] = height_sample(P, T, zn, wn, pos, min(k0 + 2 * NW * j, nh - 1));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + 2 * NW * j;
+            if (k < nh) { prow[GRX_NUM_OBS + 8 + k] = hb[j]; hsum += hb[j]; }
+        }
+    }
+    return hsum;
+}
+
 GRX_DEV float sum_abs_mask(const float a[LEG], uint32_t mask) {
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < LEG; ++k) if (mask & (1u << k)) s += fabsf(a[k]);
     return s;
+}
+
+
+// Observation-noise Philox blocks of one lane.  Streams are keyed so that every lane indexes its blocks statically:
+// base terms (ang vel, gravity; obs 3..8) = stream NOISE item i-3; dof terms = stream NOISE_DOF_L/R item
+// group*5 + k (group 0 pos, 1 vel, 2 action).  The six 10-round chains are advanced together, round by round, so
+// the 64-bit multiplies of independent chains interleave (a serial chain per value cost ~18k cycles/step, measured).
+constexpr int NZB = 6;   // slots 0..3: dof stream blocks 0..3; slots 4,5: base stream blocks 0,1 (left lane)
+GRX_DEV void noise_blocks(const KParams& P, uint32_t genv, uint32_t step, int side, U4 nzb[NZB]) {
+    uint32_t c0[NZB], c1[NZB], c2[NZB], c3[NZB];
+#pragma unroll
+    for (int b = 0; b < NZB; ++b) {
+        c0[b] = genv; c1[b] = step;
+        c2[b] = b < 4 ? (uint32_t)(side == 0 ? GRX_RNG_NOISE_DOF_L : GRX_RNG_NOISE_DOF_R) : (uint32_t)GRX_RNG_NOISE;
+        c3[b] = b < 4 ? b : b - 4;
+    }
+    uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
+#pragma unroll
+    for (int rnd = 0; rnd < 10; ++rnd) {
+#pragma unroll
+        for (int b = 0; b < NZB; ++b) {
+            uint64_t p0 = (uint64_t)0xD2511F53u * c0[b], p1 = (uint64_t)0xCD9E8D57u * c2[b];
+            uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1[b] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3[b] ^ k1;
+            c1[b] = (uint32_t)p1; c3[b] = (uint32_t)p0; c0[b] = n0; c2[b] = n2;
+        }
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int b = 0; b < NZB; ++b) { nzb[b].x = c0[b]; nzb[b].y = c1[b]; nzb[b].z = c2[b]; nzb[b].w = c3[b]; }
 }
 
 }  // namespace
@@ -591,6 +638,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __shared__ float s_wc[W == 4 ? 21 * 64 : 1];
     __shared__ float s_pb[W == 4 ? (LEG * PBR + 6) * 64 : 1];
     __shared__ float s_anch[W == 4 ? 9 * 64 : 1];     // final friction anchors of the step (wave 2 -> wave 0)
+    __shared__ uint32_t s_nz[W == 4 ? NZB * 4 * 64 : 1];   // observation-noise Philox blocks (wave 1 -> wave 0)
+    __shared__ float s_hp[W == 4 ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
+    __shared__ float s_hsum[W == 4 ? 4 * 64 : 1];          // height scan: partial sums per wave
     __shared__ int s_flag[FL_COUNT];
     const PipeLds L = {s_base, s_q, s_rec, s_rec0, s_wc, s_pb, s_wr, s_flag};
     const int tid = threadIdx.x;
@@ -633,6 +683,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             const S3 bI = {P.base_I[e], P.base_I[(size_t)N + e], P.base_I[2 * (size_t)N + e],
                            P.base_I[3 * (size_t)N + e], P.base_I[4 * (size_t)N + e], P.base_I[5 * (size_t)N + e]};
             if (wv == 1) {
+                if (P.add_noise && !noise_in) {   // wave 0 is still loading state: the noise blocks cost nothing here
+                    U4 nzb[NZB];
+                    noise_blocks(P, genv, step, side, nzb);
+                    uint32_t* z = s_nz + lane;
+#pragma unroll
+                    for (int b = 0; b < NZB; ++b) { z[(b * 4 + 0) * 64] = nzb[b].x; z[(b * 4 + 1) * 64] = nzb[b].y; z[(b * 4 + 2) * 64] = nzb[b].z; z[(b * 4 + 3) * 64] = nzb[b].w; }
+                }
                 iwave_loop(P, C, bm, bc, bI, L, lane, el);
             } else if (wv == 2) {
 #pragma unroll
@@ -649,7 +706,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             } else {
                 base_contact_loop<HF>(P, C, mu, hmax, bm, bc, bI, L, lane, el);
             }
-            __syncthreads();   // final friction anchors published
+            __syncthreads();   // final friction anchors + height-scan pose published
+            if (HF && P.measure_heights) {   // this wave's quarter of the height scan (legged_robot.py:1235-1274)
+                const float* hp = s_hp + el;
+                s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
+                                                              2 * wv + side, nh, s_pri + el * GRX_MAX_PRI);
+                __syncthreads();   // height scan complete
+            }
         } else {
             for (int deci = 0; deci < P.decimation; ++deci) {
                 __syncthreads();   // #1: base state published
@@ -760,8 +823,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         }
         avg_force += grx_sqrt(dot(so.foot_force, so.foot_force));
     }
+    const float yaw_n = fmaxf(sqrtf(st.qz * st.qz + st.qw * st.qw), 1e-9f);   // normalize(): torch_utils.py:43-45
+    const float yaw_z = st.qz / yaw_n, yaw_w = st.qw / yaw_n;
     if (W == 4) {   // the foot wave owned the friction anchors during the sub-steps
-        __syncthreads();   // final friction anchors published
+        if (side == 0) { float* hp = s_hp + el; hp[0 * EPB] = st.pos.x; hp[1 * EPB] = st.pos.y; hp[2 * EPB] = yaw_z; hp[3 * EPB] = yaw_w; }
+        __syncthreads();   // final friction anchors + height-scan pose published
         const float* a_ = s_anch + lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { st.ax[i] = a_[i * 64]; st.ay[i] = a_[(4 + i) * 64]; }
@@ -788,32 +854,22 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     V3 blv = quat_rotate_inverse(qv, st.qw, st.vel);
     V3 bav = quat_rotate_inverse(qv, st.qw, st.ang);
     V3 pg = quat_rotate_inverse(qv, st.qw, v3(0.f, 0.f, -1.f));
-    if (P.resample_command_interval > 0 && (ep_len % P.resample_command_interval) == 0)
+    if (P.resample_command_interval > 0 && ((uint32_t)ep_len % (uint32_t)P.resample_command_interval) == 0)   // ep_len <= max_episode_length + 1
         resample_commands(P, genv, step, GRX_RNG_CMD_TIME, ea.cmd);
     // measured heights: this lane samples points k = 2*i + side; raw heights parked in the pri_obs staging row
     float* prow = s_pri + el * GRX_MAX_PRI;
     float hsum = 0.f;
     if (HF && P.measure_heights) {
-        const float yaw_n = fmaxf(sqrtf(st.qz * st.qz + st.qw * st.qw), 1e-9f);   // normalize(): torch_utils.py:43-45
-        const float yaw_z = st.qz / yaw_n, yaw_w = st.qw / yaw_n;
-        for (int k0 = side; k0 < nh; k0 += 16) {
-            float hb[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {   // independent gathers: all 24 loads of the batch are in flight together
-                int k = k0 + 2 * j;
-                hb[j] = height_sample(P, s_tab, yaw_z, yaw_w, st.pos, min(k, nh - 1));
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int k = k0 + 2 * j;
-                if (k < nh) { prow[GRX_NUM_OBS + 8 + k] = hb[j]; hsum += hb[j]; }
-            }
-        }
+        if (W == 4) {   // quarter of the scan here, the other three quarters on the helper waves
+            hsum = height_scan_share<4>(P, s_tab, yaw_z, yaw_w, st.pos, side, nh, prow);
+            __syncthreads();   // height scan complete
+            hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane];
+        } else hsum = height_scan_share<1>(P, s_tab, yaw_z, yaw_w, st.pos, side, nh, prow);
         hsum = pair_sum(hsum);
     } else {
         for (int k = side; k < nh; k += 2) prow[GRX_NUM_OBS + 8 + k] = 0.f;
     }
-    if (P.push_robots && P.push_interval > 0 && (common_step % P.push_interval) == 0) {  // legged_robot.py:786-797
+    if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {  // legged_robot.py:786-797
         st.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
         st.vel.y = urand(P, genv, step, GRX_RNG_PUSH, 1, -P.max_push_vel_xy, P.max_push_vel_xy);
     }
@@ -995,45 +1051,35 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     float bho;
     {
         float sum = 0.f;
-        for (int k = side; k < nh; k += 2) {
-            float d = st.pos.z - P.base_height_target - prow[GRX_NUM_OBS + 8 + k];
-            d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
-            if (P.publish_debug && act) P.heights[(size_t)k * N + e] = prow[GRX_NUM_OBS + 8 + k];
-            prow[GRX_NUM_OBS + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -P.clip_observations), P.clip_observations);
-            sum += d;
+        for (int k0 = side; k0 < nh; k0 += 16) {   // batches of 8: one exposed LDS latency per batch, not per point
+            float hv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[j] = prow[GRX_NUM_OBS + 8 + min(k0 + 2 * j, nh - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + 2 * j;
+                if (k < nh) {
+                    float d = st.pos.z - P.base_height_target - hv[j];
+                    d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
+                    if (P.publish_debug && act) P.heights[(size_t)k * N + e] = hv[j];
+                    prow[GRX_NUM_OBS + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -P.clip_observations), P.clip_observations);
+                    sum += d;
+                }
+            }
         }
         sum = pair_sum(sum);
         bho = nh > 0 ? sum / (float)nh : 0.f;
     }
     float* orow = s_obs + el * GRX_NUM_OBS;
     const float clipo = P.clip_observations;
-    // observation noise.  Streams are keyed so that every lane indexes its blocks statically: base terms
-    // (ang vel, gravity; obs 3..8) = stream NOISE item i-3; dof terms = stream NOISE_DOF_L/R item group*5 + k
-    // (group 0 pos, 1 vel, 2 action).  The six 10-round chains are advanced together, round by round, so the
-    // 64-bit multiplies of independent chains interleave (a serial chain per value cost ~18k cycles/step, measured).
-    constexpr int NZB = 6;   // slots 0..3: dof stream blocks 0..3; slots 4,5: base stream blocks 0,1 (left lane)
+    // observation noise (noise_blocks): with 4 waves per block wave 1 computed the blocks while wave 0 loaded state
     U4 nzb[NZB];
     if (P.add_noise && !noise_in) {
-        uint32_t c0[NZB], c1[NZB], c2[NZB], c3[NZB];
+        if (W == 4) {
+            const uint32_t* z = s_nz + lane;
 #pragma unroll
-        for (int b = 0; b < NZB; ++b) {
-            c0[b] = genv; c1[b] = step;
-            c2[b] = b < 4 ? (uint32_t)(side == 0 ? GRX_RNG_NOISE_DOF_L : GRX_RNG_NOISE_DOF_R) : (uint32_t)GRX_RNG_NOISE;
-            c3[b] = b < 4 ? b : b - 4;
-        }
-        uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
-#pragma unroll
-        for (int rnd = 0; rnd < 10; ++rnd) {
-#pragma unroll
-            for (int b = 0; b < NZB; ++b) {
-                uint64_t p0 = (uint64_t)0xD2511F53u * c0[b], p1 = (uint64_t)0xCD9E8D57u * c2[b];
-                uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1[b] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3[b] ^ k1;
-                c1[b] = (uint32_t)p1; c3[b] = (uint32_t)p0; c0[b] = n0; c2[b] = n2;
-            }
-            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-        }
-#pragma unroll
-        for (int b = 0; b < NZB; ++b) { nzb[b].x = c0[b]; nzb[b].y = c1[b]; nzb[b].z = c2[b]; nzb[b].w = c3[b]; }
+            for (int b = 0; b < NZB; ++b) { nzb[b].x = z[(b * 4 + 0) * 64]; nzb[b].y = z[(b * 4 + 1) * 64]; nzb[b].z = z[(b * 4 + 2) * 64]; nzb[b].w = z[(b * 4 + 3) * 64]; }
+        } else noise_blocks(P, genv, step, side, nzb);
     }
     // item: index within the lane's stream (compile-time); slot0: first block slot of that stream
     auto put = [&](int idx, float val, float nscale, int item, int slot0) {
