@@ -7,6 +7,8 @@ the 436 885-parameter model.  Per optimizer step ONE flat fp32 bucket (gradients
 appended as the last element) is all-reduced over RCCL/xGMI and averaged, so every rank takes the
 same adaptive-LR decision and the same Adam step: replicas stay bit-identical without broadcasting.
 At 1.75 MB the collective is latency-bound; a single fused bucket keeps it at one launch."""
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -37,9 +39,18 @@ class PPO:
         # device scalar consumed by the fused Adam kernel, the NaN-skip uses Adam's found_inf hook, and the loss
         # statistics are read back once per update().  (The reference does three .item() per minibatch, ppo.py:264,308-309.)
         self._device_lr = torch.device(device).type == "cuda"
+        # ... and, single rank, the whole minibatch step (forward, losses, backward, adaptive LR, clip, fused Adam) is
+        # captured ONCE in a HIP graph and replayed 200x per update: the MLP is small, so eager mode is launch-bound
+        # (about 100 kernels of a few microseconds per minibatch).  GRX_PPO_GRAPH=0 disables the capture.
+        self._use_graph = self._device_lr and os.environ.get("GRX_PPO_GRAPH", "1") != "0"
+        self._graph, self._graph_mb, self._static, self._sums, self._restore_opt = None, None, None, None, None
         if self._device_lr:
+            # rsl_rl's `Normal.set_default_validate_args = False` (actor_critic.py) is an assignment, not a call, so the
+            # reference validates (and host-syncs) on every Normal(); here the validation really is off
+            torch.distributions.Distribution.set_default_validate_args(False)
             self._lr_t = torch.tensor(float(learning_rate), device=device)
-            self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=self._lr_t, weight_decay=weight_decay, fused=True)
+            self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=self._lr_t, weight_decay=weight_decay, fused=True,
+                                        capturable=True)
         else:
             self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate, weight_decay=weight_decay)
         self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
@@ -124,6 +135,8 @@ class PPO:
 
     def update(self):
         if self._device_lr:
+            if self._use_graph and _world() == 1:
+                return self._update_graphed()
             return self._update_device()
         mean_value_loss, mean_surrogate_loss = 0.0, 0.0
         ac, multi = self.actor_critic, _world() > 1
@@ -216,6 +229,117 @@ class PPO:
                 sums[2] = kl_mean
         self.num_updates = self.num_learning_epochs * self.num_mini_batches
         host = sums.tolist()                           # the only device->host transfer of the update
+        self.mean_kl = host[2]
+        self.learning_rate = float(self._lr_t.item())
+        return host[0] / self.num_updates, host[1] / self.num_updates
+
+    # ------------------------------------------------------------------ HIP-graph minibatch step (single rank)
+    def _minibatch_step(self, batch, sums):
+        """One PPO minibatch step on static tensors (the arithmetic of _update_device)."""
+        obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma = batch
+        ac = self.actor_critic
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        ac.update_distribution(obs)
+        logp = ac.get_actions_log_prob(actions)
+        value = ac.evaluate(cobs)
+        mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+        kl_mean = torch.zeros((), device=self.device)
+        if adaptive:
+            with torch.no_grad():
+                kl_mean = torch.sum(torch.log(sigma / old_sigma + 1.e-5) + (old_sigma.square() + (old_mu - mu).square())
+                                    / (2.0 * sigma.square()) - 0.5, axis=-1).mean()
+        ratio = torch.exp(logp - torch.squeeze(old_logp))
+        adv = torch.squeeze(advantages)
+        surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+        if self.use_clipped_value_loss:
+            clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
+            value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
+        else:
+            value_loss = (returns - value).pow(2).mean()
+        loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
+        self.optimizer.zero_grad(set_to_none=False)
+        loss.backward()
+        if adaptive:
+            self._device_lr_update(kl_mean)
+        with torch.no_grad():
+            bad = ~torch.isfinite(loss)
+            self.optimizer.found_inf = bad.float().reshape(())   # NaN-skip (ppo.py:297-299) through fused Adam's hook
+            self.optimizer.grad_scale = None
+        nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm, foreach=True)
+        self.optimizer.step()
+        with torch.no_grad():
+            ok = (~bad).float()
+            sums[0] += value_loss.detach() * ok
+            sums[1] += surrogate_loss.detach() * ok
+            sums[2] = kl_mean
+
+    def _build_graph(self, mb):
+        st, dev = self.storage, self.device
+        widths = [st.observations.shape[-1], (st.pri_observations if st.pri_observations is not None else st.observations).shape[-1],
+                  st.actions.shape[-1], 1, 1, 1, 1, st.mu.shape[-1], st.sigma.shape[-1]]
+        self._static = [torch.zeros(mb, w, device=dev) for w in widths]
+        self._sums = torch.zeros(3, device=dev)
+        # warm-up runs real optimizer steps (allocator / lazy-state initialisation): snapshot and restore everything they touch
+        ac_state = [p.detach().clone() for p in self.actor_critic.parameters()]   # (not load_state_dict: it rewrites std, AC:116-134)
+        lr0 = self._lr_t.clone()
+        self._static[8].fill_(1.0)   # sigma > 0 for the dry runs
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._minibatch_step(self._static, self._sums)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        if os.environ.get("GRX_PPO_GRAPH", "1") == "2":   # debugging aid: static buffers, eager replay
+            class _Eager:
+                def __init__(s, fn): s.fn = fn
+                def replay(s): s.fn()
+            self._graph = _Eager(lambda: self._minibatch_step(self._static, self._sums))
+        else:
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._minibatch_step(self._static, self._sums)
+        # restore: parameters, Adam moments/step counters, learning rate
+        with torch.no_grad():
+            for p, v in zip(self.actor_critic.parameters(), ac_state):
+                p.copy_(v)
+        for stt in self.optimizer.state.values():
+            for v in stt.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+        self._lr_t.copy_(lr0)
+        if self._restore_opt is not None:
+            self._load_opt_tensors(self._restore_opt)
+        self._graph_mb = mb
+
+    def _opt_tensors(self):
+        return [{k: v.clone() for k, v in stt.items() if torch.is_tensor(v)} for stt in self.optimizer.state.values()]
+
+    def _load_opt_tensors(self, saved):
+        for stt, sv in zip(self.optimizer.state.values(), saved):
+            for k, v in sv.items():
+                stt[k].copy_(v)
+
+    def _update_graphed(self):
+        st = self.storage
+        batch = st.num_envs * st.num_transitions_per_env
+        mb = batch // self.num_mini_batches
+        if self._graph is None or self._graph_mb != mb:
+            # capture after the optimizer already ran (resume / later iterations): keep its moments
+            self._restore_opt = self._opt_tensors() if len(self.optimizer.state) else None
+            self._build_graph(mb)
+        flat = lambda x: x.flatten(0, 1)
+        cobs = st.pri_observations if st.pri_observations is not None else st.observations
+        srcs = [flat(x) for x in (st.observations, cobs, st.actions, st.values, st.advantages, st.returns, st.actions_log_prob, st.mu, st.sigma)]
+        indices = torch.randperm(self.num_mini_batches * mb, requires_grad=False, device=self.device)   # RS:63-112: one permutation, reused
+        self._sums.zero_()
+        for _ in range(self.num_learning_epochs):
+            for i in range(self.num_mini_batches):
+                idx = indices[i * mb:(i + 1) * mb]
+                for buf, src in zip(self._static, srcs):
+                    torch.index_select(src, 0, idx, out=buf)
+                self._graph.replay()
+        self.num_updates = self.num_learning_epochs * self.num_mini_batches
+        host = self._sums.tolist()                     # the only device->host transfer of the update
         self.mean_kl = host[2]
         self.learning_rate = float(self._lr_t.item())
         return host[0] / self.num_updates, host[1] / self.num_updates
