@@ -535,6 +535,8 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->timing.pending.push_back(ev);
     }
+    // (folding this reduction into the step kernel's last block was tried: the agent-scope __threadfence every block
+    // then needs writes back the whole XCD L2 -- +10 us per launch, measured -- so it stays a 3.7 us kernel of its own)
     grx_launch_finalize(&s->hp, s->N, st);
     HIP_TRY(hipGetLastError());
     return GRX_OK;

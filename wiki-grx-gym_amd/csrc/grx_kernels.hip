@@ -615,6 +615,190 @@ GRX_DEV void noise_blocks(const KParams& P, uint32_t genv, uint32_t step, int si
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+// Inputs of compute_reward for one lane (one leg of one env): everything the reward terms and the episode sums read.
+struct RewIn {
+    float a_last[LEG], a_cur[LEG], q[LEG], qd[LEG], qd_last[LEG], torque[LEG];
+    float feet_height, air_time, land_time, avg_force;
+    V3 avg_speed, foot_force;
+    float contact, first_contact;   // 0 / 1
+    float cmd[3];
+    V3 blv, bav, pg;
+    float bho_stale, qx, qy, qz, qw, pen_count, reset, time_out;
+};
+constexpr int REWIN_FLOATS = 6 * LEG + 4 + 6 + 2 + 3 + 9 + 8;
+template <class F>
+GRX_DEV void rewin_fields(RewIn& r, F&& f) {
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) { f(r.a_last[k]); f(r.a_cur[k]); f(r.q[k]); f(r.qd[k]); f(r.qd_last[k]); f(r.torque[k]); }
+    f(r.feet_height); f(r.air_time); f(r.land_time); f(r.avg_force);
+    f(r.avg_speed.x); f(r.avg_speed.y); f(r.avg_speed.z); f(r.foot_force.x); f(r.foot_force.y); f(r.foot_force.z);
+    f(r.contact); f(r.first_contact);
+    f(r.cmd[0]); f(r.cmd[1]); f(r.cmd[2]);
+    f(r.blv.x); f(r.blv.y); f(r.blv.z); f(r.bav.x); f(r.bav.y); f(r.bav.z); f(r.pg.x); f(r.pg.y); f(r.pg.z);
+    f(r.bho_stale); f(r.qx); f(r.qy); f(r.qz); f(r.qw); f(r.pen_count); f(r.reset); f(r.time_out);
+}
+
+// compute_reward (legged_robot.py:355-375) + episode sums + the block's finished-episode statistics for one lane.
+// Runs on wave 0, or -- four waves per block -- on wave 1 while wave 0 goes on with reset and observations.
+// es_pre: the env's running episode sums if the caller loaded them early (their HBM latency then overlaps the state
+// update), else nullptr.
+GRX_DEV void reward_and_sums(const KParams& P, const SideConst& C, const RewIn& in, int lane, int side, int e, int N, bool act,
+                             float* s_stat, const float* es_pre) {
+    const int j0 = side * LEG;
+    const float dtp = P.sim_dt * (float)P.decimation;
+    const bool reset = in.reset != 0.f, time_out = in.time_out != 0.f;
+    float es_raw[NT];   // running episode sums
+#pragma unroll
+    for (int t = 0; t < NT; ++t) es_raw[t] = es_pre ? es_pre[t] : ((P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f);
+    // ---- compute_reward (legged_robot.py:355-375): per-lane partial sums, pair-combined
+    float r[NT];
+    {
+        const float as = P.action_scale, H = P.swing_feet_height_target, T = P.feet_air_time_target;
+        const float* sg = P.reward_sigma;
+        const uint32_t knee = (P.knee_mask >> j0) & 31u, hiproll = (P.hip_roll_mask >> j0) & 31u, hipyaw = (P.hip_yaw_mask >> j0) & 31u;
+        const uint32_t ankle = ((side ? P.ankle_right_mask : P.ankle_left_mask) >> j0) & 31u;
+        float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) {
+            float d1 = (in.a_last[k] - in.a_cur[k]) * as;
+            s1 += fabsf(d1);  // last_last_actions == last_actions (legged_robot_fftai.py:94 copies after legged_robot.py:299)
+            if (knee & (1u << k)) s3 += fabsf((in.a_cur[k] - in.a_last[k]) * as);
+            sacc += fabsf((in.qd[k] - in.qd_last[k]) / dtp);
+            stor += fabsf(in.torque[k]);
+            svel += fabsf(in.qd[k]);
+            float po = fabsf(in.q[k] - C.body[k].q0);
+            spose += po;
+            if (hipyaw & (1u << k)) shy += po;
+            float a = in.a_cur[k] * as, oa = 0.f, op = 0.f;
+            if (a - C.body[k].slo < 0.f) oa += -(a - C.body[k].slo);
+            if (a - C.body[k].shi > 0.f) oa += (a - C.body[k].shi);
+            sla += oa * oa;
+            if (in.q[k] - C.body[k].slo < 0.f) op += -(in.q[k] - C.body[k].slo);
+            if (in.q[k] - C.body[k].shi > 0.f) op += (in.q[k] - C.body[k].shi);
+            slp += fabsf(op);
+            slv += fminf(fmaxf(fabsf(in.qd[k]) - C.body[k].vlim * P.soft_dof_vel_limit, 0.f), 1.f);
+            slt += fmaxf(fabsf(in.torque[k]) - C.body[k].effort * P.soft_torque_limit, 0.f);
+        }
+        float tor_hr = sum_abs_mask(in.torque, hiproll), vel_kn = sum_abs_mask(in.qd, knee);
+        float h = in.feet_height;
+        float lift = sum_abs_mask(in.torque, ankle) * fabsf(h) * (h > H * 0.5f ? 1.f : 0.f);
+        float hmin = fminf(h, pair_swap(h));
+        float mid = fabsf(in.air_time - T * 0.5f);
+        float af = mid * in.avg_force;
+        float ah = mid * fabsf(h - hmin - H);
+        float at = expf(sg[GRX_REW_FEET_AIR_TIME] * fabsf(in.air_time - T)) * in.first_contact;
+        float le = (in.land_time - P.feet_land_time_max) * (in.land_time > P.feet_land_time_max ? 1.f : 0.f);
+        float lt = 1.f - expf(sg[GRX_REW_FEET_LAND_TIME] * le);
+        float close = fabsf(h - H * 0.25f) * (h < H * 0.25f ? 1.f : 0.f) / (H * 0.25f);
+        float exy = sqrtf(in.avg_speed.x * in.avg_speed.x + in.avg_speed.y * in.avg_speed.y) * close;
+        float far = fabsf(h - H * 3.f / 4.f) * (h > H * 3.f / 4.f ? 1.f : 0.f) / (H * 1.f / 4.f);
+        float ez = fabsf(in.avg_speed.z) * far;
+        V3 F = in.foot_force;
+        float serr = sqrtf(F.x * F.x + F.y * F.y) - P.feet_stumble_ratio * fabsf(F.z);
+        serr = serr * (serr > 0.f ? 1.f : 0.f);
+        float stum = 1.f - expf(sg[GRX_REW_FEET_STUMBLE] * serr);
+        float ncontact = in.contact;
+        s1 = pair_sum(s1); s3 = pair_sum(s3); sacc = pair_sum(sacc); stor = pair_sum(stor); svel = pair_sum(svel);
+        spose = pair_sum(spose); sla = pair_sum(sla); slp = pair_sum(slp); slt = pair_sum(slt); slv = pair_sum(slv);
+        shy = pair_sum(shy); tor_hr = pair_sum(tor_hr); vel_kn = pair_sum(vel_kn); lift = pair_sum(lift);
+        af = pair_sum(af); ah = pair_sum(ah); at = pair_sum(at); lt = pair_sum(lt); exy = pair_sum(exy); ez = pair_sum(ez);
+        stum = pair_sum(stum); ncontact = pair_sum(ncontact);
+        const float cmd_n = sqrtf(in.cmd[0] * in.cmd[0] + in.cmd[1] * in.cmd[1]);
+        const float moving = cmd_n > 0.1f ? 1.f : 0.f;
+        r[GRX_REW_ACTION_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF] * s1);
+        r[GRX_REW_ACTION_DIFF_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_DIFF] * s1);
+        r[GRX_REW_ACTION_DIFF_KNEE] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_KNEE] * s3);
+        r[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] * fabsf(0.f - in.bav.y));
+        r[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] * fabsf(0.f - in.bav.x));
+        r[GRX_REW_CMD_DIFF_ANG_VEL_YAW] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_YAW] * fabsf(in.cmd[2] - in.bav.z));
+        r[GRX_REW_CMD_DIFF_BASE_HEIGHT] = expf(sg[GRX_REW_CMD_DIFF_BASE_HEIGHT] * (fabsf(in.bho_stale) * (in.bho_stale < 0.f ? 1.f : 0.f)));
+        r[GRX_REW_CMD_DIFF_BASE_ORIENT] = expf(sg[GRX_REW_CMD_DIFF_BASE_ORIENT] * (fabsf(in.pg.x) + fabsf(in.pg.y)));
+        R3 R0 = quat_to_R(in.qx, in.qy, in.qz, in.qw);
+        {   // torso / forehead links ride on the base lump: R_link = R0 * rot; R^T(0,0,-1) = -(third row)
+            float tx = -(R0.cx.z * P.torso_rot[0] + R0.cy.z * P.torso_rot[3] + R0.cz.z * P.torso_rot[6]);
+            float ty = -(R0.cx.z * P.torso_rot[1] + R0.cy.z * P.torso_rot[4] + R0.cz.z * P.torso_rot[7]);
+            r[GRX_REW_CMD_DIFF_TORSO_ORIENT] = P.has_torso ? expf(sg[GRX_REW_CMD_DIFF_TORSO_ORIENT] * (fabsf(tx) + fabsf(ty))) : 0.f;
+            float fx = -(R0.cx.z * P.forehead_rot[0] + R0.cy.z * P.forehead_rot[3] + R0.cz.z * P.forehead_rot[6]);
+            float fy = -(R0.cx.z * P.forehead_rot[1] + R0.cy.z * P.forehead_rot[4] + R0.cz.z * P.forehead_rot[7]);
+            r[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] = P.has_forehead ? expf(sg[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] * (fabsf(fx) + fabsf(fy))) : 0.f;
+        }
+        r[GRX_REW_CMD_DIFF_LIN_VEL_X] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_X] * fabsf(in.cmd[0] - in.blv.x));
+        r[GRX_REW_CMD_DIFF_LIN_VEL_Y] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Y] * fabsf(in.cmd[1] - in.blv.y));
+        r[GRX_REW_CMD_DIFF_LIN_VEL_Z] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Z] * fabsf(0.f - in.blv.z));
+        r[GRX_REW_COLLISION] = 1.f - expf(sg[GRX_REW_COLLISION] * in.pen_count);
+        r[GRX_REW_DOF_ACC_NEW] = 1.f - expf(sg[GRX_REW_DOF_ACC_NEW] * sacc);
+        r[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] = 1.f - expf(sg[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] * lift);
+        r[GRX_REW_DOF_TOR_NEW] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW] * stor);
+        r[GRX_REW_DOF_TOR_NEW_HIP_ROLL] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW_HIP_ROLL] * tor_hr);
+        r[GRX_REW_DOF_VEL_NEW] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW] * svel);
+        r[GRX_REW_DOF_VEL_NEW_KNEE] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW_KNEE] * vel_kn);
+        r[GRX_REW_FEET_AIR_FORCE] = expf(sg[GRX_REW_FEET_AIR_FORCE] * af) * moving;
+        r[GRX_REW_FEET_AIR_HEIGHT] = expf(sg[GRX_REW_FEET_AIR_HEIGHT] * ah) * moving;
+        r[GRX_REW_FEET_AIR_TIME] = at * moving;
+        r[GRX_REW_FEET_LAND_TIME] = lt * moving;
+        r[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] = expf(sg[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] * exy);
+        r[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] = expf(sg[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] * ez);
+        r[GRX_REW_FEET_STUMBLE] = stum;
+        r[GRX_REW_LIMITS_ACTIONS] = 1.f - expf(sg[GRX_REW_LIMITS_ACTIONS] * sla);
+        r[GRX_REW_LIMITS_DOF_POS] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_POS] * slp);
+        r[GRX_REW_LIMITS_DOF_TOR] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_TOR] * slt);
+        r[GRX_REW_LIMITS_DOF_VEL] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_VEL] * slv);
+        r[GRX_REW_ON_THE_AIR] = ncontact == 0.f ? 1.f : 0.f;
+        r[GRX_REW_POSE_OFFSET] = expf(sg[GRX_REW_POSE_OFFSET] * spose);
+        r[GRX_REW_POSE_OFFSET_HIP_YAW] = 1.f - expf(sg[GRX_REW_POSE_OFFSET_HIP_YAW] * shy);
+        r[GRX_REW_STAND_STILL] = expf(sg[GRX_REW_STAND_STILL] * spose) * (cmd_n < 0.1f ? 1.f : 0.f);
+        r[GRX_REW_TERMINATION] = (reset && !time_out) ? 1.f : 0.f;
+    }
+    float rew = 0.f;
+    const bool writer = act && side == 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float sc_t = P.reward_scale_dt[t];
+        float rt = 0.f;
+        if (t != GRX_REW_TERMINATION && sc_t != 0.f) { rt = r[t] * sc_t; rew += rt; }
+        r[t] = rt;
+    }
+    if (P.only_positive_rewards) rew = fmaxf(rew, 0.f);
+    if (P.reward_scale_dt[GRX_REW_TERMINATION] != 0.f) {
+        float rt = r[GRX_REW_TERMINATION] = ((reset && !time_out) ? 1.f : 0.f) * P.reward_scale_dt[GRX_REW_TERMINATION];
+        rew += rt;
+    }
+    // episode sums; reset envs contribute to the block's episode statistics (legged_robot.py:420-424)
+    const unsigned long long reset_mask = __ballot(reset && writer);
+    float es_all[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) es_all[t] = es_raw[t] + r[t];
+    if (reset_mask) {
+        // finished episodes: a wave holds 0-2 of them per step, so walk the set bits (uniform loop) and pull the
+        // lane's sums through v_readlane instead of 36 six-step shuffle reductions (216 ds_bpermute + waits, measured)
+        float acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = 0.f;
+        unsigned long long m = reset_mask;
+        while (m) {
+            const int L = __ffsll((long long)m) - 1;
+            m &= m - 1;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] += __shfl(es_all[t], L);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) s_stat[t] = acc[t];
+        }
+    }
+    if (writer) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (P.reward_scale_dt[t] == 0.f) continue;  // uniform
+            P.episode_sums[(size_t)t * N + e] = reset ? 0.f : es_all[t];
+            if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
+        }
+    }
+    if (lane == 0) s_stat[NT] = (float)__popcll(reset_mask);
+
+    if (writer) P.rew[e] = rew;
+}
+
 // Block = W waves (W = 1, 2 or 4, chosen at launch so that every wave gets a SIMD to itself) for the same 32 envs,
 // one env per lane PAIR in each wave.  The kernel runs one wave per SIMD, i.e. at one instruction per 4 cycles, so
 // a wave's instruction count IS its time:
@@ -641,6 +825,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __shared__ uint32_t s_nz[W == 4 ? NZB * 4 * 64 : 1];   // observation-noise Philox blocks (wave 1 -> wave 0)
     __shared__ float s_hp[W == 4 ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
     __shared__ float s_hsum[W == 4 ? 4 * 64 : 1];          // height scan: partial sums per wave
+    __shared__ float s_rw[W == 4 ? REWIN_FLOATS * 64 : 1];   // reward inputs (wave 0 -> wave 1)
     __shared__ int s_flag[FL_COUNT];
     const PipeLds L = {s_base, s_q, s_rec, s_rec0, s_wc, s_pb, s_wr, s_flag};
     const int tid = threadIdx.x;
@@ -712,6 +897,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
                                                               2 * wv + side, nh, s_pri + el * GRX_MAX_PRI);
                 __syncthreads();   // height scan complete
+            }
+            if (wv == 1) {   // rewards + episode sums while wave 0 runs reset / observations / stores
+                flag_wait(s_flag + FL_REW, 1);
+                RewIn rin;
+                int i = 0;
+                rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
+                reward_and_sums(P, C, rin, lane, side, e, N, act, s_stat, nullptr);
             }
         } else {
             for (int deci = 0; deci < P.decimation; ++deci) {
@@ -846,9 +1038,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 
     GRX_TICK(3);
     // ---- post_physics_step (legged_robot.py:269-305)
-    float es_raw[NT];   // running episode sums: loads issued here so their HBM latency overlaps the state update
+    float es_early[NT];   // running episode sums: loads issued here so their HBM latency overlaps the state update
+    if (W < 4) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) es_raw[t] = (P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
+        for (int t = 0; t < NT; ++t) es_early[t] = (P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
+    }
     ep_len += 1;
     V3 qv = v3(st.qx, st.qy, st.qz);
     V3 blv = quat_rotate_inverse(qv, st.qw, st.vel);
@@ -888,152 +1082,28 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     reset = reset || time_out;
 
     GRX_TICK(5);
-    // ---- compute_reward (legged_robot.py:355-375): per-lane partial sums, pair-combined
-    float r[NT];
+    // ---- compute_reward + episode sums (reward_and_sums): here, or on wave 1 when the block has four waves
     {
-        const float as = P.action_scale, H = P.swing_feet_height_target, T = P.feet_air_time_target;
-        const float* sg = P.reward_sigma;
-        const uint32_t knee = (P.knee_mask >> j0) & 31u, hiproll = (P.hip_roll_mask >> j0) & 31u, hipyaw = (P.hip_yaw_mask >> j0) & 31u;
-        const uint32_t ankle = ((side ? P.ankle_right_mask : P.ankle_left_mask) >> j0) & 31u;
-        float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
+        RewIn rin;
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {
-            float d1 = (a_last[k] - a_cur[k]) * as;
-            s1 += fabsf(d1);  // last_last_actions == last_actions (legged_robot_fftai.py:94 copies after legged_robot.py:299)
-            if (knee & (1u << k)) s3 += fabsf((a_cur[k] - a_last[k]) * as);
-            sacc += fabsf((st.qd[k] - qd_last[k]) / dtp);
-            stor += fabsf(torque[k]);
-            svel += fabsf(st.qd[k]);
-            float po = fabsf(st.q[k] - C.body[k].q0);
-            spose += po;
-            if (hipyaw & (1u << k)) shy += po;
-            float a = a_cur[k] * as, oa = 0.f, op = 0.f;
-            if (a - C.body[k].slo < 0.f) oa += -(a - C.body[k].slo);
-            if (a - C.body[k].shi > 0.f) oa += (a - C.body[k].shi);
-            sla += oa * oa;
-            if (st.q[k] - C.body[k].slo < 0.f) op += -(st.q[k] - C.body[k].slo);
-            if (st.q[k] - C.body[k].shi > 0.f) op += (st.q[k] - C.body[k].shi);
-            slp += fabsf(op);
-            slv += fminf(fmaxf(fabsf(st.qd[k]) - C.body[k].vlim * P.soft_dof_vel_limit, 0.f), 1.f);
-            slt += fmaxf(fabsf(torque[k]) - C.body[k].effort * P.soft_torque_limit, 0.f);
+            rin.a_last[k] = a_last[k]; rin.a_cur[k] = a_cur[k]; rin.q[k] = st.q[k]; rin.qd[k] = st.qd[k];
+            rin.qd_last[k] = qd_last[k]; rin.torque[k] = torque[k];
         }
-        float tor_hr = sum_abs_mask(torque, hiproll), vel_kn = sum_abs_mask(st.qd, knee);
-        float h = feet_height;
-        float lift = sum_abs_mask(torque, ankle) * fabsf(h) * (h > H * 0.5f ? 1.f : 0.f);
-        float hmin = fminf(h, pair_swap(h));
-        float mid = fabsf(air_time - T * 0.5f);
-        float af = mid * avg_force;
-        float ah = mid * fabsf(h - hmin - H);
-        float at = expf(sg[GRX_REW_FEET_AIR_TIME] * fabsf(air_time - T)) * (first_contact ? 1.f : 0.f);
-        float le = (land_time - P.feet_land_time_max) * (land_time > P.feet_land_time_max ? 1.f : 0.f);
-        float lt = 1.f - expf(sg[GRX_REW_FEET_LAND_TIME] * le);
-        float close = fabsf(h - H * 0.25f) * (h < H * 0.25f ? 1.f : 0.f) / (H * 0.25f);
-        float exy = sqrtf(avg_speed.x * avg_speed.x + avg_speed.y * avg_speed.y) * close;
-        float far = fabsf(h - H * 3.f / 4.f) * (h > H * 3.f / 4.f ? 1.f : 0.f) / (H * 1.f / 4.f);
-        float ez = fabsf(avg_speed.z) * far;
-        V3 F = so.foot_force;
-        float serr = sqrtf(F.x * F.x + F.y * F.y) - P.feet_stumble_ratio * fabsf(F.z);
-        serr = serr * (serr > 0.f ? 1.f : 0.f);
-        float stum = 1.f - expf(sg[GRX_REW_FEET_STUMBLE] * serr);
-        float ncontact = contact ? 1.f : 0.f;
-        s1 = pair_sum(s1); s3 = pair_sum(s3); sacc = pair_sum(sacc); stor = pair_sum(stor); svel = pair_sum(svel);
-        spose = pair_sum(spose); sla = pair_sum(sla); slp = pair_sum(slp); slt = pair_sum(slt); slv = pair_sum(slv);
-        shy = pair_sum(shy); tor_hr = pair_sum(tor_hr); vel_kn = pair_sum(vel_kn); lift = pair_sum(lift);
-        af = pair_sum(af); ah = pair_sum(ah); at = pair_sum(at); lt = pair_sum(lt); exy = pair_sum(exy); ez = pair_sum(ez);
-        stum = pair_sum(stum); ncontact = pair_sum(ncontact);
-        const float cmd_n = sqrtf(ea.cmd[0] * ea.cmd[0] + ea.cmd[1] * ea.cmd[1]);
-        const float moving = cmd_n > 0.1f ? 1.f : 0.f;
-        r[GRX_REW_ACTION_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF] * s1);
-        r[GRX_REW_ACTION_DIFF_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_DIFF] * s1);
-        r[GRX_REW_ACTION_DIFF_KNEE] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_KNEE] * s3);
-        r[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] * fabsf(0.f - bav.y));
-        r[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] * fabsf(0.f - bav.x));
-        r[GRX_REW_CMD_DIFF_ANG_VEL_YAW] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_YAW] * fabsf(ea.cmd[2] - bav.z));
-        r[GRX_REW_CMD_DIFF_BASE_HEIGHT] = expf(sg[GRX_REW_CMD_DIFF_BASE_HEIGHT] * (fabsf(bho_stale) * (bho_stale < 0.f ? 1.f : 0.f)));
-        r[GRX_REW_CMD_DIFF_BASE_ORIENT] = expf(sg[GRX_REW_CMD_DIFF_BASE_ORIENT] * (fabsf(pg.x) + fabsf(pg.y)));
-        R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
-        {   // torso / forehead links ride on the base lump: R_link = R0 * rot; R^T(0,0,-1) = -(third row)
-            float tx = -(R0.cx.z * P.torso_rot[0] + R0.cy.z * P.torso_rot[3] + R0.cz.z * P.torso_rot[6]);
-            float ty = -(R0.cx.z * P.torso_rot[1] + R0.cy.z * P.torso_rot[4] + R0.cz.z * P.torso_rot[7]);
-            r[GRX_REW_CMD_DIFF_TORSO_ORIENT] = P.has_torso ? expf(sg[GRX_REW_CMD_DIFF_TORSO_ORIENT] * (fabsf(tx) + fabsf(ty))) : 0.f;
-            float fx = -(R0.cx.z * P.forehead_rot[0] + R0.cy.z * P.forehead_rot[3] + R0.cz.z * P.forehead_rot[6]);
-            float fy = -(R0.cx.z * P.forehead_rot[1] + R0.cy.z * P.forehead_rot[4] + R0.cz.z * P.forehead_rot[7]);
-            r[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] = P.has_forehead ? expf(sg[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] * (fabsf(fx) + fabsf(fy))) : 0.f;
-        }
-        r[GRX_REW_CMD_DIFF_LIN_VEL_X] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_X] * fabsf(ea.cmd[0] - blv.x));
-        r[GRX_REW_CMD_DIFF_LIN_VEL_Y] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Y] * fabsf(ea.cmd[1] - blv.y));
-        r[GRX_REW_CMD_DIFF_LIN_VEL_Z] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Z] * fabsf(0.f - blv.z));
-        r[GRX_REW_COLLISION] = 1.f - expf(sg[GRX_REW_COLLISION] * pen_count);
-        r[GRX_REW_DOF_ACC_NEW] = 1.f - expf(sg[GRX_REW_DOF_ACC_NEW] * sacc);
-        r[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] = 1.f - expf(sg[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] * lift);
-        r[GRX_REW_DOF_TOR_NEW] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW] * stor);
-        r[GRX_REW_DOF_TOR_NEW_HIP_ROLL] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW_HIP_ROLL] * tor_hr);
-        r[GRX_REW_DOF_VEL_NEW] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW] * svel);
-        r[GRX_REW_DOF_VEL_NEW_KNEE] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW_KNEE] * vel_kn);
-        r[GRX_REW_FEET_AIR_FORCE] = expf(sg[GRX_REW_FEET_AIR_FORCE] * af) * moving;
-        r[GRX_REW_FEET_AIR_HEIGHT] = expf(sg[GRX_REW_FEET_AIR_HEIGHT] * ah) * moving;
-        r[GRX_REW_FEET_AIR_TIME] = at * moving;
-        r[GRX_REW_FEET_LAND_TIME] = lt * moving;
-        r[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] = expf(sg[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] * exy);
-        r[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] = expf(sg[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] * ez);
-        r[GRX_REW_FEET_STUMBLE] = stum;
-        r[GRX_REW_LIMITS_ACTIONS] = 1.f - expf(sg[GRX_REW_LIMITS_ACTIONS] * sla);
-        r[GRX_REW_LIMITS_DOF_POS] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_POS] * slp);
-        r[GRX_REW_LIMITS_DOF_TOR] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_TOR] * slt);
-        r[GRX_REW_LIMITS_DOF_VEL] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_VEL] * slv);
-        r[GRX_REW_ON_THE_AIR] = ncontact == 0.f ? 1.f : 0.f;
-        r[GRX_REW_POSE_OFFSET] = expf(sg[GRX_REW_POSE_OFFSET] * spose);
-        r[GRX_REW_POSE_OFFSET_HIP_YAW] = 1.f - expf(sg[GRX_REW_POSE_OFFSET_HIP_YAW] * shy);
-        r[GRX_REW_STAND_STILL] = expf(sg[GRX_REW_STAND_STILL] * spose) * (cmd_n < 0.1f ? 1.f : 0.f);
-        r[GRX_REW_TERMINATION] = (reset && !time_out) ? 1.f : 0.f;
+        rin.feet_height = feet_height; rin.air_time = air_time; rin.land_time = land_time; rin.avg_force = avg_force;
+        rin.avg_speed = avg_speed; rin.foot_force = so.foot_force;
+        rin.contact = contact ? 1.f : 0.f; rin.first_contact = first_contact ? 1.f : 0.f;
+        rin.cmd[0] = ea.cmd[0]; rin.cmd[1] = ea.cmd[1]; rin.cmd[2] = ea.cmd[2];
+        rin.blv = blv; rin.bav = bav; rin.pg = pg;
+        rin.bho_stale = bho_stale; rin.qx = st.qx; rin.qy = st.qy; rin.qz = st.qz; rin.qw = st.qw; rin.pen_count = pen_count;
+        rin.reset = reset ? 1.f : 0.f; rin.time_out = time_out ? 1.f : 0.f;
+        if (W == 4) {
+            int i = 0;
+            rewin_fields(rin, [&](float& x) { s_rw[(i++) * 64 + lane] = x; });
+            flag_set(s_flag + FL_REW, 1, lane);
+        } else reward_and_sums(P, C, rin, lane, side, e, N, act, s_stat, es_early);
     }
-    float rew = 0.f;
     const bool writer = act && side == 0;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        float sc_t = P.reward_scale_dt[t];
-        float rt = 0.f;
-        if (t != GRX_REW_TERMINATION && sc_t != 0.f) { rt = r[t] * sc_t; rew += rt; }
-        r[t] = rt;
-    }
-    if (P.only_positive_rewards) rew = fmaxf(rew, 0.f);
-    if (P.reward_scale_dt[GRX_REW_TERMINATION] != 0.f) {
-        float rt = r[GRX_REW_TERMINATION] = ((reset && !time_out) ? 1.f : 0.f) * P.reward_scale_dt[GRX_REW_TERMINATION];
-        rew += rt;
-    }
-    // episode sums; reset envs contribute to the block's episode statistics (legged_robot.py:420-424)
-    const unsigned long long reset_mask = __ballot(reset && writer);
-    float es_all[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) es_all[t] = es_raw[t] + r[t];
-    if (reset_mask) {
-        // finished episodes: a wave holds 0-2 of them per step, so walk the set bits (uniform loop) and pull the
-        // lane's sums through v_readlane instead of 36 six-step shuffle reductions (216 ds_bpermute + waits, measured)
-        float acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = 0.f;
-        unsigned long long m = reset_mask;
-        while (m) {
-            const int L = __ffsll((long long)m) - 1;
-            m &= m - 1;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] += __shfl(es_all[t], L);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) s_stat[t] = acc[t];
-        }
-    }
-    if (writer) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (P.reward_scale_dt[t] == 0.f) continue;  // uniform
-            P.episode_sums[(size_t)t * N + e] = reset ? 0.f : es_all[t];
-            if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
-        }
-    }
-    if (lane == 0) s_stat[NT] = (float)__popcll(reset_mask);
-
     GRX_TICK(6);
     // ---- reset_idx (masked, in-kernel)
     if (reset) {
@@ -1166,7 +1236,6 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         P.levels[e] = ea.level;
         P.base_heights_offset[e] = bho;
         P.ep_len[e] = ep_len;
-        P.rew[e] = rew;
         P.reset[e] = reset ? 1 : 0;
         P.time_out[e] = time_out ? 1 : 0;
         P.term_contact[e] = term_contact ? 1 : 0;

@@ -39,7 +39,7 @@
 #define GRX_WAIT(f, want, slot) flag_wait(f, want)
 #endif
 
-enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_BASE = 4, FL_BIAS = 5, FL_COUNT = 8 };
+enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_BASE = 4, FL_BIAS = 5, FL_REW = 6, FL_COUNT = 8 };
 constexpr int REC = 34;   // floats per joint record: ua 3, ul 3, 1/d, A' 6, B' 9, D' 6, joint axis Sa 3, Ss 3
 constexpr int PBR = 12;   // floats per chain body from wave 3: rigid-body bias force pa 3, pl 3, velocity-product acceleration ca 3, cl 3
 
@@ -58,8 +58,8 @@ GRX_DEV void flag_set(int* f, int v, int lane) {
     if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 GRX_DEV void flag_wait(int* f, int want) {
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < want)
-        __builtin_amdgcn_s_sleep(1);
+    // pure spin (the waiter owns its SIMD; an s_sleep between polls only added detection latency: +1.3 % measured)
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {}
 }
 
 // velocity-product (bias) force of a rigid body about O, from its centre-of-mass quantities (no 3x3 world inertia):
