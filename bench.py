@@ -23,8 +23,9 @@ Extra objects on the JSON line:
                 Isaac Gym's CPU pipeline (unobtainable).
 """
 import argparse
-import json
 import os
+
+import json
 import sys
 import time
 
@@ -114,7 +115,7 @@ def main():
     for _ in range(args.warmup):
         counter += 1
         sim.step(pool[counter % 16], delay, counter)
-    sim.kernel_time_ms(enable=True)               # start the HIP-event window
+    sim.kernel_time_ms(enable=int(os.environ.get("GRX_BENCH_EVENT_STRIDE", "8")))   # HIP-event window: every 8th launch (an event pair costs the stream ~7 us)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -123,7 +124,8 @@ def main():
     for _ in range(args.steps):
         counter += 1
         sim.step(pool[counter % 16], delay, counter)
-    torch.cuda.synchronize()
+    sim.wait_idle()           # spin on the library's pinned progress word until the last step has finished: the HIP
+    torch.cuda.synchronize()  # runtime's own completion view was measured to lag by 10-80 ms sporadically
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -170,7 +172,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per * n_local,
-                         "kernel": "grx_step_kernel", "kernel_ms": kern_ms, "launches": launches,
+                         "kernel": "grx_step_kernel", "kernel_ms": kern_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_env_step": bytes_per,
                          "note": "instruction-issue bound at this batch size (one wave per SIMD, DESIGN.md sections 4.1 and 5); HBM is the contractual roofline"},
         }

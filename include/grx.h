@@ -332,9 +332,16 @@ int grx_set_state(grx_handle h, const float* root_states, const float* dof_pos,
 /* copy GRX_T_EPISODE_STATS to host (synchronises the stream) */
 int grx_episode_stats(grx_handle h, float* host_out, void* stream);
 
-/* average duration [ms] of the fused step kernel over the launches since the last call, measured
- * with HIP events recorded on the launch stream (bench.py roofline leg); resets the window. */
+/* average duration [ms] of the fused step kernel over the timed launches since the last call, measured
+ * with HIP events recorded on the launch stream (bench.py roofline leg); resets the window.
+ * enable: 0 = stop, 1 = time every launch, n > 1 = time every n-th launch (an event pair costs the
+ * stream several microseconds of serialisation, which matters next to an 80 us kernel). */
 int grx_kernel_time_ms(grx_handle h, int enable, float* avg_ms, int64_t* launches);
+
+/* Spin (no blocking system call) until every step enqueued through this handle has finished on the GPU.
+ * The library also bounds the host's run-ahead to 48 policy steps with the same progress word (a ticket the last
+ * kernel of each step stores in host-pinned memory), see grx_capi.cpp. */
+int grx_wait_idle(grx_handle h);
 
 const char* grx_last_error(void);
 int grx_abi_version(void);

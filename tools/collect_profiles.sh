@@ -17,7 +17,11 @@ if [ "$2" != "skip-tests" ]; then
     timeout 1500 python -m pytest tests -m gpu -x -q > $out/pytest_gpu.log 2>&1
     tail -3 $out/pytest_gpu.log
 fi
+# the boxes are shared: a co-tenant's kernels delay this workload's full-CU blocks by 10-80 ms now and then,
+# so the headline line is taken three times; bench_rough.json is the FIRST run, bench_rough_runs.jsonl holds all of them
 timeout 600 python bench.py 2> $out/bench_rough.err | tail -1 > $out/bench_rough.json
+cp $out/bench_rough.json $out/bench_rough_runs.jsonl
+for i in 2 3; do timeout 300 python bench.py --no-cpu-baseline 2>> $out/bench_rough.err | tail -1 >> $out/bench_rough_runs.jsonl; done
 timeout 300 python bench.py --terrain flat --no-cpu-baseline 2> $out/bench_flat.err | tail -1 > $out/bench_flat.json
 : > $out/sweep.jsonl
 for n in 8192 16384 32768 65536 131072; do
@@ -30,6 +34,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OLDPWD/$d -o b -- bash -c "cd $OLDPWD && $BENCH" > $OLDPWD/$d.log 2>&1)
 done
 cut -c1-400 $out/bench_rough.json; cut -c1-200 $out/bench_flat.json
+python -c "import json; print('rough runs ms/step:', [round(json.loads(l)['ms_per_step'], 4) for l in open('$out/bench_rough_runs.jsonl')])"
 python - <<EOF
 import json
 for l in open("$out/sweep.jsonl"):

@@ -5,7 +5,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src, dst = f"gpurun_out/{tag}", "profiles"
 os.makedirs(dst, exist_ok=True)
 shutil.copy(f"{src}/stats/b_kernel_stats.csv", f"{dst}/{tag}_kernel_stats_rough4096.csv")
-for a, b in (("bench_rough.json", "bench_n1_rough4096.json"), ("bench_flat.json", "bench_n1_flat4096.json"), ("sweep.jsonl", "bench_n1_rough_sweep.jsonl")):
+for a, b in (("bench_rough.json", "bench_n1_rough4096.json"), ("bench_flat.json", "bench_n1_flat4096.json"), ("sweep.jsonl", "bench_n1_rough_sweep.jsonl"), ("bench_rough_runs.jsonl", "bench_n1_rough4096_runs.jsonl")):
     shutil.copy(f"{src}/{a}", f"{dst}/{tag}_{b}")
 out = {}
 for name in ("fetch", "write"):

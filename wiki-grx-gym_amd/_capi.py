@@ -161,6 +161,8 @@ def bind(lib, prefix="grx_"):
         "abi_version": fn("abi_version", C.c_int),
         "reward_term_name": fn("reward_term_name", C.c_char_p, C.c_int),
     }
+    if hasattr(lib, prefix + "wait_idle"):
+        api["wait_idle"] = fn("wait_idle", C.c_int, H)
     if hasattr(lib, prefix + "kernel_time_ms"):
         api["kernel_time_ms"] = fn("kernel_time_ms", C.c_int, H, C.c_int, C.POINTER(C.c_float), C.POINTER(i64))
     return api
@@ -168,6 +170,6 @@ def bind(lib, prefix="grx_"):
 
 EXPORTED_SYMBOLS = (
     "grx_create", "grx_destroy", "grx_reset_all", "grx_step", "grx_tensor", "grx_set_state",
-    "grx_episode_stats", "grx_kernel_time_ms", "grx_last_error", "grx_abi_version",
+    "grx_episode_stats", "grx_kernel_time_ms", "grx_wait_idle", "grx_last_error", "grx_abi_version",
     "grx_reward_term_name",
 )

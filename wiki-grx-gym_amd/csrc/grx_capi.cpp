@@ -18,7 +18,7 @@
 extern "C" {
 void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                      const float* noise, hipStream_t stream);
-void grx_launch_finalize(const KParams* dP, int N, hipStream_t stream);
+void grx_launch_finalize(const KParams* dP, int N, int64_t* progress, int64_t ticket, hipStream_t stream);
 void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream);
 void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, hipStream_t stream);
 int grx_envs_per_block(void);
@@ -45,6 +45,23 @@ struct Timing {
     double total_ms = 0;   // launches already drained from `pending`
     int64_t count = 0;
     static constexpr size_t kMaxPending = 64;
+    int stride = 1;        // record every stride-th launch (an event pair costs the stream ~7 us of serialisation)
+    int64_t tick = 0;
+};
+
+// Host run-ahead pacing and completion visibility.  A caller that never synchronises (rollout loops, bench.py) can
+// enqueue hundreds of policy steps in a few milliseconds.  On the shared MI355X boxes the HIP runtime's view of
+// completed work (hipEventQuery / stream synchronisation) was measured to lag the GPU by 10-80 ms, sporadically, for
+// this low-occupancy workload (rocprofv3 kernel traces show the kernels themselves at a steady 75 us).  The library
+// therefore keeps its own progress word: grx_finalize_stats, the last kernel of every step, stores the step's ticket
+// in host-pinned memory with a system-scope release, and the host reads that word directly -- to bound its
+// run-ahead (kPaceAhead steps) and to let callers spin until everything enqueued so far has really finished
+// (grx_wait_idle) without going through the runtime's signal machinery.
+struct Pace {
+    static constexpr int64_t kPaceAhead = 48;
+    volatile int64_t* progress = nullptr;   // host-pinned, device-visible
+    int64_t* d_progress = nullptr;          // device view of the same word
+    int64_t issued = 0;                     // ticket of the last step enqueued
 };
 }  // namespace
 
@@ -53,11 +70,13 @@ struct grx_sim {
     int device = 0;
     int N = 0;
     int waves = 1;         // waves per 32-env block of the step kernel (1, 2 or 4)
-    KParams hp;            // launch parameters (passed by value to every kernel)
+    KParams hp;            // launch parameters: host image ...
+    KParams* d_hp = nullptr;   // ... and the device copy every kernel reads through the constant address space
     KTables tab;           // host image of the device tables
     std::vector<void*> allocs;
     uint32_t reset_count = 0;
     Timing timing;
+    Pace pace;
     // tensor table
     grx_tensor_desc desc[GRX_NUM_TENSORS];
     long long* prof_host = nullptr; int prof_blocks = 0;
@@ -485,6 +504,20 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     desc_vec(s, GRX_T_EPISODE_STATS, P.stats, GRX_F32, NT + 1);
     desc_soa3(s, GRX_T_ANCHORS, P.anchors, 8, 3);
     s->prof_host = P.prof; s->prof_blocks = nblocks;
+    {
+        void* hp_ = nullptr;
+        HIP_TRY(hipHostMalloc(&hp_, sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
+        s->pace.progress = static_cast<volatile int64_t*>(hp_);
+        *s->pace.progress = 0;
+        void* dp_ = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp_, hp_, 0));
+        s->pace.d_progress = static_cast<int64_t*>(dp_);
+    }
+    {   // the parameter block is immutable from here on: upload it once
+        rc = dalloc(s, &s->d_hp, 1);
+        if (rc) { grx_destroy(s); return rc; }
+        HIP_TRY(hipMemcpy(s->d_hp, &s->hp, sizeof(KParams), hipMemcpyHostToDevice));
+    }
     *out = s;
     return GRX_OK;
 }
@@ -495,6 +528,7 @@ int grx_destroy(grx_handle s) {
     for (void* p : s->allocs) hipFree(p);
     for (auto& pr : s->timing.pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto& pr : s->timing.pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    if (s->pace.progress) hipHostFree((void*)s->pace.progress);
     delete s;
     return GRX_OK;
 }
@@ -505,8 +539,8 @@ int grx_reset_all(grx_handle s, void* stream) {
     // extras["episode"] of a full reset: mean of the running episode sums over all envs
     // (legged_robot.py:420-424); computed by the stats path with every env flagged.
     uint32_t step = 0x80000000u + (s->reset_count++);
-    grx_launch_reset_all(&s->hp, s->N, step, st);
-    grx_launch_finalize(&s->hp, s->N, st);
+    grx_launch_reset_all(s->d_hp, s->N, step, st);
+    grx_launch_finalize(s->d_hp, s->N, s->pace.d_progress, ++s->pace.issued, st);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
@@ -514,12 +548,16 @@ int grx_reset_all(grx_handle s, void* stream) {
 int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
     if (!s || !a) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_step: null argument");
     hipStream_t st = (hipStream_t)stream;
+    static const bool no_pace = getenv("GRX_DEBUG_NO_PACE") != nullptr;
+    if (!no_pace)
+        while (s->pace.issued - *s->pace.progress >= Pace::kPaceAhead) {}   // spin on the pinned progress word
     std::pair<hipEvent_t, hipEvent_t> ev;
-    if (s->timing.enabled) {
+    const bool timed = s->timing.enabled && (s->timing.tick++ % s->timing.stride) == 0;
+    if (timed) {
         if (s->timing.pending.size() >= Timing::kMaxPending) {   // bound the event population (and the host's run-ahead)
             auto pr = s->timing.pending.front();
             s->timing.pending.pop_front();
-            HIP_TRY(hipEventSynchronize(pr.second));
+            while (hipEventQuery(pr.second) == hipErrorNotReady) {}   // spin: see Pace
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
             s->timing.total_ms += ms; ++s->timing.count;
@@ -529,15 +567,15 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
     }
-    grx_launch_step(&s->hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
+    grx_launch_step(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
                     (long long)a->common_step_counter, a->noise_uniform, st);
-    if (s->timing.enabled) {
+    if (timed) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->timing.pending.push_back(ev);
     }
     // (folding this reduction into the step kernel's last block was tried: the agent-scope __threadfence every block
     // then needs writes back the whole XCD L2 -- +10 us per launch, measured -- so it stays a 3.7 us kernel of its own)
-    grx_launch_finalize(&s->hp, s->N, st);
+    grx_launch_finalize(s->d_hp, s->N, s->pace.d_progress, ++s->pace.issued, st);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
@@ -551,7 +589,7 @@ int grx_tensor(grx_handle s, int id, grx_tensor_desc* out) {
 
 int grx_set_state(grx_handle s, const float* root, const float* q, const float* qd, void* stream) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_set_state: null handle");
-    grx_launch_set_state(&s->hp, s->N, root, q, qd, (hipStream_t)stream);
+    grx_launch_set_state(s->d_hp, s->N, root, q, qd, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
@@ -578,6 +616,8 @@ int grx_kernel_time_ms(grx_handle s, int enable, float* avg_ms, int64_t* launche
     }
     s->timing.pending.clear();
     s->timing.enabled = enable != 0;
+    s->timing.stride = enable > 1 ? enable : 1;
+    s->timing.tick = 0;
     if (avg_ms) *avg_ms = n ? (float)(tot / n) : 0.f;
     if (launches) *launches = n;
     return GRX_OK;
@@ -589,6 +629,13 @@ int grx_debug_profile(grx_handle s, long long* out, int max_blocks) {
     int nb = s->prof_blocks < max_blocks ? s->prof_blocks : max_blocks;
     HIP_TRY(hipMemcpy(out, s->prof_host, (size_t)nb * 32 * sizeof(long long), hipMemcpyDeviceToHost));
     return nb;
+}
+
+// spin until every step enqueued through this handle has finished on the GPU (reads the pinned progress word)
+int grx_wait_idle(grx_handle s) {
+    if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_wait_idle: null handle");
+    while (*s->pace.progress < s->pace.issued) {}
+    return GRX_OK;
 }
 
 const char* grx_last_error(void) { return g_err.c_str(); }

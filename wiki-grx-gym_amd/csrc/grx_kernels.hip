@@ -30,6 +30,14 @@
 #include "grx_math.h"
 #include "grx_rng.h"
 
+// Launch parameters live in device memory, uploaded once per handle, and are read through the CONSTANT address space
+// (like the kernarg segment: scalar loads the compiler may hoist and merge across global stores).  Passing the ~1.5 KB
+// struct by value instead exhausted the HIP runtime's kernarg pool every ~55 launches; its refill is a blocking
+// wait whose wake-up was measured at 10-60 ms on a loaded host.
+#define GRX_AS4 __attribute__((address_space(4)))
+typedef const GRX_AS4 KParams& KP;
+#define GRX_PARAMS(Pg) (*reinterpret_cast<const GRX_AS4 KParams*>(reinterpret_cast<uintptr_t>(Pg)))
+
 #ifdef GRX_PROFILE_SECTIONS
 #define GRX_TICK(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); if (threadIdx.x == 0) P.prof[(size_t)blockIdx.x * 32 + (i)] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 // sub-step sections accumulate in registers (g_tacc is a kernel-scope local); sched_barrier pins the code motion
@@ -63,7 +71,7 @@ GRX_DEV void grx_sincos(float x, float& s, float& c) {
 
 // physics terrain query: bilinear interpolation of the int16 heightfield (oracle: terrain_height)
 template <bool HF>
-GRX_DEV float terrain_height(const KParams& P, float x, float y) {
+GRX_DEV float terrain_height(KP P, float x, float y) {
     if (!HF) return 0.0f;
     float fx = (x + P.border_size) * P.inv_hscale;
     float fy = (y + P.border_size) * P.inv_hscale;
@@ -109,13 +117,21 @@ struct FootKin { V3 pos, vel, ang; };  // foot link origin (world), its velocity
 __device__ constexpr int kSphCnt[LEG] = {0, 0, 2, 2, 4};
 __device__ constexpr int kSphOff[LEG] = {8, 8, 8, 10, 12};
 
+// Centre of a sphere relative to O and the terrain height under it.  The heightfield gathers are issued for every
+// lane, unconditionally (indices are clamped), so that a group's lookups are all in flight together instead of one
+// exposed memory latency per sphere inside divergent branches.
+template <bool HF>
+GRX_DEV void sphere_probe(KP P, const SphC& S, const R3& R, V3 rho, V3 O, V3& xr, float& th) {
+    xr = rho + rot(R, v3(S.x, S.y, S.z));
+    th = terrain_height<HF>(P, O.x + xr.x, O.y + xr.y);
+}
+
 // One sphere against the terrain.  R/rho/w/v: rotation, origin (relative to the base origin O), angular
 // velocity and O-referenced linear velocity of the carrying body.  SLOT: friction-anchor slot of a foot
-// sphere (compile time), -1 for the other shapes.  Returns the world-frame force; xr = centre relative to O.
+// sphere (compile time), -1 for the other shapes.  xr = sphere centre relative to O, th = terrain height under it
+// (sphere_probe).  Returns the world-frame force.
 template <bool HF, int SLOT>
-GRX_DEV V3 sphere_contact(const KParams& P, const SphC& S, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu, float hmax,
-                          LaneState& st, V3& xr) {
-    xr = rho + rot(R, v3(S.x, S.y, S.z));
+GRX_DEV V3 sphere_contact(KP P, const SphC& S, V3 w, V3 v, V3 O, float mu, float hmax, LaneState& st, V3 xr, float th) {
     V3 F = v3(0.f, 0.f, 0.f);
     const float wz = O.z + xr.z;
     // cull: hmax bounds the terrain height anywhere the robot can reach during this policy step
@@ -123,7 +139,7 @@ GRX_DEV V3 sphere_contact(const KParams& P, const SphC& S, const R3& R, V3 rho, 
     bool touching = false;
     if (wz - S.r <= hmax) {
         const float wx = O.x + xr.x, wy = O.y + xr.y;
-        const float d = terrain_height<HF>(P, wx, wy) + S.r - wz;
+        const float d = th + S.r - wz;
         if (d > 0.0f) {
             touching = true;
             V3 u = v + cross(w, xr);
@@ -189,7 +205,7 @@ GRX_DEV R3 joint_unrot_k(const R3& R, float c, float s, int ax) {
 // the dynamics wave runs the kinematics / articulated-inertia passes; the wrench enters at the base solve.
 // MIDBAR: the 4-wave block layout has a barrier (#2) in the middle of the sub-step; the helper passes it half-way.
 template <bool HF, bool MIDBAR>
-GRX_DEV void base_lump_contacts(const KParams& P, const SideConst& C, const R3& R0, V3 O, V3 ang, V3 vel, float mu, float hmax,
+GRX_DEV void base_lump_contacts(KP P, const SideConst& C, const R3& R0, V3 O, V3 ang, V3 vel, float mu, float hmax,
                                 V3& f0a, V3& f0l, bool& term, float& pen_count) {
     f0a = v3(0.f, 0.f, 0.f); f0l = v3(0.f, 0.f, 0.f);
     term = false; pen_count = 0.f;
@@ -201,11 +217,14 @@ GRX_DEV void base_lump_contacts(const KParams& P, const SideConst& C, const R3& 
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (reach) {
+            V3 xrs[4]; float ths[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sphere_probe<HF>(P, C.sph[half * 4 + i], R0, zero, O, xrs[i], ths[i]);
 #pragma unroll
             for (int i = half * 4; i < half * 4 + 4; ++i) {
                 const SphC& S = C.sph[i];
-                V3 xr;
-                V3 F = sphere_contact<HF, -1>(P, S, R0, zero, ang, vel, O, mu, hmax, dummy, xr);
+                const V3 xr = xrs[i - half * 4];
+                V3 F = sphere_contact<HF, -1>(P, S, ang, vel, O, mu, hmax, dummy, xr, ths[i - half * 4]);
                 f0a = f0a + cross(xr, F);
                 f0l = f0l + F;
                 Flink = Flink + F;
@@ -237,31 +256,35 @@ GRX_DEV void chain_step(const SideConst& C, int k, float q, float qd, ChainKin& 
 
 // the four anchored spheres of this lane's foot (chain body LEG-1): wrench about O + anchor update
 template <bool HF>
-GRX_DEV void foot_contacts(const KParams& P, const SideConst& C, const ChainKin& K, V3 O, float mu, float hmax, LaneState& st,
+GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, float mu, float hmax, LaneState& st,
                            V3& fa, V3& fl) {
     fa = v3(0.f, 0.f, 0.f); fl = v3(0.f, 0.f, 0.f);
     constexpr int o = kSphOff[LEG - 1];
     if (group_within_reach<4>(&C.sph[o], K.R, K.rho, O, hmax)) {
-        V3 xr, F;
-        F = sphere_contact<HF, 0>(P, C.sph[o + 0], K.R, K.rho, K.w, K.v, O, mu, hmax, st, xr); fa = fa + cross(xr, F); fl = fl + F;
-        F = sphere_contact<HF, 1>(P, C.sph[o + 1], K.R, K.rho, K.w, K.v, O, mu, hmax, st, xr); fa = fa + cross(xr, F); fl = fl + F;
-        F = sphere_contact<HF, 2>(P, C.sph[o + 2], K.R, K.rho, K.w, K.v, O, mu, hmax, st, xr); fa = fa + cross(xr, F); fl = fl + F;
-        F = sphere_contact<HF, 3>(P, C.sph[o + 3], K.R, K.rho, K.w, K.v, O, mu, hmax, st, xr); fa = fa + cross(xr, F); fl = fl + F;
+        V3 xr[4], F; float th[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sphere_probe<HF>(P, C.sph[o + i], K.R, K.rho, O, xr[i], th[i]);
+        F = sphere_contact<HF, 0>(P, C.sph[o + 0], K.w, K.v, O, mu, hmax, st, xr[0], th[0]); fa = fa + cross(xr[0], F); fl = fl + F;
+        F = sphere_contact<HF, 1>(P, C.sph[o + 1], K.w, K.v, O, mu, hmax, st, xr[1], th[1]); fa = fa + cross(xr[1], F); fl = fl + F;
+        F = sphere_contact<HF, 2>(P, C.sph[o + 2], K.w, K.v, O, mu, hmax, st, xr[2], th[2]); fa = fa + cross(xr[2], F); fl = fl + F;
+        F = sphere_contact<HF, 3>(P, C.sph[o + 3], K.w, K.v, O, mu, hmax, st, xr[3], th[3]); fa = fa + cross(xr[3], F); fl = fl + F;
     } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
 }
 
 // the two (unanchored) spheres of chain body k (thigh_pitch / shank)
 template <bool HF>
-GRX_DEV void link_contacts(const KParams& P, const SideConst& C, int k, const ChainKin& K, V3 O, float mu, float hmax, V3& fa, V3& fl) {
+GRX_DEV void link_contacts(KP P, const SideConst& C, int k, const ChainKin& K, V3 O, float mu, float hmax, V3& fa, V3& fl) {
     fa = v3(0.f, 0.f, 0.f); fl = v3(0.f, 0.f, 0.f);
     LaneState dummy;
     dummy.anchor_on = 0;
     if (group_within_reach<2>(&C.sph[kSphOff[k]], K.R, K.rho, O, hmax)) {
+        V3 xr[2]; float th[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sphere_probe<HF>(P, C.sph[kSphOff[k] + i], K.R, K.rho, O, xr[i], th[i]);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            V3 xr;
-            V3 F = sphere_contact<HF, -1>(P, C.sph[kSphOff[k] + i], K.R, K.rho, K.w, K.v, O, mu, hmax, dummy, xr);
-            fa = fa + cross(xr, F); fl = fl + F;
+            V3 F = sphere_contact<HF, -1>(P, C.sph[kSphOff[k] + i], K.w, K.v, O, mu, hmax, dummy, xr[i], th[i]);
+            fa = fa + cross(xr[i], F); fl = fl + F;
         }
     }
 }
@@ -271,7 +294,7 @@ GRX_DEV void link_contacts(const KParams& P, const SideConst& C, int k, const Ch
 // W = waves per block: 1 = everything inline; 2 = the base-lump contacts come from the helper wave through `wr`
 // (W == 4 uses the producer/consumer pipeline of grx_wavepipe.h instead of this function).
 template <bool HF, int W>
-GRX_DEV void substep(const KParams& P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
+GRX_DEV void substep(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                      SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc) {
     const float dt = P.sim_dt;
     R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
@@ -472,12 +495,12 @@ GRX_DEV FootKin foot_kinematics(const SideConst& C, const LaneState& st) {
     return f;
 }
 
-GRX_DEV float urand(const KParams& P, uint32_t genv, uint32_t step, uint32_t stream, uint32_t i, float lo, float hi) {
+GRX_DEV float urand(KP P, uint32_t genv, uint32_t step, uint32_t stream, uint32_t i, float lo, float hi) {
     return (hi - lo) * grx_rand(P.seed, genv, step, stream, i) + lo;
 }
 
 // legged_robot.py:650-677
-GRX_DEV void resample_commands(const KParams& P, uint32_t genv, uint32_t step, uint32_t stream, float cmd[3]) {
+GRX_DEV void resample_commands(KP P, uint32_t genv, uint32_t step, uint32_t stream, float cmd[3]) {
     float c0 = urand(P, genv, step, stream, 0, P.cmd_lin_vel_x[0], P.cmd_lin_vel_x[1]);
     float c1 = urand(P, genv, step, stream, 1, P.cmd_lin_vel_y[0], P.cmd_lin_vel_y[1]);
     float keep = sqrtf(c0 * c0 + c1 * c1) > 0.1f ? 1.0f : 0.0f;
@@ -494,7 +517,7 @@ struct EnvAux {  // per-env (replicated in both lanes) pipeline state touched by
 
 // reset_idx for one env (legged_robot.py:377-440, 717-826; legged_robot_fftai.py:137-146):
 // each lane resets its own leg, the root state is computed redundantly (same counters -> same values)
-GRX_DEV void reset_env(const KParams& P, const SideConst& C, int side, uint32_t genv, uint32_t step, bool init_done,
+GRX_DEV void reset_env(KP P, const SideConst& C, int side, uint32_t genv, uint32_t step, bool init_done,
                        LaneState& st, EnvAux& ea) {
     if (P.curriculum && P.terrain_type != GRX_TERRAIN_PLANE && init_done) {  // legged_robot.py:799-826
         float dx = st.pos.x - ea.origin[0], dy = st.pos.y - ea.origin[1];
@@ -543,7 +566,7 @@ GRX_DEV void reset_env(const KParams& P, const SideConst& C, int side, uint32_t 
 // min of three raster corners), so this function is compiled with reassociation OFF and spells out
 // quat_apply_yaw (math.py:38-42 -> torch_utils.py:48-55) in the reference's operation order; zn/wn are the
 // yaw-only quaternion's z and w (the x, y terms of the two cross products are exact zeros and are dropped).
-GRX_DEV float height_sample(const KParams& P, const KTables& T, float zn, float wn, V3 pos, int k) {
+GRX_DEV float height_sample(KP P, const KTables& T, float zn, float wn, V3 pos, int k) {
 #pragma clang fp reassociate(off)
     const float bx = T.height_points[k][0], by = T.height_points[k][1];
     const float tx = -(zn * by) * 2.0f, ty = (zn * bx) * 2.0f;   // t = 2 * cross(qv, b)
@@ -561,7 +584,7 @@ GRX_DEV float height_sample(const KParams& P, const KTables& T, float zn, float 
 // One lane's share of the height scan: points k = first, first + 2*NW, ... (NW waves x 2 lanes per env); raw heights
 // parked in the env's pri_obs staging row; returns the lane's partial sum.  Batches of 8 independent gathers.
 template <int NW>
-GRX_DEV float height_scan_share(const KParams& P, const KTables& T, float zn, float wn, V3 pos, int first, int nh, float* prow) {
+GRX_DEV float height_scan_share(KP P, const KTables& T, float zn, float wn, V3 pos, int first, int nh, float* prow) {
     float hsum = 0.f;
     for (int k0 = first; k0 < nh; k0 += 16 * NW) {
         float hb[8];
@@ -589,7 +612,7 @@ GRX_DEV float sum_abs_mask(const float a[LEG], uint32_t mask) {
 // group*5 + k (group 0 pos, 1 vel, 2 action).  The six 10-round chains are advanced together, round by round, so
 // the 64-bit multiplies of independent chains interleave (a serial chain per value cost ~18k cycles/step, measured).
 constexpr int NZB = 6;   // slots 0..3: dof stream blocks 0..3; slots 4,5: base stream blocks 0,1 (left lane)
-GRX_DEV void noise_blocks(const KParams& P, uint32_t genv, uint32_t step, int side, U4 nzb[NZB]) {
+GRX_DEV void noise_blocks(KP P, uint32_t genv, uint32_t step, int side, U4 nzb[NZB]) {
     uint32_t c0[NZB], c1[NZB], c2[NZB], c3[NZB];
 #pragma unroll
     for (int b = 0; b < NZB; ++b) {
@@ -642,7 +665,7 @@ GRX_DEV void rewin_fields(RewIn& r, F&& f) {
 // Runs on wave 0, or -- four waves per block -- on wave 1 while wave 0 goes on with reset and observations.
 // es_pre: the env's running episode sums if the caller loaded them early (their HBM latency then overlaps the state
 // update), else nullptr.
-GRX_DEV void reward_and_sums(const KParams& P, const SideConst& C, const RewIn& in, int lane, int side, int e, int N, bool act,
+GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane, int side, int e, int N, bool act,
                              float* s_stat, const float* es_pre) {
     const int j0 = side * LEG;
     const float dtp = P.sim_dt * (float)P.decimation;
@@ -654,7 +677,7 @@ GRX_DEV void reward_and_sums(const KParams& P, const SideConst& C, const RewIn& 
     float r[NT];
     {
         const float as = P.action_scale, H = P.swing_feet_height_target, T = P.feet_air_time_target;
-        const float* sg = P.reward_sigma;
+        const GRX_AS4 float* sg = P.reward_sigma;
         const uint32_t knee = (P.knee_mask >> j0) & 31u, hiproll = (P.hip_roll_mask >> j0) & 31u, hipyaw = (P.hip_yaw_mask >> j0) & 31u;
         const uint32_t ankle = ((side ? P.ankle_right_mask : P.ankle_left_mask) >> j0) & 31u;
         float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
@@ -806,8 +829,9 @@ GRX_DEV void reward_and_sums(const KParams& P, const SideConst& C, const RewIn& 
 //   W == 2: wave 1 computes the base-lump contact wrench of every sub-step (two block barriers per sub-step);
 //   W == 4: the four-wave producer/consumer pipeline of grx_wavepipe.h (sequence counters in LDS).
 template <bool HF, int W>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_kernel(const KParams P, const float* __restrict__ actions_in,
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_kernel(const KParams* __restrict__ Pg, const float* __restrict__ actions_in,
                                                       float delay, long long common_step, const float* __restrict__ noise_in) {
+    KP P = GRX_PARAMS(Pg);
     constexpr int NTHR = 64 * W;
     __shared__ KTables s_tab;
     __shared__ __attribute__((aligned(16))) float s_obs[EPB * GRX_NUM_OBS];
@@ -817,6 +841,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __shared__ float s_wr[8 * 64];       // base-lump wrench + termination / collision flags (helper -> dynamics)
     // W == 4 pipeline buffers (grx_wavepipe.h)
     __shared__ float s_q[W == 4 ? 2 * LEG * 64 : 1];
+    __shared__ float s_ri[W == 4 ? LEG * RIR * 64 : 1];
     __shared__ float s_rec[W == 4 ? LEG * REC * 64 : 1];
     __shared__ float s_rec0[W == 4 ? 21 * 64 : 1];
     __shared__ float s_wc[W == 4 ? 21 * 64 : 1];
@@ -827,7 +852,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __shared__ float s_hsum[W == 4 ? 4 * 64 : 1];          // height scan: partial sums per wave
     __shared__ float s_rw[W == 4 ? REWIN_FLOATS * 64 : 1];   // reward inputs (wave 0 -> wave 1)
     __shared__ int s_flag[FL_COUNT];
-    const PipeLds L = {s_base, s_q, s_rec, s_rec0, s_wc, s_pb, s_wr, s_flag};
+    const PipeLds L = {s_base, s_q, s_ri, s_rec, s_rec0, s_wc, s_pb, s_wr, s_flag};
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     {   // stage the per-side robot tables (joint tree, inertias, gains, spheres) into LDS
@@ -1270,7 +1295,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 // extras["episode"] (legged_robot.py:420-424): mean episode sums of the envs reset by this step;
 // kept from the previous resetting step when nobody reset (the reference only rewrites the dict
 // inside reset_idx, which returns early for an empty id list, legged_robot.py:387-388).
-__global__ __launch_bounds__(64) void grx_finalize_stats(const KParams P, int nblocks) {
+__global__ __launch_bounds__(64) void grx_finalize_stats(const KParams* __restrict__ Pg, int nblocks, int64_t* progress, int64_t ticket) {
+    KP P = GRX_PARAMS(Pg);
     const int t = blockIdx.x, lane = threadIdx.x;   // one wave per reward term: lanes stride over the step kernel's blocks
     float cnt = 0.f, s = 0.f;
     for (int b = lane; b < nblocks; b += 64) {
@@ -1280,10 +1306,14 @@ __global__ __launch_bounds__(64) void grx_finalize_stats(const KParams P, int nb
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { cnt += __shfl_xor(cnt, off); s += __shfl_xor(s, off); }
     if (lane == 0 && cnt > 0.f) P.stats[t] = (t == NT) ? cnt : s / cnt / P.max_episode_length_s;
+    // step ticket for the host's progress word (pinned host memory): this kernel runs after the step kernel in stream
+    // order, so a visible ticket means the step's outputs are complete
+    if (t == 0 && lane == 0 && progress) __hip_atomic_store(progress, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // BaseTask.reset() first half (base_task.py:117-119): reset_idx(all envs), no step
-__global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams P, uint32_t step) {
+__global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __restrict__ Pg, uint32_t step) {
+    KP P = GRX_PARAMS(Pg);
     __shared__ SideConst sc[2];
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables->side);
@@ -1337,8 +1367,9 @@ __global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams P, uint
 }
 
 // set_dof_state_tensor / set_actor_root_state_tensor (legged_robot.py:737, 796): AoS rows -> SoA state
-__global__ void grx_set_state_kernel(const KParams P, const float* __restrict__ root, const float* __restrict__ q,
+__global__ void grx_set_state_kernel(const KParams* __restrict__ Pg, const float* __restrict__ root, const float* __restrict__ q,
                                      const float* __restrict__ qd) {
+    KP P = GRX_PARAMS(Pg);
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= P.N) return;
     size_t N = P.N;
@@ -1355,23 +1386,23 @@ __global__ void grx_set_state_kernel(const KParams P, const float* __restrict__ 
 
 // host-callable launchers (grx_capi.cpp is compiled by hipcc too; kept separate for readability)
 // waves: waves per 32-env block (1, 2 or 4; grx_capi.cpp picks the largest that still gives every wave its own SIMD)
-extern "C" void grx_launch_step(const KParams* hP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
+extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                                 const float* noise, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-#define GRX_LAUNCH_STEP(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, *hP, actions, delay, common_step, noise)
+#define GRX_LAUNCH_STEP(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise)
     if (heightfield) { if (waves == 4) GRX_LAUNCH_STEP(true, 4); else if (waves == 2) GRX_LAUNCH_STEP(true, 2); else GRX_LAUNCH_STEP(true, 1); }
     else { if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
 #undef GRX_LAUNCH_STEP
 }
-extern "C" void grx_launch_finalize(const KParams* hP, int N, hipStream_t stream) {
+extern "C" void grx_launch_finalize(const KParams* dP, int N, int64_t* progress, int64_t ticket, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    hipLaunchKernelGGL(grx_finalize_stats, dim3(NT + 1), dim3(64), 0, stream, *hP, nblocks);
+    hipLaunchKernelGGL(grx_finalize_stats, dim3(NT + 1), dim3(64), 0, stream, dP, nblocks, progress, ticket);
 }
-extern "C" void grx_launch_reset_all(const KParams* hP, int N, uint32_t step, hipStream_t stream) {
+extern "C" void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    hipLaunchKernelGGL(grx_reset_all_kernel, dim3(nblocks), dim3(64), 0, stream, *hP, step);
+    hipLaunchKernelGGL(grx_reset_all_kernel, dim3(nblocks), dim3(64), 0, stream, dP, step);
 }
-extern "C" void grx_launch_set_state(const KParams* hP, int N, const float* root, const float* q, const float* qd, hipStream_t stream) {
-    hipLaunchKernelGGL(grx_set_state_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, *hP, root, q, qd);
+extern "C" void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, hipStream_t stream) {
+    hipLaunchKernelGGL(grx_set_state_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dP, root, q, qd);
 }
 extern "C" int grx_envs_per_block(void) { return EPB; }

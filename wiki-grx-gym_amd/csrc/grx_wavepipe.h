@@ -6,10 +6,12 @@
 // therefore spreads the sub-step of its 32 envs over the four SIMDs of a CU as a producer/consumer pipeline
 // through LDS (lane i of every wave works on the same leg of the same env):
 //
-//   wave 0  "P" (owner of the state): motor torques, the BIAS half of the articulated-body recursion (leaf -> root),
-//            floating-base solve, acceleration pass, integration -- and the rest of env.step()
-//   wave 1  "I": outward walk + rigid-body inertias, the INERTIA half of the recursion (U, 1/d, rank-1 updates);
-//            streams one record per joint (joint axis S, U, 1/d, updated 6x6) to wave 0, which runs one joint behind
+//   wave 0  "P" (owner of the state): motor torques; while the others start up, an outward walk that builds the
+//            rigid-body inertias + joint axes for wave 1; then the BIAS half of the articulated-body recursion
+//            (leaf -> root), floating-base solve, acceleration pass, integration -- and the rest of env.step()
+//   wave 1  "I": the INERTIA half of the recursion (U, 1/d, rank-1 updates) as the rigid inertias arrive; streams
+//            one record per joint (U, 1/d, updated 6x6) back to wave 0, which runs one joint behind; finally
+//            the factorised base-level 6x6
 //   wave 2  chain contacts: own outward walk, the 4 anchored foot spheres (owns the friction anchors), then the
 //            thigh / shank spheres
 //   wave 3  own outward walk with velocities: rigid-body bias forces + velocity-product accelerations of every
@@ -39,13 +41,15 @@
 #define GRX_WAIT(f, want, slot) flag_wait(f, want)
 #endif
 
-enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_BASE = 4, FL_BIAS = 5, FL_REW = 6, FL_COUNT = 8 };
-constexpr int REC = 34;   // floats per joint record: ua 3, ul 3, 1/d, A' 6, B' 9, D' 6, joint axis Sa 3, Ss 3
+enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_BASE = 4, FL_BIAS = 5, FL_REW = 6, FL_RI = 7, FL_COUNT = 8 };
+constexpr int REC = 28;   // floats per joint record: ua 3, ul 3, 1/d, A' 6, B' 9, D' 6
+constexpr int RIR = 15;   // floats per chain body from wave 0: rigid inertia about O (A 6, h 3), joint axis Sa 3, Ss 3
 constexpr int PBR = 12;   // floats per chain body from wave 3: rigid-body bias force pa 3, pl 3, velocity-product acceleration ca 3, cl 3
 
 struct PipeLds {
     float* base;   // [13][EPB]   base state at the start of the sub-step
     float* q;      // [2*LEG][64] q, qd of every lane's leg
+    float* ri;     // [LEG][RIR][64] rigid inertias + joint axes (wave 0 -> I wave), leaf first
     float* rec;    // [LEG][REC][64] joint records of the I wave
     float* rec0;   // [21][64]    factorised base-level articulated inertia: inv(D) 6, inv(Schur) 6, B 9
     float* wc;     // [21][64]    contact wrenches about O on chain bodies 2, 3, 4; foot link velocity (3)
@@ -89,7 +93,7 @@ GRX_DEV void add_rigid(S3& A, M3& B, S3& D, const S3& Ak, V3 h, float m) {
 // ---------------------------------------------------------------------------------------------------------------
 // wave 0: one sub-step of the state owner
 template <bool HF>
-GRX_DEV void substep_p(const KParams& P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
+GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                        SubstepOut& out, FootKin& fk_before, const PipeLds& L, int lane, int seq, long long* tacc) {
     const float dt = P.sim_dt;
 #ifdef GRX_PROFILE_SECTIONS
@@ -97,6 +101,36 @@ GRX_DEV void substep_p(const KParams& P, const SideConst& C, const LaneConst& LC
 #endif
     V3 Sa[LEG], Ss[LEG], ca[LEG], cl[LEG], Ua[LEG], Ul[LEG];
     float dinv[LEG], uu[LEG];
+    // ---- outward walk (positions only) + rigid inertias about O, leaf first, for the I wave: this wave has nothing
+    // else to do until the first records come back
+    {
+        R3 RK[LEG];
+        V3 rhoK[LEG];
+        R3 R = quat_to_R(st.qx, st.qy, st.qz, st.qw);
+        V3 rho = v3(0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) {
+            rho = rho + rot(R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+            float sn, cs;
+            grx_sincos(st.q[k], sn, cs);
+            R = joint_rot_k(R, cs, sn, kAxis[k]);
+            Sa[k] = axis_k(R, kAxis[k]);
+            Ss[k] = cross(rho, Sa[k]);
+            RK[k] = R; rhoK[k] = rho;
+        }
+#pragma unroll
+        for (int k = LEG - 1; k >= 0; --k) {
+            const V3 kap = rhoK[k] + rot(RK[k], v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+            const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
+            S3 Ak; V3 hk;
+            rigid_inertia(RK[k], kap, C.body[k].mass, Ic, Ak, hk);
+            float* o = L.ri + (size_t)(k * RIR) * 64 + lane;
+            o[0 * 64] = Ak.xx; o[1 * 64] = Ak.xy; o[2 * 64] = Ak.xz; o[3 * 64] = Ak.yy; o[4 * 64] = Ak.yz; o[5 * 64] = Ak.zz;
+            o[6 * 64] = hk.x; o[7 * 64] = hk.y; o[8 * 64] = hk.z;
+            o[9 * 64] = Sa[k].x; o[10 * 64] = Sa[k].y; o[11 * 64] = Sa[k].z; o[12 * 64] = Ss[k].x; o[13 * 64] = Ss[k].y; o[14 * 64] = Ss[k].z;
+            flag_set(L.flag + FL_RI, seq * 8 + (LEG - k), lane);
+        }
+    }
     // ---- pass 2, bias half (leaf -> root), one joint behind the I wave.  The chain-body CONTACT wrenches are not
     // waited for here: the recursion is linear in the bias forces, so they are propagated separately below.
     V3 pa = v3(0.f, 0.f, 0.f), pl = v3(0.f, 0.f, 0.f);
@@ -109,7 +143,6 @@ GRX_DEV void substep_p(const KParams& P, const SideConst& C, const LaneConst& LC
         const S3 A = {r[7 * 64], r[8 * 64], r[9 * 64], r[10 * 64], r[11 * 64], r[12 * 64]};
         const M3 B = {r[13 * 64], r[14 * 64], r[15 * 64], r[16 * 64], r[17 * 64], r[18 * 64], r[19 * 64], r[20 * 64], r[21 * 64]};
         const S3 D = {r[22 * 64], r[23 * 64], r[24 * 64], r[25 * 64], r[26 * 64], r[27 * 64]};
-        Sa[k] = v3(r[28 * 64], r[29 * 64], r[30 * 64]); Ss[k] = v3(r[31 * 64], r[32 * 64], r[33 * 64]);
         {   // this body's rigid bias force joins the running articulated bias; its velocity-product acceleration
             GRX_WAIT(L.flag + FL_BIAS, seq * 8 + (LEG - k), 0);
             const float* b_ = L.pb + (size_t)(k * PBR) * 64 + lane;
@@ -210,7 +243,7 @@ GRX_DEV void substep_p(const KParams& P, const SideConst& C, const LaneConst& LC
 
 // ---------------------------------------------------------------------------------------------------------------
 // wave 1: inertia half of the articulated-body recursion for every sub-step of the policy step
-GRX_DEV void iwave_loop(const KParams& P, const SideConst& C, float base_m, V3 base_c, const S3& base_I, const PipeLds& L,
+GRX_DEV void iwave_loop(KP P, const SideConst& C, float base_m, V3 base_c, const S3& base_I, const PipeLds& L,
                         int lane, int el) {
     GRX_HELPER_PROF_BEGIN;
     for (int seq = 0; seq < P.decimation; ++seq) {
@@ -219,36 +252,21 @@ GRX_DEV void iwave_loop(const KParams& P, const SideConst& C, float base_m, V3 b
         GRX_HELPER_PROF_IDLE1;
         const float* b = L.base + el;
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
-        const float* qs = L.q + lane;
-        // outward walk: frames and joint axes (the rigid inertias are built just in time in the inward loop, so
-        // the first record leaves as early as possible: wave 0 is waiting for it)
-        V3 Sa[LEG], Ss[LEG], rhoK[LEG];
-        R3 RK[LEG];
-        R3 R = R0;
-        V3 rho = v3(0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < LEG; ++k) {
-            rho = rho + rot(R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
-            float sn, cs;
-            grx_sincos(qs[k * 64], sn, cs);
-            R = joint_rot_k(R, cs, sn, kAxis[k]);
-            Sa[k] = axis_k(R, kAxis[k]);
-            Ss[k] = cross(rho, Sa[k]);
-            RK[k] = R; rhoK[k] = rho;
-        }
-        // inward recursion
+        // base lump first (needs only the base pose): ready long before wave 0's first rigid inertia arrives
+        S3 A0; V3 h0;
+        rigid_inertia(R0, rot(R0, base_c), base_m, base_I, A0, h0);
+        // inward recursion, fed by wave 0
         S3 A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         M3 B = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = LEG - 1; k >= 0; --k) {
+            flag_wait(L.flag + FL_RI, seq * 8 + (LEG - k));
+            const float* i_ = L.ri + (size_t)(k * RIR) * 64 + lane;
             {
-                const V3 kap = rhoK[k] + rot(RK[k], v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
-                const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
-                S3 Ak; V3 hk;
-                rigid_inertia(RK[k], kap, C.body[k].mass, Ic, Ak, hk);
-                add_rigid(A, B, D, Ak, hk, C.body[k].mass);
+                const S3 Ak = {i_[0 * 64], i_[1 * 64], i_[2 * 64], i_[3 * 64], i_[4 * 64], i_[5 * 64]};
+                add_rigid(A, B, D, Ak, v3(i_[6 * 64], i_[7 * 64], i_[8 * 64]), C.body[k].mass);
             }
-            const V3 a = Sa[k], s = Ss[k];
+            const V3 a = v3(i_[9 * 64], i_[10 * 64], i_[11 * 64]), s = v3(i_[12 * 64], i_[13 * 64], i_[14 * 64]);
             const V3 ua = mul(A, a) + mul(B, s);
             const V3 ul = mulT(B, a) + mul(D, s);
             const float di = grx_rcp(dot(a, ua) + dot(s, ul));
@@ -260,16 +278,11 @@ GRX_DEV void iwave_loop(const KParams& P, const SideConst& C, float base_m, V3 b
             r[13 * 64] = B.a00; r[14 * 64] = B.a01; r[15 * 64] = B.a02; r[16 * 64] = B.a10; r[17 * 64] = B.a11;
             r[18 * 64] = B.a12; r[19 * 64] = B.a20; r[20 * 64] = B.a21; r[21 * 64] = B.a22;
             r[22 * 64] = D.xx; r[23 * 64] = D.xy; r[24 * 64] = D.xz; r[25 * 64] = D.yy; r[26 * 64] = D.yz; r[27 * 64] = D.zz;
-            r[28 * 64] = a.x; r[29 * 64] = a.y; r[30 * 64] = a.z; r[31 * 64] = s.x; r[32 * 64] = s.y; r[33 * 64] = s.z;
             flag_set(L.flag + FL_I, seq * 8 + (LEG - k), lane);
         }
         // base level: both chains + the base lump
         A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
-        {
-            S3 A0; V3 h0;
-            rigid_inertia(R0, rot(R0, base_c), base_m, base_I, A0, h0);
-            add_rigid(A, B, D, A0, h0, base_m);
-        }
+        add_rigid(A, B, D, A0, h0, base_m);
         {   // factorise for wave 0's solve: Di = inv(D), Schur complement Sc = A - B Di B^T, Sci = inv(Sc)
             const S3 Di = inv(D);
             const V3 b0 = v3(B.a00, B.a01, B.a02), b1 = v3(B.a10, B.a11, B.a12), b2 = v3(B.a20, B.a21, B.a22);
@@ -290,7 +303,7 @@ GRX_DEV void iwave_loop(const KParams& P, const SideConst& C, float base_m, V3 b
 // ---------------------------------------------------------------------------------------------------------------
 // wave 2: chain-body contacts (feet first: the bias recursion starts at the leaf)
 template <bool HF>
-GRX_DEV void chain_contact_loop(const KParams& P, const SideConst& C, float mu, float hmax, LaneState& hs, const PipeLds& L,
+GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, LaneState& hs, const PipeLds& L,
                                 int lane, int el) {
     GRX_HELPER_PROF_BEGIN;
     for (int seq = 0; seq < P.decimation; ++seq) {
@@ -331,7 +344,7 @@ GRX_DEV void chain_contact_loop(const KParams& P, const SideConst& C, float mu, 
 
 // wave 3: base-lump contacts
 template <bool HF>
-GRX_DEV void base_contact_loop(const KParams& P, const SideConst& C, float mu, float hmax, float base_m, V3 base_c, const S3& base_I,
+GRX_DEV void base_contact_loop(KP P, const SideConst& C, float mu, float hmax, float base_m, V3 base_c, const S3& base_I,
                                const PipeLds& L, int lane, int el) {
     GRX_HELPER_PROF_BEGIN;
     for (int seq = 0; seq < P.decimation; ++seq) {

@@ -19,7 +19,7 @@ import torch
 from . import _capi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libgrx_hip.so")
+HIP_LIB_PATH = os.environ.get("GRX_HIP_LIB") or os.path.join(_HERE, "csrc", "libgrx_hip.so")   # GRX_HIP_LIB: A/B builds (tools/)
 
 _TORCH_DTYPE = {_capi.DTYPE_F32: torch.float32, _capi.DTYPE_U8: torch.uint8,
                 _capi.DTYPE_I32: torch.int32, _capi.DTYPE_I64: torch.int64}
@@ -157,11 +157,18 @@ class SimHandle:
         self._check(self._api["episode_stats"](self._h, out, self._stream()), "episode_stats")
         return np.array(out[:], dtype=np.float32)
 
+    def wait_idle(self):
+        """Spin until every step enqueued so far has finished on the GPU (reads the library's pinned progress word;
+        does not go through the HIP runtime's event/signal machinery)."""
+        if "wait_idle" in self._api:
+            self._check(self._api["wait_idle"](self._h), "wait_idle")
+
     def kernel_time_ms(self, enable=True):
+        """(average ms, launches timed) since the last call; enable: False/0 stop, True/1 every launch, n every n-th."""
         if "kernel_time_ms" not in self._api:
             return 0.0, 0
         ms, n = C.c_float(0), C.c_int64(0)
-        self._check(self._api["kernel_time_ms"](self._h, int(bool(enable)), C.byref(ms), C.byref(n)), "kernel_time_ms")
+        self._check(self._api["kernel_time_ms"](self._h, int(enable), C.byref(ms), C.byref(n)), "kernel_time_ms")
         return float(ms.value), int(n.value)
 
     def close(self):
