@@ -339,7 +339,7 @@ int grx_episode_stats(grx_handle h, float* host_out, void* stream);
 int grx_kernel_time_ms(grx_handle h, int enable, float* avg_ms, int64_t* launches);
 
 /* Spin (no blocking system call) until every step enqueued through this handle has finished on the GPU.
- * The library also bounds the host's run-ahead to 48 policy steps with the same progress word (a ticket the last
+ * The library also bounds the host's run-ahead to 256 policy steps with the same progress word (a ticket the last
  * kernel of each step stores in host-pinned memory), see grx_capi.cpp. */
 int grx_wait_idle(grx_handle h);
 

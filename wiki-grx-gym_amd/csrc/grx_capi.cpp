@@ -55,10 +55,10 @@ struct Timing {
 // this low-occupancy workload (rocprofv3 kernel traces show the kernels themselves at a steady 75 us).  The library
 // therefore keeps its own progress word: grx_finalize_stats, the last kernel of every step, stores the step's ticket
 // in host-pinned memory with a system-scope release, and the host reads that word directly -- to bound its
-// run-ahead (kPaceAhead steps) and to let callers spin until everything enqueued so far has really finished
+// run-ahead (kPaceAhead steps: about 20 ms of queued work, enough to ride out a descheduled host thread) and to let callers spin until everything enqueued so far has really finished
 // (grx_wait_idle) without going through the runtime's signal machinery.
 struct Pace {
-    static constexpr int64_t kPaceAhead = 48;
+    static constexpr int64_t kPaceAhead = 256;
     volatile int64_t* progress = nullptr;   // host-pinned, device-visible
     int64_t* d_progress = nullptr;          // device view of the same word
     int64_t issued = 0;                     // ticket of the last step enqueued
