@@ -373,6 +373,24 @@ def gen_terrain_and_heights(out):
                         root=env.root_states.numpy().copy(), heights=h.numpy().copy())
 
 
+def gen_terrain_all_tiles(out):
+    """All seven tile families (stepping stones / gap / pit included) + the trimesh conversion, small grid."""
+    from legged_gym.utils.terrain import Terrain
+    from legged_gym.envs.base.legged_robot_config import LeggedRobotCfg
+    tcfg = LeggedRobotCfg.terrain()
+    tcfg.mesh_type = "trimesh"
+    tcfg.num_rows, tcfg.num_cols, tcfg.border_size = 3, 10, 5
+    tcfg.terrain_proportions = [0.1, 0.1, 0.2, 0.2, 0.1, 0.1, 0.1, 0.1]
+    np.random.seed(5)
+    ter = Terrain(tcfg, 30)
+    v, t = ter.vertices, ter.triangles
+    np.savez_compressed(os.path.join(out, "terrain_all_tiles.npz"), heightsamples=ter.heightsamples, env_origins=ter.env_origins,
+                        vert_sample=v[::997].copy(), tri_sample=t[::997].copy(), vert_sum=v.astype(np.float64).sum(0),
+                        tri_sum=t.astype(np.int64).sum(0), n_vert=len(v), n_tri=len(t))
+    # (cfg.selected cannot be pinned: the reference's selected_terrain raises AttributeError at terrain.py:103 --
+    #  self.vertical_scale / self.horizontal_scale do not exist -- and eval()s the generator name)
+
+
 def gen_config(out):
     from legged_gym.envs import GR1T1Cfg, GR1T1CfgPPO, GR1T2Cfg, GR1T2CfgPPO
     from legged_gym.utils.helpers import class_to_dict
@@ -448,6 +466,7 @@ def main():
     gen_pipeline(OUT)
     gen_reward_terms(OUT)
     gen_terrain_and_heights(OUT)
+    gen_terrain_all_tiles(OUT)
     gen_config(OUT)
     gen_ppo(OUT)
     for f in sorted(os.listdir(OUT)):

@@ -13,9 +13,11 @@ the global numpy generator, so a reference run seeded with ``np.random.seed(s)``
 rough-slope tiles go through a bilinear upsampling that the reference delegates to the removed
 ``scipy.interpolate.interp2d`` -- pinned within +-1 raster unit).
 
-Not implemented ("next"): stepping stones / gap / pit tiles, which the default
-``terrain_proportions`` never select, ``selected`` terrains and the trimesh conversion -- the
-physics of this build queries the height raster directly for 'heightfield' and 'trimesh' alike.
+All seven tile families of ``make_terrain`` are available (the default ``terrain_proportions`` only select the
+first five), so are ``selected`` terrains (``terrain_kwargs = {"type": <generator name>, ...}``) and the
+raster -> triangle-mesh conversion with the vertical-face correction (``slope_treshold``, default 0.75) that the
+reference applies for ``mesh_type = 'trimesh'``.  The physics of this build queries the height raster directly for
+'heightfield' and 'trimesh' alike; ``vertices`` / ``triangles`` are produced for API completeness (viewers, export).
 """
 import numpy as np
 
@@ -99,6 +101,86 @@ def discrete_obstacles(tile, rng, max_height, min_size, max_size, num_rects, pla
     tile.height_field_raw[a:b, a:b] = 0
 
 
+def stepping_stones(tile, rng, stone_size, stone_distance, max_height, platform_size, depth=-10.0):
+    """terrain_utils.py:227-283: rows of square stones over a deep pit, each row shifted by a random offset, every
+    stone at a random height in [-max_height, max_height); flat platform in the centre.  Same RNG call order."""
+    n = tile.width
+    ss, sd = int(stone_size / tile.horizontal_scale), int(stone_distance / tile.horizontal_scale)
+    mh = int(max_height / tile.vertical_scale)
+    plat = int(platform_size / tile.horizontal_scale)
+    levels = np.arange(-mh - 1, mh, step=1)
+    H = tile.height_field_raw
+    H[:, :] = int(depth / tile.vertical_scale)
+    y = 0
+    while y < n:                                   # the tile is square: the reference's length >= width branch
+        y_end = min(n, y + ss)
+        x = rng.randint(0, ss)
+        H[0:max(0, x - sd), y:y_end] = rng.choice(levels)      # partial stone before the first hole
+        while x < n:
+            H[x:min(n, x + ss), y:y_end] = rng.choice(levels)
+            x += ss + sd
+        y += ss + sd
+    a, b = (n - plat) // 2, (n + plat) // 2
+    H[a:b, a:b] = 0
+
+
+def gap(tile, gap_size, platform_size):
+    """terrain.py:166-178 gap_terrain: a bottomless square ring (raw -1000) around the central platform."""
+    n = tile.width
+    g, plat = int(gap_size / tile.horizontal_scale), int(platform_size / tile.horizontal_scale)
+    c = n // 2
+    inner = (n - plat) // 2
+    outer = inner + g
+    tile.height_field_raw[c - outer:c + outer, c - outer:c + outer] = -1000
+    tile.height_field_raw[c - inner:c + inner, c - inner:c + inner] = 0
+
+
+def pit(tile, depth, platform_size):
+    """terrain.py:180-187 pit_terrain: the central square lowered by `depth`."""
+    n = tile.width
+    d, half = int(depth / tile.vertical_scale), int(platform_size / tile.horizontal_scale / 2)
+    tile.height_field_raw[n // 2 - half:n // 2 + half, n // 2 - half:n // 2 + half] = -d
+
+
+def heightfield_to_trimesh(height_field_raw, horizontal_scale, vertical_scale, slope_threshold=None):
+    """terrain_utils.py:286-350: one vertex per raster sample, two triangles per cell.  With a slope threshold, the
+    low side of every step steeper than the threshold is moved one cell towards the high side, which turns ramps
+    of one cell into vertical faces (what a foot edge actually meets on stairs)."""
+    hf = np.asarray(height_field_raw)
+    R, Cn = hf.shape
+    xx, yy = np.meshgrid(np.linspace(0, (R - 1) * horizontal_scale, R), np.linspace(0, (Cn - 1) * horizontal_scale, Cn), indexing="ij")
+    if slope_threshold is not None:
+        thr = slope_threshold * horizontal_scale / vertical_scale
+        h = hf.astype(np.int64)
+        mx, my, mc = np.zeros((R, Cn)), np.zeros((R, Cn)), np.zeros((R, Cn))
+        mx[:-1, :] += (h[1:, :] - h[:-1, :] > thr)
+        mx[1:, :] -= (h[:-1, :] - h[1:, :] > thr)
+        my[:, :-1] += (h[:, 1:] - h[:, :-1] > thr)
+        my[:, 1:] -= (h[:, :-1] - h[:, 1:] > thr)
+        mc[:-1, :-1] += (h[1:, 1:] - h[:-1, :-1] > thr)
+        mc[1:, 1:] -= (h[:-1, :-1] - h[1:, 1:] > thr)
+        xx = xx + (mx + mc * (mx == 0)) * horizontal_scale
+        yy = yy + (my + mc * (my == 0)) * horizontal_scale
+    vertices = np.stack([xx.ravel(), yy.ravel(), hf.ravel() * vertical_scale], axis=1).astype(np.float32)
+    i0 = (np.arange(R - 1)[:, None] * Cn + np.arange(Cn - 1)[None, :]).ravel()      # cell corner (i, j)
+    i1, i2, i3 = i0 + 1, i0 + Cn, i0 + Cn + 1
+    triangles = np.empty((2 * i0.size, 3), dtype=np.uint32)
+    triangles[0::2] = np.stack([i0, i3, i1], axis=1)
+    triangles[1::2] = np.stack([i0, i2, i3], axis=1)
+    return vertices, triangles
+
+
+TILE_GENERATORS = {   # names accepted by cfg.terrain_kwargs["type"] (the reference eval()s the name)
+    "pyramid_sloped_terrain": lambda tile, rng, **kw: pyramid_slope(tile, kw.get("slope", 1), kw.get("platform_size", 1.0)),
+    "random_uniform_terrain": lambda tile, rng, **kw: uniform_noise(tile, rng, kw["min_height"], kw["max_height"], kw.get("step", 1), kw.get("downsampled_scale")),
+    "pyramid_stairs_terrain": lambda tile, rng, **kw: pyramid_stairs(tile, kw["step_width"], kw["step_height"], kw.get("platform_size", 1.0)),
+    "discrete_obstacles_terrain": lambda tile, rng, **kw: discrete_obstacles(tile, rng, kw["max_height"], kw["min_size"], kw["max_size"], kw["num_rects"], kw.get("platform_size", 1.0)),
+    "stepping_stones_terrain": lambda tile, rng, **kw: stepping_stones(tile, rng, kw["stone_size"], kw["stone_distance"], kw["max_height"], kw.get("platform_size", 1.0), kw.get("depth", -10.0)),
+    "gap_terrain": lambda tile, rng, **kw: gap(tile, kw["gap_size"], kw.get("platform_size", 1.0)),
+    "pit_terrain": lambda tile, rng, **kw: pit(tile, kw["depth"], kw.get("platform_size", 1.0)),
+}
+
+
 class Terrain:
     """Attributes used by the env (same names as the reference): ``heightsamples`` (int16
     (tot_rows, tot_cols)), ``env_origins`` ((num_rows, num_cols, 3) float), ``tot_rows``,
@@ -125,8 +207,15 @@ class Terrain:
             for j in range(cfg.num_cols):            # terrain.py:85-92: column-major tile order
                 for i in range(cfg.num_rows):
                     self._place(self._make_tile(j / cfg.num_cols + 0.001, i / cfg.num_rows), i, j)
-        elif getattr(cfg, "selected", False):
-            raise NotImplementedError("terrain.selected is not implemented (SURVEY 8f)")
+        elif getattr(cfg, "selected", False):        # terrain.py:94-106 selected_terrain: one generator for every tile
+            kw = dict(cfg.terrain_kwargs)
+            gen = TILE_GENERATORS[str(kw.pop("type")).split(".")[-1]]
+            kw = kw.get("terrain_kwargs", kw)
+            for k in range(cfg.num_rows * cfg.num_cols):
+                i, j = np.unravel_index(k, (cfg.num_rows, cfg.num_cols))
+                tile = Tile(self.tile_pixels, cfg.horizontal_scale, cfg.vertical_scale)
+                gen(tile, self.rng, **kw)
+                self._place(tile, i, j)
         else:                                        # terrain.py:74-83 randomized_terrain
             for k in range(cfg.num_rows * cfg.num_cols):
                 i, j = np.unravel_index(k, (cfg.num_rows, cfg.num_cols))
@@ -134,6 +223,9 @@ class Terrain:
                 difficulty = self.rng.choice([0.5, 0.75, 0.9])
                 self._place(self._make_tile(choice, difficulty), i, j)
         self.heightsamples = self.height_field_raw
+        if self.type == "trimesh":                   # terrain.py:68-72
+            self.vertices, self.triangles = heightfield_to_trimesh(self.height_field_raw, cfg.horizontal_scale, cfg.vertical_scale,
+                                                                   getattr(cfg, "slope_treshold", None))
 
     def _make_tile(self, choice, difficulty):
         """terrain.py:109-145 make_terrain"""
@@ -152,8 +244,12 @@ class Terrain:
             pyramid_stairs(tile, 0.31, -step_height if choice < p[2] else step_height, 3.0)
         elif choice < p[4]:
             discrete_obstacles(tile, self.rng, obstacle_height, 1.0, 2.0, 20, 3.0)
+        elif choice < p[5]:
+            stepping_stones(tile, self.rng, 1.5 * (1.05 - difficulty), 0.05 if difficulty == 0 else 0.1, 0.0, 4.0)
+        elif choice < p[6]:
+            gap(tile, 1.0 * difficulty, 3.0)
         else:
-            raise NotImplementedError("stepping-stone / gap / pit tiles are not implemented (SURVEY 8f)")
+            pit(tile, 1.0 * difficulty, 4.0)
         return tile
 
     def _place(self, tile, i, j):
