@@ -19,6 +19,14 @@ def test_make_env_step_and_short_training(tmp_path):
         o, p, r, d, ex = env.step(torch.zeros(512, 10, device="cuda"))
     assert torch.isfinite(o).all() and torch.isfinite(p).all() and torch.isfinite(r).all()
     assert d.dtype == torch.bool and "time_outs" in ex and "terrain_level" in ex["episode"]
+    # all-link kinematics on demand (torch, envs/kinematics.py) agree with what the kernel's own walk published
+    rbs = env.rigid_body_states
+    assert rbs.shape == (512, env.num_bodies, 13) and rbs is env.rigid_body_states        # cached per step
+    live = ~d
+    feet_pos = env._sim.tensor("FEET_POS")                                                   # (N, 2, 3) from the step kernel
+    assert (rbs[live][:, env.feet_indices, 0:3] - feet_pos[live]).abs().max() < 1e-4   # fp32 ulps of world coordinates up to 170 m
+    assert (rbs[:, 0, 0:3] - env.root_states[:, 0:3]).abs().max() == 0
+    assert (rbs[:, env.feet_indices, 3:7].norm(dim=-1) - 1).abs().max() < 1e-5
     tcfg = GR1T1CfgPPO()
     tcfg.runner.num_steps_per_env = 16
     runner, _ = task_registry.make_alg_runner(env, name="GR1T1", args=args, train_cfg=tcfg, log_root=str(tmp_path))

@@ -1,0 +1,69 @@
+"""All-link kinematics (envs/kinematics.py: rigid_body_states on demand) against the oracle's forward kinematics
+and against a finite difference of itself."""
+import numpy as np
+import torch
+
+from tests.helpers import make_cfg
+from wiki_grx_gym_amd.envs import build_config
+from wiki_grx_gym_amd.envs.kinematics import BodyKinematics, _matrix_to_quat, _quat_to_matrix
+from wiki_grx_gym_amd.model import RobotModel
+
+
+def _random_state(N, nd, seed):
+    g = torch.Generator().manual_seed(seed)
+    root = torch.zeros(N, 13)
+    root[:, 0:3] = torch.randn(N, 3, generator=g)
+    qt = torch.randn(N, 4, generator=g)
+    root[:, 3:7] = qt / qt.norm(dim=1, keepdim=True)
+    root[:, 7:13] = torch.randn(N, 6, generator=g)
+    return root, (torch.rand(N, nd, generator=g) - 0.5) * 1.2, torch.randn(N, nd, generator=g)
+
+
+def test_body_frames_match_the_oracle_forward_kinematics():
+    from oracle.binding import OracleSim
+    cfg = make_cfg()
+    N = 8
+    c, keep, meta = build_config.build(cfg, cfg.sim.dt, N)
+    rm = meta["robot_model"] if isinstance(meta, dict) and "robot_model" in meta else RobotModel("gr1t1_lower_limb")
+    ora = OracleSim(c, "f64", keep)
+    root, q, qd = _random_state(N, rm.num_dofs, 3)
+    ora.set_state(root, q, qd)
+    kin = BodyKinematics(rm, "cpu")
+    R, p, _, _ = kin.body_frames(ora.tensor("ROOT_STATES"), q, qd)
+    for e in range(N):
+        for b in range(rm.num_bodies):
+            Ro, po = ora.body_pose(e, b)
+            np.testing.assert_allclose(R[e, b].numpy(), Ro, atol=2e-6)
+            np.testing.assert_allclose(p[e, b].numpy(), po, atol=2e-6)
+
+
+def test_link_velocities_are_the_time_derivative_of_link_poses():
+    rm = RobotModel("gr1t1_lower_limb")
+    kin = BodyKinematics(rm, "cpu")
+    root, q, qd = _random_state(4, rm.num_dofs, 5)
+    root, q, qd = root.double(), q.double(), qd.double()
+    root[:, 3:7] /= root[:, 3:7].norm(dim=1, keepdim=True)     # unit in fp64 (the finite difference needs R0 orthogonal)
+    for t in ("axis", "rot0", "jpos", "link_rot", "link_pos"):
+        setattr(kin, t, getattr(kin, t).double())
+    s0 = kin.rigid_body_states(root, q, qd)
+    assert s0.shape == (4, rm.num_links, 13)
+    h = 1e-6
+    # advance the configuration by h along the velocities (base: v, omega in the world frame)
+    root1 = root.clone()
+    root1[:, 0:3] += h * root[:, 7:10]
+    w = root[:, 10:13]
+    dq = torch.cat([0.5 * h * w, torch.zeros(4, 1, dtype=torch.float64)], 1)
+    x, y, z, ww = root[:, 3:7].unbind(-1)
+    dx, dy, dz, _ = dq.unbind(-1)
+    root1[:, 3:7] = torch.stack([x + dx * ww + dy * z - dz * y, y - dx * z + dy * ww + dz * x, z + dx * y - dy * x + dz * ww,
+                                 ww - dx * x - dy * y - dz * z], -1)
+    root1[:, 3:7] /= root1[:, 3:7].norm(dim=1, keepdim=True)
+    s1 = kin.rigid_body_states(root1, q + h * qd, qd)
+    np.testing.assert_allclose(((s1[..., 0:3] - s0[..., 0:3]) / h).numpy(), s0[..., 7:10].numpy(), atol=2e-5)
+    # angular velocity from the rotation increment: R1 R0^T ~ 1 + h [w]x
+    R0, R1 = _quat_to_matrix(s0[..., 3:7]), _quat_to_matrix(s1[..., 3:7])
+    dR = (R1 @ R0.transpose(-1, -2) - torch.eye(3, dtype=torch.float64)) / h
+    wfd = torch.stack([dR[..., 2, 1], dR[..., 0, 2], dR[..., 1, 0]], -1)
+    np.testing.assert_allclose(wfd.numpy(), s0[..., 10:13].numpy(), atol=2e-5)
+    # quaternion <-> matrix round trip
+    np.testing.assert_allclose(_quat_to_matrix(_matrix_to_quat(R0)).numpy(), R0.numpy(), atol=1e-12)

@@ -139,6 +139,9 @@ class GRxEnv:
         self._episode_stats = t("EPISODE_STATS")
         self.episode_sums = {n: self._episode_sums[i] for n, i in self._term_index.items()}
         self.contact_forces = _FeetOnlyContactForces(self)
+        from .kinematics import BodyKinematics
+        self._kin = BodyKinematics(rm, dev)
+        self._rbs_cache = (-1, None)
         self.noise_scale_vec = self._noise_scale_vec()
         self.common_step_counter = 0
         self.extras = {}
@@ -158,6 +161,14 @@ class GRxEnv:
     def episode_length_buf(self, value):
         # the runner REBINDS this attribute (on_policy_runner.py:126): copy into the library buffer
         self._episode_length.copy_(value.to(self._episode_length.dtype))
+
+    @property
+    def rigid_body_states(self):
+        """(N, num_links, 13) pos / quat xyzw / lin vel / ang vel of every URDF link, world frame (the layout of
+        gym.acquire_rigid_body_state_tensor, legged_robot.py:113,134) -- computed on first access after a step."""
+        if self._rbs_cache[0] != self.common_step_counter:
+            self._rbs_cache = (self.common_step_counter, self._kin.rigid_body_states(self.root_states, self.dof_pos, self.dof_vel))
+        return self._rbs_cache[1]
 
     def get_observations(self):
         return self.obs_buf
