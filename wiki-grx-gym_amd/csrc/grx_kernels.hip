@@ -1289,6 +1289,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             for (int i = tid; i < nenv * npri; i += NTHR) gpri[i] = s_pri[(i / npri) * GRX_MAX_PRI + (i % npri)];
         if (tid <= NT) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + tid] = s_stat[tid];
     }
+    // (Reducing the per-block statistics rows here, in the last block to finish, was tried twice to save the
+    //  grx_finalize_stats launch: with an agent-scope __threadfence per block (whole-L2 write-back on this 8-XCD
+    //  part: +10 us per launch) and with agent-scope atomic stores / loads and no fence (bit-identical results,
+    //  but the acknowledgement wait costs +9 us).  A 4 us kernel of its own is cheaper.)
     GRX_TICK(10);
 }
 
