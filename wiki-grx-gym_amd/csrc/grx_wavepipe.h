@@ -12,10 +12,11 @@
 //   wave 1  "I": the INERTIA half of the recursion (U, 1/d, rank-1 updates) as the rigid inertias arrive; streams
 //            one record per joint (U, 1/d, updated 6x6) back to wave 0, which runs one joint behind; finally
 //            the factorised base-level 6x6
-//   wave 2  chain contacts: own outward walk, the 4 anchored foot spheres (owns the friction anchors), then the
-//            thigh / shank spheres
-//   wave 3  own outward walk with velocities: rigid-body bias forces + velocity-product accelerations of every
-//            chain body (needed by wave 0 from its first joint on), then the base-lump contacts (torso, head, arms ...)
+//   wave 2  own outward walk with velocities: rigid-body bias forces + velocity-product accelerations of every
+//            chain body (needed by wave 0 from its first joint on), then the 4 anchored foot spheres (it owns the
+//            friction anchors) and the thigh spheres
+//   wave 3  the base lump's bias force, the shank spheres (own walk to the knee), the base-lump contacts (torso,
+//            head, arms ...)
 //
 // Synchronisation is by monotone sequence counters in LDS (release store by the producer after its data, acquire
 // spin by the consumer), not block barriers, so each producer/consumer pair meets at its own time.  Every buffer is
@@ -41,7 +42,7 @@
 #define GRX_WAIT(f, want, slot) flag_wait(f, want)
 #endif
 
-enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_BASE = 4, FL_BIAS = 5, FL_REW = 6, FL_RI = 7, FL_COUNT = 8 };
+enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_BASE = 4, FL_BIAS = 5, FL_REW = 6, FL_RI = 7, FL_BASEBIAS = 8, FL_SHANK = 9, FL_COUNT = 12 };
 constexpr int REC = 28;   // floats per joint record: ua 3, ul 3, 1/d, A' 6, B' 9, D' 6
 constexpr int RIR = 15;   // floats per chain body from wave 0: rigid inertia about O (A 6, h 3), joint axis Sa 3, Ss 3
 constexpr int PBR = 12;   // floats per chain body from wave 3: rigid-body bias force pa 3, pl 3, velocity-product acceleration ca 3, cl 3
@@ -164,6 +165,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     // ---- contact wrenches on chain bodies 4 (foot), 3 (shank), 2 (thigh): delta recursion  dp -> dp + U (-S.dp)/d
     GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
     GRX_WAIT(L.flag + FL_LEGS, seq + 1, 2);
+    GRX_WAIT(L.flag + FL_SHANK, seq + 1, 2);
     {
         V3 da = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
 #pragma unroll
@@ -192,7 +194,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     }
     pa = pair_sum(pa); pl = pair_sum(pl);
     {   // base-lump bias force (wave 3; both lanes of the pair add the same value after the pair sum)
-        GRX_WAIT(L.flag + FL_BIAS, seq * 8 + LEG + 1, 0);
+        GRX_WAIT(L.flag + FL_BASEBIAS, seq + 1, 0);
         const float* b_ = L.pb + (size_t)(LEG * PBR) * 64 + lane;
         pa = pa + v3(b_[0 * 64], b_[1 * 64], b_[2 * 64]); pl = pl + v3(b_[3 * 64], b_[4 * 64], b_[5 * 64]);
     }
@@ -315,14 +317,38 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, 
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
         const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
         const float* qs = L.q + lane;
+        // outward walk with velocities; rigid-body bias forces + velocity-product accelerations of the chain bodies,
+        // leaf first (wave 0's recursion starts at the foot and needs them before anything else this wave makes)
         ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
-        ChainKin K2 = K, K3 = K;
+        ChainKin KK[LEG];
+        V3 cak[LEG], clk[LEG];
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {
-            chain_step(C, k, qs[k * 64], qs[(LEG + k) * 64], K);
-            if (k == 2) K2 = K;
-            if (k == 3) K3 = K;
+            const V3 wp = K.w, vp = K.v;   // parent velocity
+            const float qdk = qs[(LEG + k) * 64];
+            K.rho = K.rho + rot(K.R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+            float sn, cs;
+            grx_sincos(qs[k * 64], sn, cs);
+            K.R = joint_rot_k(K.R, cs, sn, kAxis[k]);
+            const V3 a = axis_k(K.R, kAxis[k]);
+            const V3 s = cross(K.rho, a);
+            cak[k] = cross(wp, a) * qdk;
+            clk[k] = (cross(vp, a) + cross(wp, s)) * qdk;
+            K.w = fma3(a, qdk, wp); K.v = fma3(s, qdk, vp);
+            KK[k] = K;
         }
+#pragma unroll
+        for (int k = LEG - 1; k >= 0; --k) {
+            const V3 kap = KK[k].rho + rot(KK[k].R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+            const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
+            V3 pa, pl;
+            rigid_bias(KK[k].R, kap, C.body[k].mass, Ic, KK[k].w, KK[k].v, pa, pl);
+            float* o = L.pb + (size_t)(k * PBR) * 64 + lane;
+            o[0 * 64] = pa.x; o[1 * 64] = pa.y; o[2 * 64] = pa.z; o[3 * 64] = pl.x; o[4 * 64] = pl.y; o[5 * 64] = pl.z;
+            o[6 * 64] = cak[k].x; o[7 * 64] = cak[k].y; o[8 * 64] = cak[k].z; o[9 * 64] = clk[k].x; o[10 * 64] = clk[k].y; o[11 * 64] = clk[k].z;
+            flag_set(L.flag + FL_BIAS, seq * 8 + (LEG - k), lane);
+        }
+        const ChainKin& K2 = KK[2];
         float* c_ = L.wc + lane;
         V3 fa, fl;
         foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl);
@@ -333,10 +359,8 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, 
             c_[18 * 64] = fv.x; c_[19 * 64] = fv.y; c_[20 * 64] = fv.z;
         }
         flag_set(L.flag + FL_FOOT, seq + 1, lane);
-        link_contacts<HF>(P, C, 2, K2, O, mu, hmax, fa, fl);
+        link_contacts<HF>(P, C, 2, K2, O, mu, hmax, fa, fl);      // thigh (the shank spheres are wave 3's)
         c_[0 * 64] = fa.x; c_[1 * 64] = fa.y; c_[2 * 64] = fa.z; c_[3 * 64] = fl.x; c_[4 * 64] = fl.y; c_[5 * 64] = fl.z;
-        link_contacts<HF>(P, C, 3, K3, O, mu, hmax, fa, fl);
-        c_[6 * 64] = fa.x; c_[7 * 64] = fa.y; c_[8 * 64] = fa.z; c_[9 * 64] = fl.x; c_[10 * 64] = fl.y; c_[11 * 64] = fl.z;
         flag_set(L.flag + FL_LEGS, seq + 1, lane);
     }
     GRX_HELPER_PROF_END(2);
@@ -355,43 +379,23 @@ GRX_DEV void base_contact_loop(KP P, const SideConst& C, float mu, float hmax, f
         const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
         const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
-        {   // rigid-body bias forces + velocity-product accelerations of the chain bodies, leaf first (wave 0's
-            // recursion starts at the foot), then the base lump's bias force
-            const float* qs = L.q + lane;
-            ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
-            ChainKin KK[LEG];
-            V3 cak[LEG], clk[LEG];
-#pragma unroll
-            for (int k = 0; k < LEG; ++k) {
-                const V3 wp = K.w, vp = K.v;   // parent velocity
-                const float qdk = qs[(LEG + k) * 64];
-                K.rho = K.rho + rot(K.R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
-                float sn, cs;
-                grx_sincos(qs[k * 64], sn, cs);
-                K.R = joint_rot_k(K.R, cs, sn, kAxis[k]);
-                const V3 a = axis_k(K.R, kAxis[k]);
-                const V3 s = cross(K.rho, a);
-                cak[k] = cross(wp, a) * qdk;
-                clk[k] = (cross(vp, a) + cross(wp, s)) * qdk;
-                K.w = fma3(a, qdk, wp); K.v = fma3(s, qdk, vp);
-                KK[k] = K;
-            }
-#pragma unroll
-            for (int k = LEG - 1; k >= 0; --k) {
-                const V3 kap = KK[k].rho + rot(KK[k].R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
-                const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
-                V3 pa, pl;
-                rigid_bias(KK[k].R, kap, C.body[k].mass, Ic, KK[k].w, KK[k].v, pa, pl);
-                float* o = L.pb + (size_t)(k * PBR) * 64 + lane;
-                o[0 * 64] = pa.x; o[1 * 64] = pa.y; o[2 * 64] = pa.z; o[3 * 64] = pl.x; o[4 * 64] = pl.y; o[5 * 64] = pl.z;
-                o[6 * 64] = cak[k].x; o[7 * 64] = cak[k].y; o[8 * 64] = cak[k].z; o[9 * 64] = clk[k].x; o[10 * 64] = clk[k].y; o[11 * 64] = clk[k].z;
-                flag_set(L.flag + FL_BIAS, seq * 8 + (LEG - k), lane);
-            }
+        {   // the base lump's rigid-body bias force (cheap; needed by wave 0 only at the base solve)
             V3 bpa, bpl;
             rigid_bias(R0, rot(R0, base_c), base_m, base_I, ang, vel, bpa, bpl);
             float* o = L.pb + (size_t)(LEG * PBR) * 64 + lane;
             o[0 * 64] = bpa.x; o[1 * 64] = bpa.y; o[2 * 64] = bpa.z; o[3 * 64] = bpl.x; o[4 * 64] = bpl.y; o[5 * 64] = bpl.z;
-            flag_set(L.flag + FL_BIAS, seq * 8 + LEG + 1, lane);
+            flag_set(L.flag + FL_BASEBIAS, seq + 1, lane);
+        }
+        {   // shank spheres (own outward walk to the knee): shares the chain-contact load with wave 2
+            const float* qs = L.q + lane;
+            ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
+#pragma unroll
+            for (int k = 0; k <= 3; ++k) chain_step(C, k, qs[k * 64], qs[(LEG + k) * 64], K);
+            V3 fa, fl;
+            link_contacts<HF>(P, C, 3, K, O, mu, hmax, fa, fl);
+            float* c_ = L.wc + lane;
+            c_[6 * 64] = fa.x; c_[7 * 64] = fa.y; c_[8 * 64] = fa.z; c_[9 * 64] = fl.x; c_[10 * 64] = fl.y; c_[11 * 64] = fl.z;
+            flag_set(L.flag + FL_SHANK, seq + 1, lane);
         }
         V3 f0a, f0l; bool term; float pen;
         base_lump_contacts<HF, false>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen);
