@@ -32,6 +32,19 @@ def test_device_update_path_matches_reference():
     _check_against_reference("cuda")
 
 
+@pytest.mark.gpu
+def test_rccl_bucket_path_matches_reference(monkeypatch):
+    """The multi-GPU update path (flat [grads | KL] bucket, ONE RCCL all-reduce per optimizer step) on a one-rank
+    process group: the collective is an identity, so the result must still equal the reference's update."""
+    import torch.distributed as dist
+    monkeypatch.setenv("GRX_PPO_FORCE_BUCKET", "1")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        _check_against_reference("cuda")
+    finally:
+        dist.destroy_process_group()
+
+
 def test_rollout_returns_and_update_match_reference():
     _check_against_reference("cpu")
 

@@ -18,6 +18,12 @@ from .modules import ActorCriticMLP  # noqa: F401
 from .storage import RolloutStorage
 
 
+def _collective_path():
+    """True when gradients go through the flat bucket + all-reduce: more than one rank, or GRX_PPO_FORCE_BUCKET=1 with
+    an initialised process group (lets a single-GPU box exercise the RCCL path: the all-reduce is then an identity)."""
+    return _world() > 1 or (os.environ.get("GRX_PPO_FORCE_BUCKET") == "1" and dist.is_available() and dist.is_initialized())
+
+
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -60,7 +66,7 @@ class PPO:
         self.num_updates = 0
         self._params = [p for p in self.actor_critic.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self._params)
-        self._bucket = torch.zeros(n + 1, device=device) if _world() > 1 else None   # grads + KL
+        self._bucket = torch.zeros(n + 1, device=device) if _collective_path() else None   # grads + KL
 
     def init_storage(self, num_envs, num_transitions_per_env, **_):
         ac = self.actor_critic
@@ -135,11 +141,11 @@ class PPO:
 
     def update(self):
         if self._device_lr:
-            if self._use_graph and _world() == 1:
+            if self._use_graph and not _collective_path():
                 return self._update_graphed()
             return self._update_device()
         mean_value_loss, mean_surrogate_loss = 0.0, 0.0
-        ac, multi = self.actor_critic, _world() > 1
+        ac, multi = self.actor_critic, _collective_path()
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         for (obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _, _) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
@@ -183,7 +189,7 @@ class PPO:
 
     def _update_device(self):
         """Same arithmetic as update(), no host round-trips inside the minibatch loop."""
-        ac, multi = self.actor_critic, _world() > 1
+        ac, multi = self.actor_critic, _collective_path()
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         sums = torch.zeros(3, device=self.device)        # value loss, surrogate loss, last KL
         for (obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _, _) in \
