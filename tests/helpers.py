@@ -12,7 +12,7 @@ CMP_EXACT = ("RESET", "TIME_OUT", "EPISODE_LENGTH", "FEET_CONTACT", "TERRAIN_LEV
 
 
 def make_cfg(task="GR1T1", noise=False, dr=False, push=None, terrain="plane", curriculum=True):
-    cfg = {"GR1T1": config.GR1T1Cfg, "GR1T2": config.GR1T2Cfg}[task]()
+    cfg = {"GR1T1": config.GR1T1Cfg, "GR1T2": config.GR1T2Cfg, "GR1T1Full": config.GR1T1FullBodyCfg}[task]()
     d = cfg.domain_rand
     if not dr:
         d.randomize_friction = d.randomize_restitution = d.randomize_base_mass = d.randomize_base_com = False

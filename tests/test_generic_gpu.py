@@ -1,0 +1,82 @@
+"""The generic-tree step kernel (csrc/grx_generic.h): any robot model include/grx.h can describe.
+ * the lower-limb model FORCED through it must match the oracle like the fast kernel does, and the fast kernel itself;
+ * the 32-DOF full-body GR1T1 (config 5 of BASELINE.json; obs 105 / pri_obs 234, build-defined) against the oracle."""
+import pytest
+import torch
+
+from tests.helpers import lockstep, make_cfg, make_sims, random_actions
+from tests.test_hip_parity import assert_phys, physics_lockstep
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lower_limb_through_the_generic_kernel(monkeypatch):
+    monkeypatch.setenv("GRX_FORCE_GENERIC", "1")
+    cfg = make_cfg(terrain="heightfield", noise=True, dr=True, push=True)
+    hip, ora = make_sims(cfg, 192, seed=1)
+    hip.reset_all(); ora.reset_all()
+    worst = physics_lockstep(hip, ora, cfg, steps=20)
+    assert_phys(worst, exact_frac=6e-3, scale=4.0)   # stair edges: one env in 192 may take the other side of a riser
+    hip.close()
+    cfg = make_cfg()
+    hip, ora = make_sims(cfg, 128)
+    hip.reset_all(); ora.reset_all()
+    worst = lockstep(hip, ora, cfg, steps=8, resync=False)       # flight phase: tight
+    assert worst["DOF_POS"][0] < 1e-4 and worst["ROOT_STATES"][0] < 1e-4
+    hip.close()
+
+
+def test_generic_and_fast_kernels_agree(monkeypatch):
+    cfg = make_cfg(noise=True, dr=True, push=True)
+    N = 256
+    outs = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("GRX_FORCE_GENERIC", "1")
+        hip, _ = make_sims(cfg, N)
+        hip.reset_all()
+        gen = torch.Generator().manual_seed(3)
+        for i in range(3):
+            hip.step(random_actions(cfg, N, gen, 0.5).cuda(), 5.0, i + 1)
+        outs.append({k: hip.tensor(k).clone() for k in ("OBS", "REW", "DOF_POS", "ROOT_STATES", "RESET")})
+        hip.close()
+    a, b = outs
+    assert torch.equal(a["RESET"], b["RESET"])
+    assert (a["DOF_POS"] - b["DOF_POS"]).abs().max() < 2e-3 and (a["ROOT_STATES"][:, :3] - b["ROOT_STATES"][:, :3]).abs().max() < 1e-3
+    assert (a["REW"] - b["REW"]).abs().max() < 5e-3
+
+
+def test_full_body_32_dof_against_the_oracle():
+    cfg = make_cfg("GR1T1Full", noise=True, dr=True, push=True)
+    hip, ora = make_sims(cfg, 128)
+    assert hip.tensor("OBS").shape == (128, 105) and hip.tensor("PRI_OBS").shape == (128, 234) and hip.tensor("DOF_POS").shape == (128, 32)
+    hip.reset_all(); ora.reset_all()
+    # one policy step at a time from the oracle's state (the wrist joints -- 0.1 kg links on kp = 10 actuators -- sit
+    # close to the explicit integrator's stability limit and amplify fp32 rounding within a few free-running steps)
+    worst = physics_lockstep(hip, ora, cfg, steps=25, scale=0.3)
+    # outlier FRACTIONS are bounded as for the lower-limb model; the maxima are not (a wrist that goes unstable in
+    # one of the two fp32 integrations differs by O(1) rad/s that step), so only kinematic quantities get a max bound
+    assert_phys(worst, exact_frac=1e-2, scale=5.0)
+    assert worst["FEET_POS"][0] < 1e-3 and worst["FEET_HEIGHT"][0] < 1e-3 and worst["REW"][0] < 1e-2, worst
+    assert torch.isfinite(hip.tensor("OBS")).all() and torch.isfinite(hip.tensor("REW")).all()
+    hip.close()
+
+
+def test_full_body_rough_terrain_runs_and_is_deterministic():
+    cfg = make_cfg("GR1T1Full", noise=True, dr=True, push=True, terrain="heightfield")
+
+    def run():
+        hip, _ = make_sims(cfg, 256, seed=1)
+        hip.reset_all()
+        gen = torch.Generator().manual_seed(0)
+        for i in range(20):
+            hip.step(random_actions(cfg, 256, gen, 1.0).cuda(), 5.0, i + 1)
+        out = {k: hip.tensor(k).clone() for k in ("OBS", "PRI_OBS", "REW", "RESET", "ROOT_STATES")}
+        hip.close()
+        return out
+    a, b = run(), run()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        if a[k].is_floating_point():
+            assert torch.isfinite(a[k]).all(), k
+    assert a["PRI_OBS"][:, 113:].abs().sum() > 0     # the height scan is live

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <deque>
 #include <string>
 #include <vector>
@@ -18,7 +19,12 @@
 extern "C" {
 void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                      const float* noise, hipStream_t stream);
-void grx_launch_finalize(const KParams* dP, int N, int64_t* progress, int64_t ticket, hipStream_t stream);
+void grx_launch_finalize(const KParams* dP, int nblocks, int64_t* progress, int64_t ticket, hipStream_t stream);
+void grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int heightfield, const float* actions, float delay,
+                             long long common_step, const float* noise, hipStream_t stream);
+void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, uint32_t step, hipStream_t stream);
+int grx_generic_tables_size(void);
+int grx_generic_ws_floats_per_env(int nb, int nlc);
 void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream);
 void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, hipStream_t stream);
 int grx_envs_per_block(void);
@@ -70,6 +76,11 @@ struct grx_sim {
     int device = 0;
     int N = 0;
     int waves = 1;         // waves per 32-env block of the step kernel (1, 2 or 4)
+    bool generic = false;  // model outside the fast kernel's lower-limb topology: generic-tree kernel (grx_generic.h)
+    int nd = GRX_ND;
+    void* d_gen = nullptr; // GenTables (device)
+    float* d_ws = nullptr; // generic workspace
+    int stat_blocks = 0;   // rows of the per-block statistics table the step kernel in use writes
     KParams hp;            // launch parameters: host image ...
     KParams* d_hp = nullptr;   // ... and the device copy every kernel reads through the constant address space
     KTables tab;           // host image of the device tables
@@ -248,6 +259,100 @@ void base_lump(const grx_model& m, float link_mass, const float link_com[3], flo
 
 }  // namespace
 
+// ---- generic-tree path: device tables mirroring grx_generic.h's GenTables (kept in sync by the size check below)
+namespace {
+constexpr int GEN_MAXLC_H = 24;
+struct GenTablesH {
+    int32_t nb, nd, nsph, nlc;
+    int32_t parent[GRX_MAX_BODIES];
+    float axis[GRX_MAX_BODIES][3], rot0[GRX_MAX_BODIES][9], jpos[GRX_MAX_BODIES][3], mass[GRX_MAX_BODIES], com[GRX_MAX_BODIES][3], Ic[GRX_MAX_BODIES][6];
+    float kp[GRX_MAX_DOFS], kd[GRX_MAX_DOFS], q0[GRX_MAX_DOFS], effort[GRX_MAX_DOFS], vlim[GRX_MAX_DOFS], qlo[GRX_MAX_DOFS], qhi[GRX_MAX_DOFS];
+    float slo[GRX_MAX_DOFS], shi[GRX_MAX_DOFS], amin[GRX_MAX_DOFS], amax[GRX_MAX_DOFS], Klim[GRX_MAX_DOFS], Clim[GRX_MAX_DOFS];
+    int32_t sph_begin[GRX_MAX_BODIES + 1];
+    float sx[GRX_MAX_SPHERES], sy[GRX_MAX_SPHERES], sz[GRX_MAX_SPHERES], sr[GRX_MAX_SPHERES], sdmax[GRX_MAX_SPHERES];
+    int32_t sslot[GRX_MAX_SPHERES];
+    int32_t slink[GRX_MAX_SPHERES];
+    uint32_t link_flags[GEN_MAXLC_H];
+    int32_t foot_body[2], foot_link[2];
+    float foot_pos[2][3];
+    int32_t torso_body, forehead_body;
+    float torso_rot[9], forehead_rot[9];
+};
+
+int build_generic(grx_sim* s, const grx_config& c) {
+    const grx_model& m = c.model;
+    if ((int)sizeof(GenTablesH) != grx_generic_tables_size()) return fail(GRX_ERR_HIP, "GenTables layout mismatch between grx_capi.cpp and grx_generic.h");
+    if (m.num_spheres > GRX_MAX_SPHERES) return fail(GRX_ERR_UNSUPPORTED_MODEL, "too many collision spheres");
+    std::vector<GenTablesH> tv(1);
+    GenTablesH& T = tv[0];
+    memset(&T, 0, sizeof T);
+    T.nb = m.num_bodies; T.nd = m.num_bodies - 1; T.nsph = m.num_spheres;
+    for (int b = 0; b < m.num_bodies; ++b) {
+        T.parent[b] = m.parent[b];
+        if (b > 0 && (m.parent[b] < 0 || m.parent[b] >= b)) return fail(GRX_ERR_UNSUPPORTED_MODEL, "bodies must be listed parents first");
+        for (int a = 0; a < 3; ++a) { T.axis[b][a] = m.joint_axis[b][a]; T.jpos[b][a] = m.joint_pos[b][a]; T.com[b][a] = m.com[b][a]; }
+        for (int a = 0; a < 9; ++a) T.rot0[b][a] = m.joint_rot0[b][a];
+        for (int a = 0; a < 6; ++a) T.Ic[b][a] = m.inertia[b][a];
+        T.mass[b] = m.mass[b];
+    }
+    for (int j = 0; j < T.nd; ++j) {
+        T.kp[j] = c.kp[j]; T.kd[j] = c.kd[j]; T.q0[j] = c.default_dof_pos[j];
+        T.effort[j] = m.dof_effort[j]; T.vlim[j] = m.dof_vel_limit[j]; T.qlo[j] = m.dof_lower[j]; T.qhi[j] = m.dof_upper[j];
+        T.Klim[j] = c.contact.k_limit * m.dof_effort[j];
+        T.Clim[j] = c.contact.c_limit * T.Klim[j];
+        T.amin[j] = c.clip_actions_min[j]; T.amax[j] = c.clip_actions_max[j];
+        const float mid = (m.dof_lower[j] + m.dof_upper[j]) / 2, rng = m.dof_upper[j] - m.dof_lower[j];
+        T.slo[j] = mid - 0.5f * rng * c.soft_dof_pos_limit;
+        T.shi[j] = mid + 0.5f * rng * c.soft_dof_pos_limit;
+    }
+    // spheres sorted by carrying body (stable: model.py emits them sorted by (body, link) already)
+    std::vector<int> order(m.num_spheres);
+    for (int i = 0; i < m.num_spheres; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return m.sph_body[a] < m.sph_body[b]; });
+    std::vector<int> link_ids;   // compact ids of the URDF links that carry shapes
+    int foot_slots[2] = {0, 0};
+    for (int f = 0; f < 2; ++f) T.foot_link[f] = -1;
+    for (int k = 0; k < m.num_spheres; ++k) {
+        const int i = order[k], b = m.sph_body[i];
+        if (b < 0 || b >= m.num_bodies) return fail(GRX_ERR_INVALID_ARGUMENT, "sphere body out of range");
+        T.sx[k] = m.sph_pos[i][0]; T.sy[k] = m.sph_pos[i][1]; T.sz[k] = m.sph_pos[i][2]; T.sr[k] = m.sph_radius[i]; T.sdmax[k] = m.sph_damp_max[i];
+        int lc = -1;
+        for (size_t t = 0; t < link_ids.size(); ++t) if (link_ids[t] == m.sph_link[i]) lc = (int)t;
+        if (lc < 0) { lc = (int)link_ids.size(); link_ids.push_back(m.sph_link[i]); }
+        if (lc >= GEN_MAXLC_H) return fail(GRX_ERR_UNSUPPORTED_MODEL, "too many links carry collision shapes");
+        T.slink[k] = lc;
+        T.link_flags[lc] |= m.sph_flags[i] & (GRX_SPH_TERMINATE | GRX_SPH_PENALISE);
+        T.sslot[k] = -1;
+        for (int f = 0; f < 2; ++f)
+            if (m.sph_flags[i] & (f == 0 ? GRX_SPH_FOOT_LEFT : GRX_SPH_FOOT_RIGHT)) {
+                if (foot_slots[f] >= 4) return fail(GRX_ERR_UNSUPPORTED_MODEL, "more than 4 anchored spheres on a foot");
+                T.sslot[k] = f * 4 + foot_slots[f]++;
+                T.foot_link[f] = lc;
+            }
+    }
+    T.nlc = (int)link_ids.size();
+    for (int f = 0; f < 2; ++f) if (T.foot_link[f] < 0) return fail(GRX_ERR_UNSUPPORTED_MODEL, "a foot carries no collision shape");
+    {
+        int k = 0;
+        for (int b = 0; b <= m.num_bodies; ++b) {
+            while (k < m.num_spheres && m.sph_body[order[k]] < b) ++k;
+            T.sph_begin[b] = k;
+        }
+    }
+    for (int f = 0; f < 2; ++f) { T.foot_body[f] = m.foot_body[f]; for (int a = 0; a < 3; ++a) T.foot_pos[f][a] = m.foot_pos[f][a]; }
+    T.torso_body = m.torso_body; T.forehead_body = m.forehead_body;
+    memcpy(T.torso_rot, m.torso_rot, sizeof T.torso_rot);
+    memcpy(T.forehead_rot, m.forehead_rot, sizeof T.forehead_rot);
+    GenTablesH* d = nullptr;
+    int rc = dalloc(s, &d, 1);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(d, &T, sizeof T, hipMemcpyHostToDevice));
+    s->d_gen = d;
+    rc = dalloc(s, &s->d_ws, (size_t)grx_generic_ws_floats_per_env(T.nb, T.nlc) * (size_t)s->N);
+    return rc;
+}
+}  // namespace
+
 extern "C" {
 
 int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
@@ -261,13 +366,17 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     const grx_config& c = *cfg;
     const grx_model& m = c.model;
     if (c.num_envs < 1) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: num_envs < 1");
+    // the lower-limb topology runs on the fused lane-pair kernel; every other tree on the generic-tree kernel
     int rc = check_topology(m);
-    if (rc) return rc;
+    const bool generic = rc != GRX_OK || getenv("GRX_FORCE_GENERIC") != nullptr;
+    g_err.clear();
+    const int nd = m.num_bodies - 1;
+    if (nd < 1 || m.num_bodies > GRX_MAX_BODIES) return fail(GRX_ERR_UNSUPPORTED_MODEL, "grx_create: unsupported body count");
     const int nh = c.measure_heights ? c.num_height_points : 0;
-    if (c.num_obs != GRX_NUM_OBS) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: num_obs must be 39");
-    if (c.num_pri_obs != c.num_obs + 8 + nh || c.num_pri_obs > GRX_MAX_PRI) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: num_pri_obs mismatch");
+    if (c.num_obs != 9 + 3 * nd) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: num_obs must be 9 + 3 * num_dofs");
+    if (c.num_pri_obs != c.num_obs + 8 + nh || (!generic && c.num_pri_obs > GRX_MAX_PRI)) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: num_pri_obs mismatch");
     if (nh > GRX_MAX_HEIGHT_POINTS) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: too many height points");
-    if ((c.ankle_left_mask >> GRX_LEG) || (c.ankle_right_mask & 31u)) return fail(GRX_ERR_UNSUPPORTED_MODEL, "ankle masks must be split left/right");
+    if (!generic && ((c.ankle_left_mask >> GRX_LEG) || (c.ankle_right_mask & 31u))) return fail(GRX_ERR_UNSUPPORTED_MODEL, "ankle masks must be split left/right");
     if (c.terrain_type == GRX_TERRAIN_HEIGHTFIELD && (!c.height_samples || !c.terrain_origins))
         return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: heightfield terrain needs height_samples and terrain_origins");
 
@@ -277,10 +386,11 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     s->cfg.terrain_origins = nullptr;
     s->device = device_id;
     s->N = c.num_envs;
+    s->generic = generic; s->nd = nd;
     const size_t N = (size_t)c.num_envs;
     KParams& P = s->hp;
     memset(&P, 0, sizeof P);
-    P.N = c.num_envs; P.env_offset = c.env_offset; P.total_envs = c.total_envs;
+    P.N = c.num_envs; P.env_offset = c.env_offset; P.total_envs = c.total_envs; P.nd = nd;
     {   // waves per block: the step kernel needs a SIMD per wave (512 registers/lane), so use the helper waves only
         // while blocks x waves still fits the device's SIMDs in one round; GRX_WAVES_PER_BLOCK overrides (tests)
         hipDeviceProp_t prop;
@@ -333,20 +443,22 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     memcpy(P.torso_rot, m.torso_rot, sizeof P.torso_rot);
     memcpy(P.forehead_rot, m.forehead_rot, sizeof P.forehead_rot);
     P.has_torso = m.torso_body >= 0; P.has_forehead = m.forehead_body >= 0;
-    rc = build_side_tables(c, s->tab);
-    if (rc) { delete s; return rc; }
+    if (!generic) {
+        rc = build_side_tables(c, s->tab);
+        if (rc) { delete s; return rc; }
+    }
 
 #define DA(field, count) do { rc = dalloc(s, &P.field, (count)); if (rc) { grx_destroy(s); return rc; } } while (0)
-    DA(q, GRX_ND * N); DA(qd, GRX_ND * N); DA(root, 13 * N); DA(anchors, 24 * N);
-    DA(last_actions, GRX_ND * N); DA(last_dof_vel, GRX_ND * N); DA(actions, GRX_ND * N); DA(torques, GRX_ND * N);
-    DA(motor_strength, GRX_ND * N); DA(base_m, N); DA(base_c, 3 * N); DA(base_I, 6 * N); DA(friction, N);
+    DA(q, nd * N); DA(qd, nd * N); DA(root, 13 * N); DA(anchors, 24 * N);
+    DA(last_actions, nd * N); DA(last_dof_vel, nd * N); DA(actions, nd * N); DA(torques, nd * N);
+    DA(motor_strength, nd * N); DA(base_m, N); DA(base_c, 3 * N); DA(base_I, 6 * N); DA(friction, N);
     DA(commands, 3 * N); DA(origins, 3 * N); DA(levels, N); DA(types, N);
     DA(air_time, 2 * N); DA(land_time, 2 * N); DA(feet_contact, 2 * N);
     DA(feet_height, 2 * N); DA(avg_force, 2 * N); DA(feet_force, 6 * N); DA(feet_pos, 6 * N); DA(avg_speed, 6 * N);
     DA(base_heights_offset, N); DA(ep_len, N); DA(rew, N); DA(reset, N); DA(time_out, N); DA(term_contact, N);
     DA(base_lin_vel, 3 * N); DA(base_ang_vel, 3 * N); DA(proj_grav, 3 * N);
     DA(episode_sums, NT * N); DA(reward_terms, NT * N); DA(heights, (size_t)(nh > 0 ? nh : 1) * N);
-    DA(obs, GRX_NUM_OBS * N + 64); DA(pri_obs, (size_t)c.num_pri_obs * N + 64);
+    DA(obs, (size_t)c.num_obs * N + 64); DA(pri_obs, (size_t)c.num_pri_obs * N + 64);
     const int nblocks = (c.num_envs + grx_envs_per_block() - 1) / grx_envs_per_block();
     DA(stat_partial, (size_t)nblocks * (NT + 1)); DA(stats, NT + 1); DA(prof, (size_t)nblocks * 32);
     float* base_mass_com = nullptr;
@@ -396,7 +508,6 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     }
     // ---- per-env constants on the host (same arithmetic as the oracle's gro_create)
     {
-        const int nd = GRX_ND;
         std::vector<float> h_strength(nd * N), h_bm(N), h_bc(3 * N), h_bI(6 * N), h_fr(N), h_or(3 * N), h_q(nd * N), h_root(13 * N, 0.f), h_bmc(4 * N);
         std::vector<int32_t> h_lv(N, 0), h_ty(N, 0);
         std::vector<uint8_t> h_reset(N, 1);
@@ -465,18 +576,18 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
 
     // ---- tensor table
     const int64_t Ni = c.num_envs;
-    desc_rows(s, GRX_T_OBS, P.obs, Ni, GRX_NUM_OBS);
+    desc_rows(s, GRX_T_OBS, P.obs, Ni, c.num_obs);
     desc_rows(s, GRX_T_PRI_OBS, P.pri_obs, Ni, c.num_pri_obs);
     desc_vec(s, GRX_T_REW, P.rew, GRX_F32, Ni);
     desc_vec(s, GRX_T_RESET, P.reset, GRX_U8, Ni);
     desc_vec(s, GRX_T_TIME_OUT, P.time_out, GRX_U8, Ni);
     desc_vec(s, GRX_T_EPISODE_LENGTH, P.ep_len, GRX_I64, Ni);
-    desc_soa(s, GRX_T_DOF_POS, P.q, GRX_F32, GRX_ND);
-    desc_soa(s, GRX_T_DOF_VEL, P.qd, GRX_F32, GRX_ND);
-    desc_soa(s, GRX_T_TORQUES, P.torques, GRX_F32, GRX_ND);
-    desc_soa(s, GRX_T_ACTIONS, P.actions, GRX_F32, GRX_ND);
-    desc_soa(s, GRX_T_LAST_ACTIONS, P.last_actions, GRX_F32, GRX_ND);
-    desc_soa(s, GRX_T_LAST_DOF_VEL, P.last_dof_vel, GRX_F32, GRX_ND);
+    desc_soa(s, GRX_T_DOF_POS, P.q, GRX_F32, nd);
+    desc_soa(s, GRX_T_DOF_VEL, P.qd, GRX_F32, nd);
+    desc_soa(s, GRX_T_TORQUES, P.torques, GRX_F32, nd);
+    desc_soa(s, GRX_T_ACTIONS, P.actions, GRX_F32, nd);
+    desc_soa(s, GRX_T_LAST_ACTIONS, P.last_actions, GRX_F32, nd);
+    desc_soa(s, GRX_T_LAST_DOF_VEL, P.last_dof_vel, GRX_F32, nd);
     desc_soa(s, GRX_T_COMMANDS, P.commands, GRX_F32, 3);
     desc_soa(s, GRX_T_ROOT_STATES, P.root, GRX_F32, 13);
     desc_soa(s, GRX_T_BASE_LIN_VEL, P.base_lin_vel, GRX_F32, 3);
@@ -497,13 +608,18 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     desc_vec(s, GRX_T_TERRAIN_LEVELS, P.levels, GRX_I32, Ni);
     desc_vec(s, GRX_T_TERRAIN_TYPES, P.types, GRX_I32, Ni);
     desc_soa(s, GRX_T_ENV_ORIGINS, P.origins, GRX_F32, 3);
-    desc_soa(s, GRX_T_MOTOR_STRENGTH, P.motor_strength, GRX_F32, GRX_ND);
+    desc_soa(s, GRX_T_MOTOR_STRENGTH, P.motor_strength, GRX_F32, nd);
     desc_vec(s, GRX_T_FRICTION, P.friction, GRX_F32, Ni);
     desc_rows(s, GRX_T_BASE_MASS_COM, base_mass_com, Ni, 4);
     desc_vec(s, GRX_T_TERM_CONTACT, P.term_contact, GRX_U8, Ni);
     desc_vec(s, GRX_T_EPISODE_STATS, P.stats, GRX_F32, NT + 1);
     desc_soa3(s, GRX_T_ANCHORS, P.anchors, 8, 3);
     s->prof_host = P.prof; s->prof_blocks = nblocks;
+    s->stat_blocks = generic ? (c.num_envs + 63) / 64 : nblocks;
+    if (generic) {
+        rc = build_generic(s, c);
+        if (rc) { grx_destroy(s); return rc; }
+    }
     {
         void* hp_ = nullptr;
         HIP_TRY(hipHostMalloc(&hp_, sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
@@ -539,8 +655,9 @@ int grx_reset_all(grx_handle s, void* stream) {
     // extras["episode"] of a full reset: mean of the running episode sums over all envs
     // (legged_robot.py:420-424); computed by the stats path with every env flagged.
     uint32_t step = 0x80000000u + (s->reset_count++);
-    grx_launch_reset_all(s->d_hp, s->N, step, st);
-    grx_launch_finalize(s->d_hp, s->N, s->pace.d_progress, ++s->pace.issued, st);
+    if (s->generic) grx_launch_reset_all_generic(s->d_hp, s->d_gen, s->N, step, st);
+    else grx_launch_reset_all(s->d_hp, s->N, step, st);
+    grx_launch_finalize(s->d_hp, s->stat_blocks, s->pace.d_progress, ++s->pace.issued, st);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
@@ -568,13 +685,17 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
         HIP_TRY(hipEventRecord(ev.first, st));
     }
     const int64_t ticket = ++s->pace.issued;
-    grx_launch_step(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
-                    (long long)a->common_step_counter, a->noise_uniform, st);
+    if (s->generic)
+        grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
+                                (long long)a->common_step_counter, a->noise_uniform, st);
+    else
+        grx_launch_step(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
+                        (long long)a->common_step_counter, a->noise_uniform, st);
     if (timed) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->timing.pending.push_back(ev);
     }
-    grx_launch_finalize(s->d_hp, s->N, s->pace.d_progress, ticket, st);   // episode statistics + the step's ticket
+    grx_launch_finalize(s->d_hp, s->stat_blocks, s->pace.d_progress, ticket, st);   // episode statistics + the step's ticket
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }

@@ -1,0 +1,707 @@
+// grx_generic.h -- the generic-tree step kernel (included by grx_kernels.hip inside its anonymous namespace).
+//
+// The fast kernel (grx_step_kernel) is specialised for the GR1 lower-limb tree: two 5-joint chains, one lane pair
+// per env.  Every other robot model that include/grx.h can describe -- in particular the 32-DOF full-body GR1T1
+// (config 5 of BASELINE.json: legs with ankle roll, 3-joint waist, head, two 7-joint arms hanging from the torso)
+// -- runs through this kernel instead:
+//
+//   * one env per lane, 64 envs per single-wave block; loops over bodies / dofs with run-time trip counts;
+//   * the same formulation as the fast kernel: spatial quantities in WORLD axes about the base origin O, so a
+//     child's articulated inertia and bias force simply ADD into the parent at every junction of the tree (no 6x6
+//     frame transforms), revolute joints about arbitrary axes (Rodrigues), Schur-complement base solve;
+//   * per-body intermediates (frames, joint axes, articulated inertias, ...) live in a global-memory workspace laid
+//     out [slot][body][env], so every access of a wave is one coalesced row -- 72 floats per body per env; the
+//     workspace of 4096 full-body envs is 39 MB and stays cache-resident;
+//   * the env pipeline (torques, timers, termination, all reward terms, reset, observations + noise) is the fast
+//     kernel's, written as plain loops over the dofs; same Philox streams (the dof-noise streams split the dof range
+//     in halves exactly as the oracle does).
+//
+// This is the correctness-first path for models the fast kernel does not cover; it is latency-bound on the
+// workspace round trips (DESIGN.md section 4.3 has the measured rate).
+#pragma once
+
+constexpr int GEN_MAXB = GRX_MAX_BODIES, GEN_MAXD = GRX_MAX_DOFS, GEN_MAXS = GRX_MAX_SPHERES, GEN_MAXLC = 24;
+constexpr int WSB = 72;   // workspace floats per body
+enum { W_R = 0, W_RHO = 9, W_W = 12, W_V = 15, W_A = 18, W_S = 21, W_CA = 24, W_CL = 27, W_IA = 30, W_IB = 36, W_ID = 45,
+       W_PA = 51, W_PL = 54, W_UA = 57, W_UL = 60, W_DI = 63, W_U = 64, W_AA = 65, W_AL = 68 };
+
+struct GenTables {
+    int32_t nb, nd, nsph, nlc;
+    int32_t parent[GEN_MAXB];
+    float axis[GEN_MAXB][3], rot0[GEN_MAXB][9], jpos[GEN_MAXB][3], mass[GEN_MAXB], com[GEN_MAXB][3], Ic[GEN_MAXB][6];
+    float kp[GEN_MAXD], kd[GEN_MAXD], q0[GEN_MAXD], effort[GEN_MAXD], vlim[GEN_MAXD], qlo[GEN_MAXD], qhi[GEN_MAXD];
+    float slo[GEN_MAXD], shi[GEN_MAXD], amin[GEN_MAXD], amax[GEN_MAXD], Klim[GEN_MAXD], Clim[GEN_MAXD];
+    int32_t sph_begin[GEN_MAXB + 1];   // spheres are sorted by carrying body
+    float sx[GEN_MAXS], sy[GEN_MAXS], sz[GEN_MAXS], sr[GEN_MAXS], sdmax[GEN_MAXS];
+    int32_t sslot[GEN_MAXS];           // friction-anchor slot 0..7 of an anchored foot sphere, -1 otherwise
+    int32_t slink[GEN_MAXS];           // compact id of the URDF link the shape belongs to (force netting)
+    uint32_t link_flags[GEN_MAXLC];    // GRX_SPH_TERMINATE / GRX_SPH_PENALISE of the compact links
+    int32_t foot_body[2], foot_link[2];
+    float foot_pos[2][3];
+    int32_t torso_body, forehead_body;
+    float torso_rot[9], forehead_rot[9];
+};
+typedef const GRX_AS4 GenTables& GT;
+
+#define WSX(b, slot) ws[((size_t)((b) * WSB + (slot))) * N]
+GRX_DEV V3 ws_v3(const float* ws, size_t N, int b, int slot) { return v3(WSX(b, slot), WSX(b, slot + 1), WSX(b, slot + 2)); }
+GRX_DEV void ws_put(float* ws, size_t N, int b, int slot, V3 x) { WSX(b, slot) = x.x; WSX(b, slot + 1) = x.y; WSX(b, slot + 2) = x.z; }
+GRX_DEV R3 ws_R(const float* ws, size_t N, int b) {
+    R3 R;
+    R.cx = ws_v3(ws, N, b, W_R); R.cy = ws_v3(ws, N, b, W_R + 3); R.cz = ws_v3(ws, N, b, W_R + 6);
+    return R;
+}
+GRX_DEV void ws_putR(float* ws, size_t N, int b, const R3& R) { ws_put(ws, N, b, W_R, R.cx); ws_put(ws, N, b, W_R + 3, R.cy); ws_put(ws, N, b, W_R + 6, R.cz); }
+
+// child rotation: R_parent * rot0 * Rot(axis, q) for a unit axis in the child frame (columns = body axes in the world)
+GRX_DEV R3 gen_joint_rot(const R3& Rp, GT T, int b, float q) {
+    float sn, cs;
+    grx_sincos(q, sn, cs);
+    const float ax = T.axis[b][0], ay = T.axis[b][1], az = T.axis[b][2], oc = 1.f - cs;
+    // Rodrigues, columns of Rq
+    const V3 qx = v3(cs + ax * ax * oc, az * sn + ax * ay * oc, -ay * sn + ax * az * oc);
+    const V3 qy = v3(-az * sn + ax * ay * oc, cs + ay * ay * oc, ax * sn + ay * az * oc);
+    const V3 qz = v3(ay * sn + ax * az * oc, -ax * sn + ay * az * oc, cs + az * az * oc);
+    // rot0 is row-major child(q=0) -> parent: J = Rp * rot0
+    R3 J;
+    J.cx = rot(Rp, v3(T.rot0[b][0], T.rot0[b][3], T.rot0[b][6]));
+    J.cy = rot(Rp, v3(T.rot0[b][1], T.rot0[b][4], T.rot0[b][7]));
+    J.cz = rot(Rp, v3(T.rot0[b][2], T.rot0[b][5], T.rot0[b][8]));
+    R3 R;
+    R.cx = rot(J, qx); R.cy = rot(J, qy); R.cz = rot(J, qz);
+    return R;
+}
+
+// one sphere of body `b` against the terrain with a run-time anchor slot; adds its force into the link accumulator
+template <bool HF>
+GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu, float hmax, float* ws, size_t N, int e,
+                      int lfbase, V3& xr) {
+    xr = rho + rot(R, v3(T.sx[i], T.sy[i], T.sz[i]));
+    V3 F = v3(0.f, 0.f, 0.f);
+    const float wz = O.z + xr.z, r = T.sr[i];
+    const int slot = T.sslot[i];
+    bool touching = false;
+    if (wz - r <= hmax) {
+        const float wx = O.x + xr.x, wy = O.y + xr.y;
+        const float d = terrain_height<HF>(P, wx, wy) + r - wz;
+        if (d > 0.0f) {
+            touching = true;
+            const V3 u = v + cross(w, xr);
+            const float cd = fminf(P.kn * d * P.dn, T.sdmax[i]);
+            const float fn = fmaxf(P.kn * d - cd * u.z, 0.0f);
+            F.z = fn;
+            const float fmax = mu * fn;
+            if (slot >= 0) {
+                float* an = P.anchors + (size_t)(slot * 3) * N + e;
+                float axx = an[0], ayy = an[N];
+                if (an[2 * N] == 0.f) { axx = wx; ayy = wy; }
+                float ftx = -P.kt * (wx - axx) - P.ct * u.x;
+                float fty = -P.kt * (wy - ayy) - P.ct * u.y;
+                const float ft = grx_sqrt(ftx * ftx + fty * fty);
+                if (ft > fmax) {
+                    const float sc = fmax * grx_rcp(ft);
+                    ftx *= sc; fty *= sc;
+                    axx = wx + ftx * P.inv_kt;
+                    ayy = wy + fty * P.inv_kt;
+                }
+                an[0] = axx; an[N] = ayy;
+                F.x = ftx; F.y = fty;
+            } else {
+                const float sp = grx_sqrt(u.x * u.x + u.y * u.y);
+                const float ft = fminf(P.cv * sp, fmax);
+                if (sp > 1e-9f) { const float k = -ft * grx_rcp(sp); F.x = k * u.x; F.y = k * u.y; }
+            }
+        }
+    }
+    if (slot >= 0) P.anchors[(size_t)(slot * 3 + 2) * N + e] = touching ? 1.f : 0.f;
+    const int L = T.slink[i];
+    ws[(size_t)(lfbase + L * 3 + 0) * N] += F.x; ws[(size_t)(lfbase + L * 3 + 1) * N] += F.y; ws[(size_t)(lfbase + L * 3 + 2) * N] += F.z;
+    return F;
+}
+
+struct GenBase { V3 pos, vel, ang; float qx, qy, qz, qw; };
+
+// foot link frames of the CURRENT state (positions walk only, up to the two foot bodies)
+GRX_DEV void gen_foot_frames(KP P, GT T, const GenBase& B, const float* q, const float* qd, float* ws, size_t N, int e, V3 fpos[2], V3 fvel[2]) {
+    ws_putR(ws, N, 0, quat_to_R(B.qx, B.qy, B.qz, B.qw));
+    ws_put(ws, N, 0, W_RHO, v3(0.f, 0.f, 0.f)); ws_put(ws, N, 0, W_W, B.ang); ws_put(ws, N, 0, W_V, B.vel);
+    for (int b = 1; b < T.nb; ++b) {
+        const int p = T.parent[b];
+        const R3 Rp = ws_R(ws, N, p);
+        const V3 rho = ws_v3(ws, N, p, W_RHO) + rot(Rp, v3(T.jpos[b][0], T.jpos[b][1], T.jpos[b][2]));
+        const R3 R = gen_joint_rot(Rp, T, b, q[(size_t)(b - 1) * N]);
+        const V3 a = rot(R, v3(T.axis[b][0], T.axis[b][1], T.axis[b][2]));
+        const float qdk = qd[(size_t)(b - 1) * N];
+        const V3 wp = ws_v3(ws, N, p, W_W), vp = ws_v3(ws, N, p, W_V);
+        ws_putR(ws, N, b, R); ws_put(ws, N, b, W_RHO, rho);
+        ws_put(ws, N, b, W_W, fma3(a, qdk, wp)); ws_put(ws, N, b, W_V, fma3(cross(rho, a), qdk, vp));
+    }
+    for (int f = 0; f < 2; ++f) {
+        const int b = T.foot_body[f];
+        const R3 R = ws_R(ws, N, b);
+        const V3 fr = ws_v3(ws, N, b, W_RHO) + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
+        fpos[f] = B.pos + fr;
+        fvel[f] = ws_v3(ws, N, b, W_V) + cross(ws_v3(ws, N, b, W_W), fr);
+    }
+}
+
+// One physics sub-step.  q / qd / torques: this env's columns of the SoA state arrays (stride N).
+template <bool HF>
+GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const float* tau, float* ws, size_t N, int e,
+                         float base_m, V3 base_c, const S3& base_I, float mu, float hmax, V3 foot_vel_before[2]) {
+    const int nb = T.nb, lfbase = nb * WSB;
+    const float dt = P.sim_dt;
+    const R3 R0 = quat_to_R(B.qx, B.qy, B.qz, B.qw);
+    const V3 O = B.pos;
+    for (int i = 0; i < T.nlc * 3; ++i) ws[(size_t)(lfbase + i) * N] = 0.f;
+    // ---- pass 1 (root -> leaves): frames, joint axes, velocity-product accelerations, rigid inertias, bias, contacts
+    ws_putR(ws, N, 0, R0);
+    ws_put(ws, N, 0, W_RHO, v3(0.f, 0.f, 0.f)); ws_put(ws, N, 0, W_W, B.ang); ws_put(ws, N, 0, W_V, B.vel);
+    for (int b = 1; b < nb; ++b) {
+        const int p = T.parent[b];
+        const R3 Rp = ws_R(ws, N, p);
+        const V3 wp = ws_v3(ws, N, p, W_W), vp = ws_v3(ws, N, p, W_V);
+        const V3 rho = ws_v3(ws, N, p, W_RHO) + rot(Rp, v3(T.jpos[b][0], T.jpos[b][1], T.jpos[b][2]));
+        const R3 R = gen_joint_rot(Rp, T, b, q[(size_t)(b - 1) * N]);
+        const V3 a = rot(R, v3(T.axis[b][0], T.axis[b][1], T.axis[b][2]));
+        const V3 s = cross(rho, a);
+        const float qdk = qd[(size_t)(b - 1) * N];
+        const V3 ca = cross(wp, a) * qdk;
+        const V3 cl = (cross(vp, a) + cross(wp, s)) * qdk;
+        const V3 w = fma3(a, qdk, wp), v = fma3(s, qdk, vp);
+        const V3 kap = rho + rot(R, v3(T.com[b][0], T.com[b][1], T.com[b][2]));
+        const S3 Ic = {T.Ic[b][0], T.Ic[b][1], T.Ic[b][2], T.Ic[b][3], T.Ic[b][4], T.Ic[b][5]};
+        const float m = T.mass[b];
+        S3 Ak; V3 h;
+        rigid_inertia(R, kap, m, Ic, Ak, h);
+        V3 pa, pl;
+        rigid_bias(R, kap, m, Ic, w, v, pa, pl);
+        for (int i = T.sph_begin[b]; i < T.sph_begin[b + 1]; ++i) {
+            V3 xr;
+            const V3 F = gen_sphere<HF>(P, T, i, R, rho, w, v, O, mu, hmax, ws, N, e, lfbase, xr);
+            pa = pa - cross(xr, F); pl = pl - F;
+        }
+        for (int f = 0; f < 2; ++f)
+            if (T.foot_body[f] == b) {   // foot link velocity BEFORE this sub-step's integration
+                const V3 fr = rho + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
+                foot_vel_before[f] = v + cross(w, fr);
+            }
+        ws_putR(ws, N, b, R); ws_put(ws, N, b, W_RHO, rho); ws_put(ws, N, b, W_W, w); ws_put(ws, N, b, W_V, v);
+        ws_put(ws, N, b, W_A, a); ws_put(ws, N, b, W_S, s); ws_put(ws, N, b, W_CA, ca); ws_put(ws, N, b, W_CL, cl);
+        WSX(b, W_IA + 0) = Ak.xx; WSX(b, W_IA + 1) = Ak.xy; WSX(b, W_IA + 2) = Ak.xz; WSX(b, W_IA + 3) = Ak.yy; WSX(b, W_IA + 4) = Ak.yz; WSX(b, W_IA + 5) = Ak.zz;
+        WSX(b, W_IB + 0) = 0.f; WSX(b, W_IB + 1) = -h.z; WSX(b, W_IB + 2) = h.y; WSX(b, W_IB + 3) = h.z; WSX(b, W_IB + 4) = 0.f;
+        WSX(b, W_IB + 5) = -h.x; WSX(b, W_IB + 6) = -h.y; WSX(b, W_IB + 7) = h.x; WSX(b, W_IB + 8) = 0.f;
+        WSX(b, W_ID + 0) = m; WSX(b, W_ID + 1) = 0.f; WSX(b, W_ID + 2) = 0.f; WSX(b, W_ID + 3) = m; WSX(b, W_ID + 4) = 0.f; WSX(b, W_ID + 5) = m;
+        ws_put(ws, N, b, W_PA, pa); ws_put(ws, N, b, W_PL, pl);
+    }
+    // base: rigid lump (randomised per env) + its contacts
+    S3 A0; V3 h0;
+    rigid_inertia(R0, rot(R0, base_c), base_m, base_I, A0, h0);
+    V3 pa0, pl0;
+    rigid_bias(R0, rot(R0, base_c), base_m, base_I, B.ang, B.vel, pa0, pl0);
+    for (int i = T.sph_begin[0]; i < T.sph_begin[1]; ++i) {
+        V3 xr;
+        const V3 F = gen_sphere<HF>(P, T, i, R0, v3(0.f, 0.f, 0.f), B.ang, B.vel, O, mu, hmax, ws, N, e, lfbase, xr);
+        pa0 = pa0 - cross(xr, F); pl0 = pl0 - F;
+    }
+    S3 Ab = A0, Db = {base_m, 0.f, 0.f, base_m, 0.f, base_m};
+    M3 Bb = {0.f, -h0.z, h0.y, h0.z, 0.f, -h0.x, -h0.y, h0.x, 0.f};
+    // ---- pass 2 (leaves -> root): articulated inertias and bias forces; a child adds into its parent
+    for (int b = nb - 1; b >= 1; --b) {
+        const int p = T.parent[b], j = b - 1;
+        S3 A = {WSX(b, W_IA), WSX(b, W_IA + 1), WSX(b, W_IA + 2), WSX(b, W_IA + 3), WSX(b, W_IA + 4), WSX(b, W_IA + 5)};
+        M3 Bm = {WSX(b, W_IB), WSX(b, W_IB + 1), WSX(b, W_IB + 2), WSX(b, W_IB + 3), WSX(b, W_IB + 4), WSX(b, W_IB + 5), WSX(b, W_IB + 6), WSX(b, W_IB + 7), WSX(b, W_IB + 8)};
+        S3 D = {WSX(b, W_ID), WSX(b, W_ID + 1), WSX(b, W_ID + 2), WSX(b, W_ID + 3), WSX(b, W_ID + 4), WSX(b, W_ID + 5)};
+        const V3 a = ws_v3(ws, N, b, W_A), s = ws_v3(ws, N, b, W_S), ca = ws_v3(ws, N, b, W_CA), cl = ws_v3(ws, N, b, W_CL);
+        const V3 pa = ws_v3(ws, N, b, W_PA), pl = ws_v3(ws, N, b, W_PL);
+        const V3 ua = mul(A, a) + mul(Bm, s);
+        const V3 ul = mulT(Bm, a) + mul(D, s);
+        const float di = grx_rcp(dot(a, ua) + dot(s, ul));
+        const float qj = q[(size_t)j * N], qdj = qd[(size_t)j * N];
+        float t = tau[(size_t)j * N];   // joint-limit spring/damper on top of the motor torque
+        if (qj < T.qlo[j]) t += T.Klim[j] * (T.qlo[j] - qj) - T.Clim[j] * qdj;
+        else if (qj > T.qhi[j]) t += T.Klim[j] * (T.qhi[j] - qj) - T.Clim[j] * qdj;
+        const float u = t - (dot(a, pa) + dot(s, pl));
+        syr(A, ua, di); ger(Bm, ua, ul, di); syr(D, ul, di);
+        const float ud = u * di;
+        const V3 npa = pa + mul(A, ca) + mul(Bm, cl) + ua * ud;
+        const V3 npl = pl + mulT(Bm, ca) + mul(D, cl) + ul * ud;
+        ws_put(ws, N, b, W_UA, ua); ws_put(ws, N, b, W_UL, ul); WSX(b, W_DI) = di; WSX(b, W_U) = u;
+        if (p == 0) {
+            Ab = Ab + A; Bb = Bb + Bm; Db = Db + D; pa0 = pa0 + npa; pl0 = pl0 + npl;
+        } else {
+            WSX(p, W_IA) += A.xx; WSX(p, W_IA + 1) += A.xy; WSX(p, W_IA + 2) += A.xz; WSX(p, W_IA + 3) += A.yy; WSX(p, W_IA + 4) += A.yz; WSX(p, W_IA + 5) += A.zz;
+            WSX(p, W_IB) += Bm.a00; WSX(p, W_IB + 1) += Bm.a01; WSX(p, W_IB + 2) += Bm.a02; WSX(p, W_IB + 3) += Bm.a10; WSX(p, W_IB + 4) += Bm.a11;
+            WSX(p, W_IB + 5) += Bm.a12; WSX(p, W_IB + 6) += Bm.a20; WSX(p, W_IB + 7) += Bm.a21; WSX(p, W_IB + 8) += Bm.a22;
+            WSX(p, W_ID) += D.xx; WSX(p, W_ID + 1) += D.xy; WSX(p, W_ID + 2) += D.xz; WSX(p, W_ID + 3) += D.yy; WSX(p, W_ID + 4) += D.yz; WSX(p, W_ID + 5) += D.zz;
+            WSX(p, W_PA) += npa.x; WSX(p, W_PA + 1) += npa.y; WSX(p, W_PA + 2) += npa.z;
+            WSX(p, W_PL) += npl.x; WSX(p, W_PL + 1) += npl.y; WSX(p, W_PL + 2) += npl.z;
+        }
+    }
+    // ---- base: [A B; B^T D][alpha; acc] = -[pa; pl]
+    const S3 Di = inv(Db);
+    const V3 b0 = v3(Bb.a00, Bb.a01, Bb.a02), b1 = v3(Bb.a10, Bb.a11, Bb.a12), b2 = v3(Bb.a20, Bb.a21, Bb.a22);
+    const V3 d0 = mul(Di, b0), d1 = mul(Di, b1), d2 = mul(Di, b2);
+    const S3 Sc = {Ab.xx - dot(b0, d0), Ab.xy - dot(b0, d1), Ab.xz - dot(b0, d2), Ab.yy - dot(b1, d1), Ab.yz - dot(b1, d2), Ab.zz - dot(b2, d2)};
+    const V3 alpha = mul(inv(Sc), mul(Bb, mul(Di, pl0)) - pa0);
+    const V3 acc = neg(mul(Di, pl0 + mulT(Bb, alpha)));
+    // ---- pass 3 (root -> leaves): accelerations, joint integration
+    ws_put(ws, N, 0, W_AA, alpha); ws_put(ws, N, 0, W_AL, acc);
+    for (int b = 1; b < nb; ++b) {
+        const int p = T.parent[b], j = b - 1;
+        const V3 a = ws_v3(ws, N, b, W_A), s = ws_v3(ws, N, b, W_S);
+        const V3 pa_ = ws_v3(ws, N, p, W_AA) + ws_v3(ws, N, b, W_CA), pl_ = ws_v3(ws, N, p, W_AL) + ws_v3(ws, N, b, W_CL);
+        const float qdd = (WSX(b, W_U) - (dot(ws_v3(ws, N, b, W_UA), pa_) + dot(ws_v3(ws, N, b, W_UL), pl_))) * WSX(b, W_DI);
+        ws_put(ws, N, b, W_AA, fma3(a, qdd, pa_)); ws_put(ws, N, b, W_AL, fma3(s, qdd, pl_));
+        float vq = fmaf(qdd, dt, qd[(size_t)j * N]);
+        vq = fminf(fmaxf(vq, -T.vlim[j]), T.vlim[j]);
+        qd[(size_t)j * N] = vq;
+        q[(size_t)j * N] = fmaf(vq, dt, q[(size_t)j * N]);
+    }
+    // ---- integrate the base (semi-implicit Euler)
+    const V3 lin = acc + cross(B.ang, B.vel);
+    B.vel = v3(B.vel.x + (lin.x + P.gravity[0]) * dt, B.vel.y + (lin.y + P.gravity[1]) * dt, B.vel.z + (lin.z + P.gravity[2]) * dt);
+    B.ang = fma3(alpha, dt, B.ang);
+    B.pos = fma3(B.vel, dt, B.pos);
+    const float hx = 0.5f * dt * B.ang.x, hy = 0.5f * dt * B.ang.y, hz = 0.5f * dt * B.ang.z;
+    const float x = B.qx, y = B.qy, z = B.qz, ww = B.qw;
+    const float nx = x + hx * ww + hy * z - hz * y, ny = y - hx * z + hy * ww + hz * x;
+    const float nz = z + hx * y - hy * x + hz * ww, nw = ww - hx * x - hy * y - hz * z;
+    const float n = grx_rsq(nx * nx + ny * ny + nz * nz + nw * nw);
+    B.qx = nx * n; B.qy = ny * n; B.qz = nz * n; B.qw = nw * n;
+}
+
+// reset_idx for one env (legged_robot.py:377-440, 717-826; legged_robot_fftai.py:137-146); state written to memory
+GRX_DEV void gen_reset_env(KP P, GT T, uint32_t genv, uint32_t step, bool init_done, GenBase& B, EnvAux& ea, float* q, float* qd, size_t N, int e) {
+    if (P.curriculum && P.terrain_type != GRX_TERRAIN_PLANE && init_done) {
+        const float dx = B.pos.x - ea.origin[0], dy = B.pos.y - ea.origin[1];
+        const float dist = sqrtf(dx * dx + dy * dy);
+        const int up = dist > P.terrain_length * 0.5f;
+        const float cn = sqrtf(ea.cmd[0] * ea.cmd[0] + ea.cmd[1] * ea.cmd[1]);
+        const int down = (dist < cn * P.max_episode_length_s * 0.5f) && !up;
+        ea.level += up - down;
+        if (ea.level >= P.num_terrain_rows) {
+            const float u = grx_rand(P.seed, genv, step, GRX_RNG_CURRICULUM, 0);
+            ea.level = min((int)(u * (float)P.num_terrain_rows), P.num_terrain_rows - 1);
+        } else if (ea.level < 0)
+            ea.level = 0;
+        const float* o = P.terrain_origins + ((size_t)ea.level * P.num_terrain_cols + ea.type) * 3;
+        ea.origin[0] = o[0]; ea.origin[1] = o[1]; ea.origin[2] = o[2];
+    }
+    for (int j = 0; j < T.nd; ++j) {
+        const float f = P.randomize_init_dof_pos ? urand(P, genv, step, GRX_RNG_RESET_DOF, (uint32_t)j, 0.5f, 1.5f) : 1.0f;
+        q[(size_t)j * N] = f * T.q0[j];
+        qd[(size_t)j * N] = 0.f;
+    }
+    B.pos = v3(P.init_pos[0] + ea.origin[0], P.init_pos[1] + ea.origin[1], P.init_pos[2] + ea.origin[2]);
+    if (P.terrain_type != GRX_TERRAIN_PLANE) {
+        B.pos.x += urand(P, genv, step, GRX_RNG_RESET_ROOT, 0, -1.0f, 1.0f);
+        B.pos.y += urand(P, genv, step, GRX_RNG_RESET_ROOT, 1, -1.0f, 1.0f);
+    }
+    const float yaw = urand(P, genv, step, GRX_RNG_RESET_ROOT, 2, -6.283185307179586f, 6.283185307179586f);
+    float sy, cy;
+    sincosf(yaw * 0.5f, &sy, &cy);
+    B.qx = 0.f; B.qy = 0.f; B.qz = sy; B.qw = cy;
+    if (P.randomize_init_base_velocity) {
+        B.vel = v3(urand(P, genv, step, GRX_RNG_RESET_ROOT, 3, -0.5f, 0.5f), urand(P, genv, step, GRX_RNG_RESET_ROOT, 4, -0.5f, 0.5f),
+                   urand(P, genv, step, GRX_RNG_RESET_ROOT, 5, -0.5f, 0.5f));
+        B.ang = v3(urand(P, genv, step, GRX_RNG_RESET_ROOT, 6, -0.5f, 0.5f), urand(P, genv, step, GRX_RNG_RESET_ROOT, 7, -0.5f, 0.5f),
+                   urand(P, genv, step, GRX_RNG_RESET_ROOT, 8, -0.5f, 0.5f));
+    } else {
+        B.vel = v3(0.f, 0.f, 0.f);
+        B.ang = v3(0.f, 0.f, 0.f);
+    }
+    resample_commands(P, genv, step, GRX_RNG_CMD_RESET, ea.cmd);
+    for (int i = 0; i < 8; ++i) P.anchors[(size_t)(i * 3 + 2) * N + e] = 0.f;
+}
+
+GRX_DEV float gen_masked_abs_sum(const float* a, size_t N, int nd, uint32_t mask) {
+    float s = 0.f;
+    for (int j = 0; j < nd; ++j) if (mask & (1u << j)) s += fabsf(a[(size_t)j * N]);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <bool HF>
+__global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict__ Pg, const GenTables* __restrict__ Tg, float* __restrict__ wsg,
+                                                       const float* __restrict__ actions_in, float delay, long long common_step,
+                                                       const float* __restrict__ noise_in) {
+    KP P = GRX_PARAMS(Pg);
+    GT T = *reinterpret_cast<const GRX_AS4 GenTables*>(reinterpret_cast<uintptr_t>(Tg));
+    __shared__ float s_stat[NT + 1];
+    const int lane = threadIdx.x;
+    if (lane <= NT) s_stat[lane] = 0.f;
+    __syncthreads();
+    const size_t N = (size_t)P.N;
+    const int e_raw = blockIdx.x * 64 + lane;
+    const bool act = e_raw < P.N;
+    const int e = act ? e_raw : P.N - 1;
+    const int nd = T.nd, nb = T.nb;
+    const uint32_t genv = (uint32_t)(P.env_offset + e), step = (uint32_t)common_step;
+    const int nh = P.nh, nobs = 9 + 3 * nd, npri = P.num_pri_obs;
+    const float dtp = P.sim_dt * (float)P.decimation;
+    float* ws = wsg + e;   // this env's column of the [slot][env] workspace
+    float* q = P.q + e; float* qd = P.qd + e;
+    float* a_cur = P.actions + e; float* a_last = P.last_actions + e; float* qd_last = P.last_dof_vel + e; float* tau = P.torques + e;
+    const float* strength = P.motor_strength + e;
+    // ---- load the base state
+    GenBase B;
+    B.pos = v3(P.root[e], P.root[N + e], P.root[2 * N + e]);
+    B.qx = P.root[3 * N + e]; B.qy = P.root[4 * N + e]; B.qz = P.root[5 * N + e]; B.qw = P.root[6 * N + e];
+    B.vel = v3(P.root[7 * N + e], P.root[8 * N + e], P.root[9 * N + e]);
+    B.ang = v3(P.root[10 * N + e], P.root[11 * N + e], P.root[12 * N + e]);
+    const float base_m = P.base_m[e];
+    const V3 base_c = v3(P.base_c[e], P.base_c[N + e], P.base_c[2 * N + e]);
+    const S3 base_I = {P.base_I[e], P.base_I[N + e], P.base_I[2 * N + e], P.base_I[3 * N + e], P.base_I[4 * N + e], P.base_I[5 * N + e]};
+    const float mu = 0.5f * (P.terrain_friction + P.friction[e]);
+    float hmax = 0.f;
+    if (HF) {
+        int ci = min(max((int)((B.pos.x + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_rows - 1);
+        int cj = min(max((int)((B.pos.y + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
+        hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
+    }
+    EnvAux ea;
+    ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[N + e]; ea.cmd[2] = P.commands[2 * N + e];
+    ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[N + e]; ea.origin[2] = P.origins[2 * N + e];
+    ea.level = P.levels[e]; ea.type = P.types[e];
+    float air_time[2] = {P.air_time[e], P.air_time[N + e]}, land_time[2] = {P.land_time[e], P.land_time[N + e]};
+    bool contact_last[2] = {P.feet_contact[e] != 0, P.feet_contact[N + e] != 0};
+    const float bho_stale = P.base_heights_offset[e];
+    long long ep_len = P.ep_len[e];
+    // ---- clip_actions (legged_robot_fftai.py:171-177); last_actions still hold the previous step's
+    for (int j = 0; j < nd; ++j) {
+        const float a = actions_in ? actions_in[(size_t)e * nd + j] : 0.f;
+        a_cur[(size_t)j * N] = fminf(fmaxf(a, T.amin[j]), T.amax[j]);
+    }
+    // ---- during_physics_step (legged_robot_fftai.py:51-88)
+    float avg_force[2] = {0.f, 0.f};
+    V3 avg_speed[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+    V3 fvel[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)}, fpos[2];
+    const int lfbase = nb * WSB;
+    for (int deci = 0; deci < P.decimation; ++deci) {
+        const bool use_last = (float)deci < delay;
+        for (int j = 0; j < nd; ++j) {   // _compute_torques legged_robot.py:679-715
+            const float a = use_last ? a_last[(size_t)j * N] : a_cur[(size_t)j * N];
+            float t = T.kp[j] * (a * P.action_scale + T.q0[j] - q[(size_t)j * N]) - T.kd[j] * qd[(size_t)j * N];
+            t *= strength[(size_t)j * N];
+            tau[(size_t)j * N] = fminf(fmaxf(t, -T.effort[j]), T.effort[j]);
+        }
+        gen_substep<HF>(P, T, B, q, qd, tau, ws, N, e, base_m, base_c, base_I, mu, hmax, fvel);
+        if (deci > 0)
+            for (int f = 0; f < 2; ++f) avg_speed[f] = v3(avg_speed[f].x + fabsf(fvel[f].x), avg_speed[f].y + fabsf(fvel[f].y), avg_speed[f].z + fabsf(fvel[f].z));
+        for (int f = 0; f < 2; ++f) {
+            const int L = T.foot_link[f];
+            const V3 F = v3(ws[(size_t)(lfbase + L * 3) * N], ws[(size_t)(lfbase + L * 3 + 1) * N], ws[(size_t)(lfbase + L * 3 + 2) * N]);
+            avg_force[f] += grx_sqrt(dot(F, F));
+        }
+    }
+    gen_foot_frames(P, T, B, q, qd, ws, N, e, fpos, fvel);   // refresh_rigid_body_state_tensor after the last sub-step
+    V3 foot_force[2];
+    for (int f = 0; f < 2; ++f) {
+        avg_speed[f] = v3((avg_speed[f].x + fabsf(fvel[f].x)) / (float)P.decimation, (avg_speed[f].y + fabsf(fvel[f].y)) / (float)P.decimation,
+                          (avg_speed[f].z + fabsf(fvel[f].z)) / (float)P.decimation);
+        avg_force[f] /= (float)P.decimation;
+        const int L = T.foot_link[f];
+        foot_force[f] = v3(ws[(size_t)(lfbase + L * 3) * N], ws[(size_t)(lfbase + L * 3 + 1) * N], ws[(size_t)(lfbase + L * 3 + 2) * N]);
+    }
+    // termination / collision from the per-link net forces of the LAST sub-step (legged_robot.py:336-353)
+    bool term_contact = false;
+    float pen_count = 0.f;
+    for (int L = 0; L < T.nlc; ++L) {
+        const V3 F = v3(ws[(size_t)(lfbase + L * 3) * N], ws[(size_t)(lfbase + L * 3 + 1) * N], ws[(size_t)(lfbase + L * 3 + 2) * N]);
+        const float n2 = dot(F, F);
+        if ((T.link_flags[L] & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term_contact = true;
+        if ((T.link_flags[L] & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.f;
+    }
+    // torso / forehead orientation (frames of the final state are in the workspace)
+    float torso_g[2] = {0.f, 0.f}, fore_g[2] = {0.f, 0.f};
+    if (T.torso_body >= 0) {
+        const R3 R = ws_R(ws, N, T.torso_body);
+        torso_g[0] = -(R.cx.z * T.torso_rot[0] + R.cy.z * T.torso_rot[3] + R.cz.z * T.torso_rot[6]);
+        torso_g[1] = -(R.cx.z * T.torso_rot[1] + R.cy.z * T.torso_rot[4] + R.cz.z * T.torso_rot[7]);
+    }
+    if (T.forehead_body >= 0) {
+        const R3 R = ws_R(ws, N, T.forehead_body);
+        fore_g[0] = -(R.cx.z * T.forehead_rot[0] + R.cy.z * T.forehead_rot[3] + R.cz.z * T.forehead_rot[6]);
+        fore_g[1] = -(R.cx.z * T.forehead_rot[1] + R.cy.z * T.forehead_rot[4] + R.cz.z * T.forehead_rot[7]);
+    }
+    // ---- post_physics_step (legged_robot.py:269-334)
+    ep_len += 1;
+    const V3 qv = v3(B.qx, B.qy, B.qz);
+    const V3 blv = quat_rotate_inverse(qv, B.qw, B.vel), bav = quat_rotate_inverse(qv, B.qw, B.ang);
+    const V3 pg = quat_rotate_inverse(qv, B.qw, v3(0.f, 0.f, -1.f));
+    if (P.resample_command_interval > 0 && ((uint32_t)ep_len % (uint32_t)P.resample_command_interval) == 0)
+        resample_commands(P, genv, step, GRX_RNG_CMD_TIME, ea.cmd);
+    float* heights = P.heights + e;   // raw measured heights (always materialised here: the reward / obs code reads them back)
+    float hsum = 0.f;
+    if (HF && P.measure_heights) {
+        const float yaw_n = fmaxf(sqrtf(B.qz * B.qz + B.qw * B.qw), 1e-9f);
+        const float yz = B.qz / yaw_n, yw = B.qw / yaw_n;
+        for (int k = 0; k < nh; ++k) {
+            const float h = height_sample(P, *P.tables, yz, yw, B.pos, k);
+            heights[(size_t)k * N] = h;
+            hsum += h;
+        }
+    } else
+        for (int k = 0; k < nh; ++k) heights[(size_t)k * N] = 0.f;
+    if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {
+        B.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
+        B.vel.y = urand(P, genv, step, GRX_RNG_PUSH, 1, -P.max_push_vel_xy, P.max_push_vel_xy);
+    }
+    // feet timers (legged_robot_fftai.py:108-133)
+    bool contact[2], contact_filt[2], first_contact[2];
+    float feet_height[2];
+    for (int f = 0; f < 2; ++f) {
+        contact[f] = foot_force[f].z > 1.0f;
+        contact_filt[f] = contact[f] || contact_last[f];
+        contact_last[f] = contact[f];
+        first_contact[f] = (air_time[f] > 0.f) && contact_filt[f];
+        air_time[f] += dtp;
+        feet_height[f] = nh > 0 ? (fpos[f].z * (float)nh - hsum) / (float)nh : fpos[f].z;
+        land_time[f] = (land_time[f] + dtp) * (contact[f] ? 1.f : 0.f);
+    }
+    bool reset = term_contact || (fabsf(pg.z) < P.termination_gravity_z);
+    const bool time_out = (float)ep_len > P.max_episode_length;
+    reset = reset || time_out;
+    // ---- compute_reward (legged_robot.py:355-375; terms legged_robot_fftai.py:180-352, gr1t1.py:338-589)
+    float r[NT];
+    {
+        const float as = P.action_scale, H = P.swing_feet_height_target, Tt = P.feet_air_time_target;
+        const GRX_AS4 float* sg = P.reward_sigma;
+        float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
+        for (int j = 0; j < nd; ++j) {
+            const float ac = a_cur[(size_t)j * N], al = a_last[(size_t)j * N], qj = q[(size_t)j * N], qdj = qd[(size_t)j * N], tj = tau[(size_t)j * N];
+            s1 += fabsf((al - ac) * as);
+            if (P.knee_mask & (1u << j)) s3 += fabsf((ac - al) * as);
+            sacc += fabsf((qdj - qd_last[(size_t)j * N]) / dtp);
+            stor += fabsf(tj);
+            svel += fabsf(qdj);
+            const float po = fabsf(qj - T.q0[j]);
+            spose += po;
+            if (P.hip_yaw_mask & (1u << j)) shy += po;
+            const float a = ac * as;
+            float oa = 0.f, op = 0.f;
+            if (a - T.slo[j] < 0.f) oa += -(a - T.slo[j]);
+            if (a - T.shi[j] > 0.f) oa += (a - T.shi[j]);
+            sla += oa * oa;
+            if (qj - T.slo[j] < 0.f) op += -(qj - T.slo[j]);
+            if (qj - T.shi[j] > 0.f) op += (qj - T.shi[j]);
+            slp += fabsf(op);
+            slv += fminf(fmaxf(fabsf(qdj) - T.vlim[j] * P.soft_dof_vel_limit, 0.f), 1.f);
+            slt += fmaxf(fabsf(tj) - T.effort[j] * P.soft_torque_limit, 0.f);
+        }
+        const float tor_hr = gen_masked_abs_sum(tau, N, nd, P.hip_roll_mask), vel_kn = gen_masked_abs_sum(qd, N, nd, P.knee_mask);
+        const float hmin = fminf(feet_height[0], feet_height[1]);
+        float lift = 0.f, af = 0.f, ah = 0.f, at = 0.f, lt = 0.f, exy = 0.f, ez = 0.f, stum = 0.f, ncontact = 0.f;
+        for (int f = 0; f < 2; ++f) {
+            const float h = feet_height[f];
+            lift += gen_masked_abs_sum(tau, N, nd, f ? P.ankle_right_mask : P.ankle_left_mask) * fabsf(h) * (h > H * 0.5f ? 1.f : 0.f);
+            const float mid = fabsf(air_time[f] - Tt * 0.5f);
+            af += mid * avg_force[f];
+            ah += mid * fabsf(h - hmin - H);
+            at += expf(sg[GRX_REW_FEET_AIR_TIME] * fabsf(air_time[f] - Tt)) * (first_contact[f] ? 1.f : 0.f);
+            const float le = (land_time[f] - P.feet_land_time_max) * (land_time[f] > P.feet_land_time_max ? 1.f : 0.f);
+            lt += 1.f - expf(sg[GRX_REW_FEET_LAND_TIME] * le);
+            const float close = fabsf(h - H * 0.25f) * (h < H * 0.25f ? 1.f : 0.f) / (H * 0.25f);
+            exy += sqrtf(avg_speed[f].x * avg_speed[f].x + avg_speed[f].y * avg_speed[f].y) * close;
+            const float far = fabsf(h - H * 3.f / 4.f) * (h > H * 3.f / 4.f ? 1.f : 0.f) / (H * 1.f / 4.f);
+            ez += fabsf(avg_speed[f].z) * far;
+            const V3 F = foot_force[f];
+            float serr = sqrtf(F.x * F.x + F.y * F.y) - P.feet_stumble_ratio * fabsf(F.z);
+            serr = serr * (serr > 0.f ? 1.f : 0.f);
+            stum += 1.f - expf(sg[GRX_REW_FEET_STUMBLE] * serr);
+            ncontact += contact[f] ? 1.f : 0.f;
+        }
+        const float cmd_n = sqrtf(ea.cmd[0] * ea.cmd[0] + ea.cmd[1] * ea.cmd[1]);
+        const float moving = cmd_n > 0.1f ? 1.f : 0.f;
+        r[GRX_REW_ACTION_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF] * s1);
+        r[GRX_REW_ACTION_DIFF_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_DIFF] * s1);   // last_last_actions == last_actions
+        r[GRX_REW_ACTION_DIFF_KNEE] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_KNEE] * s3);
+        r[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] * fabsf(0.f - bav.y));
+        r[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] * fabsf(0.f - bav.x));
+        r[GRX_REW_CMD_DIFF_ANG_VEL_YAW] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_YAW] * fabsf(ea.cmd[2] - bav.z));
+        r[GRX_REW_CMD_DIFF_BASE_HEIGHT] = expf(sg[GRX_REW_CMD_DIFF_BASE_HEIGHT] * (fabsf(bho_stale) * (bho_stale < 0.f ? 1.f : 0.f)));
+        r[GRX_REW_CMD_DIFF_BASE_ORIENT] = expf(sg[GRX_REW_CMD_DIFF_BASE_ORIENT] * (fabsf(pg.x) + fabsf(pg.y)));
+        r[GRX_REW_CMD_DIFF_TORSO_ORIENT] = T.torso_body >= 0 ? expf(sg[GRX_REW_CMD_DIFF_TORSO_ORIENT] * (fabsf(torso_g[0]) + fabsf(torso_g[1]))) : 0.f;
+        r[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] = T.forehead_body >= 0 ? expf(sg[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] * (fabsf(fore_g[0]) + fabsf(fore_g[1]))) : 0.f;
+        r[GRX_REW_CMD_DIFF_LIN_VEL_X] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_X] * fabsf(ea.cmd[0] - blv.x));
+        r[GRX_REW_CMD_DIFF_LIN_VEL_Y] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Y] * fabsf(ea.cmd[1] - blv.y));
+        r[GRX_REW_CMD_DIFF_LIN_VEL_Z] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Z] * fabsf(0.f - blv.z));
+        r[GRX_REW_COLLISION] = 1.f - expf(sg[GRX_REW_COLLISION] * pen_count);
+        r[GRX_REW_DOF_ACC_NEW] = 1.f - expf(sg[GRX_REW_DOF_ACC_NEW] * sacc);
+        r[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] = 1.f - expf(sg[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] * lift);
+        r[GRX_REW_DOF_TOR_NEW] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW] * stor);
+        r[GRX_REW_DOF_TOR_NEW_HIP_ROLL] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW_HIP_ROLL] * tor_hr);
+        r[GRX_REW_DOF_VEL_NEW] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW] * svel);
+        r[GRX_REW_DOF_VEL_NEW_KNEE] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW_KNEE] * vel_kn);
+        r[GRX_REW_FEET_AIR_FORCE] = expf(sg[GRX_REW_FEET_AIR_FORCE] * af) * moving;
+        r[GRX_REW_FEET_AIR_HEIGHT] = expf(sg[GRX_REW_FEET_AIR_HEIGHT] * ah) * moving;
+        r[GRX_REW_FEET_AIR_TIME] = at * moving;
+        r[GRX_REW_FEET_LAND_TIME] = lt * moving;
+        r[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] = expf(sg[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] * exy);
+        r[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] = expf(sg[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] * ez);
+        r[GRX_REW_FEET_STUMBLE] = stum;
+        r[GRX_REW_LIMITS_ACTIONS] = 1.f - expf(sg[GRX_REW_LIMITS_ACTIONS] * sla);
+        r[GRX_REW_LIMITS_DOF_POS] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_POS] * slp);
+        r[GRX_REW_LIMITS_DOF_TOR] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_TOR] * slt);
+        r[GRX_REW_LIMITS_DOF_VEL] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_VEL] * slv);
+        r[GRX_REW_ON_THE_AIR] = ncontact == 0.f ? 1.f : 0.f;
+        r[GRX_REW_POSE_OFFSET] = expf(sg[GRX_REW_POSE_OFFSET] * spose);
+        r[GRX_REW_POSE_OFFSET_HIP_YAW] = 1.f - expf(sg[GRX_REW_POSE_OFFSET_HIP_YAW] * shy);
+        r[GRX_REW_STAND_STILL] = expf(sg[GRX_REW_STAND_STILL] * spose) * (cmd_n < 0.1f ? 1.f : 0.f);
+        r[GRX_REW_TERMINATION] = (reset && !time_out) ? 1.f : 0.f;
+    }
+    float rew = 0.f;
+    for (int t = 0; t < NT; ++t) {
+        const float sc_t = P.reward_scale_dt[t];
+        float rt = 0.f;
+        if (t != GRX_REW_TERMINATION && sc_t != 0.f) { rt = r[t] * sc_t; rew += rt; }
+        r[t] = rt;
+    }
+    if (P.only_positive_rewards) rew = fmaxf(rew, 0.f);
+    if (P.reward_scale_dt[GRX_REW_TERMINATION] != 0.f) {
+        const float rt = r[GRX_REW_TERMINATION] = ((reset && !time_out) ? 1.f : 0.f) * P.reward_scale_dt[GRX_REW_TERMINATION];
+        rew += rt;
+    }
+    // episode sums; finished episodes -> the block's statistics row (deterministic lane order)
+    const unsigned long long reset_mask = __ballot(reset && act);
+    for (int t = 0; t < NT; ++t) {
+        const float es = ((P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f) + r[t];
+        if (reset_mask) {
+            float acc = 0.f;
+            unsigned long long m = reset_mask;
+            while (m) { const int L = __ffsll((long long)m) - 1; m &= m - 1; acc += __shfl(es, L); }
+            if (lane == 0) s_stat[t] = acc;
+        }
+        if (act && P.reward_scale_dt[t] != 0.f) {
+            P.episode_sums[(size_t)t * N + e] = reset ? 0.f : es;
+            if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
+        }
+    }
+    if (lane == 0) s_stat[NT] = (float)__popcll(reset_mask);
+    // ---- reset_idx (masked, in-kernel)
+    if (reset) {
+        gen_reset_env(P, T, genv, step, true, B, ea, q, qd, N, e);
+        for (int j = 0; j < nd; ++j) { a_last[(size_t)j * N] = 0.f; qd_last[(size_t)j * N] = 0.f; }
+        for (int f = 0; f < 2; ++f) { air_time[f] = 0.f; land_time[f] = 0.f; contact_last[f] = false; }
+        ep_len = 0;
+    }
+    // ---- compute_observations (legged_robot_fftai.py:148-167, gr1t1.py:281-336)
+    float* obs = P.obs + (size_t)e * nobs;
+    float* pri = P.pri_obs + (size_t)e * npri;
+    const float clipo = P.clip_observations;
+    float bho = 0.f;
+    {
+        float sum = 0.f;
+        for (int k = 0; k < nh; ++k) {
+            float d = B.pos.z - P.base_height_target - heights[(size_t)k * N];
+            d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
+            if (act) pri[nobs + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -clipo), clipo);
+            sum += d;
+        }
+        bho = nh > 0 ? sum / (float)nh : 0.f;
+    }
+    if (act) {
+        auto put = [&](int idx, float val, float nscale) {
+            pri[idx] = fminf(fmaxf(val, -clipo), clipo);   // pri_obs copies obs BEFORE noise
+            float ov = val;
+            if (P.add_noise && nscale != 0.f) {
+                float u;
+                if (noise_in) u = noise_in[(size_t)e * nobs + idx];
+                else if (idx < 9) u = grx_rand(P.seed, genv, step, GRX_RNG_NOISE, (uint32_t)(idx - 3));
+                else {   // dof terms: one stream per half of the dof range (the oracle's scheme)
+                    const int g = (idx - 9) / nd, j = (idx - 9) % nd, half = nd / 2;
+                    const bool right = j >= half;
+                    u = grx_rand(P.seed, genv, step, right ? GRX_RNG_NOISE_DOF_R : GRX_RNG_NOISE_DOF_L, (uint32_t)(g * half + (right ? j - half : j)));
+                }
+                ov += (2.f * u - 1.f) * nscale;
+            }
+            obs[idx] = fminf(fmaxf(ov, -clipo), clipo);
+        };
+        put(0, ea.cmd[0], 0.f); put(1, ea.cmd[1], 0.f); put(2, ea.cmd[2], 0.f);
+        const float na = P.noise_ang_vel * P.noise_level * P.obs_scale_ang_vel, ng = P.noise_gravity * P.noise_level * P.obs_scale_gravity;
+        put(3, bav.x * P.obs_scale_ang_vel, na); put(4, bav.y * P.obs_scale_ang_vel, na); put(5, bav.z * P.obs_scale_ang_vel, na);
+        put(6, pg.x * P.obs_scale_gravity, ng); put(7, pg.y * P.obs_scale_gravity, ng); put(8, pg.z * P.obs_scale_gravity, ng);
+        const float np_ = P.noise_dof_pos * P.noise_level * P.obs_scale_dof_pos, nv = P.noise_dof_vel * P.noise_level * P.obs_scale_dof_vel;
+        const float nac = P.noise_action * P.noise_level * P.obs_scale_action;
+        for (int j = 0; j < nd; ++j) {
+            put(9 + j, (q[(size_t)j * N] - T.q0[j]) * P.obs_scale_dof_pos, np_);
+            put(9 + nd + j, qd[(size_t)j * N] * P.obs_scale_dof_vel, nv);
+            put(9 + 2 * nd + j, a_cur[(size_t)j * N] * P.obs_scale_action, nac);
+        }
+        pri[nobs + 0] = fminf(fmaxf(blv.x * P.obs_scale_lin_vel, -clipo), clipo);
+        pri[nobs + 1] = fminf(fmaxf(blv.y * P.obs_scale_lin_vel, -clipo), clipo);
+        pri[nobs + 2] = fminf(fmaxf(blv.z * P.obs_scale_lin_vel, -clipo), clipo);
+        pri[nobs + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
+        for (int f = 0; f < 2; ++f) {
+            pri[nobs + 4 + f] = (reset ? false : contact[f]) ? 1.f : 0.f;   // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
+            pri[nobs + 6 + f] = fminf(fmaxf(feet_height[f] * P.obs_scale_height, -clipo), clipo);
+        }
+        // ---- store state; history: last_actions = actions, last_dof_vel = dof_vel (legged_robot.py:299-300)
+        for (int j = 0; j < nd; ++j) { a_last[(size_t)j * N] = a_cur[(size_t)j * N]; qd_last[(size_t)j * N] = qd[(size_t)j * N]; }
+        const float rs[13] = {B.pos.x, B.pos.y, B.pos.z, B.qx, B.qy, B.qz, B.qw, B.vel.x, B.vel.y, B.vel.z, B.ang.x, B.ang.y, B.ang.z};
+        for (int i = 0; i < 13; ++i) P.root[(size_t)i * N + e] = rs[i];
+        for (int f = 0; f < 2; ++f) {
+            P.air_time[(size_t)f * N + e] = air_time[f] * (contact_filt[f] ? 0.f : 1.f);   // legged_robot_fftai.py:97
+            P.land_time[(size_t)f * N + e] = land_time[f];
+            P.feet_contact[(size_t)f * N + e] = (reset ? false : contact[f]) ? 1 : 0;
+            P.feet_height[(size_t)f * N + e] = feet_height[f];
+            P.avg_force[(size_t)f * N + e] = avg_force[f];
+            const float ff[3] = {foot_force[f].x, foot_force[f].y, foot_force[f].z}, fp[3] = {fpos[f].x, fpos[f].y, fpos[f].z};
+            const float as_[3] = {avg_speed[f].x, avg_speed[f].y, avg_speed[f].z};
+            for (int i = 0; i < 3; ++i) {
+                P.feet_force[(size_t)(f * 3 + i) * N + e] = ff[i];
+                P.feet_pos[(size_t)(f * 3 + i) * N + e] = fp[i];
+                P.avg_speed[(size_t)(f * 3 + i) * N + e] = as_[i];
+            }
+        }
+        P.commands[e] = ea.cmd[0]; P.commands[N + e] = ea.cmd[1]; P.commands[2 * N + e] = ea.cmd[2];
+        P.base_lin_vel[e] = blv.x; P.base_lin_vel[N + e] = blv.y; P.base_lin_vel[2 * N + e] = blv.z;
+        P.base_ang_vel[e] = bav.x; P.base_ang_vel[N + e] = bav.y; P.base_ang_vel[2 * N + e] = bav.z;
+        P.proj_grav[e] = pg.x; P.proj_grav[N + e] = pg.y; P.proj_grav[2 * N + e] = pg.z;
+        P.origins[e] = ea.origin[0]; P.origins[N + e] = ea.origin[1]; P.origins[2 * N + e] = ea.origin[2];
+        P.levels[e] = ea.level;
+        P.base_heights_offset[e] = bho;
+        P.ep_len[e] = ep_len;
+        P.rew[e] = rew;
+        P.reset[e] = reset ? 1 : 0;
+        P.time_out[e] = time_out ? 1 : 0;
+        P.term_contact[e] = term_contact ? 1 : 0;
+    }
+    __syncthreads();
+    if (lane <= NT) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + lane] = s_stat[lane];
+}
+
+// BaseTask.reset() first half for the generic path
+__global__ __launch_bounds__(64) void grx_reset_all_generic(const KParams* __restrict__ Pg, const GenTables* __restrict__ Tg, uint32_t step) {
+    KP P = GRX_PARAMS(Pg);
+    GT T = *reinterpret_cast<const GRX_AS4 GenTables*>(reinterpret_cast<uintptr_t>(Tg));
+    const size_t N = (size_t)P.N;
+    const int lane = threadIdx.x, e_raw = blockIdx.x * 64 + lane;
+    const bool act = e_raw < P.N;
+    const int e = act ? e_raw : P.N - 1;
+    const uint32_t genv = (uint32_t)(P.env_offset + e);
+    for (int t = 0; t < NT; ++t) {   // extras["episode"]: every env is "finished"
+        float contrib = act ? P.episode_sums[(size_t)t * N + e] : 0.f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off);
+        if (lane == 0) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + t] = contrib;
+    }
+    if (lane == 0) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + NT] = (float)min(64, P.N - blockIdx.x * 64);
+    if (!act) return;
+    GenBase B;
+    B.pos = v3(P.root[e], P.root[N + e], P.root[2 * N + e]);
+    EnvAux ea;
+    ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[N + e]; ea.cmd[2] = P.commands[2 * N + e];
+    ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[N + e]; ea.origin[2] = P.origins[2 * N + e];
+    ea.level = P.levels[e]; ea.type = P.types[e];
+    gen_reset_env(P, T, genv, step, false, B, ea, P.q + e, P.qd + e, N, e);
+    for (int j = 0; j < T.nd; ++j) { P.last_actions[(size_t)j * N + e] = 0.f; P.last_dof_vel[(size_t)j * N + e] = 0.f; }
+    for (int f = 0; f < 2; ++f) { P.air_time[(size_t)f * N + e] = 0.f; P.land_time[(size_t)f * N + e] = 0.f; P.feet_contact[(size_t)f * N + e] = 0; }
+    const float rs[13] = {B.pos.x, B.pos.y, B.pos.z, B.qx, B.qy, B.qz, B.qw, B.vel.x, B.vel.y, B.vel.z, B.ang.x, B.ang.y, B.ang.z};
+    for (int i = 0; i < 13; ++i) P.root[(size_t)i * N + e] = rs[i];
+    P.commands[e] = ea.cmd[0]; P.commands[N + e] = ea.cmd[1]; P.commands[2 * N + e] = ea.cmd[2];
+    P.ep_len[e] = 0;
+    P.reset[e] = 1;
+    for (int t = 0; t < NT; ++t) P.episode_sums[(size_t)t * N + e] = 0.f;
+}

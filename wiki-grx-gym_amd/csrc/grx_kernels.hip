@@ -635,6 +635,8 @@ GRX_DEV void noise_blocks(KP P, uint32_t genv, uint32_t step, int side, U4 nzb[N
     for (int b = 0; b < NZB; ++b) { nzb[b].x = c0[b]; nzb[b].y = c1[b]; nzb[b].z = c2[b]; nzb[b].w = c3[b]; }
 }
 
+#include "grx_generic.h"
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -1383,8 +1385,9 @@ __global__ void grx_set_state_kernel(const KParams* __restrict__ Pg, const float
         float n = sqrtf(qp[0] * qp[0] + qp[1] * qp[1] + qp[2] * qp[2] + qp[3] * qp[3]);
         for (int i = 0; i < 4; ++i) P.root[(3 + i) * N + e] = qp[i] / n;
     }
-    if (q) for (int j = 0; j < GRX_ND; ++j) P.q[j * N + e] = q[(size_t)e * GRX_ND + j];
-    if (qd) for (int j = 0; j < GRX_ND; ++j) P.qd[j * N + e] = qd[(size_t)e * GRX_ND + j];
+    const int nd = P.nd;
+    if (q) for (int j = 0; j < nd; ++j) P.q[j * N + e] = q[(size_t)e * nd + j];
+    if (qd) for (int j = 0; j < nd; ++j) P.qd[j * N + e] = qd[(size_t)e * nd + j];
     for (int i = 0; i < 8; ++i) P.anchors[(size_t)(i * 3 + 2) * N + e] = 0.f;
 }
 
@@ -1398,8 +1401,20 @@ extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, int w
     else { if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
 #undef GRX_LAUNCH_STEP
 }
-extern "C" void grx_launch_finalize(const KParams* dP, int N, int64_t* progress, int64_t ticket, hipStream_t stream) {
-    int nblocks = (N + EPB - 1) / EPB;
+extern "C" void grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int heightfield, const float* actions, float delay,
+                                        long long common_step, const float* noise, hipStream_t stream) {
+    const int nblocks = (N + 63) / 64;
+    const GenTables* T = static_cast<const GenTables*>(tables);
+    if (heightfield) hipLaunchKernelGGL(grx_step_generic<true>, dim3(nblocks), dim3(64), 0, stream, dP, T, ws, actions, delay, common_step, noise);
+    else hipLaunchKernelGGL(grx_step_generic<false>, dim3(nblocks), dim3(64), 0, stream, dP, T, ws, actions, delay, common_step, noise);
+}
+extern "C" void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, uint32_t step, hipStream_t stream) {
+    hipLaunchKernelGGL(grx_reset_all_generic, dim3((N + 63) / 64), dim3(64), 0, stream, dP, static_cast<const GenTables*>(tables), step);
+}
+extern "C" int grx_generic_tables_size(void) { return (int)sizeof(GenTables); }
+extern "C" int grx_generic_ws_floats_per_env(int nb, int nlc) { return nb * WSB + 3 * nlc; }
+// nblocks: rows of the per-block statistics table (fast path: 32 envs per block, generic path: 64)
+extern "C" void grx_launch_finalize(const KParams* dP, int nblocks, int64_t* progress, int64_t ticket, hipStream_t stream) {
     hipLaunchKernelGGL(grx_finalize_stats, dim3(NT + 1), dim3(64), 0, stream, dP, nblocks, progress, ticket);
 }
 extern "C" void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream) {

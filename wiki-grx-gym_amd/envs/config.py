@@ -255,6 +255,7 @@ class GR1T1FullCfg(LeggedRobotFFTAICfg):
         clip_actions_max=_FULL_ACT_MAX + _FULL_SPAN * 0.01, clip_actions_min=_FULL_ACT_MIN - _FULL_SPAN * 0.01)
 
 
+
 class GR1T1FullCfgPPO(LeggedRobotFFTAICfgPPO, GR1T1FullCfg):
     runner_class_name = "OnPolicyRunner"
     runner = section("runner", LeggedRobotFFTAICfgPPO.runner, algorithm_class_name="PPO",
@@ -299,6 +300,17 @@ class GR1T1LowerLimbCfg(GR1T1FullCfg):
         "normalization", GR1T1FullCfg.normalization, actions_max=_LL_ACT_MAX, actions_min=_LL_ACT_MIN,
         clip_observations=100.0, clip_actions_max=_LL_ACT_MAX + np.deg2rad(np.full(10, 30.0)),
         clip_actions_min=_LL_ACT_MIN - np.deg2rad(np.full(10, 30.0)))
+
+
+
+class GR1T1FullBodyCfg(GR1T1FullCfg):
+    """Config 5 of BASELINE.json: the unfixed-upper-body GR1T1 (32 DOF).  The reference ships the config above but no
+    env class whose observation profile matches it (num_obs=121 fits none of its compute_observation_profile
+    variants), so the observation layout here is BUILD-DEFINED, the lower-limb profile (gr1t1.py:281-313) with 32
+    dofs: obs 9 + 3*32 = 105, pri_obs 105 + 3 + 1 + 2 + 2 + 121 = 234.  Runs on the generic-tree kernel."""
+    env = section("env", GR1T1FullCfg.env, num_obs=105, num_pri_obs=234, num_actions=32)
+    rewards = section("rewards", GR1T1FullCfg.rewards,
+                      scales=section("scales", GR1T1FullCfg.rewards.scales, **_LL_SCALES))   # the lower-limb task's reward mix
 
 
 class GR1T1LowerLimbCfgPPO(GR1T1FullCfgPPO, GR1T1LowerLimbCfg):
