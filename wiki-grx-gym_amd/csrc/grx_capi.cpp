@@ -20,9 +20,9 @@ extern "C" {
 void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                      const float* noise, hipStream_t stream);
 void grx_launch_finalize(const KParams* dP, int nblocks, int64_t* progress, int64_t ticket, hipStream_t stream);
-void grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int heightfield, const float* actions, float delay,
+void grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int heightfield, const float* actions, float delay,
                              long long common_step, const float* noise, hipStream_t stream);
-void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, uint32_t step, hipStream_t stream);
+void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, hipStream_t stream);
 int grx_generic_tables_size(void);
 int grx_generic_ws_floats_per_env(int nb, int nlc);
 void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream);
@@ -81,6 +81,7 @@ struct grx_sim {
     void* d_gen = nullptr; // GenTables (device)
     float* d_ws = nullptr; // generic workspace
     int stat_blocks = 0;   // rows of the per-block statistics table the step kernel in use writes
+    int gen_epb = 64;      // generic kernel: envs per (single-wave) block
     KParams hp;            // launch parameters: host image ...
     KParams* d_hp = nullptr;   // ... and the device copy every kernel reads through the constant address space
     KTables tab;           // host image of the device tables
@@ -460,7 +461,8 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(episode_sums, NT * N); DA(reward_terms, NT * N); DA(heights, (size_t)(nh > 0 ? nh : 1) * N);
     DA(obs, (size_t)c.num_obs * N + 64); DA(pri_obs, (size_t)c.num_pri_obs * N + 64);
     const int nblocks = (c.num_envs + grx_envs_per_block() - 1) / grx_envs_per_block();
-    DA(stat_partial, (size_t)nblocks * (NT + 1)); DA(stats, NT + 1); DA(prof, (size_t)nblocks * 32);
+    DA(stat_partial, (size_t)(2 * nblocks + 1) * (NT + 1));   // generic kernel: down to 16 envs per block
+    DA(stats, NT + 1); DA(prof, (size_t)nblocks * 32);
     float* base_mass_com = nullptr;
     rc = dalloc(s, &base_mass_com, 4 * N);
     if (rc) { grx_destroy(s); return rc; }
@@ -615,7 +617,10 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     desc_vec(s, GRX_T_EPISODE_STATS, P.stats, GRX_F32, NT + 1);
     desc_soa3(s, GRX_T_ANCHORS, P.anchors, 8, 3);
     s->prof_host = P.prof; s->prof_blocks = nblocks;
-    s->stat_blocks = generic ? (c.num_envs + 63) / 64 : nblocks;
+    // generic kernel: 64 envs per single-wave block (16 / 32 per block -- more, emptier waves -- measured 15-50 % slower:
+    // narrower rows of the coalesced workspace); GRX_GENERIC_EPB overrides
+    if (const char* ev = getenv("GRX_GENERIC_EPB")) { const int v = atoi(ev); if (v == 16 || v == 32 || v == 64) s->gen_epb = v; }
+    s->stat_blocks = generic ? (c.num_envs + s->gen_epb - 1) / s->gen_epb : nblocks;
     if (generic) {
         rc = build_generic(s, c);
         if (rc) { grx_destroy(s); return rc; }
@@ -655,7 +660,7 @@ int grx_reset_all(grx_handle s, void* stream) {
     // extras["episode"] of a full reset: mean of the running episode sums over all envs
     // (legged_robot.py:420-424); computed by the stats path with every env flagged.
     uint32_t step = 0x80000000u + (s->reset_count++);
-    if (s->generic) grx_launch_reset_all_generic(s->d_hp, s->d_gen, s->N, step, st);
+    if (s->generic) grx_launch_reset_all_generic(s->d_hp, s->d_gen, s->N, s->gen_epb, step, st);
     else grx_launch_reset_all(s->d_hp, s->N, step, st);
     grx_launch_finalize(s->d_hp, s->stat_blocks, s->pace.d_progress, ++s->pace.issued, st);
     HIP_TRY(hipGetLastError());
@@ -686,7 +691,7 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
     }
     const int64_t ticket = ++s->pace.issued;
     if (s->generic)
-        grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
+        grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
                                 (long long)a->common_step_counter, a->noise_uniform, st);
     else
         grx_launch_step(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,

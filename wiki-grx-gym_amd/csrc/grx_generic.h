@@ -329,11 +329,12 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
     KP P = GRX_PARAMS(Pg);
     GT T = *reinterpret_cast<const GRX_AS4 GenTables*>(reinterpret_cast<uintptr_t>(Tg));
     __shared__ float s_stat[NT + 1];
-    const int lane = threadIdx.x;
-    if (lane <= NT) s_stat[lane] = 0.f;
+    // blockDim.x = envs per block (64 by default)
+    const int lane = threadIdx.x, epb = blockDim.x;
+    for (int i = lane; i <= NT; i += epb) s_stat[i] = 0.f;
     __syncthreads();
     const size_t N = (size_t)P.N;
-    const int e_raw = blockIdx.x * 64 + lane;
+    const int e_raw = blockIdx.x * epb + lane;
     const bool act = e_raw < P.N;
     const int e = act ? e_raw : P.N - 1;
     const int nd = T.nd, nb = T.nb;
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
         P.term_contact[e] = term_contact ? 1 : 0;
     }
     __syncthreads();
-    if (lane <= NT) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + lane] = s_stat[lane];
+    for (int i = lane; i <= NT; i += epb) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + i] = s_stat[i];
 }
 
 // BaseTask.reset() first half for the generic path
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(64) void grx_reset_all_generic(const KParams* __res
     KP P = GRX_PARAMS(Pg);
     GT T = *reinterpret_cast<const GRX_AS4 GenTables*>(reinterpret_cast<uintptr_t>(Tg));
     const size_t N = (size_t)P.N;
-    const int lane = threadIdx.x, e_raw = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x, epb = blockDim.x, e_raw = blockIdx.x * epb + lane;
     const bool act = e_raw < P.N;
     const int e = act ? e_raw : P.N - 1;
     const uint32_t genv = (uint32_t)(P.env_offset + e);
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(64) void grx_reset_all_generic(const KParams* __res
         for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off);
         if (lane == 0) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + t] = contrib;
     }
-    if (lane == 0) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + NT] = (float)min(64, P.N - blockIdx.x * 64);
+    if (lane == 0) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + NT] = (float)min(epb, P.N - blockIdx.x * epb);
     if (!act) return;
     GenBase B;
     B.pos = v3(P.root[e], P.root[N + e], P.root[2 * N + e]);

@@ -1401,15 +1401,16 @@ extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, int w
     else { if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
 #undef GRX_LAUNCH_STEP
 }
-extern "C" void grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int heightfield, const float* actions, float delay,
+// epb: envs per block (= threads per block, at most 64)
+extern "C" void grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int heightfield, const float* actions, float delay,
                                         long long common_step, const float* noise, hipStream_t stream) {
-    const int nblocks = (N + 63) / 64;
+    const int nblocks = (N + epb - 1) / epb;
     const GenTables* T = static_cast<const GenTables*>(tables);
-    if (heightfield) hipLaunchKernelGGL(grx_step_generic<true>, dim3(nblocks), dim3(64), 0, stream, dP, T, ws, actions, delay, common_step, noise);
-    else hipLaunchKernelGGL(grx_step_generic<false>, dim3(nblocks), dim3(64), 0, stream, dP, T, ws, actions, delay, common_step, noise);
+    if (heightfield) hipLaunchKernelGGL(grx_step_generic<true>, dim3(nblocks), dim3(epb), 0, stream, dP, T, ws, actions, delay, common_step, noise);
+    else hipLaunchKernelGGL(grx_step_generic<false>, dim3(nblocks), dim3(epb), 0, stream, dP, T, ws, actions, delay, common_step, noise);
 }
-extern "C" void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, uint32_t step, hipStream_t stream) {
-    hipLaunchKernelGGL(grx_reset_all_generic, dim3((N + 63) / 64), dim3(64), 0, stream, dP, static_cast<const GenTables*>(tables), step);
+extern "C" void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, hipStream_t stream) {
+    hipLaunchKernelGGL(grx_reset_all_generic, dim3((N + epb - 1) / epb), dim3(epb), 0, stream, dP, static_cast<const GenTables*>(tables), step);
 }
 extern "C" int grx_generic_tables_size(void) { return (int)sizeof(GenTables); }
 extern "C" int grx_generic_ws_floats_per_env(int nb, int nlc) { return nb * WSB + 3 * nlc; }
