@@ -36,9 +36,10 @@ B_FLAT, B_ROUGH = 1750.0, 2476.0   # algorithmic bytes per env-step (SURVEY.md 8
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-def make_cfg(terrain):
+def make_cfg(terrain, robot="lower_limb"):
     from wiki_grx_gym_amd.envs import config
-    cfg = config.GR1T1Cfg()                       # registered task "GR1T1" = lower-limb config
+    # registered task "GR1T1" = lower-limb config (the headline); --robot full_body = BASELINE.json config 5 (32 DOF)
+    cfg = config.GR1T1Cfg() if robot == "lower_limb" else config.GR1T1FullBodyCfg()
     cfg.terrain.mesh_type = "heightfield" if terrain == "rough" else "plane"
     cfg.terrain.curriculum = True
     return cfg
@@ -74,6 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--terrain", choices=["rough", "flat"], default="rough")
+    ap.add_argument("--robot", choices=["lower_limb", "full_body"], default="lower_limb",
+                    help="full_body: the 32-DOF GR1T1 of BASELINE.json config 5 (generic-tree kernel), not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
@@ -102,14 +105,14 @@ def main():
     seed = 1
     n_local = args.envs_per_gpu
     n_total = n_local * world
-    cfg = make_cfg(args.terrain)
+    cfg = make_cfg(args.terrain, args.robot)
     terrain_obj = Terrain(cfg.terrain, n_total, seed=seed) if args.terrain == "rough" else None
     c, keep, _ = build_config.build(cfg, cfg.sim.dt, n_local, rank * n_local, n_total, seed, terrain_obj)
     os.environ.setdefault("GRX_PUBLISH_DEBUG", "0")   # production path: no per-term debug tensors
     sim = HipSim(c, dev, keep)
     sim.reset_all()
     gen = torch.Generator().manual_seed(rank)
-    pool = [random_actions(cfg, n_local, gen, 1.0).to(dev) for _ in range(16)]   # U[clip_min, clip_max]
+    pool = [random_actions(cfg, n_local, gen, 1.0 if args.robot == "lower_limb" else 0.3).to(dev) for _ in range(16)]   # U[clip_min, clip_max]
     delay = 5.0
     counter = 0
     for _ in range(args.warmup):
@@ -139,12 +142,14 @@ def main():
 
     if rank == 0:
         bytes_per = B_ROUGH if args.terrain == "rough" else B_FLAT
+        if args.robot == "full_body":   # B_full = 3422 B/env-step (+726 of height gathers on rough terrain)
+            bytes_per = 3422.0 + (726.0 if args.terrain == "rough" else 0.0)
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this very workload (separate FETCH_SIZE /
         # WRITE_SIZE runs, tools/collect_profiles.sh); bench.py cannot host the profiler itself.  Raw counter sum:
         # FETCH_SIZE is a lower bound on gfx950 (MI355X_MICROARCH.md), see the note inside the file.
         traffic, traffic_src = None, None
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_rough4096.json")
-        if args.terrain == "rough" and n_local == 4096 and os.path.exists(pmc):
+        if args.robot == "lower_limb" and args.terrain == "rough" and n_local == 4096 and os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 traffic = (j["FETCH_SIZE"]["mean_KB"] + j["WRITE_SIZE"]["mean_KB"]) * 1024.0
@@ -153,7 +158,8 @@ def main():
                 traffic = None
         achieved = bytes_per * n_local / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
-            "metric": "env-steps/sec GR1T1 rough-terrain @4096 envs" if args.terrain == "rough" else "env-steps/sec GR1T1 flat-terrain @4096 envs",
+            "metric": ("env-steps/sec GR1T1 rough-terrain @4096 envs" if args.terrain == "rough" else "env-steps/sec GR1T1 flat-terrain @4096 envs")
+                      + ("" if args.robot == "lower_limb" else " [full-body 32 DOF, config 5]"),
             "value": n_total * args.steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -165,16 +171,17 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"GR1T1 lower-limb (10 DOF), {'rough-terrain curriculum heightfield 10x20 tiles + 121-pt height scan' if args.terrain == 'rough' else 'flat plane'}, "
+            "config": {"workload": f"GR1T1 {'lower-limb (10 DOF)' if args.robot == 'lower_limb' else 'full body (32 DOF, generic-tree kernel)'}, {'rough-terrain curriculum heightfield 10x20 tiles + 121-pt height scan' if args.terrain == 'rough' else 'flat plane'}, "
                                    f"{n_local} envs/GPU, decimation 10 @ dt 0.002, DR+noise+push on, action latency 5 sub-steps, random actions U[clip_min,clip_max]",
                        "envs_per_gpu": n_local, "global_envs": n_total, "parallelism": f"env-sharded x{world} (no data-path collective)",
                        "finite_outputs": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per * n_local,
-                         "kernel": "grx_step_kernel", "kernel_ms": kern_ms, "launches_timed": launches,
+                         "kernel": "grx_step_kernel" if args.robot == "lower_limb" else "grx_step_generic", "kernel_ms": kern_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_env_step": bytes_per,
-                         "note": "instruction-issue bound at this batch size (one wave per SIMD, DESIGN.md sections 4.1 and 5); HBM is the contractual roofline"},
+                         "note": ("instruction-issue bound at this batch size (one wave per SIMD, DESIGN.md sections 4.1 and 5); HBM is the contractual roofline"
+                                  if args.robot == "lower_limb" else "generic-tree kernel: bound by its global-memory workspace round trips (DESIGN.md section 4.3)")},
         }
         if world == 1 and not args.no_cpu_baseline:
             steps = args.cpu_steps

@@ -80,3 +80,19 @@ def test_full_body_rough_terrain_runs_and_is_deterministic():
         if a[k].is_floating_point():
             assert torch.isfinite(a[k]).all(), k
     assert a["PRI_OBS"][:, 113:].abs().sum() > 0     # the height scan is live
+
+
+def test_full_body_task_trains_on_the_gpu(tmp_path):
+    """task_registry.make_env("GR1T1_full_body") -> GR1T1 (HipSim, generic-tree kernel) -> two PPO iterations."""
+    from wiki_grx_gym_amd.envs import GR1T1FullCfgPPO
+    from wiki_grx_gym_amd.utils import get_args, task_registry
+    args = get_args(["--task", "GR1T1_full_body", "--headless", "--num_envs", "256", "--seed", "1"])
+    env, _ = task_registry.make_env("GR1T1_full_body", args=args)
+    assert env.num_actions == 32 and env.obs_buf.is_cuda
+    obs, pri = env.reset()
+    assert obs.shape == (256, 105) and pri.shape == (256, 234)
+    tcfg = GR1T1FullCfgPPO()
+    tcfg.runner.num_steps_per_env = 8
+    runner, _ = task_registry.make_alg_runner(env, name="GR1T1_full_body", args=args, train_cfg=tcfg, log_root=str(tmp_path))
+    runner.learn(num_learning_iterations=2, init_at_random_ep_len=True)
+    assert all(torch.isfinite(p).all() for p in runner.algorithm.actor_critic.parameters())
