@@ -20,8 +20,8 @@ extern "C" {
 void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                      const float* noise, hipStream_t stream);
 void grx_launch_finalize(const KParams* dP, int nblocks, int64_t* progress, int64_t ticket, hipStream_t stream);
-void grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int heightfield, const float* actions, float delay,
-                             long long common_step, const float* noise, hipStream_t stream);
+int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int lds_bytes, int heightfield, const float* actions,
+                            float delay, long long common_step, const float* noise, hipStream_t stream);
 void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, hipStream_t stream);
 int grx_generic_tables_size(void);
 int grx_generic_ws_floats_per_env(int nb, int nlc);
@@ -82,6 +82,7 @@ struct grx_sim {
     float* d_ws = nullptr; // generic workspace
     int stat_blocks = 0;   // rows of the per-block statistics table the step kernel in use writes
     int gen_epb = 64;      // generic kernel: envs per (single-wave) block
+    int gen_lds = 0;       // generic kernel: bytes of dynamic LDS when the workspace lives there (0: global memory)
     KParams hp;            // launch parameters: host image ...
     KParams* d_hp = nullptr;   // ... and the device copy every kernel reads through the constant address space
     KTables tab;           // host image of the device tables
@@ -617,9 +618,18 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     desc_vec(s, GRX_T_EPISODE_STATS, P.stats, GRX_F32, NT + 1);
     desc_soa3(s, GRX_T_ANCHORS, P.anchors, 8, 3);
     s->prof_host = P.prof; s->prof_blocks = nblocks;
-    // generic kernel: 64 envs per single-wave block (16 / 32 per block -- more, emptier waves -- measured 15-50 % slower:
-    // narrower rows of the coalesced workspace); GRX_GENERIC_EPB overrides
-    if (const char* ev = getenv("GRX_GENERIC_EPB")) { const int v = atoi(ev); if (v == 16 || v == 32 || v == 64) s->gen_epb = v; }
+    // generic kernel: the per-body workspace goes to LDS when 16 envs' rows fit (155 KB for the 33-body robot: LDS round
+    // trips are ~5x shorter than global ones and the kernel is bound by exactly those); else 64 envs per block over the
+    // global workspace.  GRX_GENERIC_EPB = 16 / 32 / 64 forces a block size over the GLOBAL workspace (A/B runs).
+    if (generic) {
+        const size_t per_env = (size_t)grx_generic_ws_floats_per_env(m.num_bodies, 24) * sizeof(float);
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+        // one such block fills a CU's LDS, so this only pays while all blocks run in ONE round (<= 16 envs per CU:
+        // 4096 envs on an MI355X; measured 1.9 ms vs 3.2 ms at 4096 envs, but 7.5 ms vs 3.7 ms at 16384)
+        if (per_env * 16 + 1024 <= 159 * 1024 && (c.num_envs + 15) / 16 <= prop.multiProcessorCount) { s->gen_epb = 16; s->gen_lds = (int)(per_env * 16); }
+        if (const char* ev = getenv("GRX_GENERIC_EPB")) { const int v = atoi(ev); if (v == 16 || v == 32 || v == 64) { s->gen_epb = v; s->gen_lds = 0; } }
+    }
     s->stat_blocks = generic ? (c.num_envs + s->gen_epb - 1) / s->gen_epb : nblocks;
     if (generic) {
         rc = build_generic(s, c);
@@ -691,8 +701,11 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
     }
     const int64_t ticket = ++s->pace.issued;
     if (s->generic)
-        grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
-                                (long long)a->common_step_counter, a->noise_uniform, st);
+    {
+        if (grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->gen_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions,
+                                    a->delay_substeps, (long long)a->common_step_counter, a->noise_uniform, st))
+            return fail(GRX_ERR_HIP, "grx_step: cannot raise the dynamic LDS limit of the generic kernel");
+    }
     else
         grx_launch_step(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
                         (long long)a->common_step_counter, a->noise_uniform, st);

@@ -43,15 +43,15 @@ struct GenTables {
 };
 typedef const GRX_AS4 GenTables& GT;
 
-#define WSX(b, slot) ws[((size_t)((b) * WSB + (slot))) * N]
-GRX_DEV V3 ws_v3(const float* ws, size_t N, int b, int slot) { return v3(WSX(b, slot), WSX(b, slot + 1), WSX(b, slot + 2)); }
-GRX_DEV void ws_put(float* ws, size_t N, int b, int slot, V3 x) { WSX(b, slot) = x.x; WSX(b, slot + 1) = x.y; WSX(b, slot + 2) = x.z; }
-GRX_DEV R3 ws_R(const float* ws, size_t N, int b) {
+#define WSX(b, slot) ws[((size_t)((b) * WSB + (slot))) * WN]   // WN: workspace stride (envs per row)
+GRX_DEV V3 ws_v3(const float* ws, size_t WN, int b, int slot) { return v3(WSX(b, slot), WSX(b, slot + 1), WSX(b, slot + 2)); }
+GRX_DEV void ws_put(float* ws, size_t WN, int b, int slot, V3 x) { WSX(b, slot) = x.x; WSX(b, slot + 1) = x.y; WSX(b, slot + 2) = x.z; }
+GRX_DEV R3 ws_R(const float* ws, size_t WN, int b) {
     R3 R;
-    R.cx = ws_v3(ws, N, b, W_R); R.cy = ws_v3(ws, N, b, W_R + 3); R.cz = ws_v3(ws, N, b, W_R + 6);
+    R.cx = ws_v3(ws, WN, b, W_R); R.cy = ws_v3(ws, WN, b, W_R + 3); R.cz = ws_v3(ws, WN, b, W_R + 6);
     return R;
 }
-GRX_DEV void ws_putR(float* ws, size_t N, int b, const R3& R) { ws_put(ws, N, b, W_R, R.cx); ws_put(ws, N, b, W_R + 3, R.cy); ws_put(ws, N, b, W_R + 6, R.cz); }
+GRX_DEV void ws_putR(float* ws, size_t WN, int b, const R3& R) { ws_put(ws, WN, b, W_R, R.cx); ws_put(ws, WN, b, W_R + 3, R.cy); ws_put(ws, WN, b, W_R + 6, R.cz); }
 
 // child rotation: R_parent * rot0 * Rot(axis, q) for a unit axis in the child frame (columns = body axes in the world)
 GRX_DEV R3 gen_joint_rot(const R3& Rp, GT T, int b, float q) {
@@ -74,7 +74,7 @@ GRX_DEV R3 gen_joint_rot(const R3& Rp, GT T, int b, float q) {
 
 // one sphere of body `b` against the terrain with a run-time anchor slot; adds its force into the link accumulator
 template <bool HF>
-GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu, float hmax, float* ws, size_t N, int e,
+GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu, float hmax, float* ws, size_t WN, size_t N, int e,
                       int lfbase, V3& xr) {
     xr = rho + rot(R, v3(T.sx[i], T.sy[i], T.sz[i]));
     V3 F = v3(0.f, 0.f, 0.f);
@@ -115,53 +115,56 @@ GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, 
     }
     if (slot >= 0) P.anchors[(size_t)(slot * 3 + 2) * N + e] = touching ? 1.f : 0.f;
     const int L = T.slink[i];
-    ws[(size_t)(lfbase + L * 3 + 0) * N] += F.x; ws[(size_t)(lfbase + L * 3 + 1) * N] += F.y; ws[(size_t)(lfbase + L * 3 + 2) * N] += F.z;
+    ws[(size_t)(lfbase + L * 3 + 0) * WN] += F.x; ws[(size_t)(lfbase + L * 3 + 1) * WN] += F.y; ws[(size_t)(lfbase + L * 3 + 2) * WN] += F.z;
     return F;
 }
 
 struct GenBase { V3 pos, vel, ang; float qx, qy, qz, qw; };
 
 // foot link frames of the CURRENT state (positions walk only, up to the two foot bodies)
-GRX_DEV void gen_foot_frames(KP P, GT T, const GenBase& B, const float* q, const float* qd, float* ws, size_t N, int e, V3 fpos[2], V3 fvel[2]) {
-    ws_putR(ws, N, 0, quat_to_R(B.qx, B.qy, B.qz, B.qw));
-    ws_put(ws, N, 0, W_RHO, v3(0.f, 0.f, 0.f)); ws_put(ws, N, 0, W_W, B.ang); ws_put(ws, N, 0, W_V, B.vel);
+GRX_DEV void gen_foot_frames(KP P, GT T, const GenBase& B, const float* q, const float* qd, float* ws, size_t WN, size_t N, int e, V3 fpos[2], V3 fvel[2]) {
+    ws_putR(ws, WN, 0, quat_to_R(B.qx, B.qy, B.qz, B.qw));
+    ws_put(ws, WN, 0, W_RHO, v3(0.f, 0.f, 0.f)); ws_put(ws, WN, 0, W_W, B.ang); ws_put(ws, WN, 0, W_V, B.vel);
     for (int b = 1; b < T.nb; ++b) {
         const int p = T.parent[b];
-        const R3 Rp = ws_R(ws, N, p);
-        const V3 rho = ws_v3(ws, N, p, W_RHO) + rot(Rp, v3(T.jpos[b][0], T.jpos[b][1], T.jpos[b][2]));
+        const R3 Rp = ws_R(ws, WN, p);
+        const V3 rho = ws_v3(ws, WN, p, W_RHO) + rot(Rp, v3(T.jpos[b][0], T.jpos[b][1], T.jpos[b][2]));
         const R3 R = gen_joint_rot(Rp, T, b, q[(size_t)(b - 1) * N]);
         const V3 a = rot(R, v3(T.axis[b][0], T.axis[b][1], T.axis[b][2]));
         const float qdk = qd[(size_t)(b - 1) * N];
-        const V3 wp = ws_v3(ws, N, p, W_W), vp = ws_v3(ws, N, p, W_V);
-        ws_putR(ws, N, b, R); ws_put(ws, N, b, W_RHO, rho);
-        ws_put(ws, N, b, W_W, fma3(a, qdk, wp)); ws_put(ws, N, b, W_V, fma3(cross(rho, a), qdk, vp));
+        const V3 wp = ws_v3(ws, WN, p, W_W), vp = ws_v3(ws, WN, p, W_V);
+        ws_putR(ws, WN, b, R); ws_put(ws, WN, b, W_RHO, rho);
+        ws_put(ws, WN, b, W_W, fma3(a, qdk, wp)); ws_put(ws, WN, b, W_V, fma3(cross(rho, a), qdk, vp));
     }
     for (int f = 0; f < 2; ++f) {
         const int b = T.foot_body[f];
-        const R3 R = ws_R(ws, N, b);
-        const V3 fr = ws_v3(ws, N, b, W_RHO) + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
+        const R3 R = ws_R(ws, WN, b);
+        const V3 fr = ws_v3(ws, WN, b, W_RHO) + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
         fpos[f] = B.pos + fr;
-        fvel[f] = ws_v3(ws, N, b, W_V) + cross(ws_v3(ws, N, b, W_W), fr);
+        fvel[f] = ws_v3(ws, WN, b, W_V) + cross(ws_v3(ws, WN, b, W_W), fr);
     }
 }
 
 // One physics sub-step.  q / qd / torques: this env's columns of the SoA state arrays (stride N).
 template <bool HF>
-GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const float* tau, float* ws, size_t N, int e,
+GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const float* tau, float* ws, size_t WN, size_t N, int e,
                          float base_m, V3 base_c, const S3& base_I, float mu, float hmax, V3 foot_vel_before[2]) {
     const int nb = T.nb, lfbase = nb * WSB;
     const float dt = P.sim_dt;
     const R3 R0 = quat_to_R(B.qx, B.qy, B.qz, B.qw);
     const V3 O = B.pos;
-    for (int i = 0; i < T.nlc * 3; ++i) ws[(size_t)(lfbase + i) * N] = 0.f;
+    for (int i = 0; i < T.nlc * 3; ++i) ws[(size_t)(lfbase + i) * WN] = 0.f;
     // ---- pass 1 (root -> leaves): frames, joint axes, velocity-product accelerations, rigid inertias, bias, contacts
-    ws_putR(ws, N, 0, R0);
-    ws_put(ws, N, 0, W_RHO, v3(0.f, 0.f, 0.f)); ws_put(ws, N, 0, W_W, B.ang); ws_put(ws, N, 0, W_V, B.vel);
+    ws_putR(ws, WN, 0, R0);
+    ws_put(ws, WN, 0, W_RHO, v3(0.f, 0.f, 0.f)); ws_put(ws, WN, 0, W_W, B.ang); ws_put(ws, WN, 0, W_V, B.vel);
+    R3 Rprev = R0;                       // frame of body b-1: most bodies hang from their predecessor (chains), which
+    V3 rho_prev = v3(0.f, 0.f, 0.f), w_prev = B.ang, v_prev = B.vel;   // then never has to be read back from the workspace
     for (int b = 1; b < nb; ++b) {
         const int p = T.parent[b];
-        const R3 Rp = ws_R(ws, N, p);
-        const V3 wp = ws_v3(ws, N, p, W_W), vp = ws_v3(ws, N, p, W_V);
-        const V3 rho = ws_v3(ws, N, p, W_RHO) + rot(Rp, v3(T.jpos[b][0], T.jpos[b][1], T.jpos[b][2]));
+        const bool chain = p == b - 1;
+        const R3 Rp = chain ? Rprev : ws_R(ws, WN, p);
+        const V3 wp = chain ? w_prev : ws_v3(ws, WN, p, W_W), vp = chain ? v_prev : ws_v3(ws, WN, p, W_V);
+        const V3 rho = (chain ? rho_prev : ws_v3(ws, WN, p, W_RHO)) + rot(Rp, v3(T.jpos[b][0], T.jpos[b][1], T.jpos[b][2]));
         const R3 R = gen_joint_rot(Rp, T, b, q[(size_t)(b - 1) * N]);
         const V3 a = rot(R, v3(T.axis[b][0], T.axis[b][1], T.axis[b][2]));
         const V3 s = cross(rho, a);
@@ -178,7 +181,7 @@ GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const floa
         rigid_bias(R, kap, m, Ic, w, v, pa, pl);
         for (int i = T.sph_begin[b]; i < T.sph_begin[b + 1]; ++i) {
             V3 xr;
-            const V3 F = gen_sphere<HF>(P, T, i, R, rho, w, v, O, mu, hmax, ws, N, e, lfbase, xr);
+            const V3 F = gen_sphere<HF>(P, T, i, R, rho, w, v, O, mu, hmax, ws, WN, N, e, lfbase, xr);
             pa = pa - cross(xr, F); pl = pl - F;
         }
         for (int f = 0; f < 2; ++f)
@@ -186,13 +189,14 @@ GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const floa
                 const V3 fr = rho + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
                 foot_vel_before[f] = v + cross(w, fr);
             }
-        ws_putR(ws, N, b, R); ws_put(ws, N, b, W_RHO, rho); ws_put(ws, N, b, W_W, w); ws_put(ws, N, b, W_V, v);
-        ws_put(ws, N, b, W_A, a); ws_put(ws, N, b, W_S, s); ws_put(ws, N, b, W_CA, ca); ws_put(ws, N, b, W_CL, cl);
+        ws_putR(ws, WN, b, R); ws_put(ws, WN, b, W_RHO, rho); ws_put(ws, WN, b, W_W, w); ws_put(ws, WN, b, W_V, v);
+        Rprev = R; rho_prev = rho; w_prev = w; v_prev = v;
+        ws_put(ws, WN, b, W_A, a); ws_put(ws, WN, b, W_S, s); ws_put(ws, WN, b, W_CA, ca); ws_put(ws, WN, b, W_CL, cl);
         WSX(b, W_IA + 0) = Ak.xx; WSX(b, W_IA + 1) = Ak.xy; WSX(b, W_IA + 2) = Ak.xz; WSX(b, W_IA + 3) = Ak.yy; WSX(b, W_IA + 4) = Ak.yz; WSX(b, W_IA + 5) = Ak.zz;
         WSX(b, W_IB + 0) = 0.f; WSX(b, W_IB + 1) = -h.z; WSX(b, W_IB + 2) = h.y; WSX(b, W_IB + 3) = h.z; WSX(b, W_IB + 4) = 0.f;
         WSX(b, W_IB + 5) = -h.x; WSX(b, W_IB + 6) = -h.y; WSX(b, W_IB + 7) = h.x; WSX(b, W_IB + 8) = 0.f;
         WSX(b, W_ID + 0) = m; WSX(b, W_ID + 1) = 0.f; WSX(b, W_ID + 2) = 0.f; WSX(b, W_ID + 3) = m; WSX(b, W_ID + 4) = 0.f; WSX(b, W_ID + 5) = m;
-        ws_put(ws, N, b, W_PA, pa); ws_put(ws, N, b, W_PL, pl);
+        ws_put(ws, WN, b, W_PA, pa); ws_put(ws, WN, b, W_PL, pl);
     }
     // base: rigid lump (randomised per env) + its contacts
     S3 A0; V3 h0;
@@ -201,19 +205,25 @@ GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const floa
     rigid_bias(R0, rot(R0, base_c), base_m, base_I, B.ang, B.vel, pa0, pl0);
     for (int i = T.sph_begin[0]; i < T.sph_begin[1]; ++i) {
         V3 xr;
-        const V3 F = gen_sphere<HF>(P, T, i, R0, v3(0.f, 0.f, 0.f), B.ang, B.vel, O, mu, hmax, ws, N, e, lfbase, xr);
+        const V3 F = gen_sphere<HF>(P, T, i, R0, v3(0.f, 0.f, 0.f), B.ang, B.vel, O, mu, hmax, ws, WN, N, e, lfbase, xr);
         pa0 = pa0 - cross(xr, F); pl0 = pl0 - F;
     }
     S3 Ab = A0, Db = {base_m, 0.f, 0.f, base_m, 0.f, base_m};
     M3 Bb = {0.f, -h0.z, h0.y, h0.z, 0.f, -h0.x, -h0.y, h0.x, 0.f};
     // ---- pass 2 (leaves -> root): articulated inertias and bias forces; a child adds into its parent
+    int carry_to = -1;                   // a chain child (parent == b-1, processed next) hands its contribution on in registers
+    S3 cA = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cD = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    M3 cB = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    V3 cpa = v3(0.f, 0.f, 0.f), cpl = v3(0.f, 0.f, 0.f);
     for (int b = nb - 1; b >= 1; --b) {
         const int p = T.parent[b], j = b - 1;
         S3 A = {WSX(b, W_IA), WSX(b, W_IA + 1), WSX(b, W_IA + 2), WSX(b, W_IA + 3), WSX(b, W_IA + 4), WSX(b, W_IA + 5)};
         M3 Bm = {WSX(b, W_IB), WSX(b, W_IB + 1), WSX(b, W_IB + 2), WSX(b, W_IB + 3), WSX(b, W_IB + 4), WSX(b, W_IB + 5), WSX(b, W_IB + 6), WSX(b, W_IB + 7), WSX(b, W_IB + 8)};
         S3 D = {WSX(b, W_ID), WSX(b, W_ID + 1), WSX(b, W_ID + 2), WSX(b, W_ID + 3), WSX(b, W_ID + 4), WSX(b, W_ID + 5)};
-        const V3 a = ws_v3(ws, N, b, W_A), s = ws_v3(ws, N, b, W_S), ca = ws_v3(ws, N, b, W_CA), cl = ws_v3(ws, N, b, W_CL);
-        const V3 pa = ws_v3(ws, N, b, W_PA), pl = ws_v3(ws, N, b, W_PL);
+        const V3 a = ws_v3(ws, WN, b, W_A), s = ws_v3(ws, WN, b, W_S), ca = ws_v3(ws, WN, b, W_CA), cl = ws_v3(ws, WN, b, W_CL);
+        V3 pa = ws_v3(ws, WN, b, W_PA), pl = ws_v3(ws, WN, b, W_PL);
+        if (carry_to == b) { A = A + cA; Bm = Bm + cB; D = D + cD; pa = pa + cpa; pl = pl + cpl; }
+        carry_to = -1;
         const V3 ua = mul(A, a) + mul(Bm, s);
         const V3 ul = mulT(Bm, a) + mul(D, s);
         const float di = grx_rcp(dot(a, ua) + dot(s, ul));
@@ -226,9 +236,11 @@ GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const floa
         const float ud = u * di;
         const V3 npa = pa + mul(A, ca) + mul(Bm, cl) + ua * ud;
         const V3 npl = pl + mulT(Bm, ca) + mul(D, cl) + ul * ud;
-        ws_put(ws, N, b, W_UA, ua); ws_put(ws, N, b, W_UL, ul); WSX(b, W_DI) = di; WSX(b, W_U) = u;
+        ws_put(ws, WN, b, W_UA, ua); ws_put(ws, WN, b, W_UL, ul); WSX(b, W_DI) = di; WSX(b, W_U) = u;
         if (p == 0) {
             Ab = Ab + A; Bb = Bb + Bm; Db = Db + D; pa0 = pa0 + npa; pl0 = pl0 + npl;
+        } else if (p == b - 1) {
+            carry_to = p; cA = A; cB = Bm; cD = D; cpa = npa; cpl = npl;
         } else {
             WSX(p, W_IA) += A.xx; WSX(p, W_IA + 1) += A.xy; WSX(p, W_IA + 2) += A.xz; WSX(p, W_IA + 3) += A.yy; WSX(p, W_IA + 4) += A.yz; WSX(p, W_IA + 5) += A.zz;
             WSX(p, W_IB) += Bm.a00; WSX(p, W_IB + 1) += Bm.a01; WSX(p, W_IB + 2) += Bm.a02; WSX(p, W_IB + 3) += Bm.a10; WSX(p, W_IB + 4) += Bm.a11;
@@ -246,13 +258,16 @@ GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const floa
     const V3 alpha = mul(inv(Sc), mul(Bb, mul(Di, pl0)) - pa0);
     const V3 acc = neg(mul(Di, pl0 + mulT(Bb, alpha)));
     // ---- pass 3 (root -> leaves): accelerations, joint integration
-    ws_put(ws, N, 0, W_AA, alpha); ws_put(ws, N, 0, W_AL, acc);
+    ws_put(ws, WN, 0, W_AA, alpha); ws_put(ws, WN, 0, W_AL, acc);
+    V3 aa_prev = alpha, al_prev = acc;
     for (int b = 1; b < nb; ++b) {
         const int p = T.parent[b], j = b - 1;
-        const V3 a = ws_v3(ws, N, b, W_A), s = ws_v3(ws, N, b, W_S);
-        const V3 pa_ = ws_v3(ws, N, p, W_AA) + ws_v3(ws, N, b, W_CA), pl_ = ws_v3(ws, N, p, W_AL) + ws_v3(ws, N, b, W_CL);
-        const float qdd = (WSX(b, W_U) - (dot(ws_v3(ws, N, b, W_UA), pa_) + dot(ws_v3(ws, N, b, W_UL), pl_))) * WSX(b, W_DI);
-        ws_put(ws, N, b, W_AA, fma3(a, qdd, pa_)); ws_put(ws, N, b, W_AL, fma3(s, qdd, pl_));
+        const bool chain = p == b - 1;
+        const V3 a = ws_v3(ws, WN, b, W_A), s = ws_v3(ws, WN, b, W_S);
+        const V3 pa_ = (chain ? aa_prev : ws_v3(ws, WN, p, W_AA)) + ws_v3(ws, WN, b, W_CA), pl_ = (chain ? al_prev : ws_v3(ws, WN, p, W_AL)) + ws_v3(ws, WN, b, W_CL);
+        const float qdd = (WSX(b, W_U) - (dot(ws_v3(ws, WN, b, W_UA), pa_) + dot(ws_v3(ws, WN, b, W_UL), pl_))) * WSX(b, W_DI);
+        aa_prev = fma3(a, qdd, pa_); al_prev = fma3(s, qdd, pl_);
+        ws_put(ws, WN, b, W_AA, aa_prev); ws_put(ws, WN, b, W_AL, al_prev);
         float vq = fmaf(qdd, dt, qd[(size_t)j * N]);
         vq = fminf(fmaxf(vq, -T.vlim[j]), T.vlim[j]);
         qd[(size_t)j * N] = vq;
@@ -341,7 +356,11 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
     const uint32_t genv = (uint32_t)(P.env_offset + e), step = (uint32_t)common_step;
     const int nh = P.nh, nobs = 9 + 3 * nd, npri = P.num_pri_obs;
     const float dtp = P.sim_dt * (float)P.decimation;
-    float* ws = wsg + e;   // this env's column of the [slot][env] workspace
+    // workspace: LDS when the block's rows fit (blockDim.x <= 16 envs for the 33-body robot: 155 KB), else global memory
+    extern __shared__ float s_ws[];
+    const bool lds_ws = wsg == nullptr;
+    float* ws = lds_ws ? s_ws + lane : wsg + e;   // this env's column of the [slot][env] workspace
+    const size_t WN = lds_ws ? (size_t)epb : N;
     float* q = P.q + e; float* qd = P.qd + e;
     float* a_cur = P.actions + e; float* a_last = P.last_actions + e; float* qd_last = P.last_dof_vel + e; float* tau = P.torques + e;
     const float* strength = P.motor_strength + e;
@@ -387,29 +406,29 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
             t *= strength[(size_t)j * N];
             tau[(size_t)j * N] = fminf(fmaxf(t, -T.effort[j]), T.effort[j]);
         }
-        gen_substep<HF>(P, T, B, q, qd, tau, ws, N, e, base_m, base_c, base_I, mu, hmax, fvel);
+        gen_substep<HF>(P, T, B, q, qd, tau, ws, WN, N, e, base_m, base_c, base_I, mu, hmax, fvel);
         if (deci > 0)
             for (int f = 0; f < 2; ++f) avg_speed[f] = v3(avg_speed[f].x + fabsf(fvel[f].x), avg_speed[f].y + fabsf(fvel[f].y), avg_speed[f].z + fabsf(fvel[f].z));
         for (int f = 0; f < 2; ++f) {
             const int L = T.foot_link[f];
-            const V3 F = v3(ws[(size_t)(lfbase + L * 3) * N], ws[(size_t)(lfbase + L * 3 + 1) * N], ws[(size_t)(lfbase + L * 3 + 2) * N]);
+            const V3 F = v3(ws[(size_t)(lfbase + L * 3) * WN], ws[(size_t)(lfbase + L * 3 + 1) * WN], ws[(size_t)(lfbase + L * 3 + 2) * WN]);
             avg_force[f] += grx_sqrt(dot(F, F));
         }
     }
-    gen_foot_frames(P, T, B, q, qd, ws, N, e, fpos, fvel);   // refresh_rigid_body_state_tensor after the last sub-step
+    gen_foot_frames(P, T, B, q, qd, ws, WN, N, e, fpos, fvel);   // refresh_rigid_body_state_tensor after the last sub-step
     V3 foot_force[2];
     for (int f = 0; f < 2; ++f) {
         avg_speed[f] = v3((avg_speed[f].x + fabsf(fvel[f].x)) / (float)P.decimation, (avg_speed[f].y + fabsf(fvel[f].y)) / (float)P.decimation,
                           (avg_speed[f].z + fabsf(fvel[f].z)) / (float)P.decimation);
         avg_force[f] /= (float)P.decimation;
         const int L = T.foot_link[f];
-        foot_force[f] = v3(ws[(size_t)(lfbase + L * 3) * N], ws[(size_t)(lfbase + L * 3 + 1) * N], ws[(size_t)(lfbase + L * 3 + 2) * N]);
+        foot_force[f] = v3(ws[(size_t)(lfbase + L * 3) * WN], ws[(size_t)(lfbase + L * 3 + 1) * WN], ws[(size_t)(lfbase + L * 3 + 2) * WN]);
     }
     // termination / collision from the per-link net forces of the LAST sub-step (legged_robot.py:336-353)
     bool term_contact = false;
     float pen_count = 0.f;
     for (int L = 0; L < T.nlc; ++L) {
-        const V3 F = v3(ws[(size_t)(lfbase + L * 3) * N], ws[(size_t)(lfbase + L * 3 + 1) * N], ws[(size_t)(lfbase + L * 3 + 2) * N]);
+        const V3 F = v3(ws[(size_t)(lfbase + L * 3) * WN], ws[(size_t)(lfbase + L * 3 + 1) * WN], ws[(size_t)(lfbase + L * 3 + 2) * WN]);
         const float n2 = dot(F, F);
         if ((T.link_flags[L] & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term_contact = true;
         if ((T.link_flags[L] & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.f;
@@ -417,12 +436,12 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
     // torso / forehead orientation (frames of the final state are in the workspace)
     float torso_g[2] = {0.f, 0.f}, fore_g[2] = {0.f, 0.f};
     if (T.torso_body >= 0) {
-        const R3 R = ws_R(ws, N, T.torso_body);
+        const R3 R = ws_R(ws, WN, T.torso_body);
         torso_g[0] = -(R.cx.z * T.torso_rot[0] + R.cy.z * T.torso_rot[3] + R.cz.z * T.torso_rot[6]);
         torso_g[1] = -(R.cx.z * T.torso_rot[1] + R.cy.z * T.torso_rot[4] + R.cz.z * T.torso_rot[7]);
     }
     if (T.forehead_body >= 0) {
-        const R3 R = ws_R(ws, N, T.forehead_body);
+        const R3 R = ws_R(ws, WN, T.forehead_body);
         fore_g[0] = -(R.cx.z * T.forehead_rot[0] + R.cy.z * T.forehead_rot[3] + R.cz.z * T.forehead_rot[6]);
         fore_g[1] = -(R.cx.z * T.forehead_rot[1] + R.cy.z * T.forehead_rot[4] + R.cz.z * T.forehead_rot[7]);
     }

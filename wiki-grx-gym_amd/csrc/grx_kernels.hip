@@ -1401,13 +1401,23 @@ extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, int w
     else { if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
 #undef GRX_LAUNCH_STEP
 }
-// epb: envs per block (= threads per block, at most 64)
-extern "C" void grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int heightfield, const float* actions, float delay,
-                                        long long common_step, const float* noise, hipStream_t stream) {
+// epb: envs per block (= threads per block, at most 64); lds_bytes > 0: the per-body workspace lives in (dynamic) LDS
+extern "C" int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int lds_bytes, int heightfield,
+                                       const float* actions, float delay, long long common_step, const float* noise, hipStream_t stream) {
     const int nblocks = (N + epb - 1) / epb;
     const GenTables* T = static_cast<const GenTables*>(tables);
-    if (heightfield) hipLaunchKernelGGL(grx_step_generic<true>, dim3(nblocks), dim3(epb), 0, stream, dP, T, ws, actions, delay, common_step, noise);
-    else hipLaunchKernelGGL(grx_step_generic<false>, dim3(nblocks), dim3(epb), 0, stream, dP, T, ws, actions, delay, common_step, noise);
+    if (lds_bytes > 0) {
+        static bool raised = false;
+        if (!raised) {   // > 64 KB of dynamic LDS needs the opt-in
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_generic<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_generic<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
+            raised = true;
+        }
+        ws = nullptr;
+    }
+    if (heightfield) hipLaunchKernelGGL(grx_step_generic<true>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise);
+    else hipLaunchKernelGGL(grx_step_generic<false>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise);
+    return 0;
 }
 extern "C" void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, hipStream_t stream) {
     hipLaunchKernelGGL(grx_reset_all_generic, dim3((N + epb - 1) / epb), dim3(epb), 0, stream, dP, static_cast<const GenTables*>(tables), step);
