@@ -25,6 +25,8 @@ for terrain in ("plane","heightfield"):
     a=full[:,:11]
     print('   substep sections (sum over 10 substeps):', dict(zip(['pass1+chain contacts','base spheres','pass2','base solve','pass3','integrate'], np.median(full[:,16:22],axis=0).astype(int).tolist())))
     print('   helper waves (idle waiting for state, total) cycles:', {f"wave{w}": np.median(full[:,22+2*w:24+2*w],axis=0).astype(int).tolist() for w in (1,2,3)})
+    print('   obs sub-sections (cycles after tick 7): heights, noise load, side-0 puts:', np.median(full[:,11:14]-full[:,7:8],axis=0).astype(int).tolist())
+    print('   relative to tick 6 (FL_REW published): wave1 got FL_REW, wave1 rewards done, wave2 got FL_HZ, wave2 heights done, wave0 tick 9:', np.median(full[:,[14,15,30,31,9]]-full[:,6:7],axis=0).astype(int).tolist())
     d=np.diff(a,axis=1)
     print(terrain, "total cycles median", np.median(a[:,10]-a[:,0]))
     for n,v in zip(names, np.median(d,axis=0)): print(f"   {n:16s} {v:9.0f} ticks")

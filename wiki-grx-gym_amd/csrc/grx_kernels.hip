@@ -41,10 +41,12 @@ typedef const GRX_AS4 KParams& KP;
 #ifdef GRX_PROFILE_SECTIONS
 #define GRX_TICK(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); if (threadIdx.x == 0) P.prof[(size_t)blockIdx.x * 32 + (i)] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 // sub-step sections accumulate in registers (g_tacc is a kernel-scope local); sched_barrier pins the code motion
+#define GRX_TICKW(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); if ((threadIdx.x & 63) == 0) P.prof[(size_t)blockIdx.x * 32 + (i)] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define GRX_TICK2(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); tacc[(i) - 16] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define GRX_TICK2(i) do {} while (0)
 #define GRX_TICK(i) do {} while (0)
+#define GRX_TICKW(i) do {} while (0)
 #endif
 
 namespace {
@@ -599,6 +601,36 @@ GRX_DEV float height_scan_share(KP P, const KTables& T, float zn, float wn, V3 p
     return hsum;
 }
 
+// LDS row stride of the pri_obs staging rows: 2 x odd, so that the two lanes of an env (adjacent columns) and the
+// 32 envs of a wave land in 64 distinct banks (the natural stride, 168 = 8 x 21, is a 4-way conflict on every access).
+constexpr int PRS = GRX_MAX_PRI + 2;
+static_assert(PRS % 2 == 0 && (PRS / 2) % 2 == 1, "PRS must be 2 x odd");
+
+// compute_observations' height block (legged_robot.py:449-451 -> gr1t1.py:305-313): one lane's share of an env's
+// points, k = first, first + NL, ...: raw height (parked in the staging row by the scan) -> clipped, scaled offset,
+// written back in place; returns the lane's partial sum of the clipped offsets (base_heights_offset numerator).
+template <int NL>
+GRX_DEV float obs_heights_share(KP P, float posz, int first, int nh, float* prow, bool have_raw, bool act, int e, int N) {
+    float sum = 0.f;
+    for (int k0 = first; k0 < nh; k0 += 8 * NL) {   // batches of 8: one exposed LDS latency per batch, not per point
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = have_raw ? prow[GRX_NUM_OBS + 8 + min(k0 + NL * j, nh - 1)] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + NL * j;
+            if (k < nh) {
+                float d = posz - P.base_height_target - hv[j];
+                d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
+                if (P.publish_debug && act) P.heights[(size_t)k * N + e] = hv[j];
+                prow[GRX_NUM_OBS + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -P.clip_observations), P.clip_observations);
+                sum += d;
+            }
+        }
+    }
+    return sum;
+}
+
 GRX_DEV float sum_abs_mask(const float a[LEG], uint32_t mask) {
     float s = 0.f;
 #pragma unroll
@@ -663,18 +695,42 @@ GRX_DEV void rewin_fields(RewIn& r, F&& f) {
     f(r.bho_stale); f(r.qx); f(r.qy); f(r.qz); f(r.qw); f(r.pen_count); f(r.reset); f(r.time_out);
 }
 
+// Which reward terms a call of reward_and_sums owns.  PART 0: all of them (one wave).  With four waves per block the
+// terms are split over two helper waves: PART 1 = the joint-space terms (action differences, dof acc / torque /
+// velocity, limits, pose), PART 2 = the base, feet, collision and termination terms.
+template <int PART>
+__host__ __device__ constexpr bool rew_in_part(int t) {
+    if (PART == 0) return true;
+    const bool joint = t == GRX_REW_ACTION_DIFF || t == GRX_REW_ACTION_DIFF_DIFF || t == GRX_REW_ACTION_DIFF_KNEE ||
+                       t == GRX_REW_DOF_ACC_NEW || t == GRX_REW_DOF_TOR_NEW || t == GRX_REW_DOF_TOR_NEW_HIP_ROLL ||
+                       t == GRX_REW_DOF_VEL_NEW || t == GRX_REW_DOF_VEL_NEW_KNEE || t == GRX_REW_LIMITS_ACTIONS ||
+                       t == GRX_REW_LIMITS_DOF_POS || t == GRX_REW_LIMITS_DOF_TOR || t == GRX_REW_LIMITS_DOF_VEL ||
+                       t == GRX_REW_POSE_OFFSET || t == GRX_REW_POSE_OFFSET_HIP_YAW || t == GRX_REW_STAND_STILL;
+    return PART == 1 ? joint : !joint;
+}
+
+// the env's running episode sums of the terms a part owns (issued early so the HBM latency overlaps other work)
+template <int PART>
+GRX_DEV void load_episode_sums(KP P, int e, int N, float es[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) es[t] = (rew_in_part<PART>(t) && P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
+}
+
 // compute_reward (legged_robot.py:355-375) + episode sums + the block's finished-episode statistics for one lane.
-// Runs on wave 0, or -- four waves per block -- on wave 1 while wave 0 goes on with reset and observations.
-// es_pre: the env's running episode sums if the caller loaded them early (their HBM latency then overlaps the state
-// update), else nullptr.
+// Runs on wave 0 (PART 0), or -- four waves per block -- as PART 1 on wave 1 and PART 2 on wave 3 while wave 0 goes on
+// with reset and observations: PART 2 parks its partial reward in *rew_part and raises rew_flag, PART 1 adds it,
+// clips, adds the termination term and writes rew_buf.
+// es_pre: the env's running episode sums if the caller loaded them early, else nullptr.
+template <int PART>
 GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane, int side, int e, int N, bool act,
-                             float* s_stat, const float* es_pre) {
+                             float* s_stat, const float* es_pre, float* rew_part = nullptr, int* rew_flag = nullptr) {
     const int j0 = side * LEG;
     const float dtp = P.sim_dt * (float)P.decimation;
     const bool reset = in.reset != 0.f, time_out = in.time_out != 0.f;
     float es_raw[NT];   // running episode sums
 #pragma unroll
-    for (int t = 0; t < NT; ++t) es_raw[t] = es_pre ? es_pre[t] : ((P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f);
+    for (int t = 0; t < NT; ++t)
+        es_raw[t] = !rew_in_part<PART>(t) ? 0.f : (es_pre ? es_pre[t] : ((P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f));
     // ---- compute_reward (legged_robot.py:355-375): per-lane partial sums, pair-combined
     float r[NT];
     {
@@ -778,16 +834,19 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
     const bool writer = act && side == 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        float sc_t = P.reward_scale_dt[t];
         float rt = 0.f;
-        if (t != GRX_REW_TERMINATION && sc_t != 0.f) { rt = r[t] * sc_t; rew += rt; }
+        if (rew_in_part<PART>(t)) {
+            float sc_t = P.reward_scale_dt[t];
+            if (t != GRX_REW_TERMINATION && sc_t != 0.f) { rt = r[t] * sc_t; rew += rt; }
+        }
         r[t] = rt;
     }
-    if (P.only_positive_rewards) rew = fmaxf(rew, 0.f);
-    if (P.reward_scale_dt[GRX_REW_TERMINATION] != 0.f) {
-        float rt = r[GRX_REW_TERMINATION] = ((reset && !time_out) ? 1.f : 0.f) * P.reward_scale_dt[GRX_REW_TERMINATION];
-        rew += rt;
+    if (PART == 2) {   // partial reward -> the PART 1 wave
+        rew_part[lane] = rew;
+        flag_set(rew_flag, 1, lane);
     }
+    const float term_rt = ((reset && !time_out) ? 1.f : 0.f) * P.reward_scale_dt[GRX_REW_TERMINATION];
+    if (rew_in_part<PART>(GRX_REW_TERMINATION) && P.reward_scale_dt[GRX_REW_TERMINATION] != 0.f) r[GRX_REW_TERMINATION] = term_rt;
     // episode sums; reset envs contribute to the block's episode statistics (legged_robot.py:420-424)
     const unsigned long long reset_mask = __ballot(reset && writer);
     float es_all[NT];
@@ -804,24 +863,32 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
             const int L = __ffsll((long long)m) - 1;
             m &= m - 1;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] += __shfl(es_all[t], L);
+            for (int t = 0; t < NT; ++t) if (rew_in_part<PART>(t)) acc[t] += __shfl(es_all[t], L);
         }
         if (lane == 0) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) s_stat[t] = acc[t];
+            for (int t = 0; t < NT; ++t) if (rew_in_part<PART>(t)) s_stat[t] = acc[t];
         }
     }
     if (writer) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (P.reward_scale_dt[t] == 0.f) continue;  // uniform
+            if (!rew_in_part<PART>(t) || P.reward_scale_dt[t] == 0.f) continue;  // uniform
             P.episode_sums[(size_t)t * N + e] = reset ? 0.f : es_all[t];
             if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
         }
     }
-    if (lane == 0) s_stat[NT] = (float)__popcll(reset_mask);
+    if (PART != 2 && lane == 0) s_stat[NT] = (float)__popcll(reset_mask);
 
-    if (writer) P.rew[e] = rew;
+    if (PART != 2) {
+        if (PART == 1) {
+            flag_wait(rew_flag, 1);
+            rew += rew_part[lane];
+        }
+        if (P.only_positive_rewards) rew = fmaxf(rew, 0.f);
+        if (P.reward_scale_dt[GRX_REW_TERMINATION] != 0.f) rew += term_rt;
+        if (writer) P.rew[e] = rew;
+    }
 }
 
 // Block = W waves (W = 1, 2 or 4, chosen at launch so that every wave gets a SIMD to itself) for the same 32 envs,
@@ -837,7 +904,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     constexpr int NTHR = 64 * W;
     __shared__ KTables s_tab;
     __shared__ __attribute__((aligned(16))) float s_obs[EPB * GRX_NUM_OBS];
-    __shared__ __attribute__((aligned(16))) float s_pri[EPB * GRX_MAX_PRI];
+    __shared__ __attribute__((aligned(16))) float s_pri[EPB * PRS];
     __shared__ float s_stat[NT + 1];
     __shared__ float s_base[13 * EPB];   // base state at the start of the current sub-step (dynamics -> helpers)
     __shared__ float s_wr[8 * 64];       // base-lump wrench + termination / collision flags (helper -> dynamics)
@@ -850,6 +917,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __shared__ float s_pb[W == 4 ? (LEG * PBR + 6) * 64 : 1];
     __shared__ float s_anch[W == 4 ? 9 * 64 : 1];     // final friction anchors of the step (wave 2 -> wave 0)
     __shared__ uint32_t s_nz[W == 4 ? NZB * 4 * 64 : 1];   // observation-noise Philox blocks (wave 1 -> wave 0)
+    __shared__ float s_rwp[W == 4 ? 64 : 1];               // partial reward (wave 3 -> wave 1)
     __shared__ float s_hp[W == 4 ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
     __shared__ float s_hsum[W == 4 ? 4 * 64 : 1];          // height scan: partial sums per wave
     __shared__ float s_rw[W == 4 ? REWIN_FLOATS * 64 : 1];   // reward inputs (wave 0 -> wave 1)
@@ -918,19 +986,43 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             } else {
                 base_contact_loop<HF>(P, C, mu, hmax, bm, bc, bI, L, lane, el);
             }
+            float es_early[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
+            if (wv == 1) load_episode_sums<1>(P, e, N, es_early);
+            if (wv == 3) load_episode_sums<2>(P, e, N, es_early);
             __syncthreads();   // final friction anchors + height-scan pose published
             if (HF && P.measure_heights) {   // this wave's quarter of the height scan (legged_robot.py:1235-1274)
                 const float* hp = s_hp + el;
                 s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
-                                                              2 * wv + side, nh, s_pri + el * GRX_MAX_PRI);
+                                                              2 * wv + side, nh, s_pri + el * PRS);
                 __syncthreads();   // height scan complete
             }
-            if (wv == 1) {   // rewards + episode sums while wave 0 runs reset / observations / stores
+            if (wv == 3) {   // the base / feet half of the reward terms, then half of the observation height block
                 flag_wait(s_flag + FL_REW, 1);
                 RewIn rin;
                 int i = 0;
                 rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
-                reward_and_sums(P, C, rin, lane, side, e, N, act, s_stat, nullptr);
+                reward_and_sums<2>(P, C, rin, lane, side, e, N, act, s_stat, es_early, s_rwp, s_flag + FL_RWB);
+            }
+            if (wv == 1) {   // rewards + episode sums while wave 0 runs reset / observations / stores
+                flag_wait(s_flag + FL_REW, 1);
+                GRX_TICKW(14);
+                RewIn rin;
+                int i = 0;
+                rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
+                reward_and_sums<1>(P, C, rin, lane, side, e, N, act, s_stat, es_early, s_rwp, s_flag + FL_RWB);
+                GRX_TICKW(15);
+            }
+            {   // the observation height block, once wave 0 has published the (post-reset) base height: wave 2 takes
+                // the points k = 0, 1 (mod 4), waves 1 and 3 (busy with the rewards until now) k = 2, 3 and 6, 7 (mod 8)
+                flag_wait(s_flag + FL_HZ, 1);
+                if (wv == 2) GRX_TICKW(30);
+                const bool have_raw = HF && P.measure_heights;
+                float* hrow = s_pri + el * PRS;
+                const float part = wv == 2 ? obs_heights_share<4>(P, s_hp[el], side, nh, hrow, have_raw, act, e, N)
+                                           : obs_heights_share<8>(P, s_hp[el], (wv == 1 ? 2 : 6) + side, nh, hrow, have_raw, act, e, N);
+                s_hsum[wv * 64 + lane] = pair_sum(part);
+                flag_set(s_flag + FL_BHO1 + (wv - 1), 1, lane);
+                if (wv == 2) GRX_TICKW(31);
             }
         } else {
             for (int deci = 0; deci < P.decimation; ++deci) {
@@ -1078,7 +1170,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     if (P.resample_command_interval > 0 && ((uint32_t)ep_len % (uint32_t)P.resample_command_interval) == 0)   // ep_len <= max_episode_length + 1
         resample_commands(P, genv, step, GRX_RNG_CMD_TIME, ea.cmd);
     // measured heights: this lane samples points k = 2*i + side; raw heights parked in the pri_obs staging row
-    float* prow = s_pri + el * GRX_MAX_PRI;
+    float* prow = s_pri + el * PRS;
     float hsum = 0.f;
     if (HF && P.measure_heights) {
         if (W == 4) {   // quarter of the scan here, the other three quarters on the helper waves
@@ -1087,8 +1179,6 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane];
         } else hsum = height_scan_share<1>(P, s_tab, yaw_z, yaw_w, st.pos, side, nh, prow);
         hsum = pair_sum(hsum);
-    } else {
-        for (int k = side; k < nh; k += 2) prow[GRX_NUM_OBS + 8 + k] = 0.f;
     }
     if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {  // legged_robot.py:786-797
         st.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
@@ -1128,7 +1218,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             int i = 0;
             rewin_fields(rin, [&](float& x) { s_rw[(i++) * 64 + lane] = x; });
             flag_set(s_flag + FL_REW, 1, lane);
-        } else reward_and_sums(P, C, rin, lane, side, e, N, act, s_stat, es_early);
+        } else reward_and_sums<0>(P, C, rin, lane, side, e, N, act, s_stat, es_early);
     }
     const bool writer = act && side == 0;
     GRX_TICK(6);
@@ -1145,28 +1235,15 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 
     GRX_TICK(7);
     // ---- compute_observations (legged_robot.py:442-452, legged_robot_fftai.py:148-167, gr1t1.py:281-336)
-    float bho;
-    {
-        float sum = 0.f;
-        for (int k0 = side; k0 < nh; k0 += 16) {   // batches of 8: one exposed LDS latency per batch, not per point
-            float hv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) hv[j] = prow[GRX_NUM_OBS + 8 + min(k0 + 2 * j, nh - 1)];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = k0 + 2 * j;
-                if (k < nh) {
-                    float d = st.pos.z - P.base_height_target - hv[j];
-                    d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
-                    if (P.publish_debug && act) P.heights[(size_t)k * N + e] = hv[j];
-                    prow[GRX_NUM_OBS + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -P.clip_observations), P.clip_observations);
-                    sum += d;
-                }
-            }
-        }
-        sum = pair_sum(sum);
+    float bho = 0.f;
+    if (W == 4) {   // waves 2 and 3 do the height block (obs_heights_share) while this wave writes the other terms
+        if (side == 0) s_hp[el] = st.pos.z;
+        flag_set(s_flag + FL_HZ, 1, lane);
+    } else {
+        const float sum = pair_sum(obs_heights_share<2>(P, st.pos.z, side, nh, prow, HF && P.measure_heights, act, e, N));
         bho = nh > 0 ? sum / (float)nh : 0.f;
     }
+    GRX_TICK(11);
     float* orow = s_obs + el * GRX_NUM_OBS;
     const float clipo = P.clip_observations;
     // observation noise (noise_blocks): with 4 waves per block wave 1 computed the blocks while wave 0 loaded state
@@ -1178,6 +1255,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             for (int b = 0; b < NZB; ++b) { nzb[b].x = z[(b * 4 + 0) * 64]; nzb[b].y = z[(b * 4 + 1) * 64]; nzb[b].z = z[(b * 4 + 2) * 64]; nzb[b].w = z[(b * 4 + 3) * 64]; }
         } else noise_blocks(P, genv, step, side, nzb);
     }
+    GRX_TICK(12);
     // item: index within the lane's stream (compile-time); slot0: first block slot of that stream
     auto put = [&](int idx, float val, float nscale, int item, int slot0) {
         float pv = fminf(fmaxf(val, -clipo), clipo);
@@ -1204,8 +1282,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         prow[GRX_NUM_OBS + 0] = fminf(fmaxf(blv.x * P.obs_scale_lin_vel, -clipo), clipo);
         prow[GRX_NUM_OBS + 1] = fminf(fmaxf(blv.y * P.obs_scale_lin_vel, -clipo), clipo);
         prow[GRX_NUM_OBS + 2] = fminf(fmaxf(blv.z * P.obs_scale_lin_vel, -clipo), clipo);
-        prow[GRX_NUM_OBS + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
     }
+    GRX_TICK(13);
     {
         const float np_ = P.noise_dof_pos * P.noise_level * P.obs_scale_dof_pos;
         const float nv = P.noise_dof_vel * P.noise_level * P.obs_scale_dof_vel;
@@ -1219,6 +1297,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         prow[GRX_NUM_OBS + 4 + side] = feet_contact_obs ? 1.f : 0.f;
         prow[GRX_NUM_OBS + 6 + side] = fminf(fmaxf(feet_height * P.obs_scale_height, -clipo), clipo);
     }
+    if (W < 4 && side == 0) prow[GRX_NUM_OBS + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
 
     GRX_TICK(8);
     // ---- store state (SoA) -- history: last_actions = actions, last_dof_vel = dof_vel (legged_robot.py:299-300)
@@ -1261,11 +1340,19 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         P.proj_grav[e] = pg.x; P.proj_grav[(size_t)N + e] = pg.y; P.proj_grav[2 * (size_t)N + e] = pg.z;
         P.origins[e] = ea.origin[0]; P.origins[(size_t)N + e] = ea.origin[1]; P.origins[2 * (size_t)N + e] = ea.origin[2];
         P.levels[e] = ea.level;
-        P.base_heights_offset[e] = bho;
+        if (W < 4) P.base_heights_offset[e] = bho;
         P.ep_len[e] = ep_len;
         P.reset[e] = reset ? 1 : 0;
         P.time_out[e] = time_out ? 1 : 0;
         P.term_contact[e] = term_contact ? 1 : 0;
+    }
+    if (W == 4) {   // base_heights_offset: the helper waves' partial sums of the observation height block
+        flag_wait(s_flag + FL_BHO1, 1);
+        flag_wait(s_flag + FL_BHO1 + 1, 1);
+        flag_wait(s_flag + FL_BHO1 + 2, 1);
+        bho = nh > 0 ? (s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane]) / (float)nh : 0.f;
+        if (side == 0) prow[GRX_NUM_OBS + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
+        if (writer) P.base_heights_offset[e] = bho;
     }
     GRX_TICK(9);
     }   // dynamics wave
@@ -1284,11 +1371,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             for (int i = tid; i < tot; i += NTHR) gobs[i] = s_obs[i];
         float* gpri = P.pri_obs + (size_t)e0 * npri;
         if (npri == GRX_MAX_PRI && nenv == EPB) {
-            const float4* s4 = reinterpret_cast<const float4*>(s_pri);
-            float4* g4 = reinterpret_cast<float4*>(gpri);
-            for (int i = tid; i < EPB * GRX_MAX_PRI / 4; i += NTHR) g4[i] = s4[i];
+            const float2* s2 = reinterpret_cast<const float2*>(s_pri);
+            float2* g2 = reinterpret_cast<float2*>(gpri);
+            for (int i = tid; i < EPB * GRX_MAX_PRI / 2; i += NTHR) {
+                const int row = i / (GRX_MAX_PRI / 2);
+                g2[i] = s2[i + row * ((PRS - GRX_MAX_PRI) / 2)];
+            }
         } else
-            for (int i = tid; i < nenv * npri; i += NTHR) gpri[i] = s_pri[(i / npri) * GRX_MAX_PRI + (i % npri)];
+            for (int i = tid; i < nenv * npri; i += NTHR) gpri[i] = s_pri[(i / npri) * PRS + (i % npri)];
         if (tid <= NT) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + tid] = s_stat[tid];
     }
     // (Reducing the per-block statistics rows here, in the last block to finish, was tried twice to save the

@@ -42,7 +42,7 @@
 #define GRX_WAIT(f, want, slot) flag_wait(f, want)
 #endif
 
-enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_BASE = 4, FL_BIAS = 5, FL_REW = 6, FL_RI = 7, FL_BASEBIAS = 8, FL_SHANK = 9, FL_COUNT = 12 };
+enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_BASE = 4, FL_BIAS = 5, FL_REW = 6, FL_RI = 7, FL_BASEBIAS = 8, FL_SHANK = 9, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_COUNT = 16 };
 constexpr int REC = 28;   // floats per joint record: ua 3, ul 3, 1/d, A' 6, B' 9, D' 6
 constexpr int RIR = 15;   // floats per chain body from wave 0: rigid inertia about O (A 6, h 3), joint axis Sa 3, Ss 3
 constexpr int PBR = 12;   // floats per chain body from wave 3: rigid-body bias force pa 3, pl 3, velocity-product acceleration ca 3, cl 3
