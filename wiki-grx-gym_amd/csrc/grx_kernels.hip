@@ -713,7 +713,7 @@ __host__ __device__ constexpr bool rew_in_part(int t) {
 template <int PART>
 GRX_DEV void load_episode_sums(KP P, int e, int N, float es[NT]) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) es[t] = (rew_in_part<PART>(t) && P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
+    for (int t = 0; t < NT; ++t) if (rew_in_part<PART>(t)) es[t] = (P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
 }
 
 // compute_reward (legged_robot.py:355-375) + episode sums + the block's finished-episode statistics for one lane.
@@ -907,14 +907,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __shared__ __attribute__((aligned(16))) float s_pri[EPB * PRS];
     __shared__ float s_stat[NT + 1];
     __shared__ float s_base[13 * EPB];   // base state at the start of the current sub-step (dynamics -> helpers)
-    __shared__ float s_wr[8 * 64];       // base-lump wrench + termination / collision flags (helper -> dynamics)
+    __shared__ __attribute__((aligned(16))) float s_wr[8 * 64];       // base-lump wrench + termination / collision flags (helper -> dynamics)
     // W == 4 pipeline buffers (grx_wavepipe.h)
-    __shared__ float s_q[W == 4 ? 2 * LEG * 64 : 1];
-    __shared__ float s_ri[W == 4 ? LEG * RIR * 64 : 1];
-    __shared__ float s_rec[W == 4 ? LEG * REC * 64 : 1];
-    __shared__ float s_rec0[W == 4 ? 21 * 64 : 1];
-    __shared__ float s_wc[W == 4 ? 21 * 64 : 1];
-    __shared__ float s_pb[W == 4 ? (LEG * PBR + 6) * 64 : 1];
+    __shared__ float4 s_q[W == 4 ? Q4 * 64 : 1];
+    __shared__ float4 s_ri[W == 4 ? LEG * RI4 * 64 : 1];
+    __shared__ float4 s_rec[W == 4 ? LEG * REC4 * 64 : 1];
+    __shared__ float4 s_rec0[W == 4 ? REC04 * 64 : 1];
+    __shared__ float4 s_wc[W == 4 ? WC4 * 64 : 1];
+    __shared__ float4 s_pb[W == 4 ? (LEG * PB4 + 2) * 64 : 1];
     __shared__ float s_anch[W == 4 ? 9 * 64 : 1];     // final friction anchors of the step (wave 2 -> wave 0)
     __shared__ uint32_t s_nz[W == 4 ? NZB * 4 * 64 : 1];   // observation-noise Philox blocks (wave 1 -> wave 0)
     __shared__ float s_rwp[W == 4 ? 64 : 1];               // partial reward (wave 3 -> wave 1)
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __shared__ float s_hsum[W == 4 ? 4 * 64 : 1];          // height scan: partial sums per wave
     __shared__ float s_rw[W == 4 ? REWIN_FLOATS * 64 : 1];   // reward inputs (wave 0 -> wave 1)
     __shared__ int s_flag[FL_COUNT];
-    const PipeLds L = {s_base, s_q, s_ri, s_rec, s_rec0, s_wc, s_pb, s_wr, s_flag};
+    const PipeLds L = {s_base, s_q, s_ri, s_rec, s_rec0, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag};
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     {   // stage the per-side robot tables (joint tree, inertias, gains, spheres) into LDS
@@ -986,9 +986,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             } else {
                 base_contact_loop<HF>(P, C, mu, hmax, bm, bc, bI, L, lane, el);
             }
-            float es_early[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
-            if (wv == 1) load_episode_sums<1>(P, e, N, es_early);
-            if (wv == 3) load_episode_sums<2>(P, e, N, es_early);
+            float es_w1[NT], es_w3[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
+            if (wv == 1) load_episode_sums<1>(P, e, N, es_w1);
+            if (wv == 3) load_episode_sums<2>(P, e, N, es_w3);
             __syncthreads();   // final friction anchors + height-scan pose published
             if (HF && P.measure_heights) {   // this wave's quarter of the height scan (legged_robot.py:1235-1274)
                 const float* hp = s_hp + el;
@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 RewIn rin;
                 int i = 0;
                 rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
-                reward_and_sums<2>(P, C, rin, lane, side, e, N, act, s_stat, es_early, s_rwp, s_flag + FL_RWB);
+                reward_and_sums<2>(P, C, rin, lane, side, e, N, act, s_stat, es_w3, s_rwp, s_flag + FL_RWB);
             }
             if (wv == 1) {   // rewards + episode sums while wave 0 runs reset / observations / stores
                 flag_wait(s_flag + FL_REW, 1);
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 RewIn rin;
                 int i = 0;
                 rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
-                reward_and_sums<1>(P, C, rin, lane, side, e, N, act, s_stat, es_early, s_rwp, s_flag + FL_RWB);
+                reward_and_sums<1>(P, C, rin, lane, side, e, N, act, s_stat, es_w1, s_rwp, s_flag + FL_RWB);
                 GRX_TICKW(15);
             }
             {   // the observation height block, once wave 0 has published the (post-reset) base height: wave 2 takes
@@ -1114,8 +1114,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             b[10 * EPB] = st.ang.x; b[11 * EPB] = st.ang.y; b[12 * EPB] = st.ang.z;
         }
         if (W == 4) {
-#pragma unroll
-            for (int k = 0; k < LEG; ++k) { s_q[k * 64 + lane] = st.q[k]; s_q[(LEG + k) * 64 + lane] = st.qd[k]; }
+            s_q[lane] = f4(st.q[0], st.q[1], st.q[2], st.q[3]);
+            s_q[64 + lane] = f4(st.q[4], st.qd[0], st.qd[1], st.qd[2]);
+            s_q[128 + lane] = f4(st.qd[3], st.qd[4], 0.f, 0.f);
         }
         if (W == 4) flag_set(s_flag + FL_STATE, deci + 1, lane);
         else if (W == 2) __syncthreads();   // #1

@@ -43,21 +43,28 @@
 #endif
 
 enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_BASE = 4, FL_BIAS = 5, FL_REW = 6, FL_RI = 7, FL_BASEBIAS = 8, FL_SHANK = 9, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_COUNT = 16 };
-constexpr int REC = 28;   // floats per joint record: ua 3, ul 3, 1/d, A' 6, B' 9, D' 6
-constexpr int RIR = 15;   // floats per chain body from wave 0: rigid inertia about O (A 6, h 3), joint axis Sa 3, Ss 3
-constexpr int PBR = 12;   // floats per chain body from wave 3: rigid-body bias force pa 3, pl 3, velocity-product acceleration ca 3, cl 3
+// Every record is laid out [quad][lane] in float4 units, so a lane moves it with ds_read_b128 / ds_write_b128: the
+// kernel runs at one instruction issue per ~5 cycles whatever the instruction, and the records are ~350 dwords per
+// lane and sub-step on wave 0 alone -- four dwords per LDS instruction instead of one is ~1.3k cycles per sub-step.
+constexpr int REC4 = 7;   // quads per joint record: ua 3, ul 3, 1/d, A' 6, B' 9, D' 6  (28 floats)
+constexpr int RI4 = 4;    // quads per chain body from wave 0: rigid inertia about O (A 6, h 3), joint axis Sa 3, Ss 3  (15 floats)
+constexpr int PB4 = 3;    // quads per chain body from wave 2: rigid-body bias force pa 3, pl 3, velocity-product acceleration ca 3, cl 3
+constexpr int REC04 = 6;  // factorised base-level articulated inertia: inv(D) 6, inv(Schur) 6, B 9  (21 floats)
+constexpr int WC4 = 7;    // contact wrenches about O: thigh quads 0-1, shank 2-3, foot 4-6 (wrench 6 + foot link velocity 3)
+constexpr int Q4 = 3;     // q 5, qd 5 of the lane's leg
 
 struct PipeLds {
     float* base;   // [13][EPB]   base state at the start of the sub-step
-    float* q;      // [2*LEG][64] q, qd of every lane's leg
-    float* ri;     // [LEG][RIR][64] rigid inertias + joint axes (wave 0 -> I wave), leaf first
-    float* rec;    // [LEG][REC][64] joint records of the I wave
-    float* rec0;   // [21][64]    factorised base-level articulated inertia: inv(D) 6, inv(Schur) 6, B 9
-    float* wc;     // [21][64]    contact wrenches about O on chain bodies 2, 3, 4; foot link velocity (3)
-    float* pb;     // [LEG][PBR][64] + [6][64]: chain-body bias forces / accelerations (leaf first), base-lump bias force
-    float* wr;     // [8][64]     base-lump wrench, termination flag, collision count
+    float4* q;     // [Q4][64]    q, qd of every lane's leg
+    float4* ri;    // [LEG][RI4][64] rigid inertias + joint axes (wave 0 -> I wave), leaf first
+    float4* rec;   // [LEG][REC4][64] joint records of the I wave
+    float4* rec0;  // [REC04][64]
+    float4* wc;    // [WC4][64]
+    float4* pb;    // [LEG][PB4][64] + [2][64]: chain-body bias forces / accelerations (leaf first), base-lump bias force
+    float4* wr;    // [2][64]     base-lump wrench, termination flag, collision count
     int* flag;     // [FL_COUNT]
 };
+GRX_DEV float4 f4(float a, float b, float c, float d) { float4 r; r.x = a; r.y = b; r.z = c; r.w = d; return r; }
 
 GRX_DEV void flag_set(int* f, int v, int lane) {
     if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -125,10 +132,11 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
             const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
             S3 Ak; V3 hk;
             rigid_inertia(RK[k], kap, C.body[k].mass, Ic, Ak, hk);
-            float* o = L.ri + (size_t)(k * RIR) * 64 + lane;
-            o[0 * 64] = Ak.xx; o[1 * 64] = Ak.xy; o[2 * 64] = Ak.xz; o[3 * 64] = Ak.yy; o[4 * 64] = Ak.yz; o[5 * 64] = Ak.zz;
-            o[6 * 64] = hk.x; o[7 * 64] = hk.y; o[8 * 64] = hk.z;
-            o[9 * 64] = Sa[k].x; o[10 * 64] = Sa[k].y; o[11 * 64] = Sa[k].z; o[12 * 64] = Ss[k].x; o[13 * 64] = Ss[k].y; o[14 * 64] = Ss[k].z;
+            float4* o = L.ri + (k * RI4) * 64 + lane;
+            o[0 * 64] = f4(Ak.xx, Ak.xy, Ak.xz, Ak.yy);
+            o[1 * 64] = f4(Ak.yz, Ak.zz, hk.x, hk.y);
+            o[2 * 64] = f4(hk.z, Sa[k].x, Sa[k].y, Sa[k].z);
+            o[3 * 64] = f4(Ss[k].x, Ss[k].y, Ss[k].z, 0.f);
             flag_set(L.flag + FL_RI, seq * 8 + (LEG - k), lane);
         }
     }
@@ -138,17 +146,19 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
         GRX_WAIT(L.flag + FL_I, seq * 8 + (LEG - k), 1);
-        const float* r = L.rec + (size_t)(k * REC) * 64 + lane;
-        const V3 ua = v3(r[0 * 64], r[1 * 64], r[2 * 64]), ul = v3(r[3 * 64], r[4 * 64], r[5 * 64]);
-        const float di = r[6 * 64];
-        const S3 A = {r[7 * 64], r[8 * 64], r[9 * 64], r[10 * 64], r[11 * 64], r[12 * 64]};
-        const M3 B = {r[13 * 64], r[14 * 64], r[15 * 64], r[16 * 64], r[17 * 64], r[18 * 64], r[19 * 64], r[20 * 64], r[21 * 64]};
-        const S3 D = {r[22 * 64], r[23 * 64], r[24 * 64], r[25 * 64], r[26 * 64], r[27 * 64]};
+        const float4* r = L.rec + (k * REC4) * 64 + lane;
+        const float4 r0_ = r[0 * 64], r1_ = r[1 * 64], r2_ = r[2 * 64], r3_ = r[3 * 64], r4_ = r[4 * 64], r5_ = r[5 * 64], r6_ = r[6 * 64];
+        const V3 ua = v3(r0_.x, r0_.y, r0_.z), ul = v3(r0_.w, r1_.x, r1_.y);
+        const float di = r1_.z;
+        const S3 A = {r1_.w, r2_.x, r2_.y, r2_.z, r2_.w, r3_.x};
+        const M3 B = {r3_.y, r3_.z, r3_.w, r4_.x, r4_.y, r4_.z, r4_.w, r5_.x, r5_.y};
+        const S3 D = {r5_.z, r5_.w, r6_.x, r6_.y, r6_.z, r6_.w};
         {   // this body's rigid bias force joins the running articulated bias; its velocity-product acceleration
             GRX_WAIT(L.flag + FL_BIAS, seq * 8 + (LEG - k), 0);
-            const float* b_ = L.pb + (size_t)(k * PBR) * 64 + lane;
-            pa = pa + v3(b_[0 * 64], b_[1 * 64], b_[2 * 64]); pl = pl + v3(b_[3 * 64], b_[4 * 64], b_[5 * 64]);
-            ca[k] = v3(b_[6 * 64], b_[7 * 64], b_[8 * 64]); cl[k] = v3(b_[9 * 64], b_[10 * 64], b_[11 * 64]);
+            const float4* b_ = L.pb + (k * PB4) * 64 + lane;
+            const float4 b0_ = b_[0 * 64], b1_ = b_[1 * 64], b2_ = b_[2 * 64];
+            pa = pa + v3(b0_.x, b0_.y, b0_.z); pl = pl + v3(b0_.w, b1_.x, b1_.y);
+            ca[k] = v3(b1_.z, b1_.w, b2_.x); cl[k] = v3(b2_.y, b2_.z, b2_.w);
         }
         const float qdk = st.qd[k];
         // joint-limit spring/damper (oracle substep()): added to the motor torque
@@ -171,10 +181,11 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 #pragma unroll
         for (int k = LEG - 1; k >= 0; --k) {
             if (k >= 2) {
-                const float* c = L.wc + (size_t)((k - 2) * 6) * 64 + lane;
-                const V3 fa = v3(c[0 * 64], c[1 * 64], c[2 * 64]), fl = v3(c[3 * 64], c[4 * 64], c[5 * 64]);
+                const float4* c = L.wc + ((k - 2) * 2) * 64 + lane;
+                const float4 c0_ = c[0 * 64], c1_ = c[1 * 64];
+                const V3 fa = v3(c0_.x, c0_.y, c0_.z), fl = v3(c0_.w, c1_.x, c1_.y);
                 da = da - fa; dl = dl - fl;
-                if (k == LEG - 1) { out.foot_force = fl; fk_before.vel = v3(c[6 * 64], c[7 * 64], c[8 * 64]); }
+                if (k == LEG - 1) { const float4 c2_ = c[2 * 64]; out.foot_force = fl; fk_before.vel = v3(c1_.z, c1_.w, c2_.x); }
             }
             const float du = -(dot(Sa[k], da) + dot(Ss[k], dl));
             uu[k] += du;
@@ -186,25 +197,27 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     // ---- base: both chains (DPP pair exchange) + base lump, 6x6 solve
     GRX_WAIT(L.flag + FL_BASE, seq + 1, 3);
     {
-        const float* wr = L.wr + lane;
-        const V3 f0a = v3(wr[0 * 64], wr[1 * 64], wr[2 * 64]), f0l = v3(wr[3 * 64], wr[4 * 64], wr[5 * 64]);
-        out.term = wr[6 * 64] != 0.f;
-        out.pen_count = wr[7 * 64];
+        const float4 w0_ = L.wr[lane], w1_ = L.wr[64 + lane];
+        const V3 f0a = v3(w0_.x, w0_.y, w0_.z), f0l = v3(w0_.w, w1_.x, w1_.y);
+        out.term = w1_.z != 0.f;
+        out.pen_count = w1_.w;
         pa = pa - f0a; pl = pl - f0l;
     }
     pa = pair_sum(pa); pl = pair_sum(pl);
     {   // base-lump bias force (wave 3; both lanes of the pair add the same value after the pair sum)
         GRX_WAIT(L.flag + FL_BASEBIAS, seq + 1, 0);
-        const float* b_ = L.pb + (size_t)(LEG * PBR) * 64 + lane;
-        pa = pa + v3(b_[0 * 64], b_[1 * 64], b_[2 * 64]); pl = pl + v3(b_[3 * 64], b_[4 * 64], b_[5 * 64]);
+        const float4* b_ = L.pb + (LEG * PB4) * 64 + lane;
+        const float4 b0_ = b_[0 * 64], b1_ = b_[1 * 64];
+        pa = pa + v3(b0_.x, b0_.y, b0_.z); pl = pl + v3(b0_.w, b1_.x, b1_.y);
     }
     // [A B; B^T D][alpha; acc] = -[pa; pl], factorised by the I wave: Di = inv(D), Sci = inv(A - B Di B^T)
     //   alpha = Sci (B Di pl - pa),  acc = -Di (pl + B^T alpha)
     GRX_WAIT(L.flag + FL_I, seq * 8 + LEG + 1, 4);
-    const float* r0 = L.rec0 + lane;
-    const S3 Di = {r0[0 * 64], r0[1 * 64], r0[2 * 64], r0[3 * 64], r0[4 * 64], r0[5 * 64]};
-    const S3 Sci = {r0[6 * 64], r0[7 * 64], r0[8 * 64], r0[9 * 64], r0[10 * 64], r0[11 * 64]};
-    const M3 B = {r0[12 * 64], r0[13 * 64], r0[14 * 64], r0[15 * 64], r0[16 * 64], r0[17 * 64], r0[18 * 64], r0[19 * 64], r0[20 * 64]};
+    const float4* r0 = L.rec0 + lane;
+    const float4 g0_ = r0[0 * 64], g1_ = r0[1 * 64], g2_ = r0[2 * 64], g3_ = r0[3 * 64], g4_ = r0[4 * 64], g5_ = r0[5 * 64];
+    const S3 Di = {g0_.x, g0_.y, g0_.z, g0_.w, g1_.x, g1_.y};
+    const S3 Sci = {g1_.z, g1_.w, g2_.x, g2_.y, g2_.z, g2_.w};
+    const M3 B = {g3_.x, g3_.y, g3_.z, g3_.w, g4_.x, g4_.y, g4_.z, g4_.w, g5_.x};
     const V3 alpha = mul(Sci, mul(B, mul(Di, pl)) - pa);
     const V3 acc = neg(mul(Di, pl + mulT(B, alpha)));
     // ---- pass 3 (root -> leaf): accelerations
@@ -263,23 +276,25 @@ GRX_DEV void iwave_loop(KP P, const SideConst& C, float base_m, V3 base_c, const
 #pragma unroll
         for (int k = LEG - 1; k >= 0; --k) {
             flag_wait(L.flag + FL_RI, seq * 8 + (LEG - k));
-            const float* i_ = L.ri + (size_t)(k * RIR) * 64 + lane;
+            const float4* i_ = L.ri + (k * RI4) * 64 + lane;
+            const float4 i0_ = i_[0 * 64], i1_ = i_[1 * 64], i2_ = i_[2 * 64], i3_ = i_[3 * 64];
             {
-                const S3 Ak = {i_[0 * 64], i_[1 * 64], i_[2 * 64], i_[3 * 64], i_[4 * 64], i_[5 * 64]};
-                add_rigid(A, B, D, Ak, v3(i_[6 * 64], i_[7 * 64], i_[8 * 64]), C.body[k].mass);
+                const S3 Ak = {i0_.x, i0_.y, i0_.z, i0_.w, i1_.x, i1_.y};
+                add_rigid(A, B, D, Ak, v3(i1_.z, i1_.w, i2_.x), C.body[k].mass);
             }
-            const V3 a = v3(i_[9 * 64], i_[10 * 64], i_[11 * 64]), s = v3(i_[12 * 64], i_[13 * 64], i_[14 * 64]);
+            const V3 a = v3(i2_.y, i2_.z, i2_.w), s = v3(i3_.x, i3_.y, i3_.z);
             const V3 ua = mul(A, a) + mul(B, s);
             const V3 ul = mulT(B, a) + mul(D, s);
             const float di = grx_rcp(dot(a, ua) + dot(s, ul));
             syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
-            float* r = L.rec + (size_t)(k * REC) * 64 + lane;
-            r[0 * 64] = ua.x; r[1 * 64] = ua.y; r[2 * 64] = ua.z; r[3 * 64] = ul.x; r[4 * 64] = ul.y; r[5 * 64] = ul.z;
-            r[6 * 64] = di;
-            r[7 * 64] = A.xx; r[8 * 64] = A.xy; r[9 * 64] = A.xz; r[10 * 64] = A.yy; r[11 * 64] = A.yz; r[12 * 64] = A.zz;
-            r[13 * 64] = B.a00; r[14 * 64] = B.a01; r[15 * 64] = B.a02; r[16 * 64] = B.a10; r[17 * 64] = B.a11;
-            r[18 * 64] = B.a12; r[19 * 64] = B.a20; r[20 * 64] = B.a21; r[21 * 64] = B.a22;
-            r[22 * 64] = D.xx; r[23 * 64] = D.xy; r[24 * 64] = D.xz; r[25 * 64] = D.yy; r[26 * 64] = D.yz; r[27 * 64] = D.zz;
+            float4* r = L.rec + (k * REC4) * 64 + lane;
+            r[0 * 64] = f4(ua.x, ua.y, ua.z, ul.x);
+            r[1 * 64] = f4(ul.y, ul.z, di, A.xx);
+            r[2 * 64] = f4(A.xy, A.xz, A.yy, A.yz);
+            r[3 * 64] = f4(A.zz, B.a00, B.a01, B.a02);
+            r[4 * 64] = f4(B.a10, B.a11, B.a12, B.a20);
+            r[5 * 64] = f4(B.a21, B.a22, D.xx, D.xy);
+            r[6 * 64] = f4(D.xz, D.yy, D.yz, D.zz);
             flag_set(L.flag + FL_I, seq * 8 + (LEG - k), lane);
         }
         // base level: both chains + the base lump
@@ -291,11 +306,13 @@ GRX_DEV void iwave_loop(KP P, const SideConst& C, float base_m, V3 base_c, const
             const V3 d0 = mul(Di, b0), d1 = mul(Di, b1), d2 = mul(Di, b2);
             const S3 Sc = {A.xx - dot(b0, d0), A.xy - dot(b0, d1), A.xz - dot(b0, d2), A.yy - dot(b1, d1), A.yz - dot(b1, d2), A.zz - dot(b2, d2)};
             const S3 Sci = inv(Sc);
-            float* r0 = L.rec0 + lane;
-            r0[0 * 64] = Di.xx; r0[1 * 64] = Di.xy; r0[2 * 64] = Di.xz; r0[3 * 64] = Di.yy; r0[4 * 64] = Di.yz; r0[5 * 64] = Di.zz;
-            r0[6 * 64] = Sci.xx; r0[7 * 64] = Sci.xy; r0[8 * 64] = Sci.xz; r0[9 * 64] = Sci.yy; r0[10 * 64] = Sci.yz; r0[11 * 64] = Sci.zz;
-            r0[12 * 64] = B.a00; r0[13 * 64] = B.a01; r0[14 * 64] = B.a02; r0[15 * 64] = B.a10; r0[16 * 64] = B.a11;
-            r0[17 * 64] = B.a12; r0[18 * 64] = B.a20; r0[19 * 64] = B.a21; r0[20 * 64] = B.a22;
+            float4* r0 = L.rec0 + lane;
+            r0[0 * 64] = f4(Di.xx, Di.xy, Di.xz, Di.yy);
+            r0[1 * 64] = f4(Di.yz, Di.zz, Sci.xx, Sci.xy);
+            r0[2 * 64] = f4(Sci.xz, Sci.yy, Sci.yz, Sci.zz);
+            r0[3 * 64] = f4(B.a00, B.a01, B.a02, B.a10);
+            r0[4 * 64] = f4(B.a11, B.a12, B.a20, B.a21);
+            r0[5 * 64] = f4(B.a22, 0.f, 0.f, 0.f);
         }
         flag_set(L.flag + FL_I, seq * 8 + LEG + 1, lane);
     }
@@ -316,7 +333,12 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, 
         const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
         const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
-        const float* qs = L.q + lane;
+        float qs_q[LEG], qs_qd[LEG];
+        {
+            const float4 q0_ = L.q[lane], q1_ = L.q[64 + lane], q2_ = L.q[128 + lane];
+            qs_q[0] = q0_.x; qs_q[1] = q0_.y; qs_q[2] = q0_.z; qs_q[3] = q0_.w; qs_q[4] = q1_.x;
+            qs_qd[0] = q1_.y; qs_qd[1] = q1_.z; qs_qd[2] = q1_.w; qs_qd[3] = q2_.x; qs_qd[4] = q2_.y;
+        }
         // outward walk with velocities; rigid-body bias forces + velocity-product accelerations of the chain bodies,
         // leaf first (wave 0's recursion starts at the foot and needs them before anything else this wave makes)
         ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
@@ -325,10 +347,10 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, 
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {
             const V3 wp = K.w, vp = K.v;   // parent velocity
-            const float qdk = qs[(LEG + k) * 64];
+            const float qdk = qs_qd[k];
             K.rho = K.rho + rot(K.R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
             float sn, cs;
-            grx_sincos(qs[k * 64], sn, cs);
+            grx_sincos(qs_q[k], sn, cs);
             K.R = joint_rot_k(K.R, cs, sn, kAxis[k]);
             const V3 a = axis_k(K.R, kAxis[k]);
             const V3 s = cross(K.rho, a);
@@ -343,24 +365,27 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, 
             const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
             V3 pa, pl;
             rigid_bias(KK[k].R, kap, C.body[k].mass, Ic, KK[k].w, KK[k].v, pa, pl);
-            float* o = L.pb + (size_t)(k * PBR) * 64 + lane;
-            o[0 * 64] = pa.x; o[1 * 64] = pa.y; o[2 * 64] = pa.z; o[3 * 64] = pl.x; o[4 * 64] = pl.y; o[5 * 64] = pl.z;
-            o[6 * 64] = cak[k].x; o[7 * 64] = cak[k].y; o[8 * 64] = cak[k].z; o[9 * 64] = clk[k].x; o[10 * 64] = clk[k].y; o[11 * 64] = clk[k].z;
+            float4* o = L.pb + (k * PB4) * 64 + lane;
+            o[0 * 64] = f4(pa.x, pa.y, pa.z, pl.x);
+            o[1 * 64] = f4(pl.y, pl.z, cak[k].x, cak[k].y);
+            o[2 * 64] = f4(cak[k].z, clk[k].x, clk[k].y, clk[k].z);
             flag_set(L.flag + FL_BIAS, seq * 8 + (LEG - k), lane);
         }
         const ChainKin& K2 = KK[2];
-        float* c_ = L.wc + lane;
+        float4* c_ = L.wc + lane;
         V3 fa, fl;
         foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl);
-        c_[12 * 64] = fa.x; c_[13 * 64] = fa.y; c_[14 * 64] = fa.z; c_[15 * 64] = fl.x; c_[16 * 64] = fl.y; c_[17 * 64] = fl.z;
         {   // foot link velocity BEFORE this sub-step's integration (sub-step averaged foot speed, fftai.py:79-81)
             const V3 fr = K.rho + rot(K.R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
             const V3 fv = K.v + cross(K.w, fr);
-            c_[18 * 64] = fv.x; c_[19 * 64] = fv.y; c_[20 * 64] = fv.z;
+            c_[4 * 64] = f4(fa.x, fa.y, fa.z, fl.x);
+            c_[5 * 64] = f4(fl.y, fl.z, fv.x, fv.y);
+            c_[6 * 64] = f4(fv.z, 0.f, 0.f, 0.f);
         }
         flag_set(L.flag + FL_FOOT, seq + 1, lane);
         link_contacts<HF>(P, C, 2, K2, O, mu, hmax, fa, fl);      // thigh (the shank spheres are wave 3's)
-        c_[0 * 64] = fa.x; c_[1 * 64] = fa.y; c_[2 * 64] = fa.z; c_[3 * 64] = fl.x; c_[4 * 64] = fl.y; c_[5 * 64] = fl.z;
+        c_[0 * 64] = f4(fa.x, fa.y, fa.z, fl.x);
+        c_[1 * 64] = f4(fl.y, fl.z, 0.f, 0.f);
         flag_set(L.flag + FL_LEGS, seq + 1, lane);
     }
     GRX_HELPER_PROF_END(2);
@@ -382,27 +407,28 @@ GRX_DEV void base_contact_loop(KP P, const SideConst& C, float mu, float hmax, f
         {   // the base lump's rigid-body bias force (cheap; needed by wave 0 only at the base solve)
             V3 bpa, bpl;
             rigid_bias(R0, rot(R0, base_c), base_m, base_I, ang, vel, bpa, bpl);
-            float* o = L.pb + (size_t)(LEG * PBR) * 64 + lane;
-            o[0 * 64] = bpa.x; o[1 * 64] = bpa.y; o[2 * 64] = bpa.z; o[3 * 64] = bpl.x; o[4 * 64] = bpl.y; o[5 * 64] = bpl.z;
+            float4* o = L.pb + (LEG * PB4) * 64 + lane;
+            o[0 * 64] = f4(bpa.x, bpa.y, bpa.z, bpl.x);
+            o[1 * 64] = f4(bpl.y, bpl.z, 0.f, 0.f);
             flag_set(L.flag + FL_BASEBIAS, seq + 1, lane);
         }
         {   // shank spheres (own outward walk to the knee): shares the chain-contact load with wave 2
-            const float* qs = L.q + lane;
+            const float4 q0_ = L.q[lane], q1_ = L.q[64 + lane], q2_ = L.q[128 + lane];
+            const float qs_q[4] = {q0_.x, q0_.y, q0_.z, q0_.w}, qs_qd[4] = {q1_.y, q1_.z, q1_.w, q2_.x};
             ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
 #pragma unroll
-            for (int k = 0; k <= 3; ++k) chain_step(C, k, qs[k * 64], qs[(LEG + k) * 64], K);
+            for (int k = 0; k <= 3; ++k) chain_step(C, k, qs_q[k], qs_qd[k], K);
             V3 fa, fl;
             link_contacts<HF>(P, C, 3, K, O, mu, hmax, fa, fl);
-            float* c_ = L.wc + lane;
-            c_[6 * 64] = fa.x; c_[7 * 64] = fa.y; c_[8 * 64] = fa.z; c_[9 * 64] = fl.x; c_[10 * 64] = fl.y; c_[11 * 64] = fl.z;
+            float4* c_ = L.wc + lane;
+            c_[2 * 64] = f4(fa.x, fa.y, fa.z, fl.x);
+            c_[3 * 64] = f4(fl.y, fl.z, 0.f, 0.f);
             flag_set(L.flag + FL_SHANK, seq + 1, lane);
         }
         V3 f0a, f0l; bool term; float pen;
         base_lump_contacts<HF, false>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen);
-        float* w_ = L.wr + lane;
-        w_[0 * 64] = f0a.x; w_[1 * 64] = f0a.y; w_[2 * 64] = f0a.z;
-        w_[3 * 64] = f0l.x; w_[4 * 64] = f0l.y; w_[5 * 64] = f0l.z;
-        w_[6 * 64] = term ? 1.f : 0.f; w_[7 * 64] = pen;
+        L.wr[lane] = f4(f0a.x, f0a.y, f0a.z, f0l.x);
+        L.wr[64 + lane] = f4(f0l.y, f0l.z, term ? 1.f : 0.f, pen);
         flag_set(L.flag + FL_BASE, seq + 1, lane);
     }
     GRX_HELPER_PROF_END(3);
