@@ -517,10 +517,39 @@ struct EnvAux {  // per-env (replicated in both lanes) pipeline state touched by
     int level, type;
 };
 
+// The uniform draws of one lane's reset_idx: they depend on (seed, env, step) only, not on the state, so an idle
+// helper wave can have them ready before wave 0 knows who resets.  Same counters and words as grx_rand(stream, i)
+// item by item; six Philox blocks instead of one per draw.
+struct ResetRand { float dof[LEG], root[9], cmd[3]; };
+GRX_DEV ResetRand reset_rand(KP P, uint32_t genv, uint32_t step, int side) {
+    const uint32_t k0 = (uint32_t)P.seed, k1 = (uint32_t)(P.seed >> 32);
+    ResetRand r;
+    {   // RESET_DOF items side*5 + k: side 0 -> block 0 words 0..3, block 1 word 0; side 1 -> block 1 words 1..3, block 2 words 0, 1
+        const U4 a = grx_philox4x32_10(genv, step, GRX_RNG_RESET_DOF, (uint32_t)side, k0, k1);
+        const U4 b = grx_philox4x32_10(genv, step, GRX_RNG_RESET_DOF, (uint32_t)side + 1u, k0, k1);
+        r.dof[0] = grx_u01(side ? a.y : a.x); r.dof[1] = grx_u01(side ? a.z : a.y); r.dof[2] = grx_u01(side ? a.w : a.z);
+        r.dof[3] = grx_u01(side ? b.x : a.w); r.dof[4] = grx_u01(side ? b.y : b.x);
+    }
+    {
+        const U4 a = grx_philox4x32_10(genv, step, GRX_RNG_RESET_ROOT, 0u, k0, k1);
+        const U4 b = grx_philox4x32_10(genv, step, GRX_RNG_RESET_ROOT, 1u, k0, k1);
+        const U4 c = grx_philox4x32_10(genv, step, GRX_RNG_RESET_ROOT, 2u, k0, k1);
+        r.root[0] = grx_u01(a.x); r.root[1] = grx_u01(a.y); r.root[2] = grx_u01(a.z); r.root[3] = grx_u01(a.w);
+        r.root[4] = grx_u01(b.x); r.root[5] = grx_u01(b.y); r.root[6] = grx_u01(b.z); r.root[7] = grx_u01(b.w);
+        r.root[8] = grx_u01(c.x);
+    }
+    {
+        const U4 a = grx_philox4x32_10(genv, step, GRX_RNG_CMD_RESET, 0u, k0, k1);
+        r.cmd[0] = grx_u01(a.x); r.cmd[1] = grx_u01(a.y); r.cmd[2] = grx_u01(a.z);
+    }
+    return r;
+}
+GRX_DEV float lerp_u(float u, float lo, float hi) { return (hi - lo) * u + lo; }   // urand() on a ready draw
+
 // reset_idx for one env (legged_robot.py:377-440, 717-826; legged_robot_fftai.py:137-146):
 // each lane resets its own leg, the root state is computed redundantly (same counters -> same values)
 GRX_DEV void reset_env(KP P, const SideConst& C, int side, uint32_t genv, uint32_t step, bool init_done,
-                       LaneState& st, EnvAux& ea) {
+                       LaneState& st, EnvAux& ea, const ResetRand& rr) {
     if (P.curriculum && P.terrain_type != GRX_TERRAIN_PLANE && init_done) {  // legged_robot.py:799-826
         float dx = st.pos.x - ea.origin[0], dy = st.pos.y - ea.origin[1];
         float dist = sqrtf(dx * dx + dy * dy);
@@ -538,29 +567,34 @@ GRX_DEV void reset_env(KP P, const SideConst& C, int side, uint32_t genv, uint32
     }
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {  // _reset_dofs
-        float f = P.randomize_init_dof_pos ? urand(P, genv, step, GRX_RNG_RESET_DOF, (uint32_t)(side * LEG + k), 0.5f, 1.5f) : 1.0f;
+        float f = P.randomize_init_dof_pos ? lerp_u(rr.dof[k], 0.5f, 1.5f) : 1.0f;
         st.q[k] = f * C.body[k].q0;
         st.qd[k] = 0.0f;
     }
     st.pos = v3(P.init_pos[0] + ea.origin[0], P.init_pos[1] + ea.origin[1], P.init_pos[2] + ea.origin[2]);
     if (P.terrain_type != GRX_TERRAIN_PLANE) {
-        st.pos.x += urand(P, genv, step, GRX_RNG_RESET_ROOT, 0, -1.0f, 1.0f);
-        st.pos.y += urand(P, genv, step, GRX_RNG_RESET_ROOT, 1, -1.0f, 1.0f);
+        st.pos.x += lerp_u(rr.root[0], -1.0f, 1.0f);
+        st.pos.y += lerp_u(rr.root[1], -1.0f, 1.0f);
     }
-    float yaw = urand(P, genv, step, GRX_RNG_RESET_ROOT, 2, -6.283185307179586f, 6.283185307179586f);
+    float yaw = lerp_u(rr.root[2], -6.283185307179586f, 6.283185307179586f);
     float sy, cy;
     sincosf(yaw * 0.5f, &sy, &cy);
     st.qx = 0.f; st.qy = 0.f; st.qz = sy; st.qw = cy;  // quat_from_euler_xyz(0,0,yaw)
     if (P.randomize_init_base_velocity) {
-        st.vel = v3(urand(P, genv, step, GRX_RNG_RESET_ROOT, 3, -0.5f, 0.5f), urand(P, genv, step, GRX_RNG_RESET_ROOT, 4, -0.5f, 0.5f),
-                    urand(P, genv, step, GRX_RNG_RESET_ROOT, 5, -0.5f, 0.5f));
-        st.ang = v3(urand(P, genv, step, GRX_RNG_RESET_ROOT, 6, -0.5f, 0.5f), urand(P, genv, step, GRX_RNG_RESET_ROOT, 7, -0.5f, 0.5f),
-                    urand(P, genv, step, GRX_RNG_RESET_ROOT, 8, -0.5f, 0.5f));
+        st.vel = v3(lerp_u(rr.root[3], -0.5f, 0.5f), lerp_u(rr.root[4], -0.5f, 0.5f), lerp_u(rr.root[5], -0.5f, 0.5f));
+        st.ang = v3(lerp_u(rr.root[6], -0.5f, 0.5f), lerp_u(rr.root[7], -0.5f, 0.5f), lerp_u(rr.root[8], -0.5f, 0.5f));
     } else {
         st.vel = v3(0.f, 0.f, 0.f);
         st.ang = v3(0.f, 0.f, 0.f);
     }
-    resample_commands(P, genv, step, GRX_RNG_CMD_RESET, ea.cmd);
+    {   // _resample_commands (legged_robot.py:650-677) on the ready draws
+        const float c0 = lerp_u(rr.cmd[0], P.cmd_lin_vel_x[0], P.cmd_lin_vel_x[1]);
+        const float c1 = lerp_u(rr.cmd[1], P.cmd_lin_vel_y[0], P.cmd_lin_vel_y[1]);
+        const float keep = sqrtf(c0 * c0 + c1 * c1) > 0.1f ? 1.0f : 0.0f;
+        ea.cmd[0] = c0 * keep;
+        ea.cmd[1] = c1 * keep;
+        ea.cmd[2] = lerp_u(rr.cmd[2], P.cmd_ang_vel_yaw[0], P.cmd_ang_vel_yaw[1]);
+    }
     st.anchor_on = 0;
 }
 
@@ -917,6 +951,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     __shared__ float4 s_pb[W == 4 ? (LEG * PB4 + 2) * 64 : 1];
     __shared__ float s_anch[W == 4 ? 9 * 64 : 1];     // final friction anchors of the step (wave 2 -> wave 0)
     __shared__ uint32_t s_nz[W == 4 ? NZB * 4 * 64 : 1];   // observation-noise Philox blocks (wave 1 -> wave 0)
+    __shared__ float4 s_rr[W == 4 ? 5 * 64 : 1];           // reset_idx's uniform draws (wave 2 -> wave 0)
     __shared__ float s_rwp[W == 4 ? 64 : 1];               // partial reward (wave 3 -> wave 1)
     __shared__ float s_hp[W == 4 ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
     __shared__ float s_hsum[W == 4 ? 4 * 64 : 1];          // height scan: partial sums per wave
@@ -995,6 +1030,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
                                                               2 * wv + side, nh, s_pri + el * PRS);
                 __syncthreads();   // height scan complete
+            }
+            if (wv == 2) {   // reset_idx's uniform draws, ready before wave 0 knows who resets
+                const ResetRand rr = reset_rand(P, genv, step, side);
+                float4* z = s_rr + lane;
+                z[0 * 64] = f4(rr.dof[0], rr.dof[1], rr.dof[2], rr.dof[3]);
+                z[1 * 64] = f4(rr.dof[4], rr.root[0], rr.root[1], rr.root[2]);
+                z[2 * 64] = f4(rr.root[3], rr.root[4], rr.root[5], rr.root[6]);
+                z[3 * 64] = f4(rr.root[7], rr.root[8], rr.cmd[0], rr.cmd[1]);
+                z[4 * 64] = f4(rr.cmd[2], 0.f, 0.f, 0.f);
+                flag_set(s_flag + FL_RR, 1, lane);
             }
             if (wv == 3) {   // the base / feet half of the reward terms, then half of the observation height block
                 flag_wait(s_flag + FL_REW, 1);
@@ -1224,13 +1269,25 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     const bool writer = act && side == 0;
     GRX_TICK(6);
     // ---- reset_idx (masked, in-kernel)
-    if (reset) {
-        reset_env(P, C, side, genv, step, true, st, ea);
+    if (W == 4 ? __any(reset) : reset) {   // uniform test with four waves: the draws come from wave 2 through LDS
+        ResetRand rr;
+        if (W == 4) {
+            flag_wait(s_flag + FL_RR, 1);
+            const float4* z = s_rr + lane;
+            const float4 z0 = z[0 * 64], z1 = z[1 * 64], z2 = z[2 * 64], z3 = z[3 * 64], z4 = z[4 * 64];
+            rr.dof[0] = z0.x; rr.dof[1] = z0.y; rr.dof[2] = z0.z; rr.dof[3] = z0.w; rr.dof[4] = z1.x;
+            rr.root[0] = z1.y; rr.root[1] = z1.z; rr.root[2] = z1.w; rr.root[3] = z2.x; rr.root[4] = z2.y;
+            rr.root[5] = z2.z; rr.root[6] = z2.w; rr.root[7] = z3.x; rr.root[8] = z3.y;
+            rr.cmd[0] = z3.z; rr.cmd[1] = z3.w; rr.cmd[2] = z4.x;
+        } else rr = reset_rand(P, genv, step, side);
+      if (reset) {
+        reset_env(P, C, side, genv, step, true, st, ea, rr);
 #pragma unroll
         for (int k = 0; k < LEG; ++k) { a_last[k] = 0.f; qd_last[k] = 0.f; }
         air_time = 0.f; land_time = 0.f;
         contact_last = false;
         ep_len = 0;
+      }
     }
     const bool feet_contact_obs = reset ? false : contact;  // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
 
@@ -1441,7 +1498,7 @@ __global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __rest
     ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[(size_t)N + e]; ea.cmd[2] = P.commands[2 * (size_t)N + e];
     ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[(size_t)N + e]; ea.origin[2] = P.origins[2 * (size_t)N + e];
     ea.level = P.levels[e]; ea.type = P.types[e];
-    reset_env(P, C, side, genv, step, false, st, ea);
+    reset_env(P, C, side, genv, step, false, st, ea, reset_rand(P, genv, step, side));
     if (!act) return;
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
