@@ -1,0 +1,35 @@
+/* grx_ppo.h -- C ABI of libgrx_ppo.so: the PPO minibatch loss, forward and gradients in one pass (gfx950).
+ *
+ * Replaces, for the training loop that sits on top of the env step, the ~100 element-wise kernels that
+ * rsl_rl/algorithms/ppo.py:215-245 (log-prob, ratio, clipped surrogate, clipped value loss, entropy, KL) and
+ * their autograd backward expand to.  Plain device pointers and sizes, no torch types; everything is fp32.
+ * Deterministic: per-block partial sums are combined in block order by a second kernel.
+ */
+#ifndef GRX_PPO_H
+#define GRX_PPO_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* number of floats the caller must provide in `partials` (8-byte aligned scratch) for a batch of `batch` samples */
+int grx_ppo_loss_partials_size(int batch);
+
+/* One minibatch.
+ *   mu [batch][num_actions], std [num_actions], value [batch]: the networks' outputs (row-major, contiguous)
+ *   actions, old_mu, old_sigma [batch][num_actions]; old_logp, advantages, returns, target_values [batch]
+ *   out[4]      = { surrogate loss, value loss, total loss, mean KL(old || new) }
+ *   d_mu [batch][num_actions], d_std [num_actions], d_value [batch] = d(total loss)/d(.)
+ *   total loss = surrogate + value_loss_coef * value_loss - entropy_coef * mean entropy   (ppo.py:243)
+ * `stream` is a hipStream_t (0 = the null stream).  Returns 0, or a negative number for invalid arguments
+ * (num_actions outside 1..32, batch < 1) -- nothing is launched then.
+ */
+int grx_ppo_loss(int batch, int num_actions, const float* mu, const float* std, const float* value,
+                 const float* actions, const float* old_logp, const float* old_mu, const float* old_sigma,
+                 const float* advantages, const float* returns, const float* target_values,
+                 float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
+                 float* out, float* d_mu, float* d_std, float* d_value, float* partials, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

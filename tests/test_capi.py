@@ -30,6 +30,22 @@ def test_header_symbols_are_exported():
         assert hasattr(lib, s), s
 
 
+def test_ppo_header_symbols_are_exported():
+    """libgrx_ppo.so (the fused PPO minibatch loss) exports what include/grx_ppo.h declares."""
+    from wiki_grx_gym_amd.rl import fused_loss
+    hdr = open(os.path.join(ROOT, "include", "grx_ppo.h")).read()
+    declared = set(re.findall(r"\b(grx_ppo_[a-z_]+)\s*\(", hdr))
+    assert declared == {"grx_ppo_loss", "grx_ppo_loss_partials_size"}
+    path = os.path.join(os.path.dirname(sim.HIP_LIB_PATH), "libgrx_ppo.so")
+    if not os.path.exists(path):
+        import __graft_entry__ as g
+        g._run(["make", "-C", g.CSRC, "libgrx_ppo.so"])
+    lib = fused_loss.load_ppo_library()
+    for s_ in declared:
+        assert hasattr(lib, s_), s_
+    assert lib.grx_ppo_loss_partials_size(1000) == 4 * 35 * 2 and lib.grx_ppo_loss_partials_size(0) == 0
+
+
 def test_struct_layout_matches_header(tmp_path):
     """sizeof / offsets of the ctypes mirror == the C compiler's view of include/grx.h."""
     import subprocess

@@ -27,9 +27,18 @@ def _build(d, device="cpu"):
 
 
 @pytest.mark.gpu
-def test_device_update_path_matches_reference():
-    """The sync-free HIP update path (device-side adaptive LR, fused Adam, found_inf NaN-skip)."""
+def test_device_update_path_matches_reference(monkeypatch):
+    """The sync-free HIP update path (device-side adaptive LR, fused Adam, found_inf NaN-skip, HIP graph), with the loss
+    spelled in torch so that its rounding is the reference's (see `loose` above)."""
+    monkeypatch.setenv("GRX_PPO_FUSED_LOSS", "0")
     _check_against_reference("cuda")
+
+
+@pytest.mark.gpu
+def test_device_update_path_with_fused_loss_matches_reference():
+    """The default HIP path: the same, with the loss and its gradients from libgrx_ppo.so (tests/test_ppo_gpu.py pins
+    that kernel against the torch expression at 2e-5; here the whole update against the reference's)."""
+    _check_against_reference("cuda", loose=True)
 
 
 @pytest.mark.gpu
@@ -38,6 +47,7 @@ def test_rccl_bucket_path_matches_reference(monkeypatch):
     process group: the collective is an identity, so the result must still equal the reference's update."""
     import torch.distributed as dist
     monkeypatch.setenv("GRX_PPO_FORCE_BUCKET", "1")
+    monkeypatch.setenv("GRX_PPO_FUSED_LOSS", "0")
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29631", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         _check_against_reference("cuda")
@@ -49,7 +59,7 @@ def test_rollout_returns_and_update_match_reference():
     _check_against_reference("cpu")
 
 
-def _check_against_reference(device):
+def _check_against_reference(device, loose=False):
     d = np.load(os.path.join(G, "ppo.npz"))
     ac, alg, N, T = _build(d, device)
     assert sorted(ac.state_dict()) == sorted(k[3:] for k in d.files if k.startswith("w0_"))   # checkpoint key layout
@@ -79,11 +89,16 @@ def _check_against_reference(device):
         vl, sl = alg.update()
     finally:
         torch.randperm = orig_rp
-    assert vl == pytest.approx(float(d["value_loss"]), rel=1e-4)
-    assert sl == pytest.approx(float(d["surrogate_loss"]), rel=1e-4, abs=1e-6)
+    # loose: in the 7th of the 8 minibatch steps of this fixture one sample's probability ratio sits 9 ulp below the
+    # upper clip bound 1 + clip_param, where the surrogate's gradient jumps from -A to 0.  An implementation whose
+    # log-prob rounds differently in the last bit (the fused HIP loss sums the ten action terms in another order than
+    # torch) lands on the other side for that sample; both are correct, but the last step then differs at 1e-3.
+    assert vl == pytest.approx(float(d["value_loss"]), rel=1e-3 if loose else 1e-4)
+    assert sl == pytest.approx(float(d["surrogate_loss"]), rel=5e-3 if loose else 1e-4, abs=1e-6)
     assert alg.learning_rate == pytest.approx(float(d["lr_after"]), rel=1e-6)   # the device path keeps the LR in fp32
     for k, v in ac.state_dict().items():
-        np.testing.assert_allclose(v.detach().cpu().numpy(), d["w1_" + k], rtol=2e-4 if device == "cuda" else 1e-4, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(v.detach().cpu().numpy(), d["w1_" + k], rtol=2e-4 if device == "cuda" else 1e-4,
+                                   atol=2.5e-3 if loose else 2e-6, err_msg=k)   # loose: one Adam step at lr 1e-3
 
 
 def test_checkpoint_roundtrip_and_std_quirk(tmp_path):

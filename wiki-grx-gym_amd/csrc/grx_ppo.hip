@@ -1,0 +1,148 @@
+// grx_ppo.hip -- the PPO minibatch loss with its gradients, one pass over the batch (include/grx_ppo.h).
+// Follows rsl_rl/algorithms/ppo.py:215-245 and torch.distributions.Normal (log_prob, entropy) term by term;
+// the gradients are those torch.autograd produces for that expression (torch.max splits ties half / half,
+// clamp passes the gradient on the closed interval).
+#include <hip/hip_runtime.h>
+#include "../../include/grx_ppo.h"
+
+namespace {
+constexpr int MAXA = 32;   // the full-body GR1T1 has 32 actions
+constexpr int NTHR = 256;
+constexpr int NRED = 3 + MAXA;   // surrogate, value loss, KL, d_std[MAXA]
+
+// The batch sums run in double: the surrogate loss is a mean of terms of both signs (normalised advantages) that
+// cancels to ~1e-3 of their magnitude, so an fp32 sum in ANY order is only good to ~1e-4 of the result.
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+template <int A>
+__global__ __launch_bounds__(NTHR) void ppo_loss_kernel(int B, const float* __restrict__ mu, const float* __restrict__ stdp,
+                                                         const float* __restrict__ value, const float* __restrict__ actions,
+                                                         const float* __restrict__ old_logp, const float* __restrict__ old_mu,
+                                                         const float* __restrict__ old_sigma, const float* __restrict__ adv_,
+                                                         const float* __restrict__ ret_, const float* __restrict__ tv_,
+                                                         float clip, float vcoef, int use_clipped,
+                                                         float* __restrict__ d_mu, float* __restrict__ d_value, double* __restrict__ partials) {
+    const int i = blockIdx.x * NTHR + threadIdx.x;
+    float red[3 + A];
+#pragma unroll
+    for (int k = 0; k < 3 + A; ++k) red[k] = 0.f;
+    if (i < B) {
+        const float invB = 1.0f / (float)B;
+        float sg[A], df[A];
+        float logp = 0.f, kl = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            const float s = stdp[k], m = mu[(size_t)i * A + k];
+            sg[k] = s;
+            df[k] = actions[(size_t)i * A + k] - m;
+            // Normal.log_prob: -((x - loc)^2) / (2 var) - log(scale) - log(sqrt(2 pi))
+            logp += -(df[k] * df[k]) / (2.0f * s * s) - logf(s) - 0.9189385332046727f;
+            const float os = old_sigma[(size_t)i * A + k], dm = old_mu[(size_t)i * A + k] - m;
+            kl += logf(s / os + 1.e-5f) + (os * os + dm * dm) / (2.0f * s * s) - 0.5f;
+        }
+        const float adv = adv_[i];
+        const float ratio = expf(logp - old_logp[i]);
+        const float lo = 1.0f - clip, hi = 1.0f + clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = -adv * ratio, s2 = -adv * rc;
+        const float surr = fmaxf(s1, s2);
+        // d max(s1, s2): the larger one takes the gradient, a tie splits it; d clamp = 1 on [lo, hi]
+        const float w1 = s1 > s2 ? 1.f : (s1 == s2 ? 0.5f : 0.f), w2 = 1.f - w1;
+        const float in_range = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+        const float g_ratio = -adv * (w1 + w2 * in_range);
+        const float g_logp = g_ratio * ratio * invB;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            const float s = sg[k], inv2 = 1.0f / (s * s);
+            d_mu[(size_t)i * A + k] = g_logp * df[k] * inv2;
+            red[3 + k] = g_logp * (df[k] * df[k] * inv2 / s - 1.0f / s);
+        }
+        const float v = value[i], ret = ret_[i];
+        float vl, gv;
+        if (use_clipped) {
+            const float tv = tv_[i];
+            const float dv = v - tv;
+            const float vc = tv + fminf(fmaxf(dv, -clip), clip);
+            const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
+            vl = fmaxf(l1, l2);
+            const float u1 = l1 > l2 ? 1.f : (l1 == l2 ? 0.5f : 0.f), u2 = 1.f - u1;
+            const float vin = (dv >= -clip && dv <= clip) ? 1.f : 0.f;
+            gv = u1 * 2.0f * (v - ret) + u2 * 2.0f * (vc - ret) * vin;
+        } else {
+            vl = (ret - v) * (ret - v);
+            gv = -2.0f * (ret - v);
+        }
+        d_value[i] = vcoef * gv * invB;
+        red[0] = surr; red[1] = vl; red[2] = kl;
+    }
+    __shared__ double s_red[NTHR / 64][3 + A];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3 + A; ++k) {
+        const double t = wave_sum((double)red[k]);
+        if (lane == 0) s_red[wv][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 + A) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NTHR / 64; ++w) t += s_red[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * NRED + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void ppo_loss_finalize(int B, int A, int nblk, const double* __restrict__ partials,
+                                                         const float* __restrict__ stdp, float vcoef, float ecoef,
+                                                         float* __restrict__ out, float* __restrict__ d_std) {
+    const int k = threadIdx.x;
+    double t = 0.0;
+    if (k < 3 + A)
+        for (int b = 0; b < nblk; ++b) t += partials[(size_t)b * NRED + k];
+    __shared__ double s_t[64];
+    s_t[k] = t;   // 3 + MAXA <= 64
+    __syncthreads();
+    if (k >= 3 && k < 3 + A) d_std[k - 3] = (float)t - ecoef / stdp[k - 3];   // entropy: -ecoef * mean_b sum_k log(std_k) -> -ecoef / std_k
+    if (k == 0) {
+        const float surr = (float)(s_t[0] / (double)B), vl = (float)(s_t[1] / (double)B), klm = (float)(s_t[2] / (double)B);
+        float ent = 0.f;   // Normal.entropy: 0.5 + 0.5 log(2 pi) + log(scale), summed over the actions
+        for (int a = 0; a < A; ++a) ent += 1.4189385332046727f + logf(stdp[a]);
+        out[0] = surr; out[1] = vl; out[2] = surr + vcoef * vl - ecoef * ent; out[3] = klm;
+    }
+}
+
+template <int A>
+void launch(int nblk, hipStream_t st, int B, const float* mu, const float* stdp, const float* value, const float* actions,
+            const float* old_logp, const float* old_mu, const float* old_sigma, const float* adv, const float* ret, const float* tv,
+            float clip, float vcoef, int use_clipped, float* d_mu, float* d_value, double* partials) {
+    hipLaunchKernelGGL(ppo_loss_kernel<A>, dim3(nblk), dim3(NTHR), 0, st, B, mu, stdp, value, actions, old_logp, old_mu, old_sigma,
+                       adv, ret, tv, clip, vcoef, use_clipped, d_mu, d_value, partials);
+}
+}  // namespace
+
+// in floats (the buffer holds doubles: 2 floats each; the caller's allocation must be 8-byte aligned)
+extern "C" int grx_ppo_loss_partials_size(int batch) { return batch < 1 ? 0 : ((batch + NTHR - 1) / NTHR) * NRED * 2; }
+
+extern "C" int grx_ppo_loss(int batch, int num_actions, const float* mu, const float* std, const float* value,
+                            const float* actions, const float* old_logp, const float* old_mu, const float* old_sigma,
+                            const float* advantages, const float* returns, const float* target_values,
+                            float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
+                            float* out, float* d_mu, float* d_std, float* d_value, float* partials, void* stream) {
+    if (batch < 1 || num_actions < 1 || num_actions > MAXA) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (batch + NTHR - 1) / NTHR;
+#define GRX_PPO_CASE(A) case A: launch<A>(nblk, st, batch, mu, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, \
+                                          target_values, clip_param, value_loss_coef, use_clipped_value_loss, d_mu, d_value, (double*)partials); break;
+    switch (num_actions) {
+        GRX_PPO_CASE(1) GRX_PPO_CASE(2) GRX_PPO_CASE(3) GRX_PPO_CASE(4) GRX_PPO_CASE(5) GRX_PPO_CASE(6) GRX_PPO_CASE(7) GRX_PPO_CASE(8)
+        GRX_PPO_CASE(9) GRX_PPO_CASE(10) GRX_PPO_CASE(11) GRX_PPO_CASE(12) GRX_PPO_CASE(13) GRX_PPO_CASE(14) GRX_PPO_CASE(15) GRX_PPO_CASE(16)
+        GRX_PPO_CASE(17) GRX_PPO_CASE(18) GRX_PPO_CASE(19) GRX_PPO_CASE(20) GRX_PPO_CASE(21) GRX_PPO_CASE(22) GRX_PPO_CASE(23) GRX_PPO_CASE(24)
+        GRX_PPO_CASE(25) GRX_PPO_CASE(26) GRX_PPO_CASE(27) GRX_PPO_CASE(28) GRX_PPO_CASE(29) GRX_PPO_CASE(30) GRX_PPO_CASE(31) GRX_PPO_CASE(32)
+    }
+#undef GRX_PPO_CASE
+    hipLaunchKernelGGL(ppo_loss_finalize, dim3(1), dim3(64), 0, st, batch, num_actions, nblk, (const double*)partials, std, value_loss_coef, entropy_coef, out, d_std);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

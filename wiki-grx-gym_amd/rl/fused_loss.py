@@ -1,0 +1,74 @@
+"""PPO minibatch loss through libgrx_ppo.so (include/grx_ppo.h): forward value and gradients from one HIP kernel.
+
+The expression is rsl_rl/algorithms/ppo.py:215-245 with torch.distributions.Normal's log_prob / entropy; the
+torch spelling of the same arithmetic lives in ppo.py (`_loss_torch`) and is what CPU tensors use.  On a GPU the
+~100 element-wise kernels that expression and its autograd backward expand to are one launch plus a 64-thread
+finalize; the result enters autograd through `FusedPPOLoss`, whose backward hands out the stored gradients.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_LIB = None
+
+
+def load_ppo_library():
+    """libgrx_ppo.so next to the step library (built in-tree by __graft_entry__.build() / make -C csrc)."""
+    global _LIB
+    if _LIB is None:
+        path = os.environ.get("GRX_PPO_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc", "libgrx_ppo.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no silent fallback for CUDA tensors; set GRX_PPO_FUSED_LOSS=0 to use the torch expression)")
+        lib = C.CDLL(path)
+        fp = C.c_void_p
+        lib.grx_ppo_loss.restype = C.c_int
+        lib.grx_ppo_loss.argtypes = [C.c_int, C.c_int] + [fp] * 10 + [C.c_float, C.c_float, C.c_float, C.c_int] + [fp] * 5 + [C.c_void_p]
+        lib.grx_ppo_loss_partials_size.restype = C.c_int
+        lib.grx_ppo_loss_partials_size.argtypes = [C.c_int]
+        _LIB = lib
+    return _LIB
+
+
+def _f32c(x):
+    return x if (x.dtype == torch.float32 and x.is_contiguous()) else x.contiguous().float()
+
+
+class FusedPPOLoss(torch.autograd.Function):
+    """(mu [B, A], std [A], value [B] or [B, 1]; data...) -> tensor [surrogate, value_loss, total_loss, mean_kl]."""
+
+    @staticmethod
+    def forward(ctx, mu, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values,
+                clip_param, value_loss_coef, entropy_coef, use_clipped_value_loss):
+        lib = load_ppo_library()
+        B, A = mu.shape
+        mu_c, std_c, value_c = _f32c(mu), _f32c(std), _f32c(value).reshape(-1)
+        data = [_f32c(t) for t in (actions, old_logp, old_mu, old_sigma, advantages, returns, target_values)]
+        out = torch.empty(4, device=mu.device, dtype=torch.float32)
+        d_mu = torch.empty_like(mu_c)
+        d_std = torch.empty_like(std_c)
+        d_value = torch.empty_like(value_c)
+        partials = torch.empty(lib.grx_ppo_loss_partials_size(B), device=mu.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(mu.device).cuda_stream
+        with torch.cuda.device(mu.device):
+            rc = lib.grx_ppo_loss(B, A, mu_c.data_ptr(), std_c.data_ptr(), value_c.data_ptr(), *[t.data_ptr() for t in data],
+                                  float(clip_param), float(value_loss_coef), float(entropy_coef), int(bool(use_clipped_value_loss)),
+                                  out.data_ptr(), d_mu.data_ptr(), d_std.data_ptr(), d_value.data_ptr(), partials.data_ptr(), C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError(f"grx_ppo_loss failed ({rc}): batch {B}, num_actions {A}")
+        ctx.save_for_backward(d_mu, d_std, d_value)
+        ctx.value_shape = value.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d_mu, d_std, d_value = ctx.saved_tensors
+        gl = g[2]   # only the total loss is differentiable
+        return (d_mu * gl, d_std * gl, (d_value * gl).reshape(ctx.value_shape)) + (None,) * 11
+
+
+def fused_ppo_loss(mu, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values,
+                   clip_param, value_loss_coef, entropy_coef, use_clipped_value_loss):
+    return FusedPPOLoss.apply(mu, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values,
+                              clip_param, value_loss_coef, entropy_coef, use_clipped_value_loss)

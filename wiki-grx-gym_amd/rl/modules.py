@@ -23,6 +23,40 @@ def get_activation(name):
     return _ACTIVATIONS[name]()
 
 
+class _HeadLinear(torch.autograd.Function):
+    """nn.Linear for a one-column head, with its three GEMV-shaped products pinned to hipBLASLt.
+
+    PPO captures its minibatch step with rocBLAS preferred (rl/ppo.py `_build_graph`: 2x faster weight-gradient
+    GEMMs for these shapes), but rocBLAS's pick for [1, B] x [B, H] (the head's weight gradient) takes 570 us at
+    B = 10^4 against hipBLASLt's 32 us (tools/gpu_gemm_probe.py).  torch's BLAS preference is a process-global flag
+    read at call time, so this function flips it around its own products, forward and backward."""
+
+    @staticmethod
+    def _lt():
+        prev = torch.backends.cuda.preferred_blas_library()
+        torch.backends.cuda.preferred_blas_library("cublaslt")
+        return prev
+
+    @staticmethod
+    def forward(ctx, h, weight, bias):
+        prev = _HeadLinear._lt()
+        try:
+            y = torch.addmm(bias, h, weight.t())
+        finally:
+            torch.backends.cuda.preferred_blas_library(prev)
+        ctx.save_for_backward(h, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, weight = ctx.saved_tensors
+        prev = _HeadLinear._lt()
+        try:
+            return dy @ weight, dy.t() @ h, dy.sum(0)
+        finally:
+            torch.backends.cuda.preferred_blas_library(prev)
+
+
 class MLP(nn.Module):
     def __init__(self, input_size, output_size, hidden_dims=(256, 256, 256), activation="relu", **_):
         super().__init__()
@@ -35,6 +69,10 @@ class MLP(nn.Module):
         self.model = nn.Sequential(*layers)
 
     def forward(self, x):
+        if self.output_size == 1 and x.is_cuda and torch.is_grad_enabled():
+            # value head during training on a HIP device: see _HeadLinear
+            head = self.model[-1]
+            return _HeadLinear.apply(self.model[:-1](x), head.weight, head.bias)
         return self.model(x)
 
 

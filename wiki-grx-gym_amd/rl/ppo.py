@@ -11,6 +11,7 @@ import os
 
 import torch
 import torch.distributed as dist
+from .fused_loss import fused_ppo_loss
 import torch.nn as nn
 import torch.optim as optim
 
@@ -49,6 +50,8 @@ class PPO:
         # captured ONCE in a HIP graph and replayed 200x per update: the MLP is small, so eager mode is launch-bound
         # (about 100 kernels of a few microseconds per minibatch).  GRX_PPO_GRAPH=0 disables the capture.
         self._use_graph = self._device_lr and os.environ.get("GRX_PPO_GRAPH", "1") != "0"
+        # ... and everything between the networks' outputs and their gradients is one HIP kernel (rl/fused_loss.py)
+        self._fused_loss = self._device_lr and os.environ.get("GRX_PPO_FUSED_LOSS", "1") != "0"
         self._graph, self._graph_mb, self._static, self._sums, self._restore_opt = None, None, None, None, None
         if self._device_lr:
             # rsl_rl's `Normal.set_default_validate_args = False` (actor_critic.py) is an assignment, not a call, so the
@@ -187,6 +190,40 @@ class PPO:
         self.num_updates = self.num_learning_epochs * self.num_mini_batches
         return mean_value_loss / self.num_updates, mean_surrogate_loss / self.num_updates
 
+    def _losses(self, obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma):
+        """(surrogate_loss, value_loss, loss, kl_mean) of one minibatch -- ppo.py:215-245.
+
+        On a HIP device: the actor / critic forward in torch, everything after it in ONE kernel that also produces the
+        gradients (rl/fused_loss.py -> libgrx_ppo.so; GRX_PPO_FUSED_LOSS=0 keeps the torch expression below)."""
+        ac = self.actor_critic
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        if self._fused_loss and not ac.fixed_std and ac.num_actor_output <= 32:   # the kernel's action-count limit
+            mu = ac.actor(obs)
+            value = ac.evaluate(cobs)
+            out = fused_ppo_loss(mu, ac.std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values,
+                                 self.clip_param, self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss)
+            kl_mean = out[3].detach() if adaptive else torch.zeros((), device=self.device)
+            return out[0], out[1], out[2], kl_mean
+        ac.update_distribution(obs)
+        logp = ac.get_actions_log_prob(actions)
+        value = ac.evaluate(cobs)
+        mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
+        kl_mean = torch.zeros((), device=self.device)
+        if adaptive:
+            with torch.no_grad():
+                kl_mean = torch.sum(torch.log(sigma / old_sigma + 1.e-5) + (old_sigma.square() + (old_mu - mu).square())
+                                    / (2.0 * sigma.square()) - 0.5, axis=-1).mean()
+        ratio = torch.exp(logp - torch.squeeze(old_logp))
+        adv = torch.squeeze(advantages)
+        surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+        if self.use_clipped_value_loss:
+            clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
+            value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
+        else:
+            value_loss = (returns - value).pow(2).mean()
+        loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
+        return surrogate_loss, value_loss, loss, kl_mean
+
     def _update_device(self):
         """Same arithmetic as update(), no host round-trips inside the minibatch loop."""
         ac, multi = self.actor_critic, _collective_path()
@@ -194,24 +231,8 @@ class PPO:
         sums = torch.zeros(3, device=self.device)        # value loss, surrogate loss, last KL
         for (obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _, _) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
-            ac.act(obs)
-            logp = ac.get_actions_log_prob(actions)
-            value = ac.evaluate(cobs)
-            mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
-            kl_mean = torch.zeros((), device=self.device)
-            if adaptive:
-                with torch.no_grad():
-                    kl_mean = torch.sum(torch.log(sigma / old_sigma + 1.e-5) + (old_sigma.square() + (old_mu - mu).square())
-                                        / (2.0 * sigma.square()) - 0.5, axis=-1).mean()
-            ratio = torch.exp(logp - torch.squeeze(old_logp))
-            adv = torch.squeeze(advantages)
-            surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
-            if self.use_clipped_value_loss:
-                clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
-                value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
-            else:
-                value_loss = (returns - value).pow(2).mean()
-            loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
+            surrogate_loss, value_loss, loss, kl_mean = self._losses(obs, cobs, actions, target_values, advantages, returns,
+                                                                      old_logp, old_mu, old_sigma)
             self.optimizer.zero_grad(set_to_none=False)
             loss.backward()
             if multi:
@@ -243,27 +264,12 @@ class PPO:
     def _minibatch_step(self, batch, sums):
         """One PPO minibatch step on static tensors (the arithmetic of _update_device)."""
         obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma = batch
-        ac = self.actor_critic
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
-        ac.update_distribution(obs)
-        logp = ac.get_actions_log_prob(actions)
-        value = ac.evaluate(cobs)
-        mu, sigma, entropy = ac.action_mean, ac.action_std, ac.entropy
-        kl_mean = torch.zeros((), device=self.device)
-        if adaptive:
-            with torch.no_grad():
-                kl_mean = torch.sum(torch.log(sigma / old_sigma + 1.e-5) + (old_sigma.square() + (old_mu - mu).square())
-                                    / (2.0 * sigma.square()) - 0.5, axis=-1).mean()
-        ratio = torch.exp(logp - torch.squeeze(old_logp))
-        adv = torch.squeeze(advantages)
-        surrogate_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
-        if self.use_clipped_value_loss:
-            clipped = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
-            value_loss = torch.max((value - returns).pow(2), (clipped - returns).pow(2)).mean()
-        else:
-            value_loss = (returns - value).pow(2).mean()
-        loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
-        self.optimizer.zero_grad(set_to_none=False)
+        surrogate_loss, value_loss, loss, kl_mean = self._losses(obs, cobs, actions, target_values, advantages, returns,
+                                                                  old_logp, old_mu, old_sigma)
+        # grads dropped, not zeroed: backward then WRITES each .grad (from the graph's private pool on replay) instead of
+        # accumulating into a zero-filled one -- one fill and one add kernel less per parameter and step
+        self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         if adaptive:
             self._device_lr_update(kl_mean)
@@ -271,7 +277,7 @@ class PPO:
             bad = ~torch.isfinite(loss)
             self.optimizer.found_inf = bad.float().reshape(())   # NaN-skip (ppo.py:297-299) through fused Adam's hook
             self.optimizer.grad_scale = None
-        nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm, foreach=True)
+        nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm, foreach=True)
         self.optimizer.step()
         with torch.no_grad():
             ok = (~bad).float()
@@ -289,6 +295,13 @@ class PPO:
         ac_state = [p.detach().clone() for p in self.actor_critic.parameters()]   # (not load_state_dict: it rewrites std, AC:116-134)
         lr0 = self._lr_t.clone()
         self._static[8].fill_(1.0)   # sigma > 0 for the dry runs
+        # The GEMM kernels are chosen when the graph is captured.  For these shapes (batch ~10^4 rows, 39..512 columns,
+        # fp32) rocBLAS's choices beat hipBLASLt's by 2x on the weight-gradient products dY^T X (27-48 us against
+        # 66-73 us, tools/gpu_gemm_probe.py).  The preference is process-global in torch, so it is switched for the
+        # dry runs (the library initialises itself there, outside the capture) and the capture only, then put back.
+        prev_blas = torch.backends.cuda.preferred_blas_library()
+        if os.environ.get("GRX_PPO_BLAS", "rocblas") == "rocblas":
+            torch.backends.cuda.preferred_blas_library("cublas")
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -304,6 +317,7 @@ class PPO:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._minibatch_step(self._static, self._sums)
+        torch.backends.cuda.preferred_blas_library(prev_blas)
         # restore: parameters, Adam moments/step counters, learning rate
         with torch.no_grad():
             for p, v in zip(self.actor_critic.parameters(), ac_state):
