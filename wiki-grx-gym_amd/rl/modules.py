@@ -68,11 +68,15 @@ class MLP(nn.Module):
         layers.append(nn.Linear(dims[-1], output_size))
         self.model = nn.Sequential(*layers)
 
+    @torch.jit.unused
+    def _forward_pinned_head(self, x):
+        head = self.model[-1]
+        return _HeadLinear.apply(self.model[:-1](x), head.weight, head.bias)
+
     def forward(self, x):
-        if self.output_size == 1 and x.is_cuda and torch.is_grad_enabled():
-            # value head during training on a HIP device: see _HeadLinear
-            head = self.model[-1]
-            return _HeadLinear.apply(self.model[:-1](x), head.weight, head.bias)
+        if not torch.jit.is_scripting():   # (export_policy_as_jit scripts this module: the plain path)
+            if self.output_size == 1 and x.is_cuda and torch.is_grad_enabled():
+                return self._forward_pinned_head(x)   # value head during training on a HIP device: see _HeadLinear
         return self.model(x)
 
 
