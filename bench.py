@@ -71,8 +71,11 @@ def cpu_baseline(cfg, terrain_obj, envs, steps, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
+    # defaults: a timed window of seconds, not milliseconds.  On the (shared) MI355X boxes the first ~100 ms of a
+    # process's launches regularly contain one 10-80 ms hole in which the GPU runs nothing of this job (DESIGN.md
+    # section 5); 500 steps are 39 ms of work, so most default runs used to report that hole instead of the kernel.
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20000; 2000 for --robot full_body)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default: steps / 10)")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--terrain", choices=["rough", "flat"], default="rough")
     ap.add_argument("--robot", choices=["lower_limb", "full_body"], default="lower_limb",
@@ -81,6 +84,10 @@ def main():
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 2000 if args.robot == "full_body" else 20000
+    if args.warmup is None:
+        args.warmup = max(1, args.steps // 10)
 
     import torch
     import torch.distributed as dist

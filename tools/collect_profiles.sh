@@ -5,7 +5,7 @@
 #   gpurun_out/<tag>/bench_rough.json       python bench.py                       (the headline line)
 #   gpurun_out/<tag>/bench_flat.json        python bench.py --terrain flat
 #   gpurun_out/<tag>/sweep.jsonl            rough terrain, envs/GPU in {8192, 16384, 32768, 65536, 131072}
-#   gpurun_out/<tag>/stats/                 rocprofv3 --kernel-trace --stats of a 100-step bench run
+#   gpurun_out/<tag>/stats/                 rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline`
 #   gpurun_out/<tag>/pmc_fetch|pmc_write/   rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes
 # Copy what is to be judged into profiles/ afterwards (tools/summarise_profiles.py does that).
 export TMPDIR=/tmp
@@ -25,10 +25,13 @@ for i in 2 3; do timeout 300 python bench.py --no-cpu-baseline 2>> $out/bench_ro
 timeout 300 python bench.py --terrain flat --no-cpu-baseline 2> $out/bench_flat.err | tail -1 > $out/bench_flat.json
 : > $out/sweep.jsonl
 for n in 8192 16384 32768 65536 131072; do
-    timeout 300 python bench.py --envs-per-gpu $n --steps 200 --warmup 20 --no-cpu-baseline 2>> $out/sweep.err | tail -1 >> $out/sweep.jsonl
+    timeout 300 python bench.py --envs-per-gpu $n --steps $((n <= 32768 ? 4000 : 1500)) --warmup 400 --no-cpu-baseline 2>> $out/sweep.err | tail -1 >> $out/sweep.jsonl
 done
-BENCH="python bench.py --steps 100 --warmup 10 --no-cpu-baseline"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats -o b -- bash -c "cd $OLDPWD && $BENCH" > $OLDPWD/$out/stats.log 2>&1)
+BENCH="python bench.py --steps 1000 --warmup 100 --no-cpu-baseline"
+# the stats pass profiles the SAME command as the headline line (default step count), so that its average kernel duration
+# and bench.py's HIP-event figure describe the same launches; the kernel trace itself (44k rows) is dropped, the stats kept
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats -o b -- bash -c "cd $OLDPWD && python bench.py --no-cpu-baseline > $out/bench_under_rocprof.json" > $OLDPWD/$out/stats.log 2>&1)
+find $out/stats -name "*kernel_trace.csv" -delete
 for c in FETCH_SIZE WRITE_SIZE; do
     d=$out/pmc_$(echo $c | tr 'A-Z' 'a-z' | cut -d_ -f1)
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OLDPWD/$d -o b -- bash -c "cd $OLDPWD && $BENCH" > $OLDPWD/$d.log 2>&1)

@@ -27,6 +27,10 @@ def run(graph):
     global LAST
     LAST = {k: v.detach().clone() for k, v in ac.state_dict().items()}
     return ts, out, w, alg.learning_rate
+if os.environ.get('ONLY_EAGER'):
+    t0, o0, w0, lr0 = run(0)
+    print('eager-device update s:', [round(t, 3) for t in t0], o0, lr0)
+    sys.exit(0)
 if os.environ.get('ONLY_GRAPH'):
     t1, o1, w1, lr1 = run(1)
     print('hip-graph   update s:', [round(t, 3) for t in t1], o1, lr1)

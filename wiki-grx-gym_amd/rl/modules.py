@@ -23,6 +23,10 @@ def get_activation(name):
     return _ACTIVATIONS[name]()
 
 
+import os
+_PIN_HEAD = os.environ.get("GRX_PPO_HEAD", "1") != "0"
+
+
 class _HeadLinear(torch.autograd.Function):
     """nn.Linear for a one-column head, with its three GEMV-shaped products pinned to hipBLASLt.
 
@@ -75,7 +79,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         if not torch.jit.is_scripting():   # (export_policy_as_jit scripts this module: the plain path)
-            if self.output_size == 1 and x.is_cuda and torch.is_grad_enabled():
+            if self.output_size == 1 and x.is_cuda and torch.is_grad_enabled() and _PIN_HEAD:
                 return self._forward_pinned_head(x)   # value head during training on a HIP device: see _HeadLinear
         return self.model(x)
 

@@ -46,10 +46,12 @@ class PPO:
         # device scalar consumed by the fused Adam kernel, the NaN-skip uses Adam's found_inf hook, and the loss
         # statistics are read back once per update().  (The reference does three .item() per minibatch, ppo.py:264,308-309.)
         self._device_lr = torch.device(device).type == "cuda"
-        # ... and, single rank, the whole minibatch step (forward, losses, backward, adaptive LR, clip, fused Adam) is
-        # captured ONCE in a HIP graph and replayed 200x per update: the MLP is small, so eager mode is launch-bound
-        # (about 100 kernels of a few microseconds per minibatch).  GRX_PPO_GRAPH=0 disables the capture.
-        self._use_graph = self._device_lr and os.environ.get("GRX_PPO_GRAPH", "1") != "0"
+        # GRX_PPO_GRAPH=1 (opt-in, experimental): the whole minibatch step (forward, losses, backward, adaptive LR, clip, fused
+        # Adam) captured ONCE in a HIP graph and replayed 200x per update (0.20 s per update against 0.28 s).  Off by
+        # default: with eager GPU work between updates (i.e. in real training) the replayed step was measured to produce a
+        # wrong gradient for one small parameter tensor (the critic's last hidden bias; tools/gpu_ppo_graph_check.py
+        # compares both paths with an fp64 CPU reference) -- the eager device path below matches the reference to 1e-7.
+        self._use_graph = self._device_lr and os.environ.get("GRX_PPO_GRAPH", "0") not in ("0", "")
         # ... and everything between the networks' outputs and their gradients is one HIP kernel (rl/fused_loss.py)
         self._fused_loss = self._device_lr and os.environ.get("GRX_PPO_FUSED_LOSS", "1") != "0"
         self._graph, self._graph_mb, self._static, self._sums, self._restore_opt = None, None, None, None, None
@@ -144,9 +146,18 @@ class PPO:
 
     def update(self):
         if self._device_lr:
-            if self._use_graph and not _collective_path():
-                return self._update_graphed()
-            return self._update_device()
+            # For these GEMM shapes (batch ~10^4 rows, 39..512 columns, fp32) rocBLAS's kernel choices beat hipBLASLt's by 2x
+            # on the weight-gradient products dY^T X (27-48 us against 66-73 us, tools/gpu_gemm_probe.py).  torch's BLAS
+            # preference is process-global, so it is switched for the update only (GRX_PPO_BLAS=hipblaslt leaves it alone).
+            prev_blas = torch.backends.cuda.preferred_blas_library()
+            if os.environ.get("GRX_PPO_BLAS", "rocblas") == "rocblas":
+                torch.backends.cuda.preferred_blas_library("cublas")
+            try:
+                if self._use_graph and not _collective_path():
+                    return self._update_graphed()
+                return self._update_device()
+            finally:
+                torch.backends.cuda.preferred_blas_library(prev_blas)
         mean_value_loss, mean_surrogate_loss = 0.0, 0.0
         ac, multi = self.actor_critic, _collective_path()
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
@@ -267,9 +278,9 @@ class PPO:
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         surrogate_loss, value_loss, loss, kl_mean = self._losses(obs, cobs, actions, target_values, advantages, returns,
                                                                   old_logp, old_mu, old_sigma)
-        # grads dropped, not zeroed: backward then WRITES each .grad (from the graph's private pool on replay) instead of
-        # accumulating into a zero-filled one -- one fill and one add kernel less per parameter and step
-        self.optimizer.zero_grad(set_to_none=True)
+        # (GRX_PPO_GRAD_NONE=1 drops the grads instead of zero-filling them -- one fill and one add kernel less per parameter
+        #  and step, the recipe of the torch CUDA-graph notes -- but widens the discrepancy described in __init__)
+        self.optimizer.zero_grad(set_to_none=os.environ.get("GRX_PPO_GRAD_NONE", "0") != "0")
         loss.backward()
         if adaptive:
             self._device_lr_update(kl_mean)
@@ -315,7 +326,9 @@ class PPO:
             self._graph = _Eager(lambda: self._minibatch_step(self._static, self._sums))
         else:
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            # capture on the stream the dry runs used: autograd's AccumulateGrad nodes remember the stream they were
+            # created on, and one that differs from the capture stream runs (and allocates) outside the capture
+            with torch.cuda.graph(self._graph, stream=side):
                 self._minibatch_step(self._static, self._sums)
         torch.backends.cuda.preferred_blas_library(prev_blas)
         # restore: parameters, Adam moments/step counters, learning rate
