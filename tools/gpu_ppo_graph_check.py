@@ -3,7 +3,9 @@ with a synthetic rollout (alg.act / process_env_step / compute_returns) between 
 clipped gradients of the first minibatch step of the second update.  Finding (round 1): with eager GPU work between the
 updates the replayed step's gradient of critic.model.4.bias is wrong (error = its magnitude) while every other tensor
 matches the reference to 1e-7 -- hence the graph path is off by default.  MODE=alloc|act|rng|full selects the activity
-between updates; GRX_PPO_FUSED_LOSS / GRX_PPO_GRAD_NONE / GRX_PPO_BLAS / GRX_PPO_HEAD select the variant."""
+between updates; GRX_PPO_FUSED_LOSS / GRX_PPO_GRAD_NONE / GRX_PPO_GRAD_MODE=functional (autograd.grad + copies instead of backward) /
+GRX_PPO_BLAS / GRX_PPO_HEAD select the variant -- all of them show it, so neither AccumulateGrad nor the BLAS library nor
+the fused loss is the cause; the reduction that produces that bias gradient is the remaining suspect."""
 import sys, os; sys.path.insert(0, ".")
 import torch
 from wiki_grx_gym_amd.rl.modules import ActorCriticMLP

@@ -55,6 +55,7 @@ class PPO:
         # ... and everything between the networks' outputs and their gradients is one HIP kernel (rl/fused_loss.py)
         self._fused_loss = self._device_lr and os.environ.get("GRX_PPO_FUSED_LOSS", "1") != "0"
         self._graph, self._graph_mb, self._static, self._sums, self._restore_opt = None, None, None, None, None
+        self._grad_bufs = None
         if self._device_lr:
             # rsl_rl's `Normal.set_default_validate_args = False` (actor_critic.py) is an assignment, not a call, so the
             # reference validates (and host-syncs) on every Normal(); here the validation really is off
@@ -280,8 +281,19 @@ class PPO:
                                                                   old_logp, old_mu, old_sigma)
         # (GRX_PPO_GRAD_NONE=1 drops the grads instead of zero-filling them -- one fill and one add kernel less per parameter
         #  and step, the recipe of the torch CUDA-graph notes -- but widens the discrepancy described in __init__)
-        self.optimizer.zero_grad(set_to_none=os.environ.get("GRX_PPO_GRAD_NONE", "0") != "0")
-        loss.backward()
+        if os.environ.get("GRX_PPO_GRAD_MODE", "") == "functional":
+            # gradients as plain outputs of autograd.grad, copied into persistent .grad buffers: no AccumulateGrad nodes
+            # (they run on the stream they were created on) inside the captured region
+            params = self._params
+            grads = torch.autograd.grad(loss, params, allow_unused=True)
+            if self._grad_bufs is None:
+                self._grad_bufs = [torch.zeros_like(p) for p in params]
+                for p, b in zip(params, self._grad_bufs):
+                    p.grad = b
+            torch._foreach_copy_(self._grad_bufs, [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, params)])
+        else:
+            self.optimizer.zero_grad(set_to_none=os.environ.get("GRX_PPO_GRAD_NONE", "0") != "0")
+            loss.backward()
         if adaptive:
             self._device_lr_update(kl_mean)
         with torch.no_grad():
