@@ -47,6 +47,7 @@ extern "C" {
 #define GRX_MAX_BODIES 36   /* moving bodies after merging fixed joints (base + DOFs) */
 #define GRX_MAX_DOFS 32
 #define GRX_MAX_SPHERES 48  /* collision spheres (primitive URDF shapes -> sphere sets) */
+#define GRX_MAX_LINKS 40          /* URDF links (the full GR1T1 has 37): second dimension of GRX_T_CONTACT_FORCES */
 #define GRX_NUM_FEET 2
 #define GRX_NUM_CMD 3
 #define GRX_MAX_HEIGHT_POINTS 128
@@ -284,6 +285,8 @@ typedef enum grx_tensor_id {
     GRX_T_EPISODE_STATS,      /* f32 (GRX_NUM_REWARD_TERMS + 1): mean episode sums of the envs reset
                                  by the last step that reset any (legged_robot.py:420-424), [NT] = count */
     GRX_T_ANCHORS,            /* f32 (N, 8, 3) foot-sphere friction anchors xy + active flag */
+    GRX_T_CONTACT_FORCES,     /* f32 (N, GRX_MAX_LINKS, 3) net contact force per URDF link (index = grx_model.sph_link), last
+                                 sub-step: the reference's contact_forces (legged_robot.py:117,266); links without shapes stay 0 */
     GRX_NUM_TENSORS
 } grx_tensor_id;
 

@@ -53,7 +53,7 @@ typedef REAL real;
 #define NB_MAX GRX_MAX_BODIES
 #define ND_MAX GRX_MAX_DOFS
 #define NS_MAX GRX_MAX_SPHERES
-#define NL_MAX 40 /* URDF links */
+#define NL_MAX GRX_MAX_LINKS /* URDF links */
 #define NT GRX_NUM_REWARD_TERMS
 #define NFS 8     /* anchored foot spheres (4 per foot) */
 
@@ -1274,6 +1274,7 @@ static void publish(struct grx_sim* s) {
     PUB(GRX_T_PROJECTED_GRAVITY, 3, e->proj_grav[j]);
     PUB(GRX_T_FEET_CONTACT_FORCE, 6, e->feet_force[j / 3][j % 3]);
     PUB(GRX_T_FEET_POS, 6, e->feet_pos[j / 3][j % 3]);
+    PUB(GRX_T_CONTACT_FORCES, 3 * GRX_MAX_LINKS, e->link_force[j / 3][j % 3]);   /* legged_robot.py:117 contact_forces */
     PUB(GRX_T_FEET_HEIGHT, 2, e->feet_height[j]);
     PUB(GRX_T_FEET_AIR_TIME, 2, e->air_time[j]);
     PUB(GRX_T_FEET_LAND_TIME, 2, e->land_time[j]);
@@ -1324,6 +1325,7 @@ int gro_tensor(grx_handle s, int id, grx_tensor_desc* d) {
     case GRX_T_TERM_CONTACT: desc_set(d, s->scratch_u8[id], GRX_U8, 1, N, 1, 1); break;
     case GRX_T_EPISODE_STATS: desc_set(d, s->scratch[id], GRX_F32, 1, NT + 1, 1, 1); break;
     case GRX_T_ANCHORS: desc_set(d, s->scratch[id], GRX_F32, 3, N, NFS, 3); break;
+    case GRX_T_CONTACT_FORCES: desc_set(d, s->scratch[id], GRX_F32, 3, N, GRX_MAX_LINKS, 3); break;
     default: return fail(GRX_ERR_INVALID_ARGUMENT, "gro_tensor: unknown tensor id");
     }
     return GRX_OK;

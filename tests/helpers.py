@@ -5,7 +5,7 @@ import torch
 from wiki_grx_gym_amd.envs import build_config, config
 
 CMP_TENSORS = ("DOF_POS", "DOF_VEL", "ROOT_STATES", "TORQUES", "ACTIONS", "COMMANDS", "BASE_LIN_VEL", "BASE_ANG_VEL",
-               "PROJECTED_GRAVITY", "FEET_CONTACT_FORCE", "FEET_POS", "FEET_HEIGHT", "FEET_AIR_TIME", "FEET_LAND_TIME",
+               "PROJECTED_GRAVITY", "FEET_CONTACT_FORCE", "CONTACT_FORCES", "FEET_POS", "FEET_HEIGHT", "FEET_AIR_TIME", "FEET_LAND_TIME",
                "AVG_FEET_FORCE", "AVG_FEET_SPEED", "BASE_HEIGHTS_OFFSET", "REW", "OBS", "PRI_OBS", "LAST_ACTIONS",
                "LAST_DOF_VEL", "EPISODE_SUMS", "REWARD_TERMS", "MEASURED_HEIGHTS")
 CMP_EXACT = ("RESET", "TIME_OUT", "EPISODE_LENGTH", "FEET_CONTACT", "TERRAIN_LEVELS", "TERRAIN_TYPES")
@@ -57,7 +57,7 @@ def random_actions(cfg, num_envs, gen, scale=1.0):
     return (mid + (2 * u - 1) * half * scale).contiguous()
 
 
-ATOL = {"TORQUES": 2e-3, "FEET_CONTACT_FORCE": 1e-2, "AVG_FEET_FORCE": 1e-2}   # N m / N scales: kp * 1e-6 rad etc.
+ATOL = {"TORQUES": 2e-3, "FEET_CONTACT_FORCE": 1e-2, "CONTACT_FORCES": 1e-2, "AVG_FEET_FORCE": 1e-2}   # N m / N scales: kp * 1e-6 rad etc.
 
 
 def tensor_diff(a, b, name=None):

@@ -55,7 +55,9 @@ def test_vec_env_surface(oracle_backend):
     assert torch.equal(env.episode_length_buf[alive], before[alive] + 1)
     # play.py reads these (play.py:86-137)
     assert env.dof_pos.shape == (64, 10) and env.commands.shape == (64, 3) and env.base_lin_vel.shape == (64, 3)
-    assert env.contact_forces[0, env.feet_indices, 2].shape == (2,)
+    assert env.contact_forces.shape == (64, env.num_bodies, 3) and env.contact_forces[0, env.feet_indices, 2].shape == (2,)
+    assert torch.equal(env.contact_forces[:, env.feet_indices], env.feet_contact_forces)   # standing robots: feet carry the weight
+    assert float(env.contact_forces[:, env.feet_indices, 2].sum()) > 0
     assert env.cfg.control.action_scale == 1.0
     with pytest.raises(Exception):
         env.step(torch.zeros(64, 9))

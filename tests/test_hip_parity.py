@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 PHYS = {  # name: (atol, rtol, allowed fraction outside)
     "DOF_POS": (1e-4, 1e-4, 2e-3), "ROOT_STATES": (2e-4, 2e-4, 1e-2), "FEET_POS": (1e-4, 1e-4, 2e-3),
     "DOF_VEL": (5e-3, 5e-3, 1e-2), "BASE_LIN_VEL": (2e-3, 2e-3, 5e-3), "BASE_ANG_VEL": (5e-3, 5e-3, 1e-2),
-    "PROJECTED_GRAVITY": (1e-4, 1e-4, 5e-3), "TORQUES": (5e-2, 5e-3, 1e-2), "FEET_CONTACT_FORCE": (1.0, 2e-2, 2e-2),
+    "PROJECTED_GRAVITY": (1e-4, 1e-4, 5e-3), "TORQUES": (5e-2, 5e-3, 1e-2), "FEET_CONTACT_FORCE": (1.0, 2e-2, 2e-2), "CONTACT_FORCES": (1.0, 2e-2, 2e-2),
     "AVG_FEET_FORCE": (1.0, 2e-2, 2e-2), "AVG_FEET_SPEED": (2e-3, 5e-3, 1e-2), "FEET_HEIGHT": (1e-4, 1e-4, 2e-3),
     "REW": (2e-3, 2e-3, 1e-2), "ACTIONS": (0, 0, 0), "COMMANDS": (1e-6, 0, 0), "FEET_AIR_TIME": (1e-6, 0, 2e-3),
     "FEET_LAND_TIME": (1e-6, 0, 2e-3), "LAST_ACTIONS": (0, 0, 0), "LAST_DOF_VEL": (5e-3, 5e-3, 1e-2),

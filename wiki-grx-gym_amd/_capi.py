@@ -36,7 +36,7 @@ TENSOR_IDS = (
     "FEET_AIR_TIME", "FEET_LAND_TIME", "FEET_CONTACT", "AVG_FEET_FORCE", "AVG_FEET_SPEED",
     "MEASURED_HEIGHTS", "BASE_HEIGHTS_OFFSET", "EPISODE_SUMS", "REWARD_TERMS", "TERRAIN_LEVELS",
     "TERRAIN_TYPES", "ENV_ORIGINS", "MOTOR_STRENGTH", "FRICTION", "BASE_MASS_COM", "TERM_CONTACT",
-    "EPISODE_STATS", "ANCHORS",
+    "EPISODE_STATS", "ANCHORS", "CONTACT_FORCES",
 )
 T = {name: i for i, name in enumerate(TENSOR_IDS)}
 DTYPE_F32, DTYPE_U8, DTYPE_I32, DTYPE_I64 = 0, 1, 2, 3

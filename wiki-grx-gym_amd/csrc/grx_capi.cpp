@@ -185,6 +185,7 @@ int build_side_tables(const grx_config& c, KTables& P) {
     for (int i = 0; i < m.num_spheres; ++i) {
         int b = m.sph_body[i];
         if (b < 0 || b >= m.num_bodies) return fail(GRX_ERR_INVALID_ARGUMENT, "sphere body out of range");
+        if (m.sph_link[i] < 0 || m.sph_link[i] >= GRX_MAX_LINKS) return fail(GRX_ERR_INVALID_ARGUMENT, "sph_link out of range");
         if (b == 0) base_idx.push_back(i);
         else if (m.sph_flags[i] & (GRX_SPH_TERMINATE | GRX_SPH_PENALISE))
             return fail(GRX_ERR_UNSUPPORTED_MODEL, "terminating/penalised shapes must ride on the base lump");
@@ -197,7 +198,7 @@ int build_side_tables(const grx_config& c, KTables& P) {
     static const int cnt[GRX_LEG] = {0, 0, 2, 2, 4}, off[GRX_LEG] = {8, 8, 8, 10, 12};
     auto put = [&](SphC& o, int i, int slot) {
         o.x = m.sph_pos[i][0]; o.y = m.sph_pos[i][1]; o.z = m.sph_pos[i][2]; o.r = m.sph_radius[i];
-        o.flags = m.sph_flags[i]; o.slot = slot; o.link_last = 0; o.dmax = m.sph_damp_max[i];
+        o.flags = m.sph_flags[i]; o.slot = slot; o.link_last = (m.sph_link[i] + 1) << 8; o.dmax = m.sph_damp_max[i];
     };
     for (int side = 0; side < 2; ++side) {
         SideConst& S = P.side[side];
@@ -208,7 +209,7 @@ int build_side_tables(const grx_config& c, KTables& P) {
             SphC& o = S.sph[n - lo];
             put(o, base_idx[n], -1);
             bool last = (n + 1 == hi) || m.sph_link[base_idx[n + 1]] != m.sph_link[base_idx[n]];
-            o.link_last = last ? 1 : 0;
+            o.link_last |= last ? 1 : 0;
         }
         for (int k = 0; k < GRX_LEG; ++k) {
             int b = 1 + side * GRX_LEG + k, n = 0;
@@ -220,6 +221,8 @@ int build_side_tables(const grx_config& c, KTables& P) {
                 if (n >= cnt[k]) return fail(GRX_ERR_UNSUPPORTED_MODEL, "collision shapes on chain body " + std::to_string(k) + " exceed the kernel's table (0,0,2,2,4)");
                 if (foot != (k == GRX_LEG - 1)) return fail(GRX_ERR_UNSUPPORTED_MODEL, "anchored foot shapes must sit on the chain leaf");
                 put(S.sph[off[k] + n], i, foot ? n : -1);
+                if (n > 0 && m.sph_link[i] != sph_link(S.sph[off[k]]))   // GRX_T_CONTACT_FORCES nets a chain body's shapes into one row
+                    return fail(GRX_ERR_UNSUPPORTED_MODEL, "the collision shapes of a chain body must belong to one URDF link");
                 ++n;
             }
         }
@@ -275,6 +278,7 @@ struct GenTablesH {
     int32_t sslot[GRX_MAX_SPHERES];
     int32_t slink[GRX_MAX_SPHERES];
     uint32_t link_flags[GEN_MAXLC_H];
+    int32_t link_urdf[GEN_MAXLC_H];
     int32_t foot_body[2], foot_link[2];
     float foot_pos[2][3];
     int32_t torso_body, forehead_body;
@@ -322,6 +326,8 @@ int build_generic(grx_sim* s, const grx_config& c) {
         for (size_t t = 0; t < link_ids.size(); ++t) if (link_ids[t] == m.sph_link[i]) lc = (int)t;
         if (lc < 0) { lc = (int)link_ids.size(); link_ids.push_back(m.sph_link[i]); }
         if (lc >= GEN_MAXLC_H) return fail(GRX_ERR_UNSUPPORTED_MODEL, "too many links carry collision shapes");
+        if (m.sph_link[i] < 0 || m.sph_link[i] >= GRX_MAX_LINKS) return fail(GRX_ERR_INVALID_ARGUMENT, "sph_link out of range");
+        T.link_urdf[lc] = m.sph_link[i];
         T.slink[k] = lc;
         T.link_flags[lc] |= m.sph_flags[i] & (GRX_SPH_TERMINATE | GRX_SPH_PENALISE);
         T.sslot[k] = -1;
@@ -456,7 +462,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(motor_strength, nd * N); DA(base_m, N); DA(base_c, 3 * N); DA(base_I, 6 * N); DA(friction, N);
     DA(commands, 3 * N); DA(origins, 3 * N); DA(levels, N); DA(types, N);
     DA(air_time, 2 * N); DA(land_time, 2 * N); DA(feet_contact, 2 * N);
-    DA(feet_height, 2 * N); DA(avg_force, 2 * N); DA(feet_force, 6 * N); DA(feet_pos, 6 * N); DA(avg_speed, 6 * N);
+    DA(feet_height, 2 * N); DA(avg_force, 2 * N); DA(feet_force, 6 * N); DA(contact_forces, 3 * GRX_MAX_LINKS * N); DA(feet_pos, 6 * N); DA(avg_speed, 6 * N);
     DA(base_heights_offset, N); DA(ep_len, N); DA(rew, N); DA(reset, N); DA(time_out, N); DA(term_contact, N);
     DA(base_lin_vel, 3 * N); DA(base_ang_vel, 3 * N); DA(proj_grav, 3 * N);
     DA(episode_sums, NT * N); DA(reward_terms, NT * N); DA(heights, (size_t)(nh > 0 ? nh : 1) * N);
@@ -617,6 +623,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     desc_vec(s, GRX_T_TERM_CONTACT, P.term_contact, GRX_U8, Ni);
     desc_vec(s, GRX_T_EPISODE_STATS, P.stats, GRX_F32, NT + 1);
     desc_soa3(s, GRX_T_ANCHORS, P.anchors, 8, 3);
+    desc_soa3(s, GRX_T_CONTACT_FORCES, P.contact_forces, GRX_MAX_LINKS, 3);
     s->prof_host = P.prof; s->prof_blocks = nblocks;
     // generic kernel: the per-body workspace goes to LDS when 16 envs' rows fit (155 KB for the 33-body robot: LDS round
     // trips are ~5x shorter than global ones and the kernel is bound by exactly those); else 64 envs per block over the

@@ -11,13 +11,17 @@
 #define GRX_MAXSPH_SIDE 16
 #define GRX_COARSE 8     // raster cells per coarse max-map cell (0.8 m)
 
-struct SphC {
+struct SphC {   // 32 bytes
     float x, y, z, r;    // centre (body frame), radius
     uint32_t flags;      // GRX_SPH_*
     int32_t slot;        // 0..3: anchored foot sphere index within this lane's foot, -1 otherwise
-    int32_t link_last;   // 1: last sphere of its URDF link in this lane's list (per-link force netting)
+    int32_t link_last;   // bit 0: last sphere of its URDF link in this lane's list (per-link force netting);
+                         // bits 8..: URDF link index + 1 (row of GRX_T_CONTACT_FORCES; 0 = unused slot) -- see sph_link()
     float dmax;          // cap of the normal damping coefficient (grx_model.sph_damp_max)
 };
+
+__host__ __device__ inline int sph_link(const SphC& s) { return (s.link_last >> 8) - 1; }
+static_assert(sizeof(SphC) == 32, "SphC must stay two 16-byte LDS words");
 
 // Constants of one chain body + its joint, packed so that a body's dynamics constants are four adjacent
 // 16-byte LDS words (ds_read_b128: one exposed LDS latency per body instead of ~13 narrow reads).
@@ -84,6 +88,7 @@ struct KParams {
     float *air_time, *land_time;
     uint8_t* feet_contact;   // also the "contact_last" state of the next step (legged_robot_fftai.py:113,131)
     float *feet_height, *avg_force, *feet_force, *feet_pos, *avg_speed, *base_heights_offset;
+    float* contact_forces;   // [(link * 3 + c)][N]: net contact force per URDF link, last sub-step
     long long* ep_len;
     float* rew;
     uint8_t *reset, *time_out, *term_contact;

@@ -36,6 +36,7 @@ struct GenTables {
     int32_t sslot[GEN_MAXS];           // friction-anchor slot 0..7 of an anchored foot sphere, -1 otherwise
     int32_t slink[GEN_MAXS];           // compact id of the URDF link the shape belongs to (force netting)
     uint32_t link_flags[GEN_MAXLC];    // GRX_SPH_TERMINATE / GRX_SPH_PENALISE of the compact links
+    int32_t link_urdf[GEN_MAXLC];      // URDF link index of the compact links (row of GRX_T_CONTACT_FORCES)
     int32_t foot_body[2], foot_link[2];
     float foot_pos[2][3];
     int32_t torso_body, forehead_body;
@@ -432,6 +433,10 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
         const float n2 = dot(F, F);
         if ((T.link_flags[L] & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term_contact = true;
         if ((T.link_flags[L] & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.f;
+        if (act) {   // contact_forces (legged_robot.py:117): one row per URDF link
+            float* cf = P.contact_forces + (size_t)(T.link_urdf[L] * 3) * N + e;
+            cf[0] = F.x; cf[N] = F.y; cf[2 * N] = F.z;
+        }
     }
     // torso / forehead orientation (frames of the final state are in the workspace)
     float torso_g[2] = {0.f, 0.f}, fore_g[2] = {0.f, 0.f};

@@ -206,9 +206,20 @@ GRX_DEV R3 joint_unrot_k(const R3& R, float c, float s, int ax) {
 // the base state at the start of the sub-step, so with W >= 2 waves per block a HELPER WAVE evaluates them while
 // the dynamics wave runs the kinematics / articulated-inertia passes; the wrench enters at the base solve.
 // MIDBAR: the 4-wave block layout has a barrier (#2) in the middle of the sub-step; the helper passes it half-way.
+// GRX_T_CONTACT_FORCES: net contact force of one URDF link.  The tensor shows the LAST sub-step (like the reference's after
+// its last gym.simulate): `last` is wave-uniform, so the nine other sub-steps pay one scalar branch per call site.
+// cf = the env's column of the tensor, nullptr on an inactive lane.
+struct LinkForceOut { bool last; float* cf; size_t N; };
+GRX_DEV void put_link_force(const LinkForceOut& o_, const SphC& S, V3 F) {   // S: any shape of the link (table read only when last)
+    if (o_.last) {
+        const int link = sph_link(S);
+        if (o_.cf && link >= 0) { float* o = o_.cf + (size_t)(link * 3) * o_.N; o[0] = F.x; o[o_.N] = F.y; o[2 * o_.N] = F.z; }
+    }
+}
+
 template <bool HF, bool MIDBAR>
 GRX_DEV void base_lump_contacts(KP P, const SideConst& C, const R3& R0, V3 O, V3 ang, V3 vel, float mu, float hmax,
-                                V3& f0a, V3& f0l, bool& term, float& pen_count) {
+                                V3& f0a, V3& f0l, bool& term, float& pen_count, const LinkForceOut& lfo) {
     f0a = v3(0.f, 0.f, 0.f); f0l = v3(0.f, 0.f, 0.f);
     term = false; pen_count = 0.f;
     LaneState dummy;   // anchors are only touched by foot spheres (SLOT >= 0)
@@ -216,6 +227,9 @@ GRX_DEV void base_lump_contacts(KP P, const SideConst& C, const R3& R0, V3 O, V3
     const bool reach = group_within_reach<8>(&C.sph[0], R0, v3(0.f, 0.f, 0.f), O, hmax);
     V3 Flink = v3(0.f, 0.f, 0.f);
     const V3 zero = v3(0.f, 0.f, 0.f);
+    V3 lf[8];   // net force of the link that ends at shape i (stored after the loop: no extra branches inside it)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lf[i] = zero;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (reach) {
@@ -230,7 +244,8 @@ GRX_DEV void base_lump_contacts(KP P, const SideConst& C, const R3& R0, V3 O, V3
                 f0a = f0a + cross(xr, F);
                 f0l = f0l + F;
                 Flink = Flink + F;
-                if (S.link_last) {   // uniform per side: net force of one URDF link complete
+                if (S.link_last & 1) {   // uniform per side: net force of one URDF link complete
+                    lf[i] = Flink;
                     float n2 = dot(Flink, Flink);
                     if ((S.flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term = true;
                     if ((S.flags & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.0f;
@@ -239,6 +254,10 @@ GRX_DEV void base_lump_contacts(KP P, const SideConst& C, const R3& R0, V3 O, V3
             }
         }
         if (MIDBAR && half == 0) __syncthreads();   // #2
+    }
+    if (lfo.last) {   // GRX_T_CONTACT_FORCES rows of this lane's base-lump links (zeros when nothing was within reach)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (C.sph[i].link_last & 1) put_link_force(lfo, C.sph[i], lf[i]);
     }
 }
 
@@ -297,7 +316,7 @@ GRX_DEV void link_contacts(KP P, const SideConst& C, int k, const ChainKin& K, V
 // (W == 4 uses the producer/consumer pipeline of grx_wavepipe.h instead of this function).
 template <bool HF, int W>
 GRX_DEV void substep(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
-                     SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc) {
+                     SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc, const LinkForceOut& lfo) {
     const float dt = P.sim_dt;
     R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
     V3 O = st.pos;
@@ -341,6 +360,7 @@ GRX_DEV void substep(KP P, const SideConst& C, const LaneConst& LC, LaneState& s
             V3 fa, fl;
             if (kSphCnt[k] == 2) link_contacts<HF>(P, C, k, K, O, LC.mu, LC.hmax, fa, fl);
             else { foot_contacts<HF>(P, C, K, O, LC.mu, LC.hmax, st, fa, fl); out.foot_force = fl; }
+            put_link_force(lfo, C.sph[kSphOff[k]], fl);
             pa = pa - fa; pl = pl - fl;
         }
         if (k == LEG - 1) {  // foot link frame BEFORE this sub-step's integration
@@ -404,7 +424,7 @@ GRX_DEV void substep(KP P, const SideConst& C, const LaneConst& LC, LaneState& s
         pa = pa - f0a; pl = pl - f0l;
     } else {
         V3 f0a, f0l;
-        base_lump_contacts<HF, false>(P, C, R0, O, st.ang, st.vel, LC.mu, LC.hmax, f0a, f0l, out.term, out.pen_count);
+        base_lump_contacts<HF, false>(P, C, R0, O, st.ang, st.vel, LC.mu, LC.hmax, f0a, f0l, out.term, out.pen_count, lfo);
         pa = pa - f0a; pl = pl - f0l;
     }
     A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
@@ -1013,13 +1033,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                     hs.ay[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e];
                     if (P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] != 0.0f) hs.anchor_on |= (1u << i);
                 }
-                chain_contact_loop<HF>(P, C, mu, hmax, hs, L, lane, el);
+                chain_contact_loop<HF>(P, C, mu, hmax, hs, L, lane, el, act ? P.contact_forces + e : nullptr, (size_t)N);
                 float* a_ = s_anch + lane;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { a_[i * 64] = hs.ax[i]; a_[(4 + i) * 64] = hs.ay[i]; }
                 a_[8 * 64] = __uint_as_float(hs.anchor_on);
             } else {
-                base_contact_loop<HF>(P, C, mu, hmax, bm, bc, bI, L, lane, el);
+                base_contact_loop<HF>(P, C, mu, hmax, bm, bc, bI, L, lane, el, act ? P.contact_forces + e : nullptr, (size_t)N);
             }
             float es_w1[NT], es_w3[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
             if (wv == 1) load_episode_sums<1>(P, e, N, es_w1);
@@ -1077,7 +1097,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
                 const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
                 const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
                 V3 f0a, f0l; bool term; float pen;
-                base_lump_contacts<HF, false>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen);
+                base_lump_contacts<HF, false>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen,
+                                              LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N});
                 float* w_ = s_wr + lane;
                 w_[0 * 64] = f0a.x; w_[1 * 64] = f0a.y; w_[2 * 64] = f0a.z;
                 w_[3 * 64] = f0l.x; w_[4 * 64] = f0l.y; w_[5 * 64] = f0l.z;
@@ -1174,7 +1195,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
         if (W == 4) substep_p<HF>(P, C, LC, st, torque, so, fk, L, lane, deci, tacc);
-        else substep<HF, W>(P, C, LC, st, torque, so, fk, s_wr + lane, tacc);
+        else substep<HF, W>(P, C, LC, st, torque, so, fk, s_wr + lane, tacc,
+                            LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N});
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
             avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
         }

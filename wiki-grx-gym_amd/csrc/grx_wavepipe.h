@@ -323,7 +323,7 @@ GRX_DEV void iwave_loop(KP P, const SideConst& C, float base_m, V3 base_c, const
 // wave 2: chain-body contacts (feet first: the bias recursion starts at the leaf)
 template <bool HF>
 GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, LaneState& hs, const PipeLds& L,
-                                int lane, int el) {
+                                int lane, int el, float* cf_env, size_t N) {
     GRX_HELPER_PROF_BEGIN;
     for (int seq = 0; seq < P.decimation; ++seq) {
         GRX_HELPER_PROF_IDLE0;
@@ -383,7 +383,10 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, 
             c_[6 * 64] = f4(fv.z, 0.f, 0.f, 0.f);
         }
         flag_set(L.flag + FL_FOOT, seq + 1, lane);
+        const LinkForceOut lfo = {seq == P.decimation - 1, cf_env, N};   // GRX_T_CONTACT_FORCES: last sub-step only
+        put_link_force(lfo, C.sph[kSphOff[LEG - 1]], fl);
         link_contacts<HF>(P, C, 2, K2, O, mu, hmax, fa, fl);      // thigh (the shank spheres are wave 3's)
+        put_link_force(lfo, C.sph[kSphOff[2]], fl);
         c_[0 * 64] = f4(fa.x, fa.y, fa.z, fl.x);
         c_[1 * 64] = f4(fl.y, fl.z, 0.f, 0.f);
         flag_set(L.flag + FL_LEGS, seq + 1, lane);
@@ -394,7 +397,7 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, 
 // wave 3: base-lump contacts
 template <bool HF>
 GRX_DEV void base_contact_loop(KP P, const SideConst& C, float mu, float hmax, float base_m, V3 base_c, const S3& base_I,
-                               const PipeLds& L, int lane, int el) {
+                               const PipeLds& L, int lane, int el, float* cf_env, size_t N) {
     GRX_HELPER_PROF_BEGIN;
     for (int seq = 0; seq < P.decimation; ++seq) {
         GRX_HELPER_PROF_IDLE0;
@@ -404,6 +407,7 @@ GRX_DEV void base_contact_loop(KP P, const SideConst& C, float mu, float hmax, f
         const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
         const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+        const LinkForceOut lfo = {seq == P.decimation - 1, cf_env, N};
         {   // the base lump's rigid-body bias force (cheap; needed by wave 0 only at the base solve)
             V3 bpa, bpl;
             rigid_bias(R0, rot(R0, base_c), base_m, base_I, ang, vel, bpa, bpl);
@@ -420,13 +424,14 @@ GRX_DEV void base_contact_loop(KP P, const SideConst& C, float mu, float hmax, f
             for (int k = 0; k <= 3; ++k) chain_step(C, k, qs_q[k], qs_qd[k], K);
             V3 fa, fl;
             link_contacts<HF>(P, C, 3, K, O, mu, hmax, fa, fl);
+            put_link_force(lfo, C.sph[kSphOff[3]], fl);
             float4* c_ = L.wc + lane;
             c_[2 * 64] = f4(fa.x, fa.y, fa.z, fl.x);
             c_[3 * 64] = f4(fl.y, fl.z, 0.f, 0.f);
             flag_set(L.flag + FL_SHANK, seq + 1, lane);
         }
         V3 f0a, f0l; bool term; float pen;
-        base_lump_contacts<HF, false>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen);
+        base_lump_contacts<HF, false>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen, lfo);
         L.wr[lane] = f4(f0a.x, f0a.y, f0a.z, f0l.x);
         L.wr[64 + lane] = f4(f0l.y, f0l.z, term ? 1.f : 0.f, pen);
         flag_set(L.flag + FL_BASE, seq + 1, lane);

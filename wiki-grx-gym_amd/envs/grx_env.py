@@ -138,7 +138,8 @@ class GRxEnv:
         self._episode_sums = t("EPISODE_SUMS")
         self._episode_stats = t("EPISODE_STATS")
         self.episode_sums = {n: self._episode_sums[i] for n, i in self._term_index.items()}
-        self.contact_forces = _FeetOnlyContactForces(self)
+        # (N, num_bodies, 3) net contact force per URDF link, last sub-step (LR:117): zero-copy view of the library tensor
+        self.contact_forces = t("CONTACT_FORCES")[:, :self.num_bodies]
         from .kinematics import BodyKinematics
         self._kin = BodyKinematics(rm, dev)
         self._rbs_cache = (-1, None)
@@ -235,20 +236,6 @@ class GRxEnv:
         v[9 + nd:9 + 2 * nd] = n.dof_vel * lv * s.dof_vel
         v[9 + 2 * nd:9 + 3 * nd] = n.action * lv * s.action
         return v
-
-
-class _FeetOnlyContactForces:
-    """``env.contact_forces[i, env.feet_indices, 2]`` as play.py:124 reads it.  Only the foot links are
-    materialised per step (the full 37-link tensor is 'next')."""
-
-    def __init__(self, env):
-        self._env = env
-
-    def __getitem__(self, key):
-        env = self._env
-        full = torch.zeros(env.num_envs, env.num_bodies, 3, device=env.feet_contact_forces.device)
-        full[:, env.feet_indices] = env.feet_contact_forces
-        return full[key]
 
 
 def _get(obj, name, default):
