@@ -695,8 +695,8 @@ static void reset_env(struct grx_sim* s, env_t* e, int le, uint32_t step, int in
     }
     e->episode_length = 0;
     for (int i = 0; i < NFS; ++i) e->anchor_on[i] = 0;
-    memset(e->link_force, 0, sizeof e->link_force);
-    memset(e->feet_force, 0, sizeof e->feet_force);
+    /* link_force / feet_force are NOT cleared: reset_idx does not touch the contact-force tensor, which keeps the values of
+       the last gym.simulate until the next refresh (legged_robot.py:377-440 vs :266) */
 }
 
 static real sum_abs_masked(const real* a, int n, uint32_t mask) {

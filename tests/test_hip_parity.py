@@ -202,6 +202,44 @@ def test_one_step_parity_rough_terrain():
     assert mh[1] < 2e-3
 
 
+def test_contact_forces_of_every_link():
+    """GRX_T_CONTACT_FORCES (the reference's contact_forces, legged_robot.py:117): net force per URDF link on the last
+    sub-step, against the oracle's per-link forces, with robots driven to the ground so that base-lump links (torso,
+    arms, head), thighs and shanks carry load too -- not only the feet."""
+    cfg = make_cfg(dr=True, push=True)
+    N = 256
+    hip, ora = make_sims(cfg, N, seed=2)
+    hip.reset_all(); ora.reset_all()
+    feet = []
+    seen = {"other_links": set(), "bad": 0, "n": 0}
+
+    def check(s, hip_, ora_):
+        a, b = hip_.tensor("CONTACT_FORCES").cpu().double(), ora_.tensor("CONTACT_FORCES").double()
+        assert a.shape == b.shape == (N, 40, 3)
+        if not feet:   # the two foot links = the rows that equal FEET_CONTACT_FORCE once the robots have landed
+            ff = ora_.tensor("FEET_CONTACT_FORCE").double()
+            if (ff[:, 0].abs().sum() > 0) and (ff[:, 1].abs().sum() > 0):
+                for f in range(2):
+                    feet.extend(L for L in range(b.shape[1]) if torch.equal(b[:, L], ff[:, f]))
+                assert len(feet) == 2, feet
+            else:
+                return   # not every foot has landed anywhere yet
+        assert torch.equal(hip_.tensor("CONTACT_FORCES")[:, feet].cpu(), hip_.tensor("FEET_CONTACT_FORCE").cpu())
+        loaded = b.abs().sum(2) > 1.0                                   # (N, links)
+        for L in torch.nonzero(loaded.any(0)).flatten().tolist():
+            if L not in feet:
+                seen["other_links"].add(L)
+        err = (a - b).abs()
+        seen["bad"] += int((err > 1.0 + 2e-2 * b.abs()).sum())
+        seen["n"] += int(loaded.sum()) * 3
+        # a link the oracle leaves unloaded is unloaded here too (no stale rows), up to grazing contacts
+        assert float(a[~loaded].abs().max()) < 5.0
+
+    physics_lockstep(hip, ora, cfg, steps=60, scale=1.0, check=check)
+    assert len(seen["other_links"]) >= 4, seen          # torso / arm / thigh / shank links did touch the ground
+    assert seen["bad"] <= 2e-2 * seen["n"], seen
+
+
 def test_curriculum_and_episode_stats():
     """Short episodes on the curriculum terrain: terrain levels move identically, extras['episode'] means agree."""
     cfg = make_cfg(terrain="heightfield")
