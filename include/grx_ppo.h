@@ -4,6 +4,7 @@
  * rsl_rl/algorithms/ppo.py:215-245 (log-prob, ratio, clipped surrogate, clipped value loss, entropy, KL) and
  * their autograd backward expand to.  Plain device pointers and sizes, no torch types; everything is fp32.
  * Deterministic: per-block partial sums are combined in block order by a second kernel.
+ * Also here: the column sum behind every bias gradient of the two MLPs (grx_ppo_colsum).
  */
 #ifndef GRX_PPO_H
 #define GRX_PPO_H
@@ -28,6 +29,12 @@ int grx_ppo_loss(int batch, int num_actions, const float* mu, const float* std, 
                  const float* advantages, const float* returns, const float* target_values,
                  float clip_param, float value_loss_coef, float entropy_coef, int use_clipped_value_loss,
                  float* out, float* d_mu, float* d_std, float* d_value, float* partials, void* stream);
+
+/* Column sums of a row-major fp32 matrix x [rows][cols] -> out [cols] (the bias gradient of a linear layer: the sum of
+ * dY over the batch), deterministic (256-row slabs added in order).  `partials`: scratch of
+ * grx_ppo_colsum_partials_size(rows, cols) floats.  Returns 0, negative for rows < 1 or cols < 1. */
+int grx_ppo_colsum_partials_size(int rows, int cols);
+int grx_ppo_colsum(int rows, int cols, const float* x, float* out, float* partials, void* stream);
 
 #ifdef __cplusplus
 }

@@ -116,3 +116,54 @@ def test_full_size_graphed_updates_stay_finite_and_match_the_eager_path():
     assert (w0 - w1).abs().max().item() < 5e-3 * w0.abs().max().item()   # Adam amplifies last-bit GEMM differences
     for a, b in zip(o0, o1):
         assert abs(a[0]) > 1e-6 and abs(a[0] - b[0]) < 2e-3 * max(1.0, abs(a[0])) and abs(a[1] - b[1]) < 2e-3 * max(1.0, abs(a[1]))
+
+
+def test_captured_step_equals_eager_step_with_rollouts_in_between():
+    """The regression behind rl/modules.py:_TrainLinear: four updates with a synthetic rollout (alg.act / process_env_step /
+    compute_returns, i.e. eager GPU work and fresh storage contents) between them.  With torch's own column reduction in
+    the captured step the second update already differed (one bias gradient wrong by 100 %, tools/gpu_ppo_graph_check.py);
+    with the library's column sum the HIP-graph path and the eager device path agree to the last bit."""
+    N, T = 512, 24
+    res = {}
+    for graph in ("0", "1"):
+        os.environ["GRX_PPO_GRAPH"] = graph
+        try:
+            torch.manual_seed(0)
+            ac = ActorCriticMLP(39, 168, 10, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], activation="elu", init_noise_std=0.2)
+            alg = PPO(ac, num_learning_epochs=2, num_mini_batches=4, clip_param=0.2, entropy_coef=0.01, learning_rate=1e-4,
+                      schedule="adaptive", desired_kl=0.03, device="cuda:0")
+        finally:
+            del os.environ["GRX_PPO_GRAPH"]
+        assert alg._use_graph == (graph == "1")
+        alg.init_storage(N, T)
+        g = torch.Generator(device="cuda:0").manual_seed(1)
+        snaps = []
+        for u in range(4):
+            torch.manual_seed(50 + u)
+            with torch.inference_mode():
+                for _ in range(T):
+                    o = torch.randn(N, 39, device="cuda:0", generator=g); c = torch.randn(N, 168, device="cuda:0", generator=g)
+                    alg.act(o, c)
+                    r = torch.randn(N, device="cuda:0", generator=g) * 0.1
+                    d = torch.rand(N, device="cuda:0", generator=g) < 0.02
+                    alg.process_env_step(r, d, {"time_outs": torch.zeros(N, device="cuda:0", dtype=torch.bool)})
+                alg.compute_returns(c)
+            out = alg.update()
+            alg.clear_storage()
+            assert all(abs(v) > 1e-7 for v in out)
+            snaps.append(torch.cat([p.detach().flatten() for p in ac.parameters()]).clone())
+        res[graph] = snaps
+    for u in range(4):
+        a, b = res["0"][u], res["1"][u]
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 1e-6, (u, float((a - b).abs().max()))
+
+
+def test_colsum_matches_torch():
+    from wiki_grx_gym_amd.rl.fused_loss import colsum
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    for rows, cols in ((1, 1), (7, 10), (10485, 128), (10485, 512), (24576, 1), (300, 700)):
+        x = torch.randn(rows, cols, device="cuda:0", generator=g)
+        ref = x.double().sum(0)
+        got = colsum(x)
+        assert got.shape == (cols,) and float((got.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+        assert torch.equal(got, colsum(x))   # deterministic

@@ -121,7 +121,44 @@ void launch(int nblk, hipStream_t st, int B, const float* mu, const float* stdp,
     hipLaunchKernelGGL(ppo_loss_kernel<A>, dim3(nblk), dim3(NTHR), 0, st, B, mu, stdp, value, actions, old_logp, old_mu, old_sigma,
                        adv, ret, tv, clip, vcoef, use_clipped, d_mu, d_value, partials);
 }
+
+// ---- column sums of a row-major [rows][cols] matrix (bias gradients: db = sum over the batch of dY) -----------------
+// torch's own column reduction (at::native reduce_kernel) is what the captured PPO step must avoid: replayed from a HIP
+// graph with other GPU work in between it returned garbage for one 128-column case (tools/gpu_ppo_graph_check.py).
+// Two deterministic passes: 256-row slabs -> partials [slab][col] (a wave reads 64 consecutive columns of a row), then
+// one thread per column adds the slabs in order.
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_partial(int rows, int cols, const float* __restrict__ x, float* __restrict__ partials) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+    float acc = 0.f;
+    if (col < cols)
+        for (int r = r0 + wv; r < r1; r += 4) acc += x[(size_t)r * cols + col];
+    __shared__ float s_acc[4][64];
+    s_acc[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && col < cols) partials[(size_t)blockIdx.y * cols + col] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+}
+__global__ __launch_bounds__(256) void colsum_final(int cols, int nslab, const float* __restrict__ partials, float* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    float t = 0.f;
+    for (int b = 0; b < nslab; ++b) t += partials[(size_t)b * cols + col];
+    out[col] = t;
+}
 }  // namespace
+
+extern "C" int grx_ppo_colsum_partials_size(int rows, int cols) { return (rows < 1 || cols < 1) ? 0 : ((rows + CS_ROWS - 1) / CS_ROWS) * cols; }
+
+extern "C" int grx_ppo_colsum(int rows, int cols, const float* x, float* out, float* partials, void* stream) {
+    if (rows < 1 || cols < 1) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const int nslab = (rows + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(colsum_partial, dim3((cols + 63) / 64, nslab), dim3(256), 0, st, rows, cols, x, partials);
+    hipLaunchKernelGGL(colsum_final, dim3((cols + 255) / 256), dim3(256), 0, st, cols, nslab, partials, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 // in floats (the buffer holds doubles: 2 floats each; the caller's allocation must be 8-byte aligned)
 extern "C" int grx_ppo_loss_partials_size(int batch) { return batch < 1 ? 0 : ((batch + NTHR - 1) / NTHR) * NRED * 2; }

@@ -27,6 +27,10 @@ def load_ppo_library():
         lib.grx_ppo_loss.argtypes = [C.c_int, C.c_int] + [fp] * 10 + [C.c_float, C.c_float, C.c_float, C.c_int] + [fp] * 5 + [C.c_void_p]
         lib.grx_ppo_loss_partials_size.restype = C.c_int
         lib.grx_ppo_loss_partials_size.argtypes = [C.c_int]
+        lib.grx_ppo_colsum.restype = C.c_int
+        lib.grx_ppo_colsum.argtypes = [C.c_int, C.c_int, fp, fp, fp, C.c_void_p]
+        lib.grx_ppo_colsum_partials_size.restype = C.c_int
+        lib.grx_ppo_colsum_partials_size.argtypes = [C.c_int, C.c_int]
         _LIB = lib
     return _LIB
 
@@ -72,3 +76,18 @@ def fused_ppo_loss(mu, std, value, actions, old_logp, old_mu, old_sigma, advanta
                    clip_param, value_loss_coef, entropy_coef, use_clipped_value_loss):
     return FusedPPOLoss.apply(mu, std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values,
                               clip_param, value_loss_coef, entropy_coef, use_clipped_value_loss)
+
+
+def colsum(x):
+    """Sum over dim 0 of a CUDA fp32 matrix [rows, cols] through grx_ppo_colsum (deterministic; HIP-graph safe)."""
+    lib = load_ppo_library()
+    x = _f32c(x)
+    rows, cols = x.shape
+    out = torch.empty(cols, device=x.device, dtype=torch.float32)
+    partials = torch.empty(lib.grx_ppo_colsum_partials_size(rows, cols), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        rc = lib.grx_ppo_colsum(rows, cols, x.data_ptr(), out.data_ptr(), partials.data_ptr(),
+                                C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"grx_ppo_colsum failed ({rc}): {rows} x {cols}")
+    return out

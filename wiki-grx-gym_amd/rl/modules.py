@@ -24,39 +24,47 @@ def get_activation(name):
 
 
 import os
-_PIN_HEAD = os.environ.get("GRX_PPO_HEAD", "1") != "0"
+
+_TRAIN_LINEAR = os.environ.get("GRX_PPO_LINEAR", "colsum")   # "torch": plain nn.Linear autograd on a HIP device too
 
 
-class _HeadLinear(torch.autograd.Function):
-    """nn.Linear for a one-column head, with its three GEMV-shaped products pinned to hipBLASLt.
+class _TrainLinear(torch.autograd.Function):
+    """nn.Linear as PPO trains it on a HIP device: y = x W^T + b, with two departures from torch's autograd formula.
 
-    PPO captures its minibatch step with rocBLAS preferred (rl/ppo.py `_build_graph`: 2x faster weight-gradient
-    GEMMs for these shapes), but rocBLAS's pick for [1, B] x [B, H] (the head's weight gradient) takes 570 us at
-    B = 10^4 against hipBLASLt's 32 us (tools/gpu_gemm_probe.py).  torch's BLAS preference is a process-global flag
-    read at call time, so this function flips it around its own products, forward and backward."""
+    * The bias gradient is libgrx_ppo.so's deterministic column sum (`fused_loss.colsum`), not torch's column reduction:
+      replayed from a captured HIP graph with other GPU work between replays, at::native's reduce kernel returned garbage
+      for one [10485, 128] -> [128] case (the critic's last hidden bias) while every other tensor matched an fp64
+      reference to 1e-7 (tools/gpu_ppo_graph_check.py).  With this function the captured step and the eager step agree
+      bit for bit, rollouts in between included.
+    * A one-column layer (the value head) pins its three GEMV-shaped products to hipBLASLt: PPO prefers rocBLAS for the
+      duration of update() (2x faster weight-gradient GEMMs at these shapes), but rocBLAS's pick for [1, B] x [B, H]
+      takes 570 us at B = 10^4 against hipBLASLt's 32 us (tools/gpu_gemm_probe.py).  torch's BLAS preference is a
+      process-global flag read at call time, so it is flipped around those products only."""
 
     @staticmethod
-    def _lt():
+    def _blas(pin):
         prev = torch.backends.cuda.preferred_blas_library()
-        torch.backends.cuda.preferred_blas_library("cublaslt")
+        if pin:
+            torch.backends.cuda.preferred_blas_library("cublaslt")
         return prev
 
     @staticmethod
-    def forward(ctx, h, weight, bias):
-        prev = _HeadLinear._lt()
+    def forward(ctx, x, weight, bias):
+        prev = _TrainLinear._blas(weight.shape[0] == 1)
         try:
-            y = torch.addmm(bias, h, weight.t())
+            y = torch.addmm(bias, x, weight.t())
         finally:
             torch.backends.cuda.preferred_blas_library(prev)
-        ctx.save_for_backward(h, weight)
+        ctx.save_for_backward(x, weight)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        h, weight = ctx.saved_tensors
-        prev = _HeadLinear._lt()
+        from .fused_loss import colsum
+        x, weight = ctx.saved_tensors
+        prev = _TrainLinear._blas(weight.shape[0] == 1)
         try:
-            return dy @ weight, dy.t() @ h, dy.sum(0)
+            return dy @ weight, dy.t() @ x, colsum(dy)
         finally:
             torch.backends.cuda.preferred_blas_library(prev)
 
@@ -73,14 +81,15 @@ class MLP(nn.Module):
         self.model = nn.Sequential(*layers)
 
     @torch.jit.unused
-    def _forward_pinned_head(self, x):
-        head = self.model[-1]
-        return _HeadLinear.apply(self.model[:-1](x), head.weight, head.bias)
+    def _forward_train(self, x):
+        for m in self.model:
+            x = _TrainLinear.apply(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+        return x
 
     def forward(self, x):
         if not torch.jit.is_scripting():   # (export_policy_as_jit scripts this module: the plain path)
-            if self.output_size == 1 and x.is_cuda and torch.is_grad_enabled() and _PIN_HEAD:
-                return self._forward_pinned_head(x)   # value head during training on a HIP device: see _HeadLinear
+            if x.is_cuda and torch.is_grad_enabled() and x.dtype == torch.float32 and _TRAIN_LINEAR == "colsum":
+                return self._forward_train(x)   # training on a HIP device: see _TrainLinear
         return self.model(x)
 
 

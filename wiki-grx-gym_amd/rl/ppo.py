@@ -46,12 +46,11 @@ class PPO:
         # device scalar consumed by the fused Adam kernel, the NaN-skip uses Adam's found_inf hook, and the loss
         # statistics are read back once per update().  (The reference does three .item() per minibatch, ppo.py:264,308-309.)
         self._device_lr = torch.device(device).type == "cuda"
-        # GRX_PPO_GRAPH=1 (opt-in, experimental): the whole minibatch step (forward, losses, backward, adaptive LR, clip, fused
-        # Adam) captured ONCE in a HIP graph and replayed 200x per update (0.20 s per update against 0.28 s).  Off by
-        # default: with eager GPU work between updates (i.e. in real training) the replayed step was measured to produce a
-        # wrong gradient for one small parameter tensor (the critic's last hidden bias; tools/gpu_ppo_graph_check.py
-        # compares both paths with an fp64 CPU reference) -- the eager device path below matches the reference to 1e-7.
-        self._use_graph = self._device_lr and os.environ.get("GRX_PPO_GRAPH", "0") not in ("0", "")
+        # ... and, single rank, the whole minibatch step (forward, losses, backward, adaptive LR, clip, fused Adam) is
+        # captured ONCE in a HIP graph and replayed 200x per update (GRX_PPO_GRAPH=0: eager).  The captured step equals the
+        # eager one bit for bit, rollouts in between included (tests/test_ppo_gpu.py) -- provided no torch column reduction
+        # is inside it: see rl/modules.py:_TrainLinear.
+        self._use_graph = self._device_lr and os.environ.get("GRX_PPO_GRAPH", "1") not in ("0", "")
         # ... and everything between the networks' outputs and their gradients is one HIP kernel (rl/fused_loss.py)
         self._fused_loss = self._device_lr and os.environ.get("GRX_PPO_FUSED_LOSS", "1") != "0"
         self._graph, self._graph_mb, self._static, self._sums, self._restore_opt = None, None, None, None, None
@@ -279,8 +278,8 @@ class PPO:
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         surrogate_loss, value_loss, loss, kl_mean = self._losses(obs, cobs, actions, target_values, advantages, returns,
                                                                   old_logp, old_mu, old_sigma)
-        # (GRX_PPO_GRAD_NONE=1 drops the grads instead of zero-filling them -- one fill and one add kernel less per parameter
-        #  and step, the recipe of the torch CUDA-graph notes -- but widens the discrepancy described in __init__)
+        # grads dropped, not zero-filled: backward then WRITES each .grad (from the graph's private pool on replay) instead of
+        # accumulating into a zeroed one -- one fill and one add kernel less per parameter and step (GRX_PPO_GRAD_NONE=0: fill)
         if os.environ.get("GRX_PPO_GRAD_MODE", "") == "functional":
             # gradients as plain outputs of autograd.grad, copied into persistent .grad buffers: no AccumulateGrad nodes
             # (they run on the stream they were created on) inside the captured region
@@ -292,7 +291,7 @@ class PPO:
                     p.grad = b
             torch._foreach_copy_(self._grad_bufs, [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, params)])
         else:
-            self.optimizer.zero_grad(set_to_none=os.environ.get("GRX_PPO_GRAD_NONE", "0") != "0")
+            self.optimizer.zero_grad(set_to_none=os.environ.get("GRX_PPO_GRAD_NONE", "1") != "0")
             loss.backward()
         if adaptive:
             self._device_lr_update(kl_mean)
