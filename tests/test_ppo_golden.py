@@ -23,6 +23,7 @@ def _build(d, device="cpu"):
               value_loss_coef=1.0, entropy_coef=0.01, learning_rate=1e-4, learning_rate_min=1e-5, learning_rate_max=1e-3,
               max_grad_norm=1.0, use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.03, device=device)
     alg.init_storage(N, T)
+    alg._use_act_graph = False   # the rollout below injects its noise by patching Normal.sample: not capturable
     return ac, alg, N, T
 
 

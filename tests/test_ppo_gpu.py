@@ -167,3 +167,33 @@ def test_colsum_matches_torch():
         got = colsum(x)
         assert got.shape == (cols,) and float((got.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
         assert torch.equal(got, colsum(x))   # deterministic
+
+
+def test_graphed_policy_step_matches_eager():
+    """PPO.act through the captured policy step: same means / values / sigma as the eager call, log-prob consistent with the
+    sampled actions, fresh noise on every replay, and the current parameters (they change under Adam) are what it reads."""
+    torch.manual_seed(0)
+    ac = ActorCriticMLP(39, 168, 10, actor_hidden_dims=[64, 32], critic_hidden_dims=[64, 32], activation="elu", init_noise_std=0.3)
+    alg = PPO(ac, device="cuda:0")
+    assert alg._use_act_graph
+    alg.init_storage(128, 4)
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    prev_actions = None
+    for it in range(3):
+        o = torch.randn(128, 39, device="cuda:0", generator=g); c = torch.randn(128, 168, device="cuda:0", generator=g)
+        with torch.inference_mode():
+            a = alg.act(o, c).clone()
+            t = alg.transition
+            mu, sg, v, lp = t.action_mean.clone(), t.action_sigma.clone(), t.values.clone(), t.actions_log_prob.clone()
+            mu_e, v_e = ac.actor(o), ac.critic(c)
+        assert alg._act_graph is not None
+        assert torch.allclose(mu, mu_e, atol=1e-6) and torch.allclose(v, v_e, atol=1e-6) and torch.allclose(sg, ac.std.expand_as(mu))
+        ref_lp = torch.distributions.Normal(mu, sg).log_prob(a).sum(-1)
+        assert torch.allclose(lp.reshape(-1), ref_lp, atol=1e-4)
+        z = (a - mu) / sg
+        assert 0.8 < float(z.std()) < 1.2 and abs(float(z.mean())) < 0.15
+        assert prev_actions is None or not torch.equal(z, prev_actions)
+        prev_actions = z
+        with torch.no_grad():   # an optimizer step in between: the graph must see the new weights
+            for p in ac.parameters():
+                p.add_(0.01 * torch.randn_like(p))

@@ -3,8 +3,8 @@ with a synthetic rollout (alg.act / process_env_step / compute_returns) between 
 clipped gradients of the first minibatch step of the second update.  Finding (round 1): with eager GPU work between the
 updates the replayed step's gradient of critic.model.4.bias is wrong (error = its magnitude) while every other tensor
 matches the reference to 1e-7 -- hence the graph path is off by default.  MODE=alloc|act|rng|full selects the activity
-between updates; GRX_PPO_FUSED_LOSS / GRX_PPO_GRAD_NONE / GRX_PPO_GRAD_MODE=functional (autograd.grad + copies instead of backward) /
-GRX_PPO_BLAS select the variant -- all of them showed it with GRX_PPO_LINEAR=torch (torch's own autograd for nn.Linear), so
+between updates; GRX_PPO_FUSED_LOSS / GRX_PPO_GRAD_NONE / GRX_PPO_BLAS select the variant (a functional-gradient variant -- autograd.grad
+plus copies instead of backward() -- was tried as well) -- all of them showed it with GRX_PPO_LINEAR=torch (torch's own autograd for nn.Linear), so
 neither AccumulateGrad nor the BLAS library nor the fused loss is the cause; with the default GRX_PPO_LINEAR=colsum (bias
 gradients through libgrx_ppo.so's column sum instead of at::native's reduce kernel) both paths agree bit for bit."""
 import sys, os; sys.path.insert(0, ".")

@@ -54,7 +54,9 @@ class PPO:
         # ... and everything between the networks' outputs and their gradients is one HIP kernel (rl/fused_loss.py)
         self._fused_loss = self._device_lr and os.environ.get("GRX_PPO_FUSED_LOSS", "1") != "0"
         self._graph, self._graph_mb, self._static, self._sums, self._restore_opt = None, None, None, None, None
-        self._grad_bufs = None
+        # ... and so is the rollout's policy step (GRX_PPO_ACT_GRAPH=0: eager)
+        self._use_act_graph = self._device_lr and os.environ.get("GRX_PPO_ACT_GRAPH", "1") not in ("0", "")
+        self._act_graph, self._act_key, self._act_in, self._act_out = None, None, None, None
         if self._device_lr:
             # rsl_rl's `Normal.set_default_validate_args = False` (actor_critic.py) is an assignment, not a call, so the
             # reference validates (and host-syncs) on every Normal(); here the validation really is off
@@ -85,12 +87,49 @@ class PPO:
     def train_mode(self):
         self.actor_critic.train()
 
+    def _act_eager(self, actor_observations, critic_observations, capturable=False):
+        ac = self.actor_critic
+        if capturable:   # Normal.sample() = torch.normal(mean, std) checks std >= 0 on the host: not capturable
+            ac.update_distribution(actor_observations)
+            actions = (ac.action_mean + ac.action_std * torch.randn_like(ac.action_mean)).detach()
+        else:
+            actions = ac.act(actor_observations).detach()
+        values = ac.evaluate(critic_observations).detach()
+        logp = ac.get_actions_log_prob(actions).detach()
+        return actions, values, logp, ac.action_mean.detach(), ac.action_std.detach()
+
+    def _act_graphed(self, actor_observations, critic_observations):
+        """The rollout's policy step (two MLP forwards, sample, log-prob: ~35 kernels of a few microseconds) replayed from
+        a HIP graph on static input / output buffers.  The outputs are consumed (env.step, storage.add_transitions) before
+        the next call overwrites them.  The sampling draws from torch's default generator, which CUDA graphs advance per
+        replay."""
+        key = (tuple(actor_observations.shape), tuple(critic_observations.shape))
+        if self._act_graph is None or self._act_key != key:
+            # (not under inference_mode, where the runner calls act(): tensors created there -- the static buffers, the
+            #  generator's graph state -- would be inference tensors that later captures / replays may not update)
+            with torch.inference_mode(False), torch.no_grad():
+                self._act_in = (torch.zeros_like(actor_observations), torch.zeros_like(critic_observations))
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._act_eager(*self._act_in, capturable=True)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                self._act_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._act_graph, stream=side):
+                    self._act_out = self._act_eager(*self._act_in, capturable=True)
+            self._act_key = key
+        self._act_in[0].copy_(actor_observations)
+        self._act_in[1].copy_(critic_observations)
+        self._act_graph.replay()
+        return self._act_out
+
     def act(self, actor_observations, critic_observations):
-        t, ac = self.transition, self.actor_critic
-        t.actions = ac.act(actor_observations).detach()
-        t.values = ac.evaluate(critic_observations).detach()
-        t.actions_log_prob = ac.get_actions_log_prob(t.actions).detach()
-        t.action_mean, t.action_sigma = ac.action_mean.detach(), ac.action_std.detach()
+        t = self.transition
+        if self._use_act_graph and actor_observations.is_cuda and not torch.is_grad_enabled():
+            t.actions, t.values, t.actions_log_prob, t.action_mean, t.action_sigma = self._act_graphed(actor_observations, critic_observations)
+        else:
+            t.actions, t.values, t.actions_log_prob, t.action_mean, t.action_sigma = self._act_eager(actor_observations, critic_observations)
         t.observations, t.critic_observations = actor_observations, critic_observations
         return t.actions
 
@@ -280,19 +319,8 @@ class PPO:
                                                                   old_logp, old_mu, old_sigma)
         # grads dropped, not zero-filled: backward then WRITES each .grad (from the graph's private pool on replay) instead of
         # accumulating into a zeroed one -- one fill and one add kernel less per parameter and step (GRX_PPO_GRAD_NONE=0: fill)
-        if os.environ.get("GRX_PPO_GRAD_MODE", "") == "functional":
-            # gradients as plain outputs of autograd.grad, copied into persistent .grad buffers: no AccumulateGrad nodes
-            # (they run on the stream they were created on) inside the captured region
-            params = self._params
-            grads = torch.autograd.grad(loss, params, allow_unused=True)
-            if self._grad_bufs is None:
-                self._grad_bufs = [torch.zeros_like(p) for p in params]
-                for p, b in zip(params, self._grad_bufs):
-                    p.grad = b
-            torch._foreach_copy_(self._grad_bufs, [g if g is not None else torch.zeros_like(p) for g, p in zip(grads, params)])
-        else:
-            self.optimizer.zero_grad(set_to_none=os.environ.get("GRX_PPO_GRAD_NONE", "1") != "0")
-            loss.backward()
+        self.optimizer.zero_grad(set_to_none=os.environ.get("GRX_PPO_GRAD_NONE", "1") != "0")
+        loss.backward()
         if adaptive:
             self._device_lr_update(kl_mean)
         with torch.no_grad():
