@@ -133,19 +133,31 @@ __global__ __launch_bounds__(256) void colsum_partial(int rows, int cols, const 
     const int col = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
     float acc = 0.f;
-    if (col < cols)
-        for (int r = r0 + wv; r < r1; r += 4) acc += x[(size_t)r * cols + col];
+    if (col < cols) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four loads in flight per lane
+        int r = r0 + wv;
+        for (; r + 12 < r1; r += 16) {
+            a0 += x[(size_t)r * cols + col]; a1 += x[(size_t)(r + 4) * cols + col];
+            a2 += x[(size_t)(r + 8) * cols + col]; a3 += x[(size_t)(r + 12) * cols + col];
+        }
+        for (; r < r1; r += 4) a0 += x[(size_t)r * cols + col];
+        acc = (a0 + a1) + (a2 + a3);
+    }
     __shared__ float s_acc[4][64];
     s_acc[wv][lane] = acc;
     __syncthreads();
     if (wv == 0 && col < cols) partials[(size_t)blockIdx.y * cols + col] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
 }
+// one wave per column: lane l adds slabs l, l + 64, ... (in order), then a fixed shuffle tree -- deterministic, one exposed
+// load latency instead of nslab dependent ones
 __global__ __launch_bounds__(256) void colsum_final(int cols, int nslab, const float* __restrict__ partials, float* __restrict__ out) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= cols) return;
     float t = 0.f;
-    for (int b = 0; b < nslab; ++b) t += partials[(size_t)b * cols + col];
-    out[col] = t;
+    for (int b = lane; b < nslab; b += 64) t += partials[(size_t)b * cols + col];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+    if (lane == 0) out[col] = t;
 }
 }  // namespace
 
@@ -156,7 +168,7 @@ extern "C" int grx_ppo_colsum(int rows, int cols, const float* x, float* out, fl
     hipStream_t st = (hipStream_t)stream;
     const int nslab = (rows + CS_ROWS - 1) / CS_ROWS;
     hipLaunchKernelGGL(colsum_partial, dim3((cols + 63) / 64, nslab), dim3(256), 0, st, rows, cols, x, partials);
-    hipLaunchKernelGGL(colsum_final, dim3((cols + 255) / 256), dim3(256), 0, st, cols, nslab, partials, out);
+    hipLaunchKernelGGL(colsum_final, dim3((cols + 3) / 4), dim3(256), 0, st, cols, nslab, partials, out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
