@@ -64,7 +64,8 @@ class _TrainLinear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         prev = _TrainLinear._blas(weight.shape[0] == 1)
         try:
-            return dy @ weight, dy.t() @ x, colsum(dy)
+            dx = dy @ weight if ctx.needs_input_grad[0] else None   # (the first layer's input is data: no dX product)
+            return dx, dy.t() @ x, colsum(dy)
         finally:
             torch.backends.cuda.preferred_blas_library(prev)
 
