@@ -51,6 +51,11 @@ class PPO:
         # eager one bit for bit, rollouts in between included (tests/test_ppo_gpu.py) -- provided no torch column reduction
         # is inside it: see rl/modules.py:_TrainLinear.
         self._use_graph = self._device_lr and os.environ.get("GRX_PPO_GRAPH", "1") not in ("0", "")
+        if self._use_graph:
+            from . import modules
+            if modules._TRAIN_LINEAR != "colsum":   # torch's column reduction goes wrong under graph replay
+                print("PPO: GRX_PPO_LINEAR=" + modules._TRAIN_LINEAR + " -> the minibatch step runs eagerly (GRX_PPO_GRAPH=0)")
+                self._use_graph = False
         # ... and everything between the networks' outputs and their gradients is one HIP kernel (rl/fused_loss.py)
         self._fused_loss = self._device_lr and os.environ.get("GRX_PPO_FUSED_LOSS", "1") != "0"
         self._graph, self._graph_mb, self._static, self._sums, self._restore_opt = None, None, None, None, None
