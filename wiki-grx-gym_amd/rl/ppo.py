@@ -62,6 +62,10 @@ class PPO:
         # ... and so is the rollout's policy step (GRX_PPO_ACT_GRAPH=0: eager)
         self._use_act_graph = self._device_lr and os.environ.get("GRX_PPO_ACT_GRAPH", "1") not in ("0", "")
         self._act_graph, self._act_key, self._act_in, self._act_out = None, None, None, None
+        # inside the captured step the critic runs on a second stream (GRX_PPO_TWO_STREAMS=0: one stream); eagerly the extra
+        # stream bookkeeping costs more than the overlap gives
+        self._two_streams = self._use_graph and not _collective_path() and os.environ.get("GRX_PPO_TWO_STREAMS", "1") != "0"
+        self._aux_stream = None
         if self._device_lr:
             # rsl_rl's `Normal.set_default_validate_args = False` (actor_critic.py) is an assignment, not a call, so the
             # reference validates (and host-syncs) on every Normal(); here the validation really is off
@@ -253,8 +257,21 @@ class PPO:
         ac = self.actor_critic
         adaptive = self.desired_kl is not None and self.schedule == "adaptive"
         if self._fused_loss and not ac.fixed_std and ac.num_actor_output <= 32:   # the kernel's action-count limit
-            mu = ac.actor(obs)
-            value = ac.evaluate(cobs)
+            if self._two_streams:
+                # actor and critic are independent until the loss: the critic's forward (and, through autograd's stream
+                # bookkeeping, its backward) runs on a second stream
+                cur = torch.cuda.current_stream(self.device)
+                if self._aux_stream is None:
+                    self._aux_stream = torch.cuda.Stream(device=self.device)
+                self._aux_stream.wait_stream(cur)
+                with torch.cuda.stream(self._aux_stream):
+                    value = ac.evaluate(cobs)
+                mu = ac.actor(obs)
+                cur.wait_stream(self._aux_stream)
+                value.record_stream(cur)
+            else:
+                mu = ac.actor(obs)
+                value = ac.evaluate(cobs)
             out = fused_ppo_loss(mu, ac.std, value, actions, old_logp, old_mu, old_sigma, advantages, returns, target_values,
                                  self.clip_param, self.value_loss_coef, self.entropy_coef, self.use_clipped_value_loss)
             kl_mean = out[3].detach() if adaptive else torch.zeros((), device=self.device)
