@@ -346,6 +346,31 @@ int grx_kernel_time_ms(grx_handle h, int enable, float* avg_ms, int64_t* launche
  * kernel of each step stores in host-pinned memory), see grx_capi.cpp. */
 int grx_wait_idle(grx_handle h);
 
+/* ---- TEST-ONLY entry (not part of the drop-in surface; the reference has no counterpart) ----------------------
+ * State injected into the post-physics half of the step: the same record the CPU oracle's gro_debug_post_physics
+ * takes, so that tests/ can present the reference's golden fixtures (tools/gen_golden.py: legged_robot.py:269-481,
+ * legged_robot_fftai.py:90-167, gr1t1.py:281-589 evaluated on synthetic state) to the HIP kernels DIRECTLY. */
+typedef struct grx_pipeline_state {
+    float q[GRX_MAX_DOFS], qd[GRX_MAX_DOFS], root[13];
+    float actions[GRX_MAX_DOFS], last_actions[GRX_MAX_DOFS], last_last_actions[GRX_MAX_DOFS], last_dof_vel[GRX_MAX_DOFS], torques[GRX_MAX_DOFS];
+    float commands[3];
+    float air_time[2], land_time[2];
+    int32_t contact_last[2];
+    float feet_force[2][3], feet_pos[2][3];   /* contact_forces[feet], rigid_body_states[feet, 0:3] */
+    float avg_force[2], avg_speed[2][3];      /* sub-step averages (legged_robot_fftai.py:79-88) */
+    float torso_R[9];                         /* ignored by the HIP path: the torso rides on the base lump */
+    float heights[GRX_MAX_HEIGHT_POINTS];     /* ignored by the HIP path: plane = zeros, heightfield = own scan */
+    float base_heights_offset;                /* the STALE value the reward reads */
+    int64_t episode_length;
+    int32_t term_contact;                     /* a terminating link carries |F| > termination_force */
+} grx_pipeline_state;
+
+/* Run post_physics_step (everything after the sub-step loop: state update, timers, termination, rewards, reset,
+ * observations, history) of ALL envs on `states` (HOST array, num_envs entries).  args->actions is ignored (the
+ * injected actions are used), args->common_step_counter and args->noise_uniform are honoured.  apply_reset == 0:
+ * resets are reported in GRX_T_RESET but not applied.  Lower-limb (fused-kernel) models only. */
+int grx_debug_post_physics(grx_handle h, const grx_pipeline_state* states, int apply_reset, const grx_step_args* args, void* stream);
+
 const char* grx_last_error(void);
 int grx_abi_version(void);
 const char* grx_reward_term_name(int term);

@@ -20,18 +20,7 @@ def build():
     subprocess.run(["make", "-s", "-C", _HERE], check=True)
 
 
-class PipelineState(C.Structure):
-    _fields_ = [
-        ("q", C.c_float * _capi.MAX_DOFS), ("qd", C.c_float * _capi.MAX_DOFS), ("root", C.c_float * 13),
-        ("actions", C.c_float * _capi.MAX_DOFS), ("last_actions", C.c_float * _capi.MAX_DOFS),
-        ("last_last_actions", C.c_float * _capi.MAX_DOFS), ("last_dof_vel", C.c_float * _capi.MAX_DOFS),
-        ("torques", C.c_float * _capi.MAX_DOFS), ("commands", C.c_float * 3),
-        ("air_time", C.c_float * 2), ("land_time", C.c_float * 2), ("contact_last", C.c_int32 * 2),
-        ("feet_force", (C.c_float * 3) * 2), ("feet_pos", (C.c_float * 3) * 2),
-        ("avg_force", C.c_float * 2), ("avg_speed", (C.c_float * 3) * 2), ("torso_R", C.c_float * 9),
-        ("heights", C.c_float * _capi.MAX_HEIGHT_POINTS), ("base_heights_offset", C.c_float),
-        ("episode_length", C.c_int64), ("term_contact", C.c_int32),
-    ]
+PipelineState = _capi.PipelineState   # the record both gro_debug_post_physics and grx_debug_post_physics take
 
 
 _libs = {}

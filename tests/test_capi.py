@@ -55,16 +55,18 @@ def test_struct_layout_matches_header(tmp_path):
                    'size_t a(void){return sizeof(grx_config);} size_t b(void){return sizeof(grx_model);}\n'
                    'size_t c(void){return offsetof(grx_config, reward_scale);} size_t d(void){return offsetof(grx_config, height_samples);}\n'
                    'size_t e(void){return offsetof(grx_config, terrain_origins);} size_t f(void){return sizeof(grx_step_args);}\n'
-                   'size_t g(void){return sizeof(grx_tensor_desc);} int h(void){return GRX_NUM_TENSORS;} int i(void){return GRX_NUM_REWARD_TERMS;}\n')
+                   'size_t g(void){return sizeof(grx_tensor_desc);} int h(void){return GRX_NUM_TENSORS;} int i(void){return GRX_NUM_REWARD_TERMS;}\n'
+                   'size_t j(void){return sizeof(grx_pipeline_state);} size_t k(void){return offsetof(grx_pipeline_state, episode_length);}\n')
     so = tmp_path / "sz.so"
     subprocess.run(["gcc", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(so)], check=True)
     lib = C.CDLL(str(so))
-    for fn in "abcdefg":
+    for fn in "abcdefgjk":
         getattr(lib, fn).restype = C.c_size_t
     assert lib.a() == C.sizeof(_capi.Config) and lib.b() == C.sizeof(_capi.Model)
     assert lib.c() == _capi.Config.reward_scale.offset and lib.d() == _capi.Config.height_samples.offset
     assert lib.e() == _capi.Config.terrain_origins.offset
     assert lib.f() == C.sizeof(_capi.StepArgs) and lib.g() == C.sizeof(_capi.TensorDesc)
+    assert lib.j() == C.sizeof(_capi.PipelineState) and lib.k() == _capi.PipelineState.episode_length.offset
     assert lib.h() == len(_capi.TENSOR_IDS) and lib.i() == _capi.NUM_REWARD_TERMS
 
 

@@ -188,8 +188,10 @@ def test_internal_noise_stream_matches():
     assert torch.equal(hip.tensor("PRI_OBS")[:, :39], h2.tensor("PRI_OBS")[:, :39])    # pri_obs copies obs before noise
 
 
-def test_one_step_parity_rough_terrain():
-    cfg = make_cfg(terrain="heightfield", dr=True, push=True)
+@pytest.mark.parametrize("task", ["GR1T1", "GR1T2"])
+def test_one_step_parity_rough_terrain(task):
+    """Rough-terrain curriculum heightfield, both registered robots (GR1T2 rough = BASELINE.json config 4's workload)."""
+    cfg = make_cfg(task=task, terrain="heightfield", dr=True, push=True)
     hip, ora = make_sims(cfg, 320, seed=1)
     assert torch.equal(hip.tensor("TERRAIN_TYPES").cpu(), ora.tensor("TERRAIN_TYPES"))
     assert torch.equal(hip.tensor("TERRAIN_LEVELS").cpu(), ora.tensor("TERRAIN_LEVELS"))
@@ -276,15 +278,17 @@ def test_free_running_rollout_stays_close():
 
 
 # ------------------------------------------------------------------ full-size properties
-@pytest.mark.parametrize("N", [4096, 32768])
-def test_full_size_properties(N, monkeypatch):
+@pytest.mark.parametrize("task,terrain,N", [("GR1T1", "heightfield", 4096), ("GR1T1", "heightfield", 32768),
+                                             ("GR1T1", "plane", 4096),           # BASELINE.json config 2 (flat, 4096)
+                                             ("GR1T2", "heightfield", 32768)])   # config 4 (GR1T2 rough, 32768 = 8 x 4096)
+def test_full_size_properties(task, terrain, N, monkeypatch):
     """BASELINE.json sizes: finiteness, determinism (bit-identical reruns), shard invariance
     (env i does not depend on how the batch is split across ranks: the multi-GPU contract).
-    Bit-identity holds per step-kernel layout (waves per 32-env block, picked from the local batch size: 4 up to
-    8192 envs, 2 up to 16384, 1 beyond); the 32768 case pins the layout so that the shards use the full run's."""
+    Bit-identity holds per step-kernel layout (waves per 32-env block, picked from the local batch size);
+    the 32768 cases pin the layout so that the shards use the full run's."""
     if N == 32768:
         monkeypatch.setenv("GRX_WAVES_PER_BLOCK", "1")
-    cfg = make_cfg(terrain="heightfield", noise=True, dr=True, push=True)
+    cfg = make_cfg(task=task, terrain=terrain, noise=True, dr=True, push=True)
     from tests.helpers import make_terrain
     from wiki_grx_gym_amd.envs import build_config
     from wiki_grx_gym_amd.sim import HipSim
@@ -312,6 +316,12 @@ def test_full_size_properties(N, monkeypatch):
     lo, hi = run(half, 0, N), run(half, half, N)
     for k in full:
         assert torch.equal(full[k][:half], lo[k]) and torch.equal(full[k][half:], hi[k]), f"{k} depends on the sharding"
+    if N == 32768:   # ... and split eight ways, as config 4 shards it over the node: first and last rank's slices
+        q = N // 8
+        for r in (0, 7):
+            part = run(q, r * q, N)
+            for k in full:
+                assert torch.equal(full[k][r * q:(r + 1) * q], part[k]), f"{k} depends on the sharding (rank {r} of 8)"
     assert full["RESET"].sum() > 0 and (full["PRI_OBS"][:, 47:].abs().sum() > 0)
 
 

@@ -56,12 +56,36 @@ def fill_state(ps, d, pre, i):
     ps.term_contact = int(d[pre + "term_contact"][i])
 
 
-@pytest.mark.parametrize("precision,tol", [("f64", 2e-6), ("f32", 1e-4)])
-def test_pipeline_two_steps(precision, tol):
+def states_from(d, pre, N):
+    """One PipelineState record per env of a golden fixture (keys `pre` + name)."""
     from oracle.binding import PipelineState
+    arr = (PipelineState * N)()
+    for i in range(N):
+        fill_state(arr[i], d, pre, i)
+    return arr
+
+
+def inject(sim, arr, **kw):
+    """Run post_physics_step on the injected records: per env through the oracle's gro_debug_post_physics, all at
+    once through libgrx_hip.so's grx_debug_post_physics (same record type, include/grx.h)."""
+    if hasattr(sim, "post_physics"):
+        for i in range(len(arr)):
+            sim.post_physics(i, arr[i], apply_reset=False, **kw)
+    else:
+        nz = kw.pop("noise_uniform", None)
+        sim.debug_post_physics(arr, apply_reset=False, noise_uniform=None if nz is None else nz.to(sim.device), **kw)
+        torch.cuda.synchronize()
+
+
+def T_(sim, name):
+    return sim.tensor(name).detach().cpu()
+
+
+def check_pipeline_two_steps(sim, cfg, meta, tol):
+    """reference post_physics_step x2 (tests/golden/pipeline.npz: legged_robot.py:269-481, legged_robot_fftai.py:90-167,
+    gr1t1.py:281-589 on synthetic state incl. the threshold rows) vs `sim` (oracle or HIP)."""
     d = np.load(os.path.join(G, "pipeline.npz"))
     N = d["s0_in_root"].shape[0]
-    sim, cfg, meta = make_oracle(N, precision)
     names = list(d["reward_names"])
     assert names == meta["active_terms"], "active reward terms / their (alphabetical) order differ from the reference"
     term_idx = [_capi.REWARD_TERMS.index(n) for n in names]
@@ -69,10 +93,7 @@ def test_pipeline_two_steps(precision, tol):
     for s in range(2):
         pre, post = f"s{s}_in_", f"s{s}_out_"
         noise = torch.tensor(d[f"s{s}_noise_u"]).contiguous()
-        for i in range(N):
-            ps = PipelineState()
-            fill_state(ps, d, pre, i)
-            sim.post_physics(i, ps, apply_reset=False, common_step_counter=s + 1, noise_uniform=noise)
+        inject(sim, states_from(d, pre, N), common_step_counter=s + 1, noise_uniform=noise)
         resampled = np.any(d[post + "commands_after"] != d[pre + "commands"], axis=1)
         keep = ~resampled
         ever_resampled |= resampled   # their reward history differs (RNG), so do the cumulative sums
@@ -84,48 +105,52 @@ def test_pipeline_two_steps(precision, tol):
             lim = tol + tol * np.abs(want)
             assert (err <= lim).all(), f"step {s} {name}: max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
         allrows = np.ones(N, bool)
-        np.testing.assert_array_equal(sim.tensor("RESET").numpy().astype(bool), d[post + "reset"].astype(bool))
-        np.testing.assert_array_equal(sim.tensor("TIME_OUT").numpy().astype(bool), d[post + "time_out"].astype(bool))
-        np.testing.assert_array_equal(sim.tensor("FEET_CONTACT").numpy().astype(bool), d[post + "feet_contact"].astype(bool))
-        np.testing.assert_array_equal(sim.tensor("EPISODE_LENGTH").numpy(), d[post + "episode_length_after"])
-        close("base_lin_vel", sim.tensor("BASE_LIN_VEL"), d[post + "base_lin_vel"], allrows)
-        close("base_ang_vel", sim.tensor("BASE_ANG_VEL"), d[post + "base_ang_vel"], allrows)
-        close("projected_gravity", sim.tensor("PROJECTED_GRAVITY"), d[post + "projected_gravity"], allrows)
-        close("air_time", sim.tensor("FEET_AIR_TIME"), d[post + "air_time_after"], allrows)
-        close("land_time", sim.tensor("FEET_LAND_TIME"), d[post + "land_time_after"], allrows)
-        close("feet_height", sim.tensor("FEET_HEIGHT"), d[post + "feet_height"], allrows)
-        close("base_heights_offset", sim.tensor("BASE_HEIGHTS_OFFSET"), d[post + "base_heights_offset_after"], allrows)
-        close("last_actions", sim.tensor("LAST_ACTIONS"), d[post + "last_actions_after"], allrows)
-        close("rew", sim.tensor("REW"), d[post + "rew"])
-        close("obs", sim.tensor("OBS"), d[post + "obs"])
-        close("pri_obs", sim.tensor("PRI_OBS"), d[post + "pri_obs"])
-        es = sim.tensor("EPISODE_SUMS").numpy()[term_idx]          # (24, N)
+        np.testing.assert_array_equal(T_(sim, "RESET").numpy().astype(bool), d[post + "reset"].astype(bool))
+        np.testing.assert_array_equal(T_(sim, "TIME_OUT").numpy().astype(bool), d[post + "time_out"].astype(bool))
+        np.testing.assert_array_equal(T_(sim, "FEET_CONTACT").numpy().astype(bool), d[post + "feet_contact"].astype(bool))
+        np.testing.assert_array_equal(T_(sim, "EPISODE_LENGTH").numpy(), d[post + "episode_length_after"])
+        close("base_lin_vel", T_(sim, "BASE_LIN_VEL"), d[post + "base_lin_vel"], allrows)
+        close("base_ang_vel", T_(sim, "BASE_ANG_VEL"), d[post + "base_ang_vel"], allrows)
+        close("projected_gravity", T_(sim, "PROJECTED_GRAVITY"), d[post + "projected_gravity"], allrows)
+        close("air_time", T_(sim, "FEET_AIR_TIME"), d[post + "air_time_after"], allrows)
+        close("land_time", T_(sim, "FEET_LAND_TIME"), d[post + "land_time_after"], allrows)
+        close("feet_height", T_(sim, "FEET_HEIGHT"), d[post + "feet_height"], allrows)
+        close("base_heights_offset", T_(sim, "BASE_HEIGHTS_OFFSET"), d[post + "base_heights_offset_after"], allrows)
+        close("last_actions", T_(sim, "LAST_ACTIONS"), d[post + "last_actions_after"], allrows)
+        close("rew", T_(sim, "REW"), d[post + "rew"])
+        close("obs", T_(sim, "OBS"), d[post + "obs"])
+        close("pri_obs", T_(sim, "PRI_OBS"), d[post + "pri_obs"])
+        es = T_(sim, "EPISODE_SUMS").numpy()[term_idx]          # (24, N)
         close("episode_sums", es.T, d[post + "episode_sums"].T, ~ever_resampled)
         # quirk: after a step last_last_actions == last_actions == actions (fftai:94 after legged_robot.py:299)
         np.testing.assert_array_equal(d[post + "last_last_actions_after"], d[post + "last_actions_after"])
+    # the fixture's edge rows really are edge rows (F_z = 1.0 exactly, |g_z| either side of 0.33, ep_len 1000 / 1001,
+    # last_last_actions != last_actions): they are what the threshold comparisons above were fed
+    assert d["s0_in_feet_force"][3, 0, 2] == 1.0 and not d["s0_out_feet_contact"][3, 0] and d["s0_out_feet_contact"][4, 1]
+    assert d["s0_out_reset"][8] and not d["s0_out_time_out"][8] and d["s0_out_time_out"][7] and not d["s0_out_time_out"][6]
+    assert np.abs(d["s0_in_last_last_actions"] - d["s0_in_last_actions"]).max() > 0.1
     sc = np.array([cfg_scale for cfg_scale in d["reward_scales_dt"]])
     mine = np.array([getattr(cfg.rewards.scales, n) * meta["dt"] for n in names])
     np.testing.assert_allclose(mine, sc, rtol=1e-6)
 
 
 @pytest.mark.parametrize("precision,tol", [("f64", 2e-6), ("f32", 1e-4)])
-def test_every_reward_term(precision, tol):
-    """All 35 evaluable FF/G1 terms (active or not) on one synthetic state."""
-    from oracle.binding import PipelineState
+def test_pipeline_two_steps(precision, tol):
+    sim, cfg, meta = make_oracle(np.load(os.path.join(G, "pipeline.npz"))["s0_in_root"].shape[0], precision)
+    check_pipeline_two_steps(sim, cfg, meta, tol)
+
+
+def check_every_reward_term(sim, cfg, tol):
+    """The 34 FF/G1 reward terms the reference can evaluate (legged_robot_fftai.py:180-352, gr1t1.py:338-589; active or
+    not -- limits_actions has no sigma in the reference) on one synthetic state: the ACTIVE ones, scaled."""
     d = np.load(os.path.join(G, "reward_terms.npz"))
     N = d["in_root"].shape[0]
-    sim, cfg, _ = make_oracle(N, precision, noise=False)
     names = list(d["names"])
-    for i in range(N):
-        ps = PipelineState()
-        fill_state(ps, d, "in_", i)
-        sim.post_physics(i, ps, apply_reset=False)
-        # reward_terms() re-evaluates on the post-step state: restore what the history copy overwrote
-        # (the golden values were taken before compute_observations / history update)
-    # evaluate term-by-term from a fresh injection that stops before the history update is not exposed;
-    # instead compare through REWARD_TERMS for active terms and gro_debug_reward_terms for the rest
-    got_active = sim.tensor("REWARD_TERMS").numpy()
+    assert len(names) == 34 and {"limits_dof_tor", "limits_dof_vel", "on_the_air", "pose_offset"} <= set(names)
+    inject(sim, states_from(d, "in_", N))
+    got_active = T_(sim, "REWARD_TERMS").numpy()
     dt = cfg.control.decimation * cfg.sim.dt
+    checked = 0
     for n in names:
         t = _capi.REWARD_TERMS.index(n)
         scale = getattr(cfg.rewards.scales, n, 0.0)
@@ -134,13 +159,18 @@ def test_every_reward_term(precision, tol):
         want = d["values"][names.index(n)] * scale * dt
         err = np.abs(got_active[t] - want)
         assert (err <= tol + tol * np.abs(want)).all(), f"{n}: max err {err.max():.3e}"
+        checked += 1
+    assert checked == 24   # every active term of the registered GR1T1 task is pinned individually
 
 
-def test_inactive_reward_terms_formulas():
-    """Terms with zero scale in the registered config: enable them one by one in the oracle."""
-    from oracle.binding import OracleSim, PipelineState
+@pytest.mark.parametrize("precision,tol", [("f64", 2e-6), ("f32", 1e-4)])
+def test_every_reward_term(precision, tol):
+    sim, cfg, _ = make_oracle(64, precision, noise=False)
+    check_every_reward_term(sim, cfg, tol)
+
+
+def inactive_terms_cfg():
     d = np.load(os.path.join(G, "reward_terms.npz"))
-    N = d["in_root"].shape[0]
     names = list(d["names"])
     cfg = make_cfg(noise=False, dr=False)
     inactive = [n for n in names if getattr(cfg.rewards.scales, n, 0.0) == 0 and n != "termination"]
@@ -148,18 +178,28 @@ def test_inactive_reward_terms_formulas():
     for n in inactive:
         setattr(cfg.rewards.scales, n, 1.0)
     cfg.rewards.scales.termination = 1.0
-    c, keep, _ = build_config.build(cfg, cfg.sim.dt, N)
-    sim = OracleSim(c, "f64", keep)
-    for i in range(N):
-        ps = PipelineState()
-        fill_state(ps, d, "in_", i)
-        sim.post_physics(i, ps, apply_reset=False)
-    got = sim.tensor("REWARD_TERMS").numpy()
+    return cfg, inactive
+
+
+def check_inactive_reward_terms(sim, cfg, inactive, tol):
+    d = np.load(os.path.join(G, "reward_terms.npz"))
+    N = d["in_root"].shape[0]
+    names = list(d["names"])
+    inject(sim, states_from(d, "in_", N))
+    got = T_(sim, "REWARD_TERMS").numpy()
     dt = cfg.control.decimation * cfg.sim.dt
     for n in inactive + ["termination"]:
         want = d["values"][names.index(n)] * 1.0 * dt
         err = np.abs(got[_capi.REWARD_TERMS.index(n)] - want)
-        assert (err <= 2e-6 + 2e-6 * np.abs(want)).all(), f"{n}: max err {err.max():.3e}"
+        assert (err <= tol + tol * np.abs(want)).all(), f"{n}: max err {err.max():.3e}"
+
+
+def test_inactive_reward_terms_formulas():
+    """Terms with zero scale in the registered config: enabled (scale 1) in the oracle."""
+    from oracle.binding import OracleSim
+    cfg, inactive = inactive_terms_cfg()
+    c, keep, _ = build_config.build(cfg, cfg.sim.dt, 64)
+    check_inactive_reward_terms(OracleSim(c, "f64", keep), cfg, inactive, 2e-6)
 
 
 @pytest.mark.parametrize("precision,tol", [("f64", 1e-6), ("f32", 1e-4)])

@@ -342,8 +342,10 @@ def gen_reward_terms(out):
              "cmd_diff_lin_vel_z", "cmd_diff_torso_orient", "collision", "dof_acc_new", "dof_tor_ankle_feet_lift_up", "dof_tor_new",
              "dof_tor_new_hip_roll", "dof_vel_new", "dof_vel_new_knee", "feet_air_force", "feet_air_height", "feet_air_time",
              "feet_land_time", "feet_speed_xy_close_to_ground", "feet_speed_z_close_to_height_target", "feet_stumble",
-             "limits_dof_pos",   # limits_actions: the reference has no sigma_limits_actions -> AttributeError if enabled "limits_dof_tor", "limits_dof_vel", "on_the_air", "pose_offset",
+             "limits_dof_pos", "limits_dof_tor", "limits_dof_vel", "on_the_air", "pose_offset",
              "pose_offset_hip_yaw", "stand_still", "termination"]
+    # (limits_actions is the one FF/G1 term left out: the reference has no sigma_limits_actions -> AttributeError if enabled)
+    assert len(names) == 34 and names == sorted(names), len(names)
     vals = {}
     for n in names:
         v = getattr(env, "_reward_" + n)()

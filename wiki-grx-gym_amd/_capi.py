@@ -139,6 +139,21 @@ class StepArgs(C.Structure):
                 ("common_step_counter", i64), ("noise_uniform", C.c_void_p)]
 
 
+class PipelineState(C.Structure):
+    """grx_pipeline_state (TEST-ONLY entry grx_debug_post_physics; the oracle's gro_debug_post_physics takes the same record)."""
+    _fields_ = [
+        ("q", f32 * MAX_DOFS), ("qd", f32 * MAX_DOFS), ("root", f32 * 13),
+        ("actions", f32 * MAX_DOFS), ("last_actions", f32 * MAX_DOFS),
+        ("last_last_actions", f32 * MAX_DOFS), ("last_dof_vel", f32 * MAX_DOFS),
+        ("torques", f32 * MAX_DOFS), ("commands", f32 * 3),
+        ("air_time", f32 * 2), ("land_time", f32 * 2), ("contact_last", i32 * 2),
+        ("feet_force", (f32 * 3) * 2), ("feet_pos", (f32 * 3) * 2),
+        ("avg_force", f32 * 2), ("avg_speed", (f32 * 3) * 2), ("torso_R", f32 * 9),
+        ("heights", f32 * MAX_HEIGHT_POINTS), ("base_heights_offset", f32),
+        ("episode_length", i64), ("term_contact", i32),
+    ]
+
+
 def bind(lib, prefix="grx_"):
     """Declare argtypes/restypes of every entry point of include/grx.h on a loaded CDLL."""
     H = C.c_void_p
@@ -161,6 +176,8 @@ def bind(lib, prefix="grx_"):
         "abi_version": fn("abi_version", C.c_int),
         "reward_term_name": fn("reward_term_name", C.c_char_p, C.c_int),
     }
+    if hasattr(lib, prefix + "debug_post_physics") and prefix == "grx_":   # the oracle's entry of that name is per-env (oracle/binding.py)
+        api["debug_post_physics"] = fn("debug_post_physics", C.c_int, H, C.POINTER(PipelineState), C.c_int, C.POINTER(StepArgs), C.c_void_p)
     if hasattr(lib, prefix + "wait_idle"):
         api["wait_idle"] = fn("wait_idle", C.c_int, H)
     if hasattr(lib, prefix + "kernel_time_ms"):
@@ -171,5 +188,5 @@ def bind(lib, prefix="grx_"):
 EXPORTED_SYMBOLS = (
     "grx_create", "grx_destroy", "grx_reset_all", "grx_step", "grx_tensor", "grx_set_state",
     "grx_episode_stats", "grx_kernel_time_ms", "grx_wait_idle", "grx_last_error", "grx_abi_version",
-    "grx_reward_term_name",
+    "grx_reward_term_name", "grx_debug_post_physics",
 )

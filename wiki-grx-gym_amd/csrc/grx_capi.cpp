@@ -28,6 +28,9 @@ int grx_generic_ws_floats_per_env(int nb, int nlc);
 void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream);
 void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, hipStream_t stream);
 int grx_envs_per_block(void);
+void grx_launch_step_debug(const KParams* dP, int N, int heightfield, const float* actions, long long common_step, const float* noise,
+                           const float* dbg, hipStream_t stream);
+int grx_debug_rows(void);
 }
 
 namespace {
@@ -93,6 +96,8 @@ struct grx_sim {
     // tensor table
     grx_tensor_desc desc[GRX_NUM_TENSORS];
     long long* prof_host = nullptr; int prof_blocks = 0;
+    float* d_dbg = nullptr;       // grx_debug_post_physics: injected quantities [grx_debug_rows()][N]
+    float* d_dbg_actions = nullptr;   // ... and the injected (already clipped) actions, (N, nd) row-major
 };
 
 namespace {
@@ -774,6 +779,56 @@ int grx_debug_profile(grx_handle s, long long* out, int max_blocks) {
     int nb = s->prof_blocks < max_blocks ? s->prof_blocks : max_blocks;
     HIP_TRY(hipMemcpy(out, s->prof_host, (size_t)nb * 32 * sizeof(long long), hipMemcpyDeviceToHost));
     return nb;
+}
+
+// TEST-ONLY: post_physics_step of every env on injected state (include/grx.h).  Uploads the records into the SoA state
+// buffers + the debug rows, then launches the one-wave step kernel's DBG instantiation (no sub-steps).
+int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply_reset, const grx_step_args* a, void* stream) {
+    if (!s || !ps || !a) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_post_physics: null argument");
+    if (s->generic) return fail(GRX_ERR_UNSUPPORTED_MODEL, "grx_debug_post_physics: lower-limb (fused-kernel) models only");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t N = (size_t)s->N;
+    const int nd = s->nd, rows = grx_debug_rows();
+    int rc;
+    if (!s->d_dbg) {
+        if ((rc = dalloc(s, &s->d_dbg, (size_t)rows * N))) return rc;
+        if ((rc = dalloc(s, &s->d_dbg_actions, (size_t)nd * N))) return rc;
+    }
+    std::vector<float> q(nd * N), qd(nd * N), root(13 * N), la(nd * N), lqd(nd * N), cmd(3 * N), air(2 * N), land(2 * N), bho(N), dbg((size_t)rows * N), act(nd * N);
+    std::vector<uint8_t> fc(2 * N);
+    std::vector<long long> ep(N);
+    for (size_t i = 0; i < N; ++i) {
+        const grx_pipeline_state& p = ps[i];
+        for (int j = 0; j < nd; ++j) {
+            q[j * N + i] = p.q[j]; qd[j * N + i] = p.qd[j]; la[j * N + i] = p.last_actions[j]; lqd[j * N + i] = p.last_dof_vel[j];
+            act[i * nd + j] = p.actions[j];
+            dbg[(20 + j) * N + i] = p.torques[j]; dbg[(30 + j) * N + i] = p.last_last_actions[j];
+        }
+        for (int k = 0; k < 13; ++k) root[k * N + i] = p.root[k];
+        for (int k = 0; k < 3; ++k) cmd[k * N + i] = p.commands[k];
+        for (int f = 0; f < 2; ++f) {
+            air[f * N + i] = p.air_time[f]; land[f * N + i] = p.land_time[f]; fc[f * N + i] = p.contact_last[f] ? 1 : 0;
+            dbg[(12 + f) * N + i] = p.avg_force[f];
+            for (int k = 0; k < 3; ++k) {
+                dbg[(0 + f * 3 + k) * N + i] = p.feet_force[f][k]; dbg[(6 + f * 3 + k) * N + i] = p.feet_pos[f][k];
+                dbg[(14 + f * 3 + k) * N + i] = p.avg_speed[f][k];
+            }
+        }
+        bho[i] = p.base_heights_offset; ep[i] = p.episode_length;
+        dbg[40 * N + i] = p.term_contact ? 1.f : 0.f; dbg[41 * N + i] = apply_reset ? 1.f : 0.f;
+    }
+    const KParams& P = s->hp;
+#define UPS(dst, vec) HIP_TRY(hipMemcpyAsync(dst, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, st))
+    UPS(P.q, q); UPS(P.qd, qd); UPS(P.root, root); UPS(P.last_actions, la); UPS(P.last_dof_vel, lqd); UPS(P.commands, cmd);
+    UPS(P.air_time, air); UPS(P.land_time, land); UPS(P.feet_contact, fc); UPS(P.base_heights_offset, bho); UPS(P.ep_len, ep);
+    UPS(s->d_dbg, dbg); UPS(s->d_dbg_actions, act);
+#undef UPS
+    HIP_TRY(hipStreamSynchronize(st));   // the host vectors go out of scope
+    grx_launch_step_debug(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->d_dbg_actions, (long long)a->common_step_counter,
+                          a->noise_uniform, s->d_dbg, st);
+    grx_launch_finalize(s->d_hp, s->stat_blocks, s->pace.d_progress, ++s->pace.issued, st);
+    HIP_TRY(hipGetLastError());
+    return GRX_OK;
 }
 
 // spin until every step enqueued through this handle has finished on the GPU (reads the pinned progress word)

@@ -777,7 +777,8 @@ GRX_DEV void load_episode_sums(KP P, int e, int N, float es[NT]) {
 // es_pre: the env's running episode sums if the caller loaded them early, else nullptr.
 template <int PART>
 GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane, int side, int e, int N, bool act,
-                             float* s_stat, const float* es_pre, float* rew_part = nullptr, int* rew_flag = nullptr) {
+                             float* s_stat, const float* es_pre, float* rew_part = nullptr, int* rew_flag = nullptr,
+                             const float* a_ll = nullptr) {
     const int j0 = side * LEG;
     const float dtp = P.sim_dt * (float)P.decimation;
     const bool reset = in.reset != 0.f, time_out = in.time_out != 0.f;
@@ -792,11 +793,12 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
         const GRX_AS4 float* sg = P.reward_sigma;
         const uint32_t knee = (P.knee_mask >> j0) & 31u, hiproll = (P.hip_roll_mask >> j0) & 31u, hipyaw = (P.hip_yaw_mask >> j0) & 31u;
         const uint32_t ankle = ((side ? P.ankle_right_mask : P.ankle_left_mask) >> j0) & 31u;
-        float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {
             float d1 = (in.a_last[k] - in.a_cur[k]) * as;
             s1 += fabsf(d1);  // last_last_actions == last_actions (legged_robot_fftai.py:94 copies after legged_robot.py:299)
+            if (a_ll) s2 += fabsf(d1 - (a_ll[k] - in.a_last[k]) * as);   // grx_debug_post_physics only: injected last_last_actions
             if (knee & (1u << k)) s3 += fabsf((in.a_cur[k] - in.a_last[k]) * as);
             sacc += fabsf((in.qd[k] - in.qd_last[k]) / dtp);
             stor += fabsf(in.torque[k]);
@@ -833,7 +835,8 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
         serr = serr * (serr > 0.f ? 1.f : 0.f);
         float stum = 1.f - expf(sg[GRX_REW_FEET_STUMBLE] * serr);
         float ncontact = in.contact;
-        s1 = pair_sum(s1); s3 = pair_sum(s3); sacc = pair_sum(sacc); stor = pair_sum(stor); svel = pair_sum(svel);
+        s1 = pair_sum(s1); s3 = pair_sum(s3);
+        s2 = a_ll ? pair_sum(s2) : s1; sacc = pair_sum(sacc); stor = pair_sum(stor); svel = pair_sum(svel);
         spose = pair_sum(spose); sla = pair_sum(sla); slp = pair_sum(slp); slt = pair_sum(slt); slv = pair_sum(slv);
         shy = pair_sum(shy); tor_hr = pair_sum(tor_hr); vel_kn = pair_sum(vel_kn); lift = pair_sum(lift);
         af = pair_sum(af); ah = pair_sum(ah); at = pair_sum(at); lt = pair_sum(lt); exy = pair_sum(exy); ez = pair_sum(ez);
@@ -841,7 +844,7 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
         const float cmd_n = sqrtf(in.cmd[0] * in.cmd[0] + in.cmd[1] * in.cmd[1]);
         const float moving = cmd_n > 0.1f ? 1.f : 0.f;
         r[GRX_REW_ACTION_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF] * s1);
-        r[GRX_REW_ACTION_DIFF_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_DIFF] * s1);
+        r[GRX_REW_ACTION_DIFF_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_DIFF] * s2);
         r[GRX_REW_ACTION_DIFF_KNEE] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_KNEE] * s3);
         r[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] * fabsf(0.f - in.bav.y));
         r[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] * fabsf(0.f - in.bav.x));
@@ -951,9 +954,17 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
 //   W == 1: one wave does everything (large batches: every SIMD is busy with its own envs anyway);
 //   W == 2: wave 1 computes the base-lump contact wrench of every sub-step (two block barriers per sub-step);
 //   W == 4: the four-wave producer/consumer pipeline of grx_wavepipe.h (sequence counters in LDS).
-template <bool HF, int W>
+// DBG (W == 1 only, behind the test-only entry grx_debug_post_physics): no sub-steps; the quantities the physics
+// would have produced (feet forces / positions, sub-step averages, torques, termination contact) and
+// last_last_actions come from `dbg` ([DBG_ROWS][N], see DbgRow), so the post-physics half of the step can be fed the
+// reference's golden fixtures directly.
+enum DbgRow { DBG_FEET_FORCE = 0, DBG_FEET_POS = 6, DBG_AVG_FORCE = 12, DBG_AVG_SPEED = 14, DBG_TORQUES = 20, DBG_LAST_LAST_ACTIONS = 30,
+              DBG_TERM_CONTACT = 40, DBG_APPLY_RESET = 41, DBG_ROWS = 42 };
+template <bool HF, int W, bool DBG = false>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_kernel(const KParams* __restrict__ Pg, const float* __restrict__ actions_in,
-                                                      float delay, long long common_step, const float* __restrict__ noise_in) {
+                                                      float delay, long long common_step, const float* __restrict__ noise_in,
+                                                      const float* __restrict__ dbg) {
+    static_assert(!DBG || W == 1, "the debug injection path exists for the one-wave layout only");
     KP P = GRX_PARAMS(Pg);
     constexpr int NTHR = 64 * W;
     __shared__ KTables s_tab;
@@ -1166,7 +1177,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     float torque[LEG];
     SubstepOut so;
     FootKin fk;
-    for (int deci = 0; deci < P.decimation; ++deci) {
+    for (int deci = 0; deci < (DBG ? 0 : P.decimation); ++deci) {
         // keep the LDS-resident robot tables in LDS: without this barrier LICM hoists ~240 loop-invariant
         // ds_reads into VGPRs and the kernel spills to scratch (measured: 604 B/lane -> 0)
 #ifndef GRX_NO_LICM_BARRIER
@@ -1220,6 +1231,21 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
     avg_force = avg_force / (float)P.decimation;  // legged_robot_fftai.py:86-88
     avg_speed = v3(avg_speed.x / (float)P.decimation, avg_speed.y / (float)P.decimation, avg_speed.z / (float)P.decimation);
+    float a_ll[LEG];
+    bool dbg_apply_reset = true;
+    if (DBG) {   // injected "physics results" (grx_debug_post_physics)
+        const float* d = dbg + e;
+        const size_t n_ = (size_t)N;
+        so.foot_force = v3(d[(DBG_FEET_FORCE + side * 3 + 0) * n_], d[(DBG_FEET_FORCE + side * 3 + 1) * n_], d[(DBG_FEET_FORCE + side * 3 + 2) * n_]);
+        fk.pos = v3(d[(DBG_FEET_POS + side * 3 + 0) * n_], d[(DBG_FEET_POS + side * 3 + 1) * n_], d[(DBG_FEET_POS + side * 3 + 2) * n_]);
+        avg_force = d[(DBG_AVG_FORCE + side) * n_];
+        avg_speed = v3(d[(DBG_AVG_SPEED + side * 3 + 0) * n_], d[(DBG_AVG_SPEED + side * 3 + 1) * n_], d[(DBG_AVG_SPEED + side * 3 + 2) * n_]);
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) { torque[k] = d[(DBG_TORQUES + j0 + k) * n_]; a_ll[k] = d[(DBG_LAST_LAST_ACTIONS + j0 + k) * n_]; }
+        so.term = d[DBG_TERM_CONTACT * n_] != 0.f;
+        so.pen_count = 0.f;
+        dbg_apply_reset = d[DBG_APPLY_RESET * n_] != 0.f;
+    }
     const bool term_contact = __builtin_bit_cast(int, pair_swap(__builtin_bit_cast(float, (int)so.term))) | (int)so.term;
     const float pen_count = pair_sum(so.pen_count);
 
@@ -1286,12 +1312,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             int i = 0;
             rewin_fields(rin, [&](float& x) { s_rw[(i++) * 64 + lane] = x; });
             flag_set(s_flag + FL_REW, 1, lane);
-        } else reward_and_sums<0>(P, C, rin, lane, side, e, N, act, s_stat, es_early);
+        } else reward_and_sums<0>(P, C, rin, lane, side, e, N, act, s_stat, es_early, nullptr, nullptr, DBG ? a_ll : nullptr);
     }
     const bool writer = act && side == 0;
     GRX_TICK(6);
     // ---- reset_idx (masked, in-kernel)
-    if (W == 4 ? __any(reset) : reset) {   // uniform test with four waves: the draws come from wave 2 through LDS
+    const bool do_reset = DBG ? (reset && dbg_apply_reset) : reset;   // the debug entry may report a reset without applying it
+    if (W == 4 ? __any(do_reset) : do_reset) {   // uniform test with four waves: the draws come from wave 2 through LDS
         ResetRand rr;
         if (W == 4) {
             flag_wait(s_flag + FL_RR, 1);
@@ -1302,7 +1329,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             rr.root[5] = z2.z; rr.root[6] = z2.w; rr.root[7] = z3.x; rr.root[8] = z3.y;
             rr.cmd[0] = z3.z; rr.cmd[1] = z3.w; rr.cmd[2] = z4.x;
         } else rr = reset_rand(P, genv, step, side);
-      if (reset) {
+      if (do_reset) {
         reset_env(P, C, side, genv, step, true, st, ea, rr);
 #pragma unroll
         for (int k = 0; k < LEG; ++k) { a_last[k] = 0.f; qd_last[k] = 0.f; }
@@ -1311,7 +1338,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         ep_len = 0;
       }
     }
-    const bool feet_contact_obs = reset ? false : contact;  // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
+    const bool feet_contact_obs = do_reset ? false : contact;  // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
 
     GRX_TICK(7);
     // ---- compute_observations (legged_robot.py:442-452, legged_robot_fftai.py:148-167, gr1t1.py:281-336)
@@ -1566,11 +1593,19 @@ __global__ void grx_set_state_kernel(const KParams* __restrict__ Pg, const float
 extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                                 const float* noise, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-#define GRX_LAUNCH_STEP(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise)
+#define GRX_LAUNCH_STEP(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr)
     if (heightfield) { if (waves == 4) GRX_LAUNCH_STEP(true, 4); else if (waves == 2) GRX_LAUNCH_STEP(true, 2); else GRX_LAUNCH_STEP(true, 1); }
     else { if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
 #undef GRX_LAUNCH_STEP
 }
+// TEST-ONLY (grx_debug_post_physics): the post-physics half of the step on injected state, one-wave layout
+extern "C" void grx_launch_step_debug(const KParams* dP, int N, int heightfield, const float* actions, long long common_step, const float* noise,
+                                      const float* dbg, hipStream_t stream) {
+    int nblocks = (N + EPB - 1) / EPB;
+    if (heightfield) hipLaunchKernelGGL((grx_step_kernel<true, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg);
+    else hipLaunchKernelGGL((grx_step_kernel<false, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg);
+}
+extern "C" int grx_debug_rows(void) { return DBG_ROWS; }
 // epb: envs per block (= threads per block, at most 64); lds_bytes > 0: the per-body workspace lives in (dynamic) LDS
 extern "C" int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int lds_bytes, int heightfield,
                                        const float* actions, float delay, long long common_step, const float* noise, hipStream_t stream) {

@@ -152,6 +152,21 @@ class SimHandle:
         self._check(self._api["set_state"](self._h, ptr(root_states, 13), ptr(dof_pos, self.num_dofs),
                                            ptr(dof_vel, self.num_dofs), self._stream()), "set_state")
 
+    def debug_post_physics(self, states, apply_reset=False, common_step_counter=1, noise_uniform=None):
+        """TEST-ONLY (include/grx.h grx_debug_post_physics): post_physics_step of all envs on injected state.
+        states: ctypes array of _capi.PipelineState, one per env."""
+        if "debug_post_physics" not in self._api:
+            raise GrxError("this backend has no grx_debug_post_physics")
+        if len(states) != self.num_envs:
+            raise GrxError("debug_post_physics needs one record per env")
+        a = _capi.StepArgs()
+        a.common_step_counter = int(common_step_counter)
+        if noise_uniform is not None:
+            if noise_uniform.dtype != torch.float32 or not noise_uniform.is_contiguous():
+                raise GrxError("noise_uniform must be contiguous float32")
+            a.noise_uniform = noise_uniform.data_ptr()
+        self._check(self._api["debug_post_physics"](self._h, states, int(bool(apply_reset)), C.byref(a), self._stream()), "debug_post_physics")
+
     def episode_stats(self):
         out = (C.c_float * (_capi.NUM_REWARD_TERMS + 1))()
         self._check(self._api["episode_stats"](self._h, out, self._stream()), "episode_stats")
