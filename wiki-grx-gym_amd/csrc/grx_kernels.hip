@@ -49,6 +49,9 @@ typedef const GRX_AS4 KParams& KP;
 #define GRX_TICKW(i) do {} while (0)
 #endif
 
+#ifndef GRX_WPE
+#define GRX_WPE 1   // waves per SIMD the step kernel's register budget is sized for
+#endif
 namespace {
 
 constexpr int NT = GRX_NUM_REWARD_TERMS;
@@ -778,7 +781,7 @@ GRX_DEV void load_episode_sums(KP P, int e, int N, float es[NT]) {
 template <int PART>
 GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane, int side, int e, int N, bool act,
                              float* s_stat, const float* es_pre, float* rew_part = nullptr, int* rew_flag = nullptr,
-                             const float* a_ll = nullptr) {
+                             const float* a_ll = nullptr, bool keep_sums = false) {   // keep_sums: debug entry, reset reported but not applied
     const int j0 = side * LEG;
     const float dtp = P.sim_dt * (float)P.decimation;
     const bool reset = in.reset != 0.f, time_out = in.time_out != 0.f;
@@ -931,7 +934,7 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if (!rew_in_part<PART>(t) || P.reward_scale_dt[t] == 0.f) continue;  // uniform
-            P.episode_sums[(size_t)t * N + e] = reset ? 0.f : es_all[t];
+            P.episode_sums[(size_t)t * N + e] = (reset && !keep_sums) ? 0.f : es_all[t];
             if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
         }
     }
@@ -961,7 +964,7 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
 enum DbgRow { DBG_FEET_FORCE = 0, DBG_FEET_POS = 6, DBG_AVG_FORCE = 12, DBG_AVG_SPEED = 14, DBG_TORQUES = 20, DBG_LAST_LAST_ACTIONS = 30,
               DBG_TERM_CONTACT = 40, DBG_APPLY_RESET = 41, DBG_ROWS = 42 };
 template <bool HF, int W, bool DBG = false>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_kernel(const KParams* __restrict__ Pg, const float* __restrict__ actions_in,
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE, GRX_WPE))) void grx_step_kernel(const KParams* __restrict__ Pg, const float* __restrict__ actions_in,
                                                       float delay, long long common_step, const float* __restrict__ noise_in,
                                                       const float* __restrict__ dbg) {
     static_assert(!DBG || W == 1, "the debug injection path exists for the one-wave layout only");
@@ -1312,7 +1315,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             int i = 0;
             rewin_fields(rin, [&](float& x) { s_rw[(i++) * 64 + lane] = x; });
             flag_set(s_flag + FL_REW, 1, lane);
-        } else reward_and_sums<0>(P, C, rin, lane, side, e, N, act, s_stat, es_early, nullptr, nullptr, DBG ? a_ll : nullptr);
+        } else reward_and_sums<0>(P, C, rin, lane, side, e, N, act, s_stat, es_early, nullptr, nullptr, DBG ? a_ll : nullptr, DBG && !dbg_apply_reset);
     }
     const bool writer = act && side == 0;
     GRX_TICK(6);
