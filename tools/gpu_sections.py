@@ -3,7 +3,14 @@ import sys, ctypes as C, subprocess, os; sys.path.insert(0,'.')
 import numpy as np, torch
 csrc="wiki-grx-gym_amd/csrc"
 flags="-I../../include --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-hip-fp32-correctly-rounded-divide-sqrt -ffinite-math-only -fno-signed-zeros -fno-trapping-math -fassociative-math -fno-slp-vectorize -DGRX_PROFILE_SECTIONS"
-subprocess.run(f"cd {csrc} && hipcc {flags} -shared -o libgrx_hip.so grx_kernels.hip grx_capi.cpp 2>/dev/null", shell=True, check=True)
+os.makedirs(csrc + "/variants", exist_ok=True)
+PROF = os.path.abspath(csrc + "/variants/libgrx_prof.so")
+if "--build" in sys.argv or not os.path.exists(PROF):   # hipcc cross-compiles in the build container; the .so travels with gpurun
+    subprocess.run(f"cd {csrc} && hipcc {flags} -shared -o variants/libgrx_prof.so grx_kernels.hip grx_capi.cpp 2>/dev/null", shell=True, check=True)
+    if "--build" in sys.argv:
+        sys.exit(0)
+PROF = os.path.abspath(os.environ.get("GRX_PROF_LIB", PROF))
+os.environ["GRX_HIP_LIB"] = PROF
 from tests.helpers import *
 from wiki_grx_gym_amd.sim import HipSim, load_hip_library
 from wiki_grx_gym_amd.envs import build_config
@@ -18,13 +25,14 @@ for terrain in ("plane","heightfield"):
     acts=[random_actions(cfg,N,gen,1.0).cuda() for _ in range(4)]
     for i in range(40): s.step(acts[i%4],5.0,i+1)
     torch.cuda.synchronize()
-    lib=C.CDLL(csrc+"/libgrx_hip.so"); buf=(C.c_longlong*(128*32))()
+    lib=C.CDLL(PROF); buf=(C.c_longlong*(128*48))()
     lib.grx_debug_profile.argtypes=[C.c_void_p, C.c_void_p, C.c_int]
     nb=lib.grx_debug_profile(s._h, buf, 128)
-    full=np.array(buf[:],dtype=np.int64).reshape(128,32)[:nb]
+    full=np.array(buf[:],dtype=np.int64).reshape(128,48)[:nb]
     a=full[:,:11]
-    print('   substep sections (sum over 10 substeps):', dict(zip(['pass1+chain contacts','base spheres','pass2','base solve','pass3','integrate'], np.median(full[:,16:22],axis=0).astype(int).tolist())))
+    print('   wave 0, sum over 10 sub-steps:', dict(zip(['wait bias forces','wait I records','wait foot / rare contacts','-','wait base factorisation','whole sub-steps'], np.median(full[:,16:22],axis=0).astype(int).tolist())))
     print('   helper waves (idle waiting for state, total) cycles:', {f"wave{w}": np.median(full[:,22+2*w:24+2*w],axis=0).astype(int).tolist() for w in (1,2,3)})
+    print('   wave 3 rare contacts (sum over 10 sub-steps): cheap test, fine test, compaction, evaluation, pick-up + netting, -, candidates, calls with any:', np.median(full[:,32:40],axis=0).astype(int).tolist(), 'mean candidates', full[:,38].mean())
     print('   obs sub-sections (cycles after tick 7): heights, noise load, side-0 puts:', np.median(full[:,11:14]-full[:,7:8],axis=0).astype(int).tolist())
     print('   relative to tick 6 (FL_REW published): wave1 got FL_REW, wave1 rewards done, wave2 got FL_HZ, wave2 heights done, wave0 tick 9:', np.median(full[:,[14,15,30,31,9]]-full[:,6:7],axis=0).astype(int).tolist())
     d=np.diff(a,axis=1)

@@ -474,7 +474,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(obs, (size_t)c.num_obs * N + 64); DA(pri_obs, (size_t)c.num_pri_obs * N + 64);
     const int nblocks = (c.num_envs + grx_envs_per_block() - 1) / grx_envs_per_block();
     DA(stat_partial, (size_t)(2 * nblocks + 1) * (NT + 1));   // generic kernel: down to 16 envs per block
-    DA(stats, NT + 1); DA(prof, (size_t)nblocks * 32);
+    DA(stats, NT + 1); DA(prof, (size_t)nblocks * GRX_PROF_SLOTS);
     float* base_mass_com = nullptr;
     rc = dalloc(s, &base_mass_com, 4 * N);
     if (rc) { grx_destroy(s); return rc; }
@@ -485,6 +485,21 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
         if (rc) { grx_destroy(s); return rc; }
         HIP_TRY(hipMemcpy(dhf, c.height_samples, n * sizeof(int16_t), hipMemcpyHostToDevice));
         P.hf = dhf;
+        {   // per-cell max of the four corners the bilinear terrain query blends (terrain_height in grx_kernels.hip)
+            std::vector<int16_t> m4(n);
+            for (int i = 0; i < c.hf_rows; ++i)
+                for (int j = 0; j < c.hf_cols; ++j) {
+                    const int i1 = std::min(i + 1, c.hf_rows - 1), j1 = std::min(j + 1, c.hf_cols - 1);
+                    const int16_t* H = c.height_samples;
+                    m4[(size_t)i * c.hf_cols + j] = std::max(std::max(H[(size_t)i * c.hf_cols + j], H[(size_t)i1 * c.hf_cols + j]),
+                                                             std::max(H[(size_t)i * c.hf_cols + j1], H[(size_t)i1 * c.hf_cols + j1]));
+                }
+            int16_t* dm4 = nullptr;
+            rc = dalloc(s, &dm4, n);
+            if (rc) { grx_destroy(s); return rc; }
+            HIP_TRY(hipMemcpy(dm4, m4.data(), n * sizeof(int16_t), hipMemcpyHostToDevice));
+            P.hf_max4 = dm4;
+        }
         {   // coarse max map: max height over each 8x8-cell block dilated by 3 blocks (>= 2.4 m: robot reach 1.1 m
             // + travel within a policy step + bilinear support), used only to cull spheres that cannot touch
             int cr = (c.hf_rows + GRX_COARSE - 1) / GRX_COARSE, cc = (c.hf_cols + GRX_COARSE - 1) / GRX_COARSE;
@@ -777,7 +792,7 @@ int grx_kernel_time_ms(grx_handle s, int enable, float* avg_ms, int64_t* launche
 int grx_debug_profile(grx_handle s, long long* out, int max_blocks) {
     if (!s || !out) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_profile: null argument");
     int nb = s->prof_blocks < max_blocks ? s->prof_blocks : max_blocks;
-    HIP_TRY(hipMemcpy(out, s->prof_host, (size_t)nb * 32 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, s->prof_host, (size_t)nb * GRX_PROF_SLOTS * sizeof(long long), hipMemcpyDeviceToHost));
     return nb;
 }
 

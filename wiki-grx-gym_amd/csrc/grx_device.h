@@ -9,6 +9,7 @@
 #define GRX_NUM_OBS 39   // 9 + 3*GRX_ND (gr1t1.py:281-295)
 #define GRX_MAX_PRI 168  // 39 + 3 + 1 + 2 + 2 + 121 (gr1t1.py:297-313)
 #define GRX_MAXSPH_SIDE 16
+#define GRX_PROF_SLOTS 48   // GRX_PROFILE_SECTIONS builds: clock stamps per block (tools/gpu_sections.py)
 #define GRX_COARSE 8     // raster cells per coarse max-map cell (0.8 m)
 
 struct SphC {   // 32 bytes
@@ -75,6 +76,8 @@ struct KParams {
     int32_t terrain_type, measure_heights, nh;
     const int16_t* hf; int32_t hf_rows, hf_cols;
     const float* coarse_max; int32_t coarse_rows, coarse_cols;   // dilated block-max of the raster [m]: sphere culling
+    const int16_t* hf_max4;   // [hf_rows][hf_cols]: max of the four raster corners of cell (i, j) = upper bound of the bilinear
+                              // height anywhere in the cell: the exact reach test of the lane-compacted contacts (grx_rare.h)
     float horizontal_scale, vertical_scale, border_size, inv_hscale;
     int32_t curriculum, num_terrain_rows, num_terrain_cols;
     const float* terrain_origins; float terrain_length;

@@ -39,9 +39,9 @@ typedef const GRX_AS4 KParams& KP;
 #define GRX_PARAMS(Pg) (*reinterpret_cast<const GRX_AS4 KParams*>(reinterpret_cast<uintptr_t>(Pg)))
 
 #ifdef GRX_PROFILE_SECTIONS
-#define GRX_TICK(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); if (threadIdx.x == 0) P.prof[(size_t)blockIdx.x * 32 + (i)] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define GRX_TICK(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); if (threadIdx.x == 0) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + (i)] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 // sub-step sections accumulate in registers (g_tacc is a kernel-scope local); sched_barrier pins the code motion
-#define GRX_TICKW(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); if ((threadIdx.x & 63) == 0) P.prof[(size_t)blockIdx.x * 32 + (i)] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define GRX_TICKW(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); if ((threadIdx.x & 63) == 0) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + (i)] = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define GRX_TICK2(i) do { __builtin_amdgcn_sched_barrier(0); long long t_ = clock64(); tacc[(i) - 16] += t_ - tprev; tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define GRX_TICK2(i) do {} while (0)
@@ -313,13 +313,16 @@ GRX_DEV void link_contacts(KP P, const SideConst& C, int k, const ChainKin& K, V
     }
 }
 
+#include "grx_rare.h"
+
 // One physics sub-step (gym.simulate(dt), legged_robot_fftai.py:68) for this lane's half of the env.
 // tau: motor torques of this lane's 5 joints.  fk_only: just the kinematics pass (foot frames).
 // W = waves per block: 1 = everything inline; 2 = the base-lump contacts come from the helper wave through `wr`
 // (W == 4 uses the producer/consumer pipeline of grx_wavepipe.h instead of this function).
 template <bool HF, int W>
-GRX_DEV void substep(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
-                     SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc, const LinkForceOut& lfo) {
+GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
+                     SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc, const LinkForceOut& lfo,
+                     const RareBuf& RB, int lane, int el, int side) {
     const float dt = P.sim_dt;
     R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
     V3 O = st.pos;
@@ -336,6 +339,7 @@ GRX_DEV void substep(KP P, const SideConst& C, const LaneConst& LC, LaneState& s
     out.foot_force = v3(0.f, 0.f, 0.f);
     out.term = false;
     out.pen_count = 0.f;
+    ChainKin K2, K3;   // thigh / shank frames: their shapes are evaluated lane-compacted after the walk (grx_rare.h)
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
         V3 rho = rho_p + rot(Rp, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
@@ -360,11 +364,13 @@ GRX_DEV void substep(KP P, const SideConst& C, const LaneConst& LC, LaneState& s
         // contacts of the shapes carried by chain body k (thigh_pitch: 2, shank: 2, foot: 4 anchored spheres)
         if (kSphCnt[k] > 0) {
             ChainKin K = {R, rho, wk, vk};
-            V3 fa, fl;
-            if (kSphCnt[k] == 2) link_contacts<HF>(P, C, k, K, O, LC.mu, LC.hmax, fa, fl);
-            else { foot_contacts<HF>(P, C, K, O, LC.mu, LC.hmax, st, fa, fl); out.foot_force = fl; }
-            put_link_force(lfo, C.sph[kSphOff[k]], fl);
-            pa = pa - fa; pl = pl - fl;
+            if (kSphCnt[k] == 2) { if (k == 2) K2 = K; else K3 = K; }
+            else {
+                V3 fa, fl;
+                foot_contacts<HF>(P, C, K, O, LC.mu, LC.hmax, st, fa, fl); out.foot_force = fl;
+                put_link_force(lfo, C.sph[kSphOff[k]], fl);
+                pa = pa - fa; pl = pl - fl;
+            }
         }
         if (k == LEG - 1) {  // foot link frame BEFORE this sub-step's integration
             V3 fr = rho + rot(R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
@@ -376,6 +382,11 @@ GRX_DEV void substep(KP P, const SideConst& C, const LaneConst& LC, LaneState& s
         Rp = R; rho_p = rho; w = wk; v = vk;
     }
     GRX_TICK2(16);
+    // thigh / shank shapes (W == 1: and the base-lump shapes), compacted over the wave
+    RareOut ro;
+    rare_contacts<HF, (W == 1 ? 0 : 8), RC_NS>(P, T, C, RB, lane, el, side, R0, O, st.ang, st.vel, K2, K3, LC.mu, LC.hmax, ro, lfo);
+    pA[2] = pA[2] - ro.fa2; pL[2] = pL[2] - ro.fl2;
+    pA[3] = pA[3] - ro.fa3; pL[3] = pL[3] - ro.fl3;
     GRX_TICK2(17);
     // ---- pass 2: articulated inertias (leaf -> root).  w, v currently = velocity of body LEG-1.
     S3 A = IAk[LEG - 1];
@@ -426,9 +437,8 @@ GRX_DEV void substep(KP P, const SideConst& C, const LaneConst& LC, LaneState& s
         out.pen_count = wr[7 * 64];
         pa = pa - f0a; pl = pl - f0l;
     } else {
-        V3 f0a, f0l;
-        base_lump_contacts<HF, false>(P, C, R0, O, st.ang, st.vel, LC.mu, LC.hmax, f0a, f0l, out.term, out.pen_count, lfo);
-        pa = pa - f0a; pl = pl - f0l;
+        out.term = ro.term; out.pen_count = ro.pen_count;
+        pa = pa - ro.f0a; pl = pl - ro.f0l;
     }
     A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
     pa = pair_sum(pa); pl = pair_sum(pl);
@@ -971,11 +981,19 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     KP P = GRX_PARAMS(Pg);
     constexpr int NTHR = 64 * W;
     __shared__ KTables s_tab;
-    __shared__ __attribute__((aligned(16))) float s_obs[EPB * GRX_NUM_OBS];
-    __shared__ __attribute__((aligned(16))) float s_pri[EPB * PRS];
+    // One LDS arena, used twice: during the sub-steps it holds the lane-compaction buffers of the rare contacts
+    // (grx_rare.h: candidate list, result table, frames); after the decimation loop's barrier the same bytes are the
+    // AoS staging rows of obs / pri_obs and (W == 4) the reward inputs wave 0 hands to the reward waves.
+    constexpr int OBS_BYTES = EPB * GRX_NUM_OBS * 4, PRI_BYTES = EPB * PRS * 4, RW_BYTES = W == 4 ? REWIN_FLOATS * 64 * 4 : 0;
+    constexpr int POST_BYTES = OBS_BYTES + PRI_BYTES + RW_BYTES, PHYS_BYTES = (W == 2 ? 2 : 1) * RC_BYTES;
+    static_assert(OBS_BYTES % 16 == 0 && PRI_BYTES % 16 == 0 && RC_BYTES % 16 == 0, "arena pieces must stay 16-byte aligned");
+    __shared__ __attribute__((aligned(16))) char s_arena[POST_BYTES > PHYS_BYTES ? POST_BYTES : PHYS_BYTES];
+    float* const s_obs = reinterpret_cast<float*>(s_arena);
+    float* const s_pri = reinterpret_cast<float*>(s_arena + OBS_BYTES);
+    float* const s_rw = reinterpret_cast<float*>(s_arena + OBS_BYTES + PRI_BYTES);   // reward inputs (wave 0 -> waves 1, 3), W == 4
     __shared__ float s_stat[NT + 1];
-    __shared__ float s_base[13 * EPB];   // base state at the start of the current sub-step (dynamics -> helpers)
-    __shared__ __attribute__((aligned(16))) float s_wr[8 * 64];       // base-lump wrench + termination / collision flags (helper -> dynamics)
+    __shared__ float s_base[W >= 2 ? 13 * EPB : 1];   // base state at the start of the current sub-step (dynamics -> helpers)
+    __shared__ __attribute__((aligned(16))) float s_wr[W >= 2 ? 8 * 64 : 1];       // base-lump wrench + termination / collision flags (helper -> dynamics)
     // W == 4 pipeline buffers (grx_wavepipe.h)
     __shared__ float4 s_q[W == 4 ? Q4 * 64 : 1];
     __shared__ float4 s_ri[W == 4 ? LEG * RI4 * 64 : 1];
@@ -989,11 +1007,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     __shared__ float s_rwp[W == 4 ? 64 : 1];               // partial reward (wave 3 -> wave 1)
     __shared__ float s_hp[W == 4 ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
     __shared__ float s_hsum[W == 4 ? 4 * 64 : 1];          // height scan: partial sums per wave
-    __shared__ float s_rw[W == 4 ? REWIN_FLOATS * 64 : 1];   // reward inputs (wave 0 -> wave 1)
     __shared__ int s_flag[FL_COUNT];
     const PipeLds L = {s_base, s_q, s_ri, s_rec, s_rec0, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag};
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const RareBuf RB = rare_carve(s_arena + (W == 2 && wv == 1 ? RC_BYTES : 0));   // W == 4: only wave 3 evaluates rare contacts
     {   // stage the per-side robot tables (joint tree, inertias, gains, spheres) into LDS
         const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab);
@@ -1027,6 +1045,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
         LaneState hs;   // W == 4, wave 2: the friction anchors of this lane's foot
         hs.anchor_on = 0;
         if (W == 4) {
+#ifdef GRX_REG_CONSTS
+            const SideConst Ch = C;   // helper waves too: constants in registers
+#define GRX_HELPER_C Ch
+#else
+#define GRX_HELPER_C C
+#endif
             const float bm = P.base_m[e];
             const V3 bc = v3(P.base_c[e], P.base_c[(size_t)N + e], P.base_c[2 * (size_t)N + e]);
             const S3 bI = {P.base_I[e], P.base_I[(size_t)N + e], P.base_I[2 * (size_t)N + e],
@@ -1039,7 +1063,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
 #pragma unroll
                     for (int b = 0; b < NZB; ++b) { z[(b * 4 + 0) * 64] = nzb[b].x; z[(b * 4 + 1) * 64] = nzb[b].y; z[(b * 4 + 2) * 64] = nzb[b].z; z[(b * 4 + 3) * 64] = nzb[b].w; }
                 }
-                iwave_loop(P, C, bm, bc, bI, L, lane, el);
+                iwave_loop(P, GRX_HELPER_C, bm, bc, bI, L, lane, el);
             } else if (wv == 2) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1047,13 +1071,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                     hs.ay[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e];
                     if (P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] != 0.0f) hs.anchor_on |= (1u << i);
                 }
-                chain_contact_loop<HF>(P, C, mu, hmax, hs, L, lane, el, act ? P.contact_forces + e : nullptr, (size_t)N);
+                chain_contact_loop<HF>(P, GRX_HELPER_C, RB, mu, hmax, hs, L, lane, el, act ? P.contact_forces + e : nullptr, (size_t)N);
                 float* a_ = s_anch + lane;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { a_[i * 64] = hs.ax[i]; a_[(4 + i) * 64] = hs.ay[i]; }
                 a_[8 * 64] = __uint_as_float(hs.anchor_on);
             } else {
-                base_contact_loop<HF>(P, C, mu, hmax, bm, bc, bI, L, lane, el, act ? P.contact_forces + e : nullptr, (size_t)N);
+                base_contact_loop<HF>(P, s_tab, GRX_HELPER_C, RB, mu, hmax, bm, bc, bI, L, lane, el, side, act ? P.contact_forces + e : nullptr, (size_t)N);
             }
             float es_w1[NT], es_w3[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
             if (wv == 1) load_episode_sums<1>(P, e, N, es_w1);
@@ -1110,13 +1134,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
                 const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
                 const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
-                V3 f0a, f0l; bool term; float pen;
-                base_lump_contacts<HF, false>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen,
-                                              LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N});
+                RareOut ro;
+                const ChainKin nok = {R0, v3(0.f, 0.f, 0.f), ang, vel};   // no chain shapes on this wave
+                rare_contacts<HF, 0, 8>(P, s_tab, C, RB, lane, el, side, R0, O, ang, vel, nok, nok, mu, hmax, ro,
+                                        LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N});
                 float* w_ = s_wr + lane;
-                w_[0 * 64] = f0a.x; w_[1 * 64] = f0a.y; w_[2 * 64] = f0a.z;
-                w_[3 * 64] = f0l.x; w_[4 * 64] = f0l.y; w_[5 * 64] = f0l.z;
-                w_[6 * 64] = term ? 1.f : 0.f; w_[7 * 64] = pen;
+                w_[0 * 64] = ro.f0a.x; w_[1 * 64] = ro.f0a.y; w_[2 * 64] = ro.f0a.z;
+                w_[3 * 64] = ro.f0l.x; w_[4 * 64] = ro.f0l.y; w_[5 * 64] = ro.f0l.z;
+                w_[6 * 64] = ro.term ? 1.f : 0.f; w_[7 * 64] = ro.pen_count;
                 __syncthreads();   // #3: wrench published
             }
         }
@@ -1180,6 +1205,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     float torque[LEG];
     SubstepOut so;
     FootKin fk;
+#ifdef GRX_REG_CONSTS
+    // W == 4: wave 0 has a SIMD's whole register file to itself; its chain's constants live in registers during the
+    // sub-steps (every LDS read of a constant is ~64 exposed cycles on a wave that runs alone)
+    const SideConst Cr = C;
+#else
+    const SideConst& Cr = C;
+#endif
     for (int deci = 0; deci < (DBG ? 0 : P.decimation); ++deci) {
         // keep the LDS-resident robot tables in LDS: without this barrier LICM hoists ~240 loop-invariant
         // ds_reads into VGPRs and the kernel spills to scratch (measured: 604 B/lane -> 0)
@@ -1208,9 +1240,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             t *= LC.strength[k];
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
-        if (W == 4) substep_p<HF>(P, C, LC, st, torque, so, fk, L, lane, deci, tacc);
-        else substep<HF, W>(P, C, LC, st, torque, so, fk, s_wr + lane, tacc,
-                            LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N});
+        if (W == 4) substep_p<HF>(P, Cr, LC, st, torque, so, fk, L, lane, deci, tacc);
+        else substep<HF, W>(P, s_tab, C, LC, st, torque, so, fk, s_wr + lane, tacc,
+                            LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
             avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
         }
@@ -1228,7 +1260,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     }
     GRX_TICK(2);
 #ifdef GRX_PROFILE_SECTIONS
-    if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) P.prof[(size_t)blockIdx.x * 32 + 16 + i] = tacc[i];
+    if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 16 + i] = tacc[i];
 #endif
     fk = foot_kinematics(C, st);  // refresh_rigid_body_state_tensor after the last sub-step
     avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));

@@ -2,21 +2,26 @@
 // inside its anonymous namespace, after the shared contact / kinematics helpers).
 //
 // At <= 8192 envs per GPU the step kernel is a handful of waves on a 1024-SIMD machine, each running alone on its
-// SIMD at one instruction per 4 cycles: the instruction count of the longest wave IS the step time.  A block
-// therefore spreads the sub-step of its 32 envs over the four SIMDs of a CU as a producer/consumer pipeline
-// through LDS (lane i of every wave works on the same leg of the same env):
+// SIMD at one instruction per ~4.4 cycles: the instruction count of the longest dependent chain IS the step time.  A
+// block therefore spreads the sub-step of its 32 envs over the four SIMDs of a CU (lane i of every wave works on the
+// same leg of the same env), partitioned so that the four chains end together (round 2 balance, cycles per sub-step
+// on rough terrain in brackets):
 //
-//   wave 0  "P" (owner of the state): motor torques; while the others start up, an outward walk that builds the
-//            rigid-body inertias + joint axes for wave 1; then the BIAS half of the articulated-body recursion
-//            (leaf -> root), floating-base solve, acceleration pass, integration -- and the rest of env.step()
-//   wave 1  "I": the INERTIA half of the recursion (U, 1/d, rank-1 updates) as the rigid inertias arrive; streams
-//            one record per joint (U, 1/d, updated 6x6) back to wave 0, which runs one joint behind; finally
-//            the factorised base-level 6x6
-//   wave 2  own outward walk with velocities: rigid-body bias forces + velocity-product accelerations of every
-//            chain body (needed by wave 0 from its first joint on), then the 4 anchored foot spheres (it owns the
-//            friction anchors) and the thigh spheres
-//   wave 3  the base lump's bias force, the shank spheres (own walk to the knee), the base-lump contacts (torso,
-//            head, arms ...)
+//   wave 0  owner of the state: motor torques; outward walk (positions) and the rigid inertias about O, leaf first,
+//            for wave 1; then the BIAS half of the
+//            articulated-body recursion (leaf -> root) on the records wave 1 has ready by then [1.1 k]; contact
+//            wrenches by delta recursion, floating-base solve, acceleration pass, integration [1.6 k] -- and the rest
+//            of env.step()
+//   wave 1  "I": the INERTIA half of the recursion (U, 1/d, rank-1 updates) as the rigid inertias arrive; one record
+//            per joint back to wave 0; finally the factorised base-level 6x6 [done at ~5 k]
+//   wave 2  own walk with velocities; publishes the thigh / shank frames for wave 3; rigid-body bias forces and
+//            velocity-product accelerations of the chain, leaf first, for wave 0; the 4 anchored foot spheres (it owns
+//            the friction anchors)
+//   wave 3  the base lump's bias force; the seldom-touching shapes (base lump, thigh, shank), lane-compacted
+//            (grx_rare.h) [4-5.5 k]
+//
+// Round 1 had wave 2 evaluate the thigh shapes as well and wave 3 loop over all its base-lump and shank shapes
+// whenever one env of the wave had any within reach (7 k cycles per sub-step): wave 0 waited 45 % of every sub-step.
 //
 // Synchronisation is by monotone sequence counters in LDS (release store by the producer after its data, acquire
 // spin by the consumer), not block barriers, so each producer/consumer pair meets at its own time.  Every buffer is
@@ -28,7 +33,7 @@
 #define GRX_HELPER_PROF_BEGIN long long hp_idle = 0, hp_t0 = clock64(), hp_t = 0
 #define GRX_HELPER_PROF_IDLE0 hp_t = clock64()
 #define GRX_HELPER_PROF_IDLE1 hp_idle += clock64() - hp_t
-#define GRX_HELPER_PROF_END(w) do { if (lane == 0) { P.prof[(size_t)blockIdx.x * 32 + 22 + 2 * (w)] = hp_idle; P.prof[(size_t)blockIdx.x * 32 + 23 + 2 * (w)] = clock64() - hp_t0; } } while (0)
+#define GRX_HELPER_PROF_END(w) do { if (lane == 0) { P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 22 + 2 * (w)] = hp_idle; P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 23 + 2 * (w)] = clock64() - hp_t0; } } while (0)
 #else
 #define GRX_HELPER_PROF_BEGIN do {} while (0)
 #define GRX_HELPER_PROF_IDLE0 do {} while (0)
@@ -42,7 +47,7 @@
 #define GRX_WAIT(f, want, slot) flag_wait(f, want)
 #endif
 
-enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_BASE = 4, FL_BIAS = 5, FL_REW = 6, FL_RI = 7, FL_BASEBIAS = 8, FL_SHANK = 9, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_RR = 15, FL_COUNT = 16 };
+enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_REW = 6, FL_RI = 7, FL_BASEBIAS = 8, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_RR = 15, FL_COUNT = 16 };
 // Every record is laid out [quad][lane] in float4 units, so a lane moves it with ds_read_b128 / ds_write_b128: the
 // kernel runs at one instruction issue per ~5 cycles whatever the instruction, and the records are ~350 dwords per
 // lane and sub-step on wave 0 alone -- four dwords per LDS instruction instead of one is ~1.3k cycles per sub-step.
@@ -60,7 +65,7 @@ struct PipeLds {
     float4* rec;   // [LEG][REC4][64] joint records of the I wave
     float4* rec0;  // [REC04][64]
     float4* wc;    // [WC4][64]
-    float4* pb;    // [LEG][PB4][64] + [2][64]: chain-body bias forces / accelerations (leaf first), base-lump bias force
+    float4* pb;    // [LEG][PB4][64] + [2][64]: chain-body bias forces / accelerations (wave 2, leaf first), base-lump bias force (wave 3)
     float4* wr;    // [2][64]     base-lump wrench, termination flag, collision count
     int* flag;     // [FL_COUNT]
 };
@@ -175,7 +180,6 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     // ---- contact wrenches on chain bodies 4 (foot), 3 (shank), 2 (thigh): delta recursion  dp -> dp + U (-S.dp)/d
     GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
     GRX_WAIT(L.flag + FL_LEGS, seq + 1, 2);
-    GRX_WAIT(L.flag + FL_SHANK, seq + 1, 2);
     {
         V3 da = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
 #pragma unroll
@@ -195,8 +199,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         pa = pa + da; pl = pl + dl;
     }
     // ---- base: both chains (DPP pair exchange) + base lump, 6x6 solve
-    GRX_WAIT(L.flag + FL_BASE, seq + 1, 3);
-    {
+    {   // (published together with the thigh / shank wrenches: FL_LEGS)
         const float4 w0_ = L.wr[lane], w1_ = L.wr[64 + lane];
         const V3 f0a = v3(w0_.x, w0_.y, w0_.z), f0l = v3(w0_.w, w1_.x, w1_.y);
         out.term = w1_.z != 0.f;
@@ -320,9 +323,9 @@ GRX_DEV void iwave_loop(KP P, const SideConst& C, float base_m, V3 base_c, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// wave 2: chain-body contacts (feet first: the bias recursion starts at the leaf)
+// wave 2: own walk with velocities; thigh / shank frames for wave 3; the anchored foot spheres
 template <bool HF>
-GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, LaneState& hs, const PipeLds& L,
+GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, float mu, float hmax, LaneState& hs, const PipeLds& L,
                                 int lane, int el, float* cf_env, size_t N) {
     GRX_HELPER_PROF_BEGIN;
     for (int seq = 0; seq < P.decimation; ++seq) {
@@ -339,8 +342,8 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, 
             qs_q[0] = q0_.x; qs_q[1] = q0_.y; qs_q[2] = q0_.z; qs_q[3] = q0_.w; qs_q[4] = q1_.x;
             qs_qd[0] = q1_.y; qs_qd[1] = q1_.z; qs_qd[2] = q1_.w; qs_qd[3] = q2_.x; qs_qd[4] = q2_.y;
         }
-        // outward walk with velocities; rigid-body bias forces + velocity-product accelerations of the chain bodies,
-        // leaf first (wave 0's recursion starts at the foot and needs them before anything else this wave makes)
+        // outward walk with velocities; thigh / shank frames for wave 3; then the rigid-body bias forces +
+        // velocity-product accelerations of the chain bodies, leaf first (wave 0's bias recursion starts at the foot)
         ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
         ChainKin KK[LEG];
         V3 cak[LEG], clk[LEG];
@@ -358,6 +361,9 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, 
             clk[k] = (cross(vp, a) + cross(wp, s)) * qdk;
             K.w = fma3(a, qdk, wp); K.v = fma3(s, qdk, vp);
             KK[k] = K;
+            if (k == 2) rare_store_frame(RB.fchain + lane, 64, K.R, K.rho, K.w, K.v);                  // thigh
+            if (k == 3) { rare_store_frame(RB.fchain + RC_FR4 * 64 + lane, 64, K.R, K.rho, K.w, K.v);   // shank
+                          flag_set(L.flag + FL_FRAMES, seq + 1, lane); }
         }
 #pragma unroll
         for (int k = LEG - 1; k >= 0; --k) {
@@ -371,7 +377,6 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, 
             o[2 * 64] = f4(cak[k].z, clk[k].x, clk[k].y, clk[k].z);
             flag_set(L.flag + FL_BIAS, seq * 8 + (LEG - k), lane);
         }
-        const ChainKin& K2 = KK[2];
         float4* c_ = L.wc + lane;
         V3 fa, fl;
         foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl);
@@ -384,21 +389,21 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, float mu, float hmax, 
         }
         flag_set(L.flag + FL_FOOT, seq + 1, lane);
         const LinkForceOut lfo = {seq == P.decimation - 1, cf_env, N};   // GRX_T_CONTACT_FORCES: last sub-step only
-        put_link_force(lfo, C.sph[kSphOff[LEG - 1]], fl);
-        link_contacts<HF>(P, C, 2, K2, O, mu, hmax, fa, fl);      // thigh (the shank spheres are wave 3's)
-        put_link_force(lfo, C.sph[kSphOff[2]], fl);
-        c_[0 * 64] = f4(fa.x, fa.y, fa.z, fl.x);
-        c_[1 * 64] = f4(fl.y, fl.z, 0.f, 0.f);
-        flag_set(L.flag + FL_LEGS, seq + 1, lane);
+        put_link_force(lfo, C.sph[kSphOff[LEG - 1]], fl);   // (the thigh and shank shapes are wave 3's: grx_rare.h)
     }
     GRX_HELPER_PROF_END(2);
 }
 
-// wave 3: base-lump contacts
+// wave 3: the seldom-touching shapes -- base lump (torso, head, arms), thigh, shank -- lane-compacted (grx_rare.h)
 template <bool HF>
-GRX_DEV void base_contact_loop(KP P, const SideConst& C, float mu, float hmax, float base_m, V3 base_c, const S3& base_I,
-                               const PipeLds& L, int lane, int el, float* cf_env, size_t N) {
+GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, float mu, float hmax, float base_m, V3 base_c,
+                               const S3& base_I, const PipeLds& L, int lane, int el, int side, float* cf_env, size_t N) {
     GRX_HELPER_PROF_BEGIN;
+#ifdef GRX_PROFILE_SECTIONS
+    long long racc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+    long long* racc = nullptr;
+#endif
     for (int seq = 0; seq < P.decimation; ++seq) {
         GRX_HELPER_PROF_IDLE0;
         flag_wait(L.flag + FL_STATE, seq + 1);
@@ -416,25 +421,23 @@ GRX_DEV void base_contact_loop(KP P, const SideConst& C, float mu, float hmax, f
             o[1 * 64] = f4(bpl.y, bpl.z, 0.f, 0.f);
             flag_set(L.flag + FL_BASEBIAS, seq + 1, lane);
         }
-        {   // shank spheres (own outward walk to the knee): shares the chain-contact load with wave 2
-            const float4 q0_ = L.q[lane], q1_ = L.q[64 + lane], q2_ = L.q[128 + lane];
-            const float qs_q[4] = {q0_.x, q0_.y, q0_.z, q0_.w}, qs_qd[4] = {q1_.y, q1_.z, q1_.w, q2_.x};
-            ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
-#pragma unroll
-            for (int k = 0; k <= 3; ++k) chain_step(C, k, qs_q[k], qs_qd[k], K);
-            V3 fa, fl;
-            link_contacts<HF>(P, C, 3, K, O, mu, hmax, fa, fl);
-            put_link_force(lfo, C.sph[kSphOff[3]], fl);
-            float4* c_ = L.wc + lane;
-            c_[2 * 64] = f4(fa.x, fa.y, fa.z, fl.x);
-            c_[3 * 64] = f4(fl.y, fl.z, 0.f, 0.f);
-            flag_set(L.flag + FL_SHANK, seq + 1, lane);
-        }
-        V3 f0a, f0l; bool term; float pen;
-        base_lump_contacts<HF, false>(P, C, R0, O, ang, vel, mu, hmax, f0a, f0l, term, pen, lfo);
-        L.wr[lane] = f4(f0a.x, f0a.y, f0a.z, f0l.x);
-        L.wr[64 + lane] = f4(f0l.y, f0l.z, term ? 1.f : 0.f, pen);
-        flag_set(L.flag + FL_BASE, seq + 1, lane);
+        // base-lump shapes first (they need only the base state); the thigh / shank frames come from wave 2's walk
+        RareOut ro;
+        const int want = seq + 1;
+        int* const fr_flag = L.flag + FL_FRAMES;
+        rare_contacts<HF, 0, RC_NS, true>(P, T, C, RB, lane, el, side, R0, O, ang, vel, ChainKin(), ChainKin(), mu, hmax, ro, lfo, racc,
+                                          [=]() { flag_wait(fr_flag, want); });
+        float4* c_ = L.wc + lane;
+        c_[0 * 64] = f4(ro.fa2.x, ro.fa2.y, ro.fa2.z, ro.fl2.x);
+        c_[1 * 64] = f4(ro.fl2.y, ro.fl2.z, 0.f, 0.f);
+        c_[2 * 64] = f4(ro.fa3.x, ro.fa3.y, ro.fa3.z, ro.fl3.x);
+        c_[3 * 64] = f4(ro.fl3.y, ro.fl3.z, 0.f, 0.f);
+        L.wr[lane] = f4(ro.f0a.x, ro.f0a.y, ro.f0a.z, ro.f0l.x);
+        L.wr[64 + lane] = f4(ro.f0l.y, ro.f0l.z, ro.term ? 1.f : 0.f, ro.pen_count);
+        flag_set(L.flag + FL_LEGS, seq + 1, lane);   // thigh + shank wrenches and the base-lump wrench, one hand-over
     }
     GRX_HELPER_PROF_END(3);
+#ifdef GRX_PROFILE_SECTIONS
+    if (lane == 0) for (int i = 0; i < 8; ++i) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 32 + i] = racc[i];
+#endif
 }
