@@ -42,11 +42,12 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 1
+#define GRX_ABI_VERSION 2
 
 #define GRX_MAX_BODIES 36   /* moving bodies after merging fixed joints (base + DOFs) */
 #define GRX_MAX_DOFS 32
 #define GRX_MAX_SPHERES 48  /* collision spheres (primitive URDF shapes -> sphere sets) */
+#define GRX_MAX_PAIRS 192  /* collision-sphere pairs of links that can touch each other (self-collision) */
 #define GRX_MAX_LINKS 40          /* URDF links (the full GR1T1 has 37): second dimension of GRX_T_CONTACT_FORCES */
 #define GRX_NUM_FEET 2
 #define GRX_NUM_CMD 3
@@ -144,6 +145,11 @@ typedef struct grx_model {
     float sph_damp_max[GRX_MAX_SPHERES];     /* cap of the normal damping coefficient [N s/m]: alpha * m_eff / dt,
                                                 m_eff = effective mass of the carrying body at the sphere along
                                                 its z axis; keeps the explicit contact damping stable */
+    /* self-collision (legged_robot_config.py:121 self_collisions = 0 = enabled, legged_robot.py:1022-1028): sphere pairs
+     * (indices into sph_*) of URDF links on different, non-adjacent moving bodies that can reach each other within the
+     * joint limits (tools/self_collision_pairs.py).  Every sphere pair of such a link pair is listed. */
+    int32_t num_pairs;
+    int16_t pair_a[GRX_MAX_PAIRS], pair_b[GRX_MAX_PAIRS];
     /* named frames the env pipeline reads from rigid_body_states */
     int32_t foot_body[GRX_NUM_FEET];         /* moving body carrying *_foot_roll_link */
     float foot_pos[GRX_NUM_FEET][3];         /* link-frame origin in that body's frame */
@@ -198,7 +204,10 @@ typedef struct grx_config {
 
     /* domain randomisation (legged_robot_config.py:177-206) */
     int32_t randomize_friction;      float friction_range[2];
-    int32_t randomize_restitution;   float restitution_range[2];   /* stored; contact model has e=0 */
+    int32_t randomize_restitution;   float restitution_range[2];   /* per-env shape restitution (legged_robot.py:565-575) */
+    float terrain_restitution;       /* legged_robot_config.py:79; combined with the shape's by averaging */
+    float bounce_threshold_velocity; /* legged_robot_config.py:48: slower impacts do not bounce */
+    int32_t self_collisions;         /* 1: links collide with each other (the reference's self_collisions = 0) */
     int32_t randomize_base_mass;     float base_mass_range[2];
     int32_t randomize_base_com;      float base_com_range[3][2];
     int32_t randomize_motor_strength; float motor_strength_range[2];

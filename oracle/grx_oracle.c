@@ -251,6 +251,7 @@ typedef struct {
     real pos[3], quat[4], vel[3], ang[3]; /* root state, world frame (gymapi root tensor layout) */
     real anchor[NFS][2];
     int anchor_on[NFS];
+    real anchor_vimp[NFS]; /* normal approach speed at the first touch of the current contact (restitution) */
     /* env pipeline state */
     real actions[ND_MAX], last_actions[ND_MAX], last_last_actions[ND_MAX], last_dof_vel[ND_MAX];
     real torques[ND_MAX];
@@ -418,6 +419,7 @@ static void contact_forces(const struct grx_sim* s, env_t* e, const kin_t* k, sv
     memset(e->link_force, 0, sizeof e->link_force);
     memset(e->feet_force, 0, sizeof e->feet_force);
     real mu = (real)0.5 * (cp->terrain_friction + e->friction); /* PhysX friction combine: average */
+    real e_rest = (real)0.5 * (c->terrain_restitution + e->restitution);
     int foot_slot[2] = {0, 0};
     for (int i = 0; i < m->num_spheres; ++i) {
         int b = m->sph_body[i];
@@ -443,15 +445,22 @@ static void contact_forces(const struct grx_sim* s, env_t* e, const kin_t* k, sv
          * integration of the (light) foot stable; normal force never pulls */
         real cd = cp->kn * d * cp->dn;
         if (cd > m->sph_damp_max[i]) cd = m->sph_damp_max[i];
-        real fn = cp->kn * d - cd * u[2];
-        if (fn < 0) fn = 0;
-        real F[3] = {0, 0, fn};
         if (slot >= 0 && slot < NFS) {
             if (!e->anchor_on[slot]) {
                 e->anchor_on[slot] = 1;
                 e->anchor[slot][0] = x[0];
                 e->anchor[slot][1] = x[1];
+                e->anchor_vimp[slot] = u[2] < 0 ? -u[2] : 0;
             }
+            /* restitution (legged_robot.py:565-575; PhysX combines by averaging, bounce threshold
+             * legged_robot_config.py:48): a contact that began faster than the threshold keeps only the
+             * fraction (1 - e) of its damping while the sphere separates again */
+            if (u[2] > 0 && e->anchor_vimp[slot] > c->bounce_threshold_velocity) cd *= 1 - e_rest;
+        }
+        real fn = cp->kn * d - cd * u[2];
+        if (fn < 0) fn = 0;
+        real F[3] = {0, 0, fn};
+        if (slot >= 0 && slot < NFS) {
             real ftx = -cp->kt * (x[0] - e->anchor[slot][0]) - cp->ct * u[0];
             real fty = -cp->kt * (x[1] - e->anchor[slot][1]) - cp->ct * u[1];
             real ft = sqrt(ftx * ftx + fty * fty), fmax = mu * fn;
@@ -476,6 +485,61 @@ static void contact_forces(const struct grx_sim* s, env_t* e, const kin_t* k, sv
         m3_tmulv(k->R[b], F, fb);
         v3_cross(sb, fb, nb_);
         for (int j = 0; j < 3; ++j) { fext[b].v[j] += nb_[j]; fext[b].v[3 + j] += fb[j]; }
+    }
+    /* self-collision (self_collisions = 0 = enabled, legged_robot_config.py:121): sphere pairs of links that can touch.
+     * Penalty contact along the line of centres (same Hunt-Crossley law as the terrain), viscous-capped friction with
+     * the shapes' own (per-env) friction; equal and opposite forces applied at the middle of the overlap. */
+    if (c->self_collisions) {
+        for (int pi = 0; pi < m->num_pairs; ++pi) {
+            int ia = m->pair_a[pi], ib = m->pair_b[pi];
+            int ba = m->sph_body[ia], bb = m->sph_body[ib];
+            real xa[3], xb[3], ua[3], ub_[3];
+            for (int w = 0; w < 2; ++w) {
+                int i = w ? ib : ia, b = w ? bb : ba;
+                real sb[3] = {m->sph_pos[i][0], m->sph_pos[i][1], m->sph_pos[i][2]}, sw[3], wxs[3], ul[3];
+                m3_mulv(k->R[b], sb, sw);
+                v3_cross(k->v[b].v, sb, wxs);
+                for (int j = 0; j < 3; ++j) ul[j] = k->v[b].v[3 + j] + wxs[j];
+                real* x = w ? xb : xa; real* u = w ? ub_ : ua;
+                for (int j = 0; j < 3; ++j) x[j] = k->p[b][j] + sw[j];
+                m3_mulv(k->R[b], ul, u);
+            }
+            real dv[3] = {xa[0] - xb[0], xa[1] - xb[1], xa[2] - xb[2]};
+            real d2 = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2];
+            real Rs = m->sph_radius[ia] + m->sph_radius[ib];
+            if (d2 >= Rs * Rs || d2 < (real)1e-12) continue;
+            real dist = sqrt(d2), pen = Rs - dist;
+            real n[3] = {dv[0] / dist, dv[1] / dist, dv[2] / dist}; /* from b to a */
+            real ur[3] = {ua[0] - ub_[0], ua[1] - ub_[1], ua[2] - ub_[2]};
+            real un = ur[0] * n[0] + ur[1] * n[1] + ur[2] * n[2];
+            real cd = cp->kn * pen * cp->dn;
+            real dm = m->sph_damp_max[ia] < m->sph_damp_max[ib] ? m->sph_damp_max[ia] : m->sph_damp_max[ib];
+            if (cd > dm) cd = dm;
+            real fn = cp->kn * pen - cd * un;
+            if (fn < 0) fn = 0;
+            real ut[3] = {ur[0] - un * n[0], ur[1] - un * n[1], ur[2] - un * n[2]};
+            real sp = sqrt(ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]);
+            real ft = cp->cv * sp, fmax = e->friction * fn;
+            if (ft > fmax) ft = fmax;
+            real F[3] = {fn * n[0], fn * n[1], fn * n[2]};
+            if (sp > (real)1e-9) for (int j = 0; j < 3; ++j) F[j] -= ft * ut[j] / sp;
+            real pw[3];   /* point of application: middle of the overlap, world */
+            for (int j = 0; j < 3; ++j) pw[j] = xb[j] + n[j] * (m->sph_radius[ib] - (real)0.5 * pen);
+            for (int w = 0; w < 2; ++w) {
+                int i = w ? ib : ia, b = w ? bb : ba;
+                real Fw[3] = {w ? -F[0] : F[0], w ? -F[1] : F[1], w ? -F[2] : F[2]};
+                int L = m->sph_link[i];
+                uint32_t fl = m->sph_flags[i];
+                for (int j = 0; j < 3; ++j) e->link_force[L][j] += Fw[j];
+                if (fl & GRX_SPH_FOOT_LEFT) for (int j = 0; j < 3; ++j) e->feet_force[0][j] += Fw[j];
+                if (fl & GRX_SPH_FOOT_RIGHT) for (int j = 0; j < 3; ++j) e->feet_force[1][j] += Fw[j];
+                real rel[3] = {pw[0] - k->p[b][0], pw[1] - k->p[b][1], pw[2] - k->p[b][2]}, rb[3], fb[3], nb_[3];
+                m3_tmulv(k->R[b], rel, rb);
+                m3_tmulv(k->R[b], Fw, fb);
+                v3_cross(rb, fb, nb_);
+                for (int j = 0; j < 3; ++j) { fext[b].v[j] += nb_[j]; fext[b].v[3 + j] += fb[j]; }
+            }
+        }
     }
 }
 
@@ -1244,7 +1308,7 @@ static void publish(struct grx_sim* s) {
         for (int k = 0; k < 3; ++k) { root[k] = (float)e->pos[k]; root[7 + k] = (float)e->vel[k]; root[10 + k] = (float)e->ang[k]; }
         for (int k = 0; k < 4; ++k) root[3 + k] = (float)e->quat[k];
         float* an = s->scratch[GRX_T_ANCHORS] + (size_t)i * NFS * 3;
-        for (int k = 0; k < NFS; ++k) { an[3 * k] = (float)e->anchor[k][0]; an[3 * k + 1] = (float)e->anchor[k][1]; an[3 * k + 2] = (float)e->anchor_on[k]; }
+        for (int k = 0; k < NFS; ++k) { an[3 * k] = (float)e->anchor[k][0]; an[3 * k + 1] = (float)e->anchor[k][1]; an[3 * k + 2] = e->anchor_on[k] ? (float)(e->anchor_vimp[k] > (real)1e-6 ? e->anchor_vimp[k] : (real)1e-6) : 0.f; }
         for (int t = 0; t < NT; ++t) {
             s->scratch[GRX_T_EPISODE_SUMS][(size_t)t * N + i] = (float)e->episode_sums[t];
             s->scratch[GRX_T_REWARD_TERMS][(size_t)t * N + i] = (float)e->reward_terms[t];

@@ -370,3 +370,44 @@ def test_set_state_and_api_errors():
         hip.step(torch.zeros(64, 10), 5.0, 1)                      # host tensor
     with pytest.raises(GrxError):
         hip.step(torch.zeros(10, 64).cuda().t(), 5.0, 1)           # non-contiguous (gymtorch.py:98-99)
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4])
+@pytest.mark.parametrize("task", ["GR1T1", "GR1T2"])
+def test_self_collision_matches_the_oracle(task, waves, monkeypatch):
+    """self_collisions = 0 = enabled (legged_robot_config.py:121): robots in flight with their legs driven into each
+    other (hip roll adducted, knees and feet crossing).  The HIP kernels (every wave layout) against the oracle from
+    identical state; the leg links carry the contact, and it is an internal force pair: the link forces of an env sum to 0."""
+    monkeypatch.setenv("GRX_WAVES_PER_BLOCK", str(waves))
+    cfg = make_cfg(task=task, dr=True, push=False)
+    N = 96
+    hip, ora = make_sims(cfg, N, seed=5)
+    hip.reset_all(); ora.reset_all()
+    g = torch.Generator().manual_seed(3)
+    root = ora.tensor("ROOT_STATES").clone()
+    root[:, 2] = 3.0                                            # no terrain contact during the test
+    root[:, 7:13] = torch.randn(N, 6, generator=g) * 0.3
+    q = torch.tensor([[-0.35, 0.0, -0.3, 0.6, -0.3, 0.35, 0.0, -0.3, 0.6, -0.3]]).repeat(N, 1)      # both hips adducted: thighs overlap
+    q += (torch.rand(N, 10, generator=g) - 0.5) * torch.tensor([0.5, 0.8, 0.8, 0.6, 0.4] * 2)
+    qd = torch.randn(N, 10, generator=g) * 2.0
+    for s_ in (hip, ora):
+        dev = s_.device
+        s_.set_state(root.to(dev).contiguous(), q.to(dev).contiguous(), qd.to(dev).contiguous())
+    seen = 0
+    worst = {}
+    for step in range(6):
+        if step > 0:
+            sync_state(hip, ora)
+        a = random_actions(cfg, N, g, 1.0)
+        ora.step(a, 5.0, step + 1); hip.step(a.cuda(), 5.0, step + 1)
+        torch.cuda.synchronize()
+        phys_diff(hip, ora, worst)
+        cf = ora.tensor("CONTACT_FORCES").double()
+        loaded = cf.abs().sum(2) > 1.0
+        seen += int(loaded.any(1).sum())
+        h = hip.tensor("CONTACT_FORCES").cpu().double()
+        assert float(h.sum(1).abs().max()) < 1e-3 * max(1.0, float(h.abs().max()))       # internal: sums to zero per env
+        # (a foot pressed on by the other leg reports contact, as the reference's net contact force would: legged_robot_fftai.py:110)
+    assert seen > N // 2, seen                                   # most envs did have their legs in contact
+    assert_phys(worst, scale=3.0)
+    hip.close()

@@ -147,3 +147,105 @@ def test_f32_tracks_f64_over_one_policy_step():
         s64.step(a, 3.0, i + 1); s32.step(a, 3.0, i + 1)
         np.testing.assert_allclose(s32.tensor("DOF_POS").numpy(), s64.tensor("DOF_POS").numpy(), atol=2e-4)
         np.testing.assert_allclose(s32.tensor("ROOT_STATES").numpy(), s64.tensor("ROOT_STATES").numpy(), atol=2e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ self-collision, restitution (round 2)
+def _leg_squeeze(self_collisions, precision="f64", steps=400):
+    """Free-floating robot far above the ground, no gravity: the hip-roll motors drive the legs into each other."""
+    from oracle.binding import OracleSim
+    cfg = make_cfg()
+    cfg.sim.gravity = [0.0, 0.0, 0.0]
+    cfg.asset.self_collisions = 0 if self_collisions else 1      # the reference's flag: 0 = collide (legged_robot_config.py:121)
+    c, keep, meta = build_config.build(cfg, cfg.sim.dt, 1)
+    sim = OracleSim(c, precision, keep)
+    rm = meta["model"]
+    root = torch.zeros(1, 13); root[0, 2] = 50.0; root[0, 6] = 1.0
+    q0 = torch.tensor([[0, 0, -0.2618, 0.5236, -0.2618] * 2], dtype=torch.float32)
+    sim.set_state(root.contiguous(), q0.contiguous(), torch.zeros(1, 10))
+    tau = np.zeros(10)
+    names = rm.dof_names
+    for j, n in enumerate(names):
+        if "hip_roll" in n:
+            tau[j] = (-1.0 if n.startswith("l") else 1.0) * rm.dof_effort[j]     # adduct both legs at the effort limit
+    P0 = sim.energy(0)["P"].copy()
+    m = c.model
+
+    def overlap():   # deepest overlap over the listed sphere pairs, from the oracle's own kinematics
+        deep = 0.0
+        for k in range(m.num_pairs):
+            a, b = m.pair_a[k], m.pair_b[k]
+            Ra, pa = sim.body_pose(0, m.sph_body[a]); Rb, pb = sim.body_pose(0, m.sph_body[b])
+            ca = pa + Ra @ np.array(m.sph_pos[a][:]); cb = pb + Rb @ np.array(m.sph_pos[b][:])
+            deep = max(deep, m.sph_radius[a] + m.sph_radius[b] - np.linalg.norm(ca - cb))
+        return deep
+    deepest, lf_best = 0.0, np.zeros((37, 3))
+    for _ in range(steps // 5):
+        sim.substeps(0, tau, 5, contact=True)
+        deepest = max(deepest, overlap())
+        lf = sim.link_forces(0)
+        if np.abs(lf).max() > np.abs(lf_best).max():
+            lf_best = lf
+    P1 = sim.energy(0)["P"].copy()
+    return deepest, P1 - P0, lf_best, sim, meta
+
+
+def test_self_collision_keeps_the_legs_apart():
+    """legged_robot_config.py:121 self_collisions = 0 (enabled): under saturated adduction torques the thighs press on
+    each other and stop at the compliant sink (F / kn: a few millimetres); with the filter on they pass through."""
+    deep_on, dP_on, lf, sim, meta = _leg_squeeze(True)
+    deep_off, _, lf_off, _, _ = _leg_squeeze(False)
+    assert deep_off > 0.04, deep_off              # without self-collision the thighs interpenetrate by centimetres
+    assert 0.0 < deep_on < 0.012, deep_on        # with it: the compliant sink only
+    # the contact is an internal force pair: the link forces sum to zero and no momentum is created
+    assert np.abs(lf).max() > 20.0 and np.abs(lf.sum(0)).max() < 1e-6 * np.abs(lf).max()
+    M = meta["model"].total_mass()
+    assert np.abs(dP_on).max() < 1e-3 * M      # < 1 mm/s of COM velocity over 0.8 s of motor-driven squeezing: the Euler step's own error
+    assert np.abs(lf_off).max() == 0.0
+    names = meta["model"].body_names
+    loaded = {names[i] for i in np.nonzero(np.abs(lf).sum(1) > 1.0)[0]}
+    assert {"left_thigh_pitch_link", "right_thigh_pitch_link"} <= loaded, loaded
+    assert all(("thigh" in n or "shank" in n or "foot" in n) for n in loaded), loaded      # (the feet meet as well)
+
+
+def test_self_collision_pairs_come_from_the_model_table():
+    """Every listed sphere pair sits on two different, non-adjacent moving bodies (PhysX filters jointed links)."""
+    for task in ("GR1T1", "GR1T2", "GR1T1Full"):
+        cfg = make_cfg(task=task)
+        c, _, meta = build_config.build(cfg, cfg.sim.dt, 1)
+        m = c.model
+        assert m.num_pairs > 0 and c.self_collisions == 1
+        for k in range(m.num_pairs):
+            ba, bb = m.sph_body[m.pair_a[k]], m.sph_body[m.pair_b[k]]
+            assert ba != bb and m.parent[ba] != bb and m.parent[bb] != ba
+
+
+def _drop(restitution, vdown=1.5, n=400, z=0.93):
+    """Zero-torque drop of the robot onto the plane; per sub-step: sum of the foot links' normal forces, foot-sphere approach marker."""
+    from oracle.binding import OracleSim
+    cfg = make_cfg(dr=False)
+    cfg.domain_rand.randomize_restitution = True
+    cfg.domain_rand.restitution_range = [restitution, restitution]
+    c, keep, meta = build_config.build(cfg, cfg.sim.dt, 1)
+    sim = OracleSim(c, "f64", keep)
+    root = torch.zeros(1, 13); root[0, 2] = z; root[0, 6] = 1.0; root[0, 9] = -vdown
+    q = torch.tensor([[0, 0, -0.2618, 0.5236, -0.2618] * 2], dtype=torch.float32)
+    sim.set_state(root.contiguous(), q.contiguous(), torch.zeros(1, 10))
+    feet = meta["feet_links"]
+    fz = []
+    for _ in range(n):
+        sim.substeps(0, np.zeros(10), 1, contact=True)
+        fz.append(sim.link_forces(0)[feet, 2].sum())
+    return np.array(fz)
+
+
+def test_restitution_raises_the_rebound_above_the_bounce_threshold():
+    """Per-env restitution (legged_robot.py:565-575) with PhysX's bounce threshold (legged_robot_config.py:48): after a
+    1.5 m/s landing the separating foot keeps only (1 - e) of its contact damping, so from the first separating sub-step
+    on the ground pushes harder with e = 0.5 than with e = 0; a 0.2 m/s landing (below the 0.5 m/s threshold) is unaffected."""
+    f0, f5 = _drop(0.0), _drop(0.5)
+    assert f0.max() > 100.0
+    diff = np.nonzero(f0 != f5)[0]
+    assert diff.size > 0 and diff[0] > np.nonzero(f0 > 0)[0][0]      # identical through the compression phase
+    assert f5[diff[0]] > f0[diff[0]], (diff[0], f0[diff[0]], f5[diff[0]])
+    l0, l5 = _drop(0.0, vdown=0.2, n=60, z=0.90), _drop(0.5, vdown=0.2, n=60, z=0.90)      # touches at ~0.35 m/s
+    assert l0.max() > 50.0 and np.array_equal(l0, l5)

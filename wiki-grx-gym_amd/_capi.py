@@ -5,10 +5,11 @@ Field order and sizes must match the header exactly; ``grx_create`` rejects a mi
 """
 import ctypes as C
 
-GRX_ABI_VERSION = 1
+GRX_ABI_VERSION = 2
 MAX_BODIES = 36
 MAX_DOFS = 32
 MAX_SPHERES = 48
+MAX_PAIRS = 192
 NUM_FEET = 2
 MAX_HEIGHT_POINTS = 128
 
@@ -65,6 +66,8 @@ class Model(C.Structure):
         ("sph_flags", u32 * MAX_SPHERES),
         ("sph_link", i32 * MAX_SPHERES),
         ("sph_damp_max", f32 * MAX_SPHERES),
+        ("num_pairs", i32),
+        ("pair_a", C.c_int16 * MAX_PAIRS), ("pair_b", C.c_int16 * MAX_PAIRS),
         ("foot_body", i32 * NUM_FEET),
         ("foot_pos", (f32 * 3) * NUM_FEET),
         ("torso_body", i32),
@@ -96,6 +99,7 @@ class Config(C.Structure):
         ("init_pos", f32 * 3), ("init_rot", f32 * 4), ("init_lin_vel", f32 * 3), ("init_ang_vel", f32 * 3),
         ("randomize_friction", i32), ("friction_range", f32 * 2),
         ("randomize_restitution", i32), ("restitution_range", f32 * 2),
+        ("terrain_restitution", f32), ("bounce_threshold_velocity", f32), ("self_collisions", i32),
         ("randomize_base_mass", i32), ("base_mass_range", f32 * 2),
         ("randomize_base_com", i32), ("base_com_range", (f32 * 2) * 3),
         ("randomize_motor_strength", i32), ("motor_strength_range", f32 * 2),

@@ -162,9 +162,10 @@ int check_topology(const grx_model& m) {
     return GRX_OK;
 }
 
-int build_side_tables(const grx_config& c, KTables& P) {
+int build_side_tables(const grx_config& c, KTables& P, uint32_t* ll_mask) {
     const grx_model& m = c.model;
     memset(P.side, 0, sizeof P.side);
+    *ll_mask = 0;
     for (int side = 0; side < 2; ++side) {
         SideConst& S = P.side[side];
         for (int k = 0; k < GRX_LEG; ++k) {
@@ -231,6 +232,50 @@ int build_side_tables(const grx_config& c, KTables& P) {
                 ++n;
             }
         }
+        // bounding sphere of the shapes of chain bodies 2, 3, 4 (body frame): broad phase of the leg-vs-leg self-collision
+        for (int bi = 0; bi < 3; ++bi) {
+            const int k = 2 + bi;
+            float cx = 0, cy = 0, cz = 0;
+            for (int n = 0; n < cnt[k]; ++n) { const SphC& q = S.sph[off[k] + n]; cx += q.x; cy += q.y; cz += q.z; }
+            cx /= cnt[k]; cy /= cnt[k]; cz /= cnt[k];
+            float rad = 0;
+            for (int n = 0; n < cnt[k]; ++n) {
+                const SphC& q = S.sph[off[k] + n];
+                if (q.r < 0) continue;
+                rad = std::max(rad, sqrtf((q.x - cx) * (q.x - cx) + (q.y - cy) * (q.y - cy) + (q.z - cz) * (q.z - cz)) + q.r);
+            }
+            S.bs[bi][0] = cx; S.bs[bi][1] = cy; S.bs[bi][2] = cz; S.bs[bi][3] = rad;
+        }
+    }
+    // self-collision pairs (grx_model.pair_a / pair_b) -> the fused kernel's tables: left-leg x right-leg body pairs
+    // (every sphere pair of a listed link pair is in the list, so a 3 x 3 body mask carries it) and base-lump x thigh pairs
+    for (int pi = 0; pi < m.num_pairs; ++pi) {
+        int ia = m.pair_a[pi], ib = m.pair_b[pi];
+        if (ia < 0 || ib < 0 || ia >= m.num_spheres || ib >= m.num_spheres) return fail(GRX_ERR_INVALID_ARGUMENT, "self-collision pair out of range");
+        int ba = m.sph_body[ia], bb = m.sph_body[ib];
+        if (ba > bb) { std::swap(ia, ib); std::swap(ba, bb); }
+        if (ba == 0 && bb == 0) continue;
+        auto side_of = [](int b) { return (b - 1) / GRX_LEG; };
+        auto k_of = [](int b) { return (b - 1) % GRX_LEG; };
+        if (ba == 0) {   // base lump x chain shape: thigh shapes only
+            const int side = side_of(bb), k = k_of(bb);
+            if (k != 2) return fail(GRX_ERR_UNSUPPORTED_MODEL, "base-lump self-collision with a chain body other than the thigh");
+            SideConst& S = P.side[side];
+            int tsel = -1;
+            for (int n = 0; n < cnt[2]; ++n) {
+                const SphC& q = S.sph[off[2] + n];
+                if (q.x == m.sph_pos[ib][0] && q.y == m.sph_pos[ib][1] && q.z == m.sph_pos[ib][2]) tsel = n;
+            }
+            if (tsel < 0 || S.nbc >= GRX_MAX_BC) return fail(GRX_ERR_UNSUPPORTED_MODEL, "base-lump / thigh self-collision table overflow");
+            BaseChainPair& e = S.bc[S.nbc++];
+            e.x = m.sph_pos[ia][0]; e.y = m.sph_pos[ia][1]; e.z = m.sph_pos[ia][2]; e.r = m.sph_radius[ia];
+            e.dmax = m.sph_damp_max[ia]; e.tsel = tsel; e.link = m.sph_link[ia]; e.pad = 0;
+        } else {
+            if (side_of(ba) == side_of(bb)) return fail(GRX_ERR_UNSUPPORTED_MODEL, "self-collision within one leg chain");
+            const int kl = side_of(ba) == 0 ? k_of(ba) : k_of(bb), kr = side_of(ba) == 0 ? k_of(bb) : k_of(ba);
+            if (kl < 2 || kr < 2) return fail(GRX_ERR_UNSUPPORTED_MODEL, "self-collision shapes on a chain body without a shape table");
+            *ll_mask |= 1u << ((kl - 2) * 3 + (kr - 2));
+        }
     }
     return GRX_OK;
 }
@@ -288,6 +333,10 @@ struct GenTablesH {
     float foot_pos[2][3];
     int32_t torso_body, forehead_body;
     float torso_rot[9], forehead_rot[9];
+    int32_t nlp;
+    int32_t lp_a[48], lp_b[48], lp_ba[48], lp_bb[48];
+    float lp_ca[48][4], lp_cb[48][4];
+    int32_t lc_begin[GEN_MAXLC_H + 1];
 };
 
 int build_generic(grx_sim* s, const grx_config& c) {
@@ -344,6 +393,38 @@ int build_generic(grx_sim* s, const grx_config& c) {
             }
     }
     T.nlc = (int)link_ids.size();
+    {   // a compact link's shapes are contiguous (spheres sorted by (body, link)): ranges + bounding spheres (body frame)
+        std::vector<int> pos_of(m.num_spheres);   // model sphere index -> position in the sorted tables
+        for (int k = 0; k < m.num_spheres; ++k) pos_of[order[k]] = k;
+        for (int l = 0; l <= T.nlc; ++l) T.lc_begin[l] = m.num_spheres;
+        for (int k = m.num_spheres - 1; k >= 0; --k) T.lc_begin[T.slink[k]] = k;
+        for (int l = T.nlc - 1; l >= 0; --l) if (T.lc_begin[l] > T.lc_begin[l + 1]) return fail(GRX_ERR_UNSUPPORTED_MODEL, "collision shapes of a link are not contiguous");
+        auto bound = [&](int l, float out4[4]) {
+            float c[3] = {0, 0, 0};
+            const int b0 = T.lc_begin[l], b1 = T.lc_begin[l + 1];
+            for (int k = b0; k < b1; ++k) { c[0] += T.sx[k]; c[1] += T.sy[k]; c[2] += T.sz[k]; }
+            for (int a = 0; a < 3; ++a) c[a] /= (float)(b1 - b0);
+            float rad = 0;
+            for (int k = b0; k < b1; ++k)
+                rad = std::max(rad, sqrtf((T.sx[k] - c[0]) * (T.sx[k] - c[0]) + (T.sy[k] - c[1]) * (T.sy[k] - c[1]) + (T.sz[k] - c[2]) * (T.sz[k] - c[2])) + T.sr[k]);
+            out4[0] = c[0]; out4[1] = c[1]; out4[2] = c[2]; out4[3] = rad;
+        };
+        T.nlp = 0;
+        for (int pi = 0; pi < m.num_pairs; ++pi) {
+            int ka = pos_of[m.pair_a[pi]], kb = pos_of[m.pair_b[pi]];
+            int la = T.slink[ka], lb = T.slink[kb];
+            int ba = m.sph_body[order[ka]], bb = m.sph_body[order[kb]];
+            if (ba > bb) { std::swap(la, lb); std::swap(ba, bb); }   // body bb is never the base (workspace addressing)
+            bool seen = false;
+            for (int q = 0; q < T.nlp; ++q) seen = seen || (T.lp_a[q] == la && T.lp_b[q] == lb);
+            if (seen) continue;
+            if (ba == bb) return fail(GRX_ERR_INVALID_ARGUMENT, "self-collision pair within one body");
+            if (T.nlp >= 48) return fail(GRX_ERR_UNSUPPORTED_MODEL, "too many self-collision link pairs");
+            T.lp_a[T.nlp] = la; T.lp_b[T.nlp] = lb; T.lp_ba[T.nlp] = ba; T.lp_bb[T.nlp] = bb;
+            bound(la, T.lp_ca[T.nlp]); bound(lb, T.lp_cb[T.nlp]);
+            ++T.nlp;
+        }
+    }
     for (int f = 0; f < 2; ++f) if (T.foot_link[f] < 0) return fail(GRX_ERR_UNSUPPORTED_MODEL, "a foot carries no collision shape");
     {
         int k = 0;
@@ -425,6 +506,8 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     P.kn = c.contact.kn; P.dn = c.contact.dn; P.kt = c.contact.kt; P.ct = c.contact.ct; P.cv = c.contact.cv;
     P.terrain_friction = c.contact.terrain_friction;
     P.inv_kt = 1.0f / c.contact.kt;
+    P.bounce_threshold = c.bounce_threshold_velocity; P.terrain_restitution = c.terrain_restitution;
+    P.self_collisions = c.self_collisions;
     P.termination_force = c.termination_force; P.termination_gravity_z = c.termination_gravity_z;
     P.max_episode_length = c.max_episode_length; P.max_episode_length_s = c.max_episode_length_s;
     P.resample_command_interval = c.resample_command_interval;
@@ -457,14 +540,14 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     memcpy(P.forehead_rot, m.forehead_rot, sizeof P.forehead_rot);
     P.has_torso = m.torso_body >= 0; P.has_forehead = m.forehead_body >= 0;
     if (!generic) {
-        rc = build_side_tables(c, s->tab);
+        rc = build_side_tables(c, s->tab, &P.ll_mask);
         if (rc) { delete s; return rc; }
     }
 
 #define DA(field, count) do { rc = dalloc(s, &P.field, (count)); if (rc) { grx_destroy(s); return rc; } } while (0)
     DA(q, nd * N); DA(qd, nd * N); DA(root, 13 * N); DA(anchors, 24 * N);
     DA(last_actions, nd * N); DA(last_dof_vel, nd * N); DA(actions, nd * N); DA(torques, nd * N);
-    DA(motor_strength, nd * N); DA(base_m, N); DA(base_c, 3 * N); DA(base_I, 6 * N); DA(friction, N);
+    DA(motor_strength, nd * N); DA(base_m, N); DA(base_c, 3 * N); DA(base_I, 6 * N); DA(friction, N); DA(restitution, N);
     DA(commands, 3 * N); DA(origins, 3 * N); DA(levels, N); DA(types, N);
     DA(air_time, 2 * N); DA(land_time, 2 * N); DA(feet_contact, 2 * N);
     DA(feet_height, 2 * N); DA(avg_force, 2 * N); DA(feet_force, 6 * N); DA(contact_forces, 3 * GRX_MAX_LINKS * N); DA(feet_pos, 6 * N); DA(avg_speed, 6 * N);
@@ -537,7 +620,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     }
     // ---- per-env constants on the host (same arithmetic as the oracle's gro_create)
     {
-        std::vector<float> h_strength(nd * N), h_bm(N), h_bc(3 * N), h_bI(6 * N), h_fr(N), h_or(3 * N), h_q(nd * N), h_root(13 * N, 0.f), h_bmc(4 * N);
+        std::vector<float> h_strength(nd * N), h_bm(N), h_bc(3 * N), h_bI(6 * N), h_fr(N), h_rs(N), h_or(3 * N), h_q(nd * N), h_root(13 * N, 0.f), h_bmc(4 * N);
         std::vector<int32_t> h_lv(N, 0), h_ty(N, 0);
         std::vector<uint8_t> h_reset(N, 1);
         for (size_t i = 0; i < N; ++i) {
@@ -569,6 +652,13 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
                 fr = c.friction_range[0] + (c.friction_range[1] - c.friction_range[0]) * grx_rand(c.seed, b, 1, GRX_RNG_INIT_DR, 0);
             }
             h_fr[i] = fr;
+            float rs = 0.f;
+            if (c.randomize_restitution) {
+                uint32_t b = (uint32_t)(grx_rand(c.seed, ge, 0, GRX_RNG_INIT_DR, 1) * 64);
+                if (b > 63) b = 63;
+                rs = c.restitution_range[0] + (c.restitution_range[1] - c.restitution_range[0]) * grx_rand(c.seed, b, 1, GRX_RNG_INIT_DR, 1);
+            }
+            h_rs[i] = rs;
             float lm = m.base_link_mass, lc[3] = {m.base_link_com[0], m.base_link_com[1], m.base_link_com[2]};
             if (c.randomize_base_mass) lm *= c.base_mass_range[0] + (c.base_mass_range[1] - c.base_mass_range[0]) * grx_rand(c.seed, ge, 0, GRX_RNG_INIT_DR, 2);
             if (c.randomize_base_com)
@@ -590,7 +680,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
             h_root[6 * N + i] = 1.f;
         }
 #define UP(dst, vec) HIP_TRY(hipMemcpy(P.dst, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice))
-        UP(motor_strength, h_strength); UP(base_m, h_bm); UP(base_c, h_bc); UP(base_I, h_bI); UP(friction, h_fr);
+        UP(motor_strength, h_strength); UP(base_m, h_bm); UP(base_c, h_bc); UP(base_I, h_bI); UP(friction, h_fr); UP(restitution, h_rs);
         UP(origins, h_or); UP(levels, h_lv); UP(types, h_ty); UP(q, h_q); UP(root, h_root); UP(reset, h_reset);
         HIP_TRY(hipMemcpy(base_mass_com, h_bmc.data(), h_bmc.size() * sizeof(float), hipMemcpyHostToDevice));
     }

@@ -35,11 +35,24 @@ struct alignas(16) BodyC {
     float slo, shi, pad0, pad1;    // soft dof position limits (legged_robot.py:606-610)
 };
 
+// self-collision between a base-lump shape and one of this lane's two thigh shapes (grx_self.h)
+struct alignas(16) BaseChainPair {
+    float x, y, z, r;    // the base-lump sphere, base frame
+    float dmax;          // its damping cap
+    int32_t tsel;        // which thigh shape of this lane (0 / 1)
+    int32_t link;        // URDF link of the base-lump sphere (row of GRX_T_CONTACT_FORCES)
+    int32_t pad;
+};
+#define GRX_MAX_BC 8
+
 // Per-side (left leg / right leg lane) robot constants; staged into LDS by every block.
 struct alignas(16) SideConst {
     BodyC body[GRX_LEG];
     float foot_pos[3];
+    int32_t nbc;                  // base-lump / thigh self-collision pairs of this side
     SphC sph[GRX_MAXSPH_SIDE];
+    float bs[3][4];               // bounding spheres (centre in the body frame, radius) of the shapes of chain bodies 2, 3, 4
+    BaseChainPair bc[GRX_MAX_BC];
 };
 
 // Large read-only tables, in device memory.
@@ -76,6 +89,10 @@ struct KParams {
     int32_t terrain_type, measure_heights, nh;
     const int16_t* hf; int32_t hf_rows, hf_cols;
     const float* coarse_max; int32_t coarse_rows, coarse_cols;   // dilated block-max of the raster [m]: sphere culling
+    float bounce_threshold, terrain_restitution;   // legged_robot_config.py:48, :79
+    int32_t self_collisions;     // links collide with each other (legged_robot_config.py:121)
+    uint32_t ll_mask;            // bit (i * 3 + j): the shapes of LEFT chain body 2 + i can touch those of RIGHT chain body 2 + j
+    float* restitution;          // [N] per-env shape restitution (legged_robot.py:565-575)
     const int16_t* hf_max4;   // [hf_rows][hf_cols]: max of the four raster corners of cell (i, j) = upper bound of the bilinear
                               // height anywhere in the cell: the exact reach test of the lane-compacted contacts (grx_rare.h)
     float horizontal_scale, vertical_scale, border_size, inv_hscale;

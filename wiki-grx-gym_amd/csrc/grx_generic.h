@@ -20,7 +20,7 @@
 // workspace round trips (DESIGN.md section 4.3 has the measured rate).
 #pragma once
 
-constexpr int GEN_MAXB = GRX_MAX_BODIES, GEN_MAXD = GRX_MAX_DOFS, GEN_MAXS = GRX_MAX_SPHERES, GEN_MAXLC = 24;
+constexpr int GEN_MAXB = GRX_MAX_BODIES, GEN_MAXD = GRX_MAX_DOFS, GEN_MAXS = GRX_MAX_SPHERES, GEN_MAXLC = 24, GEN_MAXLP = 48;
 constexpr int WSB = 72;   // workspace floats per body
 enum { W_R = 0, W_RHO = 9, W_W = 12, W_V = 15, W_A = 18, W_S = 21, W_CA = 24, W_CL = 27, W_IA = 30, W_IB = 36, W_ID = 45,
        W_PA = 51, W_PL = 54, W_UA = 57, W_UL = 60, W_DI = 63, W_U = 64, W_AA = 65, W_AL = 68 };
@@ -41,6 +41,12 @@ struct GenTables {
     float foot_pos[2][3];
     int32_t torso_body, forehead_body;
     float torso_rot[9], forehead_rot[9];
+    // self-collision (grx_model.pair_a / pair_b grouped by link pair): compact links a, b on bodies ba, bb, bounding
+    // spheres of their shapes (body frame: xyz, radius); a compact link's shapes are sx[lc_begin[l] .. lc_begin[l + 1])
+    int32_t nlp;
+    int32_t lp_a[GEN_MAXLP], lp_b[GEN_MAXLP], lp_ba[GEN_MAXLP], lp_bb[GEN_MAXLP];
+    float lp_ca[GEN_MAXLP][4], lp_cb[GEN_MAXLP][4];
+    int32_t lc_begin[GEN_MAXLC + 1];
 };
 typedef const GRX_AS4 GenTables& GT;
 
@@ -75,20 +81,26 @@ GRX_DEV R3 gen_joint_rot(const R3& Rp, GT T, int b, float q) {
 
 // one sphere of body `b` against the terrain with a run-time anchor slot; adds its force into the link accumulator
 template <bool HF>
-GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu, float hmax, float* ws, size_t WN, size_t N, int e,
+GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu, float om_e, float hmax, float* ws, size_t WN, size_t N, int e,
                       int lfbase, V3& xr) {
     xr = rho + rot(R, v3(T.sx[i], T.sy[i], T.sz[i]));
     V3 F = v3(0.f, 0.f, 0.f);
     const float wz = O.z + xr.z, r = T.sr[i];
     const int slot = T.sslot[i];
     bool touching = false;
+    float vimp = 0.f;
     if (wz - r <= hmax) {
         const float wx = O.x + xr.x, wy = O.y + xr.y;
         const float d = terrain_height<HF>(P, wx, wy) + r - wz;
         if (d > 0.0f) {
             touching = true;
             const V3 u = v + cross(w, xr);
-            const float cd = fminf(P.kn * d * P.dn, T.sdmax[i]);
+            float cd = fminf(P.kn * d * P.dn, T.sdmax[i]);
+            if (slot >= 0) {   // restitution (same rule as the fast kernel's sphere_contact)
+                vimp = P.anchors[(size_t)(slot * 3 + 2) * N + e];
+                if (vimp == 0.f) vimp = fmaxf(fmaxf(-u.z, 0.0f), 1e-6f);
+                if (u.z > 0.0f && vimp > P.bounce_threshold) cd *= om_e;
+            }
             const float fn = fmaxf(P.kn * d - cd * u.z, 0.0f);
             F.z = fn;
             const float fmax = mu * fn;
@@ -114,7 +126,7 @@ GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, 
             }
         }
     }
-    if (slot >= 0) P.anchors[(size_t)(slot * 3 + 2) * N + e] = touching ? 1.f : 0.f;
+    if (slot >= 0) P.anchors[(size_t)(slot * 3 + 2) * N + e] = touching ? vimp : 0.f;
     const int L = T.slink[i];
     ws[(size_t)(lfbase + L * 3 + 0) * WN] += F.x; ws[(size_t)(lfbase + L * 3 + 1) * WN] += F.y; ws[(size_t)(lfbase + L * 3 + 2) * WN] += F.z;
     return F;
@@ -149,7 +161,7 @@ GRX_DEV void gen_foot_frames(KP P, GT T, const GenBase& B, const float* q, const
 // One physics sub-step.  q / qd / torques: this env's columns of the SoA state arrays (stride N).
 template <bool HF>
 GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const float* tau, float* ws, size_t WN, size_t N, int e,
-                         float base_m, V3 base_c, const S3& base_I, float mu, float hmax, V3 foot_vel_before[2]) {
+                         float base_m, V3 base_c, const S3& base_I, float mu, float om_e, float hmax, V3 foot_vel_before[2]) {
     const int nb = T.nb, lfbase = nb * WSB;
     const float dt = P.sim_dt;
     const R3 R0 = quat_to_R(B.qx, B.qy, B.qz, B.qw);
@@ -182,7 +194,7 @@ GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const floa
         rigid_bias(R, kap, m, Ic, w, v, pa, pl);
         for (int i = T.sph_begin[b]; i < T.sph_begin[b + 1]; ++i) {
             V3 xr;
-            const V3 F = gen_sphere<HF>(P, T, i, R, rho, w, v, O, mu, hmax, ws, WN, N, e, lfbase, xr);
+            const V3 F = gen_sphere<HF>(P, T, i, R, rho, w, v, O, mu, om_e, hmax, ws, WN, N, e, lfbase, xr);
             pa = pa - cross(xr, F); pl = pl - F;
         }
         for (int f = 0; f < 2; ++f)
@@ -206,8 +218,42 @@ GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const floa
     rigid_bias(R0, rot(R0, base_c), base_m, base_I, B.ang, B.vel, pa0, pl0);
     for (int i = T.sph_begin[0]; i < T.sph_begin[1]; ++i) {
         V3 xr;
-        const V3 F = gen_sphere<HF>(P, T, i, R0, v3(0.f, 0.f, 0.f), B.ang, B.vel, O, mu, hmax, ws, WN, N, e, lfbase, xr);
+        const V3 F = gen_sphere<HF>(P, T, i, R0, v3(0.f, 0.f, 0.f), B.ang, B.vel, O, mu, om_e, hmax, ws, WN, N, e, lfbase, xr);
         pa0 = pa0 - cross(xr, F); pl0 = pl0 - F;
+    }
+    // self-collision (grx_self.h has the contact law): link pairs that can touch, bounding spheres first
+    if (P.self_collisions) {
+        const float mu_self = 2.0f * mu - P.terrain_friction;
+        for (int lp = 0; lp < T.nlp; ++lp) {
+            const int ba = T.lp_ba[lp], bb = T.lp_bb[lp];
+            ChainKin Ka, Kb;
+            if (ba == 0) Ka = ChainKin{R0, v3(0.f, 0.f, 0.f), B.ang, B.vel};
+            else Ka = ChainKin{ws_R(ws, WN, ba), ws_v3(ws, WN, ba, W_RHO), ws_v3(ws, WN, ba, W_W), ws_v3(ws, WN, ba, W_V)};
+            Kb = ChainKin{ws_R(ws, WN, bb), ws_v3(ws, WN, bb, W_RHO), ws_v3(ws, WN, bb, W_W), ws_v3(ws, WN, bb, W_V)};
+            const V3 ca = Ka.rho + rot(Ka.R, v3(T.lp_ca[lp][0], T.lp_ca[lp][1], T.lp_ca[lp][2]));
+            const V3 cb = Kb.rho + rot(Kb.R, v3(T.lp_cb[lp][0], T.lp_cb[lp][1], T.lp_cb[lp][2]));
+            const V3 d = ca - cb;
+            const float R = T.lp_ca[lp][3] + T.lp_cb[lp][3];
+            if (!(dot(d, d) < R * R)) continue;
+            const int la = T.lp_a[lp], lb = T.lp_b[lp];
+            V3 Fa = v3(0.f, 0.f, 0.f), Ta = v3(0.f, 0.f, 0.f);
+            for (int i = T.lc_begin[la]; i < T.lc_begin[la + 1]; ++i) {
+                SphC si; si.x = T.sx[i]; si.y = T.sy[i]; si.z = T.sz[i]; si.r = T.sr[i]; si.dmax = T.sdmax[i];
+                const SphW a = sph_world(si, Ka);
+                for (int j = T.lc_begin[lb]; j < T.lc_begin[lb + 1]; ++j) {
+                    SphC sj; sj.x = T.sx[j]; sj.y = T.sy[j]; sj.z = T.sz[j]; sj.r = T.sr[j]; sj.dmax = T.sdmax[j];
+                    const SphW b = sph_world(sj, Kb);
+                    V3 F, pw;
+                    if (sphere_pair(P, a, b, mu_self, F, pw)) { Fa = Fa + F; Ta = Ta + cross(pw, F); }
+                }
+            }
+            // F on link a (body ba), -F on link b (body bb)
+            if (ba == 0) { pa0 = pa0 - Ta; pl0 = pl0 - Fa; }
+            else { WSX(ba, W_PA) -= Ta.x; WSX(ba, W_PA + 1) -= Ta.y; WSX(ba, W_PA + 2) -= Ta.z; WSX(ba, W_PL) -= Fa.x; WSX(ba, W_PL + 1) -= Fa.y; WSX(ba, W_PL + 2) -= Fa.z; }
+            WSX(bb, W_PA) += Ta.x; WSX(bb, W_PA + 1) += Ta.y; WSX(bb, W_PA + 2) += Ta.z; WSX(bb, W_PL) += Fa.x; WSX(bb, W_PL + 1) += Fa.y; WSX(bb, W_PL + 2) += Fa.z;
+            ws[(size_t)(lfbase + la * 3 + 0) * WN] += Fa.x; ws[(size_t)(lfbase + la * 3 + 1) * WN] += Fa.y; ws[(size_t)(lfbase + la * 3 + 2) * WN] += Fa.z;
+            ws[(size_t)(lfbase + lb * 3 + 0) * WN] -= Fa.x; ws[(size_t)(lfbase + lb * 3 + 1) * WN] -= Fa.y; ws[(size_t)(lfbase + lb * 3 + 2) * WN] -= Fa.z;
+        }
     }
     S3 Ab = A0, Db = {base_m, 0.f, 0.f, base_m, 0.f, base_m};
     M3 Bb = {0.f, -h0.z, h0.y, h0.z, 0.f, -h0.x, -h0.y, h0.x, 0.f};
@@ -375,6 +421,7 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
     const V3 base_c = v3(P.base_c[e], P.base_c[N + e], P.base_c[2 * N + e]);
     const S3 base_I = {P.base_I[e], P.base_I[N + e], P.base_I[2 * N + e], P.base_I[3 * N + e], P.base_I[4 * N + e], P.base_I[5 * N + e]};
     const float mu = 0.5f * (P.terrain_friction + P.friction[e]);
+    const float om_e = 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]);
     float hmax = 0.f;
     if (HF) {
         int ci = min(max((int)((B.pos.x + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_rows - 1);
@@ -407,7 +454,7 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
             t *= strength[(size_t)j * N];
             tau[(size_t)j * N] = fminf(fmaxf(t, -T.effort[j]), T.effort[j]);
         }
-        gen_substep<HF>(P, T, B, q, qd, tau, ws, WN, N, e, base_m, base_c, base_I, mu, hmax, fvel);
+        gen_substep<HF>(P, T, B, q, qd, tau, ws, WN, N, e, base_m, base_c, base_I, mu, om_e, hmax, fvel);
         if (deci > 0)
             for (int f = 0; f < 2; ++f) avg_speed[f] = v3(avg_speed[f].x + fabsf(fvel[f].x), avg_speed[f].y + fabsf(fvel[f].y), avg_speed[f].z + fabsf(fvel[f].z));
         for (int f = 0; f < 2; ++f) {

@@ -96,6 +96,7 @@ struct LaneState {
     V3 pos, vel, ang;
     float qx, qy, qz, qw;
     float ax[4], ay[4];  // friction anchors of the 4 spheres of this lane's foot
+    float vimp[4];       // normal approach speed at the first touch of the current contact (restitution)
     uint32_t anchor_on;  // bit i: anchor i active
 };
 
@@ -105,6 +106,7 @@ struct LaneConst {  // per-env constants held in registers
     V3 base_c;
     S3 base_I;
     float mu;
+    float om_e;   // 1 - restitution of the foot / terrain pair (legged_robot.py:565-575; PhysX combines by averaging)
     float hmax;   // upper bound of the terrain height within reach during this policy step
 };
 
@@ -136,7 +138,7 @@ GRX_DEV void sphere_probe(KP P, const SphC& S, const R3& R, V3 rho, V3 O, V3& xr
 // sphere (compile time), -1 for the other shapes.  xr = sphere centre relative to O, th = terrain height under it
 // (sphere_probe).  Returns the world-frame force.
 template <bool HF, int SLOT>
-GRX_DEV V3 sphere_contact(KP P, const SphC& S, V3 w, V3 v, V3 O, float mu, float hmax, LaneState& st, V3 xr, float th) {
+GRX_DEV V3 sphere_contact(KP P, const SphC& S, V3 w, V3 v, V3 O, float mu, float hmax, LaneState& st, V3 xr, float th, float om_e = 1.0f) {
     V3 F = v3(0.f, 0.f, 0.f);
     const float wz = O.z + xr.z;
     // cull: hmax bounds the terrain height anywhere the robot can reach during this policy step
@@ -149,6 +151,11 @@ GRX_DEV V3 sphere_contact(KP P, const SphC& S, V3 w, V3 v, V3 O, float mu, float
             touching = true;
             V3 u = v + cross(w, xr);
             float cd = fminf(P.kn * d * P.dn, S.dmax);  // Hunt-Crossley damping, mass-aware cap (oracle contact_forces())
+            if (SLOT >= 0) {   // restitution: a contact that began faster than the bounce threshold keeps (1 - e) of its damping while separating
+                constexpr int sl = SLOT < 0 ? 0 : SLOT;
+                if (!(st.anchor_on & (1u << sl))) st.vimp[sl] = fmaxf(-u.z, 0.0f);
+                if (u.z > 0.0f && st.vimp[sl] > P.bounce_threshold) cd *= om_e;
+            }
             float fn = fmaxf(P.kn * d - cd * u.z, 0.0f);
             F.z = fn;
             float fmax = mu * fn;
@@ -281,17 +288,17 @@ GRX_DEV void chain_step(const SideConst& C, int k, float q, float qd, ChainKin& 
 // the four anchored spheres of this lane's foot (chain body LEG-1): wrench about O + anchor update
 template <bool HF>
 GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, float mu, float hmax, LaneState& st,
-                           V3& fa, V3& fl) {
+                           V3& fa, V3& fl, float om_e) {
     fa = v3(0.f, 0.f, 0.f); fl = v3(0.f, 0.f, 0.f);
     constexpr int o = kSphOff[LEG - 1];
     if (group_within_reach<4>(&C.sph[o], K.R, K.rho, O, hmax)) {
         V3 xr[4], F; float th[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) sphere_probe<HF>(P, C.sph[o + i], K.R, K.rho, O, xr[i], th[i]);
-        F = sphere_contact<HF, 0>(P, C.sph[o + 0], K.w, K.v, O, mu, hmax, st, xr[0], th[0]); fa = fa + cross(xr[0], F); fl = fl + F;
-        F = sphere_contact<HF, 1>(P, C.sph[o + 1], K.w, K.v, O, mu, hmax, st, xr[1], th[1]); fa = fa + cross(xr[1], F); fl = fl + F;
-        F = sphere_contact<HF, 2>(P, C.sph[o + 2], K.w, K.v, O, mu, hmax, st, xr[2], th[2]); fa = fa + cross(xr[2], F); fl = fl + F;
-        F = sphere_contact<HF, 3>(P, C.sph[o + 3], K.w, K.v, O, mu, hmax, st, xr[3], th[3]); fa = fa + cross(xr[3], F); fl = fl + F;
+        F = sphere_contact<HF, 0>(P, C.sph[o + 0], K.w, K.v, O, mu, hmax, st, xr[0], th[0], om_e); fa = fa + cross(xr[0], F); fl = fl + F;
+        F = sphere_contact<HF, 1>(P, C.sph[o + 1], K.w, K.v, O, mu, hmax, st, xr[1], th[1], om_e); fa = fa + cross(xr[1], F); fl = fl + F;
+        F = sphere_contact<HF, 2>(P, C.sph[o + 2], K.w, K.v, O, mu, hmax, st, xr[2], th[2], om_e); fa = fa + cross(xr[2], F); fl = fl + F;
+        F = sphere_contact<HF, 3>(P, C.sph[o + 3], K.w, K.v, O, mu, hmax, st, xr[3], th[3], om_e); fa = fa + cross(xr[3], F); fl = fl + F;
     } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
 }
 
@@ -314,6 +321,7 @@ GRX_DEV void link_contacts(KP P, const SideConst& C, int k, const ChainKin& K, V
 }
 
 #include "grx_rare.h"
+#include "grx_self.h"
 
 // One physics sub-step (gym.simulate(dt), legged_robot_fftai.py:68) for this lane's half of the env.
 // tau: motor torques of this lane's 5 joints.  fk_only: just the kinematics pass (foot frames).
@@ -339,7 +347,7 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
     out.foot_force = v3(0.f, 0.f, 0.f);
     out.term = false;
     out.pen_count = 0.f;
-    ChainKin K2, K3;   // thigh / shank frames: their shapes are evaluated lane-compacted after the walk (grx_rare.h)
+    ChainKin K2, K3, K4;   // thigh / shank (/ foot) frames: rare terrain contacts (grx_rare.h) and self-collision (grx_self.h) after the walk
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
         V3 rho = rho_p + rot(Rp, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
@@ -367,9 +375,9 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
             if (kSphCnt[k] == 2) { if (k == 2) K2 = K; else K3 = K; }
             else {
                 V3 fa, fl;
-                foot_contacts<HF>(P, C, K, O, LC.mu, LC.hmax, st, fa, fl); out.foot_force = fl;
-                put_link_force(lfo, C.sph[kSphOff[k]], fl);
+                foot_contacts<HF>(P, C, K, O, LC.mu, LC.hmax, st, fa, fl, LC.om_e); out.foot_force = fl;
                 pa = pa - fa; pl = pl - fl;
+                K4 = K;
             }
         }
         if (k == LEG - 1) {  // foot link frame BEFORE this sub-step's integration
@@ -384,9 +392,17 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
     GRX_TICK2(16);
     // thigh / shank shapes (W == 1: and the base-lump shapes), compacted over the wave
     RareOut ro;
-    rare_contacts<HF, (W == 1 ? 0 : 8), RC_NS>(P, T, C, RB, lane, el, side, R0, O, st.ang, st.vel, K2, K3, LC.mu, LC.hmax, ro, lfo);
-    pA[2] = pA[2] - ro.fa2; pL[2] = pL[2] - ro.fl2;
-    pA[3] = pA[3] - ro.fa3; pL[3] = pL[3] - ro.fl3;
+    rare_contacts<HF, (W == 1 ? 0 : 8), RC_NS>(P, T, C, RB, lane, el, side, R0, O, st.ang, st.vel, K2, K3, LC.mu, LC.hmax, ro);
+    SelfOut sc;
+    {   // self-collision: leg against leg, thigh against base-lump shapes
+        const ChainKin KS[3] = {K2, K3, K4};
+        self_collision(P, C, side, R0, st.ang, st.vel, KS, 2.0f * LC.mu - P.terrain_friction, sc);
+    }
+    pA[2] = pA[2] - ro.fa2 - sc.fa[0]; pL[2] = pL[2] - ro.fl2 - sc.fl[0];
+    pA[3] = pA[3] - ro.fa3 - sc.fa[1]; pL[3] = pL[3] - ro.fl3 - sc.fl[1];
+    pA[4] = pA[4] - sc.fa[2]; pL[4] = pL[4] - sc.fl[2];
+    const V3 foot_terrain = out.foot_force;
+    out.foot_force = out.foot_force + sc.fl[2];   // net contact force on the foot link: terrain + self-collision
     GRX_TICK2(17);
     // ---- pass 2: articulated inertias (leaf -> root).  w, v currently = velocity of body LEG-1.
     S3 A = IAk[LEG - 1];
@@ -435,11 +451,16 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
         const V3 f0a = v3(wr[0 * 64], wr[1 * 64], wr[2 * 64]), f0l = v3(wr[3 * 64], wr[4 * 64], wr[5 * 64]);
         out.term = wr[6 * 64] != 0.f;
         out.pen_count = wr[7 * 64];
-        pa = pa - f0a; pl = pl - f0l;
+        pa = pa - f0a - sc.f0a; pl = pl - f0l - sc.f0l;
+        if (lfo.last) {   // the helper wave parked the per-link forces of the base-lump shapes behind its wrench
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ro.lf[i] = v3(wr[(8 + 3 * i) * 64], wr[(9 + 3 * i) * 64], wr[(10 + 3 * i) * 64]);
+        }
     } else {
         out.term = ro.term; out.pen_count = ro.pen_count;
-        pa = pa - ro.f0a; pl = pl - ro.f0l;
+        pa = pa - ro.f0a - sc.f0a; pl = pl - ro.f0l - sc.f0l;
     }
+    write_link_rows(lfo, C, ro.lf, ro.fl2, ro.fl3, foot_terrain, sc);
     A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
     pa = pair_sum(pa); pl = pair_sum(pl);
     {
@@ -991,9 +1012,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     float* const s_obs = reinterpret_cast<float*>(s_arena);
     float* const s_pri = reinterpret_cast<float*>(s_arena + OBS_BYTES);
     float* const s_rw = reinterpret_cast<float*>(s_arena + OBS_BYTES + PRI_BYTES);   // reward inputs (wave 0 -> waves 1, 3), W == 4
+    // final friction anchors of the step (W == 4: wave 2 -> wave 0 across the barrier that ends the sub-steps): behind the
+    // compaction buffers, inside what becomes s_rw only after wave 0 has picked them up
+    static_assert(W != 4 || (PHYS_BYTES >= OBS_BYTES + PRI_BYTES && PHYS_BYTES + 13 * 64 * 4 <= POST_BYTES), "s_anch must sit in the arena's tail");
+    float* const s_anch = reinterpret_cast<float*>(s_arena + PHYS_BYTES);
     __shared__ float s_stat[NT + 1];
     __shared__ float s_base[W >= 2 ? 13 * EPB : 1];   // base state at the start of the current sub-step (dynamics -> helpers)
-    __shared__ __attribute__((aligned(16))) float s_wr[W >= 2 ? 8 * 64 : 1];       // base-lump wrench + termination / collision flags (helper -> dynamics)
+    __shared__ __attribute__((aligned(16))) float s_wr[W == 2 ? 32 * 64 : (W == 4 ? 8 * 64 : 1)];       // base-lump wrench + termination / collision flags (helper -> dynamics)
     // W == 4 pipeline buffers (grx_wavepipe.h)
     __shared__ float4 s_q[W == 4 ? Q4 * 64 : 1];
     __shared__ float4 s_ri[W == 4 ? LEG * RI4 * 64 : 1];
@@ -1001,7 +1026,6 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     __shared__ float4 s_rec0[W == 4 ? REC04 * 64 : 1];
     __shared__ float4 s_wc[W == 4 ? WC4 * 64 : 1];
     __shared__ float4 s_pb[W == 4 ? (LEG * PB4 + 2) * 64 : 1];
-    __shared__ float s_anch[W == 4 ? 9 * 64 : 1];     // final friction anchors of the step (wave 2 -> wave 0)
     __shared__ uint32_t s_nz[W == 4 ? NZB * 4 * 64 : 1];   // observation-noise Philox blocks (wave 1 -> wave 0)
     __shared__ float4 s_rr[W == 4 ? 5 * 64 : 1];           // reset_idx's uniform draws (wave 2 -> wave 0)
     __shared__ float s_rwp[W == 4 ? 64 : 1];               // partial reward (wave 3 -> wave 1)
@@ -1069,15 +1093,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 for (int i = 0; i < 4; ++i) {
                     hs.ax[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 0) * N + e];
                     hs.ay[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e];
-                    if (P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] != 0.0f) hs.anchor_on |= (1u << i);
+                    hs.vimp[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e];   // 0: no contact; else the contact's approach speed
+                    if (hs.vimp[i] != 0.0f) hs.anchor_on |= (1u << i);
                 }
-                chain_contact_loop<HF>(P, GRX_HELPER_C, RB, mu, hmax, hs, L, lane, el, act ? P.contact_forces + e : nullptr, (size_t)N);
+                chain_contact_loop<HF>(P, GRX_HELPER_C, RB, mu, hmax, 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]), hs, L, lane, el, side);
                 float* a_ = s_anch + lane;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { a_[i * 64] = hs.ax[i]; a_[(4 + i) * 64] = hs.ay[i]; }
+                for (int i = 0; i < 4; ++i) { a_[i * 64] = hs.ax[i]; a_[(4 + i) * 64] = hs.ay[i]; a_[(9 + i) * 64] = hs.vimp[i]; }
                 a_[8 * 64] = __uint_as_float(hs.anchor_on);
             } else {
-                base_contact_loop<HF>(P, s_tab, GRX_HELPER_C, RB, mu, hmax, bm, bc, bI, L, lane, el, side, act ? P.contact_forces + e : nullptr, (size_t)N);
+                base_contact_loop<HF>(P, s_tab, GRX_HELPER_C, RB, mu, hmax, bm, bc, bI, L, lane, el, side);
             }
             float es_w1[NT], es_w3[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
             if (wv == 1) load_episode_sums<1>(P, e, N, es_w1);
@@ -1136,9 +1161,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
                 RareOut ro;
                 const ChainKin nok = {R0, v3(0.f, 0.f, 0.f), ang, vel};   // no chain shapes on this wave
-                rare_contacts<HF, 0, 8>(P, s_tab, C, RB, lane, el, side, R0, O, ang, vel, nok, nok, mu, hmax, ro,
-                                        LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N});
+                rare_contacts<HF, 0, 8>(P, s_tab, C, RB, lane, el, side, R0, O, ang, vel, nok, nok, mu, hmax, ro);
                 float* w_ = s_wr + lane;
+                if (deci == P.decimation - 1) {   // GRX_T_CONTACT_FORCES rows are written by the dynamics wave (it adds the self-collision forces)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { w_[(8 + 3 * i) * 64] = ro.lf[i].x; w_[(9 + 3 * i) * 64] = ro.lf[i].y; w_[(10 + 3 * i) * 64] = ro.lf[i].z; }
+                }
                 w_[0 * 64] = ro.f0a.x; w_[1 * 64] = ro.f0a.y; w_[2 * 64] = ro.f0a.z;
                 w_[3 * 64] = ro.f0l.x; w_[4 * 64] = ro.f0l.y; w_[5 * 64] = ro.f0l.z;
                 w_[6 * 64] = ro.term ? 1.f : 0.f; w_[7 * 64] = ro.pen_count;
@@ -1177,12 +1205,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     }
     st.anchor_on = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] != 0.0f) st.anchor_on |= (1u << i);
+    for (int i = 0; i < 4; ++i) {
+        st.vimp[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e];   // 0: no contact; else the contact's approach speed
+        if (st.vimp[i] != 0.0f) st.anchor_on |= (1u << i);
+    }
     LC.base_m = P.base_m[e];
     LC.base_c = v3(P.base_c[e], P.base_c[(size_t)N + e], P.base_c[2 * (size_t)N + e]);
     LC.base_I.xx = P.base_I[e]; LC.base_I.xy = P.base_I[(size_t)N + e]; LC.base_I.xz = P.base_I[2 * (size_t)N + e];
     LC.base_I.yy = P.base_I[3 * (size_t)N + e]; LC.base_I.yz = P.base_I[4 * (size_t)N + e]; LC.base_I.zz = P.base_I[5 * (size_t)N + e];
     LC.mu = 0.5f * (P.terrain_friction + P.friction[e]);
+    LC.om_e = 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]);
     LC.hmax = 0.0f;
     if (HF) {
         int ci = min(max((int)((st.pos.x + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_rows - 1);
@@ -1240,7 +1272,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             t *= LC.strength[k];
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
-        if (W == 4) substep_p<HF>(P, Cr, LC, st, torque, so, fk, L, lane, deci, tacc);
+        if (W == 4) substep_p<HF>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc,
+                                  LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N});
         else substep<HF, W>(P, s_tab, C, LC, st, torque, so, fk, s_wr + lane, tacc,
                             LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
@@ -1255,7 +1288,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
         __syncthreads();   // final friction anchors + height-scan pose published
         const float* a_ = s_anch + lane;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { st.ax[i] = a_[i * 64]; st.ay[i] = a_[(4 + i) * 64]; }
+        for (int i = 0; i < 4; ++i) { st.ax[i] = a_[i * 64]; st.ay[i] = a_[(4 + i) * 64]; st.vimp[i] = a_[(9 + i) * 64]; }
         st.anchor_on = __float_as_uint(a_[8 * 64]);
     }
     GRX_TICK(2);
@@ -1455,7 +1488,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
         for (int i = 0; i < 4; ++i) {
             P.anchors[(size_t)((side * 4 + i) * 3 + 0) * N + e] = st.ax[i];
             P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e] = st.ay[i];
-            P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] = (st.anchor_on >> i) & 1u ? 1.f : 0.f;
+            P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] = (st.anchor_on >> i) & 1u ? fmaxf(st.vimp[i], 1e-6f) : 0.f;
         }
         P.air_time[(size_t)side * N + e] = air_time * (contact_filt ? 0.f : 1.f);  // legged_robot_fftai.py:97
         P.land_time[(size_t)side * N + e] = land_time;

@@ -67,6 +67,7 @@ struct RareOut {
     V3 f0a, f0l;        // base-lump shapes
     V3 fa2, fl2;        // thigh shapes (chain body 2)
     V3 fa3, fl3;        // shank shapes (chain body 3)
+    V3 lf[8];           // net force of the base-lump URDF link that ends at table slot i (slots with link_last set)
     bool term; float pen_count;
 };
 
@@ -78,7 +79,7 @@ struct RareNoWait { GRX_DEV void operator()() const {} };
 // Must be called by all 64 lanes in wave-uniform control flow.
 template <bool HF, int S0, int S1, bool FRAMES_IN_LDS = false, class WaitFrames = RareNoWait>
 GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const RareBuf& B, int lane, int el, int side, const R3& R0, V3 O, V3 ang, V3 vel,
-                           const ChainKin& K2in, const ChainKin& K3in, float mu, float hmax, RareOut& out, const LinkForceOut& lfo,
+                           const ChainKin& K2in, const ChainKin& K3in, float mu, float hmax, RareOut& out,
                            long long* rare_acc = nullptr, WaitFrames wait_frames = WaitFrames()) {
     const V3 zero = v3(0.f, 0.f, 0.f);
 #ifdef GRX_PROFILE_SECTIONS
@@ -244,14 +245,6 @@ GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const Rar
         }
     }
     GRX_RARE_T(4);
-    if (lfo.last) {   // GRX_T_CONTACT_FORCES rows of this lane's links (zeros when nothing was within reach)
-        if (S0 < 8) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) if (C.sph[i].link_last & 1) put_link_force(lfo, C.sph[i], Fs[i]);
-        }
-        if (S1 > 8) {
-            put_link_force(lfo, C.sph[8], out.fl2);
-            put_link_force(lfo, C.sph[10], out.fl3);
-        }
-    }
+    for (int i = 0; i < 8; ++i) out.lf[i] = Fs[i];
 }

@@ -55,7 +55,8 @@ constexpr int REC4 = 7;   // quads per joint record: ua 3, ul 3, 1/d, A' 6, B' 9
 constexpr int RI4 = 4;    // quads per chain body from wave 0: rigid inertia about O (A 6, h 3), joint axis Sa 3, Ss 3  (15 floats)
 constexpr int PB4 = 3;    // quads per chain body from wave 2: rigid-body bias force pa 3, pl 3, velocity-product acceleration ca 3, cl 3
 constexpr int REC04 = 6;  // factorised base-level articulated inertia: inv(D) 6, inv(Schur) 6, B 9  (21 floats)
-constexpr int WC4 = 7;    // contact wrenches about O: thigh quads 0-1, shank 2-3, foot 4-6 (wrench 6 + foot link velocity 3)
+constexpr int WC4 = 15;   // contact wrenches about O: thigh quads 0-1, shank 2-3, foot 4-6 (wrench 6 + foot link velocity 3);
+                          // quads 7-14: self-collision (grx_self.h) on thigh, shank, foot, base lump + the forces on base-lump links
 constexpr int Q4 = 3;     // q 5, qd 5 of the lane's leg
 
 struct PipeLds {
@@ -107,7 +108,8 @@ GRX_DEV void add_rigid(S3& A, M3& B, S3& D, const S3& Ak, V3 h, float m) {
 // wave 0: one sub-step of the state owner
 template <bool HF>
 GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
-                       SubstepOut& out, FootKin& fk_before, const PipeLds& L, int lane, int seq, long long* tacc) {
+                       SubstepOut& out, FootKin& fk_before, const PipeLds& L, const RareBuf& RB, int lane, int seq, long long* tacc,
+                       const LinkForceOut& lfo) {
     const float dt = P.sim_dt;
 #ifdef GRX_PROFILE_SECTIONS
     long long tprev = clock64();
@@ -180,6 +182,17 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     // ---- contact wrenches on chain bodies 4 (foot), 3 (shank), 2 (thigh): delta recursion  dp -> dp + U (-S.dp)/d
     GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
     GRX_WAIT(L.flag + FL_LEGS, seq + 1, 2);
+    SelfOut sc;   // self-collision wrenches (wave 2)
+    {
+        const float4* c = L.wc + 7 * 64 + lane;
+        const float4 s0 = c[0 * 64], s1 = c[1 * 64], s2 = c[2 * 64], s3 = c[3 * 64], s4 = c[4 * 64], s5 = c[5 * 64], s6 = c[6 * 64], s7 = c[7 * 64];
+        sc.fa[0] = v3(s0.x, s0.y, s0.z); sc.fl[0] = v3(s0.w, s1.x, s1.y);
+        sc.fa[1] = v3(s1.z, s1.w, s2.x); sc.fl[1] = v3(s2.y, s2.z, s2.w);
+        sc.fa[2] = v3(s3.x, s3.y, s3.z); sc.fl[2] = v3(s3.w, s4.x, s4.y);
+        sc.f0a = v3(s4.z, s4.w, s5.x); sc.f0l = v3(s5.y, s5.z, s5.w);
+        sc.fbase[0] = v3(s6.x, s6.y, s6.z); sc.fbase[1] = v3(s6.w, s7.x, s7.y);
+    }
+    V3 flt[3];   // terrain forces on thigh, shank, foot (GRX_T_CONTACT_FORCES rows)
     {
         V3 da = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
 #pragma unroll
@@ -188,8 +201,9 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
                 const float4* c = L.wc + ((k - 2) * 2) * 64 + lane;
                 const float4 c0_ = c[0 * 64], c1_ = c[1 * 64];
                 const V3 fa = v3(c0_.x, c0_.y, c0_.z), fl = v3(c0_.w, c1_.x, c1_.y);
-                da = da - fa; dl = dl - fl;
-                if (k == LEG - 1) { const float4 c2_ = c[2 * 64]; out.foot_force = fl; fk_before.vel = v3(c1_.z, c1_.w, c2_.x); }
+                da = da - fa - sc.fa[k - 2]; dl = dl - fl - sc.fl[k - 2];
+                flt[k - 2] = fl;
+                if (k == LEG - 1) { const float4 c2_ = c[2 * 64]; out.foot_force = fl + sc.fl[2]; fk_before.vel = v3(c1_.z, c1_.w, c2_.x); }
             }
             const float du = -(dot(Sa[k], da) + dot(Ss[k], dl));
             uu[k] += du;
@@ -204,7 +218,14 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         const V3 f0a = v3(w0_.x, w0_.y, w0_.z), f0l = v3(w0_.w, w1_.x, w1_.y);
         out.term = w1_.z != 0.f;
         out.pen_count = w1_.w;
-        pa = pa - f0a; pl = pl - f0l;
+        pa = pa - f0a - sc.f0a; pl = pl - f0l - sc.f0l;
+    }
+    if (lfo.last) {   // GRX_T_CONTACT_FORCES rows: wave 3 parked the per-link forces of the base-lump shapes in the result table
+        V3 lf[8];
+        const float2* r = RB.res + lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float2 a = r[(2 * i) * 64], b = r[(2 * i + 1) * 64]; lf[i] = v3(a.x, a.y, b.x); }
+        write_link_rows(lfo, C, lf, flt[0], flt[1], flt[2], sc);
     }
     pa = pair_sum(pa); pl = pair_sum(pl);
     {   // base-lump bias force (wave 3; both lanes of the pair add the same value after the pair sum)
@@ -325,8 +346,8 @@ GRX_DEV void iwave_loop(KP P, const SideConst& C, float base_m, V3 base_c, const
 // ---------------------------------------------------------------------------------------------------------------
 // wave 2: own walk with velocities; thigh / shank frames for wave 3; the anchored foot spheres
 template <bool HF>
-GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, float mu, float hmax, LaneState& hs, const PipeLds& L,
-                                int lane, int el, float* cf_env, size_t N) {
+GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, float mu, float hmax, float om_e, LaneState& hs, const PipeLds& L,
+                                int lane, int el, int side) {
     GRX_HELPER_PROF_BEGIN;
     for (int seq = 0; seq < P.decimation; ++seq) {
         GRX_HELPER_PROF_IDLE0;
@@ -379,7 +400,7 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
         }
         float4* c_ = L.wc + lane;
         V3 fa, fl;
-        foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl);
+        foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl, om_e);
         {   // foot link velocity BEFORE this sub-step's integration (sub-step averaged foot speed, fftai.py:79-81)
             const V3 fr = K.rho + rot(K.R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
             const V3 fv = K.v + cross(K.w, fr);
@@ -387,9 +408,21 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
             c_[5 * 64] = f4(fl.y, fl.z, fv.x, fv.y);
             c_[6 * 64] = f4(fv.z, 0.f, 0.f, 0.f);
         }
-        flag_set(L.flag + FL_FOOT, seq + 1, lane);
-        const LinkForceOut lfo = {seq == P.decimation - 1, cf_env, N};   // GRX_T_CONTACT_FORCES: last sub-step only
-        put_link_force(lfo, C.sph[kSphOff[LEG - 1]], fl);   // (the thigh and shank shapes are wave 3's: grx_rare.h)
+        {   // self-collision: leg against leg (the partner lane is one DPP step away), thigh against base-lump shapes
+            SelfOut sc;
+            const ChainKin KS[3] = {KK[2], KK[3], K};
+            self_collision(P, C, side, R0, ang, vel, KS, 2.0f * mu - P.terrain_friction, sc);
+            float4* o = L.wc + 7 * 64 + lane;
+            o[0 * 64] = f4(sc.fa[0].x, sc.fa[0].y, sc.fa[0].z, sc.fl[0].x);
+            o[1 * 64] = f4(sc.fl[0].y, sc.fl[0].z, sc.fa[1].x, sc.fa[1].y);
+            o[2 * 64] = f4(sc.fa[1].z, sc.fl[1].x, sc.fl[1].y, sc.fl[1].z);
+            o[3 * 64] = f4(sc.fa[2].x, sc.fa[2].y, sc.fa[2].z, sc.fl[2].x);
+            o[4 * 64] = f4(sc.fl[2].y, sc.fl[2].z, sc.f0a.x, sc.f0a.y);
+            o[5 * 64] = f4(sc.f0a.z, sc.f0l.x, sc.f0l.y, sc.f0l.z);
+            o[6 * 64] = f4(sc.fbase[0].x, sc.fbase[0].y, sc.fbase[0].z, sc.fbase[1].x);
+            o[7 * 64] = f4(sc.fbase[1].y, sc.fbase[1].z, 0.f, 0.f);
+        }
+        flag_set(L.flag + FL_FOOT, seq + 1, lane);   // foot contact wrench + self-collision wrenches
     }
     GRX_HELPER_PROF_END(2);
 }
@@ -397,7 +430,7 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
 // wave 3: the seldom-touching shapes -- base lump (torso, head, arms), thigh, shank -- lane-compacted (grx_rare.h)
 template <bool HF>
 GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, float mu, float hmax, float base_m, V3 base_c,
-                               const S3& base_I, const PipeLds& L, int lane, int el, int side, float* cf_env, size_t N) {
+                               const S3& base_I, const PipeLds& L, int lane, int el, int side) {
     GRX_HELPER_PROF_BEGIN;
 #ifdef GRX_PROFILE_SECTIONS
     long long racc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -412,7 +445,6 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
         const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
-        const LinkForceOut lfo = {seq == P.decimation - 1, cf_env, N};
         {   // the base lump's rigid-body bias force (cheap; needed by wave 0 only at the base solve)
             V3 bpa, bpl;
             rigid_bias(R0, rot(R0, base_c), base_m, base_I, ang, vel, bpa, bpl);
@@ -425,8 +457,13 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         RareOut ro;
         const int want = seq + 1;
         int* const fr_flag = L.flag + FL_FRAMES;
-        rare_contacts<HF, 0, RC_NS, true>(P, T, C, RB, lane, el, side, R0, O, ang, vel, ChainKin(), ChainKin(), mu, hmax, ro, lfo, racc,
+        rare_contacts<HF, 0, RC_NS, true>(P, T, C, RB, lane, el, side, R0, O, ang, vel, ChainKin(), ChainKin(), mu, hmax, ro, racc,
                                           [=]() { flag_wait(fr_flag, want); });
+        if (seq == P.decimation - 1) {   // GRX_T_CONTACT_FORCES: per-link forces of the base-lump shapes for wave 0 (the result table is free now)
+            float2* r = RB.res + lane;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { float2 a; a.x = ro.lf[i].x; a.y = ro.lf[i].y; r[(2 * i) * 64] = a; a.x = ro.lf[i].z; a.y = 0.f; r[(2 * i + 1) * 64] = a; }
+        }
         float4* c_ = L.wc + lane;
         c_[0 * 64] = f4(ro.fa2.x, ro.fa2.y, ro.fa2.z, ro.fl2.x);
         c_[1 * 64] = f4(ro.fl2.y, ro.fl2.z, 0.f, 0.f);

@@ -77,6 +77,9 @@ def build(cfg, sim_dt, num_envs, env_offset=0, total_envs=None, seed=1, terrain=
     dr = cfg.domain_rand
     c.randomize_friction = int(dr.randomize_friction); _set(c.friction_range, dr.friction_range)
     c.randomize_restitution = int(dr.randomize_restitution); _set(c.restitution_range, dr.restitution_range)
+    c.terrain_restitution = float(cfg.terrain.restitution)
+    c.bounce_threshold_velocity = float(getattr(cfg.sim.physx, "bounce_threshold_velocity", 0.5))
+    c.self_collisions = int(cfg.asset.self_collisions == 0)   # the reference's flag is a bitwise FILTER: 0 = collide (legged_robot_config.py:121)
     c.randomize_base_mass = int(dr.randomize_base_mass); _set(c.base_mass_range, dr.multiply_base_mass_range)
     c.randomize_base_com = int(dr.randomize_base_com)
     for k, rng in enumerate((dr.add_base_com_range_x, dr.add_base_com_range_y, dr.add_base_com_range_z)):

@@ -168,6 +168,8 @@ class RobotModel:
                     raise ValueError(f"unsupported collision primitive {shp['type']}")
         if len(self.spheres) > _capi.MAX_SPHERES:
             raise ValueError("too many collision spheres")
+        # links that can touch each other (tools/self_collision_pairs.py: Monte-Carlo over the joint ranges)
+        self.self_collision_link_pairs = [tuple(p) for p in raw.get("self_collision_link_pairs", [])]
 
     # ---- name queries, the way the reference builds its index sets (gr1t1.py:18-113, 127-279)
     def links_containing(self, sub):
@@ -249,6 +251,15 @@ def fill_model(cm, rm, foot_name, torso_name, forehead_name, terminate_names, pe
         arm = np.cross(pos - rm.com[body], np.array([0.0, 0.0, 1.0]))
         inv_meff = 1.0 / rm.mass[body] + arm @ np.linalg.solve(rm.inertia[body], arm)
         cm.sph_damp_max[k] = damp_alpha / inv_meff / sim_dt
+    # self-collision: every sphere pair of every link pair that can touch
+    link_of = [rm.spheres[i][3] for i in order]
+    pairs = [(a, b) for a in range(len(order)) for b in range(a + 1, len(order))
+             if (min(link_of[a], link_of[b]), max(link_of[a], link_of[b])) in set(rm.self_collision_link_pairs)]
+    if len(pairs) > _capi.MAX_PAIRS:
+        raise ValueError(f"{len(pairs)} self-collision sphere pairs exceed GRX_MAX_PAIRS")
+    cm.num_pairs = len(pairs)
+    for k, (a, b) in enumerate(pairs):
+        cm.pair_a[k], cm.pair_b[k] = a, b
     for f in range(2):
         cm.foot_body[f] = rm.link_body[feet[f]]
         for a in range(3):
