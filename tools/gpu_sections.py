@@ -30,9 +30,10 @@ for terrain in ("plane","heightfield"):
     nb=lib.grx_debug_profile(s._h, buf, 128)
     full=np.array(buf[:],dtype=np.int64).reshape(128,48)[:nb]
     a=full[:,:11]
-    print('   wave 0, sum over 10 sub-steps:', dict(zip(['wait bias forces','wait I records','wait foot / rare contacts','-','wait base factorisation','whole sub-steps'], np.median(full[:,16:22],axis=0).astype(int).tolist())))
+    print('   wave 0, sum over 10 sub-steps:', dict(zip(['wait bias forces','wait I records','wait foot / rare contacts','wait self-collision','wait base factorisation','whole sub-steps'], np.median(full[:,16:22],axis=0).astype(int).tolist())))
     print('   helper waves (idle waiting for state, total) cycles:', {f"wave{w}": np.median(full[:,22+2*w:24+2*w],axis=0).astype(int).tolist() for w in (1,2,3)})
     print('   wave 3 rare contacts (sum over 10 sub-steps): cheap test, fine test, compaction, evaluation, pick-up + netting, -, candidates, calls with any:', np.median(full[:,32:40],axis=0).astype(int).tolist(), 'mean candidates', full[:,38].mean())
+    print('   wave 1 self-collision (sum over 10 sub-steps): cycles, candidate envs, lanes with a hit, candidate groups | cycles: centres+extents, ballot+staging, pair tests, forces:', np.mean(full[:,40:48],axis=0).astype(int).tolist())
     print('   obs sub-sections (cycles after tick 7): heights, noise load, side-0 puts:', np.median(full[:,11:14]-full[:,7:8],axis=0).astype(int).tolist())
     print('   relative to tick 6 (FL_REW published): wave1 got FL_REW, wave1 rewards done, wave2 got FL_HZ, wave2 heights done, wave0 tick 9:', np.median(full[:,[14,15,30,31,9]]-full[:,6:7],axis=0).astype(int).tolist())
     d=np.diff(a,axis=1)

@@ -162,10 +162,11 @@ int check_topology(const grx_model& m) {
     return GRX_OK;
 }
 
-int build_side_tables(const grx_config& c, KTables& P, uint32_t* ll_mask) {
+int build_side_tables(const grx_config& c, KTables& P, uint32_t* ll_mask, uint64_t* sp_mask) {
     const grx_model& m = c.model;
     memset(P.side, 0, sizeof P.side);
     *ll_mask = 0;
+    *sp_mask = 0;
     for (int side = 0; side < 2; ++side) {
         SideConst& S = P.side[side];
         for (int k = 0; k < GRX_LEG; ++k) {
@@ -275,6 +276,19 @@ int build_side_tables(const grx_config& c, KTables& P, uint32_t* ll_mask) {
             const int kl = side_of(ba) == 0 ? k_of(ba) : k_of(bb), kr = side_of(ba) == 0 ? k_of(bb) : k_of(ba);
             if (kl < 2 || kr < 2) return fail(GRX_ERR_UNSUPPORTED_MODEL, "self-collision shapes on a chain body without a shape table");
             *ll_mask |= 1u << ((kl - 2) * 3 + (kr - 2));
+            // the sphere pair itself: table slots of the left-lane and the right-lane shape
+            const int il = side_of(ba) == 0 ? ia : ib, ir = side_of(ba) == 0 ? ib : ia;
+            auto slot_of = [&](int side, int k, int isph) {
+                const SideConst& S = P.side[side];
+                for (int n = 0; n < cnt[k]; ++n) {
+                    const SphC& q = S.sph[off[k] + n];
+                    if (q.x == m.sph_pos[isph][0] && q.y == m.sph_pos[isph][1] && q.z == m.sph_pos[isph][2]) return off[k] + n;
+                }
+                return -1;
+            };
+            const int sl = slot_of(0, kl, il), sr = slot_of(1, kr, ir);
+            if (sl < 0 || sr < 0) return fail(GRX_ERR_UNSUPPORTED_MODEL, "leg x leg self-collision shape not in the kernel's tables");
+            *sp_mask |= 1ull << ((sl - 8) * 8 + (sr - 8));
         }
     }
     return GRX_OK;
@@ -508,6 +522,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     P.inv_kt = 1.0f / c.contact.kt;
     P.bounce_threshold = c.bounce_threshold_velocity; P.terrain_restitution = c.terrain_restitution;
     P.self_collisions = c.self_collisions;
+    if (const char* sc = getenv("GRX_SELF_COLLISIONS")) P.self_collisions = atoi(sc);   // A/B runs (tools/)
     P.termination_force = c.termination_force; P.termination_gravity_z = c.termination_gravity_z;
     P.max_episode_length = c.max_episode_length; P.max_episode_length_s = c.max_episode_length_s;
     P.resample_command_interval = c.resample_command_interval;
@@ -540,7 +555,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     memcpy(P.forehead_rot, m.forehead_rot, sizeof P.forehead_rot);
     P.has_torso = m.torso_body >= 0; P.has_forehead = m.forehead_body >= 0;
     if (!generic) {
-        rc = build_side_tables(c, s->tab, &P.ll_mask);
+        rc = build_side_tables(c, s->tab, &P.ll_mask, &P.sp_mask);
         if (rc) { delete s; return rc; }
     }
 

@@ -91,6 +91,7 @@ struct KParams {
     const float* coarse_max; int32_t coarse_rows, coarse_cols;   // dilated block-max of the raster [m]: sphere culling
     float bounce_threshold, terrain_restitution;   // legged_robot_config.py:48, :79
     int32_t self_collisions;     // links collide with each other (legged_robot_config.py:121)
+    uint64_t sp_mask;            // bit (a * 8 + b): shape 8 + a of the LEFT lane and shape 8 + b of the RIGHT lane can touch (self-collision)
     uint32_t ll_mask;            // bit (i * 3 + j): the shapes of LEFT chain body 2 + i can touch those of RIGHT chain body 2 + j
     float* restitution;          // [N] per-env shape restitution (legged_robot.py:565-575)
     const int16_t* hf_max4;   // [hf_rows][hf_cols]: max of the four raster corners of cell (i, j) = upper bound of the bilinear

@@ -330,7 +330,8 @@ GRX_DEV void link_contacts(KP P, const SideConst& C, int k, const ChainKin& K, V
 template <bool HF, int W>
 GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                      SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc, const LinkForceOut& lfo,
-                     const RareBuf& RB, int lane, int el, int side) {
+                     const RareBuf& RB, int lane, int el, int side, SelfNear& sn, bool first) {
+    const SelfBuf SB = self_carve(reinterpret_cast<char*>(RB.res));   // the rare contacts' result table is free again by then
     const float dt = P.sim_dt;
     R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
     V3 O = st.pos;
@@ -396,7 +397,8 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
     SelfOut sc;
     {   // self-collision: leg against leg, thigh against base-lump shapes
         const ChainKin KS[3] = {K2, K3, K4};
-        self_collision(P, C, side, R0, st.ang, st.vel, KS, 2.0f * LC.mu - P.terrain_friction, sc);
+        if (first) sn = self_broad_phase(P, C, side, R0, KS);   // wave-uniform
+        self_collision(P, C, SB, lane, side, R0, st.ang, st.vel, KS, 2.0f * LC.mu - P.terrain_friction, sn, sc);
     }
     pA[2] = pA[2] - ro.fa2 - sc.fa[0]; pL[2] = pL[2] - ro.fl2 - sc.fl[0];
     pA[3] = pA[3] - ro.fa3 - sc.fa[1]; pL[3] = pL[3] - ro.fl3 - sc.fl[1];
@@ -1014,8 +1016,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     float* const s_rw = reinterpret_cast<float*>(s_arena + OBS_BYTES + PRI_BYTES);   // reward inputs (wave 0 -> waves 1, 3), W == 4
     // final friction anchors of the step (W == 4: wave 2 -> wave 0 across the barrier that ends the sub-steps): behind the
     // compaction buffers, inside what becomes s_rw only after wave 0 has picked them up
-    static_assert(W != 4 || (PHYS_BYTES >= OBS_BYTES + PRI_BYTES && PHYS_BYTES + 13 * 64 * 4 <= POST_BYTES), "s_anch must sit in the arena's tail");
-    float* const s_anch = reinterpret_cast<float*>(s_arena + PHYS_BYTES);
+    // W == 4, same tail: the foot frames wave 2 publishes for the self-collision on wave 1 (sub-steps only), then s_anch
+    constexpr int FOOTFR_BYTES = RC_FR4 * 64 * 16;
+    static_assert(W != 4 || (PHYS_BYTES >= OBS_BYTES + PRI_BYTES && PHYS_BYTES + FOOTFR_BYTES + 13 * 64 * 4 <= POST_BYTES), "foot frames + s_anch must sit in the arena's tail");
+    float4* const s_footfr = reinterpret_cast<float4*>(s_arena + PHYS_BYTES);
+    float* const s_anch = reinterpret_cast<float*>(s_arena + PHYS_BYTES + FOOTFR_BYTES);
     __shared__ float s_stat[NT + 1];
     __shared__ float s_base[W >= 2 ? 13 * EPB : 1];   // base state at the start of the current sub-step (dynamics -> helpers)
     __shared__ __attribute__((aligned(16))) float s_wr[W == 2 ? 32 * 64 : (W == 4 ? 8 * 64 : 1)];       // base-lump wrench + termination / collision flags (helper -> dynamics)
@@ -1027,7 +1032,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     __shared__ float4 s_wc[W == 4 ? WC4 * 64 : 1];
     __shared__ float4 s_pb[W == 4 ? (LEG * PB4 + 2) * 64 : 1];
     __shared__ uint32_t s_nz[W == 4 ? NZB * 4 * 64 : 1];   // observation-noise Philox blocks (wave 1 -> wave 0)
-    __shared__ float4 s_rr[W == 4 ? 5 * 64 : 1];           // reset_idx's uniform draws (wave 2 -> wave 0)
+    float4* const s_rr = s_ri;   // reset_idx's uniform draws (wave 2 -> wave 0), W == 4: after the sub-steps, over the (then dead) rigid inertias
+    static_assert(W != 4 || LEG * RI4 >= 5, "s_rr aliases s_ri");
+    __shared__ __attribute__((aligned(16))) char s_self[W == 4 ? SELF_BYTES : 16];   // self-collision staging of wave 2 (grx_self.h)
     __shared__ float s_rwp[W == 4 ? 64 : 1];               // partial reward (wave 3 -> wave 1)
     __shared__ float s_hp[W == 4 ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
     __shared__ float s_hsum[W == 4 ? 4 * 64 : 1];          // height scan: partial sums per wave
@@ -1069,7 +1076,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
         LaneState hs;   // W == 4, wave 2: the friction anchors of this lane's foot
         hs.anchor_on = 0;
         if (W == 4) {
-#ifdef GRX_REG_CONSTS
+#if defined(GRX_REG_CONSTS) && GRX_REG_CONSTS >= 2
             const SideConst Ch = C;   // helper waves too: constants in registers
 #define GRX_HELPER_C Ch
 #else
@@ -1087,7 +1094,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
 #pragma unroll
                     for (int b = 0; b < NZB; ++b) { z[(b * 4 + 0) * 64] = nzb[b].x; z[(b * 4 + 1) * 64] = nzb[b].y; z[(b * 4 + 2) * 64] = nzb[b].z; z[(b * 4 + 3) * 64] = nzb[b].w; }
                 }
-                iwave_loop(P, GRX_HELPER_C, bm, bc, bI, L, lane, el);
+                iwave_loop(P, GRX_HELPER_C, RB, s_footfr, self_carve(s_self), P.friction[e], bm, bc, bI, L, lane, el, side);
             } else if (wv == 2) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1096,7 +1103,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                     hs.vimp[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e];   // 0: no contact; else the contact's approach speed
                     if (hs.vimp[i] != 0.0f) hs.anchor_on |= (1u << i);
                 }
-                chain_contact_loop<HF>(P, GRX_HELPER_C, RB, mu, hmax, 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]), hs, L, lane, el, side);
+                chain_contact_loop<HF>(P, GRX_HELPER_C, RB, s_footfr, mu, hmax, 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]), hs, L, lane, el, side);
                 float* a_ = s_anch + lane;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { a_[i * 64] = hs.ax[i]; a_[(4 + i) * 64] = hs.ay[i]; a_[(9 + i) * 64] = hs.vimp[i]; }
@@ -1237,6 +1244,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     float torque[LEG];
     SubstepOut so;
     FootKin fk;
+    SelfNear self_near; self_near.m = 0;   // self-collision broad phase of this policy step (W < 4; with four waves it lives on wave 2)
 #ifdef GRX_REG_CONSTS
     // W == 4: wave 0 has a SIMD's whole register file to itself; its chain's constants live in registers during the
     // sub-steps (every LDS read of a constant is ~64 exposed cycles on a wave that runs alone)
@@ -1273,9 +1281,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
         if (W == 4) substep_p<HF>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc,
-                                  LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N});
+                                  LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N}, C);
         else substep<HF, W>(P, s_tab, C, LC, st, torque, so, fk, s_wr + lane, tacc,
-                            LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side);
+                            LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side, self_near, deci == 0);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
             avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
         }

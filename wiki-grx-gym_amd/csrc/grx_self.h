@@ -59,24 +59,41 @@ GRX_DEV bool sphere_pair(KP P, const SphW& a, const SphW& b, float mu, V3& F, V3
     return true;
 }
 
-// K[0..2]: frames of this lane's chain bodies 2, 3, 4.  Must be called by all 64 lanes in wave-uniform control flow.
-GRX_DEV void self_collision(KP P, const SideConst& C, int side, const R3& R0, V3 ang, V3 vel, const ChainKin K[3], float mu, SelfOut& o) {
-    const V3 zero = v3(0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { o.fa[i] = zero; o.fl[i] = zero; }
-    o.f0a = zero; o.f0l = zero; o.fbase[0] = zero; o.fbase[1] = zero;
-    if (!P.self_collisions) return;
-    // ---- broad phase: bounding spheres of the three shape-carrying bodies of either leg
+// ---- leg x leg: compacted over the wave ------------------------------------------------------------------------------
+// Legs rarely touch, but with 32 envs per wave SOME env's legs usually are close: evaluated lane by lane, the 52 sphere
+// pairs of a leg pair would run on all 64 lanes whenever one env needs them (measured: 7 k cycles per sub-step, +60 % on
+// the launch).  Instead:
+//   policy step:  bounding spheres of the shape-carrying bodies, with a margin for the motion over the decimation
+//                 -> SelfNear (per env: can the legs meet at all; which base-lump / thigh entries are near)
+//   sub-step:     separating-plane test along the base's lateral axis (left leg's innermost extent vs the right leg's):
+//                 legs side by side, as in every sane gait, stop here
+//   candidates:   the envs that pass, eight at a time: their two lanes stage their 8 + 8 spheres (centre, radius,
+//                 velocity, damping cap) in LDS; the wave's 64 lanes then test the sphere pairs of those envs -- 8 lanes
+//                 per env, 7 pairs per lane -- and OR the overlapping ones into a 64-bit mask per env (order-free);
+//                 the env's two lanes walk the set bits in ascending order, each computing the force on ITS sphere
+//                 (bit-for-bit opposite in the two lanes: see the contact law above)
+struct SelfNear { uint32_t m; };   // bit 0: the legs' bounding spheres can meet during this policy step; bits 16..23: base-lump / thigh entries
+constexpr float kSelfMargin = 0.10f;   // 5 m/s of closing speed over the 0.02 s of a policy step
+constexpr int SELF_GROUP = 8;          // candidate envs per round
+constexpr int SELF_ST_BYTES = SELF_GROUP * 16 * 2 * 16, SELF_BYTES = SELF_ST_BYTES + SELF_GROUP * 8;
+struct SelfBuf { float4* st; unsigned long long* mask; };   // st[cand][side * 8 + shape][2]: (c.xyz, r) (u.xyz, dmax)
+GRX_DEV SelfBuf self_carve(char* p) { SelfBuf b; b.st = reinterpret_cast<float4*>(p); b.mask = reinterpret_cast<unsigned long long*>(p + SELF_ST_BYTES); return b; }
+
+GRX_DEV V3 sph_centre(const SphC& S, const ChainKin& K) { return K.rho + rot(K.R, v3(S.x, S.y, S.z)); }
+GRX_DEV V3 v3_swap(V3 a) { return v3(pair_swap(a.x), pair_swap(a.y), pair_swap(a.z)); }
+
+GRX_DEV SelfNear self_broad_phase(KP P, const SideConst& C, int side, const R3& R0, const ChainKin K[3]) {
+    SelfNear sn; sn.m = 0;
+    if (!P.self_collisions) return sn;
     V3 bc[3], oc[3];
     float br[3], orr[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         bc[i] = K[i].rho + rot(K[i].R, v3(C.bs[i][0], C.bs[i][1], C.bs[i][2]));
         br[i] = C.bs[i][3];
-        oc[i] = v3(pair_swap(bc[i].x), pair_swap(bc[i].y), pair_swap(bc[i].z));
+        oc[i] = v3_swap(bc[i]);
         orr[i] = pair_swap(br[i]);
     }
-    uint32_t near = 0;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -84,54 +101,154 @@ GRX_DEV void self_collision(KP P, const SideConst& C, int side, const R3& R0, V3
             const int bit_l = i * 3 + j, bit_r = j * 3 + i;   // the mask is indexed (left body, right body)
             const bool feasible = (P.ll_mask >> (side == 0 ? bit_l : bit_r)) & 1u;
             const V3 d = bc[i] - oc[j];
-            const float R = br[i] + orr[j];
-            if (feasible && dot(d, d) < R * R) near |= 1u << (i * 3 + j);
+            const float R = br[i] + orr[j] + kSelfMargin;
+            if (feasible && dot(d, d) < R * R) sn.m |= 1u;   // (the same verdict in both lanes of the env: symmetric arithmetic)
         }
-    // ---- narrow phase, body pair by body pair (wave-uniform skips)
-    if (__any(near != 0u)) {
-        constexpr int cnt[3] = {2, 2, 4}, off[3] = {8, 10, 12};
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            uint32_t row = (near >> (i * 3)) & 7u;
-            if (!__any(row != 0u)) continue;
-            SphW mine[4];
+    for (int e = 0; e < GRX_MAX_BC; ++e) {
+        if (!__any(e < C.nbc)) break;
+        if (e < C.nbc) {
+            const BaseChainPair& q = C.bc[e];
+            const V3 d = bc[0] - rot(R0, v3(q.x, q.y, q.z));
+            const float R = br[0] + q.r + kSelfMargin;
+            if (dot(d, d) < R * R) sn.m |= 1u << (16 + e);
+        }
+    }
+    return sn;
+}
+
+// K[0..2]: frames of this lane's chain bodies 2, 3, 4; sn:
+// this policy step's broad phase.  Must be called by all 64 lanes in wave-uniform control flow.
+GRX_DEV void self_collision(KP P, const SideConst& C, const SelfBuf& SB, int lane, int side, const R3& R0, V3 ang, V3 vel,
+                            const ChainKin K[3], float mu, const SelfNear& sn, SelfOut& o, long long* pacc = nullptr) {
+    const V3 zero = v3(0.f, 0.f, 0.f);
 #pragma unroll
-            for (int a = 0; a < cnt[i]; ++a) mine[a] = sph_world(C.sph[off[i] + a], K[i]);
+    for (int i = 0; i < 3; ++i) { o.fa[i] = zero; o.fl[i] = zero; }
+    o.f0a = zero; o.f0l = zero; o.fbase[0] = zero; o.fbase[1] = zero;
+    if (!__any(sn.m != 0u)) return;
+#ifdef GRX_PROFILE_SECTIONS
+    long long pdummy[8]; if (!pacc) pacc = pdummy;
+    const long long t0_ = clock64();
+#endif
+    constexpr int cnt[3] = {2, 2, 4}, off[3] = {8, 10, 12};
+    // ---- leg x leg
+    if (__any((sn.m & 1u) != 0u)) {
+        // separating plane along the base's lateral axis: this leg's extent towards the other one
+        const V3 yb = R0.cy;
+        float ext = side == 0 ? 1e30f : -1e30f;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                // the partner lane must take part in the exchange: its (j, i) bit is this lane's (i, j) bit seen from the other side
-                const bool pair_near = (near >> (i * 3 + j)) & 1u;
-                if (!__any(pair_near)) continue;
-                // other leg's body j shapes: computed by the partner as ITS body j, fetched by pair_swap
-                SphW theirs[4];
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int b = 0; b < cnt[j]; ++b) theirs[b] = sph_swap(sph_world(C.sph[off[j] + b], K[j]));
-                if (pair_near) {
+            for (int a = 0; a < cnt[i]; ++a) {
+                const SphC& S = C.sph[off[i] + a];
+                const float y = dot(sph_centre(S, K[i]), yb);
+                ext = side == 0 ? fminf(ext, y - S.r) : fmaxf(ext, y + S.r);   // left leg (+y side): its lowest y; right leg: its highest
+            }
+#ifdef GRX_PROFILE_SECTIONS
+        long long tp_ = clock64(); pacc[4] += tp_ - t0_;   // centres + extents
+#endif
+        const float oext = pair_swap(ext);
+        const bool cand = (sn.m & 1u) && (side == 0 ? ext <= oext : oext <= ext);   // not separated (same verdict in both lanes)
+        const unsigned long long cb = __ballot(cand && side == 0);
+#ifdef GRX_PROFILE_SECTIONS
+        pacc[1] += __popcll(cb);
+#endif
+        if (cb) {
+            const int rank = __popcll(cb & ((1ull << (lane & ~1)) - 1ull));   // candidate envs before this lane's env (same in both its lanes)
+            const int ncand = __popcll(cb);
+            for (int g0 = 0; g0 < ncand; g0 += SELF_GROUP) {
+                const bool mine = cand && rank >= g0 && rank < g0 + SELF_GROUP;   // both lanes of the env
+                const int cslot = rank - g0;
+                if (mine) {   // stage this lane's 8 spheres
 #pragma unroll
-                    for (int a = 0; a < cnt[i]; ++a)
+                    for (int i = 0; i < 3; ++i)
 #pragma unroll
-                        for (int b = 0; b < cnt[j]; ++b) {
-                            V3 F, pw;
-                            if (sphere_pair(P, mine[a], theirs[b], mu, F, pw)) { o.fa[i] = o.fa[i] + cross(pw, F); o.fl[i] = o.fl[i] + F; }
+                        for (int a = 0; a < cnt[i]; ++a) {
+                            const SphC& S = C.sph[off[i] + a];
+                            const V3 c = sph_centre(S, K[i]), u = K[i].v + cross(K[i].w, c);   // (candidates only: recomputed rather than kept)
+                            float4* d = SB.st + ((cslot * 16 + side * 8 + (off[i] - 8 + a)) * 2);
+                            d[0] = rc4(c.x, c.y, c.z, S.r); d[1] = rc4(u.x, u.y, u.z, S.dmax);
                         }
+                    if (side == 0) SB.mask[cslot] = 0ull;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef GRX_PROFILE_SECTIONS
+                { const long long t_ = clock64(); pacc[5] += t_ - tp_; tp_ = t_; }   // ballot, rank, staging
+#endif
+                {   // all 64 lanes: 8 lanes per candidate env; lane `sub` tests the right leg's shape `sub` against the
+                    // left leg's eight (pair id = left shape * 8 + right shape; P.sp_mask: the pairs the model lists)
+                    const int ws_ = lane >> 3, sub = lane & 7;
+                    unsigned long long bits = 0ull;
+                    if (g0 + ws_ < ncand) {
+                        const float4* stc = SB.st + ws_ * 32;
+                        const float4 b = stc[(8 + sub) * 2];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const float4 a = stc[t * 2];
+                            const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, Rs = a.w + b.w;
+                            if (dx * dx + dy * dy + dz * dz < Rs * Rs) bits |= 1ull << (t * 8 + sub);
+                        }
+                        bits &= P.sp_mask;
+                        if (bits) __hip_atomic_fetch_or(SB.mask + ws_, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                unsigned long long hm = mine ? SB.mask[cslot] : 0ull;
+#ifdef GRX_PROFILE_SECTIONS
+                { const long long t_ = clock64(); pacc[6] += t_ - tp_; tp_ = t_; }   // pair tests
+#endif
+#ifdef GRX_PROFILE_SECTIONS
+                pacc[2] += __popcll(__ballot(hm != 0ull)); pacc[3] += 1;
+#endif
+                while (__any(hm != 0ull)) {   // overlapping pairs of this lane's env, ascending
+                    if (hm) {
+                        const int pid = __ffsll((long long)hm) - 1;
+                        hm &= hm - 1ull;
+                        const int sa = pid >> 3, sb_ = pid & 7;      // left shape, right shape
+                        const int ms = side == 0 ? sa : sb_, os = side == 0 ? sb_ : sa;   // mine, the other leg's
+                        const float4* stc = SB.st + cslot * 32;
+                        const float4 m0 = stc[(side * 8 + ms) * 2], m1 = stc[(side * 8 + ms) * 2 + 1];
+                        const float4 o0 = stc[((side ^ 1) * 8 + os) * 2], o1 = stc[((side ^ 1) * 8 + os) * 2 + 1];
+                        SphW ma, ob;
+                        ma.c = v3(m0.x, m0.y, m0.z); ma.r = m0.w; ma.u = v3(m1.x, m1.y, m1.z); ma.dmax = m1.w;
+                        ob.c = v3(o0.x, o0.y, o0.z); ob.r = o0.w; ob.u = v3(o1.x, o1.y, o1.z); ob.dmax = o1.w;
+                        V3 F, pw;
+                        if (sphere_pair(P, ma, ob, mu, F, pw)) {
+                            const V3 Tq = cross(pw, F);
+                            const int kb = ms < 2 ? 0 : (ms < 4 ? 1 : 2);   // chain body 2 + kb carries my shape
+                            if (kb == 0) { o.fa[0] = o.fa[0] + Tq; o.fl[0] = o.fl[0] + F; }
+                            else if (kb == 1) { o.fa[1] = o.fa[1] + Tq; o.fl[1] = o.fl[1] + F; }
+                            else { o.fa[2] = o.fa[2] + Tq; o.fl[2] = o.fl[2] + F; }
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the staging rows are rewritten by the next group
+#ifdef GRX_PROFILE_SECTIONS
+                { const long long t_ = clock64(); pacc[7] += t_ - tp_; tp_ = t_; }   // forces
+#endif
             }
         }
     }
     // ---- base-lump shapes x this lane's thigh shapes
-    if (__any(C.nbc > 0)) {
-        const SphW t0 = sph_world(C.sph[8], K[0]), t1 = sph_world(C.sph[9], K[0]);
+    if (__any((sn.m >> 16) != 0u)) {
         const ChainKin KB = {R0, zero, ang, vel};
+        const V3 c0 = sph_centre(C.sph[8], K[0]), c1 = sph_centre(C.sph[9], K[0]);
         int prev_link = -1, slot = -1;
 #pragma unroll
         for (int e = 0; e < GRX_MAX_BC; ++e) {
             if (!__any(e < C.nbc)) break;
             const BaseChainPair& q = C.bc[e];
-            if (e < C.nbc) {
-                if (q.link != prev_link) { prev_link = q.link; ++slot; }
-                SphC sb; sb.x = q.x; sb.y = q.y; sb.z = q.z; sb.r = q.r; sb.dmax = q.dmax;
+            const bool mine = e < C.nbc;
+            if (mine && q.link != prev_link) { prev_link = q.link; ++slot; }
+            if (!__any((sn.m >> (16 + e)) & 1u)) continue;
+            SphC sb; sb.x = q.x; sb.y = q.y; sb.z = q.z; sb.r = q.r; sb.dmax = q.dmax;
+            const V3 d = (q.tsel ? c1 : c0) - rot(R0, v3(q.x, q.y, q.z));
+            const float Rs = q.r + (q.tsel ? C.sph[9].r : C.sph[8].r);
+            const bool hit = mine && ((sn.m >> (16 + e)) & 1u) && dot(d, d) < Rs * Rs;
+            if (!__any(hit)) continue;
+            if (hit) {
                 const SphW b = sph_world(sb, KB);
-                const SphW& t = q.tsel ? t1 : t0;
+                const SphW t = sph_world(q.tsel ? C.sph[9] : C.sph[8], K[0]);
                 V3 F, pw;
                 if (sphere_pair(P, t, b, mu, F, pw)) {
                     o.fa[0] = o.fa[0] + cross(pw, F); o.fl[0] = o.fl[0] + F;
@@ -141,6 +258,9 @@ GRX_DEV void self_collision(KP P, const SideConst& C, int side, const R3& R0, V3
             }
         }
     }
+#ifdef GRX_PROFILE_SECTIONS
+    pacc[0] += clock64() - t0_;
+#endif
 }
 
 // URDF link of the base-lump shape behind o.fbase[s] (-1: none)

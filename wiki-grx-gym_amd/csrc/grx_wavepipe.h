@@ -47,7 +47,7 @@
 #define GRX_WAIT(f, want, slot) flag_wait(f, want)
 #endif
 
-enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_REW = 6, FL_RI = 7, FL_BASEBIAS = 8, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_RR = 15, FL_COUNT = 16 };
+enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_SELF = 9, FL_REW = 6, FL_RI = 7, FL_BASEBIAS = 8, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_RR = 15, FL_COUNT = 16 };
 // Every record is laid out [quad][lane] in float4 units, so a lane moves it with ds_read_b128 / ds_write_b128: the
 // kernel runs at one instruction issue per ~5 cycles whatever the instruction, and the records are ~350 dwords per
 // lane and sub-step on wave 0 alone -- four dwords per LDS instruction instead of one is ~1.3k cycles per sub-step.
@@ -109,7 +109,7 @@ GRX_DEV void add_rigid(S3& A, M3& B, S3& D, const S3& Ak, V3 h, float m) {
 template <bool HF>
 GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                        SubstepOut& out, FootKin& fk_before, const PipeLds& L, const RareBuf& RB, int lane, int seq, long long* tacc,
-                       const LinkForceOut& lfo) {
+                       const LinkForceOut& lfo, const SideConst& Clds) {   // Clds: the LDS copy of C (tables read once per policy step)
     const float dt = P.sim_dt;
 #ifdef GRX_PROFILE_SECTIONS
     long long tprev = clock64();
@@ -170,8 +170,8 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         const float qdk = st.qd[k];
         // joint-limit spring/damper (oracle substep()): added to the motor torque
         float t = tau_m[k];
-        if (st.q[k] < C.body[k].qlo) t += C.body[k].Klim * (C.body[k].qlo - st.q[k]) - C.body[k].Clim * qdk;
-        else if (st.q[k] > C.body[k].qhi) t += C.body[k].Klim * (C.body[k].qhi - st.q[k]) - C.body[k].Clim * qdk;
+        if (st.q[k] < Clds.body[k].qlo) t += Clds.body[k].Klim * (Clds.body[k].qlo - st.q[k]) - Clds.body[k].Clim * qdk;
+        else if (st.q[k] > Clds.body[k].qhi) t += Clds.body[k].Klim * (Clds.body[k].qhi - st.q[k]) - Clds.body[k].Clim * qdk;
         const float u = t - (dot(Sa[k], pa) + dot(Ss[k], pl));
         const float ud = u * di;
         V3 npa = pa + mul(A, ca[k]) + mul(B, cl[k]) + ua * ud;
@@ -182,7 +182,8 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     // ---- contact wrenches on chain bodies 4 (foot), 3 (shank), 2 (thigh): delta recursion  dp -> dp + U (-S.dp)/d
     GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
     GRX_WAIT(L.flag + FL_LEGS, seq + 1, 2);
-    SelfOut sc;   // self-collision wrenches (wave 2)
+    GRX_WAIT(L.flag + FL_SELF, seq + 1, 3);
+    SelfOut sc;   // self-collision wrenches (wave 1, after its recursion)
     {
         const float4* c = L.wc + 7 * 64 + lane;
         const float4 s0 = c[0 * 64], s1 = c[1 * 64], s2 = c[2 * 64], s3 = c[3 * 64], s4 = c[4 * 64], s5 = c[5 * 64], s6 = c[6 * 64], s7 = c[7 * 64];
@@ -225,7 +226,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         const float2* r = RB.res + lane;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const float2 a = r[(2 * i) * 64], b = r[(2 * i + 1) * 64]; lf[i] = v3(a.x, a.y, b.x); }
-        write_link_rows(lfo, C, lf, flt[0], flt[1], flt[2], sc);
+        write_link_rows(lfo, Clds, lf, flt[0], flt[1], flt[2], sc);
     }
     pa = pair_sum(pa); pl = pair_sum(pl);
     {   // base-lump bias force (wave 3; both lanes of the pair add the same value after the pair sum)
@@ -262,7 +263,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
         float vq = fmaf(qdd[k], dt, st.qd[k]);
-        vq = fminf(fmaxf(vq, -C.body[k].vlim), C.body[k].vlim);
+        vq = fminf(fmaxf(vq, -Clds.body[k].vlim), Clds.body[k].vlim);
         st.qd[k] = vq;
         st.q[k] = fmaf(vq, dt, st.q[k]);
     }
@@ -282,9 +283,15 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 
 // ---------------------------------------------------------------------------------------------------------------
 // wave 1: inertia half of the articulated-body recursion for every sub-step of the policy step
-GRX_DEV void iwave_loop(KP P, const SideConst& C, float base_m, V3 base_c, const S3& base_I, const PipeLds& L,
-                        int lane, int el) {
+GRX_DEV void iwave_loop(KP P, const SideConst& C, const RareBuf& RB, const float4* footfr, const SelfBuf& SB, float mu_self, float base_m, V3 base_c, const S3& base_I, const PipeLds& L,
+                        int lane, int el, int side) {
     GRX_HELPER_PROF_BEGIN;
+    SelfNear sn; sn.m = 0;   // self-collision broad phase of this policy step
+#ifdef GRX_PROFILE_SECTIONS
+    long long sacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+    long long* sacc = nullptr;
+#endif
     for (int seq = 0; seq < P.decimation; ++seq) {
         GRX_HELPER_PROF_IDLE0;
         flag_wait(L.flag + FL_STATE, seq + 1);
@@ -339,14 +346,41 @@ GRX_DEV void iwave_loop(KP P, const SideConst& C, float base_m, V3 base_c, const
             r0[5 * 64] = f4(B.a22, 0.f, 0.f, 0.f);
         }
         flag_set(L.flag + FL_I, seq * 8 + LEG + 1, lane);
+        {   // this wave is idle from here to the next sub-step: self-collision (grx_self.h) -- leg against leg (the partner lane
+            // is one DPP step away), thigh against base-lump shapes -- on the chain frames wave 2 published
+            const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+            flag_wait(L.flag + FL_FRAMES, seq + 1);
+            ChainKin KS[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const RareFrame f = rare_load_frame(i < 2 ? RB.fchain + i * RC_FR4 * 64 + lane : footfr + lane, 64);
+                KS[i].R = f.R; KS[i].rho = f.rho; KS[i].w = f.w; KS[i].v = f.v;
+            }
+            if (seq == 0) sn = self_broad_phase(P, C, side, R0, KS);
+            SelfOut sc;
+            self_collision(P, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc);
+            float4* o = L.wc + 7 * 64 + lane;
+            o[0 * 64] = f4(sc.fa[0].x, sc.fa[0].y, sc.fa[0].z, sc.fl[0].x);
+            o[1 * 64] = f4(sc.fl[0].y, sc.fl[0].z, sc.fa[1].x, sc.fa[1].y);
+            o[2 * 64] = f4(sc.fa[1].z, sc.fl[1].x, sc.fl[1].y, sc.fl[1].z);
+            o[3 * 64] = f4(sc.fa[2].x, sc.fa[2].y, sc.fa[2].z, sc.fl[2].x);
+            o[4 * 64] = f4(sc.fl[2].y, sc.fl[2].z, sc.f0a.x, sc.f0a.y);
+            o[5 * 64] = f4(sc.f0a.z, sc.f0l.x, sc.f0l.y, sc.f0l.z);
+            o[6 * 64] = f4(sc.fbase[0].x, sc.fbase[0].y, sc.fbase[0].z, sc.fbase[1].x);
+            o[7 * 64] = f4(sc.fbase[1].y, sc.fbase[1].z, 0.f, 0.f);
+            flag_set(L.flag + FL_SELF, seq + 1, lane);
+        }
     }
     GRX_HELPER_PROF_END(1);
+#ifdef GRX_PROFILE_SECTIONS
+    if (lane == 0) for (int i = 0; i < 8; ++i) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 40 + i] = sacc[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // wave 2: own walk with velocities; thigh / shank frames for wave 3; the anchored foot spheres
 template <bool HF>
-GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, float mu, float hmax, float om_e, LaneState& hs, const PipeLds& L,
+GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, float4* footfr, float mu, float hmax, float om_e, LaneState& hs, const PipeLds& L,
                                 int lane, int el, int side) {
     GRX_HELPER_PROF_BEGIN;
     for (int seq = 0; seq < P.decimation; ++seq) {
@@ -383,7 +417,8 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
             K.w = fma3(a, qdk, wp); K.v = fma3(s, qdk, vp);
             KK[k] = K;
             if (k == 2) rare_store_frame(RB.fchain + lane, 64, K.R, K.rho, K.w, K.v);                  // thigh
-            if (k == 3) { rare_store_frame(RB.fchain + RC_FR4 * 64 + lane, 64, K.R, K.rho, K.w, K.v);   // shank
+            if (k == 3) rare_store_frame(RB.fchain + RC_FR4 * 64 + lane, 64, K.R, K.rho, K.w, K.v);    // shank
+            if (k == 4) { rare_store_frame(footfr + lane, 64, K.R, K.rho, K.w, K.v);   // foot (self-collision, wave 1)
                           flag_set(L.flag + FL_FRAMES, seq + 1, lane); }
         }
 #pragma unroll
@@ -408,21 +443,7 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
             c_[5 * 64] = f4(fl.y, fl.z, fv.x, fv.y);
             c_[6 * 64] = f4(fv.z, 0.f, 0.f, 0.f);
         }
-        {   // self-collision: leg against leg (the partner lane is one DPP step away), thigh against base-lump shapes
-            SelfOut sc;
-            const ChainKin KS[3] = {KK[2], KK[3], K};
-            self_collision(P, C, side, R0, ang, vel, KS, 2.0f * mu - P.terrain_friction, sc);
-            float4* o = L.wc + 7 * 64 + lane;
-            o[0 * 64] = f4(sc.fa[0].x, sc.fa[0].y, sc.fa[0].z, sc.fl[0].x);
-            o[1 * 64] = f4(sc.fl[0].y, sc.fl[0].z, sc.fa[1].x, sc.fa[1].y);
-            o[2 * 64] = f4(sc.fa[1].z, sc.fl[1].x, sc.fl[1].y, sc.fl[1].z);
-            o[3 * 64] = f4(sc.fa[2].x, sc.fa[2].y, sc.fa[2].z, sc.fl[2].x);
-            o[4 * 64] = f4(sc.fl[2].y, sc.fl[2].z, sc.f0a.x, sc.f0a.y);
-            o[5 * 64] = f4(sc.f0a.z, sc.f0l.x, sc.f0l.y, sc.f0l.z);
-            o[6 * 64] = f4(sc.fbase[0].x, sc.fbase[0].y, sc.fbase[0].z, sc.fbase[1].x);
-            o[7 * 64] = f4(sc.fbase[1].y, sc.fbase[1].z, 0.f, 0.f);
-        }
-        flag_set(L.flag + FL_FOOT, seq + 1, lane);   // foot contact wrench + self-collision wrenches
+        flag_set(L.flag + FL_FOOT, seq + 1, lane);
     }
     GRX_HELPER_PROF_END(2);
 }
