@@ -1026,20 +1026,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     __shared__ __attribute__((aligned(16))) float s_wr[W == 2 ? 32 * 64 : (W == 4 ? 8 * 64 : 1)];       // base-lump wrench + termination / collision flags (helper -> dynamics)
     // W == 4 pipeline buffers (grx_wavepipe.h)
     __shared__ float4 s_q[W == 4 ? Q4 * 64 : 1];
-    __shared__ float4 s_ri[W == 4 ? LEG * RI4 * 64 : 1];
-    __shared__ float4 s_rec[W == 4 ? LEG * REC4 * 64 : 1];
-    __shared__ float4 s_rec0[W == 4 ? REC04 * 64 : 1];
     __shared__ float4 s_wc[W == 4 ? WC4 * 64 : 1];
     __shared__ float4 s_pb[W == 4 ? (LEG * PB4 + 2) * 64 : 1];
     __shared__ uint32_t s_nz[W == 4 ? NZB * 4 * 64 : 1];   // observation-noise Philox blocks (wave 1 -> wave 0)
-    float4* const s_rr = s_ri;   // reset_idx's uniform draws (wave 2 -> wave 0), W == 4: after the sub-steps, over the (then dead) rigid inertias
-    static_assert(W != 4 || LEG * RI4 >= 5, "s_rr aliases s_ri");
+    __shared__ float4 s_rr[W == 4 ? 5 * 64 : 1];           // reset_idx's uniform draws (wave 2 -> wave 0)
     __shared__ __attribute__((aligned(16))) char s_self[W == 4 ? SELF_BYTES : 16];   // self-collision staging of wave 2 (grx_self.h)
     __shared__ float s_rwp[W == 4 ? 64 : 1];               // partial reward (wave 3 -> wave 1)
     __shared__ float s_hp[W == 4 ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
     __shared__ float s_hsum[W == 4 ? 4 * 64 : 1];          // height scan: partial sums per wave
     __shared__ int s_flag[FL_COUNT];
-    const PipeLds L = {s_base, s_q, s_ri, s_rec, s_rec0, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag};
+    const PipeLds L = {s_base, s_q, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag};
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const RareBuf RB = rare_carve(s_arena + (W == 2 && wv == 1 ? RC_BYTES : 0));   // W == 4: only wave 3 evaluates rare contacts
@@ -1094,7 +1090,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
 #pragma unroll
                     for (int b = 0; b < NZB; ++b) { z[(b * 4 + 0) * 64] = nzb[b].x; z[(b * 4 + 1) * 64] = nzb[b].y; z[(b * 4 + 2) * 64] = nzb[b].z; z[(b * 4 + 3) * 64] = nzb[b].w; }
                 }
-                iwave_loop(P, GRX_HELPER_C, RB, s_footfr, self_carve(s_self), P.friction[e], bm, bc, bI, L, lane, el, side);
+                self_loop(P, GRX_HELPER_C, RB, s_footfr, self_carve(s_self), P.friction[e], L, lane, el, side);
             } else if (wv == 2) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {

@@ -7,19 +7,19 @@
 // same leg of the same env), partitioned so that the four chains end together (round 2 balance, cycles per sub-step
 // on rough terrain in brackets):
 //
-//   wave 0  owner of the state: motor torques; outward walk (positions) and the rigid inertias about O, leaf first,
-//            for wave 1; then the BIAS half of the
-//            articulated-body recursion (leaf -> root) on the records wave 1 has ready by then [1.1 k]; contact
-//            wrenches by delta recursion, floating-base solve, acceleration pass, integration [1.6 k] -- and the rest
-//            of env.step()
-//   wave 1  "I": the INERTIA half of the recursion (U, 1/d, rank-1 updates) as the rigid inertias arrive; one record
-//            per joint back to wave 0; finally the factorised base-level 6x6 [done at ~5 k]
-//   wave 2  own walk with velocities; publishes the thigh / shank frames for wave 3; rigid-body bias forces and
+//   wave 0  owner of the state: motor torques; outward walk (positions); the whole inward recursion -- rigid inertias,
+//            articulated inertias, bias forces -- in one pass, fed with the rigid-body bias forces of wave 2; contact
+//            wrenches by delta recursion, floating-base solve, acceleration pass, integration -- and the rest of env.step()
+//   wave 1  self-collision (grx_self.h) on the chain frames wave 2 publishes: leg x leg (the partner lane is one DPP
+//            step away), thigh x base-lump shapes
+//   wave 2  own walk with velocities; publishes the thigh / shank / foot frames; rigid-body bias forces and
 //            velocity-product accelerations of the chain, leaf first, for wave 0; the 4 anchored foot spheres (it owns
 //            the friction anchors)
 //   wave 3  the base lump's bias force; the seldom-touching shapes (base lump, thigh, shank), lane-compacted
-//            (grx_rare.h) [4-5.5 k]
+//            (grx_rare.h)
 //
+// (Rounds 1 and early 2 ran the inertia half of the recursion on wave 1, streaming joint records to wave 0: that hid
+// ~1.7 k cycles of a ~9 k chain at the price of a wave; the self-collision of round 2 needs that wave more.)
 // Round 1 had wave 2 evaluate the thigh shapes as well and wave 3 loop over all its base-lump and shank shapes
 // whenever one env of the wave had any within reach (7 k cycles per sub-step): wave 0 waited 45 % of every sub-step.
 //
@@ -42,19 +42,24 @@
 #endif
 
 #ifdef GRX_PROFILE_SECTIONS
+// timeline of sub-step 5: event stamps in slots 48.. of the block's row (tools/gpu_sections.py prints them relative to EV 0)
+#define GRX_EV(i) do { if (seq == 5 && lane == 0) { __builtin_amdgcn_sched_barrier(0); P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 48 + (i)] = clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define GRX_EV(i) do {} while (0)
+#endif
+// keep a value's computation ABOVE this point (an empty asm the compiler must feed)
+#define GRX_PIN(x) asm volatile("" : "+v"(x))
+#ifdef GRX_PROFILE_SECTIONS
 #define GRX_WAIT(f, want, slot) do { long long w0_ = clock64(); flag_wait(f, want); tacc[slot] += clock64() - w0_; } while (0)
 #else
 #define GRX_WAIT(f, want, slot) flag_wait(f, want)
 #endif
 
-enum { FL_STATE = 0, FL_I = 1, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_SELF = 9, FL_REW = 6, FL_RI = 7, FL_BASEBIAS = 8, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_RR = 15, FL_COUNT = 16 };
+enum { FL_STATE = 0, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_SELF = 9, FL_REW = 6, FL_BASEBIAS = 8, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_RR = 15, FL_COUNT = 16 };
 // Every record is laid out [quad][lane] in float4 units, so a lane moves it with ds_read_b128 / ds_write_b128: the
 // kernel runs at one instruction issue per ~5 cycles whatever the instruction, and the records are ~350 dwords per
 // lane and sub-step on wave 0 alone -- four dwords per LDS instruction instead of one is ~1.3k cycles per sub-step.
-constexpr int REC4 = 7;   // quads per joint record: ua 3, ul 3, 1/d, A' 6, B' 9, D' 6  (28 floats)
-constexpr int RI4 = 4;    // quads per chain body from wave 0: rigid inertia about O (A 6, h 3), joint axis Sa 3, Ss 3  (15 floats)
-constexpr int PB4 = 3;    // quads per chain body from wave 2: rigid-body bias force pa 3, pl 3, velocity-product acceleration ca 3, cl 3
-constexpr int REC04 = 6;  // factorised base-level articulated inertia: inv(D) 6, inv(Schur) 6, B 9  (21 floats)
+constexpr int PB4 = 2;    // quads per chain body from wave 2: rigid-body bias force pa 3, pl 3
 constexpr int WC4 = 15;   // contact wrenches about O: thigh quads 0-1, shank 2-3, foot 4-6 (wrench 6 + foot link velocity 3);
                           // quads 7-14: self-collision (grx_self.h) on thigh, shank, foot, base lump + the forces on base-lump links
 constexpr int Q4 = 3;     // q 5, qd 5 of the lane's leg
@@ -62,9 +67,6 @@ constexpr int Q4 = 3;     // q 5, qd 5 of the lane's leg
 struct PipeLds {
     float* base;   // [13][EPB]   base state at the start of the sub-step
     float4* q;     // [Q4][64]    q, qd of every lane's leg
-    float4* ri;    // [LEG][RI4][64] rigid inertias + joint axes (wave 0 -> I wave), leaf first
-    float4* rec;   // [LEG][REC4][64] joint records of the I wave
-    float4* rec0;  // [REC04][64]
     float4* wc;    // [WC4][64]
     float4* pb;    // [LEG][PB4][64] + [2][64]: chain-body bias forces / accelerations (wave 2, leaf first), base-lump bias force (wave 3)
     float4* wr;    // [2][64]     base-lump wrench, termination flag, collision count
@@ -116,56 +118,84 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 #endif
     V3 Sa[LEG], Ss[LEG], ca[LEG], cl[LEG], Ua[LEG], Ul[LEG];
     float dinv[LEG], uu[LEG];
-    // ---- outward walk (positions only) + rigid inertias about O, leaf first, for the I wave: this wave has nothing
-    // else to do until the first records come back
+    GRX_EV(0);
+    // ---- outward walk with velocities: joint motion subspaces S = (a; rho x a), velocity-product accelerations and rigid
+    // inertias about O of the chain bodies
+    S3 AK[LEG];
+    V3 hK[LEG];
+    const R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
     {
-        R3 RK[LEG];
-        V3 rhoK[LEG];
-        R3 R = quat_to_R(st.qx, st.qy, st.qz, st.qw);
-        V3 rho = v3(0.f, 0.f, 0.f);
+        R3 R = R0;
+        V3 rho = v3(0.f, 0.f, 0.f), w = st.ang, v = st.vel;
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {
+            const float qdk = st.qd[k];
             rho = rho + rot(R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
             float sn, cs;
             grx_sincos(st.q[k], sn, cs);
             R = joint_rot_k(R, cs, sn, kAxis[k]);
-            Sa[k] = axis_k(R, kAxis[k]);
-            Ss[k] = cross(rho, Sa[k]);
-            RK[k] = R; rhoK[k] = rho;
-        }
-#pragma unroll
-        for (int k = LEG - 1; k >= 0; --k) {
-            const V3 kap = rhoK[k] + rot(RK[k], v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
-            const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
-            S3 Ak; V3 hk;
-            rigid_inertia(RK[k], kap, C.body[k].mass, Ic, Ak, hk);
-            float4* o = L.ri + (k * RI4) * 64 + lane;
-            o[0 * 64] = f4(Ak.xx, Ak.xy, Ak.xz, Ak.yy);
-            o[1 * 64] = f4(Ak.yz, Ak.zz, hk.x, hk.y);
-            o[2 * 64] = f4(hk.z, Sa[k].x, Sa[k].y, Sa[k].z);
-            o[3 * 64] = f4(Ss[k].x, Ss[k].y, Ss[k].z, 0.f);
-            flag_set(L.flag + FL_RI, seq * 8 + (LEG - k), lane);
+            const V3 a = axis_k(R, kAxis[k]);
+            const V3 s_ = cross(rho, a);
+            Sa[k] = a; Ss[k] = s_;
+            ca[k] = cross(w, a) * qdk;
+            cl[k] = (cross(v, a) + cross(w, s_)) * qdk;
+            w = fma3(a, qdk, w); v = fma3(s_, qdk, v);
+            const V3 kap = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+            const S3 Ic = {Clds.body[k].Ic[0], Clds.body[k].Ic[1], Clds.body[k].Ic[2], Clds.body[k].Ic[3], Clds.body[k].Ic[4], Clds.body[k].Ic[5]};   // (LDS: the register file is full)
+            rigid_inertia(R, kap, C.body[k].mass, Ic, AK[k], hK[k]);
         }
     }
-    // ---- pass 2, bias half (leaf -> root), one joint behind the I wave.  The chain-body CONTACT wrenches are not
-    // waited for here: the recursion is linear in the bias forces, so they are propagated separately below.
+    GRX_EV(1);
+    // ---- inward pass, inertia half (leaf -> root): articulated inertias, U = I^A S, 1/d, and the articulated inertia's
+    // action on the velocity-product acceleration, I^a c -- everything the bias recursion below needs from this half, as
+    // 6 + 6 + 1 numbers per joint.  No input from another wave: it runs while wave 2 is still producing the bias forces.
+    V3 Ica[LEG], Icl[LEG];
+    S3 A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    M3 B = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = LEG - 1; k >= 0; --k) {
+        add_rigid(A, B, D, AK[k], hK[k], C.body[k].mass);
+        const V3 a = Sa[k], s_ = Ss[k];
+        const V3 ua = mul(A, a) + mul(B, s_);
+        const V3 ul = mulT(B, a) + mul(D, s_);
+        const float di = grx_rcp(dot(a, ua) + dot(s_, ul));
+        syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
+        Ica[k] = mul(A, ca[k]) + mul(B, cl[k]);
+        Icl[k] = mulT(B, ca[k]) + mul(D, cl[k]);
+        Ua[k] = ua; Ul[k] = ul; dinv[k] = di;
+    }
+    // base level: both chains (DPP pair exchange) + the base lump, factorised for the solve below
+    A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
+    {
+        S3 A0; V3 h0;
+        rigid_inertia(R0, rot(R0, LC.base_c), LC.base_m, LC.base_I, A0, h0);
+        add_rigid(A, B, D, A0, h0, LC.base_m);
+    }
+    S3 Di = inv(D);
+    S3 Sci;
+    {
+        const V3 b0 = v3(B.a00, B.a01, B.a02), b1 = v3(B.a10, B.a11, B.a12), b2 = v3(B.a20, B.a21, B.a22);
+        const V3 d0 = mul(Di, b0), d1 = mul(Di, b1), d2 = mul(Di, b2);
+        const S3 Sc = {A.xx - dot(b0, d0), A.xy - dot(b0, d1), A.xz - dot(b0, d2), A.yy - dot(b1, d1), A.yz - dot(b1, d2), A.zz - dot(b2, d2)};
+        Sci = inv(Sc);
+    }
+    // The spin-waits below are atomic loads: the compiler may sink pure register arithmetic across them, and did (the
+    // whole inertia half ended up behind the last wait: 4 k cycles per sub-step, measured).  Pin the results here.
+    GRX_PIN(Sci.xx); GRX_PIN(Sci.xy); GRX_PIN(Sci.xz); GRX_PIN(Sci.yy); GRX_PIN(Sci.yz); GRX_PIN(Sci.zz);
+    GRX_PIN(Di.xx); GRX_PIN(Di.xy); GRX_PIN(Di.xz); GRX_PIN(Di.yy); GRX_PIN(Di.yz); GRX_PIN(Di.zz);
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) { GRX_PIN(Ica[k].x); GRX_PIN(Ica[k].y); GRX_PIN(Ica[k].z); GRX_PIN(Icl[k].x); GRX_PIN(Icl[k].y); GRX_PIN(Icl[k].z); }
+    GRX_EV(2);
+    // ---- inward pass, bias half (leaf -> root): the rigid-body bias forces come from wave 2, leaf first.  The chain-body
+    // CONTACT wrenches are not waited for here: the recursion is linear in the bias forces, they follow separately below.
     V3 pa = v3(0.f, 0.f, 0.f), pl = v3(0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
-        GRX_WAIT(L.flag + FL_I, seq * 8 + (LEG - k), 1);
-        const float4* r = L.rec + (k * REC4) * 64 + lane;
-        const float4 r0_ = r[0 * 64], r1_ = r[1 * 64], r2_ = r[2 * 64], r3_ = r[3 * 64], r4_ = r[4 * 64], r5_ = r[5 * 64], r6_ = r[6 * 64];
-        const V3 ua = v3(r0_.x, r0_.y, r0_.z), ul = v3(r0_.w, r1_.x, r1_.y);
-        const float di = r1_.z;
-        const S3 A = {r1_.w, r2_.x, r2_.y, r2_.z, r2_.w, r3_.x};
-        const M3 B = {r3_.y, r3_.z, r3_.w, r4_.x, r4_.y, r4_.z, r4_.w, r5_.x, r5_.y};
-        const S3 D = {r5_.z, r5_.w, r6_.x, r6_.y, r6_.z, r6_.w};
-        {   // this body's rigid bias force joins the running articulated bias; its velocity-product acceleration
+        {
             GRX_WAIT(L.flag + FL_BIAS, seq * 8 + (LEG - k), 0);
             const float4* b_ = L.pb + (k * PB4) * 64 + lane;
-            const float4 b0_ = b_[0 * 64], b1_ = b_[1 * 64], b2_ = b_[2 * 64];
+            const float4 b0_ = b_[0 * 64], b1_ = b_[1 * 64];
             pa = pa + v3(b0_.x, b0_.y, b0_.z); pl = pl + v3(b0_.w, b1_.x, b1_.y);
-            ca[k] = v3(b1_.z, b1_.w, b2_.x); cl[k] = v3(b2_.y, b2_.z, b2_.w);
         }
         const float qdk = st.qd[k];
         // joint-limit spring/damper (oracle substep()): added to the motor torque
@@ -173,15 +203,18 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         if (st.q[k] < Clds.body[k].qlo) t += Clds.body[k].Klim * (Clds.body[k].qlo - st.q[k]) - Clds.body[k].Clim * qdk;
         else if (st.q[k] > Clds.body[k].qhi) t += Clds.body[k].Klim * (Clds.body[k].qhi - st.q[k]) - Clds.body[k].Clim * qdk;
         const float u = t - (dot(Sa[k], pa) + dot(Ss[k], pl));
-        const float ud = u * di;
-        V3 npa = pa + mul(A, ca[k]) + mul(B, cl[k]) + ua * ud;
-        V3 npl = pl + mulT(B, ca[k]) + mul(D, cl[k]) + ul * ud;
-        Ua[k] = ua; Ul[k] = ul; dinv[k] = di; uu[k] = u;
-        pa = npa; pl = npl;
+        const float ud = u * dinv[k];
+        uu[k] = u;
+        pa = pa + Ica[k] + Ua[k] * ud;
+        pl = pl + Icl[k] + Ul[k] * ud;
     }
+    GRX_EV(7);
     // ---- contact wrenches on chain bodies 4 (foot), 3 (shank), 2 (thigh): delta recursion  dp -> dp + U (-S.dp)/d
+    GRX_EV(3);
     GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
+    GRX_EV(4);
     GRX_WAIT(L.flag + FL_LEGS, seq + 1, 2);
+    GRX_EV(5);
     GRX_WAIT(L.flag + FL_SELF, seq + 1, 3);
     SelfOut sc;   // self-collision wrenches (wave 1, after its recursion)
     {
@@ -235,14 +268,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         const float4 b0_ = b_[0 * 64], b1_ = b_[1 * 64];
         pa = pa + v3(b0_.x, b0_.y, b0_.z); pl = pl + v3(b0_.w, b1_.x, b1_.y);
     }
-    // [A B; B^T D][alpha; acc] = -[pa; pl], factorised by the I wave: Di = inv(D), Sci = inv(A - B Di B^T)
-    //   alpha = Sci (B Di pl - pa),  acc = -Di (pl + B^T alpha)
-    GRX_WAIT(L.flag + FL_I, seq * 8 + LEG + 1, 4);
-    const float4* r0 = L.rec0 + lane;
-    const float4 g0_ = r0[0 * 64], g1_ = r0[1 * 64], g2_ = r0[2 * 64], g3_ = r0[3 * 64], g4_ = r0[4 * 64], g5_ = r0[5 * 64];
-    const S3 Di = {g0_.x, g0_.y, g0_.z, g0_.w, g1_.x, g1_.y};
-    const S3 Sci = {g1_.z, g1_.w, g2_.x, g2_.y, g2_.z, g2_.w};
-    const M3 B = {g3_.x, g3_.y, g3_.z, g3_.w, g4_.x, g4_.y, g4_.z, g4_.w, g5_.x};
+    // [A B; B^T D][alpha; acc] = -[pa; pl]:  alpha = Sci (B Di pl - pa),  acc = -Di (pl + B^T alpha)
     const V3 alpha = mul(Sci, mul(B, mul(Di, pl)) - pa);
     const V3 acc = neg(mul(Di, pl + mulT(B, alpha)));
     // ---- pass 3 (root -> leaf): accelerations
@@ -276,15 +302,18 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     const float nw = ww - hx * x - hy * y - hz * z;
     const float n = grx_rsq(nx * nx + ny * ny + nz * nz + nw * nw);
     st.qx = nx * n; st.qy = ny * n; st.qz = nz * n; st.qw = nw * n;
+    GRX_EV(6);
 #ifdef GRX_PROFILE_SECTIONS
+    if (lane == 0) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 64 + seq] = clock64() - tprev;   // duration of every sub-step
     tacc[5] += clock64() - tprev;   // whole sub-step
 #endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// wave 1: inertia half of the articulated-body recursion for every sub-step of the policy step
-GRX_DEV void iwave_loop(KP P, const SideConst& C, const RareBuf& RB, const float4* footfr, const SelfBuf& SB, float mu_self, float base_m, V3 base_c, const S3& base_I, const PipeLds& L,
-                        int lane, int el, int side) {
+// wave 1: self-collision (grx_self.h) -- leg against leg (the partner lane is one DPP step away), thigh against base-lump
+// shapes -- on the chain frames wave 2 publishes right after its walk
+GRX_DEV void self_loop(KP P, const SideConst& C, const RareBuf& RB, const float4* footfr, const SelfBuf& SB, float mu_self, const PipeLds& L,
+                       int lane, int el, int side) {
     GRX_HELPER_PROF_BEGIN;
     SelfNear sn; sn.m = 0;   // self-collision broad phase of this policy step
 #ifdef GRX_PROFILE_SECTIONS
@@ -298,78 +327,28 @@ GRX_DEV void iwave_loop(KP P, const SideConst& C, const RareBuf& RB, const float
         GRX_HELPER_PROF_IDLE1;
         const float* b = L.base + el;
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
-        // base lump first (needs only the base pose): ready long before wave 0's first rigid inertia arrives
-        S3 A0; V3 h0;
-        rigid_inertia(R0, rot(R0, base_c), base_m, base_I, A0, h0);
-        // inward recursion, fed by wave 0
-        S3 A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        M3 B = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+        flag_wait(L.flag + FL_FRAMES, seq + 1);
+        ChainKin KS[3];
 #pragma unroll
-        for (int k = LEG - 1; k >= 0; --k) {
-            flag_wait(L.flag + FL_RI, seq * 8 + (LEG - k));
-            const float4* i_ = L.ri + (k * RI4) * 64 + lane;
-            const float4 i0_ = i_[0 * 64], i1_ = i_[1 * 64], i2_ = i_[2 * 64], i3_ = i_[3 * 64];
-            {
-                const S3 Ak = {i0_.x, i0_.y, i0_.z, i0_.w, i1_.x, i1_.y};
-                add_rigid(A, B, D, Ak, v3(i1_.z, i1_.w, i2_.x), C.body[k].mass);
-            }
-            const V3 a = v3(i2_.y, i2_.z, i2_.w), s = v3(i3_.x, i3_.y, i3_.z);
-            const V3 ua = mul(A, a) + mul(B, s);
-            const V3 ul = mulT(B, a) + mul(D, s);
-            const float di = grx_rcp(dot(a, ua) + dot(s, ul));
-            syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
-            float4* r = L.rec + (k * REC4) * 64 + lane;
-            r[0 * 64] = f4(ua.x, ua.y, ua.z, ul.x);
-            r[1 * 64] = f4(ul.y, ul.z, di, A.xx);
-            r[2 * 64] = f4(A.xy, A.xz, A.yy, A.yz);
-            r[3 * 64] = f4(A.zz, B.a00, B.a01, B.a02);
-            r[4 * 64] = f4(B.a10, B.a11, B.a12, B.a20);
-            r[5 * 64] = f4(B.a21, B.a22, D.xx, D.xy);
-            r[6 * 64] = f4(D.xz, D.yy, D.yz, D.zz);
-            flag_set(L.flag + FL_I, seq * 8 + (LEG - k), lane);
+        for (int i = 0; i < 3; ++i) {
+            const RareFrame f = rare_load_frame(i < 2 ? RB.fchain + i * RC_FR4 * 64 + lane : footfr + lane, 64);
+            KS[i].R = f.R; KS[i].rho = f.rho; KS[i].w = f.w; KS[i].v = f.v;
         }
-        // base level: both chains + the base lump
-        A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
-        add_rigid(A, B, D, A0, h0, base_m);
-        {   // factorise for wave 0's solve: Di = inv(D), Schur complement Sc = A - B Di B^T, Sci = inv(Sc)
-            const S3 Di = inv(D);
-            const V3 b0 = v3(B.a00, B.a01, B.a02), b1 = v3(B.a10, B.a11, B.a12), b2 = v3(B.a20, B.a21, B.a22);
-            const V3 d0 = mul(Di, b0), d1 = mul(Di, b1), d2 = mul(Di, b2);
-            const S3 Sc = {A.xx - dot(b0, d0), A.xy - dot(b0, d1), A.xz - dot(b0, d2), A.yy - dot(b1, d1), A.yz - dot(b1, d2), A.zz - dot(b2, d2)};
-            const S3 Sci = inv(Sc);
-            float4* r0 = L.rec0 + lane;
-            r0[0 * 64] = f4(Di.xx, Di.xy, Di.xz, Di.yy);
-            r0[1 * 64] = f4(Di.yz, Di.zz, Sci.xx, Sci.xy);
-            r0[2 * 64] = f4(Sci.xz, Sci.yy, Sci.yz, Sci.zz);
-            r0[3 * 64] = f4(B.a00, B.a01, B.a02, B.a10);
-            r0[4 * 64] = f4(B.a11, B.a12, B.a20, B.a21);
-            r0[5 * 64] = f4(B.a22, 0.f, 0.f, 0.f);
-        }
-        flag_set(L.flag + FL_I, seq * 8 + LEG + 1, lane);
-        {   // this wave is idle from here to the next sub-step: self-collision (grx_self.h) -- leg against leg (the partner lane
-            // is one DPP step away), thigh against base-lump shapes -- on the chain frames wave 2 published
-            const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
-            flag_wait(L.flag + FL_FRAMES, seq + 1);
-            ChainKin KS[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const RareFrame f = rare_load_frame(i < 2 ? RB.fchain + i * RC_FR4 * 64 + lane : footfr + lane, 64);
-                KS[i].R = f.R; KS[i].rho = f.rho; KS[i].w = f.w; KS[i].v = f.v;
-            }
-            if (seq == 0) sn = self_broad_phase(P, C, side, R0, KS);
-            SelfOut sc;
-            self_collision(P, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc);
-            float4* o = L.wc + 7 * 64 + lane;
-            o[0 * 64] = f4(sc.fa[0].x, sc.fa[0].y, sc.fa[0].z, sc.fl[0].x);
-            o[1 * 64] = f4(sc.fl[0].y, sc.fl[0].z, sc.fa[1].x, sc.fa[1].y);
-            o[2 * 64] = f4(sc.fa[1].z, sc.fl[1].x, sc.fl[1].y, sc.fl[1].z);
-            o[3 * 64] = f4(sc.fa[2].x, sc.fa[2].y, sc.fa[2].z, sc.fl[2].x);
-            o[4 * 64] = f4(sc.fl[2].y, sc.fl[2].z, sc.f0a.x, sc.f0a.y);
-            o[5 * 64] = f4(sc.f0a.z, sc.f0l.x, sc.f0l.y, sc.f0l.z);
-            o[6 * 64] = f4(sc.fbase[0].x, sc.fbase[0].y, sc.fbase[0].z, sc.fbase[1].x);
-            o[7 * 64] = f4(sc.fbase[1].y, sc.fbase[1].z, 0.f, 0.f);
-            flag_set(L.flag + FL_SELF, seq + 1, lane);
-        }
+        if (seq == 0) sn = self_broad_phase(P, C, side, R0, KS);
+        SelfOut sc;
+        self_collision(P, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc);
+        float4* o = L.wc + 7 * 64 + lane;
+        o[0 * 64] = f4(sc.fa[0].x, sc.fa[0].y, sc.fa[0].z, sc.fl[0].x);
+        o[1 * 64] = f4(sc.fl[0].y, sc.fl[0].z, sc.fa[1].x, sc.fa[1].y);
+        o[2 * 64] = f4(sc.fa[1].z, sc.fl[1].x, sc.fl[1].y, sc.fl[1].z);
+        o[3 * 64] = f4(sc.fa[2].x, sc.fa[2].y, sc.fa[2].z, sc.fl[2].x);
+        o[4 * 64] = f4(sc.fl[2].y, sc.fl[2].z, sc.f0a.x, sc.f0a.y);
+        o[5 * 64] = f4(sc.f0a.z, sc.f0l.x, sc.f0l.y, sc.f0l.z);
+        o[6 * 64] = f4(sc.fbase[0].x, sc.fbase[0].y, sc.fbase[0].z, sc.fbase[1].x);
+        o[7 * 64] = f4(sc.fbase[1].y, sc.fbase[1].z, 0.f, 0.f);
+        flag_set(L.flag + FL_SELF, seq + 1, lane);
+        GRX_EV(13);
     }
     GRX_HELPER_PROF_END(1);
 #ifdef GRX_PROFILE_SECTIONS
@@ -401,25 +380,14 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
         // velocity-product accelerations of the chain bodies, leaf first (wave 0's bias recursion starts at the foot)
         ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
         ChainKin KK[LEG];
-        V3 cak[LEG], clk[LEG];
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {
-            const V3 wp = K.w, vp = K.v;   // parent velocity
-            const float qdk = qs_qd[k];
-            K.rho = K.rho + rot(K.R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
-            float sn, cs;
-            grx_sincos(qs_q[k], sn, cs);
-            K.R = joint_rot_k(K.R, cs, sn, kAxis[k]);
-            const V3 a = axis_k(K.R, kAxis[k]);
-            const V3 s = cross(K.rho, a);
-            cak[k] = cross(wp, a) * qdk;
-            clk[k] = (cross(vp, a) + cross(wp, s)) * qdk;
-            K.w = fma3(a, qdk, wp); K.v = fma3(s, qdk, vp);
+            chain_step(C, k, qs_q[k], qs_qd[k], K);
             KK[k] = K;
             if (k == 2) rare_store_frame(RB.fchain + lane, 64, K.R, K.rho, K.w, K.v);                  // thigh
             if (k == 3) rare_store_frame(RB.fchain + RC_FR4 * 64 + lane, 64, K.R, K.rho, K.w, K.v);    // shank
             if (k == 4) { rare_store_frame(footfr + lane, 64, K.R, K.rho, K.w, K.v);   // foot (self-collision, wave 1)
-                          flag_set(L.flag + FL_FRAMES, seq + 1, lane); }
+                          flag_set(L.flag + FL_FRAMES, seq + 1, lane); GRX_EV(8); }
         }
 #pragma unroll
         for (int k = LEG - 1; k >= 0; --k) {
@@ -429,9 +397,10 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
             rigid_bias(KK[k].R, kap, C.body[k].mass, Ic, KK[k].w, KK[k].v, pa, pl);
             float4* o = L.pb + (k * PB4) * 64 + lane;
             o[0 * 64] = f4(pa.x, pa.y, pa.z, pl.x);
-            o[1 * 64] = f4(pl.y, pl.z, cak[k].x, cak[k].y);
-            o[2 * 64] = f4(cak[k].z, clk[k].x, clk[k].y, clk[k].z);
+            o[1 * 64] = f4(pl.y, pl.z, 0.f, 0.f);
             flag_set(L.flag + FL_BIAS, seq * 8 + (LEG - k), lane);
+            if (k == LEG - 1) GRX_EV(9);
+            if (k == 0) GRX_EV(10);
         }
         float4* c_ = L.wc + lane;
         V3 fa, fl;
@@ -444,6 +413,7 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
             c_[6 * 64] = f4(fv.z, 0.f, 0.f, 0.f);
         }
         flag_set(L.flag + FL_FOOT, seq + 1, lane);
+        GRX_EV(11);
     }
     GRX_HELPER_PROF_END(2);
 }
@@ -493,6 +463,7 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         L.wr[lane] = f4(ro.f0a.x, ro.f0a.y, ro.f0a.z, ro.f0l.x);
         L.wr[64 + lane] = f4(ro.f0l.y, ro.f0l.z, ro.term ? 1.f : 0.f, ro.pen_count);
         flag_set(L.flag + FL_LEGS, seq + 1, lane);   // thigh + shank wrenches and the base-lump wrench, one hand-over
+        GRX_EV(12);
     }
     GRX_HELPER_PROF_END(3);
 #ifdef GRX_PROFILE_SECTIONS
