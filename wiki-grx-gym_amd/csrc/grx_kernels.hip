@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             float es_w1[NT], es_w3[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
             if (wv == 1) load_episode_sums<1>(P, e, N, es_w1);
             if (wv == 3) load_episode_sums<2>(P, e, N, es_w3);
-            __syncthreads();   // final friction anchors + height-scan pose published
+            lds_barrier();   // final friction anchors + height-scan pose published (the last sub-step's row stores stay in flight)
             if (HF && P.measure_heights) {   // this wave's quarter of the height scan (legged_robot.py:1235-1274)
                 const float* hp = s_hp + el;
                 s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     const float yaw_z = st.qz / yaw_n, yaw_w = st.qw / yaw_n;
     if (W == 4) {   // the foot wave owned the friction anchors during the sub-steps
         if (side == 0) { float* hp = s_hp + el; hp[0 * EPB] = st.pos.x; hp[1 * EPB] = st.pos.y; hp[2 * EPB] = yaw_z; hp[3 * EPB] = yaw_w; }
-        __syncthreads();   // final friction anchors + height-scan pose published
+        lds_barrier();   // final friction anchors + height-scan pose published (the last sub-step's row stores stay in flight)
         const float* a_ = s_anch + lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { st.ax[i] = a_[i * 64]; st.ay[i] = a_[(4 + i) * 64]; st.vimp[i] = a_[(9 + i) * 64]; }

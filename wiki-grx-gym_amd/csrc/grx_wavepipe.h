@@ -74,12 +74,22 @@ struct PipeLds {
 };
 GRX_DEV float4 f4(float a, float b, float c, float d) { float4 r; r.x = a; r.y = b; r.z = c; r.w = d; return r; }
 
+// Hand-over flags and their payload live in LDS: the release / acquire fences are LDS-only ("local" address space), so a
+// wave never waits for its global stores or terrain loads in flight when it raises or polls a flag.
 GRX_DEV void flag_set(int* f, int v, int lane) {
-    if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 GRX_DEV void flag_wait(int* f, int want) {
     // pure spin (the waiter owns its SIMD; an s_sleep between polls only added detection latency: +1.3 % measured)
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {}
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {}
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// block barrier that orders LDS only (global stores stay in flight across it)
+GRX_DEV void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // velocity-product (bias) force of a rigid body about O, from its centre-of-mass quantities (no 3x3 world inertia):
@@ -179,6 +189,17 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         const S3 Sc = {A.xx - dot(b0, d0), A.xy - dot(b0, d1), A.xz - dot(b0, d2), A.yy - dot(b1, d1), A.yz - dot(b1, d2), A.zz - dot(b2, d2)};
         Sci = inv(Sc);
     }
+    // motor torque + joint-limit spring/damper (oracle substep()) of every joint: known now, needed in the bias half
+    float tq[LEG];
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        const float qdk = st.qd[k];
+        float t = tau_m[k];
+        if (st.q[k] < Clds.body[k].qlo) t += Clds.body[k].Klim * (Clds.body[k].qlo - st.q[k]) - Clds.body[k].Clim * qdk;
+        else if (st.q[k] > Clds.body[k].qhi) t += Clds.body[k].Klim * (Clds.body[k].qhi - st.q[k]) - Clds.body[k].Clim * qdk;
+        tq[k] = t;
+        GRX_PIN(tq[k]);
+    }
     // The spin-waits below are atomic loads: the compiler may sink pure register arithmetic across them, and did (the
     // whole inertia half ended up behind the last wait: 4 k cycles per sub-step, measured).  Pin the results here.
     GRX_PIN(Sci.xx); GRX_PIN(Sci.xy); GRX_PIN(Sci.xz); GRX_PIN(Sci.yy); GRX_PIN(Sci.yz); GRX_PIN(Sci.zz);
@@ -197,12 +218,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
             const float4 b0_ = b_[0 * 64], b1_ = b_[1 * 64];
             pa = pa + v3(b0_.x, b0_.y, b0_.z); pl = pl + v3(b0_.w, b1_.x, b1_.y);
         }
-        const float qdk = st.qd[k];
-        // joint-limit spring/damper (oracle substep()): added to the motor torque
-        float t = tau_m[k];
-        if (st.q[k] < Clds.body[k].qlo) t += Clds.body[k].Klim * (Clds.body[k].qlo - st.q[k]) - Clds.body[k].Clim * qdk;
-        else if (st.q[k] > Clds.body[k].qhi) t += Clds.body[k].Klim * (Clds.body[k].qhi - st.q[k]) - Clds.body[k].Clim * qdk;
-        const float u = t - (dot(Sa[k], pa) + dot(Ss[k], pl));
+        const float u = tq[k] - (dot(Sa[k], pa) + dot(Ss[k], pl));
         const float ud = u * dinv[k];
         uu[k] = u;
         pa = pa + Ica[k] + Ua[k] * ud;
