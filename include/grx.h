@@ -112,7 +112,7 @@ typedef enum grx_reward_term {
 #define GRX_SPH_TERMINATE 0x4u   /* body is in termination_contact_indices (legged_robot.py:1145-1161) */
 #define GRX_SPH_PENALISE 0x8u    /* body is in penalised_contact_indices  (legged_robot.py:1127-1143) */
 
-typedef enum grx_terrain_type { GRX_TERRAIN_PLANE = 0, GRX_TERRAIN_HEIGHTFIELD = 1 } grx_terrain_type;
+typedef enum grx_terrain_type { GRX_TERRAIN_PLANE = 0, GRX_TERRAIN_HEIGHTFIELD = 1 } grx_terrain_type;   /* 'trimesh' = heightfield + vertical_faces */
 
 /* Robot model after merging fixed-joint subtrees into their moving ancestor.  Body 0 is the
  * free-floating base (fix_base_link=False, legged_robot_config.py:119); body i>0 hangs from
@@ -244,6 +244,9 @@ typedef struct grx_config {
     const int16_t* height_samples; /* HOST pointer, (hf_rows, hf_cols) row-major; copied at create */
     int32_t hf_rows, hf_cols;
     float horizontal_scale, vertical_scale, border_size;
+    int32_t vertical_faces;      /* mesh_type 'trimesh': raster steps steeper than slope_threshold are vertical faces at the HIGH
+                                    vertex (isaacgym terrain_utils.py:286-350 convert_heightfield_to_trimesh, legged_robot.py:903-921) */
+    float slope_threshold;       /* legged_robot_config.py:99 (0.75) */
     int32_t curriculum;
     int32_t num_terrain_rows, num_terrain_cols; /* levels, types */
     int32_t max_init_terrain_level;

@@ -44,6 +44,7 @@ def load(precision="f32"):
         lib.gro_debug_substeps.argtypes = [H, C.c_int, dp, C.c_int, C.c_int]
         lib.gro_debug_body_pose.argtypes = [H, C.c_int, C.c_int, dp, dp]
         lib.gro_debug_link_forces.argtypes = [H, C.c_int, dp, C.c_int]
+        lib.gro_debug_terrain.argtypes = [H, C.c_double, C.c_double, dp]
         _libs[precision] = (lib, api)
     return _libs[precision]
 
@@ -95,6 +96,12 @@ class OracleSim(SimHandle):
         f, fp = self._d(np.zeros(3 * nlinks))
         self._check(self.lib.gro_debug_link_forces(self._h, env, fp, nlinks), "link_forces")
         return f.reshape(nlinks, 3)
+
+    def terrain(self, x, y):
+        """physics terrain query: (height, dh/dx, dh/dy) at world (x, y)"""
+        o, op = self._d(np.zeros(3))
+        self._check(self.lib.gro_debug_terrain(self._h, float(x), float(y), op), "terrain")
+        return o.copy()
 
     def post_physics(self, env, ps, apply_reset, common_step_counter=1, noise_uniform=None):
         a = _capi.StepArgs()

@@ -301,10 +301,26 @@ struct grx_sim {
 };
 
 /* ------------------------------------------------------------------ terrain */
-static real terrain_height(const struct grx_sim* s, real x, real y) {
+/* Physics terrain query: height under (x, y) and the gradient of the surface there (g[2] = dh/dx, dh/dy).
+ *  - heightfield: bilinear patch of the int16 raster.
+ *  - trimesh (vertical_faces): the reference's convert_heightfield_to_trimesh (isaacgym terrain_utils.py:286-350) moves a
+ *    low vertex next to a step steeper than slope_threshold under the high one: the low ground runs up to the HIGH vertex's
+ *    grid line and the face there is vertical.  A height function cannot hold a vertical face; along an axis whose raster
+ *    step exceeds the threshold the interpolation weight is therefore sharpened to a ramp over the last quarter cell
+ *    before the high vertex (2.5 cm at the default 0.1 m raster) -- with the surface normal from the gradient, the riser
+ *    pushes back horizontally like the wall it stands for. */
+#define RISER_BAND ((real)0.25)
+static real sharpen(real t, real lo, real hi, real thr, real* dt) {
+    /* weight of the far vertex (value hi) along one axis; lo = near vertex value; *dt = d weight / d t */
+    *dt = 1;
+    if (hi - lo > thr) { if (t <= 1 - RISER_BAND) { *dt = 0; return 0; } *dt = 1 / RISER_BAND; return (t - (1 - RISER_BAND)) / RISER_BAND; }
+    if (lo - hi > thr) { if (t >= RISER_BAND) { *dt = 0; return 1; } *dt = 1 / RISER_BAND; return t / RISER_BAND; }
+    return t;
+}
+static real terrain_query(const struct grx_sim* s, real x, real y, real g[2]) {
     const grx_config* c = &s->cfg;
+    g[0] = 0; g[1] = 0;
     if (c->terrain_type == GRX_TERRAIN_PLANE) return 0;
-    /* bilinear interpolation of the int16 heightfield (physics terrain query) */
     real fx = (x + c->border_size) / c->horizontal_scale;
     real fy = (y + c->border_size) / c->horizontal_scale;
     if (fx < 0) fx = 0;
@@ -318,7 +334,19 @@ static real terrain_height(const struct grx_sim* s, real x, real y) {
     const int16_t* H = s->hf;
     int C = c->hf_cols;
     real h00 = H[ix * C + iy], h10 = H[(ix + 1) * C + iy], h01 = H[ix * C + iy + 1], h11 = H[(ix + 1) * C + iy + 1];
+    real dtx = 1, dty = 1;
+    if (c->vertical_faces) {
+        real thr = c->slope_threshold * c->horizontal_scale / c->vertical_scale;   /* in raster units */
+        /* the steeper of the cell's two edges along an axis decides for the cell */
+        real ax0 = h10 - h00, ax1 = h11 - h01, ay0 = h01 - h00, ay1 = h11 - h10;
+        real ax = fabs(ax0) > fabs(ax1) ? ax0 : ax1, ay = fabs(ay0) > fabs(ay1) ? ay0 : ay1;
+        tx = sharpen(tx, 0, ax, thr, &dtx);
+        ty = sharpen(ty, 0, ay, thr, &dty);
+    }
     real h = (h00 * (1 - tx) + h10 * tx) * (1 - ty) + (h01 * (1 - tx) + h11 * tx) * ty;
+    real sc = c->vertical_scale / c->horizontal_scale;
+    g[0] = ((h10 - h00) * (1 - ty) + (h11 - h01) * ty) * dtx * sc;
+    g[1] = ((h01 - h00) * (1 - tx) + (h11 - h10) * tx) * dty * sc;
     return h * c->vertical_scale;
 }
 
@@ -430,17 +458,23 @@ static void contact_forces(const struct grx_sim* s, env_t* e, const kin_t* k, sv
         real sb[3] = {m->sph_pos[i][0], m->sph_pos[i][1], m->sph_pos[i][2]}, sw[3], x[3];
         m3_mulv(k->R[b], sb, sw);
         for (int j = 0; j < 3; ++j) x[j] = k->p[b][j] + sw[j];
-        real h = terrain_height(s, x[0], x[1]);
-        real d = h + m->sph_radius[i] - x[2];
-        if (d <= 0) {
+        real g[2];
+        real h = terrain_query(s, x[0], x[1], g);
+        real dv = h + m->sph_radius[i] - x[2];   /* vertical overlap */
+        if (dv <= 0) {
             if (slot >= 0) e->anchor_on[slot] = 0;
             continue;
         }
+        /* surface normal from the gradient of the patch; overlap along it (locally planar terrain) */
+        real nn = 1 / sqrt(1 + g[0] * g[0] + g[1] * g[1]);
+        real n[3] = {-g[0] * nn, -g[1] * nn, nn};
+        real d = dv * nn;
         /* sphere-centre velocity, world */
         real wxs[3], ub[3], u[3];
         v3_cross(k->v[b].v, sb, wxs);
         for (int j = 0; j < 3; ++j) ub[j] = k->v[b].v[3 + j] + wxs[j];
         m3_mulv(k->R[b], ub, u);
+        real un = u[0] * n[0] + u[1] * n[1] + u[2] * n[2];   /* > 0: separating */
         /* Hunt-Crossley damping kn*d*dn, capped by the mass-aware bound that keeps explicit
          * integration of the (light) foot stable; normal force never pulls */
         real cd = cp->kn * d * cp->dn;
@@ -450,16 +484,17 @@ static void contact_forces(const struct grx_sim* s, env_t* e, const kin_t* k, sv
                 e->anchor_on[slot] = 1;
                 e->anchor[slot][0] = x[0];
                 e->anchor[slot][1] = x[1];
-                e->anchor_vimp[slot] = u[2] < 0 ? -u[2] : 0;
+                e->anchor_vimp[slot] = un < 0 ? -un : 0;
             }
             /* restitution (legged_robot.py:565-575; PhysX combines by averaging, bounce threshold
              * legged_robot_config.py:48): a contact that began faster than the threshold keeps only the
              * fraction (1 - e) of its damping while the sphere separates again */
-            if (u[2] > 0 && e->anchor_vimp[slot] > c->bounce_threshold_velocity) cd *= 1 - e_rest;
+            if (un > 0 && e->anchor_vimp[slot] > c->bounce_threshold_velocity) cd *= 1 - e_rest;
         }
-        real fn = cp->kn * d - cd * u[2];
+        real fn = cp->kn * d - cd * un;
         if (fn < 0) fn = 0;
-        real F[3] = {0, 0, fn};
+        real F[3] = {fn * n[0], fn * n[1], fn * n[2]};
+        /* friction: in the horizontal plane (anchored stick/slip on the foot spheres, viscous-capped elsewhere) */
         if (slot >= 0 && slot < NFS) {
             real ftx = -cp->kt * (x[0] - e->anchor[slot][0]) - cp->ct * u[0];
             real fty = -cp->kt * (x[1] - e->anchor[slot][1]) - cp->ct * u[1];
@@ -470,12 +505,12 @@ static void contact_forces(const struct grx_sim* s, env_t* e, const kin_t* k, sv
                 e->anchor[slot][0] = x[0] + ftx / cp->kt;
                 e->anchor[slot][1] = x[1] + fty / cp->kt;
             }
-            F[0] = ftx; F[1] = fty;
+            F[0] += ftx; F[1] += fty;
         } else {
             real sp = sqrt(u[0] * u[0] + u[1] * u[1]);
             real ft = cp->cv * sp, fmax = mu * fn;
             if (ft > fmax) ft = fmax;
-            if (sp > (real)1e-9) { F[0] = -ft * u[0] / sp; F[1] = -ft * u[1] / sp; }
+            if (sp > (real)1e-9) { F[0] -= ft * u[0] / sp; F[1] -= ft * u[1] / sp; }
         }
         int L = m->sph_link[i];
         for (int j = 0; j < 3; ++j) e->link_force[L][j] += F[j];
@@ -1529,6 +1564,14 @@ int gro_debug_post_physics(grx_handle s, int le, const gro_pipeline_state* ps, i
     for (int j = 0; j < nd; ++j) { e->last_actions[j] = e->actions[j]; e->last_dof_vel[j] = e->qd[j]; e->last_last_actions[j] = e->last_actions[j]; }
     for (int f = 0; f < 2; ++f) e->air_time[f] = e->air_time[f] * (e->contact_filt[f] ? 0 : 1);
     publish(s);
+    return GRX_OK;
+}
+
+/* physics terrain query at world (x, y): out = {height, dh/dx, dh/dy} */
+int gro_debug_terrain(grx_handle s, double x, double y, double* out) {
+    real g[2];
+    out[0] = terrain_query(s, (real)x, (real)y, g);
+    out[1] = g[0]; out[2] = g[1];
     return GRX_OK;
 }
 

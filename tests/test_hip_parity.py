@@ -188,10 +188,11 @@ def test_internal_noise_stream_matches():
     assert torch.equal(hip.tensor("PRI_OBS")[:, :39], h2.tensor("PRI_OBS")[:, :39])    # pri_obs copies obs before noise
 
 
-@pytest.mark.parametrize("task", ["GR1T1", "GR1T2"])
-def test_one_step_parity_rough_terrain(task):
-    """Rough-terrain curriculum heightfield, both registered robots (GR1T2 rough = BASELINE.json config 4's workload)."""
-    cfg = make_cfg(task=task, terrain="heightfield", dr=True, push=True)
+@pytest.mark.parametrize("task,mesh", [("GR1T1", "heightfield"), ("GR1T2", "heightfield"), ("GR1T1", "trimesh")])
+def test_one_step_parity_rough_terrain(task, mesh):
+    """Rough-terrain curriculum, both registered robots (GR1T2 rough = BASELINE.json config 4's workload); mesh_type
+    'trimesh' = the same raster with vertical faces at the steps steeper than slope_treshold (legged_robot.py:903-921)."""
+    cfg = make_cfg(task=task, terrain=mesh, dr=True, push=True)
     hip, ora = make_sims(cfg, 320, seed=1)
     assert torch.equal(hip.tensor("TERRAIN_TYPES").cpu(), ora.tensor("TERRAIN_TYPES"))
     assert torch.equal(hip.tensor("TERRAIN_LEVELS").cpu(), ora.tensor("TERRAIN_LEVELS"))

@@ -249,3 +249,91 @@ def test_restitution_raises_the_rebound_above_the_bounce_threshold():
     assert f5[diff[0]] > f0[diff[0]], (diff[0], f0[diff[0]], f5[diff[0]])
     l0, l5 = _drop(0.0, vdown=0.2, n=60, z=0.90), _drop(0.5, vdown=0.2, n=60, z=0.90)      # touches at ~0.35 m/s
     assert l0.max() > 50.0 and np.array_equal(l0, l5)
+
+
+# ------------------------------------------------------------------ terrain normal, vertical faces of 'trimesh' (round 2)
+class _FakeTerrain:
+    """A raster handed to build_config in place of utils.terrain.Terrain (only what build_config reads)."""
+
+    def __init__(self, hs, rows=1, cols=1):
+        self.heightsamples = np.ascontiguousarray(hs, dtype=np.int16)
+        self.env_origins = np.zeros((rows, cols, 3), dtype=np.float32)
+
+
+def _terrain_sim(hs, mesh_type, friction=None, N=1):
+    from oracle.binding import OracleSim
+    cfg = make_cfg(terrain=mesh_type)
+    cfg.terrain.border_size = 0.0
+    cfg.terrain.num_rows = cfg.terrain.num_cols = 1
+    cfg.terrain.curriculum = False
+    if friction is not None:
+        cfg.terrain.static_friction = cfg.terrain.dynamic_friction = friction
+        cfg.domain_rand.randomize_friction = True
+        cfg.domain_rand.friction_range = [friction, friction]
+    c, keep, meta = build_config.build(cfg, cfg.sim.dt, N, terrain=_FakeTerrain(hs))
+    return OracleSim(c, "f64", keep), cfg, meta
+
+
+def test_stair_riser_is_a_ramp_on_the_heightfield_and_a_wall_on_the_trimesh():
+    """mesh_type 'trimesh' collides against the slope-corrected mesh (isaacgym terrain_utils.py:286-350,
+    legged_robot.py:903-921): a raster step steeper than slope_treshold (0.75) is a vertical face at the HIGH vertex.
+    On 'heightfield' the same step is the one-cell ramp PhysX's heightfield triangles make of it."""
+    hs = np.zeros((40, 40), np.int16)
+    hs[20:, :] = 40                      # a 0.2 m step (vertical_scale 0.005) between rows 19 and 20: x in [1.9, 2.0]
+    hf, _, _ = _terrain_sim(hs, "heightfield")
+    tm, _, _ = _terrain_sim(hs, "trimesh")
+    for x, want_hf, want_tm in ((1.85, 0.0, 0.0), (1.92, 0.04, 0.0), (1.95, 0.10, 0.0), (1.974, 0.148, 0.0), (1.99, 0.18, 0.12), (2.02, 0.2, 0.2)):
+        np.testing.assert_allclose(hf.terrain(x, 1.0)[0], want_hf, atol=1e-6)
+        np.testing.assert_allclose(tm.terrain(x, 1.0)[0], want_tm, atol=1e-6)
+    # gradient: 2 on the heightfield ramp, 0 in front of the trimesh wall and 8 (= 0.2 m over 2.5 cm) on its face
+    assert abs(hf.terrain(1.95, 1.0)[1] - 2.0) < 1e-6 and tm.terrain(1.95, 1.0)[1] == 0.0 and abs(tm.terrain(1.99, 1.0)[1] - 8.0) < 1e-6
+    # a gentle slope (0.4) is below the threshold: identical in both modes
+    ramp = (np.arange(40)[:, None] * 8 * np.ones((1, 40))).astype(np.int16)      # 8 units = 0.04 m per 0.1 m
+    a, _, _ = _terrain_sim(ramp, "heightfield"); b, _, _ = _terrain_sim(ramp, "trimesh")
+    np.testing.assert_allclose(a.terrain(1.234, 2.0), b.terrain(1.234, 2.0))
+    np.testing.assert_allclose(a.terrain(1.234, 2.0), [0.4 * 1.234, 0.4, 0.0], atol=1e-6)
+
+
+def test_a_foot_is_stopped_by_a_trimesh_riser():
+    """Stair-edge foot contact: a robot sliding feet-first into a 0.2 m riser.  On the trimesh the feet meet a wall
+    (horizontal contact force against the motion, the base stops short of the step); on the heightfield raster the same
+    feet ride up the one-cell ramp."""
+    hs = np.zeros((80, 40), np.int16)
+    hs[30:, :] = 40                      # step face at x = 3.0 (trimesh) / ramp over x in [2.9, 3.0] (heightfield)
+    out = {}
+    for mesh in ("heightfield", "trimesh"):
+        sim, cfg, meta = _terrain_sim(hs, mesh, friction=0.05)
+        root = torch.zeros(1, 13); root[0, 0] = 2.6; root[0, 1] = 2.0; root[0, 2] = 0.90; root[0, 6] = 1.0; root[0, 7] = 1.5
+        q = torch.tensor([[0, 0, -0.2618, 0.5236, -0.2618] * 2], dtype=torch.float32)
+        sim.set_state(root.contiguous(), q.contiguous(), torch.zeros(1, 10))
+        fx_min, x_feet = 0.0, []
+        for i in range(25):
+            sim.step(torch.zeros(1, 10), 0.0, i + 1)
+            fx_min = min(fx_min, sim.tensor("FEET_CONTACT_FORCE")[0, :, 0].min().item())
+            x_feet.append(sim.tensor("FEET_POS")[0, :, 0].max().item())
+        out[mesh] = (fx_min, max(x_feet), sim.tensor("FEET_POS")[0, :, 2].max().item())
+    toe = 0.15          # foremost sole sphere centre ahead of the foot link origin (URDF: x = 0.05 + 0.12 - 0.02)
+    tm_toe, hf_toe = out["trimesh"][1] + toe, out["heightfield"][1] + toe
+    # trimesh: the toe sphere runs on the low ground right up to the face at x = 3.0 (the ramp band is its last 2.5 cm) and stops
+    assert 2.96 < tm_toe < 3.0 and out["trimesh"][0] < -50.0, out
+    # heightfield: the one-cell ramp starts at x = 2.9: the toe is caught there, 7-8 cm earlier, and lifted
+    assert hf_toe < tm_toe - 0.05 and out["heightfield"][0] < -50.0 and out["heightfield"][2] > out["trimesh"][2] + 0.02, out
+
+
+def test_frictionless_slope_slides_downhill():
+    """Terrain normal from the gradient of the patch: on a frictionless 0.3 slope the robot accelerates downhill at about
+    g sin(theta) cos(theta) horizontally (a vertical-only contact force would leave it standing)."""
+    slope = 0.3
+    hs = (np.arange(120)[:, None] * (slope * 0.1 / 0.005) * np.ones((1, 40))).astype(np.int16)
+    sim, cfg, meta = _terrain_sim(hs, "heightfield", friction=0.0)
+    x0 = 6.0
+    root = torch.zeros(1, 13); root[0, 0] = x0; root[0, 1] = 2.0; root[0, 2] = slope * x0 + 0.90; root[0, 6] = 1.0
+    q = torch.tensor([[0, 0, -0.2618, 0.5236, -0.2618] * 2], dtype=torch.float32)
+    sim.set_state(root.contiguous(), q.contiguous(), torch.zeros(1, 10))
+    for i in range(8):                    # 0.16 s (the level-torso stance tips over on the slope soon after)
+        sim.step(torch.zeros(1, 10), 0.0, i + 1)
+    e = sim.energy(0)
+    vx = e["P"][0] / e["mass"]            # horizontal velocity of the centre of mass
+    th = np.arctan(slope)
+    want = -G9 * np.sin(th) * np.cos(th) * 0.16
+    assert 1.15 * want < vx < 0.6 * want, (vx, want)     # downhill (-x), the right size

@@ -126,6 +126,7 @@ class Config(C.Structure):
         ("height_samples", C.c_void_p),
         ("hf_rows", i32), ("hf_cols", i32),
         ("horizontal_scale", f32), ("vertical_scale", f32), ("border_size", f32),
+        ("vertical_faces", i32), ("slope_threshold", f32),
         ("curriculum", i32), ("num_terrain_rows", i32), ("num_terrain_cols", i32),
         ("max_init_terrain_level", i32),
         ("terrain_origins", C.c_void_p),

@@ -549,6 +549,8 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     P.hf_rows = c.hf_rows; P.hf_cols = c.hf_cols;
     P.horizontal_scale = c.horizontal_scale; P.vertical_scale = c.vertical_scale; P.border_size = c.border_size;
     P.inv_hscale = 1.0f / c.horizontal_scale;
+    P.vertical_faces = c.vertical_faces; P.riser_thr = c.slope_threshold * c.horizontal_scale / c.vertical_scale;
+    P.hv_scale = c.vertical_scale / c.horizontal_scale;
     P.curriculum = c.curriculum; P.num_terrain_rows = c.num_terrain_rows; P.num_terrain_cols = c.num_terrain_cols;
     P.terrain_length = c.terrain_length;
     memcpy(P.torso_rot, m.torso_rot, sizeof P.torso_rot);

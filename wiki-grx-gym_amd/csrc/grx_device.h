@@ -89,6 +89,8 @@ struct KParams {
     int32_t terrain_type, measure_heights, nh;
     const int16_t* hf; int32_t hf_rows, hf_cols;
     const float* coarse_max; int32_t coarse_rows, coarse_cols;   // dilated block-max of the raster [m]: sphere culling
+    int32_t vertical_faces; float riser_thr;       // mesh_type 'trimesh': raster steps above riser_thr [raster units] are vertical faces
+    float hv_scale;                                // vertical_scale / horizontal_scale (terrain gradient)
     float bounce_threshold, terrain_restitution;   // legged_robot_config.py:48, :79
     int32_t self_collisions;     // links collide with each other (legged_robot_config.py:121)
     uint64_t sp_mask;            // bit (a * 8 + b): shape 8 + a of the LEFT lane and shape 8 + b of the RIGHT lane can touch (self-collision)

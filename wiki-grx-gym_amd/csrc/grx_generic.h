@@ -91,18 +91,23 @@ GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, 
     float vimp = 0.f;
     if (wz - r <= hmax) {
         const float wx = O.x + xr.x, wy = O.y + xr.y;
-        const float d = terrain_height<HF>(P, wx, wy) + r - wz;
-        if (d > 0.0f) {
+        float gx, gy;
+        const float dv = terrain_height<HF>(P, wx, wy, gx, gy) + r - wz;
+        if (dv > 0.0f) {
             touching = true;
+            const float nn = grx_rsq(1.0f + gx * gx + gy * gy);   // surface normal from the gradient (fast kernel: sphere_contact)
+            const V3 n = v3(-gx * nn, -gy * nn, nn);
+            const float d = dv * nn;
             const V3 u = v + cross(w, xr);
+            const float un = dot(u, n);
             float cd = fminf(P.kn * d * P.dn, T.sdmax[i]);
             if (slot >= 0) {   // restitution (same rule as the fast kernel's sphere_contact)
                 vimp = P.anchors[(size_t)(slot * 3 + 2) * N + e];
-                if (vimp == 0.f) vimp = fmaxf(fmaxf(-u.z, 0.0f), 1e-6f);
-                if (u.z > 0.0f && vimp > P.bounce_threshold) cd *= om_e;
+                if (vimp == 0.f) vimp = fmaxf(fmaxf(-un, 0.0f), 1e-6f);
+                if (un > 0.0f && vimp > P.bounce_threshold) cd *= om_e;
             }
-            const float fn = fmaxf(P.kn * d - cd * u.z, 0.0f);
-            F.z = fn;
+            const float fn = fmaxf(P.kn * d - cd * un, 0.0f);
+            F = n * fn;
             const float fmax = mu * fn;
             if (slot >= 0) {
                 float* an = P.anchors + (size_t)(slot * 3) * N + e;
@@ -118,11 +123,11 @@ GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, 
                     ayy = wy + fty * P.inv_kt;
                 }
                 an[0] = axx; an[N] = ayy;
-                F.x = ftx; F.y = fty;
+                F.x += ftx; F.y += fty;
             } else {
                 const float sp = grx_sqrt(u.x * u.x + u.y * u.y);
                 const float ft = fminf(P.cv * sp, fmax);
-                if (sp > 1e-9f) { const float k = -ft * grx_rcp(sp); F.x = k * u.x; F.y = k * u.y; }
+                if (sp > 1e-9f) { const float k = -ft * grx_rcp(sp); F.x += k * u.x; F.y += k * u.y; }
             }
         }
     }

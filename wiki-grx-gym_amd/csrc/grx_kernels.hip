@@ -74,9 +74,21 @@ GRX_DEV void grx_sincos(float x, float& s, float& c) {
     c = __cosf(x);
 }
 
-// physics terrain query: bilinear interpolation of the int16 heightfield (oracle: terrain_height)
+// physics terrain query (oracle: terrain_query): bilinear patch of the int16 heightfield -> height and gradient
+// (gx, gy) = (dh/dx, dh/dy) of the surface under (x, y).  mesh_type 'trimesh' (P.vertical_faces): along an axis whose raster
+// step exceeds the slope threshold the weight is sharpened to a ramp over the last quarter cell before the HIGH vertex --
+// the height-function stand-in for the vertical face the reference's slope-corrected mesh has there
+// (isaacgym terrain_utils.py:286-350); with the normal taken from the gradient the riser pushes back horizontally.
+constexpr float kRiserBand = 0.25f;
+GRX_DEV float riser_weight(float t, float jump, float thr, float& dt) {
+    dt = 1.0f;
+    if (jump > thr) { dt = t <= 1.0f - kRiserBand ? 0.0f : 1.0f / kRiserBand; return t <= 1.0f - kRiserBand ? 0.0f : (t - (1.0f - kRiserBand)) * (1.0f / kRiserBand); }
+    if (-jump > thr) { dt = t >= kRiserBand ? 0.0f : 1.0f / kRiserBand; return t >= kRiserBand ? 1.0f : t * (1.0f / kRiserBand); }
+    return t;
+}
 template <bool HF>
-GRX_DEV float terrain_height(KP P, float x, float y) {
+GRX_DEV float terrain_height(KP P, float x, float y, float& gx, float& gy) {
+    gx = 0.0f; gy = 0.0f;
     if (!HF) return 0.0f;
     float fx = (x + P.border_size) * P.inv_hscale;
     float fy = (y + P.border_size) * P.inv_hscale;
@@ -86,7 +98,16 @@ GRX_DEV float terrain_height(KP P, float x, float y) {
     float tx = fx - (float)ix, ty = fy - (float)iy;
     const int16_t* H = P.hf + (size_t)ix * P.hf_cols + iy;
     float h00 = (float)H[0], h01 = (float)H[1], h10 = (float)H[P.hf_cols], h11 = (float)H[P.hf_cols + 1];
+    float dtx = 1.0f, dty = 1.0f;
+    if (P.vertical_faces) {   // uniform
+        const float ax0 = h10 - h00, ax1 = h11 - h01, ay0 = h01 - h00, ay1 = h11 - h10;
+        const float ax = fabsf(ax0) > fabsf(ax1) ? ax0 : ax1, ay = fabsf(ay0) > fabsf(ay1) ? ay0 : ay1;   // the steeper edge decides for the cell
+        tx = riser_weight(tx, ax, P.riser_thr, dtx);
+        ty = riser_weight(ty, ay, P.riser_thr, dty);
+    }
     float h = (h00 * (1.0f - tx) + h10 * tx) * (1.0f - ty) + (h01 * (1.0f - tx) + h11 * tx) * ty;
+    gx = ((h10 - h00) * (1.0f - ty) + (h11 - h01) * ty) * dtx * P.hv_scale;
+    gy = ((h01 - h00) * (1.0f - tx) + (h11 - h10) * tx) * dty * P.hv_scale;
     return h * P.vertical_scale;
 }
 
@@ -127,10 +148,11 @@ __device__ constexpr int kSphOff[LEG] = {8, 8, 8, 10, 12};
 // Centre of a sphere relative to O and the terrain height under it.  The heightfield gathers are issued for every
 // lane, unconditionally (indices are clamped), so that a group's lookups are all in flight together instead of one
 // exposed memory latency per sphere inside divergent branches.
+struct TerrainAt { float h, gx, gy; };   // height and gradient of the terrain under a sphere centre
 template <bool HF>
-GRX_DEV void sphere_probe(KP P, const SphC& S, const R3& R, V3 rho, V3 O, V3& xr, float& th) {
+GRX_DEV void sphere_probe(KP P, const SphC& S, const R3& R, V3 rho, V3 O, V3& xr, TerrainAt& th) {
     xr = rho + rot(R, v3(S.x, S.y, S.z));
-    th = terrain_height<HF>(P, O.x + xr.x, O.y + xr.y);
+    th.h = terrain_height<HF>(P, O.x + xr.x, O.y + xr.y, th.gx, th.gy);
 }
 
 // One sphere against the terrain.  R/rho/w/v: rotation, origin (relative to the base origin O), angular
@@ -138,7 +160,7 @@ GRX_DEV void sphere_probe(KP P, const SphC& S, const R3& R, V3 rho, V3 O, V3& xr
 // sphere (compile time), -1 for the other shapes.  xr = sphere centre relative to O, th = terrain height under it
 // (sphere_probe).  Returns the world-frame force.
 template <bool HF, int SLOT>
-GRX_DEV V3 sphere_contact(KP P, const SphC& S, V3 w, V3 v, V3 O, float mu, float hmax, LaneState& st, V3 xr, float th, float om_e = 1.0f) {
+GRX_DEV V3 sphere_contact(KP P, const SphC& S, V3 w, V3 v, V3 O, float mu, float hmax, LaneState& st, V3 xr, const TerrainAt& th, float om_e = 1.0f) {
     V3 F = v3(0.f, 0.f, 0.f);
     const float wz = O.z + xr.z;
     // cull: hmax bounds the terrain height anywhere the robot can reach during this policy step
@@ -146,19 +168,25 @@ GRX_DEV V3 sphere_contact(KP P, const SphC& S, V3 w, V3 v, V3 O, float mu, float
     bool touching = false;
     if (wz - S.r <= hmax) {
         const float wx = O.x + xr.x, wy = O.y + xr.y;
-        const float d = th + S.r - wz;
-        if (d > 0.0f) {
+        const float dv = th.h + S.r - wz;   // vertical overlap
+        if (dv > 0.0f) {
             touching = true;
+            // surface normal from the gradient of the patch; overlap along it (locally planar terrain).  Plane: n = (0, 0, 1)
+            const float nn = HF ? grx_rsq(1.0f + th.gx * th.gx + th.gy * th.gy) : 1.0f;
+            const V3 n = HF ? v3(-th.gx * nn, -th.gy * nn, nn) : v3(0.f, 0.f, 1.f);
+            const float d = dv * nn;
             V3 u = v + cross(w, xr);
+            const float un = HF ? dot(u, n) : u.z;   // > 0: separating
             float cd = fminf(P.kn * d * P.dn, S.dmax);  // Hunt-Crossley damping, mass-aware cap (oracle contact_forces())
             if (SLOT >= 0) {   // restitution: a contact that began faster than the bounce threshold keeps (1 - e) of its damping while separating
                 constexpr int sl = SLOT < 0 ? 0 : SLOT;
-                if (!(st.anchor_on & (1u << sl))) st.vimp[sl] = fmaxf(-u.z, 0.0f);
-                if (u.z > 0.0f && st.vimp[sl] > P.bounce_threshold) cd *= om_e;
+                if (!(st.anchor_on & (1u << sl))) st.vimp[sl] = fmaxf(-un, 0.0f);
+                if (un > 0.0f && st.vimp[sl] > P.bounce_threshold) cd *= om_e;
             }
-            float fn = fmaxf(P.kn * d - cd * u.z, 0.0f);
-            F.z = fn;
+            float fn = fmaxf(P.kn * d - cd * un, 0.0f);
+            F = n * fn;
             float fmax = mu * fn;
+            // friction: in the horizontal plane (anchored stick/slip on the foot spheres, viscous-capped elsewhere)
             if (SLOT >= 0) {
                 float axx = st.ax[SLOT < 0 ? 0 : SLOT], ayy = st.ay[SLOT < 0 ? 0 : SLOT];
                 if (!(st.anchor_on & (1u << (SLOT < 0 ? 0 : SLOT)))) { axx = wx; ayy = wy; }
@@ -172,11 +200,11 @@ GRX_DEV V3 sphere_contact(KP P, const SphC& S, V3 w, V3 v, V3 O, float mu, float
                     ayy = wy + fty * P.inv_kt;
                 }
                 st.ax[SLOT < 0 ? 0 : SLOT] = axx; st.ay[SLOT < 0 ? 0 : SLOT] = ayy;
-                F.x = ftx; F.y = fty;
+                F.x += ftx; F.y += fty;
             } else {
                 float sp = grx_sqrt(u.x * u.x + u.y * u.y);
                 float ft = fminf(P.cv * sp, fmax);
-                if (sp > 1e-9f) { float k = -ft * grx_rcp(sp); F.x = k * u.x; F.y = k * u.y; }
+                if (sp > 1e-9f) { float k = -ft * grx_rcp(sp); F.x += k * u.x; F.y += k * u.y; }
             }
         }
     }
@@ -211,11 +239,6 @@ GRX_DEV R3 joint_unrot_k(const R3& R, float c, float s, int ax) {
     return P;
 }
 
-// Contacts of the base-lump shapes (torso, head, arms, ... rigidly attached to the floating base) handled by this
-// lane's side, with per-link netting for termination / collision (legged_robot.py:336-353).  They depend only on
-// the base state at the start of the sub-step, so with W >= 2 waves per block a HELPER WAVE evaluates them while
-// the dynamics wave runs the kinematics / articulated-inertia passes; the wrench enters at the base solve.
-// MIDBAR: the 4-wave block layout has a barrier (#2) in the middle of the sub-step; the helper passes it half-way.
 // GRX_T_CONTACT_FORCES: net contact force of one URDF link.  The tensor shows the LAST sub-step (like the reference's after
 // its last gym.simulate): `last` is wave-uniform, so the nine other sub-steps pay one scalar branch per call site.
 // cf = the env's column of the tensor, nullptr on an inactive lane.
@@ -224,50 +247,6 @@ GRX_DEV void put_link_force(const LinkForceOut& o_, const SphC& S, V3 F) {   // 
     if (o_.last) {
         const int link = sph_link(S);
         if (o_.cf && link >= 0) { float* o = o_.cf + (size_t)(link * 3) * o_.N; o[0] = F.x; o[o_.N] = F.y; o[2 * o_.N] = F.z; }
-    }
-}
-
-template <bool HF, bool MIDBAR>
-GRX_DEV void base_lump_contacts(KP P, const SideConst& C, const R3& R0, V3 O, V3 ang, V3 vel, float mu, float hmax,
-                                V3& f0a, V3& f0l, bool& term, float& pen_count, const LinkForceOut& lfo) {
-    f0a = v3(0.f, 0.f, 0.f); f0l = v3(0.f, 0.f, 0.f);
-    term = false; pen_count = 0.f;
-    LaneState dummy;   // anchors are only touched by foot spheres (SLOT >= 0)
-    dummy.anchor_on = 0;
-    const bool reach = group_within_reach<8>(&C.sph[0], R0, v3(0.f, 0.f, 0.f), O, hmax);
-    V3 Flink = v3(0.f, 0.f, 0.f);
-    const V3 zero = v3(0.f, 0.f, 0.f);
-    V3 lf[8];   // net force of the link that ends at shape i (stored after the loop: no extra branches inside it)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) lf[i] = zero;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (reach) {
-            V3 xrs[4]; float ths[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sphere_probe<HF>(P, C.sph[half * 4 + i], R0, zero, O, xrs[i], ths[i]);
-#pragma unroll
-            for (int i = half * 4; i < half * 4 + 4; ++i) {
-                const SphC& S = C.sph[i];
-                const V3 xr = xrs[i - half * 4];
-                V3 F = sphere_contact<HF, -1>(P, S, ang, vel, O, mu, hmax, dummy, xr, ths[i - half * 4]);
-                f0a = f0a + cross(xr, F);
-                f0l = f0l + F;
-                Flink = Flink + F;
-                if (S.link_last & 1) {   // uniform per side: net force of one URDF link complete
-                    lf[i] = Flink;
-                    float n2 = dot(Flink, Flink);
-                    if ((S.flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term = true;
-                    if ((S.flags & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.0f;
-                    Flink = zero;
-                }
-            }
-        }
-        if (MIDBAR && half == 0) __syncthreads();   // #2
-    }
-    if (lfo.last) {   // GRX_T_CONTACT_FORCES rows of this lane's base-lump links (zeros when nothing was within reach)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) if (C.sph[i].link_last & 1) put_link_force(lfo, C.sph[i], lf[i]);
     }
 }
 
@@ -292,7 +271,7 @@ GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, fl
     fa = v3(0.f, 0.f, 0.f); fl = v3(0.f, 0.f, 0.f);
     constexpr int o = kSphOff[LEG - 1];
     if (group_within_reach<4>(&C.sph[o], K.R, K.rho, O, hmax)) {
-        V3 xr[4], F; float th[4];
+        V3 xr[4], F; TerrainAt th[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) sphere_probe<HF>(P, C.sph[o + i], K.R, K.rho, O, xr[i], th[i]);
         F = sphere_contact<HF, 0>(P, C.sph[o + 0], K.w, K.v, O, mu, hmax, st, xr[0], th[0], om_e); fa = fa + cross(xr[0], F); fl = fl + F;
@@ -300,24 +279,6 @@ GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, fl
         F = sphere_contact<HF, 2>(P, C.sph[o + 2], K.w, K.v, O, mu, hmax, st, xr[2], th[2], om_e); fa = fa + cross(xr[2], F); fl = fl + F;
         F = sphere_contact<HF, 3>(P, C.sph[o + 3], K.w, K.v, O, mu, hmax, st, xr[3], th[3], om_e); fa = fa + cross(xr[3], F); fl = fl + F;
     } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
-}
-
-// the two (unanchored) spheres of chain body k (thigh_pitch / shank)
-template <bool HF>
-GRX_DEV void link_contacts(KP P, const SideConst& C, int k, const ChainKin& K, V3 O, float mu, float hmax, V3& fa, V3& fl) {
-    fa = v3(0.f, 0.f, 0.f); fl = v3(0.f, 0.f, 0.f);
-    LaneState dummy;
-    dummy.anchor_on = 0;
-    if (group_within_reach<2>(&C.sph[kSphOff[k]], K.R, K.rho, O, hmax)) {
-        V3 xr[2]; float th[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) sphere_probe<HF>(P, C.sph[kSphOff[k] + i], K.R, K.rho, O, xr[i], th[i]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            V3 F = sphere_contact<HF, -1>(P, C.sph[kSphOff[k] + i], K.w, K.v, O, mu, hmax, dummy, xr[i], th[i]);
-            fa = fa + cross(xr[i], F); fl = fl + F;
-        }
-    }
 }
 
 #include "grx_rare.h"

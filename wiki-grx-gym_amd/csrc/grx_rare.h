@@ -199,7 +199,7 @@ GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const Rar
                 const float4 om = fb[RC_FR4 * EPB];
                 const float hmax_ = fb[4 * EPB].z;
                 const V3 Ow = v3(om.x, om.y, om.z);
-                V3 xr; float th;
+                V3 xr; TerrainAt th;
                 sphere_probe<HF>(P, S, Fr.R, Fr.rho, Ow, xr, th);
                 LaneState dummy;
                 dummy.anchor_on = 0;

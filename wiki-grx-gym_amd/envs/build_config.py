@@ -158,6 +158,8 @@ def build(cfg, sim_dt, num_envs, env_offset=0, total_envs=None, seed=1, terrain=
         c.curriculum = int(t.curriculum)
         c.num_terrain_rows, c.num_terrain_cols = int(t.num_rows), int(t.num_cols)
         c.max_init_terrain_level = int(t.max_init_terrain_level)
+        c.vertical_faces = int(t.mesh_type == "trimesh")     # legged_robot.py:903-921: the slope-corrected mesh
+        c.slope_threshold = float(getattr(t, "slope_treshold", 0.75) or 0.75)
     else:
         raise ValueError(f"Terrain mesh type '{t.mesh_type}' not supported (plane, heightfield, trimesh)")
     meta["dt"] = dt
