@@ -323,6 +323,11 @@ typedef struct grx_step_args {
                                   counter % push_interval == 0 (legged_robot.py:333) */
     const float* noise_uniform;/* device (N, num_obs) uniforms in [0,1) replacing the internal
                                   Philox stream for obs noise (parity tests); NULL = internal */
+    float* obs_out;            /* device (N, num_obs) row-major: this step's observations go HERE instead of GRX_T_OBS */
+    float* pri_obs_out;        /* device (N, num_pri_obs): likewise for GRX_T_PRI_OBS.  NULL = the library's buffer.  The env
+                                  wrapper alternates between two buffers: the reference hands out a FRESH obs tensor every
+                                  step (torch.cat / torch.clip, gr1t1.py:282, legged_robot.py:241) and rsl_rl keeps the one it
+                                  acted on until after env.step() (ppo.py:160-161, 194) -- without a copy per step */
 } grx_step_args;
 
 /* create / destroy.  device_id: HIP device ordinal. */

@@ -36,6 +36,25 @@ int grx_ppo_loss(int batch, int num_actions, const float* mu, const float* std, 
 int grx_ppo_colsum_partials_size(int rows, int cols);
 int grx_ppo_colsum(int rows, int cols, const float* x, float* out, float* partials, void* stream);
 
+/* One rollout step's bookkeeping in ONE launch (rsl_rl: PPO.process_env_step ppo.py:184-197 + RolloutStorage.add_transitions
+ * rollout_storage.py:23-59 + the runner's running episode reward / length, on_policy_runner.py:170-181 -- ~25 small torch
+ * kernels per env step otherwise).  All pointers are device pointers; N envs.
+ *   in : obs (N, num_obs), pri (N, num_pri) or NULL, actions / mu / sigma (N, num_actions), values / logp / rewards (N),
+ *        dones / time_outs (N) uint8 (time_outs may be NULL), gamma
+ *   out: the storage rows of this step, each contiguous: st_obs (N, num_obs), st_pri (N, num_pri) or NULL, st_actions / st_mu /
+ *        st_sigma (N, num_actions), st_values / st_logp / st_rewards (N), st_dones (N) uint8.
+ *        st_rewards = rewards + gamma * values * time_outs  (bootstrap on time-outs, ppo.py:190-191)
+ *   logging (all four may be NULL): cur_rew / cur_len (N) running sums, updated in place and zeroed where done; done_rew /
+ *        done_len (N): the finished episode's totals where done (left untouched elsewhere).
+ * Returns 0, negative for invalid sizes. */
+int grx_ppo_store_transition(int N, int num_obs, int num_pri, int num_actions,
+                             const float* obs, const float* pri, const float* actions, const float* mu, const float* sigma,
+                             const float* values, const float* logp, const float* rewards, const unsigned char* dones,
+                             const unsigned char* time_outs, float gamma,
+                             float* st_obs, float* st_pri, float* st_actions, float* st_mu, float* st_sigma, float* st_values,
+                             float* st_logp, float* st_rewards, unsigned char* st_dones,
+                             float* cur_rew, float* cur_len, float* done_rew, float* done_len, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

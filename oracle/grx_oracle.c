@@ -956,8 +956,8 @@ static void publish(struct grx_sim* s);
 static void build_observations(struct grx_sim* s, env_t* e, int le, const grx_step_args* args, uint32_t step) {
     const grx_config* c = &s->cfg;
     int nd = s->nd, nh = c->measure_heights ? c->num_height_points : 0;
-    float* obs = s->t_obs + (size_t)le * c->num_obs;
-    float* pri = s->t_pri + (size_t)le * c->num_pri_obs;
+    float* obs = ((args && args->obs_out) ? args->obs_out : s->t_obs) + (size_t)le * c->num_obs;
+    float* pri = ((args && args->pri_obs_out) ? args->pri_obs_out : s->t_pri) + (size_t)le * c->num_pri_obs;
     /* compute_observation_variables legged_robot_fftai.py:148-167 (uses post-reset root z, pre-reset heights) */
     real sum = 0, sur[GRX_MAX_HEIGHT_POINTS];
     for (int k = 0; k < nh; ++k) {

@@ -197,3 +197,103 @@ def test_graphed_policy_step_matches_eager():
         with torch.no_grad():   # an optimizer step in between: the graph must see the new weights
             for p in ac.parameters():
                 p.add_(0.01 * torch.randn_like(p))
+
+
+def test_fused_transition_store_matches_the_torch_bookkeeping():
+    """grx_ppo_store_transition (one kernel per rollout step) against PPO.process_env_step + RolloutStorage.add_transitions +
+    the runner's running episode sums spelled in torch (rsl_rl ppo.py:184-197, rollout_storage.py:23-59,
+    on_policy_runner.py:170-181): identical storage rows and logging buffers, three steps, time-out bootstrap included."""
+    from wiki_grx_gym_amd.rl.ppo import PPO
+    from wiki_grx_gym_amd.rl.modules import ActorCriticMLP
+    dev = "cuda:0"
+    N, T, no, npri, na = 300, 3, 39, 168, 10
+    out = {}
+    for fused in ("1", "0"):
+        os.environ["GRX_PPO_FUSED_STORE"] = fused
+        torch.manual_seed(0)
+        ac = ActorCriticMLP(no, npri, na, actor_hidden_dims=[32, 16], critic_hidden_dims=[32, 16], activation="elu", init_noise_std=0.2)
+        alg = PPO(actor_critic=ac, gamma=0.99, device=dev)
+        alg._use_act_graph = False
+        alg.init_storage(N, T)
+        g = torch.Generator(device=dev).manual_seed(1)
+        cur_rew, cur_len = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+        done_rew, done_len = torch.zeros(T, N, device=dev), torch.zeros(T, N, device=dev)
+        with torch.inference_mode():
+            for t in range(T):
+                obs = torch.randn(N, no, device=dev, generator=g); pri = torch.randn(N, npri, device=dev, generator=g)
+                torch.manual_seed(10 + t)
+                alg.act(obs, pri)
+                rew = torch.randn(N, device=dev, generator=g)
+                dones = torch.rand(N, device=dev, generator=g) < 0.2
+                to = dones & (torch.rand(N, device=dev, generator=g) < 0.5)
+                alg.process_env_step(rew, dones, {"time_outs": to}, log=(cur_rew, cur_len, done_rew[t], done_len[t]))
+        st = alg.storage
+        assert st.step == T
+        out[fused] = {k: getattr(st, k).clone() for k in ("observations", "pri_observations", "actions", "mu", "sigma", "values", "actions_log_prob", "rewards", "dones")}
+        m = st.dones.squeeze(-1).bool()
+        out[fused].update(cur_rew=cur_rew.clone(), cur_len=cur_len.clone(), done_rew=done_rew[m].clone(), done_len=done_len[m].clone())
+    os.environ.pop("GRX_PPO_FUSED_STORE", None)
+    assert out["1"]["dones"].sum() > 10
+    for k in out["1"]:
+        assert torch.equal(out["1"][k], out["0"][k]), k
+
+
+def _toy_alg(seed=0):
+    torch.manual_seed(seed)
+    ac = ActorCriticMLP(39, 168, 10, actor_hidden_dims=[64, 32], critic_hidden_dims=[64, 32], activation="elu", init_noise_std=0.2, set_std=False)
+    alg = PPO(actor_critic=ac, num_learning_epochs=2, num_mini_batches=4, clip_param=0.2, gamma=0.99, lam=0.95, value_loss_coef=1.0,
+              entropy_coef=0.01, learning_rate=1e-5, learning_rate_min=1e-6, learning_rate_max=1e-2, max_grad_norm=1.0,
+              use_clipped_value_loss=True, schedule="adaptive", desired_kl=0.03, device="cuda:0")
+    alg.init_storage(256, 8)
+    return alg
+
+
+def _toy_rollout(alg, seed):
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    with torch.inference_mode():
+        for t in range(8):
+            obs = torch.randn(256, 39, device="cuda:0", generator=g); pri = torch.randn(256, 168, device="cuda:0", generator=g)
+            torch.manual_seed(100 * seed + t)
+            alg.act(obs, pri)
+            alg.process_env_step(torch.randn(256, device="cuda:0", generator=g), torch.rand(256, device="cuda:0", generator=g) < 0.05, {})
+        alg.compute_returns(torch.randn(256, 168, device="cuda:0", generator=g))
+
+
+def test_resume_keeps_the_adaptive_learning_rate_alive(tmp_path):
+    """runner.load() on a HIP device: after optimizer.load_state_dict the learning rate Adam uses must still be the
+    device scalar the adaptive-KL rule writes, captured graphs must be dropped, std must be copied in place.  A resumed
+    trainer continues bit for bit like the one that never stopped -- and its learning rate keeps moving."""
+    a = _toy_alg()
+    for it in range(2):
+        _toy_rollout(a, it); torch.manual_seed(7 + it); a.update(); a.clear_storage()
+    ckpt = {"model": {k: v.clone() for k, v in a.actor_critic.state_dict().items()}, "opt": a.optimizer.state_dict()}
+    torch.save(ckpt, tmp_path / "c.pt")
+    lr_at_save = a.learning_rate
+    for it in range(2, 4):
+        _toy_rollout(a, it); torch.manual_seed(7 + it); a.update(); a.clear_storage()
+    b = _toy_alg(seed=5)                                   # different initial weights: everything must come from the checkpoint
+    _toy_rollout(b, 9); b.update(); b.clear_storage()     # ... and graphs captured BEFORE the load must not survive it
+    std_storage = b.actor_critic.std.data_ptr()
+    ck = torch.load(tmp_path / "c.pt", map_location="cuda:0", weights_only=False)
+    b.actor_critic.load_state_dict(ck["model"]); b.invalidate_graphs(); b.load_optimizer_state(ck["opt"])
+    assert b.actor_critic.std.data_ptr() == std_storage
+    assert b.optimizer.param_groups[0]["lr"] is b._lr_t and abs(b.learning_rate - lr_at_save) < 1e-12
+    assert b._graph is None and b._act_graph is None
+    _toy_rollout(b, 99); b.clear_storage()                 # (recapture the policy graphs here: the capturing call draws its noise
+                                                           #  at a different Philox offset than a replay does)
+    for it in range(2, 4):
+        _toy_rollout(b, it); torch.manual_seed(7 + it); b.update(); b.clear_storage()
+    assert b.learning_rate != lr_at_save                   # the adaptive rule still reaches the optimizer
+    assert abs(b.learning_rate - a.learning_rate) < 1e-12
+    for (n, p), q in zip(a.actor_critic.named_parameters(), b.actor_critic.parameters()):
+        assert torch.equal(p, q), n
+    # a reference-style checkpoint (python-float lr, not capturable) is coerced as well
+    sd = a.optimizer.state_dict()
+    sd["param_groups"][0].update(lr=3e-4, capturable=False, fused=None)
+    for st in sd["state"].values():
+        st["step"] = st["step"].cpu() if torch.is_tensor(st["step"]) else st["step"]
+    b.load_optimizer_state(sd)
+    g = b.optimizer.param_groups[0]
+    assert g["lr"] is b._lr_t and abs(float(b._lr_t) - 3e-4) < 1e-10 and g["capturable"] and g["fused"]
+    _toy_rollout(b, 11); b.update()
+    assert all(torch.isfinite(p).all() for p in b.actor_critic.parameters())

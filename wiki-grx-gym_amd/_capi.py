@@ -141,7 +141,8 @@ class TensorDesc(C.Structure):
 
 class StepArgs(C.Structure):
     _fields_ = [("actions", C.c_void_p), ("delay_substeps", f32),
-                ("common_step_counter", i64), ("noise_uniform", C.c_void_p)]
+                ("common_step_counter", i64), ("noise_uniform", C.c_void_p),
+                ("obs_out", C.c_void_p), ("pri_obs_out", C.c_void_p)]
 
 
 class PipelineState(C.Structure):

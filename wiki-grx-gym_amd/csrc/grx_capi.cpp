@@ -18,10 +18,10 @@
 
 extern "C" {
 void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
-                     const float* noise, hipStream_t stream);
+                     const float* noise, float* obs_out, float* pri_out, hipStream_t stream);
 void grx_launch_finalize(const KParams* dP, int nblocks, int64_t* progress, int64_t ticket, hipStream_t stream);
 int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int lds_bytes, int heightfield, const float* actions,
-                            float delay, long long common_step, const float* noise, hipStream_t stream);
+                            float delay, long long common_step, const float* noise, float* obs_out, float* pri_out, hipStream_t stream);
 void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, hipStream_t stream);
 int grx_generic_tables_size(void);
 int grx_generic_ws_floats_per_env(int nb, int nlc);
@@ -837,12 +837,12 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
     if (s->generic)
     {
         if (grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->gen_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions,
-                                    a->delay_substeps, (long long)a->common_step_counter, a->noise_uniform, st))
+                                    a->delay_substeps, (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, st))
             return fail(GRX_ERR_HIP, "grx_step: cannot raise the dynamic LDS limit of the generic kernel");
     }
     else
         grx_launch_step(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
-                        (long long)a->common_step_counter, a->noise_uniform, st);
+                        (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, st);
     if (timed) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->timing.pending.push_back(ev);

@@ -392,7 +392,7 @@ GRX_DEV float gen_masked_abs_sum(const float* a, size_t N, int nd, uint32_t mask
 template <bool HF>
 __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict__ Pg, const GenTables* __restrict__ Tg, float* __restrict__ wsg,
                                                        const float* __restrict__ actions_in, float delay, long long common_step,
-                                                       const float* __restrict__ noise_in) {
+                                                       const float* __restrict__ noise_in, float* __restrict__ obs_out, float* __restrict__ pri_out) {
     KP P = GRX_PARAMS(Pg);
     GT T = *reinterpret_cast<const GRX_AS4 GenTables*>(reinterpret_cast<uintptr_t>(Tg));
     __shared__ float s_stat[NT + 1];
@@ -664,8 +664,8 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
         ep_len = 0;
     }
     // ---- compute_observations (legged_robot_fftai.py:148-167, gr1t1.py:281-336)
-    float* obs = P.obs + (size_t)e * nobs;
-    float* pri = P.pri_obs + (size_t)e * npri;
+    float* obs = (obs_out ? obs_out : P.obs) + (size_t)e * nobs;
+    float* pri = (pri_out ? pri_out : P.pri_obs) + (size_t)e * npri;
     const float clipo = P.clip_observations;
     float bho = 0.f;
     {

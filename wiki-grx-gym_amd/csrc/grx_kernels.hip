@@ -960,7 +960,7 @@ enum DbgRow { DBG_FEET_FORCE = 0, DBG_FEET_POS = 6, DBG_AVG_FORCE = 12, DBG_AVG_
 template <bool HF, int W, bool DBG = false>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE, GRX_WPE))) void grx_step_kernel(const KParams* __restrict__ Pg, const float* __restrict__ actions_in,
                                                       float delay, long long common_step, const float* __restrict__ noise_in,
-                                                      const float* __restrict__ dbg) {
+                                                      const float* __restrict__ dbg, float* __restrict__ obs_out, float* __restrict__ pri_out) {
     static_assert(!DBG || W == 1, "the debug injection path exists for the one-wave layout only");
     KP P = GRX_PARAMS(Pg);
     constexpr int NTHR = 64 * W;
@@ -1501,7 +1501,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     {
         const int e0 = blockIdx.x * EPB;
         const int nenv = min(EPB, N - e0);
-        float* gobs = P.obs + (size_t)e0 * GRX_NUM_OBS;
+        float* gobs = (obs_out ? obs_out : P.obs) + (size_t)e0 * GRX_NUM_OBS;   // grx_step_args.obs_out: the caller's buffer (no copy per step)
         const int tot = nenv * GRX_NUM_OBS;
         if (nenv == EPB) {
             const float4* s4 = reinterpret_cast<const float4*>(s_obs);
@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             for (int i = tid; i < EPB * GRX_NUM_OBS / 4; i += NTHR) g4[i] = s4[i];
         } else
             for (int i = tid; i < tot; i += NTHR) gobs[i] = s_obs[i];
-        float* gpri = P.pri_obs + (size_t)e0 * npri;
+        float* gpri = (pri_out ? pri_out : P.pri_obs) + (size_t)e0 * npri;
         if (npri == GRX_MAX_PRI && nenv == EPB) {
             const float2* s2 = reinterpret_cast<const float2*>(s_pri);
             float2* g2 = reinterpret_cast<float2*>(gpri);
@@ -1624,9 +1624,9 @@ __global__ void grx_set_state_kernel(const KParams* __restrict__ Pg, const float
 // host-callable launchers (grx_capi.cpp is compiled by hipcc too; kept separate for readability)
 // waves: waves per 32-env block (1, 2 or 4; grx_capi.cpp picks the largest that still gives every wave its own SIMD)
 extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
-                                const float* noise, hipStream_t stream) {
+                                const float* noise, float* obs_out, float* pri_out, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-#define GRX_LAUNCH_STEP(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr)
+#define GRX_LAUNCH_STEP(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out)
     if (heightfield) { if (waves == 4) GRX_LAUNCH_STEP(true, 4); else if (waves == 2) GRX_LAUNCH_STEP(true, 2); else GRX_LAUNCH_STEP(true, 1); }
     else { if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
 #undef GRX_LAUNCH_STEP
@@ -1635,13 +1635,14 @@ extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, int w
 extern "C" void grx_launch_step_debug(const KParams* dP, int N, int heightfield, const float* actions, long long common_step, const float* noise,
                                       const float* dbg, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    if (heightfield) hipLaunchKernelGGL((grx_step_kernel<true, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg);
-    else hipLaunchKernelGGL((grx_step_kernel<false, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg);
+    if (heightfield) hipLaunchKernelGGL((grx_step_kernel<true, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr);
+    else hipLaunchKernelGGL((grx_step_kernel<false, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr);
 }
 extern "C" int grx_debug_rows(void) { return DBG_ROWS; }
 // epb: envs per block (= threads per block, at most 64); lds_bytes > 0: the per-body workspace lives in (dynamic) LDS
 extern "C" int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int lds_bytes, int heightfield,
-                                       const float* actions, float delay, long long common_step, const float* noise, hipStream_t stream) {
+                                       const float* actions, float delay, long long common_step, const float* noise, float* obs_out, float* pri_out,
+                                       hipStream_t stream) {
     const int nblocks = (N + epb - 1) / epb;
     const GenTables* T = static_cast<const GenTables*>(tables);
     if (lds_bytes > 0) {
@@ -1653,8 +1654,8 @@ extern "C" int grx_launch_step_generic(const KParams* dP, const void* tables, fl
         }
         ws = nullptr;
     }
-    if (heightfield) hipLaunchKernelGGL(grx_step_generic<true>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise);
-    else hipLaunchKernelGGL(grx_step_generic<false>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise);
+    if (heightfield) hipLaunchKernelGGL(grx_step_generic<true>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise, obs_out, pri_out);
+    else hipLaunchKernelGGL(grx_step_generic<false>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise, obs_out, pri_out);
     return 0;
 }
 extern "C" void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, hipStream_t stream) {

@@ -195,3 +195,54 @@ extern "C" int grx_ppo_loss(int batch, int num_actions, const float* mu, const f
     hipLaunchKernelGGL(ppo_loss_finalize, dim3(1), dim3(64), 0, st, batch, num_actions, nblk, (const double*)partials, std, value_loss_coef, entropy_coef, out, d_std);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+// ---- grx_ppo_store_transition: one rollout step's bookkeeping in one launch -----------------------------------------
+// Rows: the (N, k) blocks are contiguous, so the copies are flat; every thread walks the concatenated index space
+// [obs | pri | actions | mu | sigma] with a grid stride, then the per-env scalars.
+struct StoreArgs {
+    int N, no, np, na;
+    const float *obs, *pri, *actions, *mu, *sigma, *values, *logp, *rewards;
+    const unsigned char *dones, *time_outs;
+    float gamma;
+    float *st_obs, *st_pri, *st_actions, *st_mu, *st_sigma, *st_values, *st_logp, *st_rewards;
+    unsigned char* st_dones;
+    float *cur_rew, *cur_len, *done_rew, *done_len;
+};
+__global__ __launch_bounds__(256) void store_transition_kernel(StoreArgs a) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n_obs = (size_t)a.N * a.no, n_pri = a.pri ? (size_t)a.N * a.np : 0, n_act = (size_t)a.N * a.na;
+    for (size_t i = tid; i < n_obs; i += stride) a.st_obs[i] = a.obs[i];
+    for (size_t i = tid; i < n_pri; i += stride) a.st_pri[i] = a.pri[i];
+    for (size_t i = tid; i < n_act; i += stride) { a.st_actions[i] = a.actions[i]; a.st_mu[i] = a.mu[i]; a.st_sigma[i] = a.sigma[i]; }
+    for (size_t i = tid; i < (size_t)a.N; i += stride) {
+        const float v = a.values[i], r = a.rewards[i];
+        const bool done = a.dones[i] != 0, to = a.time_outs && a.time_outs[i] != 0;
+        a.st_values[i] = v;
+        a.st_logp[i] = a.logp[i];
+        a.st_rewards[i] = r + (to ? a.gamma * v : 0.0f);   // rewards + gamma * values * time_outs (ppo.py:190-191)
+        a.st_dones[i] = done ? 1 : 0;
+        if (a.cur_rew) {   // on_policy_runner.py:170-181 without the nonzero() + .cpu() per step
+            const float cr = a.cur_rew[i] + r, cl = a.cur_len[i] + 1.0f;
+            if (done) { a.done_rew[i] = cr; a.done_len[i] = cl; }
+            a.cur_rew[i] = done ? 0.0f : cr;
+            a.cur_len[i] = done ? 0.0f : cl;
+        }
+    }
+}
+extern "C" int grx_ppo_store_transition(int N, int num_obs, int num_pri, int num_actions,
+                                        const float* obs, const float* pri, const float* actions, const float* mu, const float* sigma,
+                                        const float* values, const float* logp, const float* rewards, const unsigned char* dones,
+                                        const unsigned char* time_outs, float gamma,
+                                        float* st_obs, float* st_pri, float* st_actions, float* st_mu, float* st_sigma, float* st_values,
+                                        float* st_logp, float* st_rewards, unsigned char* st_dones,
+                                        float* cur_rew, float* cur_len, float* done_rew, float* done_len, void* stream) {
+    if (N < 1 || num_obs < 1 || num_actions < 1 || (pri && num_pri < 1)) return -1;
+    if ((cur_rew != nullptr) != (cur_len != nullptr) || (cur_rew != nullptr) != (done_rew != nullptr) || (cur_rew != nullptr) != (done_len != nullptr)) return -1;
+    StoreArgs a = {N, num_obs, num_pri, num_actions, obs, pri, actions, mu, sigma, values, logp, rewards, dones, time_outs, gamma,
+                   st_obs, st_pri, st_actions, st_mu, st_sigma, st_values, st_logp, st_rewards, st_dones, cur_rew, cur_len, done_rew, done_len};
+    const size_t work = (size_t)N * (size_t)(num_pri > num_obs ? num_pri : num_obs);
+    int blocks = (int)((work + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(store_transition_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -106,10 +106,15 @@ class GRxEnv:
         # obs_buf / pri_obs_buf are REBOUND to fresh tensors every step, as in the reference (torch.cat / torch.clip
         # create new tensors, gr1t1.py:282, legged_robot.py:241): rsl_rl keeps a reference to the observation it
         # acted on until after env.step() (ppo.py:160-161, 194), so handing out the live library view would alias.
+        # Here: no copy either -- the step kernel writes straight into one of TWO buffers the wrapper alternates between
+        # (grx_step_args.obs_out / pri_obs_out): the tensor handed out by step t stays intact until step t + 2.
         self._obs_view = t("OBS")
         self._pri_view = t("PRI_OBS") if self.num_pri_obs is not None else None
-        self.obs_buf = self._obs_view.clone()
-        self.pri_obs_buf = self._pri_view.clone() if self._pri_view is not None else None
+        self._obs_ring = [torch.zeros_like(self._obs_view) for _ in range(2)]
+        self._pri_ring = [torch.zeros_like(self._pri_view) for _ in range(2)] if self._pri_view is not None else None
+        self._ring = 0
+        self.obs_buf = self._obs_ring[1]
+        self.pri_obs_buf = self._pri_ring[1] if self._pri_ring is not None else None
         self.rew_buf = t("REW")
         self._reset_u8 = t("RESET")
         self._timeout_u8 = t("TIME_OUT")
@@ -186,10 +191,13 @@ class GRxEnv:
         if delay is None:
             delay = max(0.0, float(self._delay_rng.normal(loc=5, scale=2, size=1)[0]))   # FF:53-54
         self.common_step_counter += 1
-        self._sim.step(a, delay, self.common_step_counter)
-        self.obs_buf = self._obs_view.clone()
-        if self._pri_view is not None:
-            self.pri_obs_buf = self._pri_view.clone()
+        k = self._ring
+        self._ring ^= 1
+        self._sim.step(a, delay, self.common_step_counter, obs_out=self._obs_ring[k],
+                       pri_obs_out=self._pri_ring[k] if self._pri_ring is not None else None)
+        self.obs_buf = self._obs_ring[k]
+        if self._pri_ring is not None:
+            self.pri_obs_buf = self._pri_ring[k]
         self._fill_extras()
         return self.obs_buf, self.pri_obs_buf, self.rew_buf, self.reset_buf, self.extras
 

@@ -31,6 +31,8 @@ def load_ppo_library():
         lib.grx_ppo_colsum.argtypes = [C.c_int, C.c_int, fp, fp, fp, C.c_void_p]
         lib.grx_ppo_colsum_partials_size.restype = C.c_int
         lib.grx_ppo_colsum_partials_size.argtypes = [C.c_int, C.c_int]
+        lib.grx_ppo_store_transition.restype = C.c_int
+        lib.grx_ppo_store_transition.argtypes = [C.c_int] * 4 + [fp] * 10 + [C.c_float] + [fp] * 13 + [C.c_void_p]
         _LIB = lib
     return _LIB
 
@@ -91,3 +93,27 @@ def colsum(x):
     if rc != 0:
         raise RuntimeError(f"grx_ppo_colsum failed ({rc}): {rows} x {cols}")
     return out
+
+
+def store_transition(storage, step, obs, pri, actions, mu, sigma, values, logp, rewards, dones, time_outs, gamma, log=None):
+    """One rollout step's bookkeeping through grx_ppo_store_transition (include/grx_ppo.h): the storage rows of `step`,
+    the time-out bootstrap, and -- log = (cur_rew, cur_len, done_rew_row, done_len_row) -- the runner's episode sums."""
+    lib = load_ppo_library()
+    N = storage.num_envs
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    for t in (obs, pri, actions, mu, sigma, values, logp, rewards):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("store_transition needs contiguous float32 CUDA tensors")
+    d8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones
+    t8 = None if time_outs is None else (time_outs.view(torch.uint8) if time_outs.dtype == torch.bool else time_outs)
+    sp = storage.pri_observations
+    lg = log if log is not None else (None, None, None, None)
+    with torch.cuda.device(obs.device):
+        rc = lib.grx_ppo_store_transition(
+            N, obs.shape[1], pri.shape[1] if (pri is not None and sp is not None) else 0, actions.shape[1],
+            ptr(obs), ptr(pri) if sp is not None else None, ptr(actions), ptr(mu), ptr(sigma), ptr(values), ptr(logp), ptr(rewards), ptr(d8), ptr(t8),
+            float(gamma), ptr(storage.observations[step]), ptr(sp[step]) if sp is not None else None, ptr(storage.actions[step]), ptr(storage.mu[step]),
+            ptr(storage.sigma[step]), ptr(storage.values[step]), ptr(storage.actions_log_prob[step]), ptr(storage.rewards[step]), ptr(storage.dones[step]),
+            ptr(lg[0]), ptr(lg[1]), ptr(lg[2]), ptr(lg[3]), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"grx_ppo_store_transition failed ({rc})")

@@ -117,11 +117,13 @@ class ActorCriticMLP(nn.Module):
         state_dict = dict(state_dict)
         if self.set_std:
             state_dict["std"] = torch.ones_like(state_dict["std"]) * self.set_noise_std
-        else:
-            self.std.data = state_dict["std"]
+        # (the reference rebinds self.std.data here, actor_critic_mlp.py:116-134; copying IN PLACE gives the same values and keeps
+        #  the storage the captured act / update graphs and the optimizer state point at)
         if self.fixed_std:
-            self.std.data = self.init_noise_std * torch.ones_like(self.std.data)
+            with torch.no_grad():
+                self.std.fill_(self.init_noise_std)
             self.std.requires_grad = False
+            state_dict["std"] = self.std.detach().clone()
         return super().load_state_dict(state_dict, strict)
 
     def reset(self, dones=None):

@@ -58,6 +58,7 @@ class PPO:
                 self._use_graph = False
         # ... and everything between the networks' outputs and their gradients is one HIP kernel (rl/fused_loss.py)
         self._fused_loss = self._device_lr and os.environ.get("GRX_PPO_FUSED_LOSS", "1") != "0"
+        self._fused_store = self._device_lr and os.environ.get("GRX_PPO_FUSED_STORE", "1") != "0"
         self._graph, self._graph_mb, self._static, self._sums, self._restore_opt = None, None, None, None, None
         # ... and so is the rollout's policy step (GRX_PPO_ACT_GRAPH=0: eager)
         self._use_act_graph = self._device_lr and os.environ.get("GRX_PPO_ACT_GRAPH", "1") not in ("0", "")
@@ -108,30 +109,60 @@ class PPO:
         return actions, values, logp, ac.action_mean.detach(), ac.action_std.detach()
 
     def _act_graphed(self, actor_observations, critic_observations):
-        """The rollout's policy step (two MLP forwards, sample, log-prob: ~35 kernels of a few microseconds) replayed from
-        a HIP graph on static input / output buffers.  The outputs are consumed (env.step, storage.add_transitions) before
-        the next call overwrites them.  The sampling draws from torch's default generator, which CUDA graphs advance per
-        replay."""
+        """The rollout's policy step replayed from HIP graphs on static input / output buffers -- TWO of them: the actor
+        (MLP forward, sample, log-prob: what env.step() waits for) on the current stream, the critic (MLP forward: only the
+        storage needs it) on a side stream, where it overlaps the env step that follows (the step kernel leaves half of the
+        chip idle at 4096 envs).  process_env_step() waits for the critic before it stores the transition.  The outputs are
+        consumed (env.step, the storage kernel) before the next call overwrites them.  The sampling draws from torch's default
+        generator, which CUDA graphs advance per replay."""
         key = (tuple(actor_observations.shape), tuple(critic_observations.shape))
+        ac = self.actor_critic
+        cur = torch.cuda.current_stream(self.device)
         if self._act_graph is None or self._act_key != key:
             # (not under inference_mode, where the runner calls act(): tensors created there -- the static buffers, the
             #  generator's graph state -- would be inference tensors that later captures / replays may not update)
             with torch.inference_mode(False), torch.no_grad():
                 self._act_in = (torch.zeros_like(actor_observations), torch.zeros_like(critic_observations))
+
+                def actor_part():
+                    ac.update_distribution(self._act_in[0])   # Normal.sample() checks std >= 0 on the host: not capturable
+                    actions = (ac.action_mean + ac.action_std * torch.randn_like(ac.action_mean)).detach()
+                    return actions, ac.get_actions_log_prob(actions).detach(), ac.action_mean.detach(), ac.action_std.detach()
+
+                def critic_part():
+                    return ac.evaluate(self._act_in[1]).detach()
                 side = torch.cuda.Stream(device=self.device)
-                side.wait_stream(torch.cuda.current_stream(self.device))
+                self._act_side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     for _ in range(2):
-                        self._act_eager(*self._act_in, capturable=True)
-                torch.cuda.current_stream(self.device).wait_stream(side)
+                        actor_part(); critic_part()
+                cur.wait_stream(side)
                 self._act_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._act_graph, stream=side):
-                    self._act_out = self._act_eager(*self._act_in, capturable=True)
+                    a_out = actor_part()
+                self._critic_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._critic_graph, stream=side):
+                    v_out = critic_part()
+                self._act_out = (a_out[0], v_out, a_out[1], a_out[2], a_out[3])
+                self._ev_obs, self._ev_critic = torch.cuda.Event(), torch.cuda.Event()
             self._act_key = key
+        self._ev_obs.record(cur)                       # this step's observations are final on the current stream
+        self._act_side.wait_event(self._ev_obs)
+        with torch.cuda.stream(self._act_side):
+            self._act_in[1].copy_(critic_observations)
+            self._critic_graph.replay()
+            self._ev_critic.record(self._act_side)
+        self._critic_pending = True
         self._act_in[0].copy_(actor_observations)
-        self._act_in[1].copy_(critic_observations)
         self._act_graph.replay()
         return self._act_out
+
+    def _join_critic(self):
+        """values of the current policy step are ready on the current stream from here on"""
+        if getattr(self, "_critic_pending", False):
+            torch.cuda.current_stream(self.device).wait_event(self._ev_critic)
+            self._critic_pending = False
 
     def act(self, actor_observations, critic_observations):
         t = self.transition
@@ -145,8 +176,30 @@ class PPO:
     def act_inference(self, obs):
         return self.actor_critic.act_inference(obs)
 
-    def process_env_step(self, rewards, dones, infos):
+    def process_env_step(self, rewards, dones, infos, log=None):
+        """ppo.py:184-197.  On a HIP device everything here -- the time-out bootstrap, the nine row copies of
+        RolloutStorage.add_transitions and (log = (cur_rew, cur_len, done_rew_row, done_len_row)) the runner's running episode
+        reward / length -- is ONE kernel (include/grx_ppo.h grx_ppo_store_transition)."""
         t = self.transition
+        st = self.storage
+        self._join_critic()
+        if self._fused_store and rewards.is_cuda and t.observations is not None and t.observations.is_contiguous():
+            if st.step >= st.num_transitions_per_env:
+                raise AssertionError("Rollout buffer overflow")
+            from .fused_loss import store_transition
+            pri = t.critic_observations if st.pri_observations is not None else None
+            store_transition(st, st.step, t.observations, pri, t.actions, t.action_mean, t.action_sigma, t.values, t.actions_log_prob,
+                             rewards if rewards.is_contiguous() else rewards.contiguous(), dones, infos.get("time_outs"), self.gamma, log)
+            st.step += 1
+            t.clear()
+            self.actor_critic.reset(dones)
+            return
+        if log is not None:   # the torch spelling of the runner's bookkeeping (on_policy_runner.py:170-181)
+            cur_rew, cur_len, done_rew, done_len = log
+            cur_rew += rewards; cur_len += 1
+            d = dones > 0
+            done_rew.copy_(cur_rew); done_len.copy_(cur_len)
+            cur_rew *= ~d; cur_len *= ~d
         t.rewards = rewards.clone()
         t.dones = dones
         if "time_outs" in infos:   # bootstrap on time-outs (ppo.py:190-191)
@@ -156,6 +209,7 @@ class PPO:
         self.actor_critic.reset(dones)
 
     def compute_returns(self, last_critic_obs):
+        self._join_critic()
         last_values = self.actor_critic.evaluate(last_critic_obs).detach()
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 
@@ -443,6 +497,36 @@ class PPO:
         self.update_learning_rate(kl_value)
         for g in self.optimizer.param_groups:
             g["lr"] = self.learning_rate
+
+    def load_optimizer_state(self, state_dict):
+        """optimizer.load_state_dict() for the device-resident update.  torch replaces param_groups[*]['lr'] with a NEW tensor
+        (or, from a reference rsl_rl checkpoint, a float with capturable=False / fused=None): the adaptive learning rate would
+        then be written to an orphaned `_lr_t`, the NaN-skip hook ignored, and graphs captured earlier would keep updating the
+        old Adam moments.  Re-attach `_lr_t`, force the fused capturable configuration, move the step counters to the device
+        and drop every captured graph."""
+        self.optimizer.load_state_dict(state_dict)
+        if self._device_lr:
+            lr = self.optimizer.param_groups[0]["lr"]
+            with torch.no_grad():
+                self._lr_t.copy_(torch.as_tensor(float(lr), device=self.device))
+            for g in self.optimizer.param_groups:
+                g["lr"] = self._lr_t
+                g["fused"], g["capturable"], g["foreach"] = True, True, False
+            for stt in self.optimizer.state.values():
+                for k, v in list(stt.items()):
+                    if torch.is_tensor(v) and (v.device != self._lr_t.device or (k == "step" and v.dtype != torch.float32)):
+                        stt[k] = v.to(device=self.device, dtype=torch.float32 if k == "step" else v.dtype)
+                    elif k == "step" and not torch.is_tensor(v):
+                        stt[k] = torch.tensor(float(v), device=self.device)
+            self.learning_rate = float(lr)
+        else:
+            self.learning_rate = float(self.optimizer.param_groups[0]["lr"])
+        self.invalidate_graphs()
+
+    def invalidate_graphs(self):
+        """captured policy / minibatch graphs refer to the tensors they were captured with: recapture on next use"""
+        self._graph, self._graph_mb, self._static, self._restore_opt = None, None, None, None
+        self._act_graph, self._act_key, self._critic_pending = None, None, False
 
     def clear_storage(self):
         self.storage.clear()

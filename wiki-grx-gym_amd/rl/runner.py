@@ -81,30 +81,29 @@ class OnPolicyRunner:
         rewbuffer, lenbuffer = deque(maxlen=100), deque(maxlen=100)
         cur_rew = torch.zeros(env.num_envs, dtype=torch.float, device=self.device)
         cur_len = torch.zeros(env.num_envs, dtype=torch.float, device=self.device)
+        done_rew = torch.zeros(self.num_steps_per_env, env.num_envs, dtype=torch.float, device=self.device)
+        done_len = torch.zeros(self.num_steps_per_env, env.num_envs, dtype=torch.float, device=self.device)
         tot_iter = self.current_learning_iteration + num_learning_iterations
         for it in range(self.current_learning_iteration, tot_iter):
             start = time.time()
-            done_rew, done_len, done_mask = [], [], []
             with torch.inference_mode():
-                for _ in range(self.num_steps_per_env):
+                for t_ in range(self.num_steps_per_env):
                     actions = alg.act(obs, critic_obs)
                     obs, pri, rewards, dones, infos = env.step(actions)
                     critic_obs = pri if pri is not None else obs
                     obs, critic_obs, rewards, dones = obs.to(self.device), critic_obs.to(self.device), rewards.to(self.device), dones.to(self.device)
-                    alg.process_env_step(rewards, dones, infos)
                     if self.log_dir is not None:
                         if "episode" in infos:
                             ep_infos.append(infos["episode"])
-                        cur_rew += rewards
-                        cur_len += 1
-                        d = dones > 0
-                        done_rew.append(cur_rew.clone()); done_len.append(cur_len.clone()); done_mask.append(d.clone())
-                        cur_rew *= ~d
-                        cur_len *= ~d
-                if done_mask:   # one device->host transfer per iteration instead of one per step
-                    m = torch.stack(done_mask)
-                    rewbuffer.extend(torch.stack(done_rew)[m].cpu().tolist())
-                    lenbuffer.extend(torch.stack(done_len)[m].cpu().tolist())
+                        # running episode reward / length and the finished episodes' totals: inside process_env_step (one kernel on a
+                        # HIP device), read back once per iteration instead of nonzero() + .cpu() per step (on_policy_runner.py:177-179)
+                        alg.process_env_step(rewards, dones, infos, log=(cur_rew, cur_len, done_rew[t_], done_len[t_]))
+                    else:
+                        alg.process_env_step(rewards, dones, infos)
+                if self.log_dir is not None:   # one device->host transfer per iteration
+                    m = alg.storage.dones.squeeze(-1).bool()
+                    rewbuffer.extend(done_rew[m].cpu().tolist())
+                    lenbuffer.extend(done_len[m].cpu().tolist())
                 collection_time = time.time() - start
                 start = time.time()
                 alg.compute_returns(critic_obs)
@@ -170,8 +169,9 @@ class OnPolicyRunner:
     def load(self, path, load_optimizer=True):
         loaded = torch.load(path, map_location=self.device, weights_only=False)
         self.algorithm.actor_critic.load_state_dict(loaded["model_state_dict"])
+        self.algorithm.invalidate_graphs()
         if load_optimizer:
-            self.algorithm.optimizer.load_state_dict(loaded["optimizer_state_dict"])
+            self.algorithm.load_optimizer_state(loaded["optimizer_state_dict"])
         self.current_learning_iteration = loaded["iter"]
         return loaded["infos"]
 

@@ -125,7 +125,7 @@ class SimHandle:
     def reset_all(self):
         self._check(self._api["reset_all"](self._h, self._stream()), "reset_all")
 
-    def step(self, actions, delay_substeps, common_step_counter, noise_uniform=None):
+    def step(self, actions, delay_substeps, common_step_counter, noise_uniform=None, obs_out=None, pri_obs_out=None):
         """actions: contiguous float32 (N, nd) tensor on self.device (borrowed for the call)."""
         if actions is not None:
             if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device.type != self.device.type:
@@ -140,6 +140,11 @@ class SimHandle:
             if noise_uniform.dtype != torch.float32 or not noise_uniform.is_contiguous():
                 raise GrxError("noise_uniform must be contiguous float32")
             a.noise_uniform = noise_uniform.data_ptr()
+        for name, t in (("obs_out", obs_out), ("pri_obs_out", pri_obs_out)):
+            if t is not None:
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.device.type != self.device.type or t.shape[0] != self.num_envs:
+                    raise GrxError(f"{name} must be a contiguous float32 (N, k) tensor on the simulation device")
+                setattr(a, name, t.data_ptr())
         self._check(self._api["step"](self._h, C.byref(a), self._stream()), "step")
 
     def set_state(self, root_states=None, dof_pos=None, dof_vel=None):
