@@ -3,6 +3,10 @@ import sys, os, time; sys.path.insert(0, ".")
 import torch
 from wiki_grx_gym_amd.rl.modules import ActorCriticMLP
 from wiki_grx_gym_amd.rl.ppo import PPO
+if os.environ.get("GRX_PPO_FORCE_BUCKET") == "1":   # the multi-rank update on a one-rank RCCL group
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29641", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 def run(graph):
     os.environ["GRX_PPO_GRAPH"] = str(graph)
     torch.manual_seed(0)

@@ -25,6 +25,13 @@ def _collective_path():
     return _world() > 1 or (os.environ.get("GRX_PPO_FORCE_BUCKET") == "1" and dist.is_available() and dist.is_initialized())
 
 
+def _capture_mode():
+    """With a process group alive, ProcessGroupNCCL's watchdog thread polls its events (hipEventQuery) at any time; under the
+    default "global" capture mode that call from ANOTHER thread invalidates a capture in progress and takes the process
+    down.  "thread_local" confines the legality check to the capturing thread."""
+    return "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+
+
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -65,7 +72,7 @@ class PPO:
         self._act_graph, self._act_key, self._act_in, self._act_out = None, None, None, None
         # inside the captured step the critic runs on a second stream (GRX_PPO_TWO_STREAMS=0: one stream); eagerly the extra
         # stream bookkeeping costs more than the overlap gives
-        self._two_streams = self._use_graph and not _collective_path() and os.environ.get("GRX_PPO_TWO_STREAMS", "1") != "0"
+        self._two_streams = self._use_graph and os.environ.get("GRX_PPO_TWO_STREAMS", "1") != "0"
         self._aux_stream = None
         if self._device_lr:
             # rsl_rl's `Normal.set_default_validate_args = False` (actor_critic.py) is an assignment, not a call, so the
@@ -83,7 +90,21 @@ class PPO:
         self.num_updates = 0
         self._params = [p for p in self.actor_critic.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self._params)
-        self._bucket = torch.zeros(n + 1, device=device) if _collective_path() else None   # grads + KL
+        # multi-rank: every .grad is a VIEW into one flat fp32 bucket [grads | minibatch KL | non-finite-loss flag], so the
+        # single all-reduce per optimizer step needs no per-parameter copies in either direction
+        # (each view starts on a 256-byte boundary like a separately allocated .grad would: torch's multi-tensor kernels pick
+        #  their vector width -- and with it the summation order of the gradient norm -- from the pointer alignment)
+        n = sum(-(-p.numel() // 64) * 64 for p in self._params)
+        self._nflat = n
+        self._bucket = torch.zeros(n + 2, device=device) if _collective_path() else None
+        self._mid = torch.zeros(2, device=device) if _collective_path() else None   # value / surrogate loss between the two halves
+        self._graph_back = None
+        if self._bucket is not None:
+            self._install_flat_grads()
+
+    def _install_flat_grads(self):
+        for p, o in zip(self._params, self._offsets()):
+            p.grad = self._bucket[o:o + p.numel()].view_as(p)
 
     def init_storage(self, num_envs, num_transitions_per_env, **_):
         ac = self.actor_critic
@@ -139,10 +160,10 @@ class PPO:
                         actor_part(); critic_part()
                 cur.wait_stream(side)
                 self._act_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._act_graph, stream=side):
+                with torch.cuda.graph(self._act_graph, stream=side, capture_error_mode=_capture_mode()):
                     a_out = actor_part()
                 self._critic_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._critic_graph, stream=side):
+                with torch.cuda.graph(self._critic_graph, stream=side, capture_error_mode=_capture_mode()):
                     v_out = critic_part()
                 self._act_out = (a_out[0], v_out, a_out[1], a_out[2], a_out[3])
                 self._ev_obs, self._ev_critic = torch.cuda.Event(), torch.cuda.Event()
@@ -219,23 +240,26 @@ class PPO:
         elif self.desired_kl / 2.0 > kl_mean > 0.0:
             self.learning_rate = min(self.learning_rate_max, self.learning_rate * 1.5)
 
-    def _sync_gradients(self, kl_mean):
-        """ONE collective per optimizer step: [flat grads | KL] summed over ranks, averaged."""
-        b, o = self._bucket, 0
-        for p in self._params:
-            n = p.numel()
-            b[o:o + n].copy_(p.grad.reshape(-1) if p.grad is not None else torch.zeros(n, device=b.device))
-            o += n
-        b[o] = kl_mean
+    def _sync_gradients(self, kl_mean, bad=None):
+        """ONE collective per optimizer step: [flat grads | KL | bad] summed over ranks, averaged.  The gradients already
+        live in the bucket (backward accumulated into the views after _zero_flat_grads).  Returns (KL, any-rank-bad)."""
+        b, n = self._bucket, self._nflat
+        b[n] = kl_mean
+        b[n + 1] = 0.0 if bad is None else bad.to(b.dtype)
         dist.all_reduce(b)
         b /= _world()
+        return b[n], b[n + 1] > 0
+
+    def _zero_flat_grads(self):
+        if any(p.grad is None or p.grad.data_ptr() != self._bucket.data_ptr() + 4 * o for p, o in zip(self._params, self._offsets())):
+            self._install_flat_grads()   # (someone ran zero_grad(set_to_none=True) in between)
+        self._bucket.zero_()
+
+    def _offsets(self):
         o = 0
         for p in self._params:
-            n = p.numel()
-            if p.grad is not None:
-                p.grad.copy_(b[o:o + n].view_as(p.grad))
-            o += n
-        return b[o]
+            yield o
+            o += -(-p.numel() // 64) * 64
 
     def _device_lr_update(self, kl_mean):
         """update_learning_rate() on the device (same branches as ppo.py:205-213)."""
@@ -255,7 +279,7 @@ class PPO:
             if os.environ.get("GRX_PPO_BLAS", "rocblas") == "rocblas":
                 torch.backends.cuda.preferred_blas_library("cublas")
             try:
-                if self._use_graph and not _collective_path():
+                if self._use_graph:
                     return self._update_graphed()
                 return self._update_device()
             finally:
@@ -288,13 +312,17 @@ class PPO:
             loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
             if not multi and torch.isnan(loss):
                 continue
-            self.optimizer.zero_grad()
+            if multi:
+                self._zero_flat_grads()
+            else:
+                self.optimizer.zero_grad()
             loss.backward()
             if multi:
-                kl_avg = self._sync_gradients(kl_mean if kl_mean is not None else torch.zeros((), device=self.device))
+                kl_avg, bad = self._sync_gradients(kl_mean if kl_mean is not None else torch.zeros((), device=self.device),
+                                                   ~torch.isfinite(loss.detach()))
                 if adaptive:
                     self._apply_kl(kl_avg.item())
-                if not all(torch.isfinite(p.grad).all() for p in self._params if p.grad is not None):
+                if bool(bad) or not bool(torch.isfinite(self._bucket[:self._nflat]).all()):
                     continue   # NaN-skip must be a collective decision: the averaged bucket is identical on every rank
             nn.utils.clip_grad_norm_(ac.parameters(), self.max_grad_norm)
             self.optimizer.step()
@@ -359,16 +387,19 @@ class PPO:
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
             surrogate_loss, value_loss, loss, kl_mean = self._losses(obs, cobs, actions, target_values, advantages, returns,
                                                                       old_logp, old_mu, old_sigma)
-            self.optimizer.zero_grad(set_to_none=False)
-            loss.backward()
             if multi:
-                kl_mean = self._sync_gradients(kl_mean)
-            if adaptive:
-                self._device_lr_update(kl_mean)
+                self._zero_flat_grads()
+            else:
+                self.optimizer.zero_grad(set_to_none=False)
+            loss.backward()
             with torch.no_grad():
                 bad = ~torch.isfinite(loss)
                 if multi:
-                    bad = bad | ~torch.isfinite(self._bucket[:-1]).all()
+                    kl_mean, bad = self._sync_gradients(kl_mean, bad)
+                    bad = bad | ~torch.isfinite(self._bucket[:self._nflat]).all()
+            if adaptive:
+                self._device_lr_update(kl_mean)
+            with torch.no_grad():
                 # NaN-skip (ppo.py:297-299) without a sync: the fused Adam kernel leaves parameters and moments
                 # untouched when found_inf is set (the GradScaler hook)
                 self.optimizer.found_inf = bad.float().reshape(())
@@ -386,7 +417,7 @@ class PPO:
         self.learning_rate = float(self._lr_t.item())
         return host[0] / self.num_updates, host[1] / self.num_updates
 
-    # ------------------------------------------------------------------ HIP-graph minibatch step (single rank)
+    # ------------------------------------------------------------------ HIP-graph minibatch step
     def _minibatch_step(self, batch, sums):
         """One PPO minibatch step on static tensors (the arithmetic of _update_device)."""
         obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma = batch
@@ -411,6 +442,44 @@ class PPO:
             sums[1] += surrogate_loss.detach() * ok
             sums[2] = kl_mean
 
+    # ... and with more than one rank the step is captured as TWO halves around the one eager RCCL all-reduce:
+    #   front  = zero the flat bucket, forward, fused loss, backward (accumulating into the bucket's views), KL and the
+    #            non-finite flag into the bucket's tail
+    #   (dist.all_reduce(bucket) -- enqueued on the same stream between the two replays; no host synchronisation)
+    #   back   = average, adaptive learning rate from the AVERAGED KL, collective NaN-skip, clip, fused Adam, statistics
+    def _mb_front(self, batch):
+        obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma = batch
+        surrogate_loss, value_loss, loss, kl_mean = self._losses(obs, cobs, actions, target_values, advantages, returns,
+                                                                  old_logp, old_mu, old_sigma)
+        self._zero_flat_grads()
+        loss.backward()
+        with torch.no_grad():
+            b, n = self._bucket, self._nflat
+            b[n] = kl_mean
+            b[n + 1] = (~torch.isfinite(loss)).float()
+            self._mid[0] = value_loss.detach()
+            self._mid[1] = surrogate_loss.detach()
+
+    def _mb_back(self, sums):
+        adaptive = self.desired_kl is not None and self.schedule == "adaptive"
+        b, n = self._bucket, self._nflat
+        with torch.no_grad():
+            b /= _world()
+            kl_mean = b[n]
+            bad = (b[n + 1] > 0) | ~torch.isfinite(b[:n]).all()
+        if adaptive:
+            self._device_lr_update(kl_mean)
+        with torch.no_grad():
+            self.optimizer.found_inf = bad.float().reshape(())
+            self.optimizer.grad_scale = None
+        nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm, foreach=True)
+        self.optimizer.step()
+        with torch.no_grad():
+            ok = (~bad).float()
+            sums[0] += self._mid[0] * ok
+            sums[1] += self._mid[1] * ok
+            sums[2] = kl_mean
+
     def _build_graph(self, mb):
         st, dev = self.storage, self.device
         widths = [st.observations.shape[-1], (st.pri_observations if st.pri_observations is not None else st.observations).shape[-1],
@@ -430,20 +499,36 @@ class PPO:
             torch.backends.cuda.preferred_blas_library("cublas")
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        multi = _collective_path()
         with torch.cuda.stream(side):
             for _ in range(3):
-                self._minibatch_step(self._static, self._sums)
+                if multi:   # (every rank builds its graphs at the same point of the run: the dry-run collectives pair up)
+                    self._mb_front(self._static)
+                    dist.all_reduce(self._bucket)
+                    self._mb_back(self._sums)
+                else:
+                    self._minibatch_step(self._static, self._sums)
         torch.cuda.current_stream(dev).wait_stream(side)
         if os.environ.get("GRX_PPO_GRAPH", "1") == "2":   # debugging aid: static buffers, eager replay
             class _Eager:
                 def __init__(s, fn): s.fn = fn
                 def replay(s): s.fn()
-            self._graph = _Eager(lambda: self._minibatch_step(self._static, self._sums))
+            if multi:
+                self._graph = _Eager(lambda: self._mb_front(self._static))
+                self._graph_back = _Eager(lambda: self._mb_back(self._sums))
+            else:
+                self._graph = _Eager(lambda: self._minibatch_step(self._static, self._sums))
+        elif multi:
+            self._graph, self._graph_back = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph, stream=side, capture_error_mode=_capture_mode()):
+                self._mb_front(self._static)
+            with torch.cuda.graph(self._graph_back, stream=side, capture_error_mode=_capture_mode()):
+                self._mb_back(self._sums)
         else:
             self._graph = torch.cuda.CUDAGraph()
             # capture on the stream the dry runs used: autograd's AccumulateGrad nodes remember the stream they were
             # created on, and one that differs from the capture stream runs (and allocates) outside the capture
-            with torch.cuda.graph(self._graph, stream=side):
+            with torch.cuda.graph(self._graph, stream=side, capture_error_mode=_capture_mode()):
                 self._minibatch_step(self._static, self._sums)
         torch.backends.cuda.preferred_blas_library(prev_blas)
         # restore: parameters, Adam moments/step counters, learning rate
@@ -480,12 +565,16 @@ class PPO:
         srcs = [flat(x) for x in (st.observations, cobs, st.actions, st.values, st.advantages, st.returns, st.actions_log_prob, st.mu, st.sigma)]
         indices = torch.randperm(self.num_mini_batches * mb, requires_grad=False, device=self.device)   # RS:63-112: one permutation, reused
         self._sums.zero_()
+        multi = _collective_path()
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 idx = indices[i * mb:(i + 1) * mb]
                 for buf, src in zip(self._static, srcs):
                     torch.index_select(src, 0, idx, out=buf)
                 self._graph.replay()
+                if multi:
+                    dist.all_reduce(self._bucket)
+                    self._graph_back.replay()
         self.num_updates = self.num_learning_epochs * self.num_mini_batches
         host = self._sums.tolist()                     # the only device->host transfer of the update
         self.mean_kl = host[2]
@@ -525,7 +614,7 @@ class PPO:
 
     def invalidate_graphs(self):
         """captured policy / minibatch graphs refer to the tensors they were captured with: recapture on next use"""
-        self._graph, self._graph_mb, self._static, self._restore_opt = None, None, None, None
+        self._graph, self._graph_back, self._graph_mb, self._static, self._restore_opt = None, None, None, None, None
         self._act_graph, self._act_key, self._critic_pending = None, None, False
 
     def clear_storage(self):
