@@ -253,6 +253,9 @@ typedef struct grx_config {
     const float* terrain_origins;  /* HOST pointer, (rows, cols, 3); copied at create */
     float terrain_length;          /* env_length: curriculum move-up threshold */
     float env_spacing;             /* plane grid (legged_robot.py:1187-1195) */
+
+    int32_t publish_reward_terms;  /* 1: also write GRX_T_REWARD_TERMS, the per-term reward table (a debugging tensor with no
+                                      reference counterpart; the parity tests read it).  Every other tensor is always current. */
 } grx_config;
 
 typedef enum grx_tensor_id {

@@ -299,10 +299,12 @@ def test_resume_keeps_the_adaptive_learning_rate_alive(tmp_path):
     assert all(torch.isfinite(p).all() for p in b.actor_critic.parameters())
 
 
-def _bucket_worker(out, force):
+def _bucket_worker(out, force, port):
     """one process, one rank: the multi-rank update (flat bucket, two captured halves around an RCCL all-reduce) when `force`"""
-    import os, time
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import os, sys, time
+    sys.stderr = sys.stdout = open(out + ".log", "w", buffering=1)
+    os.dup2(sys.stderr.fileno(), 2)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if force:
         os.environ["GRX_PPO_FORCE_BUCKET"] = "1"
     import torch.distributed as dist
@@ -329,13 +331,16 @@ def test_multi_rank_update_is_the_captured_step_around_one_all_reduce(tmp_path):
     bucket (views, no per-parameter copies), ONE RCCL all-reduce between two captured halves.  On one rank (world 1,
     GRX_PPO_FORCE_BUCKET=1) it must reproduce the single-process captured step bit for bit.  (No multi-GPU box is
     available to this suite: the N>1 arithmetic is covered by the gloo world-2 tests in test_distributed.py.)"""
+    import socket
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     res = []
     for force in (0, 1):
         out = str(tmp_path / f"b{force}.pt")
-        p = ctx.Process(target=_bucket_worker, args=(out, force)); p.start(); p.join(300)
-        assert p.exitcode == 0
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        p = ctx.Process(target=_bucket_worker, args=(out, force, port)); p.start(); p.join(300)
+        assert p.exitcode == 0, open(out + ".log").read()[-3000:]
         res.append(torch.load(out))
     assert res[0]["lr"] == res[1]["lr"]
     for x, y in zip(res[0]["params"], res[1]["params"]):

@@ -131,6 +131,7 @@ class Config(C.Structure):
         ("max_init_terrain_level", i32),
         ("terrain_origins", C.c_void_p),
         ("terrain_length", f32), ("env_spacing", f32),
+        ("publish_reward_terms", i32),
     ]
 
 

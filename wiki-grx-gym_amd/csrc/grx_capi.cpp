@@ -511,8 +511,8 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
             if (v == 1 || v == 2 || v == 4) s->waves = v;
         }
     }
-    const char* dbg = getenv("GRX_PUBLISH_DEBUG");
-    P.publish_debug = dbg ? atoi(dbg) : 1;
+    const char* dbg = getenv("GRX_PUBLISH_DEBUG");   // (tools/: overrides the config either way)
+    P.publish_debug = dbg ? atoi(dbg) : c.publish_reward_terms;
     P.seed = c.seed;
     P.sim_dt = c.sim_dt; P.decimation = c.decimation;
     for (int i = 0; i < 3; ++i) { P.gravity[i] = c.gravity[i]; P.init_pos[i] = c.init_pos[i]; }

@@ -673,7 +673,7 @@ GRX_DEV float obs_heights_share(KP P, float posz, int first, int nh, float* prow
             if (k < nh) {
                 float d = posz - P.base_height_target - hv[j];
                 d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
-                if (P.publish_debug && act) P.heights[(size_t)k * N + e] = hv[j];
+                if (act) P.heights[(size_t)k * N + e] = hv[j];   // env.measured_heights: a reference attribute, always current
                 prow[GRX_NUM_OBS + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -P.clip_observations), P.clip_observations);
                 sum += d;
             }

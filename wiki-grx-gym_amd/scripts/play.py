@@ -1,5 +1,16 @@
-"""play.py -- load the last checkpoint and roll the policy (reference legged_gym/scripts/play.py:42-137,
-without the viewer / matplotlib logger, which are out of scope)."""
+"""play.py -- load the last checkpoint, export the actor as TorchScript and roll the policy
+(reference legged_gym/scripts/play.py:42-137).
+
+Same overrides (:45-56), same export path (:67-82, `logs/<experiment>/exported/policy_jit.pt`), same loop (:96-98) and the
+same two logs as the reference's Logger calls, written as JSON lines instead of matplotlib windows (the Logger class, the
+viewer, RECORD_FRAMES and MOVE_CAMERA are out of scope):
+
+  * `exported/play_states.jsonl`  -- one record per step for the first `stop_state_log` steps with exactly the keys of the
+    dict passed to `logger.log_states` (:110-126), for robot 0 / joint 1;
+  * `exported/play_rewards.json`  -- what `logger.log_rewards` accumulates and `print_rewards` shows (:131-137): per reward
+    term, the episode means weighted by the number of episodes that ended, over the first `max_episode_length` steps.
+"""
+import json
 import os
 
 import torch
@@ -11,29 +22,89 @@ from wiki_grx_gym_amd.utils.task_registry import LEGGED_GYM_ROOT_DIR
 EXPORT_POLICY = True
 
 
-def play(args, steps=None):
+def play(args, steps=None, log_root="default"):
     env_cfg, train_cfg = task_registry.get_cfgs(name=args.task)
-    env_cfg.env.num_envs = min(env_cfg.env.num_envs, 50)          # play.py:45-54 overrides
+
+    # override some parameters for testing (play.py:45-56)
+    env_cfg.env.episode_length_s = 600.0
+    env_cfg.env.num_envs = min(env_cfg.env.num_envs, 50)
+    env_cfg.terrain.num_rows = 5
+    env_cfg.terrain.num_cols = 5
     env_cfg.terrain.curriculum = False
     env_cfg.noise.add_noise = False
     env_cfg.domain_rand.randomize_friction = False
     env_cfg.domain_rand.push_robots = False
+
     env, _ = task_registry.make_env(name=args.task, args=args, env_cfg=env_cfg)
     obs = env.get_observations()
+
     train_cfg.runner.resume = True
-    ppo_runner, train_cfg = task_registry.make_alg_runner(env=env, name=args.task, args=args, train_cfg=train_cfg)
+    ppo_runner, train_cfg = task_registry.make_alg_runner(env=env, name=args.task, args=args, train_cfg=train_cfg, log_root=log_root)
     policy = ppo_runner.get_inference_policy(device=env.device)
+
+    exp_root = os.path.join(LEGGED_GYM_ROOT_DIR, "logs", train_cfg.runner.experiment_name) if log_root == "default" else log_root
+    out_dir = os.path.join(exp_root, "exported")
+    exported = None
     if EXPORT_POLICY:
-        path = os.path.join(LEGGED_GYM_ROOT_DIR, "logs", train_cfg.runner.experiment_name, "exported", "policies")
-        export_policy_as_jit(ppo_runner.algorithm.actor_critic, path)
-        print("Exported policy as jit script to: ", path)
+        exported = export_policy_as_jit(ppo_runner.algorithm.actor_critic, out_dir)
+        print(f"EXPORT_POLICY: Exported policy as jit script to: {exported}")
+    os.makedirs(out_dir, exist_ok=True)
+
+    robot_index = 0      # which robot is used for logging
+    joint_index = 1      # which joint is used for logging
+    stop_state_log = 100                               # number of steps the states are logged for
+    stop_rew_log = int(env.max_episode_length) + 1     # number of steps before the average episode rewards are printed
     total = steps if steps is not None else 10 * int(env.max_episode_length)
-    rew = 0.0
-    for i in range(total):
-        actions = policy(obs.detach())
-        obs, _, rews, dones, infos = env.step(actions.detach())
-        rew += rews.mean().item()
-    print(f"mean reward per step over {total} steps: {rew / total:.4f}")
+    rew_sums, num_episodes_total = {}, 0
+    states_path = os.path.join(out_dir, "play_states.jsonl")
+    rewards_path = os.path.join(out_dir, "play_rewards.json")
+
+    def dump_rewards():
+        avg = {k: v / max(num_episodes_total, 1) for k, v in rew_sums.items()}
+        with open(rewards_path, "w") as f:
+            json.dump({"num_episodes": num_episodes_total, "average_per_second": avg}, f, indent=1)
+        print("Average rewards per second:")
+        for k, v in avg.items():
+            print(f" - {k}: {v}")
+        print(f"Total number of episodes: {num_episodes_total}")
+
+    with open(states_path, "w") as sf:
+        for i in range(total):
+            actions = policy(obs.detach())
+            obs, _, rews, dones, infos = env.step(actions.detach())
+
+            if i < stop_state_log:
+                rec = {   # the dict of play.py:112-125
+                    "dof_pos_target": actions[robot_index, joint_index].item() * env.cfg.control.action_scale,
+                    "dof_pos": env.dof_pos[robot_index, joint_index].item(),
+                    "dof_vel": env.dof_vel[robot_index, joint_index].item(),
+                    "dof_torque": env.torques[robot_index, joint_index].item(),
+                    "command_x": env.commands[robot_index, 0].item(),
+                    "command_y": env.commands[robot_index, 1].item(),
+                    "command_yaw": env.commands[robot_index, 2].item(),
+                    "base_vel_x": env.base_lin_vel[robot_index, 0].item(),
+                    "base_vel_y": env.base_lin_vel[robot_index, 1].item(),
+                    "base_vel_z": env.base_lin_vel[robot_index, 2].item(),
+                    "base_vel_yaw": env.base_ang_vel[robot_index, 2].item(),
+                    "contact_forces_z": env.contact_forces[robot_index, env.feet_indices, 2].cpu().tolist(),
+                }
+                sf.write(json.dumps(rec) + "\n")
+            elif i == stop_state_log:
+                sf.flush()
+
+            if 0 < i < stop_rew_log:
+                if infos["episode"]:
+                    num_episodes = int(torch.sum(env.reset_buf).item())
+                    if num_episodes > 0:          # Logger.log_rewards (logger.py:49-54): sums of value * num_episodes
+                        for key, value in infos["episode"].items():
+                            if "rew" in key:
+                                rew_sums[key] = rew_sums.get(key, 0.0) + float(value) * num_episodes
+                        num_episodes_total += num_episodes
+            elif i == stop_rew_log:
+                dump_rewards()
+    if total <= stop_rew_log:
+        dump_rewards()
+    return dict(env=env, runner=ppo_runner, exported=exported, states=states_path, rewards=rewards_path)
 
 
 if __name__ == "__main__":

@@ -45,6 +45,10 @@ class TaskRegistry:
         if not hasattr(env_cfg, "seed"):
             env_cfg.seed = self.train_cfgs[name].seed
         set_seed(env_cfg.seed)
+        # GRX_T_REWARD_TERMS (the per-term reward table, a debugging tensor the reference has no counterpart of) is only
+        # written when asked for; every reference attribute (measured_heights included) is always current
+        if not hasattr(env_cfg.env, "publish_reward_terms"):
+            env_cfg.env.publish_reward_terms = False
         sim_params = parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)})
         shard = {}
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
