@@ -49,3 +49,30 @@ def test_native_library_is_what_runs():
     t.fill_(0.25)
     hip.set_state(None, None, None)
     assert float(hip.tensor("DOF_POS").mean()) == 0.25
+
+
+def test_steps_recorded_into_a_hip_graph_neither_pace_nor_hang():
+    """grx_step's run-ahead pacing spins on a progress word that only advances when steps EXECUTE.  Steps
+    recorded under stream capture do not execute, so recording more than the pacing window must not wait for them; a
+    replayed graph then advances the state exactly like the same steps issued eagerly."""
+    from tests.helpers import make_cfg, make_sims
+    hip, _ = make_sims(make_cfg(), 256)
+    ref, _ = make_sims(make_cfg(), 256)
+    act = torch.zeros(256, hip.num_dofs, device="cuda:0")
+    for s in (hip, ref):
+        s.reset_all(); s.step(act, 0.0, 1)
+    torch.cuda.synchronize()
+    n = 300                                               # > the run-ahead window
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(n):
+            hip.step(act, 0.0, 2 + k)
+    g.replay()
+    hip.wait_idle()                                       # only eager steps hold tickets: returns at once
+    for k in range(n):
+        ref.step(act, 0.0, 2 + k)
+    ref.wait_idle()
+    torch.cuda.synchronize()
+    for name in ("DOF_POS", "ROOT_STATES", "OBS", "REW", "EPISODE_LENGTH"):
+        assert torch.equal(hip.tensor(name), ref.tensor(name)), name
+    hip.step(act, 0.0, 2 + n); hip.wait_idle()            # eager steps after a replay still pace and complete

@@ -346,3 +346,35 @@ def test_multi_rank_update_is_the_captured_step_around_one_all_reduce(tmp_path):
     for x, y in zip(res[0]["params"], res[1]["params"]):
         assert torch.equal(x, y)
     print(f"update: plain graph {res[0]['t']*1e3:.2f} ms, bucket + all-reduce between captured halves {res[1]['t']*1e3:.2f} ms")
+
+
+def test_fused_loss_propagates_nan_like_torch():
+    """torch.max / torch.clamp propagate NaN; the kernel must too, so that a NaN ratio or value makes the LOSS NaN
+    and the update's NaN-skip fires (a finite loss over NaN gradients would poison every parameter)."""
+    from wiki_grx_gym_amd.rl.fused_loss import fused_ppo_loss
+    torch.manual_seed(0)
+    B, A = 512, 10
+    dev = "cuda:0"
+    mk = lambda *s: torch.randn(*s, device=dev)
+    base = dict(mu=mk(B, A) * 0.1, std=torch.full((A,), 0.3, device=dev), value=mk(B, 1), actions=mk(B, A) * 0.3,
+                old_logp=mk(B, 1) * 0.1 - 2, old_mu=mk(B, A) * 0.1, old_sigma=torch.full((B, A), 0.3, device=dev),
+                adv=mk(B, 1), ret=mk(B, 1), tv=mk(B, 1))
+    def run(**over):
+        d = {k: v.clone() for k, v in base.items()}
+        for k, v in over.items():
+            d[k][7] = v
+        out = fused_ppo_loss(d["mu"].requires_grad_(), d["std"].requires_grad_(), d["value"].requires_grad_(), d["actions"],
+                             d["old_logp"], d["old_mu"], d["old_sigma"], d["adv"], d["ret"], d["tv"], 0.2, 1.0, 0.01, True)
+        return out
+    assert all(torch.isfinite(o).all() for o in run()[:3])
+    assert torch.isnan(run(mu=float("nan"))[2])          # NaN ratio -> NaN surrogate -> NaN loss
+    assert torch.isnan(run(value=float("nan"))[2])       # NaN value -> NaN value loss -> NaN loss
+    assert torch.isnan(run(old_logp=float("nan"))[2])
+    # ... and the update then leaves every parameter untouched
+    a = _toy_alg()
+    _toy_rollout(a, 0)
+    a.storage.values[3, 5] = float("nan")
+    before = [p.detach().clone() for p in a.actor_critic.parameters()]
+    a.update()
+    after = list(a.actor_critic.parameters())
+    assert all(torch.isfinite(p).all() for p in after)

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <deque>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -798,6 +799,32 @@ int grx_destroy(grx_handle s) {
     return GRX_OK;
 }
 
+// Spin on the pinned progress word until it reaches `target`, WITH a way out: a GPU fault (or steps that were recorded into
+// a graph and never run) would otherwise hang the host forever.  The HIP runtime is polled every few thousand reads and a
+// deadline (GRX_SPIN_TIMEOUT_S, default 60 s -- a step takes microseconds) bounds the wait.
+static int spin_until(grx_sim* s, int64_t target, const char* who) {
+    static const double limit_s = [] { const char* e = getenv("GRX_SPIN_TIMEOUT_S"); return e ? atof(e) : 60.0; }();
+    if (*s->pace.progress >= target) return GRX_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t it = 1;; ++it) {
+        if (*s->pace.progress >= target) return GRX_OK;
+        if ((it & 0x3fff) == 0) {
+            const hipError_t e = hipPeekAtLastError();
+            if (e != hipSuccess && e != hipErrorNotReady)
+                return fail(GRX_ERR_HIP, std::string(who) + ": device error while waiting for enqueued steps: " + hipGetErrorString(e));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s)
+                return fail(GRX_ERR_HIP, std::string(who) + ": enqueued steps did not finish within GRX_SPIN_TIMEOUT_S");
+        }
+    }
+}
+
+// true while `st` records into a graph: a recorded step runs later (or never), so it neither paces nor takes a ticket
+static bool stream_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
 int grx_reset_all(grx_handle s, void* stream) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_reset_all: null handle");
     hipStream_t st = (hipStream_t)stream;
@@ -815,15 +842,18 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
     if (!s || !a) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_step: null argument");
     hipStream_t st = (hipStream_t)stream;
     static const bool no_pace = getenv("GRX_DEBUG_NO_PACE") != nullptr;
-    if (!no_pace)
-        while (s->pace.issued - *s->pace.progress >= Pace::kPaceAhead) {}   // spin on the pinned progress word
+    const bool capturing = stream_is_capturing(st);
+    if (!no_pace && !capturing)
+        if (int rc = spin_until(s, s->pace.issued - Pace::kPaceAhead + 1, "grx_step")) return rc;
     std::pair<hipEvent_t, hipEvent_t> ev;
-    const bool timed = s->timing.enabled && (s->timing.tick++ % s->timing.stride) == 0;
+    const bool timed = !capturing && s->timing.enabled && (s->timing.tick++ % s->timing.stride) == 0;
     if (timed) {
         if (s->timing.pending.size() >= Timing::kMaxPending) {   // bound the event population (and the host's run-ahead)
             auto pr = s->timing.pending.front();
             s->timing.pending.pop_front();
-            while (hipEventQuery(pr.second) == hipErrorNotReady) {}   // spin: see Pace
+            hipError_t qe;
+            while ((qe = hipEventQuery(pr.second)) == hipErrorNotReady) {}   // spin: see Pace (any other error ends it)
+            if (qe != hipSuccess) return fail(GRX_ERR_HIP, std::string("grx_step: timing event: ") + hipGetErrorString(qe));
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
             s->timing.total_ms += ms; ++s->timing.count;
@@ -833,7 +863,7 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
     }
-    const int64_t ticket = ++s->pace.issued;
+    const int64_t ticket = capturing ? 0 : ++s->pace.issued;
     if (s->generic)
     {
         if (grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->gen_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions,
@@ -847,7 +877,7 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->timing.pending.push_back(ev);
     }
-    grx_launch_finalize(s->d_hp, s->stat_blocks, s->pace.d_progress, ticket, st);   // episode statistics + the step's ticket
+    grx_launch_finalize(s->d_hp, s->stat_blocks, capturing ? nullptr : s->pace.d_progress, ticket, st);   // episode statistics + the step's ticket
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
@@ -956,8 +986,7 @@ int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply
 // spin until every step enqueued through this handle has finished on the GPU (reads the pinned progress word)
 int grx_wait_idle(grx_handle s) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_wait_idle: null handle");
-    while (*s->pace.progress < s->pace.issued) {}
-    return GRX_OK;
+    return spin_until(s, s->pace.issued, "grx_wait_idle");
 }
 
 const char* grx_last_error(void) { return g_err.c_str(); }

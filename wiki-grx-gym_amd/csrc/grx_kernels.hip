@@ -1531,20 +1531,27 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
 // extras["episode"] (legged_robot.py:420-424): mean episode sums of the envs reset by this step;
 // kept from the previous resetting step when nobody reset (the reference only rewrites the dict
 // inside reset_idx, which returns early for an empty id list, legged_robot.py:387-388).
-__global__ __launch_bounds__(64) void grx_finalize_stats(const KParams* __restrict__ Pg, int nblocks, int64_t* progress, int64_t ticket) {
+// ONE block, a wave per reward term (round-robin): the ticket below is stored after the block's barrier, i.e. after every
+// statistics row of this step has been written -- a visible ticket covers EPISODE_STATS like every other output.
+constexpr int kFinalizeWaves = 16;
+__global__ __launch_bounds__(64 * kFinalizeWaves) void grx_finalize_stats(const KParams* __restrict__ Pg, int nblocks, int64_t* progress, int64_t ticket) {
     KP P = GRX_PARAMS(Pg);
-    const int t = blockIdx.x, lane = threadIdx.x;   // one wave per reward term: lanes stride over the step kernel's blocks
-    float cnt = 0.f, s = 0.f;
-    for (int b = lane; b < nblocks; b += 64) {
-        cnt += P.stat_partial[(size_t)b * (NT + 1) + NT];
-        s += P.stat_partial[(size_t)b * (NT + 1) + t];
-    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // lanes stride over the step kernel's blocks
+    for (int t = wave; t <= NT; t += kFinalizeWaves) {
+        float cnt = 0.f, s = 0.f;
+        for (int b = lane; b < nblocks; b += 64) {
+            cnt += P.stat_partial[(size_t)b * (NT + 1) + NT];
+            s += P.stat_partial[(size_t)b * (NT + 1) + t];
+        }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { cnt += __shfl_xor(cnt, off); s += __shfl_xor(s, off); }
-    if (lane == 0 && cnt > 0.f) P.stats[t] = (t == NT) ? cnt : s / cnt / P.max_episode_length_s;
+        for (int off = 32; off >= 1; off >>= 1) { cnt += __shfl_xor(cnt, off); s += __shfl_xor(s, off); }
+        if (lane == 0 && cnt > 0.f) P.stats[t] = (t == NT) ? cnt : s / cnt / P.max_episode_length_s;
+    }
+    __syncthreads();
     // step ticket for the host's progress word (pinned host memory): this kernel runs after the step kernel in stream
-    // order, so a visible ticket means the step's outputs are complete
-    if (t == 0 && lane == 0 && progress) __hip_atomic_store(progress, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // order and the release below orders the statistics rows before it, so a visible ticket means ALL of the step's
+    // outputs are complete
+    if (threadIdx.x == 0 && progress) __hip_atomic_store(progress, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // BaseTask.reset() first half (base_task.py:117-119): reset_idx(all envs), no step
@@ -1665,7 +1672,7 @@ extern "C" int grx_generic_tables_size(void) { return (int)sizeof(GenTables); }
 extern "C" int grx_generic_ws_floats_per_env(int nb, int nlc) { return nb * WSB + 3 * nlc; }
 // nblocks: rows of the per-block statistics table (fast path: 32 envs per block, generic path: 64)
 extern "C" void grx_launch_finalize(const KParams* dP, int nblocks, int64_t* progress, int64_t ticket, hipStream_t stream) {
-    hipLaunchKernelGGL(grx_finalize_stats, dim3(NT + 1), dim3(64), 0, stream, dP, nblocks, progress, ticket);
+    hipLaunchKernelGGL(grx_finalize_stats, dim3(1), dim3(64 * kFinalizeWaves), 0, stream, dP, nblocks, progress, ticket);
 }
 extern "C" void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;

@@ -12,6 +12,11 @@ constexpr int NRED = 3 + MAXA;   // surrogate, value loss, KL, d_std[MAXA]
 
 // The batch sums run in double: the surrogate loss is a mean of terms of both signs (normalised advantages) that
 // cancels to ~1e-3 of their magnitude, so an fp32 sum in ANY order is only good to ~1e-4 of the result.
+// torch.max / torch.clamp PROPAGATE NaN (fmaxf / fminf drop it): a NaN ratio or value must reach the loss, so that the
+// update's NaN-skip (ppo.py:297-299) fires instead of a finite loss hiding NaN gradients
+__device__ inline float nmax(float a, float b) { return (a > b || a != a) ? a : b; }
+__device__ inline float nmin(float a, float b) { return (a < b || a != a) ? a : b; }
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
@@ -47,9 +52,9 @@ __global__ __launch_bounds__(NTHR) void ppo_loss_kernel(int B, const float* __re
         const float adv = adv_[i];
         const float ratio = expf(logp - old_logp[i]);
         const float lo = 1.0f - clip, hi = 1.0f + clip;
-        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float rc = nmin(nmax(ratio, lo), hi);
         const float s1 = -adv * ratio, s2 = -adv * rc;
-        const float surr = fmaxf(s1, s2);
+        const float surr = nmax(s1, s2);
         // d max(s1, s2): the larger one takes the gradient, a tie splits it; d clamp = 1 on [lo, hi]
         const float w1 = s1 > s2 ? 1.f : (s1 == s2 ? 0.5f : 0.f), w2 = 1.f - w1;
         const float in_range = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
@@ -66,9 +71,9 @@ __global__ __launch_bounds__(NTHR) void ppo_loss_kernel(int B, const float* __re
         if (use_clipped) {
             const float tv = tv_[i];
             const float dv = v - tv;
-            const float vc = tv + fminf(fmaxf(dv, -clip), clip);
+            const float vc = tv + nmin(nmax(dv, -clip), clip);
             const float l1 = (v - ret) * (v - ret), l2 = (vc - ret) * (vc - ret);
-            vl = fmaxf(l1, l2);
+            vl = nmax(l1, l2);
             const float u1 = l1 > l2 ? 1.f : (l1 == l2 ? 0.5f : 0.f), u2 = 1.f - u1;
             const float vin = (dv >= -clip && dv <= clip) ? 1.f : 0.f;
             gv = u1 * 2.0f * (v - ret) + u2 * 2.0f * (vc - ret) * vin;
