@@ -35,8 +35,9 @@ for terrain in ("plane","heightfield"):
     print('   wave 3 rare contacts (sum over 10 sub-steps): cheap test, fine test, compaction, evaluation, pick-up + netting, -, candidates, calls with any:', np.median(full[:,32:40],axis=0).astype(int).tolist(), 'mean candidates', full[:,38].mean())
     print('   wave 1 self-collision (sum over 10 sub-steps): cycles, candidate envs, lanes with a hit, candidate groups | cycles: centres+extents, ballot+staging, pair tests, forces:', np.mean(full[:,40:48],axis=0).astype(int).tolist())
     ev = full[:, 48:63] - full[:, 48:49]
-    names_ev = ['w0 start', 'w0 walk done', 'w0 inertia half + base factorised', 'w0 (unused)', 'w0 got foot', 'w0 got rare', 'w0 sub-step end', 'w0 bias half done', 'w2 frames out', 'w2 bias[4] out', 'w2 bias[0] out', 'w2 foot out', 'w3 rare out', 'w1 self out', '(unused)']
+    names_ev = ['w0 start', 'w0 walk done', 'w0 inertia half + base factorised', 'w0 recursion done', 'w0 got foot', 'w0 got rare', 'w0 sub-step end', 'w0 bias half done', 'w2 frames out', 'w2 bias[4] out', 'w2 bias[0] out', 'w2 foot out', 'w3 rare out', 'w1 self out', 'w0 base assembled']
     print('   timeline of sub-step 5 (cycles after wave 0 starts it):', {n: int(v) for n, v in zip(names_ev, np.median(ev, axis=0)) if n != '-'})
+    print('   w0 base factorised at', int(np.median(full[:,79]-full[:,48])))
     print('   wave 0: duration of each of the 10 sub-steps:', np.median(full[:, 64:74], axis=0).astype(int).tolist())
     print('   obs sub-sections (cycles after tick 7): heights, noise load, side-0 puts:', np.median(full[:,11:14]-full[:,7:8],axis=0).astype(int).tolist())
     print('   relative to tick 6 (FL_REW published): wave1 got FL_REW, wave1 rewards done, wave2 got FL_HZ, wave2 heights done, wave0 tick 9:', np.median(full[:,[14,15,30,31,9]]-full[:,6:7],axis=0).astype(int).tolist())

@@ -86,18 +86,27 @@ GRX_DEV float riser_weight(float t, float jump, float thr, float& dt) {
     if (-jump > thr) { dt = t >= kRiserBand ? 0.0f : 1.0f / kRiserBand; return t >= kRiserBand ? 1.0f : t * (1.0f / kRiserBand); }
     return t;
 }
+// In two halves: the gather (four int16 loads, ~1.2 us of memory latency on this part) and the interpolation that first
+// USES them -- a caller with independent work puts it between the two.
+struct TerrainRaw { int h00, h01, h10, h11; float tx, ty; };
 template <bool HF>
-GRX_DEV float terrain_height(KP P, float x, float y, float& gx, float& gy) {
-    gx = 0.0f; gy = 0.0f;
-    if (!HF) return 0.0f;
+GRX_DEV void terrain_gather(KP P, float x, float y, TerrainRaw& r) {
+    if (!HF) return;
     float fx = (x + P.border_size) * P.inv_hscale;
     float fy = (y + P.border_size) * P.inv_hscale;
     fx = fminf(fmaxf(fx, 0.0f), (float)(P.hf_rows - 1));
     fy = fminf(fmaxf(fy, 0.0f), (float)(P.hf_cols - 1));
     int ix = min((int)fx, P.hf_rows - 2), iy = min((int)fy, P.hf_cols - 2);
-    float tx = fx - (float)ix, ty = fy - (float)iy;
+    r.tx = fx - (float)ix; r.ty = fy - (float)iy;
     const int16_t* H = P.hf + (size_t)ix * P.hf_cols + iy;
-    float h00 = (float)H[0], h01 = (float)H[1], h10 = (float)H[P.hf_cols], h11 = (float)H[P.hf_cols + 1];
+    r.h00 = H[0]; r.h01 = H[1]; r.h10 = H[P.hf_cols]; r.h11 = H[P.hf_cols + 1];
+}
+template <bool HF>
+GRX_DEV float terrain_eval(KP P, const TerrainRaw& r, float& gx, float& gy) {
+    gx = 0.0f; gy = 0.0f;
+    if (!HF) return 0.0f;
+    float tx = r.tx, ty = r.ty;
+    const float h00 = (float)r.h00, h01 = (float)r.h01, h10 = (float)r.h10, h11 = (float)r.h11;
     float dtx = 1.0f, dty = 1.0f;
     if (P.vertical_faces) {   // uniform
         const float ax0 = h10 - h00, ax1 = h11 - h01, ay0 = h01 - h00, ay1 = h11 - h10;
@@ -109,6 +118,12 @@ GRX_DEV float terrain_height(KP P, float x, float y, float& gx, float& gy) {
     gx = ((h10 - h00) * (1.0f - ty) + (h11 - h01) * ty) * dtx * P.hv_scale;
     gy = ((h01 - h00) * (1.0f - tx) + (h11 - h10) * tx) * dty * P.hv_scale;
     return h * P.vertical_scale;
+}
+template <bool HF>
+GRX_DEV float terrain_height(KP P, float x, float y, float& gx, float& gy) {
+    TerrainRaw r;
+    terrain_gather<HF>(P, x, y, r);
+    return terrain_eval<HF>(P, r, gx, gy);
 }
 
 // per-lane persistent simulation state
@@ -265,20 +280,44 @@ GRX_DEV void chain_step(const SideConst& C, int k, float q, float qd, ChainKin& 
 }
 
 // the four anchored spheres of this lane's foot (chain body LEG-1): wrench about O + anchor update
+// in two halves, so that a caller with other work at hand (wave 2 of the four-wave layout: the bias forces) can put it
+// between the heightfield gathers and their first use
+struct FootProbe { bool reach; V3 xr[4]; TerrainRaw raw[4]; };
+template <bool HF>
+GRX_DEV void foot_probe(KP P, const SideConst& C, const ChainKin& K, V3 O, float hmax, FootProbe& fp) {
+    constexpr int o = kSphOff[LEG - 1];
+    fp.reach = group_within_reach<4>(&C.sph[o], K.R, K.rho, O, hmax);
+    if (fp.reach) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fp.xr[i] = K.rho + rot(K.R, v3(C.sph[o + i].x, C.sph[o + i].y, C.sph[o + i].z));
+            terrain_gather<HF>(P, O.x + fp.xr[i].x, O.y + fp.xr[i].y, fp.raw[i]);
+        }
+    }
+}
 template <bool HF>
 GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, float mu, float hmax, LaneState& st,
-                           V3& fa, V3& fl, float om_e) {
+                           V3& fa, V3& fl, float om_e, const FootProbe& fp) {
     fa = v3(0.f, 0.f, 0.f); fl = v3(0.f, 0.f, 0.f);
     constexpr int o = kSphOff[LEG - 1];
-    if (group_within_reach<4>(&C.sph[o], K.R, K.rho, O, hmax)) {
-        V3 xr[4], F; TerrainAt th[4];
+    if (fp.reach) {
+        V3 F;
+        const V3* xr = fp.xr;
+        TerrainAt th[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sphere_probe<HF>(P, C.sph[o + i], K.R, K.rho, O, xr[i], th[i]);
+        for (int i = 0; i < 4; ++i) th[i].h = terrain_eval<HF>(P, fp.raw[i], th[i].gx, th[i].gy);
         F = sphere_contact<HF, 0>(P, C.sph[o + 0], K.w, K.v, O, mu, hmax, st, xr[0], th[0], om_e); fa = fa + cross(xr[0], F); fl = fl + F;
         F = sphere_contact<HF, 1>(P, C.sph[o + 1], K.w, K.v, O, mu, hmax, st, xr[1], th[1], om_e); fa = fa + cross(xr[1], F); fl = fl + F;
         F = sphere_contact<HF, 2>(P, C.sph[o + 2], K.w, K.v, O, mu, hmax, st, xr[2], th[2], om_e); fa = fa + cross(xr[2], F); fl = fl + F;
         F = sphere_contact<HF, 3>(P, C.sph[o + 3], K.w, K.v, O, mu, hmax, st, xr[3], th[3], om_e); fa = fa + cross(xr[3], F); fl = fl + F;
     } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
+}
+template <bool HF>
+GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, float mu, float hmax, LaneState& st,
+                           V3& fa, V3& fl, float om_e) {
+    FootProbe fp;
+    foot_probe<HF>(P, C, K, O, hmax, fp);
+    foot_contacts<HF>(P, C, K, O, mu, hmax, st, fa, fl, om_e, fp);
 }
 
 #include "grx_rare.h"
@@ -292,6 +331,7 @@ template <bool HF, int W>
 GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                      SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc, const LinkForceOut& lfo,
                      const RareBuf& RB, int lane, int el, int side, SelfNear& sn, bool first) {
+    static_assert(SELF_BYTES <= RC_RES_BYTES, "the self-collision staging reuses the rare contacts' result table");
     const SelfBuf SB = self_carve(reinterpret_cast<char*>(RB.res));   // the rare contacts' result table is free again by then
     const float dt = P.sim_dt;
     R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
@@ -359,7 +399,7 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
     {   // self-collision: leg against leg, thigh against base-lump shapes
         const ChainKin KS[3] = {K2, K3, K4};
         if (first) sn = self_broad_phase(P, C, side, R0, KS);   // wave-uniform
-        self_collision(P, C, SB, lane, side, R0, st.ang, st.vel, KS, 2.0f * LC.mu - P.terrain_friction, sn, sc);
+        self_collision(P, T, C, SB, lane, side, R0, st.ang, st.vel, KS, 2.0f * LC.mu - P.terrain_friction, sn, sc);
     }
     pA[2] = pA[2] - ro.fa2 - sc.fa[0]; pL[2] = pL[2] - ro.fl2 - sc.fl[0];
     pA[3] = pA[3] - ro.fa3 - sc.fa[1]; pL[3] = pL[3] - ro.fl3 - sc.fl[1];
@@ -388,9 +428,9 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
         float d = dot(a, ua) + dot(s, ul);
         float di = grx_rcp(d);
         // joint-limit spring/damper (oracle substep()): added to the motor torque
-        float t = tau_m[k];
-        if (st.q[k] < C.body[k].qlo) t += C.body[k].Klim * (C.body[k].qlo - st.q[k]) - C.body[k].Clim * qdk;
-        else if (st.q[k] > C.body[k].qhi) t += C.body[k].Klim * (C.body[k].qhi - st.q[k]) - C.body[k].Clim * qdk;
+        const float qk = st.q[k], qlo = C.body[k].qlo, qhi = C.body[k].qhi;   // (branch-free: see grx_wavepipe.h)
+        const float viol = qk < qlo ? qlo - qk : (qk > qhi ? qhi - qk : 0.f);
+        const float t = tau_m[k] + (C.body[k].Klim * viol - (viol != 0.f ? C.body[k].Clim * qdk : 0.f));
         float u = t - (dot(a, pa) + dot(s, pl));
         syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
         float ud = u * di;
@@ -1051,7 +1091,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
 #pragma unroll
                     for (int b = 0; b < NZB; ++b) { z[(b * 4 + 0) * 64] = nzb[b].x; z[(b * 4 + 1) * 64] = nzb[b].y; z[(b * 4 + 2) * 64] = nzb[b].z; z[(b * 4 + 3) * 64] = nzb[b].w; }
                 }
-                self_loop(P, GRX_HELPER_C, RB, s_footfr, self_carve(s_self), P.friction[e], L, lane, el, side);
+                self_loop(P, s_tab, GRX_HELPER_C, RB, s_footfr, self_carve(s_self), P.friction[e], L, lane, el, side);
             } else if (wv == 2) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {

@@ -74,10 +74,21 @@ GRX_DEV bool sphere_pair(KP P, const SphW& a, const SphW& b, float mu, V3& F, V3
 //                 (bit-for-bit opposite in the two lanes: see the contact law above)
 struct SelfNear { uint32_t m; };   // bit 0: the legs' bounding spheres can meet during this policy step; bits 16..23: base-lump / thigh entries
 constexpr float kSelfMargin = 0.10f;   // 5 m/s of closing speed over the 0.02 s of a policy step
-constexpr int SELF_GROUP = 8;          // candidate envs per round
-constexpr int SELF_ST_BYTES = SELF_GROUP * 16 * 2 * 16, SELF_BYTES = SELF_ST_BYTES + SELF_GROUP * 8;
-struct SelfBuf { float4* st; unsigned long long* mask; };   // st[cand][side * 8 + shape][2]: (c.xyz, r) (u.xyz, dmax)
-GRX_DEV SelfBuf self_carve(char* p) { SelfBuf b; b.st = reinterpret_cast<float4*>(p); b.mask = reinterpret_cast<unsigned long long*>(p + SELF_ST_BYTES); return b; }
+constexpr int SELF_GROUP = 8;          // candidate envs per round of pair tests (8 lanes each)
+// LDS staging, one row of SELF_ROW float4 per lane (env, side): its 8 sphere centres relative to O with their radii, then
+// (w, v) of its three shape-carrying bodies.  Every lane stages every sub-step, in the same pass that finds the leg's
+// lateral extent (the centres are computed once); the velocities of the few spheres that do overlap are formed from the
+// body rows by the lanes that need them.
+constexpr int SELF_ROW = 8 + 6;
+constexpr int SELF_ST_BYTES = 64 * SELF_ROW * 16, SELF_BYTES = SELF_ST_BYTES + EPB * 8 + 64;
+struct SelfBuf { float4* st; unsigned long long* mask; uint8_t* envs; };   // mask[env]: overlapping pairs; envs[rank]: candidate envs, compacted
+GRX_DEV SelfBuf self_carve(char* p) {
+    SelfBuf b;
+    b.st = reinterpret_cast<float4*>(p);
+    b.mask = reinterpret_cast<unsigned long long*>(p + SELF_ST_BYTES);
+    b.envs = reinterpret_cast<uint8_t*>(p + SELF_ST_BYTES + EPB * 8);
+    return b;
+}
 
 GRX_DEV V3 sph_centre(const SphC& S, const ChainKin& K) { return K.rho + rot(K.R, v3(S.x, S.y, S.z)); }
 GRX_DEV V3 v3_swap(V3 a) { return v3(pair_swap(a.x), pair_swap(a.y), pair_swap(a.z)); }
@@ -119,7 +130,7 @@ GRX_DEV SelfNear self_broad_phase(KP P, const SideConst& C, int side, const R3& 
 
 // K[0..2]: frames of this lane's chain bodies 2, 3, 4; sn:
 // this policy step's broad phase.  Must be called by all 64 lanes in wave-uniform control flow.
-GRX_DEV void self_collision(KP P, const SideConst& C, const SelfBuf& SB, int lane, int side, const R3& R0, V3 ang, V3 vel,
+GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const SelfBuf& SB, int lane, int side, const R3& R0, V3 ang, V3 vel,
                             const ChainKin K[3], float mu, const SelfNear& sn, SelfOut& o, long long* pacc = nullptr) {
     const V3 zero = v3(0.f, 0.f, 0.f);
 #pragma unroll
@@ -133,19 +144,27 @@ GRX_DEV void self_collision(KP P, const SideConst& C, const SelfBuf& SB, int lan
     constexpr int cnt[3] = {2, 2, 4}, off[3] = {8, 10, 12};
     // ---- leg x leg
     if (__any((sn.m & 1u) != 0u)) {
-        // separating plane along the base's lateral axis: this leg's extent towards the other one
+        // one pass over this lane's 8 spheres: centre -> LDS row, and the leg's extent towards the other leg along the
+        // base's lateral axis (the separating-plane test below)
+        const int el = lane >> 1;
+        float4* const row = SB.st + lane * SELF_ROW;
         const V3 yb = R0.cy;
         float ext = side == 0 ? 1e30f : -1e30f;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i) {
 #pragma unroll
             for (int a = 0; a < cnt[i]; ++a) {
                 const SphC& S = C.sph[off[i] + a];
-                const float y = dot(sph_centre(S, K[i]), yb);
+                const V3 c = sph_centre(S, K[i]);
+                row[off[i] - 8 + a] = rc4(c.x, c.y, c.z, S.r);
+                const float y = dot(c, yb);
                 ext = side == 0 ? fminf(ext, y - S.r) : fmaxf(ext, y + S.r);   // left leg (+y side): its lowest y; right leg: its highest
             }
+            row[8 + 2 * i] = rc4(K[i].w.x, K[i].w.y, K[i].w.z, K[i].v.x);
+            row[9 + 2 * i] = rc4(K[i].v.y, K[i].v.z, 0.f, 0.f);
+        }
 #ifdef GRX_PROFILE_SECTIONS
-        long long tp_ = clock64(); pacc[4] += tp_ - t0_;   // centres + extents
+        long long tp_ = clock64(); pacc[4] += tp_ - t0_;   // centres, extents, staging
 #endif
         const float oext = pair_swap(ext);
         const bool cand = (sn.m & 1u) && (side == 0 ? ext <= oext : oext <= ext);   // not separated (same verdict in both lanes)
@@ -154,79 +173,69 @@ GRX_DEV void self_collision(KP P, const SideConst& C, const SelfBuf& SB, int lan
         pacc[1] += __popcll(cb);
 #endif
         if (cb) {
-            const int rank = __popcll(cb & ((1ull << (lane & ~1)) - 1ull));   // candidate envs before this lane's env (same in both its lanes)
             const int ncand = __popcll(cb);
-            for (int g0 = 0; g0 < ncand; g0 += SELF_GROUP) {
-                const bool mine = cand && rank >= g0 && rank < g0 + SELF_GROUP;   // both lanes of the env
-                const int cslot = rank - g0;
-                if (mine) {   // stage this lane's 8 spheres
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int a = 0; a < cnt[i]; ++a) {
-                            const SphC& S = C.sph[off[i] + a];
-                            const V3 c = sph_centre(S, K[i]), u = K[i].v + cross(K[i].w, c);   // (candidates only: recomputed rather than kept)
-                            float4* d = SB.st + ((cslot * 16 + side * 8 + (off[i] - 8 + a)) * 2);
-                            d[0] = rc4(c.x, c.y, c.z, S.r); d[1] = rc4(u.x, u.y, u.z, S.dmax);
-                        }
-                    if (side == 0) SB.mask[cslot] = 0ull;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#ifdef GRX_PROFILE_SECTIONS
-                { const long long t_ = clock64(); pacc[5] += t_ - tp_; tp_ = t_; }   // ballot, rank, staging
-#endif
-                {   // all 64 lanes: 8 lanes per candidate env; lane `sub` tests the right leg's shape `sub` against the
-                    // left leg's eight (pair id = left shape * 8 + right shape; P.sp_mask: the pairs the model lists)
-                    const int ws_ = lane >> 3, sub = lane & 7;
-                    unsigned long long bits = 0ull;
-                    if (g0 + ws_ < ncand) {
-                        const float4* stc = SB.st + ws_ * 32;
-                        const float4 b = stc[(8 + sub) * 2];
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            const float4 a = stc[t * 2];
-                            const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, Rs = a.w + b.w;
-                            if (dx * dx + dy * dy + dz * dz < Rs * Rs) bits |= 1ull << (t * 8 + sub);
-                        }
-                        bits &= P.sp_mask;
-                        if (bits) __hip_atomic_fetch_or(SB.mask + ws_, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                unsigned long long hm = mine ? SB.mask[cslot] : 0ull;
-#ifdef GRX_PROFILE_SECTIONS
-                { const long long t_ = clock64(); pacc[6] += t_ - tp_; tp_ = t_; }   // pair tests
-#endif
-#ifdef GRX_PROFILE_SECTIONS
-                pacc[2] += __popcll(__ballot(hm != 0ull)); pacc[3] += 1;
-#endif
-                while (__any(hm != 0ull)) {   // overlapping pairs of this lane's env, ascending
-                    if (hm) {
-                        const int pid = __ffsll((long long)hm) - 1;
-                        hm &= hm - 1ull;
-                        const int sa = pid >> 3, sb_ = pid & 7;      // left shape, right shape
-                        const int ms = side == 0 ? sa : sb_, os = side == 0 ? sb_ : sa;   // mine, the other leg's
-                        const float4* stc = SB.st + cslot * 32;
-                        const float4 m0 = stc[(side * 8 + ms) * 2], m1 = stc[(side * 8 + ms) * 2 + 1];
-                        const float4 o0 = stc[((side ^ 1) * 8 + os) * 2], o1 = stc[((side ^ 1) * 8 + os) * 2 + 1];
-                        SphW ma, ob;
-                        ma.c = v3(m0.x, m0.y, m0.z); ma.r = m0.w; ma.u = v3(m1.x, m1.y, m1.z); ma.dmax = m1.w;
-                        ob.c = v3(o0.x, o0.y, o0.z); ob.r = o0.w; ob.u = v3(o1.x, o1.y, o1.z); ob.dmax = o1.w;
-                        V3 F, pw;
-                        if (sphere_pair(P, ma, ob, mu, F, pw)) {
-                            const V3 Tq = cross(pw, F);
-                            const int kb = ms < 2 ? 0 : (ms < 4 ? 1 : 2);   // chain body 2 + kb carries my shape
-                            if (kb == 0) { o.fa[0] = o.fa[0] + Tq; o.fl[0] = o.fl[0] + F; }
-                            else if (kb == 1) { o.fa[1] = o.fa[1] + Tq; o.fl[1] = o.fl[1] + F; }
-                            else { o.fa[2] = o.fa[2] + Tq; o.fl[2] = o.fl[2] + F; }
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the staging rows are rewritten by the next group
-#ifdef GRX_PROFILE_SECTIONS
-                { const long long t_ = clock64(); pacc[7] += t_ - tp_; tp_ = t_; }   // forces
-#endif
+            if (cand && side == 0) {   // compacted list of the candidate envs; their pair masks start empty
+                SB.envs[__popcll(cb & ((1ull << lane) - 1ull))] = (uint8_t)el;
+                SB.mask[el] = 0ull;
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef GRX_PROFILE_SECTIONS
+            { const long long t_ = clock64(); pacc[5] += t_ - tp_; tp_ = t_; }   // ballot, list
+#endif
+            for (int g0 = 0; g0 < ncand; g0 += SELF_GROUP) {
+                // all 64 lanes: 8 lanes per candidate env; lane `sub` tests the right leg's shape `sub` against the
+                // left leg's eight (pair id = left shape * 8 + right shape; P.sp_mask: the pairs the model lists)
+                const int ws_ = lane >> 3, sub = lane & 7;
+                if (g0 + ws_ < ncand) {
+                    const int env = SB.envs[g0 + ws_];
+                    const float4* stl = SB.st + (env * 2) * SELF_ROW;
+                    const float4 b = stl[SELF_ROW + sub];
+                    unsigned long long bits = 0ull;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float4 a = stl[t];
+                        const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z, Rs = a.w + b.w;
+                        if (dx * dx + dy * dy + dz * dz < Rs * Rs) bits |= 1ull << (t * 8 + sub);
+                    }
+                    bits &= P.sp_mask;
+                    if (bits) __hip_atomic_fetch_or(SB.mask + env, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            unsigned long long hm = cand ? SB.mask[el] : 0ull;
+#ifdef GRX_PROFILE_SECTIONS
+            { const long long t_ = clock64(); pacc[6] += t_ - tp_; tp_ = t_; }   // pair tests
+            pacc[2] += __popcll(__ballot(hm != 0ull)); pacc[3] += 1;
+#endif
+            while (__any(hm != 0ull)) {   // overlapping pairs of this lane's env, ascending
+                if (hm) {
+                    const int pid = __ffsll((long long)hm) - 1;
+                    hm &= hm - 1ull;
+                    const int sa = pid >> 3, sb_ = pid & 7;      // left shape, right shape
+                    const int ms = side == 0 ? sa : sb_, os = side == 0 ? sb_ : sa;   // mine, the other leg's
+                    const int kb = ms < 2 ? 0 : (ms < 4 ? 1 : 2), ko = os < 2 ? 0 : (os < 4 ? 1 : 2);   // carrying chain body - 2
+                    const float4* rm = SB.st + lane * SELF_ROW;
+                    const float4* ro = SB.st + (lane ^ 1) * SELF_ROW;
+                    const float4 m0 = rm[ms], o0 = ro[os];
+                    const float4 mw = rm[8 + 2 * kb], mv = rm[9 + 2 * kb], ow = ro[8 + 2 * ko], ov = ro[9 + 2 * ko];
+                    SphW ma, ob;
+                    ma.c = v3(m0.x, m0.y, m0.z); ma.r = m0.w; ma.dmax = T.side[side].sph[8 + ms].dmax;
+                    ob.c = v3(o0.x, o0.y, o0.z); ob.r = o0.w; ob.dmax = T.side[side ^ 1].sph[8 + os].dmax;
+                    ma.u = v3(mw.w, mv.x, mv.y) + cross(v3(mw.x, mw.y, mw.z), ma.c);
+                    ob.u = v3(ow.w, ov.x, ov.y) + cross(v3(ow.x, ow.y, ow.z), ob.c);
+                    V3 F, pw;
+                    if (sphere_pair(P, ma, ob, mu, F, pw)) {
+                        const V3 Tq = cross(pw, F);
+                        if (kb == 0) { o.fa[0] = o.fa[0] + Tq; o.fl[0] = o.fl[0] + F; }
+                        else if (kb == 1) { o.fa[1] = o.fa[1] + Tq; o.fl[1] = o.fl[1] + F; }
+                        else { o.fa[2] = o.fa[2] + Tq; o.fl[2] = o.fl[2] + F; }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the rows are rewritten by the next sub-step
+#ifdef GRX_PROFILE_SECTIONS
+            { const long long t_ = clock64(); pacc[7] += t_ - tp_; tp_ = t_; }   // forces
+#endif
         }
     }
     // ---- base-lump shapes x this lane's thigh shapes

@@ -155,6 +155,10 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
             rigid_inertia(R, kap, C.body[k].mass, Ic, AK[k], hK[k]);
         }
     }
+#ifdef GRX_PROFILE_SECTIONS   // (keep the walk above the stamp)
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) { GRX_PIN(Ss[k].x); GRX_PIN(cl[k].x); GRX_PIN(AK[k].xx); GRX_PIN(AK[k].yz); GRX_PIN(hK[k].x); }
+#endif
     GRX_EV(1);
     // ---- inward pass, inertia half (leaf -> root): articulated inertias, U = I^A S, 1/d, and the articulated inertia's
     // action on the velocity-product acceleration, I^a c -- everything the bias recursion below needs from this half, as
@@ -174,6 +178,12 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         Icl[k] = mulT(B, ca[k]) + mul(D, cl[k]);
         Ua[k] = ua; Ul[k] = ul; dinv[k] = di;
     }
+#ifdef GRX_PROFILE_SECTIONS
+    GRX_PIN(A.xx); GRX_PIN(B.a00); GRX_PIN(D.xx);
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) { GRX_PIN(Ica[k].x); GRX_PIN(Ica[k].y); GRX_PIN(Ica[k].z); GRX_PIN(Icl[k].x); GRX_PIN(Icl[k].y); GRX_PIN(Icl[k].z); }
+    GRX_EV(3);
+#endif
     // base level: both chains (DPP pair exchange) + the base lump, factorised for the solve below
     A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
     {
@@ -181,6 +191,10 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         rigid_inertia(R0, rot(R0, LC.base_c), LC.base_m, LC.base_I, A0, h0);
         add_rigid(A, B, D, A0, h0, LC.base_m);
     }
+#ifdef GRX_PROFILE_SECTIONS
+    GRX_PIN(A.xx); GRX_PIN(A.yz); GRX_PIN(B.a00); GRX_PIN(B.a22); GRX_PIN(D.xx); GRX_PIN(D.yz);
+    GRX_EV(14);
+#endif
     S3 Di = inv(D);
     S3 Sci;
     {
@@ -189,17 +203,10 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         const S3 Sc = {A.xx - dot(b0, d0), A.xy - dot(b0, d1), A.xz - dot(b0, d2), A.yy - dot(b1, d1), A.yz - dot(b1, d2), A.zz - dot(b2, d2)};
         Sci = inv(Sc);
     }
-    // motor torque + joint-limit spring/damper (oracle substep()) of every joint: known now, needed in the bias half
-    float tq[LEG];
-#pragma unroll
-    for (int k = 0; k < LEG; ++k) {
-        const float qdk = st.qd[k];
-        float t = tau_m[k];
-        if (st.q[k] < Clds.body[k].qlo) t += Clds.body[k].Klim * (Clds.body[k].qlo - st.q[k]) - Clds.body[k].Clim * qdk;
-        else if (st.q[k] > Clds.body[k].qhi) t += Clds.body[k].Klim * (Clds.body[k].qhi - st.q[k]) - Clds.body[k].Clim * qdk;
-        tq[k] = t;
-        GRX_PIN(tq[k]);
-    }
+#ifdef GRX_PROFILE_SECTIONS
+    GRX_PIN(Sci.xx); GRX_PIN(Sci.yz); GRX_PIN(Di.xx); GRX_PIN(Di.yz);
+    if (seq == 5 && lane == 0) { __builtin_amdgcn_sched_barrier(0); P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 79] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+#endif
     // The spin-waits below are atomic loads: the compiler may sink pure register arithmetic across them, and did (the
     // whole inertia half ended up behind the last wait: 4 k cycles per sub-step, measured).  Pin the results here.
     GRX_PIN(Sci.xx); GRX_PIN(Sci.xy); GRX_PIN(Sci.xz); GRX_PIN(Sci.yy); GRX_PIN(Sci.yz); GRX_PIN(Sci.zz);
@@ -212,13 +219,15 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     V3 pa = v3(0.f, 0.f, 0.f), pl = v3(0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
+        float tq_k;
         {
             GRX_WAIT(L.flag + FL_BIAS, seq * 8 + (LEG - k), 0);
             const float4* b_ = L.pb + (k * PB4) * 64 + lane;
             const float4 b0_ = b_[0 * 64], b1_ = b_[1 * 64];
             pa = pa + v3(b0_.x, b0_.y, b0_.z); pl = pl + v3(b0_.w, b1_.x, b1_.y);
+            tq_k = tau_m[k] + b1_.z;   // motor torque + joint-limit spring/damper (from wave 2, with the bias force)
         }
-        const float u = tq[k] - (dot(Sa[k], pa) + dot(Ss[k], pl));
+        const float u = tq_k - (dot(Sa[k], pa) + dot(Ss[k], pl));
         const float ud = u * dinv[k];
         uu[k] = u;
         pa = pa + Ica[k] + Ua[k] * ud;
@@ -226,7 +235,6 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     }
     GRX_EV(7);
     // ---- contact wrenches on chain bodies 4 (foot), 3 (shank), 2 (thigh): delta recursion  dp -> dp + U (-S.dp)/d
-    GRX_EV(3);
     GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
     GRX_EV(4);
     GRX_WAIT(L.flag + FL_LEGS, seq + 1, 2);
@@ -328,7 +336,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 // ---------------------------------------------------------------------------------------------------------------
 // wave 1: self-collision (grx_self.h) -- leg against leg (the partner lane is one DPP step away), thigh against base-lump
 // shapes -- on the chain frames wave 2 publishes right after its walk
-GRX_DEV void self_loop(KP P, const SideConst& C, const RareBuf& RB, const float4* footfr, const SelfBuf& SB, float mu_self, const PipeLds& L,
+GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, const float4* footfr, const SelfBuf& SB, float mu_self, const PipeLds& L,
                        int lane, int el, int side) {
     GRX_HELPER_PROF_BEGIN;
     SelfNear sn; sn.m = 0;   // self-collision broad phase of this policy step
@@ -353,7 +361,7 @@ GRX_DEV void self_loop(KP P, const SideConst& C, const RareBuf& RB, const float4
         }
         if (seq == 0) sn = self_broad_phase(P, C, side, R0, KS);
         SelfOut sc;
-        self_collision(P, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc);
+        self_collision(P, T, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc);
         float4* o = L.wc + 7 * 64 + lane;
         o[0 * 64] = f4(sc.fa[0].x, sc.fa[0].y, sc.fa[0].z, sc.fl[0].x);
         o[1 * 64] = f4(sc.fl[0].y, sc.fl[0].z, sc.fa[1].x, sc.fa[1].y);
@@ -378,6 +386,9 @@ template <bool HF>
 GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, float4* footfr, float mu, float hmax, float om_e, LaneState& hs, const PipeLds& L,
                                 int lane, int el, int side) {
     GRX_HELPER_PROF_BEGIN;
+    float lim_lo[LEG], lim_hi[LEG], lim_k[LEG], lim_c[LEG];   // joint-limit constants: registers for the whole policy step
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) { lim_lo[k] = C.body[k].qlo; lim_hi[k] = C.body[k].qhi; lim_k[k] = C.body[k].Klim; lim_c[k] = C.body[k].Clim; }
     for (int seq = 0; seq < P.decimation; ++seq) {
         GRX_HELPER_PROF_IDLE0;
         flag_wait(L.flag + FL_STATE, seq + 1);
@@ -405,22 +416,30 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
             if (k == 4) { rare_store_frame(footfr + lane, 64, K.R, K.rho, K.w, K.v);   // foot (self-collision, wave 1)
                           flag_set(L.flag + FL_FRAMES, seq + 1, lane); GRX_EV(8); }
         }
+        // the foot spheres' heightfield gathers go out now and land while the bias forces are computed
+        FootProbe fp;
+        foot_probe<HF>(P, C, K, O, hmax, fp);
 #pragma unroll
         for (int k = LEG - 1; k >= 0; --k) {
             const V3 kap = KK[k].rho + rot(KK[k].R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
             const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
             V3 pa, pl;
             rigid_bias(KK[k].R, kap, C.body[k].mass, Ic, KK[k].w, KK[k].v, pa, pl);
+            // joint-limit spring/damper torque of joint k (oracle substep()): rides in the hand-over's spare slot.  Branch-free,
+            // constants in this wave's registers (wave 0's are full: fetched there from LDS behind data-dependent branches
+            // it cost 1.8 k cycles per sub-step)
+            const float viol = qs_q[k] < lim_lo[k] ? lim_lo[k] - qs_q[k] : (qs_q[k] > lim_hi[k] ? lim_hi[k] - qs_q[k] : 0.f);
+            const float tlim = lim_k[k] * viol - (viol != 0.f ? lim_c[k] * qs_qd[k] : 0.f);
             float4* o = L.pb + (k * PB4) * 64 + lane;
             o[0 * 64] = f4(pa.x, pa.y, pa.z, pl.x);
-            o[1 * 64] = f4(pl.y, pl.z, 0.f, 0.f);
+            o[1 * 64] = f4(pl.y, pl.z, tlim, 0.f);
             flag_set(L.flag + FL_BIAS, seq * 8 + (LEG - k), lane);
             if (k == LEG - 1) GRX_EV(9);
             if (k == 0) GRX_EV(10);
         }
         float4* c_ = L.wc + lane;
         V3 fa, fl;
-        foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl, om_e);
+        foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl, om_e, fp);
         {   // foot link velocity BEFORE this sub-step's integration (sub-step averaged foot speed, fftai.py:79-81)
             const V3 fr = K.rho + rot(K.R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
             const V3 fv = K.v + cross(K.w, fr);
