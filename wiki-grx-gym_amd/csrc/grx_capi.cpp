@@ -575,6 +575,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(obs, (size_t)c.num_obs * N + 64); DA(pri_obs, (size_t)c.num_pri_obs * N + 64);
     const int nblocks = (c.num_envs + grx_envs_per_block() - 1) / grx_envs_per_block();
     DA(stat_partial, (size_t)(2 * nblocks + 1) * (NT + 1));   // generic kernel: down to 16 envs per block
+    P.stat_stride = 2 * nblocks + 1;
     DA(stats, NT + 1); DA(prof, (size_t)nblocks * GRX_PROF_SLOTS);
     float* base_mass_com = nullptr;
     rc = dalloc(s, &base_mass_com, 4 * N);

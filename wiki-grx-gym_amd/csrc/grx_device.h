@@ -117,6 +117,7 @@ struct KParams {
     uint8_t *reset, *time_out, *term_contact;
     float *base_lin_vel, *base_ang_vel, *proj_grav, *episode_sums, *reward_terms, *heights;
     float *obs, *pri_obs, *stat_partial, *stats;
+    int32_t stat_stride;   // stat_partial is [NT + 1][stat_stride]: one column per block of the writing kernel
     int32_t nd;        // dofs of the model (10 on the fast path)
     long long* prof;   // GRX_PROFILE_SECTIONS builds only: [nblocks][16] s_memtime stamps
 };

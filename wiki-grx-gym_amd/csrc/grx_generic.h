@@ -746,7 +746,7 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
         P.term_contact[e] = term_contact ? 1 : 0;
     }
     __syncthreads();
-    for (int i = lane; i <= NT; i += epb) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + i] = s_stat[i];
+    for (int i = lane; i <= NT; i += epb) P.stat_partial[(size_t)i * P.stat_stride + blockIdx.x] = s_stat[i];
 }
 
 // BaseTask.reset() first half for the generic path
@@ -762,9 +762,9 @@ __global__ __launch_bounds__(64) void grx_reset_all_generic(const KParams* __res
         float contrib = act ? P.episode_sums[(size_t)t * N + e] : 0.f;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off);
-        if (lane == 0) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + t] = contrib;
+        if (lane == 0) P.stat_partial[(size_t)t * P.stat_stride + blockIdx.x] = contrib;
     }
-    if (lane == 0) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + NT] = (float)min(epb, P.N - blockIdx.x * epb);
+    if (lane == 0) P.stat_partial[(size_t)NT * P.stat_stride + blockIdx.x] = (float)min(epb, P.N - blockIdx.x * epb);
     if (!act) return;
     GenBase B;
     B.pos = v3(P.root[e], P.root[N + e], P.root[2 * N + e]);

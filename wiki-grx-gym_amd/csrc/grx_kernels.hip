@@ -89,16 +89,20 @@ GRX_DEV float riser_weight(float t, float jump, float thr, float& dt) {
 // In two halves: the gather (four int16 loads, ~1.2 us of memory latency on this part) and the interpolation that first
 // USES them -- a caller with independent work puts it between the two.
 struct TerrainRaw { int h00, h01, h10, h11; float tx, ty; };
-template <bool HF>
-GRX_DEV void terrain_gather(KP P, float x, float y, TerrainRaw& r) {
-    if (!HF) return;
+// raster cell under (x, y) (index of its low corner) and the position inside it
+GRX_DEV int terrain_locate(KP P, float x, float y, float& tx, float& ty) {
     float fx = (x + P.border_size) * P.inv_hscale;
     float fy = (y + P.border_size) * P.inv_hscale;
     fx = fminf(fmaxf(fx, 0.0f), (float)(P.hf_rows - 1));
     fy = fminf(fmaxf(fy, 0.0f), (float)(P.hf_cols - 1));
-    int ix = min((int)fx, P.hf_rows - 2), iy = min((int)fy, P.hf_cols - 2);
-    r.tx = fx - (float)ix; r.ty = fy - (float)iy;
-    const int16_t* H = P.hf + (size_t)ix * P.hf_cols + iy;
+    const int ix = min((int)fx, P.hf_rows - 2), iy = min((int)fy, P.hf_cols - 2);
+    tx = fx - (float)ix; ty = fy - (float)iy;
+    return ix * P.hf_cols + iy;
+}
+template <bool HF>
+GRX_DEV void terrain_gather(KP P, float x, float y, TerrainRaw& r) {
+    if (!HF) return;
+    const int16_t* H = P.hf + terrain_locate(P, x, y, r.tx, r.ty);
     r.h00 = H[0]; r.h01 = H[1]; r.h10 = H[P.hf_cols]; r.h11 = H[P.hf_cols + 1];
 }
 template <bool HF>
@@ -1559,7 +1563,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             }
         } else
             for (int i = tid; i < nenv * npri; i += NTHR) gpri[i] = s_pri[(i / npri) * PRS + (i % npri)];
-        if (tid <= NT) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + tid] = s_stat[tid];
+        if (tid <= NT) P.stat_partial[(size_t)tid * P.stat_stride + blockIdx.x] = s_stat[tid];   // term-major: the reduction reads rows of one term
     }
     // (Reducing the per-block statistics rows here, in the last block to finish, was tried twice to save the
     //  grx_finalize_stats launch: with an agent-scope __threadfence per block (whole-L2 write-back on this 8-XCD
@@ -1571,18 +1575,26 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
 // extras["episode"] (legged_robot.py:420-424): mean episode sums of the envs reset by this step;
 // kept from the previous resetting step when nobody reset (the reference only rewrites the dict
 // inside reset_idx, which returns early for an empty id list, legged_robot.py:387-388).
-// ONE block, a wave per reward term (round-robin): the ticket below is stored after the block's barrier, i.e. after every
-// statistics row of this step has been written -- a visible ticket covers EPISODE_STATS like every other output.
+// ONE block: its ticket store comes after the block's barrier, i.e. after every statistics row of this step has been
+// written -- a visible ticket covers EPISODE_STATS like every other output.  A wave per reward term (round-robin); the
+// partial sums are stored term-major, so a wave reads its term's row coalesced, eight independent loads at a time.
 constexpr int kFinalizeWaves = 16;
 __global__ __launch_bounds__(64 * kFinalizeWaves) void grx_finalize_stats(const KParams* __restrict__ Pg, int nblocks, int64_t* progress, int64_t ticket) {
     KP P = GRX_PARAMS(Pg);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // lanes stride over the step kernel's blocks
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* const crow = P.stat_partial + (size_t)NT * P.stat_stride;
     for (int t = wave; t <= NT; t += kFinalizeWaves) {
+        const float* const row = P.stat_partial + (size_t)t * P.stat_stride;
         float cnt = 0.f, s = 0.f;
-        for (int b = lane; b < nblocks; b += 64) {
-            cnt += P.stat_partial[(size_t)b * (NT + 1) + NT];
-            s += P.stat_partial[(size_t)b * (NT + 1) + t];
+        int b = lane;
+        for (; b + 7 * 64 < nblocks; b += 8 * 64) {   // (summed in the same order as one by one)
+            float c_[8], s_[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { c_[u] = crow[b + u * 64]; s_[u] = row[b + u * 64]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { cnt += c_[u]; s += s_[u]; }
         }
+        for (; b < nblocks; b += 64) { cnt += crow[b]; s += row[b]; }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { cnt += __shfl_xor(cnt, off); s += __shfl_xor(s, off); }
         if (lane == 0 && cnt > 0.f) P.stats[t] = (t == NT) ? cnt : s / cnt / P.max_episode_length_s;
@@ -1618,9 +1630,9 @@ __global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __rest
         float contrib = writer ? P.episode_sums[(size_t)t * N + e] : 0.f;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off);
-        if (lane == 0) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + t] = contrib;
+        if (lane == 0) P.stat_partial[(size_t)t * P.stat_stride + blockIdx.x] = contrib;
     }
-    if (lane == 0) P.stat_partial[(size_t)blockIdx.x * (NT + 1) + NT] = (float)min(EPB, N - blockIdx.x * EPB);
+    if (lane == 0) P.stat_partial[(size_t)NT * P.stat_stride + blockIdx.x] = (float)min(EPB, N - blockIdx.x * EPB);
     LaneState st;
     EnvAux ea;
     st.pos = v3(P.root[e], P.root[(size_t)N + e], P.root[2 * (size_t)N + e]);
