@@ -2,7 +2,7 @@
 import sys, ctypes as C, subprocess, os; sys.path.insert(0,'.')
 import numpy as np, torch
 csrc="wiki-grx-gym_amd/csrc"
-flags="-I../../include --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-hip-fp32-correctly-rounded-divide-sqrt -ffinite-math-only -fno-signed-zeros -fno-trapping-math -fassociative-math -fno-slp-vectorize -DGRX_REG_CONSTS -mllvm -amdgpu-sched-strategy=iterative-ilp -DGRX_PROFILE_SECTIONS"
+flags="-I../../include --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-hip-fp32-correctly-rounded-divide-sqrt -ffinite-math-only -fno-signed-zeros -fno-trapping-math -fassociative-math -fno-slp-vectorize -DGRX_REG_CONSTS=2 -mllvm -amdgpu-sched-strategy=iterative-ilp -DGRX_PROFILE_SECTIONS"
 os.makedirs(csrc + "/variants", exist_ok=True)
 PROF = os.path.abspath(csrc + "/variants/libgrx_prof.so")
 if "--build" in sys.argv or not os.path.exists(PROF):   # hipcc cross-compiles in the build container; the .so travels with gpurun

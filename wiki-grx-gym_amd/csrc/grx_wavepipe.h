@@ -216,14 +216,18 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     GRX_EV(2);
     // ---- inward pass, bias half (leaf -> root): the rigid-body bias forces come from wave 2, leaf first.  The chain-body
     // CONTACT wrenches are not waited for here: the recursion is linear in the bias forces, they follow separately below.
+    // (wave 2 is done with all five long before this point: one wait, and the ten LDS reads go out together -- one exposed
+    //  LDS latency instead of one per joint)
     V3 pa = v3(0.f, 0.f, 0.f), pl = v3(0.f, 0.f, 0.f);
+    GRX_WAIT(L.flag + FL_BIAS, seq * 8 + LEG, 0);
+    float4 bq0[LEG], bq1[LEG];
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) { const float4* b_ = L.pb + (k * PB4) * 64 + lane; bq0[k] = b_[0 * 64]; bq1[k] = b_[1 * 64]; }
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
         float tq_k;
         {
-            GRX_WAIT(L.flag + FL_BIAS, seq * 8 + (LEG - k), 0);
-            const float4* b_ = L.pb + (k * PB4) * 64 + lane;
-            const float4 b0_ = b_[0 * 64], b1_ = b_[1 * 64];
+            const float4 b0_ = bq0[k], b1_ = bq1[k];
             pa = pa + v3(b0_.x, b0_.y, b0_.z); pl = pl + v3(b0_.w, b1_.x, b1_.y);
             tq_k = tau_m[k] + b1_.z;   // motor torque + joint-limit spring/damper (from wave 2, with the bias force)
         }
@@ -419,24 +423,26 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
         // the foot spheres' heightfield gathers go out now and land while the bias forces are computed
         FootProbe fp;
         foot_probe<HF>(P, C, K, O, hmax, fp);
-#pragma unroll
-        for (int k = LEG - 1; k >= 0; --k) {
+        // rigid-body bias force of chain body k -> wave 0.  The joint-limit spring/damper torque of joint k (oracle substep())
+        // rides in the hand-over's spare slot: branch-free, constants in this wave's registers (on wave 0, fetched from LDS
+        // behind data-dependent branches, it cost 1.8 k cycles per sub-step)
+        auto bias_out = [&](const int k) {
             const V3 kap = KK[k].rho + rot(KK[k].R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
             const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
             V3 pa, pl;
             rigid_bias(KK[k].R, kap, C.body[k].mass, Ic, KK[k].w, KK[k].v, pa, pl);
-            // joint-limit spring/damper torque of joint k (oracle substep()): rides in the hand-over's spare slot.  Branch-free,
-            // constants in this wave's registers (wave 0's are full: fetched there from LDS behind data-dependent branches
-            // it cost 1.8 k cycles per sub-step)
             const float viol = qs_q[k] < lim_lo[k] ? lim_lo[k] - qs_q[k] : (qs_q[k] > lim_hi[k] ? lim_hi[k] - qs_q[k] : 0.f);
             const float tlim = lim_k[k] * viol - (viol != 0.f ? lim_c[k] * qs_qd[k] : 0.f);
             float4* o = L.pb + (k * PB4) * 64 + lane;
             o[0 * 64] = f4(pa.x, pa.y, pa.z, pl.x);
             o[1 * 64] = f4(pl.y, pl.z, tlim, 0.f);
             flag_set(L.flag + FL_BIAS, seq * 8 + (LEG - k), lane);
-            if (k == LEG - 1) GRX_EV(9);
-            if (k == 0) GRX_EV(10);
-        }
+        };
+        // (foot contacts between the bias forces of shank and thigh, so that the foot wrench is out early: tried, +1.2 us on
+        //  rough terrain -- wave 0 then waits for the last bias forces instead)
+        bias_out(4); GRX_EV(9);
+        bias_out(3); bias_out(2); bias_out(1); bias_out(0);
+        GRX_EV(10);
         float4* c_ = L.wc + lane;
         V3 fa, fl;
         foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl, om_e, fp);
