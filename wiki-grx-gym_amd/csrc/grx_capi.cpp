@@ -596,6 +596,23 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
                     m4[(size_t)i * c.hf_cols + j] = std::max(std::max(H[(size_t)i * c.hf_cols + j], H[(size_t)i1 * c.hf_cols + j]),
                                                              std::max(H[(size_t)i * c.hf_cols + j1], H[(size_t)i1 * c.hf_cols + j1]));
                 }
+            {   // the four corners of every cell, packed (grx_device.h hf_cells)
+                std::vector<uint32_t> cells(2 * n);
+                for (int i = 0; i < c.hf_rows; ++i)
+                    for (int j = 0; j < c.hf_cols; ++j) {
+                        const int i1 = std::min(i + 1, c.hf_rows - 1), j1 = std::min(j + 1, c.hf_cols - 1);
+                        const int16_t* H = c.height_samples;
+                        const uint32_t h00 = (uint16_t)H[(size_t)i * c.hf_cols + j], h01 = (uint16_t)H[(size_t)i * c.hf_cols + j1];
+                        const uint32_t h10 = (uint16_t)H[(size_t)i1 * c.hf_cols + j], h11 = (uint16_t)H[(size_t)i1 * c.hf_cols + j1];
+                        cells[2 * ((size_t)i * c.hf_cols + j)] = h00 | (h01 << 16);
+                        cells[2 * ((size_t)i * c.hf_cols + j) + 1] = h10 | (h11 << 16);
+                    }
+                uint32_t* dc = nullptr;
+                rc = dalloc(s, &dc, 2 * n);
+                if (rc) { grx_destroy(s); return rc; }
+                HIP_TRY(hipMemcpy(dc, cells.data(), 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice));
+                P.hf_cells = reinterpret_cast<const uint2*>(dc);
+            }
             int16_t* dm4 = nullptr;
             rc = dalloc(s, &dm4, n);
             if (rc) { grx_destroy(s); return rc; }

@@ -96,6 +96,8 @@ struct KParams {
     uint64_t sp_mask;            // bit (a * 8 + b): shape 8 + a of the LEFT lane and shape 8 + b of the RIGHT lane can touch (self-collision)
     uint32_t ll_mask;            // bit (i * 3 + j): the shapes of LEFT chain body 2 + i can touch those of RIGHT chain body 2 + j
     float* restitution;          // [N] per-env shape restitution (legged_robot.py:565-575)
+    const uint2* hf_cells;    // [hf_rows][hf_cols]: the four raster corners of cell (i, j), (h00 | h01 << 16, h10 | h11 << 16), edges clamped:
+                              // ONE 8-byte gather per terrain lookup instead of three or four 2-byte ones
     const int16_t* hf_max4;   // [hf_rows][hf_cols]: max of the four raster corners of cell (i, j) = upper bound of the bilinear
                               // height anywhere in the cell: the exact reach test of the lane-compacted contacts (grx_rare.h)
     float horizontal_scale, vertical_scale, border_size, inv_hscale;

@@ -102,8 +102,9 @@ GRX_DEV int terrain_locate(KP P, float x, float y, float& tx, float& ty) {
 template <bool HF>
 GRX_DEV void terrain_gather(KP P, float x, float y, TerrainRaw& r) {
     if (!HF) return;
-    const int16_t* H = P.hf + terrain_locate(P, x, y, r.tx, r.ty);
-    r.h00 = H[0]; r.h01 = H[1]; r.h10 = H[P.hf_cols]; r.h11 = H[P.hf_cols + 1];
+    const uint2 cc = P.hf_cells[terrain_locate(P, x, y, r.tx, r.ty)];   // one gather for the four corners
+    r.h00 = (int16_t)(cc.x & 0xffffu); r.h01 = (int16_t)(cc.x >> 16);
+    r.h10 = (int16_t)(cc.y & 0xffffu); r.h11 = (int16_t)(cc.y >> 16);
 }
 template <bool HF>
 GRX_DEV float terrain_eval(KP P, const TerrainRaw& r, float& gx, float& gy) {
@@ -672,9 +673,9 @@ GRX_DEV float height_sample(KP P, const KTables& T, float zn, float wn, V3 pos, 
     float px = (qx_ + pos.x + P.border_size) / P.horizontal_scale;
     float py = (qy_ + pos.y + P.border_size) / P.horizontal_scale;
     int ix = min(max((int)px, 0), P.hf_rows - 2), iy = min(max((int)py, 0), P.hf_cols - 2);
-    const int16_t* H = P.hf + (size_t)ix * P.hf_cols + iy;
-    int16_t h1 = H[0], h2 = H[P.hf_cols], h3 = H[1];
-    int16_t h = min(min(h1, h2), h3);
+    const uint2 cc = P.hf_cells[(size_t)ix * P.hf_cols + iy];   // one gather: heights[ix, iy], [ix + 1, iy], [ix, iy + 1]
+    const int h1 = (int16_t)(cc.x & 0xffffu), h3 = (int16_t)(cc.x >> 16), h2 = (int16_t)(cc.y & 0xffffu);
+    const int h = min(min(h1, h2), h3);
     return (float)h * P.vertical_scale;
 }
 
