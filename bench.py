@@ -18,9 +18,16 @@ Extra objects on the JSON line:
   roofline      HBM roofline of the fused step kernel: algorithmic bytes per env-step
                 (2476 B rough / 1750 B flat) x envs per launch / average kernel
                 duration measured with HIP events on the launch stream (grx_kernel_time_ms).
+                `valu_issue_frac`: the number that actually bounds this kernel -- VALU wave-instructions
+                per launch (SQ_INSTS_VALU of the committed rocprofv3 PMC pass, profiles/r02_pmc_sq_*.json)
+                / live kernel duration, against the chip's VALU issue peak (1024 SIMDs x one wave64
+                instruction per 2 cycles at 2.4 GHz, MI355X_MICROARCH.md).
   cpu_baseline  the CPU oracle ("port": oracle/grx_oracle.c, fp32, OpenMP over envs) timed on
                 this box's host cores on a bounded sample of the same workload.  It is NOT
-                Isaac Gym's CPU pipeline (unobtainable).
+                Isaac Gym's CPU pipeline (unobtainable).  `reference_stage`
+                quotes the one piece of the reference that CAN run: its own torch-CPU
+                post_physics_step (observations / rewards / resets, no physics), timed in the build
+                container (tools/time_ref_pipeline.py -> profiles/r02_ref_python_pipeline.json).
 """
 import argparse
 import os
@@ -34,6 +41,30 @@ sys.path.insert(0, ROOT)
 
 B_FLAT, B_ROUGH = 1750.0, 2476.0   # algorithmic bytes per env-step
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E peak (MI355X_MICROARCH.md)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0   # wave64 VALU instructions / s: 256 CUs x 4 SIMDs, one per 2 cycles, 2.4 GHz
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def reference_stage():
+    """The reference's own CPU number for the ONE stage of the path it can run without Isaac Gym (build-container
+    measurement, committed): read from profiles/, never measured here (the reference does not travel)."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r02_ref_python_pipeline.json")))
+        row = [r for r in j["rows"] if r["num_envs"] == 4096 and r["terrain"].startswith("rough")][0]
+        return {"value": row["env_steps_per_s_stage_only"], "unit": "env-steps/s", "cores": j["cores"], "cpu_model": j["cpu_model"],
+                "what": "reference post_physics_step (torch CPU: observations, 34 reward terms, resets; NO physics), 4096 envs rough, build container",
+                "source": "profiles/r02_ref_python_pipeline.json"}
+    except Exception:
+        return None
 
 
 def make_cfg(terrain, robot="lower_limb"):
@@ -64,8 +95,12 @@ def cpu_baseline(cfg, terrain_obj, envs, steps, seed):
         sim.step(acts[i % 4], 5.0, 2 + i)
     dt = time.time() - t0
     sim.close()
-    return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{envs} envs x {steps} steps of the same workload, oracle/grx_oracle.c fp32 + OpenMP ({dt:.1f} s)"}
+    return {"value": envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"{envs} envs x {steps} steps of the same workload, oracle/grx_oracle.c fp32 + OpenMP ({dt:.1f} s)",
+            "note": "a C restatement of THIS build's algorithm (physics + env pipeline) on the host cores -- not the reference: Isaac Gym's "
+                    "CPU pipeline is a closed binary absent from this image (BASELINE.md 2-3, B-cpu).  The reference's own runnable CPU "
+                    "stage is quoted in reference_stage.",
+            "reference_stage": reference_stage()}
 
 
 def main():
@@ -125,7 +160,8 @@ def main():
     for _ in range(args.warmup):
         counter += 1
         sim.step(pool[counter % 16], delay, counter)
-    sim.kernel_time_ms(enable=int(os.environ.get("GRX_BENCH_EVENT_STRIDE", "8")))   # HIP-event window: every 8th launch (an event pair costs the stream ~7 us)
+    # HIP-event window: every 8th launch (an event pair costs the stream ~7 us); every 2nd when only a few steps are timed
+    sim.kernel_time_ms(enable=int(os.environ.get("GRX_BENCH_EVENT_STRIDE", "8" if args.steps >= 400 else "2")))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -154,15 +190,25 @@ def main():
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this very workload (separate FETCH_SIZE /
         # WRITE_SIZE runs, tools/collect_profiles.sh); bench.py cannot host the profiler itself.  Raw counter sum:
         # FETCH_SIZE is a lower bound on gfx950 (MI355X_MICROARCH.md), see the note inside the file.
-        traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_rough4096.json")
-        if args.robot == "lower_limb" and args.terrain == "rough" and n_local == 4096 and os.path.exists(pmc):
-            try:
-                j = json.load(open(pmc))
-                traffic = (j["FETCH_SIZE"]["mean_KB"] + j["WRITE_SIZE"]["mean_KB"]) * 1024.0
-                traffic_src = "profiles/r01_pmc_hbm_rough4096.json (FETCH_SIZE + WRITE_SIZE, bytes per launch, uncorrected)"
-            except Exception:
-                traffic = None
+        traffic, traffic_src, valu_insts, valu_src = None, None, None, None
+        headline = args.robot == "lower_limb" and args.terrain == "rough" and n_local == 4096
+        for tag in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_rough4096.json")
+            if headline and traffic is None and os.path.exists(pmc):
+                try:
+                    j = json.load(open(pmc))
+                    traffic = (j["FETCH_SIZE"]["mean_KB"] + j["WRITE_SIZE"]["mean_KB"]) * 1024.0
+                    traffic_src = (f"profiles/{tag}_pmc_hbm_rough4096.json: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this "
+                                   "workload, bytes per launch, NOT live and uncorrected (FETCH_SIZE is a lower bound on gfx950)")
+                except Exception:
+                    traffic = None
+            sq = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_rough4096.json")
+            if headline and valu_insts is None and os.path.exists(sq):
+                try:
+                    valu_insts = float(json.load(open(sq))["SQ_INSTS_VALU"])
+                    valu_src = f"profiles/{tag}_pmc_sq_rough4096.json (SQ_INSTS_VALU per launch, rocprofv3 --pmc pass of this workload; duration live)"
+                except Exception:
+                    valu_insts = None
         achieved = bytes_per * n_local / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
             "metric": ("env-steps/sec GR1T1 rough-terrain @4096 envs" if args.terrain == "rough" else "env-steps/sec GR1T1 flat-terrain @4096 envs")
@@ -187,6 +233,8 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per * n_local,
                          "kernel": "grx_step_kernel" if args.robot == "lower_limb" else "grx_step_generic", "kernel_ms": kern_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_env_step": bytes_per,
+                         "valu_issue_frac": (valu_insts / (kern_ms * 1e-3) / VALU_ISSUE_PEAK) if (valu_insts and kern_ms > 0) else None,
+                         "valu_insts_per_launch": valu_insts, "valu_issue_peak_per_s": VALU_ISSUE_PEAK, "valu_source": valu_src,
                          "note": ("instruction-issue bound at this batch size (one wave per SIMD, DESIGN.md sections 4.1 and 5); HBM is the contractual roofline"
                                   if args.robot == "lower_limb" else "generic-tree kernel: bound by its global-memory workspace round trips (DESIGN.md section 4.3)")},
         }

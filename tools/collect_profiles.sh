@@ -36,7 +36,19 @@ for c in FETCH_SIZE WRITE_SIZE; do
     d=$out/pmc_$(echo $c | tr 'A-Z' 'a-z' | cut -d_ -f1)
     (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OLDPWD/$d -o b -- bash -c "cd $OLDPWD && $BENCH" > $OLDPWD/$d.log 2>&1)
 done
-cut -c1-400 $out/bench_rough.json; cut -c1-200 $out/bench_flat.json
+# SQ counters (instruction mix, issue / wait cycles): three more passes, own runs, kernel-trace only
+i=0
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
+    i=$((i + 1)); d=$out/pmc_sq$i
+    (cd /tmp && rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/$d -o b -- bash -c "cd $OLDPWD && python bench.py --steps 300 --warmup 50 --no-cpu-baseline" > $OLDPWD/$d.log 2>&1)
+done
+# config 5 (full body, generic-tree kernel): bench lines + kernel stats
+for n in 4096 16384; do
+    timeout 600 python bench.py --robot full_body --envs-per-gpu $n --no-cpu-baseline 2>> $out/full_body.err | tail -1 > $out/bench_full_body_rough$n.json
+done
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats_full_body -o b -- bash -c "cd $OLDPWD && python bench.py --robot full_body --envs-per-gpu 16384 --steps 300 --warmup 30 --no-cpu-baseline > /dev/null" > $OLDPWD/$out/stats_full_body.log 2>&1)
+find $out/stats_full_body -name "*kernel_trace.csv" -delete
+cut -c1-400 $out/bench_rough.json; cut -c1-200 $out/bench_flat.json; cut -c1-200 $out/bench_full_body_rough16384.json
 python -c "import json; print('rough runs ms/step:', [round(json.loads(l)['ms_per_step'], 4) for l in open('$out/bench_rough_runs.jsonl')])"
 python - <<EOF
 import json

@@ -27,4 +27,29 @@ out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                "are 4-byte-per-lane SoA columns (uncalibrated width), so the fetched bytes lie between 1x and 2x the counter. "
                "WRITE_SIZE is uncalibrated.")
 json.dump(out, open(f"{dst}/{tag}_pmc_hbm_rough4096.json", "w"), indent=1)
+# SQ passes -> one JSON (mean per launch of grx_step_kernel)
+sq = {"kernel": "grx_step_kernel<true, 4>", "workload": "python bench.py --steps 300 --warmup 50 --no-cpu-baseline (rough, 4096 envs); rocprofv3 --pmc, "
+      "one pass per counter group (tools/collect_profiles.sh), mean per launch"}
+for f in sorted(glob.glob(f"{src}/pmc_sq*/**/*counter_collection.csv", recursive=True)):
+    agg = {}
+    for r in csv.DictReader(open(f)):
+        if "grx_step_kernel" in r["Kernel_Name"]:
+            agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k_, v_ in agg.items():
+        sq[k_] = round(sum(v_) / len(v_))
+if "SQ_INSTS_VALU" in sq:
+    kms = bench["roofline"]["kernel_ms"]
+    sq["derived"] = {"kernel_ms_of_the_bench_line": kms,
+                     "valu_issue_frac": sq["SQ_INSTS_VALU"] / (kms * 1e-3) / (256 * 4 * 2.4e9 / 2.0),
+                     "valu_per_wave": sq["SQ_INSTS_VALU"] / max(sq.get("SQ_WAVES", 1), 1),
+                     "wait_any_fraction": sq.get("SQ_WAIT_ANY", 0) / max(sq.get("SQ_WAVE_CYCLES", 1), 1),
+                     "note": "VALU issue peak = 1024 SIMDs x one wave64 instruction per 2 cycles x 2.4 GHz; SQ_WAIT_ANY includes the helper waves' "
+                             "spin on the LDS sequence flags"}
+    json.dump(sq, open(f"{dst}/{tag}_pmc_sq_rough4096.json", "w"), indent=1)
+for n in (4096, 16384):
+    if os.path.exists(f"{src}/bench_full_body_rough{n}.json"):
+        shutil.copy(f"{src}/bench_full_body_rough{n}.json", f"{dst}/{tag}_bench_n1_full_body_rough{n}.json")
+fb = glob.glob(f"{src}/stats_full_body/**/*kernel_stats.csv", recursive=True)
+if fb:
+    shutil.copy(fb[0], f"{dst}/{tag}_kernel_stats_full_body_rough16384.csv")
 print(json.dumps(out, indent=1)[:1500])
