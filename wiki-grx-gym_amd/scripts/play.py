@@ -2,13 +2,14 @@
 (reference legged_gym/scripts/play.py:42-137).
 
 Same overrides (:45-56), same export path (:67-82, `logs/<experiment>/exported/policy_jit.pt`), same loop (:96-98) and the
-same two logs as the reference's Logger calls, written as JSON lines instead of matplotlib windows (the Logger class, the
-viewer, RECORD_FRAMES and MOVE_CAMERA are out of scope):
+same Logger calls (:86-137; utils/logger.py here is headless: a PNG instead of a window).  No viewer on a GPU box, so
+RECORD_FRAMES and MOVE_CAMERA are out of scope.  Files under `exported/`:
 
-  * `exported/play_states.jsonl`  -- one record per step for the first `stop_state_log` steps with exactly the keys of the
-    dict passed to `logger.log_states` (:110-126), for robot 0 / joint 1;
-  * `exported/play_rewards.json`  -- what `logger.log_rewards` accumulates and `print_rewards` shows (:131-137): per reward
-    term, the episode means weighted by the number of episodes that ended, over the first `max_episode_length` steps.
+  * `play_states.jsonl`  -- one record per step for the first `stop_state_log` steps with exactly the keys of the dict
+    passed to `logger.log_states` (:110-126), for robot 0 / joint 1;
+  * `play_states.png` / `.json` -- `logger.plot_states()` at step `stop_state_log` (:128-129);
+  * `play_rewards.json`  -- what `logger.log_rewards` accumulates and `print_rewards` shows (:131-137): per reward term, the
+    episode means weighted by the number of episodes that ended, over the first `max_episode_length` steps.
 """
 import json
 import os
@@ -16,7 +17,7 @@ import os
 import torch
 
 from wiki_grx_gym_amd.envs import *  # noqa: F401,F403
-from wiki_grx_gym_amd.utils import export_policy_as_jit, get_args, task_registry
+from wiki_grx_gym_amd.utils import Logger, export_policy_as_jit, get_args, task_registry
 from wiki_grx_gym_amd.utils.task_registry import LEGGED_GYM_ROOT_DIR
 
 EXPORT_POLICY = True
@@ -55,18 +56,14 @@ def play(args, steps=None, log_root="default"):
     stop_state_log = 100                               # number of steps the states are logged for
     stop_rew_log = int(env.max_episode_length) + 1     # number of steps before the average episode rewards are printed
     total = steps if steps is not None else 10 * int(env.max_episode_length)
-    rew_sums, num_episodes_total = {}, 0
+    logger = Logger(env.dt)
     states_path = os.path.join(out_dir, "play_states.jsonl")
     rewards_path = os.path.join(out_dir, "play_rewards.json")
 
     def dump_rewards():
-        avg = {k: v / max(num_episodes_total, 1) for k, v in rew_sums.items()}
         with open(rewards_path, "w") as f:
-            json.dump({"num_episodes": num_episodes_total, "average_per_second": avg}, f, indent=1)
-        print("Average rewards per second:")
-        for k, v in avg.items():
-            print(f" - {k}: {v}")
-        print(f"Total number of episodes: {num_episodes_total}")
+            json.dump({"num_episodes": logger.num_episodes, "average_per_second": logger.average_rewards()}, f, indent=1)
+        logger.print_rewards()
 
     with open(states_path, "w") as sf:
         for i in range(total):
@@ -88,23 +85,24 @@ def play(args, steps=None, log_root="default"):
                     "base_vel_yaw": env.base_ang_vel[robot_index, 2].item(),
                     "contact_forces_z": env.contact_forces[robot_index, env.feet_indices, 2].cpu().tolist(),
                 }
+                logger.log_states(rec)
                 sf.write(json.dumps(rec) + "\n")
             elif i == stop_state_log:
                 sf.flush()
+                logger.plot_states(os.path.join(out_dir, "play_states.png"))
 
             if 0 < i < stop_rew_log:
                 if infos["episode"]:
                     num_episodes = int(torch.sum(env.reset_buf).item())
-                    if num_episodes > 0:          # Logger.log_rewards (logger.py:49-54): sums of value * num_episodes
-                        for key, value in infos["episode"].items():
-                            if "rew" in key:
-                                rew_sums[key] = rew_sums.get(key, 0.0) + float(value) * num_episodes
-                        num_episodes_total += num_episodes
+                    if num_episodes > 0:
+                        logger.log_rewards(infos["episode"], num_episodes)
             elif i == stop_rew_log:
                 dump_rewards()
     if total <= stop_rew_log:
         dump_rewards()
-    return dict(env=env, runner=ppo_runner, exported=exported, states=states_path, rewards=rewards_path)
+    if total <= stop_state_log:
+        logger.plot_states(os.path.join(out_dir, "play_states.png"))
+    return dict(env=env, runner=ppo_runner, exported=exported, states=states_path, rewards=rewards_path, logger=logger)
 
 
 if __name__ == "__main__":
