@@ -500,13 +500,15 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     KParams& P = s->hp;
     memset(&P, 0, sizeof P);
     P.N = c.num_envs; P.env_offset = c.env_offset; P.total_envs = c.total_envs; P.nd = nd;
-    {   // waves per block: the step kernel needs a SIMD per wave (512 registers/lane), so use the helper waves only
-        // while blocks x waves still fits the device's SIMDs in one round; GRX_WAVES_PER_BLOCK overrides (tests)
+    {   // waves per block: the step kernel needs a SIMD per wave (512 registers/lane).  Four waves per block while the
+        // blocks fit the device's SIMDs in at most TWO rounds (measured on MI355X, rough terrain: 16384 envs = 2 rounds of
+        // the four-wave layout 131 us, two-wave layout 152 us, one-wave layout 170 us; 20480 envs: 192 / 276 / 171 us),
+        // one wave per block beyond; the two-wave layout is never the fastest any more (kept: GRX_WAVES_PER_BLOCK, tests)
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device_id));
         const int simds = prop.multiProcessorCount * 4;
         const int nblocks = (c.num_envs + grx_envs_per_block() - 1) / grx_envs_per_block();
-        s->waves = nblocks * 4 <= simds ? 4 : (nblocks * 2 <= simds ? 2 : 1);
+        s->waves = nblocks * 4 <= 2 * simds ? 4 : 1;
         if (const char* w = getenv("GRX_WAVES_PER_BLOCK")) {
             const int v = atoi(w);
             if (v == 1 || v == 2 || v == 4) s->waves = v;
