@@ -1089,14 +1089,20 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             const S3 bI = {P.base_I[e], P.base_I[(size_t)N + e], P.base_I[2 * (size_t)N + e],
                            P.base_I[3 * (size_t)N + e], P.base_I[4 * (size_t)N + e], P.base_I[5 * (size_t)N + e]};
             if (wv == 1) {
-                if (P.add_noise && !noise_in) {   // wave 0 is still loading state: the noise blocks cost nothing here
-                    U4 nzb[NZB];
-                    noise_blocks(P, genv, step, side, nzb);
-                    uint32_t* z = s_nz + lane;
+                // the observation-noise Philox blocks are computed in the idle time after a sub-step's hand-over (this wave is on
+                // wave 0's path from the first sub-step on: before the loop they delayed it, measured)
+                const bool want_noise = P.add_noise && !noise_in;
+                const int noise_seq = P.decimation >= 2 ? P.decimation - 2 : 0;
+                self_loop<HF>(P, s_tab, GRX_HELPER_C, RB, s_footfr, self_carve(s_self), P.friction[e], L, lane, el, side,
+                              [&](const int seq) {
+                                  if (want_noise && seq == noise_seq) {
+                                      U4 nzb[NZB];
+                                      noise_blocks(P, genv, step, side, nzb);
+                                      uint32_t* z = s_nz + lane;
 #pragma unroll
-                    for (int b = 0; b < NZB; ++b) { z[(b * 4 + 0) * 64] = nzb[b].x; z[(b * 4 + 1) * 64] = nzb[b].y; z[(b * 4 + 2) * 64] = nzb[b].z; z[(b * 4 + 3) * 64] = nzb[b].w; }
-                }
-                self_loop(P, s_tab, GRX_HELPER_C, RB, s_footfr, self_carve(s_self), P.friction[e], L, lane, el, side);
+                                      for (int b = 0; b < NZB; ++b) { z[(b * 4 + 0) * 64] = nzb[b].x; z[(b * 4 + 1) * 64] = nzb[b].y; z[(b * 4 + 2) * 64] = nzb[b].z; z[(b * 4 + 3) * 64] = nzb[b].w; }
+                                  }
+                              });
             } else if (wv == 2) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {

@@ -55,7 +55,7 @@
 #define GRX_WAIT(f, want, slot) flag_wait(f, want)
 #endif
 
-enum { FL_STATE = 0, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_SELF = 9, FL_REW = 6, FL_BASEBIAS = 8, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_RR = 15, FL_COUNT = 16 };
+enum { FL_STATE = 0, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_BIAS2 = 7 /* bias forces of bodies 2..0 when wave 1 computes them (heightfield) */, FL_SELF = 9, FL_REW = 6, FL_BASEBIAS = 8, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_RR = 15, FL_COUNT = 16 };
 // Every record is laid out [quad][lane] in float4 units, so a lane moves it with ds_read_b128 / ds_write_b128: the
 // kernel runs at one instruction issue per ~5 cycles whatever the instruction, and the records are ~350 dwords per
 // lane and sub-step on wave 0 alone -- four dwords per LDS instruction instead of one is ~1.3k cycles per sub-step.
@@ -219,7 +219,8 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     // (wave 2 is done with all five long before this point: one wait, and the ten LDS reads go out together -- one exposed
     //  LDS latency instead of one per joint)
     V3 pa = v3(0.f, 0.f, 0.f), pl = v3(0.f, 0.f, 0.f);
-    GRX_WAIT(L.flag + FL_BIAS, seq * 8 + LEG, 0);
+    GRX_WAIT(L.flag + FL_BIAS, seq * 8 + (HF ? 2 : LEG), 0);
+    if (HF) GRX_WAIT(L.flag + FL_BIAS2, seq + 1, 0);   // bodies 2..0 come from wave 1 on a heightfield (see self_loop)
     float4 bq0[LEG], bq1[LEG];
 #pragma unroll
     for (int k = 0; k < LEG; ++k) { const float4* b_ = L.pb + (k * PB4) * 64 + lane; bq0[k] = b_[0 * 64]; bq1[k] = b_[1 * 64]; }
@@ -340,8 +341,13 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 // ---------------------------------------------------------------------------------------------------------------
 // wave 1: self-collision (grx_self.h) -- leg against leg (the partner lane is one DPP step away), thigh against base-lump
 // shapes -- on the chain frames wave 2 publishes right after its walk
-GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, const float4* footfr, const SelfBuf& SB, float mu_self, const PipeLds& L,
-                       int lane, int el, int side) {
+// On a HEIGHTFIELD the foot wave (wave 2) is the late one (gathers, terrain normals), so this wave -- otherwise idle until
+// wave 2's frames arrive -- walks the chain itself (same arithmetic, same frames) and takes over the bias forces of the
+// bodies wave 0 reaches last: thigh, hip yaw, hip roll.
+// `idle(seq)` runs after the hand-over of every sub-step, in the ~2 k cycles this wave then waits for wave 0's next state.
+template <bool HF, class Idle>
+GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, const float4* footfr, const SelfBuf& SB, float mu_self,
+                       const PipeLds& L, int lane, int el, int side, Idle idle) {
     GRX_HELPER_PROF_BEGIN;
     SelfNear sn; sn.m = 0;   // self-collision broad phase of this policy step
 #ifdef GRX_PROFILE_SECTIONS
@@ -349,6 +355,9 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
 #else
     long long* sacc = nullptr;
 #endif
+    float lim_lo[3], lim_hi[3], lim_k[3], lim_c[3];   // joint-limit constants of joints 0..2 (HF)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lim_lo[k] = C.body[k].qlo; lim_hi[k] = C.body[k].qhi; lim_k[k] = C.body[k].Klim; lim_c[k] = C.body[k].Clim; }
     for (int seq = 0; seq < P.decimation; ++seq) {
         GRX_HELPER_PROF_IDLE0;
         flag_wait(L.flag + FL_STATE, seq + 1);
@@ -356,12 +365,42 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
         const float* b = L.base + el;
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
         const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
-        flag_wait(L.flag + FL_FRAMES, seq + 1);
         ChainKin KS[3];
+        if (HF) {
+            float qs_q[LEG], qs_qd[LEG];
+            {
+                const float4 q0_ = L.q[lane], q1_ = L.q[64 + lane], q2_ = L.q[128 + lane];
+                qs_q[0] = q0_.x; qs_q[1] = q0_.y; qs_q[2] = q0_.z; qs_q[3] = q0_.w; qs_q[4] = q1_.x;
+                qs_qd[0] = q1_.y; qs_qd[1] = q1_.z; qs_qd[2] = q1_.w; qs_qd[3] = q2_.x; qs_qd[4] = q2_.y;
+            }
+            ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
+            ChainKin KK[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const RareFrame f = rare_load_frame(i < 2 ? RB.fchain + i * RC_FR4 * 64 + lane : footfr + lane, 64);
-            KS[i].R = f.R; KS[i].rho = f.rho; KS[i].w = f.w; KS[i].v = f.v;
+            for (int k = 0; k < LEG; ++k) {
+                chain_step(C, k, qs_q[k], qs_qd[k], K);
+                if (k < 3) KK[k] = K;
+                if (k >= 2) KS[k - 2] = K;
+            }
+#pragma unroll
+            for (int k = 2; k >= 0; --k) {   // the hand-over wave 2 makes for the other bodies (chain_contact_loop: bias_out)
+                const V3 kap = KK[k].rho + rot(KK[k].R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+                const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
+                V3 pa, pl;
+                rigid_bias(KK[k].R, kap, C.body[k].mass, Ic, KK[k].w, KK[k].v, pa, pl);
+                const float viol = qs_q[k] < lim_lo[k] ? lim_lo[k] - qs_q[k] : (qs_q[k] > lim_hi[k] ? lim_hi[k] - qs_q[k] : 0.f);
+                const float tlim = lim_k[k] * viol - (viol != 0.f ? lim_c[k] * qs_qd[k] : 0.f);
+                float4* o = L.pb + (k * PB4) * 64 + lane;
+                o[0 * 64] = f4(pa.x, pa.y, pa.z, pl.x);
+                o[1 * 64] = f4(pl.y, pl.z, tlim, 0.f);
+            }
+            flag_set(L.flag + FL_BIAS2, seq + 1, lane);
+        } else {
+            flag_wait(L.flag + FL_FRAMES, seq + 1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const RareFrame f = rare_load_frame(i < 2 ? RB.fchain + i * RC_FR4 * 64 + lane : footfr + lane, 64);
+                KS[i].R = f.R; KS[i].rho = f.rho; KS[i].w = f.w; KS[i].v = f.v;
+            }
         }
         if (seq == 0) sn = self_broad_phase(P, C, side, R0, KS);
         SelfOut sc;
@@ -377,6 +416,7 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
         o[7 * 64] = f4(sc.fbase[1].y, sc.fbase[1].z, 0.f, 0.f);
         flag_set(L.flag + FL_SELF, seq + 1, lane);
         GRX_EV(13);
+        idle(seq);
     }
     GRX_HELPER_PROF_END(1);
 #ifdef GRX_PROFILE_SECTIONS
@@ -441,7 +481,8 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
         // (foot contacts between the bias forces of shank and thigh, so that the foot wrench is out early: tried, +1.2 us on
         //  rough terrain -- wave 0 then waits for the last bias forces instead)
         bias_out(4); GRX_EV(9);
-        bias_out(3); bias_out(2); bias_out(1); bias_out(0);
+        bias_out(3);
+        if (!HF) { bias_out(2); bias_out(1); bias_out(0); }   // heightfield: wave 1 computes those (self_loop)
         GRX_EV(10);
         float4* c_ = L.wc + lane;
         V3 fa, fl;
