@@ -160,8 +160,8 @@ def main():
     for _ in range(args.warmup):
         counter += 1
         sim.step(pool[counter % 16], delay, counter)
-    # HIP-event window: every 8th launch (an event pair costs the stream ~7 us); every 2nd when only a few steps are timed
-    sim.kernel_time_ms(enable=int(os.environ.get("GRX_BENCH_EVENT_STRIDE", "8" if args.steps >= 400 else "2")))
+    # HIP-event window: every 8th launch (an event pair costs the stream ~7 us: a denser window would show up in `value`)
+    sim.kernel_time_ms(enable=int(os.environ.get("GRX_BENCH_EVENT_STRIDE", "8")))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
