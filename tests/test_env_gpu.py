@@ -76,3 +76,28 @@ def test_steps_recorded_into_a_hip_graph_neither_pace_nor_hang():
     for name in ("DOF_POS", "ROOT_STATES", "OBS", "REW", "EPISODE_LENGTH"):
         assert torch.equal(hip.tensor(name), ref.tensor(name)), name
     hip.step(act, 0.0, 2 + n); hip.wait_idle()            # eager steps after a replay still pace and complete
+
+
+def test_bench_line_has_the_contract_fields():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command): one JSON line with BASELINE.json's metric, the
+    roofline object (HBM fraction + the VALU issue fraction that actually bounds the kernel) and the cpu_baseline object."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-steps", "3"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["metric"] == "env-steps/sec GR1T1 rough-terrain @4096 envs" and j["unit"] == "env-steps/s" and j["n_gpus"] == 1
+    assert j["steps"] == 20 and j["warmup"] == 5 and j["higher_is_better"] and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"] and j["config"]["finite_outputs"]
+    assert abs(j["value"] - 4096 * 20 / (j["ms_per_step"] * 20e-3)) < 1e-3 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["kernel_ms"] > 0 and r["launches_timed"] >= 2 and abs(r["achieved"] - 2476.0 * 4096 / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["valu_issue_frac"] is None or 0.01 < r["valu_issue_frac"] < 1.0
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and c["cpu_model"] and "note" in c
+    assert c["reference_stage"] is None or c["reference_stage"]["value"] > 0
+    assert j["value"] > 20e6      # an MI355X does not fall below this even inside a 20-step window
