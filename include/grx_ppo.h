@@ -55,6 +55,21 @@ int grx_ppo_store_transition(int N, int num_obs, int num_pri, int num_actions,
                              float* st_logp, float* st_rewards, unsigned char* st_dones,
                              float* cur_rew, float* cur_len, float* done_rew, float* done_len, void* stream);
 
+/* One layer of an MLP at inference: Y [M][N] = act(X [M][K] . W^T + bias), W [N][K] row-major as torch.nn.Linear.weight,
+ * bias [N] or NULL, act = ELU(alpha 1) when `elu` != 0 -- the rollout's policy / value forward (rsl_rl modules/mlp.py:7-42,
+ * actor_critic_mlp.py act() / evaluate()) as one launch per layer: f32-input MFMA (v_mfma_f32_32x32x2_f32, exact f32:
+ * every output is a k-ordered fmaf chain), bias and activation in the epilogue.  Any M, K, N >= 1; layers narrower than 32
+ * outputs (action means, value) take a lane-per-row path.  Contiguous row-major fp32 everywhere.  Returns 0, negative for
+ * invalid arguments / a failed launch. */
+int grx_mlp_layer(int M, int K, int N, const float* X, const float* W, const float* bias, float* Y, int elu, void* stream);
+
+/* The actor's output layer fused with the rollout's sampling and log-probability (actor_critic_mlp.py act() /
+ * get_actions_log_prob() -> torch.distributions.Normal): mu = X . W^T + bias, actions = mu + std * eps,
+ * logp = sum_k -(a - mu)^2 / (2 std^2) - log(std) - log(sqrt(2 pi)); sigma = std broadcast to (M, A).
+ * X [M][K], W [A][K], std [A], eps [M][A] standard-normal draws supplied by the caller.  1 <= A <= 32. */
+int grx_mlp_policy_head(int M, int K, int A, const float* X, const float* W, const float* bias, const float* std,
+                        const float* eps, float* actions, float* logp, float* mu, float* sigma, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -378,3 +378,63 @@ def test_fused_loss_propagates_nan_like_torch():
     a.update()
     after = list(a.actor_critic.parameters())
     assert all(torch.isfinite(p).all() for p in after)
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 39, 512), (4096, 168, 512), (4096, 512, 256), (4096, 256, 128), (4100, 130, 96), (70, 33, 64),
+                                   (4096, 128, 10), (513, 128, 1)])
+def test_mlp_layer_kernel_matches_torch(M, K, N):
+    """grx_mlp_layer (f32-input MFMA, bias + ELU epilogue; narrow output layers on a masked tile) against torch, asymmetric operands,
+    ragged M / K / N."""
+    from wiki_grx_gym_amd.rl.fused_loss import load_ppo_library, _layer
+    lib = load_ppo_library()
+    g = torch.Generator(device="cuda:0").manual_seed(M + K + N)
+    x = torch.randn(M, K, device="cuda:0", generator=g)
+    w = torch.randn(N, K, device="cuda:0", generator=g) / K ** 0.5
+    w[:, 0] += torch.arange(N, device="cuda:0") * 0.01          # (row / column swaps must not cancel)
+    b = torch.randn(N, device="cuda:0", generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+    for elu in (True, False):
+        y = _layer(lib, x, w, b, elu, st)
+        ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        ref = torch.nn.functional.elu(ref) if elu else ref
+        assert (y.double() - ref).abs().max() < 2e-5 * (1 + ref.abs().max())
+    y0 = _layer(lib, x, w, None, False, st)
+    assert (y0.double() - x.double() @ w.double().t()).abs().max() < 2e-5 * (1 + ref.abs().max())
+
+
+def test_fused_policy_step_matches_the_torch_distribution_path():
+    """The rollout's policy step through libgrx_ppo.so (hidden layers on the matrix cores, output layer + sample + log-prob in
+    one kernel; critic likewise) against rsl_rl's spelling: Normal(mu, std), a = mu + std * eps, log_prob summed over actions."""
+    from wiki_grx_gym_amd.rl.fused_loss import mlp_can_fuse, mlp_forward, policy_act
+    torch.manual_seed(3)
+    ac = ActorCriticMLP(39, 168, 10, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], activation="elu",
+                        init_noise_std=0.2).to("cuda:0")
+    with torch.no_grad():
+        ac.std.mul_(torch.linspace(0.5, 1.5, 10, device="cuda:0"))
+    obs, pri = torch.randn(4096, 39, device="cuda:0"), torch.randn(4096, 168, device="cuda:0")
+    eps = torch.randn(4096, 10, device="cuda:0")
+    assert mlp_can_fuse(ac.actor, obs) and mlp_can_fuse(ac.critic, pri)
+    with torch.no_grad():
+        actions, logp, mu, sigma = policy_act(ac.actor, ac.std.detach(), obs, eps)
+        value = mlp_forward(ac.critic, pri)
+        ac.update_distribution(obs)
+        a_ref = ac.action_mean + ac.action_std * eps
+        assert (mu - ac.action_mean).abs().max() < 1e-5 and torch.equal(sigma, ac.action_std)
+        assert (actions - a_ref).abs().max() < 1e-5
+        assert (logp - ac.get_actions_log_prob(actions)).abs().max() < 1e-4
+        assert (value - ac.evaluate(pri)).abs().max() < 1e-5
+    # ... and PPO.act() uses it inside its captured graphs: same transition tensors as the eager distribution path up to rounding
+    alg = _toy_alg()
+    assert alg._use_act_graph
+    o, p = torch.randn(256, 39, device="cuda:0"), torch.randn(256, 168, device="cuda:0")
+    with torch.inference_mode():
+        torch.manual_seed(11); alg.act(o, p); alg._join_critic()
+        t = alg.transition
+        assert alg._act_fused
+        got = [x.clone() for x in (t.actions, t.values, t.actions_log_prob, t.action_mean, t.action_sigma)]
+        torch.manual_seed(11); alg.act(o, p); alg._join_critic()      # replay: fresh noise, same means
+        assert torch.equal(t.action_mean, got[3]) and not torch.equal(t.actions, got[0])
+        ac2 = alg.actor_critic
+        ac2.update_distribution(o)
+        assert (got[3] - ac2.action_mean).abs().max() < 1e-5 and (got[1].reshape(-1) - ac2.evaluate(p).reshape(-1)).abs().max() < 1e-5
+        assert (got[2].reshape(-1) - ac2.get_actions_log_prob(got[0])).abs().max() < 1e-4

@@ -3,6 +3,7 @@
 // the gradients are those torch.autograd produces for that expression (torch.max splits ties half / half,
 // clamp passes the gradient on the closed interval).
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include "../../include/grx_ppo.h"
 
 namespace {
@@ -164,7 +165,152 @@ __global__ __launch_bounds__(256) void colsum_final(int cols, int nslab, const f
     for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
     if (lane == 0) out[col] = t;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One layer of the policy / value MLP for the ROLLOUT (inference): Y = act(X W^T + b), fp32 in, fp32 accumulate on the
+// matrix cores (v_mfma_f32_32x32x2_f32: exact f32, a k-ordered fmaf chain per output).  rsl_rl's MLP is
+// Linear -> ELU -> ... -> Linear (mlp.py:7-42); a rollout step runs two of them at batch = num_envs, which through
+// torch is 8 library GEMMs + 6 ELU kernels + glue (~150 us beside a 67 us env step).  Here a layer is one launch:
+// 64 x 64 output tile per 256-thread block (four waves, a 32 x 32 MFMA tile each), K in chunks of 32 through LDS with the
+// next chunk's global loads in flight during the current chunk's 16 MFMAs, bias + ELU in the epilogue.
+// Operand maps (cdna_hip_programming.md): A: lane l holds A[i = l & 31][k = l >> 5]; B: B[k = l >> 5][j = l & 31];
+// D: col = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int ML_BM = 64, ML_BN = 64, ML_KC = 64, ML_LD = 65;   // LDS tiles are [k][row], row stride 65 (transposed stores without bank conflicts)
+
+__device__ inline float elu1(float x) { return x > 0.f ? x : expm1f(x); }   // torch.nn.ELU(alpha = 1)
+
+// 64 rows x 64 k of a row-major matrix -> registers (4 x float4 per thread: thread t, pass p -> row 16 p + t / 16, k 4 (t % 16)),
+// zero beyond the matrix; VEC: rows are 16-byte aligned (ld % 4 == 0)
+template <bool VEC>
+__device__ inline void ml_fetch(const float* __restrict__ G, int rows, int ld, int r0, int k0, int tid, float4 v[4]) {
+    const int kq = k0 + 4 * (tid & 15);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + 16 * p + (tid >> 4);
+        const float* g = G + (size_t)min(r, rows - 1) * ld + kq;
+        float4 x = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            if (VEC) { if (kq < ld) x = *reinterpret_cast<const float4*>(g); }   // (ld % 4 == 0: a quad is inside or outside as a whole)
+            else { if (kq < ld) x.x = g[0]; if (kq + 1 < ld) x.y = g[1]; if (kq + 2 < ld) x.z = g[2]; if (kq + 3 < ld) x.w = g[3]; }
+        }
+        v[p] = x;
+    }
+}
+__device__ inline void ml_stash(float* __restrict__ S, int tid, const float4 v[4]) {
+    const int kq = 4 * (tid & 15);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float* s = S + kq * ML_LD + 16 * p + (tid >> 4);
+        s[0] = v[p].x; s[ML_LD] = v[p].y; s[2 * ML_LD] = v[p].z; s[3 * ML_LD] = v[p].w;
+    }
+}
+
+// HEAD: the actor's output layer (N = number of actions <= 32) with the rollout's sampling and log-probability in the epilogue
+// (actor_critic_mlp.py act() / get_actions_log_prob(), torch.distributions.Normal): mu = X W^T + b; a = mu + std * eps;
+// logp = sum_k -(a - mu)^2 / (2 std^2) - log std - log sqrt(2 pi) -- a row's actions sit in the 32 lanes of a half wave.
+struct HeadOut { const float* stdp; const float* eps; float* actions; float* logp; float* mu; float* sigma; };
+template <bool ELU, bool VEC, bool HEAD = false>
+__global__ __launch_bounds__(256) void mlp_layer_kernel(int M, int K, int N, const float* __restrict__ X, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ Y, HeadOut ho = HeadOut()) {
+    __shared__ float Xs[2][ML_KC * ML_LD], Ws[2][ML_KC * ML_LD];   // double-buffered: chunk c + 1 lands while chunk c multiplies
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wy = wv >> 1, wx = wv & 1;
+    const int m0 = blockIdx.x * ML_BM, n0 = blockIdx.y * ML_BN;
+    float4 xr[4], wr[4];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    ml_fetch<VEC>(X, M, K, m0, 0, tid, xr);
+    ml_fetch<VEC>(W, N, K, n0, 0, tid, wr);
+    ml_stash(Xs[0], tid, xr); ml_stash(Ws[0], tid, wr);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += ML_KC, buf ^= 1) {
+        const bool more = k0 + ML_KC < K;
+        if (more) { ml_fetch<VEC>(X, M, K, m0, k0 + ML_KC, tid, xr); ml_fetch<VEC>(W, N, K, n0, k0 + ML_KC, tid, wr); }   // in flight during the MFMAs
+        const float* xa = Xs[buf] + (lane >> 5) * ML_LD + 32 * wy + (lane & 31);
+        const float* wb = Ws[buf] + (lane >> 5) * ML_LD + 32 * wx + (lane & 31);
+        const int nk = min(ML_KC, K - k0);
+        if (nk == ML_KC) {
+            // operands of the whole chunk into registers first: 64 LDS reads in flight, then 32 MFMAs back to back (read ->
+            // wait -> MFMA one by one, as the compiler orders the naive loop, exposes the LDS latency 32 times per chunk)
+            float av[ML_KC / 2], bv[ML_KC / 2];
+#pragma unroll
+            for (int kk = 0; kk < ML_KC / 2; ++kk) { av[kk] = xa[2 * kk * ML_LD]; bv[kk] = wb[2 * kk * ML_LD]; }
+#pragma unroll
+            for (int kk = 0; kk < ML_KC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+        } else {
+            for (int kk = 0; kk < (nk + 1) / 2; ++kk)   // (the tile is zero beyond K)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[2 * kk * ML_LD], wb[2 * kk * ML_LD], acc, 0, 0, 0);
+        }
+        if (more) { ml_stash(Xs[buf ^ 1], tid, xr); ml_stash(Ws[buf ^ 1], tid, wr); }
+        __syncthreads();
+    }
+    const int col = n0 + 32 * wx + (lane & 31);
+    if (HEAD) {
+        if (wx != 0) return;   // (N <= 32: the second column half of the tile is empty)
+        const bool live = col < N;
+        const float b = (live && bias) ? bias[col] : 0.f;
+        const float sd = live ? ho.stdp[col] : 1.f;
+        const float lsd = logf(sd), inv2 = 1.0f / (2.0f * sd * sd);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 32 * wy + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const bool ok = live && row < M;
+            const float m = acc[r] + b;
+            float term = 0.f;
+            if (ok) {
+                const size_t o = (size_t)row * N + col;
+                const float a = m + sd * ho.eps[o];
+                const float d = a - m;
+                term = -(d * d) * inv2 - lsd - 0.9189385332046727f;
+                ho.actions[o] = a; ho.mu[o] = m; ho.sigma[o] = sd;
+            }
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) term += __shfl_xor(term, off);   // over the 32 lanes (columns) of this row
+            if ((lane & 31) == 0 && row < M) ho.logp[row] = term;
+        }
+        return;
+    }
+    if (col < N) {
+        const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 32 * wy + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < M) { const float y = acc[r] + b; Y[(size_t)row * N + col] = ELU ? elu1(y) : y; }
+        }
+    }
+}
+
 }  // namespace
+
+
+extern "C" int grx_mlp_policy_head(int M, int K, int A, const float* X, const float* W, const float* bias, const float* std,
+                                   const float* eps, float* actions, float* logp, float* mu, float* sigma, void* stream) {
+    if (M < 1 || K < 1 || A < 1 || A > 32 || !X || !W || !std || !eps || !actions || !logp || !mu || !sigma) return -1;
+    const HeadOut ho = {std, eps, actions, logp, mu, sigma};
+    const bool vec = K % 4 == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)W % 16 == 0);
+    const dim3 grid((M + ML_BM - 1) / ML_BM, 1);
+    if (vec) hipLaunchKernelGGL((mlp_layer_kernel<false, true, true>), grid, dim3(256), 0, (hipStream_t)stream, M, K, A, X, W, bias, (float*)nullptr, ho);
+    else hipLaunchKernelGGL((mlp_layer_kernel<false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, M, K, A, X, W, bias, (float*)nullptr, ho);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int grx_mlp_layer(int M, int K, int N, const float* X, const float* W, const float* bias, float* Y, int elu, void* stream) {
+    if (M < 1 || K < 1 || N < 1 || !X || !W || !Y) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = K % 4 == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)W % 16 == 0);
+#define GRX_ML_LAUNCH(KERNEL, GRID, BLOCK)                                                                              \
+    do {                                                                                                                \
+        if (elu) { if (vec) hipLaunchKernelGGL((KERNEL<true, true>), GRID, BLOCK, 0, st, M, K, N, X, W, bias, Y, HeadOut());       \
+                   else hipLaunchKernelGGL((KERNEL<true, false>), GRID, BLOCK, 0, st, M, K, N, X, W, bias, Y, HeadOut()); }        \
+        else { if (vec) hipLaunchKernelGGL((KERNEL<false, true>), GRID, BLOCK, 0, st, M, K, N, X, W, bias, Y, HeadOut());          \
+               else hipLaunchKernelGGL((KERNEL<false, false>), GRID, BLOCK, 0, st, M, K, N, X, W, bias, Y, HeadOut()); }           \
+    } while (0)
+    GRX_ML_LAUNCH(mlp_layer_kernel, dim3((M + ML_BM - 1) / ML_BM, (N + ML_BN - 1) / ML_BN), dim3(256));
+#undef GRX_ML_LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 extern "C" int grx_ppo_colsum_partials_size(int rows, int cols) { return (rows < 1 || cols < 1) ? 0 : ((rows + CS_ROWS - 1) / CS_ROWS) * cols; }
 

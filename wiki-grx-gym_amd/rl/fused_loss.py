@@ -33,6 +33,10 @@ def load_ppo_library():
         lib.grx_ppo_colsum_partials_size.argtypes = [C.c_int, C.c_int]
         lib.grx_ppo_store_transition.restype = C.c_int
         lib.grx_ppo_store_transition.argtypes = [C.c_int] * 4 + [fp] * 10 + [C.c_float] + [fp] * 13 + [C.c_void_p]
+        lib.grx_mlp_layer.restype = C.c_int
+        lib.grx_mlp_layer.argtypes = [C.c_int] * 3 + [fp] * 4 + [C.c_int, C.c_void_p]
+        lib.grx_mlp_policy_head.restype = C.c_int
+        lib.grx_mlp_policy_head.argtypes = [C.c_int] * 3 + [fp] * 9 + [C.c_void_p]
         _LIB = lib
     return _LIB
 
@@ -117,3 +121,64 @@ def store_transition(storage, step, obs, pri, actions, mu, sigma, values, logp, 
             ptr(lg[0]), ptr(lg[1]), ptr(lg[2]), ptr(lg[3]), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"grx_ppo_store_transition failed ({rc})")
+
+
+def _linears_of(mlp):
+    """(weight, bias) of every nn.Linear of an rl.modules.MLP if it is Linear -> ELU(1) -> ... -> Linear, else None."""
+    mods = list(mlp.model)
+    lin = []
+    for i, m in enumerate(mods):
+        if i % 2 == 0:
+            if not isinstance(m, torch.nn.Linear):
+                return None
+            lin.append((m.weight, m.bias))
+        elif not (isinstance(m, torch.nn.ELU) and m.alpha == 1.0):
+            return None
+    return lin if len(mods) % 2 == 1 else None
+
+
+def mlp_can_fuse(mlp, x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and _linears_of(mlp) is not None
+
+
+def _layer(lib, x, w, b, elu, stream):
+    y = torch.empty(x.shape[0], w.shape[0], device=x.device, dtype=torch.float32)
+    rc = lib.grx_mlp_layer(x.shape[0], x.shape[1], w.shape[0], x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
+                           y.data_ptr(), int(elu), stream)
+    if rc:
+        raise RuntimeError(f"grx_mlp_layer failed ({rc})")
+    return y
+
+
+def mlp_forward(mlp, x):
+    """Inference forward of an rl.modules.MLP through libgrx_ppo.so: one MFMA launch per layer (bias + ELU in the epilogue)."""
+    lib = load_ppo_library()
+    lin = _linears_of(mlp)
+    x = _f32c(x)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    with torch.cuda.device(x.device):
+        for i, (w, b) in enumerate(lin):
+            x = _layer(lib, x, w, b, i + 1 < len(lin), stream)
+    return x
+
+
+def policy_act(mlp, std, x, eps):
+    """actor forward + sample + log-prob: (actions, logp [M], mu, sigma) -- the hidden layers as in mlp_forward, the output
+    layer fused with `mu + std * eps` and Normal.log_prob summed over the actions."""
+    lib = load_ppo_library()
+    lin = _linears_of(mlp)
+    x = _f32c(x)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    with torch.cuda.device(x.device):
+        for w, b in lin[:-1]:
+            x = _layer(lib, x, w, b, True, stream)
+        w, b = lin[-1]
+        M, A = x.shape[0], w.shape[0]
+        actions, mu, sigma = (torch.empty(M, A, device=x.device, dtype=torch.float32) for _ in range(3))
+        logp = torch.empty(M, device=x.device, dtype=torch.float32)
+        rc = lib.grx_mlp_policy_head(M, x.shape[1], A, x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                     _f32c(std).data_ptr(), _f32c(eps).data_ptr(), actions.data_ptr(), logp.data_ptr(),
+                                     mu.data_ptr(), sigma.data_ptr(), stream)
+        if rc:
+            raise RuntimeError(f"grx_mlp_policy_head failed ({rc})")
+    return actions, logp, mu, sigma

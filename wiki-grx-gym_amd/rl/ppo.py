@@ -11,7 +11,7 @@ import os
 
 import torch
 import torch.distributed as dist
-from .fused_loss import fused_ppo_loss
+from .fused_loss import fused_ppo_loss, mlp_can_fuse, mlp_forward, policy_act
 import torch.nn as nn
 import torch.optim as optim
 
@@ -145,12 +145,25 @@ class PPO:
             with torch.inference_mode(False), torch.no_grad():
                 self._act_in = (torch.zeros_like(actor_observations), torch.zeros_like(critic_observations))
 
+                # GRX_PPO_FUSED_MLP (default on): the two MLP forwards through libgrx_ppo.so -- one MFMA launch per layer with
+                # bias + ELU in the epilogue, the actor's output layer fused with the sampling and the log-probability
+                # (rl/fused_loss.py: mlp_forward / policy_act) -- instead of 8 library GEMMs, 6 ELU kernels and ~20 small
+                # distribution kernels per rollout step
+                fuse = (os.environ.get("GRX_PPO_FUSED_MLP", "1") != "0" and mlp_can_fuse(ac.actor, self._act_in[0])
+                        and mlp_can_fuse(ac.critic, self._act_in[1]) and ac.num_actor_output <= 32)
+                self._act_fused = fuse
+
                 def actor_part():
+                    if fuse:
+                        eps = torch.randn(self._act_in[0].shape[0], ac.num_actor_output, device=self.device)
+                        return policy_act(ac.actor, ac.std.detach(), self._act_in[0], eps)
                     ac.update_distribution(self._act_in[0])   # Normal.sample() checks std >= 0 on the host: not capturable
                     actions = (ac.action_mean + ac.action_std * torch.randn_like(ac.action_mean)).detach()
                     return actions, ac.get_actions_log_prob(actions).detach(), ac.action_mean.detach(), ac.action_std.detach()
 
                 def critic_part():
+                    if fuse:
+                        return mlp_forward(ac.critic, self._act_in[1])
                     return ac.evaluate(self._act_in[1]).detach()
                 side = torch.cuda.Stream(device=self.device)
                 self._act_side = torch.cuda.Stream(device=self.device)
