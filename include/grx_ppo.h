@@ -61,6 +61,12 @@ int grx_ppo_store_transition(int N, int num_obs, int num_pri, int num_actions,
  * every output is a k-ordered fmaf chain), bias and activation in the epilogue.  Any M, K, N >= 1; layers narrower than 32
  * outputs (action means, value) take a lane-per-row path.  Contiguous row-major fp32 everywhere.  Returns 0, negative for
  * invalid arguments / a failed launch. */
+/* The minibatch of one PPO step in one launch: dst[t][r][:] = src[t][idx[r]][:] for t < n_tensors (<= GRX_PPO_GATHER_MAX), r < mb;
+ * src[t] row-major fp32 with widths[t] columns, idx int64 on the device (RolloutStorage.mini_batch_generator's permutation
+ * slice, rollout_storage.py:82-112).  src / dst / widths are HOST arrays of device pointers / ints. */
+#define GRX_PPO_GATHER_MAX 12
+int grx_ppo_gather_rows(int n_tensors, const float* const* src, float* const* dst, const int* widths, const long long* idx, int mb, void* stream);
+
 int grx_mlp_layer(int M, int K, int N, const float* X, const float* W, const float* bias, float* Y, int elu, void* stream);
 
 /* The actor's output layer fused with the rollout's sampling and log-probability (actor_critic_mlp.py act() /

@@ -285,6 +285,38 @@ __global__ __launch_bounds__(256) void mlp_layer_kernel(int M, int K, int N, con
 }  // namespace
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The minibatch of one PPO step, gathered in ONE launch: rows idx[0..mb) of up to GRX_PPO_GATHER_MAX row-major fp32 tensors
+// (observations, privileged observations, actions, values, advantages, returns, log-probs, mu, sigma: rollout_storage.py:82-112)
+// into their static minibatch buffers -- nine index_select launches otherwise, 200 times per update.
+namespace {
+struct GatherArgs { const float* src[GRX_PPO_GATHER_MAX]; float* dst[GRX_PPO_GATHER_MAX]; int width[GRX_PPO_GATHER_MAX]; };
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a, const long long* __restrict__ idx, int mb) {
+    const int t = blockIdx.y, w = a.width[t];
+    const long long n = (long long)mb * w;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int row = (int)(e / w), col = (int)(e - (long long)row * w);
+        a.dst[t][e] = a.src[t][idx[row] * w + col];
+    }
+}
+}  // namespace
+
+extern "C" int grx_ppo_gather_rows(int n_tensors, const float* const* src, float* const* dst, const int* widths, const long long* idx, int mb, void* stream) {
+    if (n_tensors < 1 || n_tensors > GRX_PPO_GATHER_MAX || mb < 1 || !src || !dst || !widths || !idx) return -1;
+    GatherArgs a;
+    int wmax = 1;
+    for (int t = 0; t < GRX_PPO_GATHER_MAX; ++t) {
+        const int u = t < n_tensors ? t : 0;
+        if (!src[u] || !dst[u] || widths[u] < 1) return -1;
+        a.src[t] = src[u]; a.dst[t] = dst[u]; a.width[t] = widths[u];
+        if (widths[u] > wmax) wmax = widths[u];
+    }
+    const long long nmax = (long long)mb * wmax;
+    const int bx = (int)((nmax + 255) / 256 < 1024 ? (nmax + 255) / 256 : 1024);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(bx, n_tensors), dim3(256), 0, (hipStream_t)stream, a, idx, mb);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int grx_mlp_policy_head(int M, int K, int A, const float* X, const float* W, const float* bias, const float* std,
                                    const float* eps, float* actions, float* logp, float* mu, float* sigma, void* stream) {
     if (M < 1 || K < 1 || A < 1 || A > 32 || !X || !W || !std || !eps || !actions || !logp || !mu || !sigma) return -1;

@@ -33,6 +33,8 @@ def load_ppo_library():
         lib.grx_ppo_colsum_partials_size.argtypes = [C.c_int, C.c_int]
         lib.grx_ppo_store_transition.restype = C.c_int
         lib.grx_ppo_store_transition.argtypes = [C.c_int] * 4 + [fp] * 10 + [C.c_float] + [fp] * 13 + [C.c_void_p]
+        lib.grx_ppo_gather_rows.restype = C.c_int
+        lib.grx_ppo_gather_rows.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), fp, C.c_int, C.c_void_p]
         lib.grx_mlp_layer.restype = C.c_int
         lib.grx_mlp_layer.argtypes = [C.c_int] * 3 + [fp] * 4 + [C.c_int, C.c_void_p]
         lib.grx_mlp_policy_head.restype = C.c_int
@@ -182,3 +184,27 @@ def policy_act(mlp, std, x, eps):
         if rc:
             raise RuntimeError(f"grx_mlp_policy_head failed ({rc})")
     return actions, logp, mu, sigma
+
+
+class RowGather:
+    """dst[t] = src[t][idx] for a fixed set of (src, dst) pairs in one launch (grx_ppo_gather_rows): the pointer tables are
+    built once, a call passes the index slice."""
+
+    def __init__(self, srcs, dsts):
+        self.lib = load_ppo_library()
+        n = len(srcs)
+        assert n == len(dsts) and all(s.dtype == torch.float32 and s.is_contiguous() and d.is_contiguous() and d.dtype == torch.float32
+                                      and s.shape[1:] == d.shape[1:] for s, d in zip(srcs, dsts))
+        self.n, self.mb, self.device = n, dsts[0].shape[0], srcs[0].device
+        self.src = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+        self.dst = (C.c_void_p * n)(*[d.data_ptr() for d in dsts])
+        self.w = (C.c_int * n)(*[int(s[0].numel()) for s in srcs])
+        self.keep = (srcs, dsts)
+
+    def __call__(self, idx):
+        assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == self.mb
+        with torch.cuda.device(self.device):
+            rc = self.lib.grx_ppo_gather_rows(self.n, self.src, self.dst, self.w, idx.data_ptr(), self.mb,
+                                              torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            raise RuntimeError(f"grx_ppo_gather_rows failed ({rc})")

@@ -579,11 +579,21 @@ class PPO:
         indices = torch.randperm(self.num_mini_batches * mb, requires_grad=False, device=self.device)   # RS:63-112: one permutation, reused
         self._sums.zero_()
         multi = _collective_path()
+        gather = None
+        if self._fused_store:   # (libgrx_ppo.so is in use)
+            key = tuple(s.data_ptr() for s in srcs) + tuple(b.data_ptr() for b in self._static)
+            if getattr(self, "_gather_key", None) != key:
+                from .fused_loss import RowGather
+                self._gather, self._gather_key = RowGather(srcs, self._static), key
+            gather = self._gather
         for _ in range(self.num_learning_epochs):
             for i in range(self.num_mini_batches):
                 idx = indices[i * mb:(i + 1) * mb]
-                for buf, src in zip(self._static, srcs):
-                    torch.index_select(src, 0, idx, out=buf)
+                if gather is not None:
+                    gather(idx)   # the nine minibatch tensors in one launch
+                else:
+                    for buf, src in zip(self._static, srcs):
+                        torch.index_select(src, 0, idx, out=buf)
                 self._graph.replay()
                 if multi:
                     dist.all_reduce(self._bucket)
