@@ -36,6 +36,11 @@ int grx_ppo_loss(int batch, int num_actions, const float* mu, const float* std, 
 int grx_ppo_colsum_partials_size(int rows, int cols);
 int grx_ppo_colsum(int rows, int cols, const float* x, float* out, float* partials, void* stream);
 
+/* Backward of a hidden layer's ELU(alpha 1) fused with that layer's bias gradient: dz [rows][cols] = dy * (y > 0 ? 1 : y + 1)
+ * from the layer's OUTPUT y (torch's elu_backward on the result), out [cols] = column sums of dz (as grx_ppo_colsum:
+ * deterministic, same slab order).  `partials`: grx_ppo_colsum_partials_size(rows, cols) floats. */
+int grx_ppo_elu_backward_colsum(int rows, int cols, const float* dy, const float* y, float* dz, float* out, float* partials, void* stream);
+
 /* One rollout step's bookkeeping in ONE launch (rsl_rl: PPO.process_env_step ppo.py:184-197 + RolloutStorage.add_transitions
  * rollout_storage.py:23-59 + the runner's running episode reward / length, on_policy_runner.py:170-181 -- ~25 small torch
  * kernels per env step otherwise).  All pointers are device pointers; N envs.

@@ -35,7 +35,7 @@ def test_ppo_header_symbols_are_exported():
     from wiki_grx_gym_amd.rl import fused_loss
     hdr = open(os.path.join(ROOT, "include", "grx_ppo.h")).read()
     declared = set(re.findall(r"\b(grx_(?:ppo|mlp)_[a-z_]+)\s*\(", hdr))
-    assert declared == {"grx_ppo_loss", "grx_ppo_loss_partials_size", "grx_ppo_colsum", "grx_ppo_colsum_partials_size", "grx_ppo_store_transition", "grx_ppo_gather_rows", "grx_mlp_layer", "grx_mlp_policy_head"}
+    assert declared == {"grx_ppo_loss", "grx_ppo_loss_partials_size", "grx_ppo_colsum", "grx_ppo_colsum_partials_size", "grx_ppo_store_transition", "grx_ppo_gather_rows", "grx_ppo_elu_backward_colsum", "grx_mlp_layer", "grx_mlp_policy_head"}
     path = os.path.join(os.path.dirname(sim.HIP_LIB_PATH), "libgrx_ppo.so")
     if not os.path.exists(path):
         import __graft_entry__ as g

@@ -154,6 +154,34 @@ __global__ __launch_bounds__(256) void colsum_partial(int rows, int cols, const 
     __syncthreads();
     if (wv == 0 && col < cols) partials[(size_t)blockIdx.y * cols + col] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
 }
+// The same first pass for a hidden layer's backward: dz = dy * ELU'(y) from the layer's OUTPUT y (y > 0 ? 1 : y + 1, torch's
+// elu_backward with is_result), written out for the two GEMMs that follow, and summed per column for the bias gradient --
+// one read of dy instead of an elu_backward launch followed by colsum_partial.
+__global__ __launch_bounds__(256) void elu_bwd_colsum_partial(int rows, int cols, const float* __restrict__ dy, const float* __restrict__ y,
+                                                              float* __restrict__ dz, float* __restrict__ partials) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+    float acc = 0.f;
+    if (col < cols) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // (the same four interleaved accumulators as colsum_partial)
+        auto one = [&](const int r) -> float {
+            const size_t o = (size_t)r * cols + col;
+            const float yy = y[o];
+            const float g = dy[o] * (yy > 0.f ? 1.0f : yy + 1.0f);
+            dz[o] = g;
+            return g;
+        };
+        int r = r0 + wv;
+        for (; r + 12 < r1; r += 16) { a0 += one(r); a1 += one(r + 4); a2 += one(r + 8); a3 += one(r + 12); }
+        for (; r < r1; r += 4) a0 += one(r);
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    __shared__ float s_acc[4][64];
+    s_acc[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && col < cols) partials[(size_t)blockIdx.y * cols + col] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+}
 // one wave per column: lane l adds slabs l, l + 64, ... (in order), then a fixed shuffle tree -- deterministic, one exposed
 // load latency instead of nslab dependent ones
 __global__ __launch_bounds__(256) void colsum_final(int cols, int nslab, const float* __restrict__ partials, float* __restrict__ out) {
@@ -351,6 +379,15 @@ extern "C" int grx_ppo_colsum(int rows, int cols, const float* x, float* out, fl
     hipStream_t st = (hipStream_t)stream;
     const int nslab = (rows + CS_ROWS - 1) / CS_ROWS;
     hipLaunchKernelGGL(colsum_partial, dim3((cols + 63) / 64, nslab), dim3(256), 0, st, rows, cols, x, partials);
+    hipLaunchKernelGGL(colsum_final, dim3((cols + 3) / 4), dim3(256), 0, st, cols, nslab, partials, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int grx_ppo_elu_backward_colsum(int rows, int cols, const float* dy, const float* y, float* dz, float* out, float* partials, void* stream) {
+    if (rows < 1 || cols < 1 || !dy || !y || !dz || !out || !partials) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const int nslab = (rows + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(elu_bwd_colsum_partial, dim3((cols + 63) / 64, nslab), dim3(256), 0, st, rows, cols, dy, y, dz, partials);
     hipLaunchKernelGGL(colsum_final, dim3((cols + 3) / 4), dim3(256), 0, st, cols, nslab, partials, out);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

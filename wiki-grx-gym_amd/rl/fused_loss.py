@@ -33,6 +33,8 @@ def load_ppo_library():
         lib.grx_ppo_colsum_partials_size.argtypes = [C.c_int, C.c_int]
         lib.grx_ppo_store_transition.restype = C.c_int
         lib.grx_ppo_store_transition.argtypes = [C.c_int] * 4 + [fp] * 10 + [C.c_float] + [fp] * 13 + [C.c_void_p]
+        lib.grx_ppo_elu_backward_colsum.restype = C.c_int
+        lib.grx_ppo_elu_backward_colsum.argtypes = [C.c_int, C.c_int, fp, fp, fp, fp, fp, C.c_void_p]
         lib.grx_ppo_gather_rows.restype = C.c_int
         lib.grx_ppo_gather_rows.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), fp, C.c_int, C.c_void_p]
         lib.grx_mlp_layer.restype = C.c_int
@@ -99,6 +101,22 @@ def colsum(x):
     if rc != 0:
         raise RuntimeError(f"grx_ppo_colsum failed ({rc}): {rows} x {cols}")
     return out
+
+
+def elu_backward_colsum(dy, y):
+    """(dz, db): dz = dy * ELU'(y) from the layer's output y, db = dz.sum(0) -- one pass (grx_ppo_elu_backward_colsum)"""
+    lib = load_ppo_library()
+    dy, y = _f32c(dy), _f32c(y)
+    rows, cols = dy.shape
+    dz = torch.empty_like(dy)
+    out = torch.empty(cols, device=dy.device, dtype=torch.float32)
+    partials = torch.empty(lib.grx_ppo_colsum_partials_size(rows, cols), device=dy.device, dtype=torch.float32)
+    with torch.cuda.device(dy.device):
+        rc = lib.grx_ppo_elu_backward_colsum(rows, cols, dy.data_ptr(), y.data_ptr(), dz.data_ptr(), out.data_ptr(), partials.data_ptr(),
+                                             C.c_void_p(torch.cuda.current_stream(dy.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"grx_ppo_elu_backward_colsum failed ({rc}): {rows} x {cols}")
+    return dz, out
 
 
 def store_transition(storage, step, obs, pri, actions, mu, sigma, values, logp, rewards, dones, time_outs, gamma, log=None):

@@ -25,6 +25,7 @@ def get_activation(name):
 
 import os
 
+_FUSED_ELU_BACKWARD = os.environ.get("GRX_PPO_FUSED_ELU", "1") != "0"   # hidden layers: ELU backward + bias gradient in one pass (_TrainLinearELU)
 _TRAIN_LINEAR = os.environ.get("GRX_PPO_LINEAR", "colsum")   # "torch": plain nn.Linear autograd on a HIP device too
 
 
@@ -70,6 +71,34 @@ class _TrainLinear(torch.autograd.Function):
             torch.backends.cuda.preferred_blas_library(prev)
 
 
+class _TrainLinearELU(torch.autograd.Function):
+    """ELU(x W^T + b) of a hidden layer as PPO trains it on a HIP device: _TrainLinear's products, with the ELU's backward and the
+    bias gradient in ONE pass over dY (fused_loss.elu_backward_colsum: dZ = dY * ELU'(Y) from the saved OUTPUT, column sums of dZ)
+    instead of an elu_backward launch followed by the column sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        prev = _TrainLinear._blas(weight.shape[0] == 1)
+        try:
+            y = torch.nn.functional.elu(torch.addmm(bias, x, weight.t()))
+        finally:
+            torch.backends.cuda.preferred_blas_library(prev)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .fused_loss import elu_backward_colsum
+        x, weight, y = ctx.saved_tensors
+        dz, db = elu_backward_colsum(dy, y)
+        prev = _TrainLinear._blas(weight.shape[0] == 1)
+        try:
+            dx = dz @ weight if ctx.needs_input_grad[0] else None   # (the first layer's input is data: no dX product)
+            return dx, dz.t() @ x, db
+        finally:
+            torch.backends.cuda.preferred_blas_library(prev)
+
+
 class MLP(nn.Module):
     def __init__(self, input_size, output_size, hidden_dims=(256, 256, 256), activation="relu", **_):
         super().__init__()
@@ -83,8 +112,17 @@ class MLP(nn.Module):
 
     @torch.jit.unused
     def _forward_train(self, x):
-        for m in self.model:
+        mods = list(self.model)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ELU) and mods[i + 1].alpha == 1.0 \
+                    and _FUSED_ELU_BACKWARD:
+                x = _TrainLinearELU.apply(x, m.weight, m.bias)
+                i += 2
+                continue
             x = _TrainLinear.apply(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+            i += 1
         return x
 
     def forward(self, x):
