@@ -170,6 +170,13 @@ def _layer(lib, x, w, b, elu, stream):
     return y
 
 
+def linear_elu(x, weight, bias):
+    """ELU(x W^T + b) through grx_mlp_layer (one launch)"""
+    lib = load_ppo_library()
+    with torch.cuda.device(x.device):
+        return _layer(lib, x, weight, bias, True, torch.cuda.current_stream(x.device).cuda_stream)
+
+
 def mlp_forward(mlp, x):
     """Inference forward of an rl.modules.MLP through libgrx_ppo.so: one MFMA launch per layer (bias + ELU in the epilogue)."""
     lib = load_ppo_library()

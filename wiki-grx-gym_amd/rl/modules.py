@@ -25,6 +25,7 @@ def get_activation(name):
 
 import os
 
+_FUSED_ELU_FORWARD = os.environ.get("GRX_PPO_FUSED_FWD", "1") != "0"   # ... and their forward through grx_mlp_layer (bias + ELU epilogue)
 _FUSED_ELU_BACKWARD = os.environ.get("GRX_PPO_FUSED_ELU", "1") != "0"   # hidden layers: ELU backward + bias gradient in one pass (_TrainLinearELU)
 _TRAIN_LINEAR = os.environ.get("GRX_PPO_LINEAR", "colsum")   # "torch": plain nn.Linear autograd on a HIP device too
 
@@ -78,11 +79,15 @@ class _TrainLinearELU(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        prev = _TrainLinear._blas(weight.shape[0] == 1)
-        try:
-            y = torch.nn.functional.elu(torch.addmm(bias, x, weight.t()))
-        finally:
-            torch.backends.cuda.preferred_blas_library(prev)
+        if _FUSED_ELU_FORWARD and x.is_contiguous() and weight.is_contiguous():
+            from .fused_loss import linear_elu
+            y = linear_elu(x, weight, bias)   # libgrx_ppo.so: f32 MFMA, bias + ELU in the epilogue (one launch)
+        else:
+            prev = _TrainLinear._blas(weight.shape[0] == 1)
+            try:
+                y = torch.nn.functional.elu(torch.addmm(bias, x, weight.t()))
+            finally:
+                torch.backends.cuda.preferred_blas_library(prev)
         ctx.save_for_backward(x, weight, y)
         return y
 
