@@ -22,6 +22,27 @@ from wiki_grx_gym_amd.utils.task_registry import LEGGED_GYM_ROOT_DIR
 
 EXPORT_POLICY = True
 
+# what play.py:110-126 hands to Logger.log_states for (robot r, joint j): key -> value from the env's tensors
+_SCALARS = (
+    ("dof_pos", lambda e, r, j: e.dof_pos[r, j]),
+    ("dof_vel", lambda e, r, j: e.dof_vel[r, j]),
+    ("dof_torque", lambda e, r, j: e.torques[r, j]),
+    ("command_x", lambda e, r, j: e.commands[r, 0]),
+    ("command_y", lambda e, r, j: e.commands[r, 1]),
+    ("command_yaw", lambda e, r, j: e.commands[r, 2]),
+    ("base_vel_x", lambda e, r, j: e.base_lin_vel[r, 0]),
+    ("base_vel_y", lambda e, r, j: e.base_lin_vel[r, 1]),
+    ("base_vel_z", lambda e, r, j: e.base_lin_vel[r, 2]),
+    ("base_vel_yaw", lambda e, r, j: e.base_ang_vel[r, 2]),
+)
+
+
+def _state_record(env, actions, r, j):
+    rec = {"dof_pos_target": float(actions[r, j]) * env.cfg.control.action_scale}
+    rec.update((key, float(get(env, r, j))) for key, get in _SCALARS)
+    rec["contact_forces_z"] = env.contact_forces[r, env.feet_indices, 2].cpu().tolist()
+    return rec
+
 
 def play(args, steps=None, log_root="default"):
     env_cfg, train_cfg = task_registry.get_cfgs(name=args.task)
@@ -71,20 +92,7 @@ def play(args, steps=None, log_root="default"):
             obs, _, rews, dones, infos = env.step(actions.detach())
 
             if i < stop_state_log:
-                rec = {   # the dict of play.py:112-125
-                    "dof_pos_target": actions[robot_index, joint_index].item() * env.cfg.control.action_scale,
-                    "dof_pos": env.dof_pos[robot_index, joint_index].item(),
-                    "dof_vel": env.dof_vel[robot_index, joint_index].item(),
-                    "dof_torque": env.torques[robot_index, joint_index].item(),
-                    "command_x": env.commands[robot_index, 0].item(),
-                    "command_y": env.commands[robot_index, 1].item(),
-                    "command_yaw": env.commands[robot_index, 2].item(),
-                    "base_vel_x": env.base_lin_vel[robot_index, 0].item(),
-                    "base_vel_y": env.base_lin_vel[robot_index, 1].item(),
-                    "base_vel_z": env.base_lin_vel[robot_index, 2].item(),
-                    "base_vel_yaw": env.base_ang_vel[robot_index, 2].item(),
-                    "contact_forces_z": env.contact_forces[robot_index, env.feet_indices, 2].cpu().tolist(),
-                }
+                rec = _state_record(env, actions, robot_index, joint_index)
                 logger.log_states(rec)
                 sf.write(json.dumps(rec) + "\n")
             elif i == stop_state_log:
