@@ -32,7 +32,12 @@
  *     checkout, .MISSING_LARGE_BLOBS:7-21); there is no source, no golden rollout and no test
  *     in the reference that pins its output.  This file implements a textbook articulated-body
  *     forward dynamics + compliant contact model pinned only by physics
- *     invariants (tests/test_oracle_physics.py): ABA vs CRBA, energy, free fall, static stance.
+ *     invariants (tests/test_oracle_physics.py): ABA vs CRBA, energy, free fall, static stance;
+ *     round 2: self-collision (legs kept apart, internal force pair conserves momentum; the reference
+ *     enables it: legged_robot_config.py:121, legged_robot.py:1022-1028), restitution with the bounce
+ *     threshold (legged_robot_config.py:46-49, legged_robot.py:565-575), contact along the terrain
+ *     normal, 'trimesh' risers (legged_robot.py:903-921) -- each this build's own model of what PhysX
+ *     does there, equally unpinned.
  *
  * Build: see oracle/Makefile (REAL=float -> libgrx_oracle_f32.so, REAL=double -> ..._f64.so).
  */
