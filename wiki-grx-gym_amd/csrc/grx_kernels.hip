@@ -399,7 +399,7 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
     GRX_TICK2(16);
     // thigh / shank shapes (W == 1: and the base-lump shapes), compacted over the wave
     RareOut ro;
-    rare_contacts<HF, (W == 1 ? 0 : 8), RC_NS>(P, T, C, RB, lane, el, side, R0, O, st.ang, st.vel, K2, K3, LC.mu, LC.hmax, ro);
+    rare_contacts<HF, (W == 1 ? 0 : 8), RC_NS>(P, T, C, RB, lane, el, side, R0, O, st.ang, st.vel, K2, K3, LC.mu, LC.hmax, ro, nullptr, RareNoWait(), lfo.last);
     SelfOut sc;
     {   // self-collision: leg against leg, thigh against base-lump shapes
         const ChainKin KS[3] = {K2, K3, K4};
@@ -1176,7 +1176,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
                 RareOut ro;
                 const ChainKin nok = {R0, v3(0.f, 0.f, 0.f), ang, vel};   // no chain shapes on this wave
-                rare_contacts<HF, 0, 8>(P, s_tab, C, RB, lane, el, side, R0, O, ang, vel, nok, nok, mu, hmax, ro);
+                rare_contacts<HF, 0, 8>(P, s_tab, C, RB, lane, el, side, R0, O, ang, vel, nok, nok, mu, hmax, ro, nullptr, RareNoWait(), deci == P.decimation - 1);
                 float* w_ = s_wr + lane;
                 if (deci == P.decimation - 1) {   // GRX_T_CONTACT_FORCES rows are written by the dynamics wave (it adds the self-collision forces)
 #pragma unroll

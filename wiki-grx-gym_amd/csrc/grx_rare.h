@@ -80,7 +80,7 @@ struct RareNoWait { GRX_DEV void operator()() const {} };
 template <bool HF, int S0, int S1, bool FRAMES_IN_LDS = false, class WaitFrames = RareNoWait>
 GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const RareBuf& B, int lane, int el, int side, const R3& R0, V3 O, V3 ang, V3 vel,
                            const ChainKin& K2in, const ChainKin& K3in, float mu, float hmax, RareOut& out,
-                           long long* rare_acc = nullptr, WaitFrames wait_frames = WaitFrames()) {
+                           long long* rare_acc = nullptr, WaitFrames wait_frames = WaitFrames(), const bool want_links = true) {
     const V3 zero = v3(0.f, 0.f, 0.f);
 #ifdef GRX_PROFILE_SECTIONS
     long long rare_scratch[8];
@@ -226,7 +226,10 @@ GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const Rar
                 else { out.fa3 = out.fa3 + Tq; out.fl3 = out.fl3 + F; }
             }
         }
-        if (S0 < 8 && (act & 0xffu)) {   // per-link netting for termination / collision (legged_robot.py:336-353)
+        // (the reference looks at the net contact forces AFTER the last sub-step only -- check_termination and the collision
+        //  term read `contact_forces` of the final state, legged_robot.py:336-353, 266 -- so the callers ask for the per-link
+        //  netting on that sub-step alone: want_links, wave-uniform)
+        if (want_links && S0 < 8 && (act & 0xffu)) {   // per-link netting for termination / collision
             uint32_t fl[8]; int ll[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { fl[i] = C.sph[i].flags; ll[i] = C.sph[i].link_last; }

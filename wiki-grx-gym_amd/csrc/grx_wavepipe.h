@@ -531,7 +531,7 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         const int want = seq + 1;
         int* const fr_flag = L.flag + FL_FRAMES;
         rare_contacts<HF, 0, RC_NS, true>(P, T, C, RB, lane, el, side, R0, O, ang, vel, ChainKin(), ChainKin(), mu, hmax, ro, racc,
-                                          [=]() { flag_wait(fr_flag, want); });
+                                          [=]() { flag_wait(fr_flag, want); }, seq == P.decimation - 1);
         if (seq == P.decimation - 1) {   // GRX_T_CONTACT_FORCES: per-link forces of the base-lump shapes for wave 0 (the result table is free now)
             float2* r = RB.res + lane;
 #pragma unroll
