@@ -1117,7 +1117,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 for (int i = 0; i < 4; ++i) { a_[i * 64] = hs.ax[i]; a_[(4 + i) * 64] = hs.ay[i]; a_[(9 + i) * 64] = hs.vimp[i]; }
                 a_[8 * 64] = __uint_as_float(hs.anchor_on);
             } else {
-                base_contact_loop<HF>(P, s_tab, GRX_HELPER_C, RB, mu, hmax, bm, bc, bI, L, lane, el, side);
+                base_contact_loop<HF>(P, s_tab, GRX_HELPER_C, RB, mu, hmax, bm, bc, bI, L, lane, el, side,
+                                      LinkForceOut{true, act ? P.contact_forces + e : nullptr, (size_t)N});
             }
             float es_w1[NT], es_w3[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
             if (wv == 1) load_episode_sums<1>(P, e, N, es_w1);

@@ -283,13 +283,8 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         out.pen_count = w1_.w;
         pa = pa - f0a - sc.f0a; pl = pl - f0l - sc.f0l;
     }
-    if (lfo.last) {   // GRX_T_CONTACT_FORCES rows: wave 3 parked the per-link forces of the base-lump shapes in the result table
-        V3 lf[8];
-        const float2* r = RB.res + lane;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { const float2 a = r[(2 * i) * 64], b = r[(2 * i + 1) * 64]; lf[i] = v3(a.x, a.y, b.x); }
-        write_link_rows(lfo, Clds, lf, flt[0], flt[1], flt[2], sc);
-    }
+    // (GRX_T_CONTACT_FORCES rows of the last sub-step: written by wave 3, which has the base-lump links' forces at hand and is done
+    //  before this wave -- base_contact_loop)
     pa = pair_sum(pa); pl = pair_sum(pl);
     {   // base-lump bias force (wave 3; both lanes of the pair add the same value after the pair sum)
         GRX_WAIT(L.flag + FL_BASEBIAS, seq + 1, 0);
@@ -503,7 +498,7 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
 // wave 3: the seldom-touching shapes -- base lump (torso, head, arms), thigh, shank -- lane-compacted (grx_rare.h)
 template <bool HF>
 GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, float mu, float hmax, float base_m, V3 base_c,
-                               const S3& base_I, const PipeLds& L, int lane, int el, int side) {
+                               const S3& base_I, const PipeLds& L, int lane, int el, int side, const LinkForceOut& lfo) {
     GRX_HELPER_PROF_BEGIN;
 #ifdef GRX_PROFILE_SECTIONS
     long long racc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -532,11 +527,6 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         int* const fr_flag = L.flag + FL_FRAMES;
         rare_contacts<HF, 0, RC_NS, true>(P, T, C, RB, lane, el, side, R0, O, ang, vel, ChainKin(), ChainKin(), mu, hmax, ro, racc,
                                           [=]() { flag_wait(fr_flag, want); }, seq == P.decimation - 1);
-        if (seq == P.decimation - 1) {   // GRX_T_CONTACT_FORCES: per-link forces of the base-lump shapes for wave 0 (the result table is free now)
-            float2* r = RB.res + lane;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { float2 a; a.x = ro.lf[i].x; a.y = ro.lf[i].y; r[(2 * i) * 64] = a; a.x = ro.lf[i].z; a.y = 0.f; r[(2 * i + 1) * 64] = a; }
-        }
         float4* c_ = L.wc + lane;
         c_[0 * 64] = f4(ro.fa2.x, ro.fa2.y, ro.fa2.z, ro.fl2.x);
         c_[1 * 64] = f4(ro.fl2.y, ro.fl2.z, 0.f, 0.f);
@@ -546,6 +536,26 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         L.wr[64 + lane] = f4(ro.f0l.y, ro.f0l.z, ro.term ? 1.f : 0.f, ro.pen_count);
         flag_set(L.flag + FL_LEGS, seq + 1, lane);   // thigh + shank wrenches and the base-lump wrench, one hand-over
         GRX_EV(12);
+        if (seq == P.decimation - 1) {
+            // GRX_T_CONTACT_FORCES (net contact force per URDF link after the LAST sub-step, legged_robot.py:117, 266): this wave
+            // has the base-lump links' forces; the foot's terrain force comes from wave 2, the self-collision forces from
+            // wave 1 -- both handed over for wave 0 anyway.  Written here, off wave 0's path (it is the last to finish).
+            flag_wait(L.flag + FL_FOOT, seq + 1);
+            flag_wait(L.flag + FL_SELF, seq + 1);
+            SelfOut sc;
+            {
+                const float4* c = L.wc + 7 * 64 + lane;
+                const float4 s0 = c[0 * 64], s1 = c[1 * 64], s2 = c[2 * 64], s3 = c[3 * 64], s4 = c[4 * 64], s5 = c[5 * 64], s6 = c[6 * 64], s7 = c[7 * 64];
+                sc.fa[0] = v3(s0.x, s0.y, s0.z); sc.fl[0] = v3(s0.w, s1.x, s1.y);
+                sc.fa[1] = v3(s1.z, s1.w, s2.x); sc.fl[1] = v3(s2.y, s2.z, s2.w);
+                sc.fa[2] = v3(s3.x, s3.y, s3.z); sc.fl[2] = v3(s3.w, s4.x, s4.y);
+                sc.f0a = v3(s4.z, s4.w, s5.x); sc.f0l = v3(s5.y, s5.z, s5.w);
+                sc.fbase[0] = v3(s6.x, s6.y, s6.z); sc.fbase[1] = v3(s6.w, s7.x, s7.y);
+            }
+            const float4 f0_ = c_[4 * 64], f1_ = c_[5 * 64];
+            const V3 foot_terrain = v3(f0_.w, f1_.x, f1_.y);
+            write_link_rows(lfo, C, ro.lf, ro.fl2, ro.fl3, foot_terrain, sc);
+        }
     }
     GRX_HELPER_PROF_END(3);
 #ifdef GRX_PROFILE_SECTIONS
