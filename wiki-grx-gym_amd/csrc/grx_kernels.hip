@@ -1289,8 +1289,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             t *= LC.strength[k];
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
-        if (W == 4) substep_p<HF>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc,
-                                  LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N}, C);
+        if (W == 4) substep_p<HF>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc, C);
         else substep<HF, W>(P, s_tab, C, LC, st, torque, so, fk, s_wr + lane, tacc,
                             LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side, self_near, deci == 0);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step

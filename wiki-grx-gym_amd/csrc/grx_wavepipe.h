@@ -121,7 +121,7 @@ GRX_DEV void add_rigid(S3& A, M3& B, S3& D, const S3& Ak, V3 h, float m) {
 template <bool HF>
 GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                        SubstepOut& out, FootKin& fk_before, const PipeLds& L, const RareBuf& RB, int lane, int seq, long long* tacc,
-                       const LinkForceOut& lfo, const SideConst& Clds) {   // Clds: the LDS copy of C (tables read once per policy step)
+                       const SideConst& Clds) {   // Clds: the LDS copy of C (tables read once per policy step)
     const float dt = P.sim_dt;
 #ifdef GRX_PROFILE_SECTIONS
     long long tprev = clock64();
@@ -248,14 +248,12 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     SelfOut sc;   // self-collision wrenches (wave 1, after its recursion)
     {
         const float4* c = L.wc + 7 * 64 + lane;
-        const float4 s0 = c[0 * 64], s1 = c[1 * 64], s2 = c[2 * 64], s3 = c[3 * 64], s4 = c[4 * 64], s5 = c[5 * 64], s6 = c[6 * 64], s7 = c[7 * 64];
+        const float4 s0 = c[0 * 64], s1 = c[1 * 64], s2 = c[2 * 64], s3 = c[3 * 64], s4 = c[4 * 64], s5 = c[5 * 64];
         sc.fa[0] = v3(s0.x, s0.y, s0.z); sc.fl[0] = v3(s0.w, s1.x, s1.y);
         sc.fa[1] = v3(s1.z, s1.w, s2.x); sc.fl[1] = v3(s2.y, s2.z, s2.w);
         sc.fa[2] = v3(s3.x, s3.y, s3.z); sc.fl[2] = v3(s3.w, s4.x, s4.y);
-        sc.f0a = v3(s4.z, s4.w, s5.x); sc.f0l = v3(s5.y, s5.z, s5.w);
-        sc.fbase[0] = v3(s6.x, s6.y, s6.z); sc.fbase[1] = v3(s6.w, s7.x, s7.y);
+        sc.f0a = v3(s4.z, s4.w, s5.x); sc.f0l = v3(s5.y, s5.z, s5.w);   // (quads 6, 7: forces on base-lump links, for wave 3's contact-force rows)
     }
-    V3 flt[3];   // terrain forces on thigh, shank, foot (GRX_T_CONTACT_FORCES rows)
     {
         V3 da = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
 #pragma unroll
@@ -265,7 +263,6 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
                 const float4 c0_ = c[0 * 64], c1_ = c[1 * 64];
                 const V3 fa = v3(c0_.x, c0_.y, c0_.z), fl = v3(c0_.w, c1_.x, c1_.y);
                 da = da - fa - sc.fa[k - 2]; dl = dl - fl - sc.fl[k - 2];
-                flt[k - 2] = fl;
                 if (k == LEG - 1) { const float4 c2_ = c[2 * 64]; out.foot_force = fl + sc.fl[2]; fk_before.vel = v3(c1_.z, c1_.w, c2_.x); }
             }
             const float du = -(dot(Sa[k], da) + dot(Ss[k], dl));
