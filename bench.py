@@ -73,6 +73,9 @@ def make_cfg(terrain, robot="lower_limb"):
     cfg = config.GR1T1Cfg() if robot == "lower_limb" else config.GR1T1FullBodyCfg()
     cfg.terrain.mesh_type = "heightfield" if terrain == "rough" else "plane"
     cfg.terrain.curriculum = True
+    # API-completeness tensors nobody reads in a rollout stay off, as SURVEY 8d prices them ("not counted: rigid_body_states
+    # 1924 B"): GRX_T_RIGID_BODY_STATES (GRX_BENCH_RBS=1 turns it on for the surcharge measurement) -- like publish_reward_terms
+    cfg.env.publish_rigid_body_states = os.environ.get("GRX_BENCH_RBS", "0") == "1"
     return cfg
 
 
@@ -135,7 +138,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the GRx step has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): one process per GPU over RCCL -- the process group, the barriers and the
+    # max-over-ranks reduction below run at every world size, 1 included (tests/test_env_gpu.py drives that on one GPU)
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -175,7 +181,7 @@ def main():
     # HIP-event window: every 8th launch (an event pair costs the stream ~7 us: a denser window would show up in `value`)
     sim.kernel_time_ms(enable=int(os.environ.get("GRX_BENCH_EVENT_STRIDE", "8")))
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -184,12 +190,12 @@ def main():
         sim.step(pool[counter % 16], delay, counter)
     sim.wait_idle()           # spin on the library's pinned progress word until the last step has finished: the HIP
     torch.cuda.synchronize()  # runtime's own completion view was measured to lag by 10-80 ms sporadically
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms, launches = sim.kernel_time_ms(enable=False)
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -258,7 +264,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, terrain_obj, args.cpu_envs, steps, seed)
         print(json.dumps(out), flush=True)
     sim.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

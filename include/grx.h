@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 2
+#define GRX_ABI_VERSION 3
 
 #define GRX_MAX_BODIES 36   /* moving bodies after merging fixed joints (base + DOFs) */
 #define GRX_MAX_DOFS 32
@@ -52,6 +52,7 @@ extern "C" {
 #define GRX_NUM_FEET 2
 #define GRX_NUM_CMD 3
 #define GRX_MAX_HEIGHT_POINTS 128
+#define GRX_STATS_HISTORY 128     /* policy steps of episode statistics kept in GRX_T_EPISODE_STATS_HISTORY */
 
 typedef enum grx_status {
     GRX_OK = 0,
@@ -157,6 +158,12 @@ typedef struct grx_model {
     float torso_rot[9];                      /* torso link -> body rotation, row-major */
     int32_t forehead_body;
     float forehead_rot[9];
+    /* every URDF link frame (gym.acquire_rigid_body_state_tensor rows, legged_robot.py:113,134): the moving body that
+     * carries it after the fixed-joint merge and its pose in that body's frame */
+    int32_t num_links;
+    int32_t link_body[GRX_MAX_LINKS];
+    float link_pos[GRX_MAX_LINKS][3];
+    float link_rot[GRX_MAX_LINKS][9];        /* link -> body rotation, row-major */
 } grx_model;
 
 typedef struct grx_contact_params {
@@ -256,6 +263,8 @@ typedef struct grx_config {
 
     int32_t publish_reward_terms;  /* 1: also write GRX_T_REWARD_TERMS, the per-term reward table (a debugging tensor with no
                                       reference counterpart; the parity tests read it).  Every other tensor is always current. */
+    int32_t publish_rigid_body_states; /* 1: also write GRX_T_RIGID_BODY_STATES after the last sub-step of every step (the
+                                      reference refreshes it every sub-step, legged_robot_fftai.py:76, and reads the last one) */
 } grx_config;
 
 typedef enum grx_tensor_id {
@@ -297,11 +306,18 @@ typedef enum grx_tensor_id {
     GRX_T_FRICTION,           /* f32 (N) */
     GRX_T_BASE_MASS_COM,      /* f32 (N, 4)  randomised base_link mass, com xyz */
     GRX_T_TERM_CONTACT,       /* u8  (N) any terminating body touched the ground, last sub-step */
-    GRX_T_EPISODE_STATS,      /* f32 (GRX_NUM_REWARD_TERMS + 1): mean episode sums of the envs reset
-                                 by the last step that reset any (legged_robot.py:420-424), [NT] = count */
+    GRX_T_EPISODE_STATS,      /* f32 (GRX_NUM_REWARD_TERMS + 2): mean episode sums of the envs reset by the last step that
+                                 reset any (legged_robot.py:420-424), [NT] = their count, [NT + 1] = mean terrain level after
+                                 that step's curriculum update (legged_robot.py:427-428).  Current after grx_flush_stats /
+                                 grx_episode_stats; otherwise it may lag the last step by one (see grx_flush_stats) */
     GRX_T_ANCHORS,            /* f32 (N, 8, 3) foot-sphere friction anchors xy + active flag */
     GRX_T_CONTACT_FORCES,     /* f32 (N, GRX_MAX_LINKS, 3) net contact force per URDF link (index = grx_model.sph_link), last
                                  sub-step: the reference's contact_forces (legged_robot.py:117,266); links without shapes stay 0 */
+    GRX_T_EPISODE_STATS_HISTORY, /* f32 (GRX_STATS_HISTORY, GRX_NUM_REWARD_TERMS + 2): row (slot) = GRX_T_EPISODE_STATS as of the step
+                                 that returned grx_step_args.stats_slot = slot; a row stays valid for GRX_STATS_HISTORY - 1 later steps */
+    GRX_T_RIGID_BODY_STATES,  /* f32 (N, GRX_MAX_LINKS, 13) p3 q4(xyzw) v3 w3 of every URDF link frame, world axes, after the last
+                                 sub-step: gym.acquire_rigid_body_state_tensor (legged_robot.py:113,134); written only with
+                                 grx_config.publish_rigid_body_states */
     GRX_NUM_TENSORS
 } grx_tensor_id;
 
@@ -331,6 +347,8 @@ typedef struct grx_step_args {
                                   wrapper alternates between two buffers: the reference hands out a FRESH obs tensor every
                                   step (torch.cat / torch.clip, gr1t1.py:282, legged_robot.py:241) and rsl_rl keeps the one it
                                   acted on until after env.step() (ppo.py:160-161, 194) -- without a copy per step */
+    int64_t stats_slot;        /* OUT: row of GRX_T_EPISODE_STATS_HISTORY that holds extras["episode"] of THIS step (complete once
+                                  a later step has been enqueued, or after grx_flush_stats) */
 } grx_step_args;
 
 /* create / destroy.  device_id: HIP device ordinal. */
@@ -341,7 +359,7 @@ int grx_destroy(grx_handle h);
 int grx_reset_all(grx_handle h, void* stream);
 
 /* one policy step = LeggedRobot.step() (legged_robot.py:222-246) */
-int grx_step(grx_handle h, const grx_step_args* args, void* stream);
+int grx_step(grx_handle h, grx_step_args* args, void* stream);   /* writes args->stats_slot */
 
 /* non-owning view of a library buffer */
 int grx_tensor(grx_handle h, int tensor_id, grx_tensor_desc* out);
@@ -352,7 +370,21 @@ int grx_tensor(grx_handle h, int tensor_id, grx_tensor_desc* out);
 int grx_set_state(grx_handle h, const float* root_states, const float* dof_pos,
                   const float* dof_vel, void* stream);
 
-/* copy GRX_T_EPISODE_STATS to host (synchronises the stream) */
+/* reset the listed envs (LeggedRobot.reset_idx(env_ids), legged_robot.py:377-440) outside a step: curriculum move, dof / root /
+ * command draws, history and timers zeroed, episode sums folded into the episode statistics.  env_ids: DEVICE int32[n]. */
+int grx_reset_idx(grx_handle h, const int32_t* env_ids, int32_t n, void* stream);
+
+/* indexed variant of grx_set_state (set_dof_state_tensor_indexed / set_actor_root_state_tensor_indexed, legged_robot.py:737-740,
+ * 782-784): rows env_ids[i] of the FULL (N, k) buffers are copied; env_ids: DEVICE int32[n]. */
+int grx_set_state_indexed(grx_handle h, const int32_t* env_ids, int32_t n, const float* root_states, const float* dof_pos,
+                          const float* dof_vel, void* stream);
+
+/* The episode statistics of a step (per-block partial sums) are reduced by the NEXT step's kernel -- one launch per policy
+ * step, no host synchronisation.  grx_flush_stats reduces those of the LAST enqueued step now (one small kernel), so that
+ * GRX_T_EPISODE_STATS and that step's row of GRX_T_EPISODE_STATS_HISTORY are current in stream order. */
+int grx_flush_stats(grx_handle h, void* stream);
+
+/* grx_flush_stats, then copy GRX_T_EPISODE_STATS (GRX_NUM_REWARD_TERMS + 2 floats) to host (synchronises the stream) */
 int grx_episode_stats(grx_handle h, float* host_out, void* stream);
 
 /* average duration [ms] of the fused step kernel over the timed launches since the last call, measured
@@ -362,8 +394,8 @@ int grx_episode_stats(grx_handle h, float* host_out, void* stream);
 int grx_kernel_time_ms(grx_handle h, int enable, float* avg_ms, int64_t* launches);
 
 /* Spin (no blocking system call) until every step enqueued through this handle has finished on the GPU.
- * The library also bounds the host's run-ahead to 256 policy steps with the same progress word (a ticket the last
- * kernel of each step stores in host-pinned memory), see grx_capi.cpp. */
+ * The library also bounds the host's run-ahead to 256 policy steps with the same progress word (host-pinned: every step
+ * kernel stores, when it STARTS, the ticket of the step before it -- complete by stream order), see grx_capi.cpp. */
 int grx_wait_idle(grx_handle h);
 
 /* ---- TEST-ONLY entry (not part of the drop-in surface; the reference has no counterpart) ----------------------

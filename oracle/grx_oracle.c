@@ -297,9 +297,12 @@ struct grx_sim {
     uint8_t *t_reset, *t_timeout;
     int64_t* t_eplen;
     float* scratch[GRX_NUM_TENSORS];
+    float* t_rbs;   /* GRX_T_RIGID_BODY_STATES (N, GRX_MAX_LINKS, 13), written by the step */
     uint8_t* scratch_u8[GRX_NUM_TENSORS];
     int32_t* scratch_i32[GRX_NUM_TENSORS];
-    float stats[NT + 1];
+    float stats[NT + 2];   /* [NT] episodes that ended, [NT + 1] mean terrain level after that step's curriculum moves */
+    float hist[GRX_STATS_HISTORY][NT + 2];   /* GRX_T_EPISODE_STATS_HISTORY */
+    int64_t seq;           /* launches that may finish episodes (steps, resets): history row = seq % GRX_STATS_HISTORY */
     int64_t nsteps;
     int num_links;
     uint32_t reset_count;
@@ -723,6 +726,37 @@ static void named_frames(const struct grx_sim* s, env_t* e, const kin_t* k) {
     }
 }
 
+/* GRX_T_RIGID_BODY_STATES row of env le (gym.acquire_rigid_body_state_tensor, legged_robot.py:113,134): every URDF link frame,
+ * p3 q4(xyzw) v3 w3 in world axes, from the body frames after the last sub-step */
+static void m3_to_quat(const real R[9], real q[4]) { /* largest-component form */
+    real t0 = 1 + R[0] - R[4] - R[8], t1 = 1 - R[0] + R[4] - R[8], t2 = 1 - R[0] - R[4] + R[8], t3 = 1 + R[0] + R[4] + R[8];
+    if (t3 >= t0 && t3 >= t1 && t3 >= t2) { q[0] = R[7] - R[5]; q[1] = R[2] - R[6]; q[2] = R[3] - R[1]; q[3] = t3; }
+    else if (t0 >= t1 && t0 >= t2) { q[0] = t0; q[1] = R[1] + R[3]; q[2] = R[2] + R[6]; q[3] = R[7] - R[5]; }
+    else if (t1 >= t2) { q[0] = R[1] + R[3]; q[1] = t1; q[2] = R[5] + R[7]; q[3] = R[2] - R[6]; }
+    else { q[0] = R[2] + R[6]; q[1] = R[5] + R[7]; q[2] = t2; q[3] = R[3] - R[1]; }
+    real n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= n;
+}
+static void link_frames(struct grx_sim* s, int le, const kin_t* k) {
+    const grx_model* m = &s->cfg.model;
+    float* out = s->t_rbs + (size_t)le * GRX_MAX_LINKS * 13;
+    for (int l = 0; l < m->num_links; ++l) {
+        int b = m->link_body[l];
+        real lp[3] = {m->link_pos[l][0], m->link_pos[l][1], m->link_pos[l][2]}, off[3], wxs[3], ub[3], vw[3], ww[3], Rl[9], LR[9], q[4];
+        m3_mulv(k->R[b], lp, off);
+        v3_cross(k->v[b].v, lp, wxs);
+        for (int i = 0; i < 3; ++i) ub[i] = k->v[b].v[3 + i] + wxs[i];
+        m3_mulv(k->R[b], ub, vw);
+        m3_mulv(k->R[b], k->v[b].v, ww);
+        for (int i = 0; i < 9; ++i) LR[i] = m->link_rot[l][i];
+        m3_mul(k->R[b], LR, Rl);
+        m3_to_quat(Rl, q);
+        float* o = out + l * 13;
+        for (int i = 0; i < 3; ++i) { o[i] = (float)(k->p[b][i] + off[i]); o[7 + i] = (float)vw[i]; o[10 + i] = (float)ww[i]; }
+        for (int i = 0; i < 4; ++i) o[3 + i] = (float)q[i];
+    }
+}
+
 /* ------------------------------------------------------------------ env pipeline */
 static real urand(const struct grx_sim* s, int le, uint32_t step, uint32_t stream, uint32_t i, real lo, real hi) {
     float u = gro_rand(s->cfg.seed, (uint32_t)(s->cfg.env_offset + le), step, stream, i);
@@ -1058,6 +1092,7 @@ static int step_env(struct grx_sim* s, int le, const grx_step_args* args, real s
         if (substep(s, e, e->torques, &k)) return -1;
         forward_kinematics(s, e, &k); /* refresh_*_tensor: body states AFTER the sub-step */
         named_frames(s, e, &k);
+        if (deci == c->decimation - 1 && c->publish_rigid_body_states) link_frames(s, le, &k);   /* before reset_idx, like the reference's tensor */
         for (int f = 0; f < 2; ++f) {
             const real* F = e->feet_force[f];
             e->avg_force[f] += sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2]);
@@ -1151,7 +1186,17 @@ static int step_env(struct grx_sim* s, int le, const grx_step_args* args, real s
     return 0;
 }
 
-int gro_step(grx_handle s, const grx_step_args* args, void* stream) {
+static void stats_file(struct grx_sim* s, int cnt) {   /* after a step / reset: terrain-level mean (legged_robot.py:427-428), history row */
+    if (cnt > 0) {
+        double lv = 0;
+        for (int i = 0; i < s->N; ++i) lv += s->env[i].level;
+        s->stats[NT + 1] = (float)(lv / s->N);
+    }
+    ++s->seq;
+    memcpy(s->hist[s->seq & (GRX_STATS_HISTORY - 1)], s->stats, sizeof s->stats);
+}
+
+int gro_step(grx_handle s, grx_step_args* args, void* stream) {
     (void)stream;
     if (!s || !args) return fail(GRX_ERR_INVALID_ARGUMENT, "gro_step: null argument");
     /* caller may have written episode_length_buf (on_policy_runner.py:126) */
@@ -1181,6 +1226,8 @@ int gro_step(grx_handle s, const grx_step_args* args, void* stream) {
         for (int t = 0; t < NT; ++t) s->stats[t] = (float)(sum[t] / cnt / s->cfg.max_episode_length_s);
         s->stats[NT] = (float)cnt;
     }
+    stats_file(s, cnt);
+    args->stats_slot = s->seq & (GRX_STATS_HISTORY - 1);
     s->nsteps++;
     publish(s);
     return bad ? fail(GRX_ERR_INVALID_ARGUMENT, "gro_step: articulated inertia not SPD (diverged state)") : GRX_OK;
@@ -1200,9 +1247,41 @@ int gro_reset_all(grx_handle s, void* stream) {
     }
     for (int t = 0; t < NT; ++t) s->stats[t] = (float)(sum[t] / s->N / s->cfg.max_episode_length_s);
     s->stats[NT] = (float)s->N;
+    stats_file(s, s->N);
     publish(s);
     return GRX_OK;
 }
+
+/* LeggedRobot.reset_idx(env_ids) outside a step (legged_robot.py:377-440); env_ids: host int32[n] here */
+int gro_reset_idx(grx_handle s, const int32_t* env_ids, int32_t n, void* stream) {
+    (void)stream;
+    if (!s || (n > 0 && !env_ids)) return fail(GRX_ERR_INVALID_ARGUMENT, "gro_reset_idx: null argument");
+    if (n <= 0) return GRX_OK;
+    uint32_t step = 0x80000000u + (s->reset_count++);
+    real sum[NT];
+    memset(sum, 0, sizeof sum);
+    char* flag = (char*)calloc((size_t)s->N, 1);
+    int cnt = 0;
+    for (int k = 0; k < n; ++k) if (env_ids[k] >= 0 && env_ids[k] < s->N) flag[env_ids[k]] = 1;
+    for (int i = 0; i < s->N; ++i) {
+        if (!flag[i]) continue;
+        env_t* e = &s->env[i];
+        for (int t = 0; t < NT; ++t) { sum[t] += e->episode_sums[t]; e->episode_sums[t] = 0; }
+        reset_env(s, e, i, step, 1);
+        e->reset = 1;
+        ++cnt;
+    }
+    free(flag);
+    if (cnt > 0) {
+        for (int t = 0; t < NT; ++t) s->stats[t] = (float)(sum[t] / cnt / s->cfg.max_episode_length_s);
+        s->stats[NT] = (float)cnt;
+    }
+    stats_file(s, cnt);
+    publish(s);
+    return GRX_OK;
+}
+
+int gro_flush_stats(grx_handle s, void* stream) { (void)stream; return s ? GRX_OK : fail(GRX_ERR_INVALID_ARGUMENT, "gro_flush_stats: null handle"); }
 
 /* c10::div_floor_floating (what torch.div(..., rounding_mode='floor') evaluates in float32) */
 static float torch_div_floor(float a, float b) {
@@ -1255,6 +1334,7 @@ int gro_create(const grx_config* cfg, int device_id, grx_handle* out) {
     s->t_reset = (uint8_t*)zalloc(N);
     s->t_timeout = (uint8_t*)zalloc(N);
     s->t_eplen = (int64_t*)zalloc(sizeof(int64_t) * N);
+    s->t_rbs = (float*)zalloc(sizeof(float) * (size_t)N * GRX_MAX_LINKS * 13);
     memset(s->t_reset, 1, N); /* reset_buf starts as ones (base_task.py:71) */
     for (int id = 0; id < GRX_NUM_TENSORS; ++id) {
         s->scratch[id] = (float*)zalloc(sizeof(float) * (size_t)N * 256);
@@ -1325,7 +1405,7 @@ int gro_create(const grx_config* cfg, int device_id, grx_handle* out) {
 int gro_destroy(grx_handle s) {
     if (!s) return GRX_OK;
     for (int id = 0; id < GRX_NUM_TENSORS; ++id) { free(s->scratch[id]); free(s->scratch_u8[id]); free(s->scratch_i32[id]); }
-    free(s->t_obs); free(s->t_pri); free(s->t_rew); free(s->t_reset); free(s->t_timeout); free(s->t_eplen);
+    free(s->t_obs); free(s->t_pri); free(s->t_rew); free(s->t_reset); free(s->t_timeout); free(s->t_eplen); free(s->t_rbs);
     free(s->hf); free(s->torigins); free(s->env); free(s);
     return GRX_OK;
 }
@@ -1427,18 +1507,31 @@ int gro_tensor(grx_handle s, int id, grx_tensor_desc* d) {
     case GRX_T_TERRAIN_LEVELS: case GRX_T_TERRAIN_TYPES: desc_set(d, s->scratch_i32[id], GRX_I32, 1, N, 1, 1); break;
     case GRX_T_BASE_MASS_COM: desc_set(d, s->scratch[id], GRX_F32, 2, N, 4, 1); break;
     case GRX_T_TERM_CONTACT: desc_set(d, s->scratch_u8[id], GRX_U8, 1, N, 1, 1); break;
-    case GRX_T_EPISODE_STATS: desc_set(d, s->scratch[id], GRX_F32, 1, NT + 1, 1, 1); break;
+    case GRX_T_EPISODE_STATS: desc_set(d, s->scratch[id], GRX_F32, 1, NT + 2, 1, 1); break;
+    case GRX_T_EPISODE_STATS_HISTORY: desc_set(d, &s->hist[0][0], GRX_F32, 2, GRX_STATS_HISTORY, NT + 2, 1); break;
     case GRX_T_ANCHORS: desc_set(d, s->scratch[id], GRX_F32, 3, N, NFS, 3); break;
     case GRX_T_CONTACT_FORCES: desc_set(d, s->scratch[id], GRX_F32, 3, N, GRX_MAX_LINKS, 3); break;
+    case GRX_T_RIGID_BODY_STATES: desc_set(d, s->t_rbs, GRX_F32, 3, N, GRX_MAX_LINKS, 13); break;
     default: return fail(GRX_ERR_INVALID_ARGUMENT, "gro_tensor: unknown tensor id");
     }
     return GRX_OK;
 }
 
+static int set_state_rows(grx_handle s, const int32_t* env_ids, int n, const float* root, const float* q, const float* qd);
 int gro_set_state(grx_handle s, const float* root, const float* q, const float* qd, void* stream) {
     (void)stream;
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "gro_set_state: null handle");
-    for (int i = 0; i < s->N; ++i) {
+    return set_state_rows(s, NULL, s->N, root, q, qd);
+}
+int gro_set_state_indexed(grx_handle s, const int32_t* env_ids, int32_t n, const float* root, const float* q, const float* qd, void* stream) {
+    (void)stream;
+    if (!s || (n > 0 && !env_ids)) return fail(GRX_ERR_INVALID_ARGUMENT, "gro_set_state_indexed: null argument");
+    return n > 0 ? set_state_rows(s, env_ids, n, root, q, qd) : GRX_OK;
+}
+static int set_state_rows(grx_handle s, const int32_t* env_ids, int n, const float* root, const float* q, const float* qd) {
+    for (int k = 0; k < n; ++k) {
+        const int i = env_ids ? env_ids[k] : k;
+        if (i < 0 || i >= s->N) continue;
         env_t* e = &s->env[i];
         if (root) {
             const float* r = root + (size_t)i * 13;

@@ -1,12 +1,10 @@
-"""All-link kinematics on demand: ``rigid_body_states`` (N, num_links, 13) in the layout of Isaac Gym's
-``acquire_rigid_body_state_tensor`` (legged_robot.py:113,134: position 3, quaternion xyzw 4, linear velocity 3,
-angular velocity 3, world frame, link-frame origins).
+"""TEST HELPER: all-link kinematics in plain torch -- ``rigid_body_states`` (N, num_links, 13) in the layout of Isaac Gym's
+``acquire_rigid_body_state_tensor`` (legged_robot.py:113,134: position 3, quaternion xyzw 4, linear velocity 3, angular
+velocity 3, world frame, link-frame origins) from (root_states, dof_pos, dof_vel) and the robot model.
 
-The fused step kernel keeps the 11 moving bodies' frames in registers and publishes only what the env pipeline
-consumes (feet, torso orientation).  User-written reward terms that index arbitrary links (gr1t1.py:18-113 builds
-14 index sets) get the full tensor from here instead: an outward walk over the joint tree in plain torch on the
-library's state tensors, evaluated lazily, at most once per policy step.  Not on the hot path.
-"""
+An independent third derivation next to the oracle's forward kinematics and the step kernel's own walk: the product publishes
+GRX_T_RIGID_BODY_STATES from the fused kernel (round 3; rounds 1-2 shipped this module as envs/kinematics.py and evaluated it
+lazily in eager torch)."""
 import torch
 
 

@@ -19,14 +19,23 @@ def test_make_env_step_and_short_training(tmp_path):
         o, p, r, d, ex = env.step(torch.zeros(512, 10, device="cuda"))
     assert torch.isfinite(o).all() and torch.isfinite(p).all() and torch.isfinite(r).all()
     assert d.dtype == torch.bool and "time_outs" in ex and "terrain_level" in ex["episode"]
-    # all-link kinematics on demand (torch, envs/kinematics.py) agree with what the kernel's own walk published
+    # every URDF link frame, published by the step kernel (GRX_T_RIGID_BODY_STATES): a zero-copy view, consistent with what the
+    # kernel's own walk published for the feet and with the root state
     rbs = env.rigid_body_states
-    assert rbs.shape == (512, env.num_bodies, 13) and rbs is env.rigid_body_states        # cached per step
+    assert rbs.shape == (512, env.num_bodies, 13) and rbs is env.rigid_body_states and rbs.data_ptr() == env._sim.tensor("RIGID_BODY_STATES").data_ptr()
     live = ~d
     feet_pos = env._sim.tensor("FEET_POS")                                                   # (N, 2, 3) from the step kernel
     assert (rbs[live][:, env.feet_indices, 0:3] - feet_pos[live]).abs().max() < 1e-4   # fp32 ulps of world coordinates up to 170 m
-    assert (rbs[:, 0, 0:3] - env.root_states[:, 0:3]).abs().max() == 0
+    assert (rbs[live][:, 0, 0:3] - env.root_states[live][:, 0:3]).abs().max() == 0
     assert (rbs[:, env.feet_indices, 3:7].norm(dim=-1) - 1).abs().max() < 1e-5
+    # the body index sets of gr1t1.py:18-113 (case-sensitive substring match: GR1T1 names its IMU link "IMU_link", so imu_indices is empty there as in the reference)
+    for name, n in (("torso", 1), ("forehead", 1), ("imu", 0), ("waist", 3), ("head", 3), ("thigh", 6), ("shank", 2), ("feet", 2), ("sole", 0),
+                    ("upper_arm", 6), ("lower_arm", 2), ("hand", 6), ("arm_base", 0), ("arm_end", 0)):
+        idx = getattr(env, name + "_indices")
+        assert idx.dtype == torch.long and len(idx) == n, (name, idx)
+        assert all(getattr(env.cfg.asset, ("foot" if name == "feet" else name) + "_name") in env.body_names[i] for i in idx.tolist())
+    env.reset_idx(torch.tensor([3, 4, 100], device="cuda"))                                # callable outside step()
+    assert env.reset_buf[[3, 4, 100]].all() and (env.episode_length_buf[[3, 4, 100]] == 0).all()
     tcfg = GR1T1CfgPPO()
     tcfg.runner.num_steps_per_env = 16
     runner, _ = task_registry.make_alg_runner(env, name="GR1T1", args=args, train_cfg=tcfg, log_root=str(tmp_path))
@@ -101,3 +110,22 @@ def test_bench_line_has_the_contract_fields():
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and c["cpu_model"] and "note" in c
     assert c["reference_stage"] is None or c["reference_stage"]["value"] > 0
     assert j["value"] > 20e6      # an MI355X does not fall below this even inside a 20-step window
+
+
+def test_bench_runs_under_torchrun_with_a_real_rccl_group():
+    """bench.py's multi-rank path -- RCCL process-group init, the barriers around the timed window, the MAX all-reduce of the
+    elapsed time -- as the driver launches it (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`), on the
+    one GPU this box has: world size 1, every collective executes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29611",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "10", "--envs-per-gpu", "1024", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["steps"] == 50 and out["value"] > 1e6 and out["config"]["finite_outputs"]

@@ -1,9 +1,9 @@
 """BASELINE config 1 (plumbing, no GPU): GR1T1 flat terrain, 64 envs, PPO 10 iterations through
 task_registry.make_env / make_alg_runner, the VecEnv surface of the reference, checkpoint files.
 
-The product has no CPU simulation backend; here -- in tests only -- the env class is pointed at the
-CPU oracle through its backend hook, which exercises exactly the host-side code that runs on the
-GPU box (config -> grx_config, views, extras, runner, PPO)."""
+The product has no CPU simulation backend; here -- in tests only -- the name `HipSim` inside the env module is
+monkeypatched to the CPU oracle, which exercises exactly the host-side code that runs on the GPU box
+(config -> grx_config, views, extras, runner, PPO)."""
 import glob
 import os
 
@@ -16,11 +16,11 @@ from wiki_grx_gym_amd.utils import get_args, task_registry
 
 
 @pytest.fixture()
-def oracle_backend():
+def oracle_backend(monkeypatch):
     from oracle.binding import OracleSim
-    GRxEnv._backend_factory = staticmethod(lambda c, dev, keep: OracleSim(c, "f32", keep))
+    from wiki_grx_gym_amd.envs import grx_env
+    monkeypatch.setattr(grx_env, "HipSim", lambda c, dev, keep: OracleSim(c, "f32", keep))
     yield
-    GRxEnv._backend_factory = None
 
 
 def _args(extra=()):
@@ -67,7 +67,6 @@ def test_unregistered_task_and_cpu_device_fail_loudly():
     with pytest.raises(ValueError, match="not registered"):
         task_registry.make_env("anymal_c_flat", args=_args())
     from wiki_grx_gym_amd.sim import GrxError
-    GRxEnv._backend_factory = None
     with pytest.raises(GrxError):                     # sim_device=cpu: no CPU pipeline in the product
         task_registry.make_env("GR1T1", args=_args(), env_cfg=GR1T1Cfg())
 

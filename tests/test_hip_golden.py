@@ -89,3 +89,74 @@ def test_oracle_pin_reward_terms_on_this_box(precision, tol):
 @pytest.mark.parametrize("precision,tol", [("f64", 1e-6), ("f32", 1e-4)])
 def test_oracle_pin_torques_on_this_box(precision, tol):
     og.test_clip_actions_and_torques(precision, tol)
+
+
+def test_quat_fixture_on_the_hip_kernel():
+    """G-1 (tests/golden/quat.npz) through the step kernel's post-physics half: quat_rotate_inverse on 256 random orientations."""
+    cfg = make_cfg(noise=False, dr=False)
+    sim, _ = make_hip(cfg, 256)
+    og.check_quat_rotate_inverse(sim, 1e-4)
+
+
+def test_quat_apply_yaw_fixture_selects_the_height_scan_cells():
+    """G-1's quat_apply_yaw column on the HIP height scan (legged_robot.py:1235-1274 -> math.py:38-42): env i carries the fixture's
+    quaternion q_i and the scan's point i is the fixture's v_i (x, y), so measured_heights[i, i] reads the raster cell under
+    root_xy + quat_apply_yaw(q_i, v_i).  The raster encodes its own indices (h[r, c] = r * 181 + c, increasing both ways: the min of
+    the three corners the reference takes is h[r, c] itself), so the kernel's cell choice is compared EXACTLY with the one the
+    reference's arithmetic makes from the fixture's apply_yaw output."""
+    import types
+    from wiki_grx_gym_amd.sim import HipSim
+    d = np.load(og.os.path.join(og.G, "quat.npz"))
+    N, nh, A = 128, 121, 181
+    cfg = make_cfg(noise=False, dr=False, terrain="heightfield", curriculum=False)
+    rows = cols = 180
+    hs = (np.arange(rows)[:, None] * A + np.arange(cols)[None, :]).astype(np.int16)
+    ter = types.SimpleNamespace(heightsamples=hs, env_origins=np.zeros((cfg.terrain.num_rows, cfg.terrain.num_cols, 3), np.float32))
+    c, keep, _ = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
+    assert c.num_height_points == nh
+    scale = 3.0 / np.abs(d["v"][:nh, :2]).max()            # keep every point within 3 m of the base
+    for k in range(nh):
+        c.height_points[k][0], c.height_points[k][1] = float(d["v"][k, 0] * scale), float(d["v"][k, 1] * scale)
+    c.border_size = 0.0
+    sim = HipSim(c, "cuda:0", keep)
+    arr, _ = og.quat_states(N)
+    for i in range(N):
+        arr[i].root[0], arr[i].root[1], arr[i].root[2] = 9.0, 9.0, 100.0
+    sim.debug_post_physics(arr, apply_reset=False, common_step_counter=1)
+    torch.cuda.synchronize()
+    mh = sim.tensor("MEASURED_HEIGHTS").cpu().numpy()
+    code = np.rint(mh / np.float32(c.vertical_scale)).astype(np.int64)
+    checked = 0
+    for i in range(nh):
+        # the reference's float32 arithmetic on ITS OWN quat_apply_yaw output (legged_robot.py:1262-1268)
+        ay = (d["apply_yaw"][i, :2] * np.float32(scale)).astype(np.float32)    # quat_apply_yaw is linear in the vector
+        p = (ay + np.float32(9.0)) + np.float32(0.0)
+        f = p / np.float32(c.horizontal_scale)
+        if np.abs(f - np.rint(f)).min() < 2e-3:          # within rounding of a cell edge: either neighbour is legitimate
+            continue
+        want = int(f[0]) * A + int(f[1])
+        assert code[i, i] == want, (i, code[i, i], want)
+        checked += 1
+    assert checked >= 100
+
+
+def test_reference_torques_on_the_hip_kernel():
+    """G-2 (tests/golden/torques.npz: legged_robot_fftai.py:171-177 clip_actions, legged_robot.py:679-715 _compute_torques with the
+    reference's own motor-strength draws) on the HIP step kernel: decimation = 1 makes GRX_T_TORQUES the torque of the FIRST
+    (only) sub-step, computed from the injected (dof_pos, dof_vel); the fixture's strength factors go into the writable
+    MOTOR_STRENGTH view."""
+    d = np.load(og.os.path.join(og.G, "torques.npz"))
+    N = d["actions"].shape[0]
+    cfg = make_cfg(noise=False, dr=False)
+    cfg.control.decimation = 1
+    sim, _ = make_hip(cfg, N)
+    sim.reset_all()
+    root = torch.zeros(N, 13); root[:, 2] = 5.0; root[:, 6] = 1.0          # in the air: no contact in the way
+    sim.set_state(root.cuda(), torch.tensor(d["dof_pos"]).cuda().contiguous(), torch.tensor(d["dof_vel"]).cuda().contiguous())
+    sim.tensor("MOTOR_STRENGTH").copy_(torch.tensor(d["strength"]).cuda())
+    sim.step(torch.tensor(d["actions"]).cuda().contiguous(), 0.0, 1)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(sim.tensor("ACTIONS").cpu().numpy(), d["clipped"])
+    np.testing.assert_allclose(sim.tensor("TORQUES").cpu().numpy(), d["torques"], rtol=1e-4, atol=1e-3)
+    lim = d["torque_limits"]
+    assert (np.abs(d["torques"]) >= lim - 1e-6).any() and (np.abs(d["torques"]) < lim - 1).any()   # saturated and unsaturated rows

@@ -253,9 +253,18 @@ def test_curriculum_and_episode_stats():
     worst = physics_lockstep(hip, ora, cfg, steps=45, scale=0.2)
     assert worst["TERRAIN_LEVELS"][1] <= 2e-3 and worst["TIME_OUT"][1] <= 2e-3
     assert (ora.tensor("TERRAIN_LEVELS") != lv0).any()
-    sh, so = hip.episode_stats(), ora.episode_stats()
-    assert so[-1] > 0 and abs(sh[-1] - so[-1]) <= 1
-    np.testing.assert_allclose(sh[:-1], so[:-1], rtol=5e-3, atol=5e-4)
+    sh, so = hip.episode_stats(), ora.episode_stats()      # (flushes: a step's statistics are otherwise reduced by the next launch)
+    NT = len(sh) - 2
+    assert so[NT] > 0 and abs(sh[NT] - so[NT]) <= 1
+    np.testing.assert_allclose(sh[:NT], so[:NT], rtol=5e-3, atol=5e-4)
+    assert abs(sh[NT + 1] - so[NT + 1]) <= 2e-2 and abs(so[NT + 1] - ora.tensor("TERRAIN_LEVELS").float().mean().item()) < 1e-5   # legged_robot.py:427-428
+    # the history ring: the row of the last step equals the flushed statistics; rows of earlier steps were filed by their successors
+    hist = hip.tensor("EPISODE_STATS_HISTORY").cpu().numpy()
+    np.testing.assert_array_equal(hist[hip.last_stats_slot], sh)
+    oh = ora.tensor("EPISODE_STATS_HISTORY").numpy()
+    assert hip.last_stats_slot == ora.last_stats_slot == 46     # one reset + 45 steps
+    np.testing.assert_allclose(hist[1:47], oh[1:47], rtol=5e-3, atol=2e-2)
+    assert len({tuple(r) for r in oh[1:47]}) >= 3               # the dict did change over the rollout (time-outs at steps 20 and 40): rows are per-step snapshots
 
 
 def test_free_running_rollout_stays_close():
@@ -281,7 +290,9 @@ def test_free_running_rollout_stays_close():
 # ------------------------------------------------------------------ full-size properties
 @pytest.mark.parametrize("task,terrain,N", [("GR1T1", "heightfield", 4096), ("GR1T1", "heightfield", 32768),
                                              ("GR1T1", "plane", 4096),           # BASELINE.json config 2 (flat, 4096)
-                                             ("GR1T2", "heightfield", 32768)])   # config 4 (GR1T2 rough, 32768 = 8 x 4096)
+                                             ("GR1T1", "heightfield", 8192),     # config 3 (rough curriculum + height scan, 8192 on one GPU)
+                                             ("GR1T2", "heightfield", 32768),    # config 4 (GR1T2 rough, 32768 = 8 x 4096)
+                                             ("GR1T1Full", "heightfield", 4096)])   # config 5 (32-DOF full body, 4096 per GPU, DR on)
 def test_full_size_properties(task, terrain, N, monkeypatch):
     """BASELINE.json sizes: finiteness, determinism (bit-identical reruns), shard invariance
     (env i does not depend on how the batch is split across ranks: the multi-GPU contract).
@@ -290,6 +301,7 @@ def test_full_size_properties(task, terrain, N, monkeypatch):
     if N == 32768:
         monkeypatch.setenv("GRX_WAVES_PER_BLOCK", "1")
     cfg = make_cfg(task=task, terrain=terrain, noise=True, dr=True, push=True)
+    act_scale = 0.3 if task == "GR1T1Full" else 1.0      # (the full body's arm / waist ranges at full scale throw it around)
     from tests.helpers import make_terrain
     from wiki_grx_gym_amd.envs import build_config
     from wiki_grx_gym_amd.sim import HipSim
@@ -302,7 +314,7 @@ def test_full_size_properties(task, terrain, N, monkeypatch):
         gen = torch.Generator().manual_seed(0)
         outs = []
         for i in range(steps):
-            a = random_actions(cfg, total, gen, 1.0)[offset:offset + n].contiguous().cuda()
+            a = random_actions(cfg, total, gen, act_scale)[offset:offset + n].contiguous().cuda()
             s.step(a, 5.0, i + 1)
         outs = {k: s.tensor(k).clone() for k in ("OBS", "PRI_OBS", "REW", "RESET", "ROOT_STATES", "EPISODE_LENGTH")}
         s.close()
@@ -323,7 +335,7 @@ def test_full_size_properties(task, terrain, N, monkeypatch):
             part = run(q, r * q, N)
             for k in full:
                 assert torch.equal(full[k][r * q:(r + 1) * q], part[k]), f"{k} depends on the sharding (rank {r} of 8)"
-    assert full["RESET"].sum() > 0 and (full["PRI_OBS"][:, 47:].abs().sum() > 0)
+    assert (full["RESET"].sum() > 0 or task == "GR1T1Full") and (full["PRI_OBS"][:, -121:].abs().sum() > 0)
 
 
 @pytest.mark.parametrize("waves", [1, 2, 4])
@@ -412,3 +424,155 @@ def test_self_collision_matches_the_oracle(task, waves, monkeypatch):
     assert seen > N // 2, seen                                   # most envs did have their legs in contact
     assert_phys(worst, scale=3.0)
     hip.close()
+
+
+def test_reset_idx_and_indexed_setters_match_the_oracle():
+    """LeggedRobot.reset_idx(env_ids) and the _indexed state setters (legged_robot.py:377-440, 737-740, 782-784) outside a step:
+    the listed envs are reset exactly like the oracle's (curriculum move included), the others are untouched, their episode sums
+    go to the episode statistics."""
+    cfg = make_cfg(terrain="heightfield", dr=True)
+    hip, ora = make_sims(cfg, 300, seed=4)
+    hip.reset_all(); ora.reset_all()
+    physics_lockstep(hip, ora, cfg, steps=6, scale=0.3)
+    sync_state(hip, ora)
+    names = ("DOF_POS", "DOF_VEL", "ROOT_STATES", "COMMANDS", "LAST_ACTIONS", "LAST_DOF_VEL", "FEET_AIR_TIME", "FEET_LAND_TIME",
+             "EPISODE_LENGTH", "TERRAIN_LEVELS", "ENV_ORIGINS", "EPISODE_SUMS")
+    before = {n: hip.tensor(n).clone() for n in names}
+    ids = torch.tensor([0, 7, 8, 31, 32, 33, 150, 299], dtype=torch.int64)
+    hip.reset_idx(ids.cuda()); ora.reset_idx(ids)
+    torch.cuda.synchronize()
+    keep = torch.ones(300, dtype=torch.bool); keep[ids] = False
+    for n in names:
+        a, b = hip.tensor(n).cpu(), ora.tensor(n)
+        if n == "EPISODE_SUMS":
+            assert torch.equal(a[:, keep], before[n].cpu()[:, keep]) and float(a[:, ids].abs().max()) == 0, n
+        else:
+            assert torch.equal(a[keep], before[n].cpu()[keep]), n            # untouched
+            assert float((a[ids].double() - b[ids].double()).abs().max()) <= 1e-5, n
+    assert hip.tensor("RESET").cpu()[ids].all()
+    sh, so = hip.episode_stats(), ora.episode_stats()
+    NT = len(sh) - 2
+    assert sh[NT] == so[NT] == len(ids)
+    np.testing.assert_allclose(sh, so, rtol=1e-4, atol=1e-5)
+    hip.reset_idx(torch.zeros(0, dtype=torch.int64).cuda())                  # empty list: a no-op (legged_robot.py:387-388)
+    # indexed setters: rows env_ids of full-size tensors
+    root = torch.zeros(300, 13); root[:, 2] = 1.5; root[:, 6] = 1.0
+    q, qd = torch.full((300, 10), 0.1), torch.full((300, 10), -0.2)
+    before = {n: hip.tensor(n).clone() for n in ("DOF_POS", "DOF_VEL", "ROOT_STATES")}
+    hip.set_state_indexed(ids.cuda(), root.cuda(), q.cuda(), qd.cuda())
+    ora.set_state_indexed(ids, root, q, qd)
+    torch.cuda.synchronize()
+    for n, want in (("DOF_POS", q), ("DOF_VEL", qd), ("ROOT_STATES", root)):
+        a = hip.tensor(n).cpu()
+        assert torch.equal(a[keep], before[n].cpu()[keep]) and torch.equal(a[ids], want[ids]) and torch.equal(a, ora.tensor(n)), n
+    worst = physics_lockstep(hip, ora, cfg, steps=2, scale=0.3, start=20)     # and the env keeps stepping from there
+    assert_phys(worst, scale=3.0)
+
+
+@pytest.mark.parametrize("delay", [0.0, 3.7, 9.2, 12.0])
+def test_action_latency_real_valued(delay):
+    """Q1: sub-step `deci` still uses last_actions while deci < delay (legged_robot_fftai.py:53-61) with the REAL-valued draw
+    max(0, N(5, 2)) -- 3.7 switches after sub-step 3, 9.2 only for the last one, 12.0 never (the whole step runs on last_actions)."""
+    cfg = make_cfg(terrain="heightfield", dr=True)
+    hip, ora = make_sims(cfg, 256, seed=3)
+    hip.reset_all(); ora.reset_all()
+    worst = physics_lockstep(hip, ora, cfg, steps=6, scale=0.6, delay=delay)
+    assert_phys(worst, scale=3.0)
+    assert worst["TORQUES"][1] <= 3e-2 and worst["ACTIONS"][0] == 0
+    # and the latency really is in play: the same step with delay 0 gives different torques
+    sync_state(hip, ora)
+    gen = torch.Generator().manual_seed(11)
+    a = random_actions(cfg, 256, gen, 0.6)
+    before = {n: hip.tensor(n).clone() for n in ("DOF_POS", "DOF_VEL", "ROOT_STATES", "LAST_ACTIONS", "LAST_DOF_VEL", "ANCHORS")}
+    hip.step(a.cuda(), delay, 50)
+    q_delay = hip.tensor("DOF_POS").clone()
+    for n, v in before.items():
+        hip.tensor(n).copy_(v)
+    hip.step(a.cuda(), 0.0, 50)
+    if delay > 0:
+        assert (hip.tensor("DOF_POS") - q_delay).abs().max() > 1e-4
+    else:
+        assert torch.equal(hip.tensor("DOF_POS"), q_delay)
+
+
+@pytest.mark.parametrize("waves", [1, 2, 4])
+def test_self_collision_on_a_terminating_link_resets_the_env(waves, monkeypatch):
+    """GR1T2's thigh can press on the hand (self-collision pairs 4-25, 10-33; hand links are in
+    terminate_after_contacts_on).  check_termination reads the NET contact force per link (legged_robot.py:336-353), so a
+    thigh-hand overlap above termination_force resets the env although nothing touches the ground -- in every wave layout,
+    like the oracle, and consistently with the published CONTACT_FORCES."""
+    monkeypatch.setenv("GRX_WAVES_PER_BLOCK", str(waves))
+    cfg = make_cfg(task="GR1T2")
+    N = 64
+    hip, ora = make_sims(cfg, N)
+    hip.reset_all(); ora.reset_all()
+    q = torch.zeros(N, 10)
+    for i in range(N):
+        k, s = i % 8, i // 8
+        side = 5 * (s % 2)                                  # left leg against the left hand / right leg against the right hand
+        sign = 1.0 if side == 0 else -1.0
+        q[i, side + 0] = sign * (0.79 + 0.02 * k)           # hip roll at / beyond its limit, outwards
+        q[i, side + 1] = sign * (0.70 + 0.02 * (s // 2 % 4))
+        q[i, side + 2] = -1.75 - 0.03 * (s // 8)            # thigh swung up in front
+    root = torch.zeros(N, 13); root[:, 2] = 2.0; root[:, 6] = 1.0
+    for s_ in (hip, ora):
+        s_.set_state(root.to(s_.device), q.to(s_.device).contiguous(), torch.zeros(N, 10, device=s_.device))
+    a = torch.zeros(N, 10)
+    ora.step(a, 20.0, 1); hip.step(a.cuda(), 20.0, 1)
+    torch.cuda.synchronize()
+    hands = [25, 33]
+    fo = ora.tensor("CONTACT_FORCES")[:, hands].norm(dim=-1)
+    fh = hip.tensor("CONTACT_FORCES").cpu()[:, hands].norm(dim=-1)
+    assert (fo > 1.0).any(dim=1).sum() >= 4                                       # the scenario does load the hands
+    assert float(ora.tensor("ROOT_STATES")[~ora.tensor("RESET").bool(), 2].min()) > 1.5   # and nothing is near the ground
+    clear = ((fo - 1.0).abs() > 0.2).all(dim=1)                                   # away from the 1 N threshold
+    assert torch.equal(hip.tensor("TERM_CONTACT").cpu()[clear], ora.tensor("TERM_CONTACT")[clear])
+    assert torch.equal(hip.tensor("RESET").cpu()[clear], ora.tensor("RESET")[clear])
+    assert ora.tensor("RESET")[clear].sum() >= 4
+    assert ((fh - fo).abs() <= 1.0 + 2e-2 * fo).all()
+    # RESET agrees with the published per-link forces (the inconsistency the advisor found)
+    implied = (fh > 1.0).any(dim=1)
+    assert torch.equal(implied[clear], hip.tensor("TERM_CONTACT").cpu()[clear].bool())
+
+
+@pytest.mark.parametrize("waves", [1, 4])
+@pytest.mark.parametrize("task", ["GR1T1", "GR1T2"])
+def test_rigid_body_states_match_the_oracle(task, waves, monkeypatch):
+    """GRX_T_RIGID_BODY_STATES (gym.acquire_rigid_body_state_tensor, legged_robot.py:113,134): all link frames after the last
+    sub-step, written by the step kernel (wave 0 in the one-wave layout, the foot wave in the four-wave pipeline), against the
+    oracle's forward kinematics at 1e-4 -- resetting envs included: the tensor shows the state BEFORE reset_idx."""
+    from tests.kinematics_ref import BodyKinematics
+    from tests.test_kinematics import rbs_err
+    from wiki_grx_gym_amd.model import RobotModel
+    monkeypatch.setenv("GRX_WAVES_PER_BLOCK", str(waves))
+    cfg = make_cfg(task=task, terrain="heightfield", dr=True)
+    cfg.env.episode_length_s = 0.2          # time-outs: resetting envs in the comparison
+    hip, ora = make_sims(cfg, 200, seed=2)
+    hip.reset_all(); ora.reset_all()
+    nl = int(ora._keep[-1].model.num_links)
+    kin = BodyKinematics(RobotModel(task.lower() + "_lower_limb"), "cpu")
+    seen = {"reset": 0}
+
+    def check(s, h, o):
+        a, b = h.tensor("RIGID_BODY_STATES").cpu(), o.tensor("RIGID_BODY_STATES")
+        assert a.shape == (200, 40, 13) and float(a[:, nl:].abs().max()) == 0
+        reset = o.tensor("RESET").bool()
+        # the kernel's link frames ARE the forward kinematics of the state it publishes (envs that did not reset): fp32 rounding only
+        own = kin.rigid_body_states(h.tensor("ROOT_STATES").cpu(), h.tensor("DOF_POS").cpu(), h.tensor("DOF_VEL").cpu())
+        ep, eq, ev = rbs_err(a[~reset][:, :nl], own[~reset])
+        assert ep <= 2e-5 and eq <= 2e-5 and ev <= 1e-4, (ep, eq, ev)
+        # and they are the oracle's, resetting envs included, to the tolerance of one policy step of contact physics
+        # (test_hip_parity.PHYS: positions 1e-4, velocities 5e-3)
+        def env_err(x, y):   # per env: worst position / orientation / velocity error over the links
+            x, y = x.double(), y.double()
+            dq = torch.minimum((x[..., 3:7] - y[..., 3:7]).abs().amax(-1), (x[..., 3:7] + y[..., 3:7]).abs().amax(-1)).amax(-1)
+            rel = lambda u, v: ((u - v).abs() / (1 + v.abs())).amax(-1).amax(-1)
+            return rel(x[..., 0:3], y[..., 0:3]), dq, rel(x[..., 7:13], y[..., 7:13])
+        ep, eq, ev = env_err(a[:, :nl], b[:, :nl])
+        good = (ep <= 2e-4) & (eq <= 5e-4) & (ev <= 3e-2)
+        assert good.float().mean() >= 0.97 and float(ep.max()) < 5e-3 and float(eq.max()) < 2e-2, (good.float().mean(), ep.max(), eq.max(), ev.max())
+        if reset.any():   # pre-reset frames (the reset state sits metres away from them)
+            assert ((ep[reset] <= 2e-4) & (eq[reset] <= 5e-4)).float().mean() >= 0.9 and float(ep[reset].max()) < 5e-3
+        seen["reset"] += int(reset.sum())
+    physics_lockstep(hip, ora, cfg, steps=14, scale=0.4, check=check)
+    assert seen["reset"] > 0

@@ -1,11 +1,11 @@
-"""All-link kinematics (envs/kinematics.py: rigid_body_states on demand) against the oracle's forward kinematics
+"""All-link kinematics (tests/kinematics_ref.py, the torch restatement the published tensor is checked against) against the oracle's forward kinematics
 and against a finite difference of itself."""
 import numpy as np
 import torch
 
 from tests.helpers import make_cfg
 from wiki_grx_gym_amd.envs import build_config
-from wiki_grx_gym_amd.envs.kinematics import BodyKinematics, _matrix_to_quat, _quat_to_matrix
+from tests.kinematics_ref import BodyKinematics, _matrix_to_quat, _quat_to_matrix
 from wiki_grx_gym_amd.model import RobotModel
 
 
@@ -67,3 +67,41 @@ def test_link_velocities_are_the_time_derivative_of_link_poses():
     np.testing.assert_allclose(wfd.numpy(), s0[..., 10:13].numpy(), atol=2e-5)
     # quaternion <-> matrix round trip
     np.testing.assert_allclose(_quat_to_matrix(_matrix_to_quat(R0)).numpy(), R0.numpy(), atol=1e-12)
+
+
+def rbs_err(a, b):
+    """(N, L, 13) rigid-body states: worst error of positions (relative to 1 + |x|), orientations (up to the quaternion's sign)
+    and velocities (relative to 1 + |v|)"""
+    a, b = a.double(), b.double()
+    rel = lambda x, y: float(((x - y).abs() / (1 + y.abs())).max()) if x.numel() else 0.0
+    dq = torch.minimum((a[..., 3:7] - b[..., 3:7]).abs().amax(-1), (a[..., 3:7] + b[..., 3:7]).abs().amax(-1))
+    return rel(a[..., 0:3], b[..., 0:3]), float(dq.max()) if dq.numel() else 0.0, rel(a[..., 7:13], b[..., 7:13])
+
+
+def rbs_close(a, b, atol=1e-4, rtol=1e-4):
+    ep, eq, ev = rbs_err(a, b)
+    return ep <= atol and eq <= atol and ev <= 10 * atol
+
+
+def test_oracle_rigid_body_states_match_the_torch_restatement():
+    """GRX_T_RIGID_BODY_STATES of the oracle (link frames after the last sub-step, before reset_idx) against
+    tests/kinematics_ref.py evaluated on the step's final state, both lower-limb robots."""
+    from oracle.binding import OracleSim
+    from tests.helpers import random_actions
+    for task, key in (("GR1T1", "gr1t1_lower_limb"), ("GR1T2", "gr1t2_lower_limb")):
+        cfg = make_cfg(task=task)
+        N = 24
+        c, keep, _ = build_config.build(cfg, cfg.sim.dt, N)
+        ora = OracleSim(c, "f32", keep)
+        ora.reset_all()
+        g = torch.Generator().manual_seed(1)
+        for s in range(12):
+            ora.step(random_actions(cfg, N, g, 0.5), 5.0, s + 1)
+        rm = RobotModel(key)
+        kin = BodyKinematics(rm, "cpu")
+        alive = ~ora.tensor("RESET").bool()
+        assert alive.sum() >= N // 2
+        want = kin.rigid_body_states(ora.tensor("ROOT_STATES"), ora.tensor("DOF_POS"), ora.tensor("DOF_VEL"))
+        got = ora.tensor("RIGID_BODY_STATES")[:, :rm.num_links]
+        assert got.shape == (N, rm.num_links, 13) and rbs_close(got[alive], want[alive], 2e-5, 2e-5)
+        assert float(ora.tensor("RIGID_BODY_STATES")[:, rm.num_links:].abs().max()) == 0

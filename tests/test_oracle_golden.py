@@ -244,3 +244,71 @@ def test_noise_vector_matches_reference():
                           np.full(10, n.dof_pos * lv * s.dof_pos), np.full(10, n.dof_vel * lv * s.dof_vel),
                           np.full(10, n.action * lv * s.action)])
     np.testing.assert_allclose(vec, d["noise_vec"], rtol=1e-6)
+
+
+def quat_states(N):
+    """PipelineState records carrying the G-1 fixture (tests/golden/quat.npz: isaacgym torch_utils.py:48-81, legged_gym math.py:38-55
+    evaluated by the reference): root quaternion q_i, linear AND angular velocity v_i; everything else at rest."""
+    from oracle.binding import PipelineState
+    d = np.load(os.path.join(G, "quat.npz"))
+    arr = (PipelineState * N)()
+    for i in range(N):
+        ps = arr[i]
+        ps.root[2] = 1.0
+        for k in range(4):
+            ps.root[3 + k] = float(d["q"][i][k])
+        for k in range(3):
+            ps.root[7 + k] = float(d["v"][i][k]); ps.root[10 + k] = float(d["v"][i][k])
+            for f in range(2):
+                ps.feet_pos[f][k] = 0.0
+        for k in range(9):
+            ps.torso_R[k] = float(k % 4 == 0)
+    return arr, d
+
+
+def check_quat_rotate_inverse(sim, tol):
+    """G-1 on the env step itself: base_lin_vel / base_ang_vel = quat_rotate_inverse(base_quat, v) (legged_robot.py:284-286) and
+    projected_gravity = quat_rotate_inverse(base_quat, (0, 0, -1)) = -(third row of R(q)), 256 random orientations."""
+    arr, d = quat_states(256)
+    inject(sim, arr, common_step_counter=1)
+    want = d["rotate_inverse"].astype(np.float64)
+    for name in ("BASE_LIN_VEL", "BASE_ANG_VEL"):
+        got = T_(sim, name).double().numpy()
+        assert (np.abs(got - want) <= tol + tol * np.abs(want)).all(), name
+    # quat_rotate(q, v) is the inverse map: R(q) R(q)^T v = v ties `rotate` and `rotate_inverse` of the fixture together
+    for i in range(0, 256, 17):
+        R = quat_to_R(d["q"][i].astype(np.float64))
+        np.testing.assert_allclose(R @ d["rotate_inverse"][i], d["v"][i], atol=2e-5)
+        np.testing.assert_allclose(R @ d["v"][i], d["rotate"][i], atol=2e-5)
+        np.testing.assert_allclose(R @ d["v"][i], d["apply"][i], atol=2e-5)
+    g = T_(sim, "PROJECTED_GRAVITY").double().numpy()
+    wantg = np.stack([-quat_to_R(d["q"][i].astype(np.float64))[2] for i in range(256)])
+    assert (np.abs(g - wantg) <= 10 * tol).all()
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 2e-6), ("f32", 1e-4)])
+def test_quat_fixture_on_the_oracle(precision, tol):
+    sim, _, _ = make_oracle(256, precision, noise=False)
+    check_quat_rotate_inverse(sim, tol)
+
+
+def test_quat_fixture_reset_yaw_and_wrap():
+    """The remaining G-1 columns the path uses: the reset orientation quat_from_euler_xyz(0, 0, yaw) (legged_robot.py:765-767) is the
+    oracle's / kernels' closed form (0, 0, sin(yaw/2), cos(yaw/2)); quat_apply_yaw keeps z and rotates xy by the quaternion's yaw.
+    wrap_to_pi (heading commands, math.py:45-48) is NOT on the path: heading_command is False for the GRx tasks and build_config
+    rejects True."""
+    d = np.load(os.path.join(G, "quat.npz"))
+    e = d["euler"].astype(np.float64)
+    # general Euler -> quaternion (torch_utils.py:176-190) against the fixture, then the yaw-only special case used at reset
+    cr, sr, cp, sp, cy, sy = np.cos(e[:, 0] / 2), np.sin(e[:, 0] / 2), np.cos(e[:, 1] / 2), np.sin(e[:, 1] / 2), np.cos(e[:, 2] / 2), np.sin(e[:, 2] / 2)
+    q = np.stack([cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp, cy * cr * cp + sy * sr * sp], 1)
+    np.testing.assert_allclose(q, d["from_euler"], atol=2e-6)
+    yaw_only = np.stack([0 * sy, 0 * sy, sy, cy], 1)
+    np.testing.assert_allclose(yaw_only[np.abs(sr) + np.abs(sp) < 1e-9], q[np.abs(sr) + np.abs(sp) < 1e-9], atol=1e-12)
+    # quat_apply_yaw: z untouched, xy rotated by atan2-free yaw of the normalised (0, 0, qz, qw)
+    qz, qw = d["q"][:, 2].astype(np.float64), d["q"][:, 3].astype(np.float64)
+    n = np.sqrt(qz * qz + qw * qw)
+    c, s_ = (qw * qw - qz * qz) / (n * n), 2 * qz * qw / (n * n)
+    v = d["v"].astype(np.float64)
+    np.testing.assert_allclose(np.stack([c * v[:, 0] - s_ * v[:, 1], s_ * v[:, 0] + c * v[:, 1], v[:, 2]], 1), d["apply_yaw"], atol=2e-5)
+    np.testing.assert_allclose(np.mod(d["ang"].astype(np.float64) + np.pi, 2 * np.pi) - np.pi, d["wrap_to_pi"], atol=2e-5)

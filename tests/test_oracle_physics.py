@@ -337,3 +337,57 @@ def test_frictionless_slope_slides_downhill():
     th = np.arctan(slope)
     want = -G9 * np.sin(th) * np.cos(th) * 0.16
     assert 1.15 * want < vx < 0.6 * want, (vx, want)     # downhill (-x), the right size
+
+
+def test_single_pendulum_period_of_one_leg_link():
+    """SURVEY 8c physics pin: one leg link swinging about its joint with everything else locked.  The free-floating model has no
+    fixed joint, so the lock is inertial -- base and the other chain bodies 1e8 times heavier -- and the restoring torque is the
+    joint's own PD spring (legged_robot.py:679-715 with kd = 0) in zero gravity: the foot about the ankle axis is then the
+    textbook torsional pendulum, omega^2 = kp / I_axis with I_axis = I_yy(com) + m (c_x^2 + c_z^2).  Semi-implicit Euler at dt
+    shifts the frequency to omega_d = (2 / dt) asin(omega dt / 2) exactly; the measured period (zero crossings over ~8
+    periods, fp64) must equal 2 pi / omega_d to 1e-6 and the continuous-time period to first order in (omega dt)^2 / 24."""
+    from oracle.binding import OracleSim
+    cfg = make_cfg()
+    cfg.control.decimation = 1
+    cfg.sim.gravity = [0.0, 0.0, 0.0]
+    c, keep, _ = build_config.build(cfg, cfg.sim.dt, 1)
+    m = c.model
+    ankle = 5                                              # body index of left_foot (leaf of the left chain); its dof is 4
+    for b in range(m.num_bodies):
+        if b != ankle:
+            m.mass[b] *= 1e8
+            for k in range(6):
+                m.inertia[b][k] *= 1e8
+    m.base_link_mass *= 1e8; m.base_rest_mass *= 1e8
+    for k in range(6):
+        m.base_link_inertia[k] *= 1e8; m.base_rest_inertia[k] *= 1e8
+    kp = 4.0
+    for j in range(10):
+        c.kd[j] = 0.0
+        c.default_dof_pos[j] = 0.0
+        c.kp[j] = kp if j == ankle - 1 else 0.0
+    I = m.inertia[ankle][3] + m.mass[ankle] * (m.com[ankle][0] ** 2 + m.com[ankle][2] ** 2)
+    w = np.sqrt(kp / I)
+    dt = c.sim_dt
+    assert 5.0 < w < 60.0 and w * dt < 0.2
+    sim = OracleSim(c, "f64", keep)
+    sim.reset_all()
+    root = torch.zeros(1, 13); root[0, 2] = 5.0; root[0, 6] = 1.0
+    q = torch.zeros(1, 10); q[0, ankle - 1] = 0.1
+    sim.set_state(root, q, torch.zeros(1, 10))
+    a = torch.zeros(1, 10)
+    n = int(8.5 * 2 * np.pi / w / dt)
+    traj = np.empty(n)
+    for i in range(n):
+        sim.step(a, 0.0, i + 1)
+        traj[i] = float(sim.tensor("DOF_POS")[0, ankle - 1])
+    assert abs(traj).max() <= 0.1 * (1 + 1e-3) and abs(traj).max() > 0.0999          # undamped, bounded
+    others = sim.tensor("DOF_POS")[0].numpy().copy(); others[ankle - 1] = 0
+    assert np.abs(others).max() < 1e-6 and abs(float(sim.tensor("ROOT_STATES")[0, 2]) - 5.0) < 1e-6   # the rest IS locked
+    up = [i + traj[i] / (traj[i] - traj[i + 1]) for i in range(n - 1) if traj[i] < 0 <= traj[i + 1]]   # upward zero crossings, interpolated
+    assert len(up) >= 7
+    T = (up[-1] - up[0]) / (len(up) - 1) * dt
+    wd = 2.0 / dt * np.arcsin(w * dt / 2.0)
+    # (the tensors are published in fp32: a crossing time is good to ~1e-6 s)
+    assert abs(T - 2 * np.pi / wd) < 2e-6 * T, (T, 2 * np.pi / wd)
+    assert abs(T - 2 * np.pi / w) < 1.5 * (w * dt) ** 2 / 24 * T + 2e-6 * T

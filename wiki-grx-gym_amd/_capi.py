@@ -5,13 +5,15 @@ Field order and sizes must match the header exactly; ``grx_create`` rejects a mi
 """
 import ctypes as C
 
-GRX_ABI_VERSION = 2
+GRX_ABI_VERSION = 3
 MAX_BODIES = 36
 MAX_DOFS = 32
 MAX_SPHERES = 48
 MAX_PAIRS = 192
 NUM_FEET = 2
 MAX_HEIGHT_POINTS = 128
+MAX_LINKS = 40
+STATS_HISTORY = 128
 
 REWARD_TERMS = (
     "action_diff", "action_diff_diff", "action_diff_knee", "cmd_diff_ang_vel_pitch",
@@ -37,7 +39,7 @@ TENSOR_IDS = (
     "FEET_AIR_TIME", "FEET_LAND_TIME", "FEET_CONTACT", "AVG_FEET_FORCE", "AVG_FEET_SPEED",
     "MEASURED_HEIGHTS", "BASE_HEIGHTS_OFFSET", "EPISODE_SUMS", "REWARD_TERMS", "TERRAIN_LEVELS",
     "TERRAIN_TYPES", "ENV_ORIGINS", "MOTOR_STRENGTH", "FRICTION", "BASE_MASS_COM", "TERM_CONTACT",
-    "EPISODE_STATS", "ANCHORS", "CONTACT_FORCES",
+    "EPISODE_STATS", "ANCHORS", "CONTACT_FORCES", "EPISODE_STATS_HISTORY", "RIGID_BODY_STATES",
 )
 T = {name: i for i, name in enumerate(TENSOR_IDS)}
 DTYPE_F32, DTYPE_U8, DTYPE_I32, DTYPE_I64 = 0, 1, 2, 3
@@ -74,6 +76,10 @@ class Model(C.Structure):
         ("torso_rot", f32 * 9),
         ("forehead_body", i32),
         ("forehead_rot", f32 * 9),
+        ("num_links", i32),
+        ("link_body", i32 * MAX_LINKS),
+        ("link_pos", (f32 * 3) * MAX_LINKS),
+        ("link_rot", (f32 * 9) * MAX_LINKS),
     ]
 
 
@@ -132,6 +138,7 @@ class Config(C.Structure):
         ("terrain_origins", C.c_void_p),
         ("terrain_length", f32), ("env_spacing", f32),
         ("publish_reward_terms", i32),
+        ("publish_rigid_body_states", i32),
     ]
 
 
@@ -143,7 +150,7 @@ class TensorDesc(C.Structure):
 class StepArgs(C.Structure):
     _fields_ = [("actions", C.c_void_p), ("delay_substeps", f32),
                 ("common_step_counter", i64), ("noise_uniform", C.c_void_p),
-                ("obs_out", C.c_void_p), ("pri_obs_out", C.c_void_p)]
+                ("obs_out", C.c_void_p), ("pri_obs_out", C.c_void_p), ("stats_slot", i64)]
 
 
 class PipelineState(C.Structure):
@@ -179,6 +186,9 @@ def bind(lib, prefix="grx_"):
         "tensor": fn("tensor", C.c_int, H, C.c_int, C.POINTER(TensorDesc)),
         "set_state": fn("set_state", C.c_int, H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p),
         "episode_stats": fn("episode_stats", C.c_int, H, C.POINTER(C.c_float), C.c_void_p),
+        "flush_stats": fn("flush_stats", C.c_int, H, C.c_void_p),
+        "reset_idx": fn("reset_idx", C.c_int, H, C.c_void_p, C.c_int32, C.c_void_p),
+        "set_state_indexed": fn("set_state_indexed", C.c_int, H, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p),
         "last_error": fn("last_error", C.c_char_p),
         "abi_version": fn("abi_version", C.c_int),
         "reward_term_name": fn("reward_term_name", C.c_char_p, C.c_int),
@@ -194,6 +204,6 @@ def bind(lib, prefix="grx_"):
 
 EXPORTED_SYMBOLS = (
     "grx_create", "grx_destroy", "grx_reset_all", "grx_step", "grx_tensor", "grx_set_state",
-    "grx_episode_stats", "grx_kernel_time_ms", "grx_wait_idle", "grx_last_error", "grx_abi_version",
+    "grx_episode_stats", "grx_flush_stats", "grx_reset_idx", "grx_set_state_indexed", "grx_kernel_time_ms", "grx_wait_idle", "grx_last_error", "grx_abi_version",
     "grx_reward_term_name", "grx_debug_post_physics",
 )

@@ -19,23 +19,26 @@
 
 extern "C" {
 void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
-                     const float* noise, float* obs_out, float* pri_out, hipStream_t stream);
-void grx_launch_finalize(const KParams* dP, int nblocks, int64_t* progress, int64_t ticket, hipStream_t stream);
+                     const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream);
+void grx_launch_finalize(const KParams* dP, long long seq, long long* progress, long long ticket, hipStream_t stream);
+void grx_launch_ticket(long long* progress, long long ticket, hipStream_t stream);
 int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int lds_bytes, int heightfield, const float* actions,
-                            float delay, long long common_step, const float* noise, float* obs_out, float* pri_out, hipStream_t stream);
-void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, hipStream_t stream);
+                            float delay, long long common_step, const float* noise, float* obs_out, float* pri_out, long long seq, hipStream_t stream);
+void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, long long seq, uint8_t* mask, hipStream_t stream);
 int grx_generic_tables_size(void);
 int grx_generic_ws_floats_per_env(int nb, int nlc);
-void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream);
-void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, hipStream_t stream);
+void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, const StepSeq* sq, uint8_t* mask, hipStream_t stream);
+void grx_launch_mark(const int32_t* env_ids, int n, int N, uint8_t* mask, hipStream_t stream);
+void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, const int32_t* env_ids, int n, hipStream_t stream);
 int grx_envs_per_block(void);
 void grx_launch_step_debug(const KParams* dP, int N, int heightfield, const float* actions, long long common_step, const float* noise,
-                           const float* dbg, hipStream_t stream);
+                           const float* dbg, const StepSeq* sq, hipStream_t stream);
 int grx_debug_rows(void);
 }
 
 namespace {
 constexpr int NT = GRX_NUM_REWARD_TERMS;
+constexpr int NSTAT = GRX_NSTAT;
 thread_local std::string g_err;
 
 int fail(int code, const std::string& msg) {
@@ -63,15 +66,17 @@ struct Timing {
 // enqueue hundreds of policy steps in a few milliseconds.  On the shared MI355X boxes the HIP runtime's view of
 // completed work (hipEventQuery / stream synchronisation) was measured to lag the GPU by 10-80 ms, sporadically, for
 // this low-occupancy workload (rocprofv3 kernel traces show the kernels themselves at a steady 75 us).  The library
-// therefore keeps its own progress word: grx_finalize_stats, the last kernel of every step, stores the step's ticket
-// in host-pinned memory with a system-scope release, and the host reads that word directly -- to bound its
+// therefore keeps its own progress word in host-pinned memory: every step kernel stores, when it STARTS, the ticket of
+// the work enqueued before it (complete by stream order: one launch per step, no trailing kernel), and the host reads
+// that word directly -- to bound its
 // run-ahead (kPaceAhead steps: about 20 ms of queued work, enough to ride out a descheduled host thread) and to let callers spin until everything enqueued so far has really finished
 // (grx_wait_idle) without going through the runtime's signal machinery.
 struct Pace {
     static constexpr int64_t kPaceAhead = 256;
     volatile int64_t* progress = nullptr;   // host-pinned, device-visible
-    int64_t* d_progress = nullptr;          // device view of the same word
+    long long* d_progress = nullptr;        // device view of the same word
     int64_t issued = 0;                     // ticket of the last step enqueued
+    hipStream_t last_stream = nullptr;      // stream of the last ticketed launch (grx_wait_idle sends the closing ticket there)
 };
 }  // namespace
 
@@ -84,7 +89,9 @@ struct grx_sim {
     int nd = GRX_ND;
     void* d_gen = nullptr; // GenTables (device)
     float* d_ws = nullptr; // generic workspace
-    int stat_blocks = 0;   // rows of the per-block statistics table the step kernel in use writes
+    int64_t seq = 0;       // launches of this handle that write statistics rows (steps, resets, debug steps; recorded ones too)
+    bool stats_current = true;   // GRX_T_EPISODE_STATS already holds the statistics of launch `seq` (grx_flush_stats)
+    uint8_t* d_mask = nullptr;   // grx_reset_idx: per-env flags
     int gen_epb = 64;      // generic kernel: envs per (single-wave) block
     int gen_lds = 0;       // generic kernel: bytes of dynamic LDS when the workspace lives there (0: global memory)
     KParams hp;            // launch parameters: host image ...
@@ -291,6 +298,45 @@ int build_side_tables(const grx_config& c, KTables& P, uint32_t* ll_mask, uint64
             if (sl < 0 || sr < 0) return fail(GRX_ERR_UNSUPPORTED_MODEL, "leg x leg self-collision shape not in the kernel's tables");
             *sp_mask |= 1ull << ((sl - 8) * 8 + (sr - 8));
         }
+    }
+    return GRX_OK;
+}
+
+// GRX_T_RIGID_BODY_STATES tables of the fused kernel: chain links go to their leg's lane, the base lump's links alternate
+void rot_to_quat(const float R[9], float q[4]) {   // row-major rotation -> xyzw, largest-component form
+    const float t0 = 1 + R[0] - R[4] - R[8], t1 = 1 - R[0] + R[4] - R[8], t2 = 1 - R[0] - R[4] + R[8], t3 = 1 + R[0] + R[4] + R[8];
+    if (t3 >= t0 && t3 >= t1 && t3 >= t2) { q[0] = R[7] - R[5]; q[1] = R[2] - R[6]; q[2] = R[3] - R[1]; q[3] = t3; }
+    else if (t0 >= t1 && t0 >= t2) { q[0] = t0; q[1] = R[1] + R[3]; q[2] = R[2] + R[6]; q[3] = R[7] - R[5]; }
+    else if (t1 >= t2) { q[0] = R[1] + R[3]; q[1] = t1; q[2] = R[5] + R[7]; q[3] = R[2] - R[6]; }
+    else { q[0] = R[2] + R[6]; q[1] = R[5] + R[7]; q[2] = t2; q[3] = R[3] - R[1]; }
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= n;
+}
+int build_rbs_tables(const grx_model& m, RbsTables& T) {
+    memset(&T, 0, sizeof T);
+    if (m.num_links < 0 || m.num_links > GRX_MAX_LINKS) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_model.num_links out of range");
+    int nbase = 0;
+    std::vector<int> lists[2][GRX_LEG + 1];
+    for (int l = 0; l < m.num_links; ++l) {
+        const int b = m.link_body[l];
+        if (b < 0 || b >= m.num_bodies) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_model.link_body out of range");
+        if (b == 0) lists[(nbase++) & 1][0].push_back(l);
+        else lists[(b - 1) / GRX_LEG][1 + (b - 1) % GRX_LEG].push_back(l);
+    }
+    for (int side = 0; side < 2; ++side) {
+        int n = 0;
+        for (int lvl = 0; lvl <= GRX_LEG; ++lvl) {
+            T.off[side][lvl] = n;
+            for (int l : lists[side][lvl]) {
+                if (n >= GRX_RBS_MAX) return fail(GRX_ERR_UNSUPPORTED_MODEL, "more link frames per lane than the rigid-body-state table holds");
+                RbsEntry& E = T.e[side][n++];
+                E.px = m.link_pos[l][0]; E.py = m.link_pos[l][1]; E.pz = m.link_pos[l][2]; E.link = l;
+                float q[4];
+                rot_to_quat(m.link_rot[l], q);
+                E.qx = q[0]; E.qy = q[1]; E.qz = q[2]; E.qw = q[3];
+            }
+        }
+        T.off[side][GRX_LEG + 1] = n;
     }
     return GRX_OK;
 }
@@ -576,9 +622,25 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(episode_sums, NT * N); DA(reward_terms, NT * N); DA(heights, (size_t)(nh > 0 ? nh : 1) * N);
     DA(obs, (size_t)c.num_obs * N + 64); DA(pri_obs, (size_t)c.num_pri_obs * N + 64);
     const int nblocks = (c.num_envs + grx_envs_per_block() - 1) / grx_envs_per_block();
-    DA(stat_partial, (size_t)(2 * nblocks + 1) * (NT + 1));   // generic kernel: down to 16 envs per block
-    P.stat_stride = 2 * nblocks + 1;
-    DA(stats, NT + 1); DA(prof, (size_t)nblocks * GRX_PROF_SLOTS);
+    P.stat_stride = 2 * nblocks + 1;   // generic kernel: down to 16 envs per block
+    DA(stat_partial, (size_t)2 * NSTAT * P.stat_stride); DA(stat_nblocks, 2); DA(stat_hist, (size_t)GRX_STATS_HISTORY * NSTAT);
+    DA(stats, NSTAT); DA(prof, (size_t)nblocks * GRX_PROF_SLOTS);
+    rc = dalloc(s, &s->d_mask, N);
+    if (rc) { grx_destroy(s); return rc; }
+    P.publish_rbs = c.publish_rigid_body_states && !generic;   // (the generic-tree kernel does not publish link frames yet)
+    P.num_links = m.num_links;
+    DA(rbs, P.publish_rbs ? (size_t)13 * GRX_MAX_LINKS * N : 1);
+    if (!generic) {
+        RbsTables rt;
+        rc = build_rbs_tables(m, rt);
+        if (rc) { grx_destroy(s); return rc; }
+        RbsTables* drt = nullptr;
+        rc = dalloc(s, &drt, 1);
+        if (rc) { grx_destroy(s); return rc; }
+        HIP_TRY(hipMemcpy(drt, &rt, sizeof rt, hipMemcpyHostToDevice));
+        P.rbs_tab = drt;
+    }
+    if (c.num_terrain_rows > 255) { grx_destroy(s); return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: more than 255 terrain levels"); }
     float* base_mass_com = nullptr;
     rc = dalloc(s, &base_mass_com, 4 * N);
     if (rc) { grx_destroy(s); return rc; }
@@ -769,9 +831,12 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     desc_vec(s, GRX_T_FRICTION, P.friction, GRX_F32, Ni);
     desc_rows(s, GRX_T_BASE_MASS_COM, base_mass_com, Ni, 4);
     desc_vec(s, GRX_T_TERM_CONTACT, P.term_contact, GRX_U8, Ni);
-    desc_vec(s, GRX_T_EPISODE_STATS, P.stats, GRX_F32, NT + 1);
+    desc_vec(s, GRX_T_EPISODE_STATS, P.stats, GRX_F32, NSTAT);
+    desc_rows(s, GRX_T_EPISODE_STATS_HISTORY, P.stat_hist, GRX_STATS_HISTORY, NSTAT);
     desc_soa3(s, GRX_T_ANCHORS, P.anchors, 8, 3);
     desc_soa3(s, GRX_T_CONTACT_FORCES, P.contact_forces, GRX_MAX_LINKS, 3);
+    desc_soa3(s, GRX_T_RIGID_BODY_STATES, P.rbs, GRX_MAX_LINKS, 13);
+    if (!P.publish_rbs) s->desc[GRX_T_RIGID_BODY_STATES].data = nullptr;
     s->prof_host = P.prof; s->prof_blocks = nblocks;
     // generic kernel: the per-body workspace goes to LDS when 16 envs' rows fit (155 KB for the 33-body robot: LDS round
     // trips are ~5x shorter than global ones and the kernel is bound by exactly those); else 64 envs per block over the
@@ -785,7 +850,6 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
         if (per_env * 16 + 1024 <= 159 * 1024 && (c.num_envs + 15) / 16 <= prop.multiProcessorCount) { s->gen_epb = 16; s->gen_lds = (int)(per_env * 16); }
         if (const char* ev = getenv("GRX_GENERIC_EPB")) { const int v = atoi(ev); if (v == 16 || v == 32 || v == 64) { s->gen_epb = v; s->gen_lds = 0; } }
     }
-    s->stat_blocks = generic ? (c.num_envs + s->gen_epb - 1) / s->gen_epb : nblocks;
     if (generic) {
         rc = build_generic(s, c);
         if (rc) { grx_destroy(s); return rc; }
@@ -797,7 +861,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
         *s->pace.progress = 0;
         void* dp_ = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&dp_, hp_, 0));
-        s->pace.d_progress = static_cast<int64_t*>(dp_);
+        s->pace.d_progress = static_cast<long long*>(dp_);
     }
     {   // the parameter block is immutable from here on: upload it once
         rc = dalloc(s, &s->d_hp, 1);
@@ -845,26 +909,57 @@ static bool stream_is_capturing(hipStream_t st) {
     return cs != hipStreamCaptureStatusNone;
 }
 
+// place of the next launch in the handle's sequence: statistics parity / history row, and -- unless the stream is recording a
+// graph -- the ticket of the work before it, which that launch publishes when it starts
+static StepSeq next_seq(grx_sim* s, hipStream_t st, bool capturing) {
+    StepSeq q;
+    q.seq = ++s->seq;
+    q.progress = capturing ? nullptr : s->pace.d_progress;
+    q.ticket_done = s->pace.issued;
+    if (!capturing) { ++s->pace.issued; s->pace.last_stream = st; }
+    s->stats_current = false;
+    return q;
+}
+
 int grx_reset_all(grx_handle s, void* stream) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_reset_all: null handle");
     hipStream_t st = (hipStream_t)stream;
     // extras["episode"] of a full reset: mean of the running episode sums over all envs
     // (legged_robot.py:420-424); computed by the stats path with every env flagged.
     uint32_t step = 0x80000000u + (s->reset_count++);
-    if (s->generic) grx_launch_reset_all_generic(s->d_hp, s->d_gen, s->N, s->gen_epb, step, st);
-    else grx_launch_reset_all(s->d_hp, s->N, step, st);
-    grx_launch_finalize(s->d_hp, s->stat_blocks, s->pace.d_progress, ++s->pace.issued, st);
+    const StepSeq q = next_seq(s, st, stream_is_capturing(st));
+    if (s->generic) {
+        grx_launch_reset_all_generic(s->d_hp, s->d_gen, s->N, s->gen_epb, step, q.seq, nullptr, st);
+        grx_launch_finalize(s->d_hp, q.seq, q.progress, q.progress ? s->pace.issued : 0, st);
+        s->stats_current = true;
+    } else grx_launch_reset_all(s->d_hp, s->N, step, &q, nullptr, st);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
 
-int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
+int grx_reset_idx(grx_handle s, const int32_t* env_ids, int32_t n, void* stream) {
+    if (!s || (n > 0 && !env_ids)) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_reset_idx: null argument");
+    if (n <= 0) return GRX_OK;   // legged_robot.py:387-388
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t step = 0x80000000u + (s->reset_count++);
+    const StepSeq q = next_seq(s, st, stream_is_capturing(st));
+    grx_launch_mark(env_ids, n, s->N, s->d_mask, st);
+    if (s->generic) {
+        grx_launch_reset_all_generic(s->d_hp, s->d_gen, s->N, s->gen_epb, step, q.seq, s->d_mask, st);
+        grx_launch_finalize(s->d_hp, q.seq, q.progress, q.progress ? s->pace.issued : 0, st);
+        s->stats_current = true;
+    } else grx_launch_reset_all(s->d_hp, s->N, step, &q, s->d_mask, st);
+    HIP_TRY(hipGetLastError());
+    return GRX_OK;
+}
+
+int grx_step(grx_handle s, grx_step_args* a, void* stream) {
     if (!s || !a) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_step: null argument");
     hipStream_t st = (hipStream_t)stream;
     static const bool no_pace = getenv("GRX_DEBUG_NO_PACE") != nullptr;
     const bool capturing = stream_is_capturing(st);
-    if (!no_pace && !capturing)
-        if (int rc = spin_until(s, s->pace.issued - Pace::kPaceAhead + 1, "grx_step")) return rc;
+    if (!no_pace && !capturing)   // (the progress word trails the GPU by one launch: a step publishes its predecessor's ticket)
+        if (int rc = spin_until(s, s->pace.issued - Pace::kPaceAhead, "grx_step")) return rc;
     std::pair<hipEvent_t, hipEvent_t> ev;
     const bool timed = !capturing && s->timing.enabled && (s->timing.tick++ % s->timing.stride) == 0;
     if (timed) {
@@ -883,22 +978,35 @@ int grx_step(grx_handle s, const grx_step_args* a, void* stream) {
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
     }
-    const int64_t ticket = capturing ? 0 : ++s->pace.issued;
+    const StepSeq q = next_seq(s, st, capturing);
+    a->stats_slot = q.seq & (GRX_STATS_HISTORY - 1);
     if (s->generic)
     {
         if (grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->gen_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions,
-                                    a->delay_substeps, (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, st))
+                                    a->delay_substeps, (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, q.seq, st))
             return fail(GRX_ERR_HIP, "grx_step: cannot raise the dynamic LDS limit of the generic kernel");
     }
     else
         grx_launch_step(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
-                        (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, st);
+                        (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st);
     if (timed) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->timing.pending.push_back(ev);
     }
-    grx_launch_finalize(s->d_hp, s->stat_blocks, capturing ? nullptr : s->pace.d_progress, ticket, st);   // episode statistics + the step's ticket
+    if (s->generic) {   // the generic-tree kernel does not fold its predecessor's statistics: its own small kernel, with the step's ticket
+        grx_launch_finalize(s->d_hp, q.seq, q.progress, q.progress ? s->pace.issued : 0, st);
+        s->stats_current = true;
+    }
     HIP_TRY(hipGetLastError());
+    return GRX_OK;
+}
+
+int grx_flush_stats(grx_handle s, void* stream) {
+    if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_flush_stats: null handle");
+    if (s->stats_current) return GRX_OK;
+    grx_launch_finalize(s->d_hp, s->seq, nullptr, 0, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    if (!stream_is_capturing((hipStream_t)stream)) s->stats_current = true;
     return GRX_OK;
 }
 
@@ -911,14 +1019,23 @@ int grx_tensor(grx_handle s, int id, grx_tensor_desc* out) {
 
 int grx_set_state(grx_handle s, const float* root, const float* q, const float* qd, void* stream) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_set_state: null handle");
-    grx_launch_set_state(s->d_hp, s->N, root, q, qd, (hipStream_t)stream);
+    grx_launch_set_state(s->d_hp, s->N, root, q, qd, nullptr, 0, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return GRX_OK;
+}
+
+int grx_set_state_indexed(grx_handle s, const int32_t* env_ids, int32_t n, const float* root, const float* q, const float* qd, void* stream) {
+    if (!s || (n > 0 && !env_ids)) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_set_state_indexed: null argument");
+    if (n <= 0) return GRX_OK;
+    grx_launch_set_state(s->d_hp, s->N, root, q, qd, env_ids, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
 
 int grx_episode_stats(grx_handle s, float* host_out, void* stream) {
     if (!s || !host_out) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_episode_stats: null argument");
-    HIP_TRY(hipMemcpyAsync(host_out, s->hp.stats, (NT + 1) * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (int rc = grx_flush_stats(s, stream)) return rc;
+    HIP_TRY(hipMemcpyAsync(host_out, s->hp.stats, NSTAT * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return GRX_OK;
 }
@@ -996,16 +1113,21 @@ int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply
     UPS(s->d_dbg, dbg); UPS(s->d_dbg_actions, act);
 #undef UPS
     HIP_TRY(hipStreamSynchronize(st));   // the host vectors go out of scope
+    const StepSeq sq = next_seq(s, st, false);
     grx_launch_step_debug(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->d_dbg_actions, (long long)a->common_step_counter,
-                          a->noise_uniform, s->d_dbg, st);
-    grx_launch_finalize(s->d_hp, s->stat_blocks, s->pace.d_progress, ++s->pace.issued, st);
+                          a->noise_uniform, s->d_dbg, &sq, st);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
 
-// spin until every step enqueued through this handle has finished on the GPU (reads the pinned progress word)
+// spin until every step enqueued through this handle has finished on the GPU (reads the pinned progress word: the last
+// step's own ticket is published by a one-thread kernel behind it)
 int grx_wait_idle(grx_handle s) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_wait_idle: null handle");
+    if ((int64_t)*s->pace.progress < s->pace.issued) {
+        grx_launch_ticket(s->pace.d_progress, (long long)s->pace.issued, s->pace.last_stream);
+        HIP_TRY(hipGetLastError());
+    }
     return spin_until(s, s->pace.issued, "grx_wait_idle");
 }
 

@@ -11,6 +11,15 @@
 #define GRX_MAXSPH_SIDE 16
 #define GRX_PROF_SLOTS 80   // GRX_PROFILE_SECTIONS builds: clock stamps per block (tools/gpu_sections.py)
 #define GRX_COARSE 8     // raster cells per coarse max-map cell (0.8 m)
+// rows of the episode-statistics tables: the reward terms, [NT] the number of episodes that ended, [NT + 1] the sum of the terrain levels
+#define GRX_NSTAT (GRX_NUM_REWARD_TERMS + 2)
+
+// what every kernel that writes per-block statistics rows is told about its place in the handle's launch sequence
+struct StepSeq {
+    long long seq;          // launch number of this handle (step, reset, debug step alike): parity seq & 1 of the statistics tables, history row seq % GRX_STATS_HISTORY
+    long long* progress;    // host-pinned progress word (nullptr while a graph is being recorded) ...
+    long long ticket_done;  // ... and the ticket of the work that preceded this launch on the stream: complete when this kernel starts
+};
 
 struct SphC {   // 32 bytes
     float x, y, z, r;    // centre (body frame), radius
@@ -53,6 +62,19 @@ struct alignas(16) SideConst {
     SphC sph[GRX_MAXSPH_SIDE];
     float bs[3][4];               // bounding spheres (centre in the body frame, radius) of the shapes of chain bodies 2, 3, 4
     BaseChainPair bc[GRX_MAX_BC];
+};
+
+// GRX_T_RIGID_BODY_STATES: the URDF link frames a lane publishes -- those riding on its own chain bodies and its share of the
+// base lump's -- grouped by carrying body (level 0 = base, 1 + k = chain body k)
+#define GRX_RBS_MAX 24
+struct RbsEntry {   // 32 bytes
+    float px, py, pz;        // link origin in the carrying body's frame
+    int32_t link;            // URDF link index (row of the tensor)
+    float qx, qy, qz, qw;    // link -> body rotation
+};
+struct RbsTables {
+    int32_t off[2][GRX_LEG + 2];   // entries [off[side][lvl], off[side][lvl + 1]) ride on level lvl
+    RbsEntry e[2][GRX_RBS_MAX];
 };
 
 // Large read-only tables, in device memory.
@@ -119,7 +141,12 @@ struct KParams {
     uint8_t *reset, *time_out, *term_contact;
     float *base_lin_vel, *base_ang_vel, *proj_grav, *episode_sums, *reward_terms, *heights;
     float *obs, *pri_obs, *stat_partial, *stats;
-    int32_t stat_stride;   // stat_partial is [NT + 1][stat_stride]: one column per block of the writing kernel
+    int32_t stat_stride;   // stat_partial is [2][GRX_NSTAT][stat_stride]: launch parity x statistics row x one column per block of the writing kernel
+    int32_t* stat_nblocks; // [2]: columns the writing kernel of that parity filled
+    float* stat_hist;      // [GRX_STATS_HISTORY][GRX_NSTAT]: GRX_T_EPISODE_STATS as of every step (extras["episode"] without a copy per step)
+    float* rbs;            // GRX_T_RIGID_BODY_STATES [(link * 13 + c)][N], written when publish_rbs
+    const RbsTables* rbs_tab;
+    int32_t publish_rbs, num_links;
     int32_t nd;        // dofs of the model (10 on the fast path)
     long long* prof;   // GRX_PROFILE_SECTIONS builds only: [nblocks][16] s_memtime stamps
 };

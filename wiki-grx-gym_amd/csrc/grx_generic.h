@@ -392,13 +392,14 @@ GRX_DEV float gen_masked_abs_sum(const float* a, size_t N, int nd, uint32_t mask
 template <bool HF>
 __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict__ Pg, const GenTables* __restrict__ Tg, float* __restrict__ wsg,
                                                        const float* __restrict__ actions_in, float delay, long long common_step,
-                                                       const float* __restrict__ noise_in, float* __restrict__ obs_out, float* __restrict__ pri_out) {
+                                                       const float* __restrict__ noise_in, float* __restrict__ obs_out, float* __restrict__ pri_out,
+                                                       long long seq) {
     KP P = GRX_PARAMS(Pg);
     GT T = *reinterpret_cast<const GRX_AS4 GenTables*>(reinterpret_cast<uintptr_t>(Tg));
-    __shared__ float s_stat[NT + 1];
+    __shared__ float s_stat[NSTAT];
     // blockDim.x = envs per block (64 by default)
     const int lane = threadIdx.x, epb = blockDim.x;
-    for (int i = lane; i <= NT; i += epb) s_stat[i] = 0.f;
+    for (int i = lane; i < NSTAT; i += epb) s_stat[i] = 0.f;
     __syncthreads();
     const size_t N = (size_t)P.N;
     const int e_raw = blockIdx.x * epb + lane;
@@ -663,6 +664,10 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
         for (int f = 0; f < 2; ++f) { air_time[f] = 0.f; land_time[f] = 0.f; contact_last[f] = false; }
         ep_len = 0;
     }
+    {   // statistics row NT + 1: terrain levels after this step's curriculum moves (legged_robot.py:427-428)
+        const float ls = level_sum(ea.level, act);
+        if (lane == 0) s_stat[NT + 1] = ls;
+    }
     // ---- compute_observations (legged_robot_fftai.py:148-167, gr1t1.py:281-336)
     float* obs = (obs_out ? obs_out : P.obs) + (size_t)e * nobs;
     float* pri = (pri_out ? pri_out : P.pri_obs) + (size_t)e * npri;
@@ -746,11 +751,13 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
         P.term_contact[e] = term_contact ? 1 : 0;
     }
     __syncthreads();
-    for (int i = lane; i <= NT; i += epb) P.stat_partial[(size_t)i * P.stat_stride + blockIdx.x] = s_stat[i];
+    for (int i = lane; i < NSTAT; i += epb) stat_row(P, seq, i)[blockIdx.x] = s_stat[i];
+    if (blockIdx.x == 0 && lane == 0) P.stat_nblocks[seq & 1] = (int)gridDim.x;
 }
 
 // BaseTask.reset() first half for the generic path
-__global__ __launch_bounds__(64) void grx_reset_all_generic(const KParams* __restrict__ Pg, const GenTables* __restrict__ Tg, uint32_t step) {
+// mask: as in grx_reset_all_kernel (nullptr = every env, else reset_idx of the flagged ones)
+__global__ __launch_bounds__(64) void grx_reset_all_generic(const KParams* __restrict__ Pg, const GenTables* __restrict__ Tg, uint32_t step, long long seq, uint8_t* __restrict__ mask) {
     KP P = GRX_PARAMS(Pg);
     GT T = *reinterpret_cast<const GRX_AS4 GenTables*>(reinterpret_cast<uintptr_t>(Tg));
     const size_t N = (size_t)P.N;
@@ -758,21 +765,36 @@ __global__ __launch_bounds__(64) void grx_reset_all_generic(const KParams* __res
     const bool act = e_raw < P.N;
     const int e = act ? e_raw : P.N - 1;
     const uint32_t genv = (uint32_t)(P.env_offset + e);
-    for (int t = 0; t < NT; ++t) {   // extras["episode"]: every env is "finished"
-        float contrib = act ? P.episode_sums[(size_t)t * N + e] : 0.f;
+    const bool sel = act && (!mask || mask[e] != 0);   // this env resets
+    for (int t = 0; t < NT; ++t) {   // extras["episode"]: every resetting env is "finished"
+        float contrib = sel ? P.episode_sums[(size_t)t * N + e] : 0.f;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off);
-        if (lane == 0) P.stat_partial[(size_t)t * P.stat_stride + blockIdx.x] = contrib;
+        if (lane == 0) stat_row(P, seq, t)[blockIdx.x] = contrib;
     }
-    if (lane == 0) P.stat_partial[(size_t)NT * P.stat_stride + blockIdx.x] = (float)min(epb, P.N - blockIdx.x * epb);
-    if (!act) return;
     GenBase B;
     B.pos = v3(P.root[e], P.root[N + e], P.root[2 * N + e]);
     EnvAux ea;
     ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[N + e]; ea.cmd[2] = P.commands[2 * N + e];
     ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[N + e]; ea.origin[2] = P.origins[2 * N + e];
     ea.level = P.levels[e]; ea.type = P.types[e];
-    gen_reset_env(P, T, genv, step, false, B, ea, P.q + e, P.qd + e, N, e);
+    const int level_before = ea.level;
+    if (sel) gen_reset_env(P, T, genv, step, mask != nullptr, B, ea, P.q + e, P.qd + e, N, e);
+    {
+        const unsigned long long wm = __ballot(sel);
+        const float ls = level_sum(sel ? ea.level : level_before, act);
+        if (lane == 0) {
+            stat_row(P, seq, NT)[blockIdx.x] = (float)__popcll(wm);
+            stat_row(P, seq, NT + 1)[blockIdx.x] = ls;
+            if (blockIdx.x == 0) P.stat_nblocks[seq & 1] = (int)gridDim.x;
+        }
+    }
+    if (!sel) return;
+    if (mask) {
+        mask[e] = 0;
+        P.origins[e] = ea.origin[0]; P.origins[N + e] = ea.origin[1]; P.origins[2 * N + e] = ea.origin[2];
+        P.levels[e] = ea.level;
+    }
     for (int j = 0; j < T.nd; ++j) { P.last_actions[(size_t)j * N + e] = 0.f; P.last_dof_vel[(size_t)j * N + e] = 0.f; }
     for (int f = 0; f < 2; ++f) { P.air_time[(size_t)f * N + e] = 0.f; P.land_time[(size_t)f * N + e] = 0.f; P.feet_contact[(size_t)f * N + e] = 0; }
     const float rs[13] = {B.pos.x, B.pos.y, B.pos.z, B.qx, B.qy, B.qz, B.qw, B.vel.x, B.vel.y, B.vel.z, B.ang.x, B.ang.y, B.ang.z};

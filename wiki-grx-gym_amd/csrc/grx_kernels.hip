@@ -55,8 +55,59 @@ typedef const GRX_AS4 KParams& KP;
 namespace {
 
 constexpr int NT = GRX_NUM_REWARD_TERMS;
+constexpr int NSTAT = GRX_NSTAT;
 constexpr int LEG = GRX_LEG;
 constexpr int EPB = 32;  // envs per block (one wave64 = 32 lane pairs)
+
+// ---- episode statistics (extras["episode"], legged_robot.py:387-388, 420-428) without a kernel of their own -----------------
+// Every kernel that finishes episodes (step, reset, debug step) leaves per-block partial sums in the table of its launch parity
+// (statistics row major, one column per block); the NEXT kernel of the handle reduces them -- the kernel boundary is the
+// ordering, no fence, no atomics -- row t in block t, keeps the previous means when nobody reset, and files the result as
+// the finished launch's row of the history ring.  grx_finalize_stats does the same on demand (grx_flush_stats).
+GRX_DEV float* stat_row(KP P, long long seq, int t) { return P.stat_partial + ((size_t)(seq & 1) * NSTAT + t) * P.stat_stride; }
+// one wave: (finished episodes, sum of row t) over the nb columns of the launch `seq`, same summation order every time
+GRX_DEV void stat_reduce(KP P, long long seq, int t, int nb, int lane, float& cnt, float& s) {
+    const float* const crow = stat_row(P, seq, NT);
+    const float* const row = stat_row(P, seq, t);
+    cnt = 0.f; s = 0.f;
+    int b = lane;
+    for (; b + 7 * 64 < nb; b += 8 * 64) {   // (summed in the same order as one by one)
+        float c_[8], s_[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { c_[u] = crow[b + u * 64]; s_[u] = row[b + u * 64]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { cnt += c_[u]; s += s_[u]; }
+    }
+    for (; b < nb; b += 64) { cnt += crow[b]; s += row[b]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { cnt += __shfl_xor(cnt, off); s += __shfl_xor(s, off); }
+}
+GRX_DEV void stat_publish(KP P, long long seq, int t, float cnt, float s) {   // one lane
+    float v = P.stats[t];   // nobody reset: the reference keeps the previous dict (reset_idx returns early, legged_robot.py:387-388)
+    if (cnt > 0.f) {
+        v = t == NT ? cnt : (t == NT + 1 ? s / (float)P.N : s / cnt / P.max_episode_length_s);
+        P.stats[t] = v;
+    }
+    P.stat_hist[(size_t)(seq & (GRX_STATS_HISTORY - 1)) * NSTAT + t] = v;
+}
+// called by ONE full wave of every block at the start of a kernel: the statistics of launch sq.seq - 1, and its ticket
+GRX_DEV void stats_fold_previous(KP P, const StepSeq& sq, int lane) {
+    if (blockIdx.x == 0 && lane == 0 && sq.progress) __hip_atomic_store(sq.progress, sq.ticket_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long long prev = sq.seq - 1;
+    const int nb = P.stat_nblocks[prev & 1];
+    for (int t = blockIdx.x; t < NSTAT; t += gridDim.x) {
+        float cnt, s;
+        stat_reduce(P, prev, t, nb, lane, cnt, s);
+        if (lane == 0) stat_publish(P, prev, t, cnt, s);
+    }
+}
+// sum of the terrain levels of the block's envs (row NT + 1): ballots over the bits of the level (levels < 256), no LDS
+GRX_DEV float level_sum(int level, bool counted) {
+    int sum = 0;
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) sum += __popcll(__ballot(counted && ((level >> bit) & 1))) << bit;
+    return (float)sum;
+}
 
 // joint axes of a GR1 leg chain: hip_roll(x) hip_yaw(z) hip_pitch(y) knee_pitch(y) ankle_pitch(y)
 __device__ constexpr int kAxis[LEG] = {0, 2, 1, 1, 1};
@@ -468,7 +519,7 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
         out.term = ro.term; out.pen_count = ro.pen_count;
         pa = pa - ro.f0a - sc.f0a; pl = pl - ro.f0l - sc.f0l;
     }
-    write_link_rows(lfo, C, ro.lf, ro.fl2, ro.fl3, foot_terrain, sc);
+    write_link_rows(P, lfo, C, ro.lf, ro.fl2, ro.fl3, foot_terrain, sc, out.term, out.pen_count);   // (last sub-step: the flags from the NET link forces)
     A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
     pa = pair_sum(pa); pl = pair_sum(pl);
     {
@@ -557,6 +608,55 @@ GRX_DEV FootKin foot_kinematics(const SideConst& C, const LaneState& st) {
     f.vel = v + cross(w, fr);
     f.ang = w;
     return f;
+}
+
+// GRX_T_RIGID_BODY_STATES (gym.acquire_rigid_body_state_tensor, legged_robot.py:113,134; refreshed after every gym.simulate,
+// legged_robot_fftai.py:76): position, orientation (xyzw), linear and angular velocity of every URDF link frame in the state
+// AFTER the last sub-step and BEFORE reset_idx (the reference's tensor is not refreshed by a reset either).  One lane walks
+// its leg once more -- rotations as matrices for the offsets, as quaternions for the orientations -- and stores the frames
+// of the links its tables list (grx_capi.cpp build_rbs_tables).  Only with grx_config.publish_rigid_body_states.
+GRX_DEV void quat_mul(const float a[4], const float b[4], float o[4]) {   // xyzw
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+GRX_DEV void publish_rigid_body_states(KP P, const SideConst& C, int side, V3 pos, const float rootq[4], V3 vel, V3 ang,
+                                       const float q[LEG], const float qd[LEG], int e, int N, bool act) {
+    const RbsTables& T = *P.rbs_tab;
+    ChainKin K = {quat_to_R(rootq[0], rootq[1], rootq[2], rootq[3]), v3(0.f, 0.f, 0.f), ang, vel};
+    float bq[4] = {rootq[0], rootq[1], rootq[2], rootq[3]};
+#pragma unroll
+    for (int lvl = 0; lvl <= LEG; ++lvl) {
+        if (lvl > 0) {
+            const int k = lvl - 1;
+            chain_step(C, k, q[k], qd[k], K);
+            float sh, ch;
+            grx_sincos(0.5f * q[k], sh, ch);
+            const float jq[4] = {kAxis[k] == 0 ? sh : 0.f, kAxis[k] == 1 ? sh : 0.f, kAxis[k] == 2 ? sh : 0.f, ch};
+            float nq[4];
+            quat_mul(bq, jq, nq);
+            bq[0] = nq[0]; bq[1] = nq[1]; bq[2] = nq[2]; bq[3] = nq[3];
+        }
+        const int i0 = T.off[side][lvl], n = T.off[side][lvl + 1] - i0;
+        const int nmax = max(T.off[0][lvl + 1] - T.off[0][lvl], T.off[1][lvl + 1] - T.off[1][lvl]);   // uniform trip count
+        for (int j = 0; j < nmax; ++j) {
+            if (j < n && act) {
+                const RbsEntry E = T.e[side][i0 + j];
+                const V3 r = K.rho + rot(K.R, v3(E.px, E.py, E.pz));
+                const V3 vl = K.v + cross(K.w, r);
+                const float eq[4] = {E.qx, E.qy, E.qz, E.qw};
+                float lq[4];
+                quat_mul(bq, eq, lq);
+                float* o = P.rbs + (size_t)(E.link * 13) * N + e;
+                const size_t n_ = (size_t)N;
+                o[0] = pos.x + r.x; o[n_] = pos.y + r.y; o[2 * n_] = pos.z + r.z;
+                o[3 * n_] = lq[0]; o[4 * n_] = lq[1]; o[5 * n_] = lq[2]; o[6 * n_] = lq[3];
+                o[7 * n_] = vl.x; o[8 * n_] = vl.y; o[9 * n_] = vl.z;
+                o[10 * n_] = K.w.x; o[11 * n_] = K.w.y; o[12 * n_] = K.w.z;
+            }
+        }
+    }
 }
 
 GRX_DEV float urand(KP P, uint32_t genv, uint32_t step, uint32_t stream, uint32_t i, float lo, float hi) {
@@ -1005,7 +1105,8 @@ enum DbgRow { DBG_FEET_FORCE = 0, DBG_FEET_POS = 6, DBG_AVG_FORCE = 12, DBG_AVG_
 template <bool HF, int W, bool DBG = false>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE, GRX_WPE))) void grx_step_kernel(const KParams* __restrict__ Pg, const float* __restrict__ actions_in,
                                                       float delay, long long common_step, const float* __restrict__ noise_in,
-                                                      const float* __restrict__ dbg, float* __restrict__ obs_out, float* __restrict__ pri_out) {
+                                                      const float* __restrict__ dbg, float* __restrict__ obs_out, float* __restrict__ pri_out,
+                                                      const StepSeq sq) {
     static_assert(!DBG || W == 1, "the debug injection path exists for the one-wave layout only");
     KP P = GRX_PARAMS(Pg);
     constexpr int NTHR = 64 * W;
@@ -1027,7 +1128,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     static_assert(W != 4 || (PHYS_BYTES >= OBS_BYTES + PRI_BYTES && PHYS_BYTES + FOOTFR_BYTES + 13 * 64 * 4 <= POST_BYTES), "foot frames + s_anch must sit in the arena's tail");
     float4* const s_footfr = reinterpret_cast<float4*>(s_arena + PHYS_BYTES);
     float* const s_anch = reinterpret_cast<float*>(s_arena + PHYS_BYTES + FOOTFR_BYTES);
-    __shared__ float s_stat[NT + 1];
+    __shared__ float s_stat[NSTAT];
     __shared__ float s_base[W >= 2 ? 13 * EPB : 1];   // base state at the start of the current sub-step (dynamics -> helpers)
     __shared__ __attribute__((aligned(16))) float s_wr[W == 2 ? 32 * 64 : (W == 4 ? 8 * 64 : 1)];       // base-lump wrench + termination / collision flags (helper -> dynamics)
     // W == 4 pipeline buffers (grx_wavepipe.h)
@@ -1040,6 +1141,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     __shared__ float s_rwp[W == 4 ? 64 : 1];               // partial reward (wave 3 -> wave 1)
     __shared__ float s_hp[W == 4 ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
     __shared__ float s_hsum[W == 4 ? 4 * 64 : 1];          // height scan: partial sums per wave
+    __shared__ float s_tp[W == 4 ? 2 * 64 : 1];            // termination flag / collision count from the NET link forces of the last sub-step (wave 3 -> wave 0)
     __shared__ int s_flag[FL_COUNT];
     const PipeLds L = {s_base, s_q, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag};
     const int tid = threadIdx.x;
@@ -1049,10 +1151,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
         const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab);
         for (int i = tid; i < (int)(sizeof(KTables) / 4); i += NTHR) dst[i] = src[i];
-        if (tid <= NT) s_stat[tid] = 0.f;
+        if (tid < NSTAT) s_stat[tid] = 0.f;
         if (tid < FL_COUNT) s_flag[tid] = 0;
     }
     __syncthreads();
+    // the previous launch's episode statistics (and its ticket): on the wave that starts its sub-steps by waiting anyway
+    if (wv == W - 1) stats_fold_previous(P, sq, tid & 63);
     const int N = P.N;
     const int lane = tid & 63, el = lane >> 1, side = lane & 1;
     const int e_raw = blockIdx.x * EPB + el;
@@ -1118,7 +1222,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 a_[8 * 64] = __uint_as_float(hs.anchor_on);
             } else {
                 base_contact_loop<HF>(P, s_tab, GRX_HELPER_C, RB, mu, hmax, bm, bc, bI, L, lane, el, side,
-                                      LinkForceOut{true, act ? P.contact_forces + e : nullptr, (size_t)N});
+                                      LinkForceOut{true, act ? P.contact_forces + e : nullptr, (size_t)N}, s_tp);
             }
             float es_w1[NT], es_w3[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
             if (wv == 1) load_episode_sums<1>(P, e, N, es_w1);
@@ -1167,6 +1271,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 s_hsum[wv * 64 + lane] = pair_sum(part);
                 flag_set(s_flag + FL_BHO1 + (wv - 1), 1, lane);
                 if (wv == 2) GRX_TICKW(31);
+            }
+            if (wv == 2 && P.publish_rbs) {   // every URDF link frame of the state wave 0 published after the last sub-step
+                const float* b = s_base + el;
+                const float4 q0_ = s_q[lane], q1_ = s_q[64 + lane], q2_ = s_q[128 + lane];
+                const float fq[LEG] = {q0_.x, q0_.y, q0_.z, q0_.w, q1_.x}, fqd[LEG] = {q1_.y, q1_.z, q1_.w, q2_.x, q2_.y};
+                const float rq[4] = {b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]};
+                publish_rigid_body_states(P, C, side, v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]), rq, v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]),
+                                          v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]), fq, fqd, e, N, act);
             }
         } else {
             for (int deci = 0; deci < P.decimation; ++deci) {
@@ -1299,13 +1411,30 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     }
     const float yaw_n = fmaxf(sqrtf(st.qz * st.qz + st.qw * st.qw), 1e-9f);   // normalize(): torch_utils.py:43-45
     const float yaw_z = st.qz / yaw_n, yaw_w = st.qw / yaw_n;
+    if (W < 4 && !DBG && P.publish_rbs) {
+        const float rq[4] = {st.qx, st.qy, st.qz, st.qw};
+        publish_rigid_body_states(P, C, side, st.pos, rq, st.vel, st.ang, st.q, st.qd, e, N, act);
+    }
     if (W == 4) {   // the foot wave owned the friction anchors during the sub-steps
         if (side == 0) { float* hp = s_hp + el; hp[0 * EPB] = st.pos.x; hp[1 * EPB] = st.pos.y; hp[2 * EPB] = yaw_z; hp[3 * EPB] = yaw_w; }
+        if (P.publish_rbs) {   // the final state for the wave that publishes GRX_T_RIGID_BODY_STATES (wave 2, at the end of its work)
+            if (side == 0) {
+                float* b = s_base + el;
+                b[0 * EPB] = st.pos.x; b[1 * EPB] = st.pos.y; b[2 * EPB] = st.pos.z;
+                b[3 * EPB] = st.qx; b[4 * EPB] = st.qy; b[5 * EPB] = st.qz; b[6 * EPB] = st.qw;
+                b[7 * EPB] = st.vel.x; b[8 * EPB] = st.vel.y; b[9 * EPB] = st.vel.z;
+                b[10 * EPB] = st.ang.x; b[11 * EPB] = st.ang.y; b[12 * EPB] = st.ang.z;
+            }
+            s_q[lane] = f4(st.q[0], st.q[1], st.q[2], st.q[3]);
+            s_q[64 + lane] = f4(st.q[4], st.qd[0], st.qd[1], st.qd[2]);
+            s_q[128 + lane] = f4(st.qd[3], st.qd[4], 0.f, 0.f);
+        }
         lds_barrier();   // final friction anchors + height-scan pose published (the last sub-step's row stores stay in flight)
         const float* a_ = s_anch + lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { st.ax[i] = a_[i * 64]; st.ay[i] = a_[(4 + i) * 64]; st.vimp[i] = a_[(9 + i) * 64]; }
         st.anchor_on = __float_as_uint(a_[8 * 64]);
+        so.term = s_tp[lane] != 0.f; so.pen_count = s_tp[64 + lane];   // from the net link forces (terrain + self-collision), wave 3
     }
     GRX_TICK(2);
 #ifdef GRX_PROFILE_SECTIONS
@@ -1423,6 +1552,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
       }
     }
     const bool feet_contact_obs = do_reset ? false : contact;  // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
+    {   // statistics row NT + 1: terrain levels AFTER this step's curriculum moves (legged_robot.py:427-428)
+        const float ls = level_sum(ea.level, act && side == 0);
+        if (lane == 0) s_stat[NT + 1] = ls;
+    }
 
     GRX_TICK(7);
     // ---- compute_observations (legged_robot.py:442-452, legged_robot_fftai.py:148-167, gr1t1.py:281-336)
@@ -1570,52 +1703,44 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             }
         } else
             for (int i = tid; i < nenv * npri; i += NTHR) gpri[i] = s_pri[(i / npri) * PRS + (i % npri)];
-        if (tid <= NT) P.stat_partial[(size_t)tid * P.stat_stride + blockIdx.x] = s_stat[tid];   // term-major: the reduction reads rows of one term
+        if (tid < NSTAT) stat_row(P, sq.seq, tid)[blockIdx.x] = s_stat[tid];   // row-major: the reduction reads rows of one term
+        if (blockIdx.x == 0 && tid == 0) P.stat_nblocks[sq.seq & 1] = (int)gridDim.x;
     }
-    // (Reducing the per-block statistics rows here, in the last block to finish, was tried twice to save the
-    //  grx_finalize_stats launch: with an agent-scope __threadfence per block (whole-L2 write-back on this 8-XCD
-    //  part: +10 us per launch) and with agent-scope atomic stores / loads and no fence (bit-identical results,
-    //  but the acknowledgement wait costs +9 us).  A 4 us kernel of its own is cheaper.)
+    // (The rows are reduced by the NEXT launch of the handle -- stats_fold_previous: the kernel boundary orders them for free.
+    //  Reducing them here, in the last block to finish, was tried twice in round 1: an agent-scope __threadfence per block is a
+    //  whole-L2 write-back on this 8-XCD part, +10 us per launch; agent-scope atomics without a fence wait +9 us for the
+    //  acknowledgements.  Round 2 paid a 4.5 us kernel of its own per step instead.)
     GRX_TICK(10);
 }
 
-// extras["episode"] (legged_robot.py:420-424): mean episode sums of the envs reset by this step;
-// kept from the previous resetting step when nobody reset (the reference only rewrites the dict
-// inside reset_idx, which returns early for an empty id list, legged_robot.py:387-388).
-// ONE block: its ticket store comes after the block's barrier, i.e. after every statistics row of this step has been
-// written -- a visible ticket covers EPISODE_STATS like every other output.  A wave per reward term (round-robin); the
-// partial sums are stored term-major, so a wave reads its term's row coalesced, eight independent loads at a time.
+// extras["episode"] (legged_robot.py:420-428) ON DEMAND: the reduction stats_fold_previous would do in the handle's next launch,
+// for the launch `seq`, now (grx_flush_stats / grx_episode_stats; the generic-tree kernel's step still ends with it).  The next
+// launch repeats it with the same result.  ONE block, a wave per statistics row (round-robin); its ticket store comes after
+// the block's barrier, i.e. after every row has been published.
 constexpr int kFinalizeWaves = 16;
-__global__ __launch_bounds__(64 * kFinalizeWaves) void grx_finalize_stats(const KParams* __restrict__ Pg, int nblocks, int64_t* progress, int64_t ticket) {
+__global__ __launch_bounds__(64 * kFinalizeWaves) void grx_finalize_stats(const KParams* __restrict__ Pg, long long seq, long long* progress, long long ticket) {
     KP P = GRX_PARAMS(Pg);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float* const crow = P.stat_partial + (size_t)NT * P.stat_stride;
-    for (int t = wave; t <= NT; t += kFinalizeWaves) {
-        const float* const row = P.stat_partial + (size_t)t * P.stat_stride;
-        float cnt = 0.f, s = 0.f;
-        int b = lane;
-        for (; b + 7 * 64 < nblocks; b += 8 * 64) {   // (summed in the same order as one by one)
-            float c_[8], s_[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { c_[u] = crow[b + u * 64]; s_[u] = row[b + u * 64]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { cnt += c_[u]; s += s_[u]; }
-        }
-        for (; b < nblocks; b += 64) { cnt += crow[b]; s += row[b]; }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { cnt += __shfl_xor(cnt, off); s += __shfl_xor(s, off); }
-        if (lane == 0 && cnt > 0.f) P.stats[t] = (t == NT) ? cnt : s / cnt / P.max_episode_length_s;
+    const int nb = P.stat_nblocks[seq & 1];
+    for (int t = wave; t < NSTAT; t += kFinalizeWaves) {
+        float cnt, s;
+        stat_reduce(P, seq, t, nb, lane, cnt, s);
+        if (lane == 0) stat_publish(P, seq, t, cnt, s);
     }
     __syncthreads();
-    // step ticket for the host's progress word (pinned host memory): this kernel runs after the step kernel in stream
-    // order and the release below orders the statistics rows before it, so a visible ticket means ALL of the step's
-    // outputs are complete
     if (threadIdx.x == 0 && progress) __hip_atomic_store(progress, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the ticket alone (grx_wait_idle: everything enqueued before it on the stream has finished when it runs)
+__global__ void grx_ticket_kernel(long long* progress, long long ticket) {
+    __hip_atomic_store(progress, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // BaseTask.reset() first half (base_task.py:117-119): reset_idx(all envs), no step
-__global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __restrict__ Pg, uint32_t step) {
+// mask != nullptr: LeggedRobot.reset_idx(env_ids) (legged_robot.py:377-440) for the envs flagged in mask[N] (grx_reset_idx), with
+// the curriculum move of an initialised env; the flags are consumed
+__global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __restrict__ Pg, uint32_t step, const StepSeq sq, uint8_t* __restrict__ mask) {
     KP P = GRX_PARAMS(Pg);
+    stats_fold_previous(P, sq, threadIdx.x);
     __shared__ SideConst sc[2];
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables->side);
@@ -1628,7 +1753,8 @@ __global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __rest
     const int e_raw = blockIdx.x * EPB + el;
     const bool act = e_raw < N;
     const int e = act ? e_raw : N - 1;
-    const bool writer = act && side == 0;
+    const bool sel = act && (!mask || mask[e] != 0);   // this env resets
+    const bool writer = sel && side == 0;
     const SideConst& C = sc[side];
     const uint32_t genv = (uint32_t)(P.env_offset + e);
     const int j0 = side * LEG;
@@ -1637,17 +1763,31 @@ __global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __rest
         float contrib = writer ? P.episode_sums[(size_t)t * N + e] : 0.f;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) contrib += __shfl_xor(contrib, off);
-        if (lane == 0) P.stat_partial[(size_t)t * P.stat_stride + blockIdx.x] = contrib;
+        if (lane == 0) stat_row(P, sq.seq, t)[blockIdx.x] = contrib;
     }
-    if (lane == 0) P.stat_partial[(size_t)NT * P.stat_stride + blockIdx.x] = (float)min(EPB, N - blockIdx.x * EPB);
     LaneState st;
     EnvAux ea;
     st.pos = v3(P.root[e], P.root[(size_t)N + e], P.root[2 * (size_t)N + e]);
     ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[(size_t)N + e]; ea.cmd[2] = P.commands[2 * (size_t)N + e];
     ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[(size_t)N + e]; ea.origin[2] = P.origins[2 * (size_t)N + e];
     ea.level = P.levels[e]; ea.type = P.types[e];
-    reset_env(P, C, side, genv, step, false, st, ea, reset_rand(P, genv, step, side));
-    if (!act) return;
+    const int level_before = ea.level;
+    reset_env(P, C, side, genv, step, mask != nullptr, st, ea, reset_rand(P, genv, step, side));
+    {   // statistics rows NT (episodes that ended) and NT + 1 (terrain levels after the curriculum moves, legged_robot.py:427-428)
+        const unsigned long long wm = __ballot(writer);
+        const float ls = level_sum(sel ? ea.level : level_before, act && side == 0);
+        if (lane == 0) {
+            stat_row(P, sq.seq, NT)[blockIdx.x] = (float)__popcll(wm);
+            stat_row(P, sq.seq, NT + 1)[blockIdx.x] = ls;
+            if (blockIdx.x == 0) P.stat_nblocks[sq.seq & 1] = (int)gridDim.x;
+        }
+    }
+    if (!sel) return;
+    if (mask && side == 0) {
+        mask[e] = 0;
+        P.origins[e] = ea.origin[0]; P.origins[(size_t)N + e] = ea.origin[1]; P.origins[2 * (size_t)N + e] = ea.origin[2];
+        P.levels[e] = ea.level;
+    }
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
         size_t o = (size_t)(j0 + k) * N + e;
@@ -1668,47 +1808,55 @@ __global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __rest
     }
 }
 
-// set_dof_state_tensor / set_actor_root_state_tensor (legged_robot.py:737, 796): AoS rows -> SoA state
+// set_dof_state_tensor / set_actor_root_state_tensor (legged_robot.py:737, 796): AoS rows -> SoA state; env_ids != nullptr: the
+// _indexed variants (legged_robot.py:737-740, 782-784) -- rows env_ids[0..n) of the same full-size buffers
 __global__ void grx_set_state_kernel(const KParams* __restrict__ Pg, const float* __restrict__ root, const float* __restrict__ q,
-                                     const float* __restrict__ qd) {
+                                     const float* __restrict__ qd, const int32_t* __restrict__ env_ids, int n) {
     KP P = GRX_PARAMS(Pg);
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= P.N) return;
+    const int i_ = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i_ >= (env_ids ? n : P.N)) return;
+    const int e = env_ids ? env_ids[i_] : i_;
+    if (e < 0 || e >= P.N) return;
     size_t N = P.N;
     if (root) {
         for (int i = 0; i < 13; ++i) P.root[i * N + e] = root[(size_t)e * 13 + i];
         const float* qp = root + (size_t)e * 13 + 3;
-        float n = sqrtf(qp[0] * qp[0] + qp[1] * qp[1] + qp[2] * qp[2] + qp[3] * qp[3]);
-        for (int i = 0; i < 4; ++i) P.root[(3 + i) * N + e] = qp[i] / n;
+        float n_ = sqrtf(qp[0] * qp[0] + qp[1] * qp[1] + qp[2] * qp[2] + qp[3] * qp[3]);
+        for (int i = 0; i < 4; ++i) P.root[(3 + i) * N + e] = qp[i] / n_;
     }
     const int nd = P.nd;
     if (q) for (int j = 0; j < nd; ++j) P.q[j * N + e] = q[(size_t)e * nd + j];
     if (qd) for (int j = 0; j < nd; ++j) P.qd[j * N + e] = qd[(size_t)e * nd + j];
     for (int i = 0; i < 8; ++i) P.anchors[(size_t)(i * 3 + 2) * N + e] = 0.f;
 }
+// grx_reset_idx: flag the listed envs for the masked reset kernel
+__global__ void grx_mark_kernel(const int32_t* __restrict__ env_ids, int n, int N, uint8_t* __restrict__ mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int e = env_ids[i]; if (e >= 0 && e < N) mask[e] = 1; }
+}
 
 // host-callable launchers (grx_capi.cpp is compiled by hipcc too; kept separate for readability)
 // waves: waves per 32-env block (1, 2 or 4; grx_capi.cpp picks the largest that still gives every wave its own SIMD)
 extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
-                                const float* noise, float* obs_out, float* pri_out, hipStream_t stream) {
+                                const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-#define GRX_LAUNCH_STEP(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out)
+#define GRX_LAUNCH_STEP(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out, *sq)
     if (heightfield) { if (waves == 4) GRX_LAUNCH_STEP(true, 4); else if (waves == 2) GRX_LAUNCH_STEP(true, 2); else GRX_LAUNCH_STEP(true, 1); }
     else { if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
 #undef GRX_LAUNCH_STEP
 }
 // TEST-ONLY (grx_debug_post_physics): the post-physics half of the step on injected state, one-wave layout
 extern "C" void grx_launch_step_debug(const KParams* dP, int N, int heightfield, const float* actions, long long common_step, const float* noise,
-                                      const float* dbg, hipStream_t stream) {
+                                      const float* dbg, const StepSeq* sq, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    if (heightfield) hipLaunchKernelGGL((grx_step_kernel<true, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr);
-    else hipLaunchKernelGGL((grx_step_kernel<false, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr);
+    if (heightfield) hipLaunchKernelGGL((grx_step_kernel<true, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr, *sq);
+    else hipLaunchKernelGGL((grx_step_kernel<false, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr, *sq);
 }
 extern "C" int grx_debug_rows(void) { return DBG_ROWS; }
 // epb: envs per block (= threads per block, at most 64); lds_bytes > 0: the per-body workspace lives in (dynamic) LDS
 extern "C" int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int lds_bytes, int heightfield,
                                        const float* actions, float delay, long long common_step, const float* noise, float* obs_out, float* pri_out,
-                                       hipStream_t stream) {
+                                       long long seq, hipStream_t stream) {
     const int nblocks = (N + epb - 1) / epb;
     const GenTables* T = static_cast<const GenTables*>(tables);
     if (lds_bytes > 0) {
@@ -1720,24 +1868,33 @@ extern "C" int grx_launch_step_generic(const KParams* dP, const void* tables, fl
         }
         ws = nullptr;
     }
-    if (heightfield) hipLaunchKernelGGL(grx_step_generic<true>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise, obs_out, pri_out);
-    else hipLaunchKernelGGL(grx_step_generic<false>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise, obs_out, pri_out);
+    if (heightfield) hipLaunchKernelGGL(grx_step_generic<true>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise, obs_out, pri_out, seq);
+    else hipLaunchKernelGGL(grx_step_generic<false>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise, obs_out, pri_out, seq);
     return 0;
 }
-extern "C" void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, hipStream_t stream) {
-    hipLaunchKernelGGL(grx_reset_all_generic, dim3((N + epb - 1) / epb), dim3(epb), 0, stream, dP, static_cast<const GenTables*>(tables), step);
+extern "C" void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, long long seq, uint8_t* mask, hipStream_t stream) {
+    hipLaunchKernelGGL(grx_reset_all_generic, dim3((N + epb - 1) / epb), dim3(epb), 0, stream, dP, static_cast<const GenTables*>(tables), step, seq, mask);
 }
 extern "C" int grx_generic_tables_size(void) { return (int)sizeof(GenTables); }
 extern "C" int grx_generic_ws_floats_per_env(int nb, int nlc) { return nb * WSB + 3 * nlc; }
-// nblocks: rows of the per-block statistics table (fast path: 32 envs per block, generic path: 64)
-extern "C" void grx_launch_finalize(const KParams* dP, int nblocks, int64_t* progress, int64_t ticket, hipStream_t stream) {
-    hipLaunchKernelGGL(grx_finalize_stats, dim3(1), dim3(64 * kFinalizeWaves), 0, stream, dP, nblocks, progress, ticket);
+// the statistics of launch `seq` now (grx_flush_stats; the generic path after every step) + optionally a ticket
+extern "C" void grx_launch_finalize(const KParams* dP, long long seq, long long* progress, long long ticket, hipStream_t stream) {
+    hipLaunchKernelGGL(grx_finalize_stats, dim3(1), dim3(64 * kFinalizeWaves), 0, stream, dP, seq, progress, ticket);
 }
-extern "C" void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, hipStream_t stream) {
+extern "C" void grx_launch_ticket(long long* progress, long long ticket, hipStream_t stream) {
+    hipLaunchKernelGGL(grx_ticket_kernel, dim3(1), dim3(1), 0, stream, progress, ticket);
+}
+// mask: nullptr = every env (BaseTask.reset()); else the envs flagged there (reset_idx(env_ids))
+extern "C" void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, const StepSeq* sq, uint8_t* mask, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    hipLaunchKernelGGL(grx_reset_all_kernel, dim3(nblocks), dim3(64), 0, stream, dP, step);
+    hipLaunchKernelGGL(grx_reset_all_kernel, dim3(nblocks), dim3(64), 0, stream, dP, step, *sq, mask);
 }
-extern "C" void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, hipStream_t stream) {
-    hipLaunchKernelGGL(grx_set_state_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, dP, root, q, qd);
+extern "C" void grx_launch_mark(const int32_t* env_ids, int n, int N, uint8_t* mask, hipStream_t stream) {
+    hipLaunchKernelGGL(grx_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, env_ids, n, N, mask);
+}
+// env_ids: nullptr = all N envs, else the n listed rows
+extern "C" void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, const int32_t* env_ids, int n, hipStream_t stream) {
+    const int cnt = env_ids ? n : N;
+    hipLaunchKernelGGL(grx_set_state_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, dP, root, q, qd, env_ids, n);
 }
 extern "C" int grx_envs_per_block(void) { return EPB; }

@@ -284,8 +284,13 @@ GRX_DEV int self_base_link(const SideConst& C, int s) {
 // GRX_T_CONTACT_FORCES (the reference's contact_forces, legged_robot.py:117,266): net contact force per URDF link on the
 // LAST sub-step = terrain contacts + self-collision.  lf: RareOut.lf (base-lump links of this lane's table); fl2 / fl3 /
 // fl4: terrain forces on the thigh / shank / foot link; so: this lane's self-collision result.
-GRX_DEV void write_link_rows(const LinkForceOut& lfo, const SideConst& C, const V3 lf[8], V3 fl2, V3 fl3, V3 fl4, const SelfOut& so) {
+// The termination / collision flags (legged_robot.py:336-353, the `collision` reward term) are taken HERE, from the same net
+// forces the tensor shows -- a thigh pressing on a hand (GR1T2) terminates like a hand on the ground: term / pen_count of this
+// lane's base-lump links (terminating / penalised shapes ride on the base lump: build_side_tables).
+GRX_DEV void write_link_rows(KP P, const LinkForceOut& lfo, const SideConst& C, const V3 lf[8], V3 fl2, V3 fl3, V3 fl4, const SelfOut& so,
+                             bool& term, float& pen_count) {
     if (!lfo.last) return;
+    term = false; pen_count = 0.f;
     // forces the self-collision puts on base-lump links: mine and the partner lane's (its thigh against the same or another link)
     int lk[4]; V3 fb[4];
 #pragma unroll
@@ -302,6 +307,9 @@ GRX_DEV void write_link_rows(const LinkForceOut& lfo, const SideConst& C, const 
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) if (lk[s_] == link) f = f + fb[s_];
             put_link_force(lfo, C.sph[i], f);
+            const float n2 = dot(f, f);
+            if ((C.sph[i].flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term = true;
+            if ((C.sph[i].flags & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.0f;
         }
     put_link_force(lfo, C.sph[8], fl2 + so.fl[0]);
     put_link_force(lfo, C.sph[10], fl3 + so.fl[1]);

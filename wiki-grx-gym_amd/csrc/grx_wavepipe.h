@@ -495,7 +495,7 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
 // wave 3: the seldom-touching shapes -- base lump (torso, head, arms), thigh, shank -- lane-compacted (grx_rare.h)
 template <bool HF>
 GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, float mu, float hmax, float base_m, V3 base_c,
-                               const S3& base_I, const PipeLds& L, int lane, int el, int side, const LinkForceOut& lfo) {
+                               const S3& base_I, const PipeLds& L, int lane, int el, int side, const LinkForceOut& lfo, float* s_tp) {
     GRX_HELPER_PROF_BEGIN;
 #ifdef GRX_PROFILE_SECTIONS
     long long racc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -551,7 +551,9 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
             }
             const float4 f0_ = c_[4 * 64], f1_ = c_[5 * 64];
             const V3 foot_terrain = v3(f0_.w, f1_.x, f1_.y);
-            write_link_rows(lfo, C, ro.lf, ro.fl2, ro.fl3, foot_terrain, sc);
+            bool term; float pen;
+            write_link_rows(P, lfo, C, ro.lf, ro.fl2, ro.fl3, foot_terrain, sc, term, pen);
+            s_tp[lane] = term ? 1.f : 0.f; s_tp[64 + lane] = pen;   // picked up by wave 0 behind the barrier that ends the sub-steps
         }
     }
     GRX_HELPER_PROF_END(3);

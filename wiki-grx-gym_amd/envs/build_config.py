@@ -141,6 +141,7 @@ def build(cfg, sim_dt, num_envs, env_offset=0, total_envs=None, seed=1, terrain=
         c.height_points[k][0], c.height_points[k][1] = x, y
     c.env_spacing = float(cfg.env.env_spacing)
     c.publish_reward_terms = int(getattr(cfg.env, "publish_reward_terms", True))   # make_env turns it off
+    c.publish_rigid_body_states = int(getattr(cfg.env, "publish_rigid_body_states", True))   # bench.py turns it off
     c.horizontal_scale, c.vertical_scale, c.border_size = t.horizontal_scale, t.vertical_scale, t.border_size
     c.terrain_length = t.terrain_length
     if t.mesh_type == "plane":

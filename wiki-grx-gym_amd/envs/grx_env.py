@@ -17,6 +17,7 @@ Every buffer attribute is a zero-copy view of library-owned device memory (the
 strides (1, N).
 """
 import math
+from collections.abc import Mapping
 
 import numpy as np
 import torch
@@ -27,11 +28,36 @@ from . import build_config
 from .config import class_to_dict
 
 
+class _EpisodeInfo(Mapping):
+    """extras["episode"] of ONE step (legged_robot.py:419-428) without a kernel or a copy in env.step(): a read-only mapping over
+    that step's row of the library's statistics history ring (GRX_T_EPISODE_STATS_HISTORY).  Values are 0-dim device tensors,
+    materialised on access (the runner reads them once per iteration, on_policy_runner.py:121-133); a row stays valid for
+    GRX_STATS_HISTORY - 1 further steps."""
+    __slots__ = ("_env", "_slot", "_step")
+
+    def __init__(self, env, slot, step):
+        self._env, self._slot, self._step = env, slot, step
+
+    def _row(self):
+        env = self._env
+        if env.common_step_counter - self._step >= _capi.STATS_HISTORY - 1:
+            raise RuntimeError("extras['episode'] of a step more than GRX_STATS_HISTORY steps back has been overwritten")
+        if self._step == env.common_step_counter:
+            env._sim.flush_stats()   # the last step's statistics are otherwise reduced by the next launch
+        return env._stats_hist[self._slot]
+
+    def __getitem__(self, key):
+        return self._row()[self._env._episode_keys[key]]
+
+    def __iter__(self):
+        return iter(self._env._episode_keys)
+
+    def __len__(self):
+        return len(self._env._episode_keys)
+
+
 class GRxEnv:
     """VecEnv (rsl_rl/env/vec_env.py:7-40) implemented on libgrx_hip.so."""
-
-    # tests inject the CPU oracle here (tests/ only; the product has no CPU backend)
-    _backend_factory = None
 
     def __init__(self, cfg, sim_params=None, physics_engine=None, sim_device="cuda:0", headless=True,
                  env_offset=0, total_envs=None):
@@ -69,8 +95,7 @@ class GRxEnv:
         elif cfg.terrain.mesh_type != "plane":
             raise ValueError("Terrain mesh type not recognised. Allowed types are [plane, heightfield, trimesh]")
         c, keep, meta = build_config.build(cfg, sim_dt, self.num_envs, env_offset, total_envs, seed, self.terrain)
-        factory = type(self)._backend_factory
-        self._sim = factory(c, sim_device, keep) if factory else HipSim(c, sim_device, keep)
+        self._sim = HipSim(c, sim_device, keep)
         self.device = str(self._sim.device) if self._sim.device.type == "cpu" else f"cuda:{self._sim.device.index or 0}"
         self._meta = meta
         rm = meta["model"]
@@ -83,7 +108,11 @@ class GRxEnv:
         self.feet_indices = torch.tensor(meta["feet_links"], dtype=torch.long, device=dev)
         self.termination_contact_indices = torch.tensor(meta["termination_links"], dtype=torch.long, device=dev)
         self.penalised_contact_indices = torch.tensor(meta["penalised_links"], dtype=torch.long, device=dev)
-        self.torso_indices = torch.tensor(rm.links_containing(cfg.asset.torso_name), dtype=torch.long, device=dev)
+        # the body index sets of gr1t1.py:18-113 (_create_envs_get_indices): links whose name contains cfg.asset.<x>_name
+        for name in ("torso", "forehead", "imu", "waist", "head", "thigh", "shank", "sole", "upper_arm", "lower_arm", "hand",
+                     "arm_base", "arm_end"):
+            sub = getattr(cfg.asset, name + "_name", None)
+            setattr(self, name + "_indices", torch.tensor(rm.links_containing(sub) if sub else [], dtype=torch.long, device=dev))
         kp, kd, q0 = build_config.resolve_gains(cfg, rm.dof_names)
         self.p_gains = torch.tensor(kp, dtype=torch.float, device=dev)
         self.d_gains = torch.tensor(kd, dtype=torch.float, device=dev)
@@ -141,13 +170,14 @@ class GRxEnv:
         self.terrain_levels, self.terrain_types = t("TERRAIN_LEVELS"), t("TERRAIN_TYPES")
         self.motor_strength_scales = t("MOTOR_STRENGTH")
         self._episode_sums = t("EPISODE_SUMS")
-        self._episode_stats = t("EPISODE_STATS")
+        self._stats_hist = t("EPISODE_STATS_HISTORY")
+        self._episode_keys = {"rew_" + n: i for n, i in self._term_index.items()}
+        if self.cfg.terrain.curriculum:
+            self._episode_keys["terrain_level"] = _capi.NUM_REWARD_TERMS + 1
         self.episode_sums = {n: self._episode_sums[i] for n, i in self._term_index.items()}
         # (N, num_bodies, 3) net contact force per URDF link, last sub-step (LR:117): zero-copy view of the library tensor
         self.contact_forces = t("CONTACT_FORCES")[:, :self.num_bodies]
-        from .kinematics import BodyKinematics
-        self._kin = BodyKinematics(rm, dev)
-        self._rbs_cache = (-1, None)
+        self._rbs = None
         self.noise_scale_vec = self._noise_scale_vec()
         self.common_step_counter = 0
         self.extras = {}
@@ -170,11 +200,12 @@ class GRxEnv:
 
     @property
     def rigid_body_states(self):
-        """(N, num_links, 13) pos / quat xyzw / lin vel / ang vel of every URDF link, world frame (the layout of
-        gym.acquire_rigid_body_state_tensor, legged_robot.py:113,134) -- computed on first access after a step."""
-        if self._rbs_cache[0] != self.common_step_counter:
-            self._rbs_cache = (self.common_step_counter, self._kin.rigid_body_states(self.root_states, self.dof_pos, self.dof_vel))
-        return self._rbs_cache[1]
+        """(N, num_links, 13) pos / quat xyzw / lin vel / ang vel of every URDF link, world frame: the layout of
+        gym.acquire_rigid_body_state_tensor (legged_robot.py:113,134).  A zero-copy view of the library tensor the step kernel
+        writes after its last sub-step (cfg.env.publish_rigid_body_states, on by default; bench.py turns it off)."""
+        if self._rbs is None:
+            self._rbs = self._sim.tensor("RIGID_BODY_STATES")[:, :self.num_bodies]
+        return self._rbs
 
     def get_observations(self):
         return self.obs_buf
@@ -193,12 +224,15 @@ class GRxEnv:
         self.common_step_counter += 1
         k = self._ring
         self._ring ^= 1
-        self._sim.step(a, delay, self.common_step_counter, obs_out=self._obs_ring[k],
-                       pri_obs_out=self._pri_ring[k] if self._pri_ring is not None else None)
+        slot = self._sim.step(a, delay, self.common_step_counter, obs_out=self._obs_ring[k],
+                              pri_obs_out=self._pri_ring[k] if self._pri_ring is not None else None)
         self.obs_buf = self._obs_ring[k]
         if self._pri_ring is not None:
             self.pri_obs_buf = self._pri_ring[k]
-        self._fill_extras()
+        # extras (legged_robot.py:419-440): no kernel, no copy -- a view object over the step's statistics row
+        self.extras["episode"] = _EpisodeInfo(self, slot, self.common_step_counter)
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = self.time_out_buf
         return self.obs_buf, self.pri_obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def reset(self):
@@ -208,8 +242,20 @@ class GRxEnv:
         return obs, pri
 
     def reset_idx(self, env_ids):
-        raise NotImplementedError("resets happen inside the fused step kernel (masked, no host sync); "
-                                  "use reset() for a full reset")
+        """legged_robot.py:377-440 for callers outside step() (inside it resets are masked in the fused kernel, no host sync):
+        curriculum move, dof / root / command draws, history and timers zeroed; the envs' episode sums go to the episode
+        statistics of the next extras["episode"]."""
+        if len(env_ids) == 0:
+            return
+        self._sim.reset_idx(env_ids)
+
+    def set_dof_state_indexed(self, env_ids, dof_pos, dof_vel):
+        """gym.set_dof_state_tensor_indexed (legged_robot.py:737-740): rows env_ids of full (N, nd) tensors"""
+        self._sim.set_state_indexed(env_ids, None, dof_pos.contiguous(), dof_vel.contiguous())
+
+    def set_root_state_indexed(self, env_ids, root_states):
+        """gym.set_actor_root_state_tensor_indexed (legged_robot.py:782-784): rows env_ids of a full (N, 13) tensor"""
+        self._sim.set_state_indexed(env_ids, root_states.contiguous(), None, None)
 
     def render(self, sync_frame_time=True):
         pass  # headless only (viewer is out of scope, SURVEY section 2 #20)
@@ -221,18 +267,6 @@ class GRxEnv:
         self._sim.close()
 
     # ------------------------------------------------------------------ helpers
-    def _fill_extras(self):
-        """extras['episode'] / extras['time_outs'] (legged_robot.py:419-440) without a host sync:
-        the means live in a device buffer that the finalize kernel rewrites only on steps where some
-        env reset -- the dict semantics of the reference (it keeps the last dict otherwise)."""
-        stats = self._episode_stats.clone()           # the runner keeps one entry per step
-        ep = {"rew_" + n: stats[i] for n, i in self._term_index.items()}
-        if self.cfg.terrain.curriculum:
-            ep["terrain_level"] = self.terrain_levels.float().mean()
-        self.extras["episode"] = ep
-        if self.cfg.env.send_timeouts:
-            self.extras["time_outs"] = self.time_out_buf
-
     def _noise_scale_vec(self):
         """gr1t1.py:315-336"""
         n, s, lv = self.cfg.noise.noise_scales, self.obs_scales, self.cfg.noise.noise_level

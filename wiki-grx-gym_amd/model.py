@@ -278,4 +278,15 @@ def fill_model(cm, rm, foot_name, torso_name, forehead_name, terminate_names, pe
 
     frame(torso_name, "torso_body", "torso_rot")
     frame(forehead_name, "forehead_body", "forehead_rot")
+    # every URDF link frame (GRX_T_RIGID_BODY_STATES rows)
+    if rm.num_links > _capi.MAX_LINKS:
+        raise ValueError(f"{rm.num_links} links > GRX_MAX_LINKS")
+    cm.num_links = rm.num_links
+    for li in range(rm.num_links):
+        cm.link_body[li] = int(rm.link_body[li])
+        for a in range(3):
+            cm.link_pos[li][a] = float(rm.link_pos[li][a])
+        R = np.asarray(rm.link_rot[li]).reshape(-1)
+        for a in range(9):
+            cm.link_rot[li][a] = float(R[a])
     return {"feet_links": feet, "termination_links": sorted(term_links), "penalised_links": sorted(pen_links)}

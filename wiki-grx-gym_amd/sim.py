@@ -94,6 +94,7 @@ class SimHandle:
         self._h = C.c_void_p()
         self._check(api["create"](C.byref(cfg_struct), int(device_id), C.byref(self._h)), "create")
         self._views = {}
+        self.last_stats_slot = 0   # row of EPISODE_STATS_HISTORY holding the episode statistics of the last step
 
     # -- errors
     def _check(self, rc, what):
@@ -109,10 +110,14 @@ class SimHandle:
     # -- API
     def tensor(self, name):
         """Zero-copy torch view of a library buffer (cached)."""
+        if name == "EPISODE_STATS":
+            self.flush_stats()   # a step's statistics are reduced by the NEXT launch (include/grx.h grx_flush_stats)
         if name in self._views:
             return self._views[name]
         d = _capi.TensorDesc()
         self._check(self._api["tensor"](self._h, _capi.T[name], C.byref(d)), f"tensor({name})")
+        if not d.data:
+            raise GrxError(f"tensor {name} is not published by this handle (see the publish_* switches of grx_config)")
         shape = [int(d.shape[i]) for i in range(d.ndim)]
         stride = [int(d.stride[i]) for i in range(d.ndim)]
         if self.device.type == "cuda":
@@ -146,6 +151,21 @@ class SimHandle:
                     raise GrxError(f"{name} must be a contiguous float32 (N, k) tensor on the simulation device")
                 setattr(a, name, t.data_ptr())
         self._check(self._api["step"](self._h, C.byref(a), self._stream()), "step")
+        self.last_stats_slot = int(a.stats_slot)
+        return self.last_stats_slot
+
+    def flush_stats(self):
+        """Reduce the episode statistics of the last enqueued step now (they are otherwise folded into the next launch)."""
+        self._check(self._api["flush_stats"](self._h, self._stream()), "flush_stats")
+
+    def _ids(self, env_ids):
+        ids = torch.as_tensor(env_ids, device=self.device).to(torch.int32).contiguous().reshape(-1)
+        return ids, (ids.data_ptr() if ids.numel() else None), int(ids.numel())
+
+    def reset_idx(self, env_ids):
+        """LeggedRobot.reset_idx(env_ids) (legged_robot.py:377-440) outside a step."""
+        ids, ptr, n = self._ids(env_ids)
+        self._check(self._api["reset_idx"](self._h, ptr, n, self._stream()), "reset_idx")
 
     def set_state(self, root_states=None, dof_pos=None, dof_vel=None):
         def ptr(t, cols):
@@ -156,6 +176,19 @@ class SimHandle:
             return t.data_ptr()
         self._check(self._api["set_state"](self._h, ptr(root_states, 13), ptr(dof_pos, self.num_dofs),
                                            ptr(dof_vel, self.num_dofs), self._stream()), "set_state")
+
+    def set_state_indexed(self, env_ids, root_states=None, dof_pos=None, dof_vel=None):
+        """set_dof_state_tensor_indexed / set_actor_root_state_tensor_indexed (legged_robot.py:737-740, 782-784): rows env_ids of
+        the FULL (N, k) tensors."""
+        def ptr(t, cols):
+            if t is None:
+                return None
+            if t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (self.num_envs, cols):
+                raise GrxError("set_state tensors must be contiguous float32 (N, k)")
+            return t.data_ptr()
+        ids, p, n = self._ids(env_ids)
+        self._check(self._api["set_state_indexed"](self._h, p, n, ptr(root_states, 13), ptr(dof_pos, self.num_dofs),
+                                                   ptr(dof_vel, self.num_dofs), self._stream()), "set_state_indexed")
 
     def debug_post_physics(self, states, apply_reset=False, common_step_counter=1, noise_uniform=None):
         """TEST-ONLY (include/grx.h grx_debug_post_physics): post_physics_step of all envs on injected state.
@@ -173,7 +206,7 @@ class SimHandle:
         self._check(self._api["debug_post_physics"](self._h, states, int(bool(apply_reset)), C.byref(a), self._stream()), "debug_post_physics")
 
     def episode_stats(self):
-        out = (C.c_float * (_capi.NUM_REWARD_TERMS + 1))()
+        out = (C.c_float * (_capi.NUM_REWARD_TERMS + 2))()   # means, [NT] episodes that ended, [NT + 1] mean terrain level
         self._check(self._api["episode_stats"](self._h, out, self._stream()), "episode_stats")
         return np.array(out[:], dtype=np.float32)
 
