@@ -32,6 +32,17 @@ PHYS = {  # name: (atol, rtol, allowed fraction outside)
 }
 
 
+def set_layout(monkeypatch, layout):
+    """Step-kernel layout for handles created from here on: 1 / 2 / 4 waves per 32-env block (a lane pair per env), or "quad":
+    four waves per 16-env block with a lane QUAD per env (grx_quad.hip; picked by itself while 16-env blocks fit the CUs)."""
+    if layout == "quad":
+        monkeypatch.setenv("GRX_LANES_PER_ENV", "4")
+        monkeypatch.delenv("GRX_WAVES_PER_BLOCK", raising=False)
+    else:
+        monkeypatch.setenv("GRX_LANES_PER_ENV", "2")
+        monkeypatch.setenv("GRX_WAVES_PER_BLOCK", str(layout))
+
+
 def phys_diff(hip, ora, worst):
     for name, (atol, rtol, _) in PHYS.items():
         a, b = hip.tensor(name).detach().cpu().double(), ora.tensor(name).double()
@@ -298,8 +309,10 @@ def test_full_size_properties(task, terrain, N, monkeypatch):
     (env i does not depend on how the batch is split across ranks: the multi-GPU contract).
     Bit-identity holds per step-kernel layout (waves per 32-env block, picked from the local batch size);
     the 32768 cases pin the layout so that the shards use the full run's."""
-    if N == 32768:
-        monkeypatch.setenv("GRX_WAVES_PER_BLOCK", "1")
+    # (the library picks the layout from the LOCAL batch size -- quad up to 4096 envs, four waves up to 16384, one wave beyond;
+    #  the shards of this test are smaller than the full run, so the full run's layout is pinned for them)
+    if task != "GR1T1Full":
+        set_layout(monkeypatch, 1 if N == 32768 else (4 if N == 8192 else "quad"))
     cfg = make_cfg(task=task, terrain=terrain, noise=True, dr=True, push=True)
     act_scale = 0.3 if task == "GR1T1Full" else 1.0      # (the full body's arm / waist ranges at full scale throw it around)
     from tests.helpers import make_terrain
@@ -338,11 +351,12 @@ def test_full_size_properties(task, terrain, N, monkeypatch):
     assert (full["RESET"].sum() > 0 or task == "GR1T1Full") and (full["PRI_OBS"][:, -121:].abs().sum() > 0)
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4])
+@pytest.mark.parametrize("waves", [1, 2, 4, "quad"])
 def test_every_wave_layout_matches_the_oracle(waves, monkeypatch):
-    """The three launch layouts of the step kernel (1, 2, 4 waves per 32-env block: single wave / contact helper
-    wave / four-wave producer-consumer pipeline) run the same physics: each against the oracle, rough terrain."""
-    monkeypatch.setenv("GRX_WAVES_PER_BLOCK", str(waves))
+    """The launch layouts of the step kernel (1, 2, 4 waves per 32-env block: single wave / contact helper wave / four-wave
+    producer-consumer pipeline; "quad": that pipeline with a lane quad per env, 16 envs per block) run the same physics:
+    each against the oracle, rough terrain."""
+    set_layout(monkeypatch, waves)
     cfg = make_cfg(terrain="heightfield", noise=True, dr=True, push=True)
     hip, ora = make_sims(cfg, 320, seed=1)
     hip.reset_all(); ora.reset_all()
@@ -357,10 +371,12 @@ def test_every_wave_layout_matches_the_oracle(waves, monkeypatch):
     hip.close()
 
 
-def test_tail_block_and_small_batches():
-    """num_envs not a multiple of the 32-env block: tail lanes must not corrupt neighbours."""
+@pytest.mark.parametrize("layout", [4, "quad"])
+def test_tail_block_and_small_batches(layout, monkeypatch):
+    """num_envs not a multiple of the 32- / 16-env block: tail lanes must not corrupt neighbours."""
+    set_layout(monkeypatch, layout)
     cfg = make_cfg()
-    for N in (1, 31, 33, 100):
+    for N in (1, 15, 17, 31, 33, 100):
         hip, ora = make_sims(cfg, N)
         hip.reset_all(); ora.reset_all()
         worst = physics_lockstep(hip, ora, cfg, steps=12)
@@ -385,13 +401,13 @@ def test_set_state_and_api_errors():
         hip.step(torch.zeros(10, 64).cuda().t(), 5.0, 1)           # non-contiguous (gymtorch.py:98-99)
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4])
+@pytest.mark.parametrize("waves", [1, 2, 4, "quad"])
 @pytest.mark.parametrize("task", ["GR1T1", "GR1T2"])
 def test_self_collision_matches_the_oracle(task, waves, monkeypatch):
     """self_collisions = 0 = enabled (legged_robot_config.py:121): robots in flight with their legs driven into each
     other (hip roll adducted, knees and feet crossing).  The HIP kernels (every wave layout) against the oracle from
     identical state; the leg links carry the contact, and it is an internal force pair: the link forces of an env sum to 0."""
-    monkeypatch.setenv("GRX_WAVES_PER_BLOCK", str(waves))
+    set_layout(monkeypatch, waves)
     cfg = make_cfg(task=task, dr=True, push=False)
     N = 96
     hip, ora = make_sims(cfg, N, seed=5)
@@ -495,13 +511,13 @@ def test_action_latency_real_valued(delay):
         assert torch.equal(hip.tensor("DOF_POS"), q_delay)
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4])
+@pytest.mark.parametrize("waves", [1, 2, 4, "quad"])
 def test_self_collision_on_a_terminating_link_resets_the_env(waves, monkeypatch):
     """GR1T2's thigh can press on the hand (self-collision pairs 4-25, 10-33; hand links are in
     terminate_after_contacts_on).  check_termination reads the NET contact force per link (legged_robot.py:336-353), so a
     thigh-hand overlap above termination_force resets the env although nothing touches the ground -- in every wave layout,
     like the oracle, and consistently with the published CONTACT_FORCES."""
-    monkeypatch.setenv("GRX_WAVES_PER_BLOCK", str(waves))
+    set_layout(monkeypatch, waves)
     cfg = make_cfg(task="GR1T2")
     N = 64
     hip, ora = make_sims(cfg, N)
@@ -535,7 +551,7 @@ def test_self_collision_on_a_terminating_link_resets_the_env(waves, monkeypatch)
     assert torch.equal(implied[clear], hip.tensor("TERM_CONTACT").cpu()[clear].bool())
 
 
-@pytest.mark.parametrize("waves", [1, 4])
+@pytest.mark.parametrize("waves", [1, 4, "quad"])
 @pytest.mark.parametrize("task", ["GR1T1", "GR1T2"])
 def test_rigid_body_states_match_the_oracle(task, waves, monkeypatch):
     """GRX_T_RIGID_BODY_STATES (gym.acquire_rigid_body_state_tensor, legged_robot.py:113,134): all link frames after the last
@@ -544,7 +560,7 @@ def test_rigid_body_states_match_the_oracle(task, waves, monkeypatch):
     from tests.kinematics_ref import BodyKinematics
     from tests.test_kinematics import rbs_err
     from wiki_grx_gym_amd.model import RobotModel
-    monkeypatch.setenv("GRX_WAVES_PER_BLOCK", str(waves))
+    set_layout(monkeypatch, waves)
     cfg = make_cfg(task=task, terrain="heightfield", dr=True)
     cfg.env.episode_length_s = 0.2          # time-outs: resetting envs in the comparison
     hip, ora = make_sims(cfg, 200, seed=2)

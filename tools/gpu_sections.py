@@ -6,7 +6,7 @@ flags="-I../../include --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-hip-fp32-
 os.makedirs(csrc + "/variants", exist_ok=True)
 PROF = os.path.abspath(csrc + "/variants/libgrx_prof.so")
 if "--build" in sys.argv or not os.path.exists(PROF):   # hipcc cross-compiles in the build container; the .so travels with gpurun
-    subprocess.run(f"cd {csrc} && hipcc {flags} -shared -o variants/libgrx_prof.so grx_kernels.hip grx_capi.cpp 2>/dev/null", shell=True, check=True)
+    subprocess.run(f"cd {csrc} && hipcc {flags} -shared -o variants/libgrx_prof.so grx_kernels.hip grx_quad.hip grx_capi.cpp 2>/dev/null", shell=True, check=True)
     if "--build" in sys.argv:
         sys.exit(0)
 PROF = os.path.abspath(os.environ.get("GRX_PROF_LIB", PROF))
@@ -18,6 +18,7 @@ os.environ["GRX_PUBLISH_DEBUG"]="0"
 names=["load","substeps","footkin","update+heights","timers","reward","reset","obs","store","rows->HBM"]
 for terrain in ("plane","heightfield"):
     cfg = make_cfg(noise=True, dr=True, push=True, terrain=terrain); N=4096
+    cfg.env.publish_rigid_body_states = False   # as bench.py
     ter = make_terrain(cfg, N, 1)
     c,keep,_ = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
     s = HipSim(c, "cuda:0", keep); s.reset_all()
@@ -25,10 +26,10 @@ for terrain in ("plane","heightfield"):
     acts=[random_actions(cfg,N,gen,1.0).cuda() for _ in range(4)]
     for i in range(40): s.step(acts[i%4],5.0,i+1)
     torch.cuda.synchronize()
-    lib=C.CDLL(PROF); buf=(C.c_longlong*(128*80))()
+    lib=C.CDLL(PROF); buf=(C.c_longlong*(256*80))()
     lib.grx_debug_profile.argtypes=[C.c_void_p, C.c_void_p, C.c_int]
-    nb=lib.grx_debug_profile(s._h, buf, 128)
-    full=np.array(buf[:],dtype=np.int64).reshape(128,80)[:nb]
+    nb=lib.grx_debug_profile(s._h, buf, 256)
+    full=np.array(buf[:],dtype=np.int64).reshape(256,80)[:nb]
     a=full[:,:11]
     print('   wave 0, sum over 10 sub-steps:', dict(zip(['wait bias forces','-','wait foot / rare contacts','wait self-collision','-','whole sub-steps'], np.median(full[:,16:22],axis=0).astype(int).tolist())))
     print('   helper waves (idle waiting for state, total) cycles:', {f"wave{w}": np.median(full[:,22+2*w:24+2*w],axis=0).astype(int).tolist() for w in (1,2,3)})

@@ -20,6 +20,9 @@
 extern "C" {
 void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                      const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream);
+void grx_launch_step_quad(const KParams* dP, int N, int heightfield, const float* actions, float delay, long long common_step,
+                          const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream);
+int grx_envs_per_block_quad(void);
 void grx_launch_finalize(const KParams* dP, long long seq, long long* progress, long long ticket, hipStream_t stream);
 void grx_launch_ticket(long long* progress, long long ticket, hipStream_t stream);
 int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int lds_bytes, int heightfield, const float* actions,
@@ -85,6 +88,7 @@ struct grx_sim {
     int device = 0;
     int N = 0;
     int waves = 1;         // waves per 32-env block of the step kernel (1, 2 or 4)
+    bool quad = false;     // four waves, a lane quad per env, 16 envs per block (grx_quad.hip): while the blocks fit the CUs in one round
     bool generic = false;  // model outside the fast kernel's lower-limb topology: generic-tree kernel (grx_generic.h)
     int nd = GRX_ND;
     void* d_gen = nullptr; // GenTables (device)
@@ -559,6 +563,12 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
             const int v = atoi(w);
             if (v == 1 || v == 2 || v == 4) s->waves = v;
         }
+        // a lane QUAD per env, 16 envs per block: one block per CU needs all of the CU (four SIMDs' registers, 100+ KB of LDS),
+        // so this layout pays exactly while its blocks fit the device in ONE round -- half the CUs would otherwise idle
+        const int qblocks = (c.num_envs + grx_envs_per_block_quad() - 1) / grx_envs_per_block_quad();
+        s->quad = !generic && s->waves == 4 && qblocks <= prop.multiProcessorCount && !getenv("GRX_WAVES_PER_BLOCK");
+        if (const char* q = getenv("GRX_LANES_PER_ENV")) s->quad = !generic && atoi(q) == 4;   // tests / A-B runs: 2 or 4
+        if (s->quad) s->waves = 4;
     }
     const char* dbg = getenv("GRX_PUBLISH_DEBUG");   // (tools/: overrides the config either way)
     P.publish_debug = dbg ? atoi(dbg) : c.publish_reward_terms;
@@ -624,7 +634,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     const int nblocks = (c.num_envs + grx_envs_per_block() - 1) / grx_envs_per_block();
     P.stat_stride = 2 * nblocks + 1;   // generic kernel: down to 16 envs per block
     DA(stat_partial, (size_t)2 * NSTAT * P.stat_stride); DA(stat_nblocks, 2); DA(stat_hist, (size_t)GRX_STATS_HISTORY * NSTAT);
-    DA(stats, NSTAT); DA(prof, (size_t)nblocks * GRX_PROF_SLOTS);
+    DA(stats, NSTAT); DA(prof, (size_t)2 * nblocks * GRX_PROF_SLOTS);   // (16-env blocks in the quad layout)
     rc = dalloc(s, &s->d_mask, N);
     if (rc) { grx_destroy(s); return rc; }
     P.publish_rbs = c.publish_rigid_body_states && !generic;   // (the generic-tree kernel does not publish link frames yet)
@@ -837,7 +847,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     desc_soa3(s, GRX_T_CONTACT_FORCES, P.contact_forces, GRX_MAX_LINKS, 3);
     desc_soa3(s, GRX_T_RIGID_BODY_STATES, P.rbs, GRX_MAX_LINKS, 13);
     if (!P.publish_rbs) s->desc[GRX_T_RIGID_BODY_STATES].data = nullptr;
-    s->prof_host = P.prof; s->prof_blocks = nblocks;
+    s->prof_host = P.prof; s->prof_blocks = s->quad ? (c.num_envs + grx_envs_per_block_quad() - 1) / grx_envs_per_block_quad() : nblocks;
     // generic kernel: the per-body workspace goes to LDS when 16 envs' rows fit (155 KB for the 33-body robot: LDS round
     // trips are ~5x shorter than global ones and the kernel is bound by exactly those); else 64 envs per block over the
     // global workspace.  GRX_GENERIC_EPB = 16 / 32 / 64 forces a block size over the GLOBAL workspace (A/B runs).
@@ -987,8 +997,12 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
             return fail(GRX_ERR_HIP, "grx_step: cannot raise the dynamic LDS limit of the generic kernel");
     }
     else
-        grx_launch_step(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
-                        (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st);
+    {
+        if (s->quad) grx_launch_step_quad(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
+                                          (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st);
+        else grx_launch_step(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
+                             (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st);
+    }
     if (timed) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->timing.pending.push_back(ev);

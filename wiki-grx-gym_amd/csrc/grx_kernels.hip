@@ -57,7 +57,7 @@ namespace {
 constexpr int NT = GRX_NUM_REWARD_TERMS;
 constexpr int NSTAT = GRX_NSTAT;
 constexpr int LEG = GRX_LEG;
-constexpr int EPB = 32;  // envs per block (one wave64 = 32 lane pairs)
+constexpr int EPB = 64 / LPE;  // envs per block: one wave64 = 32 lane pairs (16 lane quads in grx_quad.hip)
 
 // ---- episode statistics (extras["episode"], legged_robot.py:387-388, 420-428) without a kernel of their own -----------------
 // Every kernel that finishes episodes (step, reset, debug step) leaves per-block partial sums in the table of its launch parity
@@ -374,6 +374,38 @@ GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, fl
     FootProbe fp;
     foot_probe<HF>(P, C, K, O, hmax, fp);
     foot_contacts<HF>(P, C, K, O, mu, hmax, st, fa, fl, om_e, fp);
+}
+
+// LPE == 4: the two lanes of a leg take two foot spheres each -- lane `half` the spheres 2 half, 2 half + 1 of the foot's table,
+// read from the LDS copy of the table (lane-dependent index); their friction anchors live in the lane's slots 0, 1
+struct FootProbeQ { bool reach; V3 xr[2]; TerrainRaw raw[2]; };
+template <bool HF>
+GRX_DEV void foot_probe_q(KP P, const SideConst& C, const SideConst& Clds, int half, const ChainKin& K, V3 O, float hmax, FootProbeQ& fp) {
+    constexpr int o = kSphOff[LEG - 1];
+    fp.reach = group_within_reach<4>(&C.sph[o], K.R, K.rho, O, hmax);
+    if (fp.reach) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const SphC& S = Clds.sph[o + 2 * half + j];
+            fp.xr[j] = K.rho + rot(K.R, v3(S.x, S.y, S.z));
+            terrain_gather<HF>(P, O.x + fp.xr[j].x, O.y + fp.xr[j].y, fp.raw[j]);
+        }
+    }
+}
+template <bool HF>
+GRX_DEV void foot_contacts_q(KP P, const SideConst& Clds, int half, const ChainKin& K, V3 O, float mu, float hmax, LaneState& st,
+                             V3& fa, V3& fl, float om_e, const FootProbeQ& fp) {
+    fa = v3(0.f, 0.f, 0.f); fl = v3(0.f, 0.f, 0.f);
+    constexpr int o = kSphOff[LEG - 1];
+    if (fp.reach) {
+        TerrainAt th[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) th[j].h = terrain_eval<HF>(P, fp.raw[j], th[j].gx, th[j].gy);
+        V3 F;
+        F = sphere_contact<HF, 0>(P, Clds.sph[o + 2 * half + 0], K.w, K.v, O, mu, hmax, st, fp.xr[0], th[0], om_e); fa = fa + cross(fp.xr[0], F); fl = fl + F;
+        F = sphere_contact<HF, 1>(P, Clds.sph[o + 2 * half + 1], K.w, K.v, O, mu, hmax, st, fp.xr[1], th[1], om_e); fa = fa + cross(fp.xr[1], F); fl = fl + F;
+        fa = half_sum(fa); fl = half_sum(fl);   // the foot's wrench: both halves
+    } else st.anchor_on = 0;
 }
 
 #include "grx_rare.h"
@@ -779,18 +811,18 @@ GRX_DEV float height_sample(KP P, const KTables& T, float zn, float wn, V3 pos, 
     return (float)h * P.vertical_scale;
 }
 
-// One lane's share of the height scan: points k = first, first + 2*NW, ... (NW waves x 2 lanes per env); raw heights
+// One lane's share of the height scan: points k = first, first + LPE*NW, ... (NW waves x LPE lanes per env); raw heights
 // parked in the env's pri_obs staging row; returns the lane's partial sum.  Batches of 8 independent gathers.
 template <int NW>
 GRX_DEV float height_scan_share(KP P, const KTables& T, float zn, float wn, V3 pos, int first, int nh, float* prow) {
     float hsum = 0.f;
-    for (int k0 = first; k0 < nh; k0 += 16 * NW) {
+    for (int k0 = first; k0 < nh; k0 += 8 * LPE * NW) {
         float hb[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hb[j] = height_sample(P, T, zn, wn, pos, min(k0 + 2 * NW * j, nh - 1));
+        for (int j = 0; j < 8; ++j) hb[j] = height_sample(P, T, zn, wn, pos, min(k0 + LPE * NW * j, nh - 1));
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = k0 + 2 * NW * j;
+            const int k = k0 + LPE * NW * j;
             if (k < nh) { prow[GRX_NUM_OBS + 8 + k] = hb[j]; hsum += hb[j]; }
         }
     }
@@ -863,7 +895,9 @@ GRX_DEV void noise_blocks(KP P, uint32_t genv, uint32_t step, int side, U4 nzb[N
     for (int b = 0; b < NZB; ++b) { nzb[b].x = c0[b]; nzb[b].y = c1[b]; nzb[b].z = c2[b]; nzb[b].w = c3[b]; }
 }
 
+#ifndef GRX_QUAD_TU
 #include "grx_generic.h"
+#endif
 
 }  // namespace
 
@@ -1030,7 +1064,7 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
         r[GRX_REW_TERMINATION] = (reset && !time_out) ? 1.f : 0.f;
     }
     float rew = 0.f;
-    const bool writer = act && side == 0;
+    const bool writer = act && side == 0 && lane_half(lane) == 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         float rt = 0.f;
@@ -1117,15 +1151,16 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     constexpr int OBS_BYTES = EPB * GRX_NUM_OBS * 4, PRI_BYTES = EPB * PRS * 4, RW_BYTES = W == 4 ? REWIN_FLOATS * 64 * 4 : 0;
     constexpr int POST_BYTES = OBS_BYTES + PRI_BYTES + RW_BYTES, PHYS_BYTES = (W == 2 ? 2 : 1) * RC_BYTES;
     static_assert(OBS_BYTES % 16 == 0 && PRI_BYTES % 16 == 0 && RC_BYTES % 16 == 0, "arena pieces must stay 16-byte aligned");
-    __shared__ __attribute__((aligned(16))) char s_arena[POST_BYTES > PHYS_BYTES ? POST_BYTES : PHYS_BYTES];
+    constexpr int FOOTFR_BYTES = RC_FR4 * 64 * 16, ANCH_BYTES = 13 * 64 * 4;
+    constexpr int TAIL_BYTES = W == 4 ? PHYS_BYTES + FOOTFR_BYTES + ANCH_BYTES : PHYS_BYTES;
+    __shared__ __attribute__((aligned(16))) char s_arena[POST_BYTES > TAIL_BYTES ? POST_BYTES : TAIL_BYTES];
     float* const s_obs = reinterpret_cast<float*>(s_arena);
     float* const s_pri = reinterpret_cast<float*>(s_arena + OBS_BYTES);
     float* const s_rw = reinterpret_cast<float*>(s_arena + OBS_BYTES + PRI_BYTES);   // reward inputs (wave 0 -> waves 1, 3), W == 4
     // final friction anchors of the step (W == 4: wave 2 -> wave 0 across the barrier that ends the sub-steps): behind the
-    // compaction buffers, inside what becomes s_rw only after wave 0 has picked them up
+    // compaction buffers (32 envs per block: inside what becomes s_rw only after wave 0 has picked them up)
     // W == 4, same tail: the foot frames wave 2 publishes for the self-collision on wave 1 (sub-steps only), then s_anch
-    constexpr int FOOTFR_BYTES = RC_FR4 * 64 * 16;
-    static_assert(W != 4 || (PHYS_BYTES >= OBS_BYTES + PRI_BYTES && PHYS_BYTES + FOOTFR_BYTES + 13 * 64 * 4 <= POST_BYTES), "foot frames + s_anch must sit in the arena's tail");
+    static_assert(W != 4 || PHYS_BYTES >= OBS_BYTES + PRI_BYTES, "foot frames + s_anch must sit behind the staging rows, in the arena's tail");
     float4* const s_footfr = reinterpret_cast<float4*>(s_arena + PHYS_BYTES);
     float* const s_anch = reinterpret_cast<float*>(s_arena + PHYS_BYTES + FOOTFR_BYTES);
     __shared__ float s_stat[NSTAT];
@@ -1158,9 +1193,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     // the previous launch's episode statistics (and its ticket): on the wave that starts its sub-steps by waiting anyway
     if (wv == W - 1) stats_fold_previous(P, sq, tid & 63);
     const int N = P.N;
-    const int lane = tid & 63, el = lane >> 1, side = lane & 1;
+    const int lane = tid & 63, el = lane_env(lane), side = lane_side(lane), half = lane_half(lane);
     const int e_raw = blockIdx.x * EPB + el;
     const bool act = e_raw < N;
+    const bool act0 = act && half == 0;   // the lane of a leg that stores the leg's outputs (LPE == 4: both halves hold them)
     const int e = act ? e_raw : N - 1;
     const SideConst& C = s_tab.side[side];
     const uint32_t genv = (uint32_t)(P.env_offset + e);
@@ -1208,21 +1244,27 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                                   }
                               });
             } else if (wv == 2) {
+                // (LPE == 4: this lane owns the foot spheres 2 half, 2 half + 1 -- slots 0, 1 here -- and parks them at the leg's first lane)
+                constexpr int NA = 4 / LPL;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    hs.ax[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 0) * N + e];
-                    hs.ay[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e];
-                    hs.vimp[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e];   // 0: no contact; else the contact's approach speed
+                for (int i = 0; i < NA; ++i) {
+                    const int gi = NA * half + i;
+                    hs.ax[i] = P.anchors[(size_t)((side * 4 + gi) * 3 + 0) * N + e];
+                    hs.ay[i] = P.anchors[(size_t)((side * 4 + gi) * 3 + 1) * N + e];
+                    hs.vimp[i] = P.anchors[(size_t)((side * 4 + gi) * 3 + 2) * N + e];   // 0: no contact; else the contact's approach speed
                     if (hs.vimp[i] != 0.0f) hs.anchor_on |= (1u << i);
                 }
-                chain_contact_loop<HF>(P, GRX_HELPER_C, RB, s_footfr, mu, hmax, 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]), hs, L, lane, el, side);
-                float* a_ = s_anch + lane;
+                chain_contact_loop<HF>(P, GRX_HELPER_C, C, RB, s_footfr, mu, hmax, 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]), hs, L, lane, el, side);
+                float* a_ = s_anch + (lane - half);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { a_[i * 64] = hs.ax[i]; a_[(4 + i) * 64] = hs.ay[i]; a_[(9 + i) * 64] = hs.vimp[i]; }
-                a_[8 * 64] = __uint_as_float(hs.anchor_on);
+                for (int i = 0; i < NA; ++i) { const int gi = NA * half + i; a_[gi * 64] = hs.ax[i]; a_[(4 + gi) * 64] = hs.ay[i]; a_[(9 + gi) * 64] = hs.vimp[i]; }
+                {
+                    const uint32_t mine = hs.anchor_on << (NA * half);
+                    a_[8 * 64] = __uint_as_float(LPL == 1 ? mine : (mine | __float_as_uint(half_swap(__uint_as_float(mine)))));
+                }
             } else {
                 base_contact_loop<HF>(P, s_tab, GRX_HELPER_C, RB, mu, hmax, bm, bc, bI, L, lane, el, side,
-                                      LinkForceOut{true, act ? P.contact_forces + e : nullptr, (size_t)N}, s_tp);
+                                      LinkForceOut{true, act0 ? P.contact_forces + e : nullptr, (size_t)N}, s_tp);
             }
             float es_w1[NT], es_w3[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
             if (wv == 1) load_episode_sums<1>(P, e, N, es_w1);
@@ -1231,8 +1273,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             if (HF && P.measure_heights) {   // this wave's quarter of the height scan (legged_robot.py:1235-1274)
                 const float* hp = s_hp + el;
                 s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
-                                                              2 * wv + side, nh, s_pri + el * PRS);
-                __syncthreads();   // height scan complete
+                                                              LPE * wv + (lane & (LPE - 1)), nh, s_pri + el * PRS);
+                lds_barrier();   // height scan complete (raw heights and partial sums are in LDS: this wave's row stores of the last sub-step stay in flight)
             }
             if (wv == 2) {   // reset_idx's uniform draws, ready before wave 0 knows who resets
                 const ResetRand rr = reset_rand(P, genv, step, side);
@@ -1266,9 +1308,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 if (wv == 2) GRX_TICKW(30);
                 const bool have_raw = HF && P.measure_heights;
                 float* hrow = s_pri + el * PRS;
-                const float part = wv == 2 ? obs_heights_share<4>(P, s_hp[el], side, nh, hrow, have_raw, act, e, N)
-                                           : obs_heights_share<8>(P, s_hp[el], (wv == 1 ? 2 : 6) + side, nh, hrow, have_raw, act, e, N);
-                s_hsum[wv * 64 + lane] = pair_sum(part);
+                const int li = lane & (LPE - 1);   // of every 4 LPE consecutive points: wave 2 takes the first 2 LPE, waves 1 and 3 LPE each
+                const float part = wv == 2 ? obs_heights_share<2 * LPE>(P, s_hp[el], li, nh, hrow, have_raw, act, e, N)
+                                           : obs_heights_share<4 * LPE>(P, s_hp[el], (wv == 1 ? LPE : 3 * LPE) + li, nh, hrow, have_raw, act, e, N);
+                s_hsum[wv * 64 + lane] = env_sum(part);
                 flag_set(s_flag + FL_BHO1 + (wv - 1), 1, lane);
                 if (wv == 2) GRX_TICKW(31);
             }
@@ -1278,7 +1321,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 const float fq[LEG] = {q0_.x, q0_.y, q0_.z, q0_.w, q1_.x}, fqd[LEG] = {q1_.y, q1_.z, q1_.w, q2_.x, q2_.y};
                 const float rq[4] = {b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]};
                 publish_rigid_body_states(P, C, side, v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]), rq, v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]),
-                                          v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]), fq, fqd, e, N, act);
+                                          v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]), fq, fqd, e, N, act0);
             }
         } else {
             for (int deci = 0; deci < P.decimation; ++deci) {
@@ -1401,9 +1444,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             t *= LC.strength[k];
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
-        if (W == 4) substep_p<HF>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc, C);
+        if (W == 4 && LPL == 2) substep_q<HF>(P, Cr, LC, st, torque, so, fk, L, lane, deci, tacc, C);
+        else if (W == 4) substep_p<HF>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc, C);
         else substep<HF, W>(P, s_tab, C, LC, st, torque, so, fk, s_wr + lane, tacc,
-                            LinkForceOut{deci == P.decimation - 1, act ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side, self_near, deci == 0);
+                            LinkForceOut{deci == P.decimation - 1, act0 ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side, self_near, deci == 0);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
             avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
         }
@@ -1413,7 +1457,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     const float yaw_z = st.qz / yaw_n, yaw_w = st.qw / yaw_n;
     if (W < 4 && !DBG && P.publish_rbs) {
         const float rq[4] = {st.qx, st.qy, st.qz, st.qw};
-        publish_rigid_body_states(P, C, side, st.pos, rq, st.vel, st.ang, st.q, st.qd, e, N, act);
+        publish_rigid_body_states(P, C, side, st.pos, rq, st.vel, st.ang, st.q, st.qd, e, N, act0);
     }
     if (W == 4) {   // the foot wave owned the friction anchors during the sub-steps
         if (side == 0) { float* hp = s_hp + el; hp[0 * EPB] = st.pos.x; hp[1 * EPB] = st.pos.y; hp[2 * EPB] = yaw_z; hp[3 * EPB] = yaw_w; }
@@ -1430,7 +1474,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             s_q[128 + lane] = f4(st.qd[3], st.qd[4], 0.f, 0.f);
         }
         lds_barrier();   // final friction anchors + height-scan pose published (the last sub-step's row stores stay in flight)
-        const float* a_ = s_anch + lane;
+        const float* a_ = s_anch + (lane - half);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { st.ax[i] = a_[i * 64]; st.ay[i] = a_[(4 + i) * 64]; st.vimp[i] = a_[(9 + i) * 64]; }
         st.anchor_on = __float_as_uint(a_[8 * 64]);
@@ -1481,11 +1525,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     float hsum = 0.f;
     if (HF && P.measure_heights) {
         if (W == 4) {   // quarter of the scan here, the other three quarters on the helper waves
-            hsum = height_scan_share<4>(P, s_tab, yaw_z, yaw_w, st.pos, side, nh, prow);
-            __syncthreads();   // height scan complete
+            hsum = height_scan_share<4>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
+            lds_barrier();   // height scan complete
             hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane];
-        } else hsum = height_scan_share<1>(P, s_tab, yaw_z, yaw_w, st.pos, side, nh, prow);
-        hsum = pair_sum(hsum);
+        } else hsum = height_scan_share<1>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
+        hsum = env_sum(hsum);
     }
     if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {  // legged_robot.py:786-797
         st.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
@@ -1527,7 +1571,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             flag_set(s_flag + FL_REW, 1, lane);
         } else reward_and_sums<0>(P, C, rin, lane, side, e, N, act, s_stat, es_early, nullptr, nullptr, DBG ? a_ll : nullptr, DBG && !dbg_apply_reset);
     }
-    const bool writer = act && side == 0;
+    const bool writer = act0 && side == 0;
     GRX_TICK(6);
     // ---- reset_idx (masked, in-kernel)
     const bool do_reset = DBG ? (reset && dbg_apply_reset) : reset;   // the debug entry may report a reset without applying it
@@ -1553,7 +1597,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     }
     const bool feet_contact_obs = do_reset ? false : contact;  // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
     {   // statistics row NT + 1: terrain levels AFTER this step's curriculum moves (legged_robot.py:427-428)
-        const float ls = level_sum(ea.level, act && side == 0);
+        const float ls = level_sum(ea.level, writer);
         if (lane == 0) s_stat[NT + 1] = ls;
     }
 
@@ -1564,7 +1608,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
         if (side == 0) s_hp[el] = st.pos.z;
         flag_set(s_flag + FL_HZ, 1, lane);
     } else {
-        const float sum = pair_sum(obs_heights_share<2>(P, st.pos.z, side, nh, prow, HF && P.measure_heights, act, e, N));
+        const float sum = env_sum(obs_heights_share<LPE>(P, st.pos.z, lane & (LPE - 1), nh, prow, HF && P.measure_heights, act, e, N));
         bho = nh > 0 ? sum / (float)nh : 0.f;
     }
     GRX_TICK(11);
@@ -1625,7 +1669,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
 
     GRX_TICK(8);
     // ---- store state (SoA) -- history: last_actions = actions, last_dof_vel = dof_vel (legged_robot.py:299-300)
-    if (act) {
+    if (act0) {
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {
             size_t o = (size_t)(j0 + k) * N + e;
@@ -1681,7 +1725,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     GRX_TICK(9);
     }   // dynamics wave
     // ---- coalesced AoS output rows (all waves): the block's 32 obs / pri_obs rows are contiguous in HBM
-    __syncthreads();
+    // (the rows and the statistics are staged in LDS: an LDS-only barrier -- a full one would drain every wave's state stores first,
+    //  measured 14 k cycles here)
+    lds_barrier();
     {
         const int e0 = blockIdx.x * EPB;
         const int nenv = min(EPB, N - e0);
@@ -1713,6 +1759,17 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     GRX_TICK(10);
 }
 
+#ifdef GRX_QUAD_TU
+// grx_quad.hip: this translation unit built with GRX_LPE = 4 -- the four-wave step kernel with a lane QUAD per env, 16 envs per
+// block: at <= 16 envs per CU (4096 envs on an MI355X) every CU gets a block instead of every other one
+extern "C" void grx_launch_step_quad(const KParams* dP, int N, int heightfield, const float* actions, float delay, long long common_step,
+                                     const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {
+    const int nblocks = (N + EPB - 1) / EPB;
+    if (heightfield) hipLaunchKernelGGL((grx_step_kernel<true, 4>), dim3(nblocks), dim3(256), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out, *sq);
+    else hipLaunchKernelGGL((grx_step_kernel<false, 4>), dim3(nblocks), dim3(256), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out, *sq);
+}
+extern "C" int grx_envs_per_block_quad(void) { return EPB; }
+#else
 // extras["episode"] (legged_robot.py:420-428) ON DEMAND: the reduction stats_fold_previous would do in the handle's next launch,
 // for the launch `seq`, now (grx_flush_stats / grx_episode_stats; the generic-tree kernel's step still ends with it).  The next
 // launch repeats it with the same result.  ONE block, a wave per statistics row (round-robin); its ticket store comes after
@@ -1898,3 +1955,4 @@ extern "C" void grx_launch_set_state(const KParams* dP, int N, const float* root
     hipLaunchKernelGGL(grx_set_state_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, dP, root, q, qd, env_ids, n);
 }
 extern "C" int grx_envs_per_block(void) { return EPB; }
+#endif   // GRX_QUAD_TU

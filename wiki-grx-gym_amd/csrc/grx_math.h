@@ -122,11 +122,29 @@ GRX_DEV R3 joint_rot(const R3& P, float c, float s) {
 template <int AX>
 GRX_DEV V3 axis_of(const R3& R) { return AX == 0 ? R.cx : (AX == 1 ? R.cy : R.cz); }
 
-// adjacent-lane exchange (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS traffic
-GRX_DEV float pair_swap(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-}
+// ---- lane <-> env mapping ------------------------------------------------------------------------------------------------
+// GRX_LPE lanes per env.  2 (default): lane 2e = left leg, 2e + 1 = right leg.  4 (grx_quad.hip, <= 16 envs per CU): a lane PAIR
+// per leg -- lanes 4e, 4e + 1 the left leg, 4e + 2, 4e + 3 the right one; the two lanes of a leg ("halves") split its work.
+// Everything below is one DPP quad_perm step away: no LDS traffic.
+#ifndef GRX_LPE
+#define GRX_LPE 2
+#endif
+constexpr int LPE = GRX_LPE, LPL = GRX_LPE / 2;   // lanes per env, lanes per leg
+static_assert(LPE == 2 || LPE == 4, "one lane or a lane pair per leg");
+GRX_DEV int lane_env(int lane) { return lane / LPE; }
+GRX_DEV int lane_side(int lane) { return (lane / LPL) & 1; }
+GRX_DEV int lane_half(int lane) { return lane & (LPL - 1); }
+template <int CTRL>
+GRX_DEV float quad_perm(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)); }
+// the same half of the env's OTHER leg
+GRX_DEV float pair_swap(float v) { return quad_perm<LPE == 2 ? 0xB1 : 0x4E>(v); }   // quad_perm [1,0,3,2] / [2,3,0,1]
+// the other half of the same leg (LPE == 4)
+GRX_DEV float half_swap(float v) { return LPE == 2 ? v : quad_perm<0xB1>(v); }
+GRX_DEV float half_sum(float v) { return LPE == 2 ? v : v + quad_perm<0xB1>(v); }
 GRX_DEV float pair_sum(float v) { return v + pair_swap(v); }
+GRX_DEV float env_sum(float v) { return pair_sum(half_sum(v)); }   // over all lanes of the env
+GRX_DEV V3 half_sum(V3 v) { return v3(half_sum(v.x), half_sum(v.y), half_sum(v.z)); }
+GRX_DEV V3 half_swap(V3 v) { return v3(half_swap(v.x), half_swap(v.y), half_swap(v.z)); }
 GRX_DEV V3 pair_sum(V3 v) { return v3(pair_sum(v.x), pair_sum(v.y), pair_sum(v.z)); }
 GRX_DEV S3 pair_sum(const S3& a) {
     S3 r = {pair_sum(a.xx), pair_sum(a.xy), pair_sum(a.xz), pair_sum(a.yy), pair_sum(a.yz), pair_sum(a.zz)};

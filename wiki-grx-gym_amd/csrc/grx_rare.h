@@ -98,35 +98,43 @@ GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const Rar
     R3 R2 = K2in.R, R3_ = K3in.R;
     V3 rho2 = K2in.rho, rho3 = K3in.rho;
     uint32_t m = 0;
+    // LPE == 4: the two lanes of a leg hold the same table; each tests (and later sums) the shapes of its own parity -- shape
+    // i0 + half, read from the LDS copy of the table (lane-dependent index); the carrying body is the same for both (i0 even)
+    constexpr int ST = LPL;
+    static_assert(ST == 1 || (S0 % 2 == 0 && S1 % 2 == 0), "shape ranges split by parity");
+    const int hf_ = lane_half(lane);
+    const SideConst& Ct = ST == 1 ? C : T.side[side];
     auto test_range = [&](const int a, const int b) {   // shapes [a, b): cheap test, then the exact one for the wave's survivors
         uint32_t mc = 0;
 #pragma unroll
-        for (int i = S0; i < S1; ++i) {
-            if (i < a || i >= b) continue;
-            const R3& R = i < 8 ? R0 : (i < 10 ? R2 : R3_);
-            const float rz = i < 8 ? 0.f : (i < 10 ? rho2.z : rho3.z);
-            const SphC& S = C.sph[i];
+        for (int i0 = S0; i0 < S1; i0 += ST) {
+            if (i0 < a || i0 >= b) continue;
+            const int i = ST == 1 ? i0 : i0 + hf_;
+            const R3& R = i0 < 8 ? R0 : (i0 < 10 ? R2 : R3_);
+            const float rz = i0 < 8 ? 0.f : (i0 < 10 ? rho2.z : rho3.z);
+            const SphC& S = Ct.sph[i];
             const float z = O.z + rz + fmaf(R.cx.z, S.x, fmaf(R.cy.z, S.y, R.cz.z * S.z));
             if (z - S.r <= hmax) mc |= 1u << i;
         }
         if (HF && __any(mc != 0u)) {
             float zb[S1 - S0];   // bottom of the shape minus the local bound
 #pragma unroll
-            for (int i = S0; i < S1; ++i) {   // all loads of the wave in flight together
-                if (i < a || i >= b) continue;
-                const R3& R = i < 8 ? R0 : (i < 10 ? R2 : R3_);
-                const V3 rho = i < 8 ? zero : (i < 10 ? rho2 : rho3);
-                const SphC& S = C.sph[i];
+            for (int i0 = S0; i0 < S1; i0 += ST) {   // all loads of the wave in flight together
+                if (i0 < a || i0 >= b) continue;
+                const int i = ST == 1 ? i0 : i0 + hf_;
+                const R3& R = i0 < 8 ? R0 : (i0 < 10 ? R2 : R3_);
+                const V3 rho = i0 < 8 ? zero : (i0 < 10 ? rho2 : rho3);
+                const SphC& S = Ct.sph[i];
                 const V3 xr = rho + rot(R, v3(S.x, S.y, S.z));
                 float fx = (O.x + xr.x + P.border_size) * P.inv_hscale, fy = (O.y + xr.y + P.border_size) * P.inv_hscale;
                 fx = fminf(fmaxf(fx, 0.0f), (float)(P.hf_rows - 1));
                 fy = fminf(fmaxf(fy, 0.0f), (float)(P.hf_cols - 1));
                 const int ix = min((int)fx, P.hf_rows - 2), iy = min((int)fy, P.hf_cols - 2);
-                zb[i - S0] = O.z + xr.z - S.r - (float)P.hf_max4[(size_t)ix * P.hf_cols + iy] * P.vertical_scale;
+                zb[i0 - S0] = O.z + xr.z - S.r - (float)P.hf_max4[(size_t)ix * P.hf_cols + iy] * P.vertical_scale;
             }
             uint32_t m2 = 0;
 #pragma unroll
-            for (int i = S0; i < S1; ++i) if (i >= a && i < b && zb[i - S0] <= 1e-4f) m2 |= 1u << i;
+            for (int i0 = S0; i0 < S1; i0 += ST) if (i0 >= a && i0 < b && zb[i0 - S0] <= 1e-4f) m2 |= 1u << (ST == 1 ? i0 : i0 + hf_);
             mc &= m2;
         }
         m |= mc;
@@ -193,8 +201,8 @@ GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const Rar
             if (idx < total) {
                 const int rec = B.list[idx];
                 const int src = rec & 63, si = rec >> 6;
-                const SphC& S = T.side[src & 1].sph[si];
-                const float4* fb = B.fbase + (src >> 1);
+                const SphC& S = T.side[lane_side(src)].sph[si];
+                const float4* fb = B.fbase + lane_env(src);
                 const RareFrame Fr = si < 8 ? rare_load_frame(fb, EPB) : rare_load_frame(B.fchain + (si < 10 ? 0 : RC_FR4 * 64) + src, 64);
                 const float4 om = fb[RC_FR4 * EPB];
                 const float hmax_ = fb[4 * EPB].z;
@@ -214,6 +222,34 @@ GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const Rar
         GRX_RARE_T(3);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // ---- 4. every owner lane sums its own shapes, in table order (shapes nobody has a candidate for: scalar skip)
+        if (ST == 2) {   // own parity: all reads in one batch (one exposed LDS latency), unselected rows dropped by the lane's mask
+            float2 ra[(S1 - S0) / 2], rb[(S1 - S0) / 2], rc[(S1 - S0) / 2];
+#pragma unroll
+            for (int i0 = S0; i0 < S1; i0 += 2) {
+                const float2* r = B.res + ((i0 + hf_) * 3) * 64 + lane;
+                ra[(i0 - S0) / 2] = r[0]; rb[(i0 - S0) / 2] = r[64]; rc[(i0 - S0) / 2] = r[128];
+            }
+            V3 mine[4] = {zero, zero, zero, zero};
+#pragma unroll
+            for (int i0 = S0; i0 < S1; i0 += 2) {
+                const bool has = (m >> (i0 + hf_)) & 1u;
+                const float2 a = ra[(i0 - S0) / 2], b = rb[(i0 - S0) / 2], c = rc[(i0 - S0) / 2];
+                const V3 F = v3(has ? a.x : 0.f, has ? a.y : 0.f, has ? b.x : 0.f), Tq = v3(has ? b.y : 0.f, has ? c.x : 0.f, has ? c.y : 0.f);
+                if (i0 < 8) { out.f0a = out.f0a + Tq; out.f0l = out.f0l + F; mine[i0 / 2] = F; }
+                else if (i0 < 10) { out.fa2 = out.fa2 + Tq; out.fl2 = out.fl2 + F; }
+                else { out.fa3 = out.fa3 + Tq; out.fl3 = out.fl3 + F; }
+            }
+            out.f0a = half_sum(out.f0a); out.f0l = half_sum(out.f0l); out.fa2 = half_sum(out.fa2); out.fl2 = half_sum(out.fl2);
+            out.fa3 = half_sum(out.fa3); out.fl3 = half_sum(out.fl3);
+            if (want_links && S0 < 8 && (act & 0xffu)) {   // all eight base-lump forces in both halves, for the per-link netting
+#pragma unroll
+                for (int q_ = 0; q_ < 4; ++q_) {
+                    const V3 oth = half_swap(mine[q_]);
+                    Fs[2 * q_] = v3(hf_ ? oth.x : mine[q_].x, hf_ ? oth.y : mine[q_].y, hf_ ? oth.z : mine[q_].z);
+                    Fs[2 * q_ + 1] = v3(hf_ ? mine[q_].x : oth.x, hf_ ? mine[q_].y : oth.y, hf_ ? mine[q_].z : oth.z);
+                }
+            }
+        } else
 #pragma unroll
         for (int i = S0; i < S1; ++i) {
             if (!((act >> i) & 1u)) continue;   // scalar

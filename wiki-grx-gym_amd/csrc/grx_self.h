@@ -146,8 +146,8 @@ GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const Se
     if (__any((sn.m & 1u) != 0u)) {
         // one pass over this lane's 8 spheres: centre -> LDS row, and the leg's extent towards the other leg along the
         // base's lateral axis (the separating-plane test below)
-        const int el = lane >> 1;
-        float4* const row = SB.st + lane * SELF_ROW;
+        const int el = lane_env(lane);
+        float4* const row = SB.st + lane * SELF_ROW;   // (LPE == 4: both halves of a leg stage the same row values, each into its own row)
         const V3 yb = R0.cy;
         float ext = side == 0 ? 1e30f : -1e30f;
 #pragma unroll
@@ -168,13 +168,13 @@ GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const Se
 #endif
         const float oext = pair_swap(ext);
         const bool cand = (sn.m & 1u) && (side == 0 ? ext <= oext : oext <= ext);   // not separated (same verdict in both lanes)
-        const unsigned long long cb = __ballot(cand && side == 0);
+        const unsigned long long cb = __ballot(cand && side == 0 && lane_half(lane) == 0);
 #ifdef GRX_PROFILE_SECTIONS
         pacc[1] += __popcll(cb);
 #endif
         if (cb) {
             const int ncand = __popcll(cb);
-            if (cand && side == 0) {   // compacted list of the candidate envs; their pair masks start empty
+            if (cand && side == 0 && lane_half(lane) == 0) {   // compacted list of the candidate envs; their pair masks start empty
                 SB.envs[__popcll(cb & ((1ull << lane) - 1ull))] = (uint8_t)el;
                 SB.mask[el] = 0ull;
             }
@@ -188,8 +188,8 @@ GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const Se
                 const int ws_ = lane >> 3, sub = lane & 7;
                 if (g0 + ws_ < ncand) {
                     const int env = SB.envs[g0 + ws_];
-                    const float4* stl = SB.st + (env * 2) * SELF_ROW;
-                    const float4 b = stl[SELF_ROW + sub];
+                    const float4* stl = SB.st + (env * LPE) * SELF_ROW;   // the left leg's row; the right leg's is LPL rows on
+                    const float4 b = stl[LPL * SELF_ROW + sub];
                     unsigned long long bits = 0ull;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
@@ -215,7 +215,7 @@ GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const Se
                     const int ms = side == 0 ? sa : sb_, os = side == 0 ? sb_ : sa;   // mine, the other leg's
                     const int kb = ms < 2 ? 0 : (ms < 4 ? 1 : 2), ko = os < 2 ? 0 : (os < 4 ? 1 : 2);   // carrying chain body - 2
                     const float4* rm = SB.st + lane * SELF_ROW;
-                    const float4* ro = SB.st + (lane ^ 1) * SELF_ROW;
+                    const float4* ro = SB.st + (lane ^ LPL) * SELF_ROW;
                     const float4 m0 = rm[ms], o0 = ro[os];
                     const float4 mw = rm[8 + 2 * kb], mv = rm[9 + 2 * kb], ow = ro[8 + 2 * ko], ov = ro[9 + 2 * ko];
                     SphW ma, ob;

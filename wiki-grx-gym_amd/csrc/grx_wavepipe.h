@@ -331,6 +331,221 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// wave 0 with a lane PAIR per leg (GRX_LPE == 4): the sub-step of substep_p with every 6-vector and the 6 x 6 articulated
+// inertia split by ROWS over the two lanes of the leg.  The "lo" half owns the angular rows -- [A B], U_a, p_a, I^a c (angular) --
+// the "hi" half the linear ones -- [B^T D], U_l, p_l, I^a c (linear).  Written once in terms of a lane's OWN and the OTHER part:
+//     u_own = X s_own + Y s_oth          X = A | D (symmetric),  Y = B | B^T,  (s_own, s_oth) = (a, s) | (s, a)
+//     d     = s_own . u_own, summed over the two halves (one DPP step);  X -= u_own u_own^T / d,  Y -= u_own u_oth^T / d
+// so both lanes run the same instruction stream on half the data: every dot product of the bias, delta and acceleration
+// recursions is a 3-term product plus one quad_perm add instead of a 6-term one.  The floating-base 6 x 6 is solved in its two
+// dual Schur forms at once: lo  alpha = (A - B D^-1 B^T)^-1 (B D^-1 p_l - p_a),  hi  acc = (D - B^T A^-1 B)^-1 (B^T A^-1 p_a - p_l)
+// (substep_p eliminates acc only; the results agree to rounding).
+GRX_DEV V3 sel3(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+GRX_DEV V3 row0(const M3& B) { return v3(B.a00, B.a01, B.a02); }
+GRX_DEV V3 row1(const M3& B) { return v3(B.a10, B.a11, B.a12); }
+GRX_DEV V3 row2(const M3& B) { return v3(B.a20, B.a21, B.a22); }
+template <bool HF>
+GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
+                       SubstepOut& out, FootKin& fk_before, const PipeLds& L, int lane, int seq, long long* tacc, const SideConst& Clds) {
+    const float dt = P.sim_dt;
+    const bool hi = lane_half(lane) != 0;
+    const float sg = hi ? -1.f : 1.f;   // Y carries +skew(h) in the lo half (B), -skew(h) in the hi half (B^T)
+#ifdef GRX_PROFILE_SECTIONS
+    long long tprev = clock64();
+#endif
+    V3 So[LEG], St[LEG], co[LEG], ct[LEG], Uo[LEG], ic[LEG], hK[LEG];
+    S3 XK[LEG];
+    float dinv[LEG], uu[LEG];
+    GRX_EV(0);
+    const R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
+    {   // ---- outward walk (both halves: the chain is serial); own / other parts picked per lane
+        R3 R = R0;
+        V3 rho = v3(0.f, 0.f, 0.f), w = st.ang, v = st.vel;
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) {
+            const float qdk = st.qd[k];
+            rho = rho + rot(R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+            float sn, cs;
+            grx_sincos(st.q[k], sn, cs);
+            R = joint_rot_k(R, cs, sn, kAxis[k]);
+            const V3 a = axis_k(R, kAxis[k]);
+            const V3 s_ = cross(rho, a);
+            const V3 ca = cross(w, a) * qdk;
+            const V3 cl = (cross(v, a) + cross(w, s_)) * qdk;
+            So[k] = sel3(hi, s_, a); St[k] = sel3(hi, a, s_);
+            co[k] = sel3(hi, cl, ca); ct[k] = sel3(hi, ca, cl);
+            w = fma3(a, qdk, w); v = fma3(s_, qdk, v);
+            const V3 kap = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+            const S3 Ic = {Clds.body[k].Ic[0], Clds.body[k].Ic[1], Clds.body[k].Ic[2], Clds.body[k].Ic[3], Clds.body[k].Ic[4], Clds.body[k].Ic[5]};
+            S3 Ak;
+            rigid_inertia(R, kap, C.body[k].mass, Ic, Ak, hK[k]);
+            const float m = C.body[k].mass;
+            XK[k].xx = hi ? m : Ak.xx; XK[k].xy = hi ? 0.f : Ak.xy; XK[k].xz = hi ? 0.f : Ak.xz;
+            XK[k].yy = hi ? m : Ak.yy; XK[k].yz = hi ? 0.f : Ak.yz; XK[k].zz = hi ? m : Ak.zz;
+        }
+    }
+    GRX_EV(1);
+    // ---- inward pass, inertia half (leaf -> root), rows split over the two halves
+    S3 X = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    M3 Y = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto add_skew = [&](V3 h) {   // Y += sg * skew(h)
+        Y.a01 = fmaf(-sg, h.z, Y.a01); Y.a02 = fmaf(sg, h.y, Y.a02); Y.a10 = fmaf(sg, h.z, Y.a10);
+        Y.a12 = fmaf(-sg, h.x, Y.a12); Y.a20 = fmaf(-sg, h.y, Y.a20); Y.a21 = fmaf(sg, h.x, Y.a21);
+    };
+#pragma unroll
+    for (int k = LEG - 1; k >= 0; --k) {
+        X = X + XK[k];
+        add_skew(hK[k]);
+        const V3 u = mul(X, So[k]) + mul(Y, St[k]);
+        const float di = grx_rcp(half_sum(dot(So[k], u)));
+        const V3 uo = half_swap(u);
+        syr(X, u, di); ger(Y, u, uo, di);
+        ic[k] = mul(X, co[k]) + mul(Y, ct[k]);
+        Uo[k] = u; dinv[k] = di;
+    }
+    GRX_EV(3);
+    // base level: both legs (quad_perm [2,3,0,1]) + the base lump, both Schur complements factorised
+    X = pair_sum(X); Y = pair_sum(Y);
+    {
+        S3 A0; V3 h0;
+        rigid_inertia(R0, rot(R0, LC.base_c), LC.base_m, LC.base_I, A0, h0);
+        const float m = LC.base_m;
+        X.xx += hi ? m : A0.xx; X.xy += hi ? 0.f : A0.xy; X.xz += hi ? 0.f : A0.xz;
+        X.yy += hi ? m : A0.yy; X.yz += hi ? 0.f : A0.yz; X.zz += hi ? m : A0.zz;
+        add_skew(h0);
+    }
+    GRX_EV(14);
+    S3 Xio;   // inverse of the OTHER half's diagonal block: lo holds D^-1, hi holds A^-1
+    {
+        const S3 Xi = inv(X);
+        Xio.xx = half_swap(Xi.xx); Xio.xy = half_swap(Xi.xy); Xio.xz = half_swap(Xi.xz);
+        Xio.yy = half_swap(Xi.yy); Xio.yz = half_swap(Xi.yz); Xio.zz = half_swap(Xi.zz);
+    }
+    S3 Sci;
+    {
+        const V3 y0 = row0(Y), y1 = row1(Y), y2 = row2(Y);
+        const V3 t0 = mul(Xio, y0), t1 = mul(Xio, y1), t2 = mul(Xio, y2);
+        const S3 Sc = {X.xx - dot(y0, t0), X.xy - dot(y0, t1), X.xz - dot(y0, t2), X.yy - dot(y1, t1), X.yz - dot(y1, t2), X.zz - dot(y2, t2)};
+        Sci = inv(Sc);
+    }
+#ifdef GRX_PROFILE_SECTIONS
+    if (seq == 5 && lane == 0) { __builtin_amdgcn_sched_barrier(0); P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 79] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+#endif
+    // (keep all of the above in front of the spin-waits: see substep_p)
+    GRX_PIN(Sci.xx); GRX_PIN(Sci.xy); GRX_PIN(Sci.xz); GRX_PIN(Sci.yy); GRX_PIN(Sci.yz); GRX_PIN(Sci.zz);
+    GRX_PIN(Xio.xx); GRX_PIN(Xio.xy); GRX_PIN(Xio.xz); GRX_PIN(Xio.yy); GRX_PIN(Xio.yz); GRX_PIN(Xio.zz);
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) { GRX_PIN(ic[k].x); GRX_PIN(ic[k].y); GRX_PIN(ic[k].z); }
+    GRX_EV(2);
+    // ---- inward pass, bias half (leaf -> root): rigid-body bias forces from waves 2 / 1, own rows only.  (Folding this chain of
+    // dependent dot / DPP / fma steps into the loop above was tried: no gain -- a lone wave issues one VALU instruction per ~4.5
+    // cycles whatever its dependencies, measured with tools/micro/operand_rate.hip -- and the wait for the bias forces moves up.)
+    V3 po = v3(0.f, 0.f, 0.f);
+    GRX_WAIT(L.flag + FL_BIAS, seq * 8 + (HF ? 2 : LEG), 0);
+    if (HF) GRX_WAIT(L.flag + FL_BIAS2, seq + 1, 0);
+    float4 bq0[LEG], bq1[LEG];
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) { const float4* b_ = L.pb + (k * PB4) * 64 + lane; bq0[k] = b_[0 * 64]; bq1[k] = b_[1 * 64]; }
+#pragma unroll
+    for (int k = LEG - 1; k >= 0; --k) {
+        const float4 b0_ = bq0[k], b1_ = bq1[k];
+        po = po + sel3(hi, v3(b0_.w, b1_.x, b1_.y), v3(b0_.x, b0_.y, b0_.z));
+        const float u = (tau_m[k] + b1_.z) - half_sum(dot(So[k], po));   // motor torque + joint-limit spring/damper - S . p
+        uu[k] = u;
+        po = po + ic[k] + Uo[k] * (u * dinv[k]);
+    }
+    GRX_EV(7);
+    // ---- contact wrenches on chain bodies 4, 3, 2: delta recursion on the own rows
+    GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
+    GRX_EV(4);
+    GRX_WAIT(L.flag + FL_LEGS, seq + 1, 2);
+    GRX_EV(5);
+    GRX_WAIT(L.flag + FL_SELF, seq + 1, 3);
+    V3 sco[3], sc0o;   // self-collision wrenches (wave 1), own rows
+    V3 scfl2;          // ... and the force on the foot link
+    {
+        const float4* c = L.wc + 7 * 64 + lane;
+        const float4 s0 = c[0 * 64], s1 = c[1 * 64], s2 = c[2 * 64], s3 = c[3 * 64], s4 = c[4 * 64], s5 = c[5 * 64];
+        sco[0] = sel3(hi, v3(s0.w, s1.x, s1.y), v3(s0.x, s0.y, s0.z));
+        sco[1] = sel3(hi, v3(s2.y, s2.z, s2.w), v3(s1.z, s1.w, s2.x));
+        scfl2 = v3(s3.w, s4.x, s4.y);
+        sco[2] = sel3(hi, scfl2, v3(s3.x, s3.y, s3.z));
+        sc0o = sel3(hi, v3(s5.y, s5.z, s5.w), v3(s4.z, s4.w, s5.x));
+    }
+    {
+        V3 dlt = v3(0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = LEG - 1; k >= 0; --k) {
+            if (k >= 2) {
+                const float4* c = L.wc + ((k - 2) * 2) * 64 + lane;
+                const float4 c0_ = c[0 * 64], c1_ = c[1 * 64];
+                const V3 fl = v3(c0_.w, c1_.x, c1_.y);
+                dlt = dlt - sel3(hi, fl, v3(c0_.x, c0_.y, c0_.z)) - sco[k - 2];
+                if (k == LEG - 1) { const float4 c2_ = c[2 * 64]; out.foot_force = fl + scfl2; fk_before.vel = v3(c1_.z, c1_.w, c2_.x); }
+            }
+            const float du = -half_sum(dot(So[k], dlt));
+            uu[k] += du;
+            dlt = fma3(Uo[k], du * dinv[k], dlt);
+        }
+        po = po + dlt;
+    }
+    {   // base-lump contact wrench + flags (published together with the thigh / shank wrenches: FL_LEGS)
+        const float4 w0_ = L.wr[lane], w1_ = L.wr[64 + lane];
+        out.term = w1_.z != 0.f;
+        out.pen_count = w1_.w;
+        po = po - sel3(hi, v3(w0_.w, w1_.x, w1_.y), v3(w0_.x, w0_.y, w0_.z)) - sc0o;
+    }
+    po = pair_sum(po);
+    {   // base-lump bias force (wave 3; the lanes of both legs add the same value after the leg sum)
+        GRX_WAIT(L.flag + FL_BASEBIAS, seq + 1, 0);
+        const float4* b_ = L.pb + (LEG * PB4) * 64 + lane;
+        const float4 b0_ = b_[0 * 64], b1_ = b_[1 * 64];
+        po = po + sel3(hi, v3(b0_.w, b1_.x, b1_.y), v3(b0_.x, b0_.y, b0_.z));
+    }
+    // lo: alpha = Sa^-1 (B D^-1 p_l - p_a);  hi: acc = Sd^-1 (B^T A^-1 p_a - p_l)
+    const V3 xo = mul(Sci, mul(Y, mul(Xio, half_swap(po))) - po);
+    // ---- pass 3 (root -> leaf): accelerations, own rows
+    float qdd[LEG];
+    {
+        V3 ao = xo;
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) {
+            const V3 p_ = ao + co[k];
+            const float qd2 = (uu[k] - half_sum(dot(Uo[k], p_))) * dinv[k];
+            qdd[k] = qd2;
+            ao = fma3(So[k], qd2, p_);
+        }
+    }
+    // ---- integrate (semi-implicit Euler), both halves alike
+    const V3 xt = half_swap(xo);
+    const V3 alpha = sel3(hi, xt, xo), acc = sel3(hi, xo, xt);
+    const V3 lin = acc + cross(st.ang, st.vel);  // classical acceleration of the base origin
+    st.vel = v3(st.vel.x + (lin.x + P.gravity[0]) * dt, st.vel.y + (lin.y + P.gravity[1]) * dt, st.vel.z + (lin.z + P.gravity[2]) * dt);
+    st.ang = fma3(alpha, dt, st.ang);
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        float vq = fmaf(qdd[k], dt, st.qd[k]);
+        vq = fminf(fmaxf(vq, -Clds.body[k].vlim), Clds.body[k].vlim);
+        st.qd[k] = vq;
+        st.q[k] = fmaf(vq, dt, st.q[k]);
+    }
+    st.pos = fma3(st.vel, dt, st.pos);
+    const float hx = 0.5f * dt * st.ang.x, hy = 0.5f * dt * st.ang.y, hz = 0.5f * dt * st.ang.z;
+    const float x = st.qx, y = st.qy, z = st.qz, ww = st.qw;
+    const float nx = x + hx * ww + hy * z - hz * y;
+    const float ny = y - hx * z + hy * ww + hz * x;
+    const float nz = z + hx * y - hy * x + hz * ww;
+    const float nw = ww - hx * x - hy * y - hz * z;
+    const float n = grx_rsq(nx * nx + ny * ny + nz * nz + nw * nw);
+    st.qx = nx * n; st.qy = ny * n; st.qz = nz * n; st.qw = nw * n;
+    GRX_EV(6);
+#ifdef GRX_PROFILE_SECTIONS
+    if (lane == 0) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 64 + seq] = clock64() - tprev;   // duration of every sub-step
+    tacc[5] += clock64() - tprev;   // whole sub-step
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // wave 1: self-collision (grx_self.h) -- leg against leg (the partner lane is one DPP step away), thigh against base-lump
 // shapes -- on the chain frames wave 2 publishes right after its walk
 // On a HEIGHTFIELD the foot wave (wave 2) is the late one (gathers, terrain normals), so this wave -- otherwise idle until
@@ -419,8 +634,9 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
 // ---------------------------------------------------------------------------------------------------------------
 // wave 2: own walk with velocities; thigh / shank frames for wave 3; the anchored foot spheres
 template <bool HF>
-GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, float4* footfr, float mu, float hmax, float om_e, LaneState& hs, const PipeLds& L,
+GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const SideConst& Clds, const RareBuf& RB, float4* footfr, float mu, float hmax, float om_e, LaneState& hs, const PipeLds& L,
                                 int lane, int el, int side) {
+    const int half = lane_half(lane);
     GRX_HELPER_PROF_BEGIN;
     float lim_lo[LEG], lim_hi[LEG], lim_k[LEG], lim_c[LEG];   // joint-limit constants: registers for the whole policy step
 #pragma unroll
@@ -454,7 +670,9 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
         }
         // the foot spheres' heightfield gathers go out now and land while the bias forces are computed
         FootProbe fp;
-        foot_probe<HF>(P, C, K, O, hmax, fp);
+        FootProbeQ fpq;
+        if (LPL == 2) foot_probe_q<HF>(P, C, Clds, half, K, O, hmax, fpq);
+        else foot_probe<HF>(P, C, K, O, hmax, fp);
         // rigid-body bias force of chain body k -> wave 0.  The joint-limit spring/damper torque of joint k (oracle substep())
         // rides in the hand-over's spare slot: branch-free, constants in this wave's registers (on wave 0, fetched from LDS
         // behind data-dependent branches, it cost 1.8 k cycles per sub-step)
@@ -478,7 +696,8 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const RareBuf& RB, flo
         GRX_EV(10);
         float4* c_ = L.wc + lane;
         V3 fa, fl;
-        foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl, om_e, fp);
+        if (LPL == 2) foot_contacts_q<HF>(P, Clds, half, K, O, mu, hmax, hs, fa, fl, om_e, fpq);
+        else foot_contacts<HF>(P, C, K, O, mu, hmax, hs, fa, fl, om_e, fp);
         {   // foot link velocity BEFORE this sub-step's integration (sub-step averaged foot speed, fftai.py:79-81)
             const V3 fr = K.rho + rot(K.R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
             const V3 fv = K.v + cross(K.w, fr);
