@@ -1,6 +1,8 @@
-"""The generic-tree step kernel (csrc/grx_generic.h): any robot model include/grx.h can describe.
- * the lower-limb model FORCED through it must match the oracle like the fast kernel does, and the fast kernel itself;
- * the 32-DOF full-body GR1T1 (config 5 of BASELINE.json; obs 105 / pri_obs 234, build-defined) against the oracle."""
+"""The step kernels for ANY robot model include/grx.h can describe: the lane-group tree kernel (csrc/grx_tree.h: 8 lanes per env,
+a chain of the tree per lane -- what runs the 32-DOF full body of BASELINE.json config 5) and the one-lane generic kernel
+(csrc/grx_generic.h: the fallback, GRX_TREE=0).
+ * the lower-limb model FORCED through either must match the oracle like the fast kernel does, and the fast kernel itself;
+ * the 32-DOF full-body GR1T1 (obs 105 / pri_obs 234, build-defined) against the oracle, and the two kernels against each other."""
 import pytest
 import torch
 
@@ -8,9 +10,16 @@ from tests.helpers import lockstep, make_cfg, make_sims, random_actions
 from tests.test_hip_parity import assert_phys, physics_lockstep
 
 pytestmark = pytest.mark.gpu
+KERNELS = pytest.mark.parametrize("kernel", ["tree", "generic"])
 
 
-def test_lower_limb_through_the_generic_kernel(monkeypatch):
+def pick(monkeypatch, kernel):
+    monkeypatch.setenv("GRX_TREE", "1" if kernel == "tree" else "0")
+
+
+@KERNELS
+def test_lower_limb_through_the_generic_kernel(kernel, monkeypatch):
+    pick(monkeypatch, kernel)
     monkeypatch.setenv("GRX_FORCE_GENERIC", "1")
     cfg = make_cfg(terrain="heightfield", noise=True, dr=True, push=True)
     hip, ora = make_sims(cfg, 192, seed=1)
@@ -26,7 +35,9 @@ def test_lower_limb_through_the_generic_kernel(monkeypatch):
     hip.close()
 
 
-def test_generic_and_fast_kernels_agree(monkeypatch):
+@KERNELS
+def test_generic_and_fast_kernels_agree(kernel, monkeypatch):
+    pick(monkeypatch, kernel)
     cfg = make_cfg(noise=True, dr=True, push=True)
     N = 256
     outs = []
@@ -46,7 +57,9 @@ def test_generic_and_fast_kernels_agree(monkeypatch):
     assert (a["REW"] - b["REW"]).abs().max() < 5e-3
 
 
-def test_full_body_32_dof_against_the_oracle():
+@KERNELS
+def test_full_body_32_dof_against_the_oracle(kernel, monkeypatch):
+    pick(monkeypatch, kernel)
     cfg = make_cfg("GR1T1Full", noise=True, dr=True, push=True)
     hip, ora = make_sims(cfg, 128)
     assert hip.tensor("OBS").shape == (128, 105) and hip.tensor("PRI_OBS").shape == (128, 234) and hip.tensor("DOF_POS").shape == (128, 32)
@@ -62,7 +75,9 @@ def test_full_body_32_dof_against_the_oracle():
     hip.close()
 
 
-def test_full_body_rough_terrain_runs_and_is_deterministic():
+@KERNELS
+def test_full_body_rough_terrain_runs_and_is_deterministic(kernel, monkeypatch):
+    pick(monkeypatch, kernel)
     cfg = make_cfg("GR1T1Full", noise=True, dr=True, push=True, terrain="heightfield")
 
     def run():
@@ -96,3 +111,27 @@ def test_full_body_task_trains_on_the_gpu(tmp_path):
     runner, _ = task_registry.make_alg_runner(env, name="GR1T1_full_body", args=args, train_cfg=tcfg, log_root=str(tmp_path))
     runner.learn(num_learning_iterations=2, init_at_random_ep_len=True)
     assert all(torch.isfinite(p).all() for p in runner.algorithm.actor_critic.parameters())
+
+
+def test_tree_and_generic_kernels_agree_on_the_full_body(monkeypatch):
+    """Two implementations of the same arithmetic -- 33 bodies on one lane vs. five chains on five lanes of a group -- from
+    identical state, rough terrain, falls and self-collision included: every tensor to fp32 rounding of one policy step."""
+    cfg = make_cfg("GR1T1Full", noise=True, dr=True, push=True, terrain="heightfield")
+    N = 200                                   # (not a multiple of the tree kernel's 16-env block)
+    outs = []
+    for kernel in ("tree", "generic"):
+        pick(monkeypatch, kernel)
+        hip, _ = make_sims(cfg, N, seed=1)
+        hip.reset_all()
+        gen = torch.Generator().manual_seed(0)
+        for i in range(6):
+            hip.step(random_actions(cfg, N, gen, 0.6).cuda(), 5.0, i + 1)
+        outs.append({k: hip.tensor(k).clone() for k in ("OBS", "PRI_OBS", "REW", "RESET", "DOF_POS", "DOF_VEL", "ROOT_STATES", "CONTACT_FORCES", "TORQUES", "EPISODE_SUMS")})
+        hip.close()
+    a, b = outs
+    same = (a["DOF_POS"] - b["DOF_POS"]).abs().amax(1) < 1e-3          # (an env whose contact switched differently drifts: bounded fraction)
+    assert same.float().mean() > 0.95
+    assert (a["RESET"] != b["RESET"]).float().mean() < 0.02
+    for k in ("REW", "OBS", "PRI_OBS"):
+        d = (a[k][same] - b[k][same]).abs()
+        assert float((d > 2e-2).float().mean()) < 0.01, k

@@ -29,6 +29,10 @@ int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, in
                             float delay, long long common_step, const float* noise, float* obs_out, float* pri_out, long long seq, hipStream_t stream);
 void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, long long seq, uint8_t* mask, hipStream_t stream);
 int grx_generic_tables_size(void);
+int grx_tree_lds_bytes(int nb, int nlc);
+int grx_tree_envs_per_block(void);
+int grx_launch_step_tree(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int lds_bytes, int heightfield, const float* actions, float delay,
+                         long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream);
 int grx_generic_ws_floats_per_env(int nb, int nlc);
 void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, const StepSeq* sq, uint8_t* mask, hipStream_t stream);
 void grx_launch_mark(const int32_t* env_ids, int n, int N, uint8_t* mask, hipStream_t stream);
@@ -92,6 +96,8 @@ struct grx_sim {
     bool generic = false;  // model outside the fast kernel's lower-limb topology: generic-tree kernel (grx_generic.h)
     int nd = GRX_ND;
     void* d_gen = nullptr; // GenTables (device)
+    void* d_tree = nullptr; // TreeTab (device): the lane-group tree kernel (grx_tree.h) runs this model
+    int tree_lds = 0;      // its dynamic LDS
     float* d_ws = nullptr; // generic workspace
     int64_t seq = 0;       // launches of this handle that write statistics rows (steps, resets, debug steps; recorded ones too)
     bool stats_current = true;   // GRX_T_EPISODE_STATS already holds the statistics of launch `seq` (grx_flush_stats)
@@ -508,7 +514,61 @@ int build_generic(grx_sim* s, const grx_config& c) {
     HIP_TRY(hipMemcpy(d, &T, sizeof T, hipMemcpyHostToDevice));
     s->d_gen = d;
     rc = dalloc(s, &s->d_ws, (size_t)grx_generic_ws_floats_per_env(T.nb, T.nlc) * (size_t)s->N);
-    return rc;
+    if (rc) return rc;
+    // ---- the lane-group tree kernel (grx_tree.h): chains of the tree -> lanes, depth levels -> steps
+    if (const char* tv_ = getenv("GRX_TREE")) if (atoi(tv_) == 0) return GRX_OK;
+    std::vector<TreeTab> tt(1);
+    TreeTab& K = tt[0];
+    memset(&K, 0, sizeof K);
+    K.nb = T.nb; K.nd = T.nd; K.nsph = T.nsph; K.nlc = T.nlc;
+    memset(K.sched, 0xff, sizeof K.sched);
+    std::vector<int> depth(T.nb, -1), lane_of(T.nb, -1), cont(T.nb, 0);
+    int nchain = 0, nstep = 0;
+    bool fits = true;
+    for (int b = 1; b < T.nb && fits; ++b) {
+        const int p = T.parent[b];
+        depth[b] = p == 0 ? 0 : depth[p] + 1;
+        TreeBody& tb = K.body[b];
+        bool head = false;
+        if (p != 0 && !cont[p]) { lane_of[b] = lane_of[p]; cont[p] = 1; }   // a body's first child continues its chain
+        else { head = true; lane_of[b] = nchain++; }
+        if (nchain > GRX_TREE_G || depth[b] >= GRX_TREE_MAXSTEP) { fits = false; break; }
+        if (head && p == 0) K.heads0[K.nh0++] = lane_of[b];
+        if (head && p != 0) { if (K.body[p].nhc >= 4) { fits = false; break; } K.body[p].hc[K.body[p].nhc++] = lane_of[b]; }
+        K.sched[lane_of[b]][depth[b]] = (int8_t)b;
+        nstep = std::max(nstep, depth[b] + 1);
+        for (int a = 0; a < 3; ++a) { tb.axis[a] = T.axis[b][a]; tb.jpos[a] = T.jpos[b][a]; tb.com[a] = T.com[b][a]; }
+        for (int a = 0; a < 9; ++a) tb.rot0[a] = T.rot0[b][a];
+        for (int a = 0; a < 6; ++a) tb.Ic[a] = T.Ic[b][a];
+        tb.mass = T.mass[b]; tb.parent = p; tb.sph_begin = T.sph_begin[b]; tb.sph_end = T.sph_begin[b + 1];
+        tb.lane = lane_of[b]; tb.step = depth[b];
+    }
+    if (!fits) return GRX_OK;   // more chains / levels than a lane group holds: the one-lane generic kernel runs it
+    K.nchain = nchain; K.nstep = nstep;
+    for (int c = 0; c < GRX_TREE_G; ++c) {
+        K.first[c] = 1; K.last[c] = 0;
+        bool any = false;
+        for (int g = 0; g < nstep; ++g) if (K.sched[c][g] >= 0) { if (!any) K.first[c] = g; K.last[c] = g; any = true; }
+    }
+    for (int j = 0; j < T.nd; ++j) {
+        TreeDof& d = K.dof[j];
+        d.kp = T.kp[j]; d.kd = T.kd[j]; d.q0 = T.q0[j]; d.effort = T.effort[j]; d.vlim = T.vlim[j]; d.qlo = T.qlo[j]; d.qhi = T.qhi[j];
+        d.slo = T.slo[j]; d.shi = T.shi[j]; d.amin = T.amin[j]; d.amax = T.amax[j]; d.Klim = T.Klim[j]; d.Clim = T.Clim[j]; d.lane = lane_of[j + 1];
+    }
+    for (int k = 0; k < T.nsph; ++k) { TreeSph& q = K.sph[k]; q.x = T.sx[k]; q.y = T.sy[k]; q.z = T.sz[k]; q.r = T.sr[k]; q.dmax = T.sdmax[k]; q.slot = T.sslot[k]; q.link = T.slink[k]; }
+    for (int l = 0; l < T.nlc; ++l) { K.link_flags[l] = T.link_flags[l]; K.link_urdf[l] = T.link_urdf[l]; }
+    for (int f = 0; f < 2; ++f) { K.foot_body[f] = T.foot_body[f]; K.foot_link[f] = T.foot_link[f]; for (int a = 0; a < 3; ++a) K.foot_pos[f][a] = T.foot_pos[f][a]; }
+    K.torso_body = T.torso_body; K.forehead_body = T.forehead_body;
+    memcpy(K.torso_rot, T.torso_rot, sizeof K.torso_rot); memcpy(K.forehead_rot, T.forehead_rot, sizeof K.forehead_rot);
+    K.sph_begin0 = T.sph_begin[0]; K.sph_end0 = T.sph_begin[1];
+    const int lds = grx_tree_lds_bytes(T.nb, T.nlc);
+    if (lds > 160 * 1024 - 1024) return GRX_OK;   // the workspace of two waves does not fit a CU's LDS
+    TreeTab* dk = nullptr;
+    rc = dalloc(s, &dk, 1);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(dk, &K, sizeof K, hipMemcpyHostToDevice));
+    s->d_tree = dk; s->tree_lds = lds;
+    return GRX_OK;
 }
 }  // namespace
 
@@ -582,6 +642,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     P.bounce_threshold = c.bounce_threshold_velocity; P.terrain_restitution = c.terrain_restitution;
     P.self_collisions = c.self_collisions;
     if (const char* sc = getenv("GRX_SELF_COLLISIONS")) P.self_collisions = atoi(sc);   // A/B runs (tools/)
+    if (getenv("GRX_NO_RESTITUTION")) P.bounce_threshold = 1e30f;   // A/B runs: no contact ever bounces (tools/train_ab.py)
     P.termination_force = c.termination_force; P.termination_gravity_z = c.termination_gravity_z;
     P.max_episode_length = c.max_episode_length; P.max_episode_length_s = c.max_episode_length_s;
     P.resample_command_interval = c.resample_command_interval;
@@ -992,7 +1053,11 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
     a->stats_slot = q.seq & (GRX_STATS_HISTORY - 1);
     if (s->generic)
     {
-        if (grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->gen_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions,
+        if (s->d_tree) {
+            if (grx_launch_step_tree(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
+                                     (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st))
+                return fail(GRX_ERR_HIP, "grx_step: cannot raise the dynamic LDS limit of the tree kernel");
+        } else if (grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->gen_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions,
                                     a->delay_substeps, (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, q.seq, st))
             return fail(GRX_ERR_HIP, "grx_step: cannot raise the dynamic LDS limit of the generic kernel");
     }
@@ -1007,7 +1072,7 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->timing.pending.push_back(ev);
     }
-    if (s->generic) {   // the generic-tree kernel does not fold its predecessor's statistics: its own small kernel, with the step's ticket
+    if (s->generic && !s->d_tree) {   // the one-lane generic kernel does not fold its predecessor's statistics: its own small kernel, with the step's ticket
         grx_launch_finalize(s->d_hp, q.seq, q.progress, q.progress ? s->pace.issued : 0, st);
         s->stats_current = true;
     }

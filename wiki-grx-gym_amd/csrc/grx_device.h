@@ -77,6 +77,44 @@ struct RbsTables {
     RbsEntry e[2][GRX_RBS_MAX];
 };
 
+// ---- tree kernel (grx_tree.h): any robot tree whose chains fit a lane group -- the 32-DOF full body of BASELINE.json config 5 ----
+// An env is a GROUP of GRX_TREE_G lanes; every lane owns one CHAIN of the tree (a path: a body's first child continues its
+// chain, further children start new ones) and at global step g works on its chain's body of depth g.
+#define GRX_TREE_G 8
+#define GRX_TREE_MAXSTEP 16
+struct TreeBody {            // 36 words
+    float axis[3], mass;     // joint axis (child frame), mass
+    float rot0[9];           // child(q = 0) -> parent rotation, row-major
+    float jpos[3];           // joint origin in the parent frame
+    float com[3];
+    float Ic[6];             // inertia about the COM: xx xy xz yy yz zz
+    int32_t parent;
+    int32_t sph_begin, sph_end;
+    int32_t nhc;             // children that START a chain (they hand their articulated inertia up through the chain's LDS slot) ...
+    int32_t hc[4];           // ... the lanes of those chains
+    int32_t lane, step;      // where this body is processed
+    int32_t pad[2];
+};
+struct TreeDof { float kp, kd, q0, effort, vlim, qlo, qhi, slo, shi, amin, amax, Klim, Clim; int32_t lane; int32_t pad[2]; };   // 16 words
+struct TreeSph { float x, y, z, r, dmax; int32_t slot, link, pad; };   // 8 words
+struct TreeTab {
+    int32_t nb, nd, nsph, nlc, nchain, nstep, nh0, pad0;
+    int32_t heads0[GRX_TREE_G];                       // lanes whose chain hangs from the base
+    int32_t first[GRX_TREE_G], last[GRX_TREE_G];      // step range of each lane's chain (first > last: no chain)
+    int8_t sched[GRX_TREE_G][GRX_TREE_MAXSTEP];       // body at (lane, step), -1: none
+    TreeBody body[GRX_MAX_BODIES];
+    TreeDof dof[GRX_MAX_DOFS];
+    TreeSph sph[GRX_MAX_SPHERES];
+    uint32_t link_flags[24];
+    int32_t link_urdf[24];
+    int32_t foot_body[2], foot_link[2];
+    float foot_pos[2][3];
+    int32_t torso_body, forehead_body;
+    float torso_rot[9], forehead_rot[9];
+    int32_t sph_begin0, sph_end0;                     // the base's own shapes
+    int32_t pad1[2];
+};
+
 // Large read-only tables, in device memory.
 struct KTables {
     SideConst side[2];

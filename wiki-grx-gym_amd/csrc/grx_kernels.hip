@@ -653,8 +653,9 @@ GRX_DEV void quat_mul(const float a[4], const float b[4], float o[4]) {   // xyz
     o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
     o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
 }
+// part / nparts: the table entries go round the nparts waves that share the work (each walks the chain: ~150 instructions)
 GRX_DEV void publish_rigid_body_states(KP P, const SideConst& C, int side, V3 pos, const float rootq[4], V3 vel, V3 ang,
-                                       const float q[LEG], const float qd[LEG], int e, int N, bool act) {
+                                       const float q[LEG], const float qd[LEG], int e, int N, bool act, int part = 0, int nparts = 1) {
     const RbsTables& T = *P.rbs_tab;
     ChainKin K = {quat_to_R(rootq[0], rootq[1], rootq[2], rootq[3]), v3(0.f, 0.f, 0.f), ang, vel};
     float bq[4] = {rootq[0], rootq[1], rootq[2], rootq[3]};
@@ -673,6 +674,7 @@ GRX_DEV void publish_rigid_body_states(KP P, const SideConst& C, int side, V3 po
         const int i0 = T.off[side][lvl], n = T.off[side][lvl + 1] - i0;
         const int nmax = max(T.off[0][lvl + 1] - T.off[0][lvl], T.off[1][lvl + 1] - T.off[1][lvl]);   // uniform trip count
         for (int j = 0; j < nmax; ++j) {
+            if ((T.off[0][lvl] + j) % nparts != part) continue;   // (wave-uniform)
             if (j < n && act) {
                 const RbsEntry E = T.e[side][i0 + j];
                 const V3 r = K.rho + rot(K.R, v3(E.px, E.py, E.pz));
@@ -897,6 +899,7 @@ GRX_DEV void noise_blocks(KP P, uint32_t genv, uint32_t step, int side, U4 nzb[N
 
 #ifndef GRX_QUAD_TU
 #include "grx_generic.h"
+#include "grx_tree.h"
 #endif
 
 }  // namespace
@@ -1315,13 +1318,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 flag_set(s_flag + FL_BHO1 + (wv - 1), 1, lane);
                 if (wv == 2) GRX_TICKW(31);
             }
-            if (wv == 2 && P.publish_rbs) {   // every URDF link frame of the state wave 0 published after the last sub-step
+            if (P.publish_rbs) {   // every URDF link frame of the state wave 0 published after the last sub-step: a third on each helper wave
                 const float* b = s_base + el;
                 const float4 q0_ = s_q[lane], q1_ = s_q[64 + lane], q2_ = s_q[128 + lane];
                 const float fq[LEG] = {q0_.x, q0_.y, q0_.z, q0_.w, q1_.x}, fqd[LEG] = {q1_.y, q1_.z, q1_.w, q2_.x, q2_.y};
                 const float rq[4] = {b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]};
                 publish_rigid_body_states(P, C, side, v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]), rq, v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]),
-                                          v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]), fq, fqd, e, N, act0);
+                                          v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]), fq, fqd, e, N, act0, wv - 1, 3);
             }
         } else {
             for (int deci = 0; deci < P.decimation; ++deci) {
@@ -1931,6 +1934,24 @@ extern "C" int grx_launch_step_generic(const KParams* dP, const void* tables, fl
 }
 extern "C" void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, long long seq, uint8_t* mask, hipStream_t stream) {
     hipLaunchKernelGGL(grx_reset_all_generic, dim3((N + epb - 1) / epb), dim3(epb), 0, stream, dP, static_cast<const GenTables*>(tables), step, seq, mask);
+}
+// the tree kernel (grx_tree.h): 8 lanes per env, two 8-env waves per block
+extern "C" int grx_tree_lds_bytes(int nb, int nlc) { return (int)sizeof(TreeTab) + TWAVES * tree_offsets(nb, nlc).total * TEPW * 4; }
+extern "C" int grx_tree_envs_per_block(void) { return TEPB; }
+extern "C" int grx_launch_step_tree(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int lds_bytes, int heightfield, const float* actions, float delay,
+                                    long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {
+    static bool raised = false;
+    if (!raised) {   // > 64 KB of dynamic LDS needs the opt-in
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+        raised = true;
+    }
+    const int nblocks = (N + TEPB - 1) / TEPB;
+    const TreeTab* Tt = static_cast<const TreeTab*>(tree_tab);
+    const GenTables* Tg = static_cast<const GenTables*>(gen_tab);
+    if (heightfield) hipLaunchKernelGGL(grx_step_tree<true>, dim3(nblocks), dim3(64 * TWAVES), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq);
+    else hipLaunchKernelGGL(grx_step_tree<false>, dim3(nblocks), dim3(64 * TWAVES), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq);
+    return 0;
 }
 extern "C" int grx_generic_tables_size(void) { return (int)sizeof(GenTables); }
 extern "C" int grx_generic_ws_floats_per_env(int nb, int nlc) { return nb * WSB + 3 * nlc; }

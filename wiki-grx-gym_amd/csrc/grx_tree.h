@@ -1,0 +1,823 @@
+// grx_tree.h -- the tree step kernel: a LANE GROUP per env, a chain of the robot's tree per lane (included by
+// grx_kernels.hip inside its anonymous namespace, after grx_generic.h whose helpers it shares).
+//
+// The 32-DOF full-body GR1T1 (BASELINE.json config 5) is six chains around the floating base: two 6-joint legs, the
+// 3-joint waist that carries the torso, and -- hanging from the torso -- the head (3 joints) and two 7-joint arms.  The
+// generic-tree kernel (grx_generic.h) walks those 32 bodies one after the other on ONE lane per env: ~50 k instructions per
+// sub-step on a wave that issues one instruction per ~4.5 cycles (tools/micro/operand_rate.hip), a 64-env wave per CU, three
+// SIMDs of four idle.  Here an env is a group of GRX_TREE_G = 8 lanes and every lane owns one chain (a body's first child
+// continues its chain, further children start new chains: legs, waist + head, arms = 5 lanes of this robot):
+//
+//   * at global step g a lane works on its chain's body of depth g: the three passes of the articulated-body algorithm are
+//     loops over the 10 depth levels of the tree instead of its 32 bodies; a chain hands frames, articulated inertias and
+//     accelerations on in registers from one step to the next;
+//   * chains meet through LDS: a chain's first body takes its parent's frame (and, in the last pass, its acceleration) from the
+//     parent's workspace row, written one step earlier by the parent's lane; on the way in it parks its articulated inertia and
+//     bias force in its chain's slot, which the parent's lane -- or, for the chains that hang from the base, every lane -- adds
+//     in a fixed order.  All lanes of an env sit in one wave: program order is the only synchronisation;
+//   * per-body intermediates, the env's joint state, link forces and friction anchors live in an LDS workspace laid out
+//     [word][env of the wave]: 8.9 KB per env of the 33-body robot, two 8-env waves per block and CU;
+//   * the same formulation as every kernel here -- spatial quantities in world axes about the base origin, so a child's
+//     inertia simply ADDS into its parent --, the same contact, self-collision and env-pipeline arithmetic as grx_generic.h
+//     (which stays as the fallback for trees with more than eight chains, and as this kernel's cross-check: GRX_TREE=0).
+#pragma once
+
+constexpr int TG = GRX_TREE_G, TEPW = 64 / TG, TWAVES = 2, TEPB = TEPW * TWAVES;   // lanes per env, envs per wave / block
+// workspace words per body
+enum { T_R = 0, T_RHO = 9, T_W = 12, T_V = 15, T_A = 18, T_S = 21, T_CA = 24, T_CL = 27, T_PA = 30, T_PL = 33, T_UA = 36, T_UL = 39,
+       T_DI = 42, T_U = 43, T_AK = 44, T_H = 50, T_NB = 53 };
+constexpr int T_UPW = 27;    // a chain's hand-over to its parent: A 6, B 9, D 6, pa 3, pl 3
+constexpr int T_MISC = 16;   // foot link velocities before the sub-step (6), foot positions (6), foot velocities (3 + 1 spare) -- see below
+enum { TD_Q = 0, TD_QD = 1, TD_TAU = 2, TD_ACUR = 3, TD_ALAST = 4, TD_N = 5 };
+
+struct TreeOff { int up, dof, lf, an, misc, total; };
+__host__ __device__ inline TreeOff tree_offsets(int nb, int nlc) {
+    TreeOff o;
+    o.up = nb * T_NB; o.dof = o.up + TG * T_UPW; o.lf = o.dof + TD_N * GRX_MAX_DOFS; o.an = o.lf + nlc * 3; o.misc = o.an + 24; o.total = o.misc + T_MISC;
+    return o;
+}
+#define TW(addr) wsw[(addr) * TEPW + ei]
+
+GRX_DEV float grp_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
+GRX_DEV float grp_bcast(float v, int lane, int src) { return __shfl(v, (lane & ~(TG - 1)) | src); }
+GRX_DEV V3 grp_bcast(V3 v, int lane, int src) { return v3(grp_bcast(v.x, lane, src), grp_bcast(v.y, lane, src), grp_bcast(v.z, lane, src)); }
+
+GRX_DEV V3 tw_v3(const float* wsw, int ei, int a) { return v3(TW(a), TW(a + 1), TW(a + 2)); }
+GRX_DEV void tw_put(float* wsw, int ei, int a, V3 x) { TW(a) = x.x; TW(a + 1) = x.y; TW(a + 2) = x.z; }
+GRX_DEV R3 tw_R(const float* wsw, int ei, int a) { R3 R; R.cx = tw_v3(wsw, ei, a); R.cy = tw_v3(wsw, ei, a + 3); R.cz = tw_v3(wsw, ei, a + 6); return R; }
+
+// child rotation R_parent * rot0 * Rot(axis, q) (gen_joint_rot on the LDS table)
+GRX_DEV R3 tree_joint_rot(const R3& Rp, const TreeBody& tb, float q) {
+    float sn, cs;
+    grx_sincos(q, sn, cs);
+    const float ax = tb.axis[0], ay = tb.axis[1], az = tb.axis[2], oc = 1.f - cs;
+    const V3 qx = v3(cs + ax * ax * oc, az * sn + ax * ay * oc, -ay * sn + ax * az * oc);
+    const V3 qy = v3(-az * sn + ax * ay * oc, cs + ay * ay * oc, ax * sn + ay * az * oc);
+    const V3 qz = v3(ay * sn + ax * az * oc, -ax * sn + ay * az * oc, cs + az * az * oc);
+    R3 J;
+    J.cx = rot(Rp, v3(tb.rot0[0], tb.rot0[3], tb.rot0[6]));
+    J.cy = rot(Rp, v3(tb.rot0[1], tb.rot0[4], tb.rot0[7]));
+    J.cz = rot(Rp, v3(tb.rot0[2], tb.rot0[5], tb.rot0[8]));
+    R3 R;
+    R.cx = rot(J, qx); R.cy = rot(J, qy); R.cz = rot(J, qz);
+    return R;
+}
+
+// one sphere against the terrain (gen_sphere with the anchors and the link-force accumulators in the LDS workspace)
+template <bool HF>
+GRX_DEV V3 tree_sphere(KP P, const TreeSph& S, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu, float om_e, float hmax, float* wsw, int ei,
+                       const TreeOff& o, V3& xr) {
+    xr = rho + rot(R, v3(S.x, S.y, S.z));
+    V3 F = v3(0.f, 0.f, 0.f);
+    const float wz = O.z + xr.z, r = S.r;
+    const int slot = S.slot;
+    bool touching = false;
+    float vimp = 0.f;
+    if (wz - r <= hmax) {
+        const float wx = O.x + xr.x, wy = O.y + xr.y;
+        float gx, gy;
+        const float dv = terrain_height<HF>(P, wx, wy, gx, gy) + r - wz;
+        if (dv > 0.0f) {
+            touching = true;
+            const float nn = grx_rsq(1.0f + gx * gx + gy * gy);
+            const V3 n = v3(-gx * nn, -gy * nn, nn);
+            const float d = dv * nn;
+            const V3 u = v + cross(w, xr);
+            const float un = dot(u, n);
+            float cd = fminf(P.kn * d * P.dn, S.dmax);
+            if (slot >= 0) {   // restitution (sphere_contact's rule)
+                vimp = TW(o.an + slot * 3 + 2);
+                if (vimp == 0.f) vimp = fmaxf(fmaxf(-un, 0.0f), 1e-6f);
+                if (un > 0.0f && vimp > P.bounce_threshold) cd *= om_e;
+            }
+            const float fn = fmaxf(P.kn * d - cd * un, 0.0f);
+            F = n * fn;
+            const float fmax = mu * fn;
+            if (slot >= 0) {
+                float axx = TW(o.an + slot * 3), ayy = TW(o.an + slot * 3 + 1);
+                if (TW(o.an + slot * 3 + 2) == 0.f) { axx = wx; ayy = wy; }
+                float ftx = -P.kt * (wx - axx) - P.ct * u.x;
+                float fty = -P.kt * (wy - ayy) - P.ct * u.y;
+                const float ft = grx_sqrt(ftx * ftx + fty * fty);
+                if (ft > fmax) {
+                    const float sc = fmax * grx_rcp(ft);
+                    ftx *= sc; fty *= sc;
+                    axx = wx + ftx * P.inv_kt;
+                    ayy = wy + fty * P.inv_kt;
+                }
+                TW(o.an + slot * 3) = axx; TW(o.an + slot * 3 + 1) = ayy;
+                F.x += ftx; F.y += fty;
+            } else {
+                const float sp = grx_sqrt(u.x * u.x + u.y * u.y);
+                const float ft = fminf(P.cv * sp, fmax);
+                if (sp > 1e-9f) { const float k = -ft * grx_rcp(sp); F.x += k * u.x; F.y += k * u.y; }
+            }
+        }
+    }
+    if (slot >= 0) TW(o.an + slot * 3 + 2) = touching ? vimp : 0.f;
+    const int L = S.link;
+    TW(o.lf + L * 3) += F.x; TW(o.lf + L * 3 + 1) += F.y; TW(o.lf + L * 3 + 2) += F.z;
+    return F;
+}
+
+struct TreeEnv {   // what every lane of the env's group holds (redundantly)
+    GenBase B;
+    float base_m; V3 base_c; S3 base_I;
+    float mu, om_e, hmax;
+};
+
+// pass 1 (root -> leaves) over the depth levels.  KIN: frames and velocities only (the state after the last sub-step).
+template <bool HF, bool KIN>
+GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0, bool use_last, const float* strength) {
+    R3 Rc = R0;
+    V3 rho_c = v3(0.f, 0.f, 0.f), w_c = E.B.ang, v_c = E.B.vel;
+    const int first = T.first[c];
+    for (int g = 0; g < T.nstep; ++g) {
+        const int b = T.sched[c][g];
+        if (b >= 0) {
+            const TreeBody& tb = T.body[b];
+            const int p = tb.parent, j = b - 1;
+            if (g == first && p != 0) {   // the chain hangs from another chain's body, processed one step earlier
+                Rc = tw_R(wsw, ei, p * T_NB + T_R); rho_c = tw_v3(wsw, ei, p * T_NB + T_RHO);
+                w_c = tw_v3(wsw, ei, p * T_NB + T_W); v_c = tw_v3(wsw, ei, p * T_NB + T_V);
+            }
+            const float qj = TW(o.dof + TD_Q * GRX_MAX_DOFS + j), qdj = TW(o.dof + TD_QD * GRX_MAX_DOFS + j);
+            const V3 rho = rho_c + rot(Rc, v3(tb.jpos[0], tb.jpos[1], tb.jpos[2]));
+            const R3 R = tree_joint_rot(Rc, tb, qj);
+            const V3 a = rot(R, v3(tb.axis[0], tb.axis[1], tb.axis[2]));
+            const V3 s = cross(rho, a);
+            const V3 w = fma3(a, qdj, w_c), v = fma3(s, qdj, v_c);
+            const int wb = b * T_NB;
+            tw_put(wsw, ei, wb + T_R, R.cx); tw_put(wsw, ei, wb + T_R + 3, R.cy); tw_put(wsw, ei, wb + T_R + 6, R.cz);
+            tw_put(wsw, ei, wb + T_RHO, rho); tw_put(wsw, ei, wb + T_W, w); tw_put(wsw, ei, wb + T_V, v);
+            if (!KIN) {
+                const TreeDof& td = T.dof[j];
+                {   // _compute_torques (legged_robot.py:679-715) + the joint-limit spring/damper of this sub-step
+                    const float act_ = use_last ? TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j) : TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j);
+                    float t = td.kp * (act_ * P.action_scale + td.q0 - qj) - td.kd * qdj;
+                    t *= strength[(size_t)j * P.N];   // (this env's column of the SoA table)
+                    TW(o.dof + TD_TAU * GRX_MAX_DOFS + j) = fminf(fmaxf(t, -td.effort), td.effort);
+                }
+                const V3 ca = cross(w_c, a) * qdj;
+                const V3 cl = (cross(v_c, a) + cross(w_c, s)) * qdj;
+                const V3 kap = rho + rot(R, v3(tb.com[0], tb.com[1], tb.com[2]));
+                const S3 Ic = {tb.Ic[0], tb.Ic[1], tb.Ic[2], tb.Ic[3], tb.Ic[4], tb.Ic[5]};
+                S3 Ak; V3 h;
+                rigid_inertia(R, kap, tb.mass, Ic, Ak, h);
+                V3 pa, pl;
+                rigid_bias(R, kap, tb.mass, Ic, w, v, pa, pl);
+                for (int i = tb.sph_begin; i < tb.sph_end; ++i) {
+                    V3 xr;
+                    const V3 F = tree_sphere<HF>(P, T.sph[i], R, rho, w, v, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr);
+                    pa = pa - cross(xr, F); pl = pl - F;
+                }
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+                    if (T.foot_body[f] == b) {   // foot link velocity BEFORE this sub-step's integration
+                        const V3 fr = rho + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
+                        tw_put(wsw, ei, o.misc + f * 3, v + cross(w, fr));
+                    }
+                tw_put(wsw, ei, wb + T_A, a); tw_put(wsw, ei, wb + T_S, s); tw_put(wsw, ei, wb + T_CA, ca); tw_put(wsw, ei, wb + T_CL, cl);
+                tw_put(wsw, ei, wb + T_PA, pa); tw_put(wsw, ei, wb + T_PL, pl);
+                TW(wb + T_AK) = Ak.xx; TW(wb + T_AK + 1) = Ak.xy; TW(wb + T_AK + 2) = Ak.xz; TW(wb + T_AK + 3) = Ak.yy; TW(wb + T_AK + 4) = Ak.yz; TW(wb + T_AK + 5) = Ak.zz;
+                tw_put(wsw, ei, wb + T_H, h);
+            }
+            Rc = R; rho_c = rho; w_c = w; v_c = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (one wave: LDS operations complete in program order)
+    }
+}
+
+// the hand-over of a chain: 27 words in the chain's slot
+GRX_DEV void tree_put_up(float* wsw, int ei, int a, const S3& A, const M3& B, const S3& D, V3 pa, V3 pl) {
+    TW(a) = A.xx; TW(a + 1) = A.xy; TW(a + 2) = A.xz; TW(a + 3) = A.yy; TW(a + 4) = A.yz; TW(a + 5) = A.zz;
+    TW(a + 6) = B.a00; TW(a + 7) = B.a01; TW(a + 8) = B.a02; TW(a + 9) = B.a10; TW(a + 10) = B.a11; TW(a + 11) = B.a12; TW(a + 12) = B.a20; TW(a + 13) = B.a21; TW(a + 14) = B.a22;
+    TW(a + 15) = D.xx; TW(a + 16) = D.xy; TW(a + 17) = D.xz; TW(a + 18) = D.yy; TW(a + 19) = D.yz; TW(a + 20) = D.zz;
+    tw_put(wsw, ei, a + 21, pa); tw_put(wsw, ei, a + 24, pl);
+}
+GRX_DEV void tree_add_up(const float* wsw, int ei, int a, S3& A, M3& B, S3& D, V3& pa, V3& pl) {
+    A.xx += TW(a); A.xy += TW(a + 1); A.xz += TW(a + 2); A.yy += TW(a + 3); A.yz += TW(a + 4); A.zz += TW(a + 5);
+    B.a00 += TW(a + 6); B.a01 += TW(a + 7); B.a02 += TW(a + 8); B.a10 += TW(a + 9); B.a11 += TW(a + 10); B.a12 += TW(a + 11); B.a20 += TW(a + 12); B.a21 += TW(a + 13); B.a22 += TW(a + 14);
+    D.xx += TW(a + 15); D.xy += TW(a + 16); D.xz += TW(a + 17); D.yy += TW(a + 18); D.yz += TW(a + 19); D.zz += TW(a + 20);
+    pa = pa + tw_v3(wsw, ei, a + 21); pl = pl + tw_v3(wsw, ei, a + 24);
+}
+
+// pass 2 (leaves -> root): articulated inertias and bias forces
+GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o) {
+    S3 cA = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cD = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    M3 cB = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    V3 cpa = v3(0.f, 0.f, 0.f), cpl = v3(0.f, 0.f, 0.f);
+    const int first = T.first[c], last = T.last[c];
+    for (int g = T.nstep - 1; g >= 0; --g) {
+        const int b = T.sched[c][g];
+        if (b >= 0) {
+            const TreeBody& tb = T.body[b];
+            const int j = b - 1, wb = b * T_NB;
+            const V3 h = tw_v3(wsw, ei, wb + T_H);
+            const float m = tb.mass;
+            S3 A = {TW(wb + T_AK), TW(wb + T_AK + 1), TW(wb + T_AK + 2), TW(wb + T_AK + 3), TW(wb + T_AK + 4), TW(wb + T_AK + 5)};
+            M3 Bm = {0.f, -h.z, h.y, h.z, 0.f, -h.x, -h.y, h.x, 0.f};
+            S3 D = {m, 0.f, 0.f, m, 0.f, m};
+            const V3 a = tw_v3(wsw, ei, wb + T_A), s = tw_v3(wsw, ei, wb + T_S), ca = tw_v3(wsw, ei, wb + T_CA), cl = tw_v3(wsw, ei, wb + T_CL);
+            V3 pa = tw_v3(wsw, ei, wb + T_PA), pl = tw_v3(wsw, ei, wb + T_PL);
+            if (g < last) { A = A + cA; Bm = Bm + cB; D = D + cD; pa = pa + cpa; pl = pl + cpl; }   // the chain's own child, in registers
+            for (int k = 0; k < tb.nhc; ++k) tree_add_up(wsw, ei, o.up + tb.hc[k] * T_UPW, A, Bm, D, pa, pl);   // chains that hang from this body, fixed order
+            const V3 ua = mul(A, a) + mul(Bm, s);
+            const V3 ul = mulT(Bm, a) + mul(D, s);
+            const float di = grx_rcp(dot(a, ua) + dot(s, ul));
+            const TreeDof& td = T.dof[j];
+            const float qj = TW(o.dof + TD_Q * GRX_MAX_DOFS + j), qdj = TW(o.dof + TD_QD * GRX_MAX_DOFS + j);
+            float t = TW(o.dof + TD_TAU * GRX_MAX_DOFS + j);   // joint-limit spring/damper on top of the motor torque
+            if (qj < td.qlo) t += td.Klim * (td.qlo - qj) - td.Clim * qdj;
+            else if (qj > td.qhi) t += td.Klim * (td.qhi - qj) - td.Clim * qdj;
+            const float u = t - (dot(a, pa) + dot(s, pl));
+            syr(A, ua, di); ger(Bm, ua, ul, di); syr(D, ul, di);
+            const float ud = u * di;
+            const V3 npa = pa + mul(A, ca) + mul(Bm, cl) + ua * ud;
+            const V3 npl = pl + mulT(Bm, ca) + mul(D, cl) + ul * ud;
+            tw_put(wsw, ei, wb + T_UA, ua); tw_put(wsw, ei, wb + T_UL, ul); TW(wb + T_DI) = di; TW(wb + T_U) = u;
+            if (g == first) tree_put_up(wsw, ei, o.up + c * T_UPW, A, Bm, D, npa, npl);
+            else { cA = A; cB = Bm; cD = D; cpa = npa; cpl = npl; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// pass 3 (root -> leaves): accelerations, joint integration
+GRX_DEV void tree_accel(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, V3 alpha, V3 acc) {
+    V3 aa_c = alpha, al_c = acc;
+    const int first = T.first[c];
+    const float dt = P.sim_dt;
+    for (int g = 0; g < T.nstep; ++g) {
+        const int b = T.sched[c][g];
+        if (b >= 0) {
+            const TreeBody& tb = T.body[b];
+            const int p = tb.parent, j = b - 1, wb = b * T_NB;
+            if (g == first && p != 0) { aa_c = tw_v3(wsw, ei, p * T_NB + T_PA); al_c = tw_v3(wsw, ei, p * T_NB + T_PL); }   // (the parent parked its acceleration there)
+            const V3 a = tw_v3(wsw, ei, wb + T_A), s = tw_v3(wsw, ei, wb + T_S);
+            const V3 pa_ = aa_c + tw_v3(wsw, ei, wb + T_CA), pl_ = al_c + tw_v3(wsw, ei, wb + T_CL);
+            const float qdd = (TW(wb + T_U) - (dot(tw_v3(wsw, ei, wb + T_UA), pa_) + dot(tw_v3(wsw, ei, wb + T_UL), pl_))) * TW(wb + T_DI);
+            aa_c = fma3(a, qdd, pa_); al_c = fma3(s, qdd, pl_);
+            tw_put(wsw, ei, wb + T_PA, aa_c); tw_put(wsw, ei, wb + T_PL, al_c);   // bias force slots are free by now: the children's parent acceleration
+            const TreeDof& td = T.dof[j];
+            float vq = fmaf(qdd, dt, TW(o.dof + TD_QD * GRX_MAX_DOFS + j));
+            vq = fminf(fmaxf(vq, -td.vlim), td.vlim);
+            TW(o.dof + TD_QD * GRX_MAX_DOFS + j) = vq;
+            TW(o.dof + TD_Q * GRX_MAX_DOFS + j) = fmaf(vq, dt, TW(o.dof + TD_Q * GRX_MAX_DOFS + j));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// self-collision (the contact law of grx_self.h, the link-pair tables of grx_generic.h): the env's lanes share the bounding
+// tests of the link pairs; the few pairs that do touch are then evaluated ONE AT A TIME, in table order, by the lane that
+// found them -- it alone adds into the bodies' bias forces and the link accumulators: no races, the same sums on every run
+GRX_DEV void tree_self_collision(KP P, const TreeTab& T, GT G, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0,
+                                 V3& pa0, V3& pl0) {
+    const float mu_self = 2.0f * E.mu - P.terrain_friction;
+    V3 dpa0 = v3(0.f, 0.f, 0.f), dpl0 = v3(0.f, 0.f, 0.f);
+    for (int lp0 = 0; lp0 < G.nlp; lp0 += TG) {
+        const int lp = lp0 + c;
+        bool hit = false;
+        int ba = 0, bb = 0;
+        ChainKin Ka, Kb;
+        if (lp < G.nlp) {
+            ba = G.lp_ba[lp]; bb = G.lp_bb[lp];
+            if (ba == 0) Ka = ChainKin{R0, v3(0.f, 0.f, 0.f), E.B.ang, E.B.vel};
+            else Ka = ChainKin{tw_R(wsw, ei, ba * T_NB + T_R), tw_v3(wsw, ei, ba * T_NB + T_RHO), tw_v3(wsw, ei, ba * T_NB + T_W), tw_v3(wsw, ei, ba * T_NB + T_V)};
+            Kb = ChainKin{tw_R(wsw, ei, bb * T_NB + T_R), tw_v3(wsw, ei, bb * T_NB + T_RHO), tw_v3(wsw, ei, bb * T_NB + T_W), tw_v3(wsw, ei, bb * T_NB + T_V)};
+            const V3 ca = Ka.rho + rot(Ka.R, v3(G.lp_ca[lp][0], G.lp_ca[lp][1], G.lp_ca[lp][2]));
+            const V3 cb = Kb.rho + rot(Kb.R, v3(G.lp_cb[lp][0], G.lp_cb[lp][1], G.lp_cb[lp][2]));
+            const V3 d = ca - cb;
+            const float R = G.lp_ca[lp][3] + G.lp_cb[lp][3];
+            hit = dot(d, d) < R * R;
+        }
+        if (!__any(hit)) continue;
+        for (int k = 0; k < TG; ++k) {   // table order within the round: lane k's pair
+            if (!__any(hit && c == k)) continue;
+            if (hit && c == k) {
+                const int la = G.lp_a[lp], lb = G.lp_b[lp];
+                V3 Fa = v3(0.f, 0.f, 0.f), Ta = v3(0.f, 0.f, 0.f);
+                for (int i = G.lc_begin[la]; i < G.lc_begin[la + 1]; ++i) {
+                    SphC si; si.x = G.sx[i]; si.y = G.sy[i]; si.z = G.sz[i]; si.r = G.sr[i]; si.dmax = G.sdmax[i];
+                    const SphW a = sph_world(si, Ka);
+                    for (int jj = G.lc_begin[lb]; jj < G.lc_begin[lb + 1]; ++jj) {
+                        SphC sj; sj.x = G.sx[jj]; sj.y = G.sy[jj]; sj.z = G.sz[jj]; sj.r = G.sr[jj]; sj.dmax = G.sdmax[jj];
+                        const SphW b_ = sph_world(sj, Kb);
+                        V3 F, pw;
+                        if (sphere_pair(P, a, b_, mu_self, F, pw)) { Fa = Fa + F; Ta = Ta + cross(pw, F); }
+                    }
+                }
+                // F on link a (body ba), -F on link b (body bb)
+                if (ba == 0) { dpa0 = dpa0 - Ta; dpl0 = dpl0 - Fa; }
+                else { const int wa = ba * T_NB; TW(wa + T_PA) -= Ta.x; TW(wa + T_PA + 1) -= Ta.y; TW(wa + T_PA + 2) -= Ta.z; TW(wa + T_PL) -= Fa.x; TW(wa + T_PL + 1) -= Fa.y; TW(wa + T_PL + 2) -= Fa.z; }
+                const int wb_ = bb * T_NB;
+                TW(wb_ + T_PA) += Ta.x; TW(wb_ + T_PA + 1) += Ta.y; TW(wb_ + T_PA + 2) += Ta.z; TW(wb_ + T_PL) += Fa.x; TW(wb_ + T_PL + 1) += Fa.y; TW(wb_ + T_PL + 2) += Fa.z;
+                TW(o.lf + la * 3) += Fa.x; TW(o.lf + la * 3 + 1) += Fa.y; TW(o.lf + la * 3 + 2) += Fa.z;
+                TW(o.lf + lb * 3) -= Fa.x; TW(o.lf + lb * 3 + 1) -= Fa.y; TW(o.lf + lb * 3 + 2) -= Fa.z;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+    // the base's share: summed over the env's lanes in lane order (only a few lanes ever hold one)
+#pragma unroll
+    for (int k = 0; k < TG; ++k) {
+        const int src = ((threadIdx.x & 63) & ~(TG - 1)) | k;
+        pa0 = pa0 + v3(__shfl(dpa0.x, src), __shfl(dpa0.y, src), __shfl(dpa0.z, src));
+        pl0 = pl0 + v3(__shfl(dpl0.x, src), __shfl(dpl0.y, src), __shfl(dpl0.z, src));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <bool HF>
+__global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __restrict__ Pg, const TreeTab* __restrict__ Tt, const GenTables* __restrict__ Tg,
+                                                             const float* __restrict__ actions_in, float delay, long long common_step,
+                                                             const float* __restrict__ noise_in, float* __restrict__ obs_out, float* __restrict__ pri_out,
+                                                             const StepSeq sq) {
+    KP P = GRX_PARAMS(Pg);
+    GT G = *reinterpret_cast<const GRX_AS4 GenTables*>(reinterpret_cast<uintptr_t>(Tg));
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    __shared__ float s_stat[NSTAT];
+    TreeTab& Tm = *reinterpret_cast<TreeTab*>(s_dyn);
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(Tt);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_dyn);
+        for (int i = threadIdx.x; i < (int)(sizeof(TreeTab) / 4); i += blockDim.x) dst[i] = src[i];
+        if (threadIdx.x < NSTAT) s_stat[threadIdx.x] = 0.f;
+    }
+    __syncthreads();
+    const TreeTab& T = Tm;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ei = lane / TG, c = lane & (TG - 1);
+    if (wave == TWAVES - 1) stats_fold_previous(P, sq, lane);   // the previous launch's episode statistics (and its ticket)
+    const TreeOff o = tree_offsets(T.nb, T.nlc);
+    float* const wsw = s_dyn + sizeof(TreeTab) / 4 + (size_t)wave * o.total * TEPW;
+    const size_t N = (size_t)P.N;
+    const int e_raw = blockIdx.x * TEPB + wave * TEPW + ei;
+    const bool act = e_raw < P.N;
+    const int e = act ? e_raw : P.N - 1;
+    const bool lead = c == 0, actl = act && lead;
+    const int nd = T.nd;
+    const uint32_t genv = (uint32_t)(P.env_offset + e), step = (uint32_t)common_step;
+    const int nh = P.nh, nobs = 9 + 3 * nd, npri = P.num_pri_obs;
+    const float dtp = P.sim_dt * (float)P.decimation;
+    const int first = T.first[c], last = T.last[c];
+    // ---- load the state: the base in every lane of the group, a chain's joints by its lane
+    TreeEnv E;
+    E.B.pos = v3(P.root[e], P.root[N + e], P.root[2 * N + e]);
+    E.B.qx = P.root[3 * N + e]; E.B.qy = P.root[4 * N + e]; E.B.qz = P.root[5 * N + e]; E.B.qw = P.root[6 * N + e];
+    E.B.vel = v3(P.root[7 * N + e], P.root[8 * N + e], P.root[9 * N + e]);
+    E.B.ang = v3(P.root[10 * N + e], P.root[11 * N + e], P.root[12 * N + e]);
+    E.base_m = P.base_m[e];
+    E.base_c = v3(P.base_c[e], P.base_c[N + e], P.base_c[2 * N + e]);
+    E.base_I = S3{P.base_I[e], P.base_I[N + e], P.base_I[2 * N + e], P.base_I[3 * N + e], P.base_I[4 * N + e], P.base_I[5 * N + e]};
+    E.mu = 0.5f * (P.terrain_friction + P.friction[e]);
+    E.om_e = 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]);
+    E.hmax = 0.f;
+    if (HF) {
+        int ci = min(max((int)((E.B.pos.x + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_rows - 1);
+        int cj = min(max((int)((E.B.pos.y + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
+        E.hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
+    }
+    EnvAux ea;
+    ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[N + e]; ea.cmd[2] = P.commands[2 * N + e];
+    ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[N + e]; ea.origin[2] = P.origins[2 * N + e];
+    ea.level = P.levels[e]; ea.type = P.types[e];
+    float air_time[2] = {P.air_time[e], P.air_time[N + e]}, land_time[2] = {P.land_time[e], P.land_time[N + e]};
+    bool contact_last[2] = {P.feet_contact[e] != 0, P.feet_contact[N + e] != 0};
+    const float bho_stale = P.base_heights_offset[e];
+    long long ep_len = P.ep_len[e];
+    for (int g = first; g <= last; ++g) {
+        const int j = T.sched[c][g] - 1;
+        const size_t oj = (size_t)j * N + e;
+        TW(o.dof + TD_Q * GRX_MAX_DOFS + j) = P.q[oj]; TW(o.dof + TD_QD * GRX_MAX_DOFS + j) = P.qd[oj];
+        TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j) = P.last_actions[oj];
+        const float a = actions_in ? actions_in[(size_t)e * nd + j] : 0.f;
+        TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j) = fminf(fmaxf(a, T.dof[j].amin), T.dof[j].amax);   // clip_actions (legged_robot_fftai.py:171-177)
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) TW(o.an + c * 3 + k) = P.anchors[(size_t)(c * 3 + k) * N + e];   // 8 anchor slots x (x, y, approach speed): one slot per lane
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- during_physics_step (legged_robot_fftai.py:51-88)
+    float avg_force[2] = {0.f, 0.f};
+    V3 avg_speed[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+    for (int deci = 0; deci < P.decimation; ++deci) {
+        for (int i = c; i < T.nlc * 3; i += TG) TW(o.lf + i) = 0.f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
+        tree_outward<HF, false>(P, T, wsw, ei, c, o, E, R0, (float)deci < delay, P.motor_strength + e);
+        // base: rigid lump (randomised per env) + its own shapes (the group's first lane; the wrench goes round by shuffle)
+        S3 Ab; V3 h0;
+        rigid_inertia(R0, rot(R0, E.base_c), E.base_m, E.base_I, Ab, h0);
+        V3 pa0, pl0;
+        rigid_bias(R0, rot(R0, E.base_c), E.base_m, E.base_I, E.B.ang, E.B.vel, pa0, pl0);
+        {
+            V3 fa = v3(0.f, 0.f, 0.f), fl = v3(0.f, 0.f, 0.f);
+            if (lead)
+                for (int i = T.sph_begin0; i < T.sph_end0; ++i) {
+                    V3 xr;
+                    const V3 F = tree_sphere<HF>(P, T.sph[i], R0, v3(0.f, 0.f, 0.f), E.B.ang, E.B.vel, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr);
+                    fa = fa + cross(xr, F); fl = fl + F;
+                }
+            pa0 = pa0 - grp_bcast(fa, lane, 0); pl0 = pl0 - grp_bcast(fl, lane, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (P.self_collisions) tree_self_collision(P, T, G, wsw, ei, c, o, E, R0, pa0, pl0);
+        tree_inward(P, T, wsw, ei, c, o);
+        // ---- base: the chains that hang from it, in table order; [A B; B^T D][alpha; acc] = -[pa; pl]
+        S3 Db = {E.base_m, 0.f, 0.f, E.base_m, 0.f, E.base_m};
+        M3 Bb = {0.f, -h0.z, h0.y, h0.z, 0.f, -h0.x, -h0.y, h0.x, 0.f};
+        for (int k = 0; k < T.nh0; ++k) tree_add_up(wsw, ei, o.up + T.heads0[k] * T_UPW, Ab, Bb, Db, pa0, pl0);
+        const S3 Di = inv(Db);
+        const V3 b0 = v3(Bb.a00, Bb.a01, Bb.a02), b1 = v3(Bb.a10, Bb.a11, Bb.a12), b2 = v3(Bb.a20, Bb.a21, Bb.a22);
+        const V3 d0 = mul(Di, b0), d1 = mul(Di, b1), d2 = mul(Di, b2);
+        const S3 Sc = {Ab.xx - dot(b0, d0), Ab.xy - dot(b0, d1), Ab.xz - dot(b0, d2), Ab.yy - dot(b1, d1), Ab.yz - dot(b1, d2), Ab.zz - dot(b2, d2)};
+        const V3 alpha = mul(inv(Sc), mul(Bb, mul(Di, pl0)) - pa0);
+        const V3 acc = neg(mul(Di, pl0 + mulT(Bb, alpha)));
+        tree_accel(P, T, wsw, ei, c, o, alpha, acc);
+        {   // integrate the base (semi-implicit Euler), every lane of the group alike
+            const float dt = P.sim_dt;
+            GenBase& B = E.B;
+            const V3 lin = acc + cross(B.ang, B.vel);
+            B.vel = v3(B.vel.x + (lin.x + P.gravity[0]) * dt, B.vel.y + (lin.y + P.gravity[1]) * dt, B.vel.z + (lin.z + P.gravity[2]) * dt);
+            B.ang = fma3(alpha, dt, B.ang);
+            B.pos = fma3(B.vel, dt, B.pos);
+            const float hx = 0.5f * dt * B.ang.x, hy = 0.5f * dt * B.ang.y, hz = 0.5f * dt * B.ang.z;
+            const float x = B.qx, y = B.qy, z = B.qz, ww = B.qw;
+            const float nx = x + hx * ww + hy * z - hz * y, ny = y - hx * z + hy * ww + hz * x;
+            const float nz = z + hx * y - hy * x + hz * ww, nw = ww - hx * x - hy * y - hz * z;
+            const float n = grx_rsq(nx * nx + ny * ny + nz * nz + nw * nw);
+            B.qx = nx * n; B.qy = ny * n; B.qz = nz * n; B.qw = nw * n;
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            if (deci > 0) {
+                const V3 fv = tw_v3(wsw, ei, o.misc + f * 3);
+                avg_speed[f] = v3(avg_speed[f].x + fabsf(fv.x), avg_speed[f].y + fabsf(fv.y), avg_speed[f].z + fabsf(fv.z));
+            }
+            const V3 F = tw_v3(wsw, ei, o.lf + T.foot_link[f] * 3);
+            avg_force[f] += grx_sqrt(dot(F, F));
+        }
+    }
+    // ---- refresh_rigid_body_state_tensor after the last sub-step: frames of the final state
+    {
+        const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
+        tree_outward<HF, true>(P, T, wsw, ei, c, o, E, R0, false, nullptr);
+    }
+    V3 fpos[2], fvel[2], foot_force[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int b = T.foot_body[f];
+        const R3 R = tw_R(wsw, ei, b * T_NB + T_R);
+        const V3 fr = tw_v3(wsw, ei, b * T_NB + T_RHO) + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
+        fpos[f] = E.B.pos + fr;
+        fvel[f] = tw_v3(wsw, ei, b * T_NB + T_V) + cross(tw_v3(wsw, ei, b * T_NB + T_W), fr);
+        avg_speed[f] = v3((avg_speed[f].x + fabsf(fvel[f].x)) / (float)P.decimation, (avg_speed[f].y + fabsf(fvel[f].y)) / (float)P.decimation,
+                          (avg_speed[f].z + fabsf(fvel[f].z)) / (float)P.decimation);
+        avg_force[f] /= (float)P.decimation;
+        foot_force[f] = tw_v3(wsw, ei, o.lf + T.foot_link[f] * 3);
+    }
+    // termination / collision from the per-link net forces of the LAST sub-step (legged_robot.py:336-353); contact_forces rows
+    bool term_contact = false;
+    float pen_count = 0.f;
+    for (int L = 0; L < T.nlc; ++L) {
+        const V3 F = tw_v3(wsw, ei, o.lf + L * 3);
+        const float n2 = dot(F, F);
+        if ((T.link_flags[L] & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term_contact = true;
+        if ((T.link_flags[L] & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.f;
+        if (act && (L & (TG - 1)) == c) {
+            float* cf = P.contact_forces + (size_t)(T.link_urdf[L] * 3) * N + e;
+            cf[0] = F.x; cf[N] = F.y; cf[2 * N] = F.z;
+        }
+    }
+    float torso_g[2] = {0.f, 0.f}, fore_g[2] = {0.f, 0.f};
+    if (T.torso_body >= 0) {
+        const R3 R = T.torso_body == 0 ? quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw) : tw_R(wsw, ei, T.torso_body * T_NB + T_R);
+        torso_g[0] = -(R.cx.z * T.torso_rot[0] + R.cy.z * T.torso_rot[3] + R.cz.z * T.torso_rot[6]);
+        torso_g[1] = -(R.cx.z * T.torso_rot[1] + R.cy.z * T.torso_rot[4] + R.cz.z * T.torso_rot[7]);
+    }
+    if (T.forehead_body >= 0) {
+        const R3 R = T.forehead_body == 0 ? quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw) : tw_R(wsw, ei, T.forehead_body * T_NB + T_R);
+        fore_g[0] = -(R.cx.z * T.forehead_rot[0] + R.cy.z * T.forehead_rot[3] + R.cz.z * T.forehead_rot[6]);
+        fore_g[1] = -(R.cx.z * T.forehead_rot[1] + R.cy.z * T.forehead_rot[4] + R.cz.z * T.forehead_rot[7]);
+    }
+    // ---- post_physics_step (legged_robot.py:269-334)
+    GenBase& B = E.B;
+    ep_len += 1;
+    const V3 qv = v3(B.qx, B.qy, B.qz);
+    const V3 blv = quat_rotate_inverse(qv, B.qw, B.vel), bav = quat_rotate_inverse(qv, B.qw, B.ang);
+    const V3 pg = quat_rotate_inverse(qv, B.qw, v3(0.f, 0.f, -1.f));
+    if (P.resample_command_interval > 0 && ((uint32_t)ep_len % (uint32_t)P.resample_command_interval) == 0)
+        resample_commands(P, genv, step, GRX_RNG_CMD_TIME, ea.cmd);
+    float* heights = P.heights + e;   // raw measured heights: the scan's points go round the group's lanes
+    float hsum = 0.f;
+    if (HF && P.measure_heights) {
+        const float yaw_n = fmaxf(sqrtf(B.qz * B.qz + B.qw * B.qw), 1e-9f);
+        const float yz = B.qz / yaw_n, yw = B.qw / yaw_n;
+        for (int k = c; k < nh; k += TG) {
+            const float h = height_sample(P, *P.tables, yz, yw, B.pos, k);
+            if (act) heights[(size_t)k * N] = h;
+            hsum += h;
+        }
+        hsum = grp_sum(hsum);
+    } else
+        for (int k = c; k < nh; k += TG) if (act) heights[(size_t)k * N] = 0.f;
+    if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {
+        B.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
+        B.vel.y = urand(P, genv, step, GRX_RNG_PUSH, 1, -P.max_push_vel_xy, P.max_push_vel_xy);
+    }
+    // feet timers (legged_robot_fftai.py:108-133)
+    bool contact[2], contact_filt[2], first_contact[2];
+    float feet_height[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        contact[f] = foot_force[f].z > 1.0f;
+        contact_filt[f] = contact[f] || contact_last[f];
+        contact_last[f] = contact[f];
+        first_contact[f] = (air_time[f] > 0.f) && contact_filt[f];
+        air_time[f] += dtp;
+        feet_height[f] = nh > 0 ? (fpos[f].z * (float)nh - hsum) / (float)nh : fpos[f].z;
+        land_time[f] = (land_time[f] + dtp) * (contact[f] ? 1.f : 0.f);
+    }
+    bool reset = term_contact || (fabsf(pg.z) < P.termination_gravity_z);
+    const bool time_out = (float)ep_len > P.max_episode_length;
+    reset = reset || time_out;
+    // ---- compute_reward (legged_robot.py:355-375; terms legged_robot_fftai.py:180-352, gr1t1.py:338-589): a lane sums over
+    // its chain's joints, the group adds up
+    float r[NT];
+    {
+        const float as = P.action_scale, H = P.swing_feet_height_target, Tt_ = P.feet_air_time_target;
+        const GRX_AS4 float* sg = P.reward_sigma;
+        float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
+        float tor_hr = 0.f, vel_kn = 0.f, ank[2] = {0.f, 0.f};
+        for (int g = first; g <= last; ++g) {
+            const int j = T.sched[c][g] - 1;
+            const TreeDof& td = T.dof[j];
+            const float ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j), al = TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j), qj = TW(o.dof + TD_Q * GRX_MAX_DOFS + j),
+                        qdj = TW(o.dof + TD_QD * GRX_MAX_DOFS + j), tj = TW(o.dof + TD_TAU * GRX_MAX_DOFS + j);
+            const uint32_t bit = 1u << j;
+            s1 += fabsf((al - ac) * as);
+            if (P.knee_mask & bit) { s3 += fabsf((ac - al) * as); vel_kn += fabsf(qdj); }
+            sacc += fabsf((qdj - P.last_dof_vel[(size_t)j * N + e]) / dtp);
+            stor += fabsf(tj);
+            svel += fabsf(qdj);
+            const float po = fabsf(qj - td.q0);
+            spose += po;
+            if (P.hip_yaw_mask & bit) shy += po;
+            if (P.hip_roll_mask & bit) tor_hr += fabsf(tj);
+            if (P.ankle_left_mask & bit) ank[0] += fabsf(tj);
+            if (P.ankle_right_mask & bit) ank[1] += fabsf(tj);
+            const float a = ac * as;
+            float oa = 0.f, op = 0.f;
+            if (a - td.slo < 0.f) oa += -(a - td.slo);
+            if (a - td.shi > 0.f) oa += (a - td.shi);
+            sla += oa * oa;
+            if (qj - td.slo < 0.f) op += -(qj - td.slo);
+            if (qj - td.shi > 0.f) op += (qj - td.shi);
+            slp += fabsf(op);
+            slv += fminf(fmaxf(fabsf(qdj) - td.vlim * P.soft_dof_vel_limit, 0.f), 1.f);
+            slt += fmaxf(fabsf(tj) - td.effort * P.soft_torque_limit, 0.f);
+        }
+        s1 = grp_sum(s1); s3 = grp_sum(s3); sacc = grp_sum(sacc); stor = grp_sum(stor); svel = grp_sum(svel); spose = grp_sum(spose);
+        sla = grp_sum(sla); slp = grp_sum(slp); slt = grp_sum(slt); slv = grp_sum(slv); shy = grp_sum(shy);
+        tor_hr = grp_sum(tor_hr); vel_kn = grp_sum(vel_kn); ank[0] = grp_sum(ank[0]); ank[1] = grp_sum(ank[1]);
+        const float hmin = fminf(feet_height[0], feet_height[1]);
+        float lift = 0.f, af = 0.f, ah = 0.f, at = 0.f, lt = 0.f, exy = 0.f, ez = 0.f, stum = 0.f, ncontact = 0.f;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const float h = feet_height[f];
+            lift += ank[f] * fabsf(h) * (h > H * 0.5f ? 1.f : 0.f);
+            const float mid = fabsf(air_time[f] - Tt_ * 0.5f);
+            af += mid * avg_force[f];
+            ah += mid * fabsf(h - hmin - H);
+            at += expf(sg[GRX_REW_FEET_AIR_TIME] * fabsf(air_time[f] - Tt_)) * (first_contact[f] ? 1.f : 0.f);
+            const float le = (land_time[f] - P.feet_land_time_max) * (land_time[f] > P.feet_land_time_max ? 1.f : 0.f);
+            lt += 1.f - expf(sg[GRX_REW_FEET_LAND_TIME] * le);
+            const float close = fabsf(h - H * 0.25f) * (h < H * 0.25f ? 1.f : 0.f) / (H * 0.25f);
+            exy += sqrtf(avg_speed[f].x * avg_speed[f].x + avg_speed[f].y * avg_speed[f].y) * close;
+            const float far = fabsf(h - H * 3.f / 4.f) * (h > H * 3.f / 4.f ? 1.f : 0.f) / (H * 1.f / 4.f);
+            ez += fabsf(avg_speed[f].z) * far;
+            const V3 F = foot_force[f];
+            float serr = sqrtf(F.x * F.x + F.y * F.y) - P.feet_stumble_ratio * fabsf(F.z);
+            serr = serr * (serr > 0.f ? 1.f : 0.f);
+            stum += 1.f - expf(sg[GRX_REW_FEET_STUMBLE] * serr);
+            ncontact += contact[f] ? 1.f : 0.f;
+        }
+        const float cmd_n = sqrtf(ea.cmd[0] * ea.cmd[0] + ea.cmd[1] * ea.cmd[1]);
+        const float moving = cmd_n > 0.1f ? 1.f : 0.f;
+        r[GRX_REW_ACTION_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF] * s1);
+        r[GRX_REW_ACTION_DIFF_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_DIFF] * s1);   // last_last_actions == last_actions
+        r[GRX_REW_ACTION_DIFF_KNEE] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_KNEE] * s3);
+        r[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] * fabsf(0.f - bav.y));
+        r[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] * fabsf(0.f - bav.x));
+        r[GRX_REW_CMD_DIFF_ANG_VEL_YAW] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_YAW] * fabsf(ea.cmd[2] - bav.z));
+        r[GRX_REW_CMD_DIFF_BASE_HEIGHT] = expf(sg[GRX_REW_CMD_DIFF_BASE_HEIGHT] * (fabsf(bho_stale) * (bho_stale < 0.f ? 1.f : 0.f)));
+        r[GRX_REW_CMD_DIFF_BASE_ORIENT] = expf(sg[GRX_REW_CMD_DIFF_BASE_ORIENT] * (fabsf(pg.x) + fabsf(pg.y)));
+        r[GRX_REW_CMD_DIFF_TORSO_ORIENT] = T.torso_body >= 0 ? expf(sg[GRX_REW_CMD_DIFF_TORSO_ORIENT] * (fabsf(torso_g[0]) + fabsf(torso_g[1]))) : 0.f;
+        r[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] = T.forehead_body >= 0 ? expf(sg[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] * (fabsf(fore_g[0]) + fabsf(fore_g[1]))) : 0.f;
+        r[GRX_REW_CMD_DIFF_LIN_VEL_X] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_X] * fabsf(ea.cmd[0] - blv.x));
+        r[GRX_REW_CMD_DIFF_LIN_VEL_Y] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Y] * fabsf(ea.cmd[1] - blv.y));
+        r[GRX_REW_CMD_DIFF_LIN_VEL_Z] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Z] * fabsf(0.f - blv.z));
+        r[GRX_REW_COLLISION] = 1.f - expf(sg[GRX_REW_COLLISION] * pen_count);
+        r[GRX_REW_DOF_ACC_NEW] = 1.f - expf(sg[GRX_REW_DOF_ACC_NEW] * sacc);
+        r[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] = 1.f - expf(sg[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] * lift);
+        r[GRX_REW_DOF_TOR_NEW] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW] * stor);
+        r[GRX_REW_DOF_TOR_NEW_HIP_ROLL] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW_HIP_ROLL] * tor_hr);
+        r[GRX_REW_DOF_VEL_NEW] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW] * svel);
+        r[GRX_REW_DOF_VEL_NEW_KNEE] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW_KNEE] * vel_kn);
+        r[GRX_REW_FEET_AIR_FORCE] = expf(sg[GRX_REW_FEET_AIR_FORCE] * af) * moving;
+        r[GRX_REW_FEET_AIR_HEIGHT] = expf(sg[GRX_REW_FEET_AIR_HEIGHT] * ah) * moving;
+        r[GRX_REW_FEET_AIR_TIME] = at * moving;
+        r[GRX_REW_FEET_LAND_TIME] = lt * moving;
+        r[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] = expf(sg[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] * exy);
+        r[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] = expf(sg[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] * ez);
+        r[GRX_REW_FEET_STUMBLE] = stum;
+        r[GRX_REW_LIMITS_ACTIONS] = 1.f - expf(sg[GRX_REW_LIMITS_ACTIONS] * sla);
+        r[GRX_REW_LIMITS_DOF_POS] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_POS] * slp);
+        r[GRX_REW_LIMITS_DOF_TOR] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_TOR] * slt);
+        r[GRX_REW_LIMITS_DOF_VEL] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_VEL] * slv);
+        r[GRX_REW_ON_THE_AIR] = ncontact == 0.f ? 1.f : 0.f;
+        r[GRX_REW_POSE_OFFSET] = expf(sg[GRX_REW_POSE_OFFSET] * spose);
+        r[GRX_REW_POSE_OFFSET_HIP_YAW] = 1.f - expf(sg[GRX_REW_POSE_OFFSET_HIP_YAW] * shy);
+        r[GRX_REW_STAND_STILL] = expf(sg[GRX_REW_STAND_STILL] * spose) * (cmd_n < 0.1f ? 1.f : 0.f);
+        r[GRX_REW_TERMINATION] = (reset && !time_out) ? 1.f : 0.f;
+    }
+    float rew = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float sc_t = P.reward_scale_dt[t];
+        float rt = 0.f;
+        if (t != GRX_REW_TERMINATION && sc_t != 0.f) { rt = r[t] * sc_t; rew += rt; }
+        r[t] = rt;
+    }
+    if (P.only_positive_rewards) rew = fmaxf(rew, 0.f);
+    if (P.reward_scale_dt[GRX_REW_TERMINATION] != 0.f) {
+        const float rt = r[GRX_REW_TERMINATION] = ((reset && !time_out) ? 1.f : 0.f) * P.reward_scale_dt[GRX_REW_TERMINATION];
+        rew += rt;
+    }
+    // episode sums (the group's first lane); finished episodes -> the block's statistics row (deterministic lane order)
+    const unsigned long long reset_mask = __ballot(reset && actl);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float es = ((P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f) + r[t];
+        if (reset_mask) {
+            float acc_ = 0.f;
+            unsigned long long m = reset_mask;
+            while (m) { const int L = __ffsll((long long)m) - 1; m &= m - 1; acc_ += __shfl(es, L); }
+            if (lane == 0) atomicAdd(&s_stat[t], acc_);   // (two waves per block: LDS float add of two values, order-free)
+        }
+        if (actl && P.reward_scale_dt[t] != 0.f) {
+            P.episode_sums[(size_t)t * N + e] = reset ? 0.f : es;
+            if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
+        }
+    }
+    if (lane == 0) atomicAdd(&s_stat[NT], (float)__popcll(reset_mask));
+    // ---- reset_idx (masked, in-kernel): a chain's joints by its lane, the base in every lane (same counters, same values)
+    if (reset) {
+        if (P.curriculum && P.terrain_type != GRX_TERRAIN_PLANE) {
+            const float dx = B.pos.x - ea.origin[0], dy = B.pos.y - ea.origin[1];
+            const float dist = sqrtf(dx * dx + dy * dy);
+            const int up = dist > P.terrain_length * 0.5f;
+            const float cn = sqrtf(ea.cmd[0] * ea.cmd[0] + ea.cmd[1] * ea.cmd[1]);
+            const int down = (dist < cn * P.max_episode_length_s * 0.5f) && !up;
+            ea.level += up - down;
+            if (ea.level >= P.num_terrain_rows) {
+                const float u = grx_rand(P.seed, genv, step, GRX_RNG_CURRICULUM, 0);
+                ea.level = min((int)(u * (float)P.num_terrain_rows), P.num_terrain_rows - 1);
+            } else if (ea.level < 0)
+                ea.level = 0;
+            const float* og = P.terrain_origins + ((size_t)ea.level * P.num_terrain_cols + ea.type) * 3;
+            ea.origin[0] = og[0]; ea.origin[1] = og[1]; ea.origin[2] = og[2];
+        }
+        for (int g = first; g <= last; ++g) {
+            const int j = T.sched[c][g] - 1;
+            const float f_ = P.randomize_init_dof_pos ? urand(P, genv, step, GRX_RNG_RESET_DOF, (uint32_t)j, 0.5f, 1.5f) : 1.0f;
+            TW(o.dof + TD_Q * GRX_MAX_DOFS + j) = f_ * T.dof[j].q0;
+            TW(o.dof + TD_QD * GRX_MAX_DOFS + j) = 0.f;
+        }
+        B.pos = v3(P.init_pos[0] + ea.origin[0], P.init_pos[1] + ea.origin[1], P.init_pos[2] + ea.origin[2]);
+        if (P.terrain_type != GRX_TERRAIN_PLANE) {
+            B.pos.x += urand(P, genv, step, GRX_RNG_RESET_ROOT, 0, -1.0f, 1.0f);
+            B.pos.y += urand(P, genv, step, GRX_RNG_RESET_ROOT, 1, -1.0f, 1.0f);
+        }
+        const float yaw = urand(P, genv, step, GRX_RNG_RESET_ROOT, 2, -6.283185307179586f, 6.283185307179586f);
+        float sy, cy;
+        sincosf(yaw * 0.5f, &sy, &cy);
+        B.qx = 0.f; B.qy = 0.f; B.qz = sy; B.qw = cy;
+        if (P.randomize_init_base_velocity) {
+            B.vel = v3(urand(P, genv, step, GRX_RNG_RESET_ROOT, 3, -0.5f, 0.5f), urand(P, genv, step, GRX_RNG_RESET_ROOT, 4, -0.5f, 0.5f),
+                       urand(P, genv, step, GRX_RNG_RESET_ROOT, 5, -0.5f, 0.5f));
+            B.ang = v3(urand(P, genv, step, GRX_RNG_RESET_ROOT, 6, -0.5f, 0.5f), urand(P, genv, step, GRX_RNG_RESET_ROOT, 7, -0.5f, 0.5f),
+                       urand(P, genv, step, GRX_RNG_RESET_ROOT, 8, -0.5f, 0.5f));
+        } else {
+            B.vel = v3(0.f, 0.f, 0.f);
+            B.ang = v3(0.f, 0.f, 0.f);
+        }
+        resample_commands(P, genv, step, GRX_RNG_CMD_RESET, ea.cmd);
+        TW(o.an + c * 3 + 2) = 0.f;   // the lane's anchor slot
+        for (int f = 0; f < 2; ++f) { air_time[f] = 0.f; land_time[f] = 0.f; contact_last[f] = false; }
+        ep_len = 0;
+    }
+    {   // statistics row NT + 1: terrain levels after this step's curriculum moves (legged_robot.py:427-428)
+        const float ls = level_sum(ea.level, actl);
+        if (lane == 0) atomicAdd(&s_stat[NT + 1], ls);
+    }
+    // ---- compute_observations (legged_robot_fftai.py:148-167, gr1t1.py:281-336)
+    float* obs = (obs_out ? obs_out : P.obs) + (size_t)e * nobs;
+    float* pri = (pri_out ? pri_out : P.pri_obs) + (size_t)e * npri;
+    const float clipo = P.clip_observations;
+    float bho = 0.f;
+    {
+        float sum = 0.f;
+        for (int k = c; k < nh; k += TG) {
+            float d = B.pos.z - P.base_height_target - heights[(size_t)k * N];
+            d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
+            if (act) pri[nobs + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -clipo), clipo);
+            sum += d;
+        }
+        sum = grp_sum(sum);
+        bho = nh > 0 ? sum / (float)nh : 0.f;
+    }
+    if (act) {
+        auto put = [&](int idx, float val, float nscale) {
+            pri[idx] = fminf(fmaxf(val, -clipo), clipo);   // pri_obs copies obs BEFORE noise
+            float ov = val;
+            if (P.add_noise && nscale != 0.f) {
+                float u;
+                if (noise_in) u = noise_in[(size_t)e * nobs + idx];
+                else if (idx < 9) u = grx_rand(P.seed, genv, step, GRX_RNG_NOISE, (uint32_t)(idx - 3));
+                else {   // dof terms: one stream per half of the dof range (the oracle's scheme)
+                    const int g_ = (idx - 9) / nd, j = (idx - 9) % nd, half_ = nd / 2;
+                    const bool right = j >= half_;
+                    u = grx_rand(P.seed, genv, step, right ? GRX_RNG_NOISE_DOF_R : GRX_RNG_NOISE_DOF_L, (uint32_t)(g_ * half_ + (right ? j - half_ : j)));
+                }
+                ov += (2.f * u - 1.f) * nscale;
+            }
+            obs[idx] = fminf(fmaxf(ov, -clipo), clipo);
+        };
+        const float np_ = P.noise_dof_pos * P.noise_level * P.obs_scale_dof_pos, nv = P.noise_dof_vel * P.noise_level * P.obs_scale_dof_vel;
+        const float nac = P.noise_action * P.noise_level * P.obs_scale_action;
+        for (int g = first; g <= last; ++g) {   // this lane's joints: observations, history, state
+            const int j = T.sched[c][g] - 1;
+            const size_t oj = (size_t)j * N + e;
+            const float qj = TW(o.dof + TD_Q * GRX_MAX_DOFS + j), qdj = TW(o.dof + TD_QD * GRX_MAX_DOFS + j), ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j);
+            put(9 + j, (qj - T.dof[j].q0) * P.obs_scale_dof_pos, np_);
+            put(9 + nd + j, qdj * P.obs_scale_dof_vel, nv);
+            put(9 + 2 * nd + j, ac * P.obs_scale_action, nac);
+            P.q[oj] = qj; P.qd[oj] = qdj; P.actions[oj] = ac; P.torques[oj] = TW(o.dof + TD_TAU * GRX_MAX_DOFS + j);
+            P.last_actions[oj] = ac; P.last_dof_vel[oj] = qdj;   // history (legged_robot.py:299-300, after reset_idx)
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P.anchors[(size_t)(c * 3 + k) * N + e] = TW(o.an + c * 3 + k);
+        if (lead) {
+            put(0, ea.cmd[0], 0.f); put(1, ea.cmd[1], 0.f); put(2, ea.cmd[2], 0.f);
+            const float na = P.noise_ang_vel * P.noise_level * P.obs_scale_ang_vel, ng = P.noise_gravity * P.noise_level * P.obs_scale_gravity;
+            put(3, bav.x * P.obs_scale_ang_vel, na); put(4, bav.y * P.obs_scale_ang_vel, na); put(5, bav.z * P.obs_scale_ang_vel, na);
+            put(6, pg.x * P.obs_scale_gravity, ng); put(7, pg.y * P.obs_scale_gravity, ng); put(8, pg.z * P.obs_scale_gravity, ng);
+            pri[nobs + 0] = fminf(fmaxf(blv.x * P.obs_scale_lin_vel, -clipo), clipo);
+            pri[nobs + 1] = fminf(fmaxf(blv.y * P.obs_scale_lin_vel, -clipo), clipo);
+            pri[nobs + 2] = fminf(fmaxf(blv.z * P.obs_scale_lin_vel, -clipo), clipo);
+            pri[nobs + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                pri[nobs + 4 + f] = (reset ? false : contact[f]) ? 1.f : 0.f;   // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
+                pri[nobs + 6 + f] = fminf(fmaxf(feet_height[f] * P.obs_scale_height, -clipo), clipo);
+            }
+            // ---- store the env's state
+            const float rs[13] = {B.pos.x, B.pos.y, B.pos.z, B.qx, B.qy, B.qz, B.qw, B.vel.x, B.vel.y, B.vel.z, B.ang.x, B.ang.y, B.ang.z};
+#pragma unroll
+            for (int i = 0; i < 13; ++i) P.root[(size_t)i * N + e] = rs[i];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                P.air_time[(size_t)f * N + e] = air_time[f] * (contact_filt[f] ? 0.f : 1.f);   // legged_robot_fftai.py:97
+                P.land_time[(size_t)f * N + e] = land_time[f];
+                P.feet_contact[(size_t)f * N + e] = (reset ? false : contact[f]) ? 1 : 0;
+                P.feet_height[(size_t)f * N + e] = feet_height[f];
+                P.avg_force[(size_t)f * N + e] = avg_force[f];
+                const float ff[3] = {foot_force[f].x, foot_force[f].y, foot_force[f].z}, fp[3] = {fpos[f].x, fpos[f].y, fpos[f].z};
+                const float as_[3] = {avg_speed[f].x, avg_speed[f].y, avg_speed[f].z};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    P.feet_force[(size_t)(f * 3 + i) * N + e] = ff[i];
+                    P.feet_pos[(size_t)(f * 3 + i) * N + e] = fp[i];
+                    P.avg_speed[(size_t)(f * 3 + i) * N + e] = as_[i];
+                }
+            }
+            P.commands[e] = ea.cmd[0]; P.commands[N + e] = ea.cmd[1]; P.commands[2 * N + e] = ea.cmd[2];
+            P.base_lin_vel[e] = blv.x; P.base_lin_vel[N + e] = blv.y; P.base_lin_vel[2 * N + e] = blv.z;
+            P.base_ang_vel[e] = bav.x; P.base_ang_vel[N + e] = bav.y; P.base_ang_vel[2 * N + e] = bav.z;
+            P.proj_grav[e] = pg.x; P.proj_grav[N + e] = pg.y; P.proj_grav[2 * N + e] = pg.z;
+            P.origins[e] = ea.origin[0]; P.origins[N + e] = ea.origin[1]; P.origins[2 * N + e] = ea.origin[2];
+            P.levels[e] = ea.level;
+            P.base_heights_offset[e] = bho;
+            P.ep_len[e] = ep_len;
+            P.rew[e] = rew;
+            P.reset[e] = reset ? 1 : 0;
+            P.time_out[e] = time_out ? 1 : 0;
+            P.term_contact[e] = term_contact ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NSTAT) stat_row(P, sq.seq, threadIdx.x)[blockIdx.x] = s_stat[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.stat_nblocks[sq.seq & 1] = (int)gridDim.x;
+}
+#undef TW
