@@ -135,3 +135,26 @@ def test_tree_and_generic_kernels_agree_on_the_full_body(monkeypatch):
     for k in ("REW", "OBS", "PRI_OBS"):
         d = (a[k][same] - b[k][same]).abs()
         assert float((d > 2e-2).float().mean()) < 0.01, k
+
+
+def test_full_body_rigid_body_states_are_the_forward_kinematics_of_the_state(monkeypatch):
+    """GRX_T_RIGID_BODY_STATES of the 37-link full body, written by the tree kernel after its last sub-step: the link frames of
+    the state it publishes (tests/kinematics_ref.py, envs that did not reset) and the oracle's."""
+    from tests.kinematics_ref import BodyKinematics
+    from tests.test_kinematics import rbs_err
+    from wiki_grx_gym_amd.model import RobotModel
+    pick(monkeypatch, "tree")
+    cfg = make_cfg("GR1T1Full", dr=True)
+    hip, ora = make_sims(cfg, 96)
+    hip.reset_all(); ora.reset_all()
+    physics_lockstep(hip, ora, cfg, steps=5, scale=0.3)
+    rm = RobotModel("gr1t1")
+    kin = BodyKinematics(rm, "cpu")
+    live = ~ora.tensor("RESET").bool() & ~hip.tensor("RESET").cpu().bool()
+    a = hip.tensor("RIGID_BODY_STATES").cpu()[:, :rm.num_links]
+    own = kin.rigid_body_states(hip.tensor("ROOT_STATES").cpu(), hip.tensor("DOF_POS").cpu(), hip.tensor("DOF_VEL").cpu())
+    ep, eq, ev = rbs_err(a[live], own[live])
+    assert live.sum() > 48 and ep <= 2e-5 and eq <= 2e-5 and ev <= 2e-4, (ep, eq, ev)
+    b = ora.tensor("RIGID_BODY_STATES")[:, :rm.num_links]
+    ep, eq, ev = rbs_err(a[live], b[live])
+    assert ep <= 1e-3 and eq <= 5e-3, (ep, eq, ev)

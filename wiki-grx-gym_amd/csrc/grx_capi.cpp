@@ -698,9 +698,26 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(stats, NSTAT); DA(prof, (size_t)2 * nblocks * GRX_PROF_SLOTS);   // (16-env blocks in the quad layout)
     rc = dalloc(s, &s->d_mask, N);
     if (rc) { grx_destroy(s); return rc; }
-    P.publish_rbs = c.publish_rigid_body_states && !generic;   // (the generic-tree kernel does not publish link frames yet)
+    P.publish_rbs = c.publish_rigid_body_states;   // (the one-lane generic fallback does not publish link frames: cleared below)
     P.num_links = m.num_links;
     DA(rbs, P.publish_rbs ? (size_t)13 * GRX_MAX_LINKS * N : 1);
+    {
+        std::vector<LinkTab> lt(1);
+        memset(&lt[0], 0, sizeof(LinkTab));
+        if (m.num_links < 0 || m.num_links > GRX_MAX_LINKS) { grx_destroy(s); return fail(GRX_ERR_INVALID_ARGUMENT, "grx_model.num_links out of range"); }
+        lt[0].n = m.num_links;
+        for (int l = 0; l < m.num_links; ++l) {
+            if (m.link_body[l] < 0 || m.link_body[l] >= m.num_bodies) { grx_destroy(s); return fail(GRX_ERR_INVALID_ARGUMENT, "grx_model.link_body out of range"); }
+            lt[0].body[l] = m.link_body[l];
+            for (int a = 0; a < 3; ++a) lt[0].pos[l][a] = m.link_pos[l][a];
+            for (int a = 0; a < 9; ++a) lt[0].rot[l][a] = m.link_rot[l][a];
+        }
+        LinkTab* dl = nullptr;
+        rc = dalloc(s, &dl, 1);
+        if (rc) { grx_destroy(s); return rc; }
+        HIP_TRY(hipMemcpy(dl, &lt[0], sizeof(LinkTab), hipMemcpyHostToDevice));
+        P.link_tab = dl;
+    }
     if (!generic) {
         RbsTables rt;
         rc = build_rbs_tables(m, rt);
@@ -924,6 +941,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     if (generic) {
         rc = build_generic(s, c);
         if (rc) { grx_destroy(s); return rc; }
+        if (!s->d_tree) { s->hp.publish_rbs = 0; s->desc[GRX_T_RIGID_BODY_STATES].data = nullptr; }
     }
     {
         void* hp_ = nullptr;

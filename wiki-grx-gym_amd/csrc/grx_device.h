@@ -115,6 +115,9 @@ struct TreeTab {
     int32_t pad1[2];
 };
 
+// every URDF link frame by carrying body (the tree kernel's GRX_T_RIGID_BODY_STATES)
+struct LinkTab { int32_t n, pad[3]; int32_t body[GRX_MAX_LINKS]; float pos[GRX_MAX_LINKS][3]; float rot[GRX_MAX_LINKS][9]; };
+
 // Large read-only tables, in device memory.
 struct KTables {
     SideConst side[2];
@@ -184,6 +187,7 @@ struct KParams {
     float* stat_hist;      // [GRX_STATS_HISTORY][GRX_NSTAT]: GRX_T_EPISODE_STATS as of every step (extras["episode"] without a copy per step)
     float* rbs;            // GRX_T_RIGID_BODY_STATES [(link * 13 + c)][N], written when publish_rbs
     const RbsTables* rbs_tab;
+    const LinkTab* link_tab;
     int32_t publish_rbs, num_links;
     int32_t nd;        // dofs of the model (10 on the fast path)
     long long* prof;   // GRX_PROFILE_SECTIONS builds only: [nblocks][16] s_memtime stamps

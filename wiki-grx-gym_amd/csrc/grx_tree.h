@@ -463,6 +463,39 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
         tree_outward<HF, true>(P, T, wsw, ei, c, o, E, R0, false, nullptr);
     }
+    if (P.publish_rbs) {   // GRX_T_RIGID_BODY_STATES (legged_robot.py:113,134): every URDF link frame of that state, the links go round the lanes
+        const LinkTab& LT = *P.link_tab;
+        const R3 Rb0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
+        for (int l = c; l < LT.n; l += TG) {
+            const int b = LT.body[l];
+            const R3 Rb = b == 0 ? Rb0 : tw_R(wsw, ei, b * T_NB + T_R);
+            const V3 rho_b = b == 0 ? v3(0.f, 0.f, 0.f) : tw_v3(wsw, ei, b * T_NB + T_RHO);
+            const V3 w_b = b == 0 ? E.B.ang : tw_v3(wsw, ei, b * T_NB + T_W), v_b = b == 0 ? E.B.vel : tw_v3(wsw, ei, b * T_NB + T_V);
+            const V3 r_ = rho_b + rot(Rb, v3(LT.pos[l][0], LT.pos[l][1], LT.pos[l][2]));
+            const V3 vl = v_b + cross(w_b, r_);
+            // R_link = R_body * (link -> body), row-major entries m[i][k]
+            float m[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const V3 col = rot(Rb, v3(LT.rot[l][k], LT.rot[l][3 + k], LT.rot[l][6 + k]));   // column k of the link rotation, in world axes
+                m[k] = col.x; m[3 + k] = col.y; m[6 + k] = col.z;
+            }
+            float qx, qy, qz, qw;   // largest-component form (the oracle's m3_to_quat)
+            const float t0 = 1 + m[0] - m[4] - m[8], t1 = 1 - m[0] + m[4] - m[8], t2 = 1 - m[0] - m[4] + m[8], t3 = 1 + m[0] + m[4] + m[8];
+            if (t3 >= t0 && t3 >= t1 && t3 >= t2) { qx = m[7] - m[5]; qy = m[2] - m[6]; qz = m[3] - m[1]; qw = t3; }
+            else if (t0 >= t1 && t0 >= t2) { qx = t0; qy = m[1] + m[3]; qz = m[2] + m[6]; qw = m[7] - m[5]; }
+            else if (t1 >= t2) { qx = m[1] + m[3]; qy = t1; qz = m[5] + m[7]; qw = m[2] - m[6]; }
+            else { qx = m[2] + m[6]; qy = m[5] + m[7]; qz = t2; qw = m[3] - m[1]; }
+            const float qn = grx_rsq(qx * qx + qy * qy + qz * qz + qw * qw);
+            if (act) {
+                float* o_ = P.rbs + (size_t)(l * 13) * N + e;
+                o_[0] = E.B.pos.x + r_.x; o_[N] = E.B.pos.y + r_.y; o_[2 * N] = E.B.pos.z + r_.z;
+                o_[3 * N] = qx * qn; o_[4 * N] = qy * qn; o_[5 * N] = qz * qn; o_[6 * N] = qw * qn;
+                o_[7 * N] = vl.x; o_[8 * N] = vl.y; o_[9 * N] = vl.z;
+                o_[10 * N] = w_b.x; o_[11 * N] = w_b.y; o_[12 * N] = w_b.z;
+            }
+        }
+    }
     V3 fpos[2], fvel[2], foot_force[2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
