@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--terrain", choices=["rough", "flat"], default="rough")
     ap.add_argument("--robot", choices=["lower_limb", "full_body"], default="lower_limb",
-                    help="full_body: the 32-DOF GR1T1 of BASELINE.json config 5 (generic-tree kernel), not the headline")
+                    help="full_body: the 32-DOF GR1T1 of BASELINE.json config 5 (tree kernel, grx_tree.h), not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=4096)
     ap.add_argument("--cpu-steps", type=int, default=0, help="0 = auto (about 15 s of CPU work)")
@@ -210,7 +210,7 @@ def main():
         # FETCH_SIZE is a lower bound on gfx950 (MI355X_MICROARCH.md), see the note inside the file.
         traffic, traffic_src, valu_insts, valu_src = None, None, None, None
         headline = args.robot == "lower_limb" and args.terrain == "rough" and n_local == 4096
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_rough4096.json")
             if headline and traffic is None and os.path.exists(pmc):
                 try:
@@ -242,19 +242,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"GR1T1 {'lower-limb (10 DOF)' if args.robot == 'lower_limb' else 'full body (32 DOF, generic-tree kernel)'}, {'rough-terrain curriculum heightfield 10x20 tiles + 121-pt height scan' if args.terrain == 'rough' else 'flat plane'}, "
+            "config": {"workload": f"GR1T1 {'lower-limb (10 DOF)' if args.robot == 'lower_limb' else 'full body (32 DOF, tree kernel)'}, {'rough-terrain curriculum heightfield 10x20 tiles + 121-pt height scan' if args.terrain == 'rough' else 'flat plane'}, "
                                    f"{n_local} envs/GPU, decimation 10 @ dt 0.002, DR+noise+push on, action latency 5 sub-steps, random actions U[clip_min,clip_max]",
                        "envs_per_gpu": n_local, "global_envs": n_total, "parallelism": f"env-sharded x{world} (no data-path collective)",
                        "finite_outputs": finite, "prespin_ms": prespin},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per * n_local,
-                         "kernel": "grx_step_kernel" if args.robot == "lower_limb" else "grx_step_generic", "kernel_ms": kern_ms, "launches_timed": launches,
+                         "kernel": ("grx_step_kernel_quad" if n_local <= 4096 else "grx_step_kernel") if args.robot == "lower_limb" else "grx_step_tree", "kernel_ms": kern_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_env_step": bytes_per,
                          "valu_issue_frac": (valu_insts / (kern_ms * 1e-3) / VALU_ISSUE_PEAK) if (valu_insts and kern_ms > 0) else None,
                          "valu_insts_per_launch": valu_insts, "valu_issue_peak_per_s": VALU_ISSUE_PEAK, "valu_source": valu_src,
                          "note": ("instruction-issue bound at this batch size (one wave per SIMD, DESIGN.md sections 4.1 and 5); HBM is the contractual roofline"
-                                  if args.robot == "lower_limb" else "generic-tree kernel: bound by its global-memory workspace round trips (DESIGN.md section 4.3)")},
+                                  if args.robot == "lower_limb" else "tree kernel (a lane group per env, a chain per lane): instruction-issue bound, two waves per CU (DESIGN.md section 4.3)")},
         }
         if world == 1 and not args.no_cpu_baseline:
             steps = args.cpu_steps

@@ -23,6 +23,10 @@ timeout 600 python bench.py 2> $out/bench_rough.err | tail -1 > $out/bench_rough
 cp $out/bench_rough.json $out/bench_rough_runs.jsonl
 for i in 2 3; do timeout 300 python bench.py --no-cpu-baseline 2>> $out/bench_rough.err | tail -1 >> $out/bench_rough_runs.jsonl; done
 timeout 300 python bench.py --terrain flat --no-cpu-baseline 2> $out/bench_flat.err | tail -1 > $out/bench_flat.json
+# the layouts side by side at the headline size, and the surcharge of GRX_T_RIGID_BODY_STATES (off in the headline)
+: > $out/layouts.jsonl
+for l in 2 4; do GRX_LANES_PER_ENV=$l timeout 300 python bench.py --no-cpu-baseline --steps 8000 --warmup 800 2>/dev/null | tail -1 >> $out/layouts.jsonl; done
+GRX_BENCH_RBS=1 timeout 300 python bench.py --no-cpu-baseline --steps 8000 --warmup 800 2>/dev/null | tail -1 >> $out/layouts.jsonl
 : > $out/sweep.jsonl
 for n in 8192 16384 32768 65536 131072; do
     timeout 300 python bench.py --envs-per-gpu $n --steps $((n <= 32768 ? 4000 : 1500)) --warmup 400 --no-cpu-baseline 2>> $out/sweep.err | tail -1 >> $out/sweep.jsonl

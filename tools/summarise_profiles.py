@@ -28,7 +28,7 @@ out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                "WRITE_SIZE is uncalibrated.")
 json.dump(out, open(f"{dst}/{tag}_pmc_hbm_rough4096.json", "w"), indent=1)
 # SQ passes -> one JSON (mean per launch of grx_step_kernel)
-sq = {"kernel": "grx_step_kernel<true, 4>", "workload": "python bench.py --steps 300 --warmup 50 --no-cpu-baseline (rough, 4096 envs); rocprofv3 --pmc, "
+sq = {"kernel": "grx_step_kernel_quad<true, 4> (the headline layout at 4096 envs)", "workload": "python bench.py --steps 300 --warmup 50 --no-cpu-baseline (rough, 4096 envs); rocprofv3 --pmc, "
       "one pass per counter group (tools/collect_profiles.sh), mean per launch"}
 for f in sorted(glob.glob(f"{src}/pmc_sq*/**/*counter_collection.csv", recursive=True)):
     agg = {}
@@ -46,6 +46,8 @@ if "SQ_INSTS_VALU" in sq:
                      "note": "VALU issue peak = 1024 SIMDs x one wave64 instruction per 2 cycles x 2.4 GHz; SQ_WAIT_ANY includes the helper waves' "
                              "spin on the LDS sequence flags"}
     json.dump(sq, open(f"{dst}/{tag}_pmc_sq_rough4096.json", "w"), indent=1)
+if os.path.exists(f"{src}/layouts.jsonl"):
+    shutil.copy(f"{src}/layouts.jsonl", f"{dst}/{tag}_bench_n1_rough4096_layouts.jsonl")
 for n in (4096, 16384):
     if os.path.exists(f"{src}/bench_full_body_rough{n}.json"):
         shutil.copy(f"{src}/bench_full_body_rough{n}.json", f"{dst}/{tag}_bench_n1_full_body_rough{n}.json")
