@@ -561,6 +561,12 @@ int build_generic(grx_sim* s, const grx_config& c) {
     K.torso_body = T.torso_body; K.forehead_body = T.forehead_body;
     memcpy(K.torso_rot, T.torso_rot, sizeof K.torso_rot); memcpy(K.forehead_rot, T.forehead_rot, sizeof K.forehead_rot);
     K.sph_begin0 = T.sph_begin[0]; K.sph_end0 = T.sph_begin[1];
+    K.nlp = T.nlp;
+    for (int q = 0; q < T.nlp; ++q) {
+        K.lp_ba[q] = (int16_t)T.lp_ba[q]; K.lp_bb[q] = (int16_t)T.lp_bb[q]; K.lp_a[q] = (int16_t)T.lp_a[q]; K.lp_b[q] = (int16_t)T.lp_b[q];
+        for (int a = 0; a < 4; ++a) { K.lp_ca[q][a] = T.lp_ca[q][a]; K.lp_cb[q][a] = T.lp_cb[q][a]; }
+    }
+    for (int l = 0; l <= GEN_MAXLC_H; ++l) K.lc_begin[l] = T.lc_begin[l];
     const int lds = grx_tree_lds_bytes(T.nb, T.nlc);
     if (lds > 160 * 1024 - 1024) return GRX_OK;   // the workspace of two waves does not fit a CU's LDS
     TreeTab* dk = nullptr;

@@ -112,7 +112,12 @@ struct TreeTab {
     int32_t torso_body, forehead_body;
     float torso_rot[9], forehead_rot[9];
     int32_t sph_begin0, sph_end0;                     // the base's own shapes
-    int32_t pad1[2];
+    int32_t nlp, pad1;
+    // self-collision link pairs (grx_generic.h GenTables.lp_*): bodies, compact links, bounding spheres (body frame xyz, radius)
+    int16_t lp_ba[48], lp_bb[48], lp_a[48], lp_b[48];
+    float lp_ca[48][4], lp_cb[48][4];
+    int32_t lc_begin[25];
+    int32_t pad2[3];
 };
 
 // every URDF link frame by carrying body (the tree kernel's GRX_T_RIGID_BODY_STATES)

@@ -28,7 +28,7 @@ enum { T_R = 0, T_RHO = 9, T_W = 12, T_V = 15, T_A = 18, T_S = 21, T_CA = 24, T_
        T_DI = 42, T_U = 43, T_AK = 44, T_H = 50, T_NB = 53 };
 constexpr int T_UPW = 27;    // a chain's hand-over to its parent: A 6, B 9, D 6, pa 3, pl 3
 constexpr int T_MISC = 16;   // foot link velocities before the sub-step (6), foot positions (6), foot velocities (3 + 1 spare) -- see below
-enum { TD_Q = 0, TD_QD = 1, TD_TAU = 2, TD_ACUR = 3, TD_ALAST = 4, TD_N = 5 };
+enum { TD_Q = 0, TD_QD = 1, TD_TAU = 2, TD_ACUR = 3, TD_ALAST = 4, TD_STR = 5, TD_N = 6 };
 
 struct TreeOff { int up, dof, lf, an, misc, total; };
 __host__ __device__ inline TreeOff tree_offsets(int nb, int nlc) {
@@ -65,9 +65,8 @@ GRX_DEV R3 tree_joint_rot(const R3& Rp, const TreeBody& tb, float q) {
 
 // one sphere against the terrain (gen_sphere with the anchors and the link-force accumulators in the LDS workspace)
 template <bool HF>
-GRX_DEV V3 tree_sphere(KP P, const TreeSph& S, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu, float om_e, float hmax, float* wsw, int ei,
-                       const TreeOff& o, V3& xr) {
-    xr = rho + rot(R, v3(S.x, S.y, S.z));
+GRX_DEV V3 tree_sphere(KP P, const TreeSph& S, V3 w, V3 v, V3 O, float mu, float om_e, float hmax, float* wsw, int ei,
+                       const TreeOff& o, V3 xr, const TerrainAt& th) {   // xr: the centre relative to O; th: the terrain under it (looked up by the caller, in batches)
     V3 F = v3(0.f, 0.f, 0.f);
     const float wz = O.z + xr.z, r = S.r;
     const int slot = S.slot;
@@ -75,8 +74,8 @@ GRX_DEV V3 tree_sphere(KP P, const TreeSph& S, const R3& R, V3 rho, V3 w, V3 v, 
     float vimp = 0.f;
     if (wz - r <= hmax) {
         const float wx = O.x + xr.x, wy = O.y + xr.y;
-        float gx, gy;
-        const float dv = terrain_height<HF>(P, wx, wy, gx, gy) + r - wz;
+        const float gx = th.gx, gy = th.gy;
+        const float dv = th.h + r - wz;
         if (dv > 0.0f) {
             touching = true;
             const float nn = grx_rsq(1.0f + gx * gx + gy * gy);
@@ -155,7 +154,7 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
                 {   // _compute_torques (legged_robot.py:679-715) + the joint-limit spring/damper of this sub-step
                     const float act_ = use_last ? TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j) : TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j);
                     float t = td.kp * (act_ * P.action_scale + td.q0 - qj) - td.kd * qdj;
-                    t *= strength[(size_t)j * P.N];   // (this env's column of the SoA table)
+                    t *= TW(o.dof + TD_STR * GRX_MAX_DOFS + j);   // motor strength of this env (domain randomisation)
                     TW(o.dof + TD_TAU * GRX_MAX_DOFS + j) = fminf(fmaxf(t, -td.effort), td.effort);
                 }
                 const V3 ca = cross(w_c, a) * qdj;
@@ -166,10 +165,22 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
                 rigid_inertia(R, kap, tb.mass, Ic, Ak, h);
                 V3 pa, pl;
                 rigid_bias(R, kap, tb.mass, Ic, w, v, pa, pl);
-                for (int i = tb.sph_begin; i < tb.sph_end; ++i) {
-                    V3 xr;
-                    const V3 F = tree_sphere<HF>(P, T.sph[i], R, rho, w, v, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr);
-                    pa = pa - cross(xr, F); pl = pl - F;
+                for (int i0 = tb.sph_begin; i0 < tb.sph_end; i0 += 4) {   // up to four shapes at a time: their terrain lookups in flight together
+                    V3 xr[4]; TerrainAt th[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i0 + u < tb.sph_end) {
+                            const TreeSph& S = T.sph[i0 + u];
+                            xr[u] = rho + rot(R, v3(S.x, S.y, S.z));
+                            th[u].h = 0.f; th[u].gx = 0.f; th[u].gy = 0.f;
+                            if (E.B.pos.z + xr[u].z - S.r <= E.hmax) th[u].h = terrain_height<HF>(P, E.B.pos.x + xr[u].x, E.B.pos.y + xr[u].y, th[u].gx, th[u].gy);
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (i0 + u < tb.sph_end) {
+                            const V3 F = tree_sphere<HF>(P, T.sph[i0 + u], w, v, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr[u], th[u]);
+                            pa = pa - cross(xr[u], F); pl = pl - F;
+                        }
                 }
 #pragma unroll
                 for (int f = 0; f < 2; ++f)
@@ -272,37 +283,37 @@ GRX_DEV void tree_accel(KP P, const TreeTab& T, float* wsw, int ei, int c, const
 // self-collision (the contact law of grx_self.h, the link-pair tables of grx_generic.h): the env's lanes share the bounding
 // tests of the link pairs; the few pairs that do touch are then evaluated ONE AT A TIME, in table order, by the lane that
 // found them -- it alone adds into the bodies' bias forces and the link accumulators: no races, the same sums on every run
-GRX_DEV void tree_self_collision(KP P, const TreeTab& T, GT G, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0,
+GRX_DEV void tree_self_collision(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0,
                                  V3& pa0, V3& pl0) {
     const float mu_self = 2.0f * E.mu - P.terrain_friction;
     V3 dpa0 = v3(0.f, 0.f, 0.f), dpl0 = v3(0.f, 0.f, 0.f);
-    for (int lp0 = 0; lp0 < G.nlp; lp0 += TG) {
+    for (int lp0 = 0; lp0 < T.nlp; lp0 += TG) {
         const int lp = lp0 + c;
         bool hit = false;
         int ba = 0, bb = 0;
         ChainKin Ka, Kb;
-        if (lp < G.nlp) {
-            ba = G.lp_ba[lp]; bb = G.lp_bb[lp];
+        if (lp < T.nlp) {
+            ba = T.lp_ba[lp]; bb = T.lp_bb[lp];
             if (ba == 0) Ka = ChainKin{R0, v3(0.f, 0.f, 0.f), E.B.ang, E.B.vel};
             else Ka = ChainKin{tw_R(wsw, ei, ba * T_NB + T_R), tw_v3(wsw, ei, ba * T_NB + T_RHO), tw_v3(wsw, ei, ba * T_NB + T_W), tw_v3(wsw, ei, ba * T_NB + T_V)};
             Kb = ChainKin{tw_R(wsw, ei, bb * T_NB + T_R), tw_v3(wsw, ei, bb * T_NB + T_RHO), tw_v3(wsw, ei, bb * T_NB + T_W), tw_v3(wsw, ei, bb * T_NB + T_V)};
-            const V3 ca = Ka.rho + rot(Ka.R, v3(G.lp_ca[lp][0], G.lp_ca[lp][1], G.lp_ca[lp][2]));
-            const V3 cb = Kb.rho + rot(Kb.R, v3(G.lp_cb[lp][0], G.lp_cb[lp][1], G.lp_cb[lp][2]));
+            const V3 ca = Ka.rho + rot(Ka.R, v3(T.lp_ca[lp][0], T.lp_ca[lp][1], T.lp_ca[lp][2]));
+            const V3 cb = Kb.rho + rot(Kb.R, v3(T.lp_cb[lp][0], T.lp_cb[lp][1], T.lp_cb[lp][2]));
             const V3 d = ca - cb;
-            const float R = G.lp_ca[lp][3] + G.lp_cb[lp][3];
+            const float R = T.lp_ca[lp][3] + T.lp_cb[lp][3];
             hit = dot(d, d) < R * R;
         }
         if (!__any(hit)) continue;
         for (int k = 0; k < TG; ++k) {   // table order within the round: lane k's pair
             if (!__any(hit && c == k)) continue;
             if (hit && c == k) {
-                const int la = G.lp_a[lp], lb = G.lp_b[lp];
+                const int la = T.lp_a[lp], lb = T.lp_b[lp];
                 V3 Fa = v3(0.f, 0.f, 0.f), Ta = v3(0.f, 0.f, 0.f);
-                for (int i = G.lc_begin[la]; i < G.lc_begin[la + 1]; ++i) {
-                    SphC si; si.x = G.sx[i]; si.y = G.sy[i]; si.z = G.sz[i]; si.r = G.sr[i]; si.dmax = G.sdmax[i];
+                for (int i = T.lc_begin[la]; i < T.lc_begin[la + 1]; ++i) {
+                    SphC si; si.x = T.sph[i].x; si.y = T.sph[i].y; si.z = T.sph[i].z; si.r = T.sph[i].r; si.dmax = T.sph[i].dmax;
                     const SphW a = sph_world(si, Ka);
-                    for (int jj = G.lc_begin[lb]; jj < G.lc_begin[lb + 1]; ++jj) {
-                        SphC sj; sj.x = G.sx[jj]; sj.y = G.sy[jj]; sj.z = G.sz[jj]; sj.r = G.sr[jj]; sj.dmax = G.sdmax[jj];
+                    for (int jj = T.lc_begin[lb]; jj < T.lc_begin[lb + 1]; ++jj) {
+                        SphC sj; sj.x = T.sph[jj].x; sj.y = T.sph[jj].y; sj.z = T.sph[jj].z; sj.r = T.sph[jj].r; sj.dmax = T.sph[jj].dmax;
                         const SphW b_ = sph_world(sj, Kb);
                         V3 F, pw;
                         if (sphere_pair(P, a, b_, mu_self, F, pw)) { Fa = Fa + F; Ta = Ta + cross(pw, F); }
@@ -335,7 +346,6 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
                                                              const float* __restrict__ noise_in, float* __restrict__ obs_out, float* __restrict__ pri_out,
                                                              const StepSeq sq) {
     KP P = GRX_PARAMS(Pg);
-    GT G = *reinterpret_cast<const GRX_AS4 GenTables*>(reinterpret_cast<uintptr_t>(Tg));
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     __shared__ float s_stat[NSTAT];
     TreeTab& Tm = *reinterpret_cast<TreeTab*>(s_dyn);
@@ -391,6 +401,7 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
         const size_t oj = (size_t)j * N + e;
         TW(o.dof + TD_Q * GRX_MAX_DOFS + j) = P.q[oj]; TW(o.dof + TD_QD * GRX_MAX_DOFS + j) = P.qd[oj];
         TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j) = P.last_actions[oj];
+        TW(o.dof + TD_STR * GRX_MAX_DOFS + j) = P.motor_strength[oj];
         const float a = actions_in ? actions_in[(size_t)e * nd + j] : 0.f;
         TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j) = fminf(fmaxf(a, T.dof[j].amin), T.dof[j].amax);   // clip_actions (legged_robot_fftai.py:171-177)
     }
@@ -414,14 +425,17 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
             V3 fa = v3(0.f, 0.f, 0.f), fl = v3(0.f, 0.f, 0.f);
             if (lead)
                 for (int i = T.sph_begin0; i < T.sph_end0; ++i) {
-                    V3 xr;
-                    const V3 F = tree_sphere<HF>(P, T.sph[i], R0, v3(0.f, 0.f, 0.f), E.B.ang, E.B.vel, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr);
+                    const TreeSph& S = T.sph[i];
+                    const V3 xr = rot(R0, v3(S.x, S.y, S.z));
+                    TerrainAt th; th.h = 0.f; th.gx = 0.f; th.gy = 0.f;
+                    if (E.B.pos.z + xr.z - S.r <= E.hmax) th.h = terrain_height<HF>(P, E.B.pos.x + xr.x, E.B.pos.y + xr.y, th.gx, th.gy);
+                    const V3 F = tree_sphere<HF>(P, S, E.B.ang, E.B.vel, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr, th);
                     fa = fa + cross(xr, F); fl = fl + F;
                 }
             pa0 = pa0 - grp_bcast(fa, lane, 0); pl0 = pl0 - grp_bcast(fl, lane, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (P.self_collisions) tree_self_collision(P, T, G, wsw, ei, c, o, E, R0, pa0, pl0);
+        if (P.self_collisions) tree_self_collision(P, T, wsw, ei, c, o, E, R0, pa0, pl0);
         tree_inward(P, T, wsw, ei, c, o);
         // ---- base: the chains that hang from it, in table order; [A B; B^T D][alpha; acc] = -[pa; pl]
         S3 Db = {E.base_m, 0.f, 0.f, E.base_m, 0.f, E.base_m};
