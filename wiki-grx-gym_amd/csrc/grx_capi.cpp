@@ -20,7 +20,7 @@
 extern "C" {
 void grx_launch_step(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                      const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream);
-void grx_launch_step_quad(const KParams* dP, int N, int heightfield, const float* actions, float delay, long long common_step,
+void grx_launch_step_quad(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                           const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream);
 int grx_envs_per_block_quad(void);
 void grx_launch_finalize(const KParams* dP, long long seq, long long* progress, long long ticket, hipStream_t stream);
@@ -634,7 +634,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
         const int qblocks = (c.num_envs + grx_envs_per_block_quad() - 1) / grx_envs_per_block_quad();
         s->quad = !generic && s->waves == 4 && qblocks <= prop.multiProcessorCount && !getenv("GRX_WAVES_PER_BLOCK");
         if (const char* q = getenv("GRX_LANES_PER_ENV")) s->quad = !generic && atoi(q) == 4;   // tests / A-B runs: 2 or 4
-        if (s->quad) s->waves = 4;
+        if (s->quad) { s->waves = 4; if (const char* w = getenv("GRX_QUAD_WAVES")) s->waves = atoi(w) == 8 ? 8 : 4; }
     }
     const char* dbg = getenv("GRX_PUBLISH_DEBUG");   // (tools/: overrides the config either way)
     P.publish_debug = dbg ? atoi(dbg) : c.publish_reward_terms;
@@ -1087,7 +1087,7 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
     }
     else
     {
-        if (s->quad) grx_launch_step_quad(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
+        if (s->quad) grx_launch_step_quad(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
                                           (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st);
         else grx_launch_step(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
                              (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st);

@@ -9,7 +9,7 @@
 #define GRX_NUM_OBS 39   // 9 + 3*GRX_ND (gr1t1.py:281-295)
 #define GRX_MAX_PRI 168  // 39 + 3 + 1 + 2 + 2 + 121 (gr1t1.py:297-313)
 #define GRX_MAXSPH_SIDE 16
-#define GRX_PROF_SLOTS 80   // GRX_PROFILE_SECTIONS builds: clock stamps per block (tools/gpu_sections.py)
+#define GRX_PROF_SLOTS 96   // GRX_PROFILE_SECTIONS builds: clock stamps per block (tools/gpu_sections.py)
 #define GRX_COARSE 8     // raster cells per coarse max-map cell (0.8 m)
 // rows of the episode-statistics tables: the reward terms, [NT] the number of episodes that ended, [NT + 1] the sum of the terrain levels
 #define GRX_NSTAT (GRX_NUM_REWARD_TERMS + 2)

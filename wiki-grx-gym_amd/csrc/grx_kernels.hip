@@ -1140,51 +1140,55 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
 enum DbgRow { DBG_FEET_FORCE = 0, DBG_FEET_POS = 6, DBG_AVG_FORCE = 12, DBG_AVG_SPEED = 14, DBG_TORQUES = 20, DBG_LAST_LAST_ACTIONS = 30,
               DBG_TERM_CONTACT = 40, DBG_APPLY_RESET = 41, DBG_ROWS = 42 };
 template <bool HF, int W, bool DBG = false>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE, GRX_WPE))) void grx_step_kernel(const KParams* __restrict__ Pg, const float* __restrict__ actions_in,
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 2 : GRX_WPE, W > 4 ? 2 : GRX_WPE))) void grx_step_kernel(const KParams* __restrict__ Pg, const float* __restrict__ actions_in,
                                                       float delay, long long common_step, const float* __restrict__ noise_in,
                                                       const float* __restrict__ dbg, float* __restrict__ obs_out, float* __restrict__ pri_out,
                                                       const StepSeq sq) {
     static_assert(!DBG || W == 1, "the debug injection path exists for the one-wave layout only");
     KP P = GRX_PARAMS(Pg);
     constexpr int NTHR = 64 * W;
+    constexpr bool PIPE = W >= 4;   // the producer/consumer pipeline of grx_wavepipe.h: four roles, or (W == 8, lane quads only) eight
+    static_assert(W != 8 || LPL == 2, "the eight-wave pipeline exists for the lane-quad layout only");
     __shared__ KTables s_tab;
     // One LDS arena, used twice: during the sub-steps it holds the lane-compaction buffers of the rare contacts
     // (grx_rare.h: candidate list, result table, frames); after the decimation loop's barrier the same bytes are the
-    // AoS staging rows of obs / pri_obs and (W == 4) the reward inputs wave 0 hands to the reward waves.
-    constexpr int OBS_BYTES = EPB * GRX_NUM_OBS * 4, PRI_BYTES = EPB * PRS * 4, RW_BYTES = W == 4 ? REWIN_FLOATS * 64 * 4 : 0;
-    constexpr int POST_BYTES = OBS_BYTES + PRI_BYTES + RW_BYTES, PHYS_BYTES = (W == 2 ? 2 : 1) * RC_BYTES;
+    // AoS staging rows of obs / pri_obs and (PIPE) the reward inputs wave 0 hands to the reward waves.
+    constexpr int OBS_BYTES = EPB * GRX_NUM_OBS * 4, PRI_BYTES = EPB * PRS * 4, RW_BYTES = PIPE ? REWIN_FLOATS * 64 * 4 : 0;
+    constexpr int POST_BYTES = OBS_BYTES + PRI_BYTES + RW_BYTES, PHYS_BYTES = (W == 2 || W == 8 ? 2 : 1) * RC_BYTES;
     static_assert(OBS_BYTES % 16 == 0 && PRI_BYTES % 16 == 0 && RC_BYTES % 16 == 0, "arena pieces must stay 16-byte aligned");
     constexpr int FOOTFR_BYTES = RC_FR4 * 64 * 16, ANCH_BYTES = 13 * 64 * 4;
-    constexpr int TAIL_BYTES = W == 4 ? PHYS_BYTES + FOOTFR_BYTES + ANCH_BYTES : PHYS_BYTES;
+    constexpr int TAIL_BYTES = PIPE ? PHYS_BYTES + FOOTFR_BYTES + ANCH_BYTES : PHYS_BYTES;
     __shared__ __attribute__((aligned(16))) char s_arena[POST_BYTES > TAIL_BYTES ? POST_BYTES : TAIL_BYTES];
     float* const s_obs = reinterpret_cast<float*>(s_arena);
     float* const s_pri = reinterpret_cast<float*>(s_arena + OBS_BYTES);
-    float* const s_rw = reinterpret_cast<float*>(s_arena + OBS_BYTES + PRI_BYTES);   // reward inputs (wave 0 -> waves 1, 3), W == 4
-    // final friction anchors of the step (W == 4: wave 2 -> wave 0 across the barrier that ends the sub-steps): behind the
+    float* const s_rw = reinterpret_cast<float*>(s_arena + OBS_BYTES + PRI_BYTES);   // reward inputs (wave 0 -> waves 1, 3), PIPE
+    // final friction anchors of the step (PIPE: wave 2 -> wave 0 across the barrier that ends the sub-steps): behind the
     // compaction buffers (32 envs per block: inside what becomes s_rw only after wave 0 has picked them up)
-    // W == 4, same tail: the foot frames wave 2 publishes for the self-collision on wave 1 (sub-steps only), then s_anch
-    static_assert(W != 4 || PHYS_BYTES >= OBS_BYTES + PRI_BYTES, "foot frames + s_anch must sit behind the staging rows, in the arena's tail");
+    // PIPE, same tail: the foot frames wave 2 publishes for the self-collision on wave 1 (sub-steps only), then s_anch
+    static_assert(!PIPE || PHYS_BYTES >= OBS_BYTES + PRI_BYTES, "foot frames + s_anch must sit behind the staging rows, in the arena's tail");
     float4* const s_footfr = reinterpret_cast<float4*>(s_arena + PHYS_BYTES);
     float* const s_anch = reinterpret_cast<float*>(s_arena + PHYS_BYTES + FOOTFR_BYTES);
     __shared__ float s_stat[NSTAT];
     __shared__ float s_base[W >= 2 ? 13 * EPB : 1];   // base state at the start of the current sub-step (dynamics -> helpers)
-    __shared__ __attribute__((aligned(16))) float s_wr[W == 2 ? 32 * 64 : (W == 4 ? 8 * 64 : 1)];       // base-lump wrench + termination / collision flags (helper -> dynamics)
-    // W == 4 pipeline buffers (grx_wavepipe.h)
-    __shared__ float4 s_q[W == 4 ? Q4 * 64 : 1];
-    __shared__ float4 s_wc[W == 4 ? WC4 * 64 : 1];
-    __shared__ float4 s_pb[W == 4 ? (LEG * PB4 + 2) * 64 : 1];
-    __shared__ uint32_t s_nz[W == 4 ? NZB * 4 * 64 : 1];   // observation-noise Philox blocks (wave 1 -> wave 0)
-    __shared__ float4 s_rr[W == 4 ? 5 * 64 : 1];           // reset_idx's uniform draws (wave 2 -> wave 0)
-    __shared__ __attribute__((aligned(16))) char s_self[W == 4 ? SELF_BYTES : 16];   // self-collision staging of wave 2 (grx_self.h)
-    __shared__ float s_rwp[W == 4 ? 64 : 1];               // partial reward (wave 3 -> wave 1)
-    __shared__ float s_hp[W == 4 ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
-    __shared__ float s_hsum[W == 4 ? 4 * 64 : 1];          // height scan: partial sums per wave
-    __shared__ float s_tp[W == 4 ? 2 * 64 : 1];            // termination flag / collision count from the NET link forces of the last sub-step (wave 3 -> wave 0)
+    __shared__ __attribute__((aligned(16))) float s_wr[W == 2 ? 32 * 64 : (PIPE ? 8 * 64 : 1)];       // base-lump wrench + termination / collision flags (helper -> dynamics)
+    // PIPE pipeline buffers (grx_wavepipe.h)
+    __shared__ float4 s_q[PIPE ? Q4 * 64 : 1];
+    __shared__ float4 s_wc[PIPE ? WC4 * 64 : 1];
+    __shared__ float4 s_pb[PIPE ? (LEG * PB4 + 2) * 64 : 1];
+    __shared__ uint32_t s_nz[PIPE ? NZB * 4 * 64 : 1];   // observation-noise Philox blocks (wave 1 -> wave 0)
+    __shared__ float4 s_rr[PIPE ? 5 * 64 : 1];           // reset_idx's uniform draws (wave 2 -> wave 0)
+    __shared__ __attribute__((aligned(16))) char s_self[PIPE ? SELF_BYTES : 16];   // self-collision staging of wave 2 (grx_self.h)
+    __shared__ float s_rwp[PIPE ? 64 : 1];               // partial reward (wave 3 -> wave 1)
+    __shared__ float s_hp[PIPE ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
+    __shared__ float s_hsum[PIPE ? 4 * 64 : 1];          // height scan: partial sums per wave
+    __shared__ float s_tp[PIPE ? 2 * 64 : 1];            // termination flag / collision count from the NET link forces of the last sub-step (wave 3 -> wave 0)
+    __shared__ float4 s_xk[W == 8 ? 9 * 64 : 1];           // W == 8: rigid inertias of chain bodies 2, 1, 0 (wave 6 -> wave 0)
+    __shared__ float4 s_fx[W == 8 ? 8 * 64 : 1];           // W == 8: base-level 6 x 6 (wave 0 -> wave 5) and its factorisation (wave 5 -> wave 0)
     __shared__ int s_flag[FL_COUNT];
-    const PipeLds L = {s_base, s_q, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag};
+    const PipeLds L = {s_base, s_q, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag, s_xk, s_fx};
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const RareBuf RB = rare_carve(s_arena + (W == 2 && wv == 1 ? RC_BYTES : 0));   // W == 4: only wave 3 evaluates rare contacts
+    const RareBuf RB = rare_carve(s_arena + (W == 2 && wv == 1 ? RC_BYTES : 0));   // PIPE: only wave 3 evaluates rare contacts
     {   // stage the per-side robot tables (joint tree, inertias, gains, spheres) into LDS
         const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab);
@@ -1218,15 +1222,21 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             int cj = min(max((int)((y0 + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
             hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
         }
-        LaneState hs;   // W == 4, wave 2: the friction anchors of this lane's foot
+        LaneState hs;   // PIPE, wave 2: the friction anchors of this lane's foot
         hs.anchor_on = 0;
-        if (W == 4) {
+        LinkPrep w3_lp;   // PIPE, wave 3: GRX_T_CONTACT_FORCES rows of the last sub-step, stored once the block is past its barrier
+        V3 w3_rows[11];
+        if (PIPE) {
 #if defined(GRX_REG_CONSTS) && GRX_REG_CONSTS >= 2
             const SideConst Ch = C;   // helper waves too: constants in registers
 #define GRX_HELPER_C Ch
 #else
 #define GRX_HELPER_C C
 #endif
+#ifndef GRX_W8_REGC
+#define GRX_W8_REGC 0x76   // eight waves (256 registers each): the waves whose constants live in registers (bit per wave; measured: waves 3, 7 only spill)
+#endif
+#define GRX_HC(w) ((W == 8 && !((GRX_W8_REGC >> (w)) & 1)) ? C : GRX_HELPER_C)
             const float bm = P.base_m[e];
             const V3 bc = v3(P.base_c[e], P.base_c[(size_t)N + e], P.base_c[2 * (size_t)N + e]);
             const S3 bI = {P.base_I[e], P.base_I[(size_t)N + e], P.base_I[2 * (size_t)N + e],
@@ -1236,7 +1246,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 // wave 0's path from the first sub-step on: before the loop they delayed it, measured)
                 const bool want_noise = P.add_noise && !noise_in;
                 const int noise_seq = P.decimation >= 2 ? P.decimation - 2 : 0;
-                self_loop<HF>(P, s_tab, GRX_HELPER_C, RB, s_footfr, self_carve(s_self), P.friction[e], L, lane, el, side,
+                self_loop<HF, HF && W != 8, W == 8>(P, s_tab, GRX_HC(1), RB, s_footfr, self_carve(s_self), P.friction[e], L, lane, el, side,
                               [&](const int seq) {
                                   if (want_noise && seq == noise_seq) {
                                       U4 nzb[NZB];
@@ -1257,7 +1267,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                     hs.vimp[i] = P.anchors[(size_t)((side * 4 + gi) * 3 + 2) * N + e];   // 0: no contact; else the contact's approach speed
                     if (hs.vimp[i] != 0.0f) hs.anchor_on |= (1u << i);
                 }
-                chain_contact_loop<HF>(P, GRX_HELPER_C, C, RB, s_footfr, mu, hmax, 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]), hs, L, lane, el, side);
+                chain_contact_loop<HF, W == 8 ? 0 : (HF ? 2 : 5)>(P, GRX_HC(2), C, RB, s_footfr, mu, hmax, 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]), hs, L, lane, el, side);
                 float* a_ = s_anch + (lane - half);
 #pragma unroll
                 for (int i = 0; i < NA; ++i) { const int gi = NA * half + i; a_[gi * 64] = hs.ax[i]; a_[(4 + gi) * 64] = hs.ay[i]; a_[(9 + gi) * 64] = hs.vimp[i]; }
@@ -1265,17 +1275,32 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                     const uint32_t mine = hs.anchor_on << (NA * half);
                     a_[8 * 64] = __uint_as_float(LPL == 1 ? mine : (mine | __float_as_uint(half_swap(__uint_as_float(mine)))));
                 }
-            } else {
-                base_contact_loop<HF>(P, s_tab, GRX_HELPER_C, RB, mu, hmax, bm, bc, bI, L, lane, el, side,
-                                      LinkForceOut{true, act0 ? P.contact_forces + e : nullptr, (size_t)N}, s_tp);
+            } else if (wv == 3) {
+                base_contact_loop<HF, W == 8>(P, s_tab, GRX_HC(3), RB, mu, hmax, bm, bc, bI, L, lane, el, side, s_tp, w3_lp, w3_rows);
+            } else if (wv == 7) {
+                RareBuf RB7 = rare_carve(s_arena + RC_BYTES);
+                RB7.fchain = RB.fchain;   // (where wave 2 publishes the thigh / shank frames)
+                chain_rare_loop<HF>(P, s_tab, GRX_HC(7), RB7, mu, hmax, L, lane, el, side);
+            } else if (wv == 4) {
+                chain_bias_loop<3, 4>(P, GRX_HC(4), L, lane, el);
+            } else if (wv == 6) {
+                chain_bias_loop<0, 2>(P, GRX_HC(6), L, lane, el);
+            } else if (wv == 5) {
+                base_service_loop(P, GRX_HC(5), C, bm, bc, bI, L, lane, el);
             }
             float es_w1[NT], es_w3[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
             if (wv == 1) load_episode_sums<1>(P, e, N, es_w1);
-            if (wv == 3) load_episode_sums<2>(P, e, N, es_w3);
+#ifdef GRX_PROFILE_SECTIONS
+            if (lane == 0) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 80 + wv] = clock64();
+#endif
             lds_barrier();   // final friction anchors + height-scan pose published (the last sub-step's row stores stay in flight)
+            if (wv == 3) {   // (this wave is the last to arrive: its HBM traffic goes out behind the barrier)
+                load_episode_sums<2>(P, e, N, es_w3);
+                store_link_rows(LinkForceOut{true, act0 ? P.contact_forces + e : nullptr, (size_t)N}, w3_lp, w3_rows);
+            }
             if (HF && P.measure_heights) {   // this wave's quarter of the height scan (legged_robot.py:1235-1274)
                 const float* hp = s_hp + el;
-                s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
+                if (wv < 4) s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
                                                               LPE * wv + (lane & (LPE - 1)), nh, s_pri + el * PRS);
                 lds_barrier();   // height scan complete (raw heights and partial sums are in LDS: this wave's row stores of the last sub-step stay in flight)
             }
@@ -1305,7 +1330,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 reward_and_sums<1>(P, C, rin, lane, side, e, N, act, s_stat, es_w1, s_rwp, s_flag + FL_RWB);
                 GRX_TICKW(15);
             }
-            {   // the observation height block, once wave 0 has published the (post-reset) base height: wave 2 takes
+            if (wv < 4) {   // the observation height block, once wave 0 has published the (post-reset) base height: wave 2 takes
                 // the points k = 0, 1 (mod 4), waves 1 and 3 (busy with the rewards until now) k = 2, 3 and 6, 7 (mod 8)
                 flag_wait(s_flag + FL_HZ, 1);
                 if (wv == 2) GRX_TICKW(30);
@@ -1318,7 +1343,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
                 flag_set(s_flag + FL_BHO1 + (wv - 1), 1, lane);
                 if (wv == 2) GRX_TICKW(31);
             }
-            if (P.publish_rbs) {   // every URDF link frame of the state wave 0 published after the last sub-step: a third on each helper wave
+            if (P.publish_rbs && wv < 4) {   // every URDF link frame of the state wave 0 published after the last sub-step: a third on each helper wave
                 const float* b = s_base + el;
                 const float4 q0_ = s_q[lane], q1_ = s_q[64 + lane], q2_ = s_q[128 + lane];
                 const float fq[LEG] = {q0_.x, q0_.y, q0_.z, q0_.w, q1_.x}, fqd[LEG] = {q1_.y, q1_.z, q1_.w, q2_.x, q2_.y};
@@ -1411,9 +1436,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     float torque[LEG];
     SubstepOut so;
     FootKin fk;
-    SelfNear self_near; self_near.m = 0;   // self-collision broad phase of this policy step (W < 4; with four waves it lives on wave 2)
+    SelfNear self_near; self_near.m = 0;   // self-collision broad phase of this policy step (!PIPE; with four waves it lives on wave 2)
 #ifdef GRX_REG_CONSTS
-    // W == 4: wave 0 has a SIMD's whole register file to itself; its chain's constants live in registers during the
+    // PIPE: wave 0 has a SIMD's whole register file to itself; its chain's constants live in registers during the
     // sub-steps (every LDS read of a constant is ~64 exposed cycles on a wave that runs alone)
     const SideConst Cr = C;
 #else
@@ -1432,12 +1457,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             b[7 * EPB] = st.vel.x; b[8 * EPB] = st.vel.y; b[9 * EPB] = st.vel.z;
             b[10 * EPB] = st.ang.x; b[11 * EPB] = st.ang.y; b[12 * EPB] = st.ang.z;
         }
-        if (W == 4) {
+        if (PIPE) {
             s_q[lane] = f4(st.q[0], st.q[1], st.q[2], st.q[3]);
             s_q[64 + lane] = f4(st.q[4], st.qd[0], st.qd[1], st.qd[2]);
             s_q[128 + lane] = f4(st.qd[3], st.qd[4], 0.f, 0.f);
         }
-        if (W == 4) flag_set(s_flag + FL_STATE, deci + 1, lane);
+        if (PIPE) flag_set(s_flag + FL_STATE, deci + 1, lane);
         else if (W == 2) __syncthreads();   // #1
         const bool use_last = (float)deci < delay;
 #pragma unroll
@@ -1447,8 +1472,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             t *= LC.strength[k];
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
-        if (W == 4 && LPL == 2) substep_q<HF>(P, Cr, LC, st, torque, so, fk, L, lane, deci, tacc, C);
-        else if (W == 4) substep_p<HF>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc, C);
+        if (PIPE && LPL == 2) substep_q<HF, W == 8>(P, Cr, LC, st, torque, so, fk, L, lane, deci, tacc, C);
+        else if (PIPE) substep_p<HF>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc, C);
         else substep<HF, W>(P, s_tab, C, LC, st, torque, so, fk, s_wr + lane, tacc,
                             LinkForceOut{deci == P.decimation - 1, act0 ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side, self_near, deci == 0);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
@@ -1458,11 +1483,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     }
     const float yaw_n = fmaxf(sqrtf(st.qz * st.qz + st.qw * st.qw), 1e-9f);   // normalize(): torch_utils.py:43-45
     const float yaw_z = st.qz / yaw_n, yaw_w = st.qw / yaw_n;
-    if (W < 4 && !DBG && P.publish_rbs) {
+    if (!PIPE && !DBG && P.publish_rbs) {
         const float rq[4] = {st.qx, st.qy, st.qz, st.qw};
         publish_rigid_body_states(P, C, side, st.pos, rq, st.vel, st.ang, st.q, st.qd, e, N, act0);
     }
-    if (W == 4) {   // the foot wave owned the friction anchors during the sub-steps
+    if (PIPE) {   // the foot wave owned the friction anchors during the sub-steps
         if (side == 0) { float* hp = s_hp + el; hp[0 * EPB] = st.pos.x; hp[1 * EPB] = st.pos.y; hp[2 * EPB] = yaw_z; hp[3 * EPB] = yaw_w; }
         if (P.publish_rbs) {   // the final state for the wave that publishes GRX_T_RIGID_BODY_STATES (wave 2, at the end of its work)
             if (side == 0) {
@@ -1476,7 +1501,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
             s_q[64 + lane] = f4(st.q[4], st.qd[0], st.qd[1], st.qd[2]);
             s_q[128 + lane] = f4(st.qd[3], st.qd[4], 0.f, 0.f);
         }
+#ifdef GRX_PROFILE_SECTIONS
+        const long long tb0_ = clock64();
+        if (lane == 0) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 80] = tb0_;
+#endif
         lds_barrier();   // final friction anchors + height-scan pose published (the last sub-step's row stores stay in flight)
+#ifdef GRX_PROFILE_SECTIONS
+        tacc[1] += clock64() - tb0_;
+#endif
         const float* a_ = s_anch + (lane - half);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { st.ax[i] = a_[i * 64]; st.ay[i] = a_[(4 + i) * 64]; st.vimp[i] = a_[(9 + i) * 64]; }
@@ -1512,7 +1544,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     GRX_TICK(3);
     // ---- post_physics_step (legged_robot.py:269-305)
     float es_early[NT];   // running episode sums: loads issued here so their HBM latency overlaps the state update
-    if (W < 4) {
+    if (!PIPE) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) es_early[t] = (P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
     }
@@ -1527,7 +1559,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     float* prow = s_pri + el * PRS;
     float hsum = 0.f;
     if (HF && P.measure_heights) {
-        if (W == 4) {   // quarter of the scan here, the other three quarters on the helper waves
+        if (PIPE) {   // quarter of the scan here, the other three quarters on the helper waves
             hsum = height_scan_share<4>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
             lds_barrier();   // height scan complete
             hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane];
@@ -1568,7 +1600,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
         rin.blv = blv; rin.bav = bav; rin.pg = pg;
         rin.bho_stale = bho_stale; rin.qx = st.qx; rin.qy = st.qy; rin.qz = st.qz; rin.qw = st.qw; rin.pen_count = pen_count;
         rin.reset = reset ? 1.f : 0.f; rin.time_out = time_out ? 1.f : 0.f;
-        if (W == 4) {
+        if (PIPE) {
             int i = 0;
             rewin_fields(rin, [&](float& x) { s_rw[(i++) * 64 + lane] = x; });
             flag_set(s_flag + FL_REW, 1, lane);
@@ -1578,9 +1610,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     GRX_TICK(6);
     // ---- reset_idx (masked, in-kernel)
     const bool do_reset = DBG ? (reset && dbg_apply_reset) : reset;   // the debug entry may report a reset without applying it
-    if (W == 4 ? __any(do_reset) : do_reset) {   // uniform test with four waves: the draws come from wave 2 through LDS
+    if (PIPE ? __any(do_reset) : do_reset) {   // uniform test with four waves: the draws come from wave 2 through LDS
         ResetRand rr;
-        if (W == 4) {
+        if (PIPE) {
             flag_wait(s_flag + FL_RR, 1);
             const float4* z = s_rr + lane;
             const float4 z0 = z[0 * 64], z1 = z[1 * 64], z2 = z[2 * 64], z3 = z[3 * 64], z4 = z[4 * 64];
@@ -1607,7 +1639,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     GRX_TICK(7);
     // ---- compute_observations (legged_robot.py:442-452, legged_robot_fftai.py:148-167, gr1t1.py:281-336)
     float bho = 0.f;
-    if (W == 4) {   // waves 2 and 3 do the height block (obs_heights_share) while this wave writes the other terms
+    if (PIPE) {   // waves 2 and 3 do the height block (obs_heights_share) while this wave writes the other terms
         if (side == 0) s_hp[el] = st.pos.z;
         flag_set(s_flag + FL_HZ, 1, lane);
     } else {
@@ -1620,7 +1652,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
     // observation noise (noise_blocks): with 4 waves per block wave 1 computed the blocks while wave 0 loaded state
     U4 nzb[NZB];
     if (P.add_noise && !noise_in) {
-        if (W == 4) {
+        if (PIPE) {
             const uint32_t* z = s_nz + lane;
 #pragma unroll
             for (int b = 0; b < NZB; ++b) { nzb[b].x = z[(b * 4 + 0) * 64]; nzb[b].y = z[(b * 4 + 1) * 64]; nzb[b].z = z[(b * 4 + 2) * 64]; nzb[b].w = z[(b * 4 + 3) * 64]; }
@@ -1668,7 +1700,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
         prow[GRX_NUM_OBS + 4 + side] = feet_contact_obs ? 1.f : 0.f;
         prow[GRX_NUM_OBS + 6 + side] = fminf(fmaxf(feet_height * P.obs_scale_height, -clipo), clipo);
     }
-    if (W < 4 && side == 0) prow[GRX_NUM_OBS + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
+    if (!PIPE && side == 0) prow[GRX_NUM_OBS + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
 
     GRX_TICK(8);
     // ---- store state (SoA) -- history: last_actions = actions, last_dof_vel = dof_vel (legged_robot.py:299-300)
@@ -1711,13 +1743,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
         P.proj_grav[e] = pg.x; P.proj_grav[(size_t)N + e] = pg.y; P.proj_grav[2 * (size_t)N + e] = pg.z;
         P.origins[e] = ea.origin[0]; P.origins[(size_t)N + e] = ea.origin[1]; P.origins[2 * (size_t)N + e] = ea.origin[2];
         P.levels[e] = ea.level;
-        if (W < 4) P.base_heights_offset[e] = bho;
+        if (!PIPE) P.base_heights_offset[e] = bho;
         P.ep_len[e] = ep_len;
         P.reset[e] = reset ? 1 : 0;
         P.time_out[e] = time_out ? 1 : 0;
         P.term_contact[e] = term_contact ? 1 : 0;
     }
-    if (W == 4) {   // base_heights_offset: the helper waves' partial sums of the observation height block
+    if (PIPE) {   // base_heights_offset: the helper waves' partial sums of the observation height block
         flag_wait(s_flag + FL_BHO1, 1);
         flag_wait(s_flag + FL_BHO1 + 1, 1);
         flag_wait(s_flag + FL_BHO1 + 2, 1);
@@ -1765,11 +1797,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(GRX_WPE,
 #ifdef GRX_QUAD_TU
 // grx_quad.hip: this translation unit built with GRX_LPE = 4 -- the four-wave step kernel with a lane QUAD per env, 16 envs per
 // block: at <= 16 envs per CU (4096 envs on an MI355X) every CU gets a block instead of every other one
-extern "C" void grx_launch_step_quad(const KParams* dP, int N, int heightfield, const float* actions, float delay, long long common_step,
+// waves: 4 (the roles of grx_wavepipe.h's header) or 8 (two waves per SIMD: four more roles take work off wave 0's chain)
+extern "C" void grx_launch_step_quad(const KParams* dP, int N, int heightfield, int waves, const float* actions, float delay, long long common_step,
                                      const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {
     const int nblocks = (N + EPB - 1) / EPB;
-    if (heightfield) hipLaunchKernelGGL((grx_step_kernel<true, 4>), dim3(nblocks), dim3(256), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out, *sq);
-    else hipLaunchKernelGGL((grx_step_kernel<false, 4>), dim3(nblocks), dim3(256), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out, *sq);
+#define GRX_LAUNCH_QUAD(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out, *sq)
+    if (heightfield) { if (waves == 8) GRX_LAUNCH_QUAD(true, 8); else GRX_LAUNCH_QUAD(true, 4); }
+    else { if (waves == 8) GRX_LAUNCH_QUAD(false, 8); else GRX_LAUNCH_QUAD(false, 4); }
+#undef GRX_LAUNCH_QUAD
 }
 extern "C" int grx_envs_per_block_quad(void) { return EPB; }
 #else

@@ -77,7 +77,9 @@ struct RareNoWait { GRX_DEV void operator()() const {} };
 // when S1 > 8).  FRAMES_IN_LDS: another wave publishes the thigh / shank frames in B.fchain (grx_wavepipe.h: wave 2's
 // walk); wait_frames() is called once the base-lump shapes have been tested, right before the frames are read.
 // Must be called by all 64 lanes in wave-uniform control flow.
-template <bool HF, int S0, int S1, bool FRAMES_IN_LDS = false, class WaitFrames = RareNoWait>
+// OWN_POS (with FRAMES_IN_LDS): the caller walked the chain itself for R, rho of K2in / K3in (the reach tests need no velocities), so
+// the tests start before the other wave's frames are out; wait_frames() is then called right before the evaluation reads them.
+template <bool HF, int S0, int S1, bool FRAMES_IN_LDS = false, bool OWN_POS = false, class WaitFrames = RareNoWait>
 GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const RareBuf& B, int lane, int el, int side, const R3& R0, V3 O, V3 ang, V3 vel,
                            const ChainKin& K2in, const ChainKin& K3in, float mu, float hmax, RareOut& out,
                            long long* rare_acc = nullptr, WaitFrames wait_frames = WaitFrames(), const bool want_links = true) {
@@ -142,7 +144,7 @@ GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const Rar
     if (S0 < 8) test_range(S0, S1 < 8 ? S1 : 8);
     GRX_RARE_T(0);
     if (S1 > 8) {
-        if (FRAMES_IN_LDS) {
+        if (FRAMES_IN_LDS && !OWN_POS) {
             wait_frames();
             const RareFrame f2 = rare_load_frame(B.fchain + lane, 64), f3 = rare_load_frame(B.fchain + RC_FR4 * 64 + lane, 64);
             R2 = f2.R; rho2 = f2.rho; R3_ = f3.R; rho3 = f3.rho;
@@ -169,6 +171,7 @@ GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const Rar
             rare_store_frame(B.fchain + lane, 64, K2in.R, K2in.rho, K2in.w, K2in.v);
             rare_store_frame(B.fchain + RC_FR4 * 64 + lane, 64, K3in.R, K3in.rho, K3in.w, K3in.v);
         }
+        if (S1 > 8 && FRAMES_IN_LDS && OWN_POS) wait_frames();
         const int cnt = __popc(m);
         int pos = 0, total = 0;
 #pragma unroll

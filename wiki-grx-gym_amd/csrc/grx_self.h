@@ -130,8 +130,12 @@ GRX_DEV SelfNear self_broad_phase(KP P, const SideConst& C, int side, const R3& 
 
 // K[0..2]: frames of this lane's chain bodies 2, 3, 4; sn:
 // this policy step's broad phase.  Must be called by all 64 lanes in wave-uniform control flow.
+struct SelfNoVel { GRX_DEV void operator()() const {} };
+// velocities(): called once the sphere centres are staged and before any body velocity K[i].w / K[i].v is read (a caller that walked
+// the chain for positions only fills them in there)
+template <class Vel = SelfNoVel>
 GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const SelfBuf& SB, int lane, int side, const R3& R0, V3 ang, V3 vel,
-                            const ChainKin K[3], float mu, const SelfNear& sn, SelfOut& o, long long* pacc = nullptr) {
+                            const ChainKin K[3], float mu, const SelfNear& sn, SelfOut& o, long long* pacc = nullptr, Vel velocities = Vel()) {
     const V3 zero = v3(0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < 3; ++i) { o.fa[i] = zero; o.fl[i] = zero; }
@@ -142,14 +146,39 @@ GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const Se
     const long long t0_ = clock64();
 #endif
     constexpr int cnt[3] = {2, 2, 4}, off[3] = {8, 10, 12};
+    bool have_vel = false;   // (wave-uniform)
+    auto need_vel = [&]() { if (!have_vel) { velocities(); have_vel = true; } };
     // ---- leg x leg
     if (__any((sn.m & 1u) != 0u)) {
         // one pass over this lane's 8 spheres: centre -> LDS row, and the leg's extent towards the other leg along the
         // base's lateral axis (the separating-plane test below)
         const int el = lane_env(lane);
-        float4* const row = SB.st + lane * SELF_ROW;   // (LPE == 4: both halves of a leg stage the same row values, each into its own row)
+        const int hf_ = lane_half(lane);
+        float4* const row = SB.st + (lane - hf_) * SELF_ROW;   // the leg's row (LPE == 4: at its first lane)
         const V3 yb = R0.cy;
         float ext = side == 0 ? 1e30f : -1e30f;
+        if (LPL == 2) {   // each half of the leg stages the spheres of its own parity: thigh, shank, and two of the foot's four
+            const SideConst& Ct = T.side[side];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = j < 2 ? j : 2;
+                const int si = 2 * j + hf_;   // 0..7
+                const SphC& S = Ct.sph[8 + si];
+                const V3 c = sph_centre(S, K[i]);
+                row[si] = rc4(c.x, c.y, c.z, S.r);
+                const float y = dot(c, yb);
+                ext = side == 0 ? fminf(ext, y - S.r) : fmaxf(ext, y + S.r);
+            }
+            const float oe = half_swap(ext);
+            ext = side == 0 ? fminf(ext, oe) : fmaxf(ext, oe);
+            need_vel();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {   // (both halves write the same body rows)
+                row[8 + 2 * i] = rc4(K[i].w.x, K[i].w.y, K[i].w.z, K[i].v.x);
+                row[9 + 2 * i] = rc4(K[i].v.y, K[i].v.z, 0.f, 0.f);
+            }
+        } else {
+        need_vel();
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -162,6 +191,7 @@ GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const Se
             }
             row[8 + 2 * i] = rc4(K[i].w.x, K[i].w.y, K[i].w.z, K[i].v.x);
             row[9 + 2 * i] = rc4(K[i].v.y, K[i].v.z, 0.f, 0.f);
+        }
         }
 #ifdef GRX_PROFILE_SECTIONS
         long long tp_ = clock64(); pacc[4] += tp_ - t0_;   // centres, extents, staging
@@ -214,8 +244,8 @@ GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const Se
                     const int sa = pid >> 3, sb_ = pid & 7;      // left shape, right shape
                     const int ms = side == 0 ? sa : sb_, os = side == 0 ? sb_ : sa;   // mine, the other leg's
                     const int kb = ms < 2 ? 0 : (ms < 4 ? 1 : 2), ko = os < 2 ? 0 : (os < 4 ? 1 : 2);   // carrying chain body - 2
-                    const float4* rm = SB.st + lane * SELF_ROW;
-                    const float4* ro = SB.st + (lane ^ LPL) * SELF_ROW;
+                    const float4* rm = SB.st + (lane - hf_) * SELF_ROW;
+                    const float4* ro = SB.st + ((lane - hf_) ^ LPL) * SELF_ROW;
                     const float4 m0 = rm[ms], o0 = ro[os];
                     const float4 mw = rm[8 + 2 * kb], mv = rm[9 + 2 * kb], ow = ro[8 + 2 * ko], ov = ro[9 + 2 * ko];
                     SphW ma, ob;
@@ -240,6 +270,7 @@ GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const Se
     }
     // ---- base-lump shapes x this lane's thigh shapes
     if (__any((sn.m >> 16) != 0u)) {
+        need_vel();
         const ChainKin KB = {R0, zero, ang, vel};
         const V3 c0 = sph_centre(C.sph[8], K[0]), c1 = sph_centre(C.sph[9], K[0]);
         int prev_link = -1, slot = -1;
@@ -287,31 +318,65 @@ GRX_DEV int self_base_link(const SideConst& C, int s) {
 // The termination / collision flags (legged_robot.py:336-353, the `collision` reward term) are taken HERE, from the same net
 // forces the tensor shows -- a thigh pressing on a hand (GR1T2) terminates like a hand on the ground: term / pen_count of this
 // lane's base-lump links (terminating / penalised shapes ride on the base lump: build_side_tables).
+// what write_link_rows reads from the lane's tables, gathered ahead of the forces (wave 3 fills it while it waits for them)
+struct LinkPrep { int lk[4]; int link[8]; uint32_t fl[8]; int chain[3]; };
+GRX_DEV LinkPrep link_prep(const SideConst& C) {
+    LinkPrep p;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+        p.lk[s_] = self_base_link(C, s_);
+        p.lk[2 + s_] = __builtin_bit_cast(int, pair_swap(__builtin_bit_cast(float, p.lk[s_])));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { p.link[i] = (C.sph[i].link_last & 1) ? sph_link(C.sph[i]) : -2; p.fl[i] = C.sph[i].flags; }
+    p.chain[0] = sph_link(C.sph[8]); p.chain[1] = sph_link(C.sph[10]); p.chain[2] = sph_link(C.sph[12]);
+    return p;
+}
+GRX_DEV void put_link_row(const LinkForceOut& o_, int link, V3 F) {
+    if (o_.cf && link >= 0) { float* o = o_.cf + (size_t)(link * 3) * o_.N; o[0] = F.x; o[o_.N] = F.y; o[2 * o_.N] = F.z; }
+}
+// net force per link: rows[0..7] the base-lump links (valid where lp.link[i] != -2), rows[8..10] thigh, shank, foot; flags from them
+GRX_DEV void net_link_forces(KP P, const LinkPrep& lp, const V3 lf[8], V3 fl2, V3 fl3, V3 fl4, const SelfOut& so, V3 rows[11], bool& term, float& pen_count) {
+    term = false; pen_count = 0.f;
+    // forces the self-collision puts on base-lump links: mine and the partner lane's (its thigh against the same or another link);
+    // seldom any in the whole wave
+    const bool anyfb = __any(dot(so.fbase[0], so.fbase[0]) + dot(so.fbase[1], so.fbase[1]) != 0.f);
+    V3 fb[4];
+    if (anyfb) {
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            fb[s_] = so.fbase[s_];
+            fb[2 + s_] = v3(pair_swap(fb[s_].x), pair_swap(fb[s_].y), pair_swap(fb[s_].z));
+        }
+    }
+    const float tf2 = P.termination_force * P.termination_force;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        V3 f = lf[i];
+        const int link = lp.link[i];
+        if (anyfb) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) if (lp.lk[s_] == link) f = f + fb[s_];
+        }
+        rows[i] = f;
+        const bool closes = link != -2;
+        const float n2 = dot(f, f);
+        if (closes && (lp.fl[i] & GRX_SPH_TERMINATE) && n2 > tf2) term = true;
+        if (closes && (lp.fl[i] & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.0f;
+    }
+    rows[8] = fl2 + so.fl[0]; rows[9] = fl3 + so.fl[1]; rows[10] = fl4 + so.fl[2];
+}
+GRX_DEV void store_link_rows(const LinkForceOut& lfo, const LinkPrep& lp, const V3 rows[11]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) if (lp.link[i] != -2) put_link_row(lfo, lp.link[i], rows[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) put_link_row(lfo, lp.chain[i], rows[8 + i]);
+}
 GRX_DEV void write_link_rows(KP P, const LinkForceOut& lfo, const SideConst& C, const V3 lf[8], V3 fl2, V3 fl3, V3 fl4, const SelfOut& so,
                              bool& term, float& pen_count) {
     if (!lfo.last) return;
-    term = false; pen_count = 0.f;
-    // forces the self-collision puts on base-lump links: mine and the partner lane's (its thigh against the same or another link)
-    int lk[4]; V3 fb[4];
-#pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_) {
-        lk[s_] = self_base_link(C, s_); fb[s_] = so.fbase[s_];
-        lk[2 + s_] = __builtin_bit_cast(int, pair_swap(__builtin_bit_cast(float, lk[s_])));
-        fb[2 + s_] = v3(pair_swap(fb[s_].x), pair_swap(fb[s_].y), pair_swap(fb[s_].z));
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (C.sph[i].link_last & 1) {
-            V3 f = lf[i];
-            const int link = sph_link(C.sph[i]);
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) if (lk[s_] == link) f = f + fb[s_];
-            put_link_force(lfo, C.sph[i], f);
-            const float n2 = dot(f, f);
-            if ((C.sph[i].flags & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term = true;
-            if ((C.sph[i].flags & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.0f;
-        }
-    put_link_force(lfo, C.sph[8], fl2 + so.fl[0]);
-    put_link_force(lfo, C.sph[10], fl3 + so.fl[1]);
-    put_link_force(lfo, C.sph[12], fl4 + so.fl[2]);
+    const LinkPrep lp = link_prep(C);
+    V3 rows[11];
+    net_link_forces(P, lp, lf, fl2, fl3, fl4, so, rows, term, pen_count);
+    store_link_rows(lfo, lp, rows);
 }

@@ -28,6 +28,12 @@
 // single: a producer only overwrites it after wave 0 has published the NEXT sub-step's state, which wave 0 does
 // only after it has consumed all outputs of the current one.
 #pragma once
+#ifndef GRX_W8_WAITALL
+#define GRX_W8_WAITALL 1
+#endif
+#ifndef GRX_W8_RARESPLIT
+#define GRX_W8_RARESPLIT 1
+#endif
 
 #ifdef GRX_PROFILE_SECTIONS   // helper waves: cycles spent waiting for the next sub-step's state vs. in total
 #define GRX_HELPER_PROF_BEGIN long long hp_idle = 0, hp_t0 = clock64(), hp_t = 0
@@ -51,11 +57,16 @@
 #define GRX_PIN(x) asm volatile("" : "+v"(x))
 #ifdef GRX_PROFILE_SECTIONS
 #define GRX_WAIT(f, want, slot) do { long long w0_ = clock64(); flag_wait(f, want); tacc[slot] += clock64() - w0_; } while (0)
+#define GRX_WAIT_ALL(f, want_mine, lane, slot) do { long long w0_ = clock64(); flag_wait_all(f, want_mine, lane); tacc[slot] += clock64() - w0_; } while (0)
 #else
 #define GRX_WAIT(f, want, slot) flag_wait(f, want)
+#define GRX_WAIT_ALL(f, want_mine, lane, slot) flag_wait_all(f, want_mine, lane)
 #endif
 
-enum { FL_STATE = 0, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_BIAS2 = 7 /* bias forces of bodies 2..0 when wave 1 computes them (heightfield) */, FL_SELF = 9, FL_REW = 6, FL_BASEBIAS = 8, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_RR = 15, FL_COUNT = 16 };
+enum { FL_STATE = 0, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_BIAS2 = 7 /* bias forces of bodies 2..0 when wave 1 computes them (heightfield) */, FL_SELF = 9, FL_REW = 6, FL_BASEBIAS = 8, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_RR = 15,
+       FL_FACT = 16 /* W == 8: the base-level 6 x 6 is out (wave 0 -> wave 5) */, FL_FACTOUT = 17 /* ... and factorised */,
+       FL_XK = 18 /* W == 8: rigid inertias of thigh, hip yaw, hip roll (wave 6 -> wave 0), seq * 4 + bodies out */,
+       FL_CHAINW = 19 /* W == 8: thigh + shank terrain wrenches (wave 7) */, FL_COUNT = 20 };
 // Every record is laid out [quad][lane] in float4 units, so a lane moves it with ds_read_b128 / ds_write_b128: the
 // kernel runs at one instruction issue per ~5 cycles whatever the instruction, and the records are ~350 dwords per
 // lane and sub-step on wave 0 alone -- four dwords per LDS instruction instead of one is ~1.3k cycles per sub-step.
@@ -71,6 +82,8 @@ struct PipeLds {
     float4* pb;    // [LEG][PB4][64] + [2][64]: chain-body bias forces / accelerations (wave 2, leaf first), base-lump bias force (wave 3)
     float4* wr;    // [2][64]     base-lump wrench, termination flag, collision count
     int* flag;     // [FL_COUNT]
+    float4* xk;    // [3][3][64]  W == 8: rigid inertia about O of chain body k = 2, 1, 0 (wave 6 -> wave 0): A 6, h = m kap 3
+    float4* fx;    // [8][64]     W == 8: quads 0-3 the base-level X, Y of both legs (wave 0 -> wave 5), 4-7 M = Sc^-1 Y Xo^-1 and Sc^-1 (wave 5 -> wave 0)
 };
 GRX_DEV float4 f4(float a, float b, float c, float d) { float4 r; r.x = a; r.y = b; r.z = c; r.w = d; return r; }
 
@@ -84,6 +97,23 @@ GRX_DEV void flag_wait(int* f, int want) {
     // pure spin (the waiter owns its SIMD; an s_sleep between polls only added detection latency: +1.3 % measured)
     while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {}
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// several flags in ONE poll: lane i < FL_COUNT watches flag i until it reaches want_mine (INT_MIN: not waited for).  A poll is an
+// LDS round trip (~100 cycles even when the flag is already up): wave 0 meets ten hand-overs per sub-step
+GRX_DEV void flag_wait_all(int* f, int want_mine, int lane) {
+    const int* const p = f + (lane < FL_COUNT ? lane : 0);
+    while (!__all(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want_mine)) {}
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+GRX_DEV int flag_want(int lane, int f0, int w0, int f1 = -1, int w1 = 0, int f2 = -1, int w2 = 0, int f3 = -1, int w3 = 0, int f4 = -1, int w4 = 0, int f5 = -1, int w5 = 0) {
+    int w = INT_MIN;
+    if (lane == f0) w = w0;
+    if (lane == f1) w = w1;
+    if (lane == f2) w = w2;
+    if (lane == f3) w = w3;
+    if (lane == f4) w = w4;
+    if (lane == f5) w = w5;
+    return w;
 }
 // block barrier that orders LDS only (global stores stay in flight across it)
 GRX_DEV void lds_barrier() {
@@ -344,7 +374,7 @@ GRX_DEV V3 sel3(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c 
 GRX_DEV V3 row0(const M3& B) { return v3(B.a00, B.a01, B.a02); }
 GRX_DEV V3 row1(const M3& B) { return v3(B.a10, B.a11, B.a12); }
 GRX_DEV V3 row2(const M3& B) { return v3(B.a20, B.a21, B.a22); }
-template <bool HF>
+template <bool HF, bool W8>
 GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                        SubstepOut& out, FootKin& fk_before, const PipeLds& L, int lane, int seq, long long* tacc, const SideConst& Clds) {
     const float dt = P.sim_dt;
@@ -358,6 +388,8 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     float dinv[LEG], uu[LEG];
     GRX_EV(0);
     const R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
+    R3 R3s = R0, R4s = R0;
+    V3 kap3 = v3(0.f, 0.f, 0.f), kap4 = kap3;
     {   // ---- outward walk (both halves: the chain is serial); own / other parts picked per lane
         R3 R = R0;
         V3 rho = v3(0.f, 0.f, 0.f), w = st.ang, v = st.vel;
@@ -370,12 +402,21 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
             R = joint_rot_k(R, cs, sn, kAxis[k]);
             const V3 a = axis_k(R, kAxis[k]);
             const V3 s_ = cross(rho, a);
-            const V3 ca = cross(w, a) * qdk;
-            const V3 cl = (cross(v, a) + cross(w, s_)) * qdk;
             So[k] = sel3(hi, s_, a); St[k] = sel3(hi, a, s_);
-            co[k] = sel3(hi, cl, ca); ct[k] = sel3(hi, ca, cl);
-            w = fma3(a, qdk, w); v = fma3(s_, qdk, v);
+            if (!W8) {   // (eight waves: the c_k are folded into the bias forces, chain_bias_loop)
+                const V3 ca = cross(w, a) * qdk;
+                const V3 cl = (cross(v, a) + cross(w, s_)) * qdk;
+                co[k] = sel3(hi, cl, ca); ct[k] = sel3(hi, ca, cl);
+                w = fma3(a, qdk, w); v = fma3(s_, qdk, v);
+            }
+            if (W8 && k < LEG - 2) continue;   // eight waves: the rigid inertias of bodies 2, 1, 0 come from wave 6
             const V3 kap = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+            if (W8) {   // ... and those of shank and foot are computed in ONE pass below, a body per half
+                hK[k] = kap * C.body[k].mass;
+                if (k == LEG - 2) { R3s = R; kap3 = kap; }
+                else { R4s = R; kap4 = kap; }
+                continue;
+            }
             const S3 Ic = {Clds.body[k].Ic[0], Clds.body[k].Ic[1], Clds.body[k].Ic[2], Clds.body[k].Ic[3], Clds.body[k].Ic[4], Clds.body[k].Ic[5]};
             S3 Ak;
             rigid_inertia(R, kap, C.body[k].mass, Ic, Ak, hK[k]);
@@ -383,6 +424,22 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
             XK[k].xx = hi ? m : Ak.xx; XK[k].xy = hi ? 0.f : Ak.xy; XK[k].xz = hi ? 0.f : Ak.xz;
             XK[k].yy = hi ? m : Ak.yy; XK[k].yz = hi ? 0.f : Ak.yz; XK[k].zz = hi ? m : Ak.zz;
         }
+    }
+    if (W8) {   // rotational inertia about O of the foot (lo half) and of the shank (hi half: the lo half needs it, one DPP step away)
+        const int kb = hi ? LEG - 2 : LEG - 1;
+        R3 Rs;
+        Rs.cx = sel3(hi, R3s.cx, R4s.cx); Rs.cy = sel3(hi, R3s.cy, R4s.cy); Rs.cz = sel3(hi, R3s.cz, R4s.cz);
+        const V3 kap = sel3(hi, kap3, kap4);
+        const float ms = hi ? C.body[LEG - 2].mass : C.body[LEG - 1].mass;
+        const S3 Ic = {Clds.body[kb].Ic[0], Clds.body[kb].Ic[1], Clds.body[kb].Ic[2], Clds.body[kb].Ic[3], Clds.body[kb].Ic[4], Clds.body[kb].Ic[5]};
+        S3 Ak; V3 h_;
+        rigid_inertia(Rs, kap, ms, Ic, Ak, h_);
+        const S3 At = {half_swap(Ak.xx), half_swap(Ak.xy), half_swap(Ak.xz), half_swap(Ak.yy), half_swap(Ak.yz), half_swap(Ak.zz)};
+        const float m4 = C.body[LEG - 1].mass, m3 = C.body[LEG - 2].mass;
+        XK[LEG - 1].xx = hi ? m4 : Ak.xx; XK[LEG - 1].xy = hi ? 0.f : Ak.xy; XK[LEG - 1].xz = hi ? 0.f : Ak.xz;
+        XK[LEG - 1].yy = hi ? m4 : Ak.yy; XK[LEG - 1].yz = hi ? 0.f : Ak.yz; XK[LEG - 1].zz = hi ? m4 : Ak.zz;
+        XK[LEG - 2].xx = hi ? m3 : At.xx; XK[LEG - 2].xy = hi ? 0.f : At.xy; XK[LEG - 2].xz = hi ? 0.f : At.xz;
+        XK[LEG - 2].yy = hi ? m3 : At.yy; XK[LEG - 2].yz = hi ? 0.f : At.yz; XK[LEG - 2].zz = hi ? m3 : At.zz;
     }
     GRX_EV(1);
     // ---- inward pass, inertia half (leaf -> root), rows split over the two halves
@@ -394,18 +451,39 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     };
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
+        if (W8 && k < LEG - 2) {
+            if (GRX_W8_WAITALL) { if (k == LEG - 3) GRX_WAIT(L.flag + FL_XK, seq * 4 + 3, 4); }
+            else GRX_WAIT(L.flag + FL_XK, seq * 4 + (LEG - 2 - k), 4);
+            // (wave 5 computes body 2 on the lo half of the leg, body 1 on the hi half, body 0 on both)
+            const float4* c = L.xk + (k * 3) * 64 + (k == 0 ? lane : (k == 2 ? lane - lane_half(lane) : lane - lane_half(lane) + 1));
+            const float4 a0 = c[0 * 64], a1 = c[1 * 64], a2 = c[2 * 64];
+            const float m = C.body[k].mass;
+            XK[k].xx = hi ? m : a0.x; XK[k].xy = hi ? 0.f : a0.y; XK[k].xz = hi ? 0.f : a0.z;
+            XK[k].yy = hi ? m : a0.w; XK[k].yz = hi ? 0.f : a1.x; XK[k].zz = hi ? m : a1.y;
+            hK[k] = v3(a1.z, a1.w, a2.x);
+        }
         X = X + XK[k];
         add_skew(hK[k]);
         const V3 u = mul(X, So[k]) + mul(Y, St[k]);
         const float di = grx_rcp(half_sum(dot(So[k], u)));
         const V3 uo = half_swap(u);
         syr(X, u, di); ger(Y, u, uo, di);
-        ic[k] = mul(X, co[k]) + mul(Y, ct[k]);
+        if (!W8) ic[k] = mul(X, co[k]) + mul(Y, ct[k]);
         Uo[k] = u; dinv[k] = di;
     }
     GRX_EV(3);
     // base level: both legs (quad_perm [2,3,0,1]) + the base lump, both Schur complements factorised
     X = pair_sum(X); Y = pair_sum(Y);
+    S3 Xio;   // inverse of the OTHER half's diagonal block: lo holds D^-1, hi holds A^-1
+    S3 Sci;
+    if (W8) {   // eight waves: wave 5 adds the base lump and factorises (base_service_loop) while this wave runs the bias half
+        float4* o = L.fx + lane;
+        o[0 * 64] = f4(X.xx, X.xy, X.xz, X.yy);
+        o[1 * 64] = f4(X.yz, X.zz, Y.a00, Y.a01);
+        o[2 * 64] = f4(Y.a02, Y.a10, Y.a11, Y.a12);
+        o[3 * 64] = f4(Y.a20, Y.a21, Y.a22, 0.f);
+        flag_set(L.flag + FL_FACT, seq + 1, lane);
+    } else {
     {
         S3 A0; V3 h0;
         rigid_inertia(R0, rot(R0, LC.base_c), LC.base_m, LC.base_I, A0, h0);
@@ -415,34 +493,39 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         add_skew(h0);
     }
     GRX_EV(14);
-    S3 Xio;   // inverse of the OTHER half's diagonal block: lo holds D^-1, hi holds A^-1
     {
         const S3 Xi = inv(X);
         Xio.xx = half_swap(Xi.xx); Xio.xy = half_swap(Xi.xy); Xio.xz = half_swap(Xi.xz);
         Xio.yy = half_swap(Xi.yy); Xio.yz = half_swap(Xi.yz); Xio.zz = half_swap(Xi.zz);
     }
-    S3 Sci;
     {
         const V3 y0 = row0(Y), y1 = row1(Y), y2 = row2(Y);
         const V3 t0 = mul(Xio, y0), t1 = mul(Xio, y1), t2 = mul(Xio, y2);
         const S3 Sc = {X.xx - dot(y0, t0), X.xy - dot(y0, t1), X.xz - dot(y0, t2), X.yy - dot(y1, t1), X.yz - dot(y1, t2), X.zz - dot(y2, t2)};
         Sci = inv(Sc);
     }
-#ifdef GRX_PROFILE_SECTIONS
-    if (seq == 5 && lane == 0) { __builtin_amdgcn_sched_barrier(0); P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 79] = clock64(); __builtin_amdgcn_sched_barrier(0); }
-#endif
     // (keep all of the above in front of the spin-waits: see substep_p)
     GRX_PIN(Sci.xx); GRX_PIN(Sci.xy); GRX_PIN(Sci.xz); GRX_PIN(Sci.yy); GRX_PIN(Sci.yz); GRX_PIN(Sci.zz);
     GRX_PIN(Xio.xx); GRX_PIN(Xio.xy); GRX_PIN(Xio.xz); GRX_PIN(Xio.yy); GRX_PIN(Xio.yz); GRX_PIN(Xio.zz);
+    }
+#ifdef GRX_PROFILE_SECTIONS
+    if (seq == 5 && lane == 0) { __builtin_amdgcn_sched_barrier(0); P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 79] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+#endif
+    if (!W8) {
 #pragma unroll
-    for (int k = 0; k < LEG; ++k) { GRX_PIN(ic[k].x); GRX_PIN(ic[k].y); GRX_PIN(ic[k].z); }
+        for (int k = 0; k < LEG; ++k) { GRX_PIN(ic[k].x); GRX_PIN(ic[k].y); GRX_PIN(ic[k].z); }
+    }
     GRX_EV(2);
     // ---- inward pass, bias half (leaf -> root): rigid-body bias forces from waves 2 / 1, own rows only.  (Folding this chain of
     // dependent dot / DPP / fma steps into the loop above was tried: no gain -- a lone wave issues one VALU instruction per ~4.5
     // cycles whatever its dependencies, measured with tools/micro/operand_rate.hip -- and the wait for the bias forces moves up.)
     V3 po = v3(0.f, 0.f, 0.f);
-    GRX_WAIT(L.flag + FL_BIAS, seq * 8 + (HF ? 2 : LEG), 0);
-    if (HF) GRX_WAIT(L.flag + FL_BIAS2, seq + 1, 0);
+    if (W8 && GRX_W8_WAITALL) GRX_WAIT_ALL(L.flag, flag_want(lane, FL_BIAS, seq * 8 + 2, FL_BIAS2, seq + 1), lane, 0);
+    else if (W8) { GRX_WAIT(L.flag + FL_BIAS, seq * 8 + 2, 0); GRX_WAIT(L.flag + FL_BIAS2, seq + 1, 0); }
+    else {
+        GRX_WAIT(L.flag + FL_BIAS, seq * 8 + (HF ? 2 : LEG), 0);
+        if (HF) GRX_WAIT(L.flag + FL_BIAS2, seq + 1, 0);
+    }
     float4 bq0[LEG], bq1[LEG];
 #pragma unroll
     for (int k = 0; k < LEG; ++k) { const float4* b_ = L.pb + (k * PB4) * 64 + lane; bq0[k] = b_[0 * 64]; bq1[k] = b_[1 * 64]; }
@@ -452,15 +535,22 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         po = po + sel3(hi, v3(b0_.w, b1_.x, b1_.y), v3(b0_.x, b0_.y, b0_.z));
         const float u = (tau_m[k] + b1_.z) - half_sum(dot(So[k], po));   // motor torque + joint-limit spring/damper - S . p
         uu[k] = u;
-        po = po + ic[k] + Uo[k] * (u * dinv[k]);
+        if (!W8) po = po + ic[k];
+        po = fma3(Uo[k], u * dinv[k], po);
     }
     GRX_EV(7);
     // ---- contact wrenches on chain bodies 4, 3, 2: delta recursion on the own rows
-    GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
-    GRX_EV(4);
-    GRX_WAIT(L.flag + FL_LEGS, seq + 1, 2);
-    GRX_EV(5);
-    GRX_WAIT(L.flag + FL_SELF, seq + 1, 3);
+    if (W8 && GRX_W8_WAITALL) {   // everything the rest of the sub-step consumes, in one poll
+        GRX_WAIT_ALL(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_LEGS, seq + 1, FL_SELF, seq + 1, FL_BASEBIAS, seq + 1, FL_FACTOUT, seq + 1, FL_CHAINW, seq + 1), lane, 2);
+        GRX_EV(5);
+    } else {
+        if (W8) { GRX_WAIT(L.flag + FL_BASEBIAS, seq + 1, 0); GRX_WAIT(L.flag + FL_FACTOUT, seq + 1, 1); GRX_WAIT(L.flag + FL_CHAINW, seq + 1, 2); }
+        GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
+        GRX_EV(4);
+        GRX_WAIT(L.flag + FL_LEGS, seq + 1, 2);
+        GRX_EV(5);
+        GRX_WAIT(L.flag + FL_SELF, seq + 1, 3);
+    }
     V3 sco[3], sc0o;   // self-collision wrenches (wave 1), own rows
     V3 scfl2;          // ... and the force on the foot link
     {
@@ -497,20 +587,29 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     }
     po = pair_sum(po);
     {   // base-lump bias force (wave 3; the lanes of both legs add the same value after the leg sum)
-        GRX_WAIT(L.flag + FL_BASEBIAS, seq + 1, 0);
+        if (!W8) GRX_WAIT(L.flag + FL_BASEBIAS, seq + 1, 0);
         const float4* b_ = L.pb + (LEG * PB4) * 64 + lane;
         const float4 b0_ = b_[0 * 64], b1_ = b_[1 * 64];
         po = po + sel3(hi, v3(b0_.w, b1_.x, b1_.y), v3(b0_.x, b0_.y, b0_.z));
     }
     // lo: alpha = Sa^-1 (B D^-1 p_l - p_a);  hi: acc = Sd^-1 (B^T A^-1 p_a - p_l)
-    const V3 xo = mul(Sci, mul(Y, mul(Xio, half_swap(po))) - po);
+    V3 xo;
+    if (W8) {   // x = M p_other - Sc^-1 p_own with M = Sc^-1 Y Xo^-1 from wave 5
+        const float4* c = L.fx + 4 * 64 + lane;
+        const float4 m0 = c[0 * 64], m1 = c[1 * 64], m2 = c[2 * 64], m3 = c[3 * 64];
+        const V3 pt = half_swap(po);
+        const S3 Si = {m2.y, m2.z, m2.w, m3.x, m3.y, m3.z};
+        xo = v3(m0.x * pt.x + m0.y * pt.y + m0.z * pt.z, m0.w * pt.x + m1.x * pt.y + m1.y * pt.z, m1.z * pt.x + m1.w * pt.y + m2.x * pt.z) - mul(Si, po);
+    } else {
+        xo = mul(Sci, mul(Y, mul(Xio, half_swap(po))) - po);
+    }
     // ---- pass 3 (root -> leaf): accelerations, own rows
     float qdd[LEG];
     {
         V3 ao = xo;
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {
-            const V3 p_ = ao + co[k];
+            const V3 p_ = W8 ? ao : ao + co[k];
             const float qd2 = (uu[k] - half_sum(dot(Uo[k], p_))) * dinv[k];
             qdd[k] = qd2;
             ao = fma3(So[k], qd2, p_);
@@ -552,7 +651,9 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 // wave 2's frames arrive -- walks the chain itself (same arithmetic, same frames) and takes over the bias forces of the
 // bodies wave 0 reaches last: thigh, hip yaw, hip roll.
 // `idle(seq)` runs after the hand-over of every sub-step, in the ~2 k cycles this wave then waits for wave 0's next state.
-template <bool HF, class Idle>
+// OWNPOS (eight waves): positions-only walk of its own for the sphere centres and pair tests; the bodies' velocities (contact damping only)
+// are picked up from wave 2's frames, which are out by the time the centres are staged
+template <bool HF, bool WALK, bool OWNPOS, class Idle>   // WALK: four waves on a heightfield (see above); else the frames come from wave 2
 GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, const float4* footfr, const SelfBuf& SB, float mu_self,
                        const PipeLds& L, int lane, int el, int side, Idle idle) {
     GRX_HELPER_PROF_BEGIN;
@@ -573,7 +674,7 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
         const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
         ChainKin KS[3];
-        if (HF) {
+        if (WALK) {
             float qs_q[LEG], qs_qd[LEG];
             {
                 const float4 q0_ = L.q[lane], q1_ = L.q[64 + lane], q2_ = L.q[128 + lane];
@@ -601,6 +702,18 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
                 o[1 * 64] = f4(pl.y, pl.z, tlim, 0.f);
             }
             flag_set(L.flag + FL_BIAS2, seq + 1, lane);
+        } else if (OWNPOS) {
+            const float4 q0_ = L.q[lane], q1_ = L.q[64 + lane];
+            const float qs[LEG] = {q0_.x, q0_.y, q0_.z, q0_.w, q1_.x};
+            ChainKin K = {R0, v3(0.f, 0.f, 0.f), ang, vel};
+#pragma unroll
+            for (int k = 0; k < LEG; ++k) {
+                K.rho = K.rho + rot(K.R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+                float sn, cs;
+                grx_sincos(qs[k], sn, cs);
+                K.R = joint_rot_k(K.R, cs, sn, kAxis[k]);
+                if (k >= 2) KS[k - 2] = K;
+            }
         } else {
             flag_wait(L.flag + FL_FRAMES, seq + 1);
 #pragma unroll
@@ -609,9 +722,21 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
                 KS[i].R = f.R; KS[i].rho = f.rho; KS[i].w = f.w; KS[i].v = f.v;
             }
         }
+        const int fr_want = seq + 1;
+        int* const fr_flag = L.flag + FL_FRAMES;
+        auto velocities = [&]() {   // OWNPOS: (w, v) of thigh, shank, foot from wave 2's frames, once the geometry is done with
+            if (!OWNPOS) return;
+            flag_wait(fr_flag, fr_want);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float4* f = i < 2 ? RB.fchain + i * RC_FR4 * 64 + lane : footfr + lane;
+                const float4 d = f[3 * 64], e_ = f[4 * 64];
+                KS[i].w = v3(d.x, d.y, d.z); KS[i].v = v3(d.w, e_.x, e_.y);
+            }
+        };
         if (seq == 0) sn = self_broad_phase(P, C, side, R0, KS);
         SelfOut sc;
-        self_collision(P, T, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc);
+        self_collision(P, T, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc, velocities);
         float4* o = L.wc + 7 * 64 + lane;
         o[0 * 64] = f4(sc.fa[0].x, sc.fa[0].y, sc.fa[0].z, sc.fl[0].x);
         o[1 * 64] = f4(sc.fl[0].y, sc.fl[0].z, sc.fa[1].x, sc.fa[1].y);
@@ -632,8 +757,228 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// wave 2: own walk with velocities; thigh / shank frames for wave 3; the anchored foot spheres
+// Eight waves per block (lane quads only; two waves per SIMD, each still issuing one instruction per ~4.5 cycles): the work the
+// four-wave layout hangs on whichever wave has slack gets waves of its own, and wave 0 sheds what others can finish in time.
+// waves 4 and 6: own walk with velocities, then the bias forces of the chain bodies KHI .. KLO (wave 4: foot, shank; wave 6: thigh,
+// hip yaw, hip roll) -- wave 2 keeps the foot contacts only.  The velocity-product accelerations c_k of the joints are FOLDED into
+// these forces: with zeta_k = sum of c_j over the joints up to k (all about O in world axes, so a plain sum) and a_k = a^_k + zeta_k,
+// body k obeys f_k = I_k a^_k + (p_k + I_k zeta_k) and the joints a^_k = a^_(k-1) + S_k qdd_k: the articulated-body recursion in a^
+// has NO c terms -- wave 0 drops I^a c (18 instructions per joint), the c_k themselves and the chain velocities of its walk -- and
+// the rigid-body bias force becomes the Newton-Euler force of body k moving with (w, v) and accelerating with zeta_k.
+struct ChainKinZ { ChainKin K; V3 za, zl; };
+GRX_DEV void chain_step_z(const SideConst& C, int k, float q, float qd, ChainKinZ& Z) {
+    ChainKin& K = Z.K;
+    K.rho = K.rho + rot(K.R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+    float sn, cs;
+    grx_sincos(q, sn, cs);
+    K.R = joint_rot_k(K.R, cs, sn, kAxis[k]);
+    const V3 a = axis_k(K.R, kAxis[k]);
+    const V3 s = cross(K.rho, a);
+    Z.za = fma3(cross(K.w, a), qd, Z.za);
+    Z.zl = fma3(cross(K.v, a) + cross(K.w, s), qd, Z.zl);
+    K.w = fma3(a, qd, K.w); K.v = fma3(s, qd, K.v);
+}
+// F = m (zl + za x kap) + w x l, l = m (v + w x kap);  torque about the centre of mass n = R (Ic zb + wb x Ic wb);  about O: n + kap x F
+GRX_DEV void rigid_bias_z(const R3& R, V3 kap, float m, const S3& Ic, V3 w, V3 v, V3 za, V3 zl, V3& pa, V3& pl) {
+    const V3 wb = rotT(R, w), zb = rotT(R, za);
+    const V3 nb = mul(Ic, zb) + cross(wb, mul(Ic, wb));
+    const V3 l = (v + cross(w, kap)) * m;
+    pl = cross(w, l) + (zl + cross(za, kap)) * m;
+    pa = rot(R, nb) + cross(kap, pl);
+}
+template <int KLO, int KHI>
+GRX_DEV void chain_bias_loop(KP P, const SideConst& C, const PipeLds& L, int lane, int el) {
+    constexpr int NB = KHI - KLO + 1;
+    float lim_lo[NB], lim_hi[NB], lim_k[NB], lim_c[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { lim_lo[k] = C.body[KLO + k].qlo; lim_hi[k] = C.body[KLO + k].qhi; lim_k[k] = C.body[KLO + k].Klim; lim_c[k] = C.body[KLO + k].Clim; }
+    for (int seq = 0; seq < P.decimation; ++seq) {
+        flag_wait(L.flag + FL_STATE, seq + 1);
+        const float* b = L.base + el;
+        const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
+        const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+        float qs_q[LEG], qs_qd[LEG];
+        {
+            const float4 q0_ = L.q[lane], q1_ = L.q[64 + lane], q2_ = L.q[128 + lane];
+            qs_q[0] = q0_.x; qs_q[1] = q0_.y; qs_q[2] = q0_.z; qs_q[3] = q0_.w; qs_q[4] = q1_.x;
+            qs_qd[0] = q1_.y; qs_qd[1] = q1_.z; qs_qd[2] = q1_.w; qs_qd[3] = q2_.x; qs_qd[4] = q2_.y;
+        }
+        ChainKinZ Z = {{R0, v3(0.f, 0.f, 0.f), ang, vel}, v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+        ChainKinZ ZZ[NB];
+#pragma unroll
+        for (int k = 0; k <= KHI; ++k) { chain_step_z(C, k, qs_q[k], qs_qd[k], Z); if (k >= KLO) ZZ[k - KLO] = Z; }
+        V3 kaps[NB];
+#pragma unroll
+        for (int k = KHI; k >= KLO; --k) {
+            const ChainKinZ& B = ZZ[k - KLO];
+            kaps[k - KLO] = B.K.rho + rot(B.K.R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+            if (false) {   // (the rigid inertias of bodies 2, 1, 0 were computed here before wave 5 took them over)
+                const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
+                S3 Ak; V3 h_;
+                rigid_inertia(B.K.R, kaps[k - KLO], C.body[k].mass, Ic, Ak, h_);
+                float4* o = L.xk + (k * 3) * 64 + lane;
+                o[0 * 64] = f4(Ak.xx, Ak.xy, Ak.xz, Ak.yy);
+                o[1 * 64] = f4(Ak.yz, Ak.zz, h_.x, h_.y);
+                o[2 * 64] = f4(h_.z, 0.f, 0.f, 0.f);
+                flag_set(L.flag + FL_XK, seq * 4 + (KHI - k + 1), lane);
+            }
+        }
+#pragma unroll
+        for (int k = KHI; k >= KLO; --k) {
+            const ChainKinZ& B = ZZ[k - KLO];
+            const V3 kap = kaps[k - KLO];
+            const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
+            V3 pa, pl;
+            rigid_bias_z(B.K.R, kap, C.body[k].mass, Ic, B.K.w, B.K.v, B.za, B.zl, pa, pl);
+            const int i = k - KLO;
+            const float viol = qs_q[k] < lim_lo[i] ? lim_lo[i] - qs_q[k] : (qs_q[k] > lim_hi[i] ? lim_hi[i] - qs_q[k] : 0.f);
+            const float tlim = lim_k[i] * viol - (viol != 0.f ? lim_c[i] * qs_qd[k] : 0.f);
+            float4* o = L.pb + (k * PB4) * 64 + lane;
+            o[0 * 64] = f4(pa.x, pa.y, pa.z, pl.x);
+            o[1 * 64] = f4(pl.y, pl.z, tlim, 0.f);
+        }
+        if (KHI == LEG - 1) { flag_set(L.flag + FL_BIAS, seq * 8 + 2, lane); GRX_EV(26); }
+        else { flag_set(L.flag + FL_BIAS2, seq + 1, lane); GRX_EV(28); }
+    }
+}
+
+// wave 7: the thigh / shank shapes of the seldom-touching set (grx_rare.h), on the frames wave 2 publishes, with a compaction
+// buffer of its own; wave 3 keeps the base-lump shapes, which need the base state only
 template <bool HF>
+GRX_DEV void chain_rare_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, float mu, float hmax, const PipeLds& L, int lane, int el, int side) {
+    for (int seq = 0; seq < P.decimation; ++seq) {
+        flag_wait(L.flag + FL_STATE, seq + 1);
+        if (!GRX_W8_RARESPLIT) { flag_set(L.flag + FL_CHAINW, seq + 1, lane); continue; }
+        const float* b = L.base + el;
+        const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
+        const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
+        const V3 zero = v3(0.f, 0.f, 0.f);
+        // own positions-only walk to thigh and shank: the reach tests start ~0.6 k cycles before wave 2's frames (with velocities) are out
+        ChainKin K3 = {R0, zero, zero, zero}, K2 = K3;
+        {
+            const float4 q0_ = L.q[lane];
+            const float qs[4] = {q0_.x, q0_.y, q0_.z, q0_.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                K3.rho = K3.rho + rot(K3.R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+                float sn, cs;
+                grx_sincos(qs[k], sn, cs);
+                K3.R = joint_rot_k(K3.R, cs, sn, kAxis[k]);
+                if (k == 2) K2 = K3;
+            }
+        }
+        RareOut ro;
+        const int want = seq + 1;
+        int* const fr_flag = L.flag + FL_FRAMES;
+        rare_contacts<HF, 8, RC_NS, true, true>(P, T, C, RB, lane, el, side, R0, O, zero, zero, K2, K3, mu, hmax, ro, nullptr,
+                                                [=]() { flag_wait(fr_flag, want); }, false);
+        float4* c_ = L.wc + lane;
+        c_[0 * 64] = f4(ro.fa2.x, ro.fa2.y, ro.fa2.z, ro.fl2.x);
+        c_[1 * 64] = f4(ro.fl2.y, ro.fl2.z, 0.f, 0.f);
+        c_[2 * 64] = f4(ro.fa3.x, ro.fa3.y, ro.fa3.z, ro.fl3.x);
+        c_[3 * 64] = f4(ro.fl3.y, ro.fl3.z, 0.f, 0.f);
+        flag_set(L.flag + FL_CHAINW, seq + 1, lane);
+        GRX_EV(14);
+    }
+}
+
+// wave 5: everything at the floating base that is not on wave 0's chain -- the base lump's bias force and rigid inertia, and the
+// factorisation of the base-level 6 x 6 (substep_q's dual Schur forms) from the X, Y wave 0 hands over after its inertia half.
+// Returns M = Sc^-1 Y Xo^-1 and Sc^-1: wave 0's solve is then x = M p_other - Sc^-1 p_own.
+GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, float base_m, V3 base_c, const S3& base_I, const PipeLds& L, int lane, int el) {
+    const bool hi = lane_half(lane) != 0;
+    const float sg = hi ? -1.f : 1.f;
+    for (int seq = 0; seq < P.decimation; ++seq) {
+        flag_wait(L.flag + FL_STATE, seq + 1);
+        const float* b = L.base + el;
+        const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
+        {   // first what wave 0 needs first: the rigid inertias about O of thigh, hip yaw, hip roll (its inertia half adds them at bodies 2,
+            // 1, 0).  Positions-only walk of three bodies, then body 2 on the lo half of the leg and body 1 on the hi half in ONE pass.
+            const float4 q0_ = L.q[lane];
+            const float qs[3] = {q0_.x, q0_.y, q0_.z};
+            R3 R = R0, Rk[3];
+            V3 rho = v3(0.f, 0.f, 0.f), kapk[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                rho = rho + rot(R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+                float sn, cs;
+                grx_sincos(qs[k], sn, cs);
+                R = joint_rot_k(R, cs, sn, kAxis[k]);
+                Rk[k] = R;
+                kapk[k] = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+            }
+            {
+                const int kb = hi ? 1 : 2;
+                R3 Rs;
+                Rs.cx = sel3(hi, Rk[1].cx, Rk[2].cx); Rs.cy = sel3(hi, Rk[1].cy, Rk[2].cy); Rs.cz = sel3(hi, Rk[1].cz, Rk[2].cz);
+                const V3 kap = sel3(hi, kapk[1], kapk[2]);
+                const float ms = hi ? C.body[1].mass : C.body[2].mass;
+                const S3 Ic = {Clds.body[kb].Ic[0], Clds.body[kb].Ic[1], Clds.body[kb].Ic[2], Clds.body[kb].Ic[3], Clds.body[kb].Ic[4], Clds.body[kb].Ic[5]};
+                S3 Ak; V3 h_;
+                rigid_inertia(Rs, kap, ms, Ic, Ak, h_);
+                float4* o = L.xk + (kb * 3) * 64 + lane;
+                o[0 * 64] = f4(Ak.xx, Ak.xy, Ak.xz, Ak.yy);
+                o[1 * 64] = f4(Ak.yz, Ak.zz, h_.x, h_.y);
+                o[2 * 64] = f4(h_.z, 0.f, 0.f, 0.f);
+            }
+            {
+                const S3 Ic = {C.body[0].Ic[0], C.body[0].Ic[1], C.body[0].Ic[2], C.body[0].Ic[3], C.body[0].Ic[4], C.body[0].Ic[5]};
+                S3 Ak; V3 h_;
+                rigid_inertia(Rk[0], kapk[0], C.body[0].mass, Ic, Ak, h_);
+                float4* o = L.xk + lane;
+                o[0 * 64] = f4(Ak.xx, Ak.xy, Ak.xz, Ak.yy);
+                o[1 * 64] = f4(Ak.yz, Ak.zz, h_.x, h_.y);
+                o[2 * 64] = f4(h_.z, 0.f, 0.f, 0.f);
+            }
+            flag_set(L.flag + FL_XK, seq * 4 + 3, lane);
+            GRX_EV(27);
+        }
+        const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+        const V3 kap0 = rot(R0, base_c);
+        {
+            V3 bpa, bpl;
+            rigid_bias(R0, kap0, base_m, base_I, ang, vel, bpa, bpl);
+            float4* o = L.pb + (LEG * PB4) * 64 + lane;
+            o[0 * 64] = f4(bpa.x, bpa.y, bpa.z, bpl.x);
+            o[1 * 64] = f4(bpl.y, bpl.z, 0.f, 0.f);
+            flag_set(L.flag + FL_BASEBIAS, seq + 1, lane);
+        }
+        S3 A0; V3 h0;
+        rigid_inertia(R0, kap0, base_m, base_I, A0, h0);
+        flag_wait(L.flag + FL_FACT, seq + 1);
+        GRX_EV(30);
+        const float4* c = L.fx + lane;
+        const float4 x0 = c[0 * 64], x1 = c[1 * 64], x2 = c[2 * 64], x3 = c[3 * 64];
+        S3 X = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y};
+        M3 Y = {x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z};
+        X.xx += hi ? base_m : A0.xx; X.xy += hi ? 0.f : A0.xy; X.xz += hi ? 0.f : A0.xz;
+        X.yy += hi ? base_m : A0.yy; X.yz += hi ? 0.f : A0.yz; X.zz += hi ? base_m : A0.zz;
+        Y.a01 = fmaf(-sg, h0.z, Y.a01); Y.a02 = fmaf(sg, h0.y, Y.a02); Y.a10 = fmaf(sg, h0.z, Y.a10);
+        Y.a12 = fmaf(-sg, h0.x, Y.a12); Y.a20 = fmaf(-sg, h0.y, Y.a20); Y.a21 = fmaf(sg, h0.x, Y.a21);
+        S3 Xio;
+        {
+            const S3 Xi = inv(X);
+            Xio.xx = half_swap(Xi.xx); Xio.xy = half_swap(Xi.xy); Xio.xz = half_swap(Xi.xz);
+            Xio.yy = half_swap(Xi.yy); Xio.yz = half_swap(Xi.yz); Xio.zz = half_swap(Xi.zz);
+        }
+        const V3 y0 = row0(Y), y1 = row1(Y), y2 = row2(Y);
+        const V3 t0 = mul(Xio, y0), t1 = mul(Xio, y1), t2 = mul(Xio, y2);   // rows of Y Xo^-1
+        const S3 Sc = {X.xx - dot(y0, t0), X.xy - dot(y0, t1), X.xz - dot(y0, t2), X.yy - dot(y1, t1), X.yz - dot(y1, t2), X.zz - dot(y2, t2)};
+        const S3 Si = inv(Sc);
+        const V3 m0 = t0 * Si.xx + t1 * Si.xy + t2 * Si.xz, m1 = t0 * Si.xy + t1 * Si.yy + t2 * Si.yz, m2 = t0 * Si.xz + t1 * Si.yz + t2 * Si.zz;
+        float4* o = L.fx + 4 * 64 + lane;
+        o[0 * 64] = f4(m0.x, m0.y, m0.z, m1.x);
+        o[1 * 64] = f4(m1.y, m1.z, m2.x, m2.y);
+        o[2 * 64] = f4(m2.z, Si.xx, Si.xy, Si.xz);
+        o[3 * 64] = f4(Si.yy, Si.yz, Si.zz, 0.f);
+        flag_set(L.flag + FL_FACTOUT, seq + 1, lane);
+        GRX_EV(29);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave 2: own walk with velocities; thigh / shank frames for wave 3; the anchored foot spheres
+template <bool HF, int NBIAS>   // NBIAS: this wave computes the bias forces of the last NBIAS chain bodies (5, 2, or 0: eight waves)
 GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const SideConst& Clds, const RareBuf& RB, float4* footfr, float mu, float hmax, float om_e, LaneState& hs, const PipeLds& L,
                                 int lane, int el, int side) {
     const int half = lane_half(lane);
@@ -690,9 +1035,8 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const SideConst& Clds,
         };
         // (foot contacts between the bias forces of shank and thigh, so that the foot wrench is out early: tried, +1.2 us on
         //  rough terrain -- wave 0 then waits for the last bias forces instead)
-        bias_out(4); GRX_EV(9);
-        bias_out(3);
-        if (!HF) { bias_out(2); bias_out(1); bias_out(0); }   // heightfield: wave 1 computes those (self_loop)
+        if (NBIAS >= 2) { bias_out(4); GRX_EV(9); bias_out(3); }
+        if (NBIAS == 5) { bias_out(2); bias_out(1); bias_out(0); }   // else wave 1 (four waves, heightfield: self_loop) or waves 4, 6 (eight waves) compute them
         GRX_EV(10);
         float4* c_ = L.wc + lane;
         V3 fa, fl;
@@ -712,9 +1056,9 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const SideConst& Clds,
 }
 
 // wave 3: the seldom-touching shapes -- base lump (torso, head, arms), thigh, shank -- lane-compacted (grx_rare.h)
-template <bool HF>
+template <bool HF, bool W8, bool SPLIT = W8 && GRX_W8_RARESPLIT>   // W8 (eight waves): base-lump shapes only -- thigh / shank shapes on wave 7 (chain_rare_loop), base bias force on wave 5
 GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, float mu, float hmax, float base_m, V3 base_c,
-                               const S3& base_I, const PipeLds& L, int lane, int el, int side, const LinkForceOut& lfo, float* s_tp) {
+                               const S3& base_I, const PipeLds& L, int lane, int el, int side, float* s_tp, LinkPrep& lp, V3 link_rows[11]) {
     GRX_HELPER_PROF_BEGIN;
 #ifdef GRX_PROFILE_SECTIONS
     long long racc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -729,7 +1073,7 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
         const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
-        {   // the base lump's rigid-body bias force (cheap; needed by wave 0 only at the base solve)
+        if (!W8) {   // the base lump's rigid-body bias force (cheap; needed by wave 0 only at the base solve)
             V3 bpa, bpl;
             rigid_bias(R0, rot(R0, base_c), base_m, base_I, ang, vel, bpa, bpl);
             float4* o = L.pb + (LEG * PB4) * 64 + lane;
@@ -741,23 +1085,33 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         RareOut ro;
         const int want = seq + 1;
         int* const fr_flag = L.flag + FL_FRAMES;
-        rare_contacts<HF, 0, RC_NS, true>(P, T, C, RB, lane, el, side, R0, O, ang, vel, ChainKin(), ChainKin(), mu, hmax, ro, racc,
-                                          [=]() { flag_wait(fr_flag, want); }, seq == P.decimation - 1);
+        rare_contacts<HF, 0, SPLIT ? 8 : RC_NS, true>(P, T, C, RB, lane, el, side, R0, O, ang, vel, ChainKin(), ChainKin(), mu, hmax, ro, racc,
+                                                   [=]() { flag_wait(fr_flag, want); }, seq == P.decimation - 1);
         float4* c_ = L.wc + lane;
-        c_[0 * 64] = f4(ro.fa2.x, ro.fa2.y, ro.fa2.z, ro.fl2.x);
-        c_[1 * 64] = f4(ro.fl2.y, ro.fl2.z, 0.f, 0.f);
-        c_[2 * 64] = f4(ro.fa3.x, ro.fa3.y, ro.fa3.z, ro.fl3.x);
-        c_[3 * 64] = f4(ro.fl3.y, ro.fl3.z, 0.f, 0.f);
+        if (!SPLIT) {
+            c_[0 * 64] = f4(ro.fa2.x, ro.fa2.y, ro.fa2.z, ro.fl2.x);
+            c_[1 * 64] = f4(ro.fl2.y, ro.fl2.z, 0.f, 0.f);
+            c_[2 * 64] = f4(ro.fa3.x, ro.fa3.y, ro.fa3.z, ro.fl3.x);
+            c_[3 * 64] = f4(ro.fl3.y, ro.fl3.z, 0.f, 0.f);
+        }
         L.wr[lane] = f4(ro.f0a.x, ro.f0a.y, ro.f0a.z, ro.f0l.x);
         L.wr[64 + lane] = f4(ro.f0l.y, ro.f0l.z, ro.term ? 1.f : 0.f, ro.pen_count);
         flag_set(L.flag + FL_LEGS, seq + 1, lane);   // thigh + shank wrenches and the base-lump wrench, one hand-over
         GRX_EV(12);
         if (seq == P.decimation - 1) {
+#ifdef GRX_PROFILE_SECTIONS
+            if (lane == 0) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 88] = clock64();
+#endif
             // GRX_T_CONTACT_FORCES (net contact force per URDF link after the LAST sub-step, legged_robot.py:117, 266): this wave
             // has the base-lump links' forces; the foot's terrain force comes from wave 2, the self-collision forces from
             // wave 1 -- both handed over for wave 0 anyway.  Written here, off wave 0's path (it is the last to finish).
-            flag_wait(L.flag + FL_FOOT, seq + 1);
-            flag_wait(L.flag + FL_SELF, seq + 1);
+            lp = link_prep(C);   // (table reads: before the forces are in)
+            if (SPLIT) flag_wait_all(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_SELF, seq + 1, FL_CHAINW, seq + 1), lane);
+            else { flag_wait(L.flag + FL_FOOT, seq + 1); flag_wait(L.flag + FL_SELF, seq + 1); }
+            if (SPLIT) {   // the terrain forces on thigh and shank come from wave 7
+                const float4 a0 = c_[0 * 64], a1 = c_[1 * 64], a2 = c_[2 * 64], a3 = c_[3 * 64];
+                ro.fl2 = v3(a0.w, a1.x, a1.y); ro.fl3 = v3(a2.w, a3.x, a3.y);
+            }
             SelfOut sc;
             {
                 const float4* c = L.wc + 7 * 64 + lane;
@@ -770,9 +1124,15 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
             }
             const float4 f0_ = c_[4 * 64], f1_ = c_[5 * 64];
             const V3 foot_terrain = v3(f0_.w, f1_.x, f1_.y);
+#ifdef GRX_PROFILE_SECTIONS
+            if (lane == 0) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 89] = clock64();
+#endif
             bool term; float pen;
-            write_link_rows(P, lfo, C, ro.lf, ro.fl2, ro.fl3, foot_terrain, sc, term, pen);
+            net_link_forces(P, lp, ro.lf, ro.fl2, ro.fl3, foot_terrain, sc, link_rows, term, pen);   // (the caller stores the rows once the block is past its barrier)
             s_tp[lane] = term ? 1.f : 0.f; s_tp[64 + lane] = pen;   // picked up by wave 0 behind the barrier that ends the sub-steps
+#ifdef GRX_PROFILE_SECTIONS
+            if (lane == 0) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 90] = clock64();
+#endif
         }
     }
     GRX_HELPER_PROF_END(3);
