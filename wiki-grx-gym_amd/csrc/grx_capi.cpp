@@ -634,7 +634,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
         const int qblocks = (c.num_envs + grx_envs_per_block_quad() - 1) / grx_envs_per_block_quad();
         s->quad = !generic && s->waves == 4 && qblocks <= prop.multiProcessorCount && !getenv("GRX_WAVES_PER_BLOCK");
         if (const char* q = getenv("GRX_LANES_PER_ENV")) s->quad = !generic && atoi(q) == 4;   // tests / A-B runs: 2 or 4
-        if (s->quad) { s->waves = 4; if (const char* w = getenv("GRX_QUAD_WAVES")) s->waves = atoi(w) == 8 ? 8 : 4; }
+        if (s->quad) { s->waves = 8; if (const char* w = getenv("GRX_QUAD_WAVES")) s->waves = atoi(w) == 4 ? 4 : 8; }   // eight waves (two per SIMD) unless a test asks for the four-role pipeline
     }
     const char* dbg = getenv("GRX_PUBLISH_DEBUG");   // (tools/: overrides the config either way)
     P.publish_debug = dbg ? atoi(dbg) : c.publish_reward_terms;

@@ -1187,7 +1187,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     __shared__ int s_flag[FL_COUNT];
     const PipeLds L = {s_base, s_q, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag, s_xk, s_fx};
     const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef GRX_W8_ROLES
+#define GRX_W8_ROLES 0x76543210u   // role of hardware wave i in nibble i (waves i and i + 4 share a SIMD: pair a busy role with a light one)
+#endif
+    const int wv_hw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = W == 8 ? (int)((GRX_W8_ROLES >> (4 * wv_hw)) & 7u) : wv_hw;   // (W == 8: `wv` is the wave's ROLE from here on)
     const RareBuf RB = rare_carve(s_arena + (W == 2 && wv == 1 ? RC_BYTES : 0));   // PIPE: only wave 3 evaluates rare contacts
     {   // stage the per-side robot tables (joint tree, inertias, gains, spheres) into LDS
         const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables);
@@ -1198,7 +1202,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     }
     __syncthreads();
     // the previous launch's episode statistics (and its ticket): on the wave that starts its sub-steps by waiting anyway
-    if (wv == W - 1) stats_fold_previous(P, sq, tid & 63);
+    if (wv == (W == 8 ? 3 : W - 1)) stats_fold_previous(P, sq, tid & 63);
     const int N = P.N;
     const int lane = tid & 63, el = lane_env(lane), side = lane_side(lane), half = lane_half(lane);
     const int e_raw = blockIdx.x * EPB + el;

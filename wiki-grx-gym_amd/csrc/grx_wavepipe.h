@@ -452,8 +452,8 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
         if (W8 && k < LEG - 2) {
-            if (GRX_W8_WAITALL) { if (k == LEG - 3) GRX_WAIT(L.flag + FL_XK, seq * 4 + 3, 4); }
-            else GRX_WAIT(L.flag + FL_XK, seq * 4 + (LEG - 2 - k), 4);
+            if (k == LEG - 3) GRX_WAIT(L.flag + FL_XK, seq * 4 + 2, 4);   // bodies 2 and 1 come together,
+            if (k == 0) GRX_WAIT(L.flag + FL_XK, seq * 4 + 3, 4);         // body 0 a little later
             // (wave 5 computes body 2 on the lo half of the leg, body 1 on the hi half, body 0 on both)
             const float4* c = L.xk + (k * 3) * 64 + (k == 0 ? lane : (k == 2 ? lane - lane_half(lane) : lane - lane_half(lane) + 1));
             const float4 a0 = c[0 * 64], a1 = c[1 * 64], a2 = c[2 * 64];
@@ -920,6 +920,7 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
                 o[0 * 64] = f4(Ak.xx, Ak.xy, Ak.xz, Ak.yy);
                 o[1 * 64] = f4(Ak.yz, Ak.zz, h_.x, h_.y);
                 o[2 * 64] = f4(h_.z, 0.f, 0.f, 0.f);
+                flag_set(L.flag + FL_XK, seq * 4 + 2, lane);
             }
             {
                 const S3 Ic = {C.body[0].Ic[0], C.body[0].Ic[1], C.body[0].Ic[2], C.body[0].Ic[3], C.body[0].Ic[4], C.body[0].Ic[5]};
