@@ -815,15 +815,15 @@ GRX_DEV float height_sample(KP P, const KTables& T, float zn, float wn, V3 pos, 
 
 // One lane's share of the height scan: points k = first, first + LPE*NW, ... (NW waves x LPE lanes per env); raw heights
 // parked in the env's pri_obs staging row; returns the lane's partial sum.  Batches of 8 independent gathers.
-template <int NW>
+template <int NW, int B = 8>   // B: gathers per batch (the reference's 121 points over 7 x 4 lanes: 5 per lane)
 GRX_DEV float height_scan_share(KP P, const KTables& T, float zn, float wn, V3 pos, int first, int nh, float* prow) {
     float hsum = 0.f;
-    for (int k0 = first; k0 < nh; k0 += 8 * LPE * NW) {
-        float hb[8];
+    for (int k0 = first; k0 < nh; k0 += B * LPE * NW) {
+        float hb[B];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hb[j] = height_sample(P, T, zn, wn, pos, min(k0 + LPE * NW * j, nh - 1));
+        for (int j = 0; j < B; ++j) hb[j] = height_sample(P, T, zn, wn, pos, min(k0 + LPE * NW * j, nh - 1));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < B; ++j) {
             const int k = k0 + LPE * NW * j;
             if (k < nh) { prow[GRX_NUM_OBS + 8 + k] = hb[j]; hsum += hb[j]; }
         }
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     __shared__ __attribute__((aligned(16))) char s_self[PIPE ? SELF_BYTES : 16];   // self-collision staging of wave 2 (grx_self.h)
     __shared__ float s_rwp[PIPE ? 64 : 1];               // partial reward (wave 3 -> wave 1)
     __shared__ float s_hp[PIPE ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
-    __shared__ float s_hsum[PIPE ? 4 * 64 : 1];          // height scan: partial sums per wave
+    __shared__ float s_hsum[PIPE ? W * 64 : 1];          // height scan: partial sums per wave
     __shared__ float s_tp[PIPE ? 2 * 64 : 1];            // termination flag / collision count from the NET link forces of the last sub-step (wave 3 -> wave 0)
     __shared__ float4 s_xk[W == 8 ? 9 * 64 : 1];           // W == 8: rigid inertias of chain bodies 2, 1, 0 (wave 6 -> wave 0)
     __shared__ float4 s_fx[W == 8 ? 8 * 64 : 1];           // W == 8: base-level 6 x 6 (wave 0 -> wave 5) and its factorisation (wave 5 -> wave 0)
@@ -1216,6 +1216,15 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     const float dtp = P.sim_dt * (float)P.decimation;
     const int j0 = side * LEG;
 
+#ifndef GRX_W8_PRIO
+#define GRX_W8_PRIO 0u
+#endif
+    if (W == 8 && GRX_W8_PRIO) {   // two waves per SIMD: the state owner and the base-service wave sit on the sub-step's critical chain
+        const int pr = (int)((GRX_W8_PRIO >> (4 * wv)) & 3u);   // (priority of role i in nibble i)
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
     if (W >= 2 && wv != 0) {
         // ---- helper waves
         const float mu = 0.5f * (P.terrain_friction + P.friction[e]);
@@ -1286,9 +1295,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 RB7.fchain = RB.fchain;   // (where wave 2 publishes the thigh / shank frames)
                 chain_rare_loop<HF>(P, s_tab, GRX_HC(7), RB7, mu, hmax, L, lane, el, side);
             } else if (wv == 4) {
-                chain_bias_loop<3, 4>(P, GRX_HC(4), L, lane, el);
+                chain_bias_loop<3, 4>(P, GRX_HC(4), C, L, lane, el);
             } else if (wv == 6) {
-                chain_bias_loop<0, 2>(P, GRX_HC(6), L, lane, el);
+                chain_bias_loop<0, 2>(P, GRX_HC(6), C, L, lane, el);
             } else if (wv == 5) {
                 base_service_loop(P, GRX_HC(5), C, bm, bc, bI, L, lane, el);
             }
@@ -1304,7 +1313,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
             }
             if (HF && P.measure_heights) {   // this wave's quarter of the height scan (legged_robot.py:1235-1274)
                 const float* hp = s_hp + el;
-                if (wv < 4) s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
+                // (eight waves: seven shares -- wave 3, the last to finish its sub-steps, has the link rows to store instead)
+                if (W == 8) { if (wv != 3) s_hsum[wv * 64 + lane] = height_scan_share<7, 5>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
+                                                                                          LPE * (wv < 3 ? wv : wv - 1) + (lane & (LPE - 1)), nh, s_pri + el * PRS); }
+                else s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
                                                               LPE * wv + (lane & (LPE - 1)), nh, s_pri + el * PRS);
                 lds_barrier();   // height scan complete (raw heights and partial sums are in LDS: this wave's row stores of the last sub-step stay in flight)
             }
@@ -1334,7 +1346,15 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 reward_and_sums<1>(P, C, rin, lane, side, e, N, act, s_stat, es_w1, s_rwp, s_flag + FL_RWB);
                 GRX_TICKW(15);
             }
-            if (wv < 4) {   // the observation height block, once wave 0 has published the (post-reset) base height: wave 2 takes
+            if (W == 8) {   // eight waves: the observation height block on the four waves that have no reward terms, a quarter each
+                if (wv >= 4) {
+                    flag_wait(s_flag + FL_HZ, 1);
+                    const bool have_raw = HF && P.measure_heights;
+                    const float part = obs_heights_share<4 * LPE>(P, s_hp[el], (wv - 4) * LPE + (lane & (LPE - 1)), nh, s_pri + el * PRS, have_raw, act, e, N);
+                    s_hsum[wv * 64 + lane] = env_sum(part);
+                    flag_set(s_flag + (wv == 7 ? FL_BHO4 : FL_BHO1 + (wv - 4)), 1, lane);
+                }
+            } else if (wv < 4) {   // the observation height block, once wave 0 has published the (post-reset) base height: wave 2 takes
                 // the points k = 0, 1 (mod 4), waves 1 and 3 (busy with the rewards until now) k = 2, 3 and 6, 7 (mod 8)
                 flag_wait(s_flag + FL_HZ, 1);
                 if (wv == 2) GRX_TICKW(30);
@@ -1564,9 +1584,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     float hsum = 0.f;
     if (HF && P.measure_heights) {
         if (PIPE) {   // quarter of the scan here, the other three quarters on the helper waves
-            hsum = height_scan_share<4>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
+            hsum = W == 8 ? height_scan_share<7, 5>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow)
+                          : height_scan_share<4>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
             lds_barrier();   // height scan complete
-            hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane];
+            if (W == 8) hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + ((s_hsum[4 * 64 + lane] + s_hsum[5 * 64 + lane]) + (s_hsum[6 * 64 + lane] + s_hsum[7 * 64 + lane]));
+            else hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane];
         } else hsum = height_scan_share<1>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
         hsum = env_sum(hsum);
     }
@@ -1754,10 +1776,15 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         P.term_contact[e] = term_contact ? 1 : 0;
     }
     if (PIPE) {   // base_heights_offset: the helper waves' partial sums of the observation height block
+        if (W == 8) {
+            flag_wait_all(s_flag, flag_want(lane, FL_BHO1, 1, FL_BHO1 + 1, 1, FL_BHO1 + 2, 1, FL_BHO4, 1), lane);
+            bho = nh > 0 ? ((s_hsum[4 * 64 + lane] + s_hsum[5 * 64 + lane]) + (s_hsum[6 * 64 + lane] + s_hsum[7 * 64 + lane])) / (float)nh : 0.f;
+        } else {
         flag_wait(s_flag + FL_BHO1, 1);
         flag_wait(s_flag + FL_BHO1 + 1, 1);
         flag_wait(s_flag + FL_BHO1 + 2, 1);
         bho = nh > 0 ? (s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane]) / (float)nh : 0.f;
+        }
         if (side == 0) prow[GRX_NUM_OBS + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
         if (writer) P.base_heights_offset[e] = bho;
     }

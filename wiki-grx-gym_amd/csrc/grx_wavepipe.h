@@ -66,7 +66,8 @@
 enum { FL_STATE = 0, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_BIAS2 = 7 /* bias forces of bodies 2..0 when wave 1 computes them (heightfield) */, FL_SELF = 9, FL_REW = 6, FL_BASEBIAS = 8, FL_HZ = 10, FL_BHO1 = 11 /* ..13: waves 1..3 */, FL_RWB = 14, FL_RR = 15,
        FL_FACT = 16 /* W == 8: the base-level 6 x 6 is out (wave 0 -> wave 5) */, FL_FACTOUT = 17 /* ... and factorised */,
        FL_XK = 18 /* W == 8: rigid inertias of thigh, hip yaw, hip roll (wave 6 -> wave 0), seq * 4 + bodies out */,
-       FL_CHAINW = 19 /* W == 8: thigh + shank terrain wrenches (wave 7) */, FL_COUNT = 20 };
+       FL_CHAINW = 19 /* W == 8: thigh + shank terrain wrenches (wave 7) */, FL_BHO4 = 20 /* W == 8: fourth share of the observation height block */,
+       FL_COUNT = 21 };
 // Every record is laid out [quad][lane] in float4 units, so a lane moves it with ds_read_b128 / ds_write_b128: the
 // kernel runs at one instruction issue per ~5 cycles whatever the instruction, and the records are ~350 dwords per
 // lane and sub-step on wave 0 alone -- four dwords per LDS instruction instead of one is ~1.3k cycles per sub-step.
@@ -83,7 +84,7 @@ struct PipeLds {
     float4* wr;    // [2][64]     base-lump wrench, termination flag, collision count
     int* flag;     // [FL_COUNT]
     float4* xk;    // [3][3][64]  W == 8: rigid inertia about O of chain body k = 2, 1, 0 (wave 6 -> wave 0): A 6, h = m kap 3
-    float4* fx;    // [8][64]     W == 8: quads 0-3 the base-level X, Y of both legs (wave 0 -> wave 5), 4-7 M = Sc^-1 Y Xo^-1 and Sc^-1 (wave 5 -> wave 0)
+    float4* fx;    // [8][64]     W == 8: quads 0-3 the base-level X, Y of both legs (wave 0 -> wave 5), 4-7 T = Y Xo^-1 and Sc^-1 (wave 5 -> wave 0)
 };
 GRX_DEV float4 f4(float a, float b, float c, float d) { float4 r; r.x = a; r.y = b; r.z = c; r.w = d; return r; }
 
@@ -403,6 +404,7 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
             const V3 a = axis_k(R, kAxis[k]);
             const V3 s_ = cross(rho, a);
             So[k] = sel3(hi, s_, a); St[k] = sel3(hi, a, s_);
+
             if (!W8) {   // (eight waves: the c_k are folded into the bias forces, chain_bias_loop)
                 const V3 ca = cross(w, a) * qdk;
                 const V3 cl = (cross(v, a) + cross(w, s_)) * qdk;
@@ -528,7 +530,10 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     }
     float4 bq0[LEG], bq1[LEG];
 #pragma unroll
-    for (int k = 0; k < LEG; ++k) { const float4* b_ = L.pb + (k * PB4) * 64 + lane; bq0[k] = b_[0 * 64]; bq1[k] = b_[1 * 64]; }
+    for (int k = 0; k < LEG; ++k) {   // (eight waves: bodies 4, 2 were computed on the lo half of the leg, 3, 1 on the hi half, 0 on both)
+        const int slot = !W8 || k == 0 ? lane : lane - lane_half(lane) + (k & 1);
+        const float4* b_ = L.pb + (k * PB4) * 64 + slot; bq0[k] = b_[0 * 64]; bq1[k] = b_[1 * 64];
+    }
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
         const float4 b0_ = bq0[k], b1_ = bq1[k];
@@ -594,12 +599,12 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     }
     // lo: alpha = Sa^-1 (B D^-1 p_l - p_a);  hi: acc = Sd^-1 (B^T A^-1 p_a - p_l)
     V3 xo;
-    if (W8) {   // x = M p_other - Sc^-1 p_own with M = Sc^-1 Y Xo^-1 from wave 5
+    if (W8) {   // x = Sc^-1 (T p_other - p_own) with T = Y Xo^-1 and Sc^-1 from wave 5
         const float4* c = L.fx + 4 * 64 + lane;
         const float4 m0 = c[0 * 64], m1 = c[1 * 64], m2 = c[2 * 64], m3 = c[3 * 64];
         const V3 pt = half_swap(po);
         const S3 Si = {m2.y, m2.z, m2.w, m3.x, m3.y, m3.z};
-        xo = v3(m0.x * pt.x + m0.y * pt.y + m0.z * pt.z, m0.w * pt.x + m1.x * pt.y + m1.y * pt.z, m1.z * pt.x + m1.w * pt.y + m2.x * pt.z) - mul(Si, po);
+        xo = mul(Si, v3(m0.x * pt.x + m0.y * pt.y + m0.z * pt.z, m0.w * pt.x + m1.x * pt.y + m1.y * pt.z, m1.z * pt.x + m1.w * pt.y + m2.x * pt.z) - po);
     } else {
         xo = mul(Sci, mul(Y, mul(Xio, half_swap(po))) - po);
     }
@@ -786,12 +791,14 @@ GRX_DEV void rigid_bias_z(const R3& R, V3 kap, float m, const S3& Ic, V3 w, V3 v
     pl = cross(w, l) + (zl + cross(za, kap)) * m;
     pa = rot(R, nb) + cross(kap, pl);
 }
+// The two lanes of a leg compute DIFFERENT bodies in one pass (lo half: body KHI, hi half: body KHI - 1 -- same instructions, selected
+// inputs; the table constants come from LDS with a lane-dependent index), a body left over (KLO, three bodies) on both halves: wave 0
+// reads the record of body k from the slot of the lane that wrote it.
 template <int KLO, int KHI>
-GRX_DEV void chain_bias_loop(KP P, const SideConst& C, const PipeLds& L, int lane, int el) {
+GRX_DEV void chain_bias_loop(KP P, const SideConst& C, const SideConst& Clds, const PipeLds& L, int lane, int el) {
     constexpr int NB = KHI - KLO + 1;
-    float lim_lo[NB], lim_hi[NB], lim_k[NB], lim_c[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) { lim_lo[k] = C.body[KLO + k].qlo; lim_hi[k] = C.body[KLO + k].qhi; lim_k[k] = C.body[KLO + k].Klim; lim_c[k] = C.body[KLO + k].Clim; }
+    static_assert(NB == 2 || NB == 3, "a pair of bodies, or a pair and a single one");
+    const bool hi = lane_half(lane) != 0;
     for (int seq = 0; seq < P.decimation; ++seq) {
         flag_wait(L.flag + FL_STATE, seq + 1);
         const float* b = L.base + el;
@@ -807,36 +814,28 @@ GRX_DEV void chain_bias_loop(KP P, const SideConst& C, const PipeLds& L, int lan
         ChainKinZ ZZ[NB];
 #pragma unroll
         for (int k = 0; k <= KHI; ++k) { chain_step_z(C, k, qs_q[k], qs_qd[k], Z); if (k >= KLO) ZZ[k - KLO] = Z; }
-        V3 kaps[NB];
-#pragma unroll
-        for (int k = KHI; k >= KLO; --k) {
-            const ChainKinZ& B = ZZ[k - KLO];
-            kaps[k - KLO] = B.K.rho + rot(B.K.R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
-            if (false) {   // (the rigid inertias of bodies 2, 1, 0 were computed here before wave 5 took them over)
-                const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
-                S3 Ak; V3 h_;
-                rigid_inertia(B.K.R, kaps[k - KLO], C.body[k].mass, Ic, Ak, h_);
-                float4* o = L.xk + (k * 3) * 64 + lane;
-                o[0 * 64] = f4(Ak.xx, Ak.xy, Ak.xz, Ak.yy);
-                o[1 * 64] = f4(Ak.yz, Ak.zz, h_.x, h_.y);
-                o[2 * 64] = f4(h_.z, 0.f, 0.f, 0.f);
-                flag_set(L.flag + FL_XK, seq * 4 + (KHI - k + 1), lane);
-            }
-        }
-#pragma unroll
-        for (int k = KHI; k >= KLO; --k) {
-            const ChainKinZ& B = ZZ[k - KLO];
-            const V3 kap = kaps[k - KLO];
-            const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
+        auto bias_out = [&](const ChainKinZ& B, const int kb, const float q, const float qd) {   // kb may differ between the halves
+            const BodyC& T_ = Clds.body[kb];
+            const V3 kap = B.K.rho + rot(B.K.R, v3(T_.com[0], T_.com[1], T_.com[2]));
+            const S3 Ic = {T_.Ic[0], T_.Ic[1], T_.Ic[2], T_.Ic[3], T_.Ic[4], T_.Ic[5]};
             V3 pa, pl;
-            rigid_bias_z(B.K.R, kap, C.body[k].mass, Ic, B.K.w, B.K.v, B.za, B.zl, pa, pl);
-            const int i = k - KLO;
-            const float viol = qs_q[k] < lim_lo[i] ? lim_lo[i] - qs_q[k] : (qs_q[k] > lim_hi[i] ? lim_hi[i] - qs_q[k] : 0.f);
-            const float tlim = lim_k[i] * viol - (viol != 0.f ? lim_c[i] * qs_qd[k] : 0.f);
-            float4* o = L.pb + (k * PB4) * 64 + lane;
+            rigid_bias_z(B.K.R, kap, T_.mass, Ic, B.K.w, B.K.v, B.za, B.zl, pa, pl);
+            const float lo_ = T_.qlo, hi_ = T_.qhi;
+            const float viol = q < lo_ ? lo_ - q : (q > hi_ ? hi_ - q : 0.f);
+            const float tlim = T_.Klim * viol - (viol != 0.f ? T_.Clim * qd : 0.f);
+            float4* o = L.pb + (kb * PB4) * 64 + lane;
             o[0 * 64] = f4(pa.x, pa.y, pa.z, pl.x);
             o[1 * 64] = f4(pl.y, pl.z, tlim, 0.f);
+        };
+        {   // bodies KHI (lo half) and KHI - 1 (hi half)
+            const ChainKinZ &A = ZZ[NB - 1], &Bq = ZZ[NB - 2];
+            ChainKinZ S_;
+            S_.K.R.cx = sel3(hi, Bq.K.R.cx, A.K.R.cx); S_.K.R.cy = sel3(hi, Bq.K.R.cy, A.K.R.cy); S_.K.R.cz = sel3(hi, Bq.K.R.cz, A.K.R.cz);
+            S_.K.rho = sel3(hi, Bq.K.rho, A.K.rho); S_.K.w = sel3(hi, Bq.K.w, A.K.w); S_.K.v = sel3(hi, Bq.K.v, A.K.v);
+            S_.za = sel3(hi, Bq.za, A.za); S_.zl = sel3(hi, Bq.zl, A.zl);
+            bias_out(S_, hi ? KHI - 1 : KHI, hi ? qs_q[KHI - 1] : qs_q[KHI], hi ? qs_qd[KHI - 1] : qs_qd[KHI]);
         }
+        if (NB == 3) bias_out(ZZ[0], KLO, qs_q[KLO], qs_qd[KLO]);
         if (KHI == LEG - 1) { flag_set(L.flag + FL_BIAS, seq * 8 + 2, lane); GRX_EV(26); }
         else { flag_set(L.flag + FL_BIAS2, seq + 1, lane); GRX_EV(28); }
     }
@@ -854,6 +853,7 @@ GRX_DEV void chain_rare_loop(KP P, const KTables& T, const SideConst& C, const R
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
         const V3 zero = v3(0.f, 0.f, 0.f);
         // own positions-only walk to thigh and shank: the reach tests start ~0.6 k cycles before wave 2's frames (with velocities) are out
+        // (taking R, rho from wave 0's walk instead was tried: the 15 record stores and two hand-overs cost wave 0 0.7 k cycles per sub-step)
         ChainKin K3 = {R0, zero, zero, zero}, K2 = K3;
         {
             const float4 q0_ = L.q[lane];
@@ -884,7 +884,7 @@ GRX_DEV void chain_rare_loop(KP P, const KTables& T, const SideConst& C, const R
 
 // wave 5: everything at the floating base that is not on wave 0's chain -- the base lump's bias force and rigid inertia, and the
 // factorisation of the base-level 6 x 6 (substep_q's dual Schur forms) from the X, Y wave 0 hands over after its inertia half.
-// Returns M = Sc^-1 Y Xo^-1 and Sc^-1: wave 0's solve is then x = M p_other - Sc^-1 p_own.
+// Returns T = Y Xo^-1 and Sc^-1: wave 0's solve is then x = Sc^-1 (T p_other - p_own).
 GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, float base_m, V3 base_c, const S3& base_I, const PipeLds& L, int lane, int el) {
     const bool hi = lane_half(lane) != 0;
     const float sg = hi ? -1.f : 1.f;
@@ -965,12 +965,11 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
         const V3 y0 = row0(Y), y1 = row1(Y), y2 = row2(Y);
         const V3 t0 = mul(Xio, y0), t1 = mul(Xio, y1), t2 = mul(Xio, y2);   // rows of Y Xo^-1
         const S3 Sc = {X.xx - dot(y0, t0), X.xy - dot(y0, t1), X.xz - dot(y0, t2), X.yy - dot(y1, t1), X.yz - dot(y1, t2), X.zz - dot(y2, t2)};
+        float4* o = L.fx + 4 * 64 + lane;   // (T = Y Xo^-1 goes out while Sc is being inverted: the product Sc^-1 T would sit on the chain)
+        o[0 * 64] = f4(t0.x, t0.y, t0.z, t1.x);
+        o[1 * 64] = f4(t1.y, t1.z, t2.x, t2.y);
         const S3 Si = inv(Sc);
-        const V3 m0 = t0 * Si.xx + t1 * Si.xy + t2 * Si.xz, m1 = t0 * Si.xy + t1 * Si.yy + t2 * Si.yz, m2 = t0 * Si.xz + t1 * Si.yz + t2 * Si.zz;
-        float4* o = L.fx + 4 * 64 + lane;
-        o[0 * 64] = f4(m0.x, m0.y, m0.z, m1.x);
-        o[1 * 64] = f4(m1.y, m1.z, m2.x, m2.y);
-        o[2 * 64] = f4(m2.z, Si.xx, Si.xy, Si.xz);
+        o[2 * 64] = f4(t2.z, Si.xx, Si.xy, Si.xz);
         o[3 * 64] = f4(Si.yy, Si.yz, Si.zz, 0.f);
         flag_set(L.flag + FL_FACTOUT, seq + 1, lane);
         GRX_EV(29);
