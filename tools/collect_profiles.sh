@@ -25,7 +25,10 @@ for i in 2 3; do timeout 300 python bench.py --no-cpu-baseline 2>> $out/bench_ro
 timeout 300 python bench.py --terrain flat --no-cpu-baseline 2> $out/bench_flat.err | tail -1 > $out/bench_flat.json
 # the layouts side by side at the headline size, and the surcharge of GRX_T_RIGID_BODY_STATES (off in the headline)
 : > $out/layouts.jsonl
-for l in 2 4; do GRX_LANES_PER_ENV=$l timeout 300 python bench.py --no-cpu-baseline --steps 8000 --warmup 800 2>/dev/null | tail -1 >> $out/layouts.jsonl; done
+# (lane pair per env, four waves; lane quad, four waves; lane quad, eight waves = the default at this size)
+GRX_LANES_PER_ENV=2 timeout 300 python bench.py --no-cpu-baseline --steps 8000 --warmup 800 2>/dev/null | tail -1 >> $out/layouts.jsonl
+GRX_LANES_PER_ENV=4 GRX_QUAD_WAVES=4 timeout 300 python bench.py --no-cpu-baseline --steps 8000 --warmup 800 2>/dev/null | tail -1 >> $out/layouts.jsonl
+timeout 300 python bench.py --no-cpu-baseline --steps 8000 --warmup 800 2>/dev/null | tail -1 >> $out/layouts.jsonl
 GRX_BENCH_RBS=1 timeout 300 python bench.py --no-cpu-baseline --steps 8000 --warmup 800 2>/dev/null | tail -1 >> $out/layouts.jsonl
 : > $out/sweep.jsonl
 for n in 8192 16384 32768 65536 131072; do

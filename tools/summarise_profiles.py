@@ -28,7 +28,7 @@ out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                "WRITE_SIZE is uncalibrated.")
 json.dump(out, open(f"{dst}/{tag}_pmc_hbm_rough4096.json", "w"), indent=1)
 # SQ passes -> one JSON (mean per launch of grx_step_kernel)
-sq = {"kernel": "grx_step_kernel_quad<true, 4> (the headline layout at 4096 envs)", "workload": "python bench.py --steps 300 --warmup 50 --no-cpu-baseline (rough, 4096 envs); rocprofv3 --pmc, "
+sq = {"kernel": "grx_step_kernel_quad<true, 8> (the headline layout at 4096 envs: eight waves per 16-env block)", "workload": "python bench.py --steps 300 --warmup 50 --no-cpu-baseline (rough, 4096 envs); rocprofv3 --pmc, "
       "one pass per counter group (tools/collect_profiles.sh), mean per launch"}
 for f in sorted(glob.glob(f"{src}/pmc_sq*/**/*counter_collection.csv", recursive=True)):
     agg = {}
