@@ -1073,6 +1073,12 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
         const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+#ifndef GRX_W8_LATE3
+#define GRX_W8_LATE3 1
+#endif
+        // eight waves: this role's output is needed last and takes 1.6 k cycles, and the first ~2 k cycles of a sub-step are the ones in
+        // which all eight waves want to issue: it starts once the rigid inertias (the first hand-over on wave 0's chain) are out
+        if (W8 && GRX_W8_LATE3) flag_wait(L.flag + FL_XK, seq * 4 + 2);
         if (!W8) {   // the base lump's rigid-body bias force (cheap; needed by wave 0 only at the base solve)
             V3 bpa, bpl;
             rigid_bias(R0, rot(R0, base_c), base_m, base_I, ang, vel, bpa, bpl);
