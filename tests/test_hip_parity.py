@@ -33,7 +33,7 @@ PHYS = {  # name: (atol, rtol, allowed fraction outside)
 
 
 def set_layout(monkeypatch, layout):
-    """Step-kernel layout for handles created from here on: 1 / 2 / 4 waves per 32-env block (a lane pair per env), or "quad" /
+    """Step-kernel layout for handles created from here on: 1 / 2 / 4 / 8 waves per 32-env block (a lane pair per env), or "quad" /
     "quad4": eight / four waves per 16-env block with a lane QUAD per env (grx_quad.hip; "quad" is picked by itself while 16-env
     blocks fit the CUs)."""
     if layout in ("quad", "quad4"):
@@ -353,7 +353,7 @@ def test_full_size_properties(task, terrain, N, monkeypatch):
     assert (full["RESET"].sum() > 0 or task == "GR1T1Full") and (full["PRI_OBS"][:, -121:].abs().sum() > 0)
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4, "quad4", "quad"])
+@pytest.mark.parametrize("waves", [1, 2, 4, 8, "quad4", "quad"])
 def test_every_wave_layout_matches_the_oracle(waves, monkeypatch):
     """The launch layouts of the step kernel (1, 2, 4 waves per 32-env block: single wave / contact helper wave / four-wave
     producer-consumer pipeline; "quad": that pipeline with a lane quad per env, 16 envs per block) run the same physics:
@@ -373,7 +373,7 @@ def test_every_wave_layout_matches_the_oracle(waves, monkeypatch):
     hip.close()
 
 
-@pytest.mark.parametrize("layout", [4, "quad4", "quad"])
+@pytest.mark.parametrize("layout", [4, 8, "quad4", "quad"])
 def test_tail_block_and_small_batches(layout, monkeypatch):
     """num_envs not a multiple of the 32- / 16-env block: tail lanes must not corrupt neighbours."""
     set_layout(monkeypatch, layout)
@@ -403,7 +403,7 @@ def test_set_state_and_api_errors():
         hip.step(torch.zeros(10, 64).cuda().t(), 5.0, 1)           # non-contiguous (gymtorch.py:98-99)
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4, "quad4", "quad"])
+@pytest.mark.parametrize("waves", [1, 2, 4, 8, "quad4", "quad"])
 @pytest.mark.parametrize("task", ["GR1T1", "GR1T2"])
 def test_self_collision_matches_the_oracle(task, waves, monkeypatch):
     """self_collisions = 0 = enabled (legged_robot_config.py:121): robots in flight with their legs driven into each
@@ -513,7 +513,7 @@ def test_action_latency_real_valued(delay):
         assert torch.equal(hip.tensor("DOF_POS"), q_delay)
 
 
-@pytest.mark.parametrize("waves", [1, 2, 4, "quad4", "quad"])
+@pytest.mark.parametrize("waves", [1, 2, 4, 8, "quad4", "quad"])
 def test_self_collision_on_a_terminating_link_resets_the_env(waves, monkeypatch):
     """GR1T2's thigh can press on the hand (self-collision pairs 4-25, 10-33; hand links are in
     terminate_after_contacts_on).  check_termination reads the NET contact force per link (legged_robot.py:336-353), so a
@@ -553,7 +553,7 @@ def test_self_collision_on_a_terminating_link_resets_the_env(waves, monkeypatch)
     assert torch.equal(implied[clear], hip.tensor("TERM_CONTACT").cpu()[clear].bool())
 
 
-@pytest.mark.parametrize("waves", [1, 4, "quad4", "quad"])
+@pytest.mark.parametrize("waves", [1, 4, 8, "quad4", "quad"])
 @pytest.mark.parametrize("task", ["GR1T1", "GR1T2"])
 def test_rigid_body_states_match_the_oracle(task, waves, monkeypatch):
     """GRX_T_RIGID_BODY_STATES (gym.acquire_rigid_body_state_tensor, legged_robot.py:113,134): all link frames after the last

@@ -627,7 +627,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
         s->waves = nblocks * 4 <= 2 * simds ? 4 : 1;
         if (const char* w = getenv("GRX_WAVES_PER_BLOCK")) {
             const int v = atoi(w);
-            if (v == 1 || v == 2 || v == 4) s->waves = v;
+            if (v == 1 || v == 2 || v == 4 || v == 8) s->waves = v;
         }
         // a lane QUAD per env, 16 envs per block: one block per CU needs all of the CU (four SIMDs' registers, 100+ KB of LDS),
         // so this layout pays exactly while its blocks fit the device in ONE round -- half the CUs would otherwise idle

@@ -1148,7 +1148,6 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     KP P = GRX_PARAMS(Pg);
     constexpr int NTHR = 64 * W;
     constexpr bool PIPE = W >= 4;   // the producer/consumer pipeline of grx_wavepipe.h: four roles, or (W == 8, lane quads only) eight
-    static_assert(W != 8 || LPL == 2, "the eight-wave pipeline exists for the lane-quad layout only");
     __shared__ KTables s_tab;
     // One LDS arena, used twice: during the sub-steps it holds the lane-compaction buffers of the rare contacts
     // (grx_rare.h: candidate list, result table, frames); after the decimation loop's barrier the same bytes are the
@@ -1183,9 +1182,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     __shared__ float s_hsum[PIPE ? W * 64 : 1];          // height scan: partial sums per wave
     __shared__ float s_tp[PIPE ? 2 * 64 : 1];            // termination flag / collision count from the NET link forces of the last sub-step (wave 3 -> wave 0)
     __shared__ float4 s_xk[W == 8 ? 9 * 64 : 1];           // W == 8: rigid inertias of chain bodies 2, 1, 0 (wave 6 -> wave 0)
-    __shared__ float4 s_fx[W == 8 ? 8 * 64 : 1];           // W == 8: base-level 6 x 6 (wave 0 -> wave 5) and its factorisation (wave 5 -> wave 0)
+    __shared__ float4 s_sb[W == 8 ? 5 * 64 : 1];           // W == 8: thigh x base-lump self-collision (wave 3 -> wave 0)
+    __shared__ float4 s_fx[W == 8 && LPL == 2 ? 8 * 64 : 1];           // W == 8: base-level 6 x 6 (wave 0 -> wave 5) and its factorisation (wave 5 -> wave 0)
     __shared__ int s_flag[FL_COUNT];
-    const PipeLds L = {s_base, s_q, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag, s_xk, s_fx};
+    const PipeLds L = {s_base, s_q, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag, s_xk, s_sb, s_fx};
     const int tid = threadIdx.x;
 #ifndef GRX_W8_ROLES
 #define GRX_W8_ROLES 0x76543210u   // role of hardware wave i in nibble i (waves i and i + 4 share a SIMD: pair a busy role with a light one)
@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
 #define GRX_HELPER_C C
 #endif
 #ifndef GRX_W8_REGC
-#define GRX_W8_REGC 0x76   // eight waves (256 registers each): the waves whose constants live in registers (bit per wave; measured: waves 3, 7 only spill)
+#define GRX_W8_REGC (LPL == 2 ? 0x7E : 0x76)   // eight waves (256 registers each): the waves whose constants live in registers (bit per wave; measured per layout)
 #endif
 #define GRX_HC(w) ((W == 8 && !((GRX_W8_REGC >> (w)) & 1)) ? C : GRX_HELPER_C)
             const float bm = P.base_m[e];
@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                     a_[8 * 64] = __uint_as_float(LPL == 1 ? mine : (mine | __float_as_uint(half_swap(__uint_as_float(mine)))));
                 }
             } else if (wv == 3) {
-                base_contact_loop<HF, W == 8>(P, s_tab, GRX_HC(3), RB, mu, hmax, bm, bc, bI, L, lane, el, side, s_tp, w3_lp, w3_rows);
+                base_contact_loop<HF, W == 8>(P, s_tab, GRX_HC(3), RB, mu, hmax, bm, bc, bI, L, lane, el, side, s_tp, w3_lp, w3_rows, s_footfr, P.friction[e]);
             } else if (wv == 7) {
                 RareBuf RB7 = rare_carve(s_arena + RC_BYTES);
                 RB7.fchain = RB.fchain;   // (where wave 2 publishes the thigh / shank frames)
@@ -1314,7 +1314,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
             if (HF && P.measure_heights) {   // this wave's quarter of the height scan (legged_robot.py:1235-1274)
                 const float* hp = s_hp + el;
                 // (eight waves: seven shares -- wave 3, the last to finish its sub-steps, has the link rows to store instead)
-                if (W == 8) { if (wv != 3) s_hsum[wv * 64 + lane] = height_scan_share<7, 5>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
+                if (W == 8) { if (wv != 3) s_hsum[wv * 64 + lane] = height_scan_share<7, (LPE == 4 ? 5 : 9)>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
                                                                                           LPE * (wv < 3 ? wv : wv - 1) + (lane & (LPE - 1)), nh, s_pri + el * PRS); }
                 else s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
                                                               LPE * wv + (lane & (LPE - 1)), nh, s_pri + el * PRS);
@@ -1497,7 +1497,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
         if (PIPE && LPL == 2) substep_q<HF, W == 8>(P, Cr, LC, st, torque, so, fk, L, lane, deci, tacc, C);
-        else if (PIPE) substep_p<HF>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc, C);
+        else if (PIPE) substep_p<HF, W == 8>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc, C);
         else substep<HF, W>(P, s_tab, C, LC, st, torque, so, fk, s_wr + lane, tacc,
                             LinkForceOut{deci == P.decimation - 1, act0 ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side, self_near, deci == 0);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     float hsum = 0.f;
     if (HF && P.measure_heights) {
         if (PIPE) {   // quarter of the scan here, the other three quarters on the helper waves
-            hsum = W == 8 ? height_scan_share<7, 5>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow)
+            hsum = W == 8 ? height_scan_share<7, (LPE == 4 ? 5 : 9)>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow)
                           : height_scan_share<4>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
             lds_barrier();   // height scan complete
             if (W == 8) hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + ((s_hsum[4 * 64 + lane] + s_hsum[5 * 64 + lane]) + (s_hsum[6 * 64 + lane] + s_hsum[7 * 64 + lane]));
@@ -1967,8 +1967,8 @@ extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, int w
                                 const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
 #define GRX_LAUNCH_STEP(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out, *sq)
-    if (heightfield) { if (waves == 4) GRX_LAUNCH_STEP(true, 4); else if (waves == 2) GRX_LAUNCH_STEP(true, 2); else GRX_LAUNCH_STEP(true, 1); }
-    else { if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
+    if (heightfield) { if (waves == 8) GRX_LAUNCH_STEP(true, 8); else if (waves == 4) GRX_LAUNCH_STEP(true, 4); else if (waves == 2) GRX_LAUNCH_STEP(true, 2); else GRX_LAUNCH_STEP(true, 1); }
+    else { if (waves == 8) GRX_LAUNCH_STEP(false, 8); else if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
 #undef GRX_LAUNCH_STEP
 }
 // TEST-ONLY (grx_debug_post_physics): the post-physics half of the step on injected state, one-wave layout

@@ -133,14 +133,15 @@ GRX_DEV SelfNear self_broad_phase(KP P, const SideConst& C, int side, const R3& 
 struct SelfNoVel { GRX_DEV void operator()() const {} };
 // velocities(): called once the sphere centres are staged and before any body velocity K[i].w / K[i].v is read (a caller that walked
 // the chain for positions only fills them in there)
-template <class Vel = SelfNoVel>
+// PARTS: 1 = leg x leg, 2 = thigh x base-lump shapes, 3 = both (eight waves per block: a part per wave)
+template <class Vel = SelfNoVel, int PARTS = 3>
 GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const SelfBuf& SB, int lane, int side, const R3& R0, V3 ang, V3 vel,
                             const ChainKin K[3], float mu, const SelfNear& sn, SelfOut& o, long long* pacc = nullptr, Vel velocities = Vel()) {
     const V3 zero = v3(0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < 3; ++i) { o.fa[i] = zero; o.fl[i] = zero; }
     o.f0a = zero; o.f0l = zero; o.fbase[0] = zero; o.fbase[1] = zero;
-    if (!__any(sn.m != 0u)) return;
+    if (!__any((sn.m & (PARTS == 1 ? 1u : (PARTS == 2 ? 0xffff0000u : 0xffffffffu))) != 0u)) return;
 #ifdef GRX_PROFILE_SECTIONS
     long long pdummy[8]; if (!pacc) pacc = pdummy;
     const long long t0_ = clock64();
@@ -149,7 +150,7 @@ GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const Se
     bool have_vel = false;   // (wave-uniform)
     auto need_vel = [&]() { if (!have_vel) { velocities(); have_vel = true; } };
     // ---- leg x leg
-    if (__any((sn.m & 1u) != 0u)) {
+    if ((PARTS & 1) && __any((sn.m & 1u) != 0u)) {
         // one pass over this lane's 8 spheres: centre -> LDS row, and the leg's extent towards the other leg along the
         // base's lateral axis (the separating-plane test below)
         const int el = lane_env(lane);
@@ -269,7 +270,7 @@ GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const Se
         }
     }
     // ---- base-lump shapes x this lane's thigh shapes
-    if (__any((sn.m >> 16) != 0u)) {
+    if ((PARTS & 2) && __any((sn.m >> 16) != 0u)) {
         need_vel();
         const ChainKin KB = {R0, zero, ang, vel};
         const V3 c0 = sph_centre(C.sph[8], K[0]), c1 = sph_centre(C.sph[9], K[0]);

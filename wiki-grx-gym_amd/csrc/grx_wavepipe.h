@@ -84,6 +84,8 @@ struct PipeLds {
     float4* wr;    // [2][64]     base-lump wrench, termination flag, collision count
     int* flag;     // [FL_COUNT]
     float4* xk;    // [3][3][64]  W == 8: rigid inertia about O of chain body k = 2, 1, 0 (wave 6 -> wave 0): A 6, h = m kap 3
+    float4* sb;    // [5][64]     W == 8: the thigh x base-lump part of the self-collision (wave 3 -> wave 0): thigh wrench 6, base-lump wrench 6,
+                   //             forces on two base-lump links 6
     float4* fx;    // [8][64]     W == 8: quads 0-3 the base-level X, Y of both legs (wave 0 -> wave 5), 4-7 T = Y Xo^-1 and Sc^-1 (wave 5 -> wave 0)
 };
 GRX_DEV float4 f4(float a, float b, float c, float d) { float4 r; r.x = a; r.y = b; r.z = c; r.w = d; return r; }
@@ -149,7 +151,8 @@ GRX_DEV void add_rigid(S3& A, M3& B, S3& D, const S3& Ak, V3 h, float m) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // wave 0: one sub-step of the state owner
-template <bool HF>
+template <bool HF, bool W8>   // W8: eight waves per block (see the second half of this file): no velocity-product terms, the rigid inertias of
+                              // bodies 2, 1, 0 and all bias forces from other waves, one poll per group of hand-overs
 GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                        SubstepOut& out, FootKin& fk_before, const PipeLds& L, const RareBuf& RB, int lane, int seq, long long* tacc,
                        const SideConst& Clds) {   // Clds: the LDS copy of C (tables read once per policy step)
@@ -178,9 +181,15 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
             const V3 a = axis_k(R, kAxis[k]);
             const V3 s_ = cross(rho, a);
             Sa[k] = a; Ss[k] = s_;
-            ca[k] = cross(w, a) * qdk;
-            cl[k] = (cross(v, a) + cross(w, s_)) * qdk;
-            w = fma3(a, qdk, w); v = fma3(s_, qdk, v);
+            if (!W8) {
+                ca[k] = cross(w, a) * qdk;
+                cl[k] = (cross(v, a) + cross(w, s_)) * qdk;
+                w = fma3(a, qdk, w); v = fma3(s_, qdk, v);
+            }
+#ifndef GRX_P8_XK
+#define GRX_P8_XK 1   // lane pairs, eight waves: 1 = the rigid inertias of bodies 2, 1, 0 come from wave 5 (as with lane quads)
+#endif
+            if (W8 && GRX_P8_XK && k < LEG - 2) continue;   // (rigid inertias of bodies 2, 1, 0: wave 5)
             const V3 kap = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
             const S3 Ic = {Clds.body[k].Ic[0], Clds.body[k].Ic[1], Clds.body[k].Ic[2], Clds.body[k].Ic[3], Clds.body[k].Ic[4], Clds.body[k].Ic[5]};   // (LDS: the register file is full)
             rigid_inertia(R, kap, C.body[k].mass, Ic, AK[k], hK[k]);
@@ -199,14 +208,24 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     M3 B = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
+        if (W8 && GRX_P8_XK && k < LEG - 2) {
+            if (k == LEG - 3) GRX_WAIT(L.flag + FL_XK, seq * 4 + 2, 4);   // bodies 2 and 1 come together,
+            if (k == 0) GRX_WAIT(L.flag + FL_XK, seq * 4 + 3, 4);         // body 0 a little later
+            const float4* c = L.xk + (k * 3) * 64 + lane;
+            const float4 a0 = c[0 * 64], a1 = c[1 * 64], a2 = c[2 * 64];
+            AK[k].xx = a0.x; AK[k].xy = a0.y; AK[k].xz = a0.z; AK[k].yy = a0.w; AK[k].yz = a1.x; AK[k].zz = a1.y;
+            hK[k] = v3(a1.z, a1.w, a2.x);
+        }
         add_rigid(A, B, D, AK[k], hK[k], C.body[k].mass);
         const V3 a = Sa[k], s_ = Ss[k];
         const V3 ua = mul(A, a) + mul(B, s_);
         const V3 ul = mulT(B, a) + mul(D, s_);
         const float di = grx_rcp(dot(a, ua) + dot(s_, ul));
         syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
-        Ica[k] = mul(A, ca[k]) + mul(B, cl[k]);
-        Icl[k] = mulT(B, ca[k]) + mul(D, cl[k]);
+        if (!W8) {
+            Ica[k] = mul(A, ca[k]) + mul(B, cl[k]);
+            Icl[k] = mulT(B, ca[k]) + mul(D, cl[k]);
+        }
         Ua[k] = ua; Ul[k] = ul; dinv[k] = di;
     }
 #ifdef GRX_PROFILE_SECTIONS
@@ -242,16 +261,21 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     // whole inertia half ended up behind the last wait: 4 k cycles per sub-step, measured).  Pin the results here.
     GRX_PIN(Sci.xx); GRX_PIN(Sci.xy); GRX_PIN(Sci.xz); GRX_PIN(Sci.yy); GRX_PIN(Sci.yz); GRX_PIN(Sci.zz);
     GRX_PIN(Di.xx); GRX_PIN(Di.xy); GRX_PIN(Di.xz); GRX_PIN(Di.yy); GRX_PIN(Di.yz); GRX_PIN(Di.zz);
+    if (!W8) {
 #pragma unroll
-    for (int k = 0; k < LEG; ++k) { GRX_PIN(Ica[k].x); GRX_PIN(Ica[k].y); GRX_PIN(Ica[k].z); GRX_PIN(Icl[k].x); GRX_PIN(Icl[k].y); GRX_PIN(Icl[k].z); }
+        for (int k = 0; k < LEG; ++k) { GRX_PIN(Ica[k].x); GRX_PIN(Ica[k].y); GRX_PIN(Ica[k].z); GRX_PIN(Icl[k].x); GRX_PIN(Icl[k].y); GRX_PIN(Icl[k].z); }
+    }
     GRX_EV(2);
     // ---- inward pass, bias half (leaf -> root): the rigid-body bias forces come from wave 2, leaf first.  The chain-body
     // CONTACT wrenches are not waited for here: the recursion is linear in the bias forces, they follow separately below.
     // (wave 2 is done with all five long before this point: one wait, and the ten LDS reads go out together -- one exposed
     //  LDS latency instead of one per joint)
     V3 pa = v3(0.f, 0.f, 0.f), pl = v3(0.f, 0.f, 0.f);
-    GRX_WAIT(L.flag + FL_BIAS, seq * 8 + (HF ? 2 : LEG), 0);
-    if (HF) GRX_WAIT(L.flag + FL_BIAS2, seq + 1, 0);   // bodies 2..0 come from wave 1 on a heightfield (see self_loop)
+    if (W8) GRX_WAIT_ALL(L.flag, flag_want(lane, FL_BIAS, seq * 8 + 2, FL_BIAS2, seq + 1), lane, 0);
+    else {
+        GRX_WAIT(L.flag + FL_BIAS, seq * 8 + (HF ? 2 : LEG), 0);
+        if (HF) GRX_WAIT(L.flag + FL_BIAS2, seq + 1, 0);   // bodies 2..0 come from wave 1 on a heightfield (see self_loop)
+    }
     float4 bq0[LEG], bq1[LEG];
 #pragma unroll
     for (int k = 0; k < LEG; ++k) { const float4* b_ = L.pb + (k * PB4) * 64 + lane; bq0[k] = b_[0 * 64]; bq1[k] = b_[1 * 64]; }
@@ -266,16 +290,22 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         const float u = tq_k - (dot(Sa[k], pa) + dot(Ss[k], pl));
         const float ud = u * dinv[k];
         uu[k] = u;
-        pa = pa + Ica[k] + Ua[k] * ud;
-        pl = pl + Icl[k] + Ul[k] * ud;
+        if (!W8) { pa = pa + Ica[k]; pl = pl + Icl[k]; }
+        pa = fma3(Ua[k], ud, pa);
+        pl = fma3(Ul[k], ud, pl);
     }
     GRX_EV(7);
     // ---- contact wrenches on chain bodies 4 (foot), 3 (shank), 2 (thigh): delta recursion  dp -> dp + U (-S.dp)/d
-    GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
-    GRX_EV(4);
-    GRX_WAIT(L.flag + FL_LEGS, seq + 1, 2);
-    GRX_EV(5);
-    GRX_WAIT(L.flag + FL_SELF, seq + 1, 3);
+    if (W8) {   // everything the rest of the sub-step consumes, in one poll
+        GRX_WAIT_ALL(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_LEGS, seq + 1, FL_SELF, seq + 1, FL_BASEBIAS, seq + 1, FL_CHAINW, seq + 1), lane, 2);
+        GRX_EV(5);
+    } else {
+        GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
+        GRX_EV(4);
+        GRX_WAIT(L.flag + FL_LEGS, seq + 1, 2);
+        GRX_EV(5);
+        GRX_WAIT(L.flag + FL_SELF, seq + 1, 3);
+    }
     SelfOut sc;   // self-collision wrenches (wave 1, after its recursion)
     {
         const float4* c = L.wc + 7 * 64 + lane;
@@ -284,6 +314,12 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         sc.fa[1] = v3(s1.z, s1.w, s2.x); sc.fl[1] = v3(s2.y, s2.z, s2.w);
         sc.fa[2] = v3(s3.x, s3.y, s3.z); sc.fl[2] = v3(s3.w, s4.x, s4.y);
         sc.f0a = v3(s4.z, s4.w, s5.x); sc.f0l = v3(s5.y, s5.z, s5.w);   // (quads 6, 7: forces on base-lump links, for wave 3's contact-force rows)
+        if (W8) {   // the thigh x base-lump part (wave 3, with its FL_LEGS hand-over)
+            const float4* d = L.sb + lane;
+            const float4 d0 = d[0 * 64], d1 = d[1 * 64], d2 = d[2 * 64];
+            sc.fa[0] = sc.fa[0] + v3(d0.x, d0.y, d0.z); sc.fl[0] = sc.fl[0] + v3(d0.w, d1.x, d1.y);
+            sc.f0a = sc.f0a + v3(d1.z, d1.w, d2.x); sc.f0l = sc.f0l + v3(d2.y, d2.z, d2.w);
+        }
     }
     {
         V3 da = v3(0.f, 0.f, 0.f), dl = v3(0.f, 0.f, 0.f);
@@ -315,7 +351,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     //  before this wave -- base_contact_loop)
     pa = pair_sum(pa); pl = pair_sum(pl);
     {   // base-lump bias force (wave 3; both lanes of the pair add the same value after the pair sum)
-        GRX_WAIT(L.flag + FL_BASEBIAS, seq + 1, 0);
+        if (!W8) GRX_WAIT(L.flag + FL_BASEBIAS, seq + 1, 0);
         const float4* b_ = L.pb + (LEG * PB4) * 64 + lane;
         const float4 b0_ = b_[0 * 64], b1_ = b_[1 * 64];
         pa = pa + v3(b0_.x, b0_.y, b0_.z); pl = pl + v3(b0_.w, b1_.x, b1_.y);
@@ -328,7 +364,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     V3 aa = alpha, al = acc;
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
-        const V3 pa_ = aa + ca[k], pl_ = al + cl[k];
+        const V3 pa_ = W8 ? aa : aa + ca[k], pl_ = W8 ? al : al + cl[k];
         const float qd2 = (uu[k] - (dot(Ua[k], pa_) + dot(Ul[k], pl_))) * dinv[k];
         qdd[k] = qd2;
         aa = fma3(Sa[k], qd2, pa_);
@@ -566,6 +602,12 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
         scfl2 = v3(s3.w, s4.x, s4.y);
         sco[2] = sel3(hi, scfl2, v3(s3.x, s3.y, s3.z));
         sc0o = sel3(hi, v3(s5.y, s5.z, s5.w), v3(s4.z, s4.w, s5.x));
+        if (W8) {   // the thigh x base-lump part (wave 3, with its FL_LEGS hand-over)
+            const float4* d = L.sb + lane;
+            const float4 d0 = d[0 * 64], d1 = d[1 * 64], d2 = d[2 * 64];
+            sco[0] = sco[0] + sel3(hi, v3(d0.w, d1.x, d1.y), v3(d0.x, d0.y, d0.z));
+            sc0o = sc0o + sel3(hi, v3(d2.y, d2.z, d2.w), v3(d1.z, d1.w, d2.x));
+        }
     }
     {
         V3 dlt = v3(0.f, 0.f, 0.f);
@@ -741,7 +783,8 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
         };
         if (seq == 0) sn = self_broad_phase(P, C, side, R0, KS);
         SelfOut sc;
-        self_collision(P, T, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc, velocities);
+        if (OWNPOS) self_collision<decltype(velocities), 1>(P, T, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc, velocities);   // (eight waves: thigh x base lump on wave 3)
+        else self_collision(P, T, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc, velocities);
         float4* o = L.wc + 7 * 64 + lane;
         o[0 * 64] = f4(sc.fa[0].x, sc.fa[0].y, sc.fa[0].z, sc.fl[0].x);
         o[1 * 64] = f4(sc.fl[0].y, sc.fl[0].z, sc.fa[1].x, sc.fa[1].y);
@@ -827,7 +870,11 @@ GRX_DEV void chain_bias_loop(KP P, const SideConst& C, const SideConst& Clds, co
             o[0 * 64] = f4(pa.x, pa.y, pa.z, pl.x);
             o[1 * 64] = f4(pl.y, pl.z, tlim, 0.f);
         };
-        {   // bodies KHI (lo half) and KHI - 1 (hi half)
+        if (LPL == 1) {   // a lane per leg: the bodies one after the other
+#pragma unroll
+            for (int k = KHI; k > KLO; --k) bias_out(ZZ[k - KLO], k, qs_q[k], qs_qd[k]);
+            if (NB == 2) bias_out(ZZ[0], KLO, qs_q[KLO], qs_qd[KLO]);
+        } else {   // bodies KHI (lo half) and KHI - 1 (hi half)
             const ChainKinZ &A = ZZ[NB - 1], &Bq = ZZ[NB - 2];
             ChainKinZ S_;
             S_.K.R.cx = sel3(hi, Bq.K.R.cx, A.K.R.cx); S_.K.R.cy = sel3(hi, Bq.K.R.cy, A.K.R.cy); S_.K.R.cz = sel3(hi, Bq.K.R.cz, A.K.R.cz);
@@ -892,7 +939,7 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
         flag_wait(L.flag + FL_STATE, seq + 1);
         const float* b = L.base + el;
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
-        {   // first what wave 0 needs first: the rigid inertias about O of thigh, hip yaw, hip roll (its inertia half adds them at bodies 2,
+        if (LPL == 2 || GRX_P8_XK) {   // first what wave 0 needs first: the rigid inertias about O of thigh, hip yaw, hip roll (its inertia half adds them at bodies 2,
             // 1, 0).  Positions-only walk of three bodies, then body 2 on the lo half of the leg and body 1 on the hi half in ONE pass.
             const float4 q0_ = L.q[lane];
             const float qs[3] = {q0_.x, q0_.y, q0_.z};
@@ -907,7 +954,19 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
                 Rk[k] = R;
                 kapk[k] = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
             }
-            {
+            if (LPL == 1) {   // a lane per leg: bodies 2 and 1 one after the other, each into its own slot
+#pragma unroll
+                for (int kb = 2; kb >= 1; --kb) {
+                    const S3 Ic = {C.body[kb].Ic[0], C.body[kb].Ic[1], C.body[kb].Ic[2], C.body[kb].Ic[3], C.body[kb].Ic[4], C.body[kb].Ic[5]};
+                    S3 Ak; V3 h_;
+                    rigid_inertia(Rk[kb], kapk[kb], C.body[kb].mass, Ic, Ak, h_);
+                    float4* o = L.xk + (kb * 3) * 64 + lane;
+                    o[0 * 64] = f4(Ak.xx, Ak.xy, Ak.xz, Ak.yy);
+                    o[1 * 64] = f4(Ak.yz, Ak.zz, h_.x, h_.y);
+                    o[2 * 64] = f4(h_.z, 0.f, 0.f, 0.f);
+                }
+                flag_set(L.flag + FL_XK, seq * 4 + 2, lane);
+            } else {
                 const int kb = hi ? 1 : 2;
                 R3 Rs;
                 Rs.cx = sel3(hi, Rk[1].cx, Rk[2].cx); Rs.cy = sel3(hi, Rk[1].cy, Rk[2].cy); Rs.cz = sel3(hi, Rk[1].cz, Rk[2].cz);
@@ -944,6 +1003,7 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
             o[1 * 64] = f4(bpl.y, bpl.z, 0.f, 0.f);
             flag_set(L.flag + FL_BASEBIAS, seq + 1, lane);
         }
+        if (LPL == 1) continue;   // (lane pairs: wave 0 factorises the base level itself)
         S3 A0; V3 h0;
         rigid_inertia(R0, kap0, base_m, base_I, A0, h0);
         flag_wait(L.flag + FL_FACT, seq + 1);
@@ -1058,8 +1118,10 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const SideConst& Clds,
 // wave 3: the seldom-touching shapes -- base lump (torso, head, arms), thigh, shank -- lane-compacted (grx_rare.h)
 template <bool HF, bool W8, bool SPLIT = W8 && GRX_W8_RARESPLIT>   // W8 (eight waves): base-lump shapes only -- thigh / shank shapes on wave 7 (chain_rare_loop), base bias force on wave 5
 GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, float mu, float hmax, float base_m, V3 base_c,
-                               const S3& base_I, const PipeLds& L, int lane, int el, int side, float* s_tp, LinkPrep& lp, V3 link_rows[11]) {
+                               const S3& base_I, const PipeLds& L, int lane, int el, int side, float* s_tp, LinkPrep& lp, V3 link_rows[11],
+                               const float4* footfr, float mu_self) {
     GRX_HELPER_PROF_BEGIN;
+    SelfNear sn3; sn3.m = 0;   // W8: this wave's copy of the self-collision broad phase (it evaluates the thigh x base-lump pairs)
 #ifdef GRX_PROFILE_SECTIONS
     long long racc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #else
@@ -1074,11 +1136,11 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
         const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
 #ifndef GRX_W8_LATE3
-#define GRX_W8_LATE3 1
+#define GRX_W8_LATE3 0   // (paid while this wave had the base-lump shapes only: +0.5 %; with the thigh x base-lump self-collision on it: -9 %)
 #endif
         // eight waves: this role's output is needed last and takes 1.6 k cycles, and the first ~2 k cycles of a sub-step are the ones in
         // which all eight waves want to issue: it starts once the rigid inertias (the first hand-over on wave 0's chain) are out
-        if (W8 && GRX_W8_LATE3) flag_wait(L.flag + FL_XK, seq * 4 + 2);
+        if (W8 && GRX_W8_LATE3 && LPL == 2) flag_wait(L.flag + FL_XK, seq * 4 + 2);   // (lane pairs: this wave tests all eight shapes per lane and is the last to finish as it is)
         if (!W8) {   // the base lump's rigid-body bias force (cheap; needed by wave 0 only at the base solve)
             V3 bpa, bpl;
             rigid_bias(R0, rot(R0, base_c), base_m, base_I, ang, vel, bpa, bpl);
@@ -1102,6 +1164,30 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         }
         L.wr[lane] = f4(ro.f0a.x, ro.f0a.y, ro.f0a.z, ro.f0l.x);
         L.wr[64 + lane] = f4(ro.f0l.y, ro.f0l.z, ro.term ? 1.f : 0.f, ro.pen_count);
+        SelfOut sb;   // W8: thigh x base-lump self-collision (the leg x leg part runs on wave 1)
+        if (W8) {
+            flag_wait(L.flag + FL_FRAMES, seq + 1);
+            ChainKin KS[3];
+            {
+                const RareFrame f = rare_load_frame(RB.fchain + lane, 64);
+                KS[0].R = f.R; KS[0].rho = f.rho; KS[0].w = f.w; KS[0].v = f.v;
+                KS[1] = KS[0]; KS[2] = KS[0];
+            }
+            if (seq == 0) {   // (the broad phase looks at all three shape-carrying bodies)
+                const RareFrame f3 = rare_load_frame(RB.fchain + RC_FR4 * 64 + lane, 64), f4_ = rare_load_frame(footfr + lane, 64);
+                KS[1].R = f3.R; KS[1].rho = f3.rho; KS[1].w = f3.w; KS[1].v = f3.v;
+                KS[2].R = f4_.R; KS[2].rho = f4_.rho; KS[2].w = f4_.w; KS[2].v = f4_.v;
+                sn3 = self_broad_phase(P, C, side, R0, KS);
+            }
+            const SelfBuf nosb = {nullptr, nullptr, nullptr};
+            self_collision<SelfNoVel, 2>(P, T, C, nosb, lane, side, R0, ang, vel, KS, mu_self, sn3, sb);
+            float4* o = L.sb + lane;
+            o[0 * 64] = f4(sb.fa[0].x, sb.fa[0].y, sb.fa[0].z, sb.fl[0].x);
+            o[1 * 64] = f4(sb.fl[0].y, sb.fl[0].z, sb.f0a.x, sb.f0a.y);
+            o[2 * 64] = f4(sb.f0a.z, sb.f0l.x, sb.f0l.y, sb.f0l.z);
+            o[3 * 64] = f4(sb.fbase[0].x, sb.fbase[0].y, sb.fbase[0].z, sb.fbase[1].x);
+            o[4 * 64] = f4(sb.fbase[1].y, sb.fbase[1].z, 0.f, 0.f);
+        }
         flag_set(L.flag + FL_LEGS, seq + 1, lane);   // thigh + shank wrenches and the base-lump wrench, one hand-over
         GRX_EV(12);
         if (seq == P.decimation - 1) {
@@ -1127,6 +1213,11 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
                 sc.fa[2] = v3(s3.x, s3.y, s3.z); sc.fl[2] = v3(s3.w, s4.x, s4.y);
                 sc.f0a = v3(s4.z, s4.w, s5.x); sc.f0l = v3(s5.y, s5.z, s5.w);
                 sc.fbase[0] = v3(s6.x, s6.y, s6.z); sc.fbase[1] = v3(s6.w, s7.x, s7.y);
+            }
+            if (W8) {   // ... plus this wave's own part
+                sc.fa[0] = sc.fa[0] + sb.fa[0]; sc.fl[0] = sc.fl[0] + sb.fl[0];
+                sc.f0a = sc.f0a + sb.f0a; sc.f0l = sc.f0l + sb.f0l;
+                sc.fbase[0] = sc.fbase[0] + sb.fbase[0]; sc.fbase[1] = sc.fbase[1] + sb.fbase[1];
             }
             const float4 f0_ = c_[4 * 64], f1_ = c_[5 * 64];
             const V3 foot_terrain = v3(f0_.w, f1_.x, f1_.y);
