@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
 #define GRX_HELPER_C C
 #endif
 #ifndef GRX_W8_REGC
-#define GRX_W8_REGC (LPL == 2 ? 0x7E : 0x76)   // eight waves (256 registers each): the waves whose constants live in registers (bit per wave; measured per layout)
+#define GRX_W8_REGC 0x76   // eight waves (256 registers each): the waves whose constants live in registers (bit per wave; measured: waves 3, 7 only spill)
 #endif
 #define GRX_HC(w) ((W == 8 && !((GRX_W8_REGC >> (w)) & 1)) ? C : GRX_HELPER_C)
             const float bm = P.base_m[e];

@@ -1122,6 +1122,10 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
                                const float4* footfr, float mu_self) {
     GRX_HELPER_PROF_BEGIN;
     SelfNear sn3; sn3.m = 0;   // W8: this wave's copy of the self-collision broad phase (it evaluates the thigh x base-lump pairs)
+#ifndef GRX_W8_SELFC_REGS
+#define GRX_W8_SELFC_REGS (LPL == 2)   // (lane pairs: wave 3 tests eight shapes per lane; the copy spills there, -2 %)
+#endif
+    const SideConst Cself = T.side[side];   // (the pair table of that part in registers: read from LDS every sub-step it costs ~1.5 k cycles)
 #ifdef GRX_PROFILE_SECTIONS
     long long racc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #else
@@ -1180,7 +1184,8 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
                 sn3 = self_broad_phase(P, C, side, R0, KS);
             }
             const SelfBuf nosb = {nullptr, nullptr, nullptr};
-            self_collision<SelfNoVel, 2>(P, T, C, nosb, lane, side, R0, ang, vel, KS, mu_self, sn3, sb);
+            if (GRX_W8_SELFC_REGS) self_collision<SelfNoVel, 2>(P, T, Cself, nosb, lane, side, R0, ang, vel, KS, mu_self, sn3, sb);
+            else self_collision<SelfNoVel, 2>(P, T, C, nosb, lane, side, R0, ang, vel, KS, mu_self, sn3, sb);
             float4* o = L.sb + lane;
             o[0 * 64] = f4(sb.fa[0].x, sb.fa[0].y, sb.fa[0].z, sb.fl[0].x);
             o[1 * 64] = f4(sb.fl[0].y, sb.fl[0].z, sb.f0a.x, sb.f0a.y);
