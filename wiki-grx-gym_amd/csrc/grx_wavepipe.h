@@ -1,5 +1,8 @@
-// grx_wavepipe.h -- the 4-waves-per-block physics pipeline of grx_step_kernel<HF, 4> (included by grx_kernels.hip
+// grx_wavepipe.h -- the waves-per-block physics pipelines of grx_step_kernel<HF, 4> and <HF, 8> (included by grx_kernels.hip
 // inside its anonymous namespace, after the shared contact / kinematics helpers).
+//
+// This header comment describes the FOUR-wave pipeline; the EIGHT-wave one (two waves per SIMD, the default since round 3) re-cuts
+// the same work into eight roles and is described where its roles begin ("Eight waves per block", further down, and DESIGN.md 4.1).
 //
 // At <= 8192 envs per GPU the step kernel is a handful of waves on a 1024-SIMD machine, each running alone on its
 // SIMD at one instruction per ~4.4 cycles: the instruction count of the longest dependent chain IS the step time.  A
