@@ -1168,7 +1168,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     float4* const s_footfr = reinterpret_cast<float4*>(s_arena + PHYS_BYTES);
     float* const s_anch = reinterpret_cast<float*>(s_arena + PHYS_BYTES + FOOTFR_BYTES);
     __shared__ float s_stat[NSTAT];
-    __shared__ float s_base[W >= 2 ? 13 * EPB : 1];   // base state at the start of the current sub-step (dynamics -> helpers)
+    __shared__ float s_base[W == 2 ? 13 * EPB : 1];   // W == 2: base state at the start of the current sub-step (dynamics -> helper)
+    __shared__ float4 s_bq[PIPE ? 4 * EPB : 1];       // the pipelines: the same as four quads per env (pipe_base_store / pipe_base_load)
     __shared__ __attribute__((aligned(16))) float s_wr[W == 2 ? 32 * 64 : (PIPE ? 8 * 64 : 1)];       // base-lump wrench + termination / collision flags (helper -> dynamics)
     // PIPE pipeline buffers (grx_wavepipe.h)
     __shared__ float4 s_q[PIPE ? Q4 * 64 : 1];
@@ -1185,7 +1186,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     __shared__ float4 s_sb[W == 8 ? 5 * 64 : 1];           // W == 8: thigh x base-lump self-collision (wave 3 -> wave 0)
     __shared__ float4 s_fx[W == 8 && LPL == 2 ? 8 * 64 : 1];           // W == 8: base-level 6 x 6 (wave 0 -> wave 5) and its factorisation (wave 5 -> wave 0)
     __shared__ int s_flag[FL_COUNT];
-    const PipeLds L = {s_base, s_q, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag, s_xk, s_sb, s_fx};
+    const PipeLds L = {s_bq, s_q, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag, s_xk, s_sb, s_fx};
     const int tid = threadIdx.x;
 #ifndef GRX_W8_ROLES
 #define GRX_W8_ROLES 0x76543210u   // role of hardware wave i in nibble i (waves i and i + 4 share a SIMD: pair a busy role with a light one)
@@ -1368,12 +1369,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 if (wv == 2) GRX_TICKW(31);
             }
             if (P.publish_rbs && wv < 4) {   // every URDF link frame of the state wave 0 published after the last sub-step: a third on each helper wave
-                const float* b = s_base + el;
+                float b_[13]; pipe_base_load(s_bq, el, b_);
+                const float* b = b_;
                 const float4 q0_ = s_q[lane], q1_ = s_q[64 + lane], q2_ = s_q[128 + lane];
                 const float fq[LEG] = {q0_.x, q0_.y, q0_.z, q0_.w, q1_.x}, fqd[LEG] = {q1_.y, q1_.z, q1_.w, q2_.x, q2_.y};
-                const float rq[4] = {b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]};
-                publish_rigid_body_states(P, C, side, v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]), rq, v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]),
-                                          v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]), fq, fqd, e, N, act0, wv - 1, 3);
+                const float rq[4] = {b[3], b[4], b[5], b[6]};
+                publish_rigid_body_states(P, C, side, v3(b[0], b[1], b[2]), rq, v3(b[7], b[8], b[9]),
+                                          v3(b[10], b[11], b[12]), fq, fqd, e, N, act0, wv - 1, 3);
             }
         } else {
             for (int deci = 0; deci < P.decimation; ++deci) {
@@ -1474,7 +1476,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
 #ifndef GRX_NO_LICM_BARRIER
         asm volatile("" ::: "memory");
 #endif
-        if (W >= 2 && side == 0) {   // publish the base state of this sub-step for the helper waves
+        if (PIPE && side == 0 && half == 0) pipe_base_store(s_bq, el, st.pos, st.qx, st.qy, st.qz, st.qw, st.vel, st.ang);
+        if (W == 2 && side == 0) {   // publish the base state of this sub-step for the helper wave
             float* b = s_base + el;
             b[0 * EPB] = st.pos.x; b[1 * EPB] = st.pos.y; b[2 * EPB] = st.pos.z;
             b[3 * EPB] = st.qx; b[4 * EPB] = st.qy; b[5 * EPB] = st.qz; b[6 * EPB] = st.qw;
@@ -1514,13 +1517,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     if (PIPE) {   // the foot wave owned the friction anchors during the sub-steps
         if (side == 0) { float* hp = s_hp + el; hp[0 * EPB] = st.pos.x; hp[1 * EPB] = st.pos.y; hp[2 * EPB] = yaw_z; hp[3 * EPB] = yaw_w; }
         if (P.publish_rbs) {   // the final state for the wave that publishes GRX_T_RIGID_BODY_STATES (wave 2, at the end of its work)
-            if (side == 0) {
-                float* b = s_base + el;
-                b[0 * EPB] = st.pos.x; b[1 * EPB] = st.pos.y; b[2 * EPB] = st.pos.z;
-                b[3 * EPB] = st.qx; b[4 * EPB] = st.qy; b[5 * EPB] = st.qz; b[6 * EPB] = st.qw;
-                b[7 * EPB] = st.vel.x; b[8 * EPB] = st.vel.y; b[9 * EPB] = st.vel.z;
-                b[10 * EPB] = st.ang.x; b[11 * EPB] = st.ang.y; b[12 * EPB] = st.ang.z;
-            }
+            if (side == 0 && half == 0) pipe_base_store(s_bq, el, st.pos, st.qx, st.qy, st.qz, st.qw, st.vel, st.ang);
             s_q[lane] = f4(st.q[0], st.q[1], st.q[2], st.q[3]);
             s_q[64 + lane] = f4(st.q[4], st.qd[0], st.qd[1], st.qd[2]);
             s_q[128 + lane] = f4(st.qd[3], st.qd[4], 0.f, 0.f);

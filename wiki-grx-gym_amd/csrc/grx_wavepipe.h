@@ -80,7 +80,7 @@ constexpr int WC4 = 15;   // contact wrenches about O: thigh quads 0-1, shank 2-
 constexpr int Q4 = 3;     // q 5, qd 5 of the lane's leg
 
 struct PipeLds {
-    float* base;   // [13][EPB]   base state at the start of the sub-step
+    float4* bq;    // [4][EPB]    base state at the start of the sub-step: (pos, q.x) (q.yzw, vel.x) (vel.yz, ang.xy) (ang.z, -, -, -)
     float4* q;     // [Q4][64]    q, qd of every lane's leg
     float4* wc;    // [WC4][64]
     float4* pb;    // [LEG][PB4][64] + [2][64]: chain-body bias forces / accelerations (wave 2, leaf first), base-lump bias force (wave 3)
@@ -92,6 +92,15 @@ struct PipeLds {
     float4* fx;    // [8][64]     W == 8: quads 0-3 the base-level X, Y of both legs (wave 0 -> wave 5), 4-7 T = Y Xo^-1 and Sc^-1 (wave 5 -> wave 0)
 };
 GRX_DEV float4 f4(float a, float b, float c, float d) { float4 r; r.x = a; r.y = b; r.z = c; r.w = d; return r; }
+GRX_DEV void pipe_base_load(const float4* bq, int el, float b[13]) {
+    const float4 a = bq[el], c = bq[EPB + el], d = bq[2 * EPB + el], e = bq[3 * EPB + el];
+    b[0] = a.x; b[1] = a.y; b[2] = a.z; b[3] = a.w; b[4] = c.x; b[5] = c.y; b[6] = c.z; b[7] = c.w;
+    b[8] = d.x; b[9] = d.y; b[10] = d.z; b[11] = d.w; b[12] = e.x;
+}
+GRX_DEV void pipe_base_store(float4* bq, int el, V3 pos, float qx, float qy, float qz, float qw, V3 vel, V3 ang) {
+    bq[el] = f4(pos.x, pos.y, pos.z, qx); bq[EPB + el] = f4(qy, qz, qw, vel.x);
+    bq[2 * EPB + el] = f4(vel.y, vel.z, ang.x, ang.y); bq[3 * EPB + el] = f4(ang.z, 0.f, 0.f, 0.f);
+}
 
 // Hand-over flags and their payload live in LDS: the release / acquire fences are LDS-only ("local" address space), so a
 // wave never waits for its global stores or terrain loads in flight when it raises or polls a flag.
@@ -720,9 +729,9 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
         GRX_HELPER_PROF_IDLE0;
         flag_wait(L.flag + FL_STATE, seq + 1);
         GRX_HELPER_PROF_IDLE1;
-        const float* b = L.base + el;
-        const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
-        const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+        float b[13]; pipe_base_load(L.bq, el, b);   // (base state: four quads per env)
+        const R3 R0 = quat_to_R(b[3], b[4], b[5], b[6]);
+        const V3 vel = v3(b[7], b[8], b[9]), ang = v3(b[10], b[11], b[12]);
         ChainKin KS[3];
         if (WALK) {
             float qs_q[LEG], qs_qd[LEG];
@@ -847,9 +856,9 @@ GRX_DEV void chain_bias_loop(KP P, const SideConst& C, const SideConst& Clds, co
     const bool hi = lane_half(lane) != 0;
     for (int seq = 0; seq < P.decimation; ++seq) {
         flag_wait(L.flag + FL_STATE, seq + 1);
-        const float* b = L.base + el;
-        const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
-        const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+        float b[13]; pipe_base_load(L.bq, el, b);   // (base state: four quads per env)
+        const R3 R0 = quat_to_R(b[3], b[4], b[5], b[6]);
+        const V3 vel = v3(b[7], b[8], b[9]), ang = v3(b[10], b[11], b[12]);
         float qs_q[LEG], qs_qd[LEG];
         {
             const float4 q0_ = L.q[lane], q1_ = L.q[64 + lane], q2_ = L.q[128 + lane];
@@ -898,9 +907,9 @@ GRX_DEV void chain_rare_loop(KP P, const KTables& T, const SideConst& C, const R
     for (int seq = 0; seq < P.decimation; ++seq) {
         flag_wait(L.flag + FL_STATE, seq + 1);
         if (!GRX_W8_RARESPLIT) { flag_set(L.flag + FL_CHAINW, seq + 1, lane); continue; }
-        const float* b = L.base + el;
-        const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
-        const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
+        float b[13]; pipe_base_load(L.bq, el, b);   // (base state: four quads per env)
+        const V3 O = v3(b[0], b[1], b[2]);
+        const R3 R0 = quat_to_R(b[3], b[4], b[5], b[6]);
         const V3 zero = v3(0.f, 0.f, 0.f);
         // own positions-only walk to thigh and shank: the reach tests start ~0.6 k cycles before wave 2's frames (with velocities) are out
         // (taking R, rho from wave 0's walk instead was tried: the 15 record stores and two hand-overs cost wave 0 0.7 k cycles per sub-step)
@@ -940,8 +949,8 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
     const float sg = hi ? -1.f : 1.f;
     for (int seq = 0; seq < P.decimation; ++seq) {
         flag_wait(L.flag + FL_STATE, seq + 1);
-        const float* b = L.base + el;
-        const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
+        float b[13]; pipe_base_load(L.bq, el, b);   // (base state: four quads per env)
+        const R3 R0 = quat_to_R(b[3], b[4], b[5], b[6]);
         if (LPL == 2 || GRX_P8_XK) {   // first what wave 0 needs first: the rigid inertias about O of thigh, hip yaw, hip roll (its inertia half adds them at bodies 2,
             // 1, 0).  Positions-only walk of three bodies, then body 2 on the lo half of the leg and body 1 on the hi half in ONE pass.
             const float4 q0_ = L.q[lane];
@@ -996,7 +1005,7 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
             flag_set(L.flag + FL_XK, seq * 4 + 3, lane);
             GRX_EV(27);
         }
-        const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+        const V3 vel = v3(b[7], b[8], b[9]), ang = v3(b[10], b[11], b[12]);
         const V3 kap0 = rot(R0, base_c);
         {
             V3 bpa, bpl;
@@ -1053,10 +1062,10 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const SideConst& Clds,
         GRX_HELPER_PROF_IDLE0;
         flag_wait(L.flag + FL_STATE, seq + 1);
         GRX_HELPER_PROF_IDLE1;
-        const float* b = L.base + el;
-        const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
-        const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
-        const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+        float b[13]; pipe_base_load(L.bq, el, b);   // (base state: four quads per env)
+        const V3 O = v3(b[0], b[1], b[2]);
+        const R3 R0 = quat_to_R(b[3], b[4], b[5], b[6]);
+        const V3 vel = v3(b[7], b[8], b[9]), ang = v3(b[10], b[11], b[12]);
         float qs_q[LEG], qs_qd[LEG];
         {
             const float4 q0_ = L.q[lane], q1_ = L.q[64 + lane], q2_ = L.q[128 + lane];
@@ -1138,10 +1147,10 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         GRX_HELPER_PROF_IDLE0;
         flag_wait(L.flag + FL_STATE, seq + 1);
         GRX_HELPER_PROF_IDLE1;
-        const float* b = L.base + el;
-        const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
-        const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
-        const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
+        float b[13]; pipe_base_load(L.bq, el, b);   // (base state: four quads per env)
+        const V3 O = v3(b[0], b[1], b[2]);
+        const R3 R0 = quat_to_R(b[3], b[4], b[5], b[6]);
+        const V3 vel = v3(b[7], b[8], b[9]), ang = v3(b[10], b[11], b[12]);
 #ifndef GRX_W8_LATE3
 #define GRX_W8_LATE3 0   // (paid while this wave had the base-lump shapes only: +0.5 %; with the thigh x base-lump self-collision on it: -9 %)
 #endif
