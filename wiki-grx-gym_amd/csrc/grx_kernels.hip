@@ -1298,7 +1298,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
             } else if (wv == 4) {
                 chain_bias_loop<3, 4>(P, GRX_HC(4), C, L, lane, el);
             } else if (wv == 6) {
-                chain_bias_loop<0, 2>(P, GRX_HC(6), C, L, lane, el);
+                if (LPL == 1) chain_bias_loop<0, 2, true>(P, GRX_HC(6), C, L, lane, el, &s_tab, &RB, s_footfr, side, P.friction[e]);
+                else chain_bias_loop<0, 2>(P, GRX_HC(6), C, L, lane, el);
             } else if (wv == 5) {
                 base_service_loop(P, GRX_HC(5), C, bm, bc, bI, L, lane, el);
             }

@@ -70,7 +70,8 @@ enum { FL_STATE = 0, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_BI
        FL_FACT = 16 /* W == 8: the base-level 6 x 6 is out (wave 0 -> wave 5) */, FL_FACTOUT = 17 /* ... and factorised */,
        FL_XK = 18 /* W == 8: rigid inertias of thigh, hip yaw, hip roll (wave 6 -> wave 0), seq * 4 + bodies out */,
        FL_CHAINW = 19 /* W == 8: thigh + shank terrain wrenches (wave 7) */, FL_BHO4 = 20 /* W == 8: fourth share of the observation height block */,
-       FL_COUNT = 21 };
+       FL_SB = 21 /* W == 8: the thigh x base-lump part of the self-collision is out (wave 3 with lane quads, wave 6 with lane pairs) */,
+       FL_COUNT = 22 };
 // Every record is laid out [quad][lane] in float4 units, so a lane moves it with ds_read_b128 / ds_write_b128: the
 // kernel runs at one instruction issue per ~5 cycles whatever the instruction, and the records are ~350 dwords per
 // lane and sub-step on wave 0 alone -- four dwords per LDS instruction instead of one is ~1.3k cycles per sub-step.
@@ -128,7 +129,8 @@ GRX_DEV void flag_wait_all(int* f, int want_mine, int lane) {
     while (!__all(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want_mine)) {}
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-GRX_DEV int flag_want(int lane, int f0, int w0, int f1 = -1, int w1 = 0, int f2 = -1, int w2 = 0, int f3 = -1, int w3 = 0, int f4 = -1, int w4 = 0, int f5 = -1, int w5 = 0) {
+GRX_DEV int flag_want(int lane, int f0, int w0, int f1 = -1, int w1 = 0, int f2 = -1, int w2 = 0, int f3 = -1, int w3 = 0, int f4 = -1, int w4 = 0, int f5 = -1, int w5 = 0,
+                      int f6 = -1, int w6 = 0) {
     int w = INT_MIN;
     if (lane == f0) w = w0;
     if (lane == f1) w = w1;
@@ -136,6 +138,7 @@ GRX_DEV int flag_want(int lane, int f0, int w0, int f1 = -1, int w1 = 0, int f2 
     if (lane == f3) w = w3;
     if (lane == f4) w = w4;
     if (lane == f5) w = w5;
+    if (lane == f6) w = w6;
     return w;
 }
 // block barrier that orders LDS only (global stores stay in flight across it)
@@ -317,7 +320,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     GRX_EV(7);
     // ---- contact wrenches on chain bodies 4 (foot), 3 (shank), 2 (thigh): delta recursion  dp -> dp + U (-S.dp)/d
     if (W8) {   // everything the rest of the sub-step consumes, in one poll
-        GRX_WAIT_ALL(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_LEGS, seq + 1, FL_SELF, seq + 1, FL_BASEBIAS, seq + 1, FL_CHAINW, seq + 1), lane, 2);
+        GRX_WAIT_ALL(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_LEGS, seq + 1, FL_SELF, seq + 1, FL_BASEBIAS, seq + 1, FL_CHAINW, seq + 1, FL_SB, seq + 1), lane, 2);
         GRX_EV(5);
     } else {
         GRX_WAIT(L.flag + FL_FOOT, seq + 1, 2);
@@ -602,7 +605,7 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     GRX_EV(7);
     // ---- contact wrenches on chain bodies 4, 3, 2: delta recursion on the own rows
     if (W8 && GRX_W8_WAITALL) {   // everything the rest of the sub-step consumes, in one poll
-        GRX_WAIT_ALL(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_LEGS, seq + 1, FL_SELF, seq + 1, FL_BASEBIAS, seq + 1, FL_FACTOUT, seq + 1, FL_CHAINW, seq + 1), lane, 2);
+        GRX_WAIT_ALL(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_LEGS, seq + 1, FL_SELF, seq + 1, FL_BASEBIAS, seq + 1, FL_FACTOUT, seq + 1, FL_CHAINW, seq + 1, FL_SB, seq + 1), lane, 2);
         GRX_EV(5);
     } else {
         if (W8) { GRX_WAIT(L.flag + FL_BASEBIAS, seq + 1, 0); GRX_WAIT(L.flag + FL_FACTOUT, seq + 1, 1); GRX_WAIT(L.flag + FL_CHAINW, seq + 1, 2); }
@@ -827,6 +830,36 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
 // ---------------------------------------------------------------------------------------------------------------
 // Eight waves per block (lane quads only; two waves per SIMD, each still issuing one instruction per ~4.5 cycles): the work the
 // four-wave layout hangs on whichever wave has slack gets waves of its own, and wave 0 sheds what others can finish in time.
+// The thigh x base-lump pairs of the self-collision (grx_self.h, PARTS = 2) on wave 2's thigh frame, with a broad phase of its own at
+// the first sub-step: wave 3 with lane quads (after its base-lump shapes), wave 6 with lane pairs (after its bias forces: wave 3 tests
+// eight shapes per lane there and is the last helper to finish as it is).  Record L.sb, hand-over FL_SB.
+GRX_DEV void thigh_base_self_step(KP P, const KTables& T, const SideConst& C /* may be a register copy */, const RareBuf& RB, const float4* footfr, const PipeLds& L,
+                                  int lane, int side, int seq, const R3& R0, V3 ang, V3 vel, float mu_self, SelfNear& sn3) {
+    flag_wait(L.flag + FL_FRAMES, seq + 1);
+    ChainKin KS[3];
+    {
+        const RareFrame f = rare_load_frame(RB.fchain + lane, 64);
+        KS[0].R = f.R; KS[0].rho = f.rho; KS[0].w = f.w; KS[0].v = f.v;
+        KS[1] = KS[0]; KS[2] = KS[0];
+    }
+    if (seq == 0) {   // (the broad phase looks at all three shape-carrying bodies)
+        const RareFrame f3 = rare_load_frame(RB.fchain + RC_FR4 * 64 + lane, 64), f4_ = rare_load_frame(footfr + lane, 64);
+        KS[1].R = f3.R; KS[1].rho = f3.rho; KS[1].w = f3.w; KS[1].v = f3.v;
+        KS[2].R = f4_.R; KS[2].rho = f4_.rho; KS[2].w = f4_.w; KS[2].v = f4_.v;
+        sn3 = self_broad_phase(P, T.side[side], side, R0, KS);   // (once per policy step: from the LDS table)
+    }
+    SelfOut sb;
+    const SelfBuf nosb = {nullptr, nullptr, nullptr};
+    self_collision<SelfNoVel, 2>(P, T, C, nosb, lane, side, R0, ang, vel, KS, mu_self, sn3, sb);
+    float4* o = L.sb + lane;
+    o[0 * 64] = f4(sb.fa[0].x, sb.fa[0].y, sb.fa[0].z, sb.fl[0].x);
+    o[1 * 64] = f4(sb.fl[0].y, sb.fl[0].z, sb.f0a.x, sb.f0a.y);
+    o[2 * 64] = f4(sb.f0a.z, sb.f0l.x, sb.f0l.y, sb.f0l.z);
+    o[3 * 64] = f4(sb.fbase[0].x, sb.fbase[0].y, sb.fbase[0].z, sb.fbase[1].x);
+    o[4 * 64] = f4(sb.fbase[1].y, sb.fbase[1].z, 0.f, 0.f);
+    flag_set(L.flag + FL_SB, seq + 1, lane);
+}
+
 // waves 4 and 6: own walk with velocities, then the bias forces of the chain bodies KHI .. KLO (wave 4: foot, shank; wave 6: thigh,
 // hip yaw, hip roll) -- wave 2 keeps the foot contacts only.  The velocity-product accelerations c_k of the joints are FOLDED into
 // these forces: with zeta_k = sum of c_j over the joints up to k (all about O in world axes, so a plain sum) and a_k = a^_k + zeta_k,
@@ -857,11 +890,13 @@ GRX_DEV void rigid_bias_z(const R3& R, V3 kap, float m, const S3& Ic, V3 w, V3 v
 // The two lanes of a leg compute DIFFERENT bodies in one pass (lo half: body KHI, hi half: body KHI - 1 -- same instructions, selected
 // inputs; the table constants come from LDS with a lane-dependent index), a body left over (KLO, three bodies) on both halves: wave 0
 // reads the record of body k from the slot of the lane that wrote it.
-template <int KLO, int KHI>
-GRX_DEV void chain_bias_loop(KP P, const SideConst& C, const SideConst& Clds, const PipeLds& L, int lane, int el) {
+template <int KLO, int KHI, bool SELFB = false>   // SELFB: then the thigh x base-lump self-collision (lane pairs, wave 6)
+GRX_DEV void chain_bias_loop(KP P, const SideConst& C, const SideConst& Clds, const PipeLds& L, int lane, int el,
+                             const KTables* T = nullptr, const RareBuf* RB = nullptr, const float4* footfr = nullptr, int side = 0, float mu_self = 0.f) {
     constexpr int NB = KHI - KLO + 1;
     static_assert(NB == 2 || NB == 3, "a pair of bodies, or a pair and a single one");
     const bool hi = lane_half(lane) != 0;
+    SelfNear sn3; sn3.m = 0;
     for (int seq = 0; seq < P.decimation; ++seq) {
         flag_wait(L.flag + FL_STATE, seq + 1);
         float b[13]; pipe_base_load(L.bq, el, b);   // (base state: four quads per env)
@@ -905,6 +940,7 @@ GRX_DEV void chain_bias_loop(KP P, const SideConst& C, const SideConst& Clds, co
         if (NB == 3) bias_out(ZZ[0], KLO, qs_q[KLO], qs_qd[KLO]);
         if (KHI == LEG - 1) { flag_set(L.flag + FL_BIAS, seq * 8 + 2, lane); GRX_EV(26); }
         else { flag_set(L.flag + FL_BIAS2, seq + 1, lane); GRX_EV(28); }
+        if (SELFB) thigh_base_self_step(P, *T, Clds, *RB, footfr, L, lane, side, seq, R0, ang, vel, mu_self, sn3);
     }
 }
 
@@ -1142,9 +1178,6 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
                                const float4* footfr, float mu_self) {
     GRX_HELPER_PROF_BEGIN;
     SelfNear sn3; sn3.m = 0;   // W8: this wave's copy of the self-collision broad phase (it evaluates the thigh x base-lump pairs)
-#ifndef GRX_W8_SELFC_REGS
-#define GRX_W8_SELFC_REGS (LPL == 2)   // (lane pairs: wave 3 tests eight shapes per lane; the copy spills there, -2 %)
-#endif
     const SideConst Cself = T.side[side];   // (the pair table of that part in registers: read from LDS every sub-step it costs ~1.5 k cycles)
 #ifdef GRX_PROFILE_SECTIONS
     long long racc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1188,32 +1221,9 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
         }
         L.wr[lane] = f4(ro.f0a.x, ro.f0a.y, ro.f0a.z, ro.f0l.x);
         L.wr[64 + lane] = f4(ro.f0l.y, ro.f0l.z, ro.term ? 1.f : 0.f, ro.pen_count);
-        SelfOut sb;   // W8: thigh x base-lump self-collision (the leg x leg part runs on wave 1)
-        if (W8) {
-            flag_wait(L.flag + FL_FRAMES, seq + 1);
-            ChainKin KS[3];
-            {
-                const RareFrame f = rare_load_frame(RB.fchain + lane, 64);
-                KS[0].R = f.R; KS[0].rho = f.rho; KS[0].w = f.w; KS[0].v = f.v;
-                KS[1] = KS[0]; KS[2] = KS[0];
-            }
-            if (seq == 0) {   // (the broad phase looks at all three shape-carrying bodies)
-                const RareFrame f3 = rare_load_frame(RB.fchain + RC_FR4 * 64 + lane, 64), f4_ = rare_load_frame(footfr + lane, 64);
-                KS[1].R = f3.R; KS[1].rho = f3.rho; KS[1].w = f3.w; KS[1].v = f3.v;
-                KS[2].R = f4_.R; KS[2].rho = f4_.rho; KS[2].w = f4_.w; KS[2].v = f4_.v;
-                sn3 = self_broad_phase(P, C, side, R0, KS);
-            }
-            const SelfBuf nosb = {nullptr, nullptr, nullptr};
-            if (GRX_W8_SELFC_REGS) self_collision<SelfNoVel, 2>(P, T, Cself, nosb, lane, side, R0, ang, vel, KS, mu_self, sn3, sb);
-            else self_collision<SelfNoVel, 2>(P, T, C, nosb, lane, side, R0, ang, vel, KS, mu_self, sn3, sb);
-            float4* o = L.sb + lane;
-            o[0 * 64] = f4(sb.fa[0].x, sb.fa[0].y, sb.fa[0].z, sb.fl[0].x);
-            o[1 * 64] = f4(sb.fl[0].y, sb.fl[0].z, sb.f0a.x, sb.f0a.y);
-            o[2 * 64] = f4(sb.f0a.z, sb.f0l.x, sb.f0l.y, sb.f0l.z);
-            o[3 * 64] = f4(sb.fbase[0].x, sb.fbase[0].y, sb.fbase[0].z, sb.fbase[1].x);
-            o[4 * 64] = f4(sb.fbase[1].y, sb.fbase[1].z, 0.f, 0.f);
-        }
         flag_set(L.flag + FL_LEGS, seq + 1, lane);   // thigh + shank wrenches and the base-lump wrench, one hand-over
+        // W8, lane quads: the thigh x base-lump self-collision (the leg x leg part runs on wave 1; lane pairs: wave 6 does this)
+        if (W8 && LPL == 2) thigh_base_self_step(P, T, Cself, RB, footfr, L, lane, side, seq, R0, ang, vel, mu_self, sn3);
         GRX_EV(12);
         if (seq == P.decimation - 1) {
 #ifdef GRX_PROFILE_SECTIONS
@@ -1223,7 +1233,7 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
             // has the base-lump links' forces; the foot's terrain force comes from wave 2, the self-collision forces from
             // wave 1 -- both handed over for wave 0 anyway.  Written here, off wave 0's path (it is the last to finish).
             lp = link_prep(C);   // (table reads: before the forces are in)
-            if (SPLIT) flag_wait_all(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_SELF, seq + 1, FL_CHAINW, seq + 1), lane);
+            if (SPLIT) flag_wait_all(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_SELF, seq + 1, FL_CHAINW, seq + 1, FL_SB, seq + 1), lane);
             else { flag_wait(L.flag + FL_FOOT, seq + 1); flag_wait(L.flag + FL_SELF, seq + 1); }
             if (SPLIT) {   // the terrain forces on thigh and shank come from wave 7
                 const float4 a0 = c_[0 * 64], a1 = c_[1 * 64], a2 = c_[2 * 64], a3 = c_[3 * 64];
@@ -1239,7 +1249,15 @@ GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const
                 sc.f0a = v3(s4.z, s4.w, s5.x); sc.f0l = v3(s5.y, s5.z, s5.w);
                 sc.fbase[0] = v3(s6.x, s6.y, s6.z); sc.fbase[1] = v3(s6.w, s7.x, s7.y);
             }
-            if (W8) {   // ... plus this wave's own part
+            if (W8) {   // ... plus the thigh x base-lump part
+                SelfOut sb;
+                {
+                    const float4* d = L.sb + lane;
+                    const float4 d0 = d[0 * 64], d1 = d[1 * 64], d2 = d[2 * 64], d3 = d[3 * 64], d4 = d[4 * 64];
+                    sb.fa[0] = v3(d0.x, d0.y, d0.z); sb.fl[0] = v3(d0.w, d1.x, d1.y);
+                    sb.f0a = v3(d1.z, d1.w, d2.x); sb.f0l = v3(d2.y, d2.z, d2.w);
+                    sb.fbase[0] = v3(d3.x, d3.y, d3.z); sb.fbase[1] = v3(d3.w, d4.x, d4.y);
+                }
                 sc.fa[0] = sc.fa[0] + sb.fa[0]; sc.fl[0] = sc.fl[0] + sb.fl[0];
                 sc.f0a = sc.f0a + sb.f0a; sc.f0l = sc.f0l + sb.f0l;
                 sc.fbase[0] = sc.fbase[0] + sb.fbase[0]; sc.fbase[1] = sc.fbase[1] + sb.fbase[1];
