@@ -212,7 +212,7 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 #ifndef GRX_P8_XK
 #define GRX_P8_XK 1   // lane pairs, eight waves: 1 = the rigid inertias of bodies 2, 1, 0 come from wave 5 (as with lane quads)
 #endif
-            if (W8 && GRX_P8_XK && k < LEG - 2) continue;   // (rigid inertias of bodies 2, 1, 0: wave 5)
+            if (W8 && GRX_P8_XK && k < 2) continue;   // (rigid inertias of bodies 1, 0: wave 5 -- this wave would only wait for body 2's)
             const V3 kap = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
             const S3 Ic = {Clds.body[k].Ic[0], Clds.body[k].Ic[1], Clds.body[k].Ic[2], Clds.body[k].Ic[3], Clds.body[k].Ic[4], Clds.body[k].Ic[5]};   // (LDS: the register file is full)
             rigid_inertia(R, kap, C.body[k].mass, Ic, AK[k], hK[k]);
@@ -231,9 +231,8 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     M3 B = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
-        if (W8 && GRX_P8_XK && k < LEG - 2) {
-            if (k == LEG - 3) GRX_WAIT(L.flag + FL_XK, seq * 4 + 2, 4);   // bodies 2 and 1 come together,
-            if (k == 0) GRX_WAIT(L.flag + FL_XK, seq * 4 + 3, 4);         // body 0 a little later
+        if (W8 && GRX_P8_XK && k < 2) {
+            if (k == 1) GRX_WAIT(L.flag + FL_XK, seq * 4 + 3, 4);
             const float4* c = L.xk + (k * 3) * 64 + lane;
             const float4 a0 = c[0 * 64], a1 = c[1 * 64], a2 = c[2 * 64];
             AK[k].xx = a0.x; AK[k].xy = a0.y; AK[k].xz = a0.z; AK[k].yy = a0.w; AK[k].yz = a1.x; AK[k].zz = a1.y;
@@ -1010,9 +1009,9 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
                 Rk[k] = R;
                 kapk[k] = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
             }
-            if (LPL == 1) {   // a lane per leg: bodies 2 and 1 one after the other, each into its own slot
+            if (LPL == 1) {   // a lane per leg: bodies 1 and 0 one after the other (wave 0 computes body 2's itself), each into its own slot
 #pragma unroll
-                for (int kb = 2; kb >= 1; --kb) {
+                for (int kb = 1; kb >= 0; --kb) {
                     const S3 Ic = {C.body[kb].Ic[0], C.body[kb].Ic[1], C.body[kb].Ic[2], C.body[kb].Ic[3], C.body[kb].Ic[4], C.body[kb].Ic[5]};
                     S3 Ak; V3 h_;
                     rigid_inertia(Rk[kb], kapk[kb], C.body[kb].mass, Ic, Ak, h_);
@@ -1021,7 +1020,7 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
                     o[1 * 64] = f4(Ak.yz, Ak.zz, h_.x, h_.y);
                     o[2 * 64] = f4(h_.z, 0.f, 0.f, 0.f);
                 }
-                flag_set(L.flag + FL_XK, seq * 4 + 2, lane);
+                flag_set(L.flag + FL_XK, seq * 4 + 3, lane);
             } else {
                 const int kb = hi ? 1 : 2;
                 R3 Rs;
@@ -1037,7 +1036,7 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
                 o[2 * 64] = f4(h_.z, 0.f, 0.f, 0.f);
                 flag_set(L.flag + FL_XK, seq * 4 + 2, lane);
             }
-            {
+            if (LPL == 2) {
                 const S3 Ic = {C.body[0].Ic[0], C.body[0].Ic[1], C.body[0].Ic[2], C.body[0].Ic[3], C.body[0].Ic[4], C.body[0].Ic[5]};
                 S3 Ak; V3 h_;
                 rigid_inertia(Rk[0], kapk[0], C.body[0].mass, Ic, Ak, h_);
@@ -1045,8 +1044,8 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
                 o[0 * 64] = f4(Ak.xx, Ak.xy, Ak.xz, Ak.yy);
                 o[1 * 64] = f4(Ak.yz, Ak.zz, h_.x, h_.y);
                 o[2 * 64] = f4(h_.z, 0.f, 0.f, 0.f);
+                flag_set(L.flag + FL_XK, seq * 4 + 3, lane);
             }
-            flag_set(L.flag + FL_XK, seq * 4 + 3, lane);
             GRX_EV(27);
         }
         const V3 vel = v3(b[7], b[8], b[9]), ang = v3(b[10], b[11], b[12]);
