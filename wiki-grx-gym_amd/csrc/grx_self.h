@@ -93,6 +93,7 @@ GRX_DEV SelfBuf self_carve(char* p) {
 GRX_DEV V3 sph_centre(const SphC& S, const ChainKin& K) { return K.rho + rot(K.R, v3(S.x, S.y, S.z)); }
 GRX_DEV V3 v3_swap(V3 a) { return v3(pair_swap(a.x), pair_swap(a.y), pair_swap(a.z)); }
 
+template <int PARTS = 3>   // 1: the leg x leg bit only, 2: the thigh x base-lump bits only (eight waves: a part per wave, like self_collision)
 GRX_DEV SelfNear self_broad_phase(KP P, const SideConst& C, int side, const R3& R0, const ChainKin K[3]) {
     SelfNear sn; sn.m = 0;
     if (!P.self_collisions) return sn;
@@ -105,6 +106,7 @@ GRX_DEV SelfNear self_broad_phase(KP P, const SideConst& C, int side, const R3& 
         oc[i] = v3_swap(bc[i]);
         orr[i] = pair_swap(br[i]);
     }
+    if (PARTS & 1)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -115,6 +117,7 @@ GRX_DEV SelfNear self_broad_phase(KP P, const SideConst& C, int side, const R3& 
             const float R = br[i] + orr[j] + kSelfMargin;
             if (feasible && dot(d, d) < R * R) sn.m |= 1u;   // (the same verdict in both lanes of the env: symmetric arithmetic)
         }
+    if (PARTS & 2)
 #pragma unroll
     for (int e = 0; e < GRX_MAX_BC; ++e) {
         if (!__any(e < C.nbc)) break;

@@ -803,7 +803,7 @@ GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf
                 KS[i].w = v3(d.x, d.y, d.z); KS[i].v = v3(d.w, e_.x, e_.y);
             }
         };
-        if (seq == 0) sn = self_broad_phase(P, C, side, R0, KS);
+        if (seq == 0) sn = OWNPOS ? self_broad_phase<1>(P, C, side, R0, KS) : self_broad_phase(P, C, side, R0, KS);   // (eight waves: the other part on the wave that evaluates it)
         SelfOut sc;
         if (OWNPOS) self_collision<decltype(velocities), 1>(P, T, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc, velocities);   // (eight waves: thigh x base lump on wave 3)
         else self_collision(P, T, C, SB, lane, side, R0, ang, vel, KS, mu_self, sn, sc, sacc, velocities);
@@ -841,12 +841,7 @@ GRX_DEV void thigh_base_self_step(KP P, const KTables& T, const SideConst& C /* 
         KS[0].R = f.R; KS[0].rho = f.rho; KS[0].w = f.w; KS[0].v = f.v;
         KS[1] = KS[0]; KS[2] = KS[0];
     }
-    if (seq == 0) {   // (the broad phase looks at all three shape-carrying bodies)
-        const RareFrame f3 = rare_load_frame(RB.fchain + RC_FR4 * 64 + lane, 64), f4_ = rare_load_frame(footfr + lane, 64);
-        KS[1].R = f3.R; KS[1].rho = f3.rho; KS[1].w = f3.w; KS[1].v = f3.v;
-        KS[2].R = f4_.R; KS[2].rho = f4_.rho; KS[2].w = f4_.w; KS[2].v = f4_.v;
-        sn3 = self_broad_phase(P, T.side[side], side, R0, KS);   // (once per policy step: from the LDS table)
-    }
+    if (seq == 0) sn3 = self_broad_phase<2>(P, T.side[side], side, R0, KS);   // (this part looks at the thigh only; once per policy step: from the LDS table)
     SelfOut sb;
     const SelfBuf nosb = {nullptr, nullptr, nullptr};
     self_collision<SelfNoVel, 2>(P, T, C, nosb, lane, side, R0, ang, vel, KS, mu_self, sn3, sb);
