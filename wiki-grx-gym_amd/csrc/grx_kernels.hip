@@ -1369,14 +1369,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 flag_set(s_flag + FL_BHO1 + (wv - 1), 1, lane);
                 if (wv == 2) GRX_TICKW(31);
             }
-            if (P.publish_rbs && wv < 4) {   // every URDF link frame of the state wave 0 published after the last sub-step: a third on each helper wave
+            if (P.publish_rbs && (W == 8 || wv < 4)) {   // every URDF link frame of the state wave 0 published after the last sub-step: a third (eight waves: a seventh) on each helper wave
                 float b_[13]; pipe_base_load(s_bq, el, b_);
                 const float* b = b_;
                 const float4 q0_ = s_q[lane], q1_ = s_q[64 + lane], q2_ = s_q[128 + lane];
                 const float fq[LEG] = {q0_.x, q0_.y, q0_.z, q0_.w, q1_.x}, fqd[LEG] = {q1_.y, q1_.z, q1_.w, q2_.x, q2_.y};
                 const float rq[4] = {b[3], b[4], b[5], b[6]};
                 publish_rigid_body_states(P, C, side, v3(b[0], b[1], b[2]), rq, v3(b[7], b[8], b[9]),
-                                          v3(b[10], b[11], b[12]), fq, fqd, e, N, act0, wv - 1, 3);
+                                          v3(b[10], b[11], b[12]), fq, fqd, e, N, act0, wv - 1, W == 8 ? 7 : 3);
             }
         } else {
             for (int deci = 0; deci < P.decimation; ++deci) {
