@@ -241,6 +241,9 @@ struct HeadOut { const float* stdp; const float* eps; float* actions; float* log
 template <bool ELU, bool VEC, bool HEAD = false>
 __global__ __launch_bounds__(256) void mlp_layer_kernel(int M, int K, int N, const float* __restrict__ X, const float* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ Y, HeadOut ho = HeadOut()) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "mlp_layer_kernel keeps 65 KB of static LDS: gfx950 (160 KB per CU) only -- this library is built for MI355X, see the Makefile"
+#endif
     __shared__ float Xs[2][ML_KC * ML_LD], Ws[2][ML_KC * ML_LD];   // double-buffered: chunk c + 1 lands while chunk c multiplies
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wy = wv >> 1, wx = wv & 1;
     const int m0 = blockIdx.x * ML_BM, n0 = blockIdx.y * ML_BN;

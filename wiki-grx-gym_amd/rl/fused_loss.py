@@ -128,8 +128,16 @@ def store_transition(storage, step, obs, pri, actions, mu, sigma, values, logp, 
     for t in (obs, pri, actions, mu, sigma, values, logp, rewards):
         if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise RuntimeError("store_transition needs contiguous float32 CUDA tensors")
-    d8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones
-    t8 = None if time_outs is None else (time_outs.view(torch.uint8) if time_outs.dtype == torch.bool else time_outs)
+    def as_u8(t):   # the kernel reads one byte per env: bool is reinterpreted, any other dtype (a reference-style long reset_buf) converted
+        if t.dtype == torch.bool:
+            t = t.view(torch.uint8)
+        elif t.dtype != torch.uint8:
+            t = (t != 0).to(torch.uint8)
+        if not (t.is_cuda and t.is_contiguous() and t.numel() == N):
+            raise RuntimeError("store_transition needs contiguous CUDA dones / time_outs with one entry per env")
+        return t
+    d8 = as_u8(dones)
+    t8 = None if time_outs is None else as_u8(time_outs)
     sp = storage.pri_observations
     lg = log if log is not None else (None, None, None, None)
     with torch.cuda.device(obs.device):
