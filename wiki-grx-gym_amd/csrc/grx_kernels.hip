@@ -1127,12 +1127,13 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
     }
 }
 
-// Block = W waves (W = 1, 2 or 4, chosen at launch so that every wave gets a SIMD to itself) for the same 32 envs,
+// Block = W waves (W = 1, 2, 4 or 8, chosen at launch: up to 4 every wave has a SIMD to itself, 8 puts two on each) for the same 32 envs,
 // one env per lane PAIR in each wave.  The kernel runs one wave per SIMD, i.e. at one instruction per 4 cycles, so
 // a wave's instruction count IS its time:
 //   W == 1: one wave does everything (large batches: every SIMD is busy with its own envs anyway);
 //   W == 2: wave 1 computes the base-lump contact wrench of every sub-step (two block barriers per sub-step);
-//   W == 4: the four-wave producer/consumer pipeline of grx_wavepipe.h (sequence counters in LDS).
+//   W == 4: the four-wave producer/consumer pipeline of grx_wavepipe.h (sequence counters in LDS);
+//   W == 8: the same work re-cut into eight roles (grx_wavepipe.h, "Eight waves per block"; the default of the pipelined layouts).
 // DBG (W == 1 only, behind the test-only entry grx_debug_post_physics): no sub-steps; the quantities the physics
 // would have produced (feet forces / positions, sub-step averages, torques, termination contact) and
 // last_last_actions come from `dbg` ([DBG_ROWS][N], see DbgRow), so the post-physics half of the step can be fed the
