@@ -311,10 +311,10 @@ def test_full_size_properties(task, terrain, N, monkeypatch):
     (env i does not depend on how the batch is split across ranks: the multi-GPU contract).
     Bit-identity holds per step-kernel layout (waves per 32-env block, picked from the local batch size);
     the 32768 cases pin the layout so that the shards use the full run's."""
-    # (the library picks the layout from the LOCAL batch size -- quad up to 4096 envs, four waves up to 16384, one wave beyond;
+    # (the library picks the layout from the LOCAL batch size -- quad up to 4096 envs, eight waves on lane pairs up to 16384, one wave beyond;
     #  the shards of this test are smaller than the full run, so the full run's layout is pinned for them)
     if task != "GR1T1Full":
-        set_layout(monkeypatch, 1 if N == 32768 else (4 if N == 8192 else "quad"))
+        set_layout(monkeypatch, 1 if N == 32768 else (8 if N == 8192 else "quad"))
     cfg = make_cfg(task=task, terrain=terrain, noise=True, dr=True, push=True)
     act_scale = 0.3 if task == "GR1T1Full" else 1.0      # (the full body's arm / waist ranges at full scale throw it around)
     from tests.helpers import make_terrain
