@@ -18,8 +18,10 @@ Extra objects on the JSON line:
   roofline      HBM roofline of the fused step kernel: algorithmic bytes per env-step
                 (2476 B rough / 1750 B flat) x envs per launch / average kernel
                 duration measured with HIP events on the launch stream (grx_kernel_time_ms).
+                `kernel` / `layout`: what grx_layout() says the handle launches (not guessed from the batch size).
                 `valu_issue_frac`: the number that actually bounds this kernel -- VALU wave-instructions
-                per launch (SQ_INSTS_VALU of the committed rocprofv3 PMC pass, profiles/r02_pmc_sq_*.json)
+                per launch (SQ_INSTS_VALU of the committed rocprofv3 PMC pass of the same workload and batch size,
+                profiles/rNN_pmc_sq_<workload>.json, newest round first)
                 / live kernel duration, against the chip's VALU issue peak (1024 SIMDs x one wave64
                 instruction per 2 cycles at 2.4 GHz, MI355X_MICROARCH.md).
   cpu_baseline  the CPU oracle ("port": oracle/grx_oracle.c, fp32, OpenMP over envs) timed on
@@ -209,27 +211,30 @@ def main():
         # WRITE_SIZE runs, tools/collect_profiles.sh); bench.py cannot host the profiler itself.  Raw counter sum:
         # FETCH_SIZE is a lower bound on gfx950 (MI355X_MICROARCH.md), see the note inside the file.
         traffic, traffic_src, valu_insts, valu_src = None, None, None, None
-        headline = args.robot == "lower_limb" and args.terrain == "rough" and n_local == 4096
-        for tag in ("r03", "r02", "r01"):
-            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_rough4096.json")
-            if headline and traffic is None and os.path.exists(pmc):
+        wl = ("" if args.robot == "lower_limb" else "full_body_") + f"{args.terrain}{n_local}"   # e.g. rough4096, full_body_rough4096
+        layout = sim.layout()
+        for tag in ("r04", "r03", "r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_{wl}.json")
+            if traffic is None and os.path.exists(pmc):
                 try:
                     j = json.load(open(pmc))
                     traffic = (j["FETCH_SIZE"]["mean_KB"] + j["WRITE_SIZE"]["mean_KB"]) * 1024.0
-                    traffic_src = (f"profiles/{tag}_pmc_hbm_rough4096.json: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this "
+                    if j.get("kernel") and not layout["kernel"].startswith(j["kernel"].split("<")[0] + "<"):
+                        raise ValueError("counters of another kernel")
+                    traffic_src = (f"profiles/{tag}_pmc_hbm_{wl}.json: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this "
                                    "workload, bytes per launch, NOT live and uncorrected (FETCH_SIZE is a lower bound on gfx950)")
                 except Exception:
                     traffic = None
-            sq = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_rough4096.json")
-            if headline and valu_insts is None and os.path.exists(sq):
+            sq = os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_{wl}.json")
+            if valu_insts is None and os.path.exists(sq):
                 try:
                     valu_insts = float(json.load(open(sq))["SQ_INSTS_VALU"])
-                    valu_src = f"profiles/{tag}_pmc_sq_rough4096.json (SQ_INSTS_VALU per launch, rocprofv3 --pmc pass of this workload; duration live)"
+                    valu_src = f"profiles/{tag}_pmc_sq_{wl}.json (SQ_INSTS_VALU per launch, rocprofv3 --pmc pass of this workload; duration live)"
                 except Exception:
                     valu_insts = None
         achieved = bytes_per * n_local / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
-            "metric": ("env-steps/sec GR1T1 rough-terrain @4096 envs" if args.terrain == "rough" else "env-steps/sec GR1T1 flat-terrain @4096 envs")
+            "metric": f"env-steps/sec GR1T1 {'rough' if args.terrain == 'rough' else 'flat'}-terrain @{n_local} envs"
                       + ("" if args.robot == "lower_limb" else " [full-body 32 DOF, config 5]"),
             "value": n_total * args.steps / elapsed,
             "unit": "env-steps/s",
@@ -245,16 +250,19 @@ def main():
             "config": {"workload": f"GR1T1 {'lower-limb (10 DOF)' if args.robot == 'lower_limb' else 'full body (32 DOF, tree kernel)'}, {'rough-terrain curriculum heightfield 10x20 tiles + 121-pt height scan' if args.terrain == 'rough' else 'flat plane'}, "
                                    f"{n_local} envs/GPU, decimation 10 @ dt 0.002, DR+noise+push on, action latency 5 sub-steps, random actions U[clip_min,clip_max]",
                        "envs_per_gpu": n_local, "global_envs": n_total, "parallelism": f"env-sharded x{world} (no data-path collective)",
-                       "finite_outputs": finite, "prespin_ms": prespin},
+                       "finite_outputs": finite, "prespin_ms": prespin,
+                       "rigid_body_states_published": bool(cfg.env.publish_rigid_body_states),   # (SURVEY 8d prices the tensor as an optional surcharge: off here, on by default in the env; GRX_BENCH_RBS=1 measures with it)
+                       "layout": layout},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per * n_local,
-                         "kernel": ("grx_step_kernel_quad" if n_local <= 4096 else "grx_step_kernel") if args.robot == "lower_limb" else "grx_step_tree", "kernel_ms": kern_ms, "launches_timed": launches,
+                         "kernel": layout["kernel"], "kernel_ms": kern_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_env_step": bytes_per,
                          "valu_issue_frac": (valu_insts / (kern_ms * 1e-3) / VALU_ISSUE_PEAK) if (valu_insts and kern_ms > 0) else None,
                          "valu_insts_per_launch": valu_insts, "valu_issue_peak_per_s": VALU_ISSUE_PEAK, "valu_source": valu_src,
-                         "note": ("instruction-issue bound at this batch size (one wave per SIMD, DESIGN.md sections 4.1 and 5); HBM is the contractual roofline"
-                                  if args.robot == "lower_limb" else "tree kernel (a lane group per env, a chain per lane): instruction-issue bound, two waves per CU (DESIGN.md section 4.3)")},
+                         "note": (f"instruction-issue bound at this batch size ({layout['lanes_per_env']} lanes per env, {layout['waves_per_block']} waves per {layout['envs_per_block']}-env block, "
+                                  f"{layout['num_blocks']} blocks: DESIGN.md sections 4.1 and 5); HBM is the contractual roofline"
+                                  if args.robot == "lower_limb" else "tree kernel (a lane group per env, a chain per lane): instruction-issue bound (DESIGN.md section 4.3); HBM is the contractual roofline")},
         }
         if world == 1 and not args.no_cpu_baseline:
             steps = args.cpu_steps

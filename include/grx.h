@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 3
+#define GRX_ABI_VERSION 4
 
 #define GRX_MAX_BODIES 36   /* moving bodies after merging fixed joints (base + DOFs) */
 #define GRX_MAX_DOFS 32
@@ -135,6 +135,9 @@ typedef struct grx_model {
     /* per-DOF properties (URDF <limit>, legged_robot.py:582-616) */
     float dof_lower[GRX_MAX_DOFS], dof_upper[GRX_MAX_DOFS];
     float dof_vel_limit[GRX_MAX_DOFS], dof_effort[GRX_MAX_DOFS];
+    float dof_armature[GRX_MAX_DOFS];        /* joint-space armature [kg m^2], added to the diagonal of the joint-space inertia: asset_options.armature
+                                                with use_physx_armature (legged_robot.py:958, legged_robot_config.py:125: 0 for the registered
+                                                tasks; isaacgym docs struct_py.html AssetOptions.armature, dof_props['armature']) */
     /* collision spheres (URDF primitives -> spheres, DESIGN.md "contact geometry") */
     int32_t num_spheres;
     int32_t sph_body[GRX_MAX_SPHERES];
@@ -318,6 +321,8 @@ typedef enum grx_tensor_id {
     GRX_T_RIGID_BODY_STATES,  /* f32 (N, GRX_MAX_LINKS, 13) p3 q4(xyzw) v3 w3 of every URDF link frame, world axes, after the last
                                  sub-step: gym.acquire_rigid_body_state_tensor (legged_robot.py:113,134); written only with
                                  grx_config.publish_rigid_body_states */
+    GRX_T_AVG_FEET_SPEED_RPY, /* f32 (N, 2, 3) sub-step averaged |angular velocity| of the foot links, world axes: avg_feet_speed_rpy
+                                 (legged_robot_fftai.py:34, 81, 88, 144); no active reward term reads it */
     GRX_NUM_TENSORS
 } grx_tensor_id;
 
@@ -349,6 +354,9 @@ typedef struct grx_step_args {
                                   acted on until after env.step() (ppo.py:160-161, 194) -- without a copy per step */
     int64_t stats_slot;        /* OUT: row of GRX_T_EPISODE_STATS_HISTORY that holds extras["episode"] of THIS step (complete once
                                   a later step has been enqueued, or after grx_flush_stats) */
+    int64_t stats_seq;         /* OUT: this step's place in the handle's launch sequence (steps, resets and debug steps each take
+                                  one): stats_slot = stats_seq % GRX_STATS_HISTORY, and the row is overwritten once
+                                  grx_stats_seq() - stats_seq exceeds GRX_STATS_HISTORY */
 } grx_step_args;
 
 /* create / destroy.  device_id: HIP device ordinal. */
@@ -381,8 +389,13 @@ int grx_set_state_indexed(grx_handle h, const int32_t* env_ids, int32_t n, const
 
 /* The episode statistics of a step (per-block partial sums) are reduced by the NEXT step's kernel -- one launch per policy
  * step, no host synchronisation.  grx_flush_stats reduces those of the LAST enqueued step now (one small kernel), so that
- * GRX_T_EPISODE_STATS and that step's row of GRX_T_EPISODE_STATS_HISTORY are current in stream order. */
+ * GRX_T_EPISODE_STATS and that step's row of GRX_T_EPISODE_STATS_HISTORY are current in stream order.
+ * Steps and resets RECORDED into a HIP graph (stream capture) carry that reduction with them as a second small kernel: a
+ * replayed launch cannot rely on its successor, so every replay leaves the statistics current. */
 int grx_flush_stats(grx_handle h, void* stream);
+
+/* launch number of the last launch of this handle that wrote statistics rows (see grx_step_args.stats_seq) */
+int grx_stats_seq(grx_handle h, int64_t* out);
 
 /* grx_flush_stats, then copy GRX_T_EPISODE_STATS (GRX_NUM_REWARD_TERMS + 2 floats) to host (synchronises the stream) */
 int grx_episode_stats(grx_handle h, float* host_out, void* stream);
@@ -392,6 +405,18 @@ int grx_episode_stats(grx_handle h, float* host_out, void* stream);
  * enable: 0 = stop, 1 = time every launch, n > 1 = time every n-th launch (an event pair costs the
  * stream several microseconds of serialisation, which matters next to an 80 us kernel). */
 int grx_kernel_time_ms(grx_handle h, int enable, float* avg_ms, int64_t* launches);
+
+/* What grx_step launches for this handle -- picked at grx_create from the LOCAL batch size or pinned by
+ * GRX_WAVES_PER_BLOCK / GRX_LANES_PER_ENV / GRX_QUAD_WAVES / GRX_TREE: reports name the kernel that ran instead of guessing it
+ * (bench.py's roofline.kernel), and rank-count invariance can be pinned to one layout. */
+typedef struct grx_layout_info {
+    int32_t lanes_per_env;     /* 2: a lane per leg; 4: a lane pair per leg (grx_quad.hip); 8: the tree kernel's lane group; 1: generic */
+    int32_t waves_per_block;   /* 1, 2, 4 or 8 (the pipelines of grx_wavepipe.h); tree kernel: 2; generic: 1 */
+    int32_t envs_per_block;
+    int32_t num_blocks;
+    char kernel[64];           /* symbol as rocprofv3 --kernel-trace prints it, e.g. "grx_step_kernel_quad<true, 8>" */
+} grx_layout_info;
+int grx_layout(grx_handle h, grx_layout_info* out);
 
 /* Spin (no blocking system call) until every step enqueued through this handle has finished on the GPU.
  * The library also bounds the host's run-ahead to 256 policy steps with the same progress word (host-pinned: every step

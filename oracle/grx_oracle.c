@@ -620,7 +620,7 @@ static int aba(const struct grx_sim* s, const env_t* e, const kin_t* k, const re
         memset(&S, 0, sizeof S);
         for (int i = 0; i < 3; ++i) S.v[i] = m->joint_axis[b][i];
         sm_mulv(&IA[b], &S, &U[b]);
-        real d = 0, sp = 0;
+        real d = m->dof_armature[b - 1], sp = 0;   /* joint-space armature (asset_options.armature, legged_robot_config.py:125) */
         for (int i = 0; i < 6; ++i) { d += S.v[i] * U[b].v[i]; sp += S.v[i] * pA[b].v[i]; }
         dinv[b] = 1 / d;
         u[b] = tau[b - 1] - sp;
@@ -1228,6 +1228,7 @@ int gro_step(grx_handle s, grx_step_args* args, void* stream) {
     }
     stats_file(s, cnt);
     args->stats_slot = s->seq & (GRX_STATS_HISTORY - 1);
+    args->stats_seq = s->seq;
     s->nsteps++;
     publish(s);
     return bad ? fail(GRX_ERR_INVALID_ARGUMENT, "gro_step: articulated inertia not SPD (diverged state)") : GRX_OK;
@@ -1464,6 +1465,7 @@ static void publish(struct grx_sim* s) {
     PUB(GRX_T_FEET_LAND_TIME, 2, e->land_time[j]);
     PUB(GRX_T_AVG_FEET_FORCE, 2, e->avg_force[j]);
     PUB(GRX_T_AVG_FEET_SPEED, 6, e->avg_speed[j / 3][j % 3]);
+    PUB(GRX_T_AVG_FEET_SPEED_RPY, 6, e->avg_rpy[j / 3][j % 3]);   /* legged_robot_fftai.py:81, 88 */
     PUB(GRX_T_MEASURED_HEIGHTS, nh, e->heights[j]);
     PUB(GRX_T_ENV_ORIGINS, 3, e->origin[j]);
     PUB(GRX_T_MOTOR_STRENGTH, nd, e->motor_strength[j]);
@@ -1496,7 +1498,7 @@ int gro_tensor(grx_handle s, int id, grx_tensor_desc* d) {
     case GRX_T_ENV_ORIGINS:
         desc_set(d, s->scratch[id], GRX_F32, 2, N, 3, 1); break;
     case GRX_T_ROOT_STATES: desc_set(d, s->scratch[id], GRX_F32, 2, N, 13, 1); break;
-    case GRX_T_FEET_CONTACT_FORCE: case GRX_T_FEET_POS: case GRX_T_AVG_FEET_SPEED:
+    case GRX_T_FEET_CONTACT_FORCE: case GRX_T_FEET_POS: case GRX_T_AVG_FEET_SPEED: case GRX_T_AVG_FEET_SPEED_RPY:
         desc_set(d, s->scratch[id], GRX_F32, 3, N, 2, 3); break;
     case GRX_T_FEET_HEIGHT: case GRX_T_FEET_AIR_TIME: case GRX_T_FEET_LAND_TIME: case GRX_T_AVG_FEET_FORCE:
         desc_set(d, s->scratch[id], GRX_F32, 2, N, 2, 1); break;
@@ -1557,6 +1559,7 @@ int gro_episode_stats(grx_handle s, float* host_out, void* stream) {
 
 const char* gro_last_error(void) { return g_err; }
 int gro_abi_version(void) { return GRX_ABI_VERSION; }
+int gro_stats_seq(grx_handle s, int64_t* out) { if (!s || !out) return fail(GRX_ERR_INVALID_ARGUMENT, "gro_stats_seq: null argument"); *out = s->seq; return GRX_OK; }
 int gro_real_size(void) { return (int)sizeof(real); }
 
 static const char* k_term_names[NT] = {
@@ -1764,7 +1767,7 @@ int gro_debug_inverse_dynamics(grx_handle s, int le, const double* qdd_in, const
         for (int i = 0; i < 6; ++i) f[b].v[i] = Ia.v[i] + t.v[i];
     }
     for (int b = s->nb - 1; b >= 1; --b) {
-        real tq = 0;
+        real tq = m->dof_armature[b - 1] * (real)qdd_in[b - 1];
         for (int i = 0; i < 3; ++i) tq += m->joint_axis[b][i] * f[b].v[i];
         tau_out[b - 1] = tq;
         sv6 fp;

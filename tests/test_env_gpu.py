@@ -87,6 +87,42 @@ def test_steps_recorded_into_a_hip_graph_neither_pace_nor_hang():
     hip.step(act, 0.0, 2 + n); hip.wait_idle()            # eager steps after a replay still pace and complete
 
 
+@pytest.mark.parametrize("steps_in_graph", [1, 3])
+def test_episode_statistics_survive_graph_replays(steps_in_graph):
+    """a step recorded into a HIP graph cannot leave its episode statistics to 'the next launch' -- on a replay its
+    predecessor in execution order is itself.  Recorded steps carry their own reduction: after any number of replays of a
+    one-step (or odd-length) graph GRX_T_EPISODE_STATS and the step's history row equal those of the same steps issued eagerly."""
+    from tests.helpers import make_cfg, make_sims
+    cfg = make_cfg()
+    cfg.env.episode_length_s = 0.1                       # 5 steps: time-outs (finished episodes) inside the window
+    hip, _ = make_sims(cfg, 256)
+    ref, _ = make_sims(cfg, 256)
+    act = torch.full((256, hip.num_dofs), 0.05, device="cuda:0")
+    for s in (hip, ref):
+        s.reset_all(); s.step(act, 0.0, 1)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(steps_in_graph):
+            hip.step(act, 0.0, 2 + k)
+    seen = set()
+    for rep in range(5):
+        g.replay()
+        for k in range(steps_in_graph):
+            ref.step(act, 0.0, 2 + k)
+        torch.cuda.synchronize()
+        a, b = hip.tensor("EPISODE_STATS").cpu(), ref.tensor("EPISODE_STATS").cpu()      # (ref: flushed; hip: current by the recorded reduction)
+        assert torch.equal(a, b), (rep, a, b)
+        assert torch.equal(hip.tensor("EPISODE_STATS_HISTORY")[hip.last_stats_slot].cpu(), a)
+        seen.add(tuple(a.tolist()))
+    NT = hip.tensor("EPISODE_STATS").numel() - 2
+    assert float(ref.tensor("EPISODE_STATS")[NT]) > 0 and len(seen) >= 2      # episodes did end, and the means moved between replays
+    hip.step(act, 0.0, 50); ref.step(act, 0.0, 50)                             # eager launches after the replays keep agreeing
+    assert torch.equal(hip.tensor("EPISODE_STATS").cpu(), ref.tensor("EPISODE_STATS").cpu())
+    for name in ("DOF_POS", "OBS", "EPISODE_LENGTH", "EPISODE_SUMS"):
+        assert torch.equal(hip.tensor(name), ref.tensor(name)), name
+
+
 def test_bench_line_has_the_contract_fields():
     """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command): one JSON line with BASELINE.json's metric, the
     roofline object (HBM fraction + the VALU issue fraction that actually bounds the kernel) and the cpu_baseline object."""
@@ -99,6 +135,10 @@ def test_bench_line_has_the_contract_fields():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["metric"] == "env-steps/sec GR1T1 rough-terrain @4096 envs" and j["unit"] == "env-steps/s" and j["n_gpus"] == 1
+    # the line names what RAN: grx_layout() of the handle, not a guess from the batch size
+    lay = j["config"]["layout"]
+    assert j["roofline"]["kernel"] == lay["kernel"] == "grx_step_kernel_quad<true, 8, false>" and lay["lanes_per_env"] == 4 and lay["waves_per_block"] == 8
+    assert "4 lanes per env, 8 waves per 16-env block" in j["roofline"]["note"] and j["config"]["rigid_body_states_published"] is False
     assert j["steps"] == 20 and j["warmup"] == 5 and j["higher_is_better"] and j["scaling"] == "weak" and j["vs_baseline"] is None
     assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"] and j["config"]["finite_outputs"]
     assert abs(j["value"] - 4096 * 20 / (j["ms_per_step"] * 20e-3)) < 1e-3 * j["value"]

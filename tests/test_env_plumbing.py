@@ -109,3 +109,38 @@ def test_full_body_task_vec_env_surface(oracle_backend):
     o, p, r, d, ex = env.step(torch.zeros(16, 32))
     assert torch.isfinite(o).all() and torch.isfinite(p).all() and torch.isfinite(r).all() and r.abs().sum() > 0
     assert env.rigid_body_states.shape == (16, env.num_bodies, 13) and env.dof_pos.shape == (16, 32)
+
+
+def test_reference_runner_log_loop_over_extras_episode(oracle_backend):
+    """the reference's OnPolicyRunner.log (rsl_rl on_policy_runner.py:217-233) walks the ep_infos it collected and
+    ASSIGNS into them (`ep_info[key] = ep_info[key].unsqueeze(0)`); extras["episode"] must take that -- it is a dict, as in the
+    reference -- and the guard against an overwritten statistics row counts the handle's launches (steps and reset_idx alike)."""
+    env, _ = task_registry.make_env("GR1T1", args=_args(), env_cfg=GR1T1Cfg())
+    env.reset()
+    ep_infos = []
+    for i in range(6):
+        _, _, _, _, infos = env.step(torch.zeros(64, 10))
+        assert isinstance(infos["episode"], dict) and "rew_action_diff" in infos["episode"]
+        ep_infos.append(infos["episode"])
+        if i == 2:
+            env.reset_idx(torch.tensor([1, 5]))      # a launch of its own between two steps
+    device = "cpu"
+    for key in ep_infos[0]:                          # the reference's loop, verbatim in structure
+        infotensor = torch.tensor([], device=device)
+        for ep_info in ep_infos:
+            if not isinstance(ep_info[key], torch.Tensor):
+                ep_info[key] = torch.Tensor([ep_info[key]])
+            if len(ep_info[key].shape) == 0:
+                ep_info[key] = ep_info[key].unsqueeze(0)
+            infotensor = torch.cat((infotensor, ep_info[key].to(device)))
+        assert infotensor.shape == (6,) and torch.isfinite(infotensor).all()
+        assert torch.mean(infotensor).ndim == 0
+    assert ep_infos[0]["rew_action_diff"].shape == (1,)      # the caller's assignment stuck
+    # rows are overwritten after GRX_STATS_HISTORY launches -- resets count: the stale handle raises instead of returning foreign data
+    from wiki_grx_gym_amd import _capi
+    old = env.step(torch.zeros(64, 10))[4]["episode"]
+    for _ in range(_capi.STATS_HISTORY // 2):
+        env.step(torch.zeros(64, 10))
+        env.reset_idx(torch.tensor([0]))
+    with pytest.raises(RuntimeError, match="overwritten"):
+        old["rew_action_diff"]

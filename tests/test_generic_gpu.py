@@ -6,11 +6,12 @@ a chain of the tree per lane -- what runs the 32-DOF full body of BASELINE.json 
 import pytest
 import torch
 
-from tests.helpers import lockstep, make_cfg, make_sims, random_actions
+from tests.helpers import lockstep, make_cfg, make_sims, random_actions, tensor_diff
 from tests.test_hip_parity import assert_phys, physics_lockstep
 
 pytestmark = pytest.mark.gpu
 KERNELS = pytest.mark.parametrize("kernel", ["tree", "generic"])
+FULL_BODY_SCALE = 3.0   # x the lower-limb budgets of tests/test_hip_parity.PHYS (1.5 x what round 4 observed on MI355X: see assert_phys)
 
 
 def pick(monkeypatch, kernel):
@@ -25,7 +26,7 @@ def test_lower_limb_through_the_generic_kernel(kernel, monkeypatch):
     hip, ora = make_sims(cfg, 192, seed=1)
     hip.reset_all(); ora.reset_all()
     worst = physics_lockstep(hip, ora, cfg, steps=20)
-    assert_phys(worst, exact_frac=6e-3, scale=4.0)   # stair edges: one env in 192 may take the other side of a riser
+    assert_phys(worst, exact_frac=6e-3, scale=2.8, hf=True)   # stair edges: one env in 192 may take the other side of a riser (observed: DOF_POS 1.82 of its budget)
     hip.close()
     cfg = make_cfg()
     hip, ora = make_sims(cfg, 128)
@@ -67,10 +68,38 @@ def test_full_body_32_dof_against_the_oracle(kernel, monkeypatch):
     # one policy step at a time from the oracle's state (the wrist joints -- 0.1 kg links on kp = 10 actuators -- sit
     # close to the explicit integrator's stability limit and amplify fp32 rounding within a few free-running steps)
     worst = physics_lockstep(hip, ora, cfg, steps=25, scale=0.3)
-    # outlier FRACTIONS are bounded as for the lower-limb model; the maxima are not (a wrist that goes unstable in
-    # one of the two fp32 integrations differs by O(1) rad/s that step), so only kinematic quantities get a max bound
-    assert_phys(worst, exact_frac=1e-2, scale=5.0)
+    # round 4: with the joint-space armature of GR1T1FullBodyCfg (0.01 kg m^2: the wrists' explicit damper was two orders of
+    # magnitude beyond its stability limit, envs/config.py) the maxima are bounded like the lower-limb model's
+    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE)
     assert worst["FEET_POS"][0] < 1e-3 and worst["FEET_HEIGHT"][0] < 1e-3 and worst["REW"][0] < 1e-2, worst
+    assert worst["DOF_VEL"][0] < 0.5 and worst["DOF_POS"][0] < 5e-3, (worst["DOF_VEL"], worst["DOF_POS"])
+    assert torch.isfinite(hip.tensor("OBS")).all() and torch.isfinite(hip.tensor("REW")).all()
+    hip.close()
+
+
+@KERNELS
+def test_full_body_rough_terrain_against_the_oracle(kernel, monkeypatch):
+    """Config 5's workload against the oracle: the 32-DOF body on the rough-terrain curriculum heightfield,
+    domain randomisation, pushes and observation noise on, 320 envs (not a multiple of the tree kernel's 16-env block), one
+    policy step at a time from the oracle's state through flight, landing and falls."""
+    pick(monkeypatch, kernel)
+    cfg = make_cfg("GR1T1Full", noise=True, dr=True, push=True, terrain="heightfield")
+    cfg.domain_rand.push_interval_s = 0.3
+    hip, ora = make_sims(cfg, 320, seed=1)
+    assert hip.layout()["kernel"].startswith("grx_step_tree<true>" if kernel == "tree" else "grx_step_generic<true>")
+    assert torch.equal(hip.tensor("TERRAIN_TYPES").cpu(), ora.tensor("TERRAIN_TYPES"))
+    hip.reset_all(); ora.reset_all()
+    seen = {"contact": 0, "reset": 0}
+
+    def check(s, h, o):
+        seen["contact"] += int(o.tensor("FEET_CONTACT").sum())
+        seen["reset"] += int(o.tensor("RESET").sum())
+    worst = physics_lockstep(hip, ora, cfg, steps=40, scale=0.5, check=check)
+    assert seen["contact"] > 2000 and seen["reset"] > 0, seen
+    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE, hf=True)
+    assert worst["FEET_POS"][0] < 5e-3 and worst["DOF_VEL"][0] < 1.0, worst
+    mh = tensor_diff(hip.tensor("MEASURED_HEIGHTS"), ora.tensor("MEASURED_HEIGHTS"))
+    assert mh[1] < 2e-3
     assert torch.isfinite(hip.tensor("OBS")).all() and torch.isfinite(hip.tensor("REW")).all()
     hip.close()
 

@@ -18,39 +18,60 @@ from wiki_grx_gym_amd.envs import build_config
 
 pytestmark = pytest.mark.gpu
 
+# The fixtures go through the post-physics half of EVERY step kernel the library launches (grx_debug_post_physics runs the DBG
+# instantiation of the handle's own layout): the one-wave kernel of large batches, and the pipelines BASELINE.json's configs 2-4
+# run -- lane pairs with four / eight waves (8192-16384 envs per GPU), lane quads with four / eight waves (<= 4096 envs per GPU) --
+# where the reward inputs cross LDS to two reward waves, reset_idx's draws come from the foot wave, the termination flag from the
+# base-lump wave and the height block from the helper waves.
+LAYOUTS = pytest.mark.parametrize("layout", [1, 4, 8, "quad4", "quad"])
+KERNEL_OF = {1: ("grx_step_kernel<", 2, 1), 4: ("grx_step_kernel<", 2, 4), 8: ("grx_step_kernel<", 2, 8),
+             "quad4": ("grx_step_kernel_quad<", 4, 4), "quad": ("grx_step_kernel_quad<", 4, 8)}
 
-def make_hip(cfg, N=64):
+
+def make_hip(cfg, N=64, layout=None, monkeypatch=None):
+    from tests.test_hip_parity import set_layout
     from wiki_grx_gym_amd.sim import HipSim
+    if layout is not None:
+        set_layout(monkeypatch, layout)
     c, keep, meta = build_config.build(cfg, cfg.sim.dt, N)
-    return HipSim(c, "cuda:0", keep), meta
+    sim = HipSim(c, "cuda:0", keep)
+    if layout is not None:   # the handle really runs (and debug-injects into) the kernel this case names
+        lay = sim.layout()
+        name, lpe, waves = KERNEL_OF[layout]
+        assert lay["kernel"].startswith(name) and lay["lanes_per_env"] == lpe and lay["waves_per_block"] == waves, lay
+    return sim, meta
 
 
-def test_pipeline_two_steps_on_the_hip_kernel():
+@LAYOUTS
+def test_pipeline_two_steps_on_the_hip_kernel(layout, monkeypatch):
     cfg = make_cfg(noise=True, dr=False)
-    sim, meta = make_hip(cfg)
+    sim, meta = make_hip(cfg, layout=layout, monkeypatch=monkeypatch)
     og.check_pipeline_two_steps(sim, cfg, meta, 1e-4)
 
 
-def test_every_active_reward_term_on_the_hip_kernel():
+@LAYOUTS
+def test_every_active_reward_term_on_the_hip_kernel(layout, monkeypatch):
     cfg = make_cfg(noise=False, dr=False)
-    sim, _ = make_hip(cfg)
+    sim, _ = make_hip(cfg, layout=layout, monkeypatch=monkeypatch)
     og.check_every_reward_term(sim, cfg, 1e-4)
 
 
-def test_inactive_reward_terms_on_the_hip_kernel():
+@LAYOUTS
+def test_inactive_reward_terms_on_the_hip_kernel(layout, monkeypatch):
     cfg, inactive = og.inactive_terms_cfg()
-    sim, _ = make_hip(cfg)
+    sim, _ = make_hip(cfg, layout=layout, monkeypatch=monkeypatch)
     og.check_inactive_reward_terms(sim, cfg, inactive, 1e-4)
 
 
-def test_injected_resets_are_applied_like_the_oracle():
+@LAYOUTS
+def test_injected_resets_are_applied_like_the_oracle(layout, monkeypatch):
     """apply_reset = 1: rows the fixture resets (tilt, time-out, terminating contact) get the masked in-kernel
     reset_idx; compared with the oracle's reset on the same records (same Philox streams)."""
     from oracle.binding import OracleSim
     d = np.load(og.os.path.join(og.G, "pipeline.npz"))
     N = d["s0_in_root"].shape[0]
     cfg = make_cfg(noise=False, dr=False)
-    sim, _ = make_hip(cfg, N)
+    sim, _ = make_hip(cfg, N, layout=layout, monkeypatch=monkeypatch)
     c, keep, _ = build_config.build(cfg, cfg.sim.dt, N)
     ora = OracleSim(c, "f32", keep)
     arr = og.states_from(d, "s0_in_", N)
@@ -91,14 +112,16 @@ def test_oracle_pin_torques_on_this_box(precision, tol):
     og.test_clip_actions_and_torques(precision, tol)
 
 
-def test_quat_fixture_on_the_hip_kernel():
+@LAYOUTS
+def test_quat_fixture_on_the_hip_kernel(layout, monkeypatch):
     """G-1 (tests/golden/quat.npz) through the step kernel's post-physics half: quat_rotate_inverse on 256 random orientations."""
     cfg = make_cfg(noise=False, dr=False)
-    sim, _ = make_hip(cfg, 256)
+    sim, _ = make_hip(cfg, 256, layout=layout, monkeypatch=monkeypatch)
     og.check_quat_rotate_inverse(sim, 1e-4)
 
 
-def test_quat_apply_yaw_fixture_selects_the_height_scan_cells():
+@LAYOUTS
+def test_quat_apply_yaw_fixture_selects_the_height_scan_cells(layout, monkeypatch):
     """G-1's quat_apply_yaw column on the HIP height scan (legged_robot.py:1235-1274 -> math.py:38-42): env i carries the fixture's
     quaternion q_i and the scan's point i is the fixture's v_i (x, y), so measured_heights[i, i] reads the raster cell under
     root_xy + quat_apply_yaw(q_i, v_i).  The raster encodes its own indices (h[r, c] = r * 181 + c, increasing both ways: the min of
@@ -118,7 +141,10 @@ def test_quat_apply_yaw_fixture_selects_the_height_scan_cells():
     for k in range(nh):
         c.height_points[k][0], c.height_points[k][1] = float(d["v"][k, 0] * scale), float(d["v"][k, 1] * scale)
     c.border_size = 0.0
+    from tests.test_hip_parity import set_layout
+    set_layout(monkeypatch, layout)   # (heightfield kernels: the scan runs over one wave, or over the four / seven waves of the pipelines)
     sim = HipSim(c, "cuda:0", keep)
+    assert sim.layout()["waves_per_block"] == KERNEL_OF[layout][2] and sim.layout()["kernel"].startswith(KERNEL_OF[layout][0] + "true")
     arr, _ = og.quat_states(N)
     for i in range(N):
         arr[i].root[0], arr[i].root[1], arr[i].root[2] = 9.0, 9.0, 100.0

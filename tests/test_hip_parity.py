@@ -25,7 +25,7 @@ PHYS = {  # name: (atol, rtol, allowed fraction outside)
     "DOF_POS": (1e-4, 1e-4, 2e-3), "ROOT_STATES": (2e-4, 2e-4, 1e-2), "FEET_POS": (1e-4, 1e-4, 2e-3),
     "DOF_VEL": (5e-3, 5e-3, 1e-2), "BASE_LIN_VEL": (2e-3, 2e-3, 5e-3), "BASE_ANG_VEL": (5e-3, 5e-3, 1e-2),
     "PROJECTED_GRAVITY": (1e-4, 1e-4, 5e-3), "TORQUES": (5e-2, 5e-3, 1e-2), "FEET_CONTACT_FORCE": (1.0, 2e-2, 2e-2), "CONTACT_FORCES": (1.0, 2e-2, 2e-2),
-    "AVG_FEET_FORCE": (1.0, 2e-2, 2e-2), "AVG_FEET_SPEED": (2e-3, 5e-3, 1e-2), "FEET_HEIGHT": (1e-4, 1e-4, 2e-3),
+    "AVG_FEET_FORCE": (1.0, 2e-2, 2e-2), "AVG_FEET_SPEED": (2e-3, 5e-3, 1e-2), "AVG_FEET_SPEED_RPY": (5e-3, 5e-3, 1e-2), "FEET_HEIGHT": (1e-4, 1e-4, 2e-3),
     "REW": (2e-3, 2e-3, 1e-2), "ACTIONS": (0, 0, 0), "COMMANDS": (1e-6, 0, 0), "FEET_AIR_TIME": (1e-6, 0, 2e-3),
     "FEET_LAND_TIME": (1e-6, 0, 2e-3), "LAST_ACTIONS": (0, 0, 0), "LAST_DOF_VEL": (5e-3, 5e-3, 1e-2),
     "BASE_HEIGHTS_OFFSET": (5e-4, 1e-4, 2e-3),
@@ -58,8 +58,37 @@ def phys_diff(hip, ora, worst):
         worst[name] = (0.0, max(w[1], float((a != b).double().mean())))
 
 
-def assert_phys(worst, exact_frac=5e-3, scale=1.0):
-    bad = [(n, worst[n]) for n, (_, _, fr) in PHYS.items() if worst[n][1] > fr * scale]
+# On a heightfield FEET_HEIGHT and BASE_HEIGHTS_OFFSET are means over the 121-point height scan, whose points are QUANTISED
+# (min of three raster corners at a truncated cell index, legged_robot.py:1263-1272): a point within fp32 rounding of a cell edge
+# reads the neighbouring cell (< 0.2 % of the points, asserted where the scan is compared), and every env that holds one such
+# point differs in both means.  Their budget there is three times the plane's.
+HF_BUDGET = {"FEET_HEIGHT": 3.0, "BASE_HEIGHTS_OFFSET": 3.0}
+
+
+def report_phys(worst, exact_frac, scale, hf=False):
+    """What the budgets are measured against: the observed outlier fraction of every tensor as a multiple of its budget at
+    scale = 1 (VERDICT r3 weak #3).  Printed (pytest -s / on failure) and appended to gpurun_out/phys_fracs.jsonl."""
+    import json
+    import os
+    need = {n: worst[n][1] / (fr * (HF_BUDGET.get(n, 1.0) if hf else 1.0)) for n, (_, _, fr) in PHYS.items() if fr > 0 and n in worst}
+    need.update({n: worst[n][1] / exact_frac for n in CMP_EXACT if n in worst})
+    top = sorted(need.items(), key=lambda kv: -kv[1])[:3]
+    rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "scale": scale, "exact_frac": exact_frac,
+           "needed_scale": round(max(need.values()), 3), "top": [(n, round(v, 3), worst[n][1]) for n, v in top]}
+    print("assert_phys:", json.dumps(rec))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/phys_fracs.jsonl", "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
+def assert_phys(worst, exact_frac=5e-3, scale=1.0, hf=False):
+    """Every tensor's outlier fraction within its budget x scale.  The scales in this suite are 1.5 x the fraction observed on
+    MI355X (gpurun_out/phys_fracs.jsonl of round 4, copied to profiles/r04_phys_fracs.jsonl), never below 1."""
+    report_phys(worst, exact_frac, scale, hf)
+    bad = [(n, worst[n]) for n, (_, _, fr) in PHYS.items() if worst[n][1] > fr * scale * (HF_BUDGET.get(n, 1.0) if hf else 1.0)]
     bad += [(n, worst[n]) for n in CMP_EXACT if worst[n][1] > exact_frac * scale]
     assert not bad, bad
 
@@ -177,7 +206,7 @@ def test_one_step_parity_dr_noise_push():
     for name in ("ROOT_STATES", "DOF_POS", "COMMANDS"):      # Philox reset streams agree
         assert tensor_diff(hip.tensor(name), ora.tensor(name))[0] < 2e-6, name
     worst = physics_lockstep(hip, ora, cfg, steps=40, noise=True)
-    assert_phys(worst, scale=2.5)     # low-friction envs slide: stick/slip transitions add outliers
+    assert_phys(worst, scale=1.5)     # low-friction envs slide: stick/slip transitions add outliers (observed: 0.98 of the budget)
 
 
 def test_internal_noise_stream_matches():
@@ -213,7 +242,7 @@ def test_one_step_parity_rough_terrain(task, mesh):
     worst = physics_lockstep(hip, ora, cfg, steps=50)
     # stairs / obstacle edges are discontinuities of the bilinear height query: a sphere within
     # rounding of an edge changes its force -> larger outlier budget than on the plane
-    assert_phys(worst, scale=3.0)
+    assert_phys(worst, scale=2.6, hf=True)   # (observed: DOF_POS 1.72 of its budget -- 0.34 % of the joint positions)
     mh = tensor_diff(hip.tensor("MEASURED_HEIGHTS"), ora.tensor("MEASURED_HEIGHTS"))
     assert mh[1] < 2e-3
 
@@ -363,7 +392,7 @@ def test_every_wave_layout_matches_the_oracle(waves, monkeypatch):
     hip, ora = make_sims(cfg, 320, seed=1)
     hip.reset_all(); ora.reset_all()
     worst = physics_lockstep(hip, ora, cfg, steps=10)
-    assert_phys(worst, exact_frac=6e-3, scale=3.0)
+    assert_phys(worst, exact_frac=6e-3, scale=1.0, hf=True)   # (observed: 0.31 of the budget in every layout)
     hip.close()
     cfg = make_cfg()
     hip, ora = make_sims(cfg, 256)
@@ -382,7 +411,7 @@ def test_tail_block_and_small_batches(layout, monkeypatch):
         hip, ora = make_sims(cfg, N)
         hip.reset_all(); ora.reset_all()
         worst = physics_lockstep(hip, ora, cfg, steps=12)
-        assert_phys(worst, exact_frac=0.04, scale=4.0)
+        assert_phys(worst)   # (observed: no outlier at all)
         hip.close()
 
 
@@ -440,7 +469,7 @@ def test_self_collision_matches_the_oracle(task, waves, monkeypatch):
         assert float(h.sum(1).abs().max()) < 1e-3 * max(1.0, float(h.abs().max()))       # internal: sums to zero per env
         # (a foot pressed on by the other leg reports contact, as the reference's net contact force would: legged_robot_fftai.py:110)
     assert seen > N // 2, seen                                   # most envs did have their legs in contact
-    assert_phys(worst, scale=3.0)
+    assert_phys(worst)   # (observed: no outlier at all)
     hip.close()
 
 
@@ -484,7 +513,7 @@ def test_reset_idx_and_indexed_setters_match_the_oracle():
         a = hip.tensor(n).cpu()
         assert torch.equal(a[keep], before[n].cpu()[keep]) and torch.equal(a[ids], want[ids]) and torch.equal(a, ora.tensor(n)), n
     worst = physics_lockstep(hip, ora, cfg, steps=2, scale=0.3, start=20)     # and the env keeps stepping from there
-    assert_phys(worst, scale=3.0)
+    assert_phys(worst, scale=1.25, hf=True)   # (observed: 0.83)
 
 
 @pytest.mark.parametrize("delay", [0.0, 3.7, 9.2, 12.0])
@@ -495,7 +524,7 @@ def test_action_latency_real_valued(delay):
     hip, ora = make_sims(cfg, 256, seed=3)
     hip.reset_all(); ora.reset_all()
     worst = physics_lockstep(hip, ora, cfg, steps=6, scale=0.6, delay=delay)
-    assert_phys(worst, scale=3.0)
+    assert_phys(worst, hf=True)   # (observed: <= 0.04 of the budget)
     assert worst["TORQUES"][1] <= 3e-2 and worst["ACTIONS"][0] == 0
     # and the latency really is in play: the same step with delay 0 gives different torques
     sync_state(hip, ora)
@@ -594,3 +623,52 @@ def test_rigid_body_states_match_the_oracle(task, waves, monkeypatch):
         seen["reset"] += int(reset.sum())
     physics_lockstep(hip, ora, cfg, steps=14, scale=0.4, check=check)
     assert seen["reset"] > 0
+
+
+def test_config4_rank_shard_matches_the_oracle(monkeypatch):
+    """BASELINE.json config 4 as ONE OF ITS EIGHT RANKS runs it: GR1T2, rough-terrain curriculum, 4096 envs with
+    env_offset = 7 * 4096 of 32768, the layout the library picks for that local batch by itself (lane quads, eight waves per
+    block), against an oracle built with the same offset -- terrain columns from the GLOBAL env index (legged_robot.py:1177-1180),
+    every Philox stream (reset, DR, pushes, observation noise) keyed by it."""
+    for k in ("GRX_WAVES_PER_BLOCK", "GRX_LANES_PER_ENV", "GRX_QUAD_WAVES"):
+        monkeypatch.delenv(k, raising=False)
+    from tests.helpers import make_terrain
+    N, R, W = 4096, 7, 8
+    cfg = make_cfg(task="GR1T2", terrain="heightfield", noise=True, dr=True, push=True)
+    cfg.domain_rand.push_interval_s = 0.2                    # pushes inside the window
+    ter = make_terrain(cfg, W * N, seed=1)
+    hip, ora = make_sims(cfg, N, seed=1, env_offset=R * N, total_envs=W * N, terrain=ter)
+    lay = hip.layout()
+    assert lay["kernel"] == "grx_step_kernel_quad<true, 8, false>" and lay["envs_per_block"] == 16 and lay["num_blocks"] == 256, lay
+    ty = ora.tensor("TERRAIN_TYPES")
+    assert torch.equal(hip.tensor("TERRAIN_TYPES").cpu(), ty) and int(ty.min()) >= 17 and int(ty.max()) == 19   # the LAST columns of the 20: discrete obstacles
+    for name in ("MOTOR_STRENGTH", "FRICTION", "BASE_MASS_COM", "ENV_ORIGINS"):
+        assert tensor_diff(hip.tensor(name), ora.tensor(name))[0] < 1e-6, name
+    hip.reset_all(); ora.reset_all()
+    for name in ("ROOT_STATES", "DOF_POS", "COMMANDS"):      # reset streams of envs 28672..32767
+        assert tensor_diff(hip.tensor(name), ora.tensor(name))[0] < 2e-6, name
+    seen = {"contact": 0}
+
+    def check(s, h, o):
+        seen["contact"] += int(o.tensor("FEET_CONTACT").sum())
+        a, b = h.tensor("OBS").cpu().double(), o.tensor("OBS").double()     # internal noise stream (not injected), keyed by the global index
+        assert float(((a - b).abs() > 5e-3 + 5e-3 * b.abs()).double().mean()) < 2e-2
+    worst = physics_lockstep(hip, ora, cfg, steps=14, check=check)
+    assert seen["contact"] > 4096, seen
+    assert_phys(worst, scale=2.6, hf=True)
+    hip.close()
+
+
+@pytest.mark.parametrize("waves", [1, 8, "quad"])
+def test_avg_feet_speed_rpy(waves, monkeypatch):
+    """avg_feet_speed_rpy (legged_robot_fftai.py:34, 81, 88, 144): |angular velocity| of the foot links averaged over the ten
+    sub-steps -- accumulated by wave 0 in the one-wave layout, by the foot wave in the pipelines -- against the oracle, and not zero."""
+    set_layout(monkeypatch, waves)
+    cfg = make_cfg(terrain="heightfield", dr=True, push=True)
+    hip, ora = make_sims(cfg, 256, seed=3)
+    hip.reset_all(); ora.reset_all()
+    worst = physics_lockstep(hip, ora, cfg, steps=12, scale=0.6)
+    assert worst["AVG_FEET_SPEED_RPY"][1] <= 1e-2, worst["AVG_FEET_SPEED_RPY"]
+    a = hip.tensor("AVG_FEET_SPEED_RPY").cpu()
+    assert a.shape == (256, 2, 3) and float(a.mean()) > 0.05 and torch.isfinite(a).all()
+    hip.close()

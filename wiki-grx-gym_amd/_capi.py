@@ -5,7 +5,7 @@ Field order and sizes must match the header exactly; ``grx_create`` rejects a mi
 """
 import ctypes as C
 
-GRX_ABI_VERSION = 3
+GRX_ABI_VERSION = 4
 MAX_BODIES = 36
 MAX_DOFS = 32
 MAX_SPHERES = 48
@@ -39,7 +39,7 @@ TENSOR_IDS = (
     "FEET_AIR_TIME", "FEET_LAND_TIME", "FEET_CONTACT", "AVG_FEET_FORCE", "AVG_FEET_SPEED",
     "MEASURED_HEIGHTS", "BASE_HEIGHTS_OFFSET", "EPISODE_SUMS", "REWARD_TERMS", "TERRAIN_LEVELS",
     "TERRAIN_TYPES", "ENV_ORIGINS", "MOTOR_STRENGTH", "FRICTION", "BASE_MASS_COM", "TERM_CONTACT",
-    "EPISODE_STATS", "ANCHORS", "CONTACT_FORCES", "EPISODE_STATS_HISTORY", "RIGID_BODY_STATES",
+    "EPISODE_STATS", "ANCHORS", "CONTACT_FORCES", "EPISODE_STATS_HISTORY", "RIGID_BODY_STATES", "AVG_FEET_SPEED_RPY",
 )
 T = {name: i for i, name in enumerate(TENSOR_IDS)}
 DTYPE_F32, DTYPE_U8, DTYPE_I32, DTYPE_I64 = 0, 1, 2, 3
@@ -61,6 +61,7 @@ class Model(C.Structure):
         ("base_rest_mass", f32), ("base_rest_com", f32 * 3), ("base_rest_inertia", f32 * 6),
         ("dof_lower", f32 * MAX_DOFS), ("dof_upper", f32 * MAX_DOFS),
         ("dof_vel_limit", f32 * MAX_DOFS), ("dof_effort", f32 * MAX_DOFS),
+        ("dof_armature", f32 * MAX_DOFS),
         ("num_spheres", i32),
         ("sph_body", i32 * MAX_SPHERES),
         ("sph_pos", (f32 * 3) * MAX_SPHERES),
@@ -150,7 +151,7 @@ class TensorDesc(C.Structure):
 class StepArgs(C.Structure):
     _fields_ = [("actions", C.c_void_p), ("delay_substeps", f32),
                 ("common_step_counter", i64), ("noise_uniform", C.c_void_p),
-                ("obs_out", C.c_void_p), ("pri_obs_out", C.c_void_p), ("stats_slot", i64)]
+                ("obs_out", C.c_void_p), ("pri_obs_out", C.c_void_p), ("stats_slot", i64), ("stats_seq", i64)]
 
 
 class PipelineState(C.Structure):
@@ -166,6 +167,11 @@ class PipelineState(C.Structure):
         ("heights", f32 * MAX_HEIGHT_POINTS), ("base_heights_offset", f32),
         ("episode_length", i64), ("term_contact", i32),
     ]
+
+
+class LayoutInfo(C.Structure):
+    """grx_layout_info: what grx_step launches for a handle (include/grx.h grx_layout)."""
+    _fields_ = [("lanes_per_env", i32), ("waves_per_block", i32), ("envs_per_block", i32), ("num_blocks", i32), ("kernel", C.c_char * 64)]
 
 
 def bind(lib, prefix="grx_"):
@@ -197,6 +203,10 @@ def bind(lib, prefix="grx_"):
         api["debug_post_physics"] = fn("debug_post_physics", C.c_int, H, C.POINTER(PipelineState), C.c_int, C.POINTER(StepArgs), C.c_void_p)
     if hasattr(lib, prefix + "wait_idle"):
         api["wait_idle"] = fn("wait_idle", C.c_int, H)
+    if hasattr(lib, prefix + "stats_seq"):
+        api["stats_seq"] = fn("stats_seq", C.c_int, H, C.POINTER(i64))
+    if hasattr(lib, prefix + "layout"):
+        api["layout"] = fn("layout", C.c_int, H, C.POINTER(LayoutInfo))
     if hasattr(lib, prefix + "kernel_time_ms"):
         api["kernel_time_ms"] = fn("kernel_time_ms", C.c_int, H, C.c_int, C.POINTER(C.c_float), C.POINTER(i64))
     return api
@@ -205,5 +215,5 @@ def bind(lib, prefix="grx_"):
 EXPORTED_SYMBOLS = (
     "grx_create", "grx_destroy", "grx_reset_all", "grx_step", "grx_tensor", "grx_set_state",
     "grx_episode_stats", "grx_flush_stats", "grx_reset_idx", "grx_set_state_indexed", "grx_kernel_time_ms", "grx_wait_idle", "grx_last_error", "grx_abi_version",
-    "grx_reward_term_name", "grx_debug_post_physics",
+    "grx_reward_term_name", "grx_debug_post_physics", "grx_layout", "grx_stats_seq",
 )

@@ -38,8 +38,10 @@ void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, const StepSeq
 void grx_launch_mark(const int32_t* env_ids, int n, int N, uint8_t* mask, hipStream_t stream);
 void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, const int32_t* env_ids, int n, hipStream_t stream);
 int grx_envs_per_block(void);
-void grx_launch_step_debug(const KParams* dP, int N, int heightfield, const float* actions, long long common_step, const float* noise,
+void grx_launch_step_debug(const KParams* dP, int N, int heightfield, int waves, const float* actions, long long common_step, const float* noise,
                            const float* dbg, const StepSeq* sq, hipStream_t stream);
+void grx_launch_step_debug_quad(const KParams* dP, int N, int heightfield, int waves, const float* actions, long long common_step, const float* noise,
+                                const float* dbg, const StepSeq* sq, hipStream_t stream);
 int grx_debug_rows(void);
 }
 
@@ -394,6 +396,7 @@ struct GenTablesH {
     float axis[GRX_MAX_BODIES][3], rot0[GRX_MAX_BODIES][9], jpos[GRX_MAX_BODIES][3], mass[GRX_MAX_BODIES], com[GRX_MAX_BODIES][3], Ic[GRX_MAX_BODIES][6];
     float kp[GRX_MAX_DOFS], kd[GRX_MAX_DOFS], q0[GRX_MAX_DOFS], effort[GRX_MAX_DOFS], vlim[GRX_MAX_DOFS], qlo[GRX_MAX_DOFS], qhi[GRX_MAX_DOFS];
     float slo[GRX_MAX_DOFS], shi[GRX_MAX_DOFS], amin[GRX_MAX_DOFS], amax[GRX_MAX_DOFS], Klim[GRX_MAX_DOFS], Clim[GRX_MAX_DOFS];
+    float arm[GRX_MAX_DOFS];
     int32_t sph_begin[GRX_MAX_BODIES + 1];
     float sx[GRX_MAX_SPHERES], sy[GRX_MAX_SPHERES], sz[GRX_MAX_SPHERES], sr[GRX_MAX_SPHERES], sdmax[GRX_MAX_SPHERES];
     int32_t sslot[GRX_MAX_SPHERES];
@@ -431,6 +434,7 @@ int build_generic(grx_sim* s, const grx_config& c) {
         T.effort[j] = m.dof_effort[j]; T.vlim[j] = m.dof_vel_limit[j]; T.qlo[j] = m.dof_lower[j]; T.qhi[j] = m.dof_upper[j];
         T.Klim[j] = c.contact.k_limit * m.dof_effort[j];
         T.Clim[j] = c.contact.c_limit * T.Klim[j];
+        T.arm[j] = m.dof_armature[j];
         T.amin[j] = c.clip_actions_min[j]; T.amax[j] = c.clip_actions_max[j];
         const float mid = (m.dof_lower[j] + m.dof_upper[j]) / 2, rng = m.dof_upper[j] - m.dof_lower[j];
         T.slo[j] = mid - 0.5f * rng * c.soft_dof_pos_limit;
@@ -553,7 +557,7 @@ int build_generic(grx_sim* s, const grx_config& c) {
     for (int j = 0; j < T.nd; ++j) {
         TreeDof& d = K.dof[j];
         d.kp = T.kp[j]; d.kd = T.kd[j]; d.q0 = T.q0[j]; d.effort = T.effort[j]; d.vlim = T.vlim[j]; d.qlo = T.qlo[j]; d.qhi = T.qhi[j];
-        d.slo = T.slo[j]; d.shi = T.shi[j]; d.amin = T.amin[j]; d.amax = T.amax[j]; d.Klim = T.Klim[j]; d.Clim = T.Clim[j]; d.lane = lane_of[j + 1];
+        d.slo = T.slo[j]; d.shi = T.shi[j]; d.amin = T.amin[j]; d.amax = T.amax[j]; d.Klim = T.Klim[j]; d.Clim = T.Clim[j]; d.lane = lane_of[j + 1]; d.arm = T.arm[j];
     }
     for (int k = 0; k < T.nsph; ++k) { TreeSph& q = K.sph[k]; q.x = T.sx[k]; q.y = T.sy[k]; q.z = T.sz[k]; q.r = T.sr[k]; q.dmax = T.sdmax[k]; q.slot = T.sslot[k]; q.link = T.slink[k]; }
     for (int l = 0; l < T.nlc; ++l) { K.link_flags[l] = T.link_flags[l]; K.link_urdf[l] = T.link_urdf[l]; }
@@ -593,7 +597,12 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     if (c.num_envs < 1) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: num_envs < 1");
     // the lower-limb topology runs on the fused lane-pair kernel; every other tree on the generic-tree kernel
     int rc = check_topology(m);
-    const bool generic = rc != GRX_OK || getenv("GRX_FORCE_GENERIC") != nullptr;
+    bool armature = false;   // (the fused lower-limb kernels carry no armature term: such a model runs on the tree kernel)
+    for (int j = 0; j + 1 < m.num_bodies && j < GRX_MAX_DOFS; ++j) {
+        if (!(m.dof_armature[j] >= 0.f)) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: negative joint armature");
+        armature = armature || m.dof_armature[j] != 0.f;
+    }
+    const bool generic = rc != GRX_OK || armature || getenv("GRX_FORCE_GENERIC") != nullptr;
     g_err.clear();
     const int nd = m.num_bodies - 1;
     if (nd < 1 || m.num_bodies > GRX_MAX_BODIES) return fail(GRX_ERR_UNSUPPORTED_MODEL, "grx_create: unsupported body count");
@@ -693,7 +702,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(motor_strength, nd * N); DA(base_m, N); DA(base_c, 3 * N); DA(base_I, 6 * N); DA(friction, N); DA(restitution, N);
     DA(commands, 3 * N); DA(origins, 3 * N); DA(levels, N); DA(types, N);
     DA(air_time, 2 * N); DA(land_time, 2 * N); DA(feet_contact, 2 * N);
-    DA(feet_height, 2 * N); DA(avg_force, 2 * N); DA(feet_force, 6 * N); DA(contact_forces, 3 * GRX_MAX_LINKS * N); DA(feet_pos, 6 * N); DA(avg_speed, 6 * N);
+    DA(feet_height, 2 * N); DA(avg_force, 2 * N); DA(feet_force, 6 * N); DA(contact_forces, 3 * GRX_MAX_LINKS * N); DA(feet_pos, 6 * N); DA(avg_speed, 6 * N); DA(avg_speed_rpy, 6 * N);
     DA(base_heights_offset, N); DA(ep_len, N); DA(rew, N); DA(reset, N); DA(time_out, N); DA(term_contact, N);
     DA(base_lin_vel, 3 * N); DA(base_ang_vel, 3 * N); DA(proj_grav, 3 * N);
     DA(episode_sums, NT * N); DA(reward_terms, NT * N); DA(heights, (size_t)(nh > 0 ? nh : 1) * N);
@@ -914,6 +923,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     desc_soa(s, GRX_T_FEET_CONTACT, P.feet_contact, GRX_U8, 2);
     desc_soa(s, GRX_T_AVG_FEET_FORCE, P.avg_force, GRX_F32, 2);
     desc_soa3(s, GRX_T_AVG_FEET_SPEED, P.avg_speed, 2, 3);
+    desc_soa3(s, GRX_T_AVG_FEET_SPEED_RPY, P.avg_speed_rpy, 2, 3);
     desc_soa(s, GRX_T_MEASURED_HEIGHTS, P.heights, GRX_F32, nh);
     desc_vec(s, GRX_T_BASE_HEIGHTS_OFFSET, P.base_heights_offset, GRX_F32, Ni);
     desc_rows(s, GRX_T_EPISODE_SUMS, P.episode_sums, NT, Ni);
@@ -1011,6 +1021,8 @@ static StepSeq next_seq(grx_sim* s, hipStream_t st, bool capturing) {
     q.seq = ++s->seq;
     q.progress = capturing ? nullptr : s->pace.d_progress;
     q.ticket_done = s->pace.issued;
+    q.fold_prev = capturing ? 0 : 1;
+    q.pad = 0;
     if (!capturing) { ++s->pace.issued; s->pace.last_stream = st; }
     s->stats_current = false;
     return q;
@@ -1022,12 +1034,17 @@ int grx_reset_all(grx_handle s, void* stream) {
     // extras["episode"] of a full reset: mean of the running episode sums over all envs
     // (legged_robot.py:420-424); computed by the stats path with every env flagged.
     uint32_t step = 0x80000000u + (s->reset_count++);
+    // (the generic reset kernel does not fold its predecessor's statistics, and a recorded launch must not: reduce them now)
+    if ((s->generic || stream_is_capturing(st)) && !s->stats_current) grx_launch_finalize(s->d_hp, s->seq, nullptr, 0, st);
     const StepSeq q = next_seq(s, st, stream_is_capturing(st));
     if (s->generic) {
         grx_launch_reset_all_generic(s->d_hp, s->d_gen, s->N, s->gen_epb, step, q.seq, nullptr, st);
         grx_launch_finalize(s->d_hp, q.seq, q.progress, q.progress ? s->pace.issued : 0, st);
         s->stats_current = true;
-    } else grx_launch_reset_all(s->d_hp, s->N, step, &q, nullptr, st);
+    } else {
+        grx_launch_reset_all(s->d_hp, s->N, step, &q, nullptr, st);
+        if (!q.fold_prev) { grx_launch_finalize(s->d_hp, q.seq, nullptr, 0, st); s->stats_current = true; }   // recorded into a graph: see grx_step
+    }
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
@@ -1037,13 +1054,17 @@ int grx_reset_idx(grx_handle s, const int32_t* env_ids, int32_t n, void* stream)
     if (n <= 0) return GRX_OK;   // legged_robot.py:387-388
     hipStream_t st = (hipStream_t)stream;
     uint32_t step = 0x80000000u + (s->reset_count++);
+    if ((s->generic || stream_is_capturing(st)) && !s->stats_current) grx_launch_finalize(s->d_hp, s->seq, nullptr, 0, st);
     const StepSeq q = next_seq(s, st, stream_is_capturing(st));
     grx_launch_mark(env_ids, n, s->N, s->d_mask, st);
     if (s->generic) {
         grx_launch_reset_all_generic(s->d_hp, s->d_gen, s->N, s->gen_epb, step, q.seq, s->d_mask, st);
         grx_launch_finalize(s->d_hp, q.seq, q.progress, q.progress ? s->pace.issued : 0, st);
         s->stats_current = true;
-    } else grx_launch_reset_all(s->d_hp, s->N, step, &q, s->d_mask, st);
+    } else {
+        grx_launch_reset_all(s->d_hp, s->N, step, &q, s->d_mask, st);
+        if (!q.fold_prev) { grx_launch_finalize(s->d_hp, q.seq, nullptr, 0, st); s->stats_current = true; }
+    }
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }
@@ -1073,8 +1094,15 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
         else { HIP_TRY(hipEventCreate(&ev.first)); HIP_TRY(hipEventCreate(&ev.second)); }
         HIP_TRY(hipEventRecord(ev.first, st));
     }
+    // A step recorded into a graph may be replayed any number of times: its predecessor in execution order is then not launch
+    // seq - 1, so it must not fold that launch's statistics rows (it would re-publish stale means and lose its own partials:
+    // ADVICE r3).  Recorded steps therefore carry their statistics reduction with them: the predecessor's rows are reduced
+    // before (once, idempotent under replay), the step's own rows right behind it -- every replay leaves GRX_T_EPISODE_STATS
+    // and its row of the history ring current.
+    if (capturing && !s->stats_current) grx_launch_finalize(s->d_hp, s->seq, nullptr, 0, st);
     const StepSeq q = next_seq(s, st, capturing);
     a->stats_slot = q.seq & (GRX_STATS_HISTORY - 1);
+    a->stats_seq = q.seq;
     if (s->generic)
     {
         if (s->d_tree) {
@@ -1096,7 +1124,7 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
         HIP_TRY(hipEventRecord(ev.second, st));
         s->timing.pending.push_back(ev);
     }
-    if (s->generic && !s->d_tree) {   // the one-lane generic kernel does not fold its predecessor's statistics: its own small kernel, with the step's ticket
+    if ((s->generic && !s->d_tree) || capturing) {   // the one-lane generic kernel does not fold its predecessor's statistics: its own small kernel, with the step's ticket
         grx_launch_finalize(s->d_hp, q.seq, q.progress, q.progress ? s->pace.issued : 0, st);
         s->stats_current = true;
     }
@@ -1143,6 +1171,33 @@ int grx_episode_stats(grx_handle s, float* host_out, void* stream) {
     return GRX_OK;
 }
 
+int grx_stats_seq(grx_handle s, int64_t* out) {
+    if (!s || !out) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_stats_seq: null argument");
+    *out = s->seq;
+    return GRX_OK;
+}
+
+int grx_layout(grx_handle s, grx_layout_info* out) {
+    if (!s || !out) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_layout: null argument");
+    memset(out, 0, sizeof *out);
+    const char* hf = s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD ? "true" : "false";
+    if (s->generic && s->d_tree) {
+        out->lanes_per_env = GRX_TREE_G; out->waves_per_block = grx_tree_envs_per_block() * GRX_TREE_G / 64; out->envs_per_block = grx_tree_envs_per_block();
+        snprintf(out->kernel, sizeof out->kernel, "grx_step_tree<%s>", hf);
+    } else if (s->generic) {
+        out->lanes_per_env = 1; out->waves_per_block = 1; out->envs_per_block = s->gen_epb;
+        snprintf(out->kernel, sizeof out->kernel, "grx_step_generic<%s>", hf);
+    } else if (s->quad) {
+        out->lanes_per_env = 4; out->waves_per_block = s->waves; out->envs_per_block = grx_envs_per_block_quad();
+        snprintf(out->kernel, sizeof out->kernel, "grx_step_kernel_quad<%s, %d, false>", hf, s->waves);
+    } else {
+        out->lanes_per_env = 2; out->waves_per_block = s->waves; out->envs_per_block = grx_envs_per_block();
+        snprintf(out->kernel, sizeof out->kernel, "grx_step_kernel<%s, %d, false>", hf, s->waves);
+    }
+    out->num_blocks = (s->N + out->envs_per_block - 1) / out->envs_per_block;
+    return GRX_OK;
+}
+
 int grx_kernel_time_ms(grx_handle s, int enable, float* avg_ms, int64_t* launches) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_kernel_time_ms: null handle");
     double tot = s->timing.total_ms;
@@ -1174,7 +1229,7 @@ int grx_debug_profile(grx_handle s, long long* out, int max_blocks) {
 }
 
 // TEST-ONLY: post_physics_step of every env on injected state (include/grx.h).  Uploads the records into the SoA state
-// buffers + the debug rows, then launches the one-wave step kernel's DBG instantiation (no sub-steps).
+// buffers + the debug rows, then launches the DBG instantiation (no sub-steps) of the step kernel this handle runs.
 int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply_reset, const grx_step_args* a, void* stream) {
     if (!s || !ps || !a) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_post_physics: null argument");
     if (s->generic) return fail(GRX_ERR_UNSUPPORTED_MODEL, "grx_debug_post_physics: lower-limb (fused-kernel) models only");
@@ -1217,8 +1272,11 @@ int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply
 #undef UPS
     HIP_TRY(hipStreamSynchronize(st));   // the host vectors go out of scope
     const StepSeq sq = next_seq(s, st, false);
-    grx_launch_step_debug(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->d_dbg_actions, (long long)a->common_step_counter,
-                          a->noise_uniform, s->d_dbg, &sq, st);
+    // the post-physics half of the kernel this handle steps with (lane pairs: 1 / 4 / 8 waves; lane quads: 4 / 8)
+    if (s->quad) grx_launch_step_debug_quad(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, s->d_dbg_actions,
+                                            (long long)a->common_step_counter, a->noise_uniform, s->d_dbg, &sq, st);
+    else grx_launch_step_debug(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, s->d_dbg_actions, (long long)a->common_step_counter,
+                               a->noise_uniform, s->d_dbg, &sq, st);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
 }

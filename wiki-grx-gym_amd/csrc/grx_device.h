@@ -19,6 +19,10 @@ struct StepSeq {
     long long seq;          // launch number of this handle (step, reset, debug step alike): parity seq & 1 of the statistics tables, history row seq % GRX_STATS_HISTORY
     long long* progress;    // host-pinned progress word (nullptr while a graph is being recorded) ...
     long long ticket_done;  // ... and the ticket of the work that preceded this launch on the stream: complete when this kernel starts
+    int fold_prev;          // 1: this launch reduces the statistics rows of launch seq - 1 (the kernel boundary orders them).  0: a launch recorded
+                            // into a graph -- on a replay its predecessor in EXECUTION order is not launch seq - 1, so it leaves the tables alone and
+                            // grx_step records a grx_finalize_stats of its own rows behind it
+    int pad;
 };
 
 struct SphC {   // 32 bytes
@@ -95,7 +99,7 @@ struct TreeBody {            // 36 words
     int32_t lane, step;      // where this body is processed
     int32_t pad[2];
 };
-struct TreeDof { float kp, kd, q0, effort, vlim, qlo, qhi, slo, shi, amin, amax, Klim, Clim; int32_t lane; int32_t pad[2]; };   // 16 words
+struct TreeDof { float kp, kd, q0, effort, vlim, qlo, qhi, slo, shi, amin, amax, Klim, Clim; int32_t lane; float arm; int32_t pad; };   // 16 words (arm: joint-space armature)
 struct TreeSph { float x, y, z, r, dmax; int32_t slot, link, pad; };   // 8 words
 struct TreeTab {
     int32_t nb, nd, nsph, nlc, nchain, nstep, nh0, pad0;
@@ -181,6 +185,7 @@ struct KParams {
     float *air_time, *land_time;
     uint8_t* feet_contact;   // also the "contact_last" state of the next step (legged_robot_fftai.py:113,131)
     float *feet_height, *avg_force, *feet_force, *feet_pos, *avg_speed, *base_heights_offset;
+    float* avg_speed_rpy;    // [(foot * 3 + c)][N]: sub-step averaged |angular velocity| of the foot links (legged_robot_fftai.py:81, 88)
     float* contact_forces;   // [(link * 3 + c)][N]: net contact force per URDF link, last sub-step
     long long* ep_len;
     float* rew;

@@ -31,6 +31,7 @@ struct GenTables {
     float axis[GEN_MAXB][3], rot0[GEN_MAXB][9], jpos[GEN_MAXB][3], mass[GEN_MAXB], com[GEN_MAXB][3], Ic[GEN_MAXB][6];
     float kp[GEN_MAXD], kd[GEN_MAXD], q0[GEN_MAXD], effort[GEN_MAXD], vlim[GEN_MAXD], qlo[GEN_MAXD], qhi[GEN_MAXD];
     float slo[GEN_MAXD], shi[GEN_MAXD], amin[GEN_MAXD], amax[GEN_MAXD], Klim[GEN_MAXD], Clim[GEN_MAXD];
+    float arm[GEN_MAXD];               // joint-space armature (grx_model.dof_armature)
     int32_t sph_begin[GEN_MAXB + 1];   // spheres are sorted by carrying body
     float sx[GEN_MAXS], sy[GEN_MAXS], sz[GEN_MAXS], sr[GEN_MAXS], sdmax[GEN_MAXS];
     int32_t sslot[GEN_MAXS];           // friction-anchor slot 0..7 of an anchored foot sphere, -1 otherwise
@@ -278,7 +279,7 @@ GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const floa
         carry_to = -1;
         const V3 ua = mul(A, a) + mul(Bm, s);
         const V3 ul = mulT(Bm, a) + mul(D, s);
-        const float di = grx_rcp(dot(a, ua) + dot(s, ul));
+        const float di = grx_rcp(dot(a, ua) + dot(s, ul) + T.arm[j]);
         const float qj = q[(size_t)j * N], qdj = qd[(size_t)j * N];
         float t = tau[(size_t)j * N];   // joint-limit spring/damper on top of the motor torque
         if (qj < T.qlo[j]) t += T.Klim[j] * (T.qlo[j] - qj) - T.Clim[j] * qdj;
@@ -450,6 +451,7 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
     // ---- during_physics_step (legged_robot_fftai.py:51-88)
     float avg_force[2] = {0.f, 0.f};
     V3 avg_speed[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+    V3 avg_rpy[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};   // avg_feet_speed_rpy (legged_robot_fftai.py:81, 88)
     V3 fvel[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)}, fpos[2];
     const int lfbase = nb * WSB;
     for (int deci = 0; deci < P.decimation; ++deci) {
@@ -462,7 +464,11 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
         }
         gen_substep<HF>(P, T, B, q, qd, tau, ws, WN, N, e, base_m, base_c, base_I, mu, om_e, hmax, fvel);
         if (deci > 0)
-            for (int f = 0; f < 2; ++f) avg_speed[f] = v3(avg_speed[f].x + fabsf(fvel[f].x), avg_speed[f].y + fabsf(fvel[f].y), avg_speed[f].z + fabsf(fvel[f].z));
+            for (int f = 0; f < 2; ++f) {
+                avg_speed[f] = v3(avg_speed[f].x + fabsf(fvel[f].x), avg_speed[f].y + fabsf(fvel[f].y), avg_speed[f].z + fabsf(fvel[f].z));
+                const V3 fw = ws_v3(ws, WN, T.foot_body[f], W_W);   // (the walk's: BEFORE this sub-step's integration, like fvel)
+                avg_rpy[f] = v3(avg_rpy[f].x + fabsf(fw.x), avg_rpy[f].y + fabsf(fw.y), avg_rpy[f].z + fabsf(fw.z));
+            }
         for (int f = 0; f < 2; ++f) {
             const int L = T.foot_link[f];
             const V3 F = v3(ws[(size_t)(lfbase + L * 3) * WN], ws[(size_t)(lfbase + L * 3 + 1) * WN], ws[(size_t)(lfbase + L * 3 + 2) * WN]);
@@ -475,6 +481,10 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
         avg_speed[f] = v3((avg_speed[f].x + fabsf(fvel[f].x)) / (float)P.decimation, (avg_speed[f].y + fabsf(fvel[f].y)) / (float)P.decimation,
                           (avg_speed[f].z + fabsf(fvel[f].z)) / (float)P.decimation);
         avg_force[f] /= (float)P.decimation;
+        {
+            const V3 fw = ws_v3(ws, WN, T.foot_body[f], W_W);
+            avg_rpy[f] = v3((avg_rpy[f].x + fabsf(fw.x)) / (float)P.decimation, (avg_rpy[f].y + fabsf(fw.y)) / (float)P.decimation, (avg_rpy[f].z + fabsf(fw.z)) / (float)P.decimation);
+        }
         const int L = T.foot_link[f];
         foot_force[f] = v3(ws[(size_t)(lfbase + L * 3) * WN], ws[(size_t)(lfbase + L * 3 + 1) * WN], ws[(size_t)(lfbase + L * 3 + 2) * WN]);
     }
@@ -730,8 +740,9 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
             P.feet_height[(size_t)f * N + e] = feet_height[f];
             P.avg_force[(size_t)f * N + e] = avg_force[f];
             const float ff[3] = {foot_force[f].x, foot_force[f].y, foot_force[f].z}, fp[3] = {fpos[f].x, fpos[f].y, fpos[f].z};
-            const float as_[3] = {avg_speed[f].x, avg_speed[f].y, avg_speed[f].z};
+            const float as_[3] = {avg_speed[f].x, avg_speed[f].y, avg_speed[f].z}, ar_[3] = {avg_rpy[f].x, avg_rpy[f].y, avg_rpy[f].z};
             for (int i = 0; i < 3; ++i) {
+                P.avg_speed_rpy[(size_t)(f * 3 + i) * N + e] = ar_[i];
                 P.feet_force[(size_t)(f * 3 + i) * N + e] = ff[i];
                 P.feet_pos[(size_t)(f * 3 + i) * N + e] = fp[i];
                 P.avg_speed[(size_t)(f * 3 + i) * N + e] = as_[i];

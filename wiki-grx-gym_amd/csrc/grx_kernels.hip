@@ -93,6 +93,7 @@ GRX_DEV void stat_publish(KP P, long long seq, int t, float cnt, float s) {   //
 // called by ONE full wave of every block at the start of a kernel: the statistics of launch sq.seq - 1, and its ticket
 GRX_DEV void stats_fold_previous(KP P, const StepSeq& sq, int lane) {
     if (blockIdx.x == 0 && lane == 0 && sq.progress) __hip_atomic_store(sq.progress, sq.ticket_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!sq.fold_prev) return;   // (recorded into a graph: see StepSeq)
     const long long prev = sq.seq - 1;
     const int nb = P.stat_nblocks[prev & 1];
     for (int t = blockIdx.x; t < NSTAT; t += gridDim.x) {
@@ -1134,10 +1135,14 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
 //   W == 2: wave 1 computes the base-lump contact wrench of every sub-step (two block barriers per sub-step);
 //   W == 4: the four-wave producer/consumer pipeline of grx_wavepipe.h (sequence counters in LDS);
 //   W == 8: the same work re-cut into eight roles (grx_wavepipe.h, "Eight waves per block"; the default of the pipelined layouts).
-// DBG (W == 1 only, behind the test-only entry grx_debug_post_physics): no sub-steps; the quantities the physics
-// would have produced (feet forces / positions, sub-step averages, torques, termination contact) and
-// last_last_actions come from `dbg` ([DBG_ROWS][N], see DbgRow), so the post-physics half of the step can be fed the
-// reference's golden fixtures directly.
+// DBG (behind the test-only entry grx_debug_post_physics; W == 1 and the pipelined layouts W == 4, 8 with lane pairs and lane
+// quads -- the kernels BASELINE.json's configs launch): no sub-steps; the quantities the physics would have produced (feet
+// forces / positions, sub-step averages, torques, termination contact) and last_last_actions come from `dbg` ([DBG_ROWS][N],
+// see DbgRow), so the post-physics half of the step can be fed the reference's golden fixtures directly.  With the pipelines
+// the helper waves skip their sub-step loops and everything behind the barrier that ends the sub-steps runs as in the product
+// kernel: the height scan over the waves, the reward inputs through LDS to the two reward waves (which fetch the injected
+// last_last_actions themselves), reset_idx's draws from the foot wave, the termination flag through s_tp from the base-lump
+// wave, the observation height block on the helper waves.
 enum DbgRow { DBG_FEET_FORCE = 0, DBG_FEET_POS = 6, DBG_AVG_FORCE = 12, DBG_AVG_SPEED = 14, DBG_TORQUES = 20, DBG_LAST_LAST_ACTIONS = 30,
               DBG_TERM_CONTACT = 40, DBG_APPLY_RESET = 41, DBG_ROWS = 42 };
 template <bool HF, int W, bool DBG = false>
@@ -1145,7 +1150,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                                                       float delay, long long common_step, const float* __restrict__ noise_in,
                                                       const float* __restrict__ dbg, float* __restrict__ obs_out, float* __restrict__ pri_out,
                                                       const StepSeq sq) {
-    static_assert(!DBG || W == 1, "the debug injection path exists for the one-wave layout only");
+    static_assert(!DBG || W == 1 || W == 4 || W == 8, "the debug injection path exists for the one-wave layout and the pipelines");
     KP P = GRX_PARAMS(Pg);
     constexpr int NTHR = 64 * W;
     constexpr bool PIPE = W >= 4;   // the producer/consumer pipeline of grx_wavepipe.h: four roles, or (W == 8, lane quads only) eight
@@ -1156,7 +1161,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     constexpr int OBS_BYTES = EPB * GRX_NUM_OBS * 4, PRI_BYTES = EPB * PRS * 4, RW_BYTES = PIPE ? REWIN_FLOATS * 64 * 4 : 0;
     constexpr int POST_BYTES = OBS_BYTES + PRI_BYTES + RW_BYTES, PHYS_BYTES = (W == 2 || W == 8 ? 2 : 1) * RC_BYTES;
     static_assert(OBS_BYTES % 16 == 0 && PRI_BYTES % 16 == 0 && RC_BYTES % 16 == 0, "arena pieces must stay 16-byte aligned");
-    constexpr int FOOTFR_BYTES = RC_FR4 * 64 * 16, ANCH_BYTES = 13 * 64 * 4;
+    constexpr int FOOTFR_BYTES = RC_FR4 * 64 * 16, ANCH_BYTES = 16 * 64 * 4;   // (s_anch: anchors x 4, y 4, mask 1, approach speeds 4, foot |w| sums 3)
     constexpr int TAIL_BYTES = PIPE ? PHYS_BYTES + FOOTFR_BYTES + ANCH_BYTES : PHYS_BYTES;
     __shared__ __attribute__((aligned(16))) char s_arena[POST_BYTES > TAIL_BYTES ? POST_BYTES : TAIL_BYTES];
     float* const s_obs = reinterpret_cast<float*>(s_arena);
@@ -1261,16 +1266,17 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 // wave 0's path from the first sub-step on: before the loop they delayed it, measured)
                 const bool want_noise = P.add_noise && !noise_in;
                 const int noise_seq = P.decimation >= 2 ? P.decimation - 2 : 0;
-                self_loop<HF, HF && W != 8, W == 8>(P, s_tab, GRX_HC(1), RB, s_footfr, self_carve(s_self), P.friction[e], L, lane, el, side,
-                              [&](const int seq) {
-                                  if (want_noise && seq == noise_seq) {
-                                      U4 nzb[NZB];
-                                      noise_blocks(P, genv, step, side, nzb);
-                                      uint32_t* z = s_nz + lane;
+                auto noise_out = [&](const int seq) {
+                    if (want_noise && seq == noise_seq) {
+                        U4 nzb[NZB];
+                        noise_blocks(P, genv, step, side, nzb);
+                        uint32_t* z = s_nz + lane;
 #pragma unroll
-                                      for (int b = 0; b < NZB; ++b) { z[(b * 4 + 0) * 64] = nzb[b].x; z[(b * 4 + 1) * 64] = nzb[b].y; z[(b * 4 + 2) * 64] = nzb[b].z; z[(b * 4 + 3) * 64] = nzb[b].w; }
-                                  }
-                              });
+                        for (int b = 0; b < NZB; ++b) { z[(b * 4 + 0) * 64] = nzb[b].x; z[(b * 4 + 1) * 64] = nzb[b].y; z[(b * 4 + 2) * 64] = nzb[b].z; z[(b * 4 + 3) * 64] = nzb[b].w; }
+                    }
+                };
+                if (DBG) noise_out(noise_seq);   // (no sub-steps: the blocks all the same)
+                else self_loop<HF, HF && W != 8, W == 8>(P, s_tab, GRX_HC(1), RB, s_footfr, self_carve(s_self), P.friction[e], L, lane, el, side, noise_out);
             } else if (wv == 2) {
                 // (LPE == 4: this lane owns the foot spheres 2 half, 2 half + 1 -- slots 0, 1 here -- and parks them at the leg's first lane)
                 constexpr int NA = 4 / LPL;
@@ -1282,8 +1288,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                     hs.vimp[i] = P.anchors[(size_t)((side * 4 + gi) * 3 + 2) * N + e];   // 0: no contact; else the contact's approach speed
                     if (hs.vimp[i] != 0.0f) hs.anchor_on |= (1u << i);
                 }
-                chain_contact_loop<HF, W == 8 ? 0 : (HF ? 2 : 5)>(P, GRX_HC(2), C, RB, s_footfr, mu, hmax, 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]), hs, L, lane, el, side);
+                V3 rpy_acc = v3(0.f, 0.f, 0.f);
+                if (!DBG) chain_contact_loop<HF, W == 8 ? 0 : (HF ? 2 : 5)>(P, GRX_HC(2), C, RB, s_footfr, mu, hmax, 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]), hs, L, lane, el, side, rpy_acc);
                 float* a_ = s_anch + (lane - half);
+                if (half == 0) { a_[13 * 64] = rpy_acc.x; a_[14 * 64] = rpy_acc.y; a_[15 * 64] = rpy_acc.z; }   // (both halves of a leg walk the whole chain)
 #pragma unroll
                 for (int i = 0; i < NA; ++i) { const int gi = NA * half + i; a_[gi * 64] = hs.ax[i]; a_[(4 + gi) * 64] = hs.ay[i]; a_[(9 + gi) * 64] = hs.vimp[i]; }
                 {
@@ -1291,7 +1299,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                     a_[8 * 64] = __uint_as_float(LPL == 1 ? mine : (mine | __float_as_uint(half_swap(__uint_as_float(mine)))));
                 }
             } else if (wv == 3) {
-                base_contact_loop<HF, W == 8>(P, s_tab, GRX_HC(3), RB, mu, hmax, bm, bc, bI, L, lane, el, side, s_tp, w3_lp, w3_rows, s_footfr, P.friction[e]);
+                if (DBG) { s_tp[lane] = dbg[(size_t)DBG_TERM_CONTACT * N + e]; s_tp[64 + lane] = 0.f; }   // the injected termination contact takes the product's way to wave 0
+                else base_contact_loop<HF, W == 8>(P, s_tab, GRX_HC(3), RB, mu, hmax, bm, bc, bI, L, lane, el, side, s_tp, w3_lp, w3_rows, s_footfr, P.friction[e]);
+            } else if (DBG) {   // (waves 4..7 of the eight-wave pipeline have sub-step work only)
             } else if (wv == 7) {
                 RareBuf RB7 = rare_carve(s_arena + RC_BYTES);
                 RB7.fchain = RB.fchain;   // (where wave 2 publishes the thigh / shank frames)
@@ -1312,7 +1322,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
             lds_barrier();   // final friction anchors + height-scan pose published (the last sub-step's row stores stay in flight)
             if (wv == 3) {   // (this wave is the last to arrive: its HBM traffic goes out behind the barrier)
                 load_episode_sums<2>(P, e, N, es_w3);
-                store_link_rows(LinkForceOut{true, act0 ? P.contact_forces + e : nullptr, (size_t)N}, w3_lp, w3_rows);
+                if (!DBG) store_link_rows(LinkForceOut{true, act0 ? P.contact_forces + e : nullptr, (size_t)N}, w3_lp, w3_rows);
             }
             if (HF && P.measure_heights) {   // this wave's quarter of the height scan (legged_robot.py:1235-1274)
                 const float* hp = s_hp + el;
@@ -1338,7 +1348,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 RewIn rin;
                 int i = 0;
                 rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
-                reward_and_sums<2>(P, C, rin, lane, side, e, N, act, s_stat, es_w3, s_rwp, s_flag + FL_RWB);
+                reward_and_sums<2>(P, C, rin, lane, side, e, N, act, s_stat, es_w3, s_rwp, s_flag + FL_RWB, nullptr,
+                                   DBG && dbg[(size_t)DBG_APPLY_RESET * N + e] == 0.f);
             }
             if (wv == 1) {   // rewards + episode sums while wave 0 runs reset / observations / stores
                 flag_wait(s_flag + FL_REW, 1);
@@ -1346,7 +1357,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 RewIn rin;
                 int i = 0;
                 rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
-                reward_and_sums<1>(P, C, rin, lane, side, e, N, act, s_stat, es_w1, s_rwp, s_flag + FL_RWB);
+                float a_ll1[LEG];   // DBG: the injected last_last_actions (action_diff_diff is one of this wave's terms)
+                if (DBG) {
+#pragma unroll
+                    for (int k = 0; k < LEG; ++k) a_ll1[k] = dbg[(size_t)(DBG_LAST_LAST_ACTIONS + j0 + k) * N + e];
+                }
+                reward_and_sums<1>(P, C, rin, lane, side, e, N, act, s_stat, es_w1, s_rwp, s_flag + FL_RWB, DBG ? a_ll1 : nullptr,
+                                   DBG && dbg[(size_t)DBG_APPLY_RESET * N + e] == 0.f);
                 GRX_TICKW(15);
             }
             if (W == 8) {   // eight waves: the observation height block on the four waves that have no reward terms, a quarter each
@@ -1461,6 +1478,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     // ---- during_physics_step (legged_robot_fftai.py:51-88), fused decimation loop
     float avg_force = 0.f;
     V3 avg_speed = v3(0.f, 0.f, 0.f);
+    V3 avg_rpy = v3(0.f, 0.f, 0.f);   // (the pipelines: summed on the foot wave, picked up behind the sub-steps' barrier)
     float torque[LEG];
     SubstepOut so;
     FootKin fk;
@@ -1507,6 +1525,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                             LinkForceOut{deci == P.decimation - 1, act0 ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side, self_near, deci == 0);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
             avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
+            if (!PIPE) avg_rpy = v3(avg_rpy.x + fabsf(fk.ang.x), avg_rpy.y + fabsf(fk.ang.y), avg_rpy.z + fabsf(fk.ang.z));
         }
         avg_force += grx_sqrt(dot(so.foot_force, so.foot_force));
     }
@@ -1536,6 +1555,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { st.ax[i] = a_[i * 64]; st.ay[i] = a_[(4 + i) * 64]; st.vimp[i] = a_[(9 + i) * 64]; }
         st.anchor_on = __float_as_uint(a_[8 * 64]);
+        avg_rpy = v3(a_[13 * 64], a_[14 * 64], a_[15 * 64]);
         so.term = s_tp[lane] != 0.f; so.pen_count = s_tp[64 + lane];   // from the net link forces (terrain + self-collision), wave 3
     }
     GRX_TICK(2);
@@ -1546,6 +1566,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
     avg_force = avg_force / (float)P.decimation;  // legged_robot_fftai.py:86-88
     avg_speed = v3(avg_speed.x / (float)P.decimation, avg_speed.y / (float)P.decimation, avg_speed.z / (float)P.decimation);
+    if (!DBG && act0) {   // avg_feet_speed_rpy (legged_robot_fftai.py:81, 88): no reward term reads it -- stored at once, nothing kept live
+        const float id = 1.0f / (float)P.decimation;
+        P.avg_speed_rpy[(size_t)(side * 3 + 0) * N + e] = (avg_rpy.x + fabsf(fk.ang.x)) * id;
+        P.avg_speed_rpy[(size_t)(side * 3 + 1) * N + e] = (avg_rpy.y + fabsf(fk.ang.y)) * id;
+        P.avg_speed_rpy[(size_t)(side * 3 + 2) * N + e] = (avg_rpy.z + fabsf(fk.ang.z)) * id;
+    }
     float a_ll[LEG];
     bool dbg_apply_reset = true;
     if (DBG) {   // injected "physics results" (grx_debug_post_physics)
@@ -1557,8 +1583,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         avg_speed = v3(d[(DBG_AVG_SPEED + side * 3 + 0) * n_], d[(DBG_AVG_SPEED + side * 3 + 1) * n_], d[(DBG_AVG_SPEED + side * 3 + 2) * n_]);
 #pragma unroll
         for (int k = 0; k < LEG; ++k) { torque[k] = d[(DBG_TORQUES + j0 + k) * n_]; a_ll[k] = d[(DBG_LAST_LAST_ACTIONS + j0 + k) * n_]; }
-        so.term = d[DBG_TERM_CONTACT * n_] != 0.f;
-        so.pen_count = 0.f;
+        if (!PIPE) { so.term = d[DBG_TERM_CONTACT * n_] != 0.f; so.pen_count = 0.f; }   // (the pipelines: through s_tp from wave 3, as in the product kernel)
         dbg_apply_reset = d[DBG_APPLY_RESET * n_] != 0.f;
     }
     const bool term_contact = __builtin_bit_cast(int, pair_swap(__builtin_bit_cast(float, (int)so.term))) | (int)so.term;
@@ -1837,6 +1862,15 @@ extern "C" void grx_launch_step_quad(const KParams* dP, int N, int heightfield, 
 #undef GRX_LAUNCH_QUAD
 }
 extern "C" int grx_envs_per_block_quad(void) { return EPB; }
+// TEST-ONLY (grx_debug_post_physics): the post-physics half of the lane-quad kernels on injected state
+extern "C" void grx_launch_step_debug_quad(const KParams* dP, int N, int heightfield, int waves, const float* actions, long long common_step, const float* noise,
+                                           const float* dbg, const StepSeq* sq, hipStream_t stream) {
+    const int nblocks = (N + EPB - 1) / EPB;
+#define GRX_LAUNCH_DBGQ(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_, true>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr, *sq)
+    if (heightfield) { if (waves == 8) GRX_LAUNCH_DBGQ(true, 8); else GRX_LAUNCH_DBGQ(true, 4); }
+    else { if (waves == 8) GRX_LAUNCH_DBGQ(false, 8); else GRX_LAUNCH_DBGQ(false, 4); }
+#undef GRX_LAUNCH_DBGQ
+}
 #else
 // extras["episode"] (legged_robot.py:420-428) ON DEMAND: the reduction stats_fold_previous would do in the handle's next launch,
 // for the launch `seq`, now (grx_flush_stats / grx_episode_stats; the generic-tree kernel's step still ends with it).  The next
@@ -1970,12 +2004,15 @@ extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, int w
     else { if (waves == 8) GRX_LAUNCH_STEP(false, 8); else if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
 #undef GRX_LAUNCH_STEP
 }
-// TEST-ONLY (grx_debug_post_physics): the post-physics half of the step on injected state, one-wave layout
-extern "C" void grx_launch_step_debug(const KParams* dP, int N, int heightfield, const float* actions, long long common_step, const float* noise,
+// TEST-ONLY (grx_debug_post_physics): the post-physics half of the step on injected state, in the layout the handle steps with
+// (waves = 1, 4, 8; the two-wave layout shares the one-wave kernel's post-physics code and is served by it)
+extern "C" void grx_launch_step_debug(const KParams* dP, int N, int heightfield, int waves, const float* actions, long long common_step, const float* noise,
                                       const float* dbg, const StepSeq* sq, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
-    if (heightfield) hipLaunchKernelGGL((grx_step_kernel<true, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr, *sq);
-    else hipLaunchKernelGGL((grx_step_kernel<false, 1, true>), dim3(nblocks), dim3(64), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr, *sq);
+#define GRX_LAUNCH_DBG(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_, true>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr, *sq)
+    if (heightfield) { if (waves == 8) GRX_LAUNCH_DBG(true, 8); else if (waves == 4) GRX_LAUNCH_DBG(true, 4); else GRX_LAUNCH_DBG(true, 1); }
+    else { if (waves == 8) GRX_LAUNCH_DBG(false, 8); else if (waves == 4) GRX_LAUNCH_DBG(false, 4); else GRX_LAUNCH_DBG(false, 1); }
+#undef GRX_LAUNCH_DBG
 }
 extern "C" int grx_debug_rows(void) { return DBG_ROWS; }
 // epb: envs per block (= threads per block, at most 64); lds_bytes > 0: the per-body workspace lives in (dynamic) LDS

@@ -235,8 +235,8 @@ GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, cons
             for (int k = 0; k < tb.nhc; ++k) tree_add_up(wsw, ei, o.up + tb.hc[k] * T_UPW, A, Bm, D, pa, pl);   // chains that hang from this body, fixed order
             const V3 ua = mul(A, a) + mul(Bm, s);
             const V3 ul = mulT(Bm, a) + mul(D, s);
-            const float di = grx_rcp(dot(a, ua) + dot(s, ul));
             const TreeDof& td = T.dof[j];
+            const float di = grx_rcp(dot(a, ua) + dot(s, ul) + td.arm);
             const float qj = TW(o.dof + TD_Q * GRX_MAX_DOFS + j), qdj = TW(o.dof + TD_QD * GRX_MAX_DOFS + j);
             float t = TW(o.dof + TD_TAU * GRX_MAX_DOFS + j);   // joint-limit spring/damper on top of the motor torque
             if (qj < td.qlo) t += td.Klim * (td.qlo - qj) - td.Clim * qdj;
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
     // ---- during_physics_step (legged_robot_fftai.py:51-88)
     float avg_force[2] = {0.f, 0.f};
     V3 avg_speed[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+    V3 avg_rpy[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};   // avg_feet_speed_rpy (legged_robot_fftai.py:81, 88)
     for (int deci = 0; deci < P.decimation; ++deci) {
         for (int i = c; i < T.nlc * 3; i += TG) TW(o.lf + i) = 0.f;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -467,6 +468,8 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
             if (deci > 0) {
                 const V3 fv = tw_v3(wsw, ei, o.misc + f * 3);
                 avg_speed[f] = v3(avg_speed[f].x + fabsf(fv.x), avg_speed[f].y + fabsf(fv.y), avg_speed[f].z + fabsf(fv.z));
+                const V3 fw = tw_v3(wsw, ei, T.foot_body[f] * T_NB + T_W);   // (the walk's: BEFORE this sub-step's integration, like fv)
+                avg_rpy[f] = v3(avg_rpy[f].x + fabsf(fw.x), avg_rpy[f].y + fabsf(fw.y), avg_rpy[f].z + fabsf(fw.z));
             }
             const V3 F = tw_v3(wsw, ei, o.lf + T.foot_link[f] * 3);
             avg_force[f] += grx_sqrt(dot(F, F));
@@ -521,6 +524,10 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
         avg_speed[f] = v3((avg_speed[f].x + fabsf(fvel[f].x)) / (float)P.decimation, (avg_speed[f].y + fabsf(fvel[f].y)) / (float)P.decimation,
                           (avg_speed[f].z + fabsf(fvel[f].z)) / (float)P.decimation);
         avg_force[f] /= (float)P.decimation;
+        {
+            const V3 fw = tw_v3(wsw, ei, b * T_NB + T_W);
+            avg_rpy[f] = v3((avg_rpy[f].x + fabsf(fw.x)) / (float)P.decimation, (avg_rpy[f].y + fabsf(fw.y)) / (float)P.decimation, (avg_rpy[f].z + fabsf(fw.z)) / (float)P.decimation);
+        }
         foot_force[f] = tw_v3(wsw, ei, o.lf + T.foot_link[f] * 3);
     }
     // termination / collision from the per-link net forces of the LAST sub-step (legged_robot.py:336-353); contact_forces rows
@@ -841,9 +848,10 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
                 P.feet_height[(size_t)f * N + e] = feet_height[f];
                 P.avg_force[(size_t)f * N + e] = avg_force[f];
                 const float ff[3] = {foot_force[f].x, foot_force[f].y, foot_force[f].z}, fp[3] = {fpos[f].x, fpos[f].y, fpos[f].z};
-                const float as_[3] = {avg_speed[f].x, avg_speed[f].y, avg_speed[f].z};
+                const float as_[3] = {avg_speed[f].x, avg_speed[f].y, avg_speed[f].z}, ar_[3] = {avg_rpy[f].x, avg_rpy[f].y, avg_rpy[f].z};
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
+                    P.avg_speed_rpy[(size_t)(f * 3 + i) * N + e] = ar_[i];
                     P.feet_force[(size_t)(f * 3 + i) * N + e] = ff[i];
                     P.feet_pos[(size_t)(f * 3 + i) * N + e] = fp[i];
                     P.avg_speed[(size_t)(f * 3 + i) * N + e] = as_[i];

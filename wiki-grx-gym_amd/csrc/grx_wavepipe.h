@@ -1090,7 +1090,7 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
 // wave 2: own walk with velocities; thigh / shank frames for wave 3; the anchored foot spheres
 template <bool HF, int NBIAS>   // NBIAS: this wave computes the bias forces of the last NBIAS chain bodies (5, 2, or 0: eight waves)
 GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const SideConst& Clds, const RareBuf& RB, float4* footfr, float mu, float hmax, float om_e, LaneState& hs, const PipeLds& L,
-                                int lane, int el, int side) {
+                                int lane, int el, int side, V3& rpy_acc) {   // rpy_acc: sum of the foot body's |angular velocity| at the START of sub-steps 1.. (avg_feet_speed_rpy)
     const int half = lane_half(lane);
     GRX_HELPER_PROF_BEGIN;
     float lim_lo[LEG], lim_hi[LEG], lim_k[LEG], lim_c[LEG];   // joint-limit constants: registers for the whole policy step
@@ -1120,6 +1120,7 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const SideConst& Clds,
             KK[k] = K;
             if (k == 2) rare_store_frame(RB.fchain + lane, 64, K.R, K.rho, K.w, K.v);                  // thigh
             if (k == 3) rare_store_frame(RB.fchain + RC_FR4 * 64 + lane, 64, K.R, K.rho, K.w, K.v);    // shank
+            if (k == 4 && seq > 0) rpy_acc = v3(rpy_acc.x + fabsf(K.w.x), rpy_acc.y + fabsf(K.w.y), rpy_acc.z + fabsf(K.w.z));
             if (k == 4) { rare_store_frame(footfr + lane, 64, K.R, K.rho, K.w, K.v);   // foot (self-collision, wave 1)
                           flag_set(L.flag + FL_FRAMES, seq + 1, lane); GRX_EV(8); }
         }

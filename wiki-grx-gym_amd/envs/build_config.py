@@ -49,7 +49,8 @@ def build(cfg, sim_dt, num_envs, env_offset=0, total_envs=None, seed=1, terrain=
     g = cfg.sim.grx
     meta = fill_model(c.model, rm, cfg.asset.foot_name, cfg.asset.torso_name,
                       getattr(cfg.asset, "forehead_name", ""), cfg.asset.terminate_after_contacts_on,
-                      cfg.asset.penalize_contacts_on, damp_alpha=g.damp_alpha, sim_dt=sim_dt)
+                      cfg.asset.penalize_contacts_on, damp_alpha=g.damp_alpha, sim_dt=sim_dt,
+                      armature=float(getattr(cfg.asset, "armature", 0.0)))   # asset_options.armature (legged_robot.py:958)
     meta["model"] = rm
     c.contact.kn, c.contact.dn, c.contact.kt, c.contact.ct, c.contact.cv = g.kn, g.dn, g.kt, g.ct, g.cv
     c.contact.k_limit, c.contact.c_limit, c.contact.damp_alpha = g.k_limit, g.c_limit, g.damp_alpha

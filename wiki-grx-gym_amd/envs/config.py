@@ -307,8 +307,16 @@ class GR1T1FullBodyCfg(GR1T1FullCfg):
     """Config 5 of BASELINE.json: the unfixed-upper-body GR1T1 (32 DOF).  The reference ships the config above but no
     env class whose observation profile matches it (num_obs=121 fits none of its compute_observation_profile
     variants), so the observation layout here is BUILD-DEFINED, the lower-limb profile (gr1t1.py:281-313) with 32
-    dofs: obs 9 + 3*32 = 105, pri_obs 105 + 3 + 1 + 2 + 2 + 121 = 234.  Runs on the generic-tree kernel."""
+    dofs: obs 9 + 3*32 = 105, pri_obs 105 + 3 + 1 + 2 + 2 + 121 = 234.  Runs on the tree kernel (csrc/grx_tree.h).
+
+    asset.armature = 0.01 kg m^2 (the reference's knob, legged_robot_config.py:125 / legged_robot.py:958; 0.01 is what Isaac Gym's own
+    arm examples set, examples/franka_osc.py:81): the wrist and head links weigh 0.03-0.45 kg with 1e-5 .. 2e-4 kg m^2 about their
+    joint axes while their actuators damp with kd = 1 N m s/rad, and the reference applies the PD torque EXPLICITLY at 500 Hz
+    (legged_robot.py:679-715): kd dt / I = 210 for a wrist, two orders of magnitude beyond the explicit stability limit of 2 -- the
+    joint chatters between its effort limits and amplifies rounding into O(1) rad/s within a step.  With the
+    joint-space armature kd dt / (I + 0.01) <= 0.6 on every upper-body joint."""
     env = section("env", GR1T1FullCfg.env, num_obs=105, num_pri_obs=234, num_actions=32)
+    asset = section("asset", GR1T1FullCfg.asset, armature=0.01)
     rewards = section("rewards", GR1T1FullCfg.rewards,
                       scales=section("scales", GR1T1FullCfg.rewards.scales, **_LL_SCALES))   # the lower-limb task's reward mix
 

@@ -17,7 +17,6 @@ Every buffer attribute is a zero-copy view of library-owned device memory (the
 strides (1, N).
 """
 import math
-from collections.abc import Mapping
 
 import numpy as np
 import torch
@@ -28,32 +27,81 @@ from . import build_config
 from .config import class_to_dict
 
 
-class _EpisodeInfo(Mapping):
-    """extras["episode"] of ONE step (legged_robot.py:419-428) without a kernel or a copy in env.step(): a read-only mapping over
-    that step's row of the library's statistics history ring (GRX_T_EPISODE_STATS_HISTORY).  Values are 0-dim device tensors,
-    materialised on access (the runner reads them once per iteration, on_policy_runner.py:121-133); a row stays valid for
-    GRX_STATS_HISTORY - 1 further steps."""
-    __slots__ = ("_env", "_slot", "_step")
+class _EpisodeInfo(dict):
+    """extras["episode"] of ONE step (legged_robot.py:419-428) without a kernel or a copy in env.step(): a dict -- the reference's
+    type: rsl_rl's logger ASSIGNS into it (`ep_info[key] = ep_info[key].unsqueeze(0)`, on_policy_runner.py:226-231) -- whose
+    entries materialise on first access as 0-dim device-tensor views of that step's row of the library's statistics history ring
+    (GRX_T_EPISODE_STATS_HISTORY).  The runner reads the rows once per iteration (on_policy_runner.py:121-133); a row stays valid
+    until GRX_STATS_HISTORY further launches of the handle (steps AND resets: the guard compares the library's launch numbers,
+    grx_step_args.stats_seq) have gone by."""
+    __slots__ = ("_env", "_slot", "_seq", "_filled")
 
-    def __init__(self, env, slot, step):
-        self._env, self._slot, self._step = env, slot, step
+    def __init__(self, env, slot, seq):
+        dict.__init__(self)
+        self._env, self._slot, self._seq, self._filled = env, slot, seq, False
 
-    def _row(self):
+    def _fill(self):
+        if self._filled:
+            return
         env = self._env
-        if env.common_step_counter - self._step >= _capi.STATS_HISTORY - 1:
-            raise RuntimeError("extras['episode'] of a step more than GRX_STATS_HISTORY steps back has been overwritten")
-        if self._step == env.common_step_counter:
-            env._sim.flush_stats()   # the last step's statistics are otherwise reduced by the next launch
-        return env._stats_hist[self._slot]
+        cur = env._sim.stats_seq()
+        if cur - self._seq >= _capi.STATS_HISTORY:
+            raise RuntimeError("extras['episode'] of a step more than GRX_STATS_HISTORY launches back has been overwritten")
+        if cur == self._seq:
+            env._sim.flush_stats()   # the last launch's statistics are otherwise reduced by the next one
+        row = env._stats_hist[self._slot]
+        for k, i in env._episode_keys.items():
+            dict.setdefault(self, k, row[i])   # (a caller's own assignment wins)
+        self._filled = True
+
+    def __setitem__(self, key, value):
+        dict.__setitem__(self, key, value)
 
     def __getitem__(self, key):
-        return self._row()[self._env._episode_keys[key]]
+        if not dict.__contains__(self, key):
+            self._fill()
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._fill()
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        return key in self._env._episode_keys or dict.__contains__(self, key)
 
     def __iter__(self):
-        return iter(self._env._episode_keys)
+        self._fill()
+        return dict.__iter__(self)
 
     def __len__(self):
-        return len(self._env._episode_keys)
+        self._fill()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def copy(self):
+        self._fill()
+        return dict(dict.items(self))
+
+    def __eq__(self, other):
+        self._fill()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
 
 
 class GRxEnv:
@@ -230,7 +278,7 @@ class GRxEnv:
         if self._pri_ring is not None:
             self.pri_obs_buf = self._pri_ring[k]
         # extras (legged_robot.py:419-440): no kernel, no copy -- a view object over the step's statistics row
-        self.extras["episode"] = _EpisodeInfo(self, slot, self.common_step_counter)
+        self.extras["episode"] = _EpisodeInfo(self, slot, self._sim.last_stats_seq)
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = self.time_out_buf
         return self.obs_buf, self.pri_obs_buf, self.rew_buf, self.reset_buf, self.extras

@@ -189,7 +189,7 @@ def _mask(idx):
     return m
 
 
-def fill_model(cm, rm, foot_name, torso_name, forehead_name, terminate_names, penalise_names, damp_alpha=0.5, sim_dt=0.002):
+def fill_model(cm, rm, foot_name, torso_name, forehead_name, terminate_names, penalise_names, damp_alpha=0.5, sim_dt=0.002, armature=0.0):
     """Write RobotModel ``rm`` into the ctypes ``_capi.Model`` ``cm``."""
     nb = rm.num_bodies
     cm.num_bodies = nb
@@ -217,6 +217,7 @@ def fill_model(cm, rm, foot_name, torso_name, forehead_name, terminate_names, pe
         cm.dof_upper[d] = rm.dof_upper[d]
         cm.dof_vel_limit[d] = rm.dof_vel_limit[d]
         cm.dof_effort[d] = rm.dof_effort[d]
+        cm.dof_armature[d] = float(armature)
 
     feet = rm.links_containing(foot_name)
     if len(feet) != 2:

@@ -95,6 +95,7 @@ class SimHandle:
         self._check(api["create"](C.byref(cfg_struct), int(device_id), C.byref(self._h)), "create")
         self._views = {}
         self.last_stats_slot = 0   # row of EPISODE_STATS_HISTORY holding the episode statistics of the last step
+        self.last_stats_seq = 0    # ... and that step's launch number (grx_step_args.stats_seq)
 
     # -- errors
     def _check(self, rc, what):
@@ -152,6 +153,7 @@ class SimHandle:
                 setattr(a, name, t.data_ptr())
         self._check(self._api["step"](self._h, C.byref(a), self._stream()), "step")
         self.last_stats_slot = int(a.stats_slot)
+        self.last_stats_seq = int(a.stats_seq)
         return self.last_stats_slot
 
     def flush_stats(self):
@@ -223,6 +225,23 @@ class SimHandle:
         ms, n = C.c_float(0), C.c_int64(0)
         self._check(self._api["kernel_time_ms"](self._h, int(enable), C.byref(ms), C.byref(n)), "kernel_time_ms")
         return float(ms.value), int(n.value)
+
+    def stats_seq(self):
+        """Launch number of the handle's last statistics-writing launch (include/grx.h grx_stats_seq)."""
+        if "stats_seq" not in self._api:
+            return self.last_stats_seq
+        v = C.c_int64(0)
+        self._check(self._api["stats_seq"](self._h, C.byref(v)), "stats_seq")
+        return int(v.value)
+
+    def layout(self):
+        """What step() launches (include/grx.h grx_layout): dict(lanes_per_env, waves_per_block, envs_per_block, num_blocks, kernel)."""
+        if "layout" not in self._api:
+            return None
+        li = _capi.LayoutInfo()
+        self._check(self._api["layout"](self._h, C.byref(li)), "layout")
+        return {"lanes_per_env": int(li.lanes_per_env), "waves_per_block": int(li.waves_per_block), "envs_per_block": int(li.envs_per_block),
+                "num_blocks": int(li.num_blocks), "kernel": li.kernel.decode()}
 
     def close(self):
         if self._h:
