@@ -11,7 +11,7 @@ from tests.test_hip_parity import assert_phys, physics_lockstep
 
 pytestmark = pytest.mark.gpu
 KERNELS = pytest.mark.parametrize("kernel", ["tree", "generic"])
-FULL_BODY_SCALE = 3.0   # x the lower-limb budgets of tests/test_hip_parity.PHYS (1.5 x what round 4 observed on MI355X: see assert_phys)
+FULL_BODY_SCALE = 1.3   # x the lower-limb budgets of tests/test_hip_parity.PHYS: 1.5 x the 0.85 round 4 observed on MI355X with the joint armature (round 3: 5.0, maxima unbounded)
 
 
 def pick(monkeypatch, kernel):
@@ -97,7 +97,7 @@ def test_full_body_rough_terrain_against_the_oracle(kernel, monkeypatch):
     worst = physics_lockstep(hip, ora, cfg, steps=40, scale=0.5, check=check)
     assert seen["contact"] > 2000 and seen["reset"] > 0, seen
     assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE, hf=True)
-    assert worst["FEET_POS"][0] < 5e-3 and worst["DOF_VEL"][0] < 1.0, worst
+    assert worst["FEET_POS"][0] < 5e-3 and worst["DOF_POS"][0] < 2e-2, worst   # (an arm hitting a stair edge a rounding apart: velocity maxima are not bounded on rough terrain)
     mh = tensor_diff(hip.tensor("MEASURED_HEIGHTS"), ora.tensor("MEASURED_HEIGHTS"))
     assert mh[1] < 2e-3
     assert torch.isfinite(hip.tensor("OBS")).all() and torch.isfinite(hip.tensor("REW")).all()
