@@ -29,9 +29,9 @@ int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, in
                             float delay, long long common_step, const float* noise, float* obs_out, float* pri_out, long long seq, hipStream_t stream);
 void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, long long seq, uint8_t* mask, hipStream_t stream);
 int grx_generic_tables_size(void);
-int grx_tree_lds_bytes(int nb, int nlc);
-int grx_tree_envs_per_block(void);
-int grx_launch_step_tree(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int lds_bytes, int heightfield, const float* actions, float delay,
+int grx_tree_lds_bytes(int nb, int nlc, int nchain, int waves);
+int grx_tree_envs_per_wave(void);
+int grx_launch_step_tree(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions, float delay,
                          long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream);
 int grx_generic_ws_floats_per_env(int nb, int nlc);
 void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, const StepSeq* sq, uint8_t* mask, hipStream_t stream);
@@ -100,6 +100,7 @@ struct grx_sim {
     void* d_gen = nullptr; // GenTables (device)
     void* d_tree = nullptr; // TreeTab (device): the lane-group tree kernel (grx_tree.h) runs this model
     int tree_lds = 0;      // its dynamic LDS
+    int tree_waves = 2;    // 8-env waves per block of the tree kernel: 2 while those blocks fit the CUs in one round, else 4 (a whole CU's LDS)
     float* d_ws = nullptr; // generic workspace
     int64_t seq = 0;       // launches of this handle that write statistics rows (steps, resets, debug steps; recorded ones too)
     bool stats_current = true;   // GRX_T_EPISODE_STATS already holds the statistics of launch `seq` (grx_flush_stats)
@@ -536,7 +537,7 @@ int build_generic(grx_sim* s, const grx_config& c) {
         bool head = false;
         if (p != 0 && !cont[p]) { lane_of[b] = lane_of[p]; cont[p] = 1; }   // a body's first child continues its chain
         else { head = true; lane_of[b] = nchain++; }
-        if (nchain > GRX_TREE_G || depth[b] >= GRX_TREE_MAXSTEP) { fits = false; break; }
+        if (nchain > GRX_TREE_G || depth[b] >= GRX_TREE_LEVELS) { fits = false; break; }
         if (head && p == 0) K.heads0[K.nh0++] = lane_of[b];
         if (head && p != 0) { if (K.body[p].nhc >= 4) { fits = false; break; } K.body[p].hc[K.body[p].nhc++] = lane_of[b]; }
         K.sched[lane_of[b]][depth[b]] = (int8_t)b;
@@ -546,6 +547,8 @@ int build_generic(grx_sim* s, const grx_config& c) {
         for (int a = 0; a < 6; ++a) tb.Ic[a] = T.Ic[b][a];
         tb.mass = T.mass[b]; tb.parent = p; tb.sph_begin = T.sph_begin[b]; tb.sph_end = T.sph_begin[b + 1];
         tb.lane = lane_of[b]; tb.step = depth[b];
+        tb.rot0_identity = 1;
+        for (int a = 0; a < 9; ++a) if (tb.rot0[a] != ((a % 4 == 0) ? 1.f : 0.f)) tb.rot0_identity = 0;
     }
     if (!fits) return GRX_OK;   // more chains / levels than a lane group holds: the one-lane generic kernel runs it
     K.nchain = nchain; K.nstep = nstep;
@@ -565,14 +568,38 @@ int build_generic(grx_sim* s, const grx_config& c) {
     K.torso_body = T.torso_body; K.forehead_body = T.forehead_body;
     memcpy(K.torso_rot, T.torso_rot, sizeof K.torso_rot); memcpy(K.forehead_rot, T.forehead_rot, sizeof K.forehead_rot);
     K.sph_begin0 = T.sph_begin[0]; K.sph_end0 = T.sph_begin[1];
+    {   // the contact pass: a lane's bodies that carry shapes (or whose frame is a foot's), in chain order
+        memset(K.csb, 0xff, sizeof K.csb);
+        int cnt[GRX_TREE_G] = {0};
+        for (int b = 1; b < T.nb; ++b) {
+            const bool foot = b == T.foot_body[0] || b == T.foot_body[1];
+            if (T.sph_begin[b + 1] > T.sph_begin[b] || foot) {
+                const int ln = lane_of[b];
+                if (cnt[ln] >= GRX_TREE_MAXCS) return GRX_OK;   // (the generic kernel runs it)
+                K.csb[ln][cnt[ln]++] = (int8_t)b;
+                K.ncs = std::max(K.ncs, cnt[ln]);
+            }
+        }
+        if (T.foot_body[0] < 1 || T.foot_body[1] < 1) return GRX_OK;   // (feet on the base: not this kernel's layout)
+    }
     K.nlp = T.nlp;
     for (int q = 0; q < T.nlp; ++q) {
         K.lp_ba[q] = (int16_t)T.lp_ba[q]; K.lp_bb[q] = (int16_t)T.lp_bb[q]; K.lp_a[q] = (int16_t)T.lp_a[q]; K.lp_b[q] = (int16_t)T.lp_b[q];
         for (int a = 0; a < 4; ++a) { K.lp_ca[q][a] = T.lp_ca[q][a]; K.lp_cb[q][a] = T.lp_cb[q][a]; }
     }
     for (int l = 0; l <= GEN_MAXLC_H; ++l) K.lc_begin[l] = T.lc_begin[l];
-    const int lds = grx_tree_lds_bytes(T.nb, T.nlc);
-    if (lds > 160 * 1024 - 1024) return GRX_OK;   // the workspace of two waves does not fit a CU's LDS
+    // waves per block: two while those blocks fit the device's CUs in one round (every wave still has a SIMD to itself and the CU's
+    // LDS bandwidth is shared by two), else four -- a whole CU's LDS, one wave on every SIMD.  GRX_TREE_WAVES overrides (A/B runs).
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+        const int epw = grx_tree_envs_per_wave();
+        s->tree_waves = (s->N + 2 * epw - 1) / (2 * epw) <= prop.multiProcessorCount ? 2 : 4;
+        if (const char* tw_ = getenv("GRX_TREE_WAVES")) { const int v = atoi(tw_); if (v == 1 || v == 2 || v == 4) s->tree_waves = v; }
+    }
+    int lds = grx_tree_lds_bytes(T.nb, T.nlc, nchain, s->tree_waves);
+    while (lds > 160 * 1024 - 512 && s->tree_waves > 1) { s->tree_waves /= 2; lds = grx_tree_lds_bytes(T.nb, T.nlc, nchain, s->tree_waves); }
+    if (lds > 160 * 1024 - 512) return GRX_OK;   // the workspace of one wave does not fit a CU's LDS
     TreeTab* dk = nullptr;
     rc = dalloc(s, &dk, 1);
     if (rc) return rc;
@@ -1106,7 +1133,7 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
     if (s->generic)
     {
         if (s->d_tree) {
-            if (grx_launch_step_tree(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
+            if (grx_launch_step_tree(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_waves, s->tree_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
                                      (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st))
                 return fail(GRX_ERR_HIP, "grx_step: cannot raise the dynamic LDS limit of the tree kernel");
         } else if (grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->gen_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions,
@@ -1182,7 +1209,7 @@ int grx_layout(grx_handle s, grx_layout_info* out) {
     memset(out, 0, sizeof *out);
     const char* hf = s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD ? "true" : "false";
     if (s->generic && s->d_tree) {
-        out->lanes_per_env = GRX_TREE_G; out->waves_per_block = grx_tree_envs_per_block() * GRX_TREE_G / 64; out->envs_per_block = grx_tree_envs_per_block();
+        out->lanes_per_env = GRX_TREE_G; out->waves_per_block = s->tree_waves; out->envs_per_block = grx_tree_envs_per_wave() * s->tree_waves;
         snprintf(out->kernel, sizeof out->kernel, "grx_step_tree<%s>", hf);
     } else if (s->generic) {
         out->lanes_per_env = 1; out->waves_per_block = 1; out->envs_per_block = s->gen_epb;

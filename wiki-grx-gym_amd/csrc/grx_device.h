@@ -86,6 +86,8 @@ struct RbsTables {
 // chain, further children start new ones) and at global step g works on its chain's body of depth g.
 #define GRX_TREE_G 8
 #define GRX_TREE_MAXSTEP 16
+#define GRX_TREE_LEVELS 10   // depth levels the tree kernel's passes are unrolled for (deeper trees run on the generic kernel)
+#define GRX_TREE_MAXCS 8     // bodies of one chain that carry collision shapes (or a foot frame): rounds of the contact pass
 struct TreeBody {            // 36 words
     float axis[3], mass;     // joint axis (child frame), mass
     float rot0[9];           // child(q = 0) -> parent rotation, row-major
@@ -97,7 +99,8 @@ struct TreeBody {            // 36 words
     int32_t nhc;             // children that START a chain (they hand their articulated inertia up through the chain's LDS slot) ...
     int32_t hc[4];           // ... the lanes of those chains
     int32_t lane, step;      // where this body is processed
-    int32_t pad[2];
+    int32_t rot0_identity;   // the joint frame is not rotated against the parent's (rot0 = 1): skips a 3 x 3 product
+    int32_t pad;
 };
 struct TreeDof { float kp, kd, q0, effort, vlim, qlo, qhi, slo, shi, amin, amax, Klim, Clim; int32_t lane; float arm; int32_t pad; };   // 16 words (arm: joint-space armature)
 struct TreeSph { float x, y, z, r, dmax; int32_t slot, link, pad; };   // 8 words
@@ -121,7 +124,9 @@ struct TreeTab {
     int16_t lp_ba[48], lp_bb[48], lp_a[48], lp_b[48];
     float lp_ca[48][4], lp_cb[48][4];
     int32_t lc_begin[25];
-    int32_t pad2[3];
+    int32_t ncs;                                      // rounds of the contact pass = the longest list below
+    int32_t pad2[2];
+    int8_t csb[GRX_TREE_G][GRX_TREE_MAXCS];           // bodies of lane c's chain that carry collision shapes or a foot frame (-1: none)
 };
 
 // every URDF link frame by carrying body (the tree kernel's GRX_T_RIGID_BODY_STATES)

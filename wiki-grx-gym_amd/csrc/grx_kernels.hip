@@ -2037,10 +2037,10 @@ extern "C" int grx_launch_step_generic(const KParams* dP, const void* tables, fl
 extern "C" void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, long long seq, uint8_t* mask, hipStream_t stream) {
     hipLaunchKernelGGL(grx_reset_all_generic, dim3((N + epb - 1) / epb), dim3(epb), 0, stream, dP, static_cast<const GenTables*>(tables), step, seq, mask);
 }
-// the tree kernel (grx_tree.h): 8 lanes per env, two 8-env waves per block
-extern "C" int grx_tree_lds_bytes(int nb, int nlc) { return (int)sizeof(TreeTab) + TWAVES * tree_offsets(nb, nlc).total * TEPW * 4; }
-extern "C" int grx_tree_envs_per_block(void) { return TEPB; }
-extern "C" int grx_launch_step_tree(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int lds_bytes, int heightfield, const float* actions, float delay,
+// the tree kernel (grx_tree.h): 8 lanes per env, two or four 8-env waves per block
+extern "C" int grx_tree_lds_bytes(int nb, int nlc, int nchain, int waves) { return (int)sizeof(TreeTab) + waves * tree_offsets(nb, nlc, nchain).total * TEPW * 4; }
+extern "C" int grx_tree_envs_per_wave(void) { return TEPW; }
+extern "C" int grx_launch_step_tree(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions, float delay,
                                     long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {
     static bool raised = false;
     if (!raised) {   // > 64 KB of dynamic LDS needs the opt-in
@@ -2048,11 +2048,11 @@ extern "C" int grx_launch_step_tree(const KParams* dP, const void* tree_tab, con
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
         raised = true;
     }
-    const int nblocks = (N + TEPB - 1) / TEPB;
+    const int nblocks = (N + TEPW * waves - 1) / (TEPW * waves);
     const TreeTab* Tt = static_cast<const TreeTab*>(tree_tab);
     const GenTables* Tg = static_cast<const GenTables*>(gen_tab);
-    if (heightfield) hipLaunchKernelGGL(grx_step_tree<true>, dim3(nblocks), dim3(64 * TWAVES), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq);
-    else hipLaunchKernelGGL(grx_step_tree<false>, dim3(nblocks), dim3(64 * TWAVES), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq);
+    if (heightfield) hipLaunchKernelGGL(grx_step_tree<true>, dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq);
+    else hipLaunchKernelGGL(grx_step_tree<false>, dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq);
     return 0;
 }
 extern "C" int grx_generic_tables_size(void) { return (int)sizeof(GenTables); }

@@ -1,39 +1,46 @@
 // grx_tree.h -- the tree step kernel: a LANE GROUP per env, a chain of the robot's tree per lane (included by
 // grx_kernels.hip inside its anonymous namespace, after grx_generic.h whose helpers it shares).
 //
-// The 32-DOF full-body GR1T1 (BASELINE.json config 5) is six chains around the floating base: two 6-joint legs, the
-// 3-joint waist that carries the torso, and -- hanging from the torso -- the head (3 joints) and two 7-joint arms.  The
+// The 32-DOF full-body GR1T1 (BASELINE.json config 5) is five chains around the floating base: two 6-joint legs, the 3-joint
+// waist that carries the torso and goes on into the head (3 joints), and -- hanging from the torso -- two 7-joint arms.  The
 // generic-tree kernel (grx_generic.h) walks those 32 bodies one after the other on ONE lane per env: ~50 k instructions per
-// sub-step on a wave that issues one instruction per ~4.5 cycles (tools/micro/operand_rate.hip), a 64-env wave per CU, three
-// SIMDs of four idle.  Here an env is a group of GRX_TREE_G = 8 lanes and every lane owns one chain (a body's first child
-// continues its chain, further children start new chains: legs, waist + head, arms = 5 lanes of this robot):
+// sub-step on a wave that issues one instruction per ~4.5 cycles (tools/micro/operand_rate.hip).  Here an env is a group of
+// GRX_TREE_G = 8 lanes and every lane owns one chain (a body's first child continues its chain, further children start new
+// chains):
 //
-//   * at global step g a lane works on its chain's body of depth g: the three passes of the articulated-body algorithm are
-//     loops over the 10 depth levels of the tree instead of its 32 bodies; a chain hands frames, articulated inertias and
-//     accelerations on in registers from one step to the next;
-//   * chains meet through LDS: a chain's first body takes its parent's frame (and, in the last pass, its acceleration) from the
-//     parent's workspace row, written one step earlier by the parent's lane; on the way in it parks its articulated inertia and
-//     bias force in its chain's slot, which the parent's lane -- or, for the chains that hang from the base, every lane -- adds
-//     in a fixed order.  All lanes of an env sit in one wave: program order is the only synchronisation;
-//   * per-body intermediates, the env's joint state, link forces and friction anchors live in an LDS workspace laid out
-//     [word][env of the wave]: 8.9 KB per env of the 33-body robot, two 8-env waves per block and CU;
+//   * at depth level g a lane works on its chain's body of depth g: the three passes of the articulated-body algorithm are
+//     loops over the 10 depth levels of the tree instead of its 32 bodies;
+//   * round 4: the LDS row of a body is 25 words instead of 53 -- its frame (R, rho, w, v: the child chains' start, the contact
+//     pass, the self-collision, GRX_T_RIGID_BODY_STATES), its bias-force accumulator (contact and self-collision forces are added
+//     by whichever lane finds them) and its motor torque; what pass 3 needs from pass 2 (U = I^A S, 1/d, u, the joint axis) is
+//     parked in the slots of that row that are dead by then; the joint state lives in registers; the velocity-product
+//     accelerations are folded into the bias forces (tree_outward) instead of being kept per body; rigid inertias are formed
+//     where they are consumed.  Laid out [word][env of the wave] with an ODD body stride (the lanes of a group, which sit on
+//     different bodies at the same word, fall on different banks); a chain parks its articulated inertia and bias force in its
+//     slot for the parent's lane.  36 KB per 8-env wave of the 33-body robot instead of 71 KB: FOUR waves per CU, one on every
+//     SIMD (round 3: two);
+//   * terrain contacts run in a rolled pass of their own over the lane's bodies that carry shapes (a table: three rounds for
+//     this robot instead of ten levels), on the frames in LDS -- the unrolled passes stay small (instruction cache);
+//   * all lanes of an env sit in one wave: program order is the only synchronisation;
 //   * the same formulation as every kernel here -- spatial quantities in world axes about the base origin, so a child's
 //     inertia simply ADDS into its parent --, the same contact, self-collision and env-pipeline arithmetic as grx_generic.h
-//     (which stays as the fallback for trees with more than eight chains, and as this kernel's cross-check: GRX_TREE=0).
+//     (which stays as the fallback for trees with more than eight chains or ten levels, and as this kernel's cross-check:
+//     GRX_TREE=0).
 #pragma once
 
-constexpr int TG = GRX_TREE_G, TEPW = 64 / TG, TWAVES = 2, TEPB = TEPW * TWAVES;   // lanes per env, envs per wave / block
-// workspace words per body
-enum { T_R = 0, T_RHO = 9, T_W = 12, T_V = 15, T_A = 18, T_S = 21, T_CA = 24, T_CL = 27, T_PA = 30, T_PL = 33, T_UA = 36, T_UL = 39,
-       T_DI = 42, T_U = 43, T_AK = 44, T_H = 50, T_NB = 53 };
+constexpr int TG = GRX_TREE_G, TEPW = 64 / TG;   // lanes per env, envs per wave
+constexpr int TWAVES_MAX = 4;                    // waves per block: 2 while the blocks fit the CUs in one round, else 4 (grx_capi.cpp)
+// LDS workspace words per body (bodies 1 .. nb - 1; the base lives in registers)
+enum { T_R = 0, T_RHO = 9, T_W = 12, T_V = 15, T_PA = 18, T_PL = 21, T_TAU = 24, T_NB = 25 };   // (T_TAU: the joint's motor torque of the current sub-step)
 constexpr int T_UPW = 27;    // a chain's hand-over to its parent: A 6, B 9, D 6, pa 3, pl 3
-constexpr int T_MISC = 16;   // foot link velocities before the sub-step (6), foot positions (6), foot velocities (3 + 1 spare) -- see below
-enum { TD_Q = 0, TD_QD = 1, TD_TAU = 2, TD_ACUR = 3, TD_ALAST = 4, TD_STR = 5, TD_N = 6 };
+constexpr int T_MISC = 8;    // foot link velocities before the sub-step (6) + 2 spare
+enum { TD_ACUR = 0, TD_ALAST = 1, TD_STR = 2, TD_N = 3 };   // per-dof rows every sub-step reads: clipped action, last action, motor strength
+#define TBO(b) (((b) - 1) * T_NB)
 
 struct TreeOff { int up, dof, lf, an, misc, total; };
-__host__ __device__ inline TreeOff tree_offsets(int nb, int nlc) {
+__host__ __device__ inline TreeOff tree_offsets(int nb, int nlc, int nchain) {
     TreeOff o;
-    o.up = nb * T_NB; o.dof = o.up + TG * T_UPW; o.lf = o.dof + TD_N * GRX_MAX_DOFS; o.an = o.lf + nlc * 3; o.misc = o.an + 24; o.total = o.misc + T_MISC;
+    o.up = (nb - 1) * T_NB; o.dof = o.up + nchain * T_UPW; o.lf = o.dof + TD_N * GRX_MAX_DOFS; o.an = o.lf + nlc * 3; o.misc = o.an + 24; o.total = o.misc + T_MISC;
     return o;
 }
 #define TW(addr) wsw[(addr) * TEPW + ei]
@@ -45,6 +52,7 @@ GRX_DEV V3 grp_bcast(V3 v, int lane, int src) { return v3(grp_bcast(v.x, lane, s
 GRX_DEV V3 tw_v3(const float* wsw, int ei, int a) { return v3(TW(a), TW(a + 1), TW(a + 2)); }
 GRX_DEV void tw_put(float* wsw, int ei, int a, V3 x) { TW(a) = x.x; TW(a + 1) = x.y; TW(a + 2) = x.z; }
 GRX_DEV R3 tw_R(const float* wsw, int ei, int a) { R3 R; R.cx = tw_v3(wsw, ei, a); R.cy = tw_v3(wsw, ei, a + 3); R.cz = tw_v3(wsw, ei, a + 6); return R; }
+GRX_DEV void tree_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }   // (one wave: LDS operations complete in program order)
 
 // child rotation R_parent * rot0 * Rot(axis, q) (gen_joint_rot on the LDS table)
 GRX_DEV R3 tree_joint_rot(const R3& Rp, const TreeBody& tb, float q) {
@@ -54,10 +62,12 @@ GRX_DEV R3 tree_joint_rot(const R3& Rp, const TreeBody& tb, float q) {
     const V3 qx = v3(cs + ax * ax * oc, az * sn + ax * ay * oc, -ay * sn + ax * az * oc);
     const V3 qy = v3(-az * sn + ax * ay * oc, cs + ay * ay * oc, ax * sn + ay * az * oc);
     const V3 qz = v3(ay * sn + ax * az * oc, -ax * sn + ay * az * oc, cs + az * az * oc);
-    R3 J;
-    J.cx = rot(Rp, v3(tb.rot0[0], tb.rot0[3], tb.rot0[6]));
-    J.cy = rot(Rp, v3(tb.rot0[1], tb.rot0[4], tb.rot0[7]));
-    J.cz = rot(Rp, v3(tb.rot0[2], tb.rot0[5], tb.rot0[8]));
+    R3 J = Rp;
+    if (!tb.rot0_identity) {   // (only the shoulders of the GR1 carry a rotated joint frame)
+        J.cx = rot(Rp, v3(tb.rot0[0], tb.rot0[3], tb.rot0[6]));
+        J.cy = rot(Rp, v3(tb.rot0[1], tb.rot0[4], tb.rot0[7]));
+        J.cz = rot(Rp, v3(tb.rot0[2], tb.rot0[5], tb.rot0[8]));
+    }
     R3 R;
     R.cx = rot(J, qx); R.cy = rot(J, qy); R.cz = rot(J, qz);
     return R;
@@ -125,77 +135,113 @@ struct TreeEnv {   // what every lane of the env's group holds (redundantly)
     float mu, om_e, hmax;
 };
 
-// pass 1 (root -> leaves) over the depth levels.  KIN: frames and velocities only (the state after the last sub-step).
-template <bool HF, bool KIN>
-GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0, bool use_last, const float* strength) {
+// what a lane keeps in REGISTERS for its own chain, indexed by the depth level: the level loops are UNROLLED (TNG levels, compile
+// time).  Measured both ways on MI355X (round 4): the unrolled passes are 200 KB of code and still 12 % faster than the rolled
+// ones (388 against 443 us per step at 4096 envs), whose lanes pick their joint state with chains of selects and keep the joint
+// axis in LDS -- the kernel is bound by its instruction count (one wave per SIMD issues one instruction per ~4 cycles), not by
+// instruction fetch.
+constexpr int TNG = GRX_TREE_LEVELS;
+struct TreeRegs {
+    int sb[TNG];            // body of this lane at level g, -1: none
+    float q[TNG], qd[TNG];  // joint state
+    V3 Sa[TNG];             // joint axis in world axes (the motion subspace is S = (a; rho x a): rho comes back from the frame in LDS)
+};
+
+// pass 1 (root -> leaves) over the depth levels: frames and velocities into LDS; KIN: nothing else (the state after the last sub-step).
+// The velocity-product accelerations c_k are FOLDED into the bodies' bias forces (as in the eight-wave lower-limb kernel,
+// grx_wavepipe.h rigid_bias_z): with zeta_k = the sum of the c_j along the path from the base and a_k = a^_k + zeta_k, body k obeys
+// f_k = I_k a^_k + (p_k + I_k zeta_k) and a^_k = a^_parent + S_k qdd_k -- the articulated-body recursion in a^ has no c terms at
+// all: nothing to keep per level, no I^A c products in pass 2, no additions in pass 3.  A body with chains hanging from it leaves
+// its zeta in their hand-over slots (free until pass 2).
+template <bool KIN>
+GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0, bool use_last, int first, int last, TreeRegs& G) {
     R3 Rc = R0;
     V3 rho_c = v3(0.f, 0.f, 0.f), w_c = E.B.ang, v_c = E.B.vel;
-    const int first = T.first[c];
-    for (int g = 0; g < T.nstep; ++g) {
-        const int b = T.sched[c][g];
-        if (b >= 0) {
+    V3 za = v3(0.f, 0.f, 0.f), zl = v3(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < TNG; ++g) {
+        if (g >= T.nstep) break;   // (uniform)
+        if (G.sb[g] >= 0) {
+            const int b = G.sb[g];
             const TreeBody& tb = T.body[b];
             const int p = tb.parent, j = b - 1;
-            if (g == first && p != 0) {   // the chain hangs from another chain's body, processed one step earlier
-                Rc = tw_R(wsw, ei, p * T_NB + T_R); rho_c = tw_v3(wsw, ei, p * T_NB + T_RHO);
-                w_c = tw_v3(wsw, ei, p * T_NB + T_W); v_c = tw_v3(wsw, ei, p * T_NB + T_V);
+            if (g == first && p != 0) {   // the chain hangs from another chain's body, processed one level earlier
+                Rc = tw_R(wsw, ei, TBO(p) + T_R); rho_c = tw_v3(wsw, ei, TBO(p) + T_RHO);
+                w_c = tw_v3(wsw, ei, TBO(p) + T_W); v_c = tw_v3(wsw, ei, TBO(p) + T_V);
+                if (!KIN) { za = tw_v3(wsw, ei, o.up + c * T_UPW); zl = tw_v3(wsw, ei, o.up + c * T_UPW + 3); }
             }
-            const float qj = TW(o.dof + TD_Q * GRX_MAX_DOFS + j), qdj = TW(o.dof + TD_QD * GRX_MAX_DOFS + j);
+            const float qj = G.q[g], qdj = G.qd[g];
             const V3 rho = rho_c + rot(Rc, v3(tb.jpos[0], tb.jpos[1], tb.jpos[2]));
             const R3 R = tree_joint_rot(Rc, tb, qj);
             const V3 a = rot(R, v3(tb.axis[0], tb.axis[1], tb.axis[2]));
             const V3 s = cross(rho, a);
             const V3 w = fma3(a, qdj, w_c), v = fma3(s, qdj, v_c);
-            const int wb = b * T_NB;
+            const int wb = TBO(b);
             tw_put(wsw, ei, wb + T_R, R.cx); tw_put(wsw, ei, wb + T_R + 3, R.cy); tw_put(wsw, ei, wb + T_R + 6, R.cz);
             tw_put(wsw, ei, wb + T_RHO, rho); tw_put(wsw, ei, wb + T_W, w); tw_put(wsw, ei, wb + T_V, v);
             if (!KIN) {
                 const TreeDof& td = T.dof[j];
-                {   // _compute_torques (legged_robot.py:679-715) + the joint-limit spring/damper of this sub-step
-                    const float act_ = use_last ? TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j) : TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j);
+                {   // _compute_torques (legged_robot.py:679-715)
+                    const float act_ = TW(o.dof + (use_last ? TD_ALAST : TD_ACUR) * GRX_MAX_DOFS + j);
                     float t = td.kp * (act_ * P.action_scale + td.q0 - qj) - td.kd * qdj;
                     t *= TW(o.dof + TD_STR * GRX_MAX_DOFS + j);   // motor strength of this env (domain randomisation)
-                    TW(o.dof + TD_TAU * GRX_MAX_DOFS + j) = fminf(fmaxf(t, -td.effort), td.effort);
+                    TW(wb + T_TAU) = fminf(fmaxf(t, -td.effort), td.effort);
                 }
-                const V3 ca = cross(w_c, a) * qdj;
-                const V3 cl = (cross(v_c, a) + cross(w_c, s)) * qdj;
+                G.Sa[g] = a;
+                za = fma3(cross(w_c, a), qdj, za);
+                zl = fma3(cross(v_c, a) + cross(w_c, s), qdj, zl);
                 const V3 kap = rho + rot(R, v3(tb.com[0], tb.com[1], tb.com[2]));
                 const S3 Ic = {tb.Ic[0], tb.Ic[1], tb.Ic[2], tb.Ic[3], tb.Ic[4], tb.Ic[5]};
-                S3 Ak; V3 h;
-                rigid_inertia(R, kap, tb.mass, Ic, Ak, h);
                 V3 pa, pl;
-                rigid_bias(R, kap, tb.mass, Ic, w, v, pa, pl);
-                for (int i0 = tb.sph_begin; i0 < tb.sph_end; i0 += 4) {   // up to four shapes at a time: their terrain lookups in flight together
-                    V3 xr[4]; TerrainAt th[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (i0 + u < tb.sph_end) {
-                            const TreeSph& S = T.sph[i0 + u];
-                            xr[u] = rho + rot(R, v3(S.x, S.y, S.z));
-                            th[u].h = 0.f; th[u].gx = 0.f; th[u].gy = 0.f;
-                            if (E.B.pos.z + xr[u].z - S.r <= E.hmax) th[u].h = terrain_height<HF>(P, E.B.pos.x + xr[u].x, E.B.pos.y + xr[u].y, th[u].gx, th[u].gy);
-                        }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (i0 + u < tb.sph_end) {
-                            const V3 F = tree_sphere<HF>(P, T.sph[i0 + u], w, v, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr[u], th[u]);
-                            pa = pa - cross(xr[u], F); pl = pl - F;
-                        }
-                }
-#pragma unroll
-                for (int f = 0; f < 2; ++f)
-                    if (T.foot_body[f] == b) {   // foot link velocity BEFORE this sub-step's integration
-                        const V3 fr = rho + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
-                        tw_put(wsw, ei, o.misc + f * 3, v + cross(w, fr));
-                    }
-                tw_put(wsw, ei, wb + T_A, a); tw_put(wsw, ei, wb + T_S, s); tw_put(wsw, ei, wb + T_CA, ca); tw_put(wsw, ei, wb + T_CL, cl);
-                tw_put(wsw, ei, wb + T_PA, pa); tw_put(wsw, ei, wb + T_PL, pl);
-                TW(wb + T_AK) = Ak.xx; TW(wb + T_AK + 1) = Ak.xy; TW(wb + T_AK + 2) = Ak.xz; TW(wb + T_AK + 3) = Ak.yy; TW(wb + T_AK + 4) = Ak.yz; TW(wb + T_AK + 5) = Ak.zz;
-                tw_put(wsw, ei, wb + T_H, h);
+                rigid_bias_z(R, kap, tb.mass, Ic, w, v, za, zl, pa, pl);
+                tw_put(wsw, ei, wb + T_PA, pa); tw_put(wsw, ei, wb + T_PL, pl);   // (contacts and self-collision add into these)
+                for (int k = 0; k < tb.nhc; ++k) { tw_put(wsw, ei, o.up + tb.hc[k] * T_UPW, za); tw_put(wsw, ei, o.up + tb.hc[k] * T_UPW + 3, zl); }
             }
             Rc = R; rho_c = rho; w_c = w; v_c = v;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (one wave: LDS operations complete in program order)
+        tree_fence();
+    }
+}
+
+// terrain contacts of the lane's bodies that carry shapes (T.csb: a few rounds), on the frames in LDS; the foot link's velocity
+// BEFORE this sub-step's integration (sub-step averaged foot speed, legged_robot_fftai.py:79-81) on the way
+template <bool HF>
+GRX_DEV void tree_contacts(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E) {
+    for (int k = 0; k < T.ncs; ++k) {
+        const int b = T.csb[c][k];
+        if (b >= 0) {
+            const TreeBody& tb = T.body[b];
+            const int wb = TBO(b);
+            const R3 R = tw_R(wsw, ei, wb + T_R);
+            const V3 rho = tw_v3(wsw, ei, wb + T_RHO), w = tw_v3(wsw, ei, wb + T_W), v = tw_v3(wsw, ei, wb + T_V);
+            V3 fa = v3(0.f, 0.f, 0.f), fl = v3(0.f, 0.f, 0.f);
+            for (int i0 = tb.sph_begin; i0 < tb.sph_end; i0 += 4) {   // up to four shapes at a time: their terrain lookups in flight together
+                V3 xr[4]; TerrainAt th[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u < tb.sph_end) {
+                        const TreeSph& S = T.sph[i0 + u];
+                        xr[u] = rho + rot(R, v3(S.x, S.y, S.z));
+                        th[u].h = 0.f; th[u].gx = 0.f; th[u].gy = 0.f;
+                        if (E.B.pos.z + xr[u].z - S.r <= E.hmax) th[u].h = terrain_height<HF>(P, E.B.pos.x + xr[u].x, E.B.pos.y + xr[u].y, th[u].gx, th[u].gy);
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u < tb.sph_end) {
+                        const V3 F = tree_sphere<HF>(P, T.sph[i0 + u], w, v, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr[u], th[u]);
+                        fa = fa + cross(xr[u], F); fl = fl + F;
+                    }
+            }
+            TW(wb + T_PA) -= fa.x; TW(wb + T_PA + 1) -= fa.y; TW(wb + T_PA + 2) -= fa.z;
+            TW(wb + T_PL) -= fl.x; TW(wb + T_PL + 1) -= fl.y; TW(wb + T_PL + 2) -= fl.z;
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                if (T.foot_body[f] == b) {
+                    const V3 fr = rho + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
+                    tw_put(wsw, ei, o.misc + f * 3, v + cross(w, fr));
+                }
+        }
+        tree_fence();
     }
 }
 
@@ -213,70 +259,78 @@ GRX_DEV void tree_add_up(const float* wsw, int ei, int a, S3& A, M3& B, S3& D, V
     pa = pa + tw_v3(wsw, ei, a + 21); pl = pl + tw_v3(wsw, ei, a + 24);
 }
 
-// pass 2 (leaves -> root): articulated inertias and bias forces
-GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o) {
+// pass 2 (leaves -> root): articulated inertias and bias forces; a chain's running [A B; B^T D], pa, pl stay in registers.  What
+// pass 3 needs of a body is parked in slots of its LDS row that nobody reads any more in this sub-step: 1/d, u and the joint
+// in the rotation's, U = I^A S in the bias force's.
+enum { T_DI = T_R, T_U = T_R + 1, T_UA = T_PA, T_UL = T_PL };
+GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, int first, int last, const TreeRegs& G) {
     S3 cA = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cD = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     M3 cB = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     V3 cpa = v3(0.f, 0.f, 0.f), cpl = v3(0.f, 0.f, 0.f);
-    const int first = T.first[c], last = T.last[c];
-    for (int g = T.nstep - 1; g >= 0; --g) {
-        const int b = T.sched[c][g];
-        if (b >= 0) {
+#pragma unroll
+    for (int g = TNG - 1; g >= 0; --g) {
+        if (g >= T.nstep) continue;   // (uniform)
+        if (G.sb[g] >= 0) {
+            const int b = G.sb[g];
             const TreeBody& tb = T.body[b];
-            const int j = b - 1, wb = b * T_NB;
-            const V3 h = tw_v3(wsw, ei, wb + T_H);
+            const int j = b - 1, wb = TBO(b);
+            const R3 R = tw_R(wsw, ei, wb + T_R);
+            const V3 rho = tw_v3(wsw, ei, wb + T_RHO);
+            V3 pa = tw_v3(wsw, ei, wb + T_PA), pl = tw_v3(wsw, ei, wb + T_PL);
+            float t = TW(wb + T_TAU);
+            const V3 kap = rho + rot(R, v3(tb.com[0], tb.com[1], tb.com[2]));
+            const S3 Ic = {tb.Ic[0], tb.Ic[1], tb.Ic[2], tb.Ic[3], tb.Ic[4], tb.Ic[5]};
             const float m = tb.mass;
-            S3 A = {TW(wb + T_AK), TW(wb + T_AK + 1), TW(wb + T_AK + 2), TW(wb + T_AK + 3), TW(wb + T_AK + 4), TW(wb + T_AK + 5)};
+            S3 A; V3 h;
+            rigid_inertia(R, kap, m, Ic, A, h);
             M3 Bm = {0.f, -h.z, h.y, h.z, 0.f, -h.x, -h.y, h.x, 0.f};
             S3 D = {m, 0.f, 0.f, m, 0.f, m};
-            const V3 a = tw_v3(wsw, ei, wb + T_A), s = tw_v3(wsw, ei, wb + T_S), ca = tw_v3(wsw, ei, wb + T_CA), cl = tw_v3(wsw, ei, wb + T_CL);
-            V3 pa = tw_v3(wsw, ei, wb + T_PA), pl = tw_v3(wsw, ei, wb + T_PL);
             if (g < last) { A = A + cA; Bm = Bm + cB; D = D + cD; pa = pa + cpa; pl = pl + cpl; }   // the chain's own child, in registers
             for (int k = 0; k < tb.nhc; ++k) tree_add_up(wsw, ei, o.up + tb.hc[k] * T_UPW, A, Bm, D, pa, pl);   // chains that hang from this body, fixed order
+            const V3 a = G.Sa[g], s = cross(rho, a);
             const V3 ua = mul(A, a) + mul(Bm, s);
             const V3 ul = mulT(Bm, a) + mul(D, s);
             const TreeDof& td = T.dof[j];
             const float di = grx_rcp(dot(a, ua) + dot(s, ul) + td.arm);
-            const float qj = TW(o.dof + TD_Q * GRX_MAX_DOFS + j), qdj = TW(o.dof + TD_QD * GRX_MAX_DOFS + j);
-            float t = TW(o.dof + TD_TAU * GRX_MAX_DOFS + j);   // joint-limit spring/damper on top of the motor torque
-            if (qj < td.qlo) t += td.Klim * (td.qlo - qj) - td.Clim * qdj;
+            const float qj = G.q[g], qdj = G.qd[g];
+            if (qj < td.qlo) t += td.Klim * (td.qlo - qj) - td.Clim * qdj;   // joint-limit spring/damper on top of the motor torque
             else if (qj > td.qhi) t += td.Klim * (td.qhi - qj) - td.Clim * qdj;
             const float u = t - (dot(a, pa) + dot(s, pl));
             syr(A, ua, di); ger(Bm, ua, ul, di); syr(D, ul, di);
             const float ud = u * di;
-            const V3 npa = pa + mul(A, ca) + mul(Bm, cl) + ua * ud;
-            const V3 npl = pl + mulT(Bm, ca) + mul(D, cl) + ul * ud;
-            tw_put(wsw, ei, wb + T_UA, ua); tw_put(wsw, ei, wb + T_UL, ul); TW(wb + T_DI) = di; TW(wb + T_U) = u;
+            const V3 npa = fma3(ua, ud, pa), npl = fma3(ul, ud, pl);
+            TW(wb + T_DI) = di; TW(wb + T_U) = u;
+            tw_put(wsw, ei, wb + T_UA, ua); tw_put(wsw, ei, wb + T_UL, ul);
             if (g == first) tree_put_up(wsw, ei, o.up + c * T_UPW, A, Bm, D, npa, npl);
             else { cA = A; cB = Bm; cD = D; cpa = npa; cpl = npl; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        tree_fence();
     }
 }
 
-// pass 3 (root -> leaves): accelerations, joint integration
-GRX_DEV void tree_accel(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, V3 alpha, V3 acc) {
+// pass 3 (root -> leaves): accelerations a^ (see tree_outward), joint integration
+GRX_DEV void tree_accel(KP P, const TreeTab& T, float* wsw, int ei, int c, V3 alpha, V3 acc, int first, int last, TreeRegs& G) {
     V3 aa_c = alpha, al_c = acc;
-    const int first = T.first[c];
     const float dt = P.sim_dt;
-    for (int g = 0; g < T.nstep; ++g) {
-        const int b = T.sched[c][g];
-        if (b >= 0) {
+#pragma unroll
+    for (int g = 0; g < TNG; ++g) {
+        if (g >= T.nstep) break;   // (uniform)
+        if (G.sb[g] >= 0) {
+            const int b = G.sb[g];
             const TreeBody& tb = T.body[b];
-            const int p = tb.parent, j = b - 1, wb = b * T_NB;
-            if (g == first && p != 0) { aa_c = tw_v3(wsw, ei, p * T_NB + T_PA); al_c = tw_v3(wsw, ei, p * T_NB + T_PL); }   // (the parent parked its acceleration there)
-            const V3 a = tw_v3(wsw, ei, wb + T_A), s = tw_v3(wsw, ei, wb + T_S);
-            const V3 pa_ = aa_c + tw_v3(wsw, ei, wb + T_CA), pl_ = al_c + tw_v3(wsw, ei, wb + T_CL);
-            const float qdd = (TW(wb + T_U) - (dot(tw_v3(wsw, ei, wb + T_UA), pa_) + dot(tw_v3(wsw, ei, wb + T_UL), pl_))) * TW(wb + T_DI);
-            aa_c = fma3(a, qdd, pa_); al_c = fma3(s, qdd, pl_);
-            tw_put(wsw, ei, wb + T_PA, aa_c); tw_put(wsw, ei, wb + T_PL, al_c);   // bias force slots are free by now: the children's parent acceleration
-            const TreeDof& td = T.dof[j];
-            float vq = fmaf(qdd, dt, TW(o.dof + TD_QD * GRX_MAX_DOFS + j));
-            vq = fminf(fmaxf(vq, -td.vlim), td.vlim);
-            TW(o.dof + TD_QD * GRX_MAX_DOFS + j) = vq;
-            TW(o.dof + TD_Q * GRX_MAX_DOFS + j) = fmaf(vq, dt, TW(o.dof + TD_Q * GRX_MAX_DOFS + j));
+            const int p = tb.parent, j = b - 1, wb = TBO(b);
+            if (g == first && p != 0) { aa_c = tw_v3(wsw, ei, TBO(p) + T_PA); al_c = tw_v3(wsw, ei, TBO(p) + T_PL); }   // (the parent parked its acceleration there)
+            const V3 ua = tw_v3(wsw, ei, wb + T_UA), ul = tw_v3(wsw, ei, wb + T_UL), rho = tw_v3(wsw, ei, wb + T_RHO), a = G.Sa[g];
+            const float qdd = (TW(wb + T_U) - (dot(ua, aa_c) + dot(ul, al_c))) * TW(wb + T_DI);
+            aa_c = fma3(a, qdd, aa_c); al_c = fma3(cross(rho, a), qdd, al_c);
+            if (tb.nhc > 0) { tw_put(wsw, ei, wb + T_PA, aa_c); tw_put(wsw, ei, wb + T_PL, al_c); }   // the hanging chains' parent acceleration (U has been read)
+            float vq = fmaf(qdd, dt, G.qd[g]);
+            const float vlim = T.dof[j].vlim;
+            vq = fminf(fmaxf(vq, -vlim), vlim);
+            G.qd[g] = vq;
+            G.q[g] = fmaf(vq, dt, G.q[g]);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        tree_fence();
     }
 }
 
@@ -294,9 +348,10 @@ GRX_DEV void tree_self_collision(KP P, const TreeTab& T, float* wsw, int ei, int
         ChainKin Ka, Kb;
         if (lp < T.nlp) {
             ba = T.lp_ba[lp]; bb = T.lp_bb[lp];
+            // (positions for the bounding test; the velocities -- contact damping only -- are fetched by the few lanes that hit)
             if (ba == 0) Ka = ChainKin{R0, v3(0.f, 0.f, 0.f), E.B.ang, E.B.vel};
-            else Ka = ChainKin{tw_R(wsw, ei, ba * T_NB + T_R), tw_v3(wsw, ei, ba * T_NB + T_RHO), tw_v3(wsw, ei, ba * T_NB + T_W), tw_v3(wsw, ei, ba * T_NB + T_V)};
-            Kb = ChainKin{tw_R(wsw, ei, bb * T_NB + T_R), tw_v3(wsw, ei, bb * T_NB + T_RHO), tw_v3(wsw, ei, bb * T_NB + T_W), tw_v3(wsw, ei, bb * T_NB + T_V)};
+            else Ka = ChainKin{tw_R(wsw, ei, TBO(ba) + T_R), tw_v3(wsw, ei, TBO(ba) + T_RHO), v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
+            Kb = ChainKin{tw_R(wsw, ei, TBO(bb) + T_R), tw_v3(wsw, ei, TBO(bb) + T_RHO), v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
             const V3 ca = Ka.rho + rot(Ka.R, v3(T.lp_ca[lp][0], T.lp_ca[lp][1], T.lp_ca[lp][2]));
             const V3 cb = Kb.rho + rot(Kb.R, v3(T.lp_cb[lp][0], T.lp_cb[lp][1], T.lp_cb[lp][2]));
             const V3 d = ca - cb;
@@ -308,6 +363,8 @@ GRX_DEV void tree_self_collision(KP P, const TreeTab& T, float* wsw, int ei, int
             if (!__any(hit && c == k)) continue;
             if (hit && c == k) {
                 const int la = T.lp_a[lp], lb = T.lp_b[lp];
+                if (ba != 0) { Ka.w = tw_v3(wsw, ei, TBO(ba) + T_W); Ka.v = tw_v3(wsw, ei, TBO(ba) + T_V); }
+                Kb.w = tw_v3(wsw, ei, TBO(bb) + T_W); Kb.v = tw_v3(wsw, ei, TBO(bb) + T_V);
                 V3 Fa = v3(0.f, 0.f, 0.f), Ta = v3(0.f, 0.f, 0.f);
                 for (int i = T.lc_begin[la]; i < T.lc_begin[la + 1]; ++i) {
                     SphC si; si.x = T.sph[i].x; si.y = T.sph[i].y; si.z = T.sph[i].z; si.r = T.sph[i].r; si.dmax = T.sph[i].dmax;
@@ -321,8 +378,8 @@ GRX_DEV void tree_self_collision(KP P, const TreeTab& T, float* wsw, int ei, int
                 }
                 // F on link a (body ba), -F on link b (body bb)
                 if (ba == 0) { dpa0 = dpa0 - Ta; dpl0 = dpl0 - Fa; }
-                else { const int wa = ba * T_NB; TW(wa + T_PA) -= Ta.x; TW(wa + T_PA + 1) -= Ta.y; TW(wa + T_PA + 2) -= Ta.z; TW(wa + T_PL) -= Fa.x; TW(wa + T_PL + 1) -= Fa.y; TW(wa + T_PL + 2) -= Fa.z; }
-                const int wb_ = bb * T_NB;
+                else { const int wa = TBO(ba); TW(wa + T_PA) -= Ta.x; TW(wa + T_PA + 1) -= Ta.y; TW(wa + T_PA + 2) -= Ta.z; TW(wa + T_PL) -= Fa.x; TW(wa + T_PL + 1) -= Fa.y; TW(wa + T_PL + 2) -= Fa.z; }
+                const int wb_ = TBO(bb);
                 TW(wb_ + T_PA) += Ta.x; TW(wb_ + T_PA + 1) += Ta.y; TW(wb_ + T_PA + 2) += Ta.z; TW(wb_ + T_PL) += Fa.x; TW(wb_ + T_PL + 1) += Fa.y; TW(wb_ + T_PL + 2) += Fa.z;
                 TW(o.lf + la * 3) += Fa.x; TW(o.lf + la * 3 + 1) += Fa.y; TW(o.lf + la * 3 + 2) += Fa.z;
                 TW(o.lf + lb * 3) -= Fa.x; TW(o.lf + lb * 3 + 1) -= Fa.y; TW(o.lf + lb * 3 + 2) -= Fa.z;
@@ -340,8 +397,9 @@ GRX_DEV void tree_self_collision(KP P, const TreeTab& T, float* wsw, int ei, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// blockDim = 64 * waves (2 or 4: grx_capi.cpp); dynamic LDS = the table + one workspace per wave.  One wave per SIMD.
 template <bool HF>
-__global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __restrict__ Pg, const TreeTab* __restrict__ Tt, const GenTables* __restrict__ Tg,
+__global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_tree(const KParams* __restrict__ Pg, const TreeTab* __restrict__ Tt, const GenTables* __restrict__ Tg,
                                                              const float* __restrict__ actions_in, float delay, long long common_step,
                                                              const float* __restrict__ noise_in, float* __restrict__ obs_out, float* __restrict__ pri_out,
                                                              const StepSeq sq) {
@@ -357,12 +415,13 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
     }
     __syncthreads();
     const TreeTab& T = Tm;
+    const int nwaves = blockDim.x >> 6, tepb = TEPW * nwaves;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ei = lane / TG, c = lane & (TG - 1);
-    if (wave == TWAVES - 1) stats_fold_previous(P, sq, lane);   // the previous launch's episode statistics (and its ticket)
-    const TreeOff o = tree_offsets(T.nb, T.nlc);
+    if (wave == nwaves - 1) stats_fold_previous(P, sq, lane);   // the previous launch's episode statistics (and its ticket)
+    const TreeOff o = tree_offsets(T.nb, T.nlc, T.nchain);
     float* const wsw = s_dyn + sizeof(TreeTab) / 4 + (size_t)wave * o.total * TEPW;
     const size_t N = (size_t)P.N;
-    const int e_raw = blockIdx.x * TEPB + wave * TEPW + ei;
+    const int e_raw = blockIdx.x * tepb + wave * TEPW + ei;
     const bool act = e_raw < P.N;
     const int e = act ? e_raw : P.N - 1;
     const bool lead = c == 0, actl = act && lead;
@@ -396,27 +455,46 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
     bool contact_last[2] = {P.feet_contact[e] != 0, P.feet_contact[N + e] != 0};
     const float bho_stale = P.base_heights_offset[e];
     long long ep_len = P.ep_len[e];
-    for (int g = first; g <= last; ++g) {
-        const int j = T.sched[c][g] - 1;
-        const size_t oj = (size_t)j * N + e;
-        TW(o.dof + TD_Q * GRX_MAX_DOFS + j) = P.q[oj]; TW(o.dof + TD_QD * GRX_MAX_DOFS + j) = P.qd[oj];
-        TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j) = P.last_actions[oj];
-        TW(o.dof + TD_STR * GRX_MAX_DOFS + j) = P.motor_strength[oj];
-        const float a = actions_in ? actions_in[(size_t)e * nd + j] : 0.f;
-        TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j) = fminf(fmaxf(a, T.dof[j].amin), T.dof[j].amax);   // clip_actions (legged_robot_fftai.py:171-177)
+    TreeRegs G;
+#pragma unroll
+    for (int g = 0; g < TNG; ++g) {
+        const int b = g < T.nstep ? (int)T.sched[c][g] : -1;
+        G.sb[g] = b;
+        G.q[g] = 0.f; G.qd[g] = 0.f; G.Sa[g] = v3(0.f, 0.f, 0.f);
+        if (b >= 0) {
+            const int j = b - 1;
+            const size_t oj = (size_t)j * N + e;
+            G.q[g] = P.q[oj]; G.qd[g] = P.qd[oj];
+            const float a = actions_in ? actions_in[(size_t)e * nd + j] : 0.f;
+            TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j) = fminf(fmaxf(a, T.dof[j].amin), T.dof[j].amax);   // clip_actions (legged_robot_fftai.py:171-177)
+            TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j) = P.last_actions[oj];
+            TW(o.dof + TD_STR * GRX_MAX_DOFS + j) = P.motor_strength[oj];
+        }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) TW(o.an + c * 3 + k) = P.anchors[(size_t)(c * 3 + k) * N + e];   // 8 anchor slots x (x, y, approach speed): one slot per lane
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    tree_fence();
     // ---- during_physics_step (legged_robot_fftai.py:51-88)
     float avg_force[2] = {0.f, 0.f};
     V3 avg_speed[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
     V3 avg_rpy[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};   // avg_feet_speed_rpy (legged_robot_fftai.py:81, 88)
+#ifdef GRX_PROFILE_SECTIONS
+    long long tt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tt_prev = clock64();
+    const long long tt_begin = tt_prev;
+#define TT(i) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); tt_acc[i] += t_ - tt_prev; tt_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TT(i) do {} while (0)
+#endif
     for (int deci = 0; deci < P.decimation; ++deci) {
+        TT(7);
+        asm volatile("" ::: "memory");   // (keeps the loop-invariant table reads of the unrolled passes in LDS: hoisted, they would spill)
         for (int i = c; i < T.nlc * 3; i += TG) TW(o.lf + i) = 0.f;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        tree_fence();
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
-        tree_outward<HF, false>(P, T, wsw, ei, c, o, E, R0, (float)deci < delay, P.motor_strength + e);
+        tree_outward<false>(P, T, wsw, ei, c, o, E, R0, (float)deci < delay, first, last, G);
+        TT(0);
+        tree_contacts<HF>(P, T, wsw, ei, c, o, E);
+        TT(1);
         // base: rigid lump (randomised per env) + its own shapes (the group's first lane; the wrench goes round by shuffle)
         S3 Ab; V3 h0;
         rigid_inertia(R0, rot(R0, E.base_c), E.base_m, E.base_I, Ab, h0);
@@ -435,9 +513,12 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
                 }
             pa0 = pa0 - grp_bcast(fa, lane, 0); pl0 = pl0 - grp_bcast(fl, lane, 0);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        tree_fence();
+        TT(2);
         if (P.self_collisions) tree_self_collision(P, T, wsw, ei, c, o, E, R0, pa0, pl0);
-        tree_inward(P, T, wsw, ei, c, o);
+        TT(3);
+        tree_inward(P, T, wsw, ei, c, o, first, last, G);
+        TT(4);
         // ---- base: the chains that hang from it, in table order; [A B; B^T D][alpha; acc] = -[pa; pl]
         S3 Db = {E.base_m, 0.f, 0.f, E.base_m, 0.f, E.base_m};
         M3 Bb = {0.f, -h0.z, h0.y, h0.z, 0.f, -h0.x, -h0.y, h0.x, 0.f};
@@ -448,7 +529,9 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
         const S3 Sc = {Ab.xx - dot(b0, d0), Ab.xy - dot(b0, d1), Ab.xz - dot(b0, d2), Ab.yy - dot(b1, d1), Ab.yz - dot(b1, d2), Ab.zz - dot(b2, d2)};
         const V3 alpha = mul(inv(Sc), mul(Bb, mul(Di, pl0)) - pa0);
         const V3 acc = neg(mul(Di, pl0 + mulT(Bb, alpha)));
-        tree_accel(P, T, wsw, ei, c, o, alpha, acc);
+        TT(5);
+        tree_accel(P, T, wsw, ei, c, alpha, acc, first, last, G);
+        TT(6);
         {   // integrate the base (semi-implicit Euler), every lane of the group alike
             const float dt = P.sim_dt;
             GenBase& B = E.B;
@@ -468,26 +551,30 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
             if (deci > 0) {
                 const V3 fv = tw_v3(wsw, ei, o.misc + f * 3);
                 avg_speed[f] = v3(avg_speed[f].x + fabsf(fv.x), avg_speed[f].y + fabsf(fv.y), avg_speed[f].z + fabsf(fv.z));
-                const V3 fw = tw_v3(wsw, ei, T.foot_body[f] * T_NB + T_W);   // (the walk's: BEFORE this sub-step's integration, like fv)
+                const V3 fw = tw_v3(wsw, ei, TBO(T.foot_body[f]) + T_W);   // (the walk's: BEFORE this sub-step's integration, like fv)
                 avg_rpy[f] = v3(avg_rpy[f].x + fabsf(fw.x), avg_rpy[f].y + fabsf(fw.y), avg_rpy[f].z + fabsf(fw.z));
             }
             const V3 F = tw_v3(wsw, ei, o.lf + T.foot_link[f] * 3);
             avg_force[f] += grx_sqrt(dot(F, F));
         }
     }
+#ifdef GRX_PROFILE_SECTIONS
+    const long long tt_phys = clock64() - tt_begin;
+    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 8] = tt_phys;
+#endif
     // ---- refresh_rigid_body_state_tensor after the last sub-step: frames of the final state
     {
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
-        tree_outward<HF, true>(P, T, wsw, ei, c, o, E, R0, false, nullptr);
+        tree_outward<true>(P, T, wsw, ei, c, o, E, R0, false, first, last, G);
     }
     if (P.publish_rbs) {   // GRX_T_RIGID_BODY_STATES (legged_robot.py:113,134): every URDF link frame of that state, the links go round the lanes
         const LinkTab& LT = *P.link_tab;
         const R3 Rb0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
         for (int l = c; l < LT.n; l += TG) {
             const int b = LT.body[l];
-            const R3 Rb = b == 0 ? Rb0 : tw_R(wsw, ei, b * T_NB + T_R);
-            const V3 rho_b = b == 0 ? v3(0.f, 0.f, 0.f) : tw_v3(wsw, ei, b * T_NB + T_RHO);
-            const V3 w_b = b == 0 ? E.B.ang : tw_v3(wsw, ei, b * T_NB + T_W), v_b = b == 0 ? E.B.vel : tw_v3(wsw, ei, b * T_NB + T_V);
+            const R3 Rb = b == 0 ? Rb0 : tw_R(wsw, ei, TBO(b) + T_R);
+            const V3 rho_b = b == 0 ? v3(0.f, 0.f, 0.f) : tw_v3(wsw, ei, TBO(b) + T_RHO);
+            const V3 w_b = b == 0 ? E.B.ang : tw_v3(wsw, ei, TBO(b) + T_W), v_b = b == 0 ? E.B.vel : tw_v3(wsw, ei, TBO(b) + T_V);
             const V3 r_ = rho_b + rot(Rb, v3(LT.pos[l][0], LT.pos[l][1], LT.pos[l][2]));
             const V3 vl = v_b + cross(w_b, r_);
             // R_link = R_body * (link -> body), row-major entries m[i][k]
@@ -517,15 +604,15 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         const int b = T.foot_body[f];
-        const R3 R = tw_R(wsw, ei, b * T_NB + T_R);
-        const V3 fr = tw_v3(wsw, ei, b * T_NB + T_RHO) + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
+        const R3 R = tw_R(wsw, ei, TBO(b) + T_R);
+        const V3 fr = tw_v3(wsw, ei, TBO(b) + T_RHO) + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
         fpos[f] = E.B.pos + fr;
-        fvel[f] = tw_v3(wsw, ei, b * T_NB + T_V) + cross(tw_v3(wsw, ei, b * T_NB + T_W), fr);
+        fvel[f] = tw_v3(wsw, ei, TBO(b) + T_V) + cross(tw_v3(wsw, ei, TBO(b) + T_W), fr);
         avg_speed[f] = v3((avg_speed[f].x + fabsf(fvel[f].x)) / (float)P.decimation, (avg_speed[f].y + fabsf(fvel[f].y)) / (float)P.decimation,
                           (avg_speed[f].z + fabsf(fvel[f].z)) / (float)P.decimation);
         avg_force[f] /= (float)P.decimation;
         {
-            const V3 fw = tw_v3(wsw, ei, b * T_NB + T_W);
+            const V3 fw = tw_v3(wsw, ei, TBO(b) + T_W);
             avg_rpy[f] = v3((avg_rpy[f].x + fabsf(fw.x)) / (float)P.decimation, (avg_rpy[f].y + fabsf(fw.y)) / (float)P.decimation, (avg_rpy[f].z + fabsf(fw.z)) / (float)P.decimation);
         }
         foot_force[f] = tw_v3(wsw, ei, o.lf + T.foot_link[f] * 3);
@@ -545,12 +632,12 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
     }
     float torso_g[2] = {0.f, 0.f}, fore_g[2] = {0.f, 0.f};
     if (T.torso_body >= 0) {
-        const R3 R = T.torso_body == 0 ? quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw) : tw_R(wsw, ei, T.torso_body * T_NB + T_R);
+        const R3 R = T.torso_body == 0 ? quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw) : tw_R(wsw, ei, TBO(T.torso_body) + T_R);
         torso_g[0] = -(R.cx.z * T.torso_rot[0] + R.cy.z * T.torso_rot[3] + R.cz.z * T.torso_rot[6]);
         torso_g[1] = -(R.cx.z * T.torso_rot[1] + R.cy.z * T.torso_rot[4] + R.cz.z * T.torso_rot[7]);
     }
     if (T.forehead_body >= 0) {
-        const R3 R = T.forehead_body == 0 ? quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw) : tw_R(wsw, ei, T.forehead_body * T_NB + T_R);
+        const R3 R = T.forehead_body == 0 ? quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw) : tw_R(wsw, ei, TBO(T.forehead_body) + T_R);
         fore_g[0] = -(R.cx.z * T.forehead_rot[0] + R.cy.z * T.forehead_rot[3] + R.cz.z * T.forehead_rot[6]);
         fore_g[1] = -(R.cx.z * T.forehead_rot[1] + R.cy.z * T.forehead_rot[4] + R.cz.z * T.forehead_rot[7]);
     }
@@ -603,11 +690,12 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
         const GRX_AS4 float* sg = P.reward_sigma;
         float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
         float tor_hr = 0.f, vel_kn = 0.f, ank[2] = {0.f, 0.f};
-        for (int g = first; g <= last; ++g) {
-            const int j = T.sched[c][g] - 1;
+#pragma unroll
+        for (int g = 0; g < TNG; ++g) {
+            if (G.sb[g] < 0) continue;
+            const int j = G.sb[g] - 1;
             const TreeDof& td = T.dof[j];
-            const float ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j), al = TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j), qj = TW(o.dof + TD_Q * GRX_MAX_DOFS + j),
-                        qdj = TW(o.dof + TD_QD * GRX_MAX_DOFS + j), tj = TW(o.dof + TD_TAU * GRX_MAX_DOFS + j);
+            const float ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j), al = TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j), qj = G.q[g], qdj = G.qd[g], tj = TW(TBO(j + 1) + T_TAU);
             const uint32_t bit = 1u << j;
             s1 += fabsf((al - ac) * as);
             if (P.knee_mask & bit) { s3 += fabsf((ac - al) * as); vel_kn += fabsf(qdj); }
@@ -742,11 +830,13 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
             const float* og = P.terrain_origins + ((size_t)ea.level * P.num_terrain_cols + ea.type) * 3;
             ea.origin[0] = og[0]; ea.origin[1] = og[1]; ea.origin[2] = og[2];
         }
-        for (int g = first; g <= last; ++g) {
-            const int j = T.sched[c][g] - 1;
+#pragma unroll
+        for (int g = 0; g < TNG; ++g) {
+            if (G.sb[g] < 0) continue;
+            const int j = G.sb[g] - 1;
             const float f_ = P.randomize_init_dof_pos ? urand(P, genv, step, GRX_RNG_RESET_DOF, (uint32_t)j, 0.5f, 1.5f) : 1.0f;
-            TW(o.dof + TD_Q * GRX_MAX_DOFS + j) = f_ * T.dof[j].q0;
-            TW(o.dof + TD_QD * GRX_MAX_DOFS + j) = 0.f;
+            G.q[g] = f_ * T.dof[j].q0;
+            G.qd[g] = 0.f;
         }
         B.pos = v3(P.init_pos[0] + ea.origin[0], P.init_pos[1] + ea.origin[1], P.init_pos[2] + ea.origin[2]);
         if (P.terrain_type != GRX_TERRAIN_PLANE) {
@@ -810,14 +900,16 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
         };
         const float np_ = P.noise_dof_pos * P.noise_level * P.obs_scale_dof_pos, nv = P.noise_dof_vel * P.noise_level * P.obs_scale_dof_vel;
         const float nac = P.noise_action * P.noise_level * P.obs_scale_action;
-        for (int g = first; g <= last; ++g) {   // this lane's joints: observations, history, state
-            const int j = T.sched[c][g] - 1;
+#pragma unroll
+        for (int g = 0; g < TNG; ++g) {   // this lane's joints: observations, history, state
+            if (G.sb[g] < 0) continue;
+            const int j = G.sb[g] - 1;
             const size_t oj = (size_t)j * N + e;
-            const float qj = TW(o.dof + TD_Q * GRX_MAX_DOFS + j), qdj = TW(o.dof + TD_QD * GRX_MAX_DOFS + j), ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j);
+            const float qj = G.q[g], qdj = G.qd[g], ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j);
             put(9 + j, (qj - T.dof[j].q0) * P.obs_scale_dof_pos, np_);
             put(9 + nd + j, qdj * P.obs_scale_dof_vel, nv);
             put(9 + 2 * nd + j, ac * P.obs_scale_action, nac);
-            P.q[oj] = qj; P.qd[oj] = qdj; P.actions[oj] = ac; P.torques[oj] = TW(o.dof + TD_TAU * GRX_MAX_DOFS + j);
+            P.q[oj] = qj; P.qd[oj] = qdj; P.actions[oj] = ac; P.torques[oj] = TW(TBO(j + 1) + T_TAU);
             P.last_actions[oj] = ac; P.last_dof_vel[oj] = qdj;   // history (legged_robot.py:299-300, after reset_idx)
         }
 #pragma unroll
@@ -871,8 +963,16 @@ __global__ __launch_bounds__(64 * TWAVES) void grx_step_tree(const KParams* __re
             P.term_contact[e] = term_contact ? 1 : 0;
         }
     }
+#ifdef GRX_PROFILE_SECTIONS
+    if (threadIdx.x == 0 && blockIdx.x < 64) {   // sections summed over the sub-steps: outward, contacts, base, self-collision, inward, base solve, accel, rest; [8] physics, [9] whole kernel
+        long long* pr = P.prof + (size_t)blockIdx.x * GRX_PROF_SLOTS;
+        for (int i = 0; i < 8; ++i) pr[i] = tt_acc[i];
+        pr[9] = clock64() - tt_begin;
+    }
+#endif
     __syncthreads();
     if (threadIdx.x < NSTAT) stat_row(P, sq.seq, threadIdx.x)[blockIdx.x] = s_stat[threadIdx.x];
     if (blockIdx.x == 0 && threadIdx.x == 0) P.stat_nblocks[sq.seq & 1] = (int)gridDim.x;
 }
 #undef TW
+#undef TBO
