@@ -288,10 +288,18 @@ int build_side_tables(const grx_config& c, KTables& P, uint32_t* ll_mask, uint64
                 const SphC& q = S.sph[off[2] + n];
                 if (q.x == m.sph_pos[ib][0] && q.y == m.sph_pos[ib][1] && q.z == m.sph_pos[ib][2]) tsel = n;
             }
-            if (tsel < 0 || S.nbc >= GRX_MAX_BC) return fail(GRX_ERR_UNSUPPORTED_MODEL, "base-lump / thigh self-collision table overflow");
-            BaseChainPair& e = S.bc[S.nbc++];
-            e.x = m.sph_pos[ia][0]; e.y = m.sph_pos[ia][1]; e.z = m.sph_pos[ia][2]; e.r = m.sph_radius[ia];
-            e.dmax = m.sph_damp_max[ia]; e.tsel = tsel; e.link = m.sph_link[ia]; e.pad = 0;
+            if (tsel < 0 || tsel > 1) return fail(GRX_ERR_UNSUPPORTED_MODEL, "base-lump / thigh self-collision: unknown thigh shape");
+            int at = -1;   // one entry per base-lump sphere (entries of one link stay adjacent: the pairs arrive sorted by sphere)
+            for (int n = 0; n < S.nbc; ++n)
+                if (S.bc[n].x == m.sph_pos[ia][0] && S.bc[n].y == m.sph_pos[ia][1] && S.bc[n].z == m.sph_pos[ia][2] && S.bc[n].link == m.sph_link[ia]) at = n;
+            if (at < 0) {
+                if (S.nbc >= GRX_MAX_BC) return fail(GRX_ERR_UNSUPPORTED_MODEL, "base-lump / thigh self-collision table overflow");
+                at = S.nbc++;
+                BaseChainPair& e = S.bc[at];
+                e.x = m.sph_pos[ia][0]; e.y = m.sph_pos[ia][1]; e.z = m.sph_pos[ia][2]; e.r = m.sph_radius[ia];
+                e.dmax = m.sph_damp_max[ia]; e.tmask = 0; e.link = m.sph_link[ia]; e.pad = 0;
+            }
+            S.bc[at].tmask |= 1 << tsel;
         } else {
             if (side_of(ba) == side_of(bb)) return fail(GRX_ERR_UNSUPPORTED_MODEL, "self-collision within one leg chain");
             const int kl = side_of(ba) == 0 ? k_of(ba) : k_of(bb), kr = side_of(ba) == 0 ? k_of(bb) : k_of(ba);

@@ -48,15 +48,16 @@ struct alignas(16) BodyC {
     float slo, shi, pad0, pad1;    // soft dof position limits (legged_robot.py:606-610)
 };
 
-// self-collision between a base-lump shape and one of this lane's two thigh shapes (grx_self.h)
+// self-collision between a base-lump shape and this lane's two thigh shapes (grx_self.h): one entry per BASE-LUMP sphere (round 4;
+// round 3 kept one per sphere pair, 64 registers on the wave that evaluates them -- the spill of the eight-wave kernels)
 struct alignas(16) BaseChainPair {
     float x, y, z, r;    // the base-lump sphere, base frame
     float dmax;          // its damping cap
-    int32_t tsel;        // which thigh shape of this lane (0 / 1)
+    int32_t tmask;       // bit t: it can touch thigh shape t of this lane (0 / 1)
     int32_t link;        // URDF link of the base-lump sphere (row of GRX_T_CONTACT_FORCES)
     int32_t pad;
 };
-#define GRX_MAX_BC 8
+#define GRX_MAX_BC 4
 
 // Per-side (left leg / right leg lane) robot constants; staged into LDS by every block.
 struct alignas(16) SideConst {

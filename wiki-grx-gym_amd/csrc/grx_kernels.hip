@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     for (int k = 0; k < LEG; ++k) {
         size_t o = (size_t)(j0 + k) * N + e;
         st.q[k] = P.q[o]; st.qd[k] = P.qd[o];
-        a_last[k] = P.last_actions[o]; qd_last[k] = P.last_dof_vel[o];
+        a_last[k] = P.last_actions[o];
         LC.strength[k] = P.motor_strength[o];
         float a = actions_in ? actions_in[(size_t)e * GRX_ND + j0 + k] : 0.0f;
         a_cur[k] = fminf(fmaxf(a, C.body[k].amin), C.body[k].amax);  // clip_actions legged_robot_fftai.py:171-177
@@ -1465,14 +1465,30 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         int cj = min(max((int)((st.pos.y + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
         LC.hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
     }
+    // What only post_physics_step reads.  One-wave layouts: loaded here, so that the HBM latency overlaps the sub-steps.  The pipelines:
+    // loaded BEHIND the sub-steps, in front of the barrier that ends them -- this wave waits there ~1 k cycles for the last helper
+    // anyway, and ~20 values fewer live across its sub-step loop is what keeps the eight-wave kernels (256 registers per wave)
+    // free of scratch (round 3: 5-9 dwords spilled around the loop).
     EnvAux ea;
-    ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[(size_t)N + e]; ea.cmd[2] = P.commands[2 * (size_t)N + e];
-    ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[(size_t)N + e]; ea.origin[2] = P.origins[2 * (size_t)N + e];
-    ea.level = P.levels[e]; ea.type = P.types[e];
-    float air_time = P.air_time[(size_t)side * N + e], land_time = P.land_time[(size_t)side * N + e];
-    bool contact_last = P.feet_contact[(size_t)side * N + e] != 0;
-    float bho_stale = P.base_heights_offset[e];
-    long long ep_len = P.ep_len[e];
+    float air_time, land_time, bho_stale;
+    bool contact_last;
+    long long ep_len;
+    auto load_post_state = [&]() {
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) qd_last[k] = P.last_dof_vel[(size_t)(j0 + k) * N + e];
+        ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[(size_t)N + e]; ea.cmd[2] = P.commands[2 * (size_t)N + e];
+        ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[(size_t)N + e]; ea.origin[2] = P.origins[2 * (size_t)N + e];
+        ea.level = P.levels[e]; ea.type = P.types[e];
+        air_time = P.air_time[(size_t)side * N + e]; land_time = P.land_time[(size_t)side * N + e];
+        contact_last = P.feet_contact[(size_t)side * N + e] != 0;
+        bho_stale = P.base_heights_offset[e];
+        ep_len = P.ep_len[e];
+    };
+#ifndef GRX_LATE_POST
+#define GRX_LATE_POST 2   // 1: every pipeline, 2: the lane-quad pipelines only (measured: with lane pairs, whose wave 0 does not idle at that barrier, the late loads cost 1-2 %)
+#endif
+    constexpr bool kLatePost = PIPE && (GRX_LATE_POST == 1 || (GRX_LATE_POST == 2 && LPL == 2));
+    if (!kLatePost) load_post_state();
 
     GRX_TICK(1);
     // ---- during_physics_step (legged_robot_fftai.py:51-88), fused decimation loop
@@ -1529,6 +1545,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         }
         avg_force += grx_sqrt(dot(so.foot_force, so.foot_force));
     }
+    if (kLatePost) load_post_state();
     const float yaw_n = fmaxf(sqrtf(st.qz * st.qz + st.qw * st.qw), 1e-9f);   // normalize(): torch_utils.py:43-45
     const float yaw_z = st.qz / yaw_n, yaw_w = st.qw / yaw_n;
     if (!PIPE && !DBG && P.publish_rbs) {

@@ -286,18 +286,22 @@ GRX_DEV void self_collision(KP P, const KTables& T, const SideConst& C, const Se
             if (mine && q.link != prev_link) { prev_link = q.link; ++slot; }
             if (!__any((sn.m >> (16 + e)) & 1u)) continue;
             SphC sb; sb.x = q.x; sb.y = q.y; sb.z = q.z; sb.r = q.r; sb.dmax = q.dmax;
-            const V3 d = (q.tsel ? c1 : c0) - rot(R0, v3(q.x, q.y, q.z));
-            const float Rs = q.r + (q.tsel ? C.sph[9].r : C.sph[8].r);
-            const bool hit = mine && ((sn.m >> (16 + e)) & 1u) && dot(d, d) < Rs * Rs;
-            if (!__any(hit)) continue;
-            if (hit) {
-                const SphW b = sph_world(sb, KB);
-                const SphW t = sph_world(q.tsel ? C.sph[9] : C.sph[8], K[0]);
-                V3 F, pw;
-                if (sphere_pair(P, t, b, mu, F, pw)) {
-                    o.fa[0] = o.fa[0] + cross(pw, F); o.fl[0] = o.fl[0] + F;
-                    o.f0a = o.f0a - cross(pw, F); o.f0l = o.f0l - F;
-                    if (slot == 0) o.fbase[0] = o.fbase[0] - F; else o.fbase[1] = o.fbase[1] - F;
+            const V3 cb = rot(R0, v3(q.x, q.y, q.z));
+#pragma unroll
+            for (int ts = 0; ts < 2; ++ts) {   // the base-lump sphere against the lane's two thigh shapes, in table order
+                const V3 d = (ts ? c1 : c0) - cb;
+                const float Rs = q.r + (ts ? C.sph[9].r : C.sph[8].r);
+                const bool hit = mine && ((sn.m >> (16 + e)) & 1u) && ((q.tmask >> ts) & 1) && dot(d, d) < Rs * Rs;
+                if (!__any(hit)) continue;
+                if (hit) {
+                    const SphW b = sph_world(sb, KB);
+                    const SphW t = sph_world(ts ? C.sph[9] : C.sph[8], K[0]);
+                    V3 F, pw;
+                    if (sphere_pair(P, t, b, mu, F, pw)) {
+                        o.fa[0] = o.fa[0] + cross(pw, F); o.fl[0] = o.fl[0] + F;
+                        o.f0a = o.f0a - cross(pw, F); o.f0l = o.f0l - F;
+                        if (slot == 0) o.fbase[0] = o.fbase[0] - F; else o.fbase[1] = o.fbase[1] - F;
+                    }
                 }
             }
         }

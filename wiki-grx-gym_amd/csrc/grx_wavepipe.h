@@ -604,7 +604,11 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     GRX_EV(7);
     // ---- contact wrenches on chain bodies 4, 3, 2: delta recursion on the own rows
     if (W8 && GRX_W8_WAITALL) {   // everything the rest of the sub-step consumes, in one poll
-        GRX_WAIT_ALL(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_LEGS, seq + 1, FL_SELF, seq + 1, FL_BASEBIAS, seq + 1, FL_FACTOUT, seq + 1, FL_CHAINW, seq + 1, FL_SB, seq + 1), lane, 2);
+#ifndef GRX_W8_LATEFACT
+#define GRX_W8_LATEFACT 1   // the factorisation (the last hand-over to arrive: 4.9 k cycles into the sub-step against 4.1 k for the contact wrenches) is waited for where it is used, behind the delta recursion
+#endif
+        if (GRX_W8_LATEFACT) GRX_WAIT_ALL(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_LEGS, seq + 1, FL_SELF, seq + 1, FL_BASEBIAS, seq + 1, FL_CHAINW, seq + 1, FL_SB, seq + 1), lane, 2);
+        else GRX_WAIT_ALL(L.flag, flag_want(lane, FL_FOOT, seq + 1, FL_LEGS, seq + 1, FL_SELF, seq + 1, FL_BASEBIAS, seq + 1, FL_FACTOUT, seq + 1, FL_CHAINW, seq + 1, FL_SB, seq + 1), lane, 2);
         GRX_EV(5);
     } else {
         if (W8) { GRX_WAIT(L.flag + FL_BASEBIAS, seq + 1, 0); GRX_WAIT(L.flag + FL_FACTOUT, seq + 1, 1); GRX_WAIT(L.flag + FL_CHAINW, seq + 1, 2); }
@@ -664,6 +668,9 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     // lo: alpha = Sa^-1 (B D^-1 p_l - p_a);  hi: acc = Sd^-1 (B^T A^-1 p_a - p_l)
     V3 xo;
     if (W8) {   // x = Sc^-1 (T p_other - p_own) with T = Y Xo^-1 and Sc^-1 from wave 5
+        if (GRX_W8_WAITALL && GRX_W8_LATEFACT) {
+            GRX_WAIT(L.flag + FL_FACTOUT, seq + 1, 1);
+        }
         const float4* c = L.fx + 4 * 64 + lane;
         const float4 m0 = c[0 * 64], m1 = c[1 * 64], m2 = c[2 * 64], m3 = c[3 * 64];
         const V3 pt = half_swap(po);
