@@ -448,6 +448,12 @@ typedef struct grx_pipeline_state {
  * resets are reported in GRX_T_RESET but not applied.  Lower-limb (fused-kernel) models only. */
 int grx_debug_post_physics(grx_handle h, const grx_pipeline_state* states, int apply_reset, const grx_step_args* args, void* stream);
 
+/* TEST-ONLY: the wave pipelines of the step kernels hand over through LDS flags and spin on them.  A library built
+ * with -DGRX_SPIN_LIMIT (csrc/variants/libgrx_spinlimit.so) bounds every spin; an expired one stores 'SP' << 48 | block << 32 | LDS
+ * address of the flag << 16 | value waited for in a host-pinned word and traps.  *code = that word (0: none expired; readable after
+ * the trap), *bounded = whether this library is such a build. */
+int grx_debug_spin_report(grx_handle h, uint64_t* code, int* bounded);
+
 const char* grx_last_error(void);
 int grx_abi_version(void);
 const char* grx_reward_term_name(int term);

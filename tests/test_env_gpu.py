@@ -123,6 +123,49 @@ def test_episode_statistics_survive_graph_replays(steps_in_graph):
         assert torch.equal(hip.tensor(name), ref.tensor(name)), name
 
 
+def test_pipelines_on_the_bounded_spin_build():
+    """the wave pipelines hand over through LDS flags and spin on them; a lost hand-over would hang the GPU.  The
+    -DGRX_SPIN_LIMIT build of the same sources (csrc/variants/libgrx_spinlimit.so, csrc/grx_flags.h) bounds every spin and, on
+    expiry, reports the flag and traps.  Every pipelined layout runs 2000 policy steps on it (rough terrain, falls and resets
+    included) in a process of its own: no spin expires.  (The protocol itself -- payload then flag without a wait in between -- is
+    checked by tools/micro/lds_handover.hip: profiles/r04_lds_handover_litmus.json, 1.2e9 hand-overs, no mismatch.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "wiki-grx-gym_amd", "csrc", "variants", "libgrx_spinlimit.so")
+    assert os.path.exists(lib), "build it: make -C wiki-grx-gym_amd/csrc variants/libgrx_spinlimit.so (build() does)"
+    prog = r"""
+import json, os, sys, torch
+sys.path.insert(0, %r)
+from tests.helpers import make_cfg, make_sims, random_actions
+out = {}
+for name, env in (("pair4", {"GRX_LANES_PER_ENV": "2", "GRX_WAVES_PER_BLOCK": "4"}), ("pair8", {"GRX_LANES_PER_ENV": "2", "GRX_WAVES_PER_BLOCK": "8"}),
+                  ("quad4", {"GRX_LANES_PER_ENV": "4", "GRX_QUAD_WAVES": "4"}), ("quad8", {"GRX_LANES_PER_ENV": "4", "GRX_QUAD_WAVES": "8"})):
+    for k in ("GRX_LANES_PER_ENV", "GRX_WAVES_PER_BLOCK", "GRX_QUAD_WAVES"): os.environ.pop(k, None)
+    os.environ.update(env)
+    cfg = make_cfg(terrain="heightfield", noise=True, dr=True, push=True)
+    hip, _ = make_sims(cfg, 512, seed=1)
+    hip.reset_all()
+    gen = torch.Generator().manual_seed(0)
+    acts = [random_actions(cfg, 512, gen, 1.0).cuda() for _ in range(8)]
+    for i in range(2000): hip.step(acts[i %% 8], 5.0, i + 1)
+    hip.wait_idle(); torch.cuda.synchronize()
+    code, bounded = hip.spin_report()
+    out[name] = {"code": code, "bounded": bounded, "layout": hip.layout()["kernel"], "obs": float(hip.tensor("OBS").double().sum()), "resets": int(hip.tensor("EPISODE_LENGTH").lt(100).sum()),
+                 "finite": bool(torch.isfinite(hip.tensor("OBS")).all())}
+    hip.close()
+print("RESULT " + json.dumps(out))
+""" % root
+    env = dict(os.environ)
+    env["GRX_HIP_LIB"] = lib
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    want = {"pair4": "grx_step_kernel<true, 4, false>", "pair8": "grx_step_kernel<true, 8, false>",
+            "quad4": "grx_step_kernel_quad<true, 4, false>", "quad8": "grx_step_kernel_quad<true, 8, false>"}
+    for name, b in res.items():
+        assert b["bounded"] and b["code"] == 0 and b["finite"] and b["resets"] > 0 and b["layout"] == want[name], (name, b)
+
+
 def test_bench_line_has_the_contract_fields():
     """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command): one JSON line with BASELINE.json's metric, the
     roofline object (HBM fraction + the VALU issue fraction that actually bounds the kernel) and the cpu_baseline object."""

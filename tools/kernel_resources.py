@@ -58,7 +58,11 @@ def kernels_of(co_bytes):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    argv = list(sys.argv[1:])
+    out_json = None
+    if "--json" in argv:
+        i = argv.index("--json"); out_json = argv[i + 1]; del argv[i:i + 2]
+    args = [a for a in argv if not a.startswith("--")]
     lib = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wiki-grx-gym_amd", "csrc", "libgrx_hip.so")
     rows = []
     for co in code_objects(open(lib, "rb").read()):
@@ -67,8 +71,8 @@ def main():
     print(f"{'kernel':58s} vgpr agpr spill scratch    lds")
     for r in rows:
         print(f"{r['kernel'][:58]:58s} {r['vgpr']:4d} {r['agpr']:4d} {r['vgpr_spill']:5d} {r['scratch_bytes']:7d} {r['lds_bytes']:6d}")
-    if "--json" in sys.argv:
-        with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
+    if out_json:
+        with open(out_json, "w") as f:
             json.dump({"library": os.path.basename(lib), "kernels": rows}, f, indent=1)
 
 

@@ -205,6 +205,8 @@ def bind(lib, prefix="grx_"):
         api["wait_idle"] = fn("wait_idle", C.c_int, H)
     if hasattr(lib, prefix + "stats_seq"):
         api["stats_seq"] = fn("stats_seq", C.c_int, H, C.POINTER(i64))
+    if hasattr(lib, prefix + "debug_spin_report"):
+        api["debug_spin_report"] = fn("debug_spin_report", C.c_int, H, C.POINTER(C.c_uint64), C.POINTER(C.c_int))
     if hasattr(lib, prefix + "layout"):
         api["layout"] = fn("layout", C.c_int, H, C.POINTER(LayoutInfo))
     if hasattr(lib, prefix + "kernel_time_ms"):
@@ -215,5 +217,5 @@ def bind(lib, prefix="grx_"):
 EXPORTED_SYMBOLS = (
     "grx_create", "grx_destroy", "grx_reset_all", "grx_step", "grx_tensor", "grx_set_state",
     "grx_episode_stats", "grx_flush_stats", "grx_reset_idx", "grx_set_state_indexed", "grx_kernel_time_ms", "grx_wait_idle", "grx_last_error", "grx_abi_version",
-    "grx_reward_term_name", "grx_debug_post_physics", "grx_layout", "grx_stats_seq",
+    "grx_reward_term_name", "grx_debug_post_physics", "grx_layout", "grx_stats_seq", "grx_debug_spin_report",
 )

@@ -43,6 +43,8 @@ void grx_launch_step_debug(const KParams* dP, int N, int heightfield, int waves,
 void grx_launch_step_debug_quad(const KParams* dP, int N, int heightfield, int waves, const float* actions, long long common_step, const float* noise,
                                 const float* dbg, const StepSeq* sq, hipStream_t stream);
 int grx_debug_rows(void);
+int grx_set_spin_word(unsigned long long* p);
+int grx_set_spin_word_quad(unsigned long long* p);
 }
 
 namespace {
@@ -117,6 +119,7 @@ struct grx_sim {
     // tensor table
     grx_tensor_desc desc[GRX_NUM_TENSORS];
     long long* prof_host = nullptr; int prof_blocks = 0;
+    bool spin_bounded = false;    // a -DGRX_SPIN_LIMIT build: LDS spins are bounded and report through pace.progress[1]
     float* d_dbg = nullptr;       // grx_debug_post_physics: injected quantities [grx_debug_rows()][N]
     float* d_dbg_actions = nullptr;   // ... and the injected (already clipped) actions, (N, nd) row-major
 };
@@ -996,12 +999,15 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     }
     {
         void* hp_ = nullptr;
-        HIP_TRY(hipHostMalloc(&hp_, sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostMalloc(&hp_, 2 * sizeof(int64_t), hipHostMallocMapped | hipHostMallocCoherent));   // [0] progress, [1] spin report
         s->pace.progress = static_cast<volatile int64_t*>(hp_);
-        *s->pace.progress = 0;
+        s->pace.progress[0] = 0; s->pace.progress[1] = 0;
         void* dp_ = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&dp_, hp_, 0));
         s->pace.d_progress = static_cast<long long*>(dp_);
+        // -DGRX_SPIN_LIMIT builds: an expired LDS spin stores its code in word [1] before it traps (grx_flags.h)
+        s->spin_bounded = grx_set_spin_word(reinterpret_cast<unsigned long long*>(s->pace.d_progress + 1)) == 1;
+        grx_set_spin_word_quad(reinterpret_cast<unsigned long long*>(s->pace.d_progress + 1));
     }
     {   // the parameter block is immutable from here on: upload it once
         rc = dalloc(s, &s->d_hp, 1);
@@ -1203,6 +1209,16 @@ int grx_episode_stats(grx_handle s, float* host_out, void* stream) {
     if (int rc = grx_flush_stats(s, stream)) return rc;
     HIP_TRY(hipMemcpyAsync(host_out, s->hp.stats, NSTAT * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GRX_OK;
+}
+
+// tests / tools: 0 = no spin of the wave pipelines has expired; else 'SP' << 48 | block << 32 | LDS address of the flag << 16 | value
+// waited for (-DGRX_SPIN_LIMIT builds; *bounded = whether this library is one).  Readable after the kernel has trapped: the word
+// is host memory.
+int grx_debug_spin_report(grx_handle s, uint64_t* code, int* bounded) {
+    if (!s || !code) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_spin_report: null argument");
+    *code = (uint64_t)s->pace.progress[1];
+    if (bounded) *bounded = s->spin_bounded ? 1 : 0;
     return GRX_OK;
 }
 

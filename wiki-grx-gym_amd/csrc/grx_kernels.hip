@@ -1866,6 +1866,20 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     GRX_TICK(10);
 }
 
+// -DGRX_SPIN_LIMIT builds (grx_flags.h): where an expired spin reports before it traps -- one pointer per translation unit
+#ifdef GRX_QUAD_TU
+extern "C" int grx_set_spin_word_quad(unsigned long long* p) {
+#else
+extern "C" int grx_set_spin_word(unsigned long long* p) {
+#endif
+#ifdef GRX_SPIN_LIMIT
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_grx_spin_word), &p, sizeof p) == hipSuccess ? 1 : -1;
+#else
+    (void)p;
+    return 0;   // (product build: spins are unbounded)
+#endif
+}
+
 #ifdef GRX_QUAD_TU
 // grx_quad.hip: this translation unit built with GRX_LPE = 4 -- the four-wave step kernel with a lane QUAD per env, 16 envs per
 // block: at <= 16 envs per CU (4096 envs on an MI355X) every CU gets a block instead of every other one

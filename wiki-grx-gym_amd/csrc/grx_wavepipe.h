@@ -103,50 +103,7 @@ GRX_DEV void pipe_base_store(float4* bq, int el, V3 pos, float qx, float qy, flo
     bq[2 * EPB + el] = f4(vel.y, vel.z, ang.x, ang.y); bq[3 * EPB + el] = f4(ang.z, 0.f, 0.f, 0.f);
 }
 
-// Hand-over flags and their payload live in LDS: the release / acquire fences are LDS-only ("local" address space), so a
-// wave never waits for its global stores or terrain loads in flight when it raises or polls a flag.
-GRX_DEV void flag_set(int* f, int v, int lane) {
-    // The LDS unit executes a wave's LDS instructions in program order (lgkmcnt returns in order for LDS-only traffic), and the flag is
-    // an LDS store like its payload: the payload is in LDS before the flag whatever the fence says.  So the release only has to order
-    // the COMPILER's stores (wavefront scope: no s_waitcnt lgkmcnt(0) that would drain the wave's LDS queue, ~100 cycles per hand-over
-    // on the producer's chain: +0.9 % on the headline).  -DGRX_FLAG_FENCED restores the workgroup-scope fence.
-#ifdef GRX_FLAG_FENCED
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-#endif
-    if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-GRX_DEV void flag_wait(int* f, int want) {
-    // pure spin (the waiter owns its SIMD; an s_sleep between polls only added detection latency: +1.3 % measured)
-    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < want) {}
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-// several flags in ONE poll: lane i < FL_COUNT watches flag i until it reaches want_mine (INT_MIN: not waited for).  A poll is an
-// LDS round trip (~100 cycles even when the flag is already up): wave 0 meets ten hand-overs per sub-step
-GRX_DEV void flag_wait_all(int* f, int want_mine, int lane) {
-    const int* const p = f + (lane < FL_COUNT ? lane : 0);
-    while (!__all(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want_mine)) {}
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-GRX_DEV int flag_want(int lane, int f0, int w0, int f1 = -1, int w1 = 0, int f2 = -1, int w2 = 0, int f3 = -1, int w3 = 0, int f4 = -1, int w4 = 0, int f5 = -1, int w5 = 0,
-                      int f6 = -1, int w6 = 0) {
-    int w = INT_MIN;
-    if (lane == f0) w = w0;
-    if (lane == f1) w = w1;
-    if (lane == f2) w = w2;
-    if (lane == f3) w = w3;
-    if (lane == f4) w = w4;
-    if (lane == f5) w = w5;
-    if (lane == f6) w = w6;
-    return w;
-}
-// block barrier that orders LDS only (global stores stay in flight across it)
-GRX_DEV void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
+#include "grx_flags.h"   // flag_set / flag_wait / flag_wait_all / lds_barrier: shared with the litmus test tools/micro/lds_handover.hip
 
 // velocity-product (bias) force of a rigid body about O, from its centre-of-mass quantities (no 3x3 world inertia):
 //   l = m (v + w x kap),  L_O = R Ic R^T w + kap x l,  p = (w x L_O + v x l ; w x l)

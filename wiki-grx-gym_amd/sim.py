@@ -234,6 +234,13 @@ class SimHandle:
         self._check(self._api["stats_seq"](self._h, C.byref(v)), "stats_seq")
         return int(v.value)
 
+    def spin_report(self):
+        """(code, bounded): code != 0 when a bounded LDS spin of the wave pipelines expired (-DGRX_SPIN_LIMIT builds, csrc/grx_flags.h);
+        bounded: whether the loaded library is such a build."""
+        code, bounded = C.c_uint64(0), C.c_int(0)
+        self._check(self._api["debug_spin_report"](self._h, C.byref(code), C.byref(bounded)), "debug_spin_report")
+        return int(code.value), bool(bounded.value)
+
     def layout(self):
         """What step() launches (include/grx.h grx_layout): dict(lanes_per_env, waves_per_block, envs_per_block, num_blocks, kernel)."""
         if "layout" not in self._api:
