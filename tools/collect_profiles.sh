@@ -55,6 +55,22 @@ for n in 4096 16384; do
 done
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats_full_body -o b -- bash -c "cd $OLDPWD && python bench.py --robot full_body --envs-per-gpu 16384 --steps 300 --warmup 30 --no-cpu-baseline > /dev/null" > $OLDPWD/$out/stats_full_body.log 2>&1)
 find $out/stats_full_body -name "*kernel_trace.csv" -delete
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats_full_body4096 -o b -- bash -c "cd $OLDPWD && python bench.py --robot full_body --envs-per-gpu 4096 --steps 600 --warmup 60 --no-cpu-baseline > /dev/null" > $OLDPWD/$out/stats_full_body4096.log 2>&1)
+find $out/stats_full_body4096 -name "*kernel_trace.csv" -delete
+# config 5 at its per-GPU size: HBM and SQ counter passes of the tree kernel (separate --pmc runs, kernel-trace only)
+FB="python bench.py --robot full_body --envs-per-gpu 4096 --steps 200 --warmup 20 --no-cpu-baseline"
+for c in FETCH_SIZE WRITE_SIZE; do
+    d=$out/fb_pmc_$(echo $c | tr 'A-Z' 'a-z' | cut -d_ -f1)
+    (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OLDPWD/$d -o b -- bash -c "cd $OLDPWD && $FB" > $OLDPWD/$d.log 2>&1)
+done
+i=0
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_IFETCH"; do
+    i=$((i + 1)); d=$out/fb_pmc_sq$i
+    (cd /tmp && rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/$d -o b -- bash -c "cd $OLDPWD && $FB" > $OLDPWD/$d.log 2>&1)
+done
+# config 3's size (8192 envs, lane pairs, eight waves): kernel stats
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$out/stats_8192 -o b -- bash -c "cd $OLDPWD && python bench.py --envs-per-gpu 8192 --steps 4000 --warmup 400 --no-cpu-baseline > $out/bench_rough8192.json" > $OLDPWD/$out/stats_8192.log 2>&1)
+find $out/stats_8192 -name "*kernel_trace.csv" -delete
 cut -c1-400 $out/bench_rough.json; cut -c1-200 $out/bench_flat.json; cut -c1-200 $out/bench_full_body_rough16384.json
 python -c "import json; print('rough runs ms/step:', [round(json.loads(l)['ms_per_step'], 4) for l in open('$out/bench_rough_runs.jsonl')])"
 python - <<EOF

@@ -18,6 +18,7 @@ for name in ("fetch", "write"):
             cname = r["Counter_Name"]
     out[cname] = {"launches": len(vals), "mean_KB": sum(vals) / len(vals), "min_KB": min(vals), "max_KB": max(vals)}
     out["kernel_resources"] = res
+    out["kernel"] = (res or {}).get("Kernel_Name", "").replace("void ", "").split("(")[0]
 bench = json.loads(open(f"{src}/bench_rough.json").read())
 alg = bench["roofline"]["algorithmic_bytes_per_env_step"] * bench["config"]["envs_per_gpu"]
 out["algorithmic_bytes_per_launch"] = alg
@@ -28,7 +29,7 @@ out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate pass
                "WRITE_SIZE is uncalibrated.")
 json.dump(out, open(f"{dst}/{tag}_pmc_hbm_rough4096.json", "w"), indent=1)
 # SQ passes -> one JSON (mean per launch of grx_step_kernel)
-sq = {"kernel": "grx_step_kernel_quad<true, 8> (the headline layout at 4096 envs: eight waves per 16-env block)", "workload": "python bench.py --steps 300 --warmup 50 --no-cpu-baseline (rough, 4096 envs); rocprofv3 --pmc, "
+sq = {"kernel": "grx_step_kernel_quad<true, 8, false> (the headline layout at 4096 envs: eight waves per 16-env block)", "workload": "python bench.py --steps 300 --warmup 50 --no-cpu-baseline (rough, 4096 envs); rocprofv3 --pmc, "
       "one pass per counter group (tools/collect_profiles.sh), mean per launch"}
 for f in sorted(glob.glob(f"{src}/pmc_sq*/**/*counter_collection.csv", recursive=True)):
     agg = {}
@@ -54,4 +55,37 @@ for n in (4096, 16384):
 fb = glob.glob(f"{src}/stats_full_body/**/*kernel_stats.csv", recursive=True)
 if fb:
     shutil.copy(fb[0], f"{dst}/{tag}_kernel_stats_full_body_rough16384.csv")
+fb = glob.glob(f"{src}/stats_full_body4096/**/*kernel_stats.csv", recursive=True)
+if fb:
+    shutil.copy(fb[0], f"{dst}/{tag}_kernel_stats_full_body_rough4096.csv")
+fb = glob.glob(f"{src}/stats_8192/**/*kernel_stats.csv", recursive=True)
+if fb:
+    shutil.copy(fb[0], f"{dst}/{tag}_kernel_stats_rough8192.csv")
+    shutil.copy(f"{src}/bench_rough8192.json", f"{dst}/{tag}_bench_n1_rough8192.json")
+# config 5 (tree kernel) counter passes
+fbo = {}
+for name in ("fetch", "write"):
+    fs = glob.glob(f"{src}/fb_pmc_{name}/**/*counter_collection.csv", recursive=True)
+    if not fs:
+        continue
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(fs[0])) if "grx_step_tree" in r["Kernel_Name"]]
+    if vals:
+        fbo[name.upper() + "_SIZE"] = {"launches": len(vals), "mean_KB": sum(vals) / len(vals), "min_KB": min(vals), "max_KB": max(vals)}
+if fbo:
+    fbo["kernel"] = "grx_step_tree<true>"
+    fbo["algorithmic_bytes_per_launch"] = (3422.0 + 726.0) * 4096
+    fbo["note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `python bench.py --robot full_body --envs-per-gpu 4096 --steps 200`; KB per launch of grx_step_tree; same gfx950 caveats as the lower-limb file"
+    json.dump(fbo, open(f"{dst}/{tag}_pmc_hbm_full_body_rough4096.json", "w"), indent=1)
+fsq = {"kernel": "grx_step_tree<true>", "workload": "python bench.py --robot full_body --envs-per-gpu 4096 --steps 200 --warmup 20 --no-cpu-baseline; rocprofv3 --pmc, one pass per counter group, mean per launch"}
+for f in sorted(glob.glob(f"{src}/fb_pmc_sq*/**/*counter_collection.csv", recursive=True)):
+    agg = {}
+    for r in csv.DictReader(open(f)):
+        if "grx_step_tree" in r["Kernel_Name"]:
+            agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k_, v_ in agg.items():
+        fsq[k_] = round(sum(v_) / len(v_))
+if "SQ_INSTS_VALU" in fsq:
+    fsq["derived"] = {"valu_per_wave": fsq["SQ_INSTS_VALU"] / max(fsq.get("SQ_WAVES", 1), 1), "lds_per_wave": fsq.get("SQ_INSTS_LDS", 0) / max(fsq.get("SQ_WAVES", 1), 1),
+                      "wait_any_fraction": fsq.get("SQ_WAIT_ANY", 0) / max(fsq.get("SQ_WAVE_CYCLES", 1), 1)}
+    json.dump(fsq, open(f"{dst}/{tag}_pmc_sq_full_body_rough4096.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
