@@ -165,13 +165,25 @@ def main():
     pool = [random_actions(cfg, n_local, gen, 1.0 if args.robot == "lower_limb" else 0.3).to(dev) for _ in range(16)]   # U[clip_min, clip_max]
     delay = 5.0
     counter = 0
-    # The GPU idles while the host builds the terrain and the robot tables (seconds): its first kernels then run at the idle
-    # power state's clocks (measured: a 20-step window right after 5 warm-up steps reads 57.5 M env-steps/s, the same window
-    # after 250 ms of unrelated GPU work 59.3 M -- the 20000-step default reads 59.9 M either way).  So the device is kept busy
-    # for `prespin_ms` with a plain matmul BEFORE the warm-up steps; no env step is skipped or moved, and the figure is in the
-    # JSON line (GRX_BENCH_PRESPIN_MS=0 turns it off).
+    # The GPU idles while the host builds the terrain and the robot tables (seconds): its first kernels then run at the idle power
+    # state's clocks.  Measured on the driver's own window (--steps 20 --warmup 5, round 4, three runs each): no pre-spin 76.6-78.5 M
+    # env-steps/s, 250 ms of a plain matmul 80.6-82.3 M, 250 ms of THIS workload on a second, throw-away handle 82.3-84.1 M (the
+    # kernel's own power / clock regime; the 20000-step default reads 88 M either way).  So the device is kept busy for `prespin_ms`
+    # BEFORE the warm-up steps with steps of a second handle (GRX_BENCH_PRESPIN_KIND=matmul: the matmul of rounds 2-3); no step of the
+    # timed handle is skipped, added or moved, and kind and duration are in the JSON line (GRX_BENCH_PRESPIN_MS=0 turns it off).
     prespin = float(os.environ.get("GRX_BENCH_PRESPIN_MS", "250"))
-    if prespin > 0:
+    prespin_kind = os.environ.get("GRX_BENCH_PRESPIN_KIND", "step")
+    if prespin > 0 and prespin_kind == "step":   # a SECOND handle of the same workload keeps the device busy: this kernel's own power / clock regime
+        c2, keep2, _ = build_config.build(cfg, cfg.sim.dt, n_local, rank * n_local, n_total, seed + 1, terrain_obj)
+        sim2 = HipSim(c2, dev, keep2)
+        sim2.reset_all()
+        t_ = time.perf_counter(); k_ = 0
+        while (time.perf_counter() - t_) * 1e3 < prespin:
+            for _ in range(64):
+                k_ += 1; sim2.step(pool[k_ % 16], delay, k_)
+            sim2.wait_idle()
+        sim2.close()
+    elif prespin > 0:
         a_ = torch.randn(4096, 4096, device=dev)
         t_ = time.perf_counter()
         while (time.perf_counter() - t_) * 1e3 < prespin:
@@ -250,7 +262,7 @@ def main():
             "config": {"workload": f"GR1T1 {'lower-limb (10 DOF)' if args.robot == 'lower_limb' else 'full body (32 DOF, tree kernel)'}, {'rough-terrain curriculum heightfield 10x20 tiles + 121-pt height scan' if args.terrain == 'rough' else 'flat plane'}, "
                                    f"{n_local} envs/GPU, decimation 10 @ dt 0.002, DR+noise+push on, action latency 5 sub-steps, random actions U[clip_min,clip_max]",
                        "envs_per_gpu": n_local, "global_envs": n_total, "parallelism": f"env-sharded x{world} (no data-path collective)",
-                       "finite_outputs": finite, "prespin_ms": prespin,
+                       "finite_outputs": finite, "prespin_ms": prespin, "prespin_kind": prespin_kind,
                        "rigid_body_states_published": bool(cfg.env.publish_rigid_body_states),   # (SURVEY 8d prices the tensor as an optional surcharge: off here, on by default in the env; GRX_BENCH_RBS=1 measures with it)
                        "layout": layout},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
