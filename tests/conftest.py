@@ -28,3 +28,12 @@ def _build_oracle():
     """The CPU oracle (test infrastructure) is compiled on demand."""
     from oracle import binding
     binding.build()
+
+
+@pytest.fixture(autouse=True)
+def _collect_garbage_between_tests():
+    """Simulation handles own device memory; a handle that dies in a LATER test -- whenever the cyclic collector happens to run,
+    e.g. inside that test's HIP-graph capture -- frees it there.  Collect after every test instead."""
+    yield
+    import gc
+    gc.collect()

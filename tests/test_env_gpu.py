@@ -72,10 +72,13 @@ def test_steps_recorded_into_a_hip_graph_neither_pace_nor_hang():
         s.reset_all(); s.step(act, 0.0, 1)
     torch.cuda.synchronize()
     n = 300                                               # > the run-ahead window
+    import gc
+    gc.collect(); gc.disable()                            # (a handle finalised inside a capture frees device memory there: not capturable)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for k in range(n):
             hip.step(act, 0.0, 2 + k)
+    gc.enable()
     g.replay()
     hip.wait_idle()                                       # only eager steps hold tickets: returns at once
     for k in range(n):
@@ -101,10 +104,13 @@ def test_episode_statistics_survive_graph_replays(steps_in_graph):
     for s in (hip, ref):
         s.reset_all(); s.step(act, 0.0, 1)
     torch.cuda.synchronize()
+    import gc
+    gc.collect(); gc.disable()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for k in range(steps_in_graph):
             hip.step(act, 0.0, 2 + k)
+    gc.enable()
     seen = set()
     for rep in range(5):
         g.replay()

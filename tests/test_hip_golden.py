@@ -23,16 +23,27 @@ pytestmark = pytest.mark.gpu
 # run -- lane pairs with four / eight waves (8192-16384 envs per GPU), lane quads with four / eight waves (<= 4096 envs per GPU) --
 # where the reward inputs cross LDS to two reward waves, reset_idx's draws come from the foot wave, the termination flag from the
 # base-lump wave and the height block from the helper waves.
-LAYOUTS = pytest.mark.parametrize("layout", [1, 4, 8, "quad4", "quad"])
+# "tree": the lower-limb model forced through the tree kernel (GRX_FORCE_GENERIC) -- the post-physics code BASELINE.json's config 5 runs
+# (csrc/grx_tree.h; the reference registers no full-body task, so its fixtures reach that code through the 10-dof robot).
+LAYOUTS = pytest.mark.parametrize("layout", [1, 4, 8, "quad4", "quad", "tree"])
 KERNEL_OF = {1: ("grx_step_kernel<", 2, 1), 4: ("grx_step_kernel<", 2, 4), 8: ("grx_step_kernel<", 2, 8),
-             "quad4": ("grx_step_kernel_quad<", 4, 4), "quad": ("grx_step_kernel_quad<", 4, 8)}
+             "quad4": ("grx_step_kernel_quad<", 4, 4), "quad": ("grx_step_kernel_quad<", 4, 8), "tree": ("grx_step_tree<", 8, 2)}
+
+
+def pick_layout(monkeypatch, layout):
+    from tests.test_hip_parity import set_layout
+    if layout == "tree":
+        monkeypatch.setenv("GRX_FORCE_GENERIC", "1")
+        monkeypatch.setenv("GRX_TREE", "1")
+    else:
+        monkeypatch.delenv("GRX_FORCE_GENERIC", raising=False)
+        set_layout(monkeypatch, layout)
 
 
 def make_hip(cfg, N=64, layout=None, monkeypatch=None):
-    from tests.test_hip_parity import set_layout
     from wiki_grx_gym_amd.sim import HipSim
     if layout is not None:
-        set_layout(monkeypatch, layout)
+        pick_layout(monkeypatch, layout)
     c, keep, meta = build_config.build(cfg, cfg.sim.dt, N)
     sim = HipSim(c, "cuda:0", keep)
     if layout is not None:   # the handle really runs (and debug-injects into) the kernel this case names
@@ -141,8 +152,7 @@ def test_quat_apply_yaw_fixture_selects_the_height_scan_cells(layout, monkeypatc
     for k in range(nh):
         c.height_points[k][0], c.height_points[k][1] = float(d["v"][k, 0] * scale), float(d["v"][k, 1] * scale)
     c.border_size = 0.0
-    from tests.test_hip_parity import set_layout
-    set_layout(monkeypatch, layout)   # (heightfield kernels: the scan runs over one wave, or over the four / seven waves of the pipelines)
+    pick_layout(monkeypatch, layout)   # (heightfield kernels: the scan runs over one wave, or over the four / seven waves of the pipelines)
     sim = HipSim(c, "cuda:0", keep)
     assert sim.layout()["waves_per_block"] == KERNEL_OF[layout][2] and sim.layout()["kernel"].startswith(KERNEL_OF[layout][0] + "true")
     arr, _ = og.quat_states(N)

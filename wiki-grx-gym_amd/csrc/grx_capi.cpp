@@ -33,6 +33,8 @@ int grx_tree_lds_bytes(int nb, int nlc, int nchain, int waves);
 int grx_tree_envs_per_wave(void);
 int grx_launch_step_tree(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions, float delay,
                          long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream);
+int grx_launch_step_tree_debug(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions,
+                               long long common_step, const float* noise, const float* dbg, const StepSeq* sq, hipStream_t stream);
 int grx_generic_ws_floats_per_env(int nb, int nlc);
 void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, const StepSeq* sq, uint8_t* mask, hipStream_t stream);
 void grx_launch_mark(const int32_t* env_ids, int n, int N, uint8_t* mask, hipStream_t stream);
@@ -1234,7 +1236,7 @@ int grx_layout(grx_handle s, grx_layout_info* out) {
     const char* hf = s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD ? "true" : "false";
     if (s->generic && s->d_tree) {
         out->lanes_per_env = GRX_TREE_G; out->waves_per_block = s->tree_waves; out->envs_per_block = grx_tree_envs_per_wave() * s->tree_waves;
-        snprintf(out->kernel, sizeof out->kernel, "grx_step_tree<%s>", hf);
+        snprintf(out->kernel, sizeof out->kernel, "grx_step_tree<%s, false>", hf);
     } else if (s->generic) {
         out->lanes_per_env = 1; out->waves_per_block = 1; out->envs_per_block = s->gen_epb;
         snprintf(out->kernel, sizeof out->kernel, "grx_step_generic<%s>", hf);
@@ -1283,7 +1285,7 @@ int grx_debug_profile(grx_handle s, long long* out, int max_blocks) {
 // buffers + the debug rows, then launches the DBG instantiation (no sub-steps) of the step kernel this handle runs.
 int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply_reset, const grx_step_args* a, void* stream) {
     if (!s || !ps || !a) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_post_physics: null argument");
-    if (s->generic) return fail(GRX_ERR_UNSUPPORTED_MODEL, "grx_debug_post_physics: lower-limb (fused-kernel) models only");
+    if (s->generic && !(s->d_tree && s->nd == GRX_ND)) return fail(GRX_ERR_UNSUPPORTED_MODEL, "grx_debug_post_physics: 10-dof models on the fused kernels or the tree kernel only");
     hipStream_t st = (hipStream_t)stream;
     const size_t N = (size_t)s->N;
     const int nd = s->nd, rows = grx_debug_rows();
@@ -1323,8 +1325,12 @@ int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply
 #undef UPS
     HIP_TRY(hipStreamSynchronize(st));   // the host vectors go out of scope
     const StepSeq sq = next_seq(s, st, false);
-    // the post-physics half of the kernel this handle steps with (lane pairs: 1 / 4 / 8 waves; lane quads: 4 / 8)
-    if (s->quad) grx_launch_step_debug_quad(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, s->d_dbg_actions,
+    // the post-physics half of the kernel this handle steps with (lane pairs: 1 / 4 / 8 waves; lane quads: 4 / 8; GRX_FORCE_GENERIC: the tree kernel)
+    if (s->generic) {
+        if (grx_launch_step_tree_debug(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_waves, s->tree_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->d_dbg_actions,
+                                       (long long)a->common_step_counter, a->noise_uniform, s->d_dbg, &sq, st))
+            return fail(GRX_ERR_HIP, "grx_debug_post_physics: cannot raise the dynamic LDS limit of the tree kernel");
+    } else if (s->quad) grx_launch_step_debug_quad(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, s->d_dbg_actions,
                                             (long long)a->common_step_counter, a->noise_uniform, s->d_dbg, &sq, st);
     else grx_launch_step_debug(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, s->d_dbg_actions, (long long)a->common_step_counter,
                                a->noise_uniform, s->d_dbg, &sq, st);

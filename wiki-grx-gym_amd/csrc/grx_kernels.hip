@@ -898,6 +898,9 @@ GRX_DEV void noise_blocks(KP P, uint32_t genv, uint32_t step, int side, U4 nzb[N
     for (int b = 0; b < NZB; ++b) { nzb[b].x = c0[b]; nzb[b].y = c1[b]; nzb[b].z = c2[b]; nzb[b].w = c3[b]; }
 }
 
+// rows of the debug-injection table ([DBG_ROWS][N], grx_debug_post_physics): see grx_step_kernel's DBG instantiations
+enum DbgRow { DBG_FEET_FORCE = 0, DBG_FEET_POS = 6, DBG_AVG_FORCE = 12, DBG_AVG_SPEED = 14, DBG_TORQUES = 20, DBG_LAST_LAST_ACTIONS = 30,
+              DBG_TERM_CONTACT = 40, DBG_APPLY_RESET = 41, DBG_ROWS = 42 };
 #ifndef GRX_QUAD_TU
 #include "grx_generic.h"
 #include "grx_tree.h"
@@ -1143,8 +1146,6 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
 // kernel: the height scan over the waves, the reward inputs through LDS to the two reward waves (which fetch the injected
 // last_last_actions themselves), reset_idx's draws from the foot wave, the termination flag through s_tp from the base-lump
 // wave, the observation height block on the helper waves.
-enum DbgRow { DBG_FEET_FORCE = 0, DBG_FEET_POS = 6, DBG_AVG_FORCE = 12, DBG_AVG_SPEED = 14, DBG_TORQUES = 20, DBG_LAST_LAST_ACTIONS = 30,
-              DBG_TERM_CONTACT = 40, DBG_APPLY_RESET = 41, DBG_ROWS = 42 };
 template <bool HF, int W, bool DBG = false>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 2 : GRX_WPE, W > 4 ? 2 : GRX_WPE))) void grx_step_kernel(const KParams* __restrict__ Pg, const float* __restrict__ actions_in,
                                                       float delay, long long common_step, const float* __restrict__ noise_in,
@@ -2075,15 +2076,31 @@ extern "C" int grx_launch_step_tree(const KParams* dP, const void* tree_tab, con
                                     long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {
     static bool raised = false;
     if (!raised) {   // > 64 KB of dynamic LDS needs the opt-in
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
         raised = true;
     }
     const int nblocks = (N + TEPW * waves - 1) / (TEPW * waves);
     const TreeTab* Tt = static_cast<const TreeTab*>(tree_tab);
     const GenTables* Tg = static_cast<const GenTables*>(gen_tab);
-    if (heightfield) hipLaunchKernelGGL(grx_step_tree<true>, dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq);
-    else hipLaunchKernelGGL(grx_step_tree<false>, dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq);
+    if (heightfield) hipLaunchKernelGGL((grx_step_tree<true, false>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq, (const float*)nullptr);
+    else hipLaunchKernelGGL((grx_step_tree<false, false>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq, (const float*)nullptr);
+    return 0;
+}
+// TEST-ONLY (grx_debug_post_physics): the post-physics half of the tree kernel on injected state (a 10-dof model forced through it)
+extern "C" int grx_launch_step_tree_debug(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions,
+                                          long long common_step, const float* noise, const float* dbg, const StepSeq* sq, hipStream_t stream) {
+    static bool raised = false;
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+        raised = true;
+    }
+    const int nblocks = (N + TEPW * waves - 1) / (TEPW * waves);
+    const TreeTab* Tt = static_cast<const TreeTab*>(tree_tab);
+    const GenTables* Tg = static_cast<const GenTables*>(gen_tab);
+    if (heightfield) hipLaunchKernelGGL((grx_step_tree<true, true>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, 0.f, common_step, noise, (float*)nullptr, (float*)nullptr, *sq, dbg);
+    else hipLaunchKernelGGL((grx_step_tree<false, true>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, 0.f, common_step, noise, (float*)nullptr, (float*)nullptr, *sq, dbg);
     return 0;
 }
 extern "C" int grx_generic_tables_size(void) { return (int)sizeof(GenTables); }

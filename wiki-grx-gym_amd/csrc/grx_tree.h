@@ -398,11 +398,14 @@ GRX_DEV void tree_self_collision(KP P, const TreeTab& T, float* wsw, int ei, int
 
 // ---------------------------------------------------------------------------------------------------------------
 // blockDim = 64 * waves (2 or 4: grx_capi.cpp); dynamic LDS = the table + one workspace per wave.  One wave per SIMD.
-template <bool HF>
+// DBG (TEST-ONLY, grx_debug_post_physics; the lower-limb model forced through this kernel, i.e. nd = 10 like the debug rows): no
+// sub-steps; foot forces / positions, sub-step averages, torques, termination contact and last_last_actions come from `dbg`
+// (grx_kernels.hip DbgRow) -- the reference's golden fixtures reach the post-physics code config 5 runs.
+template <bool HF, bool DBG = false>
 __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_tree(const KParams* __restrict__ Pg, const TreeTab* __restrict__ Tt, const GenTables* __restrict__ Tg,
                                                              const float* __restrict__ actions_in, float delay, long long common_step,
                                                              const float* __restrict__ noise_in, float* __restrict__ obs_out, float* __restrict__ pri_out,
-                                                             const StepSeq sq) {
+                                                             const StepSeq sq, const float* __restrict__ dbg = nullptr) {
     KP P = GRX_PARAMS(Pg);
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     __shared__ float s_stat[NSTAT];
@@ -485,7 +488,11 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
 #else
 #define TT(i) do {} while (0)
 #endif
-    for (int deci = 0; deci < P.decimation; ++deci) {
+    if (DBG) {
+        for (int i = c; i < T.nlc * 3; i += TG) TW(o.lf + i) = 0.f;
+        tree_fence();
+    }
+    for (int deci = 0; deci < (DBG ? 0 : P.decimation); ++deci) {
         TT(7);
         asm volatile("" ::: "memory");   // (keeps the loop-invariant table reads of the unrolled passes in LDS: hoisted, they would spill)
         for (int i = c; i < T.nlc * 3; i += TG) TW(o.lf + i) = 0.f;
@@ -617,6 +624,22 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         }
         foot_force[f] = tw_v3(wsw, ei, o.lf + T.foot_link[f] * 3);
     }
+    bool dbg_apply_reset = true;
+    if (DBG) {   // injected "physics results" (rows of DbgRow, [row][N])
+        const float* d = dbg + e;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            foot_force[f] = v3(d[(size_t)(DBG_FEET_FORCE + f * 3) * N], d[(size_t)(DBG_FEET_FORCE + f * 3 + 1) * N], d[(size_t)(DBG_FEET_FORCE + f * 3 + 2) * N]);
+            fpos[f] = v3(d[(size_t)(DBG_FEET_POS + f * 3) * N], d[(size_t)(DBG_FEET_POS + f * 3 + 1) * N], d[(size_t)(DBG_FEET_POS + f * 3 + 2) * N]);
+            avg_force[f] = d[(size_t)(DBG_AVG_FORCE + f) * N];
+            avg_speed[f] = v3(d[(size_t)(DBG_AVG_SPEED + f * 3) * N], d[(size_t)(DBG_AVG_SPEED + f * 3 + 1) * N], d[(size_t)(DBG_AVG_SPEED + f * 3 + 2) * N]);
+        }
+#pragma unroll
+        for (int g = 0; g < TNG; ++g)
+            if (G.sb[g] >= 0) TW(TBO(G.sb[g]) + T_TAU) = d[(size_t)(DBG_TORQUES + G.sb[g] - 1) * N];
+        dbg_apply_reset = d[(size_t)DBG_APPLY_RESET * N] != 0.f;
+        tree_fence();
+    }
     // termination / collision from the per-link net forces of the LAST sub-step (legged_robot.py:336-353); contact_forces rows
     bool term_contact = false;
     float pen_count = 0.f;
@@ -630,6 +653,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             cf[0] = F.x; cf[N] = F.y; cf[2 * N] = F.z;
         }
     }
+    if (DBG) { term_contact = dbg[(size_t)DBG_TERM_CONTACT * N + e] != 0.f; pen_count = 0.f; }
     float torso_g[2] = {0.f, 0.f}, fore_g[2] = {0.f, 0.f};
     if (T.torso_body >= 0) {
         const R3 R = T.torso_body == 0 ? quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw) : tw_R(wsw, ei, TBO(T.torso_body) + T_R);
@@ -688,6 +712,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     {
         const float as = P.action_scale, H = P.swing_feet_height_target, Tt_ = P.feet_air_time_target;
         const GRX_AS4 float* sg = P.reward_sigma;
+        float s2 = 0.f;   // DBG: the injected last_last_actions (otherwise last_last_actions == last_actions, legged_robot_fftai.py:94)
         float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
         float tor_hr = 0.f, vel_kn = 0.f, ank[2] = {0.f, 0.f};
 #pragma unroll
@@ -698,6 +723,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             const float ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j), al = TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j), qj = G.q[g], qdj = G.qd[g], tj = TW(TBO(j + 1) + T_TAU);
             const uint32_t bit = 1u << j;
             s1 += fabsf((al - ac) * as);
+            if (DBG) s2 += fabsf((al - ac) * as - (dbg[(size_t)(DBG_LAST_LAST_ACTIONS + j) * N + e] - al) * as);
             if (P.knee_mask & bit) { s3 += fabsf((ac - al) * as); vel_kn += fabsf(qdj); }
             sacc += fabsf((qdj - P.last_dof_vel[(size_t)j * N + e]) / dtp);
             stor += fabsf(tj);
@@ -719,6 +745,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             slv += fminf(fmaxf(fabsf(qdj) - td.vlim * P.soft_dof_vel_limit, 0.f), 1.f);
             slt += fmaxf(fabsf(tj) - td.effort * P.soft_torque_limit, 0.f);
         }
+        s2 = DBG ? grp_sum(s2) : 0.f;
         s1 = grp_sum(s1); s3 = grp_sum(s3); sacc = grp_sum(sacc); stor = grp_sum(stor); svel = grp_sum(svel); spose = grp_sum(spose);
         sla = grp_sum(sla); slp = grp_sum(slp); slt = grp_sum(slt); slv = grp_sum(slv); shy = grp_sum(shy);
         tor_hr = grp_sum(tor_hr); vel_kn = grp_sum(vel_kn); ank[0] = grp_sum(ank[0]); ank[1] = grp_sum(ank[1]);
@@ -747,7 +774,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         const float cmd_n = sqrtf(ea.cmd[0] * ea.cmd[0] + ea.cmd[1] * ea.cmd[1]);
         const float moving = cmd_n > 0.1f ? 1.f : 0.f;
         r[GRX_REW_ACTION_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF] * s1);
-        r[GRX_REW_ACTION_DIFF_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_DIFF] * s1);   // last_last_actions == last_actions
+        r[GRX_REW_ACTION_DIFF_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_DIFF] * (DBG ? s2 : s1));   // last_last_actions == last_actions
         r[GRX_REW_ACTION_DIFF_KNEE] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_KNEE] * s3);
         r[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] * fabsf(0.f - bav.y));
         r[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] * fabsf(0.f - bav.x));
@@ -808,12 +835,14 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             if (lane == 0) atomicAdd(&s_stat[t], acc_);   // (two waves per block: LDS float add of two values, order-free)
         }
         if (actl && P.reward_scale_dt[t] != 0.f) {
-            P.episode_sums[(size_t)t * N + e] = reset ? 0.f : es;
+            P.episode_sums[(size_t)t * N + e] = (reset && dbg_apply_reset) ? 0.f : es;
             if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
         }
     }
     if (lane == 0) atomicAdd(&s_stat[NT], (float)__popcll(reset_mask));
     // ---- reset_idx (masked, in-kernel): a chain's joints by its lane, the base in every lane (same counters, same values)
+    const bool reported_reset = reset;   // (the debug entry may report a reset without applying it)
+    if (DBG && !dbg_apply_reset) reset = false;
     if (reset) {
         if (P.curriculum && P.terrain_type != GRX_TERRAIN_PLANE) {
             const float dx = B.pos.x - ea.origin[0], dy = B.pos.y - ea.origin[1];
@@ -958,7 +987,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             P.base_heights_offset[e] = bho;
             P.ep_len[e] = ep_len;
             P.rew[e] = rew;
-            P.reset[e] = reset ? 1 : 0;
+            P.reset[e] = reported_reset ? 1 : 0;
             P.time_out[e] = time_out ? 1 : 0;
             P.term_contact[e] = term_contact ? 1 : 0;
         }

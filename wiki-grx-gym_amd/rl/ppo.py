@@ -7,6 +7,7 @@ the 436 885-parameter model.  Per optimizer step ONE flat fp32 bucket (gradients
 appended as the last element) is all-reduced over RCCL/xGMI and averaged, so every rank takes the
 same adaptive-LR decision and the same Adam step: replicas stay bit-identical without broadcasting.
 At 1.75 MB the collective is latency-bound; a single fused bucket keeps it at one launch."""
+import contextlib
 import os
 
 import torch
@@ -34,6 +35,27 @@ def _capture_mode():
 
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+@contextlib.contextmanager
+def _graph_capture(graph, stream):
+    """torch.cuda.graph(...) with Python's cyclic garbage collector held off for the duration of the capture.  A collection that
+    fires inside a capture -- on this thread, or on autograd's worker thread, which runs the Python backward of FusedPPOLoss /
+    _TrainLinear -- may finalise an object that owns device memory (an env handle: grx_destroy -> hipFree / hipHostFree, a torch
+    tensor's storage, an event): a free is not a capturable operation, the capture is invalidated and the HIP runtime or the
+    autograd thread aborts the process.  Seen once in three runs of the full GPU suite in round 4 (129 tests' worth of garbage
+    before the capture in test_rccl_bucket_path_matches_reference); a training job that drops an env while the update graph is being
+    built would hit the same."""
+    import gc
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode=_capture_mode()):
+            yield
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 class PPO:
@@ -175,10 +197,10 @@ class PPO:
                         actor_part(); critic_part()
                 cur.wait_stream(side)
                 self._act_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._act_graph, stream=side, capture_error_mode=_capture_mode()):
+                with _graph_capture(self._act_graph, side):
                     a_out = actor_part()
                 self._critic_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._critic_graph, stream=side, capture_error_mode=_capture_mode()):
+                with _graph_capture(self._critic_graph, side):
                     v_out = critic_part()
                 self._act_out = (a_out[0], v_out, a_out[1], a_out[2], a_out[3])
                 self._ev_obs, self._ev_critic = torch.cuda.Event(), torch.cuda.Event()
@@ -535,15 +557,15 @@ class PPO:
                 self._graph = _Eager(lambda: self._minibatch_step(self._static, self._sums))
         elif multi:
             self._graph, self._graph_back = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph, stream=side, capture_error_mode=_capture_mode()):
+            with _graph_capture(self._graph, side):
                 self._mb_front(self._static)
-            with torch.cuda.graph(self._graph_back, stream=side, capture_error_mode=_capture_mode()):
+            with _graph_capture(self._graph_back, side):
                 self._mb_back(self._sums)
         else:
             self._graph = torch.cuda.CUDAGraph()
             # capture on the stream the dry runs used: autograd's AccumulateGrad nodes remember the stream they were
             # created on, and one that differs from the capture stream runs (and allocates) outside the capture
-            with torch.cuda.graph(self._graph, stream=side, capture_error_mode=_capture_mode()):
+            with _graph_capture(self._graph, side):
                 self._minibatch_step(self._static, self._sums)
         torch.backends.cuda.preferred_blas_library(prev_blas)
         # restore: parameters, Adam moments/step counters, learning rate
