@@ -581,19 +581,34 @@ int build_generic(grx_sim* s, const grx_config& c) {
     K.torso_body = T.torso_body; K.forehead_body = T.forehead_body;
     memcpy(K.torso_rot, T.torso_rot, sizeof K.torso_rot); memcpy(K.forehead_rot, T.forehead_rot, sizeof K.forehead_rot);
     K.sph_begin0 = T.sph_begin[0]; K.sph_end0 = T.sph_begin[1];
-    {   // the contact pass: a lane's bodies that carry shapes (or whose frame is a foot's), in chain order
-        memset(K.csb, 0xff, sizeof K.csb);
-        int cnt[GRX_TREE_G] = {0};
-        for (int b = 1; b < T.nb; ++b) {
+    {   // the contact pass's work list (TreeTab.cw): every body's shapes in chunks of two, the largest bodies first, dealt to the eight
+        // lanes round by round; chunks of one body that land in the same round take turns at its accumulators.  A foot body is listed
+        // even without shapes (its frame gives the sub-step averaged foot speed).
+        struct Item { int body, s0, s1, turn; };
+        std::vector<Item> items;
+        std::vector<int> order;
+        for (int b = 0; b < T.nb; ++b) order.push_back(b);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b_) { return (T.sph_begin[a + 1] - T.sph_begin[a]) > (T.sph_begin[b_ + 1] - T.sph_begin[b_]); });
+        for (int b : order) {
+            const int n0 = T.sph_begin[b], n1 = T.sph_begin[b + 1];
             const bool foot = b == T.foot_body[0] || b == T.foot_body[1];
-            if (T.sph_begin[b + 1] > T.sph_begin[b] || foot) {
-                const int ln = lane_of[b];
-                if (cnt[ln] >= GRX_TREE_MAXCS) return GRX_OK;   // (the generic kernel runs it)
-                K.csb[ln][cnt[ln]++] = (int8_t)b;
-                K.ncs = std::max(K.ncs, cnt[ln]);
-            }
+            if (n1 == n0 && foot) items.push_back({b, n0, n0, 0});
+            for (int i = n0; i < n1; i += 2) items.push_back({b, i, std::min(i + 2, n1), 0});
         }
         if (T.foot_body[0] < 1 || T.foot_body[1] < 1) return GRX_OK;   // (feet on the base: not this kernel's layout)
+        const int rounds = ((int)items.size() + GRX_TREE_G - 1) / GRX_TREE_G;
+        if (rounds > GRX_TREE_MAXCS) return GRX_OK;   // (the generic kernel runs it)
+        memset(K.cw, 0xff, sizeof K.cw);
+        K.ncs = rounds; K.nturn = 1;
+        for (int r = 0; r < rounds; ++r)
+            for (int ln = 0; ln < GRX_TREE_G; ++ln) {
+                const size_t k = (size_t)r * GRX_TREE_G + ln;
+                if (k >= items.size()) continue;
+                Item it = items[k];
+                for (int l2 = 0; l2 < ln; ++l2) if (K.cw[r][l2].body == it.body) it.turn = std::max(it.turn, K.cw[r][l2].turn + 1);
+                K.cw[r][ln].body = (int8_t)it.body; K.cw[r][ln].s0 = (int8_t)it.s0; K.cw[r][ln].s1 = (int8_t)it.s1; K.cw[r][ln].turn = (int8_t)it.turn;
+                K.nturn = std::max(K.nturn, it.turn + 1);
+            }
     }
     K.nlp = T.nlp;
     for (int q = 0; q < T.nlp; ++q) {

@@ -125,9 +125,13 @@ struct TreeTab {
     int16_t lp_ba[48], lp_bb[48], lp_a[48], lp_b[48];
     float lp_ca[48][4], lp_cb[48][4];
     int32_t lc_begin[25];
-    int32_t ncs;                                      // rounds of the contact pass = the longest list below
-    int32_t pad2[2];
-    int8_t csb[GRX_TREE_G][GRX_TREE_MAXCS];           // bodies of lane c's chain that carry collision shapes or a foot frame (-1: none)
+    int32_t ncs;                                      // rounds of the contact pass
+    int32_t nturn;                                    // items of one round that share a body add their forces in turns 0 .. nturn - 1
+    int32_t pad2;
+    // the contact pass's work list: round r, lane c evaluates shapes [s0, s1) (at most two) of `body` (-1: nothing; 0: the base) on
+    // the frame in LDS -- ANY lane may take any body's shapes, so the three lanes of a group that own no chain work too and a foot's
+    // four spheres go to two lanes (round 4: four sphere-slots per sub-step for the full body instead of eight)
+    struct { int8_t body, s0, s1, turn; } cw[GRX_TREE_MAXCS][GRX_TREE_G];
 };
 
 // every URDF link frame by carrying body (the tree kernel's GRX_T_RIGID_BODY_STATES)

@@ -49,6 +49,9 @@ typedef const GRX_AS4 KParams& KP;
 #define GRX_TICKW(i) do {} while (0)
 #endif
 
+#ifndef GRX_W1_SCAN_BATCH
+#define GRX_W1_SCAN_BATCH 8   // one-wave layout: heightfield gathers in flight per batch of the 121-point scan (16 and 31 measured at 32768 envs: +0.5 %, within noise)
+#endif
 #ifndef GRX_WPE
 #define GRX_WPE 1   // waves per SIMD the step kernel's register budget is sized for
 #endif
@@ -1631,7 +1634,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
             lds_barrier();   // height scan complete
             if (W == 8) hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + ((s_hsum[4 * 64 + lane] + s_hsum[5 * 64 + lane]) + (s_hsum[6 * 64 + lane] + s_hsum[7 * 64 + lane]));
             else hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane];
-        } else hsum = height_scan_share<1>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
+        } else hsum = height_scan_share<1, GRX_W1_SCAN_BATCH>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
         hsum = env_sum(hsum);
     }
     if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {  // legged_robot.py:786-797

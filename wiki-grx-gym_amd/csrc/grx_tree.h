@@ -33,7 +33,7 @@ constexpr int TWAVES_MAX = 4;                    // waves per block: 2 while the
 // LDS workspace words per body (bodies 1 .. nb - 1; the base lives in registers)
 enum { T_R = 0, T_RHO = 9, T_W = 12, T_V = 15, T_PA = 18, T_PL = 21, T_TAU = 24, T_NB = 25 };   // (T_TAU: the joint's motor torque of the current sub-step)
 constexpr int T_UPW = 27;    // a chain's hand-over to its parent: A 6, B 9, D 6, pa 3, pl 3
-constexpr int T_MISC = 8;    // foot link velocities before the sub-step (6) + 2 spare
+constexpr int T_MISC = 14;   // foot link velocities before the sub-step (6), 2 spare, the terrain wrench on the base (6)
 enum { TD_ACUR = 0, TD_ALAST = 1, TD_STR = 2, TD_N = 3 };   // per-dof rows every sub-step reads: clipped action, last action, motor strength
 #define TBO(b) (((b) - 1) * T_NB)
 
@@ -74,7 +74,7 @@ GRX_DEV R3 tree_joint_rot(const R3& Rp, const TreeBody& tb, float q) {
 }
 
 // one sphere against the terrain (gen_sphere with the anchors and the link-force accumulators in the LDS workspace)
-template <bool HF>
+template <bool HF, bool LF = true>   // LF: add the force to the link's accumulator here (false: the caller does, in its turn)
 GRX_DEV V3 tree_sphere(KP P, const TreeSph& S, V3 w, V3 v, V3 O, float mu, float om_e, float hmax, float* wsw, int ei,
                        const TreeOff& o, V3 xr, const TerrainAt& th) {   // xr: the centre relative to O; th: the terrain under it (looked up by the caller, in batches)
     V3 F = v3(0.f, 0.f, 0.f);
@@ -124,8 +124,10 @@ GRX_DEV V3 tree_sphere(KP P, const TreeSph& S, V3 w, V3 v, V3 O, float mu, float
         }
     }
     if (slot >= 0) TW(o.an + slot * 3 + 2) = touching ? vimp : 0.f;
-    const int L = S.link;
-    TW(o.lf + L * 3) += F.x; TW(o.lf + L * 3 + 1) += F.y; TW(o.lf + L * 3 + 2) += F.z;
+    if (LF) {
+        const int L = S.link;
+        TW(o.lf + L * 3) += F.x; TW(o.lf + L * 3 + 1) += F.y; TW(o.lf + L * 3 + 2) += F.z;
+    }
     return F;
 }
 
@@ -203,45 +205,58 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
     }
 }
 
-// terrain contacts of the lane's bodies that carry shapes (T.csb: a few rounds), on the frames in LDS; the foot link's velocity
-// BEFORE this sub-step's integration (sub-step averaged foot speed, legged_robot_fftai.py:79-81) on the way
+// terrain contacts: a work list (TreeTab.cw) deals the bodies' shapes, two at a time, to ALL lanes of the group -- the frames are in
+// LDS, so a lane need not own the body: the lanes without a chain work too and a foot's four spheres go to two lanes.  Lanes whose
+// items share a body add their wrench (and the link forces) in turns.  The base's own shapes are items like any other (body 0: the
+// frame is in registers, the wrench goes to the group through o.misc).  On the way: the foot link's velocity BEFORE this sub-step's
+// integration (sub-step averaged foot speed, legged_robot_fftai.py:79-81).
 template <bool HF>
-GRX_DEV void tree_contacts(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E) {
-    for (int k = 0; k < T.ncs; ++k) {
-        const int b = T.csb[c][k];
+GRX_DEV void tree_contacts(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0) {
+    for (int r = 0; r < T.ncs; ++r) {
+        const int b = T.cw[r][c].body, s0 = T.cw[r][c].s0, s1 = T.cw[r][c].s1, turn = T.cw[r][c].turn;
+        V3 fa = v3(0.f, 0.f, 0.f), fl = v3(0.f, 0.f, 0.f), Fs[2] = {fa, fa};
+        R3 R = R0;
+        V3 rho = v3(0.f, 0.f, 0.f), w = E.B.ang, v = E.B.vel;
         if (b >= 0) {
-            const TreeBody& tb = T.body[b];
-            const int wb = TBO(b);
-            const R3 R = tw_R(wsw, ei, wb + T_R);
-            const V3 rho = tw_v3(wsw, ei, wb + T_RHO), w = tw_v3(wsw, ei, wb + T_W), v = tw_v3(wsw, ei, wb + T_V);
-            V3 fa = v3(0.f, 0.f, 0.f), fl = v3(0.f, 0.f, 0.f);
-            for (int i0 = tb.sph_begin; i0 < tb.sph_end; i0 += 4) {   // up to four shapes at a time: their terrain lookups in flight together
-                V3 xr[4]; TerrainAt th[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (i0 + u < tb.sph_end) {
-                        const TreeSph& S = T.sph[i0 + u];
-                        xr[u] = rho + rot(R, v3(S.x, S.y, S.z));
-                        th[u].h = 0.f; th[u].gx = 0.f; th[u].gy = 0.f;
-                        if (E.B.pos.z + xr[u].z - S.r <= E.hmax) th[u].h = terrain_height<HF>(P, E.B.pos.x + xr[u].x, E.B.pos.y + xr[u].y, th[u].gx, th[u].gy);
-                    }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (i0 + u < tb.sph_end) {
-                        const V3 F = tree_sphere<HF>(P, T.sph[i0 + u], w, v, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr[u], th[u]);
-                        fa = fa + cross(xr[u], F); fl = fl + F;
-                    }
+            if (b > 0) {
+                const int wb = TBO(b);
+                R = tw_R(wsw, ei, wb + T_R);
+                rho = tw_v3(wsw, ei, wb + T_RHO); w = tw_v3(wsw, ei, wb + T_W); v = tw_v3(wsw, ei, wb + T_V);
             }
-            TW(wb + T_PA) -= fa.x; TW(wb + T_PA + 1) -= fa.y; TW(wb + T_PA + 2) -= fa.z;
-            TW(wb + T_PL) -= fl.x; TW(wb + T_PL + 1) -= fl.y; TW(wb + T_PL + 2) -= fl.z;
+            V3 xr[2]; TerrainAt th[2];
 #pragma unroll
-            for (int f = 0; f < 2; ++f)
-                if (T.foot_body[f] == b) {
-                    const V3 fr = rho + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
-                    tw_put(wsw, ei, o.misc + f * 3, v + cross(w, fr));
+            for (int u = 0; u < 2; ++u)   // two shapes: their terrain lookups in flight together
+                if (s0 + u < s1) {
+                    const TreeSph& S = T.sph[s0 + u];
+                    xr[u] = rho + rot(R, v3(S.x, S.y, S.z));
+                    th[u].h = 0.f; th[u].gx = 0.f; th[u].gy = 0.f;
+                    if (E.B.pos.z + xr[u].z - S.r <= E.hmax) th[u].h = terrain_height<HF>(P, E.B.pos.x + xr[u].x, E.B.pos.y + xr[u].y, th[u].gx, th[u].gy);
+                }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (s0 + u < s1) {
+                    Fs[u] = tree_sphere<HF, false>(P, T.sph[s0 + u], w, v, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr[u], th[u]);
+                    fa = fa + cross(xr[u], Fs[u]); fl = fl + Fs[u];
                 }
         }
-        tree_fence();
+        for (int t = 0; t < T.nturn; ++t) {
+            if (b >= 0 && turn == t) {
+                const int wa = b > 0 ? TBO(b) + T_PA : o.misc + 8;   // (the base: its terrain wrench, SUBTRACTED from the bias force like everyone's)
+                TW(wa) -= fa.x; TW(wa + 1) -= fa.y; TW(wa + 2) -= fa.z; TW(wa + 3) -= fl.x; TW(wa + 4) -= fl.y; TW(wa + 5) -= fl.z;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (s0 + u < s1) { const int L = T.sph[s0 + u].link; TW(o.lf + L * 3) += Fs[u].x; TW(o.lf + L * 3 + 1) += Fs[u].y; TW(o.lf + L * 3 + 2) += Fs[u].z; }
+                if (t == 0) {
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+                        if (T.foot_body[f] == b) {
+                            const V3 fr = rho + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
+                            tw_put(wsw, ei, o.misc + f * 3, v + cross(w, fr));
+                        }
+                }
+            }
+            tree_fence();
+        }
     }
 }
 
@@ -263,10 +278,13 @@ GRX_DEV void tree_add_up(const float* wsw, int ei, int a, S3& A, M3& B, S3& D, V
 // pass 3 needs of a body is parked in slots of its LDS row that nobody reads any more in this sub-step: 1/d, u and the joint
 // in the rotation's, U = I^A S in the bias force's.
 enum { T_DI = T_R, T_U = T_R + 1, T_UA = T_PA, T_UL = T_PL };
-GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, int first, int last, const TreeRegs& G) {
-    S3 cA = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cD = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    M3 cB = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    V3 cpa = v3(0.f, 0.f, 0.f), cpl = v3(0.f, 0.f, 0.f);
+GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, int first, int last, TreeRegs& G) {
+    // The lane's chain is ONE run of levels (first .. last): its running articulated inertia [A B; B^T D] and bias force are the working
+    // set itself -- zero before the chain's leaf, every level ADDS its rigid body and downdates in place, the chain's first body hands
+    // them up.  (Round 4, from the ISA: separate per-level values copied into a carry cost 127 v_mov per level, a fifth of the pass.)
+    S3 A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    M3 Bm = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    V3 pa = v3(0.f, 0.f, 0.f), pl = v3(0.f, 0.f, 0.f);
 #pragma unroll
     for (int g = TNG - 1; g >= 0; --g) {
         if (g >= T.nstep) continue;   // (uniform)
@@ -276,16 +294,16 @@ GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, cons
             const int j = b - 1, wb = TBO(b);
             const R3 R = tw_R(wsw, ei, wb + T_R);
             const V3 rho = tw_v3(wsw, ei, wb + T_RHO);
-            V3 pa = tw_v3(wsw, ei, wb + T_PA), pl = tw_v3(wsw, ei, wb + T_PL);
+            pa = pa + tw_v3(wsw, ei, wb + T_PA); pl = pl + tw_v3(wsw, ei, wb + T_PL);
             float t = TW(wb + T_TAU);
             const V3 kap = rho + rot(R, v3(tb.com[0], tb.com[1], tb.com[2]));
             const S3 Ic = {tb.Ic[0], tb.Ic[1], tb.Ic[2], tb.Ic[3], tb.Ic[4], tb.Ic[5]};
             const float m = tb.mass;
-            S3 A; V3 h;
-            rigid_inertia(R, kap, m, Ic, A, h);
-            M3 Bm = {0.f, -h.z, h.y, h.z, 0.f, -h.x, -h.y, h.x, 0.f};
-            S3 D = {m, 0.f, 0.f, m, 0.f, m};
-            if (g < last) { A = A + cA; Bm = Bm + cB; D = D + cD; pa = pa + cpa; pl = pl + cpl; }   // the chain's own child, in registers
+            {
+                S3 Ar; V3 h;
+                rigid_inertia(R, kap, m, Ic, Ar, h);
+                add_rigid(A, Bm, D, Ar, h, m);
+            }
             for (int k = 0; k < tb.nhc; ++k) tree_add_up(wsw, ei, o.up + tb.hc[k] * T_UPW, A, Bm, D, pa, pl);   // chains that hang from this body, fixed order
             const V3 a = G.Sa[g], s = cross(rho, a);
             const V3 ua = mul(A, a) + mul(Bm, s);
@@ -298,11 +316,10 @@ GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, cons
             const float u = t - (dot(a, pa) + dot(s, pl));
             syr(A, ua, di); ger(Bm, ua, ul, di); syr(D, ul, di);
             const float ud = u * di;
-            const V3 npa = fma3(ua, ud, pa), npl = fma3(ul, ud, pl);
+            pa = fma3(ua, ud, pa); pl = fma3(ul, ud, pl);
             TW(wb + T_DI) = di; TW(wb + T_U) = u;
             tw_put(wsw, ei, wb + T_UA, ua); tw_put(wsw, ei, wb + T_UL, ul);
-            if (g == first) tree_put_up(wsw, ei, o.up + c * T_UPW, A, Bm, D, npa, npl);
-            else { cA = A; cB = Bm; cD = D; cpa = npa; cpl = npl; }
+            if (g == first) tree_put_up(wsw, ei, o.up + c * T_UPW, A, Bm, D, pa, pl);
         }
         tree_fence();
     }
@@ -496,30 +513,19 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         TT(7);
         asm volatile("" ::: "memory");   // (keeps the loop-invariant table reads of the unrolled passes in LDS: hoisted, they would spill)
         for (int i = c; i < T.nlc * 3; i += TG) TW(o.lf + i) = 0.f;
+        if (c < 6) TW(o.misc + 8 + c) = 0.f;
         tree_fence();
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
         tree_outward<false>(P, T, wsw, ei, c, o, E, R0, (float)deci < delay, first, last, G);
         TT(0);
-        tree_contacts<HF>(P, T, wsw, ei, c, o, E);
+        tree_contacts<HF>(P, T, wsw, ei, c, o, E, R0);
         TT(1);
-        // base: rigid lump (randomised per env) + its own shapes (the group's first lane; the wrench goes round by shuffle)
+        // base: rigid lump (randomised per env); the terrain wrench on its own shapes was left in o.misc by the contact pass
         S3 Ab; V3 h0;
         rigid_inertia(R0, rot(R0, E.base_c), E.base_m, E.base_I, Ab, h0);
         V3 pa0, pl0;
         rigid_bias(R0, rot(R0, E.base_c), E.base_m, E.base_I, E.B.ang, E.B.vel, pa0, pl0);
-        {
-            V3 fa = v3(0.f, 0.f, 0.f), fl = v3(0.f, 0.f, 0.f);
-            if (lead)
-                for (int i = T.sph_begin0; i < T.sph_end0; ++i) {
-                    const TreeSph& S = T.sph[i];
-                    const V3 xr = rot(R0, v3(S.x, S.y, S.z));
-                    TerrainAt th; th.h = 0.f; th.gx = 0.f; th.gy = 0.f;
-                    if (E.B.pos.z + xr.z - S.r <= E.hmax) th.h = terrain_height<HF>(P, E.B.pos.x + xr.x, E.B.pos.y + xr.y, th.gx, th.gy);
-                    const V3 F = tree_sphere<HF>(P, S, E.B.ang, E.B.vel, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr, th);
-                    fa = fa + cross(xr, F); fl = fl + F;
-                }
-            pa0 = pa0 - grp_bcast(fa, lane, 0); pl0 = pl0 - grp_bcast(fl, lane, 0);
-        }
+        pa0 = pa0 + tw_v3(wsw, ei, o.misc + 8); pl0 = pl0 + tw_v3(wsw, ei, o.misc + 11);
         tree_fence();
         TT(2);
         if (P.self_collisions) tree_self_collision(P, T, wsw, ei, c, o, E, R0, pa0, pl0);
