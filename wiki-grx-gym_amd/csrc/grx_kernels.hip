@@ -424,6 +424,10 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
                      SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc, const LinkForceOut& lfo,
                      const RareBuf& RB, int lane, int el, int side, SelfNear& sn, bool first) {
     static_assert(SELF_BYTES <= RC_RES_BYTES, "the self-collision staging reuses the rare contacts' result table");
+#ifndef GRX_W1_FOLDC
+#define GRX_W1_FOLDC 1   // one- and two-wave layouts: the velocity-product accelerations folded into the bias forces (+1 % at >= 32768 envs, measured)
+#endif
+    constexpr bool kFoldC = GRX_W1_FOLDC != 0;
     const SelfBuf SB = self_carve(reinterpret_cast<char*>(RB.res));   // the rare contacts' result table is free again by then
     const float dt = P.sim_dt;
     R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
@@ -438,6 +442,7 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
     R3 Rp = R0;
     V3 rho_p = v3(0.f, 0.f, 0.f);
     V3 w = st.ang, v = st.vel;
+    V3 za = v3(0.f, 0.f, 0.f), zl = v3(0.f, 0.f, 0.f);
     out.foot_force = v3(0.f, 0.f, 0.f);
     out.term = false;
     out.pen_count = 0.f;
@@ -463,6 +468,13 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
         V3 ha = mul(A, wk) + cross(h, vk);
         V3 pa = cross(wk, ha) + cross(vk, hl);
         V3 pl = cross(wk, hl);
+        if (kFoldC) {   // velocity-product accelerations folded into the bias forces (grx_wavepipe.h, "eight waves"): with zeta_k = sum_{j <= k} c_j
+            // and a_k = a^_k + zeta_k the recursion in a^ has no c terms; body k's bias force gains I_k zeta_k (rigid inertia about O)
+            za = za + cross(w, a) * st.qd[k];
+            zl = zl + (cross(v, a) + cross(w, s)) * st.qd[k];
+            pa = pa + mul(A, za) + cross(h, zl);
+            pl = pl + zl * m - cross(h, za);
+        }
         // contacts of the shapes carried by chain body k (thigh_pitch: 2, shank: 2, foot: 4 anchored spheres)
         if (kSphCnt[k] > 0) {
             ChainKin K = {R, rho, wk, vk};
@@ -486,12 +498,17 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
     GRX_TICK2(16);
     // thigh / shank shapes (W == 1: and the base-lump shapes), compacted over the wave
     RareOut ro;
-    rare_contacts<HF, (W == 1 ? 0 : 8), RC_NS>(P, T, C, RB, lane, el, side, R0, O, st.ang, st.vel, K2, K3, LC.mu, LC.hmax, ro, nullptr, RareNoWait(), lfo.last);
+#ifdef GRX_PROFILE_SECTIONS
+    long long* const racc_ = tacc + 6; long long* const sacc_ = tacc + 14;   // (one-wave layout: the phases of the two compacted evaluations)
+#else
+    long long* const racc_ = nullptr; long long* const sacc_ = nullptr;
+#endif
+    rare_contacts<HF, (W == 1 ? 0 : 8), RC_NS>(P, T, C, RB, lane, el, side, R0, O, st.ang, st.vel, K2, K3, LC.mu, LC.hmax, ro, racc_, RareNoWait(), lfo.last);
     SelfOut sc;
     {   // self-collision: leg against leg, thigh against base-lump shapes
         const ChainKin KS[3] = {K2, K3, K4};
         if (first) sn = self_broad_phase(P, C, side, R0, KS);   // wave-uniform
-        self_collision(P, T, C, SB, lane, side, R0, st.ang, st.vel, KS, 2.0f * LC.mu - P.terrain_friction, sn, sc);
+        self_collision(P, T, C, SB, lane, side, R0, st.ang, st.vel, KS, 2.0f * LC.mu - P.terrain_friction, sn, sc, sacc_);
     }
     pA[2] = pA[2] - ro.fa2 - sc.fa[0]; pL[2] = pL[2] - ro.fl2 - sc.fl[0];
     pA[3] = pA[3] - ro.fa3 - sc.fa[1]; pL[3] = pL[3] - ro.fl3 - sc.fl[1];
@@ -512,9 +529,12 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
     for (int k = LEG - 1; k >= 0; --k) {
         V3 a = Sa[k], s = Ss[k];
         float qdk = st.qd[k];
-        w = fma3(a, -qdk, w); v = fma3(s, -qdk, v);  // parent velocity
-        V3 cak = cross(w, a) * qdk;
-        V3 clk = (cross(v, a) + cross(w, s)) * qdk;
+        V3 cak = v3(0.f, 0.f, 0.f), clk = cak;
+        if (!kFoldC) {
+            w = fma3(a, -qdk, w); v = fma3(s, -qdk, v);  // parent velocity
+            cak = cross(w, a) * qdk;
+            clk = (cross(v, a) + cross(w, s)) * qdk;
+        }
         V3 ua = mul(A, a) + mul(B, s);
         V3 ul = mulT(B, a) + mul(D, s);
         float d = dot(a, ua) + dot(s, ul);
@@ -526,8 +546,8 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
         float u = t - (dot(a, pa) + dot(s, pl));
         syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
         float ud = u * di;
-        V3 npa = pa + mul(A, cak) + mul(B, clk) + ua * ud;
-        V3 npl = pl + mulT(B, cak) + mul(D, clk) + ul * ud;
+        V3 npa = kFoldC ? fma3(ua, ud, pa) : pa + mul(A, cak) + mul(B, clk) + ua * ud;
+        V3 npl = kFoldC ? fma3(ul, ud, pl) : pl + mulT(B, cak) + mul(D, clk) + ul * ud;
         Ua[k] = ua; Ul[k] = ul; dinv[k] = di; uu[k] = u; ca[k] = cak; cl[k] = clk;
         pa = npa; pl = npl;
         if (k > 0) {  // add the parent's rigid inertia: [A B; B^T D] += rigid(k-1)
@@ -591,7 +611,7 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
     V3 aa = alpha, al = acc;
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
-        V3 pa_ = aa + ca[k], pl_ = al + cl[k];
+        V3 pa_ = kFoldC ? aa : aa + ca[k], pl_ = kFoldC ? al : al + cl[k];
         float qd2 = (uu[k] - (dot(Ua[k], pa_) + dot(Ul[k], pl_))) * dinv[k];
         qdd[k] = qd2;
         aa = fma3(Sa[k], qd2, pa_);
@@ -1424,7 +1444,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     } else {
 
 #ifdef GRX_PROFILE_SECTIONS
-    long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    long long tacc[22] = {};
 #else
     long long* tacc = nullptr;
 #endif
@@ -1582,6 +1602,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     GRX_TICK(2);
 #ifdef GRX_PROFILE_SECTIONS
     if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 16 + i] = tacc[i];
+    if (!PIPE && W == 1 && threadIdx.x == 0) for (int i = 0; i < 16; ++i) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 32 + i] = tacc[6 + i];
 #endif
     fk = foot_kinematics(C, st);  // refresh_rigid_body_state_tensor after the last sub-step
     avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
