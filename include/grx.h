@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 4
+#define GRX_ABI_VERSION 5
 
 #define GRX_MAX_BODIES 36   /* moving bodies after merging fixed joints (base + DOFs) */
 #define GRX_MAX_DOFS 32
@@ -53,6 +53,10 @@ extern "C" {
 #define GRX_NUM_CMD 3
 #define GRX_MAX_HEIGHT_POINTS 128
 #define GRX_STATS_HISTORY 128     /* policy steps of episode statistics kept in GRX_T_EPISODE_STATS_HISTORY */
+
+/* cfg.control.control_type (legged_robot.py:693-707): torques = p_gains (a s + q0 - q) - d_gains qd  |  p_gains (a s - qd) - d_gains (qd -
+   last_dof_vel) / sim_dt  |  a s   (a = clipped action, s = action_scale; then x motor strength, clipped to the torque limits) */
+typedef enum { GRX_CONTROL_P = 0, GRX_CONTROL_V = 1, GRX_CONTROL_T = 2 } grx_control_type;
 
 typedef enum grx_status {
     GRX_OK = 0,
@@ -268,6 +272,14 @@ typedef struct grx_config {
                                       reference counterpart; the parity tests read it).  Every other tensor is always current. */
     int32_t publish_rigid_body_states; /* 1: also write GRX_T_RIGID_BODY_STATES after the last sub-step of every step (the
                                       reference refreshes it every sub-step, legged_robot_fftai.py:76, and reads the last one) */
+
+    /* ABI 5: the reference's options that the GRx tasks leave off.  A handle with either of them set runs the general one-wave
+       (lower-limb robots) or tree / generic layout: the wave pipelines keep the registered tasks' code path. */
+    int32_t control_type;        /* grx_control_type: how _compute_torques reads the action (legged_robot.py:693-707) */
+    int32_t heading_command;     /* 1: commands[:, 2] = clip(0.5 wrap_to_pi(commands_heading - heading), ang_vel_yaw range) after every
+                                    time-based resample (legged_robot.py:320-326); the yaw command is then not drawn at resample
+                                    (legged_robot.py:668-676).  commands_heading is the reference's all-zero buffer (gr1t1.py:124: it is
+                                    never written; the draw of legged_robot.py:669 lands in commands[:, 3], which nothing reads) */
 } grx_config;
 
 typedef enum grx_tensor_id {

@@ -763,6 +763,36 @@ static real urand(const struct grx_sim* s, int le, uint32_t step, uint32_t strea
     return (hi - lo) * (real)u + lo; /* torch_rand_float: (upper-lower)*rand + lower (torch_utils.py:193-196) */
 }
 
+/* _compute_torques before the motor-strength ratio and the clip (legged_robot.py:693-707): a = the clipped action */
+static real control_torque(const grx_config* c, const env_t* e, int j, real a) {
+    const real as = a * c->action_scale;
+    if (c->control_type == GRX_CONTROL_V)
+        return c->kp[j] * (as - e->qd[j]) - c->kd[j] * (e->qd[j] - e->last_dof_vel[j]) / c->sim_dt;
+    if (c->control_type == GRX_CONTROL_T) return as;
+    return c->kp[j] * (as + c->default_dof_pos[j] - e->q[j]) - c->kd[j] * e->qd[j];
+}
+
+/* isaacgym torch_utils / legged_gym math.py:38-41 wrap_to_pi: angles %= 2 pi (Python: result in [0, 2 pi)); angles -= 2 pi (angles > pi) */
+static real wrap_to_pi(real x) {
+    const real tp = (real)(2.0 * 3.14159265358979323846);
+    real r = fmod(x, tp);
+    if (r < 0) r += tp;
+    if (r > (real)3.14159265358979323846) r -= tp;
+    return r;
+}
+
+/* legged_robot.py:320-326: the yaw command from the heading error, commands_heading = 0 (gr1t1.py:124: never written) */
+static void heading_rule(const grx_config* c, env_t* e) {
+    if (!c->heading_command) return;
+    const real fwd0[3] = {1, 0, 0};
+    real fwd[3];
+    quat_apply(e->quat, fwd0, fwd);
+    real y = (real)0.5 * wrap_to_pi((real)0 - atan2(fwd[1], fwd[0]));
+    if (y < c->cmd_ang_vel_yaw[0]) y = c->cmd_ang_vel_yaw[0];
+    if (y > c->cmd_ang_vel_yaw[1]) y = c->cmd_ang_vel_yaw[1];
+    e->commands[2] = y;
+}
+
 /* legged_robot.py:650-677 */
 static void resample_commands(const struct grx_sim* s, env_t* e, int le, uint32_t step, uint32_t stream) {
     const grx_config* c = &s->cfg;
@@ -772,7 +802,8 @@ static void resample_commands(const struct grx_sim* s, env_t* e, int le, uint32_
     real keep = n > (real)0.1 ? 1 : 0; /* set small commands to zero (legged_robot.py:666) */
     e->commands[0] *= keep;
     e->commands[1] *= keep;
-    e->commands[2] = urand(s, le, step, stream, 2, c->cmd_ang_vel_yaw[0], c->cmd_ang_vel_yaw[1]);
+    /* heading mode: the draw goes to commands[:, 3], which nothing reads (legged_robot.py:668-671; commands_heading stays 0) */
+    if (!c->heading_command) e->commands[2] = urand(s, le, step, stream, 2, c->cmd_ang_vel_yaw[0], c->cmd_ang_vel_yaw[1]);
 }
 
 static void env_origin_from_terrain(const struct grx_sim* s, env_t* e) {
@@ -1080,8 +1111,8 @@ static int step_env(struct grx_sim* s, int le, const grx_step_args* args, real s
     static __thread kin_t k;
     for (int deci = 0; deci < c->decimation; ++deci) {
         const real* act = ((real)deci < (real)args->delay_substeps) ? e->last_actions : e->actions;
-        for (int j = 0; j < nd; ++j) { /* _compute_torques legged_robot.py:679-715, control_type 'P' */
-            real t = c->kp[j] * (act[j] * c->action_scale + c->default_dof_pos[j] - e->q[j]) - c->kd[j] * e->qd[j];
+        for (int j = 0; j < nd; ++j) { /* _compute_torques legged_robot.py:679-715 */
+            real t = control_torque(c, e, j, act[j]);
             t *= e->motor_strength[j];
             real lim = m->dof_effort[j];
             if (t > lim) t = lim;
@@ -1115,6 +1146,7 @@ static int step_env(struct grx_sim* s, int le, const grx_step_args* args, real s
     quat_rotate_inverse(e->quat, g, e->proj_grav);
     if (c->resample_command_interval > 0 && e->episode_length % c->resample_command_interval == 0)
         resample_commands(s, e, le, step, GRO_RNG_CMD_TIME);
+    heading_rule(c, e);
     if (c->measure_heights) measure_heights(s, e);
     if (c->push_robots && c->push_interval > 0 && args->common_step_counter % c->push_interval == 0) {
         /* _push_robots legged_robot.py:786-797 */
@@ -1626,6 +1658,7 @@ int gro_debug_post_physics(grx_handle s, int le, const gro_pipeline_state* ps, i
     quat_rotate_inverse(e->quat, e->vel, e->base_lin_vel);
     quat_rotate_inverse(e->quat, e->ang, e->base_ang_vel);
     quat_rotate_inverse(e->quat, g, e->proj_grav);
+    heading_rule(c, e);   /* (the time-based resample itself is left out here: its draws are not the reference's) */
     int nh = c->measure_heights ? c->num_height_points : 0;
     if (c->measure_heights) {
         if (c->terrain_type == GRX_TERRAIN_PLANE) for (int k = 0; k < nh; ++k) e->heights[k] = ps->heights[k];
@@ -1694,7 +1727,7 @@ int gro_debug_torques(grx_handle s, const float* actions, float* clipped, float*
             if (a < c->clip_actions_min[j]) a = c->clip_actions_min[j];
             if (a > c->clip_actions_max[j]) a = c->clip_actions_max[j];
             clipped[(size_t)i * s->nd + j] = (float)a;
-            real t = c->kp[j] * (a * c->action_scale + c->default_dof_pos[j] - e->q[j]) - c->kd[j] * e->qd[j];
+            real t = control_torque(c, e, j, a);
             t *= e->motor_strength[j];
             real lim = c->model.dof_effort[j];
             if (t > lim) t = lim;

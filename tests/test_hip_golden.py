@@ -196,3 +196,43 @@ def test_reference_torques_on_the_hip_kernel():
     np.testing.assert_allclose(sim.tensor("TORQUES").cpu().numpy(), d["torques"], rtol=1e-4, atol=1e-3)
     lim = d["torque_limits"]
     assert (np.abs(d["torques"]) >= lim - 1e-6).any() and (np.abs(d["torques"]) < lim - 1).any()   # saturated and unsaturated rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ct", ["P", "V", "T"])
+def test_control_types_on_the_hip_kernel(ct):
+    """cfg.control.control_type 'P' / 'V' / 'T' (legged_robot.py:693-707; tests/golden/control_modes.npz holds the reference's own
+    _compute_torques for each) on the HIP step kernel: decimation = 1 makes GRX_T_TORQUES the first (only) sub-step's torque; the
+    fixture's last_dof_vel and motor-strength draws go into the writable LAST_DOF_VEL / MOTOR_STRENGTH views.  'V' and 'T' handles run
+    the general one-wave layout (include/grx.h, ABI 5)."""
+    d = np.load(og.os.path.join(og.G, "control_modes.npz"))
+    N = d["actions"].shape[0]
+    cfg = make_cfg(noise=False, dr=False)
+    cfg.control.decimation = 1
+    cfg.control.control_type = ct
+    sim, _ = make_hip(cfg, N)
+    lay = sim.layout()
+    assert ct == "P" or (lay["kernel"].startswith("grx_step_kernel<") and lay["waves_per_block"] == 1), lay
+    sim.reset_all()
+    root = torch.zeros(N, 13); root[:, 2] = 5.0; root[:, 6] = 1.0          # in the air: no contact in the way
+    sim.set_state(root.cuda(), torch.tensor(d["dof_pos"]).cuda().contiguous(), torch.tensor(d["dof_vel"]).cuda().contiguous())
+    sim.tensor("MOTOR_STRENGTH").copy_(torch.tensor(d["strength"]).cuda())
+    sim.tensor("LAST_DOF_VEL").copy_(torch.tensor(d["last_dof_vel"]).cuda())
+    sim.step(torch.tensor(d["actions"]).cuda().contiguous(), 0.0, 1)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(sim.tensor("ACTIONS").cpu().numpy(), d["clipped"])
+    # (the velocity law divides a velocity difference by sim_dt: fp32 keeps ~1e-7 x 0.4 x 500 x d_gain of it)
+    np.testing.assert_allclose(sim.tensor("TORQUES").cpu().numpy(), d["torques_" + ct], rtol=1e-4, atol=5e-3 if ct == "V" else 1e-3)
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_heading_command_on_the_hip_kernel():
+    """legged_robot.py:320-326 through the HIP kernel's post-physics half (grx_debug_post_physics): the reference's commands[:, 2]."""
+    cfg = make_cfg(noise=True, dr=False)
+    cfg.commands.heading_command = True
+    sim, _ = make_hip(cfg, 64)
+    lay = sim.layout()
+    assert lay["kernel"].startswith("grx_step_kernel<") and lay["waves_per_block"] == 1, lay
+    og.check_heading_command(sim, 1e-4)
+    sim.close()

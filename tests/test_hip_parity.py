@@ -672,3 +672,37 @@ def test_avg_feet_speed_rpy(waves, monkeypatch):
     a = hip.tensor("AVG_FEET_SPEED_RPY").cpu()
     assert a.shape == (256, 2, 3) and float(a.mean()) > 0.05 and torch.isfinite(a).all()
     hip.close()
+
+
+@pytest.mark.parametrize("ct,heading", [("V", False), ("T", False), ("P", True), ("V", True)])
+def test_control_types_and_heading_command_against_the_oracle(ct, heading):
+    """The reference options the GRx tasks leave off (legged_robot.py:693-707, 320-326) through physics: HIP vs oracle, one policy step at a
+    time from identical state, rough terrain, DR on.  Such handles run the one-wave layout (grx_capi.cpp)."""
+    cfg = make_cfg(terrain="heightfield", dr=True)
+    cfg.control.control_type = ct
+    cfg.commands.heading_command = heading
+    cfg.commands.resampling_command_interval_s = 0.1   # the time-based resample (which must leave the yaw command alone in heading mode) every 5 steps
+    hip, ora = make_sims(cfg, 256, seed=5)
+    assert hip.layout()["waves_per_block"] == 1 and hip.layout()["lanes_per_env"] == 2, hip.layout()
+    hip.reset_all(); ora.reset_all()
+    seen = {"contact": 0}
+
+    def check(s, h, o):
+        seen["contact"] += int(o.tensor("FEET_CONTACT").sum())
+        if heading:   # commands[:, 2] is the heading rule's value on both sides, inside the yaw range
+            c = h.tensor("COMMANDS").cpu()
+            assert (c[:, 2] - o.tensor("COMMANDS")[:, 2]).abs().max() < (5e-3 if ct == "V" else 1e-4)
+            assert c[:, 2].abs().max() <= max(abs(v) for v in cfg.commands.ranges.ang_vel_yaw) + 1e-6
+    # 'T': the action IS the torque (action_scale 1): scale it to what the legs can take.
+    # 'V': d_gains (qd - last_dof_vel) / sim_dt is a velocity servo of gain 500 d_gain applied explicitly at 500 Hz -- beyond the explicit
+    # stability limit of the leg links: the joints chatter between their effort limits within a policy step and rounding decides.  The law
+    # is compared over the first policy step from the reset pose (the reference's own torques: tests/test_hip_golden.py).
+    steps = 1 if ct == "V" else 30
+    worst = physics_lockstep(hip, ora, cfg, steps=steps, scale=(20.0 if ct == "T" else (0.05 if ct == "V" else 0.5)), check=check)
+    assert ct == "V" or seen["contact"] > 500, seen
+    if heading:   # the yaw command is a float computation in this mode (atan2): compared above at 1e-4, not bit for bit
+        assert worst["COMMANDS"][0] < (5e-3 if ct == "V" else 1e-4)
+        worst["COMMANDS"] = (worst["COMMANDS"][0], 0.0)
+        assert hip.tensor("COMMANDS")[:, 2].abs().max() > 0.05
+    assert_phys(worst, scale=(8.0 if ct == "V" else 2.6), hf=True)
+    hip.close()

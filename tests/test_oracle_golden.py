@@ -312,3 +312,81 @@ def test_quat_fixture_reset_yaw_and_wrap():
     v = d["v"].astype(np.float64)
     np.testing.assert_allclose(np.stack([c * v[:, 0] - s_ * v[:, 1], s_ * v[:, 0] + c * v[:, 1], v[:, 2]], 1), d["apply_yaw"], atol=2e-5)
     np.testing.assert_allclose(np.mod(d["ang"].astype(np.float64) + np.pi, 2 * np.pi) - np.pi, d["wrap_to_pi"], atol=2e-5)
+
+
+# ---- the reference options the GRx tasks leave off (tests/golden/control_modes.npz, tools/gen_golden.py gen_control_modes) ---------
+def control_torque_formula(d, ct, scale=1.0):
+    """legged_robot.py:693-707 on the fixture's inputs (before the motor-strength ratio and the clip)."""
+    from wiki_grx_gym_amd.envs.config import GR1T1LowerLimbCfg  # noqa: F401
+    t = np.load(os.path.join(G, "torques.npz"))
+    kp, kd, q0 = t["p_gains"].astype(np.float64), t["d_gains"].astype(np.float64), t["default_dof_pos"].astype(np.float64)
+    a, q, qd, qdl = (d[k].astype(np.float64) for k in ("clipped", "dof_pos", "dof_vel", "last_dof_vel"))
+    if ct == "P":
+        return kp * (a * scale + q0 - q) - kd * qd
+    if ct == "V":
+        return kp * (a * scale - qd) - kd * (qd - qdl) / 0.002
+    return a * scale
+
+
+def check_heading_command(sim, tol):
+    """legged_robot.py:320-326 through one injected post_physics_step: commands[:, 2] of EVERY env is the clipped half heading error
+    against commands_heading = 0; the yaw command is not drawn at the time-based resample (legged_robot.py:668-676)."""
+    d = np.load(os.path.join(G, "control_modes.npz"))
+    N = d["h_in_root"].shape[0]
+    inject(sim, states_from(d, "h_in_", N), common_step_counter=1, noise_uniform=torch.tensor(d["h_noise_u"]).contiguous())
+    got = T_(sim, "COMMANDS").numpy()
+    want = d["h_out_commands"]
+    np.testing.assert_allclose(got[:, 2], want[:, 2], rtol=tol, atol=tol)
+    np.testing.assert_allclose(T_(sim, "OBS").numpy()[:, 2], d["h_out_obs"][:, 2], rtol=tol, atol=tol)
+    lo, hi = d["h_yaw_range"]
+    assert (want[:, 2] == lo).any() and (want[:, 2] == hi).any() and ((want[:, 2] > lo) & (want[:, 2] < hi)).sum() > N // 4   # clipped and free rows
+    assert np.abs(want[:, 2] - d["h_in_commands"][:, 2]).max() > 0.1                                                          # the rule did overwrite the command
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-6), ("f32", 1e-4)])
+@pytest.mark.parametrize("ct", ["P", "V", "T"])
+def test_control_types_match_the_reference(ct, precision, tol):
+    """cfg.control.control_type 'P' / 'V' / 'T' (legged_robot.py:693-707) in the oracle against the reference's own _compute_torques."""
+    from oracle.binding import OracleSim, PipelineState
+    d = np.load(os.path.join(G, "control_modes.npz"))
+    N = d["actions"].shape[0]
+    cfg = make_cfg(noise=False, dr=False)
+    cfg.control.control_type = ct
+    c, keep, meta = build_config.build(cfg, cfg.sim.dt, N)
+    sim = OracleSim(c, precision, keep)
+    # last_dof_vel: post_physics_step leaves last_dof_vel = dof_vel (legged_robot.py:300) -- inject records whose dof_vel is the fixture's last_dof_vel
+    arr = (PipelineState * N)()
+    for i in range(N):
+        arr[i].root[2] = 1.0; arr[i].root[6] = 1.0
+        for k in range(9):
+            arr[i].torso_R[k] = 1.0 if k % 4 == 0 else 0.0
+        for j in range(10):
+            arr[i].qd[j] = float(d["last_dof_vel"][i][j])
+    inject(sim, arr)
+    sim.set_state(None, torch.tensor(d["dof_pos"]).contiguous(), torch.tensor(d["dof_vel"]).contiguous())
+    clipped, tq = sim.torques(d["actions"])
+    np.testing.assert_allclose(clipped, d["clipped"], rtol=tol, atol=tol)
+    base = control_torque_formula(d, ct, cfg.control.action_scale)
+    lim = d["torque_limits"]
+    # (the velocity law divides a difference of two velocities by sim_dt: fp32 keeps ~1e-7 x 20 x 500 of it)
+    np.testing.assert_allclose(tq, np.clip(base, -lim, lim), rtol=tol, atol=tol * (100 if ct == "V" else 10))
+    # ... and the reference's own torques are that formula times its strength factors
+    np.testing.assert_allclose(d["torques_" + ct], np.clip(base * d["strength"], -lim, lim), rtol=1e-5, atol=2e-3 if ct == "V" else 1e-4)
+    sat = np.abs(d["torques_" + ct]) >= lim - 1e-6
+    assert ct == "T" or (sat.any() and (~sat).any())
+
+
+def test_unknown_control_type_raises_like_the_reference():
+    cfg = make_cfg(noise=False, dr=False)
+    cfg.control.control_type = "X"
+    with pytest.raises(NameError):   # legged_robot.py:707
+        build_config.build(cfg, cfg.sim.dt, 4)
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 2e-6), ("f32", 1e-4)])
+def test_heading_command_matches_the_reference(precision, tol):
+    from oracle.binding import OracleSim
+    cfg = make_cfg(noise=True, dr=False)
+    cfg.commands.heading_command = True
+    c, keep, meta = build_config.build(cfg, cfg.sim.dt, 64)
+    check_heading_command(OracleSim(c, precision, keep), tol)

@@ -217,6 +217,51 @@ def gen_torques(out):
              clip_min=np.asarray(env.cfg.normalization.clip_actions_min), clip_max=np.asarray(env.cfg.normalization.clip_actions_max))
 
 
+def gen_control_modes(out):
+    """The reference options the GRx tasks leave off (missing #4): _compute_torques with control_type 'V' and 'T'
+    (legged_robot.py:699-704) on the G-2 inputs plus a last_dof_vel, and the heading command (legged_robot.py:320-326) through one
+    post_physics_step() with cfg.commands.heading_command = True (num_commands = 4, as that mode needs)."""
+    env, g, body_names = make_ref_env(64, 13)
+    env.dof_pos[:] = env.default_dof_pos + (torch.rand(64, 10, generator=g) - 0.5)
+    env.dof_vel[:] = (torch.rand(64, 10, generator=g) - 0.5) * 0.8
+    env.last_dof_vel = env.dof_vel + (torch.rand(64, 10, generator=g) - 0.5) * 0.03   # (a velocity difference through d_gains / sim_dt: small, or every row saturates)
+    env.motor_strength_scales = 0.9 + 0.2 * torch.rand(64, 10, generator=g)
+    a = (torch.rand(64, 10, generator=g) - 0.5) * 1.2
+    a[::7] *= 5                                            # some rows beyond the action clip
+    clipped = env.clip_actions(a)
+    data = dict(dof_pos=env.dof_pos.numpy().copy(), dof_vel=env.dof_vel.numpy().copy(), last_dof_vel=env.last_dof_vel.numpy().copy(),
+                strength=env.motor_strength_scales.numpy(), actions=a.numpy(), clipped=clipped.numpy(), torque_limits=env.torque_limits.numpy())
+    for ct in ("P", "V", "T"):
+        env.cfg.control.control_type = ct
+        data["torques_" + ct] = env._compute_torques(clipped.clone()).numpy().copy()
+    env.cfg.control.control_type = "P"
+    # heading command
+    N = 64
+    env, g, body_names = make_ref_env(N, 17)
+    env.cfg.domain_rand.push_robots = False
+    randomize_state(env, g, body_names, N, 0)
+    env.cfg.commands.heading_command = True
+    env.cfg.commands.num_commands = 4
+    env.commands = torch.cat([env.commands, torch.zeros(N, 1)], 1)
+    inp = snapshot_inputs(env)
+    env.reset_idx = lambda ids: None
+    noise_u = torch.rand(N, 39, generator=g)
+    orig_rand_like = torch.rand_like
+    torch.rand_like = lambda t, _u=noise_u: _u.clone()
+    try:
+        env.post_physics_step()
+    finally:
+        torch.rand_like = orig_rand_like
+    for k, v in inp.items():
+        data["h_in_" + k] = v
+    data["h_in_commands"] = inp["commands"][:, :3] if inp["commands"].shape[1] > 3 else inp["commands"]
+    data["h_out_commands"] = env.commands.numpy().copy()
+    data["h_out_obs"] = torch.clip(env.obs_buf, -100, 100).numpy().copy()
+    data["h_noise_u"] = noise_u.numpy()
+    data["h_yaw_range"] = np.asarray(env.command_ranges["ang_vel_yaw"], dtype=np.float32)
+    np.savez(os.path.join(out, "control_modes.npz"), **data)
+
+
 def randomize_state(env, g, body_names, N, step):
     """Synthetic post-physics state incl. edge rows (thresholds, timers at zero, near limits)."""
     feet = env.feet_indices
@@ -465,6 +510,7 @@ def main():
     install_stub()
     gen_quat(OUT)
     gen_torques(OUT)
+    gen_control_modes(OUT)
     gen_pipeline(OUT)
     gen_reward_terms(OUT)
     gen_terrain_and_heights(OUT)

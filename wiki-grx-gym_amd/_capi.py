@@ -5,7 +5,8 @@ Field order and sizes must match the header exactly; ``grx_create`` rejects a mi
 """
 import ctypes as C
 
-GRX_ABI_VERSION = 4
+GRX_ABI_VERSION = 5
+CONTROL_TYPES = {"P": 0, "V": 1, "T": 2}   # grx_control_type (legged_robot.py:693-707)
 MAX_BODIES = 36
 MAX_DOFS = 32
 MAX_SPHERES = 48
@@ -140,6 +141,7 @@ class Config(C.Structure):
         ("terrain_length", f32), ("env_spacing", f32),
         ("publish_reward_terms", i32),
         ("publish_rigid_body_states", i32),
+        ("control_type", i32), ("heading_command", i32),
     ]
 
 

@@ -699,6 +699,9 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
         s->quad = !generic && s->waves >= 4 && qblocks <= prop.multiProcessorCount && !getenv("GRX_WAVES_PER_BLOCK");
         if (const char* q = getenv("GRX_LANES_PER_ENV")) s->quad = !generic && atoi(q) == 4;   // tests / A-B runs: 2 or 4
         if (s->quad) { s->waves = 8; if (const char* w = getenv("GRX_QUAD_WAVES")) s->waves = atoi(w) == 4 ? 4 : 8; }   // eight waves (two per SIMD) unless a test asks for the four-role pipeline
+        // control_type 'V' / 'T' and heading_command (ABI 5; off in every registered task) live in the general one-wave layout only:
+        // the wave pipelines keep the registered tasks' code path
+        if (c.control_type != GRX_CONTROL_P || c.heading_command) { s->quad = false; s->waves = 1; }
     }
     const char* dbg = getenv("GRX_PUBLISH_DEBUG");   // (tools/: overrides the config either way)
     P.publish_debug = dbg ? atoi(dbg) : c.publish_reward_terms;
@@ -706,6 +709,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     P.sim_dt = c.sim_dt; P.decimation = c.decimation;
     for (int i = 0; i < 3; ++i) { P.gravity[i] = c.gravity[i]; P.init_pos[i] = c.init_pos[i]; }
     P.action_scale = c.action_scale;
+    P.control_type = c.control_type; P.heading_command = c.heading_command;
     P.kn = c.contact.kn; P.dn = c.contact.dn; P.kt = c.contact.kt; P.ct = c.contact.ct; P.cv = c.contact.cv;
     P.terrain_friction = c.contact.terrain_friction;
     P.inv_kt = 1.0f / c.contact.kt;

@@ -151,6 +151,7 @@ struct KParams {
     uint64_t seed;
     float sim_dt; int32_t decimation; float gravity[3];
     float action_scale;
+    int32_t control_type, heading_command;   // grx_control_type; legged_robot.py:320-326 (one-wave / tree / generic layouts only)
     float kn, dn, kt, ct, cv, terrain_friction, inv_kt;
     float termination_force, termination_gravity_z;
     float max_episode_length, max_episode_length_s;

@@ -458,7 +458,7 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
         const bool use_last = (float)deci < delay;
         for (int j = 0; j < nd; ++j) {   // _compute_torques legged_robot.py:679-715
             const float a = use_last ? a_last[(size_t)j * N] : a_cur[(size_t)j * N];
-            float t = T.kp[j] * (a * P.action_scale + T.q0[j] - q[(size_t)j * N]) - T.kd[j] * qd[(size_t)j * N];
+            float t = control_torque(P, T.kp[j], T.kd[j], T.q0[j], a, q[(size_t)j * N], qd[(size_t)j * N], P.last_dof_vel + (size_t)j * N + e);
             t *= strength[(size_t)j * N];
             tau[(size_t)j * N] = fminf(fmaxf(t, -T.effort[j]), T.effort[j]);
         }
@@ -520,6 +520,7 @@ __global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict
     const V3 pg = quat_rotate_inverse(qv, B.qw, v3(0.f, 0.f, -1.f));
     if (P.resample_command_interval > 0 && ((uint32_t)ep_len % (uint32_t)P.resample_command_interval) == 0)
         resample_commands(P, genv, step, GRX_RNG_CMD_TIME, ea.cmd);
+    if (P.heading_command) ea.cmd[2] = heading_yaw_command(P, qv, B.qw);   // legged_robot.py:320-326
     float* heights = P.heights + e;   // raw measured heights (always materialised here: the reward / obs code reads them back)
     float hsum = 0.f;
     if (HF && P.measure_heights) {

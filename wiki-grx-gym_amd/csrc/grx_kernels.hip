@@ -721,6 +721,13 @@ GRX_DEV float urand(KP P, uint32_t genv, uint32_t step, uint32_t stream, uint32_
     return (hi - lo) * grx_rand(P.seed, genv, step, stream, i) + lo;
 }
 
+// _compute_torques before the motor-strength ratio and the clip (legged_robot.py:693-707), any control type: the tree / generic kernels
+// (the fused kernels spell the 'P' law out in their sub-step loop; 'V' and 'T' run in the one-wave layout only)
+GRX_DEV float control_torque(KP P, float kp, float kd, float q0, float a, float q, float qd, const float* qd_last) {
+    if (P.control_type == GRX_CONTROL_T) return a * P.action_scale;
+    if (P.control_type == GRX_CONTROL_V) return kp * (a * P.action_scale - qd) - kd * (qd - *qd_last) / P.sim_dt;
+    return kp * (a * P.action_scale + q0 - q) - kd * qd;
+}
 // legged_robot.py:650-677
 GRX_DEV void resample_commands(KP P, uint32_t genv, uint32_t step, uint32_t stream, float cmd[3]) {
     float c0 = urand(P, genv, step, stream, 0, P.cmd_lin_vel_x[0], P.cmd_lin_vel_x[1]);
@@ -728,7 +735,17 @@ GRX_DEV void resample_commands(KP P, uint32_t genv, uint32_t step, uint32_t stre
     float keep = sqrtf(c0 * c0 + c1 * c1) > 0.1f ? 1.0f : 0.0f;
     cmd[0] = c0 * keep;
     cmd[1] = c1 * keep;
-    cmd[2] = urand(P, genv, step, stream, 2, P.cmd_ang_vel_yaw[0], P.cmd_ang_vel_yaw[1]);
+    // heading mode: the reference's draw goes to commands[:, 3], which nothing reads (legged_robot.py:668-671)
+    if (!P.heading_command) cmd[2] = urand(P, genv, step, stream, 2, P.cmd_ang_vel_yaw[0], P.cmd_ang_vel_yaw[1]);
+}
+// legged_robot.py:320-326: the yaw command from the heading error; commands_heading is the reference's all-zero buffer (gr1t1.py:124)
+GRX_DEV float heading_yaw_command(KP P, V3 qv, float qw) {
+    const V3 fwd = quat_apply(qv, qw, v3(1.f, 0.f, 0.f));
+    const float tp = 6.283185307179586f;
+    float r = fmodf(0.f - atan2f(fwd.y, fwd.x), tp);   // wrap_to_pi (math.py:38-41): Python's %, then -2 pi above pi
+    if (r < 0.f) r += tp;
+    if (r > 3.14159265358979f) r -= tp;
+    return fminf(fmaxf(0.5f * r, P.cmd_ang_vel_yaw[0]), P.cmd_ang_vel_yaw[1]);
 }
 
 struct EnvAux {  // per-env (replicated in both lanes) pipeline state touched by reset
@@ -813,7 +830,7 @@ GRX_DEV void reset_env(KP P, const SideConst& C, int side, uint32_t genv, uint32
         const float keep = sqrtf(c0 * c0 + c1 * c1) > 0.1f ? 1.0f : 0.0f;
         ea.cmd[0] = c0 * keep;
         ea.cmd[1] = c1 * keep;
-        ea.cmd[2] = lerp_u(rr.cmd[2], P.cmd_ang_vel_yaw[0], P.cmd_ang_vel_yaw[1]);
+        if (!P.heading_command) ea.cmd[2] = lerp_u(rr.cmd[2], P.cmd_ang_vel_yaw[0], P.cmd_ang_vel_yaw[1]);
     }
     st.anchor_on = 0;
 }
@@ -1187,7 +1204,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     static_assert(OBS_BYTES % 16 == 0 && PRI_BYTES % 16 == 0 && RC_BYTES % 16 == 0, "arena pieces must stay 16-byte aligned");
     constexpr int FOOTFR_BYTES = RC_FR4 * 64 * 16, ANCH_BYTES = 16 * 64 * 4;   // (s_anch: anchors x 4, y 4, mask 1, approach speeds 4, foot |w| sums 3)
     constexpr int TAIL_BYTES = PIPE ? PHYS_BYTES + FOOTFR_BYTES + ANCH_BYTES : PHYS_BYTES;
+#ifdef GRX_FAKE_ARENA   // compile-only experiments on the register budget at two waves per SIMD (the result does not run)
+    __shared__ __attribute__((aligned(16))) char s_arena[GRX_FAKE_ARENA];
+#else
     __shared__ __attribute__((aligned(16))) char s_arena[POST_BYTES > TAIL_BYTES ? POST_BYTES : TAIL_BYTES];
+#endif
     float* const s_obs = reinterpret_cast<float*>(s_arena);
     float* const s_pri = reinterpret_cast<float*>(s_arena + OBS_BYTES);
     float* const s_rw = reinterpret_cast<float*>(s_arena + OBS_BYTES + PRI_BYTES);   // reward inputs (wave 0 -> waves 1, 3), PIPE
@@ -1556,6 +1577,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         for (int k = 0; k < LEG; ++k) {  // _compute_torques legged_robot.py:679-715
             float a = use_last ? a_last[k] : a_cur[k];
             float t = C.body[k].kp * (a * P.action_scale + C.body[k].q0 - st.q[k]) - C.body[k].kd * st.qd[k];
+            if (!PIPE && P.control_type != GRX_CONTROL_P)   // 'V' / 'T' (legged_robot.py:699-704): the one-wave layout only (grx_capi.cpp)
+                t = P.control_type == GRX_CONTROL_T ? a * P.action_scale
+                                                    : C.body[k].kp * (a * P.action_scale - st.qd[k]) - C.body[k].kd * (st.qd[k] - qd_last[k]) / P.sim_dt;
             t *= LC.strength[k];
             torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
         }
@@ -1645,6 +1669,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     V3 pg = quat_rotate_inverse(qv, st.qw, v3(0.f, 0.f, -1.f));
     if (P.resample_command_interval > 0 && ((uint32_t)ep_len % (uint32_t)P.resample_command_interval) == 0)   // ep_len <= max_episode_length + 1
         resample_commands(P, genv, step, GRX_RNG_CMD_TIME, ea.cmd);
+    if (!PIPE && P.heading_command) ea.cmd[2] = heading_yaw_command(P, v3(st.qx, st.qy, st.qz), st.qw);
     // measured heights: this lane samples points k = 2*i + side; raw heights parked in the pri_obs staging row
     float* prow = s_pri + el * PRS;
     float hsum = 0.f;

@@ -156,7 +156,8 @@ struct TreeRegs {
 // all: nothing to keep per level, no I^A c products in pass 2, no additions in pass 3.  A body with chains hanging from it leaves
 // its zeta in their hand-over slots (free until pass 2).
 template <bool KIN>
-GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0, bool use_last, int first, int last, TreeRegs& G) {
+GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0, bool use_last, int first, int last, TreeRegs& G,
+                          const float* qd_last_e = nullptr) {   // qd_last_e: P.last_dof_vel + e (read by control type 'V' only)
     R3 Rc = R0;
     V3 rho_c = v3(0.f, 0.f, 0.f), w_c = E.B.ang, v_c = E.B.vel;
     V3 za = v3(0.f, 0.f, 0.f), zl = v3(0.f, 0.f, 0.f);
@@ -185,7 +186,7 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
                 const TreeDof& td = T.dof[j];
                 {   // _compute_torques (legged_robot.py:679-715)
                     const float act_ = TW(o.dof + (use_last ? TD_ALAST : TD_ACUR) * GRX_MAX_DOFS + j);
-                    float t = td.kp * (act_ * P.action_scale + td.q0 - qj) - td.kd * qdj;
+                    float t = control_torque(P, td.kp, td.kd, td.q0, act_, qj, qdj, qd_last_e + (size_t)j * (size_t)P.N);
                     t *= TW(o.dof + TD_STR * GRX_MAX_DOFS + j);   // motor strength of this env (domain randomisation)
                     TW(wb + T_TAU) = fminf(fmaxf(t, -td.effort), td.effort);
                 }
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         if (c < 6) TW(o.misc + 8 + c) = 0.f;
         tree_fence();
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
-        tree_outward<false>(P, T, wsw, ei, c, o, E, R0, (float)deci < delay, first, last, G);
+        tree_outward<false>(P, T, wsw, ei, c, o, E, R0, (float)deci < delay, first, last, G, P.last_dof_vel + e);
         TT(0);
         tree_contacts<HF>(P, T, wsw, ei, c, o, E, R0);
         TT(1);
@@ -679,6 +680,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     const V3 pg = quat_rotate_inverse(qv, B.qw, v3(0.f, 0.f, -1.f));
     if (P.resample_command_interval > 0 && ((uint32_t)ep_len % (uint32_t)P.resample_command_interval) == 0)
         resample_commands(P, genv, step, GRX_RNG_CMD_TIME, ea.cmd);
+    if (P.heading_command) ea.cmd[2] = heading_yaw_command(P, qv, B.qw);   // legged_robot.py:320-326
     float* heights = P.heights + e;   // raw measured heights: the scan's points go round the group's lanes
     float hsum = 0.f;
     if (HF && P.measure_heights) {

@@ -58,8 +58,9 @@ def build(cfg, sim_dt, num_envs, env_offset=0, total_envs=None, seed=1, terrain=
     c.sim_dt = float(sim_dt)
     c.decimation = int(cfg.control.decimation)
     _set(c.gravity, cfg.sim.gravity)
-    if cfg.control.control_type != "P":
-        raise ValueError("only control_type 'P' is implemented (the GRx tasks use P, legged_robot_config.py:159)")
+    if cfg.control.control_type not in _capi.CONTROL_TYPES:
+        raise NameError(f"Unknown controller type: {cfg.control.control_type}")   # (the reference's own error, legged_robot.py:707)
+    c.control_type = _capi.CONTROL_TYPES[cfg.control.control_type]
     kp, kd, q0 = resolve_gains(cfg, rm.dof_names)
     _set(c.kp, kp); _set(c.kd, kd); _set(c.default_dof_pos, q0)
     c.action_scale = float(cfg.control.action_scale)
@@ -71,8 +72,7 @@ def build(cfg, sim_dt, num_envs, env_offset=0, total_envs=None, seed=1, terrain=
     c.resample_command_interval = int(cfg.commands.resampling_command_interval_s / dt)
     r = cfg.commands.ranges
     _set(c.cmd_lin_vel_x, r.lin_vel_x); _set(c.cmd_lin_vel_y, r.lin_vel_y); _set(c.cmd_ang_vel_yaw, r.ang_vel_yaw)
-    if cfg.commands.heading_command:
-        raise ValueError("heading_command=True is not implemented (GRx tasks set it False, gr1t1_config.py:151)")
+    c.heading_command = int(bool(cfg.commands.heading_command))   # legged_robot.py:320-326 (GRx tasks: False, gr1t1_config.py:151)
     _set(c.init_pos, cfg.init_state.pos); _set(c.init_rot, cfg.init_state.rot)
     _set(c.init_lin_vel, cfg.init_state.lin_vel); _set(c.init_ang_vel, cfg.init_state.ang_vel)
     dr = cfg.domain_rand
