@@ -640,6 +640,184 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
     st.qx = nx * n; st.qy = ny * n; st.qz = nz * n; st.qw = nw * n;
     GRX_TICK2(21);
 }
+
+// rigid inertia of a body about O in world axes: A (rotational 3x3) and h = m kap  (= grx_wavepipe.h rigid_inertia, which is declared further down)
+GRX_DEV void rigid_inertia_lean(const R3& R, V3 kap, float m, const S3& Ic, S3& A, V3& h) {
+    A = rot_sym(R, Ic);
+    const float kk = dot(kap, kap);
+    A.xx += m * (kk - kap.x * kap.x); A.xy -= m * kap.x * kap.y; A.xz -= m * kap.x * kap.z;
+    A.yy += m * (kk - kap.y * kap.y); A.yz -= m * kap.y * kap.z; A.zz += m * (kk - kap.z * kap.z);
+    h = kap * m;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same sub-step, REGISTER-LEAN (round 4; the one-wave layout at two waves per SIMD, GRX_W1_DUO): substep() keeps ~105 values of
+// its outward pass (motion subspaces, rigid inertias, bias forces of five bodies) and the three contact frames live across the two
+// wave-cooperative contact evaluations -- 360 spilled dwords when the kernel is held to 256 registers.  Here the contacts come
+// FIRST, on a walk that keeps nothing but the three frames; the inward pass then starts from the LEAF frame and recomputes every
+// body's frame, velocity and accumulated velocity-product acceleration going DOWN the chain (R_{k-1} = R_k Rot(-q_k), rho_{k-1} =
+// rho_k - R_{k-1} r_k, w_{k-1} = w_k - a_k qd_k, zeta_{k-1} = zeta_k - c_k), forming the rigid inertia and the bias force of a body
+// where they are consumed: per joint only S, U = I^A S, 1/d and u survive for the acceleration pass.  ~45 instructions more per
+// joint, a third of the live values.  Same physics; results agree with substep() to rounding (the recomputed frames differ in the
+// last bit).
+// EXPERIMENT, compiled only with -DGRX_W1_LEAN (profiles/r04_experiments_session3.md): at the one-wave kernel's 512-register budget it
+// needs 448 registers and no scratch (substep(): 512 + 8-15 spilled dwords) and runs 1.7 % SLOWER (190.3 against 193.5 M env-steps/s
+// at 32768 envs: the extra instructions); held to 256 registers (-DGRX_WPE=2 with a small arena, compile only) the kernel around it
+// still spills 224 dwords (substep(): 360) -- the post-physics state carried across the sub-step loop and the contact evaluations'
+// own temporaries are the next ~150.  Two waves per SIMD at > 16384 envs per GPU need that AND 20 KB of LDS per wave (37 KB now):
+// not reached this round.
+template <bool HF>
+GRX_DEV void substep_lean(KP P, const KTables& T, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
+                          SubstepOut& out, FootKin& fk_before, const LinkForceOut& lfo,
+                          const RareBuf& RB, int lane, int el, int side, SelfNear& sn, bool first) {
+    const SelfBuf SB = self_carve(reinterpret_cast<char*>(RB.res));   // the rare contacts' result table is free again by then
+    const float dt = P.sim_dt;
+    const R3 R0 = quat_to_R(st.qx, st.qy, st.qz, st.qw);
+    const V3 O = st.pos;
+    const V3 zero = v3(0.f, 0.f, 0.f);
+    // ---- walk 1 (root -> leaf): frames with velocities of the three shape-carrying bodies; zeta of the leaf
+    float cs[LEG], sn_[LEG];
+    V3 za = zero, zl = zero;
+    R3 R = R0;
+    V3 rho = zero, w = st.ang, v = st.vel;
+    V3 ca2, cl2, ca3, cl3, ca4, cl4, c0a, c0l;   // contact wrenches about O on thigh, shank, foot and on the base lump
+    {
+        ChainKin K2, K3;
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) {
+            rho = rho + rot(R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+            grx_sincos(st.q[k], sn_[k], cs[k]);
+            R = joint_rot_k(R, cs[k], sn_[k], kAxis[k]);
+            const V3 a = axis_k(R, kAxis[k]);
+            const V3 s = cross(rho, a);
+            const float qdk = st.qd[k];
+            za = za + cross(w, a) * qdk;
+            zl = zl + (cross(v, a) + cross(w, s)) * qdk;
+            w = fma3(a, qdk, w); v = fma3(s, qdk, v);
+            if (k == 2) K2 = ChainKin{R, rho, w, v};
+            if (k == 3) K3 = ChainKin{R, rho, w, v};
+        }
+        const ChainKin K4 = {R, rho, w, v};
+        {   // foot link frame BEFORE this sub-step's integration
+            const V3 fr = rho + rot(R, v3(C.foot_pos[0], C.foot_pos[1], C.foot_pos[2]));
+            fk_before.pos = O + fr;
+            fk_before.vel = v + cross(w, fr);
+            fk_before.ang = w;
+        }
+        foot_contacts<HF>(P, C, K4, O, LC.mu, LC.hmax, st, ca4, cl4, LC.om_e);
+        const V3 foot_terrain = cl4;
+        RareOut ro;
+        rare_contacts<HF, 0, RC_NS>(P, T, C, RB, lane, el, side, R0, O, st.ang, st.vel, K2, K3, LC.mu, LC.hmax, ro, nullptr, RareNoWait(), lfo.last);
+        SelfOut sc;
+        {
+            const ChainKin KS[3] = {K2, K3, K4};
+            if (first) sn = self_broad_phase(P, C, side, R0, KS);   // wave-uniform
+            self_collision(P, T, C, SB, lane, side, R0, st.ang, st.vel, KS, 2.0f * LC.mu - P.terrain_friction, sn, sc);
+        }
+        out.term = ro.term; out.pen_count = ro.pen_count;
+        out.foot_force = cl4 + sc.fl[2];   // net contact force on the foot link: terrain + self-collision
+        write_link_rows(P, lfo, C, ro.lf, ro.fl2, ro.fl3, foot_terrain, sc, out.term, out.pen_count);   // (last sub-step: the flags from the NET link forces)
+        ca2 = ro.fa2 + sc.fa[0]; cl2 = ro.fl2 + sc.fl[0];
+        ca3 = ro.fa3 + sc.fa[1]; cl3 = ro.fl3 + sc.fl[1];
+        ca4 = ca4 + sc.fa[2]; cl4 = cl4 + sc.fl[2];
+        c0a = ro.f0a + sc.f0a; c0l = ro.f0l + sc.f0l;
+    }
+    // ---- inward pass from the leaf frame: frames recomputed downwards, rigid inertia + bias force formed where consumed
+    S3 A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    M3 B = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    V3 pa = zero, pl = zero;
+    V3 Sa[LEG], Ss[LEG], Ua[LEG], Ul[LEG];
+    float dinv[LEG], uu[LEG];
+#pragma unroll
+    for (int k = LEG - 1; k >= 0; --k) {
+        const V3 a = axis_k(R, kAxis[k]);
+        const V3 s = cross(rho, a);
+        const float m = C.body[k].mass;
+        {
+            const V3 kap = rho + rot(R, v3(C.body[k].com[0], C.body[k].com[1], C.body[k].com[2]));
+            const S3 Ic = {C.body[k].Ic[0], C.body[k].Ic[1], C.body[k].Ic[2], C.body[k].Ic[3], C.body[k].Ic[4], C.body[k].Ic[5]};
+            S3 Ak; V3 h;
+            rigid_inertia_lean(R, kap, m, Ic, Ak, h);
+            const V3 hl = fma3(v, m, cross(w, h));
+            const V3 ha = mul(Ak, w) + cross(h, v);
+            V3 bpa = cross(w, ha) + cross(v, hl) + mul(Ak, za) + cross(h, zl);   // velocity-product bias + I_k zeta_k (substep(): kFoldC)
+            V3 bpl = cross(w, hl) + zl * m - cross(h, za);
+            if (k == 2) { bpa = bpa - ca2; bpl = bpl - cl2; }
+            if (k == 3) { bpa = bpa - ca3; bpl = bpl - cl3; }
+            if (k == 4) { bpa = bpa - ca4; bpl = bpl - cl4; }
+            A = A + Ak;
+            B.a01 -= h.z; B.a02 += h.y; B.a10 += h.z; B.a12 -= h.x; B.a20 -= h.y; B.a21 += h.x;
+            D.xx += m; D.yy += m; D.zz += m;
+            pa = pa + bpa; pl = pl + bpl;
+        }
+        const V3 ua = mul(A, a) + mul(B, s);
+        const V3 ul = mulT(B, a) + mul(D, s);
+        const float di = grx_rcp(dot(a, ua) + dot(s, ul));
+        const float qk = st.q[k], qdk = st.qd[k], qlo = C.body[k].qlo, qhi = C.body[k].qhi;
+        const float viol = qk < qlo ? qlo - qk : (qk > qhi ? qhi - qk : 0.f);
+        const float t = tau_m[k] + (C.body[k].Klim * viol - (viol != 0.f ? C.body[k].Clim * qdk : 0.f));   // joint-limit spring/damper on top of the motor torque
+        const float u = t - (dot(a, pa) + dot(s, pl));
+        syr(A, ua, di); ger(B, ua, ul, di); syr(D, ul, di);
+        const float ud = u * di;
+        pa = fma3(ua, ud, pa); pl = fma3(ul, ud, pl);
+        Sa[k] = a; Ss[k] = s; Ua[k] = ua; Ul[k] = ul; dinv[k] = di; uu[k] = u;
+        if (k > 0) {   // down to the parent's frame
+            w = fma3(a, -qdk, w); v = fma3(s, -qdk, v);
+            za = za - cross(w, a) * qdk;
+            zl = zl - (cross(v, a) + cross(w, s)) * qdk;
+            R = joint_rot_k(R, cs[k], -sn_[k], kAxis[k]);
+            rho = rho - rot(R, v3(C.body[k].r[0], C.body[k].r[1], C.body[k].r[2]));
+        }
+    }
+    // ---- base: both chains (DPP pair exchange), the base lump, the 6 x 6
+    pa = pa - c0a; pl = pl - c0l;
+    A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
+    pa = pair_sum(pa); pl = pair_sum(pl);
+    {
+        const V3 kap = rot(R0, LC.base_c);
+        const float m = LC.base_m;
+        S3 A0; V3 h;
+        rigid_inertia_lean(R0, kap, m, LC.base_I, A0, h);
+        const V3 w0 = st.ang, v0 = st.vel;
+        const V3 hl = fma3(v0, m, cross(w0, h));
+        const V3 ha = mul(A0, w0) + cross(h, v0);
+        pa = pa + cross(w0, ha) + cross(v0, hl);
+        pl = pl + cross(w0, hl);
+        A = A + A0;
+        B.a01 -= h.z; B.a02 += h.y; B.a10 += h.z; B.a12 -= h.x; B.a20 -= h.y; B.a21 += h.x;
+        D.xx += m; D.yy += m; D.zz += m;
+    }
+    const S3 Di = inv(D);
+    const V3 b0 = v3(B.a00, B.a01, B.a02), b1 = v3(B.a10, B.a11, B.a12), b2 = v3(B.a20, B.a21, B.a22);
+    const V3 d0 = mul(Di, b0), d1 = mul(Di, b1), d2 = mul(Di, b2);
+    const S3 Sc = {A.xx - dot(b0, d0), A.xy - dot(b0, d1), A.xz - dot(b0, d2), A.yy - dot(b1, d1), A.yz - dot(b1, d2), A.zz - dot(b2, d2)};
+    const V3 alpha = mul(inv(Sc), mul(B, mul(Di, pl)) - pa);
+    const V3 acc = neg(mul(Di, pl + mulT(B, alpha)));
+    // ---- accelerations (root -> leaf), integration (semi-implicit Euler)
+    V3 aa = alpha, al = acc;
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) {
+        const float qd2 = (uu[k] - (dot(Ua[k], aa) + dot(Ul[k], al))) * dinv[k];
+        aa = fma3(Sa[k], qd2, aa);
+        al = fma3(Ss[k], qd2, al);
+        float vq = fmaf(qd2, dt, st.qd[k]);
+        vq = fminf(fmaxf(vq, -C.body[k].vlim), C.body[k].vlim);
+        st.qd[k] = vq;
+        st.q[k] = fmaf(vq, dt, st.q[k]);
+    }
+    const V3 lin = acc + cross(st.ang, st.vel);  // classical acceleration of the base origin
+    st.vel = v3(st.vel.x + (lin.x + P.gravity[0]) * dt, st.vel.y + (lin.y + P.gravity[1]) * dt, st.vel.z + (lin.z + P.gravity[2]) * dt);
+    st.ang = fma3(alpha, dt, st.ang);
+    st.pos = fma3(st.vel, dt, st.pos);
+    const float hx = 0.5f * dt * st.ang.x, hy = 0.5f * dt * st.ang.y, hz = 0.5f * dt * st.ang.z;
+    const float x = st.qx, y = st.qy, z = st.qz, ww = st.qw;
+    const float nx = x + hx * ww + hy * z - hz * y;
+    const float ny = y - hx * z + hy * ww + hz * x;
+    const float nz = z + hx * y - hy * x + hz * ww;
+    const float nw = ww - hx * x - hy * y - hz * z;
+    const float n = grx_rsq(nx * nx + ny * ny + nz * nz + nw * nw);
+    st.qx = nx * n; st.qy = ny * n; st.qz = nz * n; st.qw = nw * n;
+}
 #include "grx_wavepipe.h"
 
 // kinematics only: this lane's foot link frame in the current state
@@ -1585,6 +1763,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         }
         if (PIPE && LPL == 2) substep_q<HF, W == 8>(P, Cr, LC, st, torque, so, fk, L, lane, deci, tacc, C);
         else if (PIPE) substep_p<HF, W == 8>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc, C);
+#ifdef GRX_W1_LEAN
+        else if (W == 1) substep_lean<HF>(P, s_tab, C, LC, st, torque, so, fk,
+                                          LinkForceOut{deci == P.decimation - 1, act0 ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side, self_near, deci == 0);
+#endif
         else substep<HF, W>(P, s_tab, C, LC, st, torque, so, fk, s_wr + lane, tacc,
                             LinkForceOut{deci == P.decimation - 1, act0 ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side, self_near, deci == 0);
         if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
