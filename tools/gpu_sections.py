@@ -43,6 +43,8 @@ for terrain in ("plane","heightfield"):
     print('   wave 3, last sub-step, relative to wave 0 at the barrier: rare out, inputs of the link rows in, link rows written:', np.median(full[:,88:91]-full[:,80:81],axis=0).astype(int).tolist())
     if os.environ.get("GRX_QUAD_WAVES") == "8":
         print('   eight waves: w4 bias out, w6 rigid inertias out, w6 bias out, w5 factorisation out, w5 got X Y:', np.median(full[:,74:79]-full[:,48:49],axis=0).astype(int).tolist())
+    if os.environ.get("GRX_LANES_PER_ENV") == "2" and os.environ.get("GRX_WAVES_PER_BLOCK") == "8":
+        print('   lane pairs, eight waves: w0 reaches the wait for wave 5\'s rigid inertias, w0 has them:', np.median(full[:,91:93]-full[:,48:49],axis=0).astype(int).tolist())
     print('   wave 0: duration of each of the 10 sub-steps:', np.median(full[:, 64:74], axis=0).astype(int).tolist())
     print('   obs sub-sections (cycles after tick 7): heights, noise load, side-0 puts:', np.median(full[:,11:14]-full[:,7:8],axis=0).astype(int).tolist())
     print('   relative to tick 6 (FL_REW published): wave1 got FL_REW, wave1 rewards done, wave2 got FL_HZ, wave2 heights done, wave0 tick 9:', np.median(full[:,[14,15,30,31,9]]-full[:,6:7],axis=0).astype(int).tolist())

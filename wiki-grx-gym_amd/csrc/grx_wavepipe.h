@@ -189,7 +189,22 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
         if (W8 && GRX_P8_XK && k < 2) {
+#ifndef GRX_P8_PINXK
+#define GRX_P8_PINXK 1   // joints 4, 3, 2 of the inertia half stay IN FRONT of the wait for wave 5's rigid inertias (the compiler sinks register
+                         // arithmetic across the spin: without the pins this wave idled at the flag and ran all five joints behind it)
+#endif
+            if (k == 1 && GRX_P8_PINXK) {
+                GRX_PIN(A.xx); GRX_PIN(A.xy); GRX_PIN(A.xz); GRX_PIN(A.yy); GRX_PIN(A.yz); GRX_PIN(A.zz);
+                GRX_PIN(B.a00); GRX_PIN(B.a01); GRX_PIN(B.a02); GRX_PIN(B.a10); GRX_PIN(B.a11); GRX_PIN(B.a12); GRX_PIN(B.a20); GRX_PIN(B.a21); GRX_PIN(B.a22);
+                GRX_PIN(D.xx); GRX_PIN(D.xy); GRX_PIN(D.xz); GRX_PIN(D.yy); GRX_PIN(D.yz); GRX_PIN(D.zz);
+            }
+#ifdef GRX_PROFILE_SECTIONS
+            if (k == 1 && seq == 5 && lane == 0) { __builtin_amdgcn_sched_barrier(0); P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 91] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+#endif
             if (k == 1) GRX_WAIT(L.flag + FL_XK, seq * 4 + 3, 4);
+#ifdef GRX_PROFILE_SECTIONS
+            if (k == 1 && seq == 5 && lane == 0) { __builtin_amdgcn_sched_barrier(0); P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 92] = clock64(); __builtin_amdgcn_sched_barrier(0); }
+#endif
             const float4* c = L.xk + (k * 3) * 64 + lane;
             const float4 a0 = c[0 * 64], a1 = c[1 * 64], a2 = c[2 * 64];
             AK[k].xx = a0.x; AK[k].xy = a0.y; AK[k].xz = a0.z; AK[k].yy = a0.w; AK[k].yz = a1.x; AK[k].zz = a1.y;
