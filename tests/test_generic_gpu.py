@@ -10,12 +10,13 @@ from tests.helpers import lockstep, make_cfg, make_sims, random_actions, tensor_
 from tests.test_hip_parity import assert_phys, physics_lockstep
 
 pytestmark = pytest.mark.gpu
-KERNELS = pytest.mark.parametrize("kernel", ["tree", "generic"])
+KERNELS = pytest.mark.parametrize("kernel", ["tree", "tree16", "generic"])   # tree: 8 lanes per env (grx_tree.h), tree16: 16 (grx_tree16.hip)
 FULL_BODY_SCALE = 1.3   # x the lower-limb budgets of tests/test_hip_parity.PHYS: 1.5 x the 0.85 round 4 observed on MI355X with the joint armature (round 3: 5.0, maxima unbounded)
 
 
 def pick(monkeypatch, kernel):
-    monkeypatch.setenv("GRX_TREE", "1" if kernel == "tree" else "0")
+    monkeypatch.setenv("GRX_TREE", "0" if kernel == "generic" else "1")
+    monkeypatch.setenv("GRX_TREE_G", "16" if kernel == "tree16" else "8")   # (the library's own choice: 16 while N x 16 lanes fit the SIMDs in one round)
 
 
 @KERNELS
@@ -86,7 +87,8 @@ def test_full_body_rough_terrain_against_the_oracle(kernel, monkeypatch):
     cfg = make_cfg("GR1T1Full", noise=True, dr=True, push=True, terrain="heightfield")
     cfg.domain_rand.push_interval_s = 0.3
     hip, ora = make_sims(cfg, 320, seed=1)
-    assert hip.layout()["kernel"].startswith("grx_step_tree<true" if kernel == "tree" else "grx_step_generic<true")
+    assert hip.layout()["kernel"].startswith({"tree": "grx_step_tree<true", "tree16": "grx_step_tree16<true", "generic": "grx_step_generic<true"}[kernel])
+    assert hip.layout()["lanes_per_env"] == {"tree": 8, "tree16": 16, "generic": 1}[kernel]
     assert torch.equal(hip.tensor("TERRAIN_TYPES").cpu(), ora.tensor("TERRAIN_TYPES"))
     hip.reset_all(); ora.reset_all()
     seen = {"contact": 0, "reset": 0}
@@ -148,7 +150,7 @@ def test_tree_and_generic_kernels_agree_on_the_full_body(monkeypatch):
     cfg = make_cfg("GR1T1Full", noise=True, dr=True, push=True, terrain="heightfield")
     N = 200                                   # (not a multiple of the tree kernel's 16-env block)
     outs = []
-    for kernel in ("tree", "generic"):
+    for kernel in ("tree", "tree16", "generic"):
         pick(monkeypatch, kernel)
         hip, _ = make_sims(cfg, N, seed=1)
         hip.reset_all()
@@ -157,22 +159,23 @@ def test_tree_and_generic_kernels_agree_on_the_full_body(monkeypatch):
             hip.step(random_actions(cfg, N, gen, 0.6).cuda(), 5.0, i + 1)
         outs.append({k: hip.tensor(k).clone() for k in ("OBS", "PRI_OBS", "REW", "RESET", "DOF_POS", "DOF_VEL", "ROOT_STATES", "CONTACT_FORCES", "TORQUES", "EPISODE_SUMS")})
         hip.close()
-    a, b = outs
-    same = (a["DOF_POS"] - b["DOF_POS"]).abs().amax(1) < 1e-3          # (an env whose contact switched differently drifts: bounded fraction)
-    assert same.float().mean() > 0.95
-    assert (a["RESET"] != b["RESET"]).float().mean() < 0.02
-    for k in ("REW", "OBS", "PRI_OBS"):
-        d = (a[k][same] - b[k][same]).abs()
-        assert float((d > 2e-2).float().mean()) < 0.01, k
+    for a, b in ((outs[0], outs[2]), (outs[1], outs[2]), (outs[0], outs[1])):   # tree vs generic, tree16 vs generic, tree vs tree16
+        same = (a["DOF_POS"] - b["DOF_POS"]).abs().amax(1) < 1e-3          # (an env whose contact switched differently drifts: bounded fraction)
+        assert same.float().mean() > 0.95
+        assert (a["RESET"] != b["RESET"]).float().mean() < 0.02
+        for k in ("REW", "OBS", "PRI_OBS"):
+            d = (a[k][same] - b[k][same]).abs()
+            assert float((d > 2e-2).float().mean()) < 0.01, k
 
 
-def test_full_body_rigid_body_states_are_the_forward_kinematics_of_the_state(monkeypatch):
+@pytest.mark.parametrize("kernel", ["tree", "tree16"])
+def test_full_body_rigid_body_states_are_the_forward_kinematics_of_the_state(kernel, monkeypatch):
     """GRX_T_RIGID_BODY_STATES of the 37-link full body, written by the tree kernel after its last sub-step: the link frames of
     the state it publishes (tests/kinematics_ref.py, envs that did not reset) and the oracle's."""
     from tests.kinematics_ref import BodyKinematics
     from tests.test_kinematics import rbs_err
     from wiki_grx_gym_amd.model import RobotModel
-    pick(monkeypatch, "tree")
+    pick(monkeypatch, kernel)
     cfg = make_cfg("GR1T1Full", dr=True)
     hip, ora = make_sims(cfg, 96)
     hip.reset_all(); ora.reset_all()
@@ -209,3 +212,19 @@ def test_full_body_control_types_and_heading_against_the_oracle(kernel, ct, monk
     worst["COMMANDS"] = (worst["COMMANDS"][0], 0.0)
     assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE * (4.0 if ct == "V" else 1.0))
     hip.close()
+
+
+def test_the_library_picks_sixteen_lanes_while_they_fit_the_simds(monkeypatch):
+    """grx_capi.cpp: the 16-lane group (four envs per wave: twice the waves of the 8-lane kernel) while N x 16 lanes still get a SIMD per
+    wave -- BASELINE.json config 5's 4096 envs per GPU on an MI355X --, the 8-lane group beyond."""
+    monkeypatch.delenv("GRX_TREE_G", raising=False)
+    monkeypatch.setenv("GRX_TREE", "1")
+    cfg = make_cfg("GR1T1Full", terrain="heightfield")
+    for N, lanes in ((4096, 16), (4352, 8)):
+        hip, _ = make_sims(cfg, N)
+        lay = hip.layout()
+        assert lay["lanes_per_env"] == lanes and lay["kernel"].startswith("grx_step_tree16<" if lanes == 16 else "grx_step_tree<"), (N, lay)
+        hip.reset_all()
+        hip.step(torch.zeros(N, 32, device="cuda"), 5.0, 1)
+        assert torch.isfinite(hip.tensor("OBS")).all()
+        hip.close()

@@ -25,16 +25,17 @@ pytestmark = pytest.mark.gpu
 # base-lump wave and the height block from the helper waves.
 # "tree": the lower-limb model forced through the tree kernel (GRX_FORCE_GENERIC) -- the post-physics code BASELINE.json's config 5 runs
 # (csrc/grx_tree.h; the reference registers no full-body task, so its fixtures reach that code through the 10-dof robot).
-LAYOUTS = pytest.mark.parametrize("layout", [1, 4, 8, "quad4", "quad", "tree"])
+LAYOUTS = pytest.mark.parametrize("layout", [1, 4, 8, "quad4", "quad", "tree", "tree16"])
 KERNEL_OF = {1: ("grx_step_kernel<", 2, 1), 4: ("grx_step_kernel<", 2, 4), 8: ("grx_step_kernel<", 2, 8),
-             "quad4": ("grx_step_kernel_quad<", 4, 4), "quad": ("grx_step_kernel_quad<", 4, 8), "tree": ("grx_step_tree<", 8, 2)}
+             "quad4": ("grx_step_kernel_quad<", 4, 4), "quad": ("grx_step_kernel_quad<", 4, 8), "tree": ("grx_step_tree<", 8, 2), "tree16": ("grx_step_tree16<", 16, 2)}
 
 
 def pick_layout(monkeypatch, layout):
     from tests.test_hip_parity import set_layout
-    if layout == "tree":
+    if layout in ("tree", "tree16"):
         monkeypatch.setenv("GRX_FORCE_GENERIC", "1")
         monkeypatch.setenv("GRX_TREE", "1")
+        monkeypatch.setenv("GRX_TREE_G", "16" if layout == "tree16" else "8")
     else:
         monkeypatch.delenv("GRX_FORCE_GENERIC", raising=False)
         set_layout(monkeypatch, layout)

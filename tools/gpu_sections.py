@@ -6,7 +6,7 @@ flags="-I../../include --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-hip-fp32-
 os.makedirs(csrc + "/variants", exist_ok=True)
 PROF = os.path.abspath(csrc + "/variants/libgrx_prof.so")
 if "--build" in sys.argv or not os.path.exists(PROF):   # hipcc cross-compiles in the build container; the .so travels with gpurun
-    subprocess.run(f"cd {csrc} && hipcc {flags} -shared -o variants/libgrx_prof.so grx_kernels.hip grx_quad.hip grx_capi.cpp 2>/dev/null", shell=True, check=True)
+    subprocess.run(f"cd {csrc} && hipcc {flags} -shared -o variants/libgrx_prof.so grx_kernels.hip grx_quad.hip grx_tree16.hip grx_capi.cpp 2>/dev/null", shell=True, check=True)
     if "--build" in sys.argv:
         sys.exit(0)
 PROF = os.path.abspath(os.environ.get("GRX_PROF_LIB", PROF))

@@ -68,15 +68,18 @@ for name in ("fetch", "write"):
     fs = glob.glob(f"{src}/fb_pmc_{name}/**/*counter_collection.csv", recursive=True)
     if not fs:
         continue
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(fs[0])) if "grx_step_tree" in r["Kernel_Name"]]
+    rows_ = [r for r in csv.DictReader(open(fs[0])) if "grx_step_tree" in r["Kernel_Name"]]
+    vals = [float(r["Counter_Value"]) for r in rows_]
+    if rows_:   # the kernel that ran (grx_step_tree<...> with 8 lanes per env, grx_step_tree16<...> with 16): bench.py matches it against grx_layout
+        fb_kernel = rows_[0]["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     if vals:
         fbo[name.upper() + "_SIZE"] = {"launches": len(vals), "mean_KB": sum(vals) / len(vals), "min_KB": min(vals), "max_KB": max(vals)}
 if fbo:
-    fbo["kernel"] = "grx_step_tree<true>"
+    fbo["kernel"] = fb_kernel
     fbo["algorithmic_bytes_per_launch"] = (3422.0 + 726.0) * 4096
     fbo["note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `python bench.py --robot full_body --envs-per-gpu 4096 --steps 200`; KB per launch of grx_step_tree; same gfx950 caveats as the lower-limb file"
     json.dump(fbo, open(f"{dst}/{tag}_pmc_hbm_full_body_rough4096.json", "w"), indent=1)
-fsq = {"kernel": "grx_step_tree<true>", "workload": "python bench.py --robot full_body --envs-per-gpu 4096 --steps 200 --warmup 20 --no-cpu-baseline; rocprofv3 --pmc, one pass per counter group, mean per launch"}
+fsq = {"kernel": fb_kernel if "fb_kernel" in dir() else "grx_step_tree<true>", "workload": "python bench.py --robot full_body --envs-per-gpu 4096 --steps 200 --warmup 20 --no-cpu-baseline; rocprofv3 --pmc, one pass per counter group, mean per launch"}
 for f in sorted(glob.glob(f"{src}/fb_pmc_sq*/**/*counter_collection.csv", recursive=True)):
     agg = {}
     for r in csv.DictReader(open(f)):

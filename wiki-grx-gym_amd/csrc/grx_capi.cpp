@@ -36,6 +36,13 @@ int grx_launch_step_tree(const KParams* dP, const void* tree_tab, const void* ge
 int grx_launch_step_tree_debug(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions,
                                long long common_step, const float* noise, const float* dbg, const StepSeq* sq, hipStream_t stream);
 int grx_generic_ws_floats_per_env(int nb, int nlc);
+// csrc/grx_tree16.hip: the tree kernel with a 16-lane group per env (four envs per wave)
+int grx_tree_lds_bytes16(int nb, int nlc, int nchain, int waves);
+int grx_tree_envs_per_wave16(void);
+int grx_launch_step_tree16(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions, float delay,
+                           long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream);
+int grx_launch_step_tree_debug16(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions,
+                                 long long common_step, const float* noise, const float* dbg, const StepSeq* sq, hipStream_t stream);
 void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, const StepSeq* sq, uint8_t* mask, hipStream_t stream);
 void grx_launch_mark(const int32_t* env_ids, int n, int N, uint8_t* mask, hipStream_t stream);
 void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, const int32_t* env_ids, int n, hipStream_t stream);
@@ -104,6 +111,7 @@ struct grx_sim {
     void* d_gen = nullptr; // GenTables (device)
     void* d_tree = nullptr; // TreeTab (device): the lane-group tree kernel (grx_tree.h) runs this model
     int tree_lds = 0;      // its dynamic LDS
+    int tree_g = GRX_TREE_G;   // lanes per env of the tree kernel this handle launches: 8, or 16 (grx_tree16.hip) while 16-lane groups still fit the SIMDs in one round
     int tree_waves = 2;    // 8-env waves per block of the tree kernel: 2 while those blocks fit the CUs in one round, else 4 (a whole CU's LDS)
     float* d_ws = nullptr; // generic workspace
     int64_t seq = 0;       // launches of this handle that write statistics rows (steps, resets, debug steps; recorded ones too)
@@ -538,6 +546,16 @@ int build_generic(grx_sim* s, const grx_config& c) {
     std::vector<TreeTab> tt(1);
     TreeTab& K = tt[0];
     memset(&K, 0, sizeof K);
+    // lanes per env: 8 (eight envs per wave), or 16 (four envs per wave: the passes are bound by the tree's depth levels whatever the group
+    // size, but twice the waves) while those waves still have a SIMD each -- 4096 envs on an MI355X, BASELINE.json config 5's per-GPU size
+    int G = GRX_TREE_G;
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+        if ((long long)s->N * GRX_TREE_GMAX <= 64ll * 4 * prop.multiProcessorCount) G = GRX_TREE_GMAX;
+        if (const char* g_ = getenv("GRX_TREE_G")) { const int v = atoi(g_); if (v == GRX_TREE_G || v == GRX_TREE_GMAX) G = v; }
+    }
+    K.g = G; s->tree_g = G;
     K.nb = T.nb; K.nd = T.nd; K.nsph = T.nsph; K.nlc = T.nlc;
     memset(K.sched, 0xff, sizeof K.sched);
     std::vector<int> depth(T.nb, -1), lane_of(T.nb, -1), cont(T.nb, 0);
@@ -565,7 +583,7 @@ int build_generic(grx_sim* s, const grx_config& c) {
     }
     if (!fits) return GRX_OK;   // more chains / levels than a lane group holds: the one-lane generic kernel runs it
     K.nchain = nchain; K.nstep = nstep;
-    for (int c = 0; c < GRX_TREE_G; ++c) {
+    for (int c = 0; c < GRX_TREE_GMAX; ++c) {
         K.first[c] = 1; K.last[c] = 0;
         bool any = false;
         for (int g = 0; g < nstep; ++g) if (K.sched[c][g] >= 0) { if (!any) K.first[c] = g; K.last[c] = g; any = true; }
@@ -596,13 +614,13 @@ int build_generic(grx_sim* s, const grx_config& c) {
             for (int i = n0; i < n1; i += 2) items.push_back({b, i, std::min(i + 2, n1), 0});
         }
         if (T.foot_body[0] < 1 || T.foot_body[1] < 1) return GRX_OK;   // (feet on the base: not this kernel's layout)
-        const int rounds = ((int)items.size() + GRX_TREE_G - 1) / GRX_TREE_G;
+        const int rounds = ((int)items.size() + G - 1) / G;
         if (rounds > GRX_TREE_MAXCS) return GRX_OK;   // (the generic kernel runs it)
         memset(K.cw, 0xff, sizeof K.cw);
         K.ncs = rounds; K.nturn = 1;
         for (int r = 0; r < rounds; ++r)
-            for (int ln = 0; ln < GRX_TREE_G; ++ln) {
-                const size_t k = (size_t)r * GRX_TREE_G + ln;
+            for (int ln = 0; ln < G; ++ln) {
+                const size_t k = (size_t)r * G + ln;
                 if (k >= items.size()) continue;
                 Item it = items[k];
                 for (int l2 = 0; l2 < ln; ++l2) if (K.cw[r][l2].body == it.body) it.turn = std::max(it.turn, K.cw[r][l2].turn + 1);
@@ -621,12 +639,13 @@ int build_generic(grx_sim* s, const grx_config& c) {
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-        const int epw = grx_tree_envs_per_wave();
+        const int epw = G == GRX_TREE_GMAX ? grx_tree_envs_per_wave16() : grx_tree_envs_per_wave();
         s->tree_waves = (s->N + 2 * epw - 1) / (2 * epw) <= prop.multiProcessorCount ? 2 : 4;
         if (const char* tw_ = getenv("GRX_TREE_WAVES")) { const int v = atoi(tw_); if (v == 1 || v == 2 || v == 4) s->tree_waves = v; }
     }
-    int lds = grx_tree_lds_bytes(T.nb, T.nlc, nchain, s->tree_waves);
-    while (lds > 160 * 1024 - 512 && s->tree_waves > 1) { s->tree_waves /= 2; lds = grx_tree_lds_bytes(T.nb, T.nlc, nchain, s->tree_waves); }
+    auto lds_of = [&](int waves) { return G == GRX_TREE_GMAX ? grx_tree_lds_bytes16(T.nb, T.nlc, nchain, waves) : grx_tree_lds_bytes(T.nb, T.nlc, nchain, waves); };
+    int lds = lds_of(s->tree_waves);
+    while (lds > 160 * 1024 - 512 && s->tree_waves > 1) { s->tree_waves /= 2; lds = lds_of(s->tree_waves); }
     if (lds > 160 * 1024 - 512) return GRX_OK;   // the workspace of one wave does not fit a CU's LDS
     TreeTab* dk = nullptr;
     rc = dalloc(s, &dk, 1);
@@ -1168,7 +1187,7 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
     if (s->generic)
     {
         if (s->d_tree) {
-            if (grx_launch_step_tree(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_waves, s->tree_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
+            if ((s->tree_g == GRX_TREE_GMAX ? grx_launch_step_tree16 : grx_launch_step_tree)(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_waves, s->tree_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
                                      (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st))
                 return fail(GRX_ERR_HIP, "grx_step: cannot raise the dynamic LDS limit of the tree kernel");
         } else if (grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->gen_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions,
@@ -1254,8 +1273,8 @@ int grx_layout(grx_handle s, grx_layout_info* out) {
     memset(out, 0, sizeof *out);
     const char* hf = s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD ? "true" : "false";
     if (s->generic && s->d_tree) {
-        out->lanes_per_env = GRX_TREE_G; out->waves_per_block = s->tree_waves; out->envs_per_block = grx_tree_envs_per_wave() * s->tree_waves;
-        snprintf(out->kernel, sizeof out->kernel, "grx_step_tree<%s, false>", hf);
+        out->lanes_per_env = s->tree_g; out->waves_per_block = s->tree_waves; out->envs_per_block = (s->tree_g == GRX_TREE_GMAX ? grx_tree_envs_per_wave16() : grx_tree_envs_per_wave()) * s->tree_waves;
+        snprintf(out->kernel, sizeof out->kernel, s->tree_g == GRX_TREE_GMAX ? "grx_step_tree16<%s, false>" : "grx_step_tree<%s, false>", hf);
     } else if (s->generic) {
         out->lanes_per_env = 1; out->waves_per_block = 1; out->envs_per_block = s->gen_epb;
         snprintf(out->kernel, sizeof out->kernel, "grx_step_generic<%s>", hf);
@@ -1346,7 +1365,7 @@ int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply
     const StepSeq sq = next_seq(s, st, false);
     // the post-physics half of the kernel this handle steps with (lane pairs: 1 / 4 / 8 waves; lane quads: 4 / 8; GRX_FORCE_GENERIC: the tree kernel)
     if (s->generic) {
-        if (grx_launch_step_tree_debug(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_waves, s->tree_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->d_dbg_actions,
+        if ((s->tree_g == GRX_TREE_GMAX ? grx_launch_step_tree_debug16 : grx_launch_step_tree_debug)(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_waves, s->tree_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->d_dbg_actions,
                                        (long long)a->common_step_counter, a->noise_uniform, s->d_dbg, &sq, st))
             return fail(GRX_ERR_HIP, "grx_debug_post_physics: cannot raise the dynamic LDS limit of the tree kernel");
     } else if (s->quad) grx_launch_step_debug_quad(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, s->d_dbg_actions,

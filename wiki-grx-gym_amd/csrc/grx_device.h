@@ -85,7 +85,9 @@ struct RbsTables {
 // ---- tree kernel (grx_tree.h): any robot tree whose chains fit a lane group -- the 32-DOF full body of BASELINE.json config 5 ----
 // An env is a GROUP of GRX_TREE_G lanes; every lane owns one CHAIN of the tree (a path: a body's first child continues its
 // chain, further children start new ones) and at global step g works on its chain's body of depth g.
-#define GRX_TREE_G 8
+#define GRX_TREE_G 8        // lanes per env of the default build of grx_tree.h
+#define GRX_TREE_GMAX 16    // ... and of csrc/grx_tree16.hip (the same source with 16: four envs per wave -- twice the waves, for batches that leave half the
+                            // SIMDs idle with eight lanes per env); the tables are sized for it, TreeTab.g says which one a table was built for
 #define GRX_TREE_MAXSTEP 16
 #define GRX_TREE_LEVELS 10   // depth levels the tree kernel's passes are unrolled for (deeper trees run on the generic kernel)
 #define GRX_TREE_MAXCS 8     // bodies of one chain that carry collision shapes (or a foot frame): rounds of the contact pass
@@ -106,10 +108,10 @@ struct TreeBody {            // 36 words
 struct TreeDof { float kp, kd, q0, effort, vlim, qlo, qhi, slo, shi, amin, amax, Klim, Clim; int32_t lane; float arm; int32_t pad; };   // 16 words (arm: joint-space armature)
 struct TreeSph { float x, y, z, r, dmax; int32_t slot, link, pad; };   // 8 words
 struct TreeTab {
-    int32_t nb, nd, nsph, nlc, nchain, nstep, nh0, pad0;
-    int32_t heads0[GRX_TREE_G];                       // lanes whose chain hangs from the base
-    int32_t first[GRX_TREE_G], last[GRX_TREE_G];      // step range of each lane's chain (first > last: no chain)
-    int8_t sched[GRX_TREE_G][GRX_TREE_MAXSTEP];       // body at (lane, step), -1: none
+    int32_t nb, nd, nsph, nlc, nchain, nstep, nh0, g;   // g: lanes per env this table was built for (work list, link / pair rounds)
+    int32_t heads0[GRX_TREE_GMAX];                       // lanes whose chain hangs from the base
+    int32_t first[GRX_TREE_GMAX], last[GRX_TREE_GMAX];      // step range of each lane's chain (first > last: no chain)
+    int8_t sched[GRX_TREE_GMAX][GRX_TREE_MAXSTEP];       // body at (lane, step), -1: none
     TreeBody body[GRX_MAX_BODIES];
     TreeDof dof[GRX_MAX_DOFS];
     TreeSph sph[GRX_MAX_SPHERES];
@@ -131,7 +133,7 @@ struct TreeTab {
     // the contact pass's work list: round r, lane c evaluates shapes [s0, s1) (at most two) of `body` (-1: nothing; 0: the base) on
     // the frame in LDS -- ANY lane may take any body's shapes, so the three lanes of a group that own no chain work too and a foot's
     // four spheres go to two lanes (round 4: four sphere-slots per sub-step for the full body instead of eight)
-    struct { int8_t body, s0, s1, turn; } cw[GRX_TREE_MAXCS][GRX_TREE_G];
+    struct { int8_t body, s0, s1, turn; } cw[GRX_TREE_MAXCS][GRX_TREE_GMAX];
 };
 
 // every URDF link frame by carrying body (the tree kernel's GRX_T_RIGID_BODY_STATES)

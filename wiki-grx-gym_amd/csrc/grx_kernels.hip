@@ -2099,7 +2099,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
 }
 
 // -DGRX_SPIN_LIMIT builds (grx_flags.h): where an expired spin reports before it traps -- one pointer per translation unit
-#ifdef GRX_QUAD_TU
+#if defined(GRX_TREE16_TU)
+extern "C" int grx_set_spin_word_tree16(unsigned long long* p) {
+#elif defined(GRX_QUAD_TU)
 extern "C" int grx_set_spin_word_quad(unsigned long long* p) {
 #else
 extern "C" int grx_set_spin_word(unsigned long long* p) {
@@ -2135,6 +2137,7 @@ extern "C" void grx_launch_step_debug_quad(const KParams* dP, int N, int heightf
 #undef GRX_LAUNCH_DBGQ
 }
 #else
+#ifndef GRX_TREE16_TU   // (grx_tree16.hip: only the tree kernel's launchers below)
 // extras["episode"] (legged_robot.py:420-428) ON DEMAND: the reduction stats_fold_previous would do in the handle's next launch,
 // for the launch `seq`, now (grx_flush_stats / grx_episode_stats; the generic-tree kernel's step still ends with it).  The next
 // launch repeats it with the same result.  ONE block, a wave per statistics row (round-robin); its ticket store comes after
@@ -2300,10 +2303,16 @@ extern "C" int grx_launch_step_generic(const KParams* dP, const void* tables, fl
 extern "C" void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, long long seq, uint8_t* mask, hipStream_t stream) {
     hipLaunchKernelGGL(grx_reset_all_generic, dim3((N + epb - 1) / epb), dim3(epb), 0, stream, dP, static_cast<const GenTables*>(tables), step, seq, mask);
 }
-// the tree kernel (grx_tree.h): 8 lanes per env, two or four 8-env waves per block
-extern "C" int grx_tree_lds_bytes(int nb, int nlc, int nchain, int waves) { return (int)sizeof(TreeTab) + waves * tree_offsets(nb, nlc, nchain).total * TEPW * 4; }
-extern "C" int grx_tree_envs_per_wave(void) { return TEPW; }
-extern "C" int grx_launch_step_tree(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions, float delay,
+#endif   // !GRX_TREE16_TU
+// the tree kernel (grx_tree.h): 8 lanes per env, two or four 8-env waves per block; grx_tree16.hip: the same with 16 lanes per env (names + "16")
+#ifdef GRX_TREE16_TU
+#define GRX_TREE_FN(n) n##16
+#else
+#define GRX_TREE_FN(n) n
+#endif
+extern "C" int GRX_TREE_FN(grx_tree_lds_bytes)(int nb, int nlc, int nchain, int waves) { return (int)sizeof(TreeTab) + waves * tree_offsets(nb, nlc, nchain).total * TEPW * 4; }
+extern "C" int GRX_TREE_FN(grx_tree_envs_per_wave)(void) { return TEPW; }
+extern "C" int GRX_TREE_FN(grx_launch_step_tree)(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions, float delay,
                                     long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {
     static bool raised = false;
     if (!raised) {   // > 64 KB of dynamic LDS needs the opt-in
@@ -2319,7 +2328,7 @@ extern "C" int grx_launch_step_tree(const KParams* dP, const void* tree_tab, con
     return 0;
 }
 // TEST-ONLY (grx_debug_post_physics): the post-physics half of the tree kernel on injected state (a 10-dof model forced through it)
-extern "C" int grx_launch_step_tree_debug(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions,
+extern "C" int GRX_TREE_FN(grx_launch_step_tree_debug)(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions,
                                           long long common_step, const float* noise, const float* dbg, const StepSeq* sq, hipStream_t stream) {
     static bool raised = false;
     if (!raised) {
@@ -2334,6 +2343,7 @@ extern "C" int grx_launch_step_tree_debug(const KParams* dP, const void* tree_ta
     else hipLaunchKernelGGL((grx_step_tree<false, true>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, 0.f, common_step, noise, (float*)nullptr, (float*)nullptr, *sq, dbg);
     return 0;
 }
+#ifndef GRX_TREE16_TU
 extern "C" int grx_generic_tables_size(void) { return (int)sizeof(GenTables); }
 extern "C" int grx_generic_ws_floats_per_env(int nb, int nlc) { return nb * WSB + 3 * nlc; }
 // the statistics of launch `seq` now (grx_flush_stats; the generic path after every step) + optionally a ticket
@@ -2357,4 +2367,5 @@ extern "C" void grx_launch_set_state(const KParams* dP, int N, const float* root
     hipLaunchKernelGGL(grx_set_state_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, dP, root, q, qd, env_ids, n);
 }
 extern "C" int grx_envs_per_block(void) { return EPB; }
+#endif   // !GRX_TREE16_TU
 #endif   // GRX_QUAD_TU

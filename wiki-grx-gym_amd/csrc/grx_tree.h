@@ -28,7 +28,11 @@
 //     GRX_TREE=0).
 #pragma once
 
-constexpr int TG = GRX_TREE_G, TEPW = 64 / TG;   // lanes per env, envs per wave
+#ifndef GRX_TREE_GDEV
+#define GRX_TREE_GDEV GRX_TREE_G   // (grx_tree16.hip compiles this header with 16)
+#endif
+constexpr int TG = GRX_TREE_GDEV, TEPW = 64 / TG;   // lanes per env, envs per wave
+static_assert(TG == GRX_TREE_G || TG == GRX_TREE_GMAX, "an 8- or a 16-lane group per env");
 constexpr int TWAVES_MAX = 4;                    // waves per block: 2 while the blocks fit the CUs in one round, else 4 (grx_capi.cpp)
 // LDS workspace words per body (bodies 1 .. nb - 1; the base lives in registers)
 enum { T_R = 0, T_RHO = 9, T_W = 12, T_V = 15, T_PA = 18, T_PL = 21, T_TAU = 24, T_NB = 25 };   // (T_TAU: the joint's motor torque of the current sub-step)
@@ -45,7 +49,7 @@ __host__ __device__ inline TreeOff tree_offsets(int nb, int nlc, int nchain) {
 }
 #define TW(addr) wsw[(addr) * TEPW + ei]
 
-GRX_DEV float grp_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
+GRX_DEV float grp_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); if (TG == 16) v += __shfl_xor(v, 8); return v; }
 GRX_DEV float grp_bcast(float v, int lane, int src) { return __shfl(v, (lane & ~(TG - 1)) | src); }
 GRX_DEV V3 grp_bcast(V3 v, int lane, int src) { return v3(grp_bcast(v.x, lane, src), grp_bcast(v.y, lane, src), grp_bcast(v.z, lane, src)); }
 
@@ -377,23 +381,30 @@ GRX_DEV void tree_self_collision(KP P, const TreeTab& T, float* wsw, int ei, int
             hit = dot(d, d) < R * R;
         }
         if (!__any(hit)) continue;
+        // Round 4: the lanes that hit evaluate their pairs TOGETHER (the nested sphere x sphere loops: ~800 instructions a pair, and the
+        // bounding spheres of neighbouring links -- upper arm x torso -- overlap in every pose, so every round has some); only the
+        // accumulation into the bodies' bias forces and the link forces goes one lane at a time, in table order, as before: the same
+        // sums on every run, bit for bit the sums of the one-at-a-time evaluation.
+        V3 Fa = v3(0.f, 0.f, 0.f), Ta = v3(0.f, 0.f, 0.f);
+        int la = 0, lb = 0;
+        if (hit) {
+            la = T.lp_a[lp]; lb = T.lp_b[lp];
+            if (ba != 0) { Ka.w = tw_v3(wsw, ei, TBO(ba) + T_W); Ka.v = tw_v3(wsw, ei, TBO(ba) + T_V); }
+            Kb.w = tw_v3(wsw, ei, TBO(bb) + T_W); Kb.v = tw_v3(wsw, ei, TBO(bb) + T_V);
+            for (int i = T.lc_begin[la]; i < T.lc_begin[la + 1]; ++i) {
+                SphC si; si.x = T.sph[i].x; si.y = T.sph[i].y; si.z = T.sph[i].z; si.r = T.sph[i].r; si.dmax = T.sph[i].dmax;
+                const SphW a = sph_world(si, Ka);
+                for (int jj = T.lc_begin[lb]; jj < T.lc_begin[lb + 1]; ++jj) {
+                    SphC sj; sj.x = T.sph[jj].x; sj.y = T.sph[jj].y; sj.z = T.sph[jj].z; sj.r = T.sph[jj].r; sj.dmax = T.sph[jj].dmax;
+                    const SphW b_ = sph_world(sj, Kb);
+                    V3 F, pw;
+                    if (sphere_pair(P, a, b_, mu_self, F, pw)) { Fa = Fa + F; Ta = Ta + cross(pw, F); }
+                }
+            }
+        }
         for (int k = 0; k < TG; ++k) {   // table order within the round: lane k's pair
             if (!__any(hit && c == k)) continue;
             if (hit && c == k) {
-                const int la = T.lp_a[lp], lb = T.lp_b[lp];
-                if (ba != 0) { Ka.w = tw_v3(wsw, ei, TBO(ba) + T_W); Ka.v = tw_v3(wsw, ei, TBO(ba) + T_V); }
-                Kb.w = tw_v3(wsw, ei, TBO(bb) + T_W); Kb.v = tw_v3(wsw, ei, TBO(bb) + T_V);
-                V3 Fa = v3(0.f, 0.f, 0.f), Ta = v3(0.f, 0.f, 0.f);
-                for (int i = T.lc_begin[la]; i < T.lc_begin[la + 1]; ++i) {
-                    SphC si; si.x = T.sph[i].x; si.y = T.sph[i].y; si.z = T.sph[i].z; si.r = T.sph[i].r; si.dmax = T.sph[i].dmax;
-                    const SphW a = sph_world(si, Ka);
-                    for (int jj = T.lc_begin[lb]; jj < T.lc_begin[lb + 1]; ++jj) {
-                        SphC sj; sj.x = T.sph[jj].x; sj.y = T.sph[jj].y; sj.z = T.sph[jj].z; sj.r = T.sph[jj].r; sj.dmax = T.sph[jj].dmax;
-                        const SphW b_ = sph_world(sj, Kb);
-                        V3 F, pw;
-                        if (sphere_pair(P, a, b_, mu_self, F, pw)) { Fa = Fa + F; Ta = Ta + cross(pw, F); }
-                    }
-                }
                 // F on link a (body ba), -F on link b (body bb)
                 if (ba == 0) { dpa0 = dpa0 - Ta; dpl0 = dpl0 - Fa; }
                 else { const int wa = TBO(ba); TW(wa + T_PA) -= Ta.x; TW(wa + T_PA + 1) -= Ta.y; TW(wa + T_PA + 2) -= Ta.z; TW(wa + T_PL) -= Fa.x; TW(wa + T_PL + 1) -= Fa.y; TW(wa + T_PL + 2) -= Fa.z; }
@@ -492,8 +503,10 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             TW(o.dof + TD_STR * GRX_MAX_DOFS + j) = P.motor_strength[oj];
         }
     }
+    if (c < 8) {   // 8 anchor slots x (x, y, approach speed): one slot per lane (of the group's first eight)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) TW(o.an + c * 3 + k) = P.anchors[(size_t)(c * 3 + k) * N + e];   // 8 anchor slots x (x, y, approach speed): one slot per lane
+        for (int k = 0; k < 3; ++k) TW(o.an + c * 3 + k) = P.anchors[(size_t)(c * 3 + k) * N + e];
+    }
     tree_fence();
     // ---- during_physics_step (legged_robot_fftai.py:51-88)
     float avg_force[2] = {0.f, 0.f};
@@ -894,7 +907,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             B.ang = v3(0.f, 0.f, 0.f);
         }
         resample_commands(P, genv, step, GRX_RNG_CMD_RESET, ea.cmd);
-        TW(o.an + c * 3 + 2) = 0.f;   // the lane's anchor slot
+        if (c < 8) TW(o.an + c * 3 + 2) = 0.f;   // the lane's anchor slot
         for (int f = 0; f < 2; ++f) { air_time[f] = 0.f; land_time[f] = 0.f; contact_last[f] = false; }
         ep_len = 0;
     }
@@ -949,8 +962,10 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             P.q[oj] = qj; P.qd[oj] = qdj; P.actions[oj] = ac; P.torques[oj] = TW(TBO(j + 1) + T_TAU);
             P.last_actions[oj] = ac; P.last_dof_vel[oj] = qdj;   // history (legged_robot.py:299-300, after reset_idx)
         }
+        if (c < 8) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) P.anchors[(size_t)(c * 3 + k) * N + e] = TW(o.an + c * 3 + k);
+            for (int k = 0; k < 3; ++k) P.anchors[(size_t)(c * 3 + k) * N + e] = TW(o.an + c * 3 + k);
+        }
         if (lead) {
             put(0, ea.cmd[0], 0.f); put(1, ea.cmd[1], 0.f); put(2, ea.cmd[2], 0.f);
             const float na = P.noise_ang_vel * P.noise_level * P.obs_scale_ang_vel, ng = P.noise_gravity * P.noise_level * P.obs_scale_gravity;
