@@ -197,14 +197,28 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
                 G.Sa[g] = a;
                 za = fma3(cross(w_c, a), qdj, za);
                 zl = fma3(cross(v_c, a) + cross(w_c, s), qdj, zl);
-                const V3 kap = rho + rot(R, v3(tb.com[0], tb.com[1], tb.com[2]));
-                const S3 Ic = {tb.Ic[0], tb.Ic[1], tb.Ic[2], tb.Ic[3], tb.Ic[4], tb.Ic[5]};
-                V3 pa, pl;
-                rigid_bias_z(R, kap, tb.mass, Ic, w, v, za, zl, pa, pl);
-                tw_put(wsw, ei, wb + T_PA, pa); tw_put(wsw, ei, wb + T_PL, pl);   // (contacts and self-collision add into these)
+                // the body's zeta is parked where its bias force goes: the force itself needs nothing from the chain any more and is
+                // formed for ALL bodies at once behind the walk (below) -- 33 bodies go round the group's lanes in 2-4 rounds instead of
+                // riding on the 10 depth levels
+                tw_put(wsw, ei, wb + T_PA, za); tw_put(wsw, ei, wb + T_PL, zl);
                 for (int k = 0; k < tb.nhc; ++k) { tw_put(wsw, ei, o.up + tb.hc[k] * T_UPW, za); tw_put(wsw, ei, o.up + tb.hc[k] * T_UPW + 3, zl); }
             }
             Rc = R; rho_c = rho; w_c = w; v_c = v;
+        }
+        tree_fence();
+    }
+    if (!KIN) {   // rigid-body bias forces p_k + I_k zeta_k of every body, from the frames in LDS (contacts and self-collision add into these)
+        for (int b = 1 + c; b < T.nb; b += TG) {
+            const TreeBody& tb = T.body[b];
+            const int wb = TBO(b);
+            const R3 R = tw_R(wsw, ei, wb + T_R);
+            const V3 rho = tw_v3(wsw, ei, wb + T_RHO), w = tw_v3(wsw, ei, wb + T_W), v = tw_v3(wsw, ei, wb + T_V);
+            const V3 za = tw_v3(wsw, ei, wb + T_PA), zl = tw_v3(wsw, ei, wb + T_PL);
+            const V3 kap = rho + rot(R, v3(tb.com[0], tb.com[1], tb.com[2]));
+            const S3 Ic = {tb.Ic[0], tb.Ic[1], tb.Ic[2], tb.Ic[3], tb.Ic[4], tb.Ic[5]};
+            V3 pa, pl;
+            rigid_bias_z(R, kap, tb.mass, Ic, w, v, za, zl, pa, pl);
+            tw_put(wsw, ei, wb + T_PA, pa); tw_put(wsw, ei, wb + T_PL, pl);
         }
         tree_fence();
     }
@@ -283,6 +297,24 @@ GRX_DEV void tree_add_up(const float* wsw, int ei, int a, S3& A, M3& B, S3& D, V
 // pass 3 needs of a body is parked in slots of its LDS row that nobody reads any more in this sub-step: 1/d, u and the joint
 // in the rotation's, U = I^A S in the bias force's.
 enum { T_DI = T_R, T_U = T_R + 1, T_UA = T_PA, T_UL = T_PL };
+// ... and what pass 2 itself needs of a body beyond its bias force -- the rigid inertia about O, A (6 words) and h = m kap (3) -- comes
+// from a pass over ALL bodies at once (they go round the group's lanes: 2-4 rounds instead of the 10 depth levels), parked in the
+// rotation's nine slots: contacts and self-collision are done with the frames by then, the next outward pass rewrites them
+enum { T_AK = T_R, T_HK = T_R + 6 };
+GRX_DEV void tree_rigid_inertias(const TreeTab& T, float* wsw, int ei, int c) {
+    for (int b = 1 + c; b < T.nb; b += TG) {
+        const TreeBody& tb = T.body[b];
+        const int wb = TBO(b);
+        const R3 R = tw_R(wsw, ei, wb + T_R);
+        const V3 kap = tw_v3(wsw, ei, wb + T_RHO) + rot(R, v3(tb.com[0], tb.com[1], tb.com[2]));
+        const S3 Ic = {tb.Ic[0], tb.Ic[1], tb.Ic[2], tb.Ic[3], tb.Ic[4], tb.Ic[5]};
+        S3 Ar; V3 h;
+        rigid_inertia(R, kap, tb.mass, Ic, Ar, h);
+        TW(wb + T_AK) = Ar.xx; TW(wb + T_AK + 1) = Ar.xy; TW(wb + T_AK + 2) = Ar.xz; TW(wb + T_AK + 3) = Ar.yy; TW(wb + T_AK + 4) = Ar.yz; TW(wb + T_AK + 5) = Ar.zz;
+        tw_put(wsw, ei, wb + T_HK, h);
+    }
+    tree_fence();
+}
 GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, int first, int last, TreeRegs& G) {
     // The lane's chain is ONE run of levels (first .. last): its running articulated inertia [A B; B^T D] and bias force are the working
     // set itself -- zero before the chain's leaf, every level ADDS its rigid body and downdates in place, the chain's first body hands
@@ -297,17 +329,12 @@ GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, cons
             const int b = G.sb[g];
             const TreeBody& tb = T.body[b];
             const int j = b - 1, wb = TBO(b);
-            const R3 R = tw_R(wsw, ei, wb + T_R);
             const V3 rho = tw_v3(wsw, ei, wb + T_RHO);
             pa = pa + tw_v3(wsw, ei, wb + T_PA); pl = pl + tw_v3(wsw, ei, wb + T_PL);
             float t = TW(wb + T_TAU);
-            const V3 kap = rho + rot(R, v3(tb.com[0], tb.com[1], tb.com[2]));
-            const S3 Ic = {tb.Ic[0], tb.Ic[1], tb.Ic[2], tb.Ic[3], tb.Ic[4], tb.Ic[5]};
-            const float m = tb.mass;
-            {
-                S3 Ar; V3 h;
-                rigid_inertia(R, kap, m, Ic, Ar, h);
-                add_rigid(A, Bm, D, Ar, h, m);
+            {   // the body's rigid inertia about O: formed for all bodies at once by tree_rigid_inertias, parked in the rotation's slots
+                const S3 Ar = {TW(wb + T_AK), TW(wb + T_AK + 1), TW(wb + T_AK + 2), TW(wb + T_AK + 3), TW(wb + T_AK + 4), TW(wb + T_AK + 5)};
+                add_rigid(A, Bm, D, Ar, tw_v3(wsw, ei, wb + T_HK), tb.mass);
             }
             for (int k = 0; k < tb.nhc; ++k) tree_add_up(wsw, ei, o.up + tb.hc[k] * T_UPW, A, Bm, D, pa, pl);   // chains that hang from this body, fixed order
             const V3 a = G.Sa[g], s = cross(rho, a);
@@ -332,6 +359,8 @@ GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, cons
 
 // pass 3 (root -> leaves): accelerations a^ (see tree_outward), joint integration
 GRX_DEV void tree_accel(KP P, const TreeTab& T, float* wsw, int ei, int c, V3 alpha, V3 acc, int first, int last, TreeRegs& G) {
+    // (fetching a level's U, 1/d, u, rho one level AHEAD of the arithmetic -- here and in tree_inward -- was measured: 3 % SLOWER, and the
+    //  kernels then need all 512 registers and spill; the scheduler already overlaps what the level fences allow)
     V3 aa_c = alpha, al_c = acc;
     const float dt = P.sim_dt;
 #pragma unroll
@@ -416,12 +445,11 @@ GRX_DEV void tree_self_collision(KP P, const TreeTab& T, float* wsw, int ei, int
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
-    // the base's share: summed over the env's lanes in lane order (only a few lanes ever hold one)
-#pragma unroll
-    for (int k = 0; k < TG; ++k) {
-        const int src = ((threadIdx.x & 63) & ~(TG - 1)) | k;
-        pa0 = pa0 + v3(__shfl(dpa0.x, src), __shfl(dpa0.y, src), __shfl(dpa0.z, src));
-        pl0 = pl0 + v3(__shfl(dpl0.x, src), __shfl(dpl0.y, src), __shfl(dpl0.z, src));
+    // the base's share (only a few lanes ever hold one: skipped when nobody in the wave does): the group's lanes add up in the fixed
+    // order of the butterfly
+    if (__any(dot(dpa0, dpa0) + dot(dpl0, dpl0) != 0.f)) {
+        pa0 = pa0 + v3(grp_sum(dpa0.x), grp_sum(dpa0.y), grp_sum(dpa0.z));
+        pl0 = pl0 + v3(grp_sum(dpl0.x), grp_sum(dpl0.y), grp_sum(dpl0.z));
     }
 }
 
@@ -544,6 +572,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         TT(2);
         if (P.self_collisions) tree_self_collision(P, T, wsw, ei, c, o, E, R0, pa0, pl0);
         TT(3);
+        tree_rigid_inertias(T, wsw, ei, c);
         tree_inward(P, T, wsw, ei, c, o, first, last, G);
         TT(4);
         // ---- base: the chains that hang from it, in table order; [A B; B^T D][alpha; acc] = -[pa; pl]
