@@ -117,10 +117,17 @@ def test_full_body_rough_terrain_runs_and_is_deterministic(kernel, monkeypatch):
         gen = torch.Generator().manual_seed(0)
         for i in range(20):
             hip.step(random_actions(cfg, 256, gen, 1.0).cuda(), 5.0, i + 1)
-        out = {k: hip.tensor(k).clone() for k in ("OBS", "PRI_OBS", "REW", "RESET", "ROOT_STATES")}
+        out = {k: hip.tensor(k).clone() for k in ("OBS", "PRI_OBS", "REW", "RESET", "ROOT_STATES", "EPISODE_STATS")}
         hip.close()
         return out
     a, b = run(), run()
+    if kernel != "generic":   # four waves per block (what 16384 envs -- and 4096 with 16 lanes per env -- run): the block's statistics are added in wave order
+        monkeypatch.setenv("GRX_TREE_WAVES", "4")
+        c, d = run(), run()
+        monkeypatch.delenv("GRX_TREE_WAVES")
+        for k in c:
+            assert torch.equal(c[k], d[k]), ("four waves per block", k)
+        assert torch.equal(c["RESET"], a["RESET"]) and (c["EPISODE_STATS"] - a["EPISODE_STATS"]).abs().max() < 1e-4
     for k in a:
         assert torch.equal(a[k], b[k]), k
         if a[k].is_floating_point():

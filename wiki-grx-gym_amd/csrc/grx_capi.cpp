@@ -645,8 +645,8 @@ int build_generic(grx_sim* s, const grx_config& c) {
     }
     auto lds_of = [&](int waves) { return G == GRX_TREE_GMAX ? grx_tree_lds_bytes16(T.nb, T.nlc, nchain, waves) : grx_tree_lds_bytes(T.nb, T.nlc, nchain, waves); };
     int lds = lds_of(s->tree_waves);
-    while (lds > 160 * 1024 - 512 && s->tree_waves > 1) { s->tree_waves /= 2; lds = lds_of(s->tree_waves); }
-    if (lds > 160 * 1024 - 512) return GRX_OK;   // the workspace of one wave does not fit a CU's LDS
+    while (lds > 160 * 1024 - 1024 && s->tree_waves > 1) { s->tree_waves /= 2; lds = lds_of(s->tree_waves); }
+    if (lds > 160 * 1024 - 1024) return GRX_OK;   // the workspace of one wave does not fit a CU's LDS
     TreeTab* dk = nullptr;
     rc = dalloc(s, &dk, 1);
     if (rc) return rc;
@@ -786,7 +786,9 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(episode_sums, NT * N); DA(reward_terms, NT * N); DA(heights, (size_t)(nh > 0 ? nh : 1) * N);
     DA(obs, (size_t)c.num_obs * N + 64); DA(pri_obs, (size_t)c.num_pri_obs * N + 64);
     const int nblocks = (c.num_envs + grx_envs_per_block() - 1) / grx_envs_per_block();
-    P.stat_stride = 2 * nblocks + 1;   // generic kernel: down to 16 envs per block
+    // a column per block of the writing kernel: 16-env blocks at the least for the fused kernels (lane quads) and the one-lane generic kernel;
+    // the tree kernel goes down to one four-env wave per block (16 lanes per env, GRX_TREE_WAVES=1)
+    P.stat_stride = (generic ? 8 : 2) * nblocks + 1;
     DA(stat_partial, (size_t)2 * NSTAT * P.stat_stride); DA(stat_nblocks, 2); DA(stat_hist, (size_t)GRX_STATS_HISTORY * NSTAT);
     DA(stats, NSTAT); DA(prof, (size_t)2 * nblocks * GRX_PROF_SLOTS);   // (16-env blocks in the quad layout)
     rc = dalloc(s, &s->d_mask, N);

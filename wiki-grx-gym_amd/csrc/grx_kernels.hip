@@ -2316,8 +2316,8 @@ extern "C" int GRX_TREE_FN(grx_launch_step_tree)(const KParams* dP, const void* 
                                     long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {
     static bool raised = false;
     if (!raised) {   // > 64 KB of dynamic LDS needs the opt-in
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
         raised = true;
     }
     const int nblocks = (N + TEPW * waves - 1) / (TEPW * waves);
@@ -2332,8 +2332,8 @@ extern "C" int GRX_TREE_FN(grx_launch_step_tree_debug)(const KParams* dP, const 
                                           long long common_step, const float* noise, const float* dbg, const StepSeq* sq, hipStream_t stream) {
     static bool raised = false;
     if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
         raised = true;
     }
     const int nblocks = (N + TEPW * waves - 1) / (TEPW * waves);

@@ -33,7 +33,7 @@
 #endif
 constexpr int TG = GRX_TREE_GDEV, TEPW = 64 / TG;   // lanes per env, envs per wave
 static_assert(TG == GRX_TREE_G || TG == GRX_TREE_GMAX, "an 8- or a 16-lane group per env");
-constexpr int TWAVES_MAX = 4;                    // waves per block: 2 while the blocks fit the CUs in one round, else 4 (grx_capi.cpp)
+constexpr int TWAVES_MAX = 4;                    // (the statistics rows at the kernel's end are added as four: keep in step) waves per block: 2 while the blocks fit the CUs in one round, else 4 (grx_capi.cpp)
 // LDS workspace words per body (bodies 1 .. nb - 1; the base lives in registers)
 enum { T_R = 0, T_RHO = 9, T_W = 12, T_V = 15, T_PA = 18, T_PL = 21, T_TAU = 24, T_NB = 25 };   // (T_TAU: the joint's motor torque of the current sub-step)
 constexpr int T_UPW = 27;    // a chain's hand-over to its parent: A 6, B 9, D 6, pa 3, pl 3
@@ -465,13 +465,14 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
                                                              const StepSeq sq, const float* __restrict__ dbg = nullptr) {
     KP P = GRX_PARAMS(Pg);
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    __shared__ float s_stat[NSTAT];
+    __shared__ float s_stat[TWAVES_MAX][NSTAT];   // a row per wave, added in wave order at the end: the same sums on every run (float atomics of four waves
+                                                  // would add in arrival order)
     TreeTab& Tm = *reinterpret_cast<TreeTab*>(s_dyn);
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(Tt);
         uint32_t* dst = reinterpret_cast<uint32_t*>(s_dyn);
         for (int i = threadIdx.x; i < (int)(sizeof(TreeTab) / 4); i += blockDim.x) dst[i] = src[i];
-        if (threadIdx.x < NSTAT) s_stat[threadIdx.x] = 0.f;
+        for (int i = threadIdx.x; i < TWAVES_MAX * NSTAT; i += blockDim.x) (&s_stat[0][0])[i] = 0.f;
     }
     __syncthreads();
     const TreeTab& T = Tm;
@@ -882,14 +883,14 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             float acc_ = 0.f;
             unsigned long long m = reset_mask;
             while (m) { const int L = __ffsll((long long)m) - 1; m &= m - 1; acc_ += __shfl(es, L); }
-            if (lane == 0) atomicAdd(&s_stat[t], acc_);   // (two waves per block: LDS float add of two values, order-free)
+            if (lane == 0) s_stat[wave][t] += acc_;
         }
         if (actl && P.reward_scale_dt[t] != 0.f) {
             P.episode_sums[(size_t)t * N + e] = (reset && dbg_apply_reset) ? 0.f : es;
             if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
         }
     }
-    if (lane == 0) atomicAdd(&s_stat[NT], (float)__popcll(reset_mask));
+    if (lane == 0) s_stat[wave][NT] += (float)__popcll(reset_mask);
     // ---- reset_idx (masked, in-kernel): a chain's joints by its lane, the base in every lane (same counters, same values)
     const bool reported_reset = reset;   // (the debug entry may report a reset without applying it)
     if (DBG && !dbg_apply_reset) reset = false;
@@ -942,7 +943,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     }
     {   // statistics row NT + 1: terrain levels after this step's curriculum moves (legged_robot.py:427-428)
         const float ls = level_sum(ea.level, actl);
-        if (lane == 0) atomicAdd(&s_stat[NT + 1], ls);
+        if (lane == 0) s_stat[wave][NT + 1] += ls;
     }
     // ---- compute_observations (legged_robot_fftai.py:148-167, gr1t1.py:281-336)
     float* obs = (obs_out ? obs_out : P.obs) + (size_t)e * nobs;
@@ -1052,7 +1053,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     }
 #endif
     __syncthreads();
-    if (threadIdx.x < NSTAT) stat_row(P, sq.seq, threadIdx.x)[blockIdx.x] = s_stat[threadIdx.x];
+    if (threadIdx.x < NSTAT) stat_row(P, sq.seq, threadIdx.x)[blockIdx.x] = (s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x]) + (s_stat[2][threadIdx.x] + s_stat[3][threadIdx.x]);
     if (blockIdx.x == 0 && threadIdx.x == 0) P.stat_nblocks[sq.seq & 1] = (int)gridDim.x;
 }
 #undef TW
