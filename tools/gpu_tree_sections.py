@@ -26,4 +26,6 @@ for terrain in ("plane", "heightfield"):
     med = np.median(full[:, :10], axis=0)
     print(terrain, s.layout(), "cycles per policy step (wave 0, median over blocks): physics", int(med[8]), "whole kernel", int(med[9]))
     for n, v in zip(names, med[:8]): print(f"   {n:16s} {v:9.0f}  ({v / 10:7.0f} per sub-step)")
+    m2 = np.median(full[:, 8:14], axis=0)
+    print("   behind the sub-steps (cycles since the kernel's start): physics done", int(m2[0]), "final frames / link frames / feet done", int(m2[2]), "state update + height scan done", int(m2[3]), "rewards done", int(m2[4]), "reset done", int(m2[5]), "end", int(m2[1]))
     s.close()

@@ -715,6 +715,9 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         fore_g[0] = -(R.cx.z * T.forehead_rot[0] + R.cy.z * T.forehead_rot[3] + R.cz.z * T.forehead_rot[6]);
         fore_g[1] = -(R.cx.z * T.forehead_rot[1] + R.cy.z * T.forehead_rot[4] + R.cz.z * T.forehead_rot[7]);
     }
+#ifdef GRX_PROFILE_SECTIONS
+    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 10] = clock64() - tt_begin;
+#endif
     // ---- post_physics_step (legged_robot.py:269-334)
     GenBase& B = E.B;
     ep_len += 1;
@@ -757,6 +760,9 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     bool reset = term_contact || (fabsf(pg.z) < P.termination_gravity_z);
     const bool time_out = (float)ep_len > P.max_episode_length;
     reset = reset || time_out;
+#ifdef GRX_PROFILE_SECTIONS
+    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 11] = clock64() - tt_begin;
+#endif
     // ---- compute_reward (legged_robot.py:355-375; terms legged_robot_fftai.py:180-352, gr1t1.py:338-589): a lane sums over
     // its chain's joints, the group adds up
     float r[NT];
@@ -891,6 +897,9 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         }
     }
     if (lane == 0) s_stat[wave][NT] += (float)__popcll(reset_mask);
+#ifdef GRX_PROFILE_SECTIONS
+    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 12] = clock64() - tt_begin;
+#endif
     // ---- reset_idx (masked, in-kernel): a chain's joints by its lane, the base in every lane (same counters, same values)
     const bool reported_reset = reset;   // (the debug entry may report a reset without applying it)
     if (DBG && !dbg_apply_reset) reset = false;
@@ -945,6 +954,9 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         const float ls = level_sum(ea.level, actl);
         if (lane == 0) s_stat[wave][NT + 1] += ls;
     }
+#ifdef GRX_PROFILE_SECTIONS
+    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 13] = clock64() - tt_begin;
+#endif
     // ---- compute_observations (legged_robot_fftai.py:148-167, gr1t1.py:281-336)
     float* obs = (obs_out ? obs_out : P.obs) + (size_t)e * nobs;
     float* pri = (pri_out ? pri_out : P.pri_obs) + (size_t)e * npri;
@@ -961,19 +973,35 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         sum = grp_sum(sum);
         bho = nh > 0 ? sum / (float)nh : 0.f;
     }
+    // observation noise: the env's Philox blocks -- 2 of the base stream, ceil(3 (nd / 2) / 4) per half of the dof range (the oracle's scheme:
+    // item i of a stream is word i & 3 of block i >> 2) -- computed ONCE, the blocks going round the group's lanes, and parked in the
+    // bias-force slots of bodies 1.. (dead behind the sub-steps).  (Round 4, from the section profile: one whole Philox block per
+    // observation ELEMENT, 30 per lane with the level loop unrolled, and an integer division to find the element's stream made this
+    // section 40 k cycles of a 650 k step.)
+    const int half_ = nd / 2, nblk_dof = (3 * half_ + 3) / 4, nblk = 2 + 2 * nblk_dof;
+    const bool own_noise = P.add_noise && !noise_in, noise_lds = own_noise && nblk <= T.nb - 1;
+    if (noise_lds) {
+        for (int k = c; k < nblk; k += TG) {
+            const uint32_t stream = k < 2 ? (uint32_t)GRX_RNG_NOISE : (k < 2 + nblk_dof ? (uint32_t)GRX_RNG_NOISE_DOF_L : (uint32_t)GRX_RNG_NOISE_DOF_R);
+            const uint32_t blk = k < 2 ? (uint32_t)k : (uint32_t)(k < 2 + nblk_dof ? k - 2 : k - 2 - nblk_dof);
+            const U4 o4 = grx_philox4x32_10(genv, step, stream, blk, (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
+            const int wa = TBO(k + 1) + T_PA;
+            TW(wa) = __uint_as_float(o4.x); TW(wa + 1) = __uint_as_float(o4.y); TW(wa + 2) = __uint_as_float(o4.z); TW(wa + 3) = __uint_as_float(o4.w);
+        }
+        tree_fence();
+    }
     if (act) {
-        auto put = [&](int idx, float val, float nscale) {
+        // slot: block of the env's noise table (0, 1: base stream; 2..: left dofs; 2 + nblk_dof..: right dofs), item: index within the stream
+        auto noise_u = [&](uint32_t stream, int slot0, int item) -> float {
+            if (noise_lds) return grx_u01(__float_as_uint(TW(TBO(slot0 + (item >> 2) + 1) + T_PA + (item & 3))));
+            return grx_rand(P.seed, genv, step, stream, (uint32_t)item);
+        };
+        // idx: column of the observation; (stream, slot0, item): where its noise uniform comes from
+        auto put = [&](int idx, float val, float nscale, uint32_t stream, int slot0, int item) {
             pri[idx] = fminf(fmaxf(val, -clipo), clipo);   // pri_obs copies obs BEFORE noise
             float ov = val;
             if (P.add_noise && nscale != 0.f) {
-                float u;
-                if (noise_in) u = noise_in[(size_t)e * nobs + idx];
-                else if (idx < 9) u = grx_rand(P.seed, genv, step, GRX_RNG_NOISE, (uint32_t)(idx - 3));
-                else {   // dof terms: one stream per half of the dof range (the oracle's scheme)
-                    const int g_ = (idx - 9) / nd, j = (idx - 9) % nd, half_ = nd / 2;
-                    const bool right = j >= half_;
-                    u = grx_rand(P.seed, genv, step, right ? GRX_RNG_NOISE_DOF_R : GRX_RNG_NOISE_DOF_L, (uint32_t)(g_ * half_ + (right ? j - half_ : j)));
-                }
+                const float u = noise_in ? noise_in[(size_t)e * nobs + idx] : noise_u(stream, slot0, item);
                 ov += (2.f * u - 1.f) * nscale;
             }
             obs[idx] = fminf(fmaxf(ov, -clipo), clipo);
@@ -986,9 +1014,13 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             const int j = G.sb[g] - 1;
             const size_t oj = (size_t)j * N + e;
             const float qj = G.q[g], qdj = G.qd[g], ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j);
-            put(9 + j, (qj - T.dof[j].q0) * P.obs_scale_dof_pos, np_);
-            put(9 + nd + j, qdj * P.obs_scale_dof_vel, nv);
-            put(9 + 2 * nd + j, ac * P.obs_scale_action, nac);
+            // dof terms: one stream per half of the dof range, item = group * (nd / 2) + joint within the half (group 0 pos, 1 vel, 2 action)
+            const bool right = j >= half_;
+            const uint32_t ds_ = right ? (uint32_t)GRX_RNG_NOISE_DOF_R : (uint32_t)GRX_RNG_NOISE_DOF_L;
+            const int s0_ = right ? 2 + nblk_dof : 2, jj = right ? j - half_ : j;
+            put(9 + j, (qj - T.dof[j].q0) * P.obs_scale_dof_pos, np_, ds_, s0_, jj);
+            put(9 + nd + j, qdj * P.obs_scale_dof_vel, nv, ds_, s0_, half_ + jj);
+            put(9 + 2 * nd + j, ac * P.obs_scale_action, nac, ds_, s0_, 2 * half_ + jj);
             P.q[oj] = qj; P.qd[oj] = qdj; P.actions[oj] = ac; P.torques[oj] = TW(TBO(j + 1) + T_TAU);
             P.last_actions[oj] = ac; P.last_dof_vel[oj] = qdj;   // history (legged_robot.py:299-300, after reset_idx)
         }
@@ -997,10 +1029,12 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             for (int k = 0; k < 3; ++k) P.anchors[(size_t)(c * 3 + k) * N + e] = TW(o.an + c * 3 + k);
         }
         if (lead) {
-            put(0, ea.cmd[0], 0.f); put(1, ea.cmd[1], 0.f); put(2, ea.cmd[2], 0.f);
+            put(0, ea.cmd[0], 0.f, 0u, 0, 0); put(1, ea.cmd[1], 0.f, 0u, 0, 0); put(2, ea.cmd[2], 0.f, 0u, 0, 0);
             const float na = P.noise_ang_vel * P.noise_level * P.obs_scale_ang_vel, ng = P.noise_gravity * P.noise_level * P.obs_scale_gravity;
-            put(3, bav.x * P.obs_scale_ang_vel, na); put(4, bav.y * P.obs_scale_ang_vel, na); put(5, bav.z * P.obs_scale_ang_vel, na);
-            put(6, pg.x * P.obs_scale_gravity, ng); put(7, pg.y * P.obs_scale_gravity, ng); put(8, pg.z * P.obs_scale_gravity, ng);
+            const float bo[6] = {bav.x * P.obs_scale_ang_vel, bav.y * P.obs_scale_ang_vel, bav.z * P.obs_scale_ang_vel,
+                                 pg.x * P.obs_scale_gravity, pg.y * P.obs_scale_gravity, pg.z * P.obs_scale_gravity};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) put(3 + i, bo[i], i < 3 ? na : ng, (uint32_t)GRX_RNG_NOISE, 0, i);   // base stream: item = column - 3
             pri[nobs + 0] = fminf(fmaxf(blv.x * P.obs_scale_lin_vel, -clipo), clipo);
             pri[nobs + 1] = fminf(fmaxf(blv.y * P.obs_scale_lin_vel, -clipo), clipo);
             pri[nobs + 2] = fminf(fmaxf(blv.z * P.obs_scale_lin_vel, -clipo), clipo);
