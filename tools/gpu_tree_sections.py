@@ -28,4 +28,6 @@ for terrain in ("plane", "heightfield"):
     for n, v in zip(names, med[:8]): print(f"   {n:16s} {v:9.0f}  ({v / 10:7.0f} per sub-step)")
     m2 = np.median(full[:, 8:14], axis=0)
     print("   behind the sub-steps (cycles since the kernel's start): physics done", int(m2[0]), "final frames / link frames / feet done", int(m2[2]), "state update + height scan done", int(m2[3]), "rewards done", int(m2[4]), "reset done", int(m2[5]), "end", int(m2[1]))
+    m3 = np.median(full[:, 14:17], axis=0)
+    print("   inside the rewards: per-joint sums done", int(m3[0]), "group sums done", int(m3[1]), "terms done", int(m3[2]))
     s.close()

@@ -766,6 +766,14 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     // ---- compute_reward (legged_robot.py:355-375; terms legged_robot_fftai.py:180-352, gr1t1.py:338-589): a lane sums over
     // its chain's joints, the group adds up
     float r[NT];
+    // the running episode sums: requested HERE, in one batch, so that their memory latency passes behind the reward arithmetic (read inside the
+    // loop that folds them, behind its wave-uniform branches, each of the 36 loads was an exposed round trip: 27 k cycles, gpu_tree_sections.py)
+    float es_old[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) es_old[t] = (P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
+    float qd_prev[TNG];   // last_dof_vel of this lane's joints: likewise in one batch (inside the unrolled level loop each was a round trip of its own)
+#pragma unroll
+    for (int g = 0; g < TNG; ++g) qd_prev[g] = G.sb[g] >= 0 ? P.last_dof_vel[(size_t)(G.sb[g] - 1) * N + e] : 0.f;
     {
         const float as = P.action_scale, H = P.swing_feet_height_target, Tt_ = P.feet_air_time_target;
         const GRX_AS4 float* sg = P.reward_sigma;
@@ -782,7 +790,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             s1 += fabsf((al - ac) * as);
             if (DBG) s2 += fabsf((al - ac) * as - (dbg[(size_t)(DBG_LAST_LAST_ACTIONS + j) * N + e] - al) * as);
             if (P.knee_mask & bit) { s3 += fabsf((ac - al) * as); vel_kn += fabsf(qdj); }
-            sacc += fabsf((qdj - P.last_dof_vel[(size_t)j * N + e]) / dtp);
+            sacc += fabsf((qdj - qd_prev[g]) / dtp);
             stor += fabsf(tj);
             svel += fabsf(qdj);
             const float po = fabsf(qj - td.q0);
@@ -802,10 +810,16 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             slv += fminf(fmaxf(fabsf(qdj) - td.vlim * P.soft_dof_vel_limit, 0.f), 1.f);
             slt += fmaxf(fabsf(tj) - td.effort * P.soft_torque_limit, 0.f);
         }
+#ifdef GRX_PROFILE_SECTIONS
+        if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 14] = clock64() - tt_begin;
+#endif
         s2 = DBG ? grp_sum(s2) : 0.f;
         s1 = grp_sum(s1); s3 = grp_sum(s3); sacc = grp_sum(sacc); stor = grp_sum(stor); svel = grp_sum(svel); spose = grp_sum(spose);
         sla = grp_sum(sla); slp = grp_sum(slp); slt = grp_sum(slt); slv = grp_sum(slv); shy = grp_sum(shy);
         tor_hr = grp_sum(tor_hr); vel_kn = grp_sum(vel_kn); ank[0] = grp_sum(ank[0]); ank[1] = grp_sum(ank[1]);
+#ifdef GRX_PROFILE_SECTIONS
+        if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 15] = clock64() - tt_begin;
+#endif
         const float hmin = fminf(feet_height[0], feet_height[1]);
         float lift = 0.f, af = 0.f, ah = 0.f, at = 0.f, lt = 0.f, exy = 0.f, ez = 0.f, stum = 0.f, ncontact = 0.f;
 #pragma unroll
@@ -867,6 +881,9 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         r[GRX_REW_STAND_STILL] = expf(sg[GRX_REW_STAND_STILL] * spose) * (cmd_n < 0.1f ? 1.f : 0.f);
         r[GRX_REW_TERMINATION] = (reset && !time_out) ? 1.f : 0.f;
     }
+#ifdef GRX_PROFILE_SECTIONS
+    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 16] = clock64() - tt_begin;
+#endif
     float rew = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -884,19 +901,21 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     const unsigned long long reset_mask = __ballot(reset && actl);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float es = ((P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f) + r[t];
-        if (reset_mask) {
+        const float es = es_old[t] + r[t];
+        if (reset_mask) {   // the finished episodes' sums, added in lane order: the groups' first lanes through v_readlane (an LDS shuffle per
+            // finished env and term -- 36 dependent round trips per env -- was most of this section)
+            const int esm = __float_as_int((reset && actl) ? es : 0.f);
             float acc_ = 0.f;
-            unsigned long long m = reset_mask;
-            while (m) { const int L = __ffsll((long long)m) - 1; m &= m - 1; acc_ += __shfl(es, L); }
-            if (lane == 0) s_stat[wave][t] += acc_;
+#pragma unroll
+            for (int k = 0; k < TEPW; ++k) acc_ += __int_as_float(__builtin_amdgcn_readlane(esm, k * TG));
+            if (lane == 0) s_stat[wave][t] = acc_;   // (the wave's row was zeroed at the kernel's start and this is its only writer: no read-modify-write)
         }
         if (actl && P.reward_scale_dt[t] != 0.f) {
             P.episode_sums[(size_t)t * N + e] = (reset && dbg_apply_reset) ? 0.f : es;
             if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
         }
     }
-    if (lane == 0) s_stat[wave][NT] += (float)__popcll(reset_mask);
+    if (lane == 0) s_stat[wave][NT] = (float)__popcll(reset_mask);
 #ifdef GRX_PROFILE_SECTIONS
     if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 12] = clock64() - tt_begin;
 #endif
@@ -952,7 +971,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     }
     {   // statistics row NT + 1: terrain levels after this step's curriculum moves (legged_robot.py:427-428)
         const float ls = level_sum(ea.level, actl);
-        if (lane == 0) s_stat[wave][NT + 1] += ls;
+        if (lane == 0) s_stat[wave][NT + 1] = ls;
     }
 #ifdef GRX_PROFILE_SECTIONS
     if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 13] = clock64() - tt_begin;
