@@ -729,17 +729,31 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     if (P.heading_command) ea.cmd[2] = heading_yaw_command(P, qv, B.qw);   // legged_robot.py:320-326
     float* heights = P.heights + e;   // raw measured heights: the scan's points go round the group's lanes
     float hsum = 0.f;
+    // the lane's points of the scan (k = c, c + TG, ...): unrolled over the most a lane can hold, so that the points' table reads and raster
+    // gathers are in flight together (a rolled loop made every point two exposed memory round trips), and kept in registers for the
+    // observation block below (it used to read them back from memory)
+    constexpr int HPL = (GRX_MAX_HEIGHT_POINTS + TG - 1) / TG;
+    float hraw[HPL];
+#pragma unroll
+    for (int i = 0; i < HPL; ++i) hraw[i] = 0.f;
     if (HF && P.measure_heights) {
         const float yaw_n = fmaxf(sqrtf(B.qz * B.qz + B.qw * B.qw), 1e-9f);
         const float yz = B.qz / yaw_n, yw = B.qw / yaw_n;
-        for (int k = c; k < nh; k += TG) {
-            const float h = height_sample(P, *P.tables, yz, yw, B.pos, k);
-            if (act) heights[(size_t)k * N] = h;
-            hsum += h;
+#pragma unroll
+        for (int i = 0; i < HPL; ++i) {
+            const int k = c + i * TG;
+            if (k < nh) hraw[i] = height_sample(P, *P.tables, yz, yw, B.pos, k);
+        }
+#pragma unroll
+        for (int i = 0; i < HPL; ++i) {   // (summed in the order of the rolled loop)
+            const int k = c + i * TG;
+            if (k < nh) { if (act) heights[(size_t)k * N] = hraw[i]; hsum += hraw[i]; }
         }
         hsum = grp_sum(hsum);
-    } else
-        for (int k = c; k < nh; k += TG) if (act) heights[(size_t)k * N] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < HPL; ++i) { const int k = c + i * TG; if (k < nh && act) heights[(size_t)k * N] = 0.f; }
+    }
     if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {
         B.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
         B.vel.y = urand(P, genv, step, GRX_RNG_PUSH, 1, -P.max_push_vel_xy, P.max_push_vel_xy);
@@ -983,11 +997,15 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     float bho = 0.f;
     {
         float sum = 0.f;
-        for (int k = c; k < nh; k += TG) {
-            float d = B.pos.z - P.base_height_target - heights[(size_t)k * N];
-            d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
-            if (act) pri[nobs + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -clipo), clipo);
-            sum += d;
+#pragma unroll
+        for (int i = 0; i < HPL; ++i) {
+            const int k = c + i * TG;
+            if (k < nh) {
+                float d = B.pos.z - P.base_height_target - hraw[i];
+                d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
+                if (act) pri[nobs + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -clipo), clipo);
+                sum += d;
+            }
         }
         sum = grp_sum(sum);
         bho = nh > 0 ? sum / (float)nh : 0.f;
