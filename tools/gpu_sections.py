@@ -48,6 +48,7 @@ for terrain in ("plane","heightfield"):
     print('   wave 0: duration of each of the 10 sub-steps:', np.median(full[:, 64:74], axis=0).astype(int).tolist())
     print('   obs sub-sections (cycles after tick 7): heights, noise load, side-0 puts:', np.median(full[:,11:14]-full[:,7:8],axis=0).astype(int).tolist())
     print('   relative to tick 6 (FL_REW published): wave1 got FL_REW, wave1 rewards done, wave2 got FL_HZ, wave2 heights done, wave0 tick 9:', np.median(full[:,[14,15,30,31,9]]-full[:,6:7],axis=0).astype(int).tolist())
+    print('   wave 0, store section (cycles after tick 8): leg columns stored, env columns stored, tick 9 (height-block sums in):', np.median(full[:,[93,94,9]]-full[:,8:9],axis=0).astype(int).tolist())
     d=np.diff(a,axis=1)
     print(terrain, "total cycles median", np.median(a[:,10]-a[:,0]))
     for n,v in zip(names, np.median(d,axis=0)): print(f"   {n:16s} {v:9.0f} ticks")

@@ -2032,6 +2032,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
             P.avg_speed[(size_t)(side * 3 + i) * N + e] = as_;
         }
     }
+    GRX_TICK(93);
     if (writer) {
         float rs[13] = {st.pos.x, st.pos.y, st.pos.z, st.qx, st.qy, st.qz, st.qw, st.vel.x, st.vel.y, st.vel.z, st.ang.x, st.ang.y, st.ang.z};
 #pragma unroll
@@ -2048,6 +2049,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         P.time_out[e] = time_out ? 1 : 0;
         P.term_contact[e] = term_contact ? 1 : 0;
     }
+    GRX_TICK(94);
     if (PIPE) {   // base_heights_offset: the helper waves' partial sums of the observation height block
         if (W == 8) {
             flag_wait_all(s_flag, flag_want(lane, FL_BHO1, 1, FL_BHO1 + 1, 1, FL_BHO1 + 2, 1, FL_BHO4, 1), lane);
