@@ -583,6 +583,8 @@ int build_generic(grx_sim* s, const grx_config& c) {
     }
     if (!fits) return GRX_OK;   // more chains / levels than a lane group holds: the one-lane generic kernel runs it
     K.nchain = nchain; K.nstep = nstep;
+    K.nstep_kin = 0;   // (the arms of the full body hang four levels deeper than anything the env pipeline reads)
+    for (int b : {T.foot_body[0], T.foot_body[1], T.torso_body, T.forehead_body}) if (b >= 1) K.nstep_kin = std::max(K.nstep_kin, depth[b] + 1);
     for (int c = 0; c < GRX_TREE_GMAX; ++c) {
         K.first[c] = 1; K.last[c] = 0;
         bool any = false;

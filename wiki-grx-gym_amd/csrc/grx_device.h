@@ -129,7 +129,7 @@ struct TreeTab {
     int32_t lc_begin[25];
     int32_t ncs;                                      // rounds of the contact pass
     int32_t nturn;                                    // items of one round that share a body add their forces in turns 0 .. nturn - 1
-    int32_t pad2;
+    int32_t nstep_kin;                                // depth levels that hold a foot, the torso or the forehead: all the final-frames walk needs without GRX_T_RIGID_BODY_STATES
     // the contact pass's work list: round r, lane c evaluates shapes [s0, s1) (at most two) of `body` (-1: nothing; 0: the base) on
     // the frame in LDS -- ANY lane may take any body's shapes, so the three lanes of a group that own no chain work too and a foot's
     // four spheres go to two lanes (round 4: four sphere-slots per sub-step for the full body instead of eight)

@@ -165,10 +165,12 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
     R3 Rc = R0;
     V3 rho_c = v3(0.f, 0.f, 0.f), w_c = E.B.ang, v_c = E.B.vel;
     V3 za = v3(0.f, 0.f, 0.f), zl = v3(0.f, 0.f, 0.f);
+    // final frames (KIN): only as deep as a foot, the torso, the forehead -- the arms hang four levels deeper -- unless every link frame is published
+    const int kin_levels = KIN && !P.publish_rbs ? T.nstep_kin : TNG;
 #pragma unroll
     for (int g = 0; g < TNG; ++g) {
         if (g >= T.nstep) break;   // (uniform)
-        if (G.sb[g] >= 0) {
+        if (G.sb[g] >= 0 && (!KIN || g < kin_levels)) {
             const int b = G.sb[g];
             const TreeBody& tb = T.body[b];
             const int p = tb.parent, j = b - 1;
