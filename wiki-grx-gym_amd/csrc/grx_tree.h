@@ -787,26 +787,29 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     float es_old[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) es_old[t] = (P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
-    float qd_prev[TNG];   // last_dof_vel of this lane's joints: likewise in one batch (inside the unrolled level loop each was a round trip of its own)
+    // The joint terms go round the group's lanes BY JOINT (two rounds of 16 lanes, four of 8) instead of riding on the ten depth levels of
+    // the lane's chain (a wave executes all ten whatever its lanes hold): the chains' owners publish q, qd in two slots of the body's row
+    // that are dead behind the sub-steps.
+    enum { T_QPUB = T_PL + 1, T_QDPUB = T_PL + 2 };
 #pragma unroll
-    for (int g = 0; g < TNG; ++g) qd_prev[g] = G.sb[g] >= 0 ? P.last_dof_vel[(size_t)(G.sb[g] - 1) * N + e] : 0.f;
+    for (int g = 0; g < TNG; ++g)
+        if (G.sb[g] >= 0) { TW(TBO(G.sb[g]) + T_QPUB) = G.q[g]; TW(TBO(G.sb[g]) + T_QDPUB) = G.qd[g]; }
+    tree_fence();
     {
         const float as = P.action_scale, H = P.swing_feet_height_target, Tt_ = P.feet_air_time_target;
         const GRX_AS4 float* sg = P.reward_sigma;
         float s2 = 0.f;   // DBG: the injected last_last_actions (otherwise last_last_actions == last_actions, legged_robot_fftai.py:94)
         float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
         float tor_hr = 0.f, vel_kn = 0.f, ank[2] = {0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < TNG; ++g) {
-            if (G.sb[g] < 0) continue;
-            const int j = G.sb[g] - 1;
+        for (int j = c; j < nd; j += TG) {
             const TreeDof& td = T.dof[j];
-            const float ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j), al = TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j), qj = G.q[g], qdj = G.qd[g], tj = TW(TBO(j + 1) + T_TAU);
+            const float ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j), al = TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j), tj = TW(TBO(j + 1) + T_TAU);
+            const float qj = TW(TBO(j + 1) + T_QPUB), qdj = TW(TBO(j + 1) + T_QDPUB);
             const uint32_t bit = 1u << j;
             s1 += fabsf((al - ac) * as);
             if (DBG) s2 += fabsf((al - ac) * as - (dbg[(size_t)(DBG_LAST_LAST_ACTIONS + j) * N + e] - al) * as);
             if (P.knee_mask & bit) { s3 += fabsf((ac - al) * as); vel_kn += fabsf(qdj); }
-            sacc += fabsf((qdj - qd_prev[g]) / dtp);
+            sacc += fabsf((qdj - P.last_dof_vel[(size_t)j * N + e]) / dtp);
             stor += fabsf(tj);
             svel += fabsf(qdj);
             const float po = fabsf(qj - td.q0);
@@ -1017,6 +1020,10 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     // bias-force slots of bodies 1.. (dead behind the sub-steps).  (Round 4, from the section profile: one whole Philox block per
     // observation ELEMENT, 30 per lane with the level loop unrolled, and an integer division to find the element's stream made this
     // section 40 k cycles of a 650 k step.)
+#pragma unroll
+    for (int g = 0; g < TNG; ++g)   // q, qd after reset_idx, for the joint-parallel loop below
+        if (G.sb[g] >= 0) { TW(TBO(G.sb[g]) + T_QPUB) = G.q[g]; TW(TBO(G.sb[g]) + T_QDPUB) = G.qd[g]; }
+    tree_fence();
     const int half_ = nd / 2, nblk_dof = (3 * half_ + 3) / 4, nblk = 2 + 2 * nblk_dof;
     const bool own_noise = P.add_noise && !noise_in, noise_lds = own_noise && nblk <= T.nb - 1;
     if (noise_lds) {
@@ -1047,12 +1054,9 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         };
         const float np_ = P.noise_dof_pos * P.noise_level * P.obs_scale_dof_pos, nv = P.noise_dof_vel * P.noise_level * P.obs_scale_dof_vel;
         const float nac = P.noise_action * P.noise_level * P.obs_scale_action;
-#pragma unroll
-        for (int g = 0; g < TNG; ++g) {   // this lane's joints: observations, history, state
-            if (G.sb[g] < 0) continue;
-            const int j = G.sb[g] - 1;
+        for (int j = c; j < nd; j += TG) {   // the joints go round the group's lanes (as in the reward terms): observations, history, state
             const size_t oj = (size_t)j * N + e;
-            const float qj = G.q[g], qdj = G.qd[g], ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j);
+            const float qj = TW(TBO(j + 1) + T_QPUB), qdj = TW(TBO(j + 1) + T_QDPUB), ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j);
             // dof terms: one stream per half of the dof range, item = group * (nd / 2) + joint within the half (group 0 pos, 1 vel, 2 action)
             const bool right = j >= half_;
             const uint32_t ds_ = right ? (uint32_t)GRX_RNG_NOISE_DOF_R : (uint32_t)GRX_RNG_NOISE_DOF_L;
