@@ -17,7 +17,7 @@ from wiki_grx_gym_amd.envs import build_config
 os.environ["GRX_PUBLISH_DEBUG"]="0"
 names=["load","substeps","footkin","update+heights","timers","reward","reset","obs","store","rows->HBM"]
 for terrain in ("plane","heightfield"):
-    cfg = make_cfg(noise=True, dr=True, push=True, terrain=terrain); N=4096
+    cfg = make_cfg(noise=True, dr=True, push=True, terrain=terrain); N=int(os.environ.get("N", 4096))
     cfg.env.publish_rigid_body_states = False   # as bench.py
     ter = make_terrain(cfg, N, 1)
     c,keep,_ = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
@@ -26,10 +26,10 @@ for terrain in ("plane","heightfield"):
     acts=[random_actions(cfg,N,gen,1.0).cuda() for _ in range(4)]
     for i in range(40): s.step(acts[i%4],5.0,i+1)
     torch.cuda.synchronize()
-    lib=C.CDLL(PROF); buf=(C.c_longlong*(256*96))()
+    lib=C.CDLL(PROF); buf=(C.c_longlong*(1024*96))()
     lib.grx_debug_profile.argtypes=[C.c_void_p, C.c_void_p, C.c_int]
-    nb=lib.grx_debug_profile(s._h, buf, 256)
-    full=np.array(buf[:],dtype=np.int64).reshape(256,96)[:nb]
+    nb=lib.grx_debug_profile(s._h, buf, 1024)
+    full=np.array(buf[:],dtype=np.int64).reshape(1024,96)[:nb]
     a=full[:,:11]
     print('   wave 0, sum over 10 sub-steps:', dict(zip(['wait bias forces','barrier after the sub-steps','wait foot / rare contacts','wait self-collision','wait rigid inertias','whole sub-steps'], np.median(full[:,16:22],axis=0).astype(int).tolist())))
     print('   helper waves (idle waiting for state, total) cycles:', {f"wave{w}": np.median(full[:,22+2*w:24+2*w],axis=0).astype(int).tolist() for w in (1,2,3)})
