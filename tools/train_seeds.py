@@ -1,7 +1,8 @@
 """The second half of BASELINE.json's metric on the kernels as built: GR1T1 (registered lower-limb task) on FLAT terrain, 4096 envs,
 PPO with the reference's hyper-parameters, N seeds x 1500 iterations.  Reports reward@1500 (mean of the last 100 iterations) mean +- sd
 over the seeds, episode length, wall-clock and the training env-steps/s, plus which step kernel ran (grx_layout).
-    python tools/train_seeds.py [iterations=1500] [seeds=3] [envs=4096] [terrain=plane]   ->  gpurun_out/learning_curve_<terrain>_<envs>.json"""
+    python tools/train_seeds.py [iterations=1500] [seeds=3] [envs=4096] [terrain=plane] [task=GR1T1]   ->  gpurun_out/learning_curve_<terrain>_<envs>.json
+(task GR1T1_full_body: the 32-DOF robot of BASELINE.json's fifth configuration on the tree kernel -> ..._full_body_<terrain>_<envs>.json)"""
 import contextlib, io, json, os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -10,22 +11,25 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 envs = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 terrain = sys.argv[4] if len(sys.argv) > 4 else "plane"
+task = sys.argv[5] if len(sys.argv) > 5 else "GR1T1"
+full = task == "GR1T1_full_body"
+tag = ("full_body_" if full else "") + terrain
 os.makedirs("gpurun_out", exist_ok=True)
 runs = []
 for seed in range(1, seeds + 1):
     import torch
-    from wiki_grx_gym_amd.envs import GR1T1Cfg, GR1T1CfgPPO
+    from wiki_grx_gym_amd.envs import GR1T1Cfg, GR1T1CfgPPO, GR1T1FullBodyCfg, GR1T1FullCfgPPO
     from wiki_grx_gym_amd.utils import get_args, task_registry
-    args = get_args(["--task", "GR1T1", "--headless", "--num_envs", str(envs), "--seed", str(seed), "--max_iterations", str(iters)])
-    cfg = GR1T1Cfg()
+    args = get_args(["--task", task, "--headless", "--num_envs", str(envs), "--seed", str(seed), "--max_iterations", str(iters)])
+    cfg = GR1T1FullBodyCfg() if full else GR1T1Cfg()
     cfg.terrain.mesh_type = terrain
     cfg.seed = seed
-    env, _ = task_registry.make_env("GR1T1", args=args, env_cfg=cfg)
+    env, _ = task_registry.make_env(task, args=args, env_cfg=cfg)
     layout = env._sim.layout()
-    tcfg = GR1T1CfgPPO()
+    tcfg = GR1T1FullCfgPPO() if full else GR1T1CfgPPO()
     tcfg.seed = seed
     tcfg.runner.save_interval = 10 ** 9
-    runner, tcfg = task_registry.make_alg_runner(env, name="GR1T1", args=args, train_cfg=tcfg, log_root=f"gpurun_out/train_{terrain}_s{seed}")
+    runner, tcfg = task_registry.make_alg_runner(env, name=task, args=args, train_cfg=tcfg, log_root=f"gpurun_out/train_{tag}_s{seed}")
     t0 = time.time()
     with contextlib.redirect_stdout(io.StringIO()):
         runner.learn(num_learning_iterations=iters, init_at_random_ep_len=True)
@@ -37,19 +41,20 @@ for seed in range(1, seeds + 1):
     res = {"seed": seed, "iterations": iters, "wall_s": dt, "train_env_steps_per_s": iters * 64 * envs / dt,
            "reward_at_end": float(rew[-100:].mean()), "episode_length_at_end": float(eplen[-100:].mean()),
            "first_iteration_with_reward_above_60": int(np.argmax(rew > 60.0)) if (rew > 60.0).any() else None,
+           "first_iteration_with_episode_length_above_900": int(np.argmax(eplen > 900.0)) if (eplen > 900.0).any() else None,
            "collection_s_per_iteration": float(series("Perf/collection time")[-200:].mean()), "learning_s_per_iteration": float(series("Perf/learning_time")[-200:].mean()),
            "reward_every_50": rew[::50].round(2).tolist(), "episode_length_every_50": eplen[::50].round(1).tolist(),
            "noise_std_every_100": series("Policy/mean_noise_std")[::100].round(4).tolist()}
     runs.append(res)
     print(json.dumps({k: v for k, v in res.items() if not isinstance(v, list)}), flush=True)
     r_ = np.array([r["reward_at_end"] for r in runs]); l_ = np.array([r["episode_length_at_end"] for r in runs]); w_ = np.array([r["wall_s"] for r in runs])
-    summary = {"task": "GR1T1 (lower limb), " + ("flat plane" if terrain == "plane" else terrain), "num_envs": envs, "iterations": iters, "seeds": len(runs),
+    summary = {"task": ("GR1T1 full body (32 DOF), " if full else "GR1T1 (lower limb), ") + ("flat plane" if terrain == "plane" else terrain), "num_envs": envs, "iterations": iters, "seeds": len(runs),
                "step_kernel": layout, "reward_at_1500_mean": float(r_.mean()), "reward_at_1500_sd": float(r_.std(ddof=1)) if len(runs) > 1 else None,
                "episode_length_mean": float(l_.mean()), "wall_s_mean": float(w_.mean()), "wall_s_sd": float(w_.std(ddof=1)) if len(runs) > 1 else None,
                "note": "reward_at_end = mean of Train/mean_reward over the last 100 iterations; PPO hyper-parameters of the registered GR1T1 task "
-                       "(gr1t1_lower_limb_config.py); no reference curve exists to compare with (Isaac Gym is absent: BASELINE.md)",
+                       "(gr1t1_lower_limb_config.py; the full-body task: this build's GR1T1FullCfgPPO); no reference curve exists to compare with (Isaac Gym is absent: BASELINE.md)",
                "runs": runs}
-    json.dump(summary, open(f"gpurun_out/learning_curve_{terrain}_{envs}.json", "w"), indent=1)
+    json.dump(summary, open(f"gpurun_out/learning_curve_{tag}_{envs}.json", "w"), indent=1)
     env.close()
     del runner, env
     torch.cuda.empty_cache()

@@ -1438,7 +1438,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     const int e_raw = blockIdx.x * EPB + el;
     const bool act = e_raw < N;
     const bool act0 = act && half == 0;   // the lane of a leg that stores the leg's outputs (LPE == 4: both halves hold them)
-    const int e = act ? e_raw : N - 1;
+    int e = act ? e_raw : N - 1;   // (not const: laundered behind the sub-steps, see there)
     const SideConst& C = s_tab.side[side];
     const uint32_t genv = (uint32_t)(P.env_offset + e);
     const uint32_t step = (uint32_t)common_step;
@@ -1775,6 +1775,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         }
         avg_force += grx_sqrt(dot(so.foot_force, so.foot_force));
     }
+#ifndef GRX_NO_ADDR_LAUNDER
+    // The column addresses of this lane (64-bit: base + (row * N + e) * 4) are the same for the loads above and the stores below, and
+    // the compiler kept them across the sub-steps rather than form them twice -- 31 register pairs of the 92 dwords the lane-pair
+    // eight-wave kernel had in scratch.  Behind this the env index is a new value to it, and the addresses are formed again: 60 dwords
+    // of scratch instead of 92 there (+1.5 % at 8192 envs), none and 484 registers instead of 512 in the one-wave kernel (+1 % at
+    // 32768 and 131072 envs).  Not in the lane-quad pipelines, which load that state behind the sub-steps and kept nothing (-1 %).
+    if (!kLatePost) asm volatile("" : "+v"(e));   // (the lane's side / joint offset / LDS row laundered as well: 442 registers and 41 dwords, and the same rates)
+#endif
     if (kLatePost) load_post_state();
     const float yaw_n = fmaxf(sqrtf(st.qz * st.qz + st.qw * st.qw), 1e-9f);   // normalize(): torch_utils.py:43-45
     const float yaw_z = st.qz / yaw_n, yaw_w = st.qw / yaw_n;
