@@ -17,7 +17,8 @@ is measurement only.
 Extra objects on the JSON line:
   roofline      HBM roofline of the fused step kernel: algorithmic bytes per env-step
                 (2476 B rough / 1750 B flat) x envs per launch / average kernel
-                duration measured with HIP events on the launch stream (grx_kernel_time_ms).
+                duration measured live with a HIP event pair around the timed region's launches, on the launch stream
+                ((stop - start) / steps; GRX_BENCH_EVENT_STRIDE=n: a pair around every n-th launch, grx_kernel_time_ms).
                 `kernel` / `layout`: what grx_layout() says the handle launches (not guessed from the batch size).
                 `valu_issue_frac`: the number that actually bounds this kernel -- VALU wave-instructions
                 per launch (SQ_INSTS_VALU of the committed rocprofv3 PMC pass of the same workload and batch size,
@@ -192,23 +193,37 @@ def main():
     for _ in range(args.warmup):
         counter += 1
         sim.step(pool[counter % 16], delay, counter)
-    # HIP-event window: every 8th launch (an event pair costs the stream ~7 us: a denser window would show up in `value`)
-    sim.kernel_time_ms(enable=int(os.environ.get("GRX_BENCH_EVENT_STRIDE", "8")))
+    # The step kernel's launch duration, live, by HIP events on the stream it is launched on (HipSim launches on torch's current stream):
+    # ONE pair around the K launches of the timed region -- (stop - start) / K, the gaps between back-to-back launches included, so an
+    # upper bound of the kernel's own duration (rocprofv3 reads 0.7 us less per launch at 4096 envs).  GRX_BENCH_EVENT_STRIDE=n > 0
+    # brackets every n-th launch with a pair of its own inside the library instead (rounds 1-4: a pair costs the stream ~7 us and brackets
+    # the dispatch as well -- 48.8 us where rocprofv3 reads 45.8 -- and three of them are 2 % of the driver's 20-step window).
+    ev_stride = int(os.environ.get("GRX_BENCH_EVENT_STRIDE", "0"))
+    if ev_stride > 0:
+        sim.kernel_time_ms(enable=ev_stride)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    if ev_stride <= 0:
+        ev0.record()   # (the device is idle: stamped at once; enqueued ahead of the host clock's start so that its ~5 us call is not in `value`)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         counter += 1
         sim.step(pool[counter % 16], delay, counter)
+    if ev_stride <= 0:
+        ev1.record()
     sim.wait_idle()           # spin on the library's pinned progress word until the last step has finished: the HIP
     torch.cuda.synchronize()  # runtime's own completion view was measured to lag by 10-80 ms sporadically
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms, launches = sim.kernel_time_ms(enable=False)
+    if ev_stride > 0:
+        kern_ms, launches = sim.kernel_time_ms(enable=False)
+    else:
+        kern_ms, launches = ev0.elapsed_time(ev1) / args.steps, args.steps
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -269,6 +284,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per * n_local,
                          "kernel": layout["kernel"], "kernel_ms": kern_ms, "launches_timed": launches,
+                         "kernel_ms_method": ("one HIP event pair around the timed region's launches, (stop - start) / steps: the gaps between launches included" if ev_stride <= 0
+                                              else f"HIP event pairs around every {ev_stride}th launch (each pair brackets the dispatch as well)"),
                          "algorithmic_bytes_per_env_step": bytes_per,
                          "valu_issue_frac": (valu_insts / (kern_ms * 1e-3) / VALU_ISSUE_PEAK) if (valu_insts and kern_ms > 0) else None,
                          "valu_insts_per_launch": valu_insts, "valu_issue_peak_per_s": VALU_ISSUE_PEAK, "valu_source": valu_src,
