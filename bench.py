@@ -218,7 +218,7 @@ def main():
     torch.cuda.synchronize()  # runtime's own completion view was measured to lag by 10-80 ms sporadically
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()   # (one process: the synchronize above is the bracket; a second one on an idle device is ~10 us of a 1 ms window)
     elapsed = time.perf_counter() - t0
     if ev_stride > 0:
         kern_ms, launches = sim.kernel_time_ms(enable=False)
