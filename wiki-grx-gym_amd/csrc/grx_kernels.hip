@@ -24,11 +24,19 @@
 //     (legged_robot.py:292, 317 each force one in the reference).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/grx.h"
 #include "grx_device.h"
 #include "grx_math.h"
 #include "grx_rng.h"
+// A per-env column element with the byte offset formed in 32 bits (base: a uniform pointer of KParams): `global_load v, v_off, s[base]`
+// instead of a 64-bit address per lane.  Valid while rows * N * sizeof(element) < 4 GiB (grx_create checks N).
+#if !defined(GRX_NO_GCOL) && !(defined(GRX_LPE) && GRX_LPE == 4)   // (the lane-quad pipelines: measured 1 % slower with it -- their wave 0 keeps no addresses, see the env index behind the sub-steps)
+#define GCOL(base, idx) (*reinterpret_cast<std::remove_reference_t<decltype(*(base))>*>(reinterpret_cast<char*>(const_cast<std::remove_const_t<std::remove_reference_t<decltype(*(base))>>*>(base)) + (uint32_t)((uint32_t)(idx) * (uint32_t)sizeof(*(base)))))
+#else
+#define GCOL(base, idx) ((base)[idx])
+#endif
 
 // Launch parameters live in device memory, uploaded once per handle, and are read through the CONSTANT address space
 // (like the kernarg segment: scalar loads the compiler may hoist and merge across global stores).  Passing the ~1.5 KB
@@ -1655,33 +1663,33 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
 #pragma unroll
     for (int k = 0; k < LEG; ++k) {
         size_t o = (size_t)(j0 + k) * N + e;
-        st.q[k] = P.q[o]; st.qd[k] = P.qd[o];
-        a_last[k] = P.last_actions[o];
-        LC.strength[k] = P.motor_strength[o];
+        st.q[k] = GCOL(P.q, o); st.qd[k] = GCOL(P.qd, o);
+        a_last[k] = GCOL(P.last_actions, o);
+        LC.strength[k] = GCOL(P.motor_strength, o);
         float a = actions_in ? actions_in[(size_t)e * GRX_ND + j0 + k] : 0.0f;
         a_cur[k] = fminf(fmaxf(a, C.body[k].amin), C.body[k].amax);  // clip_actions legged_robot_fftai.py:171-177
     }
-    st.pos = v3(P.root[0 * (size_t)N + e], P.root[1 * (size_t)N + e], P.root[2 * (size_t)N + e]);
-    st.qx = P.root[3 * (size_t)N + e]; st.qy = P.root[4 * (size_t)N + e]; st.qz = P.root[5 * (size_t)N + e]; st.qw = P.root[6 * (size_t)N + e];
-    st.vel = v3(P.root[7 * (size_t)N + e], P.root[8 * (size_t)N + e], P.root[9 * (size_t)N + e]);
-    st.ang = v3(P.root[10 * (size_t)N + e], P.root[11 * (size_t)N + e], P.root[12 * (size_t)N + e]);
+    st.pos = v3(GCOL(P.root, 0 * (size_t)N + e), GCOL(P.root, 1 * (size_t)N + e), GCOL(P.root, 2 * (size_t)N + e));
+    st.qx = GCOL(P.root, 3 * (size_t)N + e); st.qy = GCOL(P.root, 4 * (size_t)N + e); st.qz = GCOL(P.root, 5 * (size_t)N + e); st.qw = GCOL(P.root, 6 * (size_t)N + e);
+    st.vel = v3(GCOL(P.root, 7 * (size_t)N + e), GCOL(P.root, 8 * (size_t)N + e), GCOL(P.root, 9 * (size_t)N + e));
+    st.ang = v3(GCOL(P.root, 10 * (size_t)N + e), GCOL(P.root, 11 * (size_t)N + e), GCOL(P.root, 12 * (size_t)N + e));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        st.ax[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 0) * N + e];
-        st.ay[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e];
+        st.ax[i] = GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 0) * N + e);
+        st.ay[i] = GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 1) * N + e);
     }
     st.anchor_on = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        st.vimp[i] = P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e];   // 0: no contact; else the contact's approach speed
+        st.vimp[i] = GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 2) * N + e);   // 0: no contact; else the contact's approach speed
         if (st.vimp[i] != 0.0f) st.anchor_on |= (1u << i);
     }
-    LC.base_m = P.base_m[e];
-    LC.base_c = v3(P.base_c[e], P.base_c[(size_t)N + e], P.base_c[2 * (size_t)N + e]);
+    LC.base_m = GCOL(P.base_m, e);
+    LC.base_c = v3(GCOL(P.base_c, e), GCOL(P.base_c, (size_t)N + e), GCOL(P.base_c, 2 * (size_t)N + e));
     LC.base_I.xx = P.base_I[e]; LC.base_I.xy = P.base_I[(size_t)N + e]; LC.base_I.xz = P.base_I[2 * (size_t)N + e];
     LC.base_I.yy = P.base_I[3 * (size_t)N + e]; LC.base_I.yz = P.base_I[4 * (size_t)N + e]; LC.base_I.zz = P.base_I[5 * (size_t)N + e];
-    LC.mu = 0.5f * (P.terrain_friction + P.friction[e]);
-    LC.om_e = 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]);
+    LC.mu = 0.5f * (P.terrain_friction + GCOL(P.friction, e));
+    LC.om_e = 1.0f - 0.5f * (P.terrain_restitution + GCOL(P.restitution, e));
     LC.hmax = 0.0f;
     if (HF) {
         int ci = min(max((int)((st.pos.x + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_rows - 1);
@@ -1698,14 +1706,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     long long ep_len;
     auto load_post_state = [&]() {
 #pragma unroll
-        for (int k = 0; k < LEG; ++k) qd_last[k] = P.last_dof_vel[(size_t)(j0 + k) * N + e];
-        ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[(size_t)N + e]; ea.cmd[2] = P.commands[2 * (size_t)N + e];
-        ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[(size_t)N + e]; ea.origin[2] = P.origins[2 * (size_t)N + e];
-        ea.level = P.levels[e]; ea.type = P.types[e];
-        air_time = P.air_time[(size_t)side * N + e]; land_time = P.land_time[(size_t)side * N + e];
-        contact_last = P.feet_contact[(size_t)side * N + e] != 0;
-        bho_stale = P.base_heights_offset[e];
-        ep_len = P.ep_len[e];
+        for (int k = 0; k < LEG; ++k) qd_last[k] = GCOL(P.last_dof_vel, (size_t)(j0 + k) * N + e);
+        ea.cmd[0] = GCOL(P.commands, e); ea.cmd[1] = GCOL(P.commands, (size_t)N + e); ea.cmd[2] = GCOL(P.commands, 2 * (size_t)N + e);
+        ea.origin[0] = GCOL(P.origins, e); ea.origin[1] = GCOL(P.origins, (size_t)N + e); ea.origin[2] = GCOL(P.origins, 2 * (size_t)N + e);
+        ea.level = GCOL(P.levels, e); ea.type = GCOL(P.types, e);
+        air_time = GCOL(P.air_time, (size_t)side * N + e); land_time = GCOL(P.land_time, (size_t)side * N + e);
+        contact_last = GCOL(P.feet_contact, (size_t)side * N + e) != 0;
+        bho_stale = GCOL(P.base_heights_offset, e);
+        ep_len = GCOL(P.ep_len, e);
     };
 #ifndef GRX_LATE_POST
 #define GRX_LATE_POST 2   // 1: every pipeline, 2: the lane-quad pipelines only (measured: with lane pairs, whose wave 0 does not idle at that barrier, the late loads cost 1-2 %)
@@ -1824,9 +1832,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     avg_speed = v3(avg_speed.x / (float)P.decimation, avg_speed.y / (float)P.decimation, avg_speed.z / (float)P.decimation);
     if (!DBG && act0) {   // avg_feet_speed_rpy (legged_robot_fftai.py:81, 88): no reward term reads it -- stored at once, nothing kept live
         const float id = 1.0f / (float)P.decimation;
-        P.avg_speed_rpy[(size_t)(side * 3 + 0) * N + e] = (avg_rpy.x + fabsf(fk.ang.x)) * id;
-        P.avg_speed_rpy[(size_t)(side * 3 + 1) * N + e] = (avg_rpy.y + fabsf(fk.ang.y)) * id;
-        P.avg_speed_rpy[(size_t)(side * 3 + 2) * N + e] = (avg_rpy.z + fabsf(fk.ang.z)) * id;
+        GCOL(P.avg_speed_rpy, (size_t)(side * 3 + 0) * N + e) = (avg_rpy.x + fabsf(fk.ang.x)) * id;
+        GCOL(P.avg_speed_rpy, (size_t)(side * 3 + 1) * N + e) = (avg_rpy.y + fabsf(fk.ang.y)) * id;
+        GCOL(P.avg_speed_rpy, (size_t)(side * 3 + 2) * N + e) = (avg_rpy.z + fabsf(fk.ang.z)) * id;
     }
     float a_ll[LEG];
     bool dbg_apply_reset = true;
@@ -1850,7 +1858,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     float es_early[NT];   // running episode sums: loads issued here so their HBM latency overlaps the state update
     if (!PIPE) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) es_early[t] = (P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
+        for (int t = 0; t < NT; ++t) es_early[t] = (P.reward_scale_dt[t] != 0.f) ? GCOL(P.episode_sums, (size_t)t * N + e) : 0.f;
     }
     ep_len += 1;
     V3 qv = v3(st.qx, st.qy, st.qz);
@@ -2015,47 +2023,47 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {
             size_t o = (size_t)(j0 + k) * N + e;
-            P.q[o] = st.q[k]; P.qd[o] = st.qd[k];
-            P.last_actions[o] = a_cur[k]; P.last_dof_vel[o] = st.qd[k];
-            P.actions[o] = a_cur[k]; P.torques[o] = torque[k];
+            GCOL(P.q, o) = st.q[k]; GCOL(P.qd, o) = st.qd[k];
+            GCOL(P.last_actions, o) = a_cur[k]; GCOL(P.last_dof_vel, o) = st.qd[k];
+            GCOL(P.actions, o) = a_cur[k]; GCOL(P.torques, o) = torque[k];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            P.anchors[(size_t)((side * 4 + i) * 3 + 0) * N + e] = st.ax[i];
-            P.anchors[(size_t)((side * 4 + i) * 3 + 1) * N + e] = st.ay[i];
-            P.anchors[(size_t)((side * 4 + i) * 3 + 2) * N + e] = (st.anchor_on >> i) & 1u ? fmaxf(st.vimp[i], 1e-6f) : 0.f;
+            GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 0) * N + e) = st.ax[i];
+            GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 1) * N + e) = st.ay[i];
+            GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 2) * N + e) = (st.anchor_on >> i) & 1u ? fmaxf(st.vimp[i], 1e-6f) : 0.f;
         }
-        P.air_time[(size_t)side * N + e] = air_time * (contact_filt ? 0.f : 1.f);  // legged_robot_fftai.py:97
-        P.land_time[(size_t)side * N + e] = land_time;
-        P.feet_contact[(size_t)side * N + e] = feet_contact_obs ? 1 : 0;
-        P.feet_height[(size_t)side * N + e] = feet_height;
-        P.avg_force[(size_t)side * N + e] = avg_force;
+        GCOL(P.air_time, (size_t)side * N + e) = air_time * (contact_filt ? 0.f : 1.f);  // legged_robot_fftai.py:97
+        GCOL(P.land_time, (size_t)side * N + e) = land_time;
+        GCOL(P.feet_contact, (size_t)side * N + e) = feet_contact_obs ? 1 : 0;
+        GCOL(P.feet_height, (size_t)side * N + e) = feet_height;
+        GCOL(P.avg_force, (size_t)side * N + e) = avg_force;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             float ff = i == 0 ? so.foot_force.x : (i == 1 ? so.foot_force.y : so.foot_force.z);
             float fp = i == 0 ? fk.pos.x : (i == 1 ? fk.pos.y : fk.pos.z);
             float as_ = i == 0 ? avg_speed.x : (i == 1 ? avg_speed.y : avg_speed.z);
-            P.feet_force[(size_t)(side * 3 + i) * N + e] = ff;
-            P.feet_pos[(size_t)(side * 3 + i) * N + e] = fp;
-            P.avg_speed[(size_t)(side * 3 + i) * N + e] = as_;
+            GCOL(P.feet_force, (size_t)(side * 3 + i) * N + e) = ff;
+            GCOL(P.feet_pos, (size_t)(side * 3 + i) * N + e) = fp;
+            GCOL(P.avg_speed, (size_t)(side * 3 + i) * N + e) = as_;
         }
     }
     GRX_TICK(93);
     if (writer) {
         float rs[13] = {st.pos.x, st.pos.y, st.pos.z, st.qx, st.qy, st.qz, st.qw, st.vel.x, st.vel.y, st.vel.z, st.ang.x, st.ang.y, st.ang.z};
 #pragma unroll
-        for (int i = 0; i < 13; ++i) P.root[(size_t)i * N + e] = rs[i];
-        P.commands[e] = ea.cmd[0]; P.commands[(size_t)N + e] = ea.cmd[1]; P.commands[2 * (size_t)N + e] = ea.cmd[2];
-        P.base_lin_vel[e] = blv.x; P.base_lin_vel[(size_t)N + e] = blv.y; P.base_lin_vel[2 * (size_t)N + e] = blv.z;
-        P.base_ang_vel[e] = bav.x; P.base_ang_vel[(size_t)N + e] = bav.y; P.base_ang_vel[2 * (size_t)N + e] = bav.z;
-        P.proj_grav[e] = pg.x; P.proj_grav[(size_t)N + e] = pg.y; P.proj_grav[2 * (size_t)N + e] = pg.z;
-        P.origins[e] = ea.origin[0]; P.origins[(size_t)N + e] = ea.origin[1]; P.origins[2 * (size_t)N + e] = ea.origin[2];
-        P.levels[e] = ea.level;
-        if (!PIPE) P.base_heights_offset[e] = bho;
-        P.ep_len[e] = ep_len;
-        P.reset[e] = reset ? 1 : 0;
-        P.time_out[e] = time_out ? 1 : 0;
-        P.term_contact[e] = term_contact ? 1 : 0;
+        for (int i = 0; i < 13; ++i) GCOL(P.root, (size_t)i * N + e) = rs[i];
+        GCOL(P.commands, e) = ea.cmd[0]; GCOL(P.commands, (size_t)N + e) = ea.cmd[1]; GCOL(P.commands, 2 * (size_t)N + e) = ea.cmd[2];
+        GCOL(P.base_lin_vel, e) = blv.x; GCOL(P.base_lin_vel, (size_t)N + e) = blv.y; GCOL(P.base_lin_vel, 2 * (size_t)N + e) = blv.z;
+        GCOL(P.base_ang_vel, e) = bav.x; GCOL(P.base_ang_vel, (size_t)N + e) = bav.y; GCOL(P.base_ang_vel, 2 * (size_t)N + e) = bav.z;
+        GCOL(P.proj_grav, e) = pg.x; GCOL(P.proj_grav, (size_t)N + e) = pg.y; GCOL(P.proj_grav, 2 * (size_t)N + e) = pg.z;
+        GCOL(P.origins, e) = ea.origin[0]; GCOL(P.origins, (size_t)N + e) = ea.origin[1]; GCOL(P.origins, 2 * (size_t)N + e) = ea.origin[2];
+        GCOL(P.levels, e) = ea.level;
+        if (!PIPE) GCOL(P.base_heights_offset, e) = bho;
+        GCOL(P.ep_len, e) = ep_len;
+        GCOL(P.reset, e) = reset ? 1 : 0;
+        GCOL(P.time_out, e) = time_out ? 1 : 0;
+        GCOL(P.term_contact, e) = term_contact ? 1 : 0;
     }
     GRX_TICK(94);
     if (PIPE) {   // base_heights_offset: the helper waves' partial sums of the observation height block
@@ -2069,7 +2077,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         bho = nh > 0 ? (s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane]) / (float)nh : 0.f;
         }
         if (side == 0) prow[GRX_NUM_OBS + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
-        if (writer) P.base_heights_offset[e] = bho;
+        if (writer) GCOL(P.base_heights_offset, e) = bho;
     }
     GRX_TICK(9);
     }   // dynamics wave
