@@ -1737,9 +1737,6 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
 #else
     const SideConst& Cr = C;
 #endif
-    float a_now[LEG];
-#pragma unroll
-    for (int k = 0; k < LEG; ++k) a_now[k] = 0.f < delay ? a_last[k] : a_cur[k];
     for (int deci = 0; deci < (DBG ? 0 : P.decimation); ++deci) {
         // keep the LDS-resident robot tables in LDS: without this barrier LICM hoists ~240 loop-invariant
         // ds_reads into VGPRs and the kernel spills to scratch (measured: 604 B/lane -> 0)
@@ -1761,15 +1758,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         }
         if (PIPE) flag_set(s_flag + FL_STATE, deci + 1, lane);
         else if (W == 2) __syncthreads();   // #1
-        // (the action in force: the previous step's until the latency has passed -- switched ONCE, in the sub-step where that happens, so
-        //  that the loop carries one action per joint and not two with a select)
-        if (deci > 0 && !((float)deci < delay) && (float)(deci - 1) < delay) {   // uniform
-#pragma unroll
-            for (int k = 0; k < LEG; ++k) a_now[k] = a_cur[k];
-        }
+        const bool use_last = (float)deci < delay;
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {  // _compute_torques legged_robot.py:679-715
-            float a = a_now[k];
+            float a = use_last ? a_last[k] : a_cur[k];
             float t = C.body[k].kp * (a * P.action_scale + C.body[k].q0 - st.q[k]) - C.body[k].kd * st.qd[k];
             if (!PIPE && P.control_type != GRX_CONTROL_P)   // 'V' / 'T' (legged_robot.py:699-704): the one-wave layout only (grx_capi.cpp)
                 t = P.control_type == GRX_CONTROL_T ? a * P.action_scale
