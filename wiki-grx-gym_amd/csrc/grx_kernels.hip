@@ -58,7 +58,7 @@ typedef const GRX_AS4 KParams& KP;
 #endif
 
 #ifndef GRX_W1_SCAN_BATCH
-#define GRX_W1_SCAN_BATCH 8   // one-wave layout: heightfield gathers in flight per batch of the 121-point scan (16 and 31 measured at 32768 envs: +0.5 %, within noise)
+#define GRX_W1_SCAN_BATCH 31   // one-wave layout: heightfield gathers in flight per batch of the 121-point scan -- a lane's 61 points in two batches (8: -0.4 % at 32768 envs, -0.8 % at 131072; 16: -1 %; 61, one batch: 28 spilled dwords, -4 %; round 4, 458 registers)
 #endif
 #ifndef GRX_WPE
 #define GRX_WPE 1   // waves per SIMD the step kernel's register budget is sized for
