@@ -44,6 +44,23 @@ def test_make_env_step_and_short_training(tmp_path):
     assert all(torch.isfinite(p).all() for p in runner.algorithm.actor_critic.parameters())
 
 
+def test_create_refuses_env_counts_beyond_32_bit_column_offsets():
+    """The step kernels form a column element's byte offset in 32 bits (csrc/grx_kernels.hip GCOL): grx_create has to refuse an env
+    count whose tallest column table (GRX_MAX_HEIGHT_POINTS rows of floats) would pass 4 GiB -- before it allocates anything."""
+    import ctypes as C
+    from wiki_grx_gym_amd import sim
+    from wiki_grx_gym_amd.envs import build_config
+    from tests.helpers import make_cfg
+    cfg = make_cfg()
+    c, keep, _ = build_config.build(cfg, cfg.sim.dt, 8)
+    api = sim.load_hip_library()
+    h = C.c_void_p()
+    c.num_envs = (1 << 32) // (128 * 4)       # 8 388 608: the first count that does not fit
+    assert api["create"](C.byref(c), 0, C.byref(h)) != 0 and b"32-bit column offsets" in api["last_error"]()
+    c.num_envs = 0
+    assert api["create"](C.byref(c), 0, C.byref(h)) != 0 and b"num_envs < 1" in api["last_error"]()
+
+
 def test_native_library_is_what_runs():
     """The tensors are zero-copy views of libgrx_hip.so's device memory (no silent torch fallback)."""
     import ctypes

@@ -672,7 +672,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     const grx_model& m = c.model;
     if (c.num_envs < 1) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: num_envs < 1");
     // (the step kernels form a column element's byte offset in 32 bits -- GCOL, grx_kernels.hip: rows * N * 4 < 4 GiB for the tallest column
-    //  table, the 187-row height scan; a single MI355X holds ~100 x fewer envs than this bound)
+    //  table, the height scan's GRX_MAX_HEIGHT_POINTS rows: 8.4 M envs, ~30 x what fits one MI355X)
     if ((long long)c.num_envs * GRX_MAX_HEIGHT_POINTS * 4 >= (1ll << 32)) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: num_envs too large for 32-bit column offsets");
     // the lower-limb topology runs on the fused lane-pair kernel; every other tree on the generic-tree kernel
     int rc = check_topology(m);
