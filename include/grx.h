@@ -422,8 +422,8 @@ int grx_kernel_time_ms(grx_handle h, int enable, float* avg_ms, int64_t* launche
  * GRX_WAVES_PER_BLOCK / GRX_LANES_PER_ENV / GRX_QUAD_WAVES / GRX_TREE: reports name the kernel that ran instead of guessing it
  * (bench.py's roofline.kernel), and rank-count invariance can be pinned to one layout. */
 typedef struct grx_layout_info {
-    int32_t lanes_per_env;     /* 2: a lane per leg; 4: a lane pair per leg (grx_quad.hip); 8: the tree kernel's lane group; 1: generic */
-    int32_t waves_per_block;   /* 1, 2, 4 or 8 (the pipelines of grx_wavepipe.h); tree kernel: 2; generic: 1 */
+    int32_t lanes_per_env;     /* 2: a lane per leg; 4: a lane pair per leg (grx_quad.hip); 8 / 16: the tree kernel's lane group (grx_tree.h / grx_tree16.hip); 1: generic */
+    int32_t waves_per_block;   /* 1, 2, 4 or 8 (the pipelines of grx_wavepipe.h); tree kernel: 1, 2 or 4 (GRX_TREE_WAVES); generic: 1 */
     int32_t envs_per_block;
     int32_t num_blocks;
     char kernel[64];           /* symbol as rocprofv3 --kernel-trace prints it, e.g. "grx_step_kernel_quad<true, 8>" */
@@ -468,6 +468,11 @@ int grx_debug_spin_report(grx_handle h, uint64_t* code, int* bounded);
 
 const char* grx_last_error(void);
 int grx_abi_version(void);
+/* sizeof() of the structs that cross this boundary, as THIS library was compiled: a binding checks its own mirror against it before the
+ * first call (a short grx_step_args would be overrun by grx_step's OUT fields: INTEGRATION.md 1a, tests/test_capi.py).  -1: unknown id. */
+typedef enum grx_struct_id { GRX_STRUCT_CONFIG = 0, GRX_STRUCT_STEP_ARGS = 1, GRX_STRUCT_TENSOR_DESC = 2, GRX_STRUCT_PIPELINE_STATE = 3,
+                             GRX_STRUCT_LAYOUT_INFO = 4, GRX_STRUCT_MODEL = 5 } grx_struct_id;
+int grx_sizeof(int struct_id);
 const char* grx_reward_term_name(int term);
 
 #ifdef __cplusplus

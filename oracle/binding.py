@@ -45,6 +45,7 @@ def load(precision="f32"):
         lib.gro_debug_body_pose.argtypes = [H, C.c_int, C.c_int, dp, dp]
         lib.gro_debug_link_forces.argtypes = [H, C.c_int, dp, C.c_int]
         lib.gro_debug_terrain.argtypes = [H, C.c_double, C.c_double, dp]
+        lib.gro_debug_import_state.argtypes = [H]
         _libs[precision] = (lib, api)
     return _libs[precision]
 
@@ -102,6 +103,10 @@ class OracleSim(SimHandle):
         o, op = self._d(np.zeros(3))
         self._check(self.lib.gro_debug_terrain(self._h, float(x), float(y), op), "terrain")
         return o.copy()
+
+    def import_state(self):
+        """Continue from the state written into the published views (tests.helpers.STATE_TENSORS): gro_debug_import_state."""
+        self._check(self.lib.gro_debug_import_state(self._h), "import_state")
 
     def post_physics(self, env, ps, apply_reset, common_step_counter=1, noise_uniform=None):
         a = _capi.StepArgs()

@@ -1589,6 +1589,44 @@ int gro_episode_stats(grx_handle s, float* host_out, void* stream) {
     return GRX_OK;
 }
 
+/* TEST SUPPORT: the inverse of publish() for the simulation STATE -- what tests/helpers.STATE_TENSORS lists, i.e. exactly what the HIP
+ * library keeps between two steps.  The float32 views handed out by gro_tensor are OUTPUTS of the oracle (its state lives in `real`
+ * env_t records); a test that wants the oracle to continue from a state it wrote into those views (the perturbed twins of
+ * tests/test_hip_parity.py: the oracle's own sensitivity to a 1e-6 nudge, per env) calls this first. */
+int gro_debug_import_state(grx_handle s) {
+    if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "gro_debug_import_state: null handle");
+    const int N = s->N, nd = s->nd;
+    for (int i = 0; i < N; ++i) {
+        env_t* e = &s->env[i];
+        for (int j = 0; j < nd; ++j) {
+            e->q[j] = s->scratch[GRX_T_DOF_POS][(size_t)i * nd + j];
+            e->qd[j] = s->scratch[GRX_T_DOF_VEL][(size_t)i * nd + j];
+            e->last_actions[j] = s->scratch[GRX_T_LAST_ACTIONS][(size_t)i * nd + j];
+            e->last_last_actions[j] = e->last_actions[j];   /* legged_robot_fftai.py:94: equal after every step */
+            e->last_dof_vel[j] = s->scratch[GRX_T_LAST_DOF_VEL][(size_t)i * nd + j];
+        }
+        const float* root = s->scratch[GRX_T_ROOT_STATES] + (size_t)i * 13;
+        for (int k = 0; k < 3; ++k) { e->pos[k] = root[k]; e->vel[k] = root[7 + k]; e->ang[k] = root[10 + k]; }
+        for (int k = 0; k < 4; ++k) e->quat[k] = root[3 + k];
+        const float* an = s->scratch[GRX_T_ANCHORS] + (size_t)i * NFS * 3;
+        for (int k = 0; k < NFS; ++k) {
+            e->anchor[k][0] = an[3 * k]; e->anchor[k][1] = an[3 * k + 1];
+            e->anchor_on[k] = an[3 * k + 2] > 0.f; e->anchor_vimp[k] = an[3 * k + 2] > 0.f ? an[3 * k + 2] : 0;
+        }
+        for (int k = 0; k < 3; ++k) { e->commands[k] = s->scratch[GRX_T_COMMANDS][(size_t)i * 3 + k]; e->origin[k] = s->scratch[GRX_T_ENV_ORIGINS][(size_t)i * 3 + k]; }
+        for (int f = 0; f < 2; ++f) {
+            e->air_time[f] = s->scratch[GRX_T_FEET_AIR_TIME][(size_t)i * 2 + f];
+            e->land_time[f] = s->scratch[GRX_T_FEET_LAND_TIME][(size_t)i * 2 + f];
+            e->contact[f] = e->contact_last[f] = s->scratch_u8[GRX_T_FEET_CONTACT][2 * i + f];
+        }
+        e->base_heights_offset = s->scratch[GRX_T_BASE_HEIGHTS_OFFSET][i];
+        e->episode_length = s->t_eplen[i];
+        for (int t = 0; t < NT; ++t) e->episode_sums[t] = s->scratch[GRX_T_EPISODE_SUMS][(size_t)t * N + i];
+        e->level = s->scratch_i32[GRX_T_TERRAIN_LEVELS][i];
+    }
+    return GRX_OK;
+}
+
 const char* gro_last_error(void) { return g_err; }
 int gro_abi_version(void) { return GRX_ABI_VERSION; }
 int gro_stats_seq(grx_handle s, int64_t* out) { if (!s || !out) return fail(GRX_ERR_INVALID_ARGUMENT, "gro_stats_seq: null argument"); *out = s->seq; return GRX_OK; }

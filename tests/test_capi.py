@@ -92,3 +92,36 @@ def test_no_cpu_fallback():
     assert rc == -4 and b"no HIP device" in api["last_error"]()
     c.struct_size = 12
     assert api["create"](C.byref(c), 0, C.byref(h)) == -6
+
+
+def test_the_integration_stub_matches_the_library():
+    """INTEGRATION.md 1a is what a reference maintainer pastes: its struct mirrors are EXECUTED here (the snippet's class statements,
+    verbatim) and their sizes and fields compared with libgrx_hip.so's own sizeof (grx_sizeof) and with the tested mirror of
+    _capi.py -- round 4 shipped an ABI-3 grx_step_args there (no stats_seq), which grx_step would have overrun by 8 bytes."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = md[md.index("```python\n# legged_gym/legged_gym/envs/base/grx_backend.py"):]
+    code = code[len("```python\n"):code.index("```", 10)]
+    # keep the struct declarations only: the CDLL / torch lines need the library on the loader path and a GPU-side module
+    keep, take = [], False
+    for line in code.splitlines():
+        if line.startswith("class "):
+            take = True
+        elif line and not line.startswith(" ") and not line.startswith("class "):
+            take = False
+        if take:
+            keep.append(line)
+    ns = {"C": C}
+    exec("\n".join(keep), ns)
+    assert {"StepArgs", "TensorDesc"} <= set(ns)
+    api = _capi.bind(_lib())
+    assert api["sizeof"](_capi.STRUCT_IDS["STEP_ARGS"][0]) == C.sizeof(ns["StepArgs"]) == C.sizeof(_capi.StepArgs)
+    assert api["sizeof"](_capi.STRUCT_IDS["TENSOR_DESC"][0]) == C.sizeof(ns["TensorDesc"]) == C.sizeof(_capi.TensorDesc)
+    assert [(n, C.sizeof(t)) for n, t in ns["StepArgs"]._fields_] == [(n, C.sizeof(t)) for n, t in _capi.StepArgs._fields_]
+    assert [(n, C.sizeof(t)) for n, t in ns["TensorDesc"]._fields_] == [(n, C.sizeof(t)) for n, t in _capi.TensorDesc._fields_]
+    # and every struct of the full mirror against the library (sim.load_hip_library does this once per process)
+    for name, (sid, cls) in _capi.STRUCT_IDS.items():
+        assert api["sizeof"](sid) == C.sizeof(cls), name
+    assert api["sizeof"](99) == -1
+    assert "grx_sizeof(1) == C.sizeof(StepArgs)" in code      # the stub itself carries the check
+    hdr = open(os.path.join(ROOT, "include", "grx.h")).read()
+    assert f"#define GRX_ABI_VERSION {_capi.GRX_ABI_VERSION}" in hdr and f"ABI {_capi.GRX_ABI_VERSION})" in code

@@ -91,6 +91,7 @@ def test_steps_recorded_into_a_hip_graph_neither_pace_nor_hang():
     n = 300                                               # > the run-ahead window
     import gc
     gc.collect(); gc.disable()                            # (a handle finalised inside a capture frees device memory there: not capturable)
+    hip.flush_stats()                                     # capture starts from reduced statistics (include/grx.h grx_flush_stats)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for k in range(n):
@@ -123,6 +124,7 @@ def test_episode_statistics_survive_graph_replays(steps_in_graph):
     torch.cuda.synchronize()
     import gc
     gc.collect(); gc.disable()
+    hip.flush_stats()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for k in range(steps_in_graph):
@@ -142,6 +144,54 @@ def test_episode_statistics_survive_graph_replays(steps_in_graph):
     assert float(ref.tensor("EPISODE_STATS")[NT]) > 0 and len(seen) >= 2      # episodes did end, and the means moved between replays
     hip.step(act, 0.0, 50); ref.step(act, 0.0, 50)                             # eager launches after the replays keep agreeing
     assert torch.equal(hip.tensor("EPISODE_STATS").cpu(), ref.tensor("EPISODE_STATS").cpu())
+    for name in ("DOF_POS", "OBS", "EPISODE_LENGTH", "EPISODE_SUMS"):
+        assert torch.equal(hip.tensor(name), ref.tensor(name)), name
+
+
+def test_a_recorded_step_that_never_runs_leaves_the_statistics_alone():
+    """(i) a capture that begins with unreduced statistics is refused -- recorded, the reduction of the last eager launch's
+    rows would run at replay time on whichever launch then holds that parity; (ii) a step that was recorded but never replayed changes
+    nothing: the statistics stay those of the last eager step, and the eager steps that follow agree with a handle that never captured."""
+    from tests.helpers import make_cfg, make_sims
+    from wiki_grx_gym_amd.sim import GrxError
+    cfg = make_cfg()
+    cfg.env.episode_length_s = 0.1                       # 5 steps: time-outs inside the window
+    hip, _ = make_sims(cfg, 256)
+    ref, _ = make_sims(cfg, 256)
+    act = torch.full((256, hip.num_dofs), 0.05, device="cuda:0")
+    for s in (hip, ref):
+        s.reset_all()
+        for k in range(7):
+            s.step(act, 0.0, 1 + k)
+    torch.cuda.synchronize()
+    import gc
+    gc.collect(); gc.disable()
+    side = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(side):
+            side.wait_stream(torch.cuda.default_stream())
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin()
+            try:
+                with pytest.raises(GrxError, match="grx_flush_stats"):
+                    hip.step(act, 0.0, 8)                 # (i) statistics of step 7 are still unreduced
+            finally:
+                g.capture_end()
+        before = hip.tensor("EPISODE_STATS").clone()      # (flushes)
+        with torch.cuda.stream(side):
+            g2 = torch.cuda.CUDAGraph()
+            g2.capture_begin()
+            hip.step(act, 0.0, 8)                         # (ii) recorded, never replayed
+            g2.capture_end()
+    finally:
+        gc.enable()
+    torch.cuda.synchronize()
+    assert torch.equal(hip.tensor("EPISODE_STATS"), before)
+    assert torch.equal(hip.tensor("EPISODE_STATS").cpu(), ref.tensor("EPISODE_STATS").cpu())
+    for k in range(6):                                    # eager steps behind the dead recording: same rows, same means as without it
+        hip.step(act, 0.0, 8 + k); ref.step(act, 0.0, 8 + k)
+        torch.cuda.synchronize()
+        assert torch.equal(hip.tensor("EPISODE_STATS").cpu(), ref.tensor("EPISODE_STATS").cpu()), k
     for name in ("DOF_POS", "OBS", "EPISODE_LENGTH", "EPISODE_SUMS"):
         assert torch.equal(hip.tensor(name), ref.tensor(name)), name
 

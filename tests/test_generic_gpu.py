@@ -11,7 +11,13 @@ from tests.test_hip_parity import assert_phys, physics_lockstep
 
 pytestmark = pytest.mark.gpu
 KERNELS = pytest.mark.parametrize("kernel", ["tree", "tree16", "generic"])   # tree: 8 lanes per env (grx_tree.h), tree16: 16 (grx_tree16.hip)
-FULL_BODY_SCALE = 1.3   # x the lower-limb budgets of tests/test_hip_parity.PHYS: 1.5 x the 0.85 round 4 observed on MI355X with the joint armature (round 3: 5.0, maxima unbounded)
+# x the lower-limb budgets of tests/test_hip_parity.PHYS: 1.5 x what round 5 observed on MI355X (plane 2.44, rough terrain 5.47).  Round 4 ran at
+# 1.3 with a joint armature of 0.01 kg m^2 on ALL 32 joints -- more than an ankle's own inertia: the legs' contact dynamics were softer than the
+# lower-limb task's.  Since round 5 only the joints whose explicit damper is unstable carry it (envs/config.py GR1T1FullBodyCfg),
+# the legs run the reference's armature 0, and with the free ankle-roll joint (kp 0.25) under the stiff foot contact the body amplifies
+# rounding more than the lower-limb robot does.  Every out-of-tolerance row is still explained (tests/test_hip_parity.assert_phys).
+FULL_BODY_SCALE = 3.7
+FULL_BODY_SCALE_ROUGH = 8.2
 
 
 def pick(monkeypatch, kernel):
@@ -69,11 +75,11 @@ def test_full_body_32_dof_against_the_oracle(kernel, monkeypatch):
     # one policy step at a time from the oracle's state (the wrist joints -- 0.1 kg links on kp = 10 actuators -- sit
     # close to the explicit integrator's stability limit and amplify fp32 rounding within a few free-running steps)
     worst = physics_lockstep(hip, ora, cfg, steps=25, scale=0.3)
-    # round 4: with the joint-space armature of GR1T1FullBodyCfg (0.01 kg m^2: the wrists' explicit damper was two orders of
-    # magnitude beyond its stability limit, envs/config.py) the maxima are bounded like the lower-limb model's
+    # with the joint-space armature of GR1T1FullBodyCfg on the wrist / head / shoulder pitch + yaw joints (0.01 kg m^2: their explicit
+    # damper was up to two orders of magnitude beyond its stability limit, envs/config.py) the maxima are bounded
     assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE)
-    assert worst["FEET_POS"][0] < 1e-3 and worst["FEET_HEIGHT"][0] < 1e-3 and worst["REW"][0] < 1e-2, worst
-    assert worst["DOF_VEL"][0] < 0.5 and worst["DOF_POS"][0] < 5e-3, (worst["DOF_VEL"], worst["DOF_POS"])
+    assert worst["FEET_POS"][0] < 2e-3 and worst["FEET_HEIGHT"][0] < 2e-3 and worst["REW"][0] < 1e-2, worst   # (1.7 x observed; every row is also capped and explained by assert_phys)
+    assert worst["DOF_VEL"][0] < 0.5 and worst["DOF_POS"][0] < 1e-2, (worst["DOF_VEL"], worst["DOF_POS"])
     assert torch.isfinite(hip.tensor("OBS")).all() and torch.isfinite(hip.tensor("REW")).all()
     hip.close()
 
@@ -98,8 +104,8 @@ def test_full_body_rough_terrain_against_the_oracle(kernel, monkeypatch):
         seen["reset"] += int(o.tensor("RESET").sum())
     worst = physics_lockstep(hip, ora, cfg, steps=40, scale=0.5, check=check)
     assert seen["contact"] > 2000 and seen["reset"] > 0, seen
-    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE, hf=True)
-    assert worst["FEET_POS"][0] < 5e-3 and worst["DOF_POS"][0] < 2e-2, worst   # (an arm hitting a stair edge a rounding apart: velocity maxima are not bounded on rough terrain)
+    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE_ROUGH, hf=True)
+    assert worst["FEET_POS"][0] < 1e-2 and worst["DOF_POS"][0] < 7e-2, worst   # (an arm hitting a stair edge a rounding apart: velocity maxima are not bounded on rough terrain)
     mh = tensor_diff(hip.tensor("MEASURED_HEIGHTS"), ora.tensor("MEASURED_HEIGHTS"))
     assert mh[1] < 2e-3
     assert torch.isfinite(hip.tensor("OBS")).all() and torch.isfinite(hip.tensor("REW")).all()
@@ -217,7 +223,7 @@ def test_full_body_control_types_and_heading_against_the_oracle(kernel, ct, monk
     worst = physics_lockstep(hip, ora, cfg, steps=(2 if ct == "V" else 12), scale=(5.0 if ct == "T" else 0.3))
     assert worst["COMMANDS"][0] < 1e-4   # (heading mode: the yaw command is a float computation, atan2 -- not compared bit for bit)
     worst["COMMANDS"] = (worst["COMMANDS"][0], 0.0)
-    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE * (4.0 if ct == "V" else 1.0))
+    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE * (3.2 if ct == "V" else 1.0), chatter=(ct == "V"))   # ('V': 7.7 observed)
     hip.close()
 
 

@@ -237,3 +237,39 @@ def test_heading_command_on_the_hip_kernel():
     assert lay["kernel"].startswith("grx_step_kernel<") and lay["waves_per_block"] == 1, lay
     og.check_heading_command(sim, 1e-4)
     sim.close()
+
+
+# ---- the reference's rough raster on the HIP kernels --------------------------------------------------
+def make_hip_on_reference_raster(N, layout, monkeypatch, noise=True):
+    from wiki_grx_gym_amd.sim import HipSim
+    ter, d = og.reference_raster_terrain()
+    cfg = og.rough_cfg(noise)
+    pick_layout(monkeypatch, layout)
+    c, keep, meta = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
+    sim = HipSim(c, "cuda:0", keep)
+    lay = sim.layout()
+    name, lpe, waves = KERNEL_OF[layout]
+    assert lay["kernel"].startswith(name + "true") and lay["lanes_per_env"] == lpe and lay["waves_per_block"] == waves, lay
+    return sim, cfg, meta, d
+
+
+@LAYOUTS
+def test_get_heights_fixture_on_the_hip_kernel(layout, monkeypatch):
+    """SURVEY G-7 on the HIP height scan itself: tests/golden/terrain.npz -- the reference's raster, 64 root poses incl. negative
+    coordinates (`.long()` truncates towards zero) and poses beyond the map (index clamps 0 / dim - 2), the reference's
+    _get_heights output (legged_robot.py:1235-1274) -- through grx_debug_post_physics on every layout: MEASURED_HEIGHTS exact,
+    except scan points that sit within fp32 rounding of a cell edge (each differing point is verified to be one)."""
+    d = np.load(og.os.path.join(og.G, "terrain.npz"))
+    sim, _, _, _ = make_hip_on_reference_raster(d["root"].shape[0], layout, monkeypatch, noise=False)
+    n_edge = og.check_get_heights(sim, d, 2e-3)
+    print("height samples on a cell edge within rounding:", n_edge, "of", d["heights"].size)
+    sim.close()
+
+
+@LAYOUTS
+def test_pipeline_on_the_rough_raster_on_the_hip_kernel(layout, monkeypatch):
+    """tests/golden/pipeline_rough.npz (one reference post_physics_step on the rough raster, heights from the reference's own
+    _get_heights): the height block of pri_obs, feet_height, base_heights_offset, obs, rewards on every layout at 1e-4."""
+    sim, cfg, meta, _ = make_hip_on_reference_raster(64, layout, monkeypatch)
+    og.check_pipeline_rough(sim, cfg, meta, 1e-4)
+    sim.close()

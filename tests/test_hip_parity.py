@@ -6,6 +6,8 @@ both robots), plus size-independent properties at BASELINE.json's full sizes.
 Tolerance: 1e-4 absolute + 1e-4 relative (fp32, north_star) on every exposed tensor; discrete
 outputs (reset / time-out / contact flags / episode length / terrain levels) must be identical
 except where a threshold is hit within rounding (bounded fraction)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -45,13 +47,98 @@ def set_layout(monkeypatch, layout):
         monkeypatch.setenv("GRX_WAVES_PER_BLOCK", str(layout))
 
 
-def phys_diff(hip, ora, worst):
+# A tensor's outlier FRACTION says nothing about how far out the outliers are, nor where they sit (a bug confined to
+# 0.1 % of the envs -- one block's tail lanes -- would pass a fraction budget).  Two more bounds therefore apply to every comparison:
+#   * every env whose row is out of tolerance must be EXPLAINED -- either by a discrete contact event of this policy step that differs
+#     between the HIP kernel and the oracle (contact_events below), or by the oracle's OWN sensitivity in that env on that step: three
+#     twins of the fp32 oracle run the same step from the same state perturbed by PERT = 1e-6 relative (what separates the kernel's
+#     world-axes recursion with v_rcp / v_sin from the oracle's body-frame 6 x 6 algebra per sub-step), and the HIP row may
+#     be out by at most SENS_K x the largest response of the twins in that env.  The compliant contact (kn = 2.5e4 N/m on ~0.2 kg of
+#     effective foot mass, explicit at 500 Hz: omega dt = 0.7) amplifies such a perturbation by 1e2-1e4 within the ten sub-steps of SOME
+#     env-steps -- the twins show which.  "Unexplained" rows are counted per tensor and must be ZERO;
+#   * the error of ANY row is capped at HARD_CAP x its tolerance -- explained or not.
+PERT = float(os.environ.get("GRX_PHYS_PERT", "1e-6"))
+SENS_K = 10.0
+# (error / tolerance of the worst row of any GPU test, explained rows included: 1.7 x what round 5's calibration runs showed on MI355X --
+#  profiles/r05_phys_fracs_calibration.jsonl; a toe or a forearm that catches a stair edge on one side and clears it on the other is worth
+#  4 rad/s on a 0.5 kg link within a policy step)
+HARD_CAP = {"DOF_VEL": 1500.0, "LAST_DOF_VEL": 1500.0, "ROOT_STATES": 1300.0, "TORQUES": 800.0, "DOF_POS": 700.0}
+HARD_CAP_DEFAULT = 200.0
+# Heightfields add a discrete event the detector below cannot see from the outside: WHICH raster cell a contact sphere (or a scan point) is
+# over.  A sphere within rounding of a cell edge / stair riser takes the other cell on one side; a twin explains it only if one of its
+# random nudges crosses the same edge (six twins there: > 98 % of such rows).  What is left is bounded in number and in size.
+HF_UNEXPLAINED_FRAC = 1e-3     # of the env-steps of a test, per tensor
+HF_UNEXPLAINED_CAP = 15.0      # x tolerance
+PERT_ABS = {"DOF_POS": 0.1, "DOF_VEL": 0.1, "ROOT_STATES": 1.0, "ANCHORS": 0.0}     # floor of |x| in the relative perturbation
+
+
+def oracle_twin(ora):
+    """A second fp32 oracle on the same config struct (SimHandle keeps it alive in _keep)."""
+    from oracle.binding import OracleSim
+    t = OracleSim(ora._keep[-1], "f32", ora._keep[:-1])
+    t.reset_all()
+    return t
+
+
+def perturbed_copy(ora, twin, gen):
+    """twin <- the oracle's complete simulation state, with (q, qd, root, anchor xy) moved by PERT relative, random signs."""
+    from tests.helpers import STATE_TENSORS
+    for name in STATE_TENSORS:
+        src = ora.tensor(name)
+        if name in PERT_ABS:
+            u = torch.rand(src.shape, generator=gen) * 2 - 1
+            d = PERT * (src.abs() + PERT_ABS[name]) * u
+            if name == "ANCHORS":
+                d[..., 2] = 0          # (the active flag / approach speed column)
+            src = src + d.to(src.dtype)
+        twin.tensor(name).copy_(src)
+    twin.import_state()
+
+
+def contact_events(hip, ora, pre_on):
+    """(N,) bool: envs in which a discrete contact event of this policy step DIFFERS between the two sides: a foot sphere's friction
+    anchor is active on one side only, or was captured / dragged at a different place (the sub-step of first touch, or a stick -> slip
+    clamp, differs: the anchor is the contact point at that instant, so it moves by v dt ~ millimetres per sub-step -- rounding moves it by
+    1e-7); FEET_CONTACT, TERM_CONTACT or RESET differ; or a link other than the feet carries load on one side only."""
+    ah, ao = hip.tensor("ANCHORS").detach().cpu(), ora.tensor("ANCHORS")
+    on_h, on_o = ah[..., 2] > 0, ao[..., 2] > 0
+    ev = (on_h != on_o).any(1)
+    both = on_h & on_o
+    ev |= (((ah[..., :2] - ao[..., :2]).abs().amax(-1) > 1e-4) & both).any(1)
+    ev |= ((ah[..., 2] - ao[..., 2]).abs() > 1e-3).any(1) & both.any(1)        # approach speed at the first touch (restitution's memory)
+    for name in ("FEET_CONTACT", "TERM_CONTACT", "RESET"):
+        a, b = hip.tensor(name).cpu().to(torch.int64), ora.tensor(name).to(torch.int64)
+        ev |= (a != b).reshape(a.shape[0], -1).any(1)
+    ch, co = hip.tensor("CONTACT_FORCES").detach().cpu().abs().sum(2) > 1e-3, ora.tensor("CONTACT_FORCES").abs().sum(2) > 1e-3   # (N, links)
+    ev |= (ch != co).any(1)
+    return ev
+
+
+def phys_diff(hip, ora, worst, pre_on=None, twins=()):
+    ev = contact_events(hip, ora, pre_on) if pre_on is not None else None
+    q = worst.setdefault("_rows", {})   # name -> [max error / tol over all rows, the same over rows that are neither events nor sensitive, unexplained rows, event envs, envs, largest err / response]
     for name, (atol, rtol, _) in PHYS.items():
         a, b = hip.tensor(name).detach().cpu().double(), ora.tensor(name).double()
         err = (a - b).abs()
-        frac = float((err > atol + rtol * b.abs()).double().mean())
+        tol = atol + rtol * b.abs()
+        frac = float((err > tol).double().mean())
         w = worst.get(name, (0.0, 0.0))
         worst[name] = (max(w[0], float(err.max())), max(w[1], frac))
+        if ev is not None and atol > 0:
+            N = err.shape[0]
+            ratio = (err / tol).reshape(N, -1).amax(1)            # per env
+            sens = torch.zeros(N, dtype=torch.float64)
+            for t in twins:                                       # the oracle's own response to a PERT-sized nudge of the state, per env
+                sens = torch.maximum(sens, ((t.tensor(name).double() - b).abs() / tol).reshape(N, -1).amax(1))
+            explained = ev | (ratio <= SENS_K * sens)
+            r = q.setdefault(name, [0.0, 0.0, 0, 0, 0, 0.0])
+            r[0] = max(r[0], float(ratio.max()))
+            if (~explained).any():
+                r[1] = max(r[1], float(ratio[~explained].max()))
+            out = (ratio > 1.0) & ~ev
+            if out.any():
+                r[5] = max(r[5], float((ratio[out] / sens[out].clamp_min(1e-3)).max()))
+            r[2] += int(((ratio > 1.0) & ~explained).sum()); r[3] += int(ev.sum()); r[4] += int(ev.numel())
     for name in CMP_EXACT:
         a, b = hip.tensor(name).cpu().to(torch.int64), ora.tensor(name).to(torch.int64)
         w = worst.get(name, (0.0, 0.0))
@@ -75,6 +162,11 @@ def report_phys(worst, exact_frac, scale, hf=False):
     top = sorted(need.items(), key=lambda kv: -kv[1])[:3]
     rec = {"test": os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], "scale": scale, "exact_frac": exact_frac,
            "needed_scale": round(max(need.values()), 3), "top": [(n, round(v, 3), worst[n][1]) for n, v in top]}
+    rows = worst.get("_rows", {})
+    if rows:   # per tensor: [max error / tolerance, the same over unexplained envs, unexplained rows, largest (error / twins' response) among non-event outliers]; event envs / env-steps
+        rec["rows"] = {n: [round(r[0], 2), round(r[1], 3), r[2], round(r[5], 2)] for n, r in rows.items() if r[0] > 1.0}
+        any_r = next(iter(rows.values()))
+        rec["event_envs"], rec["env_steps"] = any_r[3], any_r[4]
     print("assert_phys:", json.dumps(rec))
     try:
         os.makedirs("gpurun_out", exist_ok=True)
@@ -84,13 +176,26 @@ def report_phys(worst, exact_frac, scale, hf=False):
         pass
 
 
-def assert_phys(worst, exact_frac=5e-3, scale=1.0, hf=False):
+def assert_phys(worst, exact_frac=5e-3, scale=1.0, hf=False, chatter=False):
     """Every tensor's outlier fraction within its budget x scale.  The scales in this suite are 1.5 x the fraction observed on
     MI355X (gpurun_out/phys_fracs.jsonl of round 4, copied to profiles/r04_phys_fracs.jsonl), never below 1."""
     report_phys(worst, exact_frac, scale, hf)
     bad = [(n, worst[n]) for n, (_, _, fr) in PHYS.items() if worst[n][1] > fr * scale * (HF_BUDGET.get(n, 1.0) if hf else 1.0)]
     bad += [(n, worst[n]) for n in CMP_EXACT if worst[n][1] > exact_frac * scale]
     assert not bad, bad
+    rows = worst.get("_rows", {})
+    if os.environ.get("GRX_PHYS_CALIBRATE"):     # calibration runs (tools/): report, do not fail
+        return
+    beyond = {n: round(r[0], 1) for n, r in rows.items() if r[0] > HARD_CAP.get(n, HARD_CAP_DEFAULT)}
+    assert not beyond, f"maximum error / tolerance beyond the hard cap: {beyond}"
+    if chatter:      # (a control law that chatters between the effort limits by construction: rounding decides every row -- see the caller)
+        return
+    if hf:
+        unexplained = {n: (r[2], round(r[1], 2)) for n, r in rows.items() if r[2] > max(1.0, HF_UNEXPLAINED_FRAC * r[4]) or (r[2] > 0 and r[1] > HF_UNEXPLAINED_CAP)}
+    else:
+        unexplained = {n: (r[2], round(r[1], 2)) for n, r in rows.items() if r[2] > 0}
+    assert not unexplained, ("rows out of tolerance in envs with neither a differing contact event nor a matching sensitivity of the oracle "
+                             f"(tensor: (rows, largest error / tolerance among them)): {unexplained}")
 
 
 def assert_worst(worst, exact_frac=2e-3):  # strict 1e-4 on everything
@@ -99,19 +204,28 @@ def assert_worst(worst, exact_frac=2e-3):  # strict 1e-4 on everything
     assert not bad, bad
 
 
-def physics_lockstep(hip, ora, cfg, steps, seed=0, scale=0.5, delay=5.0, noise=False, start=1, check=None):
+def physics_lockstep(hip, ora, cfg, steps, seed=0, scale=0.5, delay=5.0, noise=False, start=1, check=None, twins=3):
     gen = torch.Generator().manual_seed(seed)
+    pgen = torch.Generator().manual_seed(1000 + seed)
     N = ora.num_envs
     worst = {}
+    if twins and cfg.terrain.mesh_type != "plane":
+        twins *= 2        # (cell edges: see HF_UNEXPLAINED_FRAC)
+    tw = [oracle_twin(ora) for _ in range(twins)]
     for s in range(steps):
         if s > 0:
             sync_state(hip, ora)
+        for t in tw:
+            perturbed_copy(ora, t, pgen)
         a = random_actions(cfg, N, gen, scale)
         nz = torch.rand(N, 39, generator=gen).contiguous() if noise else None
+        pre_on = (ora.tensor("ANCHORS")[..., 2] > 0).clone()      # (both sides start the step from this state)
         ora.step(a, delay, start + s, nz)
         hip.step(a.cuda(), delay, start + s, nz.cuda() if noise else None)
+        for t in tw:
+            t.step(a, delay, start + s, nz)
         torch.cuda.synchronize()
-        phys_diff(hip, ora, worst)
+        phys_diff(hip, ora, worst, pre_on, tw)
         if check:
             check(s, hip, ora)
     return worst

@@ -390,3 +390,111 @@ def test_heading_command_matches_the_reference(precision, tol):
     cfg.commands.heading_command = True
     c, keep, meta = build_config.build(cfg, cfg.sim.dt, 64)
     check_heading_command(OracleSim(c, precision, keep), tol)
+
+
+# ---- the reference's rough-terrain raster: _get_heights and one post_physics_step ON it (tests/golden/terrain.npz, pipeline_rough.npz) ----
+def reference_raster_terrain():
+    """The reference's own 10 x 20 curriculum raster (seed 1) and tile origins as build_config.build's `terrain` argument."""
+    import types
+    d = np.load(os.path.join(G, "terrain.npz"))
+    return types.SimpleNamespace(heightsamples=d["heightsamples"].copy(), env_origins=d["env_origins"].astype(np.float32).copy()), d
+
+
+def rough_cfg(noise=True):
+    return make_cfg(noise=noise, dr=False, terrain="heightfield")
+
+
+def get_heights_states(d):
+    """terrain.npz's 64 root poses (incl. negative coordinates and poses beyond the map: the clamps of legged_robot.py:1262-1265)."""
+    from oracle.binding import PipelineState
+    N = d["root"].shape[0]
+    arr = (PipelineState * N)()
+    for i in range(N):
+        for k in range(13):
+            arr[i].root[k] = float(d["root"][i][k])
+        arr[i].torso_R[0] = arr[i].torso_R[4] = arr[i].torso_R[8] = 1.0
+    return arr
+
+
+def check_get_heights(sim, d, max_frac):
+    """MEASURED_HEIGHTS of `sim` (oracle or HIP) on terrain.npz's poses against the reference's _get_heights (legged_robot.py:1235-1274).
+    Heights are quantised (min of three raster corners at a truncated cell index): a scan point within fp32 rounding of a cell edge may
+    read the neighbouring cell -- every differing point must BE such a point (fp64 distance to the edge < 1e-3 cells), and there may be
+    at most max_frac of them."""
+    inject(sim, get_heights_states(d))
+    got = T_(sim, "MEASURED_HEIGHTS").numpy()
+    bad = np.abs(got - d["heights"]) > 1e-6
+    cfg = rough_cfg()
+    hp = np.asarray(sim_height_points(cfg), dtype=np.float64)                      # (121, 2) base-frame points
+    q = d["root"][:, 3:7].astype(np.float64)
+    n2 = q[:, 2] ** 2 + q[:, 3] ** 2                                               # quat_apply_yaw: yaw of the normalised (0, 0, z, w)
+    c, s = (q[:, 3] ** 2 - q[:, 2] ** 2) / n2, 2 * q[:, 2] * q[:, 3] / n2
+    x = c[:, None] * hp[None, :, 0] - s[:, None] * hp[None, :, 1] + d["root"][:, 0:1].astype(np.float64)
+    y = s[:, None] * hp[None, :, 0] + c[:, None] * hp[None, :, 1] + d["root"][:, 1:2].astype(np.float64)
+    f = np.stack([x, y], -1) + cfg.terrain.border_size
+    f = f / cfg.terrain.horizontal_scale
+    edge = np.abs(f - np.rint(f)).min(-1) < 1e-3
+    assert not (bad & ~edge).any(), f"{(bad & ~edge).sum()} height samples differ away from any cell edge"
+    assert bad.mean() <= max_frac, f"{bad.sum()} of {bad.size} height samples differ"
+    # the fixture's clamp rows are clamp rows: env 0 sits below index 0 on both axes, env 1 beyond dim - 2
+    assert d["root"][0, 0] < -25 and d["root"][1, 0] > 105 and (d["root"][:, 0] < 0).sum() >= 2
+    return int(bad.sum())
+
+
+def sim_height_points(cfg):
+    """measured_points_x x measured_points_y in meshgrid order (legged_robot.py:1219-1233)."""
+    xs, ys = cfg.terrain.measured_points_x, cfg.terrain.measured_points_y
+    return [(x, y) for x in xs for y in ys]
+
+
+def test_get_heights_fixture_on_the_oracle():
+    from oracle.binding import OracleSim
+    ter, d = reference_raster_terrain()
+    cfg = rough_cfg()
+    N = d["root"].shape[0]
+    for prec, frac in (("f64", 0.0), ("f32", 2e-3)):
+        c, keep, _ = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
+        check_get_heights(OracleSim(c, prec, keep), d, frac)
+
+
+def check_pipeline_rough(sim, cfg, meta, tol):
+    """pipeline_rough.npz: one reference post_physics_step() on the rough raster, heights from the reference's own _get_heights
+    inside the step: the 121-entry height block of pri_obs (gr1t1.py:281-313: clip(z - target - h_k) x 5 x 5,
+    Q5), feet_height = mean_k(z_foot - h_k) (legged_robot_fftai.py:118-124), base_heights_offset, rewards that read them."""
+    d = np.load(os.path.join(G, "pipeline_rough.npz"))
+    N = d["in_root"].shape[0]
+    names = list(d["reward_names"])
+    assert names == meta["active_terms"]
+    inject(sim, states_from(d, "in_", N), common_step_counter=1, noise_uniform=torch.tensor(d["noise_u"]).contiguous())
+    keep = ~np.any(d["out_commands_after"] != d["in_commands"], axis=1)     # rows whose commands the step redrew (RNG)
+    assert keep.sum() >= N - 3
+
+    def close(name, got, want, rows=np.ones(N, bool), t=tol):
+        got, want = np.asarray(got, dtype=np.float64)[rows], np.asarray(want, dtype=np.float64)[rows]
+        err = np.abs(got - want)
+        assert (err <= t + t * np.abs(want)).all(), f"{name}: max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    mh = T_(sim, "MEASURED_HEIGHTS").numpy()
+    np.testing.assert_allclose(mh, d["out_measured_heights"], atol=1e-6, rtol=0)        # every scan point reads the reference's cell
+    assert d["out_measured_heights"].std(axis=1).max() > 0.05                             # ... on terrain that is not flat
+    close("feet_height", T_(sim, "FEET_HEIGHT"), d["out_feet_height"])
+    close("base_heights_offset", T_(sim, "BASE_HEIGHTS_OFFSET"), d["out_base_heights_offset_after"])
+    pri = T_(sim, "PRI_OBS").numpy()
+    close("pri_obs height block", pri[:, 47:168], d["out_pri_obs"][:, 47:168])
+    hb = d["out_pri_obs"][:, 47:168]
+    assert (np.abs(hb) == 25.0).any() and (np.abs(hb) < 24.0).any()                      # clipped (x25: Q5) and free entries both occur
+    close("pri_obs", pri, d["out_pri_obs"], keep)
+    close("obs", T_(sim, "OBS"), d["out_obs"], keep)
+    close("rew", T_(sim, "REW"), d["out_rew"], keep)
+    np.testing.assert_array_equal(T_(sim, "RESET").numpy().astype(bool), d["out_reset"].astype(bool))
+    np.testing.assert_array_equal(T_(sim, "FEET_CONTACT").numpy().astype(bool), d["out_feet_contact"].astype(bool))
+    term_idx = [_capi.REWARD_TERMS.index(n) for n in names]
+    close("episode_sums", T_(sim, "EPISODE_SUMS").numpy()[term_idx].T, d["out_episode_sums"].T, keep)
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 2e-6), ("f32", 1e-4)])
+def test_pipeline_on_the_rough_raster(precision, tol):
+    from oracle.binding import OracleSim
+    ter, _ = reference_raster_terrain()
+    cfg = rough_cfg()
+    c, keep, meta = build_config.build(cfg, cfg.sim.dt, 64, terrain=ter)
+    check_pipeline_rough(OracleSim(c, precision, keep), cfg, meta, tol)

@@ -391,3 +391,32 @@ def test_single_pendulum_period_of_one_leg_link():
     # (the tensors are published in fp32: a crossing time is good to ~1e-6 s)
     assert abs(T - 2 * np.pi / wd) < 2e-6 * T, (T, 2 * np.pi / wd)
     assert abs(T - 2 * np.pi / w) < 1.5 * (w * dt) ** 2 / 24 * T + 2e-6 * T
+
+
+def test_import_state_continues_bit_for_bit():
+    """gro_debug_import_state (test support of the oracle: the inverse of its publish step for tests.helpers.STATE_TENSORS) -- a twin
+    oracle that imports the state of another one reproduces that one's next policy step BIT FOR BIT, through contact, resets and
+    the curriculum; nudged by 1e-6 it does not (what tests/test_hip_parity.py's sensitivity twins rely on)."""
+    import tests.test_hip_parity as hp
+    from tests.helpers import CMP_EXACT, CMP_TENSORS, make_cfg, make_sims, random_actions
+    cfg = make_cfg(terrain="heightfield", dr=True, push=True, noise=True)
+    cfg.env.episode_length_s = 0.5
+    _, ora = make_sims(cfg, 48, hip=False)
+    ora.reset_all()
+    exact, nudged = hp.oracle_twin(ora), hp.oracle_twin(ora)
+    gen, pg = torch.Generator().manual_seed(0), torch.Generator().manual_seed(1)
+    moved = 0.0
+    for s in range(30):
+        keep, hp.PERT = hp.PERT, 0.0
+        try:
+            hp.perturbed_copy(ora, exact, pg)
+        finally:
+            hp.PERT = keep
+        hp.perturbed_copy(ora, nudged, pg)
+        a = random_actions(cfg, 48, gen, 0.5)
+        for sim in (ora, exact, nudged):
+            sim.step(a, 5.0, s + 1)
+        for name in CMP_TENSORS + CMP_EXACT:
+            assert torch.equal(exact.tensor(name), ora.tensor(name)), (s, name)
+        moved = max(moved, float((nudged.tensor("DOF_VEL") - ora.tensor("DOF_VEL")).abs().max()))
+    assert int(ora.tensor("EPISODE_LENGTH").min()) < 25 and moved > 1e-5      # resets happened; the nudge is felt

@@ -369,6 +369,81 @@ def gen_pipeline(out):
     np.savez(os.path.join(out, "pipeline.npz"), **data)
 
 
+def gen_pipeline_rough(out):
+    """One reference post_physics_step() ON THE ROUGH-TERRAIN RASTER: the raster of terrain.npz (seed 1,
+    10 x 20 curriculum tiles), the reference's own _get_heights (legged_robot.py:1235-1274) inside the step, so that the 121-entry
+    height block of pri_obs with NON-UNIFORM heights, feet_height = mean(z_foot - h_k) (legged_robot_fftai.py:118-124), the x25
+    scaling (gr1t1.py:281-313, Q5) and base_heights_offset come from the reference on a real raster.  A scan point within fp32
+    rounding of a cell edge may legitimately read the neighbouring cell; poses are redrawn until every point of the env sits at
+    least 5e-4 cells (5e-5 m) from an edge in fp64, so the fixture compares without an allowance."""
+    from legged_gym.utils.terrain import Terrain
+    from legged_gym.envs.base.legged_robot_config import LeggedRobotCfg
+    from legged_gym.utils.math import quat_apply_yaw
+    tcfg = LeggedRobotCfg.terrain()
+    tcfg.mesh_type = "heightfield"
+    np.random.seed(1)
+    ter = Terrain(tcfg, 64)          # the raster of terrain.npz (same seed, same call): the tests load it from there
+    N = 64
+    env, g, body_names = make_ref_env(N, 31, terrain_obj=ter)
+    env.cfg.domain_rand.push_robots = False
+    assert env.cfg.terrain.measure_heights
+    noise_u = torch.rand(N, 39, generator=g)
+    randomize_state(env, g, body_names, N, 0)
+    hs = torch.tensor(ter.heightsamples.astype(np.int64))
+    feet = env.feet_indices
+    torso = int(env.torso_indices[0])
+
+    def edge_margin(i):
+        pts = quat_apply_yaw(env.base_quat[i:i + 1].repeat(1, 121), env.height_points[i:i + 1]).double() + env.root_states[i:i + 1, :3].double().unsqueeze(1)
+        f = (pts[0, :, :2] + tcfg.border_size) / tcfg.horizontal_scale
+        return float((f - torch.round(f)).abs().min())
+    redraws = 0
+    for i in range(N):
+        while True:
+            # over the tiles (10 rows x 8 m, 20 columns x 8 m), yaw anywhere, modest tilt; rows 0 / 1 keep randomize_state's poses near
+            # the map corner: the border flat and the first tile
+            if i >= 2:
+                env.root_states[i, 0] = torch.rand((), generator=g) * 78 + 1
+                env.root_states[i, 1] = torch.rand((), generator=g) * 158 + 1
+            env.root_states[i, 3:7] = rand_quat(1, g, tilt=0.4)[0] if i not in (8, 9) else env.root_states[i, 3:7]
+            if edge_margin(i) >= 5e-4:
+                break
+            if i < 2:
+                env.root_states[i, 0:2] += 0.013
+            redraws += 1
+    # heights under the base: put the base and the feet at plausible heights ABOVE the local terrain
+    px = ((env.root_states[:, 0] + tcfg.border_size) / tcfg.horizontal_scale).long().clip(0, hs.shape[0] - 2)
+    py = ((env.root_states[:, 1] + tcfg.border_size) / tcfg.horizontal_scale).long().clip(0, hs.shape[1] - 2)
+    ground = hs[px, py].float() * tcfg.vertical_scale
+    env.root_states[:, 2] = ground + 0.6 + 0.5 * torch.rand(N, generator=g)
+    env.root_states[11, 2] = ground[11] + 2.5        # clip(z - target - h_k, -1, 1) saturates at +1 -> +25 in pri_obs (Q5) ...
+    env.root_states[12, 2] = ground[12] - 0.5        # ... and at -1 -> -25
+    env.rigid_body_states[:, :, 0:3] = env.root_states[:, None, 0:3]
+    env.rigid_body_states[:, feet, 2] = ground[:, None] + torch.rand(N, 2, generator=g) * 0.25
+    env.rigid_body_states[:, torso, 3:7] = env.root_states[:, 3:7]
+    inp = snapshot_inputs(env)
+    env.reset_idx = lambda ids: None
+    orig_rand_like = torch.rand_like
+    torch.rand_like = lambda t, _u=noise_u: _u.clone()
+    try:
+        env.post_physics_step()
+    finally:
+        torch.rand_like = orig_rand_like
+    mh = env.measured_heights.numpy().copy()
+    assert mh.std(axis=1).max() > 0.05 and (mh.std(axis=1) > 1e-3).sum() > N // 2, "the scans must see non-uniform terrain"
+    outd = dict(obs=torch.clip(env.obs_buf, -100, 100).numpy().copy(), pri_obs=torch.clip(env.pri_obs_buf, -100, 100).numpy().copy(),
+                rew=env.rew_buf.numpy().copy(), reset=env.reset_buf.numpy().copy(), time_out=env.time_out_buf.numpy().copy(),
+                measured_heights=mh, feet_height=env.feet_height.numpy().copy(), feet_contact=env.feet_contact.numpy().copy(),
+                base_heights_offset_after=env.base_heights_offset.numpy().copy(), commands_after=env.commands.numpy().copy(),
+                episode_sums=np.stack([env.episode_sums[n].numpy().copy() for n in env.reward_names]))
+    data = {"in_" + k: v for k, v in inp.items()}
+    data.update({"out_" + k: v for k, v in outd.items()})
+    data["noise_u"] = noise_u.numpy()
+    data["reward_names"] = np.array(env.reward_names)
+    data["redraws"] = redraws
+    np.savez_compressed(os.path.join(out, "pipeline_rough.npz"), **data)
+
+
 def gen_reward_terms(out):
     """Every implemented FF/G1 reward term (active or not) evaluated by the reference on one state."""
     N = 64
@@ -508,10 +583,15 @@ def gen_ppo(out):
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_stub()
+    if len(sys.argv) > 1:            # python tools/gen_golden.py gen_pipeline_rough  -> only the named fixtures
+        for name in sys.argv[1:]:
+            globals()[name](OUT)
+        return
     gen_quat(OUT)
     gen_torques(OUT)
     gen_control_modes(OUT)
     gen_pipeline(OUT)
+    gen_pipeline_rough(OUT)
     gen_reward_terms(OUT)
     gen_terrain_and_heights(OUT)
     gen_terrain_all_tiles(OUT)

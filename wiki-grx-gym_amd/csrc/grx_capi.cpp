@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <deque>
+#include <memory>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -115,7 +116,9 @@ struct grx_sim {
     int tree_waves = 2;    // 8-env waves per block of the tree kernel: 2 while those blocks fit the CUs in one round, else 4 (a whole CU's LDS)
     float* d_ws = nullptr; // generic workspace
     int64_t seq = 0;       // launches of this handle that write statistics rows (steps, resets, debug steps; recorded ones too)
-    bool stats_current = true;   // GRX_T_EPISODE_STATS already holds the statistics of launch `seq` (grx_flush_stats)
+    int64_t eager_seq = 0; // ... the last of them that was launched eagerly (its rows are what grx_flush_stats reduces)
+    bool stats_current = true;   // GRX_T_EPISODE_STATS already holds the statistics of the last EAGER launch (grx_flush_stats)
+    bool prev_recorded = false;  // the last launch in host order was recorded into a graph: its successor must not fold "launch seq - 1"
     uint8_t* d_mask = nullptr;   // grx_reset_idx: per-env flags
     int gen_epb = 64;      // generic kernel: envs per (single-wave) block
     int gen_lds = 0;       // generic kernel: bytes of dynamic LDS when the workspace lives there (0: global memory)
@@ -304,7 +307,8 @@ int build_side_tables(const grx_config& c, KTables& P, uint32_t* ll_mask, uint64
             if (tsel < 0 || tsel > 1) return fail(GRX_ERR_UNSUPPORTED_MODEL, "base-lump / thigh self-collision: unknown thigh shape");
             int at = -1;   // one entry per base-lump sphere (entries of one link stay adjacent: the pairs arrive sorted by sphere)
             for (int n = 0; n < S.nbc; ++n)
-                if (S.bc[n].x == m.sph_pos[ia][0] && S.bc[n].y == m.sph_pos[ia][1] && S.bc[n].z == m.sph_pos[ia][2] && S.bc[n].link == m.sph_link[ia]) at = n;
+                if (S.bc[n].x == m.sph_pos[ia][0] && S.bc[n].y == m.sph_pos[ia][1] && S.bc[n].z == m.sph_pos[ia][2] && S.bc[n].link == m.sph_link[ia] &&
+                    S.bc[n].r == m.sph_radius[ia] && S.bc[n].dmax == m.sph_damp_max[ia]) at = n;   // (coincident spheres of different size or damping stay apart)
             if (at < 0) {
                 if (S.nbc >= GRX_MAX_BC) return fail(GRX_ERR_UNSUPPORTED_MODEL, "base-lump / thigh self-collision table overflow");
                 at = S.nbc++;
@@ -681,7 +685,19 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
         if (!(m.dof_armature[j] >= 0.f)) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: negative joint armature");
         armature = armature || m.dof_armature[j] != 0.f;
     }
-    const bool generic = rc != GRX_OK || armature || getenv("GRX_FORCE_GENERIC") != nullptr;
+    bool generic = rc != GRX_OK || armature || getenv("GRX_FORCE_GENERIC") != nullptr;
+    // control_type outside {P, V, T}: the reference raises (legged_robot.py:707); a C caller gets the status code (the Python host raises NameError before)
+    if (c.control_type != GRX_CONTROL_P && c.control_type != GRX_CONTROL_V && c.control_type != GRX_CONTROL_T)
+        return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: control_type must be GRX_CONTROL_P, _V or _T");
+    // the fused lower-limb kernels hold fixed-size shape / pair tables: a lower-limb model that overflows them (say, more base-lump spheres near
+    // the thighs than GRX_MAX_BC) is not refused -- it runs on the tree kernel like every other model
+    std::unique_ptr<KTables> side_tab(new KTables());
+    uint32_t side_ll = 0; uint64_t side_sp = 0;
+    if (!generic) {
+        const int rs = build_side_tables(c, *side_tab, &side_ll, &side_sp);
+        if (rs == GRX_ERR_UNSUPPORTED_MODEL) generic = true;
+        else if (rs) return rs;
+    }
     g_err.clear();
     const int nd = m.num_bodies - 1;
     if (nd < 1 || m.num_bodies > GRX_MAX_BODIES) return fail(GRX_ERR_UNSUPPORTED_MODEL, "grx_create: unsupported body count");
@@ -733,7 +749,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     P.sim_dt = c.sim_dt; P.decimation = c.decimation;
     for (int i = 0; i < 3; ++i) { P.gravity[i] = c.gravity[i]; P.init_pos[i] = c.init_pos[i]; }
     P.action_scale = c.action_scale;
-    P.control_type = c.control_type; P.heading_command = c.heading_command;
+    P.control_type = c.control_type; P.heading_command = c.heading_command ? 1 : 0;
     P.kn = c.contact.kn; P.dn = c.contact.dn; P.kt = c.contact.kt; P.ct = c.contact.ct; P.cv = c.contact.cv;
     P.terrain_friction = c.contact.terrain_friction;
     P.inv_kt = 1.0f / c.contact.kt;
@@ -774,10 +790,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     memcpy(P.torso_rot, m.torso_rot, sizeof P.torso_rot);
     memcpy(P.forehead_rot, m.forehead_rot, sizeof P.forehead_rot);
     P.has_torso = m.torso_body >= 0; P.has_forehead = m.forehead_body >= 0;
-    if (!generic) {
-        rc = build_side_tables(c, s->tab, &P.ll_mask, &P.sp_mask);
-        if (rc) { delete s; return rc; }
-    }
+    if (!generic) { memcpy(s->tab.side, side_tab->side, sizeof s->tab.side); P.ll_mask = side_ll; P.sp_mask = side_sp; }
 
 #define DA(field, count) do { rc = dalloc(s, &P.field, (count)); if (rc) { grx_destroy(s); return rc; } } while (0)
     DA(q, nd * N); DA(qd, nd * N); DA(root, 13 * N); DA(anchors, 24 * N);
@@ -795,7 +808,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     // the tree kernel goes down to one four-env wave per block (16 lanes per env, GRX_TREE_WAVES=1)
     P.stat_stride = (generic ? 8 : 2) * nblocks + 1;
     DA(stat_partial, (size_t)2 * NSTAT * P.stat_stride); DA(stat_nblocks, 2); DA(stat_hist, (size_t)GRX_STATS_HISTORY * NSTAT);
-    DA(stats, NSTAT); DA(prof, (size_t)2 * nblocks * GRX_PROF_SLOTS);   // (16-env blocks in the quad layout)
+    DA(stats, NSTAT); DA(prof, (size_t)std::max(2 * nblocks, 64) * GRX_PROF_SLOTS);   // (16-env blocks in the quad layout; the tree kernel stamps blocks 0..63 whatever their size)
     rc = dalloc(s, &s->d_mask, N);
     if (rc) { grx_destroy(s); return rc; }
     P.publish_rbs = c.publish_rigid_body_states;   // (the one-lane generic fallback does not publish link frames: cleared below)
@@ -1109,11 +1122,21 @@ static StepSeq next_seq(grx_sim* s, hipStream_t st, bool capturing) {
     q.seq = ++s->seq;
     q.progress = capturing ? nullptr : s->pace.d_progress;
     q.ticket_done = s->pace.issued;
-    q.fold_prev = capturing ? 0 : 1;
+    // a recorded launch runs later, any number of times, or never: neither it nor the first eager launch behind it may fold the rows of
+    // "launch seq - 1" (an eager step after a captured-but-never-replayed one folded partials of a launch that had not run)
+    q.fold_prev = (capturing || s->prev_recorded) ? 0 : 1;
     q.pad = 0;
-    if (!capturing) { ++s->pace.issued; s->pace.last_stream = st; }
-    s->stats_current = false;
+    s->prev_recorded = capturing;
+    if (!capturing) { ++s->pace.issued; s->pace.last_stream = st; s->stats_current = false; s->eager_seq = q.seq; }   // (recorded work changes nothing until it is replayed)
     return q;
+}
+
+// Stream capture starts from reduced statistics: the rows of the last EAGER launch cannot be reduced by a recorded kernel (replayed later,
+// between other launches, it would reduce some other launch's rows of that parity and overwrite a history row that is not its own).
+static int capture_needs_flushed_stats(grx_sim* s, const char* who) {
+    if (s->stats_current) return GRX_OK;
+    return fail(GRX_ERR_INVALID_ARGUMENT, std::string(who) + ": call grx_flush_stats() on this stream BEFORE stream capture begins (the episode statistics of the last eager "
+                "launch are still unreduced, and a recorded kernel cannot reduce them)");
 }
 
 int grx_reset_all(grx_handle s, void* stream) {
@@ -1121,17 +1144,19 @@ int grx_reset_all(grx_handle s, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // extras["episode"] of a full reset: mean of the running episode sums over all envs
     // (legged_robot.py:420-424); computed by the stats path with every env flagged.
+    const bool capturing = stream_is_capturing(st);
+    if (capturing) if (int rc = capture_needs_flushed_stats(s, "grx_reset_all")) return rc;
     uint32_t step = 0x80000000u + (s->reset_count++);
-    // (the generic reset kernel does not fold its predecessor's statistics, and a recorded launch must not: reduce them now)
-    if ((s->generic || stream_is_capturing(st)) && !s->stats_current) grx_launch_finalize(s->d_hp, s->seq, nullptr, 0, st);
-    const StepSeq q = next_seq(s, st, stream_is_capturing(st));
+    // (the generic reset kernel does not fold its predecessor's statistics: reduce them now)
+    if (s->generic && !s->stats_current) grx_launch_finalize(s->d_hp, s->eager_seq, nullptr, 0, st);
+    const StepSeq q = next_seq(s, st, capturing);
     if (s->generic) {
         grx_launch_reset_all_generic(s->d_hp, s->d_gen, s->N, s->gen_epb, step, q.seq, nullptr, st);
         grx_launch_finalize(s->d_hp, q.seq, q.progress, q.progress ? s->pace.issued : 0, st);
-        s->stats_current = true;
+        if (!capturing) s->stats_current = true;
     } else {
         grx_launch_reset_all(s->d_hp, s->N, step, &q, nullptr, st);
-        if (!q.fold_prev) { grx_launch_finalize(s->d_hp, q.seq, nullptr, 0, st); s->stats_current = true; }   // recorded into a graph: see grx_step
+        if (capturing) grx_launch_finalize(s->d_hp, q.seq, nullptr, 0, st);   // recorded into a graph: carries its own reduction, see grx_step
     }
     HIP_TRY(hipGetLastError());
     return GRX_OK;
@@ -1141,17 +1166,19 @@ int grx_reset_idx(grx_handle s, const int32_t* env_ids, int32_t n, void* stream)
     if (!s || (n > 0 && !env_ids)) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_reset_idx: null argument");
     if (n <= 0) return GRX_OK;   // legged_robot.py:387-388
     hipStream_t st = (hipStream_t)stream;
+    const bool capturing = stream_is_capturing(st);
+    if (capturing) if (int rc = capture_needs_flushed_stats(s, "grx_reset_idx")) return rc;
     uint32_t step = 0x80000000u + (s->reset_count++);
-    if ((s->generic || stream_is_capturing(st)) && !s->stats_current) grx_launch_finalize(s->d_hp, s->seq, nullptr, 0, st);
-    const StepSeq q = next_seq(s, st, stream_is_capturing(st));
+    if (s->generic && !s->stats_current) grx_launch_finalize(s->d_hp, s->eager_seq, nullptr, 0, st);
+    const StepSeq q = next_seq(s, st, capturing);
     grx_launch_mark(env_ids, n, s->N, s->d_mask, st);
     if (s->generic) {
         grx_launch_reset_all_generic(s->d_hp, s->d_gen, s->N, s->gen_epb, step, q.seq, s->d_mask, st);
         grx_launch_finalize(s->d_hp, q.seq, q.progress, q.progress ? s->pace.issued : 0, st);
-        s->stats_current = true;
+        if (!capturing) s->stats_current = true;
     } else {
         grx_launch_reset_all(s->d_hp, s->N, step, &q, s->d_mask, st);
-        if (!q.fold_prev) { grx_launch_finalize(s->d_hp, q.seq, nullptr, 0, st); s->stats_current = true; }
+        if (capturing) grx_launch_finalize(s->d_hp, q.seq, nullptr, 0, st);
     }
     HIP_TRY(hipGetLastError());
     return GRX_OK;
@@ -1184,10 +1211,10 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
     }
     // A step recorded into a graph may be replayed any number of times: its predecessor in execution order is then not launch
     // seq - 1, so it must not fold that launch's statistics rows (it would re-publish stale means and lose its own partials:
-    // ADVICE r3).  Recorded steps therefore carry their statistics reduction with them: the predecessor's rows are reduced
-    // before (once, idempotent under replay), the step's own rows right behind it -- every replay leaves GRX_T_EPISODE_STATS
-    // and its row of the history ring current.
-    if (capturing && !s->stats_current) grx_launch_finalize(s->d_hp, s->seq, nullptr, 0, st);
+    // ADVICE r3).  Recorded steps therefore carry their statistics reduction with them, right behind the step: every replay leaves
+    // GRX_T_EPISODE_STATS and its row of the history ring current.  The rows of the last EAGER launch must have been reduced before
+    // the capture began (grx_flush_stats; ADVICE r4: recorded, that reduction ran at replay time on whatever launch then held the parity).
+    if (capturing) if (int rc = capture_needs_flushed_stats(s, "grx_step")) return rc;
     const StepSeq q = next_seq(s, st, capturing);
     a->stats_slot = q.seq & (GRX_STATS_HISTORY - 1);
     a->stats_seq = q.seq;
@@ -1214,7 +1241,7 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
     }
     if ((s->generic && !s->d_tree) || capturing) {   // the one-lane generic kernel does not fold its predecessor's statistics: its own small kernel, with the step's ticket
         grx_launch_finalize(s->d_hp, q.seq, q.progress, q.progress ? s->pace.issued : 0, st);
-        s->stats_current = true;
+        if (!capturing) s->stats_current = true;
     }
     HIP_TRY(hipGetLastError());
     return GRX_OK;
@@ -1223,9 +1250,11 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
 int grx_flush_stats(grx_handle s, void* stream) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_flush_stats: null handle");
     if (s->stats_current) return GRX_OK;
-    grx_launch_finalize(s->d_hp, s->seq, nullptr, 0, (hipStream_t)stream);
+    if (stream_is_capturing((hipStream_t)stream)) return capture_needs_flushed_stats(s, "grx_flush_stats");
+    // (the last launch in host order may be a recorded one that has not run: the rows to reduce are those of the last EAGER launch)
+    grx_launch_finalize(s->d_hp, s->eager_seq, nullptr, 0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
-    if (!stream_is_capturing((hipStream_t)stream)) s->stats_current = true;
+    s->stats_current = true;
     return GRX_OK;
 }
 
@@ -1396,6 +1425,18 @@ int grx_wait_idle(grx_handle s) {
 
 const char* grx_last_error(void) { return g_err.c_str(); }
 int grx_abi_version(void) { return GRX_ABI_VERSION; }
+
+int grx_sizeof(int id) {
+    switch (id) {
+        case GRX_STRUCT_CONFIG: return (int)sizeof(grx_config);
+        case GRX_STRUCT_STEP_ARGS: return (int)sizeof(grx_step_args);
+        case GRX_STRUCT_TENSOR_DESC: return (int)sizeof(grx_tensor_desc);
+        case GRX_STRUCT_PIPELINE_STATE: return (int)sizeof(grx_pipeline_state);
+        case GRX_STRUCT_LAYOUT_INFO: return (int)sizeof(grx_layout_info);
+        case GRX_STRUCT_MODEL: return (int)sizeof(grx_model);
+    }
+    return -1;
+}
 
 const char* grx_reward_term_name(int t) {
     static const char* names[NT] = {

@@ -34,6 +34,21 @@ def resolve_gains(cfg, dof_names):
     return kp, kd, q0
 
 
+def dof_armature(value, dof_names):
+    """cfg.asset.armature -> one value per DOF.  A number is the reference's asset_options.armature (legged_robot.py:958,
+    legged_robot_config.py:125): every DOF gets it.  A dict {substring of the joint name: kg m^2} -- the form cfg.control.stiffness /
+    damping take (legged_robot.py:1060-1072) -- names the joints that get one; the others keep the reference's default, 0."""
+    if isinstance(value, dict):
+        out = []
+        for n in dof_names:
+            hit = [v for k, v in value.items() if k in n]
+            if len(hit) > 1 and len(set(hit)) > 1:
+                raise ValueError(f"cfg.asset.armature: joint '{n}' matches several keys with different values")
+            out.append(float(hit[0]) if hit else 0.0)
+        return out
+    return [float(value)] * len(dof_names)
+
+
 def build(cfg, sim_dt, num_envs, env_offset=0, total_envs=None, seed=1, terrain=None):
     """Returns (cfg_struct, keepalive, meta).  ``terrain``: utils.terrain.Terrain or None."""
     total_envs = num_envs if total_envs is None else total_envs
@@ -50,7 +65,7 @@ def build(cfg, sim_dt, num_envs, env_offset=0, total_envs=None, seed=1, terrain=
     meta = fill_model(c.model, rm, cfg.asset.foot_name, cfg.asset.torso_name,
                       getattr(cfg.asset, "forehead_name", ""), cfg.asset.terminate_after_contacts_on,
                       cfg.asset.penalize_contacts_on, damp_alpha=g.damp_alpha, sim_dt=sim_dt,
-                      armature=float(getattr(cfg.asset, "armature", 0.0)))   # asset_options.armature (legged_robot.py:958)
+                      armature=dof_armature(getattr(cfg.asset, "armature", 0.0), rm.dof_names))
     meta["model"] = rm
     c.contact.kn, c.contact.dn, c.contact.kt, c.contact.ct, c.contact.cv = g.kn, g.dn, g.kt, g.ct, g.cv
     c.contact.k_limit, c.contact.c_limit, c.contact.damp_alpha = g.k_limit, g.c_limit, g.damp_alpha

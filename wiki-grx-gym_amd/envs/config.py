@@ -309,14 +309,17 @@ class GR1T1FullBodyCfg(GR1T1FullCfg):
     variants), so the observation layout here is BUILD-DEFINED, the lower-limb profile (gr1t1.py:281-313) with 32
     dofs: obs 9 + 3*32 = 105, pri_obs 105 + 3 + 1 + 2 + 2 + 121 = 234.  Runs on the tree kernel (csrc/grx_tree.h).
 
-    asset.armature = 0.01 kg m^2 (the reference's knob, legged_robot_config.py:125 / legged_robot.py:958; 0.01 is what Isaac Gym's own
-    arm examples set, examples/franka_osc.py:81): the wrist and head links weigh 0.03-0.45 kg with 1e-5 .. 2e-4 kg m^2 about their
-    joint axes while their actuators damp with kd = 1 N m s/rad, and the reference applies the PD torque EXPLICITLY at 500 Hz
-    (legged_robot.py:679-715): kd dt / I = 210 for a wrist, two orders of magnitude beyond the explicit stability limit of 2 -- the
-    joint chatters between its effort limits and amplifies rounding into O(1) rad/s within a step.  With the
-    joint-space armature kd dt / (I + 0.01) <= 0.6 on every upper-body joint."""
+    asset.armature (the reference's knob, legged_robot_config.py:125 / legged_robot.py:958; default 0) is set PER JOINT here, and only where
+    the reference's own actuator model is numerically unstable: the PD torque is applied EXPLICITLY at 500 Hz (legged_robot.py:679-715), an
+    explicit damper is stable while kd dt / I < 2, and with I the smallest composite inertia of the joint's subtree about its axis over the
+    joint range the ratio is 106-142 for wrist roll / pitch (0.03 kg links, kd = 1 N m s/rad), 8.5 for shoulder yaw, 5.8 for wrist yaw and
+    1.1-2.0 for head yaw / roll / pitch and shoulder pitch: those joints chatter between their effort limits and amplify rounding into
+    O(1) rad/s within a step.  They get 0.01 kg m^2 (what Isaac Gym's own arm examples set, examples/franka_osc.py:81):
+    ratio <= 0.6.  Every other joint -- the LEGS, the waist, shoulder roll, the elbows: ratio <= 0.52 as they are -- keeps the reference's
+    0, so the leg dynamics of this task are those of the lower-limb task (round 4 gave all 32 joints the armature, 0.01 kg m^2
+    being more than an ankle's own inertia).  NON-REFERENCE where set: bench.py's full-body line and DESIGN.md say so."""
     env = section("env", GR1T1FullCfg.env, num_obs=105, num_pri_obs=234, num_actions=32)
-    asset = section("asset", GR1T1FullCfg.asset, armature=0.01)
+    asset = section("asset", GR1T1FullCfg.asset, armature={"head": 0.01, "shoulder_pitch": 0.01, "shoulder_yaw": 0.01, "wrist": 0.01})
     rewards = section("rewards", GR1T1FullCfg.rewards,
                       scales=section("scales", GR1T1FullCfg.rewards.scales, **_LL_SCALES))   # the lower-limb task's reward mix
 

@@ -217,7 +217,7 @@ def fill_model(cm, rm, foot_name, torso_name, forehead_name, terminate_names, pe
         cm.dof_upper[d] = rm.dof_upper[d]
         cm.dof_vel_limit[d] = rm.dof_vel_limit[d]
         cm.dof_effort[d] = rm.dof_effort[d]
-        cm.dof_armature[d] = float(armature)
+        cm.dof_armature[d] = float(armature[d]) if hasattr(armature, "__len__") else float(armature)
 
     feet = rm.links_containing(foot_name)
     if len(feet) != 2:

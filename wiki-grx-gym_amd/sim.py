@@ -277,6 +277,9 @@ def load_hip_library():
         _hip_api = _capi.bind(lib, "grx_")
         if _hip_api["abi_version"]() != _capi.GRX_ABI_VERSION:
             raise GrxError("libgrx_hip.so ABI version mismatch")
+        for name, (sid, cls) in _capi.STRUCT_IDS.items():   # a short mirror of grx_step_args would be overrun by grx_step's OUT fields
+            if _hip_api["sizeof"](sid) != C.sizeof(cls):
+                raise GrxError(f"libgrx_hip.so: sizeof(grx_{name.lower()}) = {_hip_api['sizeof'](sid)} but the ctypes mirror has {C.sizeof(cls)} bytes")
     return _hip_api
 
 
