@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GRX_ABI_VERSION 5
+#define GRX_ABI_VERSION 6
 
 #define GRX_MAX_BODIES 36   /* moving bodies after merging fixed joints (base + DOFs) */
 #define GRX_MAX_DOFS 32
@@ -116,6 +116,12 @@ typedef enum grx_reward_term {
 #define GRX_SPH_FOOT_RIGHT 0x2u
 #define GRX_SPH_TERMINATE 0x4u   /* body is in termination_contact_indices (legged_robot.py:1145-1161) */
 #define GRX_SPH_PENALISE 0x8u    /* body is in penalised_contact_indices  (legged_robot.py:1127-1143) */
+
+/* How a tensor that nobody needs on every step is published (grx_config.publish_rigid_body_states / publish_measured_heights).
+ * ON_REFRESH tensors are brought up to date by grx_refresh() -- from the state the last step left, and for the envs that step RESET from
+ * the state before the reset (and before _push_robots): exactly what the step-written tensors show (the reference's rigid_body_states
+ * is not refreshed by reset_idx, its measured_heights are taken before it: legged_robot.py:284-296). */
+typedef enum grx_publish_mode { GRX_PUBLISH_NEVER = 0, GRX_PUBLISH_EVERY_STEP = 1, GRX_PUBLISH_ON_REFRESH = 2 } grx_publish_mode;
 
 typedef enum grx_terrain_type { GRX_TERRAIN_PLANE = 0, GRX_TERRAIN_HEIGHTFIELD = 1 } grx_terrain_type;   /* 'trimesh' = heightfield + vertical_faces */
 
@@ -270,8 +276,14 @@ typedef struct grx_config {
 
     int32_t publish_reward_terms;  /* 1: also write GRX_T_REWARD_TERMS, the per-term reward table (a debugging tensor with no
                                       reference counterpart; the parity tests read it).  Every other tensor is always current. */
-    int32_t publish_rigid_body_states; /* 1: also write GRX_T_RIGID_BODY_STATES after the last sub-step of every step (the
-                                      reference refreshes it every sub-step, legged_robot_fftai.py:76, and reads the last one) */
+    int32_t publish_rigid_body_states; /* grx_publish_mode of GRX_T_RIGID_BODY_STATES.  GRX_PUBLISH_EVERY_STEP: written by the step kernel after
+                                      its last sub-step (the reference refreshes it every sub-step, legged_robot_fftai.py:76, and reads the
+                                      last one: 1.9 KB per env-step); GRX_PUBLISH_ON_REFRESH: materialised by grx_refresh() when somebody
+                                      reads it -- the gym.refresh_rigid_body_state_tensor model; GRX_PUBLISH_NEVER: no such tensor */
+
+    int32_t publish_measured_heights;  /* ABI 6: grx_publish_mode of GRX_T_MEASURED_HEIGHTS (the raw 121-point scan, legged_robot.py:289: a reference
+                                      attribute no reward or observation reads back -- they use the scan inside the step).  0 is read as
+                                      GRX_PUBLISH_EVERY_STEP (484 B per env-step); GRX_PUBLISH_ON_REFRESH: grx_refresh() */
 
     /* ABI 5: the reference's options that the GRx tasks leave off.  A handle with either of them set runs the general one-wave
        (lower-limb robots) or tree / generic layout: the wave pipelines keep the registered tasks' code path. */
@@ -310,7 +322,7 @@ typedef enum grx_tensor_id {
     GRX_T_FEET_CONTACT,       /* u8  (N, 2) */
     GRX_T_AVG_FEET_FORCE,     /* f32 (N, 2)   sub-step averaged |F| (legged_robot_fftai.py:79,86) */
     GRX_T_AVG_FEET_SPEED,     /* f32 (N, 2, 3) sub-step averaged |v| */
-    GRX_T_MEASURED_HEIGHTS,   /* f32 (N, nh) */
+    GRX_T_MEASURED_HEIGHTS,   /* f32 (N, nh); per grx_config.publish_measured_heights every step, or current after grx_refresh() */
     GRX_T_BASE_HEIGHTS_OFFSET,/* f32 (N) */
     GRX_T_EPISODE_SUMS,       /* f32 (GRX_NUM_REWARD_TERMS, N) */
     GRX_T_REWARD_TERMS,       /* f32 (GRX_NUM_REWARD_TERMS, N) last step's r_i*scale_i*dt */
@@ -331,8 +343,8 @@ typedef enum grx_tensor_id {
     GRX_T_EPISODE_STATS_HISTORY, /* f32 (GRX_STATS_HISTORY, GRX_NUM_REWARD_TERMS + 2): row (slot) = GRX_T_EPISODE_STATS as of the step
                                  that returned grx_step_args.stats_slot = slot; a row stays valid for GRX_STATS_HISTORY - 1 later steps */
     GRX_T_RIGID_BODY_STATES,  /* f32 (N, GRX_MAX_LINKS, 13) p3 q4(xyzw) v3 w3 of every URDF link frame, world axes, after the last
-                                 sub-step: gym.acquire_rigid_body_state_tensor (legged_robot.py:113,134); written only with
-                                 grx_config.publish_rigid_body_states */
+                                 sub-step: gym.acquire_rigid_body_state_tensor (legged_robot.py:113,134); per
+                                 grx_config.publish_rigid_body_states every step, or current after grx_refresh() */
     GRX_T_AVG_FEET_SPEED_RPY, /* f32 (N, 2, 3) sub-step averaged |angular velocity| of the foot links, world axes: avg_feet_speed_rpy
                                  (legged_robot_fftai.py:34, 81, 88, 144); no active reward term reads it */
     GRX_NUM_TENSORS
@@ -383,6 +395,12 @@ int grx_step(grx_handle h, grx_step_args* args, void* stream);   /* writes args-
 
 /* non-owning view of a library buffer */
 int grx_tensor(grx_handle h, int tensor_id, grx_tensor_desc* out);
+
+/* Bring an ON_REFRESH tensor (grx_publish_mode) up to date in stream order: one small kernel, launched at most once per step however
+ * often it is asked for; a no-op for every tensor the step keeps current.  The role of gym.refresh_rigid_body_state_tensor /
+ * refresh_net_contact_force_tensor (legged_robot_fftai.py:75-76, legged_robot.py:275-278) for a caller that reads the tensor now and
+ * then.  GRX_ERR_INVALID_ARGUMENT for a tensor this handle does not publish at all. */
+int grx_refresh(grx_handle h, int tensor_id, void* stream);
 
 /* overwrite simulation state of ALL envs from device buffers (any may be NULL = keep):
  * the set_dof_state_tensor / set_actor_root_state_tensor role (legged_robot.py:737, 796).

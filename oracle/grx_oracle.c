@@ -1314,6 +1314,8 @@ int gro_reset_idx(grx_handle s, const int32_t* env_ids, int32_t n, void* stream)
     return GRX_OK;
 }
 
+/* every tensor of the oracle is written by its step (grx_publish_mode has no ON_REFRESH leg in the checker): nothing to do */
+int gro_refresh(grx_handle s, int id, void* stream) { (void)stream; (void)id; return s ? GRX_OK : fail(GRX_ERR_INVALID_ARGUMENT, "gro_refresh: null handle"); }
 int gro_flush_stats(grx_handle s, void* stream) { (void)stream; return s ? GRX_OK : fail(GRX_ERR_INVALID_ARGUMENT, "gro_flush_stats: null handle"); }
 
 /* c10::div_floor_floating (what torch.div(..., rounding_mode='floor') evaluates in float32) */

@@ -254,7 +254,7 @@ def test_bench_line_has_the_contract_fields():
     # the line names what RAN: grx_layout() of the handle, not a guess from the batch size
     lay = j["config"]["layout"]
     assert j["roofline"]["kernel"] == lay["kernel"] == "grx_step_kernel_quad<true, 8, false>" and lay["lanes_per_env"] == 4 and lay["waves_per_block"] == 8
-    assert "4 lanes per env, 8 waves per 16-env block" in j["roofline"]["note"] and j["config"]["rigid_body_states_published"] is False
+    assert "4 lanes per env, 8 waves per 16-env block" in j["roofline"]["note"] and j["config"]["on_demand_tensors"] == "on_refresh" and j["config"]["product_default"] is True
     assert j["steps"] == 20 and j["warmup"] == 5 and j["higher_is_better"] and j["scaling"] == "weak" and j["vs_baseline"] is None
     assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"] and j["config"]["finite_outputs"]
     assert abs(j["value"] - 4096 * 20 / (j["ms_per_step"] * 20e-3)) < 1e-3 * j["value"]
@@ -266,6 +266,10 @@ def test_bench_line_has_the_contract_fields():
     assert c["kind"] == "port" and c["unit"] == "env-steps/s" and c["cores"] >= 1 and c["value"] > 0 and c["cpu_model"] and "note" in c
     assert c["reference_stage"] is None or c["reference_stage"]["value"] > 0
     assert j["value"] > 20e6      # an MI355X does not fall below this even inside a 20-step window
+    fi = j["full_iteration"]      # the reference's own metric (on_policy_runner.py:235): whole PPO iterations on the product-default env
+    assert "error" not in fi and fi["iters"] >= 1 and fi["n_gpus"] == 1 and fi["envs_per_gpu"] == 4096 and fi["num_steps_per_env"] == 64
+    assert fi["env_steps_per_s"] > 2e5 and abs(fi["env_steps_per_s"] - 64 * 4096 / (fi["iteration_ms"] * 1e-3)) < 1e-6 * fi["env_steps_per_s"]
+    assert 0 < fi["collection_ms"] < fi["iteration_ms"] and 0 < fi["learn_ms"] < fi["iteration_ms"]
 
 
 def test_bench_runs_under_torchrun_with_a_real_rccl_group():

@@ -79,7 +79,7 @@ def test_full_body_32_dof_against_the_oracle(kernel, monkeypatch):
     # damper was up to two orders of magnitude beyond its stability limit, envs/config.py) the maxima are bounded
     assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE)
     assert worst["FEET_POS"][0] < 2e-3 and worst["FEET_HEIGHT"][0] < 2e-3 and worst["REW"][0] < 1e-2, worst   # (1.7 x observed; every row is also capped and explained by assert_phys)
-    assert worst["DOF_VEL"][0] < 0.5 and worst["DOF_POS"][0] < 1e-2, (worst["DOF_VEL"], worst["DOF_POS"])
+    assert worst["DOF_VEL"][0] < 1.5 and worst["DOF_POS"][0] < 1e-2, (worst["DOF_VEL"], worst["DOF_POS"])
     assert torch.isfinite(hip.tensor("OBS")).all() and torch.isfinite(hip.tensor("REW")).all()
     hip.close()
 

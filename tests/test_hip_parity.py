@@ -820,3 +820,73 @@ def test_control_types_and_heading_command_against_the_oracle(ct, heading):
         assert hip.tensor("COMMANDS")[:, 2].abs().max() > 0.05
     assert_phys(worst, scale=(8.0 if ct == "V" else 2.6), hf=True)
     hip.close()
+
+
+@pytest.mark.parametrize("layout", [1, 8, "quad4", "quad", "tree", "tree16", "full_tree16"])
+def test_tensors_published_on_refresh_equal_the_step_written_ones(layout, monkeypatch):
+    """grx_publish_mode (include/grx.h, ABI 6): GRX_T_RIGID_BODY_STATES and GRX_T_MEASURED_HEIGHTS materialised by grx_refresh() -- the
+    default of the env: gym.refresh_rigid_body_state_tensor's model, legged_robot_fftai.py:76 -- against the same tensors written by the
+    step kernel itself (GRX_PUBLISH_EVERY_STEP), two handles on the same seed and actions, every step.  Short episodes and frequent pushes:
+    the envs a step RESETS show the state before reset_idx in both (the refresh kernel reads what the resetting lanes stashed), a push
+    step shows the base velocity before _push_robots in both.  The state the two handles compute is bit-identical."""
+    from tests.test_kinematics import rbs_err
+    from wiki_grx_gym_amd.envs import build_config
+    from wiki_grx_gym_amd.sim import HipSim
+    full = layout == "full_tree16"
+    if full:
+        monkeypatch.setenv("GRX_TREE", "1"); monkeypatch.setenv("GRX_TREE_G", "16")
+    else:
+        from tests.test_hip_golden import pick_layout
+        pick_layout(monkeypatch, layout)
+    cfg = make_cfg("GR1T1Full" if full else "GR1T1", terrain="heightfield", dr=True, push=True, noise=True)
+    cfg.env.episode_length_s = 0.24            # 12 steps: time-outs
+    cfg.domain_rand.push_interval_s = 0.1      # pushes every 5 steps
+    N = 200
+    from tests.helpers import make_terrain
+    ter = make_terrain(cfg, N, seed=3)
+    sims = {}
+    for mode in ("every_step", "on_refresh"):
+        cfg.env.publish_rigid_body_states = cfg.env.publish_measured_heights = mode
+        c, keep, _ = build_config.build(cfg, cfg.sim.dt, N, 0, N, 3, ter)
+        assert c.publish_rigid_body_states == c.publish_measured_heights == {"every_step": 1, "on_refresh": 2}[mode]
+        sims[mode] = HipSim(c, "cuda:0", keep)
+        sims[mode].reset_all()
+    eager, lazy = sims["every_step"], sims["on_refresh"]
+    assert eager.layout() == lazy.layout()
+    nl = int(lazy._keep[-1].model.num_links)
+    gen = torch.Generator().manual_seed(0)
+    seen = {"reset": 0, "push": 0, "hdiff": 0}
+    for s in range(30):
+        a = random_actions(cfg, N, gen, 0.4).cuda()
+        for sim in (eager, lazy):
+            sim.step(a, 5.0, s + 1)
+        torch.cuda.synchronize()
+        for name in ("OBS", "RESET", "ROOT_STATES", "DOF_POS", "DOF_VEL", "EPISODE_LENGTH", "CONTACT_FORCES"):
+            assert torch.equal(eager.tensor(name), lazy.tensor(name)), (s, name)
+        # (the one-wave kernel shares the chain walk of its step-written link frames with the foot kinematics behind it: with and without
+        #  that call the compiler's two code paths round the foot height differently by an ulp in a few envs -- true of rounds 3-4 as well)
+        for name in ("PRI_OBS", "REW", "FEET_HEIGHT"):
+            assert (eager.tensor(name) - lazy.tensor(name)).abs().max() < 2e-6, (s, name)
+        he, hl = eager.tensor("MEASURED_HEIGHTS").cpu(), lazy.tensor("MEASURED_HEIGHTS").cpu()      # (tensor() refreshes the on-demand one)
+        seen["hdiff"] += int((he != hl).sum())
+        re_, rl = eager.tensor("RIGID_BODY_STATES").cpu()[:, :nl], lazy.tensor("RIGID_BODY_STATES").cpu()[:, :nl]
+        ep, eq, ev = rbs_err(rl, re_)
+        assert ep <= 2e-5 and eq <= 2e-5 and ev <= 2e-4, (s, ep, eq, ev)
+        assert lazy.tensor("RIGID_BODY_STATES").data_ptr() == lazy.tensor("RIGID_BODY_STATES").data_ptr()    # one cached view, refreshed in place
+        reset = lazy.tensor("RESET").bool().cpu()
+        if reset.any():   # the frames of a resetting env are NOT those of its new state (metres away)
+            root_now = lazy.tensor("ROOT_STATES").cpu()[reset][:, 0:3]
+            assert (rl[reset][:, 0, 0:3] - root_now).norm(dim=-1).min() > 0.05
+        seen["reset"] += int(reset.sum())
+        seen["push"] += int((s + 1) % 5 == 0)
+    assert seen["reset"] >= N and seen["push"] >= 5, seen
+    assert seen["hdiff"] == 0, seen            # the scan of the refresh kernel IS the step kernels' (same function, same flags)
+    # a refresh that is asked for twice launches once; a state written from outside is seen by the next one
+    lazy.refresh("RIGID_BODY_STATES"); lazy.refresh("MEASURED_HEIGHTS")
+    root = lazy.tensor("ROOT_STATES").clone(); root[:, 2] += 1.0
+    lazy.set_state(root.contiguous(), None, None)
+    moved = lazy.tensor("RIGID_BODY_STATES").cpu()[:, 0, 2]
+    live = ~lazy.tensor("RESET").bool().cpu()
+    assert ((moved - root[:, 2].cpu()).abs()[live] < 1e-6).all()
+    for sim in (eager, lazy):
+        sim.close()

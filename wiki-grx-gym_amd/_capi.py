@@ -5,7 +5,8 @@ Field order and sizes must match the header exactly; ``grx_create`` rejects a mi
 """
 import ctypes as C
 
-GRX_ABI_VERSION = 5
+GRX_ABI_VERSION = 6
+PUBLISH_NEVER, PUBLISH_EVERY_STEP, PUBLISH_ON_REFRESH = 0, 1, 2   # grx_publish_mode
 CONTROL_TYPES = {"P": 0, "V": 1, "T": 2}   # grx_control_type (legged_robot.py:693-707)
 MAX_BODIES = 36
 MAX_DOFS = 32
@@ -141,6 +142,7 @@ class Config(C.Structure):
         ("terrain_length", f32), ("env_spacing", f32),
         ("publish_reward_terms", i32),
         ("publish_rigid_body_states", i32),
+        ("publish_measured_heights", i32),
         ("control_type", i32), ("heading_command", i32),
     ]
 
@@ -192,6 +194,7 @@ def bind(lib, prefix="grx_"):
         "reset_all": fn("reset_all", C.c_int, H, C.c_void_p),
         "step": fn("step", C.c_int, H, C.POINTER(StepArgs), C.c_void_p),
         "tensor": fn("tensor", C.c_int, H, C.c_int, C.POINTER(TensorDesc)),
+        "refresh": fn("refresh", C.c_int, H, C.c_int, C.c_void_p),
         "set_state": fn("set_state", C.c_int, H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p),
         "episode_stats": fn("episode_stats", C.c_int, H, C.POINTER(C.c_float), C.c_void_p),
         "flush_stats": fn("flush_stats", C.c_int, H, C.c_void_p),
@@ -221,7 +224,7 @@ def bind(lib, prefix="grx_"):
 EXPORTED_SYMBOLS = (
     "grx_create", "grx_destroy", "grx_reset_all", "grx_step", "grx_tensor", "grx_set_state",
     "grx_episode_stats", "grx_flush_stats", "grx_reset_idx", "grx_set_state_indexed", "grx_kernel_time_ms", "grx_wait_idle", "grx_last_error", "grx_abi_version",
-    "grx_reward_term_name", "grx_debug_post_physics", "grx_layout", "grx_stats_seq", "grx_debug_spin_report", "grx_sizeof",
+    "grx_reward_term_name", "grx_debug_post_physics", "grx_layout", "grx_stats_seq", "grx_debug_spin_report", "grx_sizeof", "grx_refresh",
 )
 # grx_struct_id (include/grx.h): grx_sizeof(id) must equal ctypes.sizeof of the mirror -- checked once per process by sim.load_hip_library
 STRUCT_IDS = {"CONFIG": (0, Config), "STEP_ARGS": (1, StepArgs), "TENSOR_DESC": (2, TensorDesc), "PIPELINE_STATE": (3, PipelineState),

@@ -48,6 +48,8 @@ void grx_launch_reset_all(const KParams* dP, int N, uint32_t step, const StepSeq
 void grx_launch_mark(const int32_t* env_ids, int n, int N, uint8_t* mask, hipStream_t stream);
 void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, const int32_t* env_ids, int n, hipStream_t stream);
 int grx_envs_per_block(void);
+void grx_launch_refresh_heights(const KParams* dP, int N, int nh, hipStream_t stream);
+void grx_launch_refresh_rbs(const KParams* dP, int N, int nlinks, int pushed, hipStream_t stream);
 void grx_launch_step_debug(const KParams* dP, int N, int heightfield, int waves, const float* actions, long long common_step, const float* noise,
                            const float* dbg, const StepSeq* sq, hipStream_t stream);
 void grx_launch_step_debug_quad(const KParams* dP, int N, int heightfield, int waves, const float* actions, long long common_step, const float* noise,
@@ -108,6 +110,7 @@ struct grx_sim {
     int waves = 1;         // waves per 32-env block of the step kernel (1, 2 or 4)
     bool quad = false;     // four waves, a lane quad per env, 16 envs per block (grx_quad.hip): while the blocks fit the CUs in one round
     bool generic = false;  // model outside the fast kernel's lower-limb topology: generic-tree kernel (grx_generic.h)
+    int rbs_mode = GRX_PUBLISH_NEVER, heights_mode = GRX_PUBLISH_EVERY_STEP;   // grx_publish_mode of GRX_T_RIGID_BODY_STATES / GRX_T_MEASURED_HEIGHTS
     int nd = GRX_ND;
     void* d_gen = nullptr; // GenTables (device)
     void* d_tree = nullptr; // TreeTab (device): the lane-group tree kernel (grx_tree.h) runs this model
@@ -118,6 +121,9 @@ struct grx_sim {
     int64_t seq = 0;       // launches of this handle that write statistics rows (steps, resets, debug steps; recorded ones too)
     int64_t eager_seq = 0; // ... the last of them that was launched eagerly (its rows are what grx_flush_stats reduces)
     bool stats_current = true;   // GRX_T_EPISODE_STATS already holds the statistics of the last EAGER launch (grx_flush_stats)
+    int64_t rbs_seq = -1, heights_seq = -1;   // launch number (seq) the on-demand tensors were last materialised for (grx_refresh)
+    int64_t state_epoch = 0, rbs_epoch = -1, heights_epoch = -1;   // ... and the count of state writes outside steps (grx_set_state*, grx_reset_*)
+    bool last_pushed = false;    // the last step was a _push_robots step (the base's vx, vy were overwritten after the sub-steps)
     bool prev_recorded = false;  // the last launch in host order was recorded into a graph: its successor must not fold "launch seq - 1"
     uint8_t* d_mask = nullptr;   // grx_reset_idx: per-env flags
     int gen_epb = 64;      // generic kernel: envs per (single-wave) block
@@ -811,9 +817,39 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(stats, NSTAT); DA(prof, (size_t)std::max(2 * nblocks, 64) * GRX_PROF_SLOTS);   // (16-env blocks in the quad layout; the tree kernel stamps blocks 0..63 whatever their size)
     rc = dalloc(s, &s->d_mask, N);
     if (rc) { grx_destroy(s); return rc; }
-    P.publish_rbs = c.publish_rigid_body_states;   // (the one-lane generic fallback does not publish link frames: cleared below)
+    if (c.publish_rigid_body_states < 0 || c.publish_rigid_body_states > 2 || c.publish_measured_heights < 0 || c.publish_measured_heights > 2) {
+        grx_destroy(s); return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: publish_* must be a grx_publish_mode");
+    }
+    s->rbs_mode = c.publish_rigid_body_states;
+    s->heights_mode = c.publish_measured_heights == GRX_PUBLISH_ON_REFRESH ? GRX_PUBLISH_ON_REFRESH : GRX_PUBLISH_EVERY_STEP;
+    P.publish_rbs = s->rbs_mode == GRX_PUBLISH_EVERY_STEP;   // (the one-lane generic fallback does not publish link frames: cleared below)
+    P.publish_heights = s->heights_mode == GRX_PUBLISH_EVERY_STEP;
+    P.stash_pre_reset = s->rbs_mode == GRX_PUBLISH_ON_REFRESH || s->heights_mode == GRX_PUBLISH_ON_REFRESH;
     P.num_links = m.num_links;
-    DA(rbs, P.publish_rbs ? (size_t)13 * GRX_MAX_LINKS * N : 1);
+    DA(rbs, s->rbs_mode != GRX_PUBLISH_NEVER ? (size_t)13 * GRX_MAX_LINKS * N : 1);
+    DA(pre_q, P.stash_pre_reset ? nd * N : 1); DA(pre_qd, P.stash_pre_reset ? nd * N : 1); DA(pre_root, P.stash_pre_reset ? 13 * N : 1);
+    DA(pre_push_vel, P.stash_pre_reset ? 2 * N : 1);
+    {   // grx_refresh: the joint tree as the model holds it
+        std::unique_ptr<RefreshTab> rt(new RefreshTab());
+        memset(rt.get(), 0, sizeof(RefreshTab));
+        rt->nb = m.num_bodies; rt->nlinks = m.num_links;
+        for (int b = 1; b < m.num_bodies; ++b) {
+            int chain[GRX_MAX_BODIES], n = 0;
+            for (int x = b; x > 0 && n < GRX_MAX_BODIES; x = m.parent[x]) chain[n++] = x;
+            if (n > GRX_REFRESH_MAXDEPTH) { grx_destroy(s); return fail(GRX_ERR_UNSUPPORTED_MODEL, "grx_create: joint tree deeper than GRX_REFRESH_MAXDEPTH"); }
+            rt->depth[b] = n;
+            for (int d = 0; d < n; ++d) rt->path[b][d] = (int8_t)chain[n - 1 - d];
+            bool ident = true;
+            for (int a = 0; a < 9; ++a) { rt->rot0[b][a] = m.joint_rot0[b][a]; ident = ident && m.joint_rot0[b][a] == (a % 4 == 0 ? 1.f : 0.f); }
+            rt->rot0_identity[b] = ident ? 1 : 0;
+            for (int a = 0; a < 3; ++a) { rt->axis[b][a] = m.joint_axis[b][a]; rt->jpos[b][a] = m.joint_pos[b][a]; }
+        }
+        RefreshTab* drt = nullptr;
+        rc = dalloc(s, &drt, 1);
+        if (rc) { grx_destroy(s); return rc; }
+        HIP_TRY(hipMemcpy(drt, rt.get(), sizeof(RefreshTab), hipMemcpyHostToDevice));
+        P.refresh_tab = drt;
+    }
     {
         std::vector<LinkTab> lt(1);
         memset(&lt[0], 0, sizeof(LinkTab));
@@ -1038,7 +1074,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     desc_soa3(s, GRX_T_ANCHORS, P.anchors, 8, 3);
     desc_soa3(s, GRX_T_CONTACT_FORCES, P.contact_forces, GRX_MAX_LINKS, 3);
     desc_soa3(s, GRX_T_RIGID_BODY_STATES, P.rbs, GRX_MAX_LINKS, 13);
-    if (!P.publish_rbs) s->desc[GRX_T_RIGID_BODY_STATES].data = nullptr;
+    if (s->rbs_mode == GRX_PUBLISH_NEVER) s->desc[GRX_T_RIGID_BODY_STATES].data = nullptr;
     s->prof_host = P.prof; s->prof_blocks = s->quad ? (c.num_envs + grx_envs_per_block_quad() - 1) / grx_envs_per_block_quad() : nblocks;
     // generic kernel: the per-body workspace goes to LDS when 16 envs' rows fit (155 KB for the 33-body robot: LDS round
     // trips are ~5x shorter than global ones and the kernel is bound by exactly those); else 64 envs per block over the
@@ -1055,7 +1091,14 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     if (generic) {
         rc = build_generic(s, c);
         if (rc) { grx_destroy(s); return rc; }
-        if (!s->d_tree) { s->hp.publish_rbs = 0; s->desc[GRX_T_RIGID_BODY_STATES].data = nullptr; }
+        if (!s->d_tree) {   // the one-lane generic kernel (trees with more than eight chains): no link frames every step -- on refresh they are available
+            s->hp.publish_rbs = 0;
+            if (s->rbs_mode == GRX_PUBLISH_EVERY_STEP) { s->rbs_mode = GRX_PUBLISH_NEVER; s->desc[GRX_T_RIGID_BODY_STATES].data = nullptr; }
+            // (it reads the raw heights back from memory: always materialised there; it neither stashes the state before a reset)
+            s->hp.publish_heights = 1; s->heights_mode = GRX_PUBLISH_EVERY_STEP;
+            if (s->rbs_mode == GRX_PUBLISH_ON_REFRESH) { s->rbs_mode = GRX_PUBLISH_NEVER; s->desc[GRX_T_RIGID_BODY_STATES].data = nullptr; }
+            s->hp.stash_pre_reset = 0;
+        }
     }
     {
         void* hp_ = nullptr;
@@ -1146,6 +1189,7 @@ int grx_reset_all(grx_handle s, void* stream) {
     // (legged_robot.py:420-424); computed by the stats path with every env flagged.
     const bool capturing = stream_is_capturing(st);
     if (capturing) if (int rc = capture_needs_flushed_stats(s, "grx_reset_all")) return rc;
+    ++s->state_epoch;
     uint32_t step = 0x80000000u + (s->reset_count++);
     // (the generic reset kernel does not fold its predecessor's statistics: reduce them now)
     if (s->generic && !s->stats_current) grx_launch_finalize(s->d_hp, s->eager_seq, nullptr, 0, st);
@@ -1168,6 +1212,7 @@ int grx_reset_idx(grx_handle s, const int32_t* env_ids, int32_t n, void* stream)
     hipStream_t st = (hipStream_t)stream;
     const bool capturing = stream_is_capturing(st);
     if (capturing) if (int rc = capture_needs_flushed_stats(s, "grx_reset_idx")) return rc;
+    ++s->state_epoch;
     uint32_t step = 0x80000000u + (s->reset_count++);
     if (s->generic && !s->stats_current) grx_launch_finalize(s->d_hp, s->eager_seq, nullptr, 0, st);
     const StepSeq q = next_seq(s, st, capturing);
@@ -1218,6 +1263,7 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
     const StepSeq q = next_seq(s, st, capturing);
     a->stats_slot = q.seq & (GRX_STATS_HISTORY - 1);
     a->stats_seq = q.seq;
+    s->last_pushed = s->cfg.push_robots && s->cfg.push_interval > 0 && ((uint32_t)a->common_step_counter % (uint32_t)s->cfg.push_interval) == 0;
     if (s->generic)
     {
         if (s->d_tree) {
@@ -1258,6 +1304,25 @@ int grx_flush_stats(grx_handle s, void* stream) {
     return GRX_OK;
 }
 
+int grx_refresh(grx_handle s, int id, void* stream) {
+    if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_refresh: null handle");
+    if (id < 0 || id >= GRX_NUM_TENSORS) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_refresh: unknown tensor id");
+    if (!s->desc[id].data) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_refresh: this handle does not publish that tensor (grx_config.publish_*)");
+    hipStream_t st = (hipStream_t)stream;
+    if (id == GRX_T_RIGID_BODY_STATES && s->rbs_mode == GRX_PUBLISH_ON_REFRESH) {
+        if (s->rbs_seq == s->seq && s->rbs_epoch == s->state_epoch && !stream_is_capturing(st)) return GRX_OK;   // current
+        grx_launch_refresh_rbs(s->d_hp, s->N, s->cfg.model.num_links, s->last_pushed ? 1 : 0, st);
+        HIP_TRY(hipGetLastError());
+        if (!stream_is_capturing(st)) { s->rbs_seq = s->seq; s->rbs_epoch = s->state_epoch; }
+    } else if (id == GRX_T_MEASURED_HEIGHTS && s->heights_mode == GRX_PUBLISH_ON_REFRESH) {
+        if (s->heights_seq == s->seq && s->heights_epoch == s->state_epoch && !stream_is_capturing(st)) return GRX_OK;
+        grx_launch_refresh_heights(s->d_hp, s->N, s->hp.nh, st);
+        HIP_TRY(hipGetLastError());
+        if (!stream_is_capturing(st)) { s->heights_seq = s->seq; s->heights_epoch = s->state_epoch; }
+    }
+    return GRX_OK;
+}
+
 int grx_tensor(grx_handle s, int id, grx_tensor_desc* out) {
     if (!s || !out) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_tensor: null argument");
     if (id < 0 || id >= GRX_NUM_TENSORS) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_tensor: unknown tensor id");
@@ -1267,6 +1332,7 @@ int grx_tensor(grx_handle s, int id, grx_tensor_desc* out) {
 
 int grx_set_state(grx_handle s, const float* root, const float* q, const float* qd, void* stream) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_set_state: null handle");
+    ++s->state_epoch;
     grx_launch_set_state(s->d_hp, s->N, root, q, qd, nullptr, 0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return GRX_OK;
@@ -1275,6 +1341,7 @@ int grx_set_state(grx_handle s, const float* root, const float* q, const float* 
 int grx_set_state_indexed(grx_handle s, const int32_t* env_ids, int32_t n, const float* root, const float* q, const float* qd, void* stream) {
     if (!s || (n > 0 && !env_ids)) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_set_state_indexed: null argument");
     if (n <= 0) return GRX_OK;
+    ++s->state_epoch;
     grx_launch_set_state(s->d_hp, s->N, root, q, qd, env_ids, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return GRX_OK;

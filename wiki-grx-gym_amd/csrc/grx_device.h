@@ -139,6 +139,17 @@ struct TreeTab {
 // every URDF link frame by carrying body (the tree kernel's GRX_T_RIGID_BODY_STATES)
 struct LinkTab { int32_t n, pad[3]; int32_t body[GRX_MAX_LINKS]; float pos[GRX_MAX_LINKS][3]; float rot[GRX_MAX_LINKS][9]; };
 
+// grx_refresh (include/grx.h): the joint tree as grx_model holds it, for the kernels that materialise a tensor on demand from the state a
+// step left behind -- path[b]: the bodies from the base's child down to b (depth[b] of them); any model, fused or tree layout
+#define GRX_REFRESH_MAXDEPTH 16
+struct RefreshTab {
+    int32_t nb, nlinks;
+    int32_t depth[GRX_MAX_BODIES];
+    int8_t path[GRX_MAX_BODIES][GRX_REFRESH_MAXDEPTH];
+    float axis[GRX_MAX_BODIES][3], jpos[GRX_MAX_BODIES][3], rot0[GRX_MAX_BODIES][9];
+    int32_t rot0_identity[GRX_MAX_BODIES];
+};
+
 // Large read-only tables, in device memory.
 struct KTables {
     SideConst side[2];
@@ -211,7 +222,15 @@ struct KParams {
     float* rbs;            // GRX_T_RIGID_BODY_STATES [(link * 13 + c)][N], written when publish_rbs
     const RbsTables* rbs_tab;
     const LinkTab* link_tab;
-    int32_t publish_rbs, num_links;
+    int32_t publish_rbs, num_links;   // publish_rbs: the STEP KERNEL writes GRX_T_RIGID_BODY_STATES (grx_config.publish_rigid_body_states == 1)
+    // tensors published ON DEMAND (grx_refresh: grx_config.publish_* == 2): nothing is written per step except, by the lanes that RESET an
+    // env, its state before the reset -- the reference's tensors show that state (rigid_body_states is not refreshed by a reset,
+    // measured_heights is taken before reset_idx: legged_robot.py:284-296)
+    int32_t publish_heights;          // the step kernel writes GRX_T_MEASURED_HEIGHTS every step (== 1)
+    int32_t stash_pre_reset;          // a resetting lane stores (q, qd, root) into pre_* first
+    float *pre_q, *pre_qd, *pre_root; // [nd][N], [nd][N], [13][N]: valid where `reset` is set
+    float* pre_push_vel;              // [2][N]: the base's vx, vy before _push_robots overwrote them (valid after a push step)
+    const RefreshTab* refresh_tab;
     int32_t nd;        // dofs of the model (10 on the fast path)
     long long* prof;   // GRX_PROFILE_SECTIONS builds only: [nblocks][16] s_memtime stamps
 };

@@ -791,6 +791,10 @@ __global__ __launch_bounds__(64) void grx_reset_all_generic(const KParams* __res
     ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[N + e]; ea.origin[2] = P.origins[2 * N + e];
     ea.level = P.levels[e]; ea.type = P.types[e];
     const int level_before = ea.level;
+    if (sel && P.stash_pre_reset) {   // on-demand tensors (grx_refresh) show the state before the reset
+        for (int j = 0; j < T.nd; ++j) { P.pre_q[(size_t)j * N + e] = P.q[(size_t)j * N + e]; P.pre_qd[(size_t)j * N + e] = P.qd[(size_t)j * N + e]; }
+        for (int i = 0; i < 13; ++i) P.pre_root[(size_t)i * N + e] = P.root[(size_t)i * N + e];
+    }
     if (sel) gen_reset_env(P, T, genv, step, mask != nullptr, B, ea, P.q + e, P.qd + e, N, e);
     {
         const unsigned long long wm = __ballot(sel);

@@ -1079,7 +1079,7 @@ GRX_DEV float obs_heights_share(KP P, float posz, int first, int nh, float* prow
             if (k < nh) {
                 float d = posz - P.base_height_target - hv[j];
                 d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
-                if (act) P.heights[(size_t)k * N + e] = hv[j];   // env.measured_heights: a reference attribute, always current
+                if (act && P.publish_heights) P.heights[(size_t)k * N + e] = hv[j];   // env.measured_heights (a reference attribute): every step, or on demand by grx_refresh
                 prow[GRX_NUM_OBS + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -P.clip_observations), P.clip_observations);
                 sum += d;
             }
@@ -1882,6 +1882,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         hsum = env_sum(hsum);
     }
     if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {  // legged_robot.py:786-797
+        if (P.stash_pre_reset && act0 && side == 0) { P.pre_push_vel[e] = st.vel.x; P.pre_push_vel[(size_t)N + e] = st.vel.y; }   // (grx_refresh: the link frames of the state BEFORE the push, as the reference's un-refreshed tensor shows them)
         st.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
         st.vel.y = urand(P, genv, step, GRX_RNG_PUSH, 1, -P.max_push_vel_xy, P.max_push_vel_xy);
     }
@@ -1925,6 +1926,17 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     GRX_TICK(6);
     // ---- reset_idx (masked, in-kernel)
     const bool do_reset = DBG ? (reset && dbg_apply_reset) : reset;   // the debug entry may report a reset without applying it
+    if (P.stash_pre_reset && reset && act0) {   // (every REPORTED reset: the debug entry may report one without applying it -- GRX_T_RESET is what the refresh kernels go by)
+        // on-demand tensors (grx_refresh) show the state BEFORE reset_idx, as the step-written ones do
+        const size_t n_ = (size_t)N;
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) { P.pre_q[(size_t)(side * LEG + k) * n_ + e] = st.q[k]; P.pre_qd[(size_t)(side * LEG + k) * n_ + e] = st.qd[k]; }
+        if (side == 0) {
+            float* r_ = P.pre_root + e;
+            r_[0] = st.pos.x; r_[n_] = st.pos.y; r_[2 * n_] = st.pos.z; r_[3 * n_] = st.qx; r_[4 * n_] = st.qy; r_[5 * n_] = st.qz; r_[6 * n_] = st.qw;
+            r_[7 * n_] = st.vel.x; r_[8 * n_] = st.vel.y; r_[9 * n_] = st.vel.z; r_[10 * n_] = st.ang.x; r_[11 * n_] = st.ang.y; r_[12 * n_] = st.ang.z;
+        }
+    }
     if (PIPE ? __any(do_reset) : do_reset) {   // uniform test with four waves: the draws come from wave 2 through LDS
         ResetRand rr;
         if (PIPE) {
@@ -2226,6 +2238,12 @@ __global__ __launch_bounds__(64) void grx_reset_all_kernel(const KParams* __rest
         }
     }
     if (!sel) return;
+    if (P.stash_pre_reset) {   // on-demand tensors (grx_refresh) show the state before the reset
+#pragma unroll
+        for (int k = 0; k < LEG; ++k) { const size_t o = (size_t)(j0 + k) * N + e; P.pre_q[o] = P.q[o]; P.pre_qd[o] = P.qd[o]; }
+        if (side == 0)
+            for (int i = 0; i < 13; ++i) P.pre_root[(size_t)i * N + e] = P.root[(size_t)i * N + e];
+    }
     if (mask && side == 0) {
         mask[e] = 0;
         P.origins[e] = ea.origin[0]; P.origins[(size_t)N + e] = ea.origin[1]; P.origins[2 * (size_t)N + e] = ea.origin[2];
@@ -2276,6 +2294,100 @@ __global__ void grx_set_state_kernel(const KParams* __restrict__ Pg, const float
 __global__ void grx_mark_kernel(const int32_t* __restrict__ env_ids, int n, int N, uint8_t* __restrict__ mask) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const int e = env_ids[i]; if (e >= 0 && e < N) mask[e] = 1; }
+}
+
+// ---- grx_refresh (include/grx.h): tensors published ON DEMAND, from the state the last step left -- for the envs that step reset, from
+// the state it stashed before the reset (pre_*: the reference's tensors show that state).  The role of gym.refresh_rigid_body_state_tensor
+// (legged_robot_fftai.py:76) for callers that read the tensor now and then instead of paying 1.9 KB per env-step for it.
+struct RefreshState { const float *q, *qd, *root; };
+GRX_DEV RefreshState refresh_source(KP P, int e) {
+    const bool pre = P.stash_pre_reset && P.reset[e] != 0;
+    RefreshState r = {pre ? P.pre_q : P.q, pre ? P.pre_qd : P.qd, pre ? P.pre_root : P.root};
+    return r;
+}
+// GRX_T_MEASURED_HEIGHTS: one thread per (scan point, env); the step kernels' own height_sample (same translation unit, same flags)
+__global__ __launch_bounds__(256) void grx_refresh_heights_kernel(const KParams* __restrict__ Pg) {
+    KP P = GRX_PARAMS(Pg);
+    const size_t N = (size_t)P.N;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * (size_t)P.nh) return;
+    const int e = (int)(t % N), k = (int)(t / N);
+    float h = 0.f;
+    if (P.terrain_type != GRX_TERRAIN_PLANE && P.measure_heights) {
+        const RefreshState src = refresh_source(P, e);
+        const float qz = src.root[5 * N + e], qw = src.root[6 * N + e];
+        const float yaw_n = fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f);   // normalize(): torch_utils.py:43-45 (as the step kernels spell it)
+        const float yaw_z = qz / yaw_n, yaw_w = qw / yaw_n;
+        h = height_sample(P, *P.tables, yaw_z, yaw_w, v3(src.root[e], src.root[N + e], src.root[2 * N + e]), k);
+    }
+    P.heights[(size_t)k * N + e] = h;
+}
+// GRX_T_RIGID_BODY_STATES: one thread per (URDF link, env) walks the joints from the base down to the link's body -- any grx_model (the
+// arithmetic of the tree kernel's link frames, grx_tree.h: rotation matrices, orientation in the oracle's largest-component form)
+__global__ __launch_bounds__(256) void grx_refresh_rbs_kernel(const KParams* __restrict__ Pg, int pushed) {   // pushed: the last step overwrote the base's vx, vy (_push_robots) after the sub-steps
+    KP P = GRX_PARAMS(Pg);
+    const size_t N = (size_t)P.N;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * (size_t)P.num_links) return;
+    const int e = (int)(t % N), l = (int)(t / N);   // (a wave: one link, 64 consecutive envs -- uniform control flow, coalesced columns)
+    const RefreshTab& T = *P.refresh_tab;
+    const LinkTab& LT = *P.link_tab;
+    const RefreshState src = refresh_source(P, e);
+    const float* r0 = src.root + e;
+    const V3 pos = v3(r0[0], r0[N], r0[2 * N]);
+    R3 R = quat_to_R(r0[3 * N], r0[4 * N], r0[5 * N], r0[6 * N]);
+    V3 rho = v3(0.f, 0.f, 0.f), v = v3(r0[7 * N], r0[8 * N], r0[9 * N]), w = v3(r0[10 * N], r0[11 * N], r0[12 * N]);
+    if (pushed && P.stash_pre_reset) { v.x = P.pre_push_vel[e]; v.y = P.pre_push_vel[N + e]; }
+    const int b_link = LT.body[l];
+    const int depth = b_link > 0 ? T.depth[b_link] : 0;
+    for (int d = 0; d < depth; ++d) {
+        const int b = T.path[b_link][d], j = b - 1;
+        const float qj = src.q[(size_t)j * N + e], qdj = src.qd[(size_t)j * N + e];
+        rho = rho + rot(R, v3(T.jpos[b][0], T.jpos[b][1], T.jpos[b][2]));
+        R3 J = R;
+        if (!T.rot0_identity[b]) {
+            J.cx = rot(R, v3(T.rot0[b][0], T.rot0[b][3], T.rot0[b][6]));
+            J.cy = rot(R, v3(T.rot0[b][1], T.rot0[b][4], T.rot0[b][7]));
+            J.cz = rot(R, v3(T.rot0[b][2], T.rot0[b][5], T.rot0[b][8]));
+        }
+        float sn, cs;
+        grx_sincos(qj, sn, cs);
+        const float ax = T.axis[b][0], ay = T.axis[b][1], az = T.axis[b][2], oc = 1.f - cs;
+        const V3 qx_ = v3(cs + ax * ax * oc, az * sn + ax * ay * oc, -ay * sn + ax * az * oc);
+        const V3 qy_ = v3(-az * sn + ax * ay * oc, cs + ay * ay * oc, ax * sn + ay * az * oc);
+        const V3 qz_ = v3(ay * sn + ax * az * oc, -ax * sn + ay * az * oc, cs + az * az * oc);
+        R.cx = rot(J, qx_); R.cy = rot(J, qy_); R.cz = rot(J, qz_);
+        const V3 a = rot(R, v3(ax, ay, az));
+        w = fma3(a, qdj, w); v = fma3(cross(rho, a), qdj, v);   // (world axes about the base origin: a body's v is the velocity of its point at O)
+    }
+    const V3 r_ = rho + rot(R, v3(LT.pos[l][0], LT.pos[l][1], LT.pos[l][2]));
+    const V3 vl = v + cross(w, r_);
+    float m[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const V3 col = rot(R, v3(LT.rot[l][k], LT.rot[l][3 + k], LT.rot[l][6 + k]));
+        m[k] = col.x; m[3 + k] = col.y; m[6 + k] = col.z;
+    }
+    float qx, qy, qz, qw;   // largest-component form (the oracle's m3_to_quat)
+    const float t0 = 1 + m[0] - m[4] - m[8], t1 = 1 - m[0] + m[4] - m[8], t2 = 1 - m[0] - m[4] + m[8], t3 = 1 + m[0] + m[4] + m[8];
+    if (t3 >= t0 && t3 >= t1 && t3 >= t2) { qx = m[7] - m[5]; qy = m[2] - m[6]; qz = m[3] - m[1]; qw = t3; }
+    else if (t0 >= t1 && t0 >= t2) { qx = t0; qy = m[1] + m[3]; qz = m[2] + m[6]; qw = m[7] - m[5]; }
+    else if (t1 >= t2) { qx = m[1] + m[3]; qy = t1; qz = m[5] + m[7]; qw = m[2] - m[6]; }
+    else { qx = m[2] + m[6]; qy = m[5] + m[7]; qz = t2; qw = m[3] - m[1]; }
+    const float qn = grx_rsq(qx * qx + qy * qy + qz * qz + qw * qw);
+    float* o_ = P.rbs + (size_t)(l * 13) * N + e;
+    o_[0] = pos.x + r_.x; o_[N] = pos.y + r_.y; o_[2 * N] = pos.z + r_.z;
+    o_[3 * N] = qx * qn; o_[4 * N] = qy * qn; o_[5 * N] = qz * qn; o_[6 * N] = qw * qn;
+    o_[7 * N] = vl.x; o_[8 * N] = vl.y; o_[9 * N] = vl.z;
+    o_[10 * N] = w.x; o_[11 * N] = w.y; o_[12 * N] = w.z;
+}
+extern "C" void grx_launch_refresh_heights(const KParams* dP, int N, int nh, hipStream_t stream) {
+    const size_t n = (size_t)N * (size_t)nh;
+    if (n) hipLaunchKernelGGL(grx_refresh_heights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dP);
+}
+extern "C" void grx_launch_refresh_rbs(const KParams* dP, int N, int nlinks, int pushed, hipStream_t stream) {
+    const size_t n = (size_t)N * (size_t)nlinks;
+    if (n) hipLaunchKernelGGL(grx_refresh_rbs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dP, pushed);
 }
 
 // host-callable launchers (grx_capi.cpp is compiled by hipcc too; kept separate for readability)

@@ -749,14 +749,15 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int i = 0; i < HPL; ++i) {   // (summed in the order of the rolled loop)
             const int k = c + i * TG;
-            if (k < nh) { if (act) heights[(size_t)k * N] = hraw[i]; hsum += hraw[i]; }
+            if (k < nh) { if (act && P.publish_heights) heights[(size_t)k * N] = hraw[i]; hsum += hraw[i]; }
         }
         hsum = grp_sum(hsum);
     } else {
 #pragma unroll
-        for (int i = 0; i < HPL; ++i) { const int k = c + i * TG; if (k < nh && act) heights[(size_t)k * N] = 0.f; }
+        for (int i = 0; i < HPL; ++i) { const int k = c + i * TG; if (k < nh && act && P.publish_heights) heights[(size_t)k * N] = 0.f; }
     }
     if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {
+        if (P.stash_pre_reset && actl) { P.pre_push_vel[e] = B.vel.x; P.pre_push_vel[(size_t)N + e] = B.vel.y; }   // (grx_refresh: link frames of the state BEFORE the push)
         B.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
         B.vel.y = urand(P, genv, step, GRX_RNG_PUSH, 1, -P.max_push_vel_xy, P.max_push_vel_xy);
     }
@@ -939,6 +940,17 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 12] = clock64() - tt_begin;
 #endif
     // ---- reset_idx (masked, in-kernel): a chain's joints by its lane, the base in every lane (same counters, same values)
+    if (P.stash_pre_reset && reset && act) {   // on-demand tensors (grx_refresh) show the state BEFORE reset_idx: a chain's joints by its lane, the base by lane 0 of the group
+        const size_t n_ = (size_t)N;
+#pragma unroll
+        for (int g = 0; g < TNG; ++g)
+            if (G.sb[g] >= 0) { const int j = G.sb[g] - 1; P.pre_q[(size_t)j * n_ + e] = G.q[g]; P.pre_qd[(size_t)j * n_ + e] = G.qd[g]; }
+        if (c == 0) {
+            float* r_ = P.pre_root + e;
+            r_[0] = B.pos.x; r_[n_] = B.pos.y; r_[2 * n_] = B.pos.z; r_[3 * n_] = B.qx; r_[4 * n_] = B.qy; r_[5 * n_] = B.qz; r_[6 * n_] = B.qw;
+            r_[7 * n_] = B.vel.x; r_[8 * n_] = B.vel.y; r_[9 * n_] = B.vel.z; r_[10 * n_] = B.ang.x; r_[11 * n_] = B.ang.y; r_[12 * n_] = B.ang.z;
+        }
+    }
     const bool reported_reset = reset;   // (the debug entry may report a reset without applying it)
     if (DBG && !dbg_apply_reset) reset = false;
     if (reset) {

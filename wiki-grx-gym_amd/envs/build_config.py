@@ -34,6 +34,17 @@ def resolve_gains(cfg, dof_names):
     return kp, kd, q0
 
 
+def publish_mode(v):
+    import os
+    if v is False or v is None or v == 0 or v == "never":
+        return _capi.PUBLISH_NEVER
+    if v == "every_step" or v == _capi.PUBLISH_EVERY_STEP and v is not True or os.environ.get("GRX_PUBLISH_EVERY_STEP") == "1":
+        return _capi.PUBLISH_EVERY_STEP
+    if v is True or v == "on_refresh" or v == _capi.PUBLISH_ON_REFRESH:
+        return _capi.PUBLISH_ON_REFRESH
+    raise ValueError(f"publish mode {v!r}: True / 'on_refresh', 'every_step' or False")
+
+
 def dof_armature(value, dof_names):
     """cfg.asset.armature -> one value per DOF.  A number is the reference's asset_options.armature (legged_robot.py:958,
     legged_robot_config.py:125): every DOF gets it.  A dict {substring of the joint name: kg m^2} -- the form cfg.control.stiffness /
@@ -157,7 +168,12 @@ def build(cfg, sim_dt, num_envs, env_offset=0, total_envs=None, seed=1, terrain=
         c.height_points[k][0], c.height_points[k][1] = x, y
     c.env_spacing = float(cfg.env.env_spacing)
     c.publish_reward_terms = int(getattr(cfg.env, "publish_reward_terms", True))   # make_env turns it off
-    c.publish_rigid_body_states = int(getattr(cfg.env, "publish_rigid_body_states", True))   # bench.py turns it off
+    # tensors nobody needs on every step (include/grx.h grx_publish_mode): True / "on_refresh" -- the default -- = materialised when somebody
+    # reads them (sim.tensor / env.rigid_body_states / env.measured_heights call grx_refresh: the gym.refresh_*_tensor model), "every_step" =
+    # written by the step kernel (1.9 KB + 0.5 KB per env-step), False = no such tensor (rigid_body_states only).  GRX_PUBLISH_EVERY_STEP=1
+    # forces the step-written mode (A/B runs, tests)
+    c.publish_rigid_body_states = publish_mode(getattr(cfg.env, "publish_rigid_body_states", True))
+    c.publish_measured_heights = publish_mode(getattr(cfg.env, "publish_measured_heights", True)) or _capi.PUBLISH_EVERY_STEP
     c.horizontal_scale, c.vertical_scale, c.border_size = t.horizontal_scale, t.vertical_scale, t.border_size
     c.terrain_length = t.terrain_length
     if t.mesh_type == "plane":

@@ -212,7 +212,7 @@ class GRxEnv:
         self.feet_contact = t("FEET_CONTACT").view(torch.bool)
         self.feet_air_time, self.feet_land_time, self.feet_height = t("FEET_AIR_TIME"), t("FEET_LAND_TIME"), t("FEET_HEIGHT")
         self.avg_feet_contact_force, self.avg_feet_speed_xyz = t("AVG_FEET_FORCE"), t("AVG_FEET_SPEED")
-        self.measured_heights = t("MEASURED_HEIGHTS")
+        self._measured_heights = None
         self.base_heights_offset = t("BASE_HEIGHTS_OFFSET")
         self.env_origins = t("ENV_ORIGINS")
         self.terrain_levels, self.terrain_types = t("TERRAIN_LEVELS"), t("TERRAIN_TYPES")
@@ -249,11 +249,21 @@ class GRxEnv:
     @property
     def rigid_body_states(self):
         """(N, num_links, 13) pos / quat xyzw / lin vel / ang vel of every URDF link, world frame: the layout of
-        gym.acquire_rigid_body_state_tensor (legged_robot.py:113,134).  A zero-copy view of the library tensor the step kernel
-        writes after its last sub-step (cfg.env.publish_rigid_body_states, on by default; bench.py turns it off)."""
+        gym.acquire_rigid_body_state_tensor (legged_robot.py:113,134).  A zero-copy view of the library tensor, brought up to date
+        WHEN READ (cfg.env.publish_rigid_body_states = True: grx_refresh, one small launch per step at most -- the
+        gym.refresh_rigid_body_state_tensor model, legged_robot_fftai.py:76; "every_step": the step kernel writes it after its last
+        sub-step, 1.9 KB per env-step).  Either way it shows the state before reset_idx / _push_robots, as the reference's does."""
+        full = self._sim.tensor("RIGID_BODY_STATES")     # (refreshes an on-demand tensor; the view object is cached)
         if self._rbs is None:
-            self._rbs = self._sim.tensor("RIGID_BODY_STATES")[:, :self.num_bodies]
+            self._rbs = full[:, :self.num_bodies]
         return self._rbs
+
+    @property
+    def measured_heights(self):
+        """(N, 121) raw terrain heights under the scan points (legged_robot.py:289, 1235-1274), taken before reset_idx: a zero-copy view,
+        brought up to date when read (cfg.env.publish_measured_heights = True) or written by every step ("every_step")."""
+        self._measured_heights = self._sim.tensor("MEASURED_HEIGHTS")
+        return self._measured_heights
 
     def get_observations(self):
         return self.obs_buf

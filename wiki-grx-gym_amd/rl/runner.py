@@ -65,6 +65,11 @@ class OnPolicyRunner:
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
         self.is_main = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # Perf/collection time and Perf/learning_time of the last iteration (on_policy_runner.py:235's inputs), also without a log directory;
+        # sync_timers: drain the device before each clock is read (bench.py's full_iteration leg: an iteration otherwise ends on the
+        # update's .item(), which is a synchronisation too, but the split between the two halves is the host's enqueue time)
+        self.last_collection_time = self.last_learn_time = 0.0
+        self.sync_timers = False
 
     def learn(self, num_learning_iterations, init_at_random_ep_len=False):
         env, alg = self.env, self.algorithm
@@ -104,12 +109,17 @@ class OnPolicyRunner:
                     m = alg.storage.dones.squeeze(-1).bool()
                     rewbuffer.extend(done_rew[m].cpu().tolist())
                     lenbuffer.extend(done_len[m].cpu().tolist())
+                if self.sync_timers:
+                    torch.cuda.synchronize()
                 collection_time = time.time() - start
                 start = time.time()
                 alg.compute_returns(critic_obs)
             mean_value_loss, mean_surrogate_loss = alg.update()
             alg.clear_storage()
+            if self.sync_timers:
+                torch.cuda.synchronize()
             learn_time = time.time() - start
+            self.last_collection_time, self.last_learn_time = collection_time, learn_time
             if self.log_dir is not None and self.is_main:
                 self.log(locals())
             if self.log_dir is not None and self.is_main and it % self.save_interval == 0:

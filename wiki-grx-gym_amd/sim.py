@@ -94,6 +94,9 @@ class SimHandle:
         self._h = C.c_void_p()
         self._check(api["create"](C.byref(cfg_struct), int(device_id), C.byref(self._h)), "create")
         self._views = {}
+        # tensors this handle publishes ON REFRESH (grx_publish_mode): tensor() brings them up to date before it hands out the view
+        self._on_refresh = {name for name, field in (("RIGID_BODY_STATES", "publish_rigid_body_states"), ("MEASURED_HEIGHTS", "publish_measured_heights"))
+                            if int(getattr(cfg_struct, field)) == _capi.PUBLISH_ON_REFRESH}
         self.last_stats_slot = 0   # row of EPISODE_STATS_HISTORY holding the episode statistics of the last step
         self.last_stats_seq = 0    # ... and that step's launch number (grx_step_args.stats_seq)
 
@@ -113,6 +116,8 @@ class SimHandle:
         """Zero-copy torch view of a library buffer (cached)."""
         if name == "EPISODE_STATS":
             self.flush_stats()   # a step's statistics are reduced by the NEXT launch (include/grx.h grx_flush_stats)
+        if name in self._on_refresh:
+            self.refresh(name)   # one small launch per step at most (include/grx.h grx_refresh); the view itself is cached
         if name in self._views:
             return self._views[name]
         d = _capi.TensorDesc()
@@ -127,6 +132,10 @@ class SimHandle:
             t = _wrap_host(d.data, d.dtype, shape, stride)
         self._views[name] = t
         return t
+
+    def refresh(self, name):
+        """gym.refresh_*_tensor for a tensor published ON REFRESH (include/grx.h grx_refresh); a no-op for those a step keeps current."""
+        self._check(self._api["refresh"](self._h, _capi.T[name], self._stream()), f"refresh({name})")
 
     def reset_all(self):
         self._check(self._api["reset_all"](self._h, self._stream()), "reset_all")
