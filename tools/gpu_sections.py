@@ -18,7 +18,7 @@ os.environ["GRX_PUBLISH_DEBUG"]="0"
 names=["load","substeps","footkin","update+heights","timers","reward","reset","obs","store","rows->HBM"]
 for terrain in ("plane","heightfield"):
     cfg = make_cfg(noise=True, dr=True, push=True, terrain=terrain); N=int(os.environ.get("N", 4096))
-    cfg.env.publish_rigid_body_states = False   # as bench.py
+    pass   # (bench.py = the product default: on-demand tensors on refresh)
     ter = make_terrain(cfg, N, 1)
     c,keep,_ = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
     s = HipSim(c, "cuda:0", keep); s.reset_all()

@@ -14,7 +14,7 @@ names = ["load", "substeps", "footkin", "update+heights", "timers", "reward", "r
 sub = ["walk + bias + foot contacts", "rare contacts + self-collision", "inertia / bias recursion", "base 6x6", "acceleration pass", "integration"]
 for terrain in ("plane", "heightfield"):
     cfg = make_cfg(noise=True, dr=True, push=True, terrain=terrain)
-    cfg.env.publish_rigid_body_states = False   # as bench.py
+    pass   # (bench.py = the product default: on-demand tensors on refresh)
     ter = make_terrain(cfg, N, 1)
     c, keep, _ = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
     s = HipSim(c, "cuda:0", keep); s.reset_all()

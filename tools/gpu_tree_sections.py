@@ -11,7 +11,7 @@ os.environ["GRX_PUBLISH_DEBUG"] = "0"
 names = ["outward", "contacts", "base lump", "self-collision", "inward", "base solve", "accel", "integrate+avg"]
 for terrain in ("plane", "heightfield"):
     cfg = make_cfg("GR1T1Full", noise=True, dr=True, push=True, terrain=terrain); N = int(os.environ.get("N", "4096"))
-    cfg.env.publish_rigid_body_states = False
+    pass   # (the product default: on-demand tensors on refresh)
     ter = make_terrain(cfg, N, 1)
     c, keep, _ = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
     s = HipSim(c, "cuda:0", keep); s.reset_all()

@@ -91,7 +91,9 @@ struct RbsTables {
 #define GRX_TREE_MAXSTEP 16
 #define GRX_TREE_LEVELS 10   // depth levels the tree kernel's passes are unrolled for (deeper trees run on the generic kernel)
 #define GRX_TREE_MAXCS 8     // bodies of one chain that carry collision shapes (or a foot frame): rounds of the contact pass
-struct TreeBody {            // 36 words
+// (LDS tables indexed by a lane's OWN body / joint / shape: an odd stride in words, so that the lanes of a group -- on different entries at the
+//  same field -- fall on different banks.  Round 4's TreeDof (16 words) and TreeSph (8) put them in 2 and 4 bank classes.)
+struct TreeBody {            // 37 words
     float axis[3], mass;     // joint axis (child frame), mass
     float rot0[9];           // child(q = 0) -> parent rotation, row-major
     float jpos[3];           // joint origin in the parent frame
@@ -105,8 +107,9 @@ struct TreeBody {            // 36 words
     int32_t rot0_identity;   // the joint frame is not rotated against the parent's (rot0 = 1): skips a 3 x 3 product
     int32_t pad;
 };
-struct TreeDof { float kp, kd, q0, effort, vlim, qlo, qhi, slo, shi, amin, amax, Klim, Clim; int32_t lane; float arm; int32_t pad; };   // 16 words (arm: joint-space armature)
-struct TreeSph { float x, y, z, r, dmax; int32_t slot, link, pad; };   // 8 words
+struct TreeDof { float kp, kd, q0, effort, vlim, qlo, qhi, slo, shi, amin, amax, Klim, Clim; int32_t lane; float arm; int32_t pad[2]; };   // 17 words (arm: joint-space armature)
+struct TreeSph { float x, y, z, r, dmax; int32_t slot, link, pad[2]; };   // 9 words
+static_assert(sizeof(TreeBody) == 37 * 4 && sizeof(TreeDof) == 17 * 4 && sizeof(TreeSph) == 9 * 4, "odd strides");
 struct TreeTab {
     int32_t nb, nd, nsph, nlc, nchain, nstep, nh0, g;   // g: lanes per env this table was built for (work list, link / pair rounds)
     int32_t heads0[GRX_TREE_GMAX];                       // lanes whose chain hangs from the base

@@ -47,7 +47,16 @@ __host__ __device__ inline TreeOff tree_offsets(int nb, int nlc, int nchain) {
     o.up = (nb - 1) * T_NB; o.dof = o.up + nchain * T_UPW; o.lf = o.dof + TD_N * GRX_MAX_DOFS; o.an = o.lf + nlc * 3; o.misc = o.an + 24; o.total = o.misc + T_MISC;
     return o;
 }
-#define TW(addr) wsw[(addr) * TEPW + ei]
+// LDS addressing (round 5).  ds_read_b32 / ds_write_b32 bank by (word address mod 32) and serve a wave as its two 32-lane HALVES, one LDS cycle
+// per half when its lanes fall on distinct banks (MI355X_MICROARCH.md, LDS).  Rounds 3-4 laid the rows out [word][env of the WAVE]: a half holds
+// only half of the wave's envs, so half of the banks idled and the lanes of a group -- on different bodies at the same word -- shared
+// 32 / TEPW = 4 (8) row classes: 26 % of the LDS-active cycles were conflicts (profiles/r04_pmc_sq_full_body_rough4096.json).  Now every HALF
+// keeps its own block of rows, [word][env of the half]: bank = (row mod (32 / TEH)) * TEH + env -- 8 (16) row classes over all 32 banks, and
+// with the odd body stride (25 = 1 mod 8, 9 mod 16) the bodies a group's lanes work on at one depth level (b, b + 6, b + 12, ...: the chains
+// are numbered consecutively) fall in different classes.  `ei` below is the lane's offset (half * block + env of the half), not an env index.
+constexpr int TEH = TEPW / 2;      // envs per half wave
+__host__ __device__ inline int tree_half_words(int total) { return (total * TEH + 31) / 32 * 32; }   // a half's block, bank-aligned
+#define TW(addr) wsw[(addr) * TEH + ei]
 
 GRX_DEV float grp_sum(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); if (TG == 16) v += __shfl_xor(v, 8); return v; }
 GRX_DEV float grp_bcast(float v, int lane, int src) { return __shfl(v, (lane & ~(TG - 1)) | src); }
@@ -479,12 +488,14 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     __syncthreads();
     const TreeTab& T = Tm;
     const int nwaves = blockDim.x >> 6, tepb = TEPW * nwaves;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ei = lane / TG, c = lane & (TG - 1);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ew = lane / TG, c = lane & (TG - 1);   // ew: the env of the wave
     if (wave == nwaves - 1) stats_fold_previous(P, sq, lane);   // the previous launch's episode statistics (and its ticket)
     const TreeOff o = tree_offsets(T.nb, T.nlc, T.nchain);
-    float* const wsw = s_dyn + sizeof(TreeTab) / 4 + (size_t)wave * o.total * TEPW;
+    const int thalf = tree_half_words(o.total);
+    float* const wsw = s_dyn + sizeof(TreeTab) / 4 + (size_t)wave * 2 * thalf;
+    const int ei = (ew / TEH) * thalf + (ew % TEH);   // (TW: the lane's offset into its half's block)
     const size_t N = (size_t)P.N;
-    const int e_raw = blockIdx.x * tepb + wave * TEPW + ei;
+    const int e_raw = blockIdx.x * tepb + wave * TEPW + ew;
     const bool act = e_raw < P.N;
     const int e = act ? e_raw : P.N - 1;
     const bool lead = c == 0, actl = act && lead;
