@@ -98,7 +98,7 @@ def full_iteration(args, n_local, iters, warm=2):
     cfg = make_cfg(args.terrain, args.robot)
     cfg.seed = 1
     env, _ = task_registry.make_env(task, args=a, env_cfg=cfg)
-    tcfg = config.GR1T1CfgPPO() if args.robot == "lower_limb" else config.GR1T1FullCfgPPO()
+    tcfg = config.GR1T1CfgPPO() if args.robot == "lower_limb" else config.GR1T1FullBodyCfgPPO()
     tcfg.seed = 1
     runner, _ = task_registry.make_alg_runner(env, name=task, args=a, train_cfg=tcfg, log_root=None)
     runner.sync_timers = True

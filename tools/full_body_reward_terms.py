@@ -7,10 +7,10 @@ from tests.helpers import *
 from wiki_grx_gym_amd.sim import HipSim
 from wiki_grx_gym_amd.envs import build_config
 N = 1024
+STDS = [float(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0.0, 0.2]
 for robot, nd in (("GR1T1", 10), ("GR1T1Full", 32)):
-    for std in (0.0, 0.2):
+    for std in STDS:
         cfg = make_cfg(robot, noise=True, dr=True, push=False, terrain="heightfield")
-        cfg.env.publish_rigid_body_states = False
         ter = make_terrain(cfg, N, 1)
         c, keep, info = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
         s = HipSim(c, "cuda:0", keep); s.reset_all()

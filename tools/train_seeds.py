@@ -18,20 +18,27 @@ os.makedirs("gpurun_out", exist_ok=True)
 runs = []
 for seed in range(1, seeds + 1):
     import torch
-    from wiki_grx_gym_amd.envs import GR1T1Cfg, GR1T1CfgPPO, GR1T1FullBodyCfg, GR1T1FullCfgPPO
+    from wiki_grx_gym_amd.envs import GR1T1Cfg, GR1T1CfgPPO, GR1T1FullBodyCfg, GR1T1FullBodyCfgPPO
     from wiki_grx_gym_amd.utils import get_args, task_registry
     args = get_args(["--task", task, "--headless", "--num_envs", str(envs), "--seed", str(seed), "--max_iterations", str(iters)])
     cfg = GR1T1FullBodyCfg() if full else GR1T1Cfg()
     cfg.terrain.mesh_type = terrain
     if os.environ.get("GRX_TRAIN_ONLY_POSITIVE") == "1":   # (diagnosis of the 32-DOF task: legged_robot.py:251-252's clip of the total reward at zero, off in the GR1T1 configs)
         cfg.rewards.only_positive_rewards = True
+    if os.environ.get("GRX_TRAIN_ANKLE_ROLL"):   # (diagnosis of the 32-DOF task: "kp,kd" of the ankle-roll actuators, reference 0.25 / 0.01 -- practically free)
+        kp_, kd_ = (float(x) for x in os.environ["GRX_TRAIN_ANKLE_ROLL"].split(","))
+        cfg.control.stiffness = dict(cfg.control.stiffness, ankle_roll=kp_); cfg.control.damping = dict(cfg.control.damping, ankle_roll=kd_)
+    if os.environ.get("GRX_TRAIN_TERMINATION"):   # (diagnosis: scale of the `termination` term, reference -0.0)
+        cfg.rewards.scales.termination = float(os.environ["GRX_TRAIN_TERMINATION"])
     cfg.seed = seed
     env, _ = task_registry.make_env(task, args=args, env_cfg=cfg)
     layout = env._sim.layout()
-    tcfg = GR1T1FullCfgPPO() if full else GR1T1CfgPPO()
+    tcfg = GR1T1FullBodyCfgPPO() if full else GR1T1CfgPPO()
     tcfg.seed = seed
     if os.environ.get("GRX_TRAIN_INIT_NOISE"):   # (diagnosis of the 32-DOF task: exploration noise of the fresh policy, reference 0.2)
         tcfg.policy.init_noise_std = float(os.environ["GRX_TRAIN_INIT_NOISE"])
+    if os.environ.get("GRX_TRAIN_ENTROPY"):
+        tcfg.algorithm.entropy_coef = float(os.environ["GRX_TRAIN_ENTROPY"])
     tcfg.runner.save_interval = 10 ** 9
     runner, tcfg = task_registry.make_alg_runner(env, name=task, args=args, train_cfg=tcfg, log_root=f"gpurun_out/train_{tag}_s{seed}")
     t0 = time.time()
@@ -57,9 +64,9 @@ for seed in range(1, seeds + 1):
                "episode_length_mean": float(l_.mean()), "wall_s_mean": float(w_.mean()), "wall_s_sd": float(w_.std(ddof=1)) if len(runs) > 1 else None,
                "note": "reward_at_end = mean of Train/mean_reward over the last 100 iterations; PPO hyper-parameters of the registered GR1T1 task "
                        "(gr1t1_lower_limb_config.py; the full-body task: this build's GR1T1FullCfgPPO); no reference curve exists to compare with (Isaac Gym is absent: BASELINE.md)",
-               "overrides": {k: os.environ[k] for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE") if k in os.environ},
+               "overrides": {k: os.environ[k] for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE", "GRX_TRAIN_ANKLE_ROLL", "GRX_TRAIN_TERMINATION", "GRX_TRAIN_ENTROPY") if k in os.environ},
                "runs": runs}
-    json.dump(summary, open(f"gpurun_out/learning_curve_{tag}_{envs}" + ("_overrides" if any(k in os.environ for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE")) else "") + ".json", "w"), indent=1)
+    json.dump(summary, open(f"gpurun_out/learning_curve_{tag}_{envs}" + ("_overrides" if any(k in os.environ for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE", "GRX_TRAIN_ANKLE_ROLL", "GRX_TRAIN_TERMINATION", "GRX_TRAIN_ENTROPY")) else "") + ".json", "w"), indent=1)
     env.close()
     del runner, env
     torch.cuda.empty_cache()
