@@ -478,6 +478,11 @@ typedef struct grx_pipeline_state {
  * resets are reported in GRX_T_RESET but not applied.  Lower-limb (fused-kernel) models only. */
 int grx_debug_post_physics(grx_handle h, const grx_pipeline_state* states, int apply_reset, const grx_step_args* args, void* stream);
 
+/* TEST-ONLY: the step kernels' PHYSICS terrain query -- height and gradient (dh/dx, dh/dy) of the contact surface under n points: xy HOST
+ * float[n][2] (world coordinates), out HOST float[n][3].  The oracle's twin is gro_debug_terrain; tests/test_terrain_golden.py ray-casts the
+ * reference's slope-corrected triangle mesh (isaacgym terrain_utils.py:286-350) against both. */
+int grx_debug_terrain(grx_handle h, const float* xy, int32_t n, float* out, void* stream);
+
 /* TEST-ONLY: the wave pipelines of the step kernels hand over through LDS flags and spin on them.  A library built
  * with -DGRX_SPIN_LIMIT (csrc/variants/libgrx_spinlimit.so) bounds every spin; an expired one stores 'SP' << 48 | block << 32 | LDS
  * address of the flag << 16 | value waited for in a host-pinned word and traps.  *code = that word (0: none expired; readable after

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from tests.helpers import make_cfg, make_sims
@@ -115,3 +116,115 @@ def test_selected_terrain_builds_every_tile_from_one_generator():
         stepping_stones(tile, rng, 0.8, 0.2, 0.05, 2.0)
         np.testing.assert_array_equal(ter.heightsamples[b + i * px: b + (i + 1) * px, b + j * px: b + (j + 1) * px], tile.height_field_raw)
     assert ter.heightsamples.min() == -2000
+
+
+# ---- mesh_type 'trimesh': the physics terrain surface against the reference's slope-corrected triangle mesh ----
+def _mesh_height(v, t, pts):
+    """Height of the TOP surface of the triangle mesh (v, t) under the (n, 2) points: a vertical ray, the highest hit; triangles whose
+    projection is degenerate (the corrected, vertical faces) do not count."""
+    a, b, c = v[t[:, 0]], v[t[:, 1]], v[t[:, 2]]
+    den = (b[:, 1] - c[:, 1]) * (a[:, 0] - c[:, 0]) + (c[:, 0] - b[:, 0]) * (a[:, 1] - c[:, 1])
+    ok = np.abs(den) > 1e-9
+    a, b, c, den = a[ok], b[ok], c[ok], den[ok]
+    out = np.full(len(pts), -1e9)
+    for i0 in range(0, len(pts), 256):
+        p = pts[i0:i0 + 256]
+        l1 = ((b[None, :, 1] - c[None, :, 1]) * (p[:, None, 0] - c[None, :, 0]) + (c[None, :, 0] - b[None, :, 0]) * (p[:, None, 1] - c[None, :, 1])) / den[None]
+        l2 = ((c[None, :, 1] - a[None, :, 1]) * (p[:, None, 0] - c[None, :, 0]) + (a[None, :, 0] - c[None, :, 0]) * (p[:, None, 1] - c[None, :, 1])) / den[None]
+        l3 = 1 - l1 - l2
+        z = np.where((l1 >= -1e-9) & (l2 >= -1e-9) & (l3 >= -1e-9), l1 * a[None, :, 2] + l2 * b[None, :, 2] + l3 * c[None, :, 2], -1e9)
+        out[i0:i0 + 256] = z.max(1)
+    return out
+
+
+def _trimesh_tile(name):
+    """(cfg, terrain namespace, fixture arrays) of one tile of tests/golden/trimesh_tiles.npz as a 1 x 1 terrain without border."""
+    import types
+    d = np.load(os.path.join(G, "trimesh_tiles.npz"))
+    cfg = make_cfg(terrain="trimesh", curriculum=False)
+    cfg.terrain.border_size = 0.0
+    cfg.terrain.num_rows = cfg.terrain.num_cols = 1
+    assert cfg.terrain.horizontal_scale == float(d["horizontal_scale"]) and cfg.terrain.vertical_scale == float(d["vertical_scale"]) and cfg.terrain.slope_treshold == float(d["slope_threshold"])
+    blk = d[name + "_raster"]
+    ter = types.SimpleNamespace(heightsamples=blk, env_origins=np.zeros((1, 1, 3), np.float32))
+    return cfg, ter, blk, d[name + "_vertices"].astype(np.float64), d[name + "_triangles"]
+
+
+def check_trimesh_surface(query, name, tol):
+    """`query((n, 2) points) -> heights` of the build's physics terrain (oracle or HIP) against a vertical ray cast onto the REFERENCE's mesh of the
+    same raster (isaacgym terrain_utils.py:286-350 with slope_threshold 0.75, the call of legged_robot.py:903-921).  The build keeps the raster and
+    stands a corrected (vertical) face up as a ramp over the last quarter cell before its HIGH vertex (csrc/grx_kernels.hip riser_weight), so:
+      * OUTSIDE THE BAND -- the cells that hold a corrected edge or a vertex the reference moved -- the two surfaces are the same to `tol`
+        (the band is 57 % of the pyramid-stairs tile, whose treads are three cells deep, and 16 % of the discrete-obstacles tile);
+      * in a band cell that is steep along ONE axis, the surfaces differ by more than a millimetre only inside that last quarter cell (2.5 cm)
+        before the high vertex: the tread keeps its height up to there, the riser stands within 2.5 cm of where the reference has it;
+      * anywhere, the difference is bounded by the raster's local step."""
+    cfg, ter, blk, v, t = _trimesh_tile(name)
+    hs, vs = cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale
+    H = blk.astype(np.int32)
+    n = H.shape[0]
+    T = cfg.terrain.slope_treshold * hs / vs
+    gx, gy = np.meshgrid(np.arange(n) * hs, np.arange(n) * hs, indexing="ij")
+    moved = (np.abs(v[:, 0].reshape(n, n) - gx) > 1e-6) | (np.abs(v[:, 1].reshape(n, n) - gy) > 1e-6)
+    sx, sy = np.abs(np.diff(H, axis=0)) > T, np.abs(np.diff(H, axis=1)) > T
+    cell_sx, cell_sy = sx[:, :-1] | sx[:, 1:], sy[:-1, :] | sy[1:, :]
+    band = cell_sx | cell_sy | moved[:-1, :-1] | moved[1:, :-1] | moved[:-1, 1:] | moved[1:, 1:]
+    assert moved.sum() > 400 and 0.1 < band.mean() < 0.7, (name, moved.sum(), band.mean())
+    g = np.arange(0.513, 7.4, 0.0731)                      # 95 x 95 points, incommensurate with the 0.1 m raster
+    pts = np.array([(x, y) for x in g for y in g])
+    hm = _mesh_height(v, t, pts)
+    hq = np.asarray(query(pts), dtype=np.float64)
+    dev = np.abs(hm - hq)
+    ij = np.floor(pts / hs).astype(int)
+    inb = band[ij[:, 0], ij[:, 1]]
+    assert (~inb).sum() > 1500 and dev[~inb].max() <= tol, (name, dev[~inb].max())
+    for axis, cs, other in ((0, cell_sx, cell_sy), (1, cell_sy, cell_sx)):
+        sel = (cs & ~other)[ij[:, 0], ij[:, 1]]
+        f = pts[:, axis] / hs - ij[:, axis]
+        hi = H[ij[:, 0] + (axis == 0), ij[:, 1] + (axis == 1)] - H[ij[:, 0], ij[:, 1]]
+        in_quarter = ((hi > T) & (f > 0.75)) | ((-hi > T) & (f < 0.25))
+        big = sel & (dev > 1e-3)
+        assert sel.sum() > 100 and (big & ~in_quarter).sum() <= 0.02 * max(big.sum(), 1) + 1, (name, axis, int(sel.sum()), int(big.sum()), int((big & ~in_quarter).sum()))
+    # bounded by the local step of the raster (3 x 3 vertices around the cell)
+    pad = np.pad(H, 1, mode="edge")
+    loc = np.stack([pad[1 + di:1 + di + n, 1 + dj:1 + dj + n] for di in (-1, 0, 1) for dj in (-1, 0, 1)])
+    step = (loc.max(0) - loc.min(0)) * vs
+    cell_step = np.maximum.reduce([step[:-1, :-1], step[1:, :-1], step[:-1, 1:], step[1:, 1:]])
+    assert (dev <= cell_step[ij[:, 0], ij[:, 1]] + tol).all()
+    return float(inb.mean()), float(dev[~inb].max())
+
+
+@pytest.mark.parametrize("name", ["stairs", "obstacles"])
+def test_trimesh_surface_against_the_reference_mesh(name):
+    from oracle.binding import OracleSim
+    from wiki_grx_gym_amd.envs import build_config
+    cfg, ter, _, _, _ = _trimesh_tile(name)
+    c, keep, _ = build_config.build(cfg, cfg.sim.dt, 1, terrain=ter)
+    assert c.vertical_faces == 1
+    for prec, tol in (("f64", 1e-6), ("f32", 2e-5)):
+        ora = OracleSim(c, prec, keep)
+        check_trimesh_surface(lambda pts: [ora.terrain(x, y)[0] for x, y in pts], name, tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["stairs", "obstacles"])
+def test_trimesh_surface_of_the_hip_kernels_against_the_reference_mesh(name):
+    """The same check on the step kernels' own terrain query (grx_debug_terrain launches terrain_height<true>), and HIP = oracle point by point."""
+    from oracle.binding import OracleSim
+    from wiki_grx_gym_amd.envs import build_config
+    from wiki_grx_gym_amd.sim import HipSim
+    cfg, ter, _, _, _ = _trimesh_tile(name)
+    c, keep, _ = build_config.build(cfg, cfg.sim.dt, 16, terrain=ter)
+    sim = HipSim(c, "cuda:0", keep)
+    band_frac, worst = check_trimesh_surface(lambda pts: sim.debug_terrain(pts)[:, 0], name, 2e-5)
+    print(name, "band", band_frac, "largest deviation outside it", worst)
+    c2, keep2, _ = build_config.build(cfg, cfg.sim.dt, 16, terrain=ter)
+    ora = OracleSim(c2, "f32", keep2)
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(0.05, 7.85, size=(2000, 2))
+    a = sim.debug_terrain(pts)
+    b = np.array([ora.terrain(x, y) for x, y in pts.astype(np.float32)])
+    # (a point within rounding of a cell edge or of the quarter-cell ramp's start may sit on the other side in one of the two)
+    close = (np.abs(a[:, 0] - b[:, 0]) <= 2e-5) & (np.abs(a[:, 1:] - b[:, 1:]) <= 1e-3 + 1e-3 * np.abs(b[:, 1:])).all(1)
+    assert close.mean() >= 0.995, close.mean()
+    sim.close()

@@ -513,6 +513,35 @@ def gen_terrain_all_tiles(out):
     #  self.vertical_scale / self.horizontal_scale do not exist -- and eval()s the generator name)
 
 
+def gen_trimesh_tiles(out):
+    """The reference's slope-corrected triangle mesh (isaacgym terrain_utils.py:286-350 convert_heightfield_to_trimesh, slope_threshold 0.75:
+    legged_robot.py:903-921 passes cfg.terrain.slope_treshold) of two tiles of the curriculum raster of terrain_all_tiles.npz -- one
+    pyramid-stairs tile, one discrete-obstacles tile: raster block in, vertices + triangles out.  The build's physics
+    keeps the raster and models a corrected (vertical) face as a ramp over the last quarter cell before its HIGH vertex
+    (csrc/grx_kernels.hip riser_weight); tests/test_terrain_golden.py ray-casts this mesh against that height function."""
+    from legged_gym.utils.terrain import Terrain
+    from legged_gym.envs.base.legged_robot_config import LeggedRobotCfg
+    from isaacgym.terrain_utils import convert_heightfield_to_trimesh
+    tcfg = LeggedRobotCfg.terrain()
+    tcfg.mesh_type = "trimesh"
+    tcfg.num_rows, tcfg.num_cols, tcfg.border_size = 3, 10, 5
+    tcfg.terrain_proportions = [0.1, 0.1, 0.2, 0.2, 0.1, 0.1, 0.1, 0.1]
+    np.random.seed(5)
+    ter = Terrain(tcfg, 30)          # the raster of terrain_all_tiles.npz
+    b, px = ter.border, ter.length_per_env_pixels
+    data = {"horizontal_scale": tcfg.horizontal_scale, "vertical_scale": tcfg.vertical_scale, "slope_threshold": tcfg.slope_treshold}
+    for name, (row, col) in (("stairs", (2, 3)), ("obstacles", (2, 6))):      # hardest level of a stairs-up column and of the discrete-obstacles column
+        blk = ter.height_field_raw[b + row * px: b + (row + 1) * px, b + col * px: b + (col + 1) * px].copy()
+        v, t = convert_heightfield_to_trimesh(blk, tcfg.horizontal_scale, tcfg.vertical_scale, tcfg.slope_treshold)
+        moved = (np.abs(v[:, 0] / tcfg.horizontal_scale - np.rint(v[:, 0] / tcfg.horizontal_scale)) > 1e-3).sum()
+        assert blk.max() - blk.min() > 20 and (np.abs(np.diff(blk.astype(np.int32), axis=0)) > tcfg.slope_treshold * tcfg.horizontal_scale / tcfg.vertical_scale).any(), name
+        data[name + "_raster"] = blk.astype(np.int16)
+        data[name + "_vertices"] = v.astype(np.float32)
+        data[name + "_triangles"] = t.astype(np.int32)
+        print(name, blk.shape, "raster range", blk.min(), blk.max(), "vertices", v.shape, "triangles", t.shape, "off-grid x", int(moved))
+    np.savez_compressed(os.path.join(out, "trimesh_tiles.npz"), **data)
+
+
 def gen_config(out):
     from legged_gym.envs import GR1T1Cfg, GR1T1CfgPPO, GR1T2Cfg, GR1T2CfgPPO
     from legged_gym.utils.helpers import class_to_dict
@@ -595,6 +624,7 @@ def main():
     gen_reward_terms(OUT)
     gen_terrain_and_heights(OUT)
     gen_terrain_all_tiles(OUT)
+    gen_trimesh_tiles(OUT)
     gen_config(OUT)
     gen_ppo(OUT)
     for f in sorted(os.listdir(OUT)):

@@ -49,6 +49,7 @@ void grx_launch_mark(const int32_t* env_ids, int n, int N, uint8_t* mask, hipStr
 void grx_launch_set_state(const KParams* dP, int N, const float* root, const float* q, const float* qd, const int32_t* env_ids, int n, hipStream_t stream);
 int grx_envs_per_block(void);
 void grx_launch_refresh_heights(const KParams* dP, int N, int nh, hipStream_t stream);
+void grx_launch_debug_terrain(const KParams* dP, const float* xy, int n, float* out, hipStream_t stream);
 void grx_launch_refresh_rbs(const KParams* dP, int N, int nlinks, int pushed, hipStream_t stream);
 void grx_launch_step_debug(const KParams* dP, int N, int heightfield, int waves, const float* actions, long long common_step, const float* noise,
                            const float* dbg, const StepSeq* sq, hipStream_t stream);
@@ -1476,6 +1477,23 @@ int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply
     else grx_launch_step_debug(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, s->d_dbg_actions, (long long)a->common_step_counter,
                                a->noise_uniform, s->d_dbg, &sq, st);
     HIP_TRY(hipGetLastError());
+    return GRX_OK;
+}
+
+// TEST-ONLY: the step kernels' physics terrain query at n host points (x, y) -> host (height, dh/dx, dh/dy) each (include/grx.h)
+int grx_debug_terrain(grx_handle s, const float* xy, int32_t n, float* out, void* stream) {
+    if (!s || (n > 0 && (!xy || !out))) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_terrain: null argument");
+    if (n <= 0) return GRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float *dxy = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&dxy, (size_t)n * 2 * sizeof(float)));
+    if (hipMalloc(&dout, (size_t)n * 3 * sizeof(float)) != hipSuccess) { hipFree(dxy); return fail(GRX_ERR_OUT_OF_MEMORY, "grx_debug_terrain: out of device memory"); }
+    hipError_t e = hipMemcpyAsync(dxy, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) { grx_launch_debug_terrain(s->d_hp, dxy, n, dout, st); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(dxy); hipFree(dout);
+    if (e != hipSuccess) return fail(GRX_ERR_HIP, std::string("grx_debug_terrain: ") + hipGetErrorString(e));
     return GRX_OK;
 }
 

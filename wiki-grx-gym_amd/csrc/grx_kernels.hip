@@ -2381,6 +2381,18 @@ __global__ __launch_bounds__(256) void grx_refresh_rbs_kernel(const KParams* __r
     o_[7 * N] = vl.x; o_[8 * N] = vl.y; o_[9 * N] = vl.z;
     o_[10 * N] = w.x; o_[11 * N] = w.y; o_[12 * N] = w.z;
 }
+// TEST-ONLY (grx_debug_terrain): the physics terrain query of the step kernels -- height and gradient of the surface under (x, y) -- at n points
+__global__ void grx_debug_terrain_kernel(const KParams* __restrict__ Pg, const float* __restrict__ xy, int n, float* __restrict__ out) {
+    KP P = GRX_PARAMS(Pg);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gx = 0.f, gy = 0.f, h = 0.f;
+    if (P.terrain_type != GRX_TERRAIN_PLANE) h = terrain_height<true>(P, xy[2 * i], xy[2 * i + 1], gx, gy);
+    out[3 * i] = h; out[3 * i + 1] = gx; out[3 * i + 2] = gy;
+}
+extern "C" void grx_launch_debug_terrain(const KParams* dP, const float* xy, int n, float* out, hipStream_t stream) {
+    if (n > 0) hipLaunchKernelGGL(grx_debug_terrain_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dP, xy, n, out);
+}
 extern "C" void grx_launch_refresh_heights(const KParams* dP, int N, int nh, hipStream_t stream) {
     const size_t n = (size_t)N * (size_t)nh;
     if (n) hipLaunchKernelGGL(grx_refresh_heights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dP);

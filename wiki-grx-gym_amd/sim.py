@@ -216,6 +216,14 @@ class SimHandle:
             a.noise_uniform = noise_uniform.data_ptr()
         self._check(self._api["debug_post_physics"](self._h, states, int(bool(apply_reset)), C.byref(a), self._stream()), "debug_post_physics")
 
+    def debug_terrain(self, xy):
+        """TEST-ONLY (include/grx.h grx_debug_terrain): (n, 3) height and gradient of the physics terrain surface under the (n, 2) points."""
+        xy = np.ascontiguousarray(xy, dtype=np.float32)
+        out = np.zeros((xy.shape[0], 3), dtype=np.float32)
+        self._check(self._api["debug_terrain"](self._h, xy.ctypes.data_as(C.POINTER(C.c_float)), int(xy.shape[0]),
+                                               out.ctypes.data_as(C.POINTER(C.c_float)), self._stream()), "debug_terrain")
+        return out
+
     def episode_stats(self):
         out = (C.c_float * (_capi.NUM_REWARD_TERMS + 2))()   # means, [NT] episodes that ended, [NT + 1] mean terrain level
         self._check(self._api["episode_stats"](self._h, out, self._stream()), "episode_stats")
