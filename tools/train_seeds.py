@@ -30,13 +30,16 @@ for seed in range(1, seeds + 1):
         cfg.control.stiffness = dict(cfg.control.stiffness, ankle_roll=kp_); cfg.control.damping = dict(cfg.control.damping, ankle_roll=kd_)
     if os.environ.get("GRX_TRAIN_TERMINATION"):   # (diagnosis: scale of the `termination` term, reference -0.0)
         cfg.rewards.scales.termination = float(os.environ["GRX_TRAIN_TERMINATION"])
+    for kv in os.environ.get("GRX_TRAIN_SET", "").split(";"):      # (diagnosis) e.g. "control.stiffness['ankle_roll']=28.6;asset.armature['ankle_roll']=0.01"
+        if kv.strip():
+            exec("cfg." + kv.strip(), {"cfg": cfg})
     cfg.seed = seed
     env, _ = task_registry.make_env(task, args=args, env_cfg=cfg)
     layout = env._sim.layout()
     tcfg = GR1T1FullBodyCfgPPO() if full else GR1T1CfgPPO()
     tcfg.seed = seed
     if os.environ.get("GRX_TRAIN_INIT_NOISE"):   # (diagnosis of the 32-DOF task: exploration noise of the fresh policy, reference 0.2)
-        tcfg.policy.init_noise_std = float(os.environ["GRX_TRAIN_INIT_NOISE"])
+        tcfg.policy.init_noise_std = [float(x) for x in os.environ["GRX_TRAIN_INIT_NOISE"].split(",")] if "," in os.environ["GRX_TRAIN_INIT_NOISE"] else float(os.environ["GRX_TRAIN_INIT_NOISE"])
     if os.environ.get("GRX_TRAIN_ENTROPY"):
         tcfg.algorithm.entropy_coef = float(os.environ["GRX_TRAIN_ENTROPY"])
     tcfg.runner.save_interval = 10 ** 9
@@ -46,6 +49,9 @@ for seed in range(1, seeds + 1):
         runner.learn(num_learning_iterations=iters, init_at_random_ep_len=True)
     dt = time.time() - t0
     rows = [json.loads(l) for l in open(os.path.join(runner.log_dir, "scalars.jsonl"))]
+    for f_ in os.listdir(runner.log_dir):      # (gpurun merges at most 64 MiB back: the checkpoints of a curve run are not needed)
+        if f_.endswith(".pt") or f_.startswith("events.out"):
+            os.remove(os.path.join(runner.log_dir, f_))
     def series(tag):
         return np.array([r["value"] for r in rows if r["tag"] == tag], dtype=np.float64)
     rew, eplen = series("Train/mean_reward"), series("Train/mean_episode_length")
@@ -64,9 +70,9 @@ for seed in range(1, seeds + 1):
                "episode_length_mean": float(l_.mean()), "wall_s_mean": float(w_.mean()), "wall_s_sd": float(w_.std(ddof=1)) if len(runs) > 1 else None,
                "note": "reward_at_end = mean of Train/mean_reward over the last 100 iterations; PPO hyper-parameters of the registered GR1T1 task "
                        "(gr1t1_lower_limb_config.py; the full-body task: this build's GR1T1FullCfgPPO); no reference curve exists to compare with (Isaac Gym is absent: BASELINE.md)",
-               "overrides": {k: os.environ[k] for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE", "GRX_TRAIN_ANKLE_ROLL", "GRX_TRAIN_TERMINATION", "GRX_TRAIN_ENTROPY") if k in os.environ},
+               "overrides": {k: os.environ[k] for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE", "GRX_TRAIN_ANKLE_ROLL", "GRX_TRAIN_TERMINATION", "GRX_TRAIN_ENTROPY", "GRX_TRAIN_SET") if k in os.environ},
                "runs": runs}
-    json.dump(summary, open(f"gpurun_out/learning_curve_{tag}_{envs}" + ("_overrides" if any(k in os.environ for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE", "GRX_TRAIN_ANKLE_ROLL", "GRX_TRAIN_TERMINATION", "GRX_TRAIN_ENTROPY")) else "") + ".json", "w"), indent=1)
+    json.dump(summary, open(f"gpurun_out/learning_curve_{tag}_{envs}" + ("_overrides" if any(k in os.environ for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE", "GRX_TRAIN_ANKLE_ROLL", "GRX_TRAIN_TERMINATION", "GRX_TRAIN_ENTROPY", "GRX_TRAIN_SET")) else "") + ".json", "w"), indent=1)
     env.close()
     del runner, env
     torch.cuda.empty_cache()

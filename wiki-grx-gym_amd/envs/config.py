@@ -337,15 +337,14 @@ class GR1T1FullBodyCfg(GR1T1FullCfg):
 
 
 class GR1T1FullBodyCfgPPO(GR1T1FullCfgPPO):
-    """PPO settings of the build-defined 32-DOF task (registered as "GR1T1_full_body").  The reference's, except the two that scale with the
-    number of action dimensions: the entropy bonus (the Gaussian's entropy grows linearly with the 32 dimensions: 0.01 drove the action noise UP
-    from the start, 0.10 -> 0.16 in 500 iterations, while the reward gradient was still weak) and the initial action noise (0.2 rad on the
-    shoulder / elbow / waist actuators, kp / kd = 36 1/s, commands 7.2 rad/s -- beyond their URDF velocity limits: limits_dof_vel alone cost
-    -0.05 per step).  Measured in round 5 (profiles/r05_learning_full_body_trials.json): with these the episode reward rises (-3.9 -> +2.1 in
-    500 iterations) instead of collapsing to 4-step episodes; the episode LENGTH stays at ~60 steps in every variant tried -- the robot does
-    not learn to catch its fall within 500 iterations."""
-    algorithm = section("algorithm", GR1T1FullCfgPPO.algorithm, entropy_coef=0.01 * 10.0 / 32.0)
-    policy = section("policy", GR1T1FullCfgPPO.policy, init_noise_std=0.1)
+    """PPO settings of the build-defined 32-DOF task (registered as "GR1T1_full_body"): the reference's, except the INITIAL action noise of the
+    upper-body joints.  0.2 rad on the legs, as in the lower-limb task -- round 5 measured that the legs need that exploration to discover
+    the stepping that keeps the robot up (with 0.1 and a smaller entropy bonus the reward rose but the episodes stayed at ~60 steps for
+    every variant of the robot: profiles/r05_learning_full_body_trials.json) --, 0.05 rad on the waist / head / arm joints: their actuators
+    (kp / kd = 36 1/s on shoulders, elbows and waist) turn 0.2 rad of noise into 7.2 rad/s, beyond their URDF velocity limits, and
+    limits_dof_vel then costs more per step than standing earns -- ending the episode pays and the run collapses to 4-step episodes
+    (rounds 4-5).  The standard deviations stay learnable parameters; the entropy bonus raises them once balance is learnt."""
+    policy = section("policy", GR1T1FullCfgPPO.policy, init_noise_std=[0.2] * 12 + [0.05] * 20)
 
 
 class GR1T1LowerLimbCfgPPO(GR1T1FullCfgPPO, GR1T1LowerLimbCfg):

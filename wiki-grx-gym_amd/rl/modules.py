@@ -149,7 +149,8 @@ class ActorCriticMLP(nn.Module):
         self.actor = MLP(actor_num_input, actor_num_output, actor_hidden_dims, activation)
         self.critic = MLP(critic_num_input, 1, critic_hidden_dims, activation)
         self.fixed_std, self.init_noise_std = fixed_std, init_noise_std
-        self.std = nn.Parameter(init_noise_std * torch.ones(actor_num_output))
+        # (a number, as in the reference -- actor_critic_mlp.py -- or one value per action: the 32-DOF task starts its upper-body joints quieter)
+        self.std = nn.Parameter(torch.as_tensor(init_noise_std, dtype=torch.float32) * torch.ones(actor_num_output))
         self.set_std, self.set_noise_std = set_std, set_noise_std
         self.distribution = None
         Normal.set_default_validate_args = False
@@ -164,7 +165,7 @@ class ActorCriticMLP(nn.Module):
         #  the storage the captured act / update graphs and the optimizer state point at)
         if self.fixed_std:
             with torch.no_grad():
-                self.std.fill_(self.init_noise_std)
+                self.std.copy_(torch.as_tensor(self.init_noise_std, dtype=torch.float32) * torch.ones_like(self.std))
             self.std.requires_grad = False
             state_dict["std"] = self.std.detach().clone()
         return super().load_state_dict(state_dict, strict)
