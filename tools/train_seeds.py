@@ -66,7 +66,7 @@ for seed in range(1, seeds + 1):
     print(json.dumps({k: v for k, v in res.items() if not isinstance(v, list)}), flush=True)
     r_ = np.array([r["reward_at_end"] for r in runs]); l_ = np.array([r["episode_length_at_end"] for r in runs]); w_ = np.array([r["wall_s"] for r in runs])
     summary = {"task": ("GR1T1 full body (32 DOF), " if full else "GR1T1 (lower limb), ") + ("flat plane" if terrain == "plane" else terrain), "num_envs": envs, "iterations": iters, "seeds": len(runs),
-               "step_kernel": layout, "reward_at_1500_mean": float(r_.mean()), "reward_at_1500_sd": float(r_.std(ddof=1)) if len(runs) > 1 else None,
+               "step_kernel": layout, "reward_at_end_mean": float(r_.mean()), "iterations_run": iters, "reward_at_end_sd": float(r_.std(ddof=1)) if len(runs) > 1 else None,
                "episode_length_mean": float(l_.mean()), "wall_s_mean": float(w_.mean()), "wall_s_sd": float(w_.std(ddof=1)) if len(runs) > 1 else None,
                "note": "reward_at_end = mean of Train/mean_reward over the last 100 iterations; PPO hyper-parameters of the registered GR1T1 task "
                        "(gr1t1_lower_limb_config.py; the full-body task: this build's GR1T1FullCfgPPO); no reference curve exists to compare with (Isaac Gym is absent: BASELINE.md)",
