@@ -123,3 +123,27 @@ def test_checkpoint_roundtrip_and_std_quirk(tmp_path):
 def test_parameter_count_of_the_registered_policy():
     ac = ActorCriticMLP(39, 168, 10, actor_hidden_dims=[512, 256, 128], critic_hidden_dims=[512, 256, 128], init_noise_std=0.2)
     assert sum(p.numel() for p in ac.parameters()) == 436885          # 1 747 540 B fp32
+
+
+def test_actor_critic_init_options_of_the_32_dof_task():
+    """GR1T1FullBodyCfgPPO's two policy options (not in the reference, default = the reference's behaviour): one initial action noise per action, and an
+    output-layer gain that starts the mean action near zero.  Defaults leave the reference's initialisation untouched (same RNG stream, same weights)."""
+    from wiki_grx_gym_amd.envs import GR1T1FullBodyCfgPPO
+    from wiki_grx_gym_amd.envs.config import class_to_dict
+    from wiki_grx_gym_amd.rl.modules import ActorCriticMLP
+    pol = class_to_dict(GR1T1FullBodyCfgPPO())["policy"]
+    assert pol["init_noise_std"] == [0.2] * 12 + [0.05] * 20 and pol["actor_output_gain"] == 0.01
+    torch.manual_seed(3)
+    a = ActorCriticMLP(105, 234, 32, **pol)
+    torch.manual_seed(3)
+    ref = ActorCriticMLP(105, 234, 32, **{**pol, "init_noise_std": 0.2, "actor_output_gain": 1.0})
+    assert torch.equal(a.std.detach(), torch.tensor([0.2] * 12 + [0.05] * 20))
+    la, lr = [m for m in a.actor.model if isinstance(m, torch.nn.Linear)], [m for m in ref.actor.model if isinstance(m, torch.nn.Linear)]
+    for x, y in zip(la[:-1], lr[:-1]):
+        assert torch.equal(x.weight, y.weight) and torch.equal(x.bias, y.bias)
+    assert torch.allclose(la[-1].weight, lr[-1].weight * 0.01) and torch.allclose(la[-1].bias, lr[-1].bias * 0.01)
+    for x, y in zip(a.critic.model, ref.critic.model):
+        if isinstance(x, torch.nn.Linear):
+            assert torch.equal(x.weight, y.weight)
+    obs = torch.randn(16, 105)
+    assert a.act_inference(obs).abs().max() < 0.02 < ref.act_inference(obs).abs().max()

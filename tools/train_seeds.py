@@ -40,6 +40,8 @@ for seed in range(1, seeds + 1):
     tcfg.seed = seed
     if os.environ.get("GRX_TRAIN_INIT_NOISE"):   # (diagnosis of the 32-DOF task: exploration noise of the fresh policy, reference 0.2)
         tcfg.policy.init_noise_std = [float(x) for x in os.environ["GRX_TRAIN_INIT_NOISE"].split(",")] if "," in os.environ["GRX_TRAIN_INIT_NOISE"] else float(os.environ["GRX_TRAIN_INIT_NOISE"])
+    if os.environ.get("GRX_TRAIN_ACTOR_GAIN"):
+        tcfg.policy.actor_output_gain = float(os.environ["GRX_TRAIN_ACTOR_GAIN"])
     if os.environ.get("GRX_TRAIN_ENTROPY"):
         tcfg.algorithm.entropy_coef = float(os.environ["GRX_TRAIN_ENTROPY"])
     tcfg.runner.save_interval = 10 ** 9
@@ -70,9 +72,9 @@ for seed in range(1, seeds + 1):
                "episode_length_mean": float(l_.mean()), "wall_s_mean": float(w_.mean()), "wall_s_sd": float(w_.std(ddof=1)) if len(runs) > 1 else None,
                "note": "reward_at_end = mean of Train/mean_reward over the last 100 iterations; PPO hyper-parameters of the registered GR1T1 task "
                        "(gr1t1_lower_limb_config.py; the full-body task: this build's GR1T1FullCfgPPO); no reference curve exists to compare with (Isaac Gym is absent: BASELINE.md)",
-               "overrides": {k: os.environ[k] for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE", "GRX_TRAIN_ANKLE_ROLL", "GRX_TRAIN_TERMINATION", "GRX_TRAIN_ENTROPY", "GRX_TRAIN_SET") if k in os.environ},
+               "overrides": {k: os.environ[k] for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE", "GRX_TRAIN_ANKLE_ROLL", "GRX_TRAIN_TERMINATION", "GRX_TRAIN_ENTROPY", "GRX_TRAIN_SET", "GRX_TRAIN_ACTOR_GAIN") if k in os.environ},
                "runs": runs}
-    json.dump(summary, open(f"gpurun_out/learning_curve_{tag}_{envs}" + ("_overrides" if any(k in os.environ for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE", "GRX_TRAIN_ANKLE_ROLL", "GRX_TRAIN_TERMINATION", "GRX_TRAIN_ENTROPY", "GRX_TRAIN_SET")) else "") + ".json", "w"), indent=1)
+    json.dump(summary, open(f"gpurun_out/learning_curve_{tag}_{envs}" + ("_overrides" if any(k in os.environ for k in ("GRX_TRAIN_ONLY_POSITIVE", "GRX_TRAIN_INIT_NOISE", "GRX_TRAIN_ANKLE_ROLL", "GRX_TRAIN_TERMINATION", "GRX_TRAIN_ENTROPY", "GRX_TRAIN_SET", "GRX_TRAIN_ACTOR_GAIN")) else "") + ".json", "w"), indent=1)
     env.close()
     del runner, env
     torch.cuda.empty_cache()

@@ -101,6 +101,18 @@ GRX_DEV void stat_publish(KP P, long long seq, int t, float cnt, float s) {   //
     }
     P.stat_hist[(size_t)(seq & (GRX_STATS_HISTORY - 1)) * NSTAT + t] = v;
 }
+// Which 32- / 16-env group of the batch a block of the STEP kernel works on.  Workgroup b is dispatched to XCD b % 8 (observed, MI355X_MICROARCH.md
+// "Workgroup dispatch"): with the identity mapping every XCD's L2 sees envs from all over the batch -- i.e., with the terrain types assigned by env
+// index (legged_robot.py:1177-1180), robots from all 20 columns of the 21.8 MB cell table.  Mapped like this an XCD works on ONE contiguous eighth
+// of the envs (two or three terrain columns) and its 4 MiB L2 keeps that part of the raster.  A bijection of the block indices: results do not
+// depend on it (the statistics rows are indexed by the group, as before).
+#ifndef GRX_XCD_REMAP
+#define GRX_XCD_REMAP 1
+#endif
+GRX_DEV int step_group() {
+    const int b = blockIdx.x, n = gridDim.x;
+    return (GRX_XCD_REMAP && (n & 7) == 0) ? (b & 7) * (n >> 3) + (b >> 3) : b;
+}
 // called by ONE full wave of every block at the start of a kernel: the statistics of launch sq.seq - 1, and its ticket
 GRX_DEV void stats_fold_previous(KP P, const StepSeq& sq, int lane) {
     if (blockIdx.x == 0 && lane == 0 && sq.progress) __hip_atomic_store(sq.progress, sq.ticket_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1443,7 +1455,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     if (wv == (W == 8 ? 3 : W - 1)) stats_fold_previous(P, sq, tid & 63);
     const int N = P.N;
     const int lane = tid & 63, el = lane_env(lane), side = lane_side(lane), half = lane_half(lane);
-    const int e_raw = blockIdx.x * EPB + el;
+    const int grp = step_group();
+    const int e_raw = grp * EPB + el;
     const bool act = e_raw < N;
     const bool act0 = act && half == 0;   // the lane of a leg that stores the leg's outputs (LPE == 4: both halves hold them)
     int e = act ? e_raw : N - 1;   // (not const: laundered behind the sub-steps, see there)
@@ -2098,7 +2111,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     //  measured 14 k cycles here)
     lds_barrier();
     {
-        const int e0 = blockIdx.x * EPB;
+        const int e0 = grp * EPB;
         const int nenv = min(EPB, N - e0);
         float* gobs = (obs_out ? obs_out : P.obs) + (size_t)e0 * GRX_NUM_OBS;   // grx_step_args.obs_out: the caller's buffer (no copy per step)
         const int tot = nenv * GRX_NUM_OBS;
@@ -2118,7 +2131,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
             }
         } else
             for (int i = tid; i < nenv * npri; i += NTHR) gpri[i] = s_pri[(i / npri) * PRS + (i % npri)];
-        if (tid < NSTAT) stat_row(P, sq.seq, tid)[blockIdx.x] = s_stat[tid];   // row-major: the reduction reads rows of one term
+        if (tid < NSTAT) stat_row(P, sq.seq, tid)[grp] = s_stat[tid];   // row-major: the reduction reads rows of one term
         if (blockIdx.x == 0 && tid == 0) P.stat_nblocks[sq.seq & 1] = (int)gridDim.x;
     }
     // (The rows are reduced by the NEXT launch of the handle -- stats_fold_previous: the kernel boundary orders them for free.

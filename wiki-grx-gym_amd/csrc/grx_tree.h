@@ -495,7 +495,8 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     float* const wsw = s_dyn + sizeof(TreeTab) / 4 + (size_t)wave * 2 * thalf;
     const int ei = (ew / TEH) * thalf + (ew % TEH);   // (TW: the lane's offset into its half's block)
     const size_t N = (size_t)P.N;
-    const int e_raw = blockIdx.x * tepb + wave * TEPW + ew;
+    const int grp = step_group();   // (XCD-aware: grx_kernels.hip)
+    const int e_raw = grp * tepb + wave * TEPW + ew;
     const bool act = e_raw < P.N;
     const int e = act ? e_raw : P.N - 1;
     const bool lead = c == 0, actl = act && lead;
@@ -1153,7 +1154,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     }
 #endif
     __syncthreads();
-    if (threadIdx.x < NSTAT) stat_row(P, sq.seq, threadIdx.x)[blockIdx.x] = (s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x]) + (s_stat[2][threadIdx.x] + s_stat[3][threadIdx.x]);
+    if (threadIdx.x < NSTAT) stat_row(P, sq.seq, threadIdx.x)[grp] = (s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x]) + (s_stat[2][threadIdx.x] + s_stat[3][threadIdx.x]);
     if (blockIdx.x == 0 && threadIdx.x == 0) P.stat_nblocks[sq.seq & 1] = (int)gridDim.x;
 }
 #undef TW

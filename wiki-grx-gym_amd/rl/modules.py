@@ -140,7 +140,7 @@ class MLP(nn.Module):
 class ActorCriticMLP(nn.Module):
     def __init__(self, actor_num_input, critic_num_input, actor_num_output, actor_hidden_dims=(256, 256, 256),
                  critic_hidden_dims=(256, 256, 256), activation="elu", fixed_std=False, init_noise_std=1.0,
-                 set_std=True, set_noise_std=1.0, actor_output_activation=None, critic_output_activation=None, **kwargs):
+                 set_std=True, set_noise_std=1.0, actor_output_activation=None, critic_output_activation=None, actor_output_gain=1.0, **kwargs):
         if kwargs:
             print("ActorCritic.__init__ got unexpected arguments, which will be ignored: " + str(list(kwargs)))
         super().__init__()
@@ -148,6 +148,10 @@ class ActorCriticMLP(nn.Module):
         self.num_critic_input, self.num_critic_output = critic_num_input, 1
         self.actor = MLP(actor_num_input, actor_num_output, actor_hidden_dims, activation)
         self.critic = MLP(critic_num_input, 1, critic_hidden_dims, activation)
+        if actor_output_gain != 1.0:   # (not in the reference, whose layers keep PyTorch's default init: 1.0.  The build-defined 32-DOF task starts its
+            with torch.no_grad():      #  policy near the zero action -- the PD targets' default pose --: envs/config.py GR1T1FullBodyCfgPPO)
+                last = [m for m in self.actor.model if isinstance(m, nn.Linear)][-1]
+                last.weight.mul_(float(actor_output_gain)); last.bias.mul_(float(actor_output_gain))
         self.fixed_std, self.init_noise_std = fixed_std, init_noise_std
         # (a number, as in the reference -- actor_critic_mlp.py -- or one value per action: the 32-DOF task starts its upper-body joints quieter)
         self.std = nn.Parameter(torch.as_tensor(init_noise_std, dtype=torch.float32) * torch.ones(actor_num_output))
