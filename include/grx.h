@@ -399,7 +399,9 @@ int grx_tensor(grx_handle h, int tensor_id, grx_tensor_desc* out);
 /* Bring an ON_REFRESH tensor (grx_publish_mode) up to date in stream order: one small kernel, launched at most once per step however
  * often it is asked for; a no-op for every tensor the step keeps current.  The role of gym.refresh_rigid_body_state_tensor /
  * refresh_net_contact_force_tensor (legged_robot_fftai.py:75-76, legged_robot.py:275-278) for a caller that reads the tensor now and
- * then.  GRX_ERR_INVALID_ARGUMENT for a tensor this handle does not publish at all. */
+ * then.  GRX_ERR_INVALID_ARGUMENT for a tensor this handle does not publish at all.  "Up to date" means: as of the last launch of this handle (step,
+ * reset, grx_set_state*); a caller that writes simulation state THROUGH the zero-copy views (the reference's set_*_tensor role is grx_set_state) sees it in an
+ * on-refresh tensor after the next such launch, exactly as the reference's tensors change at the next simulate. */
 int grx_refresh(grx_handle h, int tensor_id, void* stream);
 
 /* overwrite simulation state of ALL envs from device buffers (any may be NULL = keep):

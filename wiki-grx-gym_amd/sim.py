@@ -116,8 +116,8 @@ class SimHandle:
         """Zero-copy torch view of a library buffer (cached)."""
         if name == "EPISODE_STATS":
             self.flush_stats()   # a step's statistics are reduced by the NEXT launch (include/grx.h grx_flush_stats)
-        if name in self._on_refresh:
-            self.refresh(name)   # one small launch per step at most (include/grx.h grx_refresh); the view itself is cached
+        if name in self._on_refresh and self._api["refresh"](self._h, _capi.T[name], self._stream()) != 0:
+            self._on_refresh.discard(name)   # (the library publishes it differently for this handle -- the one-lane generic kernel has no on-demand link frames: the descriptor below says so)
         if name in self._views:
             return self._views[name]
         d = _capi.TensorDesc()
