@@ -127,7 +127,7 @@ def full_iteration(args, n_local, iters, warm=2):
            "rollout_env_steps_per_s": T * n_local * world / (coll / iters) if coll > 0 else None,
            "definition": "num_steps_per_env * num_envs / (collection_time + learn_time), rsl_rl/runners/on_policy_runner.py:235 -- over whole iterations by the wall clock "
                          "(max over ranks), device drained at both ends; collection_ms / learn_ms: rank 0's split with the device drained at the boundary",
-           "policy": "ActorCritic MLP [512, 256, 128] actor + critic, PPO 8 epochs x 25 minibatches, adaptive LR (the registered task's GR1T1CfgPPO)",
+           "policy": "ActorCritic MLP [512, 256, 128] actor + critic, PPO 8 epochs x 25 minibatches, adaptive LR (the registered task's " + type(tcfg).__name__ + ")",
            "env": "task_registry.make_env default (rigid_body_states / measured_heights on refresh), action latency drawn per step N(5, 2) as in training",
            "multi_gpu": None if world == 1 else "envs sharded by global index; ONE flat-bucket RCCL all-reduce of the gradients per optimizer step (DESIGN.md 7)"}
     env.close()
