@@ -545,10 +545,66 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
     V3 pa = pA[LEG - 1], pl = pL[LEG - 1];
     V3 Ua[LEG], Ul[LEG], ca[LEG], cl[LEG];
     float dinv[LEG], uu[LEG];
+#ifndef GRX_PK_INERTIA
+#define GRX_PK_INERTIA 0   // 1: hand-packed fp32 (v_pk_fma_f32) in the articulated-inertia recursion.  MEASURED SLOWER (round 5): 179.3 against 164.1 us per step at
+                           // 32768 envs (512 registers + 17-22 spilled; see grx_wavepipe.h substep_p) -- kept as the record of the experiment, off
+#endif
+    constexpr bool kPk = GRX_PK_INERTIA && kFoldC;
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    struct C6 { f2_t r01, r23, r45; };
+    C6 c6[6];   // the 6 x 6 [A B; B^T D] as six columns of three float2 (rows 01 | 23 | 45)
+    auto pk_add_rigid = [&](const S3& K, V3 h, float m) {
+        c6[0].r01 += f2_t{K.xx, K.xy}; c6[0].r23.x += K.xz;            c6[0].r45 += f2_t{-h.z, h.y};
+        c6[1].r01 += f2_t{K.xy, K.yy}; c6[1].r23 += f2_t{K.yz, h.z};   c6[1].r45.y += -h.x;
+        c6[2].r01 += f2_t{K.xz, K.yz}; c6[2].r23 += f2_t{K.zz, -h.y};  c6[2].r45.x += h.x;
+        c6[3].r01.y += h.z;            c6[3].r23 += f2_t{-h.y, m};
+        c6[4].r01.x += -h.z;           c6[4].r23.x += h.x;             c6[4].r45.x += m;
+        c6[5].r01 += f2_t{h.y, -h.x};                                  c6[5].r45.y += m;
+    };
+    if (kPk) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { c6[j].r01 = f2_t{0.f, 0.f}; c6[j].r23 = f2_t{0.f, 0.f}; c6[j].r45 = f2_t{0.f, 0.f}; }
+        pk_add_rigid(IAk[LEG - 1], h4, m4);
+    }
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
         V3 a = Sa[k], s = Ss[k];
         float qdk = st.qd[k];
+        if (kPk) {
+            const float sj[6] = {a.x, a.y, a.z, s.x, s.y, s.z};
+            f2_t u01 = c6[0].r01 * f2_t{sj[0], sj[0]}, u23 = c6[0].r23 * f2_t{sj[0], sj[0]}, u45 = c6[0].r45 * f2_t{sj[0], sj[0]};
+#pragma unroll
+            for (int j = 1; j < 6; ++j) {
+                u01 = __builtin_elementwise_fma(c6[j].r01, f2_t{sj[j], sj[j]}, u01);
+                u23 = __builtin_elementwise_fma(c6[j].r23, f2_t{sj[j], sj[j]}, u23);
+                u45 = __builtin_elementwise_fma(c6[j].r45, f2_t{sj[j], sj[j]}, u45);
+            }
+            f2_t t_ = f2_t{a.x, a.y} * u01;
+            t_ = __builtin_elementwise_fma(f2_t{a.z, s.x}, u23, t_);
+            t_ = __builtin_elementwise_fma(f2_t{s.y, s.z}, u45, t_);
+            const float di = grx_rcp(t_.x + t_.y);
+            const V3 ua = v3(u01.x, u01.y, u23.x), ul = v3(u23.y, u45.x, u45.y);
+            const float qk = st.q[k], qlo = C.body[k].qlo, qhi = C.body[k].qhi;
+            const float viol = qk < qlo ? qlo - qk : (qk > qhi ? qhi - qk : 0.f);
+            const float t = tau_m[k] + (C.body[k].Klim * viol - (viol != 0.f ? C.body[k].Clim * qdk : 0.f));
+            const float u = t - (dot(a, pa) + dot(s, pl));
+            const f2_t w01 = u01 * f2_t{di, di}, w23 = u23 * f2_t{di, di}, w45 = u45 * f2_t{di, di};
+            const float wj[6] = {w01.x, w01.y, w23.x, w23.y, w45.x, w45.y};
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                c6[j].r01 = __builtin_elementwise_fma(-u01, f2_t{wj[j], wj[j]}, c6[j].r01);
+                c6[j].r23 = __builtin_elementwise_fma(-u23, f2_t{wj[j], wj[j]}, c6[j].r23);
+                c6[j].r45 = __builtin_elementwise_fma(-u45, f2_t{wj[j], wj[j]}, c6[j].r45);
+            }
+            const float ud = u * di;
+            Ua[k] = ua; Ul[k] = ul; dinv[k] = di; uu[k] = u; ca[k] = v3(0.f, 0.f, 0.f); cl[k] = ca[k];
+            pa = fma3(ua, ud, pa); pl = fma3(ul, ud, pl);
+            if (k > 0) {
+                pk_add_rigid(IAk[k - 1], Ih[k - 1], C.body[k - 1].mass);
+                pa = pa + pA[k - 1]; pl = pl + pL[k - 1];
+            }
+            continue;
+        }
         V3 cak = v3(0.f, 0.f, 0.f), clk = cak;
         if (!kFoldC) {
             w = fma3(a, -qdk, w); v = fma3(s, -qdk, v);  // parent velocity
@@ -596,6 +652,12 @@ GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst
         pa = pa - ro.f0a - sc.f0a; pl = pl - ro.f0l - sc.f0l;
     }
     write_link_rows(P, lfo, C, ro.lf, ro.fl2, ro.fl3, foot_terrain, sc, out.term, out.pen_count);   // (last sub-step: the flags from the NET link forces)
+    if (kPk) {
+        A.xx = c6[0].r01.x; A.xy = c6[0].r01.y; A.xz = c6[0].r23.x; A.yy = c6[1].r01.y; A.yz = c6[1].r23.x; A.zz = c6[2].r23.x;
+        B.a00 = c6[3].r01.x; B.a10 = c6[3].r01.y; B.a20 = c6[3].r23.x; B.a01 = c6[4].r01.x; B.a11 = c6[4].r01.y; B.a21 = c6[4].r23.x;
+        B.a02 = c6[5].r01.x; B.a12 = c6[5].r01.y; B.a22 = c6[5].r23.x;
+        D.xx = c6[3].r23.y; D.xy = c6[4].r23.y; D.xz = c6[5].r23.y; D.yy = c6[4].r45.x; D.yz = c6[5].r45.x; D.zz = c6[5].r45.y;
+    }
     A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
     pa = pair_sum(pa); pl = pair_sum(pl);
     {

@@ -186,6 +186,17 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     V3 Ica[LEG], Icl[LEG];
     S3 A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     M3 B = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifndef GRX_PK_INERTIA
+#define GRX_PK_INERTIA 0   // 1: hand-packed fp32 (v_pk_fma_f32) in the inertia half of the lane-pair eight-wave kernel.  MEASURED SLOWER (round 5, alternating runs,
+                           // profiles/r05_experiments.md): 58.1 / 58.3 against 56.9 us per step at 8192 envs (52 spilled registers instead of 48; 36 updated entries
+                           // instead of the symmetric form's 21 at 5.3 cycles per v_pk_fma against 4.5) -- kept as the record of the experiment, off
+#endif
+    constexpr bool kPk = W8 && GRX_PK_INERTIA;
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    struct C6 { f2_t r01, r23, r45; };
+    C6 c6[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { c6[j].r01 = f2_t{0.f, 0.f}; c6[j].r23 = f2_t{0.f, 0.f}; c6[j].r45 = f2_t{0.f, 0.f}; }
 #pragma unroll
     for (int k = LEG - 1; k >= 0; --k) {
         if (W8 && GRX_P8_XK && k < 2) {
@@ -193,7 +204,11 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 #define GRX_P8_PINXK 1   // joints 4, 3, 2 of the inertia half stay IN FRONT of the wait for wave 5's rigid inertias (the compiler sinks register
                          // arithmetic across the spin: without the pins this wave idled at the flag and ran all five joints behind it)
 #endif
-            if (k == 1 && GRX_P8_PINXK) {
+            if (k == 1 && GRX_P8_PINXK && kPk) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { GRX_PIN(c6[j].r01); GRX_PIN(c6[j].r23); GRX_PIN(c6[j].r45); }
+            }
+            if (k == 1 && GRX_P8_PINXK && !kPk) {
                 GRX_PIN(A.xx); GRX_PIN(A.xy); GRX_PIN(A.xz); GRX_PIN(A.yy); GRX_PIN(A.yz); GRX_PIN(A.zz);
                 GRX_PIN(B.a00); GRX_PIN(B.a01); GRX_PIN(B.a02); GRX_PIN(B.a10); GRX_PIN(B.a11); GRX_PIN(B.a12); GRX_PIN(B.a20); GRX_PIN(B.a21); GRX_PIN(B.a22);
                 GRX_PIN(D.xx); GRX_PIN(D.xy); GRX_PIN(D.xz); GRX_PIN(D.yy); GRX_PIN(D.yz); GRX_PIN(D.zz);
@@ -209,6 +224,41 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
             const float4 a0 = c[0 * 64], a1 = c[1 * 64], a2 = c[2 * 64];
             AK[k].xx = a0.x; AK[k].xy = a0.y; AK[k].xz = a0.z; AK[k].yy = a0.w; AK[k].yz = a1.x; AK[k].zz = a1.y;
             hK[k] = v3(a1.z, a1.w, a2.x);
+        }
+        if (kPk) {   // the full 6 x 6 [A B; B^T D] as six columns of three float2 (rows 01 | 23 | 45): U = sum_j col_j S_j and col_j -= U (U_j / d) are
+                     // v_pk_fma_f32 with a broadcast scalar (op_sel picks the half of a register pair: no moves) -- tools/micro/pk_recursion.hip
+            const S3 K = AK[k];
+            const V3 h = hK[k];
+            const float m = C.body[k].mass;
+            c6[0].r01 += f2_t{K.xx, K.xy}; c6[0].r23.x += K.xz;            c6[0].r45 += f2_t{-h.z, h.y};
+            c6[1].r01 += f2_t{K.xy, K.yy}; c6[1].r23 += f2_t{K.yz, h.z};   c6[1].r45.y += -h.x;
+            c6[2].r01 += f2_t{K.xz, K.yz}; c6[2].r23 += f2_t{K.zz, -h.y};  c6[2].r45.x += h.x;
+            c6[3].r01.y += h.z;            c6[3].r23 += f2_t{-h.y, m};
+            c6[4].r01.x += -h.z;           c6[4].r23.x += h.x;             c6[4].r45.x += m;
+            c6[5].r01 += f2_t{h.y, -h.x};                                  c6[5].r45.y += m;
+            const V3 a = Sa[k], s_ = Ss[k];
+            const float sj[6] = {a.x, a.y, a.z, s_.x, s_.y, s_.z};
+            f2_t u01 = c6[0].r01 * f2_t{sj[0], sj[0]}, u23 = c6[0].r23 * f2_t{sj[0], sj[0]}, u45 = c6[0].r45 * f2_t{sj[0], sj[0]};
+#pragma unroll
+            for (int j = 1; j < 6; ++j) {
+                u01 = __builtin_elementwise_fma(c6[j].r01, f2_t{sj[j], sj[j]}, u01);
+                u23 = __builtin_elementwise_fma(c6[j].r23, f2_t{sj[j], sj[j]}, u23);
+                u45 = __builtin_elementwise_fma(c6[j].r45, f2_t{sj[j], sj[j]}, u45);
+            }
+            f2_t t_ = f2_t{a.x, a.y} * u01;
+            t_ = __builtin_elementwise_fma(f2_t{a.z, s_.x}, u23, t_);
+            t_ = __builtin_elementwise_fma(f2_t{s_.y, s_.z}, u45, t_);
+            const float di = grx_rcp(t_.x + t_.y);
+            const f2_t w01 = u01 * f2_t{di, di}, w23 = u23 * f2_t{di, di}, w45 = u45 * f2_t{di, di};
+            const float wj[6] = {w01.x, w01.y, w23.x, w23.y, w45.x, w45.y};
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                c6[j].r01 = __builtin_elementwise_fma(-u01, f2_t{wj[j], wj[j]}, c6[j].r01);
+                c6[j].r23 = __builtin_elementwise_fma(-u23, f2_t{wj[j], wj[j]}, c6[j].r23);
+                c6[j].r45 = __builtin_elementwise_fma(-u45, f2_t{wj[j], wj[j]}, c6[j].r45);
+            }
+            Ua[k] = v3(u01.x, u01.y, u23.x); Ul[k] = v3(u23.y, u45.x, u45.y); dinv[k] = di;
+            continue;
         }
         add_rigid(A, B, D, AK[k], hK[k], C.body[k].mass);
         const V3 a = Sa[k], s_ = Ss[k];
@@ -228,6 +278,12 @@ GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState&
     for (int k = 0; k < LEG; ++k) { GRX_PIN(Ica[k].x); GRX_PIN(Ica[k].y); GRX_PIN(Ica[k].z); GRX_PIN(Icl[k].x); GRX_PIN(Icl[k].y); GRX_PIN(Icl[k].z); }
     GRX_EV(3);
 #endif
+    if (kPk) {
+        A.xx = c6[0].r01.x; A.xy = c6[0].r01.y; A.xz = c6[0].r23.x; A.yy = c6[1].r01.y; A.yz = c6[1].r23.x; A.zz = c6[2].r23.x;
+        B.a00 = c6[3].r01.x; B.a10 = c6[3].r01.y; B.a20 = c6[3].r23.x; B.a01 = c6[4].r01.x; B.a11 = c6[4].r01.y; B.a21 = c6[4].r23.x;
+        B.a02 = c6[5].r01.x; B.a12 = c6[5].r01.y; B.a22 = c6[5].r23.x;
+        D.xx = c6[3].r23.y; D.xy = c6[4].r23.y; D.xz = c6[5].r23.y; D.yy = c6[4].r45.x; D.yz = c6[5].r45.x; D.zz = c6[5].r45.y;
+    }
     // base level: both chains (DPP pair exchange) + the base lump, factorised for the solve below
     A = pair_sum(A); B = pair_sum(B); D = pair_sum(D);
     {
