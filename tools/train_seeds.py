@@ -13,15 +13,16 @@ envs = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 terrain = sys.argv[4] if len(sys.argv) > 4 else "plane"
 task = sys.argv[5] if len(sys.argv) > 5 else "GR1T1"
 full = task == "GR1T1_full_body"
-tag = ("full_body_" if full else "") + terrain
+gr1t2 = task == "GR1T2"   # (BASELINE.json's fourth configuration: one rank's 4096-env shard of the 32768)
+tag = ("full_body_" if full else "gr1t2_" if gr1t2 else "") + terrain
 os.makedirs("gpurun_out", exist_ok=True)
 runs = []
 for seed in range(1, seeds + 1):
     import torch
-    from wiki_grx_gym_amd.envs import GR1T1Cfg, GR1T1CfgPPO, GR1T1FullBodyCfg, GR1T1FullBodyCfgPPO
+    from wiki_grx_gym_amd.envs import GR1T1Cfg, GR1T1CfgPPO, GR1T1FullBodyCfg, GR1T1FullBodyCfgPPO, GR1T2Cfg, GR1T2CfgPPO
     from wiki_grx_gym_amd.utils import get_args, task_registry
     args = get_args(["--task", task, "--headless", "--num_envs", str(envs), "--seed", str(seed), "--max_iterations", str(iters)])
-    cfg = GR1T1FullBodyCfg() if full else GR1T1Cfg()
+    cfg = GR1T1FullBodyCfg() if full else GR1T2Cfg() if gr1t2 else GR1T1Cfg()
     cfg.terrain.mesh_type = terrain
     if os.environ.get("GRX_TRAIN_ONLY_POSITIVE") == "1":   # (diagnosis of the 32-DOF task: legged_robot.py:251-252's clip of the total reward at zero, off in the GR1T1 configs)
         cfg.rewards.only_positive_rewards = True
@@ -36,7 +37,7 @@ for seed in range(1, seeds + 1):
     cfg.seed = seed
     env, _ = task_registry.make_env(task, args=args, env_cfg=cfg)
     layout = env._sim.layout()
-    tcfg = GR1T1FullBodyCfgPPO() if full else GR1T1CfgPPO()
+    tcfg = GR1T1FullBodyCfgPPO() if full else GR1T2CfgPPO() if gr1t2 else GR1T1CfgPPO()
     tcfg.seed = seed
     if os.environ.get("GRX_TRAIN_INIT_NOISE"):   # (diagnosis of the 32-DOF task: exploration noise of the fresh policy, reference 0.2)
         tcfg.policy.init_noise_std = [float(x) for x in os.environ["GRX_TRAIN_INIT_NOISE"].split(",")] if "," in os.environ["GRX_TRAIN_INIT_NOISE"] else float(os.environ["GRX_TRAIN_INIT_NOISE"])
@@ -67,7 +68,7 @@ for seed in range(1, seeds + 1):
     runs.append(res)
     print(json.dumps({k: v for k, v in res.items() if not isinstance(v, list)}), flush=True)
     r_ = np.array([r["reward_at_end"] for r in runs]); l_ = np.array([r["episode_length_at_end"] for r in runs]); w_ = np.array([r["wall_s"] for r in runs])
-    summary = {"task": ("GR1T1 full body (32 DOF), " if full else "GR1T1 (lower limb), ") + ("flat plane" if terrain == "plane" else terrain), "num_envs": envs, "iterations": iters, "seeds": len(runs),
+    summary = {"task": ("GR1T1 full body (32 DOF), " if full else "GR1T2 (lower limb), " if gr1t2 else "GR1T1 (lower limb), ") + ("flat plane" if terrain == "plane" else terrain), "num_envs": envs, "iterations": iters, "seeds": len(runs),
                "step_kernel": layout, "reward_at_end_mean": float(r_.mean()), "iterations_run": iters, "reward_at_end_sd": float(r_.std(ddof=1)) if len(runs) > 1 else None,
                "episode_length_mean": float(l_.mean()), "wall_s_mean": float(w_.mean()), "wall_s_sd": float(w_.std(ddof=1)) if len(runs) > 1 else None,
                "note": "reward_at_end = mean of Train/mean_reward over the last 100 iterations; PPO hyper-parameters of the registered GR1T1 task "
