@@ -73,7 +73,8 @@ def reference_stage():
 def make_cfg(terrain, robot="lower_limb"):
     from wiki_grx_gym_amd.envs import config
     # registered task "GR1T1" = lower-limb config (the headline); --robot full_body = BASELINE.json config 5 (32 DOF)
-    cfg = config.GR1T1Cfg() if robot == "lower_limb" else config.GR1T1FullBodyCfg()
+    # --robot gr1t2 = the robot of BASELINE.json's fourth configuration (GR1T2 lower limb, same fused kernels; a rank's 4096-env shard)
+    cfg = config.GR1T1Cfg() if robot == "lower_limb" else config.GR1T2Cfg() if robot == "gr1t2" else config.GR1T1FullBodyCfg()
     cfg.terrain.mesh_type = "heightfield" if terrain == "rough" else "plane"
     cfg.terrain.curriculum = True
     # THE PRODUCT DEFAULT (round 5): the tensors nobody reads in a rollout -- rigid_body_states ("not counted, 1924 B"),
@@ -93,12 +94,12 @@ def full_iteration(args, n_local, iters, warm=2):
     import torch.distributed as dist
     from wiki_grx_gym_amd.envs import config
     from wiki_grx_gym_amd.utils import get_args, task_registry
-    task = "GR1T1" if args.robot == "lower_limb" else "GR1T1_full_body"
+    task = {"lower_limb": "GR1T1", "gr1t2": "GR1T2", "full_body": "GR1T1_full_body"}[args.robot]
     a = get_args(["--task", task, "--headless", "--num_envs", str(n_local), "--seed", "1"])
     cfg = make_cfg(args.terrain, args.robot)
     cfg.seed = 1
     env, _ = task_registry.make_env(task, args=a, env_cfg=cfg)
-    tcfg = config.GR1T1CfgPPO() if args.robot == "lower_limb" else config.GR1T1FullBodyCfgPPO()
+    tcfg = config.GR1T1CfgPPO() if args.robot == "lower_limb" else config.GR1T2CfgPPO() if args.robot == "gr1t2" else config.GR1T1FullBodyCfgPPO()
     tcfg.seed = 1
     runner, _ = task_registry.make_alg_runner(env, name=task, args=a, train_cfg=tcfg, log_root=None)
     runner.sync_timers = True
@@ -171,8 +172,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default: steps / 10)")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--terrain", choices=["rough", "flat"], default="rough")
-    ap.add_argument("--robot", choices=["lower_limb", "full_body"], default="lower_limb",
-                    help="full_body: the 32-DOF GR1T1 of BASELINE.json config 5 (tree kernel, grx_tree.h), not the headline")
+    ap.add_argument("--robot", choices=["lower_limb", "gr1t2", "full_body"], default="lower_limb",
+                    help="full_body: the 32-DOF GR1T1 of BASELINE.json config 5 (tree kernel, grx_tree.h), not the headline; "
+                         "gr1t2: the GR1T2 lower-limb robot of config 4 on the headline's kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-iters", type=int, default=5, help="PPO iterations timed for the `full_iteration` object (the reference's own fps metric, "
                     "on_policy_runner.py:235); 0 = skip it")
@@ -218,7 +220,7 @@ def main():
     sim = HipSim(c, dev, keep)
     sim.reset_all()
     gen = torch.Generator().manual_seed(rank)
-    pool = [random_actions(cfg, n_local, gen, 1.0 if args.robot == "lower_limb" else 0.3).to(dev) for _ in range(16)]   # U[clip_min, clip_max]
+    pool = [random_actions(cfg, n_local, gen, 0.3 if args.robot == "full_body" else 1.0).to(dev) for _ in range(16)]   # U[clip_min, clip_max]
     delay = 5.0
     counter = 0
     # The GPU idles while the host builds the terrain and the robot tables (seconds): its first kernels then run at the idle power
@@ -294,7 +296,7 @@ def main():
         # WRITE_SIZE runs, tools/collect_profiles.sh); bench.py cannot host the profiler itself.  Raw counter sum:
         # FETCH_SIZE is a lower bound on gfx950 (MI355X_MICROARCH.md), see the note inside the file.
         traffic, traffic_src, valu_insts, valu_src = None, None, None, None
-        wl = ("" if args.robot == "lower_limb" else "full_body_") + f"{args.terrain}{n_local}"   # e.g. rough4096, full_body_rough4096
+        wl = {"lower_limb": "", "gr1t2": "gr1t2_", "full_body": "full_body_"}[args.robot] + f"{args.terrain}{n_local}"   # e.g. rough4096, full_body_rough4096
         for tag in ("r05", "r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_{wl}.json")
             if traffic is None and os.path.exists(pmc):
@@ -316,8 +318,8 @@ def main():
                     valu_insts = None
         achieved = bytes_per * n_local / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
-            "metric": f"env-steps/sec GR1T1 {'rough' if args.terrain == 'rough' else 'flat'}-terrain @{n_local} envs"
-                      + ("" if args.robot == "lower_limb" else " [full-body 32 DOF, config 5]"),
+            "metric": f"env-steps/sec {'GR1T2' if args.robot == 'gr1t2' else 'GR1T1'} {'rough' if args.terrain == 'rough' else 'flat'}-terrain @{n_local} envs"
+                      + (" [full-body 32 DOF, config 5]" if args.robot == "full_body" else ""),
             "value": n_total * args.steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -329,7 +331,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"GR1T1 {'lower-limb (10 DOF)' if args.robot == 'lower_limb' else 'full body (32 DOF, tree kernel)'}, {'rough-terrain curriculum heightfield 10x20 tiles + 121-pt height scan' if args.terrain == 'rough' else 'flat plane'}, "
+            "config": {"workload": f"{'GR1T2' if args.robot == 'gr1t2' else 'GR1T1'} {'full body (32 DOF, tree kernel)' if args.robot == 'full_body' else 'lower-limb (10 DOF)'}, {'rough-terrain curriculum heightfield 10x20 tiles + 121-pt height scan' if args.terrain == 'rough' else 'flat plane'}, "
                                    f"{n_local} envs/GPU, decimation 10 @ dt 0.002, DR+noise+push on, action latency 5 sub-steps, random actions U[clip_min,clip_max]",
                        "envs_per_gpu": n_local, "global_envs": n_total, "parallelism": f"env-sharded x{world} (no data-path collective)",
                        "finite_outputs": finite, "prespin_ms": prespin, "prespin_kind": prespin_kind,
@@ -349,7 +351,7 @@ def main():
                          "valu_insts_per_launch": valu_insts, "valu_issue_peak_per_s": VALU_ISSUE_PEAK, "valu_source": valu_src,
                          "note": (f"instruction-issue bound at this batch size ({layout['lanes_per_env']} lanes per env, {layout['waves_per_block']} waves per {layout['envs_per_block']}-env block, "
                                   f"{layout['num_blocks']} blocks: DESIGN.md sections 4.1 and 5); HBM is the contractual roofline"
-                                  if args.robot == "lower_limb" else "tree kernel (a lane group per env, a chain per lane): instruction-issue bound (DESIGN.md section 4.3); HBM is the contractual roofline")},
+                                  if args.robot != "full_body" else "tree kernel (a lane group per env, a chain per lane): instruction-issue bound (DESIGN.md section 4.3); HBM is the contractual roofline")},
         }
     sim.close()
     # ---- the reference's own metric beside the headline (VERDICT r4 missing #2): whole PPO iterations, every rank takes part.  Guarded by a
