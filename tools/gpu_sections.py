@@ -17,7 +17,7 @@ from wiki_grx_gym_amd.envs import build_config
 os.environ["GRX_PUBLISH_DEBUG"]="0"
 names=["load","substeps","footkin","update+heights","timers","reward","reset","obs","store","rows->HBM"]
 for terrain in ("plane","heightfield"):
-    cfg = make_cfg(noise=True, dr=True, push=True, terrain=terrain); N=int(os.environ.get("N", 4096))
+    cfg = make_cfg(noise=True, dr=True, push=True, terrain=terrain, task=os.environ.get("TASK", "GR1T1")); N=int(os.environ.get("N", 4096))
     pass   # (bench.py = the product default: on-demand tensors on refresh)
     ter = make_terrain(cfg, N, 1)
     c,keep,_ = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
