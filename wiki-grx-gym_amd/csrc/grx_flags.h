@@ -39,6 +39,15 @@ GRX_DEV void flag_set(int* f, int v, int lane) {
 #endif
     if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// a flag that COUNTS its producers (the eight-wave layouts' height scan): same release as flag_set, an LDS atomic add from lane 0
+GRX_DEV void flag_add(int* f, int lane) {
+#ifdef GRX_FLAG_FENCED
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+#endif
+    if (lane == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 GRX_DEV void flag_wait(int* f, int want) {
     // pure spin (the waiter owns its SIMD; an s_sleep between polls only added detection latency: +1.3 % measured)
     GRX_SPIN_DECL;

@@ -1431,6 +1431,14 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
     }
 }
 
+// Eight waves: feet_height = foot z - mean of the measured heights, formed by whoever needs it once the six scanning waves have counted in (FL_SCAN)
+GRX_DEV float scan_feet_height(KP P, int* s_flag, const float* s_hsum, float foot_z, int nh, int lane) {
+    if (!P.measure_heights || P.terrain_type == GRX_TERRAIN_PLANE) return foot_z;   // (feet_height was final already)
+    flag_wait(s_flag + FL_SCAN, 6);
+    const float hsum = env_sum(s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + ((s_hsum[4 * 64 + lane] + s_hsum[5 * 64 + lane]) + (s_hsum[6 * 64 + lane] + s_hsum[7 * 64 + lane])));
+    return nh > 0 ? (foot_z * (float)nh - hsum) / (float)nh : foot_z;
+}
+
 // Block = W waves (W = 1, 2, 4 or 8, chosen at launch: up to 4 every wave has a SIMD to itself, 8 puts two on each) for the same 32 envs,
 // one env per lane PAIR in each wave.  The kernel runs one wave per SIMD, i.e. at one instruction per 4 cycles, so
 // a wave's instruction count IS its time:
@@ -1492,6 +1500,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     __shared__ float s_rwp[PIPE ? 64 : 1];               // partial reward (wave 3 -> wave 1)
     __shared__ float s_hp[PIPE ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
     __shared__ float s_hsum[PIPE ? W * 64 : 1];          // height scan: partial sums per wave
+    __shared__ float s_bho[W == 8 ? 4 * 64 : 1];         // W == 8: partial sums of the observation height block (waves 4..7; s_hsum keeps the scan's until the kernel ends)
     __shared__ float s_tp[PIPE ? 2 * 64 : 1];            // termination flag / collision count from the NET link forces of the last sub-step (wave 3 -> wave 0)
     __shared__ float4 s_xk[W == 8 ? 9 * 64 : 1];           // W == 8: rigid inertias of chain bodies 2, 1, 0 (wave 6 -> wave 0)
     __shared__ float4 s_sb[W == 8 ? 5 * 64 : 1];           // W == 8: thigh x base-lump self-collision (wave 3 -> wave 0)
@@ -1633,11 +1642,18 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
             if (HF && P.measure_heights) {   // this wave's quarter of the height scan (legged_robot.py:1235-1274)
                 const float* hp = s_hp + el;
                 // (eight waves: seven shares -- wave 3, the last to finish its sub-steps, has the link rows to store instead)
-                if (W == 8) { if (wv != 3) s_hsum[wv * 64 + lane] = height_scan_share<7, (LPE == 4 ? 5 : 9)>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
-                                                                                          LPE * (wv < 3 ? wv : wv - 1) + (lane & (LPE - 1)), nh, s_pri + el * PRS); }
-                else s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
+                // Eight waves: SIX shares -- wave 3, the last to finish its sub-steps, has the link rows to store instead, and WAVE 0 TAKES NO PART (round 5): the scan's
+                // gathers are a memory round trip it used to sit out at the barrier below (2.6 k cycles per step on the heightfield, tools/gpu_sections.py).  The scan's
+                // consumers -- the reward waves for feet_height, waves 4..7 for the observation height block, wave 0 when it writes feet_height -- wait for the COUNTER
+                // FL_SCAN instead of a block barrier.
+                if (W == 8) { if (wv != 3) { s_hsum[wv * 64 + lane] = height_scan_share<6, (LPE == 4 ? 6 : 11)>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
+                                                                                           LPE * (wv < 3 ? wv - 1 : wv - 2) + (lane & (LPE - 1)), nh, s_pri + el * PRS);
+                                             flag_add(s_flag + FL_SCAN, lane); } }
+                else {
+                s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
                                                               LPE * wv + (lane & (LPE - 1)), nh, s_pri + el * PRS);
                 lds_barrier();   // height scan complete (raw heights and partial sums are in LDS: this wave's row stores of the last sub-step stay in flight)
+                }
             }
             if (wv == 2) {   // reset_idx's uniform draws, ready before wave 0 knows who resets
                 const ResetRand rr = reset_rand(P, genv, step, side);
@@ -1654,6 +1670,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 RewIn rin;
                 int i = 0;
                 rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
+                if (W == 8) rin.feet_height = scan_feet_height(P, s_flag, s_hsum, rin.feet_height, nh, lane);
                 reward_and_sums<2>(P, C, rin, lane, side, e, N, act, s_stat, es_w3, s_rwp, s_flag + FL_RWB, nullptr,
                                    DBG && dbg[(size_t)DBG_APPLY_RESET * N + e] == 0.f);
             }
@@ -1663,6 +1680,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 RewIn rin;
                 int i = 0;
                 rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
+                if (W == 8) rin.feet_height = scan_feet_height(P, s_flag, s_hsum, rin.feet_height, nh, lane);
                 float a_ll1[LEG];   // DBG: the injected last_last_actions (action_diff_diff is one of this wave's terms)
                 if (DBG) {
 #pragma unroll
@@ -1676,8 +1694,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 if (wv >= 4) {
                     flag_wait(s_flag + FL_HZ, 1);
                     const bool have_raw = HF && P.measure_heights;
+                    if (have_raw) flag_wait(s_flag + FL_SCAN, 6);   // every wave's raw heights are in the staging rows
                     const float part = obs_heights_share<4 * LPE>(P, s_hp[el], (wv - 4) * LPE + (lane & (LPE - 1)), nh, s_pri + el * PRS, have_raw, act, e, N);
-                    s_hsum[wv * 64 + lane] = env_sum(part);
+                    s_bho[(wv - 4) * 64 + lane] = env_sum(part);
                     flag_set(s_flag + (wv == 7 ? FL_BHO4 : FL_BHO1 + (wv - 4)), 1, lane);
                 }
             } else if (wv < 4) {   // the observation height block, once wave 0 has published the (post-reset) base height: wave 2 takes
@@ -1948,11 +1967,11 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     float hsum = 0.f;
     if (HF && P.measure_heights) {
         if (PIPE) {   // quarter of the scan here, the other three quarters on the helper waves
-            hsum = W == 8 ? height_scan_share<7, (LPE == 4 ? 5 : 9)>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow)
-                          : height_scan_share<4>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
+            if (W != 8) {   // (eight waves: the scan runs on six helper waves and this wave picks its sum up when it writes feet_height -- see FL_SCAN)
+            hsum = height_scan_share<4>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
             lds_barrier();   // height scan complete
-            if (W == 8) hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + ((s_hsum[4 * 64 + lane] + s_hsum[5 * 64 + lane]) + (s_hsum[6 * 64 + lane] + s_hsum[7 * 64 + lane]));
-            else hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane];
+            hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane];
+            }
         } else hsum = height_scan_share<1, GRX_W1_SCAN_BATCH>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
         hsum = env_sum(hsum);
     }
@@ -1968,7 +1987,9 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     contact_last = contact;
     const bool first_contact = (air_time > 0.f) && contact_filt;
     air_time += dtp;
-    const float feet_height = nh > 0 ? (fk.pos.z * (float)nh - hsum) / (float)nh : fk.pos.z;
+    constexpr bool kLateScan = PIPE && W == 8 && HF;   // the height scan's sum arrives later (FL_SCAN): the reward waves and this wave's observation code form feet_height themselves
+    const bool late_scan = kLateScan && P.measure_heights;
+    float feet_height = late_scan ? fk.pos.z : (nh > 0 ? (fk.pos.z * (float)nh - hsum) / (float)nh : fk.pos.z);   // (late: the foot's z for now, scan_feet_height finishes it)
     land_time = (land_time + dtp) * (contact ? 1.0f : 0.0f);
     // check_termination (legged_robot.py:336-353)
     bool reset = term_contact || (fabsf(pg.z) < P.termination_gravity_z);
@@ -2099,6 +2120,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
             put(9 + GRX_ND + j0 + k, st.qd[k] * P.obs_scale_dof_vel, nv, 5 + k, 0);
             put(9 + 2 * GRX_ND + j0 + k, a_cur[k] * P.obs_scale_action, nac, 10 + k, 0);
         }
+        if (late_scan) feet_height = scan_feet_height(P, s_flag, s_hsum, feet_height, nh, lane);
         prow[GRX_NUM_OBS + 4 + side] = feet_contact_obs ? 1.f : 0.f;
         prow[GRX_NUM_OBS + 6 + side] = fminf(fmaxf(feet_height * P.obs_scale_height, -clipo), clipo);
     }
@@ -2156,7 +2178,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     if (PIPE) {   // base_heights_offset: the helper waves' partial sums of the observation height block
         if (W == 8) {
             flag_wait_all(s_flag, flag_want(lane, FL_BHO1, 1, FL_BHO1 + 1, 1, FL_BHO1 + 2, 1, FL_BHO4, 1), lane);
-            bho = nh > 0 ? ((s_hsum[4 * 64 + lane] + s_hsum[5 * 64 + lane]) + (s_hsum[6 * 64 + lane] + s_hsum[7 * 64 + lane])) / (float)nh : 0.f;
+            bho = nh > 0 ? ((s_bho[0 * 64 + lane] + s_bho[1 * 64 + lane]) + (s_bho[2 * 64 + lane] + s_bho[3 * 64 + lane])) / (float)nh : 0.f;
         } else {
         flag_wait(s_flag + FL_BHO1, 1);
         flag_wait(s_flag + FL_BHO1 + 1, 1);
