@@ -3,6 +3,17 @@
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 tag=r05; out=gpurun_out/$tag; mkdir -p $out
+# counters
+bash tools/collect_pmc.sh $tag rough4096 --steps 400 --warmup 50
+bash tools/collect_pmc.sh $tag rough8192 --envs-per-gpu 8192 --steps 300 --warmup 40
+bash tools/collect_pmc.sh $tag rough16384 --envs-per-gpu 16384 --steps 200 --warmup 30
+bash tools/collect_pmc.sh $tag rough32768 --envs-per-gpu 32768 --steps 150 --warmup 20
+bash tools/collect_pmc.sh $tag full_body_rough4096 --robot full_body --envs-per-gpu 4096 --steps 150 --warmup 20
+bash tools/collect_pmc.sh $tag full_body_rough16384 --robot full_body --envs-per-gpu 16384 --steps 80 --warmup 10
+for w in rough4096:10141696 rough8192:20283392 rough16384:40566784 rough32768:81133568 full_body_rough4096:16990208 full_body_rough16384:67960832; do
+    python tools/summarise_pmc.py $tag ${w%%:*} ${w##*:} > /dev/null   # profiles/r05_pmc_{hbm,sq}_<workload>.json: what the bench lines below read
+done
+mkdir -p $out/pmc_json; cp profiles/${tag}_pmc_*.json $out/pmc_json/
 # headline: three runs of the driver's default command, flat, the layouts, the sweep
 timeout 600 python bench.py 2> $out/bench_rough.err | tail -1 > $out/bench_rough.json
 cp $out/bench_rough.json $out/bench_rough_runs.jsonl
@@ -29,13 +40,6 @@ stats rough16384 --envs-per-gpu 16384 --steps 2000 --warmup 200
 stats rough32768 --envs-per-gpu 32768 --steps 1500 --warmup 150
 stats full_body_rough4096 --robot full_body --envs-per-gpu 4096 --steps 600 --warmup 60
 stats full_body_rough16384 --robot full_body --envs-per-gpu 16384 --steps 300 --warmup 30
-# counters
-bash tools/collect_pmc.sh $tag rough4096 --steps 400 --warmup 50
-bash tools/collect_pmc.sh $tag rough8192 --envs-per-gpu 8192 --steps 300 --warmup 40
-bash tools/collect_pmc.sh $tag rough16384 --envs-per-gpu 16384 --steps 200 --warmup 30
-bash tools/collect_pmc.sh $tag rough32768 --envs-per-gpu 32768 --steps 150 --warmup 20
-bash tools/collect_pmc.sh $tag full_body_rough4096 --robot full_body --envs-per-gpu 4096 --steps 150 --warmup 20
-bash tools/collect_pmc.sh $tag full_body_rough16384 --robot full_body --envs-per-gpu 16384 --steps 80 --warmup 10
 python -c "
 import json
 for f in ('bench_rough','bench_flat','bench_driver_window','bench_rough_every_step','bench_full_body_rough4096','bench_full_body_rough16384'):

@@ -1433,7 +1433,7 @@ GRX_DEV void reward_and_sums(KP P, const SideConst& C, const RewIn& in, int lane
 
 // Eight waves: feet_height = foot z - mean of the measured heights, formed by whoever needs it once the six scanning waves have counted in (FL_SCAN)
 GRX_DEV float scan_feet_height(KP P, int* s_flag, const float* s_hsum, float foot_z, int nh, int lane) {
-    if (!P.measure_heights || P.terrain_type == GRX_TERRAIN_PLANE) return foot_z;   // (feet_height was final already)
+    if (!P.measure_heights) return foot_z;   // (feet_height was final already; heightfield kernels only)
     flag_wait(s_flag + FL_SCAN, 6);
     const float hsum = env_sum(s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + ((s_hsum[4 * 64 + lane] + s_hsum[5 * 64 + lane]) + (s_hsum[6 * 64 + lane] + s_hsum[7 * 64 + lane])));
     return nh > 0 ? (foot_z * (float)nh - hsum) / (float)nh : foot_z;
@@ -1500,7 +1500,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     __shared__ float s_rwp[PIPE ? 64 : 1];               // partial reward (wave 3 -> wave 1)
     __shared__ float s_hp[PIPE ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
     __shared__ float s_hsum[PIPE ? W * 64 : 1];          // height scan: partial sums per wave
-    __shared__ float s_bho[W == 8 ? 4 * 64 : 1];         // W == 8: partial sums of the observation height block (waves 4..7; s_hsum keeps the scan's until the kernel ends)
+    __shared__ float s_bho[W == 8 && HF ? 4 * 64 : 1];   // W == 8, heightfield: partial sums of the observation height block (waves 4..7; s_hsum keeps the scan's until the kernel ends)
     __shared__ float s_tp[PIPE ? 2 * 64 : 1];            // termination flag / collision count from the NET link forces of the last sub-step (wave 3 -> wave 0)
     __shared__ float4 s_xk[W == 8 ? 9 * 64 : 1];           // W == 8: rigid inertias of chain bodies 2, 1, 0 (wave 6 -> wave 0)
     __shared__ float4 s_sb[W == 8 ? 5 * 64 : 1];           // W == 8: thigh x base-lump self-collision (wave 3 -> wave 0)
@@ -1670,7 +1670,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 RewIn rin;
                 int i = 0;
                 rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
-                if (W == 8) rin.feet_height = scan_feet_height(P, s_flag, s_hsum, rin.feet_height, nh, lane);
+                if (W == 8 && HF) rin.feet_height = scan_feet_height(P, s_flag, s_hsum, rin.feet_height, nh, lane);
                 reward_and_sums<2>(P, C, rin, lane, side, e, N, act, s_stat, es_w3, s_rwp, s_flag + FL_RWB, nullptr,
                                    DBG && dbg[(size_t)DBG_APPLY_RESET * N + e] == 0.f);
             }
@@ -1680,7 +1680,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                 RewIn rin;
                 int i = 0;
                 rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
-                if (W == 8) rin.feet_height = scan_feet_height(P, s_flag, s_hsum, rin.feet_height, nh, lane);
+                if (W == 8 && HF) rin.feet_height = scan_feet_height(P, s_flag, s_hsum, rin.feet_height, nh, lane);
                 float a_ll1[LEG];   // DBG: the injected last_last_actions (action_diff_diff is one of this wave's terms)
                 if (DBG) {
 #pragma unroll
@@ -1696,7 +1696,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
                     const bool have_raw = HF && P.measure_heights;
                     if (have_raw) flag_wait(s_flag + FL_SCAN, 6);   // every wave's raw heights are in the staging rows
                     const float part = obs_heights_share<4 * LPE>(P, s_hp[el], (wv - 4) * LPE + (lane & (LPE - 1)), nh, s_pri + el * PRS, have_raw, act, e, N);
-                    s_bho[(wv - 4) * 64 + lane] = env_sum(part);
+                    if (HF) s_bho[(wv - 4) * 64 + lane] = env_sum(part);
+                    else s_hsum[wv * 64 + lane] = env_sum(part);   // (plane: no scan, the rows of waves 4..7 in s_hsum as before)
                     flag_set(s_flag + (wv == 7 ? FL_BHO4 : FL_BHO1 + (wv - 4)), 1, lane);
                 }
             } else if (wv < 4) {   // the observation height block, once wave 0 has published the (post-reset) base height: wave 2 takes
@@ -2178,7 +2179,8 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
     if (PIPE) {   // base_heights_offset: the helper waves' partial sums of the observation height block
         if (W == 8) {
             flag_wait_all(s_flag, flag_want(lane, FL_BHO1, 1, FL_BHO1 + 1, 1, FL_BHO1 + 2, 1, FL_BHO4, 1), lane);
-            bho = nh > 0 ? ((s_bho[0 * 64 + lane] + s_bho[1 * 64 + lane]) + (s_bho[2 * 64 + lane] + s_bho[3 * 64 + lane])) / (float)nh : 0.f;
+            if (HF) bho = nh > 0 ? ((s_bho[0 * 64 + lane] + s_bho[1 * 64 + lane]) + (s_bho[2 * 64 + lane] + s_bho[3 * 64 + lane])) / (float)nh : 0.f;
+            else bho = nh > 0 ? ((s_hsum[4 * 64 + lane] + s_hsum[5 * 64 + lane]) + (s_hsum[6 * 64 + lane] + s_hsum[7 * 64 + lane])) / (float)nh : 0.f;
         } else {
         flag_wait(s_flag + FL_BHO1, 1);
         flag_wait(s_flag + FL_BHO1 + 1, 1);

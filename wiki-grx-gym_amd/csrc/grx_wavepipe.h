@@ -71,8 +71,8 @@ enum { FL_STATE = 0, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_BI
        FL_XK = 18 /* W == 8: rigid inertias of thigh, hip yaw, hip roll (wave 6 -> wave 0), seq * 4 + bodies out */,
        FL_CHAINW = 19 /* W == 8: thigh + shank terrain wrenches (wave 7) */, FL_BHO4 = 20 /* W == 8: fourth share of the observation height block */,
        FL_SB = 21 /* W == 8: the thigh x base-lump part of the self-collision is out (wave 3 with lane quads, wave 6 with lane pairs) */,
-       FL_SCAN = 22 /* W == 8: COUNTER of the waves whose share of the height scan is in LDS (six: waves 1, 2, 4..7) */,
-       FL_COUNT = 23 };
+       FL_SCAN = 1 /* W == 8: COUNTER of the waves whose share of the height scan is in LDS (six: waves 1, 2, 4..7) */,
+       FL_COUNT = 22 };
 // Every record is laid out [quad][lane] in float4 units, so a lane moves it with ds_read_b128 / ds_write_b128: the
 // kernel runs at one instruction issue per ~5 cycles whatever the instruction, and the records are ~350 dwords per
 // lane and sub-step on wave 0 alone -- four dwords per LDS instruction instead of one is ~1.3k cycles per sub-step.
