@@ -73,6 +73,18 @@ enum { FL_STATE = 0, FL_FOOT = 2, FL_LEGS = 3, FL_FRAMES = 4, FL_BIAS = 5, FL_BI
        FL_SB = 21 /* W == 8: the thigh x base-lump part of the self-collision is out (wave 3 with lane quads, wave 6 with lane pairs) */,
        FL_SCAN = 1 /* W == 8: COUNTER of the waves whose share of the height scan is in LDS (six: waves 1, 2, 4..7) */,
        FL_COUNT = 22 };
+// every flag a slot of its own (FL_BHO1 stands for three: waves 1..3; the enumerators above are not in order, so a clash would go unnoticed)
+constexpr bool flag_slots_distinct() {
+    const int f[] = {FL_STATE, FL_SCAN, FL_FOOT, FL_LEGS, FL_FRAMES, FL_BIAS, FL_REW, FL_BIAS2, FL_BASEBIAS, FL_SELF, FL_HZ, FL_BHO1, FL_BHO1 + 1, FL_BHO1 + 2, FL_RWB, FL_RR,
+                     FL_FACT, FL_FACTOUT, FL_XK, FL_CHAINW, FL_BHO4, FL_SB};
+    constexpr int n = sizeof(f) / sizeof(f[0]);
+    for (int i = 0; i < n; ++i) {
+        if (f[i] < 0 || f[i] >= FL_COUNT) return false;
+        for (int j = i + 1; j < n; ++j) if (f[i] == f[j]) return false;
+    }
+    return n == FL_COUNT;
+}
+static_assert(flag_slots_distinct(), "hand-over flags must occupy distinct slots of s_flag, all of them");
 // Every record is laid out [quad][lane] in float4 units, so a lane moves it with ds_read_b128 / ds_write_b128: the
 // kernel runs at one instruction issue per ~5 cycles whatever the instruction, and the records are ~350 dwords per
 // lane and sub-step on wave 0 alone -- four dwords per LDS instruction instead of one is ~1.3k cycles per sub-step.
