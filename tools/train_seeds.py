@@ -17,7 +17,7 @@ gr1t2 = task == "GR1T2"   # (BASELINE.json's fourth configuration: one rank's 40
 tag = ("full_body_" if full else "gr1t2_" if gr1t2 else "") + terrain
 os.makedirs("gpurun_out", exist_ok=True)
 runs = []
-for seed in range(1, seeds + 1):
+for seed in range(int(os.environ.get("GRX_TRAIN_FIRST_SEED", "1")), int(os.environ.get("GRX_TRAIN_FIRST_SEED", "1")) + seeds):
     import torch
     from wiki_grx_gym_amd.envs import GR1T1Cfg, GR1T1CfgPPO, GR1T1FullBodyCfg, GR1T1FullBodyCfgPPO, GR1T2Cfg, GR1T2CfgPPO
     from wiki_grx_gym_amd.utils import get_args, task_registry
