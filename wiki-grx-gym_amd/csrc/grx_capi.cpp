@@ -30,7 +30,7 @@ int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, in
                             float delay, long long common_step, const float* noise, float* obs_out, float* pri_out, long long seq, hipStream_t stream);
 void grx_launch_reset_all_generic(const KParams* dP, const void* tables, int N, int epb, uint32_t step, long long seq, uint8_t* mask, hipStream_t stream);
 int grx_generic_tables_size(void);
-int grx_tree_lds_bytes(int nb, int nlc, int nchain, int waves);
+int grx_tree_lds_bytes(int nb, int nlc, int nchain, int nsph, int waves);
 int grx_tree_envs_per_wave(void);
 int grx_launch_step_tree(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions, float delay,
                          long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream);
@@ -38,7 +38,7 @@ int grx_launch_step_tree_debug(const KParams* dP, const void* tree_tab, const vo
                                long long common_step, const float* noise, const float* dbg, const StepSeq* sq, hipStream_t stream);
 int grx_generic_ws_floats_per_env(int nb, int nlc);
 // csrc/grx_tree16.hip: the tree kernel with a 16-lane group per env (four envs per wave)
-int grx_tree_lds_bytes16(int nb, int nlc, int nchain, int waves);
+int grx_tree_lds_bytes16(int nb, int nlc, int nchain, int nsph, int waves);
 int grx_tree_envs_per_wave16(void);
 int grx_launch_step_tree16(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions, float delay,
                            long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream);
@@ -642,9 +642,29 @@ int build_generic(grx_sim* s, const grx_config& c) {
             }
     }
     K.nlp = T.nlp;
-    for (int q = 0; q < T.nlp; ++q) {
-        K.lp_ba[q] = (int16_t)T.lp_ba[q]; K.lp_bb[q] = (int16_t)T.lp_bb[q]; K.lp_a[q] = (int16_t)T.lp_a[q]; K.lp_b[q] = (int16_t)T.lp_b[q];
-        for (int a = 0; a < 4; ++a) { K.lp_ca[q][a] = T.lp_ca[q][a]; K.lp_cb[q][a] = T.lp_cb[q][a]; }
+    for (int q = 0; q < T.nlp; ++q) { K.lp_ba[q] = (int16_t)T.lp_ba[q]; K.lp_bb[q] = (int16_t)T.lp_bb[q]; K.lp_a[q] = (int16_t)T.lp_a[q]; K.lp_b[q] = (int16_t)T.lp_b[q]; }
+    {   // the broad phase's sphere pairs: every pair of grx_model.pair_a/b with its link pair; (ra + rb + margin)^2 -- the margin (0.1 mm) keeps the
+        // test on the contact pass's centres a superset of sphere_pair's own (the two form a centre with differently rounded products)
+        if (T.nsph > 255) return GRX_OK;
+        std::vector<int> pos_of(m.num_spheres);
+        {
+            std::vector<int> ord(m.num_spheres);
+            for (int i = 0; i < m.num_spheres; ++i) ord[i] = i;
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return m.sph_body[a] < m.sph_body[b]; });
+            for (int k = 0; k < m.num_spheres; ++k) pos_of[ord[k]] = k;
+        }
+        K.nsp = 0;
+        for (int pi = 0; pi < m.num_pairs; ++pi) {
+            int ka = pos_of[m.pair_a[pi]], kb = pos_of[m.pair_b[pi]];
+            int la = T.slink[ka], lb = T.slink[kb];
+            int lp = -1;
+            for (int q = 0; q < T.nlp; ++q) if ((T.lp_a[q] == la && T.lp_b[q] == lb) || (T.lp_a[q] == lb && T.lp_b[q] == la)) lp = q;
+            if (lp < 0) return fail(GRX_ERR_INVALID_ARGUMENT, "self-collision sphere pair without a link pair");
+            const float rs = T.sr[ka] + T.sr[kb] + 1e-4f;
+            K.sp[K.nsp] = (uint32_t)ka | ((uint32_t)kb << 8) | ((uint32_t)lp << 16);
+            K.sp_r2[K.nsp] = rs * rs;
+            ++K.nsp;
+        }
     }
     for (int l = 0; l <= GEN_MAXLC_H; ++l) K.lc_begin[l] = T.lc_begin[l];
     // waves per block: two while those blocks fit the device's CUs in one round (every wave still has a SIMD to itself and the CU's
@@ -656,7 +676,7 @@ int build_generic(grx_sim* s, const grx_config& c) {
         s->tree_waves = (s->N + 2 * epw - 1) / (2 * epw) <= prop.multiProcessorCount ? 2 : 4;
         if (const char* tw_ = getenv("GRX_TREE_WAVES")) { const int v = atoi(tw_); if (v == 1 || v == 2 || v == 4) s->tree_waves = v; }
     }
-    auto lds_of = [&](int waves) { return G == GRX_TREE_GMAX ? grx_tree_lds_bytes16(T.nb, T.nlc, nchain, waves) : grx_tree_lds_bytes(T.nb, T.nlc, nchain, waves); };
+    auto lds_of = [&](int waves) { return G == GRX_TREE_GMAX ? grx_tree_lds_bytes16(T.nb, T.nlc, nchain, T.nsph, waves) : grx_tree_lds_bytes(T.nb, T.nlc, nchain, T.nsph, waves); };
     int lds = lds_of(s->tree_waves);
     while (lds > 160 * 1024 - 1024 && s->tree_waves > 1) { s->tree_waves /= 2; lds = lds_of(s->tree_waves); }
     if (lds > 160 * 1024 - 1024) return GRX_OK;   // the workspace of one wave does not fit a CU's LDS

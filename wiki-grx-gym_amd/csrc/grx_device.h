@@ -126,9 +126,15 @@ struct TreeTab {
     float torso_rot[9], forehead_rot[9];
     int32_t sph_begin0, sph_end0;                     // the base's own shapes
     int32_t nlp, pad1;
-    // self-collision link pairs (grx_generic.h GenTables.lp_*): bodies, compact links, bounding spheres (body frame xyz, radius)
+    // self-collision link pairs (grx_generic.h GenTables.lp_*): bodies, compact links
     int16_t lp_ba[48], lp_bb[48], lp_a[48], lp_b[48];
-    float lp_ca[48][4], lp_cb[48][4];
+    // ... and their sphere pairs (round 6): the broad phase tests EVERY sphere pair of the model (grx_model.pair_a/b) on the sphere centres the
+    // contact pass leaves in LDS -- centre distance against (ra + rb + margin)^2 -- and raises the bit of the pair's LINK pair; the narrow phase
+    // then runs on the raised link pairs only, i.e. on links that really touch (rounds 2-5 tested the links' bounding spheres, which overlap in
+    // every pose for neighbours like upper arm x torso: the 800-instruction narrow phase ran in every round of every sub-step)
+    int32_t nsp, pad2;
+    uint32_t sp[GRX_MAX_PAIRS];                       // sphere of link a | sphere of link b << 8 | link pair << 16 (positions in sph[])
+    float sp_r2[GRX_MAX_PAIRS];                       // (ra + rb + margin)^2
     int32_t lc_begin[25];
     int32_t ncs;                                      // rounds of the contact pass
     int32_t nturn;                                    // items of one round that share a body add their forces in turns 0 .. nturn - 1

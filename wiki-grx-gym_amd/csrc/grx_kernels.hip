@@ -2551,7 +2551,7 @@ extern "C" void grx_launch_reset_all_generic(const KParams* dP, const void* tabl
 #else
 #define GRX_TREE_FN(n) n
 #endif
-extern "C" int GRX_TREE_FN(grx_tree_lds_bytes)(int nb, int nlc, int nchain, int waves) { return (int)sizeof(TreeTab) + waves * 2 * tree_half_words(tree_offsets(nb, nlc, nchain).total) * 4; }
+extern "C" int GRX_TREE_FN(grx_tree_lds_bytes)(int nb, int nlc, int nchain, int nsph, int waves) { return (int)sizeof(TreeTab) + waves * 2 * tree_half_words(tree_offsets(nb, nlc, nchain, nsph).total) * 4; }
 extern "C" int GRX_TREE_FN(grx_tree_envs_per_wave)(void) { return TEPW; }
 extern "C" int GRX_TREE_FN(grx_launch_step_tree)(const KParams* dP, const void* tree_tab, const void* gen_tab, int N, int waves, int lds_bytes, int heightfield, const float* actions, float delay,
                                     long long common_step, const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {

@@ -42,9 +42,12 @@ enum { TD_ACUR = 0, TD_ALAST = 1, TD_STR = 2, TD_N = 3 };   // per-dof rows ever
 #define TBO(b) (((b) - 1) * T_NB)
 
 struct TreeOff { int up, dof, lf, an, misc, total; };
-__host__ __device__ inline TreeOff tree_offsets(int nb, int nlc, int nchain) {
+// (the hand-over region doubles as the table of the spheres' world centres -- 3 words a sphere -- between the contact pass, which forms them,
+//  and the inward pass: the self-collision's broad phase reads them, tree_self_collision)
+__host__ __device__ inline TreeOff tree_offsets(int nb, int nlc, int nchain, int nsph) {
     TreeOff o;
-    o.up = (nb - 1) * T_NB; o.dof = o.up + nchain * T_UPW; o.lf = o.dof + TD_N * GRX_MAX_DOFS; o.an = o.lf + nlc * 3; o.misc = o.an + 24; o.total = o.misc + T_MISC;
+    const int upw = nchain * T_UPW > nsph * 3 ? nchain * T_UPW : nsph * 3;
+    o.up = (nb - 1) * T_NB; o.dof = o.up + upw; o.lf = o.dof + TD_N * GRX_MAX_DOFS; o.an = o.lf + nlc * 3; o.misc = o.an + 24; o.total = o.misc + T_MISC;
     return o;
 }
 // LDS addressing (round 5).  ds_read_b32 / ds_write_b32 bank by (word address mod 32) and serve a wave as its two 32-lane HALVES, one LDS cycle
@@ -67,23 +70,41 @@ GRX_DEV void tw_put(float* wsw, int ei, int a, V3 x) { TW(a) = x.x; TW(a + 1) = 
 GRX_DEV R3 tw_R(const float* wsw, int ei, int a) { R3 R; R.cx = tw_v3(wsw, ei, a); R.cy = tw_v3(wsw, ei, a + 3); R.cz = tw_v3(wsw, ei, a + 6); return R; }
 GRX_DEV void tree_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }   // (one wave: LDS operations complete in program order)
 
-// child rotation R_parent * rot0 * Rot(axis, q) (gen_joint_rot on the LDS table)
-GRX_DEV R3 tree_joint_rot(const R3& Rp, const TreeBody& tb, float q) {
-    float sn, cs;
-    grx_sincos(q, sn, cs);
-    const float ax = tb.axis[0], ay = tb.axis[1], az = tb.axis[2], oc = 1.f - cs;
-    const V3 qx = v3(cs + ax * ax * oc, az * sn + ax * ay * oc, -ay * sn + ax * az * oc);
-    const V3 qy = v3(-az * sn + ax * ay * oc, cs + ay * ay * oc, ax * sn + ay * az * oc);
-    const V3 qz = v3(ay * sn + ax * az * oc, -ax * sn + ay * az * oc, cs + az * az * oc);
-    R3 J = Rp;
-    if (!tb.rot0_identity) {   // (only the shoulders of the GR1 carry a rotated joint frame)
-        J.cx = rot(Rp, v3(tb.rot0[0], tb.rot0[3], tb.rot0[6]));
-        J.cy = rot(Rp, v3(tb.rot0[1], tb.rot0[4], tb.rot0[7]));
-        J.cz = rot(Rp, v3(tb.rot0[2], tb.rot0[5], tb.rot0[8]));
+// Round 6 -- the JOINT-LOCAL phase.  A wave alone on its SIMD issues one instruction per ~4 cycles and every LDS round trip on the way costs
+// ~100 more: rounds 4-5 rode the joint's rotation (sincos, Rodrigues, the rot0 product behind a branch on a table word), the motor torque (five
+// table words, the action, the strength: three dependent batches) and the hanging chains' hand-over on EVERY ONE of the ten depth levels of the
+// outward walk -- ~350 instructions and six dependent LDS round trips a level (from the ISA).  Nothing of that depends on the parent's frame:
+// it is formed here for ALL bodies at once, the bodies going round the group's lanes (2 rounds of 16 lanes, 4 of 8), and parked in the body's
+// row -- the local rotation rot0 * Rot(axis, q) in the rotation's nine slots (the walk reads it and writes the world rotation over it), the
+// clipped motor torque in T_TAU.  q, qd come from two slots of the row (the rotation's, dead between the acceleration pass, which leaves the
+// integrated state there, and this phase).
+enum { T_Q = T_R + 2, T_QD = T_R + 3 };
+template <bool KIN>
+GRX_DEV void tree_joint_phase(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, bool use_last, const float* qd_last_e) {
+    for (int b = 1 + c; b < T.nb; b += TG) {
+        const TreeBody& tb = T.body[b];
+        const int j = b - 1, wb = TBO(b);
+        const float qj = TW(wb + T_Q), qdj = TW(wb + T_QD);
+        float sn, cs;
+        grx_sincos(qj, sn, cs);
+        const float ax = tb.axis[0], ay = tb.axis[1], az = tb.axis[2], oc = 1.f - cs;
+        const V3 qx = v3(cs + ax * ax * oc, az * sn + ax * ay * oc, -ay * sn + ax * az * oc);
+        const V3 qy = v3(-az * sn + ax * ay * oc, cs + ay * ay * oc, ax * sn + ay * az * oc);
+        const V3 qz = v3(ay * sn + ax * az * oc, -ax * sn + ay * az * oc, cs + az * az * oc);
+        // rot0 * Rot(axis, q), unconditionally (only the shoulders of the GR1 carry a rotated joint frame; the product with the unit matrix is
+        // exact, and the branch on a table word it replaces was a dependent LDS round trip)
+        R3 J;
+        J.cx = v3(tb.rot0[0], tb.rot0[3], tb.rot0[6]); J.cy = v3(tb.rot0[1], tb.rot0[4], tb.rot0[7]); J.cz = v3(tb.rot0[2], tb.rot0[5], tb.rot0[8]);
+        tw_put(wsw, ei, wb + T_R, rot(J, qx)); tw_put(wsw, ei, wb + T_R + 3, rot(J, qy)); tw_put(wsw, ei, wb + T_R + 6, rot(J, qz));
+        if (!KIN) {   // _compute_torques (legged_robot.py:679-715)
+            const TreeDof& td = T.dof[j];
+            const float act_ = TW(o.dof + (use_last ? TD_ALAST : TD_ACUR) * GRX_MAX_DOFS + j);
+            float t = control_torque(P, td.kp, td.kd, td.q0, act_, qj, qdj, qd_last_e + (size_t)j * (size_t)P.N);
+            t *= TW(o.dof + TD_STR * GRX_MAX_DOFS + j);   // motor strength of this env (domain randomisation)
+            TW(wb + T_TAU) = fminf(fmaxf(t, -td.effort), td.effort);
+        }
     }
-    R3 R;
-    R.cx = rot(J, qx); R.cy = rot(J, qy); R.cz = rot(J, qz);
-    return R;
+    tree_fence();
 }
 
 // one sphere against the terrain (gen_sphere with the anchors and the link-force accumulators in the LDS workspace)
@@ -162,57 +183,71 @@ struct TreeRegs {
     V3 Sa[TNG];             // joint axis in world axes (the motion subspace is S = (a; rho x a): rho comes back from the frame in LDS)
 };
 
+// what a chain's lane knows of its chain without asking the tables (registers, set once per launch): a level of a pass then needs ONE batch
+// of LDS reads, all issued together, instead of a dependent round trip per table word it used to branch on
+struct TreeChain {
+    int first, last;   // the chain's run of levels (first > last: no chain)
+    int hangp;         // the body the chain hangs from (0: the base)
+    uint32_t hcmask;   // bit g: the chain's body of level g carries hanging chains
+};
+
 // pass 1 (root -> leaves) over the depth levels: frames and velocities into LDS; KIN: nothing else (the state after the last sub-step).
 // The velocity-product accelerations c_k are FOLDED into the bodies' bias forces (as in the eight-wave lower-limb kernel,
 // grx_wavepipe.h rigid_bias_z): with zeta_k = the sum of the c_j along the path from the base and a_k = a^_k + zeta_k, body k obeys
 // f_k = I_k a^_k + (p_k + I_k zeta_k) and a^_k = a^_parent + S_k qdd_k -- the articulated-body recursion in a^ has no c terms at
-// all: nothing to keep per level, no I^A c products in pass 2, no additions in pass 3.  A body with chains hanging from it leaves
-// its zeta in their hand-over slots (free until pass 2).
+// all: nothing to keep per level, no I^A c products in pass 2, no additions in pass 3.  A body's zeta is parked where its bias force goes
+// (the force itself is formed for ALL bodies at once behind the walk); a chain that hangs from it PULLS it from there when it starts
+// (rounds 4-5: the parent pushed it into every hanging chain's hand-over slot, a loop over a table count on every level).
+// Round 6: a level is ONE batch of LDS reads (the joint-local rotation tree_joint_phase left in the row, the joint's origin and axis),
+// ~80 multiply-adds and the stores -- see tree_joint_phase.
+struct TreeOutIn { R3 L; V3 jp, ax; };
+GRX_DEV TreeOutIn tree_out_fetch(const TreeTab& T, const float* wsw, int ei, int b) {
+    TreeOutIn x;
+    const TreeBody& tb = T.body[b];
+    x.L = tw_R(wsw, ei, TBO(b) + T_R);
+    x.jp = v3(tb.jpos[0], tb.jpos[1], tb.jpos[2]); x.ax = v3(tb.axis[0], tb.axis[1], tb.axis[2]);
+    return x;
+}
 template <bool KIN>
-GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0, bool use_last, int first, int last, TreeRegs& G,
-                          const float* qd_last_e = nullptr) {   // qd_last_e: P.last_dof_vel + e (read by control type 'V' only)
+GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0, const TreeChain& CH, int nstep, TreeRegs& G) {
     R3 Rc = R0;
     V3 rho_c = v3(0.f, 0.f, 0.f), w_c = E.B.ang, v_c = E.B.vel;
     V3 za = v3(0.f, 0.f, 0.f), zl = v3(0.f, 0.f, 0.f);
     // final frames (KIN): only as deep as a foot, the torso, the forehead -- the arms hang four levels deeper -- unless every link frame is published
     const int kin_levels = KIN && !P.publish_rbs ? T.nstep_kin : TNG;
+    // (a level's batch is requested one level ahead, unconditionally -- see tree_accel; the loop has no exit at the tree's depth either: with a
+    //  loop-invariant bound a `break` makes the trip count a run-time value, the pass is no longer unrolled and its level-indexed registers go
+    //  to scratch -- measured)
+    TreeOutIn nx = tree_out_fetch(T, wsw, ei, max(G.sb[0], 1));
 #pragma unroll
     for (int g = 0; g < TNG; ++g) {
-        if (g >= T.nstep) break;   // (uniform)
+        const TreeOutIn in = nx;
+        if (g + 1 < TNG) nx = tree_out_fetch(T, wsw, ei, max(G.sb[g + 1 < TNG ? g + 1 : g], 1));
         if (G.sb[g] >= 0 && (!KIN || g < kin_levels)) {
             const int b = G.sb[g];
-            const TreeBody& tb = T.body[b];
-            const int p = tb.parent, j = b - 1;
-            if (g == first && p != 0) {   // the chain hangs from another chain's body, processed one level earlier
-                Rc = tw_R(wsw, ei, TBO(p) + T_R); rho_c = tw_v3(wsw, ei, TBO(p) + T_RHO);
-                w_c = tw_v3(wsw, ei, TBO(p) + T_W); v_c = tw_v3(wsw, ei, TBO(p) + T_V);
-                if (!KIN) { za = tw_v3(wsw, ei, o.up + c * T_UPW); zl = tw_v3(wsw, ei, o.up + c * T_UPW + 3); }
+            const int wb = TBO(b);
+            const R3 L = in.L;
+            const V3 jp = in.jp, ax = in.ax;
+            if (g == CH.first && CH.hangp != 0) {   // the chain hangs from another chain's body, processed one level earlier
+                const int wp = TBO(CH.hangp);
+                Rc = tw_R(wsw, ei, wp + T_R); rho_c = tw_v3(wsw, ei, wp + T_RHO);
+                w_c = tw_v3(wsw, ei, wp + T_W); v_c = tw_v3(wsw, ei, wp + T_V);
+                if (!KIN) { za = tw_v3(wsw, ei, wp + T_PA); zl = tw_v3(wsw, ei, wp + T_PL); }
             }
-            const float qj = G.q[g], qdj = G.qd[g];
-            const V3 rho = rho_c + rot(Rc, v3(tb.jpos[0], tb.jpos[1], tb.jpos[2]));
-            const R3 R = tree_joint_rot(Rc, tb, qj);
-            const V3 a = rot(R, v3(tb.axis[0], tb.axis[1], tb.axis[2]));
+            const float qdj = G.qd[g];
+            const V3 rho = rho_c + rot(Rc, jp);
+            R3 R;
+            R.cx = rot(Rc, L.cx); R.cy = rot(Rc, L.cy); R.cz = rot(Rc, L.cz);
+            const V3 a = rot(R, ax);
             const V3 s = cross(rho, a);
             const V3 w = fma3(a, qdj, w_c), v = fma3(s, qdj, v_c);
-            const int wb = TBO(b);
             tw_put(wsw, ei, wb + T_R, R.cx); tw_put(wsw, ei, wb + T_R + 3, R.cy); tw_put(wsw, ei, wb + T_R + 6, R.cz);
             tw_put(wsw, ei, wb + T_RHO, rho); tw_put(wsw, ei, wb + T_W, w); tw_put(wsw, ei, wb + T_V, v);
             if (!KIN) {
-                const TreeDof& td = T.dof[j];
-                {   // _compute_torques (legged_robot.py:679-715)
-                    const float act_ = TW(o.dof + (use_last ? TD_ALAST : TD_ACUR) * GRX_MAX_DOFS + j);
-                    float t = control_torque(P, td.kp, td.kd, td.q0, act_, qj, qdj, qd_last_e + (size_t)j * (size_t)P.N);
-                    t *= TW(o.dof + TD_STR * GRX_MAX_DOFS + j);   // motor strength of this env (domain randomisation)
-                    TW(wb + T_TAU) = fminf(fmaxf(t, -td.effort), td.effort);
-                }
                 G.Sa[g] = a;
                 za = fma3(cross(w_c, a), qdj, za);
                 zl = fma3(cross(v_c, a) + cross(w_c, s), qdj, zl);
-                // the body's zeta is parked where its bias force goes: the force itself needs nothing from the chain any more and is
-                // formed for ALL bodies at once behind the walk (below) -- 33 bodies go round the group's lanes in 2-4 rounds instead of
-                // riding on the 10 depth levels
                 tw_put(wsw, ei, wb + T_PA, za); tw_put(wsw, ei, wb + T_PL, zl);
-                for (int k = 0; k < tb.nhc; ++k) { tw_put(wsw, ei, o.up + tb.hc[k] * T_UPW, za); tw_put(wsw, ei, o.up + tb.hc[k] * T_UPW + 3, zl); }
             }
             Rc = R; rho_c = rho; w_c = w; v_c = v;
         }
@@ -224,11 +259,11 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
             const int wb = TBO(b);
             const R3 R = tw_R(wsw, ei, wb + T_R);
             const V3 rho = tw_v3(wsw, ei, wb + T_RHO), w = tw_v3(wsw, ei, wb + T_W), v = tw_v3(wsw, ei, wb + T_V);
-            const V3 za = tw_v3(wsw, ei, wb + T_PA), zl = tw_v3(wsw, ei, wb + T_PL);
+            const V3 za_ = tw_v3(wsw, ei, wb + T_PA), zl_ = tw_v3(wsw, ei, wb + T_PL);
             const V3 kap = rho + rot(R, v3(tb.com[0], tb.com[1], tb.com[2]));
             const S3 Ic = {tb.Ic[0], tb.Ic[1], tb.Ic[2], tb.Ic[3], tb.Ic[4], tb.Ic[5]};
             V3 pa, pl;
-            rigid_bias_z(R, kap, tb.mass, Ic, w, v, za, zl, pa, pl);
+            rigid_bias_z(R, kap, tb.mass, Ic, w, v, za_, zl_, pa, pl);
             tw_put(wsw, ei, wb + T_PA, pa); tw_put(wsw, ei, wb + T_PL, pl);
         }
         tree_fence();
@@ -259,6 +294,7 @@ GRX_DEV void tree_contacts(KP P, const TreeTab& T, float* wsw, int ei, int c, co
                 if (s0 + u < s1) {
                     const TreeSph& S = T.sph[s0 + u];
                     xr[u] = rho + rot(R, v3(S.x, S.y, S.z));
+                    tw_put(wsw, ei, o.up + (s0 + u) * 3, xr[u]);   // (the self-collision's broad phase reads the centres from here)
                     th[u].h = 0.f; th[u].gx = 0.f; th[u].gy = 0.f;
                     if (E.B.pos.z + xr[u].z - S.r <= E.hmax) th[u].h = terrain_height<HF>(P, E.B.pos.x + xr[u].x, E.B.pos.y + xr[u].y, th[u].gx, th[u].gy);
                 }
@@ -326,111 +362,156 @@ GRX_DEV void tree_rigid_inertias(const TreeTab& T, float* wsw, int ei, int c) {
     }
     tree_fence();
 }
-GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, int first, int last, TreeRegs& G) {
+struct TreeInIn { V3 rho, pab, plb, hk; S3 Ar; float t, mass, arm, qlo, qhi, Klim, Clim; };
+GRX_DEV TreeInIn tree_in_fetch(const TreeTab& T, const float* wsw, int ei, int b) {
+    TreeInIn x;
+    const TreeBody& tb = T.body[b];
+    const TreeDof& td = T.dof[b - 1];
+    const int wb = TBO(b);
+    x.rho = tw_v3(wsw, ei, wb + T_RHO); x.pab = tw_v3(wsw, ei, wb + T_PA); x.plb = tw_v3(wsw, ei, wb + T_PL);
+    x.t = TW(wb + T_TAU);
+    x.Ar = S3{TW(wb + T_AK), TW(wb + T_AK + 1), TW(wb + T_AK + 2), TW(wb + T_AK + 3), TW(wb + T_AK + 4), TW(wb + T_AK + 5)};
+    x.hk = tw_v3(wsw, ei, wb + T_HK);
+    x.mass = tb.mass; x.arm = td.arm; x.qlo = td.qlo; x.qhi = td.qhi; x.Klim = td.Klim; x.Clim = td.Clim;
+    return x;
+}
+GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeChain& CH, int nstep, TreeRegs& G) {
     // The lane's chain is ONE run of levels (first .. last): its running articulated inertia [A B; B^T D] and bias force are the working
     // set itself -- zero before the chain's leaf, every level ADDS its rigid body and downdates in place, the chain's first body hands
     // them up.  (Round 4, from the ISA: separate per-level values copied into a carry cost 127 v_mov per level, a fifth of the pass.)
+    // Round 6: a level's operands -- the body's row and the joint's limits and armature -- are ONE batch of LDS reads (the joint-limit
+    // spring used to fetch its table words behind two branches: three dependent round trips a level), the limit torque is branch-free,
+    // and whether a body carries hanging chains is a bit of a register, not a table word.  The batch -- contacts, self-collision and
+    // tree_rigid_inertias are done with the rows -- is requested ONE LEVEL AHEAD (unconditionally: see tree_accel), so that its latency passes
+    // behind the previous level's ~100 multiply-adds; only the hanging chains' hand-over, written one level earlier, is read in its level.
     S3 A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, D = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     M3 Bm = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     V3 pa = v3(0.f, 0.f, 0.f), pl = v3(0.f, 0.f, 0.f);
+    TreeInIn nx = tree_in_fetch(T, wsw, ei, max(G.sb[TNG - 1], 1));
 #pragma unroll
     for (int g = TNG - 1; g >= 0; --g) {
-        if (g >= T.nstep) continue;   // (uniform)
+        const TreeInIn in = nx;
+        if (g > 0) nx = tree_in_fetch(T, wsw, ei, max(G.sb[g > 0 ? g - 1 : 0], 1));
         if (G.sb[g] >= 0) {
             const int b = G.sb[g];
             const TreeBody& tb = T.body[b];
-            const int j = b - 1, wb = TBO(b);
-            const V3 rho = tw_v3(wsw, ei, wb + T_RHO);
-            pa = pa + tw_v3(wsw, ei, wb + T_PA); pl = pl + tw_v3(wsw, ei, wb + T_PL);
-            float t = TW(wb + T_TAU);
-            {   // the body's rigid inertia about O: formed for all bodies at once by tree_rigid_inertias, parked in the rotation's slots
-                const S3 Ar = {TW(wb + T_AK), TW(wb + T_AK + 1), TW(wb + T_AK + 2), TW(wb + T_AK + 3), TW(wb + T_AK + 4), TW(wb + T_AK + 5)};
-                add_rigid(A, Bm, D, Ar, tw_v3(wsw, ei, wb + T_HK), tb.mass);
-            }
-            for (int k = 0; k < tb.nhc; ++k) tree_add_up(wsw, ei, o.up + tb.hc[k] * T_UPW, A, Bm, D, pa, pl);   // chains that hang from this body, fixed order
+            const int wb = TBO(b);
+            const V3 rho = in.rho;
+            float t = in.t;
+            const float arm = in.arm, qlo = in.qlo, qhi = in.qhi, Klim = in.Klim, Clim = in.Clim;
+            pa = pa + in.pab; pl = pl + in.plb;
+            add_rigid(A, Bm, D, in.Ar, in.hk, in.mass);
+            if (CH.hcmask & (1u << g))   // chains that hang from this body, fixed order
+                for (int k = 0; k < tb.nhc; ++k) tree_add_up(wsw, ei, o.up + tb.hc[k] * T_UPW, A, Bm, D, pa, pl);
             const V3 a = G.Sa[g], s = cross(rho, a);
             const V3 ua = mul(A, a) + mul(Bm, s);
             const V3 ul = mulT(Bm, a) + mul(D, s);
-            const TreeDof& td = T.dof[j];
-            const float di = grx_rcp(dot(a, ua) + dot(s, ul) + td.arm);
+            const float di = grx_rcp(dot(a, ua) + dot(s, ul) + arm);
             const float qj = G.q[g], qdj = G.qd[g];
-            if (qj < td.qlo) t += td.Klim * (td.qlo - qj) - td.Clim * qdj;   // joint-limit spring/damper on top of the motor torque
-            else if (qj > td.qhi) t += td.Klim * (td.qhi - qj) - td.Clim * qdj;
+            {   // joint-limit spring/damper on top of the motor torque
+                const float viol = qj < qlo ? qlo - qj : (qj > qhi ? qhi - qj : 0.f);
+                t += Klim * viol - (viol != 0.f ? Clim * qdj : 0.f);
+            }
             const float u = t - (dot(a, pa) + dot(s, pl));
             syr(A, ua, di); ger(Bm, ua, ul, di); syr(D, ul, di);
             const float ud = u * di;
             pa = fma3(ua, ud, pa); pl = fma3(ul, ud, pl);
             TW(wb + T_DI) = di; TW(wb + T_U) = u;
             tw_put(wsw, ei, wb + T_UA, ua); tw_put(wsw, ei, wb + T_UL, ul);
-            if (g == first) tree_put_up(wsw, ei, o.up + c * T_UPW, A, Bm, D, pa, pl);
+            if (g == CH.first) tree_put_up(wsw, ei, o.up + c * T_UPW, A, Bm, D, pa, pl);
         }
         tree_fence();
     }
 }
 
-// pass 3 (root -> leaves): accelerations a^ (see tree_outward), joint integration
-GRX_DEV void tree_accel(KP P, const TreeTab& T, float* wsw, int ei, int c, V3 alpha, V3 acc, int first, int last, TreeRegs& G) {
-    // (fetching a level's U, 1/d, u, rho one level AHEAD of the arithmetic -- here and in tree_inward -- was measured: 3 % SLOWER, and the
-    //  kernels then need all 512 registers and spill; the scheduler already overlaps what the level fences allow)
+// pass 3 (root -> leaves): accelerations a^ (see tree_outward), joint integration.  The pass is a chain of ten short dependent steps: what
+// a level reads of its body's row (U, 1/d, u, rho: written by pass 2, nobody touches them any more) is requested ONE LEVEL AHEAD, so that the
+// LDS latency passes behind the previous level's arithmetic (round 6; rounds 4-5 waited ~300 of a level's ~640 cycles for it).  The
+// integrated joint state goes to the row's T_Q / T_QD for the next sub-step's joint-local phase.
+struct TreeAccIn { V3 ua, ul, rho; float u, di, vlim; };
+GRX_DEV TreeAccIn tree_acc_fetch(const TreeTab& T, const float* wsw, int ei, int b) {
+    TreeAccIn x;
+    const int wb = TBO(b);
+    x.ua = tw_v3(wsw, ei, wb + T_UA); x.ul = tw_v3(wsw, ei, wb + T_UL); x.rho = tw_v3(wsw, ei, wb + T_RHO);
+    x.u = TW(wb + T_U); x.di = TW(wb + T_DI); x.vlim = T.dof[b - 1].vlim;
+    return x;
+}
+GRX_DEV void tree_accel(KP P, const TreeTab& T, float* wsw, int ei, int c, V3 alpha, V3 acc, const TreeChain& CH, int nstep, TreeRegs& G) {
     V3 aa_c = alpha, al_c = acc;
     const float dt = P.sim_dt;
+    // (the request is UNCONDITIONAL -- a lane without a body on the next level reads body 1's row and drops it: a fetch under the lane's
+    //  predicate makes the value a merge of two definitions, whose copies wait for the data at the top of the level; and the levels are not
+    //  cut short at the tree's depth: a level nobody holds is one skipped branch)
+    TreeAccIn nx = tree_acc_fetch(T, wsw, ei, max(G.sb[0], 1));
 #pragma unroll
     for (int g = 0; g < TNG; ++g) {
-        if (g >= T.nstep) break;   // (uniform)
+        const TreeAccIn in = nx;
+        if (g + 1 < TNG) nx = tree_acc_fetch(T, wsw, ei, max(G.sb[g + 1 < TNG ? g + 1 : g], 1));
         if (G.sb[g] >= 0) {
-            const int b = G.sb[g];
-            const TreeBody& tb = T.body[b];
-            const int p = tb.parent, j = b - 1, wb = TBO(b);
-            if (g == first && p != 0) { aa_c = tw_v3(wsw, ei, TBO(p) + T_PA); al_c = tw_v3(wsw, ei, TBO(p) + T_PL); }   // (the parent parked its acceleration there)
-            const V3 ua = tw_v3(wsw, ei, wb + T_UA), ul = tw_v3(wsw, ei, wb + T_UL), rho = tw_v3(wsw, ei, wb + T_RHO), a = G.Sa[g];
-            const float qdd = (TW(wb + T_U) - (dot(ua, aa_c) + dot(ul, al_c))) * TW(wb + T_DI);
-            aa_c = fma3(a, qdd, aa_c); al_c = fma3(cross(rho, a), qdd, al_c);
-            if (tb.nhc > 0) { tw_put(wsw, ei, wb + T_PA, aa_c); tw_put(wsw, ei, wb + T_PL, al_c); }   // the hanging chains' parent acceleration (U has been read)
+            const int b = G.sb[g], wb = TBO(b);
+            if (g == CH.first && CH.hangp != 0) { aa_c = tw_v3(wsw, ei, TBO(CH.hangp) + T_PA); al_c = tw_v3(wsw, ei, TBO(CH.hangp) + T_PL); }   // (the parent parked its acceleration there)
+            const V3 a = G.Sa[g];
+            const float qdd = (in.u - (dot(in.ua, aa_c) + dot(in.ul, al_c))) * in.di;
+            aa_c = fma3(a, qdd, aa_c); al_c = fma3(cross(in.rho, a), qdd, al_c);
+            if (CH.hcmask & (1u << g)) { tw_put(wsw, ei, wb + T_PA, aa_c); tw_put(wsw, ei, wb + T_PL, al_c); }   // the hanging chains' parent acceleration (U has been read)
             float vq = fmaf(qdd, dt, G.qd[g]);
-            const float vlim = T.dof[j].vlim;
-            vq = fminf(fmaxf(vq, -vlim), vlim);
+            vq = fminf(fmaxf(vq, -in.vlim), in.vlim);
             G.qd[g] = vq;
             G.q[g] = fmaf(vq, dt, G.q[g]);
+            TW(wb + T_Q) = G.q[g]; TW(wb + T_QD) = vq;
         }
         tree_fence();
     }
 }
 
-// self-collision (the contact law of grx_self.h, the link-pair tables of grx_generic.h): the env's lanes share the bounding
-// tests of the link pairs; the few pairs that do touch are then evaluated ONE AT A TIME, in table order, by the lane that
-// found them -- it alone adds into the bodies' bias forces and the link accumulators: no races, the same sums on every run
+// self-collision (the contact law of grx_self.h, the link-pair tables of grx_generic.h).  Round 6 -- an exact BROAD PHASE: the model's
+// sphere pairs (TreeTab.sp: every sphere pair of every link pair that can meet) go round the group's lanes, each a centre-distance test on
+// the world centres the contact pass left in LDS (o.up) against (ra + rb + margin)^2; a pair that passes raises the bit of its LINK pair.
+// Links that do not touch stop here -- in a walking robot that is all of them, nearly always.  (Rounds 2-5 tested the links' bounding
+// spheres, which for neighbours like upper arm x torso overlap in every pose: the ~800-instruction narrow phase ran in every round of
+// every sub-step, 6.7 k of a sub-step's 55 k cycles.)  The raised link pairs are then evaluated as before: by the lanes that hold them,
+// together; only the accumulation into the bodies' bias forces and the link forces goes one lane at a time, in table order -- no races,
+// the same sums on every run, and bit for bit the sums of rounds 4-5 (the margin keeps the broad phase a superset of sphere_pair's own test).
+GRX_DEV uint32_t grp_or(uint32_t v) {
+    v |= (uint32_t)__shfl_xor((int)v, 1); v |= (uint32_t)__shfl_xor((int)v, 2); v |= (uint32_t)__shfl_xor((int)v, 4);
+    if (TG == 16) v |= (uint32_t)__shfl_xor((int)v, 8);
+    return v;
+}
 GRX_DEV void tree_self_collision(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0,
                                  V3& pa0, V3& pl0) {
+    uint32_t m0 = 0u, m1 = 0u;   // raised link pairs 0..31, 32..47
+    {
+        const int nsp = T.nsp;
+#pragma unroll 4
+        for (int k0 = 0; k0 < nsp; k0 += TG) {
+            const int k = k0 + c;
+            if (k < nsp) {
+                const uint32_t e_ = T.sp[k];
+                const float r2 = T.sp_r2[k];
+                const int ia = (int)(e_ & 255u), ib = (int)((e_ >> 8) & 255u), lp = (int)(e_ >> 16);
+                const V3 d = tw_v3(wsw, ei, o.up + ia * 3) - tw_v3(wsw, ei, o.up + ib * 3);
+                if (dot(d, d) < r2) { if (lp < 32) m0 |= 1u << lp; else m1 |= 1u << (lp - 32); }
+            }
+        }
+    }
+    if (!__any((m0 | m1) != 0u)) return;
+    m0 = grp_or(m0); m1 = grp_or(m1);
     const float mu_self = 2.0f * E.mu - P.terrain_friction;
     V3 dpa0 = v3(0.f, 0.f, 0.f), dpl0 = v3(0.f, 0.f, 0.f);
     for (int lp0 = 0; lp0 < T.nlp; lp0 += TG) {
         const int lp = lp0 + c;
-        bool hit = false;
-        int ba = 0, bb = 0;
-        ChainKin Ka, Kb;
-        if (lp < T.nlp) {
-            ba = T.lp_ba[lp]; bb = T.lp_bb[lp];
-            // (positions for the bounding test; the velocities -- contact damping only -- are fetched by the few lanes that hit)
-            if (ba == 0) Ka = ChainKin{R0, v3(0.f, 0.f, 0.f), E.B.ang, E.B.vel};
-            else Ka = ChainKin{tw_R(wsw, ei, TBO(ba) + T_R), tw_v3(wsw, ei, TBO(ba) + T_RHO), v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
-            Kb = ChainKin{tw_R(wsw, ei, TBO(bb) + T_R), tw_v3(wsw, ei, TBO(bb) + T_RHO), v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
-            const V3 ca = Ka.rho + rot(Ka.R, v3(T.lp_ca[lp][0], T.lp_ca[lp][1], T.lp_ca[lp][2]));
-            const V3 cb = Kb.rho + rot(Kb.R, v3(T.lp_cb[lp][0], T.lp_cb[lp][1], T.lp_cb[lp][2]));
-            const V3 d = ca - cb;
-            const float R = T.lp_ca[lp][3] + T.lp_cb[lp][3];
-            hit = dot(d, d) < R * R;
-        }
+        const bool hit = lp < T.nlp && (((lp < 32 ? m0 >> lp : m1 >> (lp - 32)) & 1u) != 0u);
         if (!__any(hit)) continue;
-        // Round 4: the lanes that hit evaluate their pairs TOGETHER (the nested sphere x sphere loops: ~800 instructions a pair, and the
-        // bounding spheres of neighbouring links -- upper arm x torso -- overlap in every pose, so every round has some); only the
-        // accumulation into the bodies' bias forces and the link forces goes one lane at a time, in table order, as before: the same
-        // sums on every run, bit for bit the sums of the one-at-a-time evaluation.
+        // the lanes that hit evaluate their pairs TOGETHER (the nested sphere x sphere loops: ~800 instructions a pair)
         V3 Fa = v3(0.f, 0.f, 0.f), Ta = v3(0.f, 0.f, 0.f);
-        int la = 0, lb = 0;
+        int la = 0, lb = 0, ba = 0, bb = 0;
         if (hit) {
+            ba = T.lp_ba[lp]; bb = T.lp_bb[lp];
             la = T.lp_a[lp]; lb = T.lp_b[lp];
-            if (ba != 0) { Ka.w = tw_v3(wsw, ei, TBO(ba) + T_W); Ka.v = tw_v3(wsw, ei, TBO(ba) + T_V); }
-            Kb.w = tw_v3(wsw, ei, TBO(bb) + T_W); Kb.v = tw_v3(wsw, ei, TBO(bb) + T_V);
+            ChainKin Ka, Kb;
+            if (ba == 0) Ka = ChainKin{R0, v3(0.f, 0.f, 0.f), E.B.ang, E.B.vel};
+            else Ka = ChainKin{tw_R(wsw, ei, TBO(ba) + T_R), tw_v3(wsw, ei, TBO(ba) + T_RHO), tw_v3(wsw, ei, TBO(ba) + T_W), tw_v3(wsw, ei, TBO(ba) + T_V)};
+            Kb = ChainKin{tw_R(wsw, ei, TBO(bb) + T_R), tw_v3(wsw, ei, TBO(bb) + T_RHO), tw_v3(wsw, ei, TBO(bb) + T_W), tw_v3(wsw, ei, TBO(bb) + T_V)};
             for (int i = T.lc_begin[la]; i < T.lc_begin[la + 1]; ++i) {
                 SphC si; si.x = T.sph[i].x; si.y = T.sph[i].y; si.z = T.sph[i].z; si.r = T.sph[i].r; si.dmax = T.sph[i].dmax;
                 const SphW a = sph_world(si, Ka);
@@ -490,7 +571,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     const int nwaves = blockDim.x >> 6, tepb = TEPW * nwaves;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ew = lane / TG, c = lane & (TG - 1);   // ew: the env of the wave
     if (wave == nwaves - 1) stats_fold_previous(P, sq, lane);   // the previous launch's episode statistics (and its ticket)
-    const TreeOff o = tree_offsets(T.nb, T.nlc, T.nchain);
+    const TreeOff o = tree_offsets(T.nb, T.nlc, T.nchain, T.nsph);
     const int thalf = tree_half_words(o.total);
     float* const wsw = s_dyn + sizeof(TreeTab) / 4 + (size_t)wave * 2 * thalf;
     const int ei = (ew / TEH) * thalf + (ew % TEH);   // (TW: the lane's offset into its half's block)
@@ -504,7 +585,6 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     const uint32_t genv = (uint32_t)(P.env_offset + e), step = (uint32_t)common_step;
     const int nh = P.nh, nobs = 9 + 3 * nd, npri = P.num_pri_obs;
     const float dtp = P.sim_dt * (float)P.decimation;
-    const int first = T.first[c], last = T.last[c];
     // ---- load the state: the base in every lane of the group, a chain's joints by its lane
     TreeEnv E;
     E.B.pos = v3(P.root[e], P.root[N + e], P.root[2 * N + e]);
@@ -531,15 +611,21 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     const float bho_stale = P.base_heights_offset[e];
     long long ep_len = P.ep_len[e];
     TreeRegs G;
+    TreeChain CH;
+    CH.first = T.first[c]; CH.last = T.last[c]; CH.hangp = 0; CH.hcmask = 0u;
+    const int nstep = __builtin_amdgcn_readfirstlane(T.nstep);
 #pragma unroll
     for (int g = 0; g < TNG; ++g) {
-        const int b = g < T.nstep ? (int)T.sched[c][g] : -1;
+        const int b = g < nstep ? (int)T.sched[c][g] : -1;
         G.sb[g] = b;
         G.q[g] = 0.f; G.qd[g] = 0.f; G.Sa[g] = v3(0.f, 0.f, 0.f);
         if (b >= 0) {
             const int j = b - 1;
             const size_t oj = (size_t)j * N + e;
             G.q[g] = P.q[oj]; G.qd[g] = P.qd[oj];
+            TW(TBO(b) + T_Q) = G.q[g]; TW(TBO(b) + T_QD) = G.qd[g];   // (the joint-local phase reads them from the row)
+            if (g == CH.first) CH.hangp = T.body[b].parent;
+            if (T.body[b].nhc > 0) CH.hcmask |= 1u << g;
             const float a = actions_in ? actions_in[(size_t)e * nd + j] : 0.f;
             TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j) = fminf(fmaxf(a, T.dof[j].amin), T.dof[j].amax);   // clip_actions (legged_robot_fftai.py:171-177)
             TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j) = P.last_actions[oj];
@@ -573,7 +659,8 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         if (c < 6) TW(o.misc + 8 + c) = 0.f;
         tree_fence();
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
-        tree_outward<false>(P, T, wsw, ei, c, o, E, R0, (float)deci < delay, first, last, G, P.last_dof_vel + e);
+        tree_joint_phase<false>(P, T, wsw, ei, c, o, (float)deci < delay, P.last_dof_vel + e);
+        tree_outward<false>(P, T, wsw, ei, c, o, E, R0, CH, nstep, G);
         TT(0);
         tree_contacts<HF>(P, T, wsw, ei, c, o, E, R0);
         TT(1);
@@ -588,7 +675,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         if (P.self_collisions) tree_self_collision(P, T, wsw, ei, c, o, E, R0, pa0, pl0);
         TT(3);
         tree_rigid_inertias(T, wsw, ei, c);
-        tree_inward(P, T, wsw, ei, c, o, first, last, G);
+        tree_inward(P, T, wsw, ei, c, o, CH, nstep, G);
         TT(4);
         // ---- base: the chains that hang from it, in table order; [A B; B^T D][alpha; acc] = -[pa; pl]
         S3 Db = {E.base_m, 0.f, 0.f, E.base_m, 0.f, E.base_m};
@@ -601,7 +688,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         const V3 alpha = mul(inv(Sc), mul(Bb, mul(Di, pl0)) - pa0);
         const V3 acc = neg(mul(Di, pl0 + mulT(Bb, alpha)));
         TT(5);
-        tree_accel(P, T, wsw, ei, c, alpha, acc, first, last, G);
+        tree_accel(P, T, wsw, ei, c, alpha, acc, CH, nstep, G);
         TT(6);
         {   // integrate the base (semi-implicit Euler), every lane of the group alike
             const float dt = P.sim_dt;
@@ -636,7 +723,8 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     // ---- refresh_rigid_body_state_tensor after the last sub-step: frames of the final state
     {
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
-        tree_outward<true>(P, T, wsw, ei, c, o, E, R0, false, first, last, G);
+        tree_joint_phase<true>(P, T, wsw, ei, c, o, false, nullptr);
+        tree_outward<true>(P, T, wsw, ei, c, o, E, R0, CH, nstep, G);
     }
     if (P.publish_rbs) {   // GRX_T_RIGID_BODY_STATES (legged_robot.py:113,134): every URDF link frame of that state, the links go round the lanes
         const LinkTab& LT = *P.link_tab;
