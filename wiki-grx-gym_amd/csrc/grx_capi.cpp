@@ -661,10 +661,14 @@ int build_generic(grx_sim* s, const grx_config& c) {
             for (int q = 0; q < T.nlp; ++q) if ((T.lp_a[q] == la && T.lp_b[q] == lb) || (T.lp_a[q] == lb && T.lp_b[q] == la)) lp = q;
             if (lp < 0) return fail(GRX_ERR_INVALID_ARGUMENT, "self-collision sphere pair without a link pair");
             const float rs = T.sr[ka] + T.sr[kb] + 1e-4f;
-            K.sp[K.nsp] = (uint32_t)ka | ((uint32_t)kb << 8) | ((uint32_t)lp << 16);
-            K.sp_r2[K.nsp] = rs * rs;
+            K.sp[K.nsp].ab = (uint32_t)ka | ((uint32_t)kb << 8) | ((uint32_t)lp << 16);
+            K.sp[K.nsp].r2 = rs * rs;
             ++K.nsp;
         }
+        // the broad phase takes the table four rounds of the group's lanes at a time, without a bounds test: padded with pairs that never pass
+        K.nsp_batches = (K.nsp + 4 * G - 1) / (4 * G);
+        if (K.nsp_batches * 4 * G > GRX_MAX_PAIRS) return GRX_OK;
+        for (int k = K.nsp; k < K.nsp_batches * 4 * G; ++k) { K.sp[k].ab = 0u; K.sp[k].r2 = -1.f; }
     }
     for (int l = 0; l <= GEN_MAXLC_H; ++l) K.lc_begin[l] = T.lc_begin[l];
     // waves per block: two while those blocks fit the device's CUs in one round (every wave still has a SIMD to itself and the CU's

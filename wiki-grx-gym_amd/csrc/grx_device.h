@@ -132,9 +132,8 @@ struct TreeTab {
     // contact pass leaves in LDS -- centre distance against (ra + rb + margin)^2 -- and raises the bit of the pair's LINK pair; the narrow phase
     // then runs on the raised link pairs only, i.e. on links that really touch (rounds 2-5 tested the links' bounding spheres, which overlap in
     // every pose for neighbours like upper arm x torso: the 800-instruction narrow phase ran in every round of every sub-step)
-    int32_t nsp, pad2;
-    uint32_t sp[GRX_MAX_PAIRS];                       // sphere of link a | sphere of link b << 8 | link pair << 16 (positions in sph[])
-    float sp_r2[GRX_MAX_PAIRS];                       // (ra + rb + margin)^2
+    int32_t nsp, nsp_batches;                         // pairs; batches of 4 rounds of the group's lanes (the table is padded with pairs that never pass)
+    struct { uint32_t ab; float r2; } sp[GRX_MAX_PAIRS];   // ab: sphere of link a | sphere of link b << 8 | link pair << 16 (positions in sph[]); r2: (ra + rb + margin)^2
     int32_t lc_begin[25];
     int32_t ncs;                                      // rounds of the contact pass
     int32_t nturn;                                    // items of one round that share a body add their forces in turns 0 .. nturn - 1

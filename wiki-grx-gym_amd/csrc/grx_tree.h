@@ -253,21 +253,22 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
         }
         tree_fence();
     }
-    if (!KIN) {   // rigid-body bias forces p_k + I_k zeta_k of every body, from the frames in LDS (contacts and self-collision add into these)
-        for (int b = 1 + c; b < T.nb; b += TG) {
-            const TreeBody& tb = T.body[b];
-            const int wb = TBO(b);
-            const R3 R = tw_R(wsw, ei, wb + T_R);
-            const V3 rho = tw_v3(wsw, ei, wb + T_RHO), w = tw_v3(wsw, ei, wb + T_W), v = tw_v3(wsw, ei, wb + T_V);
-            const V3 za_ = tw_v3(wsw, ei, wb + T_PA), zl_ = tw_v3(wsw, ei, wb + T_PL);
-            const V3 kap = rho + rot(R, v3(tb.com[0], tb.com[1], tb.com[2]));
-            const S3 Ic = {tb.Ic[0], tb.Ic[1], tb.Ic[2], tb.Ic[3], tb.Ic[4], tb.Ic[5]};
-            V3 pa, pl;
-            rigid_bias_z(R, kap, tb.mass, Ic, w, v, za_, zl_, pa, pl);
-            tw_put(wsw, ei, wb + T_PA, pa); tw_put(wsw, ei, wb + T_PL, pl);
-        }
-        tree_fence();
+}
+// rigid-body bias forces p_k + I_k zeta_k of every body, from the frames and the zeta the walk left in LDS (contacts and self-collision add into these)
+GRX_DEV void tree_bias_all(const TreeTab& T, float* wsw, int ei, int c) {
+    for (int b = 1 + c; b < T.nb; b += TG) {
+        const TreeBody& tb = T.body[b];
+        const int wb = TBO(b);
+        const R3 R = tw_R(wsw, ei, wb + T_R);
+        const V3 rho = tw_v3(wsw, ei, wb + T_RHO), w = tw_v3(wsw, ei, wb + T_W), v = tw_v3(wsw, ei, wb + T_V);
+        const V3 za_ = tw_v3(wsw, ei, wb + T_PA), zl_ = tw_v3(wsw, ei, wb + T_PL);
+        const V3 kap = rho + rot(R, v3(tb.com[0], tb.com[1], tb.com[2]));
+        const S3 Ic = {tb.Ic[0], tb.Ic[1], tb.Ic[2], tb.Ic[3], tb.Ic[4], tb.Ic[5]};
+        V3 pa, pl;
+        rigid_bias_z(R, kap, tb.mass, Ic, w, v, za_, zl_, pa, pl);
+        tw_put(wsw, ei, wb + T_PA, pa); tw_put(wsw, ei, wb + T_PL, pl);
     }
+    tree_fence();
 }
 
 // terrain contacts: a work list (TreeTab.cw) deals the bodies' shapes, two at a time, to ALL lanes of the group -- the frames are in
@@ -275,34 +276,63 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
 // items share a body add their wrench (and the link forces) in turns.  The base's own shapes are items like any other (body 0: the
 // frame is in registers, the wrench goes to the group through o.misc).  On the way: the foot link's velocity BEFORE this sub-step's
 // integration (sub-step averaged foot speed, legged_robot_fftai.py:79-81).
+// Round 6: a round is taken in two halves.  tree_contact_probe forms the item's sphere centres (left in LDS for the self-collision's broad
+// phase) and ISSUES the terrain gathers -- ~1.2 us of memory latency on this part, which a wave alone on its SIMD cannot hide --;
+// tree_contacts evaluates them.  The kernel puts the bias forces of all bodies (tree_bias_all) between the two halves of round 0.
+struct TreeContactPre { V3 xr[2]; uint2 cc[2]; float tx[2], ty[2]; };   // cc: the raster cell's four corners as gathered (unpacked where they are used: a conversion next to the load would wait for it there)
 template <bool HF>
-GRX_DEV void tree_contacts(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0) {
+GRX_DEV TreeContactPre tree_contact_probe(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0, int r) {
+    TreeContactPre pr;
+    const int b = T.cw[r][c].body, s0 = T.cw[r][c].s0, s1 = T.cw[r][c].s1;
+    R3 R = R0;
+    V3 rho = v3(0.f, 0.f, 0.f);
+    if (b > 0) { R = tw_R(wsw, ei, TBO(b) + T_R); rho = tw_v3(wsw, ei, TBO(b) + T_RHO); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {   // two shapes: their terrain lookups in flight together
+        pr.xr[u] = v3(0.f, 0.f, 0.f);
+        if (b >= 0 && s0 + u < s1) {
+            const TreeSph& S = T.sph[s0 + u];
+            pr.xr[u] = rho + rot(R, v3(S.x, S.y, S.z));
+            tw_put(wsw, ei, o.up + (s0 + u) * 3, pr.xr[u]);   // (the self-collision's broad phase reads the centres from here)
+        }
+    }
+    // the gathers are issued for EVERY lane, unconditionally (the cell index is clamped), back to back: both in flight together, nothing waits here
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        pr.cc[u] = make_uint2(0u, 0u); pr.tx[u] = 0.f; pr.ty[u] = 0.f;
+        if (HF) pr.cc[u] = P.hf_cells[terrain_locate(P, E.B.pos.x + pr.xr[u].x, E.B.pos.y + pr.xr[u].y, pr.tx[u], pr.ty[u])];
+    }
+    return pr;
+}
+template <bool HF>
+GRX_DEV void tree_contacts(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0, const TreeContactPre& pre0) {
     for (int r = 0; r < T.ncs; ++r) {
         const int b = T.cw[r][c].body, s0 = T.cw[r][c].s0, s1 = T.cw[r][c].s1, turn = T.cw[r][c].turn;
         V3 fa = v3(0.f, 0.f, 0.f), fl = v3(0.f, 0.f, 0.f), Fs[2] = {fa, fa};
         R3 R = R0;
         V3 rho = v3(0.f, 0.f, 0.f), w = E.B.ang, v = E.B.vel;
+        TreeContactPre pr = pre0;
+        if (r > 0) pr = tree_contact_probe<HF>(P, T, wsw, ei, c, o, E, R0, r);
         if (b >= 0) {
             if (b > 0) {
                 const int wb = TBO(b);
                 R = tw_R(wsw, ei, wb + T_R);
                 rho = tw_v3(wsw, ei, wb + T_RHO); w = tw_v3(wsw, ei, wb + T_W); v = tw_v3(wsw, ei, wb + T_V);
             }
-            V3 xr[2]; TerrainAt th[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)   // two shapes: their terrain lookups in flight together
-                if (s0 + u < s1) {
-                    const TreeSph& S = T.sph[s0 + u];
-                    xr[u] = rho + rot(R, v3(S.x, S.y, S.z));
-                    tw_put(wsw, ei, o.up + (s0 + u) * 3, xr[u]);   // (the self-collision's broad phase reads the centres from here)
-                    th[u].h = 0.f; th[u].gx = 0.f; th[u].gy = 0.f;
-                    if (E.B.pos.z + xr[u].z - S.r <= E.hmax) th[u].h = terrain_height<HF>(P, E.B.pos.x + xr[u].x, E.B.pos.y + xr[u].y, th[u].gx, th[u].gy);
-                }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
                 if (s0 + u < s1) {
-                    Fs[u] = tree_sphere<HF, false>(P, T.sph[s0 + u], w, v, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, xr[u], th[u]);
-                    fa = fa + cross(xr[u], Fs[u]); fl = fl + Fs[u];
+                    TerrainAt th;
+                    th.h = 0.f; th.gx = 0.f; th.gy = 0.f;
+                    if (HF && E.B.pos.z + pr.xr[u].z - T.sph[s0 + u].r <= E.hmax) {
+                        TerrainRaw raw;
+                        raw.h00 = (int16_t)(pr.cc[u].x & 0xffffu); raw.h01 = (int16_t)(pr.cc[u].x >> 16);
+                        raw.h10 = (int16_t)(pr.cc[u].y & 0xffffu); raw.h11 = (int16_t)(pr.cc[u].y >> 16);
+                        raw.tx = pr.tx[u]; raw.ty = pr.ty[u];
+                        th.h = terrain_eval<HF>(P, raw, th.gx, th.gy);
+                    }
+                    Fs[u] = tree_sphere<HF, false>(P, T.sph[s0 + u], w, v, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, pr.xr[u], th);
+                    fa = fa + cross(pr.xr[u], Fs[u]); fl = fl + Fs[u];
                 }
         }
         for (int t = 0; t < T.nturn; ++t) {
@@ -480,18 +510,20 @@ GRX_DEV uint32_t grp_or(uint32_t v) {
 GRX_DEV void tree_self_collision(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0,
                                  V3& pa0, V3& pl0) {
     uint32_t m0 = 0u, m1 = 0u;   // raised link pairs 0..31, 32..47
-    {
-        const int nsp = T.nsp;
-#pragma unroll 4
-        for (int k0 = 0; k0 < nsp; k0 += TG) {
-            const int k = k0 + c;
-            if (k < nsp) {
-                const uint32_t e_ = T.sp[k];
-                const float r2 = T.sp_r2[k];
-                const int ia = (int)(e_ & 255u), ib = (int)((e_ >> 8) & 255u), lp = (int)(e_ >> 16);
-                const V3 d = tw_v3(wsw, ei, o.up + ia * 3) - tw_v3(wsw, ei, o.up + ib * 3);
-                if (dot(d, d) < r2) { if (lp < 32) m0 |= 1u << lp; else m1 |= 1u << (lp - 32); }
-            }
+    for (int r0 = 0; r0 < T.nsp_batches; ++r0) {   // four rounds of the group's lanes per batch, branch-free: the table words and then the
+        uint32_t ab[4]; float r2[4], d2[4];      // centres of all four are requested together (two LDS round trips a batch, not eight)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k = (r0 * 4 + u) * TG + c; ab[u] = T.sp[k].ab; r2[u] = T.sp[k].r2; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ia = (int)(ab[u] & 255u), ib = (int)((ab[u] >> 8) & 255u);
+            const V3 d = tw_v3(wsw, ei, o.up + ia * 3) - tw_v3(wsw, ei, o.up + ib * 3);
+            d2[u] = dot(d, d);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t lp = ab[u] >> 16, bit = d2[u] < r2[u] ? 1u << (lp & 31u) : 0u;
+            m0 |= lp < 32u ? bit : 0u; m1 |= lp < 32u ? 0u : bit;
         }
     }
     if (!__any((m0 | m1) != 0u)) return;
@@ -602,14 +634,6 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         int cj = min(max((int)((E.B.pos.y + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
         E.hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
     }
-    EnvAux ea;
-    ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[N + e]; ea.cmd[2] = P.commands[2 * N + e];
-    ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[N + e]; ea.origin[2] = P.origins[2 * N + e];
-    ea.level = P.levels[e]; ea.type = P.types[e];
-    float air_time[2] = {P.air_time[e], P.air_time[N + e]}, land_time[2] = {P.land_time[e], P.land_time[N + e]};
-    bool contact_last[2] = {P.feet_contact[e] != 0, P.feet_contact[N + e] != 0};
-    const float bho_stale = P.base_heights_offset[e];
-    long long ep_len = P.ep_len[e];
     TreeRegs G;
     TreeChain CH;
     CH.first = T.first[c]; CH.last = T.last[c]; CH.hangp = 0; CH.hcmask = 0u;
@@ -661,8 +685,12 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
         tree_joint_phase<false>(P, T, wsw, ei, c, o, (float)deci < delay, P.last_dof_vel + e);
         tree_outward<false>(P, T, wsw, ei, c, o, E, R0, CH, nstep, G);
-        TT(0);
-        tree_contacts<HF>(P, T, wsw, ei, c, o, E, R0);
+        {
+            const TreeContactPre pre0 = tree_contact_probe<HF>(P, T, wsw, ei, c, o, E, R0, 0);   // (the terrain gathers fly behind the bias forces)
+            tree_bias_all(T, wsw, ei, c);
+            TT(0);
+            tree_contacts<HF>(P, T, wsw, ei, c, o, E, R0, pre0);
+        }
         TT(1);
         // base: rigid lump (randomised per env); the terrain wrench on its own shapes was left in o.misc by the contact pass
         S3 Ab; V3 h0;
@@ -720,6 +748,16 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     const long long tt_phys = clock64() - tt_begin;
     if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 8] = tt_phys;
 #endif
+    // ---- what only the env pipeline behind the sub-steps reads is requested HERE (round 6: loaded at the kernel's start, these ~17 values sat in
+    // registers through all ten sub-steps of a kernel that needs every one of its 512); the final-frames walk below hides the latency
+    EnvAux ea;
+    ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[N + e]; ea.cmd[2] = P.commands[2 * N + e];
+    ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[N + e]; ea.origin[2] = P.origins[2 * N + e];
+    ea.level = P.levels[e]; ea.type = P.types[e];
+    float air_time[2] = {P.air_time[e], P.air_time[N + e]}, land_time[2] = {P.land_time[e], P.land_time[N + e]};
+    bool contact_last[2] = {P.feet_contact[e] != 0, P.feet_contact[N + e] != 0};
+    const float bho_stale = P.base_heights_offset[e];
+    long long ep_len = P.ep_len[e];
     // ---- refresh_rigid_body_state_tensor after the last sub-step: frames of the final state
     {
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
