@@ -28,6 +28,8 @@ for terrain in ("plane", "heightfield"):
     for n, v in zip(names, med[:8]): print(f"   {n:16s} {v:9.0f}  ({v / 10:7.0f} per sub-step)")
     m2 = np.median(full[:, 8:14], axis=0)
     print("   behind the sub-steps (cycles since the kernel's start): physics done", int(m2[0]), "final frames / link frames / feet done", int(m2[2]), "state update + height scan done", int(m2[3]), "rewards done", int(m2[4]), "reset done", int(m2[5]), "end", int(m2[1]))
-    m3 = np.median(full[:, 14:17], axis=0)
-    print("   inside the rewards: per-joint sums done", int(m3[0]), "group sums done", int(m3[1]), "terms done", int(m3[2]))
+    m4 = np.median(full[:, 20:24], axis=0)
+    print("   inside 'outward': joint-local phase", int(m4[0] / 10), "walk", int(m4[1] / 10), "contact probe", int(m4[2] / 10), "(the rest: bias forces of all bodies);  inside 'inward': rigid inertias of all bodies", int(m4[3] / 10), " [cycles per sub-step]")
+    m3 = np.median(full[:, 14:18], axis=0)
+    print("   inside the rewards: per-joint sums done", int(m3[0]), "group sums done", int(m3[1]), "terms done", int(m3[2]), "scaled and summed", int(m3[3]))
     s.close()

@@ -79,30 +79,63 @@ GRX_DEV void tree_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"
 // clipped motor torque in T_TAU.  q, qd come from two slots of the row (the rotation's, dead between the acceleration pass, which leaves the
 // integrated state there, and this phase).
 enum { T_Q = T_R + 2, T_QD = T_R + 3 };
+// The loop takes TWO rounds of the group's lanes per iteration, their LDS operands requested together and without a branch in between (a lane
+// past the last body works on the last body again and drops the result): one LDS round trip per pair of rounds instead of three per round.
+#define TREE_BODY_ROUNDS2(b0_, ok0_, b1_, ok1_) \
+    for (int r2_ = 1 + c; r2_ < T.nb; r2_ += 2 * TG) \
+        if (const int b0_ = r2_, b1_ = min(r2_ + TG, T.nb - 1); true) \
+            if (const bool ok0_ = true, ok1_ = r2_ + TG < T.nb; true)
+struct TreeJointIn { float q, qd, ax, ay, az, r0[9], kp, kd, q0, effort, act, str; };
+template <bool KIN>
+GRX_DEV TreeJointIn tree_joint_fetch(const TreeTab& T, const float* wsw, int ei, const TreeOff& o, int b, bool use_last) {
+    TreeJointIn x;
+    const TreeBody& tb = T.body[b];
+    const int j = b - 1, wb = TBO(b);
+    x.q = TW(wb + T_Q); x.qd = TW(wb + T_QD);
+    x.ax = tb.axis[0]; x.ay = tb.axis[1]; x.az = tb.axis[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) x.r0[k] = tb.rot0[k];
+    x.kp = 0.f; x.kd = 0.f; x.q0 = 0.f; x.effort = 0.f; x.act = 0.f; x.str = 0.f;
+    if (!KIN) {
+        const TreeDof& td = T.dof[j];
+        x.kp = td.kp; x.kd = td.kd; x.q0 = td.q0; x.effort = td.effort;
+        x.act = TW(o.dof + (use_last ? TD_ALAST : TD_ACUR) * GRX_MAX_DOFS + j);
+        x.str = TW(o.dof + TD_STR * GRX_MAX_DOFS + j);   // motor strength of this env (domain randomisation)
+    }
+    return x;
+}
+template <bool KIN>
+GRX_DEV void tree_joint_one(KP P, float* wsw, int ei, int b, bool ok, const TreeJointIn& x, const float* qd_last_e) {
+    const int wb = TBO(b);
+    float sn, cs;
+    grx_sincos(x.q, sn, cs);
+    const float ax = x.ax, ay = x.ay, az = x.az, oc = 1.f - cs;
+    const V3 qx = v3(cs + ax * ax * oc, az * sn + ax * ay * oc, -ay * sn + ax * az * oc);
+    const V3 qy = v3(-az * sn + ax * ay * oc, cs + ay * ay * oc, ax * sn + ay * az * oc);
+    const V3 qz = v3(ay * sn + ax * az * oc, -ax * sn + ay * az * oc, cs + az * az * oc);
+    // rot0 * Rot(axis, q), unconditionally (only the shoulders of the GR1 carry a rotated joint frame; the product with the unit matrix is
+    // exact, and the branch on a table word it replaces was a dependent LDS round trip)
+    R3 J;
+    J.cx = v3(x.r0[0], x.r0[3], x.r0[6]); J.cy = v3(x.r0[1], x.r0[4], x.r0[7]); J.cz = v3(x.r0[2], x.r0[5], x.r0[8]);
+    const V3 lx = rot(J, qx), ly = rot(J, qy), lz = rot(J, qz);
+    float tq = 0.f;
+    if (!KIN) {   // _compute_torques (legged_robot.py:679-715): the 'P' law spelled out, the other control types (one with a global read) behind a uniform branch
+        float t = x.kp * (x.act * P.action_scale + x.q0 - x.q) - x.kd * x.qd;
+        if (P.control_type != GRX_CONTROL_P) t = control_torque(P, x.kp, x.kd, x.q0, x.act, x.q, x.qd, qd_last_e + (size_t)(b - 1) * (size_t)P.N);
+        t *= x.str;
+        tq = fminf(fmaxf(t, -x.effort), x.effort);
+    }
+    if (ok) {
+        tw_put(wsw, ei, wb + T_R, lx); tw_put(wsw, ei, wb + T_R + 3, ly); tw_put(wsw, ei, wb + T_R + 6, lz);
+        if (!KIN) TW(wb + T_TAU) = tq;
+    }
+}
 template <bool KIN>
 GRX_DEV void tree_joint_phase(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, bool use_last, const float* qd_last_e) {
-    for (int b = 1 + c; b < T.nb; b += TG) {
-        const TreeBody& tb = T.body[b];
-        const int j = b - 1, wb = TBO(b);
-        const float qj = TW(wb + T_Q), qdj = TW(wb + T_QD);
-        float sn, cs;
-        grx_sincos(qj, sn, cs);
-        const float ax = tb.axis[0], ay = tb.axis[1], az = tb.axis[2], oc = 1.f - cs;
-        const V3 qx = v3(cs + ax * ax * oc, az * sn + ax * ay * oc, -ay * sn + ax * az * oc);
-        const V3 qy = v3(-az * sn + ax * ay * oc, cs + ay * ay * oc, ax * sn + ay * az * oc);
-        const V3 qz = v3(ay * sn + ax * az * oc, -ax * sn + ay * az * oc, cs + az * az * oc);
-        // rot0 * Rot(axis, q), unconditionally (only the shoulders of the GR1 carry a rotated joint frame; the product with the unit matrix is
-        // exact, and the branch on a table word it replaces was a dependent LDS round trip)
-        R3 J;
-        J.cx = v3(tb.rot0[0], tb.rot0[3], tb.rot0[6]); J.cy = v3(tb.rot0[1], tb.rot0[4], tb.rot0[7]); J.cz = v3(tb.rot0[2], tb.rot0[5], tb.rot0[8]);
-        tw_put(wsw, ei, wb + T_R, rot(J, qx)); tw_put(wsw, ei, wb + T_R + 3, rot(J, qy)); tw_put(wsw, ei, wb + T_R + 6, rot(J, qz));
-        if (!KIN) {   // _compute_torques (legged_robot.py:679-715)
-            const TreeDof& td = T.dof[j];
-            const float act_ = TW(o.dof + (use_last ? TD_ALAST : TD_ACUR) * GRX_MAX_DOFS + j);
-            float t = control_torque(P, td.kp, td.kd, td.q0, act_, qj, qdj, qd_last_e + (size_t)j * (size_t)P.N);
-            t *= TW(o.dof + TD_STR * GRX_MAX_DOFS + j);   // motor strength of this env (domain randomisation)
-            TW(wb + T_TAU) = fminf(fmaxf(t, -td.effort), td.effort);
-        }
+    TREE_BODY_ROUNDS2(b0, ok0, b1, ok1) {
+        const TreeJointIn x0 = tree_joint_fetch<KIN>(T, wsw, ei, o, b0, use_last), x1 = tree_joint_fetch<KIN>(T, wsw, ei, o, b1, use_last);
+        tree_joint_one<KIN>(P, wsw, ei, b0, ok0, x0, qd_last_e);
+        tree_joint_one<KIN>(P, wsw, ei, b1, ok1, x1, qd_last_e);
     }
     tree_fence();
 }
@@ -256,7 +289,7 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
 }
 // rigid-body bias forces p_k + I_k zeta_k of every body, from the frames and the zeta the walk left in LDS (contacts and self-collision add into these)
 GRX_DEV void tree_bias_all(const TreeTab& T, float* wsw, int ei, int c) {
-    for (int b = 1 + c; b < T.nb; b += TG) {
+    for (int b = 1 + c; b < T.nb; b += TG) {   // (two rounds per iteration as in tree_joint_phase: measured, not faster -- this loop is bound by its arithmetic)
         const TreeBody& tb = T.body[b];
         const int wb = TBO(b);
         const R3 R = tw_R(wsw, ei, wb + T_R);
@@ -666,7 +699,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     V3 avg_speed[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
     V3 avg_rpy[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};   // avg_feet_speed_rpy (legged_robot_fftai.py:81, 88)
 #ifdef GRX_PROFILE_SECTIONS
-    long long tt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tt_prev = clock64();
+    long long tt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tt_prev = clock64();   // (8..: finer stamps inside the passes, slots 20.. of the block's row)
     const long long tt_begin = tt_prev;
 #define TT(i) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); tt_acc[i] += t_ - tt_prev; tt_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -684,9 +717,12 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         tree_fence();
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
         tree_joint_phase<false>(P, T, wsw, ei, c, o, (float)deci < delay, P.last_dof_vel + e);
+        TT(8);
         tree_outward<false>(P, T, wsw, ei, c, o, E, R0, CH, nstep, G);
+        TT(9);
         {
             const TreeContactPre pre0 = tree_contact_probe<HF>(P, T, wsw, ei, c, o, E, R0, 0);   // (the terrain gathers fly behind the bias forces)
+            TT(10);
             tree_bias_all(T, wsw, ei, c);
             TT(0);
             tree_contacts<HF>(P, T, wsw, ei, c, o, E, R0, pre0);
@@ -703,6 +739,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         if (P.self_collisions) tree_self_collision(P, T, wsw, ei, c, o, E, R0, pa0, pl0);
         TT(3);
         tree_rigid_inertias(T, wsw, ei, c);
+        TT(11);
         tree_inward(P, T, wsw, ei, c, o, CH, nstep, G);
         TT(4);
         // ---- base: the chains that hang from it, in table order; [A B; B^T D][alpha; acc] = -[pa; pl]
@@ -758,6 +795,11 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     bool contact_last[2] = {P.feet_contact[e] != 0, P.feet_contact[N + e] != 0};
     const float bho_stale = P.base_heights_offset[e];
     long long ep_len = P.ep_len[e];
+    // (the running episode sums too, AHEAD of the kernel's first global stores: vmcnt counts loads and stores in one order, so a load requested
+    //  behind the contact_forces / height rows waits for those stores to be acknowledged by memory -- 12 k cycles of this section, measured)
+    float es_old[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) es_old[t] = (P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
     // ---- refresh_rigid_body_state_tensor after the last sub-step: frames of the final state
     {
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
@@ -921,11 +963,8 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     // ---- compute_reward (legged_robot.py:355-375; terms legged_robot_fftai.py:180-352, gr1t1.py:338-589): a lane sums over
     // its chain's joints, the group adds up
     float r[NT];
-    // the running episode sums: requested HERE, in one batch, so that their memory latency passes behind the reward arithmetic (read inside the
-    // loop that folds them, behind its wave-uniform branches, each of the 36 loads was an exposed round trip: 27 k cycles, gpu_tree_sections.py)
-    float es_old[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) es_old[t] = (P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
+    // (the running episode sums were requested in one batch behind the sub-steps: read inside the loop that folds them, behind its wave-uniform
+    //  branches, each of the 36 loads was an exposed round trip: 27 k cycles, gpu_tree_sections.py)
     // The joint terms go round the group's lanes BY JOINT (two rounds of 16 lanes, four of 8) instead of riding on the ten depth levels of
     // the lane's chain (a wave executes all ten whatever its lanes hold): the chains' owners publish q, qd in two slots of the body's row
     // that are dead behind the sub-steps.
@@ -1056,6 +1095,9 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         rew += rt;
     }
     // episode sums (the group's first lane); finished episodes -> the block's statistics row (deterministic lane order)
+#ifdef GRX_PROFILE_SECTIONS
+    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 17] = clock64() - tt_begin;
+#endif
     const unsigned long long reset_mask = __ballot(reset && actl);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1275,7 +1317,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
 #ifdef GRX_PROFILE_SECTIONS
     if (threadIdx.x == 0 && blockIdx.x < 64) {   // sections summed over the sub-steps: outward, contacts, base, self-collision, inward, base solve, accel, rest; [8] physics, [9] whole kernel
         long long* pr = P.prof + (size_t)blockIdx.x * GRX_PROF_SLOTS;
-        for (int i = 0; i < 8; ++i) pr[i] = tt_acc[i];
+        for (int i = 0; i < 8; ++i) { pr[i] = tt_acc[i]; pr[20 + i] = tt_acc[8 + i]; }
         pr[9] = clock64() - tt_begin;
     }
 #endif
