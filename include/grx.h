@@ -477,7 +477,8 @@ typedef struct grx_pipeline_state {
 /* Run post_physics_step (everything after the sub-step loop: state update, timers, termination, rewards, reset,
  * observations, history) of ALL envs on `states` (HOST array, num_envs entries).  args->actions is ignored (the
  * injected actions are used), args->common_step_counter and args->noise_uniform are honoured.  apply_reset == 0:
- * resets are reported in GRX_T_RESET but not applied.  Lower-limb (fused-kernel) models only. */
+ * resets are reported in GRX_T_RESET but not applied.  Any model the fused kernels or the tree kernel run (round 6: the
+ * 32-DOF full body too -- its torso / forehead orientations come from the kernel's own walk over the injected joint positions). */
 int grx_debug_post_physics(grx_handle h, const grx_pipeline_state* states, int apply_reset, const grx_step_args* args, void* stream);
 
 /* TEST-ONLY: the step kernels' PHYSICS terrain query -- height and gradient (dh/dx, dh/dy) of the contact surface under n points: xy HOST

@@ -273,3 +273,31 @@ def test_pipeline_on_the_rough_raster_on_the_hip_kernel(layout, monkeypatch):
     sim, cfg, meta, _ = make_hip_on_reference_raster(64, layout, monkeypatch)
     og.check_pipeline_rough(sim, cfg, meta, 1e-4)
     sim.close()
+
+
+# ---- round 6 (VERDICT r5 #4b): reference-generated fixtures of the robots beyond the 10-DOF GR1T1 -- the GR1T2 lower limb (20-body termination
+# set incl. imu_link) on the fused kernels it runs on, and the 32-DOF full body (the reference's GR1T1 class fed the full-body names: 105 / 234
+# observation columns, 32-joint reward sums, its own joint index sets) on the tree kernels BASELINE.json's config 5 runs
+@pytest.mark.parametrize("layout", [1, 8, "quad"])
+def test_gr1t2_pipeline_fixture_on_the_hip_kernel(layout, monkeypatch):
+    pick_layout(monkeypatch, layout)
+    from wiki_grx_gym_amd.sim import HipSim
+    cfg, c, keep, meta = og.make_other_robot("gr1t2", 64)
+    sim = HipSim(c, "cuda:0", keep)
+    name, lpe, waves = KERNEL_OF[layout]
+    lay = sim.layout()
+    assert lay["kernel"].startswith(name) and lay["lanes_per_env"] == lpe and lay["waves_per_block"] == waves, lay
+    og.check_pipeline_other_robot(sim, cfg, meta, 1e-4, "gr1t2")
+
+
+@pytest.mark.parametrize("group", [8, 16])
+def test_full_body_pipeline_fixture_on_the_tree_kernel(group, monkeypatch):
+    monkeypatch.delenv("GRX_FORCE_GENERIC", raising=False)
+    monkeypatch.setenv("GRX_TREE", "1")
+    monkeypatch.setenv("GRX_TREE_G", str(group))
+    from wiki_grx_gym_amd.sim import HipSim
+    cfg, c, keep, meta = og.make_other_robot("full_body", 64)
+    sim = HipSim(c, "cuda:0", keep)
+    lay = sim.layout()
+    assert lay["kernel"].startswith("grx_step_tree16<" if group == 16 else "grx_step_tree<") and lay["lanes_per_env"] == group, lay
+    og.check_pipeline_other_robot(sim, cfg, meta, 1e-4, "full_body")

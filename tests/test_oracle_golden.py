@@ -498,3 +498,71 @@ def test_pipeline_on_the_rough_raster(precision, tol):
     cfg = rough_cfg()
     c, keep, meta = build_config.build(cfg, cfg.sim.dt, 64, terrain=ter)
     check_pipeline_rough(OracleSim(c, precision, keep), cfg, meta, tol)
+
+
+# ---- the robots the round 1-5 fixtures did not cover: GR1T2 (20-body termination set) and the 32-DOF full body (VERDICT r5 #4b) ----
+OTHER_ROBOTS = {"gr1t2": ("pipeline_gr1t2.npz", "GR1T2", 10), "full_body": ("pipeline_full_body.npz", "GR1T1Full", 32)}
+
+
+def check_pipeline_other_robot(sim, cfg, meta, tol, which):
+    """tests/golden/pipeline_gr1t2.npz / pipeline_full_body.npz (tools/gen_golden.py gen_pipeline_other_robots): one post_physics_step() of
+    the reference's GR1T2 class with GR1T2LowerLimbCfg, and of its GR1T1 class on the 32-DOF full body with the build's task values
+    (gr1t1.py:18-113 index sets, 281-336 observation columns: 105 / 234; legged_robot.py:336-353 termination) against `sim` (oracle or HIP)."""
+    fixture, _, nd = OTHER_ROBOTS[which]
+    d = np.load(os.path.join(G, fixture))
+    N = d["in_root"].shape[0]
+    assert d["in_dof_pos"].shape == (N, nd) and d["out_obs"].shape == (N, 9 + 3 * nd) and d["out_pri_obs"].shape == (N, 9 + 3 * nd + 129)
+    names = list(d["reward_names"])
+    assert names == meta["active_terms"], "active reward terms / their (alphabetical) order differ from the reference"
+    term_idx = [_capi.REWARD_TERMS.index(n) for n in names]
+    inject(sim, states_from(d, "in_", N), common_step_counter=1, noise_uniform=torch.tensor(d["noise_u"]).contiguous())
+    keep = ~np.any(d["out_commands_after"] != d["in_commands"], axis=1)   # rows whose commands the reference redrew (its RNG)
+    assert keep.sum() >= N - 4
+
+    def close(name, got, want, rows=keep):
+        got, want = np.asarray(got, dtype=np.float64)[rows], np.asarray(want, dtype=np.float64)[rows]
+        err = np.abs(got - want)
+        assert (err <= tol + tol * np.abs(want)).all(), f"{which} {name}: max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    allrows = np.ones(N, bool)
+    np.testing.assert_array_equal(T_(sim, "RESET").numpy().astype(bool), d["out_reset"].astype(bool))
+    np.testing.assert_array_equal(T_(sim, "TIME_OUT").numpy().astype(bool), d["out_time_out"].astype(bool))
+    np.testing.assert_array_equal(T_(sim, "FEET_CONTACT").numpy().astype(bool), d["out_feet_contact"].astype(bool))
+    np.testing.assert_array_equal(T_(sim, "EPISODE_LENGTH").numpy(), d["out_episode_length_after"])
+    close("base_lin_vel", T_(sim, "BASE_LIN_VEL"), d["out_base_lin_vel"], allrows)
+    close("base_ang_vel", T_(sim, "BASE_ANG_VEL"), d["out_base_ang_vel"], allrows)
+    close("projected_gravity", T_(sim, "PROJECTED_GRAVITY"), d["out_projected_gravity"], allrows)
+    close("air_time", T_(sim, "FEET_AIR_TIME"), d["out_air_time_after"], allrows)
+    close("land_time", T_(sim, "FEET_LAND_TIME"), d["out_land_time_after"], allrows)
+    close("feet_height", T_(sim, "FEET_HEIGHT"), d["out_feet_height"], allrows)
+    close("last_actions", T_(sim, "LAST_ACTIONS"), d["out_last_actions_after"], allrows)
+    dt = cfg.control.decimation * cfg.sim.dt
+    terms = T_(sim, "REWARD_TERMS").numpy()[term_idx]                      # every active term on its own, scaled
+    want_terms = d["out_term_values"] * np.array([getattr(cfg.rewards.scales, n) * dt for n in names])[:, None]
+    for k, n in enumerate(names):
+        if n != "termination":
+            close("term " + n, terms[k], want_terms[k])
+    close("rew", T_(sim, "REW"), d["out_rew"])
+    close("obs", T_(sim, "OBS"), d["out_obs"])
+    close("pri_obs", T_(sim, "PRI_OBS"), d["out_pri_obs"])
+    close("episode_sums", T_(sim, "EPISODE_SUMS").numpy()[term_idx].T, d["out_episode_sums"].T)
+    np.testing.assert_allclose(np.array([getattr(cfg.rewards.scales, n) * meta["dt"] for n in names]), d["reward_scales_dt"], rtol=1e-6)
+    # the rows the fixture was built for: eight different terminating bodies reset, a body outside the set does not; GR1T2: imu_link does
+    assert d["out_reset"][16:24].all() and not d["out_reset"][24] and d["in_term_contact"][16:24].all() and not d["in_term_contact"][24]
+    if which == "gr1t2":
+        assert "imu_link" in list(d["termination_bodies"]) and len(d["termination_bodies"]) == 20 and d["out_reset"][25] and d["in_term_contact"][25]
+
+
+def make_other_robot(which, N, precision=None, noise=True):
+    cfg = make_cfg(OTHER_ROBOTS[which][1], noise=noise, dr=False)
+    c, keep, meta = build_config.build(cfg, cfg.sim.dt, N)
+    if precision is None:
+        return cfg, c, keep, meta
+    from oracle.binding import OracleSim
+    return OracleSim(c, precision, keep), cfg, meta
+
+
+@pytest.mark.parametrize("which", sorted(OTHER_ROBOTS))
+@pytest.mark.parametrize("precision,tol", [("f64", 2e-6), ("f32", 1e-4)])
+def test_pipeline_of_the_other_robots(which, precision, tol):
+    sim, cfg, meta = make_other_robot(which, 64, precision)
+    check_pipeline_other_robot(sim, cfg, meta, tol, which)

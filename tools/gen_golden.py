@@ -60,20 +60,65 @@ def install_stub():
     import legged_gym.envs  # noqa: F401  -- must precede legged_gym.utils (circular import, task_registry.py:42)
 
 
-def make_ref_env(N, seed, terrain_obj=None):
-    """A reference GR1T1 instance without Isaac Gym: attributes set by hand on a bare object."""
+def build_full_body_cfg():
+    """The BUILD's 32-DOF task configuration (wiki-grx-gym_amd/envs/config.py GR1T1FullBodyCfg: the reference ships no runnable full-body
+    task) laid over the REFERENCE's own full-body config object (gr1t1_config.py GR1T1Cfg): every value the reference's
+    post_physics_step reads -- reward scales and sigmas, thresholds, observation scales, noise, commands, default joint angles -- is the
+    build's; every formula, index set and column layout that consumes it is the reference's."""
+    from legged_gym.envs.gr1t1.gr1t1_config import GR1T1Cfg
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    from wiki_grx_gym_amd.envs.config import GR1T1FullBodyCfg as B
+    cfg = GR1T1Cfg()
+
+    def values(sec):
+        return {k: getattr(sec, k) for k in dir(sec) if not k.startswith("_") and not isinstance(getattr(sec, k), type) and not callable(getattr(sec, k))}
+    for name in ("env", "rewards", "normalization", "noise", "commands", "init_state", "control", "terrain", "domain_rand"):
+        ref_sec, my_sec = getattr(cfg, name), getattr(B, name)
+        for k, v in values(my_sec).items():
+            setattr(ref_sec, k, v)
+        for sub in [k for k in dir(my_sec) if not k.startswith("_") and isinstance(getattr(my_sec, k), type)]:
+            ref_sub = getattr(ref_sec, sub)
+            if sub == "scales" and name == "rewards":   # a scale the build does not list is off
+                for k in values(ref_sub):
+                    setattr(ref_sub, k, 0.0)
+            for k, v in values(getattr(my_sec, sub)).items():
+                setattr(ref_sub, k, v)
+    cfg.asset.terminate_after_contacts_on = list(B.asset.terminate_after_contacts_on)
+    cfg.asset.penalize_contacts_on = list(B.asset.penalize_contacts_on)
+    return cfg
+
+
+ROBOTS = {   # model table, reference class, reference config, dofs
+    "gr1t1_lower_limb": ("gr1t1_lower_limb", "GR1T1", "legged_gym.envs.gr1t1.gr1t1_lower_limb_config:GR1T1LowerLimbCfg", 10),
+    "gr1t2_lower_limb": ("gr1t2_lower_limb", "GR1T2", "legged_gym.envs.gr1t2.gr1t2_lower_limb_config:GR1T2LowerLimbCfg", 10),
+    "gr1t1": ("gr1t1", "GR1T1", None, 32),
+}
+
+
+def make_ref_env(N, seed, terrain_obj=None, robot="gr1t1_lower_limb"):
+    """A reference GR1T1 / GR1T2 instance without Isaac Gym: attributes set by hand on a bare object.  robot = "gr1t1": the reference's
+    GR1T1 class -- it is DOF-count agnostic (gr1t1.py:281-313 emits 3 + 3 + 3 + 3 nd columns, the reward sums run over num_dof) -- on the
+    32-DOF full body: body / dof names of GR1T1.urdf, the index sets of gr1t1.py:18-113 / 137-279 drawn from them by the reference's own code."""
     import legged_gym.envs as E  # noqa: F401  (must be imported before legged_gym.utils)
-    from legged_gym.envs import GR1T1
-    from legged_gym.envs.gr1t1.gr1t1_lower_limb_config import GR1T1LowerLimbCfg
+    import legged_gym.envs as envs_mod
     from isaacgym.torch_utils import quat_rotate_inverse
+    model_key, cls_name, cfg_path, nd = ROBOTS[robot]
     torch.manual_seed(seed)
     g = torch.Generator().manual_seed(seed)
-    cfg = GR1T1LowerLimbCfg()
-    env = object.__new__(GR1T1)
+    if cfg_path is None:
+        cfg = build_full_body_cfg()
+    else:
+        mod, cname = cfg_path.split(":")
+        cfg = getattr(importlib.import_module(mod), cname)()
+    nobs, npri = 9 + 3 * nd, 9 + 3 * nd + 3 + 1 + 2 + 2 + 121
+    assert (cfg.env.num_obs, cfg.env.num_pri_obs, cfg.env.num_actions) == (nobs, npri, nd), (cfg.env.num_obs, cfg.env.num_pri_obs, cfg.env.num_actions)
+    env = object.__new__(getattr(envs_mod, cls_name))
     env.cfg = cfg
     env.device = "cpu"
-    env.num_envs, env.num_obs, env.num_pri_obs, env.num_actions = N, 39, 168, 10
-    env.num_dof = env.num_dofs = 10
+    env.num_envs, env.num_obs, env.num_pri_obs, env.num_actions = N, nobs, npri, nd
+    env.num_dof = env.num_dofs = nd
     env.gym = MagicMock()
     env.sim = MagicMock()
     env.viewer = None
@@ -84,8 +129,8 @@ def make_ref_env(N, seed, terrain_obj=None):
     env.height_samples = None
     env.debug_viz = False
     env._parse_cfg()
-    nb = 37
-    names = json.load(open(os.path.join(os.path.dirname(OUT), "..", "wiki-grx-gym_amd", "assets", "gr1t1_lower_limb.model.json")))
+    names = json.load(open(os.path.join(os.path.dirname(OUT), "..", "wiki-grx-gym_amd", "assets", model_key + ".model.json")))
+    nb = len(names["body_names"])
     body_names, dof_names = names["body_names"], names["dof_names"]
     env.dof_names = dof_names
     idx = lambda sub: torch.tensor([i for i, n in enumerate(body_names) if sub in n], dtype=torch.long)
@@ -98,8 +143,8 @@ def make_ref_env(N, seed, terrain_obj=None):
     env.termination_contact_indices = torch.tensor(term, dtype=torch.long)
     env.penalised_contact_indices = torch.zeros(0, dtype=torch.long)
     # buffers (BaseTask.__init__ / _init_buffers)
-    env.obs_buf = torch.zeros(N, 39)
-    env.pri_obs_buf = torch.zeros(N, 168)
+    env.obs_buf = torch.zeros(N, nobs)
+    env.pri_obs_buf = torch.zeros(N, npri)
     env.rew_buf = torch.zeros(N)
     env.reset_buf = torch.ones(N, dtype=torch.long)
     env.episode_length_buf = torch.zeros(N, dtype=torch.long)
@@ -108,11 +153,11 @@ def make_ref_env(N, seed, terrain_obj=None):
     env.common_step_counter = 0
     env.root_states = torch.zeros(N, 13)
     env.root_states[:, 6] = 1
-    env.dof_state = torch.zeros(N * 10, 2)
-    env.dof_pos = env.dof_state.view(N, 10, 2)[..., 0]
-    env.dof_vel = env.dof_state.view(N, 10, 2)[..., 1]
-    env.dof_acc = torch.zeros(N, 10)
-    env.dof_pos_offset = torch.zeros(N, 10)
+    env.dof_state = torch.zeros(N * nd, 2)
+    env.dof_pos = env.dof_state.view(N, nd, 2)[..., 0]
+    env.dof_vel = env.dof_state.view(N, nd, 2)[..., 1]
+    env.dof_acc = torch.zeros(N, nd)
+    env.dof_pos_offset = torch.zeros(N, nd)
     env.base_pos = env.root_states[:, 0:3]
     env.base_quat = env.root_states[:, 3:7]
     env.contact_forces = torch.zeros(N, nb, 3)
@@ -120,10 +165,10 @@ def make_ref_env(N, seed, terrain_obj=None):
     env.rigid_body_states[:, :, 6] = 1
     env.gravity_vec = torch.tensor([0., 0., -1.]).repeat(N, 1)
     env.forward_vec = torch.tensor([1., 0., 0.]).repeat(N, 1)
-    env.torques = torch.zeros(N, 10)
-    env.p_gains = torch.zeros(10)
-    env.d_gains = torch.zeros(10)
-    env.default_dof_pos = torch.zeros(10)
+    env.torques = torch.zeros(N, nd)
+    env.p_gains = torch.zeros(nd)
+    env.d_gains = torch.zeros(nd)
+    env.default_dof_pos = torch.zeros(nd)
     for i, name in enumerate(dof_names):
         env.default_dof_pos[i] = cfg.init_state.default_joint_angles[name]
         for k in cfg.control.stiffness:
@@ -131,11 +176,11 @@ def make_ref_env(N, seed, terrain_obj=None):
                 env.p_gains[i] = cfg.control.stiffness[k]
                 env.d_gains[i] = cfg.control.damping[k]
     env.default_dof_pos = env.default_dof_pos.unsqueeze(0)
-    env.default_dof_pos_tenors = torch.ones(N, 10) * env.default_dof_pos
-    env.last_dof_vel = torch.zeros(N, 10)
-    env.actions = torch.zeros(N, 10)
-    env.last_actions = torch.zeros(N, 10)
-    env.last_last_actions = torch.zeros(N, 10)
+    env.default_dof_pos_tenors = torch.ones(N, nd) * env.default_dof_pos
+    env.last_dof_vel = torch.zeros(N, nd)
+    env.actions = torch.zeros(N, nd)
+    env.last_actions = torch.zeros(N, nd)
+    env.last_last_actions = torch.zeros(N, nd)
     env.commands = torch.zeros(N, 3)
     env.commands_heading = torch.zeros(N)
     env.commands_scale = torch.ones(N, 3)
@@ -150,12 +195,12 @@ def make_ref_env(N, seed, terrain_obj=None):
     env.avg_feet_speed_rpy = torch.zeros(N, 2, 3)
     for nm in ("feet_contact", "feet_contact_last", "feet_contact_filt"):
         setattr(env, nm, torch.zeros(N, 2, dtype=torch.bool))
-    env.motor_strength_scales = torch.ones(N, 10)
+    env.motor_strength_scales = torch.ones(N, nd)
     # URDF limits (legged_robot.py:582-616)
     links = {l["joint_name"]: l for l in names["links"] if l["joint_name"]}
-    env.dof_pos_limits = torch.zeros(10, 2)
-    env.dof_vel_limits = torch.zeros(10)
-    env.torque_limits = torch.zeros(10)
+    env.dof_pos_limits = torch.zeros(nd, 2)
+    env.dof_vel_limits = torch.zeros(nd)
+    env.torque_limits = torch.zeros(nd)
     for i, dn in enumerate(dof_names):
         lim = links[dn]["limit"]
         env.dof_pos_limits[i, 0], env.dof_pos_limits[i, 1] = lim["lower"], lim["upper"]
@@ -266,16 +311,17 @@ def randomize_state(env, g, body_names, N, step):
     """Synthetic post-physics state incl. edge rows (thresholds, timers at zero, near limits)."""
     feet = env.feet_indices
     torso = int(env.torso_indices[0])
+    nd = env.num_dof
     env.root_states[:, 0:2] = (torch.rand(N, 2, generator=g) - 0.5) * 4
     env.root_states[:, 2] = 0.6 + 0.5 * torch.rand(N, generator=g)
     env.root_states[:, 3:7] = rand_quat(N, g, tilt=0.5)
     env.root_states[:, 7:13] = torch.randn(N, 6, generator=g)
-    env.dof_pos[:] = env.default_dof_pos + (torch.rand(N, 10, generator=g) - 0.5) * 1.5
-    env.dof_vel[:] = torch.randn(N, 10, generator=g) * 8
+    env.dof_pos[:] = env.default_dof_pos + (torch.rand(N, nd, generator=g) - 0.5) * 1.5
+    env.dof_vel[:] = torch.randn(N, nd, generator=g) * 8
     env.dof_vel[::7] *= 4                                   # some rows beyond the soft velocity limit
-    env.torques = torch.randn(N, 10, generator=g) * 40
+    env.torques = torch.randn(N, nd, generator=g) * 40
     env.torques[::5] *= 3                                   # some rows beyond the soft torque limit
-    env.actions = env.clip_actions(torch.randn(N, 10, generator=g))
+    env.actions = env.clip_actions(torch.randn(N, nd, generator=g))
     env.commands[:] = (torch.rand(N, 3, generator=g) * 2 - 1) * torch.tensor([1.0, 0.5, 1.0])
     env.commands[::4, :2] = 0.0                             # standing commands
     env.contact_forces[:] = 0
@@ -298,9 +344,9 @@ def randomize_state(env, g, body_names, N, step):
         env.episode_length_buf[5] = 499                     # resample-by-time row
         env.episode_length_buf[6] = 999                     # becomes 1000: not yet a time-out
         env.episode_length_buf[7] = 1000                    # becomes 1001: time-out
-        env.last_actions = torch.randn(N, 10, generator=g) * 0.5
-        env.last_last_actions = torch.randn(N, 10, generator=g) * 0.5
-        env.last_dof_vel = torch.randn(N, 10, generator=g) * 8
+        env.last_actions = torch.randn(N, nd, generator=g) * 0.5
+        env.last_last_actions = torch.randn(N, nd, generator=g) * 0.5
+        env.last_dof_vel = torch.randn(N, nd, generator=g) * 8
         env.base_heights_offset = (torch.rand(N, generator=g) - 0.5) * 2   # stale value used by the reward (Q4)
     # termination rows
     tilt = rand_quat(N, g, tilt=0.0)
@@ -442,6 +488,90 @@ def gen_pipeline_rough(out):
     data["reward_names"] = np.array(env.reward_names)
     data["redraws"] = redraws
     np.savez_compressed(os.path.join(out, "pipeline_rough.npz"), **data)
+
+
+def gen_pipeline_other_robots(out):
+    """One reference post_physics_step() for the robots the round 1-5 fixtures did not cover (VERDICT r5 #4b):
+      pipeline_gr1t2.npz      the reference's GR1T2 class with GR1T2LowerLimbCfg and the body names of GR1T2_lower_limb.urdf: its 20-body
+                              termination set (terminate_after_contacts_on, 'imu' matches imu_link) decides the injected contact rows;
+      pipeline_full_body.npz  the reference's GR1T1 class on the 32-DOF GR1T1.urdf (build_full_body_cfg): obs 105 / pri_obs 234 columns,
+                              32-joint reward sums, the joint index sets the reference draws from the full-body dof names (gr1t1.py:137-279:
+                              hip_roll, hip_yaw, knee, ankle ...).  The torso link's orientation in rigid_body_states is the forward
+                              kinematics of (root, dof_pos) -- in the full body the torso hangs from the three waist joints -- computed in
+                              fp64 from the model table (tests/kinematics_ref.py), as PhysX would report it.
+    Same record layout as pipeline_rough.npz (in_* / out_*), resets recorded but not applied."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    for robot, fname, seed in (("gr1t2_lower_limb", "pipeline_gr1t2.npz", 41), ("gr1t1", "pipeline_full_body.npz", 43)):
+        N = 64
+        env, g, body_names = make_ref_env(N, seed, robot=robot)
+        nd = env.num_dof
+        env.cfg.domain_rand.push_robots = False
+        noise_u = torch.rand(N, env.num_obs, generator=g)
+        randomize_state(env, g, body_names, N, 0)
+        # contact rows over the robot's own termination set: a force above the threshold on a DIFFERENT terminating body per row, and one on
+        # a body outside the set (no reset); GR1T2: imu_link is one of them
+        term = [int(i) for i in env.termination_contact_indices]
+        non_term = [i for i in range(len(body_names)) if i not in term and i not in [int(f) for f in env.feet_indices]]
+        env.contact_forces[10] = 0
+        for r, bidx in enumerate(term[:8]):
+            env.contact_forces[16 + r, bidx, r % 3] = 2.0 + r
+        if non_term:
+            env.contact_forces[24, non_term[0], 2] = 50.0
+        if robot == "gr1t2_lower_limb":
+            imu = body_names.index("imu_link")
+            assert imu in term, "GR1T2: 'imu' of terminate_after_contacts_on matches imu_link"
+            env.contact_forces[25, imu, 0] = 3.0
+        if robot == "gr1t1":
+            from wiki_grx_gym_amd.model import RobotModel
+            from tests.kinematics_ref import BodyKinematics
+            rm = RobotModel("gr1t1")
+            kin = BodyKinematics(rm, "cpu")
+            for attr in ("axis", "rot0", "jpos", "link_rot", "link_pos"):
+                setattr(kin, attr, getattr(kin, attr).double())
+            rbs = kin.rigid_body_states(env.root_states.double(), env.dof_pos.double(), env.dof_vel.double())
+            torso = int(env.torso_indices[0])
+            env.rigid_body_states[:, torso, 3:7] = rbs[:, torso, 3:7].float()
+            for fi in env.forehead_indices:
+                env.rigid_body_states[:, int(fi), 3:7] = rbs[:, int(fi), 3:7].float()
+        inp = snapshot_inputs(env)
+        env.reset_idx = lambda ids: None
+        seen = {}   # every active term on its own (unscaled) AS compute_reward evaluates it inside the step (legged_robot.py:355-375)
+
+        def recorder(name, fn):
+            def wrapped():
+                v = fn()
+                seen[name] = v.float().numpy().copy()
+                return v
+            return wrapped
+        env.reward_functions = [recorder(n, f) for n, f in zip(env.reward_names, env.reward_functions)]
+        orig_rand_like = torch.rand_like
+        torch.rand_like = lambda t, _u=noise_u: _u.clone()
+        try:
+            env.post_physics_step()
+        finally:
+            torch.rand_like = orig_rand_like
+        outd = dict(obs=torch.clip(env.obs_buf, -100, 100).numpy().copy(), pri_obs=torch.clip(env.pri_obs_buf, -100, 100).numpy().copy(),
+                    rew=env.rew_buf.numpy().copy(), reset=env.reset_buf.numpy().copy(), time_out=env.time_out_buf.numpy().copy(),
+                    base_lin_vel=env.base_lin_vel.numpy().copy(), base_ang_vel=env.base_ang_vel.numpy().copy(),
+                    projected_gravity=env.base_projected_gravity.numpy().copy(), commands_after=env.commands.numpy().copy(),
+                    feet_contact=env.feet_contact.numpy().copy(), air_time_after=env.feet_air_time.numpy().copy(),
+                    land_time_after=env.feet_land_time.numpy().copy(), feet_height=env.feet_height.numpy().copy(),
+                    base_heights_offset_after=env.base_heights_offset.numpy().copy(),
+                    episode_sums=np.stack([env.episode_sums[n].numpy().copy() for n in env.reward_names]),
+                    episode_length_after=env.episode_length_buf.numpy().copy(), last_actions_after=env.last_actions.numpy().copy())
+        outd["term_values"] = np.stack([seen[n] for n in env.reward_names])
+        data = {"in_" + k: v for k, v in inp.items()}
+        data.update({"out_" + k: v for k, v in outd.items()})
+        data["noise_u"] = noise_u.numpy()
+        data["reward_names"] = np.array(env.reward_names)
+        data["reward_scales_dt"] = np.array([env.reward_scales[n] for n in env.reward_names])
+        data["termination_bodies"] = np.array([body_names[i] for i in term])
+        data["index_sets"] = np.array(json.dumps({k: [int(i) for i in getattr(env, k)] for k in sorted(dir(env))
+                                                  if k.endswith("_indices") and ((torch.is_tensor(getattr(env, k)) and getattr(env, k).dim() == 1) or isinstance(getattr(env, k), list))}))
+        assert int(outd["reset"].sum()) >= 9 and not outd["reset"][24], "the contact rows: terminating bodies reset, the other body does not"
+        np.savez_compressed(os.path.join(out, fname), **data)
 
 
 def gen_reward_terms(out):
@@ -621,6 +751,7 @@ def main():
     gen_control_modes(OUT)
     gen_pipeline(OUT)
     gen_pipeline_rough(OUT)
+    gen_pipeline_other_robots(OUT)
     gen_reward_terms(OUT)
     gen_terrain_and_heights(OUT)
     gen_terrain_all_tiles(OUT)

@@ -56,6 +56,7 @@ void grx_launch_step_debug(const KParams* dP, int N, int heightfield, int waves,
 void grx_launch_step_debug_quad(const KParams* dP, int N, int heightfield, int waves, const float* actions, long long common_step, const float* noise,
                                 const float* dbg, const StepSeq* sq, hipStream_t stream);
 int grx_debug_rows(void);
+int grx_debug_row_of(int what);   // 0: torques, 1: last_last_actions, 2: termination contact, 3: apply_reset
 int grx_set_spin_word(unsigned long long* p);
 int grx_set_spin_word_quad(unsigned long long* p);
 }
@@ -1451,10 +1452,10 @@ int grx_debug_profile(grx_handle s, long long* out, int max_blocks) {
 // buffers + the debug rows, then launches the DBG instantiation (no sub-steps) of the step kernel this handle runs.
 int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply_reset, const grx_step_args* a, void* stream) {
     if (!s || !ps || !a) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_post_physics: null argument");
-    if (s->generic && !(s->d_tree && s->nd == GRX_ND)) return fail(GRX_ERR_UNSUPPORTED_MODEL, "grx_debug_post_physics: 10-dof models on the fused kernels or the tree kernel only");
+    if (s->generic && !s->d_tree) return fail(GRX_ERR_UNSUPPORTED_MODEL, "grx_debug_post_physics: the fused kernels or the tree kernel only (this model runs on the one-lane generic kernel)");
     hipStream_t st = (hipStream_t)stream;
     const size_t N = (size_t)s->N;
-    const int nd = s->nd, rows = grx_debug_rows();
+    const int nd = s->nd, rows = grx_debug_rows(), r_tor = grx_debug_row_of(0), r_lla = grx_debug_row_of(1), r_term = grx_debug_row_of(2), r_apply = grx_debug_row_of(3);
     int rc;
     if (!s->d_dbg) {
         if ((rc = dalloc(s, &s->d_dbg, (size_t)rows * N))) return rc;
@@ -1468,7 +1469,7 @@ int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply
         for (int j = 0; j < nd; ++j) {
             q[j * N + i] = p.q[j]; qd[j * N + i] = p.qd[j]; la[j * N + i] = p.last_actions[j]; lqd[j * N + i] = p.last_dof_vel[j];
             act[i * nd + j] = p.actions[j];
-            dbg[(20 + j) * N + i] = p.torques[j]; dbg[(30 + j) * N + i] = p.last_last_actions[j];
+            dbg[(r_tor + j) * N + i] = p.torques[j]; dbg[(r_lla + j) * N + i] = p.last_last_actions[j];
         }
         for (int k = 0; k < 13; ++k) root[k * N + i] = p.root[k];
         for (int k = 0; k < 3; ++k) cmd[k * N + i] = p.commands[k];
@@ -1481,7 +1482,7 @@ int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply
             }
         }
         bho[i] = p.base_heights_offset; ep[i] = p.episode_length;
-        dbg[40 * N + i] = p.term_contact ? 1.f : 0.f; dbg[41 * N + i] = apply_reset ? 1.f : 0.f;
+        dbg[(size_t)r_term * N + i] = p.term_contact ? 1.f : 0.f; dbg[(size_t)r_apply * N + i] = apply_reset ? 1.f : 0.f;
     }
     const KParams& P = s->hp;
 #define UPS(dst, vec) HIP_TRY(hipMemcpyAsync(dst, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, st))

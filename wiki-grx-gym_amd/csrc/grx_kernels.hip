@@ -1199,8 +1199,8 @@ GRX_DEV void noise_blocks(KP P, uint32_t genv, uint32_t step, int side, U4 nzb[N
 }
 
 // rows of the debug-injection table ([DBG_ROWS][N], grx_debug_post_physics): see grx_step_kernel's DBG instantiations
-enum DbgRow { DBG_FEET_FORCE = 0, DBG_FEET_POS = 6, DBG_AVG_FORCE = 12, DBG_AVG_SPEED = 14, DBG_TORQUES = 20, DBG_LAST_LAST_ACTIONS = 30,
-              DBG_TERM_CONTACT = 40, DBG_APPLY_RESET = 41, DBG_ROWS = 42 };
+enum DbgRow { DBG_FEET_FORCE = 0, DBG_FEET_POS = 6, DBG_AVG_FORCE = 12, DBG_AVG_SPEED = 14, DBG_TORQUES = 20, DBG_LAST_LAST_ACTIONS = DBG_TORQUES + GRX_MAX_DOFS,
+              DBG_TERM_CONTACT = DBG_LAST_LAST_ACTIONS + GRX_MAX_DOFS, DBG_APPLY_RESET = DBG_TERM_CONTACT + 1, DBG_ROWS = DBG_APPLY_RESET + 1 };   // (a row per dof of ANY model: the 32-DOF full body's fixture goes through the tree kernel)
 #ifndef GRX_QUAD_TU
 #include "grx_generic.h"
 #include "grx_tree.h"
@@ -2522,6 +2522,7 @@ extern "C" void grx_launch_step_debug(const KParams* dP, int N, int heightfield,
 #undef GRX_LAUNCH_DBG
 }
 extern "C" int grx_debug_rows(void) { return DBG_ROWS; }
+extern "C" int grx_debug_row_of(int what) { return what == 0 ? (int)DBG_TORQUES : what == 1 ? (int)DBG_LAST_LAST_ACTIONS : what == 2 ? (int)DBG_TERM_CONTACT : (int)DBG_APPLY_RESET; }
 // epb: envs per block (= threads per block, at most 64); lds_bytes > 0: the per-body workspace lives in (dynamic) LDS
 extern "C" int grx_launch_step_generic(const KParams* dP, const void* tables, float* ws, int N, int epb, int lds_bytes, int heightfield,
                                        const float* actions, float delay, long long common_step, const float* noise, float* obs_out, float* pri_out,
