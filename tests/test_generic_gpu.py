@@ -77,7 +77,7 @@ def test_full_body_32_dof_against_the_oracle(kernel, monkeypatch):
     worst = physics_lockstep(hip, ora, cfg, steps=25, scale=0.3)
     # with the joint-space armature of GR1T1FullBodyCfg on the wrist / head / shoulder pitch + yaw joints (0.01 kg m^2: their explicit
     # damper was up to two orders of magnitude beyond its stability limit, envs/config.py) the maxima are bounded
-    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE)
+    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE, full_body=True)
     assert worst["FEET_POS"][0] < 2e-3 and worst["FEET_HEIGHT"][0] < 2e-3 and worst["REW"][0] < 1e-2, worst   # (1.7 x observed; every row is also capped and explained by assert_phys)
     assert worst["DOF_VEL"][0] < 1.5 and worst["DOF_POS"][0] < 1e-2, (worst["DOF_VEL"], worst["DOF_POS"])
     assert torch.isfinite(hip.tensor("OBS")).all() and torch.isfinite(hip.tensor("REW")).all()
@@ -104,7 +104,7 @@ def test_full_body_rough_terrain_against_the_oracle(kernel, monkeypatch):
         seen["reset"] += int(o.tensor("RESET").sum())
     worst = physics_lockstep(hip, ora, cfg, steps=40, scale=0.5, check=check)
     assert seen["contact"] > 2000 and seen["reset"] > 0, seen
-    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE_ROUGH, hf=True)
+    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE_ROUGH, hf=True, full_body=True)
     assert worst["FEET_POS"][0] < 1e-2 and worst["DOF_POS"][0] < 7e-2, worst   # (an arm hitting a stair edge a rounding apart: velocity maxima are not bounded on rough terrain)
     mh = tensor_diff(hip.tensor("MEASURED_HEIGHTS"), ora.tensor("MEASURED_HEIGHTS"))
     assert mh[1] < 2e-3
@@ -223,7 +223,7 @@ def test_full_body_control_types_and_heading_against_the_oracle(kernel, ct, monk
     worst = physics_lockstep(hip, ora, cfg, steps=(2 if ct == "V" else 12), scale=(5.0 if ct == "T" else 0.3))
     assert worst["COMMANDS"][0] < 1e-4   # (heading mode: the yaw command is a float computation, atan2 -- not compared bit for bit)
     worst["COMMANDS"] = (worst["COMMANDS"][0], 0.0)
-    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE * (3.2 if ct == "V" else 1.0), chatter=(ct == "V"))   # ('V': 7.7 observed)
+    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE * (3.2 if ct == "V" else 1.0), chatter=(ct == "V"), full_body=True)   # ('V': 7.7 observed)
     hip.close()
 
 

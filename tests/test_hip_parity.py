@@ -56,14 +56,26 @@ def set_layout(monkeypatch, layout):
 #     be out by at most SENS_K x the largest response of the twins in that env.  The compliant contact (kn = 2.5e4 N/m on ~0.2 kg of
 #     effective foot mass, explicit at 500 Hz: omega dt = 0.7) amplifies such a perturbation by 1e2-1e4 within the ten sub-steps of SOME
 #     env-steps -- the twins show which.  "Unexplained" rows are counted per tensor and must be ZERO;
-#   * the error of ANY row is capped at HARD_CAP x its tolerance -- explained or not.
+#   * the error of ANY row is capped at HARD_CAP x its tolerance -- explained or not;
+#   * (round 6) a differing contact event does not excuse a row by itself any more without being COUNTED: rows that are
+#     out of tolerance, sit in an event env and are NOT within SENS_K x the twins' response ("event-only" rows -- exactly where a
+#     contact-coupled bug, a wrong impulse on anchor capture or a wrong force on first touch, would hide) are counted per tensor and test
+#     and may be at most EV_ONLY_FRAC of the test's env-steps.
 PERT = float(os.environ.get("GRX_PHYS_PERT", "1e-6"))
 SENS_K = 10.0
 # (error / tolerance of the worst row of any GPU test, explained rows included: 1.7 x what round 5's calibration runs showed on MI355X --
 #  profiles/r05_phys_fracs_calibration.jsonl; a toe or a forearm that catches a stair edge on one side and clears it on the other is worth
 #  4 rad/s on a 0.5 kg link within a policy step)
-HARD_CAP = {"DOF_VEL": 1500.0, "LAST_DOF_VEL": 1500.0, "ROOT_STATES": 1300.0, "TORQUES": 800.0, "DOF_POS": 700.0}
-HARD_CAP_DEFAULT = 200.0
+# Round 6: ONE table per test class, each entry ~2 x the largest ratio any test of that class showed in round 5 (profiles/r05_phys_fracs.jsonl;
+# round 5 used the rough full body's numbers for every test, so a plane test could be out by 1500 x its tolerance and pass):
+#   (heightfield?, full body?) -> {tensor: cap}, "*": every other tensor
+HARD_CAPS = {
+    (False, False): {"ROOT_STATES": 180.0, "*": 100.0},                                                             # observed <= 88 / 49
+    (False, True): {"DOF_POS": 470.0, "ROOT_STATES": 450.0, "COMMANDS": 200.0, "TORQUES": 160.0, "DOF_VEL": 120.0, "LAST_DOF_VEL": 120.0, "*": 100.0},   # 234 / 220 / 95 / 80 / 60
+    (True, False): {"DOF_VEL": 1500.0, "LAST_DOF_VEL": 1500.0, "TORQUES": 170.0, "ROOT_STATES": 130.0, "*": 100.0},   # 879 / 82 / 63 (a toe on a stair edge)
+    (True, True): {"ROOT_STATES": 1300.0, "DOF_VEL": 1200.0, "LAST_DOF_VEL": 1200.0, "TORQUES": 800.0, "DOF_POS": 700.0, "*": 200.0},   # 765 / 598 / 466 / 394
+}
+EV_ONLY_FRAC = 2e-3            # event-only rows of a tensor, of the env-steps of a test
 # Heightfields add a discrete event the detector below cannot see from the outside: WHICH raster cell a contact sphere (or a scan point) is
 # over.  A sphere within rounding of a cell edge / stair riser takes the other cell on one side; a twin explains it only if one of its
 # random nudges crosses the same edge (six twins there: > 98 % of such rows).  What is left is bounded in number and in size.
@@ -130,8 +142,12 @@ def phys_diff(hip, ora, worst, pre_on=None, twins=()):
             sens = torch.zeros(N, dtype=torch.float64)
             for t in twins:                                       # the oracle's own response to a PERT-sized nudge of the state, per env
                 sens = torch.maximum(sens, ((t.tensor(name).double() - b).abs() / tol).reshape(N, -1).amax(1))
-            explained = ev | (ratio <= SENS_K * sens)
-            r = q.setdefault(name, [0.0, 0.0, 0, 0, 0, 0.0])
+            by_twins = ratio <= SENS_K * sens
+            explained = ev | by_twins
+            r = q.setdefault(name, [0.0, 0.0, 0, 0, 0, 0.0, 0, 0.0])   # (.. [6] event-only rows, [7] their largest error / tolerance)
+            ev_only = (ratio > 1.0) & ev & ~by_twins
+            if ev_only.any():
+                r[6] += int(ev_only.sum()); r[7] = max(r[7], float(ratio[ev_only].max()))
             r[0] = max(r[0], float(ratio.max()))
             if (~explained).any():
                 r[1] = max(r[1], float(ratio[~explained].max()))
@@ -164,7 +180,7 @@ def report_phys(worst, exact_frac, scale, hf=False):
            "needed_scale": round(max(need.values()), 3), "top": [(n, round(v, 3), worst[n][1]) for n, v in top]}
     rows = worst.get("_rows", {})
     if rows:   # per tensor: [max error / tolerance, the same over unexplained envs, unexplained rows, largest (error / twins' response) among non-event outliers]; event envs / env-steps
-        rec["rows"] = {n: [round(r[0], 2), round(r[1], 3), r[2], round(r[5], 2)] for n, r in rows.items() if r[0] > 1.0}
+        rec["rows"] = {n: [round(r[0], 2), round(r[1], 3), r[2], round(r[5], 2), r[6], round(r[7], 2)] for n, r in rows.items() if r[0] > 1.0}   # (.., event-only rows, their largest ratio)
         any_r = next(iter(rows.values()))
         rec["event_envs"], rec["env_steps"] = any_r[3], any_r[4]
     print("assert_phys:", json.dumps(rec))
@@ -176,7 +192,7 @@ def report_phys(worst, exact_frac, scale, hf=False):
         pass
 
 
-def assert_phys(worst, exact_frac=5e-3, scale=1.0, hf=False, chatter=False):
+def assert_phys(worst, exact_frac=5e-3, scale=1.0, hf=False, chatter=False, full_body=False):
     """Every tensor's outlier fraction within its budget x scale.  The scales in this suite are 1.5 x the fraction observed on
     MI355X (gpurun_out/phys_fracs.jsonl of round 4, copied to profiles/r04_phys_fracs.jsonl), never below 1."""
     report_phys(worst, exact_frac, scale, hf)
@@ -186,8 +202,14 @@ def assert_phys(worst, exact_frac=5e-3, scale=1.0, hf=False, chatter=False):
     rows = worst.get("_rows", {})
     if os.environ.get("GRX_PHYS_CALIBRATE"):     # calibration runs (tools/): report, do not fail
         return
-    beyond = {n: round(r[0], 1) for n, r in rows.items() if r[0] > HARD_CAP.get(n, HARD_CAP_DEFAULT)}
-    assert not beyond, f"maximum error / tolerance beyond the hard cap: {beyond}"
+    caps = HARD_CAPS[(bool(hf), bool(full_body))]
+    if chatter:     # (see below: such a law's rows are decided by rounding; they keep the widest table)
+        caps = HARD_CAPS[(True, True)]
+    beyond = {n: round(r[0], 1) for n, r in rows.items() if r[0] > caps.get(n, caps["*"])}
+    assert not beyond, f"maximum error / tolerance beyond the hard cap of this test class {(bool(hf), bool(full_body))}: {beyond}"
+    ev_only = {n: (r[6], round(r[7], 1)) for n, r in rows.items() if r[6] > max(1.0, EV_ONLY_FRAC * r[4])}
+    assert not ev_only or chatter, ("rows out of tolerance that only a differing contact event excuses -- the oracle's twins do not respond like that -- beyond "
+                                    f"{EV_ONLY_FRAC:.1%} of the env-steps (tensor: (rows, largest error / tolerance)): {ev_only}")
     if chatter:      # (a control law that chatters between the effort limits by construction: rounding decides every row -- see the caller)
         return
     if hf:
