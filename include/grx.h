@@ -401,7 +401,10 @@ int grx_tensor(grx_handle h, int tensor_id, grx_tensor_desc* out);
  * refresh_net_contact_force_tensor (legged_robot_fftai.py:75-76, legged_robot.py:275-278) for a caller that reads the tensor now and
  * then.  GRX_ERR_INVALID_ARGUMENT for a tensor this handle does not publish at all.  "Up to date" means: as of the last launch of this handle (step,
  * reset, grx_set_state*); a caller that writes simulation state THROUGH the zero-copy views (the reference's set_*_tensor role is grx_set_state) sees it in an
- * on-refresh tensor after the next such launch, exactly as the reference's tensors change at the next simulate. */
+ * on-refresh tensor after the next such launch, exactly as the reference's tensors change at the next simulate.
+ * Graph capture: the "at most once per step" saving is keyed on the HOST's count of launches, which a replayed graph does not pass through --
+ * from the first launch a handle records into a graph on, grx_refresh launches its kernel on every call (eagerly or recorded) and is correct
+ * after any number of replays (tests/test_env_gpu.py::test_refresh_after_graph_replays). */
 int grx_refresh(grx_handle h, int tensor_id, void* stream);
 
 /* overwrite simulation state of ALL envs from device buffers (any may be NULL = keep):

@@ -289,3 +289,55 @@ def test_bench_runs_under_torchrun_with_a_real_rccl_group():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["steps"] == 50 and out["value"] > 1e6 and out["config"]["finite_outputs"]
+
+
+def test_refresh_after_graph_replays():
+    """grx_refresh keyed its 'already current' shortcut on the host's launch counter; a step replayed through a graph advances the
+    simulation without touching it, so the second refresh between replays returned without launching and RIGID_BODY_STATES / MEASURED_HEIGHTS
+    kept the first replay's data.  From the first recorded launch on the shortcut is off: after every replay the on-refresh tensors equal those
+    of a handle that ran the same steps eagerly and writes them every step."""
+    import gc
+    from tests.helpers import make_cfg, make_terrain
+    from wiki_grx_gym_amd.envs import build_config
+    from wiki_grx_gym_amd.sim import HipSim
+    cfg = make_cfg(terrain="heightfield")
+    N = 256
+    ter = make_terrain(cfg, N, 1)
+
+    def make(mode):
+        c, keep, _ = build_config.build(cfg, cfg.sim.dt, N, terrain=ter)
+        c.publish_rigid_body_states = mode; c.publish_measured_heights = mode
+        s = HipSim(c, "cuda:0", keep)
+        s.reset_all()
+        return s
+    from wiki_grx_gym_amd import _capi
+    hip, ref = make(_capi.PUBLISH_ON_REFRESH), make(_capi.PUBLISH_EVERY_STEP)
+    act = torch.full((N, hip.num_dofs), 0.1, device="cuda:0")
+    for s in (hip, ref):
+        s.step(act, 0.0, 1)
+    hip.tensor("EPISODE_STATS")                              # (flushes the statistics: a capture refuses to begin on unreduced rows)
+    torch.cuda.synchronize()
+    gc.collect(); gc.disable()
+    side = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(side):
+            side.wait_stream(torch.cuda.default_stream())
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin()
+            hip.step(act, 0.0, 2)
+            g.capture_end()
+    finally:
+        gc.enable()
+    torch.cuda.synchronize()
+    for k in range(3):
+        g.replay(); ref.step(act, 0.0, 2)
+        torch.cuda.synchronize()
+        from tests.test_kinematics import rbs_err                  # (positions, quaternions up to sign, velocities)
+        nl = int(hip._keep[-1].model.num_links)
+        a, b = hip.tensor("RIGID_BODY_STATES").cpu()[:, :nl], ref.tensor("RIGID_BODY_STATES").cpu()[:, :nl]     # (sim.tensor refreshes an on-refresh tensor)
+        ep, eq, ev = rbs_err(a, b)
+        assert ep <= 2e-5 and eq <= 2e-5 and ev <= 2e-4, (k, ep, eq, ev)
+        assert torch.equal(hip.tensor("MEASURED_HEIGHTS").cpu(), ref.tensor("MEASURED_HEIGHTS").cpu()), k
+        if k:
+            assert float((a[..., :3] - first).abs().max()) > 1e-4, "the robot moved between the replays"
+        first = a[..., :3].clone()

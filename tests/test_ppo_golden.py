@@ -147,3 +147,7 @@ def test_actor_critic_init_options_of_the_32_dof_task():
             assert torch.equal(x.weight, y.weight)
     obs = torch.randn(16, 105)
     assert a.act_inference(obs).abs().max() < 0.02 < ref.act_inference(obs).abs().max()
+    # with fixed_std the per-action list reaches the distribution as a tensor (it used to be added to one as a Python list)
+    f = ActorCriticMLP(105, 234, 32, **{**pol, "fixed_std": True})
+    f.update_distribution(obs)
+    assert torch.equal(f.action_std[0], torch.tensor([0.2] * 12 + [0.05] * 20)) and f.act(obs).shape == (16, 32)

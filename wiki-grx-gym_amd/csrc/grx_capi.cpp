@@ -123,6 +123,8 @@ struct grx_sim {
     int64_t seq = 0;       // launches of this handle that write statistics rows (steps, resets, debug steps; recorded ones too)
     int64_t eager_seq = 0; // ... the last of them that was launched eagerly (its rows are what grx_flush_stats reduces)
     bool stats_current = true;   // GRX_T_EPISODE_STATS already holds the statistics of the last EAGER launch (grx_flush_stats)
+    bool has_recorded = false;   // a launch of this handle was recorded into a graph: replays advance the simulation without passing through the host
+                                 // counters below, so grx_refresh no longer trusts them and always launches
     int64_t rbs_seq = -1, heights_seq = -1;   // launch number (seq) the on-demand tensors were last materialised for (grx_refresh)
     int64_t state_epoch = 0, rbs_epoch = -1, heights_epoch = -1;   // ... and the count of state writes outside steps (grx_set_state*, grx_reset_*)
     bool last_pushed = false;    // the last step was a _push_robots step (the base's vx, vy were overwritten after the sub-steps)
@@ -855,14 +857,20 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     DA(rbs, s->rbs_mode != GRX_PUBLISH_NEVER ? (size_t)13 * GRX_MAX_LINKS * N : 1);
     DA(pre_q, P.stash_pre_reset ? nd * N : 1); DA(pre_qd, P.stash_pre_reset ? nd * N : 1); DA(pre_root, P.stash_pre_reset ? 13 * N : 1);
     DA(pre_push_vel, P.stash_pre_reset ? 2 * N : 1);
-    {   // grx_refresh: the joint tree as the model holds it
+    if (s->rbs_mode == GRX_PUBLISH_ON_REFRESH) {   // grx_refresh: the joint tree as the model holds it (built only for the handles that refresh link
+        // frames; a tree deeper than the refresh kernel walks -- such models run on the one-lane generic kernel -- loses the tensor, not the handle)
         std::unique_ptr<RefreshTab> rt(new RefreshTab());
         memset(rt.get(), 0, sizeof(RefreshTab));
         rt->nb = m.num_bodies; rt->nlinks = m.num_links;
+        bool too_deep = false;
         for (int b = 1; b < m.num_bodies; ++b) {
+            int n = 0;
+            for (int x = b; x > 0 && n <= GRX_MAX_BODIES; x = m.parent[x]) ++n;
+            too_deep = too_deep || n > GRX_REFRESH_MAXDEPTH;
+        }
+        for (int b = 1; b < m.num_bodies && !too_deep; ++b) {
             int chain[GRX_MAX_BODIES], n = 0;
             for (int x = b; x > 0 && n < GRX_MAX_BODIES; x = m.parent[x]) chain[n++] = x;
-            if (n > GRX_REFRESH_MAXDEPTH) { grx_destroy(s); return fail(GRX_ERR_UNSUPPORTED_MODEL, "grx_create: joint tree deeper than GRX_REFRESH_MAXDEPTH"); }
             rt->depth[b] = n;
             for (int d = 0; d < n; ++d) rt->path[b][d] = (int8_t)chain[n - 1 - d];
             bool ident = true;
@@ -870,11 +878,14 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
             rt->rot0_identity[b] = ident ? 1 : 0;
             for (int a = 0; a < 3; ++a) { rt->axis[b][a] = m.joint_axis[b][a]; rt->jpos[b][a] = m.joint_pos[b][a]; }
         }
-        RefreshTab* drt = nullptr;
-        rc = dalloc(s, &drt, 1);
-        if (rc) { grx_destroy(s); return rc; }
-        HIP_TRY(hipMemcpy(drt, rt.get(), sizeof(RefreshTab), hipMemcpyHostToDevice));
-        P.refresh_tab = drt;
+        if (too_deep) s->rbs_mode = GRX_PUBLISH_NEVER;   // (desc[GRX_T_RIGID_BODY_STATES].data is cleared with the other NEVER handles below)
+        else {
+            RefreshTab* drt = nullptr;
+            rc = dalloc(s, &drt, 1);
+            if (rc) { grx_destroy(s); return rc; }
+            HIP_TRY(hipMemcpy(drt, rt.get(), sizeof(RefreshTab), hipMemcpyHostToDevice));
+            P.refresh_tab = drt;
+        }
     }
     {
         std::vector<LinkTab> lt(1);
@@ -1117,7 +1128,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     if (generic) {
         rc = build_generic(s, c);
         if (rc) { grx_destroy(s); return rc; }
-        if (!s->d_tree) {   // the one-lane generic kernel (trees with more than eight chains): no link frames every step -- on refresh they are available
+        if (!s->d_tree) {   // the one-lane generic kernel (trees with more than eight chains): no link frames, neither every step nor on refresh (it does not stash the state before a reset)
             s->hp.publish_rbs = 0;
             if (s->rbs_mode == GRX_PUBLISH_EVERY_STEP) { s->rbs_mode = GRX_PUBLISH_NEVER; s->desc[GRX_T_RIGID_BODY_STATES].data = nullptr; }
             // (it reads the raw heights back from memory: always materialised there; it neither stashes the state before a reset)
@@ -1214,6 +1225,7 @@ int grx_reset_all(grx_handle s, void* stream) {
     // extras["episode"] of a full reset: mean of the running episode sums over all envs
     // (legged_robot.py:420-424); computed by the stats path with every env flagged.
     const bool capturing = stream_is_capturing(st);
+    if (capturing) s->has_recorded = true;
     if (capturing) if (int rc = capture_needs_flushed_stats(s, "grx_reset_all")) return rc;
     ++s->state_epoch;
     uint32_t step = 0x80000000u + (s->reset_count++);
@@ -1237,6 +1249,7 @@ int grx_reset_idx(grx_handle s, const int32_t* env_ids, int32_t n, void* stream)
     if (n <= 0) return GRX_OK;   // legged_robot.py:387-388
     hipStream_t st = (hipStream_t)stream;
     const bool capturing = stream_is_capturing(st);
+    if (capturing) s->has_recorded = true;
     if (capturing) if (int rc = capture_needs_flushed_stats(s, "grx_reset_idx")) return rc;
     ++s->state_epoch;
     uint32_t step = 0x80000000u + (s->reset_count++);
@@ -1260,6 +1273,7 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     static const bool no_pace = getenv("GRX_DEBUG_NO_PACE") != nullptr;
     const bool capturing = stream_is_capturing(st);
+    if (capturing) s->has_recorded = true;
     if (!no_pace && !capturing)   // (the progress word trails the GPU by one launch: a step publishes its predecessor's ticket)
         if (int rc = spin_until(s, s->pace.issued - Pace::kPaceAhead, "grx_step")) return rc;
     std::pair<hipEvent_t, hipEvent_t> ev;
@@ -1336,12 +1350,12 @@ int grx_refresh(grx_handle s, int id, void* stream) {
     if (!s->desc[id].data) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_refresh: this handle does not publish that tensor (grx_config.publish_*)");
     hipStream_t st = (hipStream_t)stream;
     if (id == GRX_T_RIGID_BODY_STATES && s->rbs_mode == GRX_PUBLISH_ON_REFRESH) {
-        if (s->rbs_seq == s->seq && s->rbs_epoch == s->state_epoch && !stream_is_capturing(st)) return GRX_OK;   // current
+        if (s->rbs_seq == s->seq && s->rbs_epoch == s->state_epoch && !s->has_recorded && !stream_is_capturing(st)) return GRX_OK;   // current
         grx_launch_refresh_rbs(s->d_hp, s->N, s->cfg.model.num_links, s->last_pushed ? 1 : 0, st);
         HIP_TRY(hipGetLastError());
         if (!stream_is_capturing(st)) { s->rbs_seq = s->seq; s->rbs_epoch = s->state_epoch; }
     } else if (id == GRX_T_MEASURED_HEIGHTS && s->heights_mode == GRX_PUBLISH_ON_REFRESH) {
-        if (s->heights_seq == s->seq && s->heights_epoch == s->state_epoch && !stream_is_capturing(st)) return GRX_OK;
+        if (s->heights_seq == s->seq && s->heights_epoch == s->state_epoch && !s->has_recorded && !stream_is_capturing(st)) return GRX_OK;
         grx_launch_refresh_heights(s->d_hp, s->N, s->hp.nh, st);
         HIP_TRY(hipGetLastError());
         if (!stream_is_capturing(st)) { s->heights_seq = s->seq; s->heights_epoch = s->state_epoch; }
@@ -1358,6 +1372,7 @@ int grx_tensor(grx_handle s, int id, grx_tensor_desc* out) {
 
 int grx_set_state(grx_handle s, const float* root, const float* q, const float* qd, void* stream) {
     if (!s) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_set_state: null handle");
+    if (stream_is_capturing((hipStream_t)stream)) s->has_recorded = true;
     ++s->state_epoch;
     grx_launch_set_state(s->d_hp, s->N, root, q, qd, nullptr, 0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -1367,6 +1382,7 @@ int grx_set_state(grx_handle s, const float* root, const float* q, const float* 
 int grx_set_state_indexed(grx_handle s, const int32_t* env_ids, int32_t n, const float* root, const float* q, const float* qd, void* stream) {
     if (!s || (n > 0 && !env_ids)) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_set_state_indexed: null argument");
     if (n <= 0) return GRX_OK;
+    if (stream_is_capturing((hipStream_t)stream)) s->has_recorded = true;
     ++s->state_epoch;
     grx_launch_set_state(s->d_hp, s->N, root, q, qd, env_ids, n, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());

@@ -2388,6 +2388,13 @@ __global__ void grx_set_state_kernel(const KParams* __restrict__ Pg, const float
     if (q) for (int j = 0; j < nd; ++j) P.q[j * N + e] = q[(size_t)e * nd + j];
     if (qd) for (int j = 0; j < nd; ++j) P.qd[j * N + e] = qd[(size_t)e * nd + j];
     for (int i = 0; i < 8; ++i) P.anchors[(size_t)(i * 3 + 2) * N + e] = 0.f;
+    // grx_refresh shows the state "as of the last launch" -- this one: whatever an earlier step stashed for this env (its state before a reset,
+    // the base velocity before a push: refresh_source) is replaced by the state just written
+    if (P.stash_pre_reset) {
+        for (int i = 0; i < 13; ++i) P.pre_root[i * N + e] = P.root[i * N + e];
+        for (int j = 0; j < nd; ++j) { P.pre_q[j * N + e] = P.q[j * N + e]; P.pre_qd[j * N + e] = P.qd[j * N + e]; }
+        P.pre_push_vel[e] = P.root[7 * N + e]; P.pre_push_vel[N + e] = P.root[8 * N + e];
+    }
 }
 // grx_reset_idx: flag the listed envs for the masked reset kernel
 __global__ void grx_mark_kernel(const int32_t* __restrict__ env_ids, int n, int N, uint8_t* __restrict__ mask) {

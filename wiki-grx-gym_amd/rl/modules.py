@@ -155,6 +155,8 @@ class ActorCriticMLP(nn.Module):
         self.fixed_std, self.init_noise_std = fixed_std, init_noise_std
         # (a number, as in the reference -- actor_critic_mlp.py -- or one value per action: the 32-DOF task starts its upper-body joints quieter)
         self.std = nn.Parameter(torch.as_tensor(init_noise_std, dtype=torch.float32) * torch.ones(actor_num_output))
+        # (a scalar or one value per action -- GR1T1FullBodyCfgPPO --: a buffer, so that the fixed_std paths see a tensor on the module's device)
+        self.register_buffer("init_std", torch.as_tensor(init_noise_std, dtype=torch.float32) * torch.ones(actor_num_output), persistent=False)
         self.set_std, self.set_noise_std = set_std, set_noise_std
         self.distribution = None
         Normal.set_default_validate_args = False
@@ -194,7 +196,7 @@ class ActorCriticMLP(nn.Module):
 
     def update_distribution(self, observations):
         mean = self.actor(observations)
-        std = self.init_noise_std if self.fixed_std else self.std.to(mean.device)
+        std = self.init_std.to(mean.device) if self.fixed_std else self.std.to(mean.device)
         self.distribution = Normal(mean, mean * 0.0 + std)
 
     def act(self, observations, **_):

@@ -179,7 +179,7 @@ class PPO:
                     if fuse:
                         eps = torch.randn(self._act_in[0].shape[0], ac.num_actor_output, device=self.device)
                         # (fixed_std: update_distribution -- and so the update's log-prob -- uses init_noise_std, not the parameter)
-                        std = torch.full_like(ac.std, float(ac.init_noise_std)) if getattr(ac, "fixed_std", False) else ac.std.detach()
+                        std = ac.init_std.to(ac.std.device).clone() if getattr(ac, "fixed_std", False) else ac.std.detach()
                         return policy_act(ac.actor, std, self._act_in[0], eps)
                     ac.update_distribution(self._act_in[0])   # Normal.sample() checks std >= 0 on the host: not capturable
                     actions = (ac.action_mean + ac.action_std * torch.randn_like(ac.action_mean)).detach()
