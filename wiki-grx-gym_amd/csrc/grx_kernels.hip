@@ -1828,10 +1828,25 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
 #ifdef GRX_REG_CONSTS
     // PIPE: wave 0 has a SIMD's whole register file to itself; its chain's constants live in registers during the
     // sub-steps (every LDS read of a constant is ~64 exposed cycles on a wave that runs alone)
-    const SideConst Cr = C;
+#ifndef GRX_W8_PAIR_LDS_CONSTS
+#define GRX_W8_PAIR_LDS_CONSTS 1   // (round 6: the eight-wave lane-pair kernel -- 256 registers per wave, a second wave on the SIMD to cover the LDS latency -- reads them from LDS: 51 -> 18 spilled registers, -1.1 % at 8192 envs)
+#endif
+    typename std::conditional<GRX_W8_PAIR_LDS_CONSTS && W == 8 && LPL == 1, const SideConst&, const SideConst>::type Cr = C;
 #else
     const SideConst& Cr = C;
 #endif
+    // Round 6: the eight-wave lane-pair kernel -- 256 registers per wave -- kept BOTH action vectors live across the sub-step loop
+    // for `use_last ? a_last : a_cur`; the allocator sent them to scratch and every sub-step reloaded eight of them (80 scratch loads per policy
+    // step in wave 0's loop, the kernel's only in-loop scratch traffic).  There the loop holds the five actions IN FORCE and swaps them once, at the
+    // sub-step the delayed action arrives; a_last / a_cur are then cold until the rewards.
+#ifndef GRX_SEL_ACT
+#define GRX_SEL_ACT 1
+#endif
+    constexpr bool kSelAct = GRX_SEL_ACT && PIPE && W == 8 && LPL == 1;
+    float a_sel[LEG];
+    bool sel_last = 0.f < delay;
+#pragma unroll
+    for (int k = 0; k < LEG; ++k) a_sel[k] = sel_last ? a_last[k] : a_cur[k];
     for (int deci = 0; deci < (DBG ? 0 : P.decimation); ++deci) {
         // keep the LDS-resident robot tables in LDS: without this barrier LICM hoists ~240 loop-invariant
         // ds_reads into VGPRs and the kernel spills to scratch (measured: 604 B/lane -> 0)
@@ -1854,9 +1869,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
         if (PIPE) flag_set(s_flag + FL_STATE, deci + 1, lane);
         else if (W == 2) __syncthreads();   // #1
         const bool use_last = (float)deci < delay;
+        if (kSelAct && sel_last && !use_last) {   // (uniform: the sub-step the delayed action arrives at)
+#pragma unroll
+            for (int k = 0; k < LEG; ++k) a_sel[k] = a_cur[k];
+            sel_last = false;
+        }
 #pragma unroll
         for (int k = 0; k < LEG; ++k) {  // _compute_torques legged_robot.py:679-715
-            float a = use_last ? a_last[k] : a_cur[k];
+            float a = kSelAct ? a_sel[k] : (use_last ? a_last[k] : a_cur[k]);
             float t = C.body[k].kp * (a * P.action_scale + C.body[k].q0 - st.q[k]) - C.body[k].kd * st.qd[k];
             if (!PIPE && P.control_type != GRX_CONTROL_P)   // 'V' / 'T' (legged_robot.py:699-704): the one-wave layout only (grx_capi.cpp)
                 t = P.control_type == GRX_CONTROL_T ? a * P.action_scale
