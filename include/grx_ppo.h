@@ -69,6 +69,41 @@ int grx_ppo_store_transition(int N, int num_obs, int num_pri, int num_actions,
 /* The minibatch of one PPO step in one launch: dst[t][r][:] = src[t][idx[r]][:] for t < n_tensors (<= GRX_PPO_GATHER_MAX), r < mb;
  * src[t] row-major fp32 with widths[t] columns, idx int64 on the device (RolloutStorage.mini_batch_generator's permutation
  * slice, rollout_storage.py:82-112).  src / dst / widths are HOST arrays of device pointers / ints. */
+/* The TAIL of one PPO minibatch step in two launches: everything rsl_rl/algorithms/ppo.py:264-311 does between loss.backward() and the
+ * next minibatch -- the adaptive learning rate from the minibatch KL (ppo.py:205-213), the NaN-skip (ppo.py:297-299),
+ * nn.utils.clip_grad_norm_ and Adam.step() -- which PyTorch runs as ~20 small kernels (comparisons, clamps, wheres, a foreach norm, a
+ * foreach multiply, the fused-Adam kernel's 42 us multi-tensor launch, statistics adds): 145 us of a 790 us captured step at the GR1T1
+ * train shape, all of it on the step's critical path (profiles/r06_ppo_update_kernel_stats.txt).
+ *   launch 1: per-chunk sums of squares of the gradients -> partials (deterministic order); block 0: lr <- adaptive rule(kl);
+ *             the chunk-0 block of every tensor: its Adam step counter += 1 unless the loss is not finite
+ *   launch 2: every block adds the partials in a fixed order -> per-tensor norms -> total norm -> clip coefficient (clip_grad_norm_'s
+ *             formulas); unless the loss is not finite: Adam on its chunk with the CLIPPED gradient -- the arithmetic of ATen's
+ *             fused_adam_utils.cuh adam_math (double constants, float state), bias corrections from the step counter; block 0: the
+ *             update's running statistics sums[0] += value_loss, sums[1] += surrogate_loss (finite steps only), sums[2] = kl.
+ * weight_decay = 0, no amsgrad, no maximize (the reference's optimizer).  Tensor pointers travel BY VALUE in the launch arguments: a captured
+ * graph keeps the addresses of its capture (PyTorch's graph pool keeps gradient buffers where they were).  All pointers: device memory. */
+#define GRX_PPO_TAIL_MAX 24
+typedef struct grx_ppo_tail_tensors {
+    int n, pad;
+    float* param[GRX_PPO_TAIL_MAX]; const float* grad[GRX_PPO_TAIL_MAX]; float* exp_avg[GRX_PPO_TAIL_MAX]; float* exp_avg_sq[GRX_PPO_TAIL_MAX];
+    float* step[GRX_PPO_TAIL_MAX];          /* the optimizer's per-parameter step counter (a float scalar on the device, torch's capturable Adam) */
+    long long numel[GRX_PPO_TAIL_MAX];
+} grx_ppo_tail_tensors;
+typedef struct grx_ppo_tail_args {
+    const float* loss;                      /* total loss of the minibatch: a non-finite one skips the step */
+    const float* bad_flag;                  /* optional: != 0 skips the step too (the multi-rank path's collective decision) */
+    const float* kl;                        /* minibatch mean KL */
+    float* lr;                              /* learning rate, in / out */
+    const float *value_loss, *surrogate_loss;
+    float* sums;                            /* [3] running statistics of the update (may be NULL) */
+    float* partials;                        /* scratch: grx_ppo_step_tail_blocks(tensors) floats */
+    int adaptive, pad;
+    float desired_kl, lr_min, lr_max, max_grad_norm;
+    double beta1, beta2, eps;
+} grx_ppo_tail_args;
+int grx_ppo_step_tail_blocks(const grx_ppo_tail_tensors* t);
+int grx_ppo_step_tail(const grx_ppo_tail_tensors* t, const grx_ppo_tail_args* a, void* stream);
+
 #define GRX_PPO_GATHER_MAX 12
 int grx_ppo_gather_rows(int n_tensors, const float* const* src, float* const* dst, const int* widths, const long long* idx, int mb, void* stream);
 

@@ -438,3 +438,35 @@ def test_fused_policy_step_matches_the_torch_distribution_path():
         ac2.update_distribution(o)
         assert (got[3] - ac2.action_mean).abs().max() < 1e-5 and (got[1].reshape(-1) - ac2.evaluate(p).reshape(-1)).abs().max() < 1e-5
         assert (got[2].reshape(-1) - ac2.get_actions_log_prob(got[0])).abs().max() < 1e-4
+
+
+def test_fused_step_tail_tracks_the_torch_tail(monkeypatch):
+    """libgrx_ppo.so's step tail (grx_ppo_step_tail: adaptive learning rate, NaN-skip, clip_grad_norm_, Adam.step() in two launches) against
+    the torch tail it replaces (ppo.py:264-311 through PPO._device_lr_update, nn.utils.clip_grad_norm_, torch.optim.Adam fused / capturable):
+    same rollouts, three updates each -- the learning rate takes the same decisions bit for bit, the step counters agree, parameters and
+    moments agree to rounding (the two Adam kernels contract their multiply-adds differently); a minibatch with a non-finite loss leaves
+    parameters, moments and step counters untouched in both."""
+    algs = {}
+    for tail in ("1", "0"):
+        monkeypatch.setenv("GRX_PPO_FUSED_TAIL", tail)
+        a = _toy_alg()
+        assert a._fused_tail == (tail == "1")
+        for it in range(3):
+            _toy_rollout(a, it); torch.manual_seed(7 + it); a.update(); a.clear_storage()
+        algs[tail] = a
+    f, t = algs["1"], algs["0"]
+    assert f._tail is not None and t._tail is None
+    assert f.learning_rate == t.learning_rate and f.learning_rate != 1e-5
+    for (n, p), q in zip(f.actor_critic.named_parameters(), t.actor_critic.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), (n, float((p - q).abs().max()))
+    for p, q in zip(f.actor_critic.parameters(), t.actor_critic.parameters()):
+        sf, st = f.optimizer.state[p], t.optimizer.state[q]
+        assert float(sf["step"]) == float(st["step"]) == 24.0          # 3 updates x 2 epochs x 4 minibatches
+        assert torch.allclose(sf["exp_avg"], st["exp_avg"], rtol=1e-4, atol=1e-8) and torch.allclose(sf["exp_avg_sq"], st["exp_avg_sq"], rtol=1e-4, atol=1e-12)
+    # NaN-skip: poison the returns of one rollout -> every minibatch loss is non-finite -> nothing moves
+    for a in (f, t):
+        before = [p.detach().clone() for p in a.actor_critic.parameters()]
+        steps = [float(a.optimizer.state[p]["step"]) for p in a.actor_critic.parameters()]
+        _toy_rollout(a, 5); a.storage.returns.fill_(float("nan")); a.update(); a.clear_storage()
+        for p, b, s in zip(a.actor_critic.parameters(), before, steps):
+            assert torch.equal(p, b) and float(a.optimizer.state[p]["step"]) == s

@@ -375,6 +375,102 @@ extern "C" int grx_mlp_layer(int M, int K, int N, const float* X, const float* W
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// ---- the tail of a minibatch step (include/grx_ppo.h grx_ppo_step_tail)
+namespace {
+constexpr int TAIL_CHUNK = 4096, TAIL_THR = 256;
+struct TailWhere { int t; long long begin, count; };   // the tensor a block works on and its chunk of it
+__device__ inline TailWhere tail_locate(const grx_ppo_tail_tensors& T, int block) {
+    int b = block;
+    for (int t = 0; t < T.n; ++t) {
+        const int nb = (int)((T.numel[t] + TAIL_CHUNK - 1) / TAIL_CHUNK);
+        if (b < nb) { const long long beg = (long long)b * TAIL_CHUNK; return TailWhere{t, beg, min((long long)TAIL_CHUNK, T.numel[t] - beg)}; }
+        b -= nb;
+    }
+    return TailWhere{-1, 0, 0};
+}
+__device__ inline bool tail_bad(const grx_ppo_tail_args& A) { return !isfinite(*A.loss) || (A.bad_flag && *A.bad_flag != 0.f); }
+__global__ __launch_bounds__(TAIL_THR) void tail_norm_kernel(const grx_ppo_tail_tensors T, const grx_ppo_tail_args A) {
+    __shared__ float red[TAIL_THR];
+    const TailWhere w = tail_locate(T, blockIdx.x);
+    float s = 0.f;
+    if (w.t >= 0) {
+        const float* g = T.grad[w.t] + w.begin;
+        for (long long i = threadIdx.x; i < w.count; i += TAIL_THR) s += g[i] * g[i];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = TAIL_THR / 2; k > 0; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+        A.partials[blockIdx.x] = red[0];
+        if (w.t >= 0 && w.begin == 0 && !tail_bad(A)) *T.step[w.t] += 1.f;   // (torch: _foreach_add_(steps, 1), taken back under found_inf)
+        if (blockIdx.x == 0 && A.adaptive) {   // update_learning_rate (ppo.py:205-213), the branches of PPO._device_lr_update
+            const float lr = *A.lr, kl = *A.kl;
+            const float down = fmaxf(lr * (1.0f / 1.5f), A.lr_min), up = fminf(lr * 1.5f, A.lr_max);   // (torch divides a device tensor by a host scalar as a product with its fp32 reciprocal: the same bits as PPO._device_lr_update)
+            *A.lr = kl > A.desired_kl * 2.0f ? down : ((kl < A.desired_kl / 2.0f && kl > 0.0f) ? up : lr);
+        }
+    }
+}
+__global__ __launch_bounds__(TAIL_THR) void tail_apply_kernel(const grx_ppo_tail_tensors T, const grx_ppo_tail_args A, int nblocks) {
+    __shared__ float s_clip;
+    const bool bad = tail_bad(A);
+    if (threadIdx.x == 0) {
+        // clip_grad_norm_: per-tensor 2-norms, the 2-norm of those, max_norm / (total + 1e-6) clamped to 1 -- every block adds the same
+        // partials in the same order
+        float tot = 0.f;
+        int b = 0;
+        for (int t = 0; t < T.n; ++t) {
+            const int nb = (int)((T.numel[t] + TAIL_CHUNK - 1) / TAIL_CHUNK);
+            float st = 0.f;
+            for (int k = 0; k < nb; ++k) st += A.partials[b + k];
+            b += nb;
+            const float nt = sqrtf(st);
+            tot += nt * nt;
+        }
+        const float total = sqrtf(tot);
+        s_clip = fminf(A.max_grad_norm / (total + 1e-6f), 1.0f);
+        if (blockIdx.x == 0 && A.sums) {
+            const float ok = bad ? 0.f : 1.f;
+            A.sums[0] += *A.value_loss * ok; A.sums[1] += *A.surrogate_loss * ok; A.sums[2] = *A.kl;
+        }
+    }
+    __syncthreads();
+    if (bad) return;
+    const TailWhere w = tail_locate(T, blockIdx.x);
+    if (w.t < 0) return;
+    const float clip = s_clip;
+    const double lr = (double)*A.lr, beta1 = A.beta1, beta2 = A.beta2, eps = A.eps;
+    const float stepc = *T.step[w.t];                                  // (already counted by tail_norm_kernel)
+    const float bias_correction1 = (float)(1.0 - pow(beta1, (double)stepc));
+    const float bias_correction2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)stepc));
+    float* p = T.param[w.t] + w.begin; const float* g = T.grad[w.t] + w.begin;
+    float* m = T.exp_avg[w.t] + w.begin; float* v = T.exp_avg_sq[w.t] + w.begin;
+    for (long long i = threadIdx.x; i < w.count; i += TAIL_THR) {
+        float param = p[i];
+        const float grad = g[i] * clip;
+        float exp_avg = m[i], exp_avg_sq = v[i];
+        exp_avg = (float)(beta1 * exp_avg + (1 - beta1) * grad);               // (fused_adam_utils.cuh adam_math: double constants, float state)
+        exp_avg_sq = (float)(beta2 * exp_avg_sq + (1 - beta2) * grad * grad);
+        const float step_size = (float)(lr / bias_correction1);
+        const float denom = (float)((sqrtf(exp_avg_sq) / bias_correction2_sqrt) + eps);
+        param -= step_size * exp_avg / denom;
+        p[i] = param; m[i] = exp_avg; v[i] = exp_avg_sq;
+    }
+}
+}  // namespace
+extern "C" int grx_ppo_step_tail_blocks(const grx_ppo_tail_tensors* t) {
+    if (!t || t->n < 1 || t->n > GRX_PPO_TAIL_MAX) return -1;
+    long long nb = 0;
+    for (int i = 0; i < t->n; ++i) { if (t->numel[i] < 1) return -1; nb += (t->numel[i] + TAIL_CHUNK - 1) / TAIL_CHUNK; }
+    return nb > 65535 ? -1 : (int)nb;
+}
+extern "C" int grx_ppo_step_tail(const grx_ppo_tail_tensors* t, const grx_ppo_tail_args* a, void* stream) {
+    const int nb = grx_ppo_step_tail_blocks(t);
+    if (nb < 1 || !a || !a->loss || !a->kl || !a->lr || !a->partials) return -1;
+    hipLaunchKernelGGL(tail_norm_kernel, dim3(nb), dim3(TAIL_THR), 0, (hipStream_t)stream, *t, *a);
+    hipLaunchKernelGGL(tail_apply_kernel, dim3(nb), dim3(TAIL_THR), 0, (hipStream_t)stream, *t, *a, nb);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 extern "C" int grx_ppo_colsum_partials_size(int rows, int cols) { return (rows < 1 || cols < 1) ? 0 : ((rows + CS_ROWS - 1) / CS_ROWS) * cols; }
 
 extern "C" int grx_ppo_colsum(int rows, int cols, const float* x, float* out, float* partials, void* stream) {

@@ -41,8 +41,90 @@ def load_ppo_library():
         lib.grx_mlp_layer.argtypes = [C.c_int] * 3 + [fp] * 4 + [C.c_int, C.c_void_p]
         lib.grx_mlp_policy_head.restype = C.c_int
         lib.grx_mlp_policy_head.argtypes = [C.c_int] * 3 + [fp] * 9 + [C.c_void_p]
+        lib.grx_ppo_step_tail.restype = C.c_int
+        lib.grx_ppo_step_tail.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.grx_ppo_step_tail_blocks.restype = C.c_int
+        lib.grx_ppo_step_tail_blocks.argtypes = [C.c_void_p]
         _LIB = lib
     return _LIB
+
+
+TAIL_MAX = 24
+
+
+class _TailTensors(C.Structure):   # include/grx_ppo.h grx_ppo_tail_tensors
+    _fields_ = [("n", C.c_int), ("pad", C.c_int), ("param", C.c_void_p * TAIL_MAX), ("grad", C.c_void_p * TAIL_MAX),
+                ("exp_avg", C.c_void_p * TAIL_MAX), ("exp_avg_sq", C.c_void_p * TAIL_MAX), ("step", C.c_void_p * TAIL_MAX),
+                ("numel", C.c_longlong * TAIL_MAX)]
+
+
+class _TailArgs(C.Structure):      # grx_ppo_tail_args
+    _fields_ = [("loss", C.c_void_p), ("bad_flag", C.c_void_p), ("kl", C.c_void_p), ("lr", C.c_void_p), ("value_loss", C.c_void_p),
+                ("surrogate_loss", C.c_void_p), ("sums", C.c_void_p), ("partials", C.c_void_p), ("adaptive", C.c_int), ("pad", C.c_int),
+                ("desired_kl", C.c_float), ("lr_min", C.c_float), ("lr_max", C.c_float), ("max_grad_norm", C.c_float),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double)]
+
+
+class StepTail:
+    """grx_ppo_step_tail for one torch.optim.Adam (fused, capturable, one param group, no weight decay / amsgrad / maximize): the adaptive
+    learning rate, the NaN-skip, clip_grad_norm_ and Adam.step() of a PPO minibatch step in two launches.  The optimizer's own state tensors
+    (exp_avg, exp_avg_sq, step) are updated in place -- created here, as torch creates them lazily, if the optimizer has not stepped yet --,
+    so optimizer.state_dict() / load_state_dict() and checkpoints are those of the torch path."""
+
+    @staticmethod
+    def supported(optimizer, params):
+        g = optimizer.param_groups
+        return (len(g) == 1 and len(params) <= TAIL_MAX and not g[0].get("amsgrad") and not g[0].get("maximize") and g[0].get("weight_decay", 0) == 0
+                and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params))
+
+    def __init__(self, optimizer, params, lr_t):
+        self.lib = load_ppo_library()
+        self.opt, self.params, self.lr_t = optimizer, list(params), lr_t
+        self.t, self.a = _TailTensors(), _TailArgs()
+        self.key, self.partials = None, None
+
+    def _state(self, p):
+        st = self.opt.state[p]
+        if "exp_avg" not in st:   # torch's lazy initialisation (optim/adam.py _init_group), capturable / fused: the step counter is a device scalar
+            st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    def __call__(self, loss, kl, value_loss, surrogate_loss, sums, adaptive, desired_kl, lr_min, lr_max, max_grad_norm, bad_flag=None):
+        t, a = self.t, self.a
+        sts = [self._state(p) for p in self.params]
+        key = tuple(x.data_ptr() for p, st in zip(self.params, sts) for x in (p, st["exp_avg"], st["exp_avg_sq"], st["step"]))
+        if key != self.key:
+            t.n = len(self.params)
+            for i, (p, st) in enumerate(zip(self.params, sts)):
+                if not (st["step"].is_cuda and st["step"].dtype == torch.float32 and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
+                    raise RuntimeError("StepTail: the optimizer state is not torch's fused / capturable layout")
+                t.param[i], t.exp_avg[i], t.exp_avg_sq[i], t.step[i], t.numel[i] = p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel()
+            nb = self.lib.grx_ppo_step_tail_blocks(C.byref(t))
+            if nb < 1:
+                raise RuntimeError("grx_ppo_step_tail_blocks failed")
+            self.partials = torch.empty(nb, device=self.params[0].device, dtype=torch.float32)
+            self.key = key
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+                raise RuntimeError("StepTail: every parameter needs a contiguous fp32 .grad")
+            t.grad[i] = g.data_ptr()
+        g0 = self.opt.param_groups[0]
+        a.loss, a.kl, a.lr = loss.data_ptr(), kl.data_ptr(), self.lr_t.data_ptr()
+        a.bad_flag = bad_flag.data_ptr() if bad_flag is not None else None
+        a.value_loss, a.surrogate_loss = value_loss.data_ptr(), surrogate_loss.data_ptr()
+        a.sums = sums.data_ptr() if sums is not None else None
+        a.partials = self.partials.data_ptr()
+        a.adaptive = int(bool(adaptive))
+        a.desired_kl, a.lr_min, a.lr_max, a.max_grad_norm = float(desired_kl or 0.0), float(lr_min), float(lr_max), float(max_grad_norm)
+        a.beta1, a.beta2, a.eps = float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"])
+        dev = self.params[0].device
+        with torch.cuda.device(dev):
+            rc = self.lib.grx_ppo_step_tail(C.byref(t), C.byref(a), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"grx_ppo_step_tail failed ({rc})")
 
 
 def _f32c(x):

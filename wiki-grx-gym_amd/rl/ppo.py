@@ -88,6 +88,10 @@ class PPO:
         # ... and everything between the networks' outputs and their gradients is one HIP kernel (rl/fused_loss.py)
         self._fused_loss = self._device_lr and os.environ.get("GRX_PPO_FUSED_LOSS", "1") != "0"
         self._fused_store = self._device_lr and os.environ.get("GRX_PPO_FUSED_STORE", "1") != "0"
+        # ... and everything behind loss.backward() -- adaptive learning rate, NaN-skip, gradient clip, Adam -- is two launches of
+        # libgrx_ppo.so (rl/fused_loss.py StepTail) instead of ~20 small torch kernels on the step's critical path (GRX_PPO_FUSED_TAIL=0: torch)
+        self._fused_tail = self._device_lr and os.environ.get("GRX_PPO_FUSED_TAIL", "1") != "0"
+        self._tail = None
         self._graph, self._graph_mb, self._static, self._sums, self._restore_opt = None, None, None, None, None
         # ... and so is the rollout's policy step (GRX_PPO_ACT_GRAPH=0: eager)
         self._use_act_graph = self._device_lr and os.environ.get("GRX_PPO_ACT_GRAPH", "1") not in ("0", "")
@@ -429,11 +433,15 @@ class PPO:
             else:
                 self.optimizer.zero_grad(set_to_none=False)
             loss.backward()
+            if not multi and self._step_tail(loss, kl_mean, value_loss, surrogate_loss, sums, adaptive):
+                continue
             with torch.no_grad():
                 bad = ~torch.isfinite(loss)
                 if multi:
                     kl_mean, bad = self._sync_gradients(kl_mean, bad)
                     bad = bad | ~torch.isfinite(self._bucket[:self._nflat]).all()
+            if multi and self._step_tail(value_loss, kl_mean, value_loss, surrogate_loss, sums, adaptive, bad_flag=bad.float()):
+                continue
             if adaptive:
                 self._device_lr_update(kl_mean)
             with torch.no_grad():
@@ -465,6 +473,8 @@ class PPO:
         # accumulating into a zeroed one -- one fill and one add kernel less per parameter and step (GRX_PPO_GRAD_NONE=0: fill)
         self.optimizer.zero_grad(set_to_none=os.environ.get("GRX_PPO_GRAD_NONE", "1") != "0")
         loss.backward()
+        if self._step_tail(loss, kl_mean, value_loss, surrogate_loss, sums, adaptive):
+            return
         if adaptive:
             self._device_lr_update(kl_mean)
         with torch.no_grad():
@@ -478,6 +488,22 @@ class PPO:
             sums[0] += value_loss.detach() * ok
             sums[1] += surrogate_loss.detach() * ok
             sums[2] = kl_mean
+
+    def _step_tail(self, loss, kl_mean, value_loss, surrogate_loss, sums, adaptive, bad_flag=None):
+        """Adaptive learning rate, NaN-skip, clip_grad_norm_, Adam.step() and the update's statistics through libgrx_ppo.so (two launches);
+        False: not available here (GRX_PPO_FUSED_TAIL=0, an optimizer configuration it does not cover) -- the caller runs the torch tail."""
+        if not self._fused_tail:
+            return False
+        if self._tail is None:
+            from .fused_loss import StepTail
+            if not StepTail.supported(self.optimizer, self._params) or any(p.grad is None for p in self._params):
+                self._fused_tail = False
+                return False
+            self._tail = StepTail(self.optimizer, self._params, self._lr_t)
+        with torch.no_grad():
+            self._tail(loss.detach(), kl_mean.detach(), value_loss.detach(), surrogate_loss.detach(), sums, adaptive, self.desired_kl,
+                       self.learning_rate_min, self.learning_rate_max, self.max_grad_norm, bad_flag=bad_flag)
+        return True
 
     # ... and with more than one rank the step is captured as TWO halves around the one eager RCCL all-reduce:
     #   front  = zero the flat bucket, forward, fused loss, backward (accumulating into the bucket's views), KL and the
@@ -504,6 +530,8 @@ class PPO:
             b /= _world()
             kl_mean = b[n]
             bad = (b[n + 1] > 0) | ~torch.isfinite(b[:n]).all()
+        if self._step_tail(self._mid[0], kl_mean, self._mid[0], self._mid[1], sums, adaptive, bad_flag=bad.float()):
+            return   # (the collective NaN decision travels as the flag; _mid[0], the value loss, stands in for the total loss: not finite -> bad anyway)
         if adaptive:
             self._device_lr_update(kl_mean)
         with torch.no_grad():
