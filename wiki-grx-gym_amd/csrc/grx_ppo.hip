@@ -412,7 +412,10 @@ __global__ __launch_bounds__(TAIL_THR) void tail_norm_kernel(const grx_ppo_tail_
 }
 __global__ __launch_bounds__(TAIL_THR) void tail_apply_kernel(const grx_ppo_tail_tensors T, const grx_ppo_tail_args A, int nblocks) {
     __shared__ float s_clip;
+    __shared__ float s_part[1024];
     const bool bad = tail_bad(A);
+    for (int i = threadIdx.x; i < nblocks && i < 1024; i += TAIL_THR) s_part[i] = A.partials[i];   // (one parallel fetch; the sums below then run on LDS)
+    __syncthreads();
     if (threadIdx.x == 0) {
         // clip_grad_norm_: per-tensor 2-norms, the 2-norm of those, max_norm / (total + 1e-6) clamped to 1 -- every block adds the same
         // partials in the same order
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(TAIL_THR) void tail_apply_kernel(const grx_ppo_tail
         for (int t = 0; t < T.n; ++t) {
             const int nb = (int)((T.numel[t] + TAIL_CHUNK - 1) / TAIL_CHUNK);
             float st = 0.f;
-            for (int k = 0; k < nb; ++k) st += A.partials[b + k];
+            for (int k = 0; k < nb; ++k) st += (b + k < 1024 ? s_part[b + k] : A.partials[b + k]);
             b += nb;
             const float nt = sqrtf(st);
             tot += nt * nt;
