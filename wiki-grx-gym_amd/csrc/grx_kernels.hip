@@ -1831,7 +1831,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
 #ifndef GRX_W8_PAIR_LDS_CONSTS
 #define GRX_W8_PAIR_LDS_CONSTS 1   // (round 6: the eight-wave lane-pair kernel -- 256 registers per wave, a second wave on the SIMD to cover the LDS latency -- reads them from LDS: 51 -> 18 spilled registers, -1.1 % at 8192 envs)
 #endif
-    typename std::conditional<GRX_W8_PAIR_LDS_CONSTS && W == 8 && LPL == 1, const SideConst&, const SideConst>::type Cr = C;
+#ifndef GRX_W8_QUAD_LDS_CONSTS
+#define GRX_W8_QUAD_LDS_CONSTS 1   // (the lane-quad kernel too: -0.5 % at 4096 envs, two runs each, profiles/r06_experiments.md)
+#endif
+    typename std::conditional<W == 8 && ((GRX_W8_PAIR_LDS_CONSTS && LPL == 1) || (GRX_W8_QUAD_LDS_CONSTS && LPL == 2)), const SideConst&, const SideConst>::type Cr = C;
 #else
     const SideConst& Cr = C;
 #endif
@@ -1842,7 +1845,10 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 
 #ifndef GRX_SEL_ACT
 #define GRX_SEL_ACT 1
 #endif
-    constexpr bool kSelAct = GRX_SEL_ACT && PIPE && W == 8 && LPL == 1;
+#ifndef GRX_SEL_ACT_QUAD
+#define GRX_SEL_ACT_QUAD 0
+#endif
+    constexpr bool kSelAct = GRX_SEL_ACT && PIPE && W == 8 && (LPL == 1 || GRX_SEL_ACT_QUAD);
     float a_sel[LEG];
     bool sel_last = 0.f < delay;
 #pragma unroll
