@@ -297,7 +297,7 @@ def main():
         # FETCH_SIZE is a lower bound on gfx950 (MI355X_MICROARCH.md), see the note inside the file.
         traffic, traffic_src, valu_insts, valu_src = None, None, None, None
         wl = {"lower_limb": "", "gr1t2": "gr1t2_", "full_body": "full_body_"}[args.robot] + f"{args.terrain}{n_local}"   # e.g. rough4096, full_body_rough4096
-        for tag in ("r05", "r04", "r03", "r02", "r01"):
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_{wl}.json")
             if traffic is None and os.path.exists(pmc):
                 try:

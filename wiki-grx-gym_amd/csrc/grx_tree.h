@@ -797,9 +797,17 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     long long ep_len = P.ep_len[e];
     // (the running episode sums too, AHEAD of the kernel's first global stores: vmcnt counts loads and stores in one order, so a load requested
     //  behind the contact_forces / height rows waits for those stores to be acknowledged by memory -- 12 k cycles of this section, measured)
+    // The reward scales, ONE per lane (lane t holds term t's), and the set of active terms as one scalar mask: the three loops over the terms
+    // below asked the parameter block for scale[t] -- and for the episode_sums pointer again -- behind a branch per term: ~100 dependent
+    // scalar-load round trips, 12 k cycles of this kernel's tail (from the ISA: s_load_dword / s_waitcnt lgkmcnt(0) / branch / s_load_dwordx2 ...).
+    static_assert(NT <= 64, "a reward term per lane");
+    const float scale_v = P.reward_scale_dt[lane < NT ? lane : 0];
+    const unsigned long long term_on = __ballot(lane < NT && scale_v != 0.f);
+    auto scale_of = [&](int t) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scale_v), t)); };
+    float* const es_col = P.episode_sums + e;
     float es_old[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) es_old[t] = (P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f;
+    for (int t = 0; t < NT; ++t) es_old[t] = ((term_on >> t) & 1ull) ? es_col[(size_t)t * N] : 0.f;
     // ---- refresh_rigid_body_state_tensor after the last sub-step: frames of the final state
     {
         const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
@@ -1084,14 +1092,14 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     float rew = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float sc_t = P.reward_scale_dt[t];
+        const float sc_t = scale_of(t);
         float rt = 0.f;
-        if (t != GRX_REW_TERMINATION && sc_t != 0.f) { rt = r[t] * sc_t; rew += rt; }
+        if (t != GRX_REW_TERMINATION && ((term_on >> t) & 1ull)) { rt = r[t] * sc_t; rew += rt; }
         r[t] = rt;
     }
     if (P.only_positive_rewards) rew = fmaxf(rew, 0.f);
-    if (P.reward_scale_dt[GRX_REW_TERMINATION] != 0.f) {
-        const float rt = r[GRX_REW_TERMINATION] = ((reset && !time_out) ? 1.f : 0.f) * P.reward_scale_dt[GRX_REW_TERMINATION];
+    if ((term_on >> GRX_REW_TERMINATION) & 1ull) {
+        const float rt = r[GRX_REW_TERMINATION] = ((reset && !time_out) ? 1.f : 0.f) * scale_of(GRX_REW_TERMINATION);
         rew += rt;
     }
     // episode sums (the group's first lane); finished episodes -> the block's statistics row (deterministic lane order)
@@ -1099,6 +1107,8 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 17] = clock64() - tt_begin;
 #endif
     const unsigned long long reset_mask = __ballot(reset && actl);
+    const bool publish_debug = P.publish_debug != 0;
+    float* const rt_col = P.reward_terms + e;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const float es = es_old[t] + r[t];
@@ -1110,9 +1120,9 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
             for (int k = 0; k < TEPW; ++k) acc_ += __int_as_float(__builtin_amdgcn_readlane(esm, k * TG));
             if (lane == 0) s_stat[wave][t] = acc_;   // (the wave's row was zeroed at the kernel's start and this is its only writer: no read-modify-write)
         }
-        if (actl && P.reward_scale_dt[t] != 0.f) {
-            P.episode_sums[(size_t)t * N + e] = (reset && dbg_apply_reset) ? 0.f : es;
-            if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
+        if (actl && ((term_on >> t) & 1ull)) {
+            es_col[(size_t)t * N] = (reset && dbg_apply_reset) ? 0.f : es;
+            if (publish_debug) rt_col[(size_t)t * N] = r[t];
         }
     }
     if (lane == 0) s_stat[wave][NT] = (float)__popcll(reset_mask);
