@@ -106,8 +106,15 @@ __global__ __launch_bounds__(64) void ppo_loss_finalize(int B, int A, int nblk, 
                                                          float* __restrict__ out, float* __restrict__ d_std) {
     const int k = threadIdx.x;
     double t = 0.0;
+    constexpr int STAGE = 4096;   // doubles: the partials of a minibatch fit (41 blocks at 10^4 samples); fetched in parallel, added from LDS in the SAME order
+    __shared__ double s_p[STAGE];
+    const bool staged = nblk * NRED <= STAGE;
+    if (staged) {
+        for (int i = k; i < nblk * NRED; i += 64) s_p[i] = partials[i];
+        __syncthreads();
+    }
     if (k < 3 + A)
-        for (int b = 0; b < nblk; ++b) t += partials[(size_t)b * NRED + k];
+        for (int b = 0; b < nblk; ++b) t += staged ? s_p[b * NRED + k] : partials[(size_t)b * NRED + k];
     __shared__ double s_t[64];
     s_t[k] = t;   // 3 + MAXA <= 64
     __syncthreads();
@@ -377,7 +384,7 @@ extern "C" int grx_mlp_layer(int M, int K, int N, const float* X, const float* W
 
 // ---- the tail of a minibatch step (include/grx_ppo.h grx_ppo_step_tail)
 namespace {
-constexpr int TAIL_CHUNK = 4096, TAIL_THR = 256;
+constexpr int TAIL_CHUNK = 4096, TAIL_THR = 256, TAIL_SPLIT = 4;   // (the apply kernel: TAIL_SPLIT blocks per chunk of the norm kernel -- 4 elements per thread)
 struct TailWhere { int t; long long begin, count; };   // the tensor a block works on and its chunk of it
 __device__ inline TailWhere tail_locate(const grx_ppo_tail_tensors& T, int block) {
     int b = block;
@@ -438,8 +445,13 @@ __global__ __launch_bounds__(TAIL_THR) void tail_apply_kernel(const grx_ppo_tail
     }
     __syncthreads();
     if (bad) return;
-    const TailWhere w = tail_locate(T, blockIdx.x);
+    TailWhere w = tail_locate(T, blockIdx.x / TAIL_SPLIT);
     if (w.t < 0) return;
+    {   // this block's part of the chunk
+        const long long sub = (TAIL_CHUNK / TAIL_SPLIT) * (long long)(blockIdx.x % TAIL_SPLIT);
+        if (sub >= w.count) return;
+        w.begin += sub; w.count = min((long long)(TAIL_CHUNK / TAIL_SPLIT), w.count - sub);
+    }
     const float clip = s_clip;
     const double lr = (double)*A.lr, beta1 = A.beta1, beta2 = A.beta2, eps = A.eps;
     const float stepc = *T.step[w.t];                                  // (already counted by tail_norm_kernel)
@@ -470,7 +482,7 @@ extern "C" int grx_ppo_step_tail(const grx_ppo_tail_tensors* t, const grx_ppo_ta
     const int nb = grx_ppo_step_tail_blocks(t);
     if (nb < 1 || !a || !a->loss || !a->kl || !a->lr || !a->partials) return -1;
     hipLaunchKernelGGL(tail_norm_kernel, dim3(nb), dim3(TAIL_THR), 0, (hipStream_t)stream, *t, *a);
-    hipLaunchKernelGGL(tail_apply_kernel, dim3(nb), dim3(TAIL_THR), 0, (hipStream_t)stream, *t, *a, nb);
+    hipLaunchKernelGGL(tail_apply_kernel, dim3(nb * TAIL_SPLIT), dim3(TAIL_THR), 0, (hipStream_t)stream, *t, *a, nb);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
