@@ -3,7 +3,7 @@
 # passes as tools/collect_r05.sh: counters, kernel stats, then the bench line (which reads the counter summary just made).
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-tag=r05; wl=gr1t2_rough4096; out=gpurun_out/$tag; mkdir -p $out
+tag=r06; wl=gr1t2_rough4096; out=gpurun_out/$tag; mkdir -p $out
 bash tools/collect_pmc.sh $tag $wl --robot gr1t2 --steps 400 --warmup 50
 python tools/summarise_pmc.py $tag $wl 10141696
 d=$out/stats_$wl
