@@ -30,6 +30,8 @@ for terrain in ("plane", "heightfield"):
     print("   behind the sub-steps (cycles since the kernel's start): physics done", int(m2[0]), "final frames / link frames / feet done", int(m2[2]), "state update + height scan done", int(m2[3]), "rewards done", int(m2[4]), "reset done", int(m2[5]), "end", int(m2[1]))
     m4 = np.median(full[:, 20:24], axis=0)
     print("   inside 'outward': joint-local phase", int(m4[0] / 10), "walk", int(m4[1] / 10), "contact probe", int(m4[2] / 10), "(the rest: bias forces of all bodies);  inside 'inward': rigid inertias of all bodies", int(m4[3] / 10), " [cycles per sub-step]")
+    lv = np.median(np.diff(full[:, 30:41], axis=1), axis=0); lo = np.median(np.diff(full[:, 44:55], axis=1), axis=0)
+    print("   last sub-step, cycles per depth level: inward (leaf level first)", [int(x) for x in lv], " outward walk (level 0 first)", [int(x) for x in lo])
     m3 = np.median(full[:, 14:18], axis=0)
     print("   inside the rewards: per-joint sums done", int(m3[0]), "group sums done", int(m3[1]), "terms done", int(m3[2]), "scaled and summed", int(m3[3]))
     s.close()

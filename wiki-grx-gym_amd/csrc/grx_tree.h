@@ -73,6 +73,11 @@ GRX_DEV V3 grp_bcast(V3 v, int lane, int src) { return v3(grp_bcast(v.x, lane, s
 GRX_DEV V3 tw_v3(const float* wsw, int ei, int a) { return v3(TW(a), TW(a + 1), TW(a + 2)); }
 GRX_DEV void tw_put(float* wsw, int ei, int a, V3 x) { TW(a) = x.x; TW(a + 1) = x.y; TW(a + 2) = x.z; }
 GRX_DEV R3 tw_R(const float* wsw, int ei, int a) { R3 R; R.cx = tw_v3(wsw, ei, a); R.cy = tw_v3(wsw, ei, a + 3); R.cz = tw_v3(wsw, ei, a + 6); return R; }
+#ifdef GRX_PROFILE_SECTIONS
+#define TLV(P_, slot) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 64) (P_).prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + (slot)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TLV(P_, slot) do {} while (0)
+#endif
 GRX_DEV void tree_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }   // (one wave: LDS operations complete in program order)
 
 // Round 6 -- the JOINT-LOCAL phase.  A wave alone on its SIMD issues one instruction per ~4 cycles and every LDS round trip on the way costs
@@ -257,6 +262,7 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
     //  loop-invariant bound a `break` makes the trip count a run-time value, the pass is no longer unrolled and its level-indexed registers go
     //  to scratch -- measured)
     TreeOutIn nx = tree_out_fetch(T, wsw, ei, max(G.sb[0], 1));
+    if (!KIN) TLV(P, 44);
 #pragma unroll
     for (int g = 0; g < TNG; ++g) {
         const TreeOutIn in = nx;
@@ -290,6 +296,7 @@ GRX_DEV void tree_outward(KP P, const TreeTab& T, float* wsw, int ei, int c, con
             Rc = R; rho_c = rho; w_c = w; v_c = v;
         }
         tree_fence();
+        if (!KIN) TLV(P, 45 + g);
     }
 }
 // rigid-body bias forces p_k + I_k zeta_k of every body, from the frames and the zeta the walk left in LDS (contacts and self-collision add into these)
@@ -456,6 +463,7 @@ GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, cons
     M3 Bm = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     V3 pa = v3(0.f, 0.f, 0.f), pl = v3(0.f, 0.f, 0.f);
     TreeInIn nx = tree_in_fetch(T, wsw, ei, max(G.sb[TNG - 1], 1));
+    TLV(P, 30);
 #pragma unroll
     for (int g = TNG - 1; g >= 0; --g) {
         const TreeInIn in = nx;
@@ -489,6 +497,7 @@ GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, cons
             if (g == CH.first) tree_put_up(wsw, ei, o.up + c * T_UPW, A, Bm, D, pa, pl);
         }
         tree_fence();
+        TLV(P, 31 + (TNG - 1 - g));
     }
 }
 

@@ -38,9 +38,12 @@ def publish_mode(v):
     import os
     if v is False or v is None or v == 0 or v == "never":
         return _capi.PUBLISH_NEVER
-    if v == "every_step" or v == _capi.PUBLISH_EVERY_STEP and v is not True or os.environ.get("GRX_PUBLISH_EVERY_STEP") == "1":
+    # (True == 1 == PUBLISH_EVERY_STEP in Python: the bool is tested by identity first -- True means "publish", i.e. on refresh)
+    every = v == "every_step" or (v is not True and v == _capi.PUBLISH_EVERY_STEP)
+    on_refresh = v is True or v == "on_refresh" or v == _capi.PUBLISH_ON_REFRESH
+    if every or (on_refresh and os.environ.get("GRX_PUBLISH_EVERY_STEP") == "1"):   # (the environment knob turns a published tensor into a step-written one)
         return _capi.PUBLISH_EVERY_STEP
-    if v is True or v == "on_refresh" or v == _capi.PUBLISH_ON_REFRESH:
+    if on_refresh:
         return _capi.PUBLISH_ON_REFRESH
     raise ValueError(f"publish mode {v!r}: True / 'on_refresh', 'every_step' or False")
 

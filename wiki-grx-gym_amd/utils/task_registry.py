@@ -46,7 +46,9 @@ class TaskRegistry:
             env_cfg.seed = self.train_cfgs[name].seed
         set_seed(env_cfg.seed)
         # GRX_T_REWARD_TERMS (the per-term reward table, a debugging tensor the reference has no counterpart of) is only
-        # written when asked for; every reference attribute (measured_heights included) is always current
+        # written when asked for.  rigid_body_states and measured_heights are published ON REFRESH (grx_publish_mode, ABI 6): the env's properties
+        # refresh them when read, a caller that keeps the raw view must call env._sim.refresh / read the property again after a step
+        # (env.publish_* = "every_step" restores the step-written tensors of rounds 3-4); every other reference attribute is always current
         if not hasattr(env_cfg.env, "publish_reward_terms"):
             env_cfg.env.publish_reward_terms = False
         sim_params = parse_sim_params(args, {"sim": class_to_dict(env_cfg.sim)})
