@@ -35,7 +35,7 @@ def test_ppo_header_symbols_are_exported():
     from wiki_grx_gym_amd.rl import fused_loss
     hdr = open(os.path.join(ROOT, "include", "grx_ppo.h")).read()
     declared = set(re.findall(r"\b(grx_(?:ppo|mlp)_[a-z_]+)\s*\(", hdr))
-    assert declared == {"grx_ppo_loss", "grx_ppo_loss_partials_size", "grx_ppo_colsum", "grx_ppo_colsum_partials_size", "grx_ppo_store_transition", "grx_ppo_gather_rows", "grx_ppo_elu_backward_colsum", "grx_mlp_layer", "grx_mlp_policy_head"}
+    assert declared == {"grx_ppo_loss", "grx_ppo_loss_partials_size", "grx_ppo_colsum", "grx_ppo_colsum_partials_size", "grx_ppo_store_transition", "grx_ppo_gather_rows", "grx_ppo_elu_backward_colsum", "grx_mlp_layer", "grx_mlp_policy_head", "grx_ppo_step_tail", "grx_ppo_step_tail_blocks"}
     path = os.path.join(os.path.dirname(sim.HIP_LIB_PATH), "libgrx_ppo.so")
     if not os.path.exists(path):
         import __graft_entry__ as g
@@ -45,6 +45,23 @@ def test_ppo_header_symbols_are_exported():
         assert hasattr(lib, s_), s_
     assert lib.grx_ppo_loss_partials_size(1000) == 4 * 35 * 2 and lib.grx_ppo_loss_partials_size(0) == 0
     assert lib.grx_ppo_colsum_partials_size(10485, 128) == 41 * 128 and lib.grx_ppo_colsum_partials_size(0, 5) == 0
+    # the step tail's two argument structs travel by value: the ctypes mirrors (rl/fused_loss.py) against the C compiler's view of the header
+    import ctypes as C, subprocess, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "sz.c")
+        open(src, "w").write('#include <stddef.h>\n#include "grx_ppo.h"\nsize_t a(void){return sizeof(grx_ppo_tail_tensors);} size_t b(void){return sizeof(grx_ppo_tail_args);}\n'
+                             'size_t c(void){return offsetof(grx_ppo_tail_tensors, numel);} size_t e(void){return offsetof(grx_ppo_tail_args, beta1);} int f(void){return GRX_PPO_TAIL_MAX;}\n')
+        so = os.path.join(d, "sz.so")
+        subprocess.check_call(["gcc", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), src, "-o", so])
+        z = C.CDLL(so)
+        for f_ in (z.a, z.b, z.c, z.e):
+            f_.restype = C.c_size_t
+        assert z.a() == C.sizeof(fused_loss._TailTensors) and z.b() == C.sizeof(fused_loss._TailArgs)
+        assert z.c() == fused_loss._TailTensors.numel.offset and z.e() == fused_loss._TailArgs.beta1.offset and z.f() == fused_loss.TAIL_MAX
+    t = fused_loss._TailTensors(); t.n = 0
+    assert lib.grx_ppo_step_tail_blocks(C.byref(t)) == -1       # (argument checks only: nothing is launched without a GPU)
+    t.n = 2; t.numel[0] = 5000; t.numel[1] = 4096
+    assert lib.grx_ppo_step_tail_blocks(C.byref(t)) == 3
 
 
 def test_struct_layout_matches_header(tmp_path):
