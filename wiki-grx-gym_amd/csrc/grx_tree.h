@@ -682,6 +682,7 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         E.hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
     }
     TreeRegs G;
+    const float *const qcol = P.q + e, *const qdcol = P.qd + e, *const lacol = P.last_actions + e, *const mscol = P.motor_strength + e;   // (per-lane column bases: the ten unrolled levels below each re-fetched the four pointers from the parameter block)
     TreeChain CH;
     CH.first = T.first[c]; CH.last = T.last[c]; CH.hangp = 0; CH.hcmask = 0u;
     const int nstep = __builtin_amdgcn_readfirstlane(T.nstep);
@@ -692,15 +693,14 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
         G.q[g] = 0.f; G.qd[g] = 0.f; G.Sa[g] = v3(0.f, 0.f, 0.f);
         if (b >= 0) {
             const int j = b - 1;
-            const size_t oj = (size_t)j * N + e;
-            G.q[g] = P.q[oj]; G.qd[g] = P.qd[oj];
+            G.q[g] = qcol[(size_t)j * N]; G.qd[g] = qdcol[(size_t)j * N];
             TW(TBO(b) + T_Q) = G.q[g]; TW(TBO(b) + T_QD) = G.qd[g];   // (the joint-local phase reads them from the row)
             if (g == CH.first) CH.hangp = T.body[b].parent;
             if (T.body[b].nhc > 0) CH.hcmask |= 1u << g;
             const float a = actions_in ? actions_in[(size_t)e * nd + j] : 0.f;
             TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j) = fminf(fmaxf(a, T.dof[j].amin), T.dof[j].amax);   // clip_actions (legged_robot_fftai.py:171-177)
-            TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j) = P.last_actions[oj];
-            TW(o.dof + TD_STR * GRX_MAX_DOFS + j) = P.motor_strength[oj];
+            TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j) = lacol[(size_t)j * N];
+            TW(o.dof + TD_STR * GRX_MAX_DOFS + j) = mscol[(size_t)j * N];
         }
     }
     if (c < 8) {   // 8 anchor slots x (x, y, approach speed): one slot per lane (of the group's first eight)
@@ -943,20 +943,21 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     if (HF && P.measure_heights) {
         const float yaw_n = fmaxf(sqrtf(B.qz * B.qz + B.qw * B.qw), 1e-9f);
         const float yz = B.qz / yaw_n, yw = B.qw / yaw_n;
+        // (a lane's points are sampled WITHOUT a branch, the index clamped -- as the fused kernels' height_scan_share does: under `if (k < nh)`
+        //  every point re-fetched the raster's parameters from the parameter block behind its own branch, eight dependent scalar round trips)
+        const bool pub_h = act && P.publish_heights;
 #pragma unroll
-        for (int i = 0; i < HPL; ++i) {
-            const int k = c + i * TG;
-            if (k < nh) hraw[i] = height_sample(P, *P.tables, yz, yw, B.pos, k);
-        }
+        for (int i = 0; i < HPL; ++i) hraw[i] = height_sample(P, *P.tables, yz, yw, B.pos, min(c + i * TG, nh - 1));
 #pragma unroll
         for (int i = 0; i < HPL; ++i) {   // (summed in the order of the rolled loop)
             const int k = c + i * TG;
-            if (k < nh) { if (act && P.publish_heights) heights[(size_t)k * N] = hraw[i]; hsum += hraw[i]; }
+            if (k < nh) { if (pub_h) heights[(size_t)k * N] = hraw[i]; hsum += hraw[i]; } else hraw[i] = 0.f;
         }
         hsum = grp_sum(hsum);
     } else {
+        const bool pub_h = act && P.publish_heights;
 #pragma unroll
-        for (int i = 0; i < HPL; ++i) { const int k = c + i * TG; if (k < nh && act && P.publish_heights) heights[(size_t)k * N] = 0.f; }
+        for (int i = 0; i < HPL; ++i) { const int k = c + i * TG; if (k < nh && pub_h) heights[(size_t)k * N] = 0.f; }
     }
     if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {
         if (P.stash_pre_reset && actl) { P.pre_push_vel[e] = B.vel.x; P.pre_push_vel[(size_t)N + e] = B.vel.y; }   // (grx_refresh: link frames of the state BEFORE the push)
@@ -1218,13 +1219,15 @@ __global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu
     float bho = 0.f;
     {
         float sum = 0.f;
+        const float bht = P.base_height_target, osh = P.obs_scale_height;   // (fetched once, not behind every point's branch)
+        float* const prih = pri + nobs + 8;
 #pragma unroll
         for (int i = 0; i < HPL; ++i) {
             const int k = c + i * TG;
             if (k < nh) {
-                float d = B.pos.z - P.base_height_target - hraw[i];
-                d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
-                if (act) pri[nobs + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -clipo), clipo);
+                float d = B.pos.z - bht - hraw[i];
+                d = fminf(fmaxf(d, -1.f), 1.f) * osh;
+                if (act) prih[k] = fminf(fmaxf(d * osh, -clipo), clipo);
                 sum += d;
             }
         }
