@@ -157,6 +157,10 @@ GRX_DEV V3 tree_sphere(KP P, const TreeSph& S, V3 w, V3 v, V3 O, float mu, float
     V3 F = v3(0.f, 0.f, 0.f);
     const float wz = O.z + xr.z, r = S.r;
     const int slot = S.slot;
+    // the sphere's friction anchor (x, y, approach speed): requested up front, in one batch -- read where it is used, behind the nested
+    // branches below, each of its three words was a dependent LDS round trip (round 6)
+    const int sa = o.an + max(slot, 0) * 3;
+    const float an_x = TW(sa), an_y = TW(sa + 1), an_v = TW(sa + 2);
     bool touching = false;
     float vimp = 0.f;
     if (wz - r <= hmax) {
@@ -172,7 +176,7 @@ GRX_DEV V3 tree_sphere(KP P, const TreeSph& S, V3 w, V3 v, V3 O, float mu, float
             const float un = dot(u, n);
             float cd = fminf(P.kn * d * P.dn, S.dmax);
             if (slot >= 0) {   // restitution (sphere_contact's rule)
-                vimp = TW(o.an + slot * 3 + 2);
+                vimp = an_v;
                 if (vimp == 0.f) vimp = fmaxf(fmaxf(-un, 0.0f), 1e-6f);
                 if (un > 0.0f && vimp > P.bounce_threshold) cd *= om_e;
             }
@@ -180,8 +184,8 @@ GRX_DEV V3 tree_sphere(KP P, const TreeSph& S, V3 w, V3 v, V3 O, float mu, float
             F = n * fn;
             const float fmax = mu * fn;
             if (slot >= 0) {
-                float axx = TW(o.an + slot * 3), ayy = TW(o.an + slot * 3 + 1);
-                if (TW(o.an + slot * 3 + 2) == 0.f) { axx = wx; ayy = wy; }
+                float axx = an_x, ayy = an_y;
+                if (an_v == 0.f) { axx = wx; ayy = wy; }
                 float ftx = -P.kt * (wx - axx) - P.ct * u.x;
                 float fty = -P.kt * (wy - ayy) - P.ct * u.y;
                 const float ft = grx_sqrt(ftx * ftx + fty * fty);
