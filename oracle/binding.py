@@ -45,6 +45,7 @@ def load(precision="f32"):
         lib.gro_debug_body_pose.argtypes = [H, C.c_int, C.c_int, dp, dp]
         lib.gro_debug_link_forces.argtypes = [H, C.c_int, dp, C.c_int]
         lib.gro_debug_terrain.argtypes = [H, C.c_double, C.c_double, dp]
+        lib.gro_debug_wall.argtypes = [H, C.c_double, C.c_double, C.c_double, C.c_double, dp]
         lib.gro_debug_import_state.argtypes = [H]
         _libs[precision] = (lib, api)
     return _libs[precision]
@@ -102,6 +103,12 @@ class OracleSim(SimHandle):
         """physics terrain query: (height, dh/dx, dh/dy) at world (x, y)"""
         o, op = self._d(np.zeros(3))
         self._check(self.lib.gro_debug_terrain(self._h, float(x), float(y), op), "terrain")
+        return o.copy()
+
+    def wall(self, x, y, z, r):
+        """mesh_type 'trimesh': (overlap, nx, ny, nz) of a sphere with the vertical faces of the corrected mesh next to it"""
+        o, op = self._d(np.zeros(4))
+        self._check(self.lib.gro_debug_wall(self._h, float(x), float(y), float(z), float(r), op), "wall")
         return o.copy()
 
     def import_state(self):

@@ -291,6 +291,8 @@ struct grx_sim {
     int N, nd, nb;
     env_t* env;
     int16_t* hf;
+    int16_t* tm_cells;   /* mesh_type 'trimesh': [cell][6] ground corners of the reference's slope-corrected mesh under the cell's two triangle halves: (e00, e01, e11) where ty >= tx, (e00, e10, e11) where tx > ty; raster units */
+    int16_t* tm_walls;   /* [cell][8] tops of the vertical faces on the cell's sides (x-, x+, y-, y+) and of the posts at its corners (00, 10, 01, 11); TM_NONE = none */
     float* torigins;
     /* published float32 views (row-major) */
     float *t_obs, *t_pri, *t_rew;
@@ -309,26 +311,160 @@ struct grx_sim {
 };
 
 /* ------------------------------------------------------------------ terrain */
+/* mesh_type 'trimesh' (vertical_faces): the surface IS the reference's slope-corrected triangle mesh.
+ * convert_heightfield_to_trimesh (isaacgym terrain_utils.py:286-350, called by legged_robot.py:903-921) keeps the raster's heights
+ * and MOVES vertices by whole cells: a vertex whose +x / -x / +y / -y / diagonal neighbour stands more than slope_threshold above
+ * it goes under that neighbour (:313-325), so the low ground runs up to the high vertex's grid line and the face there is vertical.
+ * Every vertex of the corrected mesh is therefore still a grid point, and the mesh over one raster cell is described by two tables
+ * built once (trimesh_build):
+ *   tm_cells: the height of the top surface at the cell's four corners, approached from inside the cell -- the two planes found by
+ *     a vertical ray cast at the centroids of the cell's two triangle halves (split along the (0,0)-(1,1) diagonal like :335-347),
+ *     evaluated at the corners.  Exact wherever one plane covers each half: every undeformed cell, and every cell a flat tread was
+ *     stretched over (stairs, obstacles, stones, gaps, pits: tests/golden/trimesh_tiles.npz); where a SLOPED neighbour was stretched
+ *     over the cell its two-cell interpolation is kept at the corners and rounded to the raster unit.
+ *   tm_walls: the vertical faces (triangles whose projection is a segment of a grid line) that stand on the cell's four sides and,
+ *     as posts, the ends of faces that run away from its four corners; kept where they rise above the cell's own ground.
+ * terrain_query interpolates tm_cells per triangle half; wall_contact (below) is the sphere against the faces and posts. */
+#define TM_NONE INT16_MIN
+typedef struct { double x, y, z; } tmv_t;
+static void tm_vertex(const int16_t* H, const int8_t* mv, int C, int a, int b, tmv_t* v) {
+    size_t k = (size_t)a * C + b;
+    v->x = a + mv[2 * k]; v->y = b + mv[2 * k + 1]; v->z = H[k];
+}
+/* the two triangles of raster cell (a, b) in the reference's order (terrain_utils.py:339-347): (ind0, ind3, ind1), (ind0, ind2, ind3) */
+static void tm_triangle(const int16_t* H, const int8_t* mv, int C, int a, int b, int second, tmv_t t[3]) {
+    tm_vertex(H, mv, C, a, b, &t[0]);
+    if (!second) { tm_vertex(H, mv, C, a + 1, b + 1, &t[1]); tm_vertex(H, mv, C, a, b + 1, &t[2]); }
+    else { tm_vertex(H, mv, C, a + 1, b, &t[1]); tm_vertex(H, mv, C, a + 1, b + 1, &t[2]); }
+}
+/* vertical ray at the raster point (px, py): plane (z there, dz/dx, dz/dy) of the highest triangle hit; 0 if none */
+static int tm_plane_at(const int16_t* H, const int8_t* mv, int R, int C, double px, double py, double pl[3]) {
+    int ci = (int)floor(px), cj = (int)floor(py), found = 0;
+    for (int a = ci - 1; a <= ci + 1; ++a) {
+        if (a < 0 || a > R - 2) continue;
+        for (int b = cj - 1; b <= cj + 1; ++b) {
+            if (b < 0 || b > C - 2) continue;
+            for (int k = 0; k < 2; ++k) {
+                tmv_t t[3];
+                tm_triangle(H, mv, C, a, b, k, t);
+                double ux = t[1].x - t[0].x, uy = t[1].y - t[0].y, vx = t[2].x - t[0].x, vy = t[2].y - t[0].y;
+                double den = ux * vy - vx * uy;
+                if (fabs(den) < 1e-9) continue;   /* a vertical face */
+                double qx = px - t[0].x, qy = py - t[0].y;
+                double w1 = (qx * vy - vx * qy) / den, w2 = (ux * qy - qx * uy) / den;
+                if (w1 < -1e-9 || w2 < -1e-9 || 1 - w1 - w2 < -1e-9) continue;
+                double uz = t[1].z - t[0].z, vz = t[2].z - t[0].z;
+                double z = t[0].z + w1 * uz + w2 * vz;
+                if (!found || z > pl[0]) { pl[0] = z; pl[1] = (uz * vy - vz * uy) / den; pl[2] = (ux * vz - vx * uz) / den; found = 1; }
+            }
+        }
+    }
+    return found;
+}
+static int16_t tm_round(double z) { return (int16_t)lrint(z < -32767 ? -32767 : z > 32767 ? 32767 : z); }
+static void trimesh_build(struct grx_sim* s) {
+    const grx_config* c = &s->cfg;
+    const int R = c->hf_rows, C = c->hf_cols;
+    const int16_t* H = s->hf;
+    const size_t n = (size_t)R * C;
+    /* the vertex moves (terrain_utils.py:310-325): in double like numpy, threshold in raster units */
+    const double thr = (double)c->slope_threshold * ((double)c->horizontal_scale / (double)c->vertical_scale);
+    int8_t* mv = (int8_t*)calloc(2 * n, 1);
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            const int h = H[(size_t)i * C + j];
+#define TM_UP(di, dj) ((i + (di) >= 0 && i + (di) < R && j + (dj) >= 0 && j + (dj) < C && H[(size_t)(i + (di)) * C + j + (dj)] - h > thr) ? 1 : 0)
+            const int mx = TM_UP(1, 0) - TM_UP(-1, 0), my = TM_UP(0, 1) - TM_UP(0, -1), mc = TM_UP(1, 1) - TM_UP(-1, -1);
+#undef TM_UP
+            mv[2 * ((size_t)i * C + j)] = (int8_t)(mx + (mx == 0 ? mc : 0));
+            mv[2 * ((size_t)i * C + j) + 1] = (int8_t)(my + (my == 0 ? mc : 0));
+        }
+    /* ground corners, per triangle half (the surface may break along the cell's diagonal: a concave corner of a raised block leaves one
+     * half on the upper level and the other on the lower one) */
+    s->tm_cells = (int16_t*)malloc(6 * n * sizeof(int16_t));
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            const int i1 = i + 1 < R ? i + 1 : R - 1, j1 = j + 1 < C ? j + 1 : C - 1;
+            int16_t* e = s->tm_cells + 6 * ((size_t)i * C + j);
+            e[0] = e[3] = H[(size_t)i * C + j]; e[1] = H[(size_t)i * C + j1]; e[4] = H[(size_t)i1 * C + j]; e[2] = e[5] = H[(size_t)i1 * C + j1];
+            if (i > R - 2 || j > C - 2) continue;
+            double p[3];
+            const double x1 = i + 1.0 / 3, y1 = j + 2.0 / 3, x2 = i + 2.0 / 3, y2 = j + 1.0 / 3;   /* centroids of the halves ty >= tx, tx > ty */
+#define TM_AT(px, py, cx, cy) tm_round(p[0] + p[1] * ((cx) - (px)) + p[2] * ((cy) - (py)))
+            if (tm_plane_at(H, mv, R, C, x1, y1, p)) { e[0] = TM_AT(x1, y1, i, j); e[1] = TM_AT(x1, y1, i, j + 1); e[2] = TM_AT(x1, y1, i + 1, j + 1); }
+            if (tm_plane_at(H, mv, R, C, x2, y2, p)) { e[3] = TM_AT(x2, y2, i, j); e[4] = TM_AT(x2, y2, i + 1, j); e[5] = TM_AT(x2, y2, i + 1, j + 1); }
+#undef TM_AT
+        }
+    /* vertical faces: per unit segment of the grid lines x = X (segx[X][k]: y in [k, k + 1]) and y = Y (segy[Y][k]: x in [k, k + 1]) the
+     * top of the faces on it AT ITS TWO ENDS ([0]: at k, [1]: at k + 1) -- where three levels meet, the vertices the reference slides along a
+     * face leave it triangular (a top running down to the lower level within one cell) */
+    int16_t* segx = (int16_t*)malloc(2 * n * sizeof(int16_t));
+    int16_t* segy = (int16_t*)malloc(2 * n * sizeof(int16_t));
+    for (size_t k = 0; k < 2 * n; ++k) segx[k] = segy[k] = TM_NONE;
+    for (int a = 0; a < R - 1; ++a)
+        for (int b = 0; b < C - 1; ++b)
+            for (int k = 0; k < 2; ++k) {
+                tmv_t t[3];
+                tm_triangle(H, mv, C, a, b, k, t);
+                const double den = (t[1].x - t[0].x) * (t[2].y - t[0].y) - (t[2].x - t[0].x) * (t[1].y - t[0].y);
+                if (fabs(den) > 1e-9) continue;
+                if (fmax(t[0].z, fmax(t[1].z, t[2].z)) <= fmin(t[0].z, fmin(t[1].z, t[2].z))) continue;
+                const int along_y = t[0].x == t[1].x && t[0].x == t[2].x, along_x = t[0].y == t[1].y && t[0].y == t[2].y;
+                if (along_y == along_x) continue;   /* a needle, or a face across the grid (not produced by axis-aligned steps) */
+                const int L = (int)(along_y ? t[0].x : t[0].y);
+                double sp[3];   /* position along the line */
+                for (int q = 0; q < 3; ++q) sp[q] = along_y ? t[q].y : t[q].x;
+                const int lo = (int)fmin(sp[0], fmin(sp[1], sp[2])), hi = (int)fmax(sp[0], fmax(sp[1], sp[2]));
+                if (hi <= lo) continue;   /* a needle */
+                int16_t* seg = along_y ? segx : segy;
+                const int nl = along_y ? R : C, ns = along_y ? C - 1 : R - 1, stride = along_y ? C : R;
+                if (L < 0 || L >= nl) continue;
+                for (int q = lo < 0 ? 0 : lo; q < hi && q < ns; ++q)
+                    for (int end = 0; end < 2; ++end) {
+                        const double at = q + end;
+                        double top = -1e30;   /* the highest point of the triangle over `at` */
+                        for (int m_ = 0; m_ < 3; ++m_) {
+                            const int m2 = (m_ + 1) % 3;
+                            if (at < fmin(sp[m_], sp[m2]) || at > fmax(sp[m_], sp[m2])) continue;
+                            const double z = sp[m_] == sp[m2] ? fmax(t[m_].z, t[m2].z) : t[m_].z + (t[m2].z - t[m_].z) * (at - sp[m_]) / (sp[m2] - sp[m_]);
+                            if (z > top) top = z;
+                        }
+                        int16_t* o = seg + 2 * ((size_t)L * stride + q) + end;
+                        if (top > -1e29 && tm_round(top) > *o) *o = tm_round(top);
+                    }
+            }
+    s->tm_walls = (int16_t*)malloc(8 * n * sizeof(int16_t));
+#define SEGX(X, k, end) (((X) >= 0 && (X) < R && (k) >= 0 && (k) < C - 1) ? segx[2 * ((size_t)(X) * C + (k)) + (end)] : TM_NONE)
+#define SEGY(Y, k, end) (((Y) >= 0 && (Y) < C && (k) >= 0 && (k) < R - 1) ? segy[2 * ((size_t)(Y) * R + (k)) + (end)] : TM_NONE)
+#define MIN2(a_, b_) ((a_) < (b_) ? (a_) : (b_))
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            const int16_t* e = s->tm_cells + 6 * ((size_t)i * C + j);
+            int16_t* w = s->tm_walls + 8 * ((size_t)i * C + j);
+#define MAX2(a_, b_) ((a_) > (b_) ? (a_) : (b_))
+            /* a side's face: the rectangle up to the lower of its two end tops (TM_NONE when an end has none) */
+            const int16_t side[4] = {MIN2(SEGX(i, j, 0), SEGX(i, j, 1)), MIN2(SEGX(i + 1, j, 0), SEGX(i + 1, j, 1)),
+                                     MIN2(SEGY(j, i, 0), SEGY(j, i, 1)), MIN2(SEGY(j + 1, i, 0), SEGY(j + 1, i, 1))};
+            /* the cell's own ground along the side: x- and y+ bound the half ty >= tx, x+ and y- the half tx > ty */
+            const int16_t ground[4] = {MAX2(e[0], e[1]), MAX2(e[4], e[5]), MAX2(e[3], e[4]), MAX2(e[1], e[2])};
+            for (int q = 0; q < 4; ++q) w[q] = side[q] > ground[q] ? side[q] : TM_NONE;
+            /* posts: faces that run AWAY from a corner along either grid line through it */
+            const int16_t pa[4] = {SEGX(i, j - 1, 1), SEGX(i + 1, j - 1, 1), SEGX(i, j + 1, 0), SEGX(i + 1, j + 1, 0)};
+            const int16_t pb[4] = {SEGY(j, i - 1, 1), SEGY(j, i + 1, 0), SEGY(j + 1, i - 1, 1), SEGY(j + 1, i + 1, 0)};
+            const int16_t pg[4] = {MAX2(e[0], e[3]), e[4], e[1], MAX2(e[2], e[5])};   /* corners 00, 10, 01, 11 */
+            for (int q = 0; q < 4; ++q) { const int16_t t_ = MAX2(pa[q], pb[q]); w[4 + q] = t_ > pg[q] ? t_ : TM_NONE; }
+#undef MAX2
+        }
+#undef SEGX
+#undef SEGY
+#undef MIN2
+    free(segx); free(segy); free(mv);
+}
+
 /* Physics terrain query: height under (x, y) and the gradient of the surface there (g[2] = dh/dx, dh/dy).
  *  - heightfield: bilinear patch of the int16 raster.
- *  - trimesh (vertical_faces): the reference's convert_heightfield_to_trimesh (isaacgym terrain_utils.py:286-350) moves a
- *    low vertex next to a step steeper than slope_threshold under the high one: the low ground runs up to the HIGH vertex's
- *    grid line and the face there is vertical.  A height function cannot hold a vertical face; along an axis whose raster
- *    step exceeds the threshold the interpolation weight is therefore sharpened to a ramp over the last quarter cell
- *    before the high vertex (2.5 cm at the default 0.1 m raster) -- with the surface normal from the gradient, the riser
- *    pushes back horizontally like the wall it stands for. */
-#define RISER_BAND ((real)0.25)
-static real sharpen(real t, real lo, real hi, real thr, real* dt) {
-    /* weight of the far vertex (value hi) along one axis; lo = near vertex value; *dt = d weight / d t */
-    *dt = 1;
-    if (hi - lo > thr) { if (t <= 1 - RISER_BAND) { *dt = 0; return 0; } *dt = 1 / RISER_BAND; return (t - (1 - RISER_BAND)) / RISER_BAND; }
-    if (lo - hi > thr) { if (t >= RISER_BAND) { *dt = 0; return 1; } *dt = 1 / RISER_BAND; return t / RISER_BAND; }
-    return t;
-}
-static real terrain_query(const struct grx_sim* s, real x, real y, real g[2]) {
-    const grx_config* c = &s->cfg;
-    g[0] = 0; g[1] = 0;
-    if (c->terrain_type == GRX_TERRAIN_PLANE) return 0;
+ *  - trimesh: the triangle half of the cell under the point, on the corrected mesh's corner heights (tm_cells). */
+static int terrain_locate(const grx_config* c, real x, real y, real* tx, real* ty) {
     real fx = (x + c->border_size) / c->horizontal_scale;
     real fy = (y + c->border_size) / c->horizontal_scale;
     if (fx < 0) fx = 0;
@@ -338,24 +474,58 @@ static real terrain_query(const struct grx_sim* s, real x, real y, real g[2]) {
     int ix = (int)fx, iy = (int)fy;
     if (ix > c->hf_rows - 2) ix = c->hf_rows - 2;
     if (iy > c->hf_cols - 2) iy = c->hf_cols - 2;
-    real tx = fx - ix, ty = fy - iy;
-    const int16_t* H = s->hf;
-    int C = c->hf_cols;
-    real h00 = H[ix * C + iy], h10 = H[(ix + 1) * C + iy], h01 = H[ix * C + iy + 1], h11 = H[(ix + 1) * C + iy + 1];
-    real dtx = 1, dty = 1;
+    *tx = fx - ix; *ty = fy - iy;
+    return ix * c->hf_cols + iy;
+}
+static real terrain_query(const struct grx_sim* s, real x, real y, real g[2]) {
+    const grx_config* c = &s->cfg;
+    g[0] = 0; g[1] = 0;
+    if (c->terrain_type == GRX_TERRAIN_PLANE) return 0;
+    real tx, ty;
+    const int cell = terrain_locate(c, x, y, &tx, &ty);
+    const int C = c->hf_cols;
+    const real sc = c->vertical_scale / c->horizontal_scale;
     if (c->vertical_faces) {
-        real thr = c->slope_threshold * c->horizontal_scale / c->vertical_scale;   /* in raster units */
-        /* the steeper of the cell's two edges along an axis decides for the cell */
-        real ax0 = h10 - h00, ax1 = h11 - h01, ay0 = h01 - h00, ay1 = h11 - h10;
-        real ax = fabs(ax0) > fabs(ax1) ? ax0 : ax1, ay = fabs(ay0) > fabs(ay1) ? ay0 : ay1;
-        tx = sharpen(tx, 0, ax, thr, &dtx);
-        ty = sharpen(ty, 0, ay, thr, &dty);
+        const int16_t* e = s->tm_cells + 6 * (size_t)cell + (ty >= tx ? 0 : 3);
+        const real e00 = e[0], e11 = e[2];
+        real h;
+        if (ty >= tx) { g[0] = e11 - e[1]; g[1] = e[1] - e00; }
+        else { g[0] = e[1] - e00; g[1] = e11 - e[1]; }
+        h = e00 + g[0] * tx + g[1] * ty;
+        g[0] *= sc; g[1] *= sc;
+        return h * c->vertical_scale;
     }
+    const int16_t* H = s->hf;
+    real h00 = H[cell], h10 = H[cell + C], h01 = H[cell + 1], h11 = H[cell + C + 1];
     real h = (h00 * (1 - tx) + h10 * tx) * (1 - ty) + (h01 * (1 - tx) + h11 * tx) * ty;
-    real sc = c->vertical_scale / c->horizontal_scale;
-    g[0] = ((h10 - h00) * (1 - ty) + (h11 - h01) * ty) * dtx * sc;
-    g[1] = ((h01 - h00) * (1 - tx) + (h11 - h10) * tx) * dty * sc;
+    g[0] = ((h10 - h00) * (1 - ty) + (h11 - h01) * ty) * sc;
+    g[1] = ((h01 - h00) * (1 - tx) + (h11 - h10) * tx) * sc;
     return h * c->vertical_scale;
+}
+/* mesh_type 'trimesh': the deepest overlap of a sphere (centre x, radius r) with the vertical faces on the sides of the raster cell
+ * under its centre and with the posts at that cell's corners (tm_walls).  A face spans its whole side, from the ground up to its top;
+ * the closest point on it is at the centre's own position along the side and at min(centre height, top) -- above the top the contact
+ * is with the face's upper edge.  Returns the overlap (<= 0: none) and the unit direction n from the closest point to the centre. */
+static real wall_overlap(const struct grx_sim* s, const real x[3], real r, real n[3]) {
+    const grx_config* c = &s->cfg;
+    real tx, ty;
+    const int cell = terrain_locate(c, x[0], x[1], &tx, &ty);
+    const int16_t* w = s->tm_walls + 8 * (size_t)cell;
+    const real hs = c->horizontal_scale;
+    const real dx[2] = {tx * hs, (tx - 1) * hs}, dy[2] = {ty * hs, (ty - 1) * hs};   /* from the low / high grid line to the centre */
+    real best = 0;
+    for (int q = 0; q < 8; ++q) {
+        if (w[q] == TM_NONE) continue;
+        real d[3];
+        if (q < 2) { d[0] = dx[q]; d[1] = 0; }
+        else if (q < 4) { d[0] = 0; d[1] = dy[q - 2]; }
+        else { d[0] = dx[(q - 4) & 1]; d[1] = dy[(q - 4) >> 1]; }
+        d[2] = x[2] - w[q] * c->vertical_scale;
+        if (d[2] < 0) d[2] = 0;
+        const real dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        if (r - dist > best && dist > (real)1e-9) { best = r - dist; for (int j = 0; j < 3; ++j) n[j] = d[j] / dist; }
+    }
+    return best;
 }
 
 /* legged_robot.py:1235-1274 _get_heights */
@@ -469,19 +639,19 @@ static void contact_forces(const struct grx_sim* s, env_t* e, const kin_t* k, sv
         real g[2];
         real h = terrain_query(s, x[0], x[1], g);
         real dv = h + m->sph_radius[i] - x[2];   /* vertical overlap */
-        if (dv <= 0) {
-            if (slot >= 0) e->anchor_on[slot] = 0;
-            continue;
-        }
-        /* surface normal from the gradient of the patch; overlap along it (locally planar terrain) */
-        real nn = 1 / sqrt(1 + g[0] * g[0] + g[1] * g[1]);
-        real n[3] = {-g[0] * nn, -g[1] * nn, nn};
-        real d = dv * nn;
+        real F[3] = {0, 0, 0};
         /* sphere-centre velocity, world */
         real wxs[3], ub[3], u[3];
         v3_cross(k->v[b].v, sb, wxs);
         for (int j = 0; j < 3; ++j) ub[j] = k->v[b].v[3 + j] + wxs[j];
         m3_mulv(k->R[b], ub, u);
+        if (dv <= 0) {
+            if (slot >= 0) e->anchor_on[slot] = 0;
+        } else {
+        /* surface normal from the gradient of the patch; overlap along it (locally planar terrain) */
+        real nn = 1 / sqrt(1 + g[0] * g[0] + g[1] * g[1]);
+        real n[3] = {-g[0] * nn, -g[1] * nn, nn};
+        real d = dv * nn;
         real un = u[0] * n[0] + u[1] * n[1] + u[2] * n[2];   /* > 0: separating */
         /* Hunt-Crossley damping kn*d*dn, capped by the mass-aware bound that keeps explicit
          * integration of the (light) foot stable; normal force never pulls */
@@ -501,7 +671,7 @@ static void contact_forces(const struct grx_sim* s, env_t* e, const kin_t* k, sv
         }
         real fn = cp->kn * d - cd * un;
         if (fn < 0) fn = 0;
-        real F[3] = {fn * n[0], fn * n[1], fn * n[2]};
+        for (int j = 0; j < 3; ++j) F[j] = fn * n[j];
         /* friction: in the horizontal plane (anchored stick/slip on the foot spheres, viscous-capped elsewhere) */
         if (slot >= 0 && slot < NFS) {
             real ftx = -cp->kt * (x[0] - e->anchor[slot][0]) - cp->ct * u[0];
@@ -520,6 +690,26 @@ static void contact_forces(const struct grx_sim* s, env_t* e, const kin_t* k, sv
             if (ft > fmax) ft = fmax;
             if (sp > (real)1e-9) { F[0] -= ft * u[0] / sp; F[1] -= ft * u[1] / sp; }
         }
+        }
+        /* mesh_type 'trimesh': the vertical faces of the corrected mesh next to the sphere (wall_overlap) -- the same normal law,
+         * friction viscous and capped by the cone in the face's tangent plane; one contact, the deepest */
+        if (c->terrain_type == GRX_TERRAIN_HEIGHTFIELD && c->vertical_faces) {
+            real n[3];
+            const real d = wall_overlap(s, x, m->sph_radius[i], n);
+            if (d > 0) {
+                const real un = u[0] * n[0] + u[1] * n[1] + u[2] * n[2];
+                real cd = cp->kn * d * cp->dn;
+                if (cd > m->sph_damp_max[i]) cd = m->sph_damp_max[i];
+                real fn = cp->kn * d - cd * un;
+                if (fn < 0) fn = 0;
+                real ut[3] = {u[0] - un * n[0], u[1] - un * n[1], u[2] - un * n[2]};
+                const real sp = sqrt(ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]);
+                real ft = cp->cv * sp;
+                if (ft > mu * fn) ft = mu * fn;
+                for (int j = 0; j < 3; ++j) F[j] += fn * n[j] - (sp > (real)1e-9 ? ft * ut[j] / sp : 0);
+            }
+        }
+        if (F[0] == 0 && F[1] == 0 && F[2] == 0) continue;
         int L = m->sph_link[i];
         for (int j = 0; j < 3; ++j) e->link_force[L][j] += F[j];
         if (fl & GRX_SPH_FOOT_LEFT) for (int j = 0; j < 3; ++j) e->feet_force[0][j] += F[j];
@@ -1357,6 +1547,7 @@ int gro_create(const grx_config* cfg, int device_id, grx_handle* out) {
         size_t n = (size_t)cfg->hf_rows * cfg->hf_cols;
         s->hf = (int16_t*)malloc(n * sizeof(int16_t));
         memcpy(s->hf, cfg->height_samples, n * sizeof(int16_t));
+        if (cfg->vertical_faces) trimesh_build(s);
         size_t no = (size_t)cfg->num_terrain_rows * cfg->num_terrain_cols * 3;
         s->torigins = (float*)malloc(no * sizeof(float));
         memcpy(s->torigins, cfg->terrain_origins, no * sizeof(float));
@@ -1441,7 +1632,7 @@ int gro_destroy(grx_handle s) {
     if (!s) return GRX_OK;
     for (int id = 0; id < GRX_NUM_TENSORS; ++id) { free(s->scratch[id]); free(s->scratch_u8[id]); free(s->scratch_i32[id]); }
     free(s->t_obs); free(s->t_pri); free(s->t_rew); free(s->t_reset); free(s->t_timeout); free(s->t_eplen); free(s->t_rbs);
-    free(s->hf); free(s->torigins); free(s->env); free(s);
+    free(s->hf); free(s->tm_cells); free(s->tm_walls); free(s->torigins); free(s->env); free(s);
     return GRX_OK;
 }
 
@@ -1746,6 +1937,16 @@ int gro_debug_terrain(grx_handle s, double x, double y, double* out) {
     real g[2];
     out[0] = terrain_query(s, (real)x, (real)y, g);
     out[1] = g[0]; out[2] = g[1];
+    return GRX_OK;
+}
+
+/* mesh_type 'trimesh': overlap of a sphere (centre x y z, radius r) with the vertical faces next to it: out = {overlap, nx, ny, nz} (0 0 0 0: none) */
+int gro_debug_wall(grx_handle s, double x, double y, double z, double r, double* out) {
+    real n[3] = {0, 0, 0}, c[3] = {(real)x, (real)y, (real)z};
+    real d = 0;
+    if (s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD && s->cfg.vertical_faces) d = wall_overlap(s, c, (real)r, n);
+    out[0] = d > 0 ? d : 0;
+    for (int j = 0; j < 3; ++j) out[1 + j] = d > 0 ? n[j] : 0;
     return GRX_OK;
 }
 

@@ -194,6 +194,71 @@ def check_trimesh_surface(query, name, tol):
     return float(inb.mean()), float(dev[~inb].max())
 
 
+def _closest_point_on_triangles(p, a, b, c):
+    """closest point of each triangle (a, b, c: (n, 3)) to the point p (3,): Ericson's region walk, vectorised over the triangles"""
+    ab, ac, ap = b - a, c - a, p - a
+    d1, d2 = (ab * ap).sum(1), (ac * ap).sum(1)
+    bp = p - b; d3, d4 = (ab * bp).sum(1), (ac * bp).sum(1)
+    cp = p - c; d5, d6 = (ab * cp).sum(1), (ac * cp).sum(1)
+    vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+    out, done = np.zeros_like(a), np.zeros(len(a), bool)
+
+    def take(m, val):
+        m = m & ~done
+        out[m] = val[m]
+        done[m] = True
+    with np.errstate(all="ignore"):
+        take((d1 <= 0) & (d2 <= 0), a)
+        take((d3 >= 0) & (d4 <= d3), b)
+        take((vc <= 0) & (d1 >= 0) & (d3 <= 0), a + (d1 / (d1 - d3))[:, None] * ab)
+        take((d6 >= 0) & (d5 <= d6), c)
+        take((vb <= 0) & (d2 >= 0) & (d6 <= 0), a + (d2 / (d2 - d6))[:, None] * ac)
+        take((va <= 0) & (d4 - d3 >= 0) & (d5 - d6 >= 0), b + ((d4 - d3) / ((d4 - d3) + (d5 - d6)))[:, None] * (c - b))
+        den = 1 / (va + vb + vc)
+        take(np.ones(len(a), bool), a + ab * (vb * den)[:, None] + ac * (vc * den)[:, None])
+    return out
+
+
+def check_trimesh_walls(ground, wall, name, tol, n_points=4000):
+    """`wall(x, y, z, r) -> (overlap, nx, ny, nz)` of the build (oracle or HIP) against the REFERENCE mesh's vertical faces: the triangles of
+    tests/golden/trimesh_tiles.npz whose projection is a segment.  For spheres of radius 4 cm resting up to 12 cm above the build's ground at random
+    places, the true overlap is r - (distance to the closest such triangle whose closest point stands above the ground under the centre).
+    The build keeps, per raster cell, the faces on the cell's four sides as rectangles and the ends of faces at its four corners as posts
+    (oracle trimesh_build / csrc/grx_capi.cpp build_trimesh_tables); what that cannot hold -- the notch the corrected mesh leaves along a cell's
+    diagonal at a concave corner, the triangular fins where three levels meet -- is a bounded fraction of the contacts, counted here."""
+    cfg, ter, blk, v, t = _trimesh_tile(name)
+    a, b, c = v[t[:, 0]], v[t[:, 1]], v[t[:, 2]]
+    den = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (c[:, 0] - a[:, 0]) * (b[:, 1] - a[:, 1])
+    vert = (np.abs(den) < 1e-9) & (np.linalg.norm(np.cross(b - a, c - a), axis=1) > 1e-9)
+    A, B, Cc = a[vert], b[vert], c[vert]
+    assert vert.sum() > 500
+    rng = np.random.default_rng(2)
+    pts = rng.uniform(0.3, 7.7, (n_points, 2))
+    lift = rng.uniform(0.0, 0.12, n_points)
+    r = 0.04
+    g = np.asarray(ground(pts), dtype=np.float64)
+    got = np.asarray(wall(np.column_stack([pts, g + lift, np.full(n_points, r)])), dtype=np.float64)
+    touching = both = wrong = 0
+    for k, (x, y) in enumerate(pts):
+        p = np.array([x, y, g[k] + lift[k]])
+        near = (np.abs(A[:, 0] - x) < 0.25) & (np.abs(A[:, 1] - y) < 0.25)
+        d_ref, n_ref = 0.0, np.zeros(3)
+        if near.any():
+            q = _closest_point_on_triangles(p, A[near], B[near], Cc[near])
+            dist = np.linalg.norm(q - p, axis=1)
+            ok = (q[:, 2] > g[k] + 1e-4) & (dist > 1e-9)
+            if ok.any() and r - dist[ok].min() > 0:
+                m = np.argmin(np.where(ok, dist, 1e9))
+                d_ref, n_ref = r - dist[m], (p - q[m]) / dist[m]
+        if d_ref > 0 or got[k, 0] > 0:
+            touching += 1
+            if abs(got[k, 0] - d_ref) <= tol and (d_ref == 0 or np.abs(got[k, 1:] - n_ref).max() <= 1e-3 + 50 * tol / r):
+                both += 1
+            else:
+                wrong += 1
+    return touching, both, wrong
+
+
 @pytest.mark.parametrize("name", ["stairs", "obstacles"])
 def test_trimesh_surface_against_the_reference_mesh(name):
     from oracle.binding import OracleSim
