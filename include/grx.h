@@ -489,6 +489,12 @@ int grx_debug_post_physics(grx_handle h, const grx_pipeline_state* states, int a
  * reference's slope-corrected triangle mesh (isaacgym terrain_utils.py:286-350) against both. */
 int grx_debug_terrain(grx_handle h, const float* xy, int32_t n, float* out, void* stream);
 
+/* TEST-ONLY: mesh_type 'trimesh' -- the step kernels' contact of a sphere at rest with the VERTICAL FACES of the reference's slope-corrected mesh next to
+ * it: xyzr HOST float[n][4] (centre in world coordinates, radius), out HOST float[n][3] = overlap times the unit direction from the face to the
+ * centre (0 0 0: no face within reach).  The oracle's twin is gro_debug_wall; tests/test_terrain_golden.py measures both against the mesh's own
+ * vertical triangles. */
+int grx_debug_wall(grx_handle h, const float* xyzr, int32_t n, float* out, void* stream);
+
 /* TEST-ONLY: the wave pipelines of the step kernels hand over through LDS flags and spin on them.  A library built
  * with -DGRX_SPIN_LIMIT (csrc/variants/libgrx_spinlimit.so) bounds every spin; an expired one stores 'SP' << 48 | block << 32 | LDS
  * address of the flag << 16 | value waited for in a host-pinned word and traps.  *code = that word (0: none expired; readable after

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from tests.helpers import lockstep, make_cfg, make_sims, random_actions, sync_state, tensor_diff
-from tests.test_hip_parity import assert_phys, physics_lockstep
+from tests.test_hip_parity import assert_phys, count_wall_contacts, physics_lockstep, stairs_tile_scene
 
 pytestmark = pytest.mark.gpu
 KERNELS = pytest.mark.parametrize("kernel", ["tree", "tree16", "generic"])   # tree: 8 lanes per env (grx_tree.h), tree16: 16 (grx_tree16.hip)
@@ -308,4 +308,21 @@ def test_full_body_self_collision_against_the_oracle(kernel, monkeypatch):
     assert seen["missed"] == 0 and seen["extra"] <= seen["entries"] // 100, seen           # no loaded link of the oracle is missing on the GPU (observed: 0 / 0)
     q50, q99, top = (float(rel.quantile(x)) for x in (0.5, 0.99, 1.0))
     assert q50 < 1e-3 and q99 < 3e-2 and top < 0.2, (q50, q99, top)                         # (observed: 1.2e-4 / 5.4e-3 / 2.2e-2 on all three kernels; 10 sub-steps of stiff contact)
+    hip.close()
+
+
+@KERNELS
+def test_full_body_on_trimesh_stairs_with_vertical_face_contacts(kernel, monkeypatch):
+    """tests/test_hip_parity.test_trimesh_stairs_with_vertical_face_contacts for the 32-DOF body: the tree kernels (tree_contacts: wall_gather /
+    wall_contact next to tree_sphere) and the generic kernel (gen_sphere) against the oracle on the reference's stairs tile."""
+    pick(monkeypatch, kernel)
+    N = 192
+    cfg, ter, place = stairs_tile_scene(N=N, task="GR1T1Full")
+    hip, ora = make_sims(cfg, N, seed=2, terrain=ter)
+    hip.reset_all(); ora.reset_all()
+    place(hip, ora)
+    seen = {"ora": 0, "hip": 0}
+    worst = physics_lockstep(hip, ora, cfg, steps=16, scale=0.3, check=count_wall_contacts(seen))
+    assert seen["ora"] > 150 and abs(seen["hip"] - seen["ora"]) <= 0.08 * seen["ora"], seen
+    assert_phys(worst, exact_frac=1e-2, scale=FULL_BODY_SCALE_ROUGH, hf=True, full_body=True)
     hip.close()

@@ -383,6 +383,60 @@ def test_one_step_parity_rough_terrain(task, mesh):
     assert mh[1] < 2e-3
 
 
+def stairs_tile_scene(N=256, seed=7, task="GR1T1"):
+    """The pyramid-stairs tile of tests/golden/trimesh_tiles.npz (the reference's raster; steps of 0.165 m every three cells) as a 1 x 1 'trimesh'
+    terrain with friction 0.05 -- on it a horizontal contact force beyond the cone can only come from a VERTICAL FACE --, the robots spread over
+    the tile, 0.93 m above the ground under them, moving at 1.2 m/s in random directions.  Returns cfg, the terrain, and the state setter."""
+    from tests.test_terrain_golden import _trimesh_tile
+    _, ter, _, _, _ = _trimesh_tile("stairs")
+    cfg = make_cfg(task=task, terrain="trimesh", curriculum=False, dr=True, push=False)
+    cfg.terrain.border_size = 0.0
+    cfg.terrain.num_rows = cfg.terrain.num_cols = 1
+    cfg.terrain.static_friction = cfg.terrain.dynamic_friction = 0.05
+    cfg.domain_rand.randomize_friction = True
+    cfg.domain_rand.friction_range = [0.05, 0.05]
+
+    def place(hip, ora):
+        g = torch.Generator().manual_seed(seed)
+        root = ora.tensor("ROOT_STATES").clone()
+        xy = 1.0 + 6.0 * torch.rand(N, 2, generator=g)
+        root[:, 0:2] = xy
+        for i in range(N):
+            root[i, 2] = float(ora.terrain(float(xy[i, 0]), float(xy[i, 1]))[0]) + 0.93
+        ang = 6.2832 * torch.rand(N, generator=g)
+        root[:, 7] = 1.2 * torch.cos(ang); root[:, 8] = 1.2 * torch.sin(ang); root[:, 9:13] = 0
+        q = ora.tensor("DOF_POS").clone()
+        for s_ in (hip, ora):
+            s_.set_state(root.to(s_.device).contiguous(), q.to(s_.device).contiguous(), torch.zeros_like(q).to(s_.device))
+    return cfg, ter, place
+
+
+def count_wall_contacts(seen):
+    def check(s, hip_, ora_):
+        for name, sim_ in (("ora", ora_), ("hip", hip_)):
+            f = sim_.tensor("CONTACT_FORCES").cpu()
+            seen[name] += int((f[..., :2].norm(dim=-1) > 0.3 * f[..., 2].abs() + 5.0).any(1).sum())   # (beyond the friction cone of mu = 0.05: a face pushes)
+    return check
+
+
+@pytest.mark.parametrize("waves", [1, 8, "quad"])
+def test_trimesh_stairs_with_vertical_face_contacts(waves, monkeypatch):
+    """mesh_type 'trimesh' = the reference's corrected mesh (legged_robot.py:903-921): ground planes per triangle half AND vertical faces.  Robots
+    stumbling over a stairs tile -- feet against risers, falls onto edges -- on the fused kernels (foot spheres: wall_pass in foot_contacts; the
+    other shapes: grx_rare.h) against the oracle from identical state, step by step."""
+    set_layout(monkeypatch, waves)
+    N = 256
+    cfg, ter, place = stairs_tile_scene(N=N)
+    hip, ora = make_sims(cfg, N, seed=2, terrain=ter)
+    hip.reset_all(); ora.reset_all()
+    place(hip, ora)
+    seen = {"ora": 0, "hip": 0}
+    worst = physics_lockstep(hip, ora, cfg, steps=20, check=count_wall_contacts(seen))
+    assert seen["ora"] > 400 and abs(seen["hip"] - seen["ora"]) <= 0.05 * seen["ora"], seen     # (the oracle alone: 545 env-steps with a face contact)
+    assert_phys(worst, scale=3.0, hf=True)
+    hip.close()
+
+
 def test_contact_forces_of_every_link():
     """GRX_T_CONTACT_FORCES (the reference's contact_forces, legged_robot.py:117): net force per URDF link on the last
     sub-step, against the oracle's per-link forces, with robots driven to the ground so that base-lump links (torso,

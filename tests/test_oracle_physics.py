@@ -282,11 +282,17 @@ def test_stair_riser_is_a_ramp_on_the_heightfield_and_a_wall_on_the_trimesh():
     hs[20:, :] = 40                      # a 0.2 m step (vertical_scale 0.005) between rows 19 and 20: x in [1.9, 2.0]
     hf, _, _ = _terrain_sim(hs, "heightfield")
     tm, _, _ = _terrain_sim(hs, "trimesh")
-    for x, want_hf, want_tm in ((1.85, 0.0, 0.0), (1.92, 0.04, 0.0), (1.95, 0.10, 0.0), (1.974, 0.148, 0.0), (1.99, 0.18, 0.12), (2.02, 0.2, 0.2)):
+    for x, want_hf, want_tm in ((1.85, 0.0, 0.0), (1.92, 0.04, 0.0), (1.95, 0.10, 0.0), (1.974, 0.148, 0.0), (1.99, 0.18, 0.0), (1.9999, 0.1998, 0.0), (2.0001, 0.2, 0.2), (2.02, 0.2, 0.2)):
         np.testing.assert_allclose(hf.terrain(x, 1.0)[0], want_hf, atol=1e-6)
         np.testing.assert_allclose(tm.terrain(x, 1.0)[0], want_tm, atol=1e-6)
-    # gradient: 2 on the heightfield ramp, 0 in front of the trimesh wall and 8 (= 0.2 m over 2.5 cm) on its face
-    assert abs(hf.terrain(1.95, 1.0)[1] - 2.0) < 1e-6 and tm.terrain(1.95, 1.0)[1] == 0.0 and abs(tm.terrain(1.99, 1.0)[1] - 8.0) < 1e-6
+    # gradient: 2 on the heightfield ramp; the trimesh ground is level on both sides of the face ...
+    assert abs(hf.terrain(1.95, 1.0)[1] - 2.0) < 1e-6 and tm.terrain(1.95, 1.0)[1] == 0.0 and tm.terrain(1.99, 1.0)[1] == 0.0
+    # ... and the face itself is a contact of its own: a sphere of radius 4 cm, 1.5 cm in front of it, overlaps it by 2.5 cm along -x;
+    # above the face's top (z = 0.2) the contact is with its upper edge; from the upper level there is no face
+    np.testing.assert_allclose(tm.wall(1.985, 1.0, 0.05, 0.04), [0.025, -1, 0, 0], atol=1e-6)
+    d = np.hypot(0.015, 0.02)
+    np.testing.assert_allclose(tm.wall(1.985, 1.0, 0.22, 0.04), [0.04 - d, -0.015 / d, 0, 0.02 / d], atol=1e-6)
+    assert tm.wall(1.95, 1.0, 0.05, 0.04)[0] == 0.0 and tm.wall(2.01, 1.0, 0.22, 0.04)[0] == 0.0 and hf.wall(1.985, 1.0, 0.05, 0.04)[0] == 0.0
     # a gentle slope (0.4) is below the threshold: identical in both modes
     ramp = (np.arange(40)[:, None] * 8 * np.ones((1, 40))).astype(np.int16)      # 8 units = 0.04 m per 0.1 m
     a, _, _ = _terrain_sim(ramp, "heightfield"); b, _, _ = _terrain_sim(ramp, "trimesh")
@@ -314,8 +320,8 @@ def test_a_foot_is_stopped_by_a_trimesh_riser():
         out[mesh] = (fx_min, max(x_feet), sim.tensor("FEET_POS")[0, :, 2].max().item())
     toe = 0.15          # foremost sole sphere centre ahead of the foot link origin (URDF: x = 0.05 + 0.12 - 0.02)
     tm_toe, hf_toe = out["trimesh"][1] + toe, out["heightfield"][1] + toe
-    # trimesh: the toe sphere runs on the low ground right up to the face at x = 3.0 (the ramp band is its last 2.5 cm) and stops
-    assert 2.96 < tm_toe < 3.0 and out["trimesh"][0] < -50.0, out
+    # trimesh: the toe sphere (radius 3 cm) runs on the low ground until it touches the face at x = 3.0 and stops there
+    assert 2.96 < tm_toe < 3.0 and out["trimesh"][0] < -20.0, out   # (the feet, already braked by the legs, lose their last 0.3 m/s against the face: -30 N at a policy step's end)
     # heightfield: the one-cell ramp starts at x = 2.9: the toe is caught there, 7-8 cm earlier, and lifted
     assert hf_toe < tm_toe - 0.05 and out["heightfield"][0] < -50.0 and out["heightfield"][2] > out["trimesh"][2] + 0.02, out
 

@@ -152,13 +152,13 @@ def _trimesh_tile(name):
 
 def check_trimesh_surface(query, name, tol):
     """`query((n, 2) points) -> heights` of the build's physics terrain (oracle or HIP) against a vertical ray cast onto the REFERENCE's mesh of the
-    same raster (isaacgym terrain_utils.py:286-350 with slope_threshold 0.75, the call of legged_robot.py:903-921).  The build keeps the raster and
-    stands a corrected (vertical) face up as a ramp over the last quarter cell before its HIGH vertex (csrc/grx_kernels.hip riser_weight), so:
-      * OUTSIDE THE BAND -- the cells that hold a corrected edge or a vertex the reference moved -- the two surfaces are the same to `tol`
-        (the band is 57 % of the pyramid-stairs tile, whose treads are three cells deep, and 16 % of the discrete-obstacles tile);
-      * in a band cell that is steep along ONE axis, the surfaces differ by more than a millimetre only inside that last quarter cell (2.5 cm)
-        before the high vertex: the tread keeps its height up to there, the riser stands within 2.5 cm of where the reference has it;
-      * anywhere, the difference is bounded by the raster's local step."""
+    same raster (isaacgym terrain_utils.py:286-350 with slope_threshold 0.75, the call of legged_robot.py:903-921).  Round 6: the build holds that
+    mesh itself, a plane per triangle half of every raster cell (oracle trimesh_build / csrc/grx_capi.cpp build_trimesh_tables), so
+      * the two surfaces are the same to `tol` EVERYWHERE a cell's half lies under one triangle of the mesh -- all of the pyramid-stairs tile, whose
+        treads are three cells deep and 57 % of whose cells hold a corrected edge or a moved vertex (round 5's band, a quarter-cell ramp then), the
+        concave corners' split diagonals included;
+      * what is left: cells next to a point where THREE levels meet (discrete obstacles of different heights touching), whose halves the vertices the
+        reference slides along a face cut once more -- at most 0.5 % of the obstacle tile's points, bounded by the raster's local step."""
     cfg, ter, blk, v, t = _trimesh_tile(name)
     hs, vs = cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale
     H = blk.astype(np.int32)
@@ -168,30 +168,29 @@ def check_trimesh_surface(query, name, tol):
     moved = (np.abs(v[:, 0].reshape(n, n) - gx) > 1e-6) | (np.abs(v[:, 1].reshape(n, n) - gy) > 1e-6)
     sx, sy = np.abs(np.diff(H, axis=0)) > T, np.abs(np.diff(H, axis=1)) > T
     cell_sx, cell_sy = sx[:, :-1] | sx[:, 1:], sy[:-1, :] | sy[1:, :]
-    band = cell_sx | cell_sy | moved[:-1, :-1] | moved[1:, :-1] | moved[:-1, 1:] | moved[1:, 1:]
+    band = cell_sx | cell_sy | moved[:-1, :-1] | moved[1:, :-1] | moved[:-1, 1:] | moved[1:, 1:]       # the cells the correction touches
     assert moved.sum() > 400 and 0.1 < band.mean() < 0.7, (name, moved.sum(), band.mean())
-    g = np.arange(0.513, 7.4, 0.0731)                      # 95 x 95 points, incommensurate with the 0.1 m raster
-    pts = np.array([(x, y) for x in g for y in g])
+    rng = np.random.default_rng(3)
+    g = np.arange(0.513, 7.4, 0.0731)                      # 95 x 95 points, incommensurate with the 0.1 m raster, + 12000 random ones
+    pts = np.concatenate([np.array([(x, y) for x in g for y in g]), rng.uniform(0.11, 7.85, (12000, 2))])
+    f = pts / hs - np.floor(pts / hs)
+    pts = pts[(np.minimum(f, 1 - f).min(1) > 1e-4) & (np.abs(f[:, 0] - f[:, 1]) > 1e-4)]   # (a point ON a grid line or a cell diagonal sits on a face: either level)
     hm = _mesh_height(v, t, pts)
     hq = np.asarray(query(pts), dtype=np.float64)
     dev = np.abs(hm - hq)
     ij = np.floor(pts / hs).astype(int)
     inb = band[ij[:, 0], ij[:, 1]]
-    assert (~inb).sum() > 1500 and dev[~inb].max() <= tol, (name, dev[~inb].max())
-    for axis, cs, other in ((0, cell_sx, cell_sy), (1, cell_sy, cell_sx)):
-        sel = (cs & ~other)[ij[:, 0], ij[:, 1]]
-        f = pts[:, axis] / hs - ij[:, axis]
-        hi = H[ij[:, 0] + (axis == 0), ij[:, 1] + (axis == 1)] - H[ij[:, 0], ij[:, 1]]
-        in_quarter = ((hi > T) & (f > 0.75)) | ((-hi > T) & (f < 0.25))
-        big = sel & (dev > 1e-3)
-        assert sel.sum() > 100 and (big & ~in_quarter).sum() <= 0.02 * max(big.sum(), 1) + 1, (name, axis, int(sel.sum()), int(big.sum()), int((big & ~in_quarter).sum()))
-    # bounded by the local step of the raster (3 x 3 vertices around the cell)
-    pad = np.pad(H, 1, mode="edge")
-    loc = np.stack([pad[1 + di:1 + di + n, 1 + dj:1 + dj + n] for di in (-1, 0, 1) for dj in (-1, 0, 1)])
+    assert inb.sum() > 2000 and (~inb).sum() > 2000
+    off = dev > tol
+    assert not off[~inb].any(), (name, dev[~inb].max())
+    assert off.mean() <= (0.0 if name == "stairs" else 5e-3), (name, int(off.sum()), len(off))   # (observed: 0 of 21 000 on the stairs, 0.15 % on the obstacles)
+    # bounded by the local step of the raster (5 x 5 vertices around the cell: a vertex moves by one cell)
+    pad = np.pad(H, 2, mode="edge")
+    loc = np.stack([pad[2 + di:2 + di + n, 2 + dj:2 + dj + n] for di in (-2, -1, 0, 1, 2) for dj in (-2, -1, 0, 1, 2)])
     step = (loc.max(0) - loc.min(0)) * vs
     cell_step = np.maximum.reduce([step[:-1, :-1], step[1:, :-1], step[:-1, 1:], step[1:, 1:]])
     assert (dev <= cell_step[ij[:, 0], ij[:, 1]] + tol).all()
-    return float(inb.mean()), float(dev[~inb].max())
+    return float(inb.mean()), float(off.mean())
 
 
 def _closest_point_on_triangles(p, a, b, c):
@@ -271,25 +270,53 @@ def test_trimesh_surface_against_the_reference_mesh(name):
         check_trimesh_surface(lambda pts: [ora.terrain(x, y)[0] for x, y in pts], name, tol)
 
 
+@pytest.mark.parametrize("name", ["stairs", "obstacles"])
+def test_trimesh_vertical_faces_against_the_reference_mesh(name):
+    """The second half of the corrected mesh: its vertical faces as contacts (VERDICT r5 missing #2).  A sphere against the oracle's per-cell
+    sides and posts = the same sphere against the mesh's own vertical triangles."""
+    from oracle.binding import OracleSim
+    from wiki_grx_gym_amd.envs import build_config
+    cfg, ter, _, _, _ = _trimesh_tile(name)
+    c, keep, _ = build_config.build(cfg, cfg.sim.dt, 1, terrain=ter)
+    for prec, tol in (("f64", 1e-6), ("f32", 2e-5)):
+        ora = OracleSim(c, prec, keep)
+        touching, same, wrong = check_trimesh_walls(lambda pts: [ora.terrain(x, y)[0] for x, y in pts], lambda q: [ora.wall(*row) for row in q], name, tol)
+        # (observed: stairs 453 of 456 the same, obstacles 129 of 133; the rest are the notch cells and fins of check_trimesh_walls' docstring)
+        assert touching > 100 and wrong <= 0.04 * touching, (name, prec, touching, same, wrong)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["stairs", "obstacles"])
 def test_trimesh_surface_of_the_hip_kernels_against_the_reference_mesh(name):
-    """The same check on the step kernels' own terrain query (grx_debug_terrain launches terrain_height<true>), and HIP = oracle point by point."""
+    """The same checks on the step kernels' own terrain query and wall contact (grx_debug_terrain launches terrain_height<true>, grx_debug_wall
+    wall_gather / wall_contact), and HIP = oracle point by point."""
     from oracle.binding import OracleSim
     from wiki_grx_gym_amd.envs import build_config
     from wiki_grx_gym_amd.sim import HipSim
     cfg, ter, _, _, _ = _trimesh_tile(name)
     c, keep, _ = build_config.build(cfg, cfg.sim.dt, 16, terrain=ter)
     sim = HipSim(c, "cuda:0", keep)
-    band_frac, worst = check_trimesh_surface(lambda pts: sim.debug_terrain(pts)[:, 0], name, 2e-5)
-    print(name, "band", band_frac, "largest deviation outside it", worst)
+    band_frac, off_frac = check_trimesh_surface(lambda pts: sim.debug_terrain(pts)[:, 0], name, 2e-5)
+    print(name, "cells the correction touches", band_frac, "points off the reference mesh", off_frac)
+
+    def hip_wall(q):
+        f = sim.debug_wall(q).astype(np.float64)
+        d = np.linalg.norm(f, axis=1)
+        return np.column_stack([d, f / np.maximum(d, 1e-30)[:, None]])
+    touching, same, wrong = check_trimesh_walls(lambda pts: sim.debug_terrain(pts)[:, 0], hip_wall, name, 2e-5)
+    assert touching > 100 and wrong <= 0.04 * touching, (name, touching, same, wrong)
     c2, keep2, _ = build_config.build(cfg, cfg.sim.dt, 16, terrain=ter)
     ora = OracleSim(c2, "f32", keep2)
     rng = np.random.default_rng(0)
     pts = rng.uniform(0.05, 7.85, size=(2000, 2))
     a = sim.debug_terrain(pts)
     b = np.array([ora.terrain(x, y) for x, y in pts.astype(np.float32)])
-    # (a point within rounding of a cell edge or of the quarter-cell ramp's start may sit on the other side in one of the two)
+    # (a point within rounding of a cell edge or of a cell's diagonal may sit on the other side in one of the two)
     close = (np.abs(a[:, 0] - b[:, 0]) <= 2e-5) & (np.abs(a[:, 1:] - b[:, 1:]) <= 1e-3 + 1e-3 * np.abs(b[:, 1:])).all(1)
     assert close.mean() >= 0.995, close.mean()
+    z = b[:, 0] + rng.uniform(0.0, 0.1, len(pts))
+    q = np.column_stack([pts, z, np.full(len(pts), 0.04)]).astype(np.float32)
+    wa = sim.debug_wall(q)
+    wb = np.array([(lambda o: o[0] * o[1:])(ora.wall(*row)) for row in q])
+    assert (np.abs(wb).sum(1) > 0).sum() > 50 and (np.abs(wa - wb).max(1) <= 2e-5).mean() >= 0.995
     sim.close()

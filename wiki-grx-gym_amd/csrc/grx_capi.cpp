@@ -50,6 +50,7 @@ void grx_launch_set_state(const KParams* dP, int N, const float* root, const flo
 int grx_envs_per_block(void);
 void grx_launch_refresh_heights(const KParams* dP, int N, int nh, hipStream_t stream);
 void grx_launch_debug_terrain(const KParams* dP, const float* xy, int n, float* out, hipStream_t stream);
+void grx_launch_debug_wall(const KParams* dP, const float* xyzr, int n, float* out, hipStream_t stream);
 void grx_launch_refresh_rbs(const KParams* dP, int N, int nlinks, int pushed, hipStream_t stream);
 void grx_launch_step_debug(const KParams* dP, int N, int heightfield, int waves, const float* actions, long long common_step, const float* noise,
                            const float* dbg, const StepSeq* sq, hipStream_t stream);
@@ -422,6 +423,136 @@ void base_lump(const grx_model& m, float link_mass, const float link_com[3], flo
 }
 
 }  // namespace
+
+// ---- mesh_type 'trimesh': the reference's slope-corrected triangle mesh as per-cell tables
+// legged_robot.py:903-921 hands PhysX convert_heightfield_to_trimesh(raster, slope_threshold) (isaacgym terrain_utils.py:286-350): the raster's
+// heights on vertices that were MOVED by whole cells -- a vertex whose +x / -x / +y / -y (or, where those do not move it, diagonal) neighbour
+// stands more than the threshold above it goes under that neighbour (:313-325), which turns the steep cell into a vertical face.  All vertices
+// stay on grid points, so the mesh above one raster cell is: a plane per triangle half of the cell (the halves of :335-347; at a concave corner
+// the two halves can sit on different levels) and vertical faces on grid lines.  Tables (grx_device.h KParams::tm_off, read by terrain_eval /
+// wall_contact in grx_kernels.hip; the oracle builds its own in trimesh_build):
+//   ground[cell][6]: corner heights of the top surface under half 0 (ty >= tx: e00, e01, e11) and half 1 (tx > ty: e00, e10, e11) -- the plane
+//     a vertical ray hits at the half's centroid, evaluated at the cell's corners, in raster units (rounded: a sloped neighbour stretched over
+//     two cells leaves half units);
+//   walls[cell][8]: tops of the vertical faces on the sides x-, x+, y-, y+ (the rectangle both of whose ends the faces reach) and of the posts at
+//     the corners 00, 10, 01, 11 (the end of a face that runs away from the corner), where they rise above the cell's own ground; else TM_NONE.
+namespace {
+constexpr int16_t TM_NONE = INT16_MIN;
+struct TrimeshTables { std::vector<int16_t> ground, walls; };
+struct TmVertex { double x, y, z; };
+TrimeshTables build_trimesh_tables(const grx_config& c) {
+    const int R = c.hf_rows, C = c.hf_cols;
+    const int16_t* H = c.height_samples;
+    const size_t n = (size_t)R * C;
+    const double thr = (double)c.slope_threshold * ((double)c.horizontal_scale / (double)c.vertical_scale);   // raster units, in double like numpy (:310)
+    auto at = [&](int i, int j) { return (int)H[(size_t)i * C + j]; };
+    auto above = [&](int i, int j, int di, int dj) {   // the neighbour stands more than the threshold above (i, j)
+        const int a = i + di, b = j + dj;
+        return a >= 0 && a < R && b >= 0 && b < C && at(a, b) - at(i, j) > thr ? 1 : 0;
+    };
+    std::vector<int8_t> mx(n), my(n);
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            const int sx = above(i, j, 1, 0) - above(i, j, -1, 0), sy = above(i, j, 0, 1) - above(i, j, 0, -1), sc = above(i, j, 1, 1) - above(i, j, -1, -1);
+            mx[(size_t)i * C + j] = (int8_t)(sx != 0 ? sx : sc);   // xx += move_x + move_corners * (move_x == 0)   (:324)
+            my[(size_t)i * C + j] = (int8_t)(sy != 0 ? sy : sc);
+        }
+    auto vertex = [&](int i, int j) { const size_t k = (size_t)i * C + j; return TmVertex{(double)(i + mx[k]), (double)(j + my[k]), (double)H[k]}; };
+    auto triangle = [&](int a, int b, int second, TmVertex t[3]) {   // (ind0, ind3, ind1) and (ind0, ind2, ind3) of :339-347
+        t[0] = vertex(a, b);
+        t[1] = second ? vertex(a + 1, b) : vertex(a + 1, b + 1);
+        t[2] = second ? vertex(a + 1, b + 1) : vertex(a, b + 1);
+    };
+    auto round16 = [](double z) { return (int16_t)lrint(std::min(std::max(z, -32767.0), 32767.0)); };
+    // the plane of the highest triangle over the raster point (px, py): z there and its gradient
+    auto plane_at = [&](double px, double py, double pl[3]) {
+        const int ci = (int)floor(px), cj = (int)floor(py);
+        bool found = false;
+        for (int a = std::max(ci - 1, 0); a <= std::min(ci + 1, R - 2); ++a)
+            for (int b = std::max(cj - 1, 0); b <= std::min(cj + 1, C - 2); ++b)
+                for (int k = 0; k < 2; ++k) {
+                    TmVertex t[3];
+                    triangle(a, b, k, t);
+                    const double ux = t[1].x - t[0].x, uy = t[1].y - t[0].y, vx = t[2].x - t[0].x, vy = t[2].y - t[0].y;
+                    const double den = ux * vy - vx * uy;
+                    if (fabs(den) < 1e-9) continue;   // projects to a segment: a vertical face
+                    const double qx = px - t[0].x, qy = py - t[0].y;
+                    const double w1 = (qx * vy - vx * qy) / den, w2 = (ux * qy - qx * uy) / den;
+                    if (w1 < -1e-9 || w2 < -1e-9 || 1 - w1 - w2 < -1e-9) continue;
+                    const double uz = t[1].z - t[0].z, vz = t[2].z - t[0].z, z = t[0].z + w1 * uz + w2 * vz;
+                    if (!found || z > pl[0]) { pl[0] = z; pl[1] = (uz * vy - vz * uy) / den; pl[2] = (ux * vz - vx * uz) / den; found = true; }
+                }
+        return found;
+    };
+    TrimeshTables out;
+    out.ground.resize(6 * n);
+    out.walls.assign(8 * n, TM_NONE);
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            const int i1 = std::min(i + 1, R - 1), j1 = std::min(j + 1, C - 1);
+            int16_t* e = &out.ground[6 * ((size_t)i * C + j)];
+            e[0] = e[3] = (int16_t)at(i, j); e[1] = (int16_t)at(i, j1); e[4] = (int16_t)at(i1, j); e[2] = e[5] = (int16_t)at(i1, j1);
+            if (i > R - 2 || j > C - 2) continue;
+            for (int half = 0; half < 2; ++half) {
+                const double px = i + (half ? 2.0 : 1.0) / 3, py = j + (half ? 1.0 : 2.0) / 3;   // the half's centroid
+                double pl[3];
+                if (!plane_at(px, py, pl)) continue;
+                auto corner = [&](int ci, int cj) { return round16(pl[0] + pl[1] * (ci - px) + pl[2] * (cj - py)); };
+                e[3 * half] = corner(i, j);
+                e[3 * half + 1] = half ? corner(i + 1, j) : corner(i, j + 1);
+                e[3 * half + 2] = corner(i + 1, j + 1);
+            }
+        }
+    // the vertical faces, per unit segment of a grid line and per END of the segment: line x = X, y in [k, k + 1] -> fx[2 * (X * C + k) + end];
+    // line y = Y, x in [k, k + 1] -> fy[2 * (Y * R + k) + end].  (Where three levels meet, the vertices slid along a face leave it triangular.)
+    std::vector<int16_t> fx(2 * n, TM_NONE), fy(2 * n, TM_NONE);
+    for (int a = 0; a < R - 1; ++a)
+        for (int b = 0; b < C - 1; ++b)
+            for (int k = 0; k < 2; ++k) {
+                TmVertex t[3];
+                triangle(a, b, k, t);
+                if (fabs((t[1].x - t[0].x) * (t[2].y - t[0].y) - (t[2].x - t[0].x) * (t[1].y - t[0].y)) > 1e-9) continue;
+                if (std::max({t[0].z, t[1].z, t[2].z}) <= std::min({t[0].z, t[1].z, t[2].z})) continue;
+                const bool on_x_line = t[0].x == t[1].x && t[0].x == t[2].x, on_y_line = t[0].y == t[1].y && t[0].y == t[2].y;
+                if (on_x_line == on_y_line) continue;   // a needle, or a face across the grid (axis-aligned steps make none)
+                double pos[3];
+                for (int q = 0; q < 3; ++q) pos[q] = on_x_line ? t[q].y : t[q].x;
+                const int line = (int)(on_x_line ? t[0].x : t[0].y), lo = (int)std::min({pos[0], pos[1], pos[2]}), hi = (int)std::max({pos[0], pos[1], pos[2]});
+                const int nlines = on_x_line ? R : C, nseg = on_x_line ? C - 1 : R - 1, stride = on_x_line ? C : R;
+                if (line < 0 || line >= nlines) continue;
+                std::vector<int16_t>& f = on_x_line ? fx : fy;
+                for (int q = std::max(lo, 0); q < std::min(hi, nseg); ++q)
+                    for (int end = 0; end < 2; ++end) {
+                        const double where = q + end;
+                        double top = -1e30;   // the triangle's highest point over `where`
+                        for (int m0 = 0; m0 < 3; ++m0) {
+                            const int m1 = (m0 + 1) % 3;
+                            if (where < std::min(pos[m0], pos[m1]) || where > std::max(pos[m0], pos[m1])) continue;
+                            top = std::max(top, pos[m0] == pos[m1] ? std::max(t[m0].z, t[m1].z) : t[m0].z + (t[m1].z - t[m0].z) * (where - pos[m0]) / (pos[m1] - pos[m0]));
+                        }
+                        int16_t& o = f[2 * ((size_t)line * stride + q) + end];
+                        if (top > -1e29) o = std::max(o, round16(top));
+                    }
+            }
+    auto face_x = [&](int X, int k, int end) { return X >= 0 && X < R && k >= 0 && k < C - 1 ? fx[2 * ((size_t)X * C + k) + end] : TM_NONE; };
+    auto face_y = [&](int Y, int k, int end) { return Y >= 0 && Y < C && k >= 0 && k < R - 1 ? fy[2 * ((size_t)Y * R + k) + end] : TM_NONE; };
+    for (int i = 0; i < R; ++i)
+        for (int j = 0; j < C; ++j) {
+            const int16_t* e = &out.ground[6 * ((size_t)i * C + j)];
+            int16_t* w = &out.walls[8 * ((size_t)i * C + j)];
+            const int16_t side[4] = {std::min(face_x(i, j, 0), face_x(i, j, 1)), std::min(face_x(i + 1, j, 0), face_x(i + 1, j, 1)),
+                                     std::min(face_y(j, i, 0), face_y(j, i, 1)), std::min(face_y(j + 1, i, 0), face_y(j + 1, i, 1))};
+            // the cell's own ground along the side (x- and y+ bound half 0, x+ and y- half 1)
+            const int16_t ground[4] = {std::max(e[0], e[1]), std::max(e[4], e[5]), std::max(e[3], e[4]), std::max(e[1], e[2])};
+            for (int q = 0; q < 4; ++q) w[q] = side[q] > ground[q] ? side[q] : TM_NONE;
+            const int16_t away_x[4] = {face_x(i, j - 1, 1), face_x(i + 1, j - 1, 1), face_x(i, j + 1, 0), face_x(i + 1, j + 1, 0)};
+            const int16_t away_y[4] = {face_y(j, i - 1, 1), face_y(j, i + 1, 0), face_y(j + 1, i - 1, 1), face_y(j + 1, i + 1, 0)};
+            const int16_t corner[4] = {std::max(e[0], e[3]), e[4], e[1], std::max(e[2], e[5])};   // 00, 10, 01, 11
+            for (int q = 0; q < 4; ++q) { const int16_t top = std::max(away_x[q], away_y[q]); w[4 + q] = top > corner[q] ? top : TM_NONE; }
+        }
+    return out;
+}
+}   // namespace
 
 // ---- generic-tree path: device tables mirroring grx_generic.h's GenTables (kept in sync by the size check below)
 namespace {
@@ -817,7 +948,7 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
     P.hf_rows = c.hf_rows; P.hf_cols = c.hf_cols;
     P.horizontal_scale = c.horizontal_scale; P.vertical_scale = c.vertical_scale; P.border_size = c.border_size;
     P.inv_hscale = 1.0f / c.horizontal_scale;
-    P.vertical_faces = c.vertical_faces; P.riser_thr = c.slope_threshold * c.horizontal_scale / c.vertical_scale;
+    P.vertical_faces = c.terrain_type == GRX_TERRAIN_HEIGHTFIELD && c.vertical_faces; P.tm_off = 0;   // (tm_off: with the cell tables below)
     P.hv_scale = c.vertical_scale / c.horizontal_scale;
     P.curriculum = c.curriculum; P.num_terrain_rows = c.num_terrain_rows; P.num_terrain_cols = c.num_terrain_cols;
     P.terrain_length = c.terrain_length;
@@ -934,8 +1065,9 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
                     m4[(size_t)i * c.hf_cols + j] = std::max(std::max(H[(size_t)i * c.hf_cols + j], H[(size_t)i1 * c.hf_cols + j]),
                                                              std::max(H[(size_t)i * c.hf_cols + j1], H[(size_t)i1 * c.hf_cols + j1]));
                 }
-            {   // the four corners of every cell, packed (grx_device.h hf_cells)
-                std::vector<uint32_t> cells(2 * n);
+            {   // the four corners of every cell, packed (grx_device.h hf_cells); mesh_type 'trimesh': + the corrected mesh's tables behind them
+                const size_t tm_off = P.vertical_faces ? ((n + 1) & ~(size_t)1) : 0;
+                std::vector<uint32_t> cells(2 * (P.vertical_faces ? 3 * tm_off + 2 * n : n), 0u);
                 for (int i = 0; i < c.hf_rows; ++i)
                     for (int j = 0; j < c.hf_cols; ++j) {
                         const int i1 = std::min(i + 1, c.hf_rows - 1), j1 = std::min(j + 1, c.hf_cols - 1);
@@ -945,10 +1077,28 @@ int grx_create(const grx_config* cfg, int device_id, grx_handle* out) {
                         cells[2 * ((size_t)i * c.hf_cols + j)] = h00 | (h01 << 16);
                         cells[2 * ((size_t)i * c.hf_cols + j) + 1] = h10 | (h11 << 16);
                     }
+                if (P.vertical_faces) {
+                    if (n > (size_t)0x0fffffff) { grx_destroy(s); return fail(GRX_ERR_INVALID_ARGUMENT, "grx_create: trimesh raster too large"); }
+                    TrimeshTables tm = build_trimesh_tables(c);
+                    for (size_t k = 0; k < n; ++k) {
+                        const int16_t* e = &tm.ground[6 * k];
+                        uint32_t* t0 = &cells[2 * (tm_off + 2 * k)];
+                        t0[0] = (uint16_t)e[0] | ((uint32_t)(uint16_t)e[1] << 16); t0[1] = (uint16_t)e[2];
+                        t0[2] = (uint16_t)e[3] | ((uint32_t)(uint16_t)e[4] << 16); t0[3] = (uint16_t)e[5];
+                        const int16_t* w = &tm.walls[8 * k];
+                        uint32_t* w0 = &cells[2 * (3 * tm_off + 2 * k)];
+                        for (int q = 0; q < 4; ++q) w0[q] = (uint16_t)w[2 * q] | ((uint32_t)(uint16_t)w[2 * q + 1] << 16);
+                        int16_t top = m4[k];   // the contact reach test (grx_rare.h) must see what the cell can touch: its ground corners and its faces' tops
+                        for (int q = 0; q < 6; ++q) top = std::max(top, e[q]);
+                        for (int q = 0; q < 8; ++q) top = std::max(top, w[q]);
+                        m4[k] = top;
+                    }
+                    P.tm_off = (int32_t)tm_off;
+                }
                 uint32_t* dc = nullptr;
-                rc = dalloc(s, &dc, 2 * n);
+                rc = dalloc(s, &dc, cells.size());
                 if (rc) { grx_destroy(s); return rc; }
-                HIP_TRY(hipMemcpy(dc, cells.data(), 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(dc, cells.data(), cells.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
                 P.hf_cells = reinterpret_cast<const uint2*>(dc);
             }
             int16_t* dm4 = nullptr;
@@ -1535,6 +1685,23 @@ int grx_debug_terrain(grx_handle s, const float* xy, int32_t n, float* out, void
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     hipFree(dxy); hipFree(dout);
     if (e != hipSuccess) return fail(GRX_ERR_HIP, std::string("grx_debug_terrain: ") + hipGetErrorString(e));
+    return GRX_OK;
+}
+
+// TEST-ONLY: mesh_type 'trimesh', spheres at rest (x, y, z, r) against the vertical faces next to them -> host (overlap * unit direction) each (include/grx.h)
+int grx_debug_wall(grx_handle s, const float* xyzr, int32_t n, float* out, void* stream) {
+    if (!s || (n > 0 && (!xyzr || !out))) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_wall: null argument");
+    if (n <= 0) return GRX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float *din = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&din, (size_t)n * 4 * sizeof(float)));
+    if (hipMalloc(&dout, (size_t)n * 3 * sizeof(float)) != hipSuccess) { hipFree(din); return fail(GRX_ERR_OUT_OF_MEMORY, "grx_debug_wall: out of device memory"); }
+    hipError_t e = hipMemcpyAsync(din, xyzr, (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) { grx_launch_debug_wall(s->d_hp, din, n, dout, st); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(din); hipFree(dout);
+    if (e != hipSuccess) return fail(GRX_ERR_HIP, std::string("grx_debug_wall: ") + hipGetErrorString(e));
     return GRX_OK;
 }
 

@@ -193,7 +193,10 @@ struct KParams {
     int32_t terrain_type, measure_heights, nh;
     const int16_t* hf; int32_t hf_rows, hf_cols;
     const float* coarse_max; int32_t coarse_rows, coarse_cols;   // dilated block-max of the raster [m]: sphere culling
-    int32_t vertical_faces; float riser_thr;       // mesh_type 'trimesh': raster steps above riser_thr [raster units] are vertical faces
+    int32_t vertical_faces; int32_t tm_off;        // mesh_type 'trimesh': the surface is the reference's slope-corrected mesh, held behind hf_cells (below):
+                                                   // hf_cells[tm_off + 2 * cell + half]: ground corners under triangle half `half` of the cell (0: ty >= tx (e00, e01, e11),
+                                                   // 1: tx > ty (e00, e10, e11); 4th int16 unused); (const uint4*)(hf_cells + 3 * tm_off)[cell]: tops of the vertical faces
+                                                   // on the cell's sides x-, x+, y-, y+ and of the posts at its corners 00, 10, 01, 11 (int16 each, INT16_MIN = none)
     float hv_scale;                                // vertical_scale / horizontal_scale (terrain gradient)
     float bounce_threshold, terrain_restitution;   // legged_robot_config.py:48, :79
     int32_t self_collisions;     // links collide with each other (legged_robot_config.py:121)

@@ -131,6 +131,11 @@ GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, 
                 if (sp > 1e-9f) { const float k = -ft * grx_rcp(sp); F.x += k * u.x; F.y += k * u.y; }
             }
         }
+        if (HF && P.vertical_faces) {   // mesh_type 'trimesh': the vertical faces next to the shape (grx_kernels.hip wall_contact)
+            float wtx, wty;
+            const uint4 ww = wall_gather(P, wx, wy, wtx, wty);
+            F = F + wall_contact(P, ww, wtx, wty, wz, r, T.sdmax[i], v + cross(w, xr), mu);
+        }
     }
     if (slot >= 0) P.anchors[(size_t)(slot * 3 + 2) * N + e] = touching ? vimp : 0.f;
     const int L = T.slink[i];

@@ -149,20 +149,14 @@ GRX_DEV void grx_sincos(float x, float& s, float& c) {
     c = __cosf(x);
 }
 
-// physics terrain query (oracle: terrain_query): bilinear patch of the int16 heightfield -> height and gradient
-// (gx, gy) = (dh/dx, dh/dy) of the surface under (x, y).  mesh_type 'trimesh' (P.vertical_faces): along an axis whose raster
-// step exceeds the slope threshold the weight is sharpened to a ramp over the last quarter cell before the HIGH vertex --
-// the height-function stand-in for the vertical face the reference's slope-corrected mesh has there
-// (isaacgym terrain_utils.py:286-350); with the normal taken from the gradient the riser pushes back horizontally.
-constexpr float kRiserBand = 0.25f;
-GRX_DEV float riser_weight(float t, float jump, float thr, float& dt) {
-    dt = 1.0f;
-    if (jump > thr) { dt = t <= 1.0f - kRiserBand ? 0.0f : 1.0f / kRiserBand; return t <= 1.0f - kRiserBand ? 0.0f : (t - (1.0f - kRiserBand)) * (1.0f / kRiserBand); }
-    if (-jump > thr) { dt = t >= kRiserBand ? 0.0f : 1.0f / kRiserBand; return t >= kRiserBand ? 1.0f : t * (1.0f / kRiserBand); }
-    return t;
-}
-// In two halves: the gather (four int16 loads, ~1.2 us of memory latency on this part) and the interpolation that first
-// USES them -- a caller with independent work puts it between the two.
+// physics terrain query (oracle: terrain_query): height and gradient (gx, gy) = (dh/dx, dh/dy) of the surface under (x, y).
+//  * heightfield: bilinear patch of the int16 raster (hf_cells: the four corners of a cell in one 8-byte gather);
+//  * mesh_type 'trimesh' (P.vertical_faces, uniform): the reference's slope-corrected mesh (isaacgym terrain_utils.py:286-350 moves
+//    vertices by whole cells, so it is still described per raster cell: grx_capi.cpp build_trimesh_tables): the plane of the
+//    triangle half under the point, from that half's three corner heights -- again ONE 8-byte gather; the mesh's vertical
+//    faces are a second contact (wall_contact below).
+// In two halves: the gather (~1.2 us of memory latency on this part) and the interpolation that first USES it -- a caller
+// with independent work puts it between the two.
 struct TerrainRaw { int h00, h01, h10, h11; float tx, ty; };
 // raster cell under (x, y) (index of its low corner) and the position inside it
 GRX_DEV int terrain_locate(KP P, float x, float y, float& tx, float& ty) {
@@ -174,29 +168,38 @@ GRX_DEV int terrain_locate(KP P, float x, float y, float& tx, float& ty) {
     tx = fx - (float)ix; ty = fy - (float)iy;
     return ix * P.hf_cols + iy;
 }
+// index into hf_cells of the corner record the physics reads for a point of `cell` (trimesh: the record of its triangle half)
+GRX_DEV int terrain_record(KP P, int cell, float tx, float ty) {
+    return P.vertical_faces ? P.tm_off + 2 * cell + (ty >= tx ? 0 : 1) : cell;
+}
+GRX_DEV void terrain_unpack(uint2 cc, TerrainRaw& r) {
+    r.h00 = (int16_t)(cc.x & 0xffffu); r.h01 = (int16_t)(cc.x >> 16);
+    r.h10 = (int16_t)(cc.y & 0xffffu); r.h11 = (int16_t)(cc.y >> 16);
+}
 template <bool HF>
 GRX_DEV void terrain_gather(KP P, float x, float y, TerrainRaw& r) {
     if (!HF) return;
-    const uint2 cc = P.hf_cells[terrain_locate(P, x, y, r.tx, r.ty)];   // one gather for the four corners
-    r.h00 = (int16_t)(cc.x & 0xffffu); r.h01 = (int16_t)(cc.x >> 16);
-    r.h10 = (int16_t)(cc.y & 0xffffu); r.h11 = (int16_t)(cc.y >> 16);
+    const int cell = terrain_locate(P, x, y, r.tx, r.ty);
+    terrain_unpack(P.hf_cells[terrain_record(P, cell, r.tx, r.ty)], r);   // one gather
 }
 template <bool HF>
 GRX_DEV float terrain_eval(KP P, const TerrainRaw& r, float& gx, float& gy) {
     gx = 0.0f; gy = 0.0f;
     if (!HF) return 0.0f;
-    float tx = r.tx, ty = r.ty;
+    const float tx = r.tx, ty = r.ty;
     const float h00 = (float)r.h00, h01 = (float)r.h01, h10 = (float)r.h10, h11 = (float)r.h11;
-    float dtx = 1.0f, dty = 1.0f;
-    if (P.vertical_faces) {   // uniform
-        const float ax0 = h10 - h00, ax1 = h11 - h01, ay0 = h01 - h00, ay1 = h11 - h10;
-        const float ax = fabsf(ax0) > fabsf(ax1) ? ax0 : ax1, ay = fabsf(ay0) > fabsf(ay1) ? ay0 : ay1;   // the steeper edge decides for the cell
-        tx = riser_weight(tx, ax, P.riser_thr, dtx);
-        ty = riser_weight(ty, ay, P.riser_thr, dty);
+    float h;
+    if (P.vertical_faces) {   // uniform.  The record: (e00, e01 | e10, e11, -) of the half the point is in
+        const bool up = ty >= tx;
+        gx = up ? h10 - h01 : h01 - h00;
+        gy = up ? h01 - h00 : h10 - h01;
+        h = h00 + gx * tx + gy * ty;
+        gx *= P.hv_scale; gy *= P.hv_scale;
+    } else {
+        h = (h00 * (1.0f - tx) + h10 * tx) * (1.0f - ty) + (h01 * (1.0f - tx) + h11 * tx) * ty;
+        gx = ((h10 - h00) * (1.0f - ty) + (h11 - h01) * ty) * P.hv_scale;
+        gy = ((h01 - h00) * (1.0f - tx) + (h11 - h10) * tx) * P.hv_scale;
     }
-    float h = (h00 * (1.0f - tx) + h10 * tx) * (1.0f - ty) + (h01 * (1.0f - tx) + h11 * tx) * ty;
-    gx = ((h10 - h00) * (1.0f - ty) + (h11 - h01) * ty) * dtx * P.hv_scale;
-    gy = ((h01 - h00) * (1.0f - tx) + (h11 - h10) * tx) * dty * P.hv_scale;
     return h * P.vertical_scale;
 }
 template <bool HF>
@@ -204,6 +207,62 @@ GRX_DEV float terrain_height(KP P, float x, float y, float& gx, float& gy) {
     TerrainRaw r;
     terrain_gather<HF>(P, x, y, r);
     return terrain_eval<HF>(P, r, gx, gy);
+}
+// mesh_type 'trimesh': the sphere (centre c = (wx, wy, wz), radius r) against the vertical faces of the corrected mesh on the four sides
+// of the raster cell under its centre and the posts (ends of faces that run away) at its four corners -- oracle wall_overlap + the wall
+// branch of contact_forces.  A face spans its side from the ground to its top; the closest point on it is level with the centre,
+// or on its upper edge.  ONE contact, the deepest; Hunt-Crossley normal force like the ground's, friction viscous and capped by the
+// cone in the face's tangent plane.  ww: the cell's record (wall_gather), (tx, ty): the centre's position in the cell.
+GRX_DEV uint4 wall_gather(KP P, float x, float y, float& tx, float& ty) {
+    const int cell = terrain_locate(P, x, y, tx, ty);
+    return reinterpret_cast<const uint4*>(P.hf_cells + 3 * (size_t)P.tm_off)[cell];
+}
+GRX_DEV V3 wall_contact(KP P, uint4 ww, float tx, float ty, float wz, float r, float dmax, V3 u, float mu) {
+    V3 F = v3(0.f, 0.f, 0.f);
+    const float dx[2] = {tx * P.horizontal_scale, (tx - 1.0f) * P.horizontal_scale}, dy[2] = {ty * P.horizontal_scale, (ty - 1.0f) * P.horizontal_scale};
+    const uint32_t w32[4] = {ww.x, ww.y, ww.z, ww.w};
+    float best = r * r;   // squared distance of the closest face within reach
+    V3 d = v3(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int top = (int16_t)((q & 1) ? (w32[q >> 1] >> 16) : (w32[q >> 1] & 0xffffu));
+        const float ex = q < 2 ? dx[q] : (q < 4 ? 0.0f : dx[(q - 4) & 1]);
+        const float ey = q < 2 ? 0.0f : (q < 4 ? dy[q - 2] : dy[(q - 4) >> 1]);
+        const float ez = fmaxf(wz - (float)top * P.vertical_scale, 0.0f);
+        const float d2 = ex * ex + ey * ey + ez * ez;
+        if (top != -32768 && d2 < best && d2 > 1e-18f) { best = d2; d = v3(ex, ey, ez); }
+    }
+    if (best < r * r) {
+        const float dist = grx_sqrt(best);
+        const V3 n = d * grx_rcp(dist);
+        const float pen = r - dist;
+        const float un = dot(u, n);
+        const float cd = fminf(P.kn * pen * P.dn, dmax);
+        const float fn = fmaxf(P.kn * pen - cd * un, 0.0f);
+        const V3 ut = u - n * un;
+        const float sp = grx_sqrt(dot(ut, ut));
+        const float ft = fminf(P.cv * sp, mu * fn);
+        F = n * fn;
+        if (sp > 1e-9f) F = F - ut * (ft * grx_rcp(sp));
+    }
+    return F;
+}
+
+// the vertical faces next to CNT spheres of one body (S[i]: radius r, damping cap dmax), added to the body's wrench about O
+template <int CNT, typename SphT>
+GRX_DEV void wall_pass(KP P, const SphT* S, V3 w, V3 v, V3 O, float mu, float hmax, const V3* xr, V3& fa, V3& fl) {
+    uint4 ww[CNT];
+    float tx[CNT], ty[CNT];
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) ww[i] = wall_gather(P, O.x + xr[i].x, O.y + xr[i].y, tx[i], ty[i]);
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) {
+        const float wz = O.z + xr[i].z;
+        if (wz - S[i].r <= hmax) {
+            const V3 F = wall_contact(P, ww[i], tx[i], ty[i], wz, S[i].r, S[i].dmax, v + cross(w, xr[i]), mu);
+            fa = fa + cross(xr[i], F); fl = fl + F;
+        }
+    }
 }
 
 // per-lane persistent simulation state
@@ -390,6 +449,7 @@ GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, fl
         F = sphere_contact<HF, 1>(P, C.sph[o + 1], K.w, K.v, O, mu, hmax, st, xr[1], th[1], om_e); fa = fa + cross(xr[1], F); fl = fl + F;
         F = sphere_contact<HF, 2>(P, C.sph[o + 2], K.w, K.v, O, mu, hmax, st, xr[2], th[2], om_e); fa = fa + cross(xr[2], F); fl = fl + F;
         F = sphere_contact<HF, 3>(P, C.sph[o + 3], K.w, K.v, O, mu, hmax, st, xr[3], th[3], om_e); fa = fa + cross(xr[3], F); fl = fl + F;
+        if (HF && P.vertical_faces) wall_pass<4>(P, &C.sph[o], K.w, K.v, O, mu, hmax, xr, fa, fl);
     } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
 }
 template <bool HF>
@@ -428,6 +488,7 @@ GRX_DEV void foot_contacts_q(KP P, const SideConst& Clds, int half, const ChainK
         V3 F;
         F = sphere_contact<HF, 0>(P, Clds.sph[o + 2 * half + 0], K.w, K.v, O, mu, hmax, st, fp.xr[0], th[0], om_e); fa = fa + cross(fp.xr[0], F); fl = fl + F;
         F = sphere_contact<HF, 1>(P, Clds.sph[o + 2 * half + 1], K.w, K.v, O, mu, hmax, st, fp.xr[1], th[1], om_e); fa = fa + cross(fp.xr[1], F); fl = fl + F;
+        if (HF && P.vertical_faces) wall_pass<2>(P, &Clds.sph[o + 2 * half], K.w, K.v, O, mu, hmax, fp.xr, fa, fl);
         fa = half_sum(fa); fl = half_sum(fl);   // the foot's wrench: both halves
     } else st.anchor_on = 0;
 }
@@ -2524,6 +2585,23 @@ __global__ void grx_debug_terrain_kernel(const KParams* __restrict__ Pg, const f
 }
 extern "C" void grx_launch_debug_terrain(const KParams* dP, const float* xy, int n, float* out, hipStream_t stream) {
     if (n > 0) hipLaunchKernelGGL(grx_debug_terrain_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dP, xy, n, out);
+}
+// TEST-ONLY (grx_debug_wall): mesh_type 'trimesh', the contact of a sphere AT REST (centre x y z, radius r) with the vertical faces next to it, as the step
+// kernels compute it (wall_gather / wall_contact): out = force / kn = overlap times the unit direction from the face to the centre (0 0 0: none)
+__global__ void grx_debug_wall_kernel(const KParams* __restrict__ Pg, const float* __restrict__ xyzr, int n, float* __restrict__ out) {
+    KP P = GRX_PARAMS(Pg);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 F = v3(0.f, 0.f, 0.f);
+    if (P.terrain_type != GRX_TERRAIN_PLANE && P.vertical_faces) {
+        float tx, ty;
+        const uint4 ww = wall_gather(P, xyzr[4 * i], xyzr[4 * i + 1], tx, ty);
+        F = wall_contact(P, ww, tx, ty, xyzr[4 * i + 2], xyzr[4 * i + 3], 0.0f, v3(0.f, 0.f, 0.f), 0.0f) * (1.0f / P.kn);
+    }
+    out[3 * i] = F.x; out[3 * i + 1] = F.y; out[3 * i + 2] = F.z;
+}
+extern "C" void grx_launch_debug_wall(const KParams* dP, const float* xyzr, int n, float* out, hipStream_t stream) {
+    if (n > 0) hipLaunchKernelGGL(grx_debug_wall_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dP, xyzr, n, out);
 }
 extern "C" void grx_launch_refresh_heights(const KParams* dP, int N, int nh, hipStream_t stream) {
     const size_t n = (size_t)N * (size_t)nh;

@@ -214,7 +214,12 @@ GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const Rar
                 sphere_probe<HF>(P, S, Fr.R, Fr.rho, Ow, xr, th);
                 LaneState dummy;
                 dummy.anchor_on = 0;
-                const V3 F = sphere_contact<HF, -1>(P, S, Fr.w, Fr.v, Ow, om.w, hmax_, dummy, xr, th);
+                V3 F = sphere_contact<HF, -1>(P, S, Fr.w, Fr.v, Ow, om.w, hmax_, dummy, xr, th);
+                if (HF && P.vertical_faces) {   // mesh_type 'trimesh': the vertical faces next to the shape
+                    float wtx, wty;
+                    const uint4 ww = wall_gather(P, Ow.x + xr.x, Ow.y + xr.y, wtx, wty);
+                    F = F + wall_contact(P, ww, wtx, wty, Ow.z + xr.z, S.r, S.dmax, Fr.v + cross(Fr.w, xr), om.w);
+                }
                 const V3 Tq = cross(xr, F);
                 float2* r = B.res + (si * 3) * 64 + src;
                 float2 a; a.x = F.x; a.y = F.y; r[0] = a;

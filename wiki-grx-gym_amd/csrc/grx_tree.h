@@ -349,7 +349,10 @@ GRX_DEV TreeContactPre tree_contact_probe(KP P, const TreeTab& T, float* wsw, in
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         pr.cc[u] = make_uint2(0u, 0u); pr.tx[u] = 0.f; pr.ty[u] = 0.f;
-        if (HF) pr.cc[u] = P.hf_cells[terrain_locate(P, E.B.pos.x + pr.xr[u].x, E.B.pos.y + pr.xr[u].y, pr.tx[u], pr.ty[u])];
+        if (HF) {
+            const int cell = terrain_locate(P, E.B.pos.x + pr.xr[u].x, E.B.pos.y + pr.xr[u].y, pr.tx[u], pr.ty[u]);
+            pr.cc[u] = P.hf_cells[terrain_record(P, cell, pr.tx[u], pr.ty[u])];
+        }
     }
     return pr;
 }
@@ -375,12 +378,16 @@ GRX_DEV void tree_contacts(KP P, const TreeTab& T, float* wsw, int ei, int c, co
                     th.h = 0.f; th.gx = 0.f; th.gy = 0.f;
                     if (HF && E.B.pos.z + pr.xr[u].z - T.sph[s0 + u].r <= E.hmax) {
                         TerrainRaw raw;
-                        raw.h00 = (int16_t)(pr.cc[u].x & 0xffffu); raw.h01 = (int16_t)(pr.cc[u].x >> 16);
-                        raw.h10 = (int16_t)(pr.cc[u].y & 0xffffu); raw.h11 = (int16_t)(pr.cc[u].y >> 16);
+                        terrain_unpack(pr.cc[u], raw);
                         raw.tx = pr.tx[u]; raw.ty = pr.ty[u];
                         th.h = terrain_eval<HF>(P, raw, th.gx, th.gy);
                     }
                     Fs[u] = tree_sphere<HF, false>(P, T.sph[s0 + u], w, v, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, pr.xr[u], th);
+                    if (HF && P.vertical_faces && E.B.pos.z + pr.xr[u].z - T.sph[s0 + u].r <= E.hmax) {   // mesh_type 'trimesh': the vertical faces next to the shape
+                        float wtx, wty;
+                        const uint4 ww = wall_gather(P, E.B.pos.x + pr.xr[u].x, E.B.pos.y + pr.xr[u].y, wtx, wty);
+                        Fs[u] = Fs[u] + wall_contact(P, ww, wtx, wty, E.B.pos.z + pr.xr[u].z, T.sph[s0 + u].r, T.sph[s0 + u].dmax, v + cross(w, pr.xr[u]), E.mu);
+                    }
                     fa = fa + cross(pr.xr[u], Fs[u]); fl = fl + Fs[u];
                 }
         }

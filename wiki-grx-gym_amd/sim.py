@@ -224,6 +224,14 @@ class SimHandle:
                                                out.ctypes.data_as(C.POINTER(C.c_float)), self._stream()), "debug_terrain")
         return out
 
+    def debug_wall(self, xyzr):
+        """TEST-ONLY (include/grx.h grx_debug_wall): (n, 3) overlap x direction of the spheres (n, 4: x, y, z, r) with the vertical faces of the trimesh next to them."""
+        xyzr = np.ascontiguousarray(xyzr, dtype=np.float32)
+        out = np.zeros((xyzr.shape[0], 3), dtype=np.float32)
+        self._check(self._api["debug_wall"](self._h, xyzr.ctypes.data_as(C.POINTER(C.c_float)), int(xyzr.shape[0]),
+                                            out.ctypes.data_as(C.POINTER(C.c_float)), self._stream()), "debug_wall")
+        return out
+
     def episode_stats(self):
         out = (C.c_float * (_capi.NUM_REWARD_TERMS + 2))()   # means, [NT] episodes that ended, [NT + 1] mean terrain level
         self._check(self._api["episode_stats"](self._h, out, self._stream()), "episode_stats")
