@@ -75,7 +75,7 @@ def make_cfg(terrain, robot="lower_limb"):
     # registered task "GR1T1" = lower-limb config (the headline); --robot full_body = BASELINE.json config 5 (32 DOF)
     # --robot gr1t2 = the robot of BASELINE.json's fourth configuration (GR1T2 lower limb, same fused kernels; a rank's 4096-env shard)
     cfg = config.GR1T1Cfg() if robot == "lower_limb" else config.GR1T2Cfg() if robot == "gr1t2" else config.GR1T1FullBodyCfg()
-    cfg.terrain.mesh_type = "heightfield" if terrain == "rough" else "plane"
+    cfg.terrain.mesh_type = {"rough": "heightfield", "trimesh": "trimesh", "flat": "plane"}[terrain]
     cfg.terrain.curriculum = True
     # THE PRODUCT DEFAULT (round 5): the tensors nobody reads in a rollout -- rigid_body_states ("not counted, 1924 B"),
     # measured_heights -- are published ON REFRESH (include/grx.h grx_publish_mode: materialised by grx_refresh when read), which is what
@@ -171,7 +171,8 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20000; 2000 for --robot full_body)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default: steps / 10)")
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
-    ap.add_argument("--terrain", choices=["rough", "flat"], default="rough")
+    ap.add_argument("--terrain", choices=["rough", "flat", "trimesh"], default="rough",
+                    help="rough: the curriculum raster as a heightfield (BASELINE.json's configurations); trimesh: the same raster as the reference's slope-corrected triangle mesh (vertical faces)")
     ap.add_argument("--robot", choices=["lower_limb", "gr1t2", "full_body"], default="lower_limb",
                     help="full_body: the 32-DOF GR1T1 of BASELINE.json config 5 (tree kernel, grx_tree.h), not the headline; "
                          "gr1t2: the GR1T2 lower-limb robot of config 4 on the headline's kernels")
@@ -214,7 +215,7 @@ def main():
     n_local = args.envs_per_gpu
     n_total = n_local * world
     cfg = make_cfg(args.terrain, args.robot)
-    terrain_obj = Terrain(cfg.terrain, n_total, seed=seed) if args.terrain == "rough" else None
+    terrain_obj = Terrain(cfg.terrain, n_total, seed=seed) if args.terrain != "flat" else None
     c, keep, _ = build_config.build(cfg, cfg.sim.dt, n_local, rank * n_local, n_total, seed, terrain_obj)
     os.environ.setdefault("GRX_PUBLISH_DEBUG", "0")   # production path: no per-term debug tensors
     sim = HipSim(c, dev, keep)
@@ -289,9 +290,9 @@ def main():
     out = None
     layout = sim.layout()
     if rank == 0:
-        bytes_per = B_ROUGH if args.terrain == "rough" else B_FLAT
+        bytes_per = B_ROUGH if args.terrain != "flat" else B_FLAT
         if args.robot == "full_body":   # B_full = 3422 B/env-step (+726 of height gathers on rough terrain)
-            bytes_per = 3422.0 + (726.0 if args.terrain == "rough" else 0.0)
+            bytes_per = 3422.0 + (726.0 if args.terrain != "flat" else 0.0)
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this very workload (separate FETCH_SIZE /
         # WRITE_SIZE runs, tools/collect_profiles.sh); bench.py cannot host the profiler itself.  Raw counter sum:
         # FETCH_SIZE is a lower bound on gfx950 (MI355X_MICROARCH.md), see the note inside the file.
@@ -318,7 +319,7 @@ def main():
                     valu_insts = None
         achieved = bytes_per * n_local / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         out = {
-            "metric": f"env-steps/sec {'GR1T2' if args.robot == 'gr1t2' else 'GR1T1'} {'rough' if args.terrain == 'rough' else 'flat'}-terrain @{n_local} envs"
+            "metric": f"env-steps/sec {'GR1T2' if args.robot == 'gr1t2' else 'GR1T1'} {'flat' if args.terrain == 'flat' else 'rough'}-terrain{' (trimesh)' if args.terrain == 'trimesh' else ''} @{n_local} envs"
                       + (" [full-body 32 DOF, config 5]" if args.robot == "full_body" else ""),
             "value": n_total * args.steps / elapsed,
             "unit": "env-steps/s",
@@ -331,7 +332,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{'GR1T2' if args.robot == 'gr1t2' else 'GR1T1'} {'full body (32 DOF, tree kernel)' if args.robot == 'full_body' else 'lower-limb (10 DOF)'}, {'rough-terrain curriculum heightfield 10x20 tiles + 121-pt height scan' if args.terrain == 'rough' else 'flat plane'}, "
+            "config": {"workload": f"{'GR1T2' if args.robot == 'gr1t2' else 'GR1T1'} {'full body (32 DOF, tree kernel)' if args.robot == 'full_body' else 'lower-limb (10 DOF)'}, {'flat plane' if args.terrain == 'flat' else 'rough-terrain curriculum ' + ('trimesh (the raster as the slope-corrected triangle mesh, vertical faces)' if args.terrain == 'trimesh' else 'heightfield') + ' 10x20 tiles + 121-pt height scan'}, "
                                    f"{n_local} envs/GPU, decimation 10 @ dt 0.002, DR+noise+push on, action latency 5 sub-steps, random actions U[clip_min,clip_max]",
                        "envs_per_gpu": n_local, "global_envs": n_total, "parallelism": f"env-sharded x{world} (no data-path collective)",
                        "finite_outputs": finite, "prespin_ms": prespin, "prespin_kind": prespin_kind,

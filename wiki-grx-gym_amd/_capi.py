@@ -216,6 +216,7 @@ def bind(lib, prefix="grx_"):
         api["layout"] = fn("layout", C.c_int, H, C.POINTER(LayoutInfo))
     if hasattr(lib, prefix + "debug_terrain") and prefix == "grx_":   # (the oracle's entry of that name takes one point: oracle/binding.py)
         api["debug_terrain"] = fn("debug_terrain", C.c_int, H, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.c_void_p)
+    if hasattr(lib, prefix + "debug_wall") and prefix == "grx_":
         api["debug_wall"] = fn("debug_wall", C.c_int, H, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.c_void_p)
     if hasattr(lib, prefix + "sizeof"):
         api["sizeof"] = fn("sizeof", C.c_int, C.c_int)

@@ -1418,6 +1418,9 @@ int grx_reset_idx(grx_handle s, const int32_t* env_ids, int32_t n, void* stream)
     return GRX_OK;
 }
 
+// the launchers' `heightfield` argument: 0 plane, 1 the raster as a heightfield, 2 mesh_type 'trimesh' (the *_trimesh kernels: the reference's corrected mesh)
+static int terrain_mode(const grx_sim* s) { return s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD ? (s->cfg.vertical_faces ? 2 : 1) : 0; }
+
 int grx_step(grx_handle s, grx_step_args* a, void* stream) {
     if (!s || !a) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_step: null argument");
     hipStream_t st = (hipStream_t)stream;
@@ -1457,18 +1460,18 @@ int grx_step(grx_handle s, grx_step_args* a, void* stream) {
     if (s->generic)
     {
         if (s->d_tree) {
-            if ((s->tree_g == GRX_TREE_GMAX ? grx_launch_step_tree16 : grx_launch_step_tree)(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_waves, s->tree_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions, a->delay_substeps,
+            if ((s->tree_g == GRX_TREE_GMAX ? grx_launch_step_tree16 : grx_launch_step_tree)(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_waves, s->tree_lds, terrain_mode(s), a->actions, a->delay_substeps,
                                      (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st))
                 return fail(GRX_ERR_HIP, "grx_step: cannot raise the dynamic LDS limit of the tree kernel");
-        } else if (grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->gen_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, a->actions,
+        } else if (grx_launch_step_generic(s->d_hp, s->d_gen, s->d_ws, s->N, s->gen_epb, s->gen_lds, terrain_mode(s), a->actions,
                                     a->delay_substeps, (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, q.seq, st))
             return fail(GRX_ERR_HIP, "grx_step: cannot raise the dynamic LDS limit of the generic kernel");
     }
     else
     {
-        if (s->quad) grx_launch_step_quad(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
+        if (s->quad) grx_launch_step_quad(s->d_hp, s->N, terrain_mode(s), s->waves, a->actions, a->delay_substeps,
                                           (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st);
-        else grx_launch_step(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, a->actions, a->delay_substeps,
+        else grx_launch_step(s->d_hp, s->N, terrain_mode(s), s->waves, a->actions, a->delay_substeps,
                              (long long)a->common_step_counter, a->noise_uniform, a->obs_out, a->pri_obs_out, &q, st);
     }
     if (timed) {
@@ -1567,18 +1570,23 @@ int grx_layout(grx_handle s, grx_layout_info* out) {
     if (!s || !out) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_layout: null argument");
     memset(out, 0, sizeof *out);
     const char* hf = s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD ? "true" : "false";
+    const bool tm = terrain_mode(s) == 2;   // mesh_type 'trimesh': the *_trimesh entries of the same kernels
     if (s->generic && s->d_tree) {
         out->lanes_per_env = s->tree_g; out->waves_per_block = s->tree_waves; out->envs_per_block = (s->tree_g == GRX_TREE_GMAX ? grx_tree_envs_per_wave16() : grx_tree_envs_per_wave()) * s->tree_waves;
-        snprintf(out->kernel, sizeof out->kernel, s->tree_g == GRX_TREE_GMAX ? "grx_step_tree16<%s, false>" : "grx_step_tree<%s, false>", hf);
+        if (tm) snprintf(out->kernel, sizeof out->kernel, s->tree_g == GRX_TREE_GMAX ? "grx_step_tree16_trimesh<false>" : "grx_step_tree_trimesh<false>");
+        else snprintf(out->kernel, sizeof out->kernel, s->tree_g == GRX_TREE_GMAX ? "grx_step_tree16<%s, false>" : "grx_step_tree<%s, false>", hf);
     } else if (s->generic) {
         out->lanes_per_env = 1; out->waves_per_block = 1; out->envs_per_block = s->gen_epb;
-        snprintf(out->kernel, sizeof out->kernel, "grx_step_generic<%s>", hf);
+        if (tm) snprintf(out->kernel, sizeof out->kernel, "grx_step_generic_trimesh");
+        else snprintf(out->kernel, sizeof out->kernel, "grx_step_generic<%s>", hf);
     } else if (s->quad) {
         out->lanes_per_env = 4; out->waves_per_block = s->waves; out->envs_per_block = grx_envs_per_block_quad();
-        snprintf(out->kernel, sizeof out->kernel, "grx_step_kernel_quad<%s, %d, false>", hf, s->waves);
+        if (tm) snprintf(out->kernel, sizeof out->kernel, "grx_step_kernel_quad_trimesh<%d, false>", s->waves);
+        else snprintf(out->kernel, sizeof out->kernel, "grx_step_kernel_quad<%s, %d, false>", hf, s->waves);
     } else {
         out->lanes_per_env = 2; out->waves_per_block = s->waves; out->envs_per_block = grx_envs_per_block();
-        snprintf(out->kernel, sizeof out->kernel, "grx_step_kernel<%s, %d, false>", hf, s->waves);
+        if (tm) snprintf(out->kernel, sizeof out->kernel, "grx_step_kernel_trimesh<%d, false>", s->waves);
+        else snprintf(out->kernel, sizeof out->kernel, "grx_step_kernel<%s, %d, false>", hf, s->waves);
     }
     out->num_blocks = (s->N + out->envs_per_block - 1) / out->envs_per_block;
     return GRX_OK;
@@ -1660,12 +1668,12 @@ int grx_debug_post_physics(grx_handle s, const grx_pipeline_state* ps, int apply
     const StepSeq sq = next_seq(s, st, false);
     // the post-physics half of the kernel this handle steps with (lane pairs: 1 / 4 / 8 waves; lane quads: 4 / 8; GRX_FORCE_GENERIC: the tree kernel)
     if (s->generic) {
-        if ((s->tree_g == GRX_TREE_GMAX ? grx_launch_step_tree_debug16 : grx_launch_step_tree_debug)(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_waves, s->tree_lds, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->d_dbg_actions,
+        if ((s->tree_g == GRX_TREE_GMAX ? grx_launch_step_tree_debug16 : grx_launch_step_tree_debug)(s->d_hp, s->d_tree, s->d_gen, s->N, s->tree_waves, s->tree_lds, terrain_mode(s), s->d_dbg_actions,
                                        (long long)a->common_step_counter, a->noise_uniform, s->d_dbg, &sq, st))
             return fail(GRX_ERR_HIP, "grx_debug_post_physics: cannot raise the dynamic LDS limit of the tree kernel");
-    } else if (s->quad) grx_launch_step_debug_quad(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, s->d_dbg_actions,
+    } else if (s->quad) grx_launch_step_debug_quad(s->d_hp, s->N, terrain_mode(s), s->waves, s->d_dbg_actions,
                                             (long long)a->common_step_counter, a->noise_uniform, s->d_dbg, &sq, st);
-    else grx_launch_step_debug(s->d_hp, s->N, s->cfg.terrain_type == GRX_TERRAIN_HEIGHTFIELD, s->waves, s->d_dbg_actions, (long long)a->common_step_counter,
+    else grx_launch_step_debug(s->d_hp, s->N, terrain_mode(s), s->waves, s->d_dbg_actions, (long long)a->common_step_counter,
                                a->noise_uniform, s->d_dbg, &sq, st);
     HIP_TRY(hipGetLastError());
     return GRX_OK;

@@ -81,7 +81,7 @@ GRX_DEV R3 gen_joint_rot(const R3& Rp, GT T, int b, float q) {
 }
 
 // one sphere of body `b` against the terrain with a run-time anchor slot; adds its force into the link accumulator
-template <bool HF>
+template <int HF>
 GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, float mu, float om_e, float hmax, float* ws, size_t WN, size_t N, int e,
                       int lfbase, V3& xr) {
     xr = rho + rot(R, v3(T.sx[i], T.sy[i], T.sz[i]));
@@ -131,7 +131,7 @@ GRX_DEV V3 gen_sphere(KP P, GT T, int i, const R3& R, V3 rho, V3 w, V3 v, V3 O, 
                 if (sp > 1e-9f) { const float k = -ft * grx_rcp(sp); F.x += k * u.x; F.y += k * u.y; }
             }
         }
-        if (HF && P.vertical_faces) {   // mesh_type 'trimesh': the vertical faces next to the shape (grx_kernels.hip wall_contact)
+        if (HF == GRX_HF_TRIMESH) {   // mesh_type 'trimesh': the vertical faces next to the shape (grx_kernels.hip wall_contact)
             float wtx, wty;
             const uint4 ww = wall_gather(P, wx, wy, wtx, wty);
             F = F + wall_contact(P, ww, wtx, wty, wz, r, T.sdmax[i], v + cross(w, xr), mu);
@@ -170,7 +170,7 @@ GRX_DEV void gen_foot_frames(KP P, GT T, const GenBase& B, const float* q, const
 }
 
 // One physics sub-step.  q / qd / torques: this env's columns of the SoA state arrays (stride N).
-template <bool HF>
+template <int HF>
 GRX_DEV void gen_substep(KP P, GT T, GenBase& B, float* q, float* qd, const float* tau, float* ws, size_t WN, size_t N, int e,
                          float base_m, V3 base_c, const S3& base_I, float mu, float om_e, float hmax, V3 foot_vel_before[2]) {
     const int nb = T.nb, lfbase = nb * WSB;
@@ -395,381 +395,15 @@ GRX_DEV float gen_masked_abs_sum(const float* a, size_t N, int nd, uint32_t mask
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+#define GRX_STEP_GENERIC_ARGS const KParams* __restrict__ Pg, const GenTables* __restrict__ Tg, float* __restrict__ wsg, const float* __restrict__ actions_in, float delay, long long common_step, \
+                              const float* __restrict__ noise_in, float* __restrict__ obs_out, float* __restrict__ pri_out, long long seq
 template <bool HF>
-__global__ __launch_bounds__(64) void grx_step_generic(const KParams* __restrict__ Pg, const GenTables* __restrict__ Tg, float* __restrict__ wsg,
-                                                       const float* __restrict__ actions_in, float delay, long long common_step,
-                                                       const float* __restrict__ noise_in, float* __restrict__ obs_out, float* __restrict__ pri_out,
-                                                       long long seq) {
-    KP P = GRX_PARAMS(Pg);
-    GT T = *reinterpret_cast<const GRX_AS4 GenTables*>(reinterpret_cast<uintptr_t>(Tg));
-    __shared__ float s_stat[NSTAT];
-    // blockDim.x = envs per block (64 by default)
-    const int lane = threadIdx.x, epb = blockDim.x;
-    for (int i = lane; i < NSTAT; i += epb) s_stat[i] = 0.f;
-    __syncthreads();
-    const size_t N = (size_t)P.N;
-    const int e_raw = blockIdx.x * epb + lane;
-    const bool act = e_raw < P.N;
-    const int e = act ? e_raw : P.N - 1;
-    const int nd = T.nd, nb = T.nb;
-    const uint32_t genv = (uint32_t)(P.env_offset + e), step = (uint32_t)common_step;
-    const int nh = P.nh, nobs = 9 + 3 * nd, npri = P.num_pri_obs;
-    const float dtp = P.sim_dt * (float)P.decimation;
-    // workspace: LDS when the block's rows fit (blockDim.x <= 16 envs for the 33-body robot: 155 KB), else global memory
-    extern __shared__ float s_ws[];
-    const bool lds_ws = wsg == nullptr;
-    float* ws = lds_ws ? s_ws + lane : wsg + e;   // this env's column of the [slot][env] workspace
-    const size_t WN = lds_ws ? (size_t)epb : N;
-    float* q = P.q + e; float* qd = P.qd + e;
-    float* a_cur = P.actions + e; float* a_last = P.last_actions + e; float* qd_last = P.last_dof_vel + e; float* tau = P.torques + e;
-    const float* strength = P.motor_strength + e;
-    // ---- load the base state
-    GenBase B;
-    B.pos = v3(P.root[e], P.root[N + e], P.root[2 * N + e]);
-    B.qx = P.root[3 * N + e]; B.qy = P.root[4 * N + e]; B.qz = P.root[5 * N + e]; B.qw = P.root[6 * N + e];
-    B.vel = v3(P.root[7 * N + e], P.root[8 * N + e], P.root[9 * N + e]);
-    B.ang = v3(P.root[10 * N + e], P.root[11 * N + e], P.root[12 * N + e]);
-    const float base_m = P.base_m[e];
-    const V3 base_c = v3(P.base_c[e], P.base_c[N + e], P.base_c[2 * N + e]);
-    const S3 base_I = {P.base_I[e], P.base_I[N + e], P.base_I[2 * N + e], P.base_I[3 * N + e], P.base_I[4 * N + e], P.base_I[5 * N + e]};
-    const float mu = 0.5f * (P.terrain_friction + P.friction[e]);
-    const float om_e = 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]);
-    float hmax = 0.f;
-    if (HF) {
-        int ci = min(max((int)((B.pos.x + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_rows - 1);
-        int cj = min(max((int)((B.pos.y + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
-        hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
-    }
-    EnvAux ea;
-    ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[N + e]; ea.cmd[2] = P.commands[2 * N + e];
-    ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[N + e]; ea.origin[2] = P.origins[2 * N + e];
-    ea.level = P.levels[e]; ea.type = P.types[e];
-    float air_time[2] = {P.air_time[e], P.air_time[N + e]}, land_time[2] = {P.land_time[e], P.land_time[N + e]};
-    bool contact_last[2] = {P.feet_contact[e] != 0, P.feet_contact[N + e] != 0};
-    const float bho_stale = P.base_heights_offset[e];
-    long long ep_len = P.ep_len[e];
-    // ---- clip_actions (legged_robot_fftai.py:171-177); last_actions still hold the previous step's
-    for (int j = 0; j < nd; ++j) {
-        const float a = actions_in ? actions_in[(size_t)e * nd + j] : 0.f;
-        a_cur[(size_t)j * N] = fminf(fmaxf(a, T.amin[j]), T.amax[j]);
-    }
-    // ---- during_physics_step (legged_robot_fftai.py:51-88)
-    float avg_force[2] = {0.f, 0.f};
-    V3 avg_speed[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
-    V3 avg_rpy[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};   // avg_feet_speed_rpy (legged_robot_fftai.py:81, 88)
-    V3 fvel[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)}, fpos[2];
-    const int lfbase = nb * WSB;
-    for (int deci = 0; deci < P.decimation; ++deci) {
-        const bool use_last = (float)deci < delay;
-        for (int j = 0; j < nd; ++j) {   // _compute_torques legged_robot.py:679-715
-            const float a = use_last ? a_last[(size_t)j * N] : a_cur[(size_t)j * N];
-            float t = control_torque(P, T.kp[j], T.kd[j], T.q0[j], a, q[(size_t)j * N], qd[(size_t)j * N], P.last_dof_vel + (size_t)j * N + e);
-            t *= strength[(size_t)j * N];
-            tau[(size_t)j * N] = fminf(fmaxf(t, -T.effort[j]), T.effort[j]);
-        }
-        gen_substep<HF>(P, T, B, q, qd, tau, ws, WN, N, e, base_m, base_c, base_I, mu, om_e, hmax, fvel);
-        if (deci > 0)
-            for (int f = 0; f < 2; ++f) {
-                avg_speed[f] = v3(avg_speed[f].x + fabsf(fvel[f].x), avg_speed[f].y + fabsf(fvel[f].y), avg_speed[f].z + fabsf(fvel[f].z));
-                const V3 fw = ws_v3(ws, WN, T.foot_body[f], W_W);   // (the walk's: BEFORE this sub-step's integration, like fvel)
-                avg_rpy[f] = v3(avg_rpy[f].x + fabsf(fw.x), avg_rpy[f].y + fabsf(fw.y), avg_rpy[f].z + fabsf(fw.z));
-            }
-        for (int f = 0; f < 2; ++f) {
-            const int L = T.foot_link[f];
-            const V3 F = v3(ws[(size_t)(lfbase + L * 3) * WN], ws[(size_t)(lfbase + L * 3 + 1) * WN], ws[(size_t)(lfbase + L * 3 + 2) * WN]);
-            avg_force[f] += grx_sqrt(dot(F, F));
-        }
-    }
-    gen_foot_frames(P, T, B, q, qd, ws, WN, N, e, fpos, fvel);   // refresh_rigid_body_state_tensor after the last sub-step
-    V3 foot_force[2];
-    for (int f = 0; f < 2; ++f) {
-        avg_speed[f] = v3((avg_speed[f].x + fabsf(fvel[f].x)) / (float)P.decimation, (avg_speed[f].y + fabsf(fvel[f].y)) / (float)P.decimation,
-                          (avg_speed[f].z + fabsf(fvel[f].z)) / (float)P.decimation);
-        avg_force[f] /= (float)P.decimation;
-        {
-            const V3 fw = ws_v3(ws, WN, T.foot_body[f], W_W);
-            avg_rpy[f] = v3((avg_rpy[f].x + fabsf(fw.x)) / (float)P.decimation, (avg_rpy[f].y + fabsf(fw.y)) / (float)P.decimation, (avg_rpy[f].z + fabsf(fw.z)) / (float)P.decimation);
-        }
-        const int L = T.foot_link[f];
-        foot_force[f] = v3(ws[(size_t)(lfbase + L * 3) * WN], ws[(size_t)(lfbase + L * 3 + 1) * WN], ws[(size_t)(lfbase + L * 3 + 2) * WN]);
-    }
-    // termination / collision from the per-link net forces of the LAST sub-step (legged_robot.py:336-353)
-    bool term_contact = false;
-    float pen_count = 0.f;
-    for (int L = 0; L < T.nlc; ++L) {
-        const V3 F = v3(ws[(size_t)(lfbase + L * 3) * WN], ws[(size_t)(lfbase + L * 3 + 1) * WN], ws[(size_t)(lfbase + L * 3 + 2) * WN]);
-        const float n2 = dot(F, F);
-        if ((T.link_flags[L] & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term_contact = true;
-        if ((T.link_flags[L] & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.f;
-        if (act) {   // contact_forces (legged_robot.py:117): one row per URDF link
-            float* cf = P.contact_forces + (size_t)(T.link_urdf[L] * 3) * N + e;
-            cf[0] = F.x; cf[N] = F.y; cf[2 * N] = F.z;
-        }
-    }
-    // torso / forehead orientation (frames of the final state are in the workspace)
-    float torso_g[2] = {0.f, 0.f}, fore_g[2] = {0.f, 0.f};
-    if (T.torso_body >= 0) {
-        const R3 R = ws_R(ws, WN, T.torso_body);
-        torso_g[0] = -(R.cx.z * T.torso_rot[0] + R.cy.z * T.torso_rot[3] + R.cz.z * T.torso_rot[6]);
-        torso_g[1] = -(R.cx.z * T.torso_rot[1] + R.cy.z * T.torso_rot[4] + R.cz.z * T.torso_rot[7]);
-    }
-    if (T.forehead_body >= 0) {
-        const R3 R = ws_R(ws, WN, T.forehead_body);
-        fore_g[0] = -(R.cx.z * T.forehead_rot[0] + R.cy.z * T.forehead_rot[3] + R.cz.z * T.forehead_rot[6]);
-        fore_g[1] = -(R.cx.z * T.forehead_rot[1] + R.cy.z * T.forehead_rot[4] + R.cz.z * T.forehead_rot[7]);
-    }
-    // ---- post_physics_step (legged_robot.py:269-334)
-    ep_len += 1;
-    const V3 qv = v3(B.qx, B.qy, B.qz);
-    const V3 blv = quat_rotate_inverse(qv, B.qw, B.vel), bav = quat_rotate_inverse(qv, B.qw, B.ang);
-    const V3 pg = quat_rotate_inverse(qv, B.qw, v3(0.f, 0.f, -1.f));
-    if (P.resample_command_interval > 0 && ((uint32_t)ep_len % (uint32_t)P.resample_command_interval) == 0)
-        resample_commands(P, genv, step, GRX_RNG_CMD_TIME, ea.cmd);
-    if (P.heading_command) ea.cmd[2] = heading_yaw_command(P, qv, B.qw);   // legged_robot.py:320-326
-    float* heights = P.heights + e;   // raw measured heights (always materialised here: the reward / obs code reads them back)
-    float hsum = 0.f;
-    if (HF && P.measure_heights) {
-        const float yaw_n = fmaxf(sqrtf(B.qz * B.qz + B.qw * B.qw), 1e-9f);
-        const float yz = B.qz / yaw_n, yw = B.qw / yaw_n;
-        for (int k = 0; k < nh; ++k) {
-            const float h = height_sample(P, *P.tables, yz, yw, B.pos, k);
-            heights[(size_t)k * N] = h;
-            hsum += h;
-        }
-    } else
-        for (int k = 0; k < nh; ++k) heights[(size_t)k * N] = 0.f;
-    if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {
-        B.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
-        B.vel.y = urand(P, genv, step, GRX_RNG_PUSH, 1, -P.max_push_vel_xy, P.max_push_vel_xy);
-    }
-    // feet timers (legged_robot_fftai.py:108-133)
-    bool contact[2], contact_filt[2], first_contact[2];
-    float feet_height[2];
-    for (int f = 0; f < 2; ++f) {
-        contact[f] = foot_force[f].z > 1.0f;
-        contact_filt[f] = contact[f] || contact_last[f];
-        contact_last[f] = contact[f];
-        first_contact[f] = (air_time[f] > 0.f) && contact_filt[f];
-        air_time[f] += dtp;
-        feet_height[f] = nh > 0 ? (fpos[f].z * (float)nh - hsum) / (float)nh : fpos[f].z;
-        land_time[f] = (land_time[f] + dtp) * (contact[f] ? 1.f : 0.f);
-    }
-    bool reset = term_contact || (fabsf(pg.z) < P.termination_gravity_z);
-    const bool time_out = (float)ep_len > P.max_episode_length;
-    reset = reset || time_out;
-    // ---- compute_reward (legged_robot.py:355-375; terms legged_robot_fftai.py:180-352, gr1t1.py:338-589)
-    float r[NT];
-    {
-        const float as = P.action_scale, H = P.swing_feet_height_target, Tt = P.feet_air_time_target;
-        const GRX_AS4 float* sg = P.reward_sigma;
-        float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
-        for (int j = 0; j < nd; ++j) {
-            const float ac = a_cur[(size_t)j * N], al = a_last[(size_t)j * N], qj = q[(size_t)j * N], qdj = qd[(size_t)j * N], tj = tau[(size_t)j * N];
-            s1 += fabsf((al - ac) * as);
-            if (P.knee_mask & (1u << j)) s3 += fabsf((ac - al) * as);
-            sacc += fabsf((qdj - qd_last[(size_t)j * N]) / dtp);
-            stor += fabsf(tj);
-            svel += fabsf(qdj);
-            const float po = fabsf(qj - T.q0[j]);
-            spose += po;
-            if (P.hip_yaw_mask & (1u << j)) shy += po;
-            const float a = ac * as;
-            float oa = 0.f, op = 0.f;
-            if (a - T.slo[j] < 0.f) oa += -(a - T.slo[j]);
-            if (a - T.shi[j] > 0.f) oa += (a - T.shi[j]);
-            sla += oa * oa;
-            if (qj - T.slo[j] < 0.f) op += -(qj - T.slo[j]);
-            if (qj - T.shi[j] > 0.f) op += (qj - T.shi[j]);
-            slp += fabsf(op);
-            slv += fminf(fmaxf(fabsf(qdj) - T.vlim[j] * P.soft_dof_vel_limit, 0.f), 1.f);
-            slt += fmaxf(fabsf(tj) - T.effort[j] * P.soft_torque_limit, 0.f);
-        }
-        const float tor_hr = gen_masked_abs_sum(tau, N, nd, P.hip_roll_mask), vel_kn = gen_masked_abs_sum(qd, N, nd, P.knee_mask);
-        const float hmin = fminf(feet_height[0], feet_height[1]);
-        float lift = 0.f, af = 0.f, ah = 0.f, at = 0.f, lt = 0.f, exy = 0.f, ez = 0.f, stum = 0.f, ncontact = 0.f;
-        for (int f = 0; f < 2; ++f) {
-            const float h = feet_height[f];
-            lift += gen_masked_abs_sum(tau, N, nd, f ? P.ankle_right_mask : P.ankle_left_mask) * fabsf(h) * (h > H * 0.5f ? 1.f : 0.f);
-            const float mid = fabsf(air_time[f] - Tt * 0.5f);
-            af += mid * avg_force[f];
-            ah += mid * fabsf(h - hmin - H);
-            at += expf(sg[GRX_REW_FEET_AIR_TIME] * fabsf(air_time[f] - Tt)) * (first_contact[f] ? 1.f : 0.f);
-            const float le = (land_time[f] - P.feet_land_time_max) * (land_time[f] > P.feet_land_time_max ? 1.f : 0.f);
-            lt += 1.f - expf(sg[GRX_REW_FEET_LAND_TIME] * le);
-            const float close = fabsf(h - H * 0.25f) * (h < H * 0.25f ? 1.f : 0.f) / (H * 0.25f);
-            exy += sqrtf(avg_speed[f].x * avg_speed[f].x + avg_speed[f].y * avg_speed[f].y) * close;
-            const float far = fabsf(h - H * 3.f / 4.f) * (h > H * 3.f / 4.f ? 1.f : 0.f) / (H * 1.f / 4.f);
-            ez += fabsf(avg_speed[f].z) * far;
-            const V3 F = foot_force[f];
-            float serr = sqrtf(F.x * F.x + F.y * F.y) - P.feet_stumble_ratio * fabsf(F.z);
-            serr = serr * (serr > 0.f ? 1.f : 0.f);
-            stum += 1.f - expf(sg[GRX_REW_FEET_STUMBLE] * serr);
-            ncontact += contact[f] ? 1.f : 0.f;
-        }
-        const float cmd_n = sqrtf(ea.cmd[0] * ea.cmd[0] + ea.cmd[1] * ea.cmd[1]);
-        const float moving = cmd_n > 0.1f ? 1.f : 0.f;
-        r[GRX_REW_ACTION_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF] * s1);
-        r[GRX_REW_ACTION_DIFF_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_DIFF] * s1);   // last_last_actions == last_actions
-        r[GRX_REW_ACTION_DIFF_KNEE] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_KNEE] * s3);
-        r[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] * fabsf(0.f - bav.y));
-        r[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] * fabsf(0.f - bav.x));
-        r[GRX_REW_CMD_DIFF_ANG_VEL_YAW] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_YAW] * fabsf(ea.cmd[2] - bav.z));
-        r[GRX_REW_CMD_DIFF_BASE_HEIGHT] = expf(sg[GRX_REW_CMD_DIFF_BASE_HEIGHT] * (fabsf(bho_stale) * (bho_stale < 0.f ? 1.f : 0.f)));
-        r[GRX_REW_CMD_DIFF_BASE_ORIENT] = expf(sg[GRX_REW_CMD_DIFF_BASE_ORIENT] * (fabsf(pg.x) + fabsf(pg.y)));
-        r[GRX_REW_CMD_DIFF_TORSO_ORIENT] = T.torso_body >= 0 ? expf(sg[GRX_REW_CMD_DIFF_TORSO_ORIENT] * (fabsf(torso_g[0]) + fabsf(torso_g[1]))) : 0.f;
-        r[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] = T.forehead_body >= 0 ? expf(sg[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] * (fabsf(fore_g[0]) + fabsf(fore_g[1]))) : 0.f;
-        r[GRX_REW_CMD_DIFF_LIN_VEL_X] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_X] * fabsf(ea.cmd[0] - blv.x));
-        r[GRX_REW_CMD_DIFF_LIN_VEL_Y] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Y] * fabsf(ea.cmd[1] - blv.y));
-        r[GRX_REW_CMD_DIFF_LIN_VEL_Z] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Z] * fabsf(0.f - blv.z));
-        r[GRX_REW_COLLISION] = 1.f - expf(sg[GRX_REW_COLLISION] * pen_count);
-        r[GRX_REW_DOF_ACC_NEW] = 1.f - expf(sg[GRX_REW_DOF_ACC_NEW] * sacc);
-        r[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] = 1.f - expf(sg[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] * lift);
-        r[GRX_REW_DOF_TOR_NEW] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW] * stor);
-        r[GRX_REW_DOF_TOR_NEW_HIP_ROLL] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW_HIP_ROLL] * tor_hr);
-        r[GRX_REW_DOF_VEL_NEW] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW] * svel);
-        r[GRX_REW_DOF_VEL_NEW_KNEE] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW_KNEE] * vel_kn);
-        r[GRX_REW_FEET_AIR_FORCE] = expf(sg[GRX_REW_FEET_AIR_FORCE] * af) * moving;
-        r[GRX_REW_FEET_AIR_HEIGHT] = expf(sg[GRX_REW_FEET_AIR_HEIGHT] * ah) * moving;
-        r[GRX_REW_FEET_AIR_TIME] = at * moving;
-        r[GRX_REW_FEET_LAND_TIME] = lt * moving;
-        r[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] = expf(sg[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] * exy);
-        r[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] = expf(sg[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] * ez);
-        r[GRX_REW_FEET_STUMBLE] = stum;
-        r[GRX_REW_LIMITS_ACTIONS] = 1.f - expf(sg[GRX_REW_LIMITS_ACTIONS] * sla);
-        r[GRX_REW_LIMITS_DOF_POS] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_POS] * slp);
-        r[GRX_REW_LIMITS_DOF_TOR] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_TOR] * slt);
-        r[GRX_REW_LIMITS_DOF_VEL] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_VEL] * slv);
-        r[GRX_REW_ON_THE_AIR] = ncontact == 0.f ? 1.f : 0.f;
-        r[GRX_REW_POSE_OFFSET] = expf(sg[GRX_REW_POSE_OFFSET] * spose);
-        r[GRX_REW_POSE_OFFSET_HIP_YAW] = 1.f - expf(sg[GRX_REW_POSE_OFFSET_HIP_YAW] * shy);
-        r[GRX_REW_STAND_STILL] = expf(sg[GRX_REW_STAND_STILL] * spose) * (cmd_n < 0.1f ? 1.f : 0.f);
-        r[GRX_REW_TERMINATION] = (reset && !time_out) ? 1.f : 0.f;
-    }
-    float rew = 0.f;
-    for (int t = 0; t < NT; ++t) {
-        const float sc_t = P.reward_scale_dt[t];
-        float rt = 0.f;
-        if (t != GRX_REW_TERMINATION && sc_t != 0.f) { rt = r[t] * sc_t; rew += rt; }
-        r[t] = rt;
-    }
-    if (P.only_positive_rewards) rew = fmaxf(rew, 0.f);
-    if (P.reward_scale_dt[GRX_REW_TERMINATION] != 0.f) {
-        const float rt = r[GRX_REW_TERMINATION] = ((reset && !time_out) ? 1.f : 0.f) * P.reward_scale_dt[GRX_REW_TERMINATION];
-        rew += rt;
-    }
-    // episode sums; finished episodes -> the block's statistics row (deterministic lane order)
-    const unsigned long long reset_mask = __ballot(reset && act);
-    for (int t = 0; t < NT; ++t) {
-        const float es = ((P.reward_scale_dt[t] != 0.f) ? P.episode_sums[(size_t)t * N + e] : 0.f) + r[t];
-        if (reset_mask) {
-            float acc = 0.f;
-            unsigned long long m = reset_mask;
-            while (m) { const int L = __ffsll((long long)m) - 1; m &= m - 1; acc += __shfl(es, L); }
-            if (lane == 0) s_stat[t] = acc;
-        }
-        if (act && P.reward_scale_dt[t] != 0.f) {
-            P.episode_sums[(size_t)t * N + e] = reset ? 0.f : es;
-            if (P.publish_debug) P.reward_terms[(size_t)t * N + e] = r[t];
-        }
-    }
-    if (lane == 0) s_stat[NT] = (float)__popcll(reset_mask);
-    // ---- reset_idx (masked, in-kernel)
-    if (reset) {
-        gen_reset_env(P, T, genv, step, true, B, ea, q, qd, N, e);
-        for (int j = 0; j < nd; ++j) { a_last[(size_t)j * N] = 0.f; qd_last[(size_t)j * N] = 0.f; }
-        for (int f = 0; f < 2; ++f) { air_time[f] = 0.f; land_time[f] = 0.f; contact_last[f] = false; }
-        ep_len = 0;
-    }
-    {   // statistics row NT + 1: terrain levels after this step's curriculum moves (legged_robot.py:427-428)
-        const float ls = level_sum(ea.level, act);
-        if (lane == 0) s_stat[NT + 1] = ls;
-    }
-    // ---- compute_observations (legged_robot_fftai.py:148-167, gr1t1.py:281-336)
-    float* obs = (obs_out ? obs_out : P.obs) + (size_t)e * nobs;
-    float* pri = (pri_out ? pri_out : P.pri_obs) + (size_t)e * npri;
-    const float clipo = P.clip_observations;
-    float bho = 0.f;
-    {
-        float sum = 0.f;
-        for (int k = 0; k < nh; ++k) {
-            float d = B.pos.z - P.base_height_target - heights[(size_t)k * N];
-            d = fminf(fmaxf(d, -1.f), 1.f) * P.obs_scale_height;
-            if (act) pri[nobs + 8 + k] = fminf(fmaxf(d * P.obs_scale_height, -clipo), clipo);
-            sum += d;
-        }
-        bho = nh > 0 ? sum / (float)nh : 0.f;
-    }
-    if (act) {
-        auto put = [&](int idx, float val, float nscale) {
-            pri[idx] = fminf(fmaxf(val, -clipo), clipo);   // pri_obs copies obs BEFORE noise
-            float ov = val;
-            if (P.add_noise && nscale != 0.f) {
-                float u;
-                if (noise_in) u = noise_in[(size_t)e * nobs + idx];
-                else if (idx < 9) u = grx_rand(P.seed, genv, step, GRX_RNG_NOISE, (uint32_t)(idx - 3));
-                else {   // dof terms: one stream per half of the dof range (the oracle's scheme)
-                    const int g = (idx - 9) / nd, j = (idx - 9) % nd, half = nd / 2;
-                    const bool right = j >= half;
-                    u = grx_rand(P.seed, genv, step, right ? GRX_RNG_NOISE_DOF_R : GRX_RNG_NOISE_DOF_L, (uint32_t)(g * half + (right ? j - half : j)));
-                }
-                ov += (2.f * u - 1.f) * nscale;
-            }
-            obs[idx] = fminf(fmaxf(ov, -clipo), clipo);
-        };
-        put(0, ea.cmd[0], 0.f); put(1, ea.cmd[1], 0.f); put(2, ea.cmd[2], 0.f);
-        const float na = P.noise_ang_vel * P.noise_level * P.obs_scale_ang_vel, ng = P.noise_gravity * P.noise_level * P.obs_scale_gravity;
-        put(3, bav.x * P.obs_scale_ang_vel, na); put(4, bav.y * P.obs_scale_ang_vel, na); put(5, bav.z * P.obs_scale_ang_vel, na);
-        put(6, pg.x * P.obs_scale_gravity, ng); put(7, pg.y * P.obs_scale_gravity, ng); put(8, pg.z * P.obs_scale_gravity, ng);
-        const float np_ = P.noise_dof_pos * P.noise_level * P.obs_scale_dof_pos, nv = P.noise_dof_vel * P.noise_level * P.obs_scale_dof_vel;
-        const float nac = P.noise_action * P.noise_level * P.obs_scale_action;
-        for (int j = 0; j < nd; ++j) {
-            put(9 + j, (q[(size_t)j * N] - T.q0[j]) * P.obs_scale_dof_pos, np_);
-            put(9 + nd + j, qd[(size_t)j * N] * P.obs_scale_dof_vel, nv);
-            put(9 + 2 * nd + j, a_cur[(size_t)j * N] * P.obs_scale_action, nac);
-        }
-        pri[nobs + 0] = fminf(fmaxf(blv.x * P.obs_scale_lin_vel, -clipo), clipo);
-        pri[nobs + 1] = fminf(fmaxf(blv.y * P.obs_scale_lin_vel, -clipo), clipo);
-        pri[nobs + 2] = fminf(fmaxf(blv.z * P.obs_scale_lin_vel, -clipo), clipo);
-        pri[nobs + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
-        for (int f = 0; f < 2; ++f) {
-            pri[nobs + 4 + f] = (reset ? false : contact[f]) ? 1.f : 0.f;   // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
-            pri[nobs + 6 + f] = fminf(fmaxf(feet_height[f] * P.obs_scale_height, -clipo), clipo);
-        }
-        // ---- store state; history: last_actions = actions, last_dof_vel = dof_vel (legged_robot.py:299-300)
-        for (int j = 0; j < nd; ++j) { a_last[(size_t)j * N] = a_cur[(size_t)j * N]; qd_last[(size_t)j * N] = qd[(size_t)j * N]; }
-        const float rs[13] = {B.pos.x, B.pos.y, B.pos.z, B.qx, B.qy, B.qz, B.qw, B.vel.x, B.vel.y, B.vel.z, B.ang.x, B.ang.y, B.ang.z};
-        for (int i = 0; i < 13; ++i) P.root[(size_t)i * N + e] = rs[i];
-        for (int f = 0; f < 2; ++f) {
-            P.air_time[(size_t)f * N + e] = air_time[f] * (contact_filt[f] ? 0.f : 1.f);   // legged_robot_fftai.py:97
-            P.land_time[(size_t)f * N + e] = land_time[f];
-            P.feet_contact[(size_t)f * N + e] = (reset ? false : contact[f]) ? 1 : 0;
-            P.feet_height[(size_t)f * N + e] = feet_height[f];
-            P.avg_force[(size_t)f * N + e] = avg_force[f];
-            const float ff[3] = {foot_force[f].x, foot_force[f].y, foot_force[f].z}, fp[3] = {fpos[f].x, fpos[f].y, fpos[f].z};
-            const float as_[3] = {avg_speed[f].x, avg_speed[f].y, avg_speed[f].z}, ar_[3] = {avg_rpy[f].x, avg_rpy[f].y, avg_rpy[f].z};
-            for (int i = 0; i < 3; ++i) {
-                P.avg_speed_rpy[(size_t)(f * 3 + i) * N + e] = ar_[i];
-                P.feet_force[(size_t)(f * 3 + i) * N + e] = ff[i];
-                P.feet_pos[(size_t)(f * 3 + i) * N + e] = fp[i];
-                P.avg_speed[(size_t)(f * 3 + i) * N + e] = as_[i];
-            }
-        }
-        P.commands[e] = ea.cmd[0]; P.commands[N + e] = ea.cmd[1]; P.commands[2 * N + e] = ea.cmd[2];
-        P.base_lin_vel[e] = blv.x; P.base_lin_vel[N + e] = blv.y; P.base_lin_vel[2 * N + e] = blv.z;
-        P.base_ang_vel[e] = bav.x; P.base_ang_vel[N + e] = bav.y; P.base_ang_vel[2 * N + e] = bav.z;
-        P.proj_grav[e] = pg.x; P.proj_grav[N + e] = pg.y; P.proj_grav[2 * N + e] = pg.z;
-        P.origins[e] = ea.origin[0]; P.origins[N + e] = ea.origin[1]; P.origins[2 * N + e] = ea.origin[2];
-        P.levels[e] = ea.level;
-        P.base_heights_offset[e] = bho;
-        P.ep_len[e] = ep_len;
-        P.rew[e] = rew;
-        P.reset[e] = reset ? 1 : 0;
-        P.time_out[e] = time_out ? 1 : 0;
-        P.term_contact[e] = term_contact ? 1 : 0;
-    }
-    __syncthreads();
-    for (int i = lane; i < NSTAT; i += epb) stat_row(P, seq, i)[blockIdx.x] = s_stat[i];
-    if (blockIdx.x == 0 && lane == 0) P.stat_nblocks[seq & 1] = (int)gridDim.x;
+__global__ __launch_bounds__(64) void grx_step_generic(GRX_STEP_GENERIC_ARGS) {
+#include "grx_step_generic_body.inc"
+}
+__global__ __launch_bounds__(64) void grx_step_generic_trimesh(GRX_STEP_GENERIC_ARGS) {   // mesh_type 'trimesh'
+    constexpr int HF = GRX_HF_TRIMESH;
+#include "grx_step_generic_body.inc"
 }
 
 // BaseTask.reset() first half for the generic path

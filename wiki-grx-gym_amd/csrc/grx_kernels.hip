@@ -151,12 +151,15 @@ GRX_DEV void grx_sincos(float x, float& s, float& c) {
 
 // physics terrain query (oracle: terrain_query): height and gradient (gx, gy) = (dh/dx, dh/dy) of the surface under (x, y).
 //  * heightfield: bilinear patch of the int16 raster (hf_cells: the four corners of a cell in one 8-byte gather);
-//  * mesh_type 'trimesh' (P.vertical_faces, uniform): the reference's slope-corrected mesh (isaacgym terrain_utils.py:286-350 moves
+//  * mesh_type 'trimesh' (HF == 2: kernels of their own, grx_step_*_trimesh, so that the heightfield's code is what it was): the reference's slope-corrected mesh (isaacgym terrain_utils.py:286-350 moves
 //    vertices by whole cells, so it is still described per raster cell: grx_capi.cpp build_trimesh_tables): the plane of the
 //    triangle half under the point, from that half's three corner heights -- again ONE 8-byte gather; the mesh's vertical
 //    faces are a second contact (wall_contact below).
 // In two halves: the gather (~1.2 us of memory latency on this part) and the interpolation that first USES it -- a caller
 // with independent work puts it between the two.
+#ifndef GRX_TE_BARRIER
+#define GRX_TE_BARRIER (GRX_LPE == 4)   // see terrain_eval
+#endif
 struct TerrainRaw { int h00, h01, h10, h11; float tx, ty; };
 // raster cell under (x, y) (index of its low corner) and the position inside it
 GRX_DEV int terrain_locate(KP P, float x, float y, float& tx, float& ty) {
@@ -168,28 +171,36 @@ GRX_DEV int terrain_locate(KP P, float x, float y, float& tx, float& ty) {
     tx = fx - (float)ix; ty = fy - (float)iy;
     return ix * P.hf_cols + iy;
 }
+// HF template parameter of everything below: the terrain the kernel is compiled for
+enum { GRX_HF_PLANE = 0, GRX_HF_RASTER = 1, GRX_HF_TRIMESH = 2 };
 // index into hf_cells of the corner record the physics reads for a point of `cell` (trimesh: the record of its triangle half)
+template <int HF>
 GRX_DEV int terrain_record(KP P, int cell, float tx, float ty) {
-    return P.vertical_faces ? P.tm_off + 2 * cell + (ty >= tx ? 0 : 1) : cell;
+    return HF == GRX_HF_TRIMESH ? P.tm_off + 2 * cell + (ty >= tx ? 0 : 1) : cell;
 }
 GRX_DEV void terrain_unpack(uint2 cc, TerrainRaw& r) {
     r.h00 = (int16_t)(cc.x & 0xffffu); r.h01 = (int16_t)(cc.x >> 16);
     r.h10 = (int16_t)(cc.y & 0xffffu); r.h11 = (int16_t)(cc.y >> 16);
 }
-template <bool HF>
+template <int HF>
 GRX_DEV void terrain_gather(KP P, float x, float y, TerrainRaw& r) {
     if (!HF) return;
     const int cell = terrain_locate(P, x, y, r.tx, r.ty);
-    terrain_unpack(P.hf_cells[terrain_record(P, cell, r.tx, r.ty)], r);   // one gather
+    terrain_unpack(P.hf_cells[terrain_record<HF>(P, cell, r.tx, r.ty)], r);   // one gather
 }
-template <bool HF>
+template <int HF>
 GRX_DEV float terrain_eval(KP P, const TerrainRaw& r, float& gx, float& gy) {
     gx = 0.0f; gy = 0.0f;
     if (!HF) return 0.0f;
+#if GRX_TE_BARRIER
+    // (round 6) nothing is scheduled across the start of a heightfield evaluation: the lane-quad kernels' waves keep the work their roles put between the
+    // gathers and this first use of them there (4096 envs: 45.4 -> 44.9 us; the lane-pair kernels lose 1 % with it: profiles/r06_experiments.md)
+    if (HF == GRX_HF_RASTER) __builtin_amdgcn_sched_barrier(0);
+#endif
     const float tx = r.tx, ty = r.ty;
     const float h00 = (float)r.h00, h01 = (float)r.h01, h10 = (float)r.h10, h11 = (float)r.h11;
     float h;
-    if (P.vertical_faces) {   // uniform.  The record: (e00, e01 | e10, e11, -) of the half the point is in
+    if (HF == GRX_HF_TRIMESH) {   // the record: (e00, e01 | e10, e11, -) of the half the point is in
         const bool up = ty >= tx;
         gx = up ? h10 - h01 : h01 - h00;
         gy = up ? h01 - h00 : h10 - h01;
@@ -202,7 +213,7 @@ GRX_DEV float terrain_eval(KP P, const TerrainRaw& r, float& gx, float& gy) {
     }
     return h * P.vertical_scale;
 }
-template <bool HF>
+template <int HF>
 GRX_DEV float terrain_height(KP P, float x, float y, float& gx, float& gy) {
     TerrainRaw r;
     terrain_gather<HF>(P, x, y, r);
@@ -217,8 +228,10 @@ GRX_DEV uint4 wall_gather(KP P, float x, float y, float& tx, float& ty) {
     const int cell = terrain_locate(P, x, y, tx, ty);
     return reinterpret_cast<const uint4*>(P.hf_cells + 3 * (size_t)P.tm_off)[cell];
 }
+GRX_DEV bool wall_none(uint4 ww) { return (ww.x & ww.y & ww.z & ww.w) == 0x80008000u && (ww.x | ww.y | ww.z | ww.w) == 0x80008000u; }   // all eight tops INT16_MIN: no face at this cell
 GRX_DEV V3 wall_contact(KP P, uint4 ww, float tx, float ty, float wz, float r, float dmax, V3 u, float mu) {
     V3 F = v3(0.f, 0.f, 0.f);
+    if (wall_none(ww)) return F;   // (most cells)
     const float dx[2] = {tx * P.horizontal_scale, (tx - 1.0f) * P.horizontal_scale}, dy[2] = {ty * P.horizontal_scale, (ty - 1.0f) * P.horizontal_scale};
     const uint32_t w32[4] = {ww.x, ww.y, ww.z, ww.w};
     float best = r * r;   // squared distance of the closest face within reach
@@ -255,6 +268,10 @@ GRX_DEV void wall_pass(KP P, const SphT* S, V3 w, V3 v, V3 O, float mu, float hm
     float tx[CNT], ty[CNT];
 #pragma unroll
     for (int i = 0; i < CNT; ++i) ww[i] = wall_gather(P, O.x + xr[i].x, O.y + xr[i].y, tx[i], ty[i]);
+    bool some = false;
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) some = some || !wall_none(ww[i]);
+    if (!__any(some)) return;   // nobody in the wave stands next to a face
 #pragma unroll
     for (int i = 0; i < CNT; ++i) {
         const float wz = O.z + xr[i].z;
@@ -303,7 +320,7 @@ __device__ constexpr int kSphOff[LEG] = {8, 8, 8, 10, 12};
 // lane, unconditionally (indices are clamped), so that a group's lookups are all in flight together instead of one
 // exposed memory latency per sphere inside divergent branches.
 struct TerrainAt { float h, gx, gy; };   // height and gradient of the terrain under a sphere centre
-template <bool HF>
+template <int HF>
 GRX_DEV void sphere_probe(KP P, const SphC& S, const R3& R, V3 rho, V3 O, V3& xr, TerrainAt& th) {
     xr = rho + rot(R, v3(S.x, S.y, S.z));
     th.h = terrain_height<HF>(P, O.x + xr.x, O.y + xr.y, th.gx, th.gy);
@@ -313,7 +330,7 @@ GRX_DEV void sphere_probe(KP P, const SphC& S, const R3& R, V3 rho, V3 O, V3& xr
 // velocity and O-referenced linear velocity of the carrying body.  SLOT: friction-anchor slot of a foot
 // sphere (compile time), -1 for the other shapes.  xr = sphere centre relative to O, th = terrain height under it
 // (sphere_probe).  Returns the world-frame force.
-template <bool HF, int SLOT>
+template <int HF, int SLOT>
 GRX_DEV V3 sphere_contact(KP P, const SphC& S, V3 w, V3 v, V3 O, float mu, float hmax, LaneState& st, V3 xr, const TerrainAt& th, float om_e = 1.0f) {
     V3 F = v3(0.f, 0.f, 0.f);
     const float wz = O.z + xr.z;
@@ -422,7 +439,7 @@ GRX_DEV void chain_step(const SideConst& C, int k, float q, float qd, ChainKin& 
 // in two halves, so that a caller with other work at hand (wave 2 of the four-wave layout: the bias forces) can put it
 // between the heightfield gathers and their first use
 struct FootProbe { bool reach; V3 xr[4]; TerrainRaw raw[4]; };
-template <bool HF>
+template <int HF>
 GRX_DEV void foot_probe(KP P, const SideConst& C, const ChainKin& K, V3 O, float hmax, FootProbe& fp) {
     constexpr int o = kSphOff[LEG - 1];
     fp.reach = group_within_reach<4>(&C.sph[o], K.R, K.rho, O, hmax);
@@ -434,7 +451,7 @@ GRX_DEV void foot_probe(KP P, const SideConst& C, const ChainKin& K, V3 O, float
         }
     }
 }
-template <bool HF>
+template <int HF>
 GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, float mu, float hmax, LaneState& st,
                            V3& fa, V3& fl, float om_e, const FootProbe& fp) {
     fa = v3(0.f, 0.f, 0.f); fl = v3(0.f, 0.f, 0.f);
@@ -449,10 +466,10 @@ GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, fl
         F = sphere_contact<HF, 1>(P, C.sph[o + 1], K.w, K.v, O, mu, hmax, st, xr[1], th[1], om_e); fa = fa + cross(xr[1], F); fl = fl + F;
         F = sphere_contact<HF, 2>(P, C.sph[o + 2], K.w, K.v, O, mu, hmax, st, xr[2], th[2], om_e); fa = fa + cross(xr[2], F); fl = fl + F;
         F = sphere_contact<HF, 3>(P, C.sph[o + 3], K.w, K.v, O, mu, hmax, st, xr[3], th[3], om_e); fa = fa + cross(xr[3], F); fl = fl + F;
-        if (HF && P.vertical_faces) wall_pass<4>(P, &C.sph[o], K.w, K.v, O, mu, hmax, xr, fa, fl);
+        if (HF == GRX_HF_TRIMESH) wall_pass<4>(P, &C.sph[o], K.w, K.v, O, mu, hmax, xr, fa, fl);
     } else st.anchor_on = 0;   // nobody in the wave can touch: all four anchors released
 }
-template <bool HF>
+template <int HF>
 GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, float mu, float hmax, LaneState& st,
                            V3& fa, V3& fl, float om_e) {
     FootProbe fp;
@@ -463,7 +480,7 @@ GRX_DEV void foot_contacts(KP P, const SideConst& C, const ChainKin& K, V3 O, fl
 // LPE == 4: the two lanes of a leg take two foot spheres each -- lane `half` the spheres 2 half, 2 half + 1 of the foot's table,
 // read from the LDS copy of the table (lane-dependent index); their friction anchors live in the lane's slots 0, 1
 struct FootProbeQ { bool reach; V3 xr[2]; TerrainRaw raw[2]; };
-template <bool HF>
+template <int HF>
 GRX_DEV void foot_probe_q(KP P, const SideConst& C, const SideConst& Clds, int half, const ChainKin& K, V3 O, float hmax, FootProbeQ& fp) {
     constexpr int o = kSphOff[LEG - 1];
     fp.reach = group_within_reach<4>(&C.sph[o], K.R, K.rho, O, hmax);
@@ -476,7 +493,7 @@ GRX_DEV void foot_probe_q(KP P, const SideConst& C, const SideConst& Clds, int h
         }
     }
 }
-template <bool HF>
+template <int HF>
 GRX_DEV void foot_contacts_q(KP P, const SideConst& Clds, int half, const ChainKin& K, V3 O, float mu, float hmax, LaneState& st,
                              V3& fa, V3& fl, float om_e, const FootProbeQ& fp) {
     fa = v3(0.f, 0.f, 0.f); fl = v3(0.f, 0.f, 0.f);
@@ -488,7 +505,7 @@ GRX_DEV void foot_contacts_q(KP P, const SideConst& Clds, int half, const ChainK
         V3 F;
         F = sphere_contact<HF, 0>(P, Clds.sph[o + 2 * half + 0], K.w, K.v, O, mu, hmax, st, fp.xr[0], th[0], om_e); fa = fa + cross(fp.xr[0], F); fl = fl + F;
         F = sphere_contact<HF, 1>(P, Clds.sph[o + 2 * half + 1], K.w, K.v, O, mu, hmax, st, fp.xr[1], th[1], om_e); fa = fa + cross(fp.xr[1], F); fl = fl + F;
-        if (HF && P.vertical_faces) wall_pass<2>(P, &Clds.sph[o + 2 * half], K.w, K.v, O, mu, hmax, fp.xr, fa, fl);
+        if (HF == GRX_HF_TRIMESH) wall_pass<2>(P, &Clds.sph[o + 2 * half], K.w, K.v, O, mu, hmax, fp.xr, fa, fl);
         fa = half_sum(fa); fl = half_sum(fl);   // the foot's wrench: both halves
     } else st.anchor_on = 0;
 }
@@ -500,7 +517,7 @@ GRX_DEV void foot_contacts_q(KP P, const SideConst& Clds, int half, const ChainK
 // tau: motor torques of this lane's 5 joints.  fk_only: just the kinematics pass (foot frames).
 // W = waves per block: 1 = everything inline; 2 = the base-lump contacts come from the helper wave through `wr`
 // (W == 4 uses the producer/consumer pipeline of grx_wavepipe.h instead of this function).
-template <bool HF, int W>
+template <int HF, int W>
 GRX_DEV void substep(KP P, const KTables& T, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                      SubstepOut& out, FootKin& fk_before, const float* wr, long long* tacc, const LinkForceOut& lfo,
                      const RareBuf& RB, int lane, int el, int side, SelfNear& sn, bool first) {
@@ -809,7 +826,7 @@ GRX_DEV void rigid_inertia_lean(const R3& R, V3 kap, float m, const S3& Ic, S3& 
 // still spills 224 dwords (substep(): 360) -- the post-physics state carried across the sub-step loop and the contact evaluations'
 // own temporaries are the next ~150.  Two waves per SIMD at > 16384 envs per GPU need that AND 20 KB of LDS per wave (37 KB now):
 // not reached this round.
-template <bool HF>
+template <int HF>
 GRX_DEV void substep_lean(KP P, const KTables& T, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                           SubstepOut& out, FootKin& fk_before, const LinkForceOut& lfo,
                           const RareBuf& RB, int lane, int el, int side, SelfNear& sn, bool first) {
@@ -1515,803 +1532,18 @@ GRX_DEV float scan_feet_height(KP P, int* s_flag, const float* s_hsum, float foo
 // kernel: the height scan over the waves, the reward inputs through LDS to the two reward waves (which fetch the injected
 // last_last_actions themselves), reset_idx's draws from the foot wave, the termination flag through s_tp from the base-lump
 // wave, the observation height block on the helper waves.
+#define GRX_STEP_KERNEL_ARGS const KParams* __restrict__ Pg, const float* __restrict__ actions_in, float delay, long long common_step, const float* __restrict__ noise_in, \
+                             const float* __restrict__ dbg, float* __restrict__ obs_out, float* __restrict__ pri_out, const StepSeq sq
+// (the body is a file of its own, compiled under two heads: the terrain as a compile-time property without a third value in the kernels' names)
 template <bool HF, int W, bool DBG = false>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 2 : GRX_WPE, W > 4 ? 2 : GRX_WPE))) void grx_step_kernel(const KParams* __restrict__ Pg, const float* __restrict__ actions_in,
-                                                      float delay, long long common_step, const float* __restrict__ noise_in,
-                                                      const float* __restrict__ dbg, float* __restrict__ obs_out, float* __restrict__ pri_out,
-                                                      const StepSeq sq) {
-    static_assert(!DBG || W == 1 || W == 4 || W == 8, "the debug injection path exists for the one-wave layout and the pipelines");
-    KP P = GRX_PARAMS(Pg);
-    constexpr int NTHR = 64 * W;
-    constexpr bool PIPE = W >= 4;   // the producer/consumer pipeline of grx_wavepipe.h: four roles, or (W == 8, lane quads only) eight
-    __shared__ KTables s_tab;
-    // One LDS arena, used twice: during the sub-steps it holds the lane-compaction buffers of the rare contacts
-    // (grx_rare.h: candidate list, result table, frames); after the decimation loop's barrier the same bytes are the
-    // AoS staging rows of obs / pri_obs and (PIPE) the reward inputs wave 0 hands to the reward waves.
-    constexpr int OBS_BYTES = EPB * GRX_NUM_OBS * 4, PRI_BYTES = EPB * PRS * 4, RW_BYTES = PIPE ? REWIN_FLOATS * 64 * 4 : 0;
-    constexpr int POST_BYTES = OBS_BYTES + PRI_BYTES + RW_BYTES, PHYS_BYTES = (W == 2 || W == 8 ? 2 : 1) * RC_BYTES;
-    static_assert(OBS_BYTES % 16 == 0 && PRI_BYTES % 16 == 0 && RC_BYTES % 16 == 0, "arena pieces must stay 16-byte aligned");
-    constexpr int FOOTFR_BYTES = RC_FR4 * 64 * 16, ANCH_BYTES = 16 * 64 * 4;   // (s_anch: anchors x 4, y 4, mask 1, approach speeds 4, foot |w| sums 3)
-    constexpr int TAIL_BYTES = PIPE ? PHYS_BYTES + FOOTFR_BYTES + ANCH_BYTES : PHYS_BYTES;
-#ifdef GRX_FAKE_ARENA   // compile-only experiments on the register budget at two waves per SIMD (the result does not run)
-    __shared__ __attribute__((aligned(16))) char s_arena[GRX_FAKE_ARENA];
-#else
-    __shared__ __attribute__((aligned(16))) char s_arena[POST_BYTES > TAIL_BYTES ? POST_BYTES : TAIL_BYTES];
-#endif
-    float* const s_obs = reinterpret_cast<float*>(s_arena);
-    float* const s_pri = reinterpret_cast<float*>(s_arena + OBS_BYTES);
-    float* const s_rw = reinterpret_cast<float*>(s_arena + OBS_BYTES + PRI_BYTES);   // reward inputs (wave 0 -> waves 1, 3), PIPE
-    // final friction anchors of the step (PIPE: wave 2 -> wave 0 across the barrier that ends the sub-steps): behind the
-    // compaction buffers (32 envs per block: inside what becomes s_rw only after wave 0 has picked them up)
-    // PIPE, same tail: the foot frames wave 2 publishes for the self-collision on wave 1 (sub-steps only), then s_anch
-    static_assert(!PIPE || PHYS_BYTES >= OBS_BYTES + PRI_BYTES, "foot frames + s_anch must sit behind the staging rows, in the arena's tail");
-    float4* const s_footfr = reinterpret_cast<float4*>(s_arena + PHYS_BYTES);
-    float* const s_anch = reinterpret_cast<float*>(s_arena + PHYS_BYTES + FOOTFR_BYTES);
-    __shared__ float s_stat[NSTAT];
-    __shared__ float s_base[W == 2 ? 13 * EPB : 1];   // W == 2: base state at the start of the current sub-step (dynamics -> helper)
-    __shared__ float4 s_bq[PIPE ? 4 * EPB : 1];       // the pipelines: the same as four quads per env (pipe_base_store / pipe_base_load)
-    __shared__ __attribute__((aligned(16))) float s_wr[W == 2 ? 32 * 64 : (PIPE ? 8 * 64 : 1)];       // base-lump wrench + termination / collision flags (helper -> dynamics)
-    // PIPE pipeline buffers (grx_wavepipe.h)
-    __shared__ float4 s_q[PIPE ? Q4 * 64 : 1];
-    __shared__ float4 s_wc[PIPE ? WC4 * 64 : 1];
-    __shared__ float4 s_pb[PIPE ? (LEG * PB4 + 2) * 64 : 1];
-    __shared__ uint32_t s_nz[PIPE ? NZB * 4 * 64 : 1];   // observation-noise Philox blocks (wave 1 -> wave 0)
-    __shared__ float4 s_rr[PIPE ? 5 * 64 : 1];           // reset_idx's uniform draws (wave 2 -> wave 0)
-    __shared__ __attribute__((aligned(16))) char s_self[PIPE ? SELF_BYTES : 16];   // self-collision staging of wave 2 (grx_self.h)
-    __shared__ float s_rwp[PIPE ? 64 : 1];               // partial reward (wave 3 -> wave 1)
-    __shared__ float s_hp[PIPE ? 4 * EPB : 1];           // height scan: base x, y, yaw quaternion z, w (wave 0 -> all)
-    __shared__ float s_hsum[PIPE ? W * 64 : 1];          // height scan: partial sums per wave
-    __shared__ float s_bho[W == 8 && HF ? 4 * 64 : 1];   // W == 8, heightfield: partial sums of the observation height block (waves 4..7; s_hsum keeps the scan's until the kernel ends)
-    __shared__ float s_tp[PIPE ? 2 * 64 : 1];            // termination flag / collision count from the NET link forces of the last sub-step (wave 3 -> wave 0)
-    __shared__ float4 s_xk[W == 8 ? 9 * 64 : 1];           // W == 8: rigid inertias of chain bodies 2, 1, 0 (wave 6 -> wave 0)
-    __shared__ float4 s_sb[W == 8 ? 5 * 64 : 1];           // W == 8: thigh x base-lump self-collision (wave 3 -> wave 0)
-    __shared__ float4 s_fx[W == 8 && LPL == 2 ? 8 * 64 : 1];           // W == 8: base-level 6 x 6 (wave 0 -> wave 5) and its factorisation (wave 5 -> wave 0)
-    __shared__ int s_flag[FL_COUNT];
-    const PipeLds L = {s_bq, s_q, s_wc, s_pb, reinterpret_cast<float4*>(s_wr), s_flag, s_xk, s_sb, s_fx};
-    const int tid = threadIdx.x;
-#ifndef GRX_W8_ROLES
-#define GRX_W8_ROLES 0x76543210u   // role of hardware wave i in nibble i (waves i and i + 4 share a SIMD: pair a busy role with a light one)
-#endif
-    const int wv_hw = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wv = W == 8 ? (int)((GRX_W8_ROLES >> (4 * wv_hw)) & 7u) : wv_hw;   // (W == 8: `wv` is the wave's ROLE from here on)
-    const RareBuf RB = rare_carve(s_arena + (W == 2 && wv == 1 ? RC_BYTES : 0));   // PIPE: only wave 3 evaluates rare contacts
-    {   // stage the per-side robot tables (joint tree, inertias, gains, spheres) into LDS
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tables);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&s_tab);
-        for (int i = tid; i < (int)(sizeof(KTables) / 4); i += NTHR) dst[i] = src[i];
-        if (tid < NSTAT) s_stat[tid] = 0.f;
-        if (tid < FL_COUNT) s_flag[tid] = 0;
-    }
-    __syncthreads();
-    // the previous launch's episode statistics (and its ticket): on the wave that starts its sub-steps by waiting anyway
-    if (wv == (W == 8 ? 3 : W - 1)) stats_fold_previous(P, sq, tid & 63);
-    const int N = P.N;
-    const int lane = tid & 63, el = lane_env(lane), side = lane_side(lane), half = lane_half(lane);
-    const int grp = step_group();
-    const int e_raw = grp * EPB + el;
-    const bool act = e_raw < N;
-    const bool act0 = act && half == 0;   // the lane of a leg that stores the leg's outputs (LPE == 4: both halves hold them)
-    int e = act ? e_raw : N - 1;   // (not const: laundered behind the sub-steps, see there)
-    const SideConst& C = s_tab.side[side];
-    const uint32_t genv = (uint32_t)(P.env_offset + e);
-    const uint32_t step = (uint32_t)common_step;
-    const int nh = P.nh, npri = P.num_pri_obs;
-    const float dtp = P.sim_dt * (float)P.decimation;
-    const int j0 = side * LEG;
-
-#ifndef GRX_W8_PRIO
-#define GRX_W8_PRIO 0u
-#endif
-    if (W == 8 && GRX_W8_PRIO) {   // two waves per SIMD: the state owner and the base-service wave sit on the sub-step's critical chain
-        const int pr = (int)((GRX_W8_PRIO >> (4 * wv)) & 3u);   // (priority of role i in nibble i)
-        if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-    }
-    if (W >= 2 && wv != 0) {
-        // ---- helper waves
-        const float mu = 0.5f * (P.terrain_friction + P.friction[e]);
-        float hmax = 0.0f;
-        if (HF) {
-            const float x0 = P.root[0 * (size_t)N + e], y0 = P.root[1 * (size_t)N + e];
-            int ci = min(max((int)((x0 + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_rows - 1);
-            int cj = min(max((int)((y0 + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
-            hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
-        }
-        LaneState hs;   // PIPE, wave 2: the friction anchors of this lane's foot
-        hs.anchor_on = 0;
-        LinkPrep w3_lp;   // PIPE, wave 3: GRX_T_CONTACT_FORCES rows of the last sub-step, stored once the block is past its barrier
-        V3 w3_rows[11];
-        if (PIPE) {
-#if defined(GRX_REG_CONSTS) && GRX_REG_CONSTS >= 2
-            const SideConst Ch = C;   // helper waves too: constants in registers
-#define GRX_HELPER_C Ch
-#else
-#define GRX_HELPER_C C
-#endif
-#ifndef GRX_W8_REGC
-#define GRX_W8_REGC 0x76   // eight waves (256 registers each): the waves whose constants live in registers (bit per wave; measured: waves 3, 7 only spill)
-#endif
-#define GRX_HC(w) ((W == 8 && !((GRX_W8_REGC >> (w)) & 1)) ? C : GRX_HELPER_C)
-            const float bm = P.base_m[e];
-            const V3 bc = v3(P.base_c[e], P.base_c[(size_t)N + e], P.base_c[2 * (size_t)N + e]);
-            const S3 bI = {P.base_I[e], P.base_I[(size_t)N + e], P.base_I[2 * (size_t)N + e],
-                           P.base_I[3 * (size_t)N + e], P.base_I[4 * (size_t)N + e], P.base_I[5 * (size_t)N + e]};
-            if (wv == 1) {
-                // the observation-noise Philox blocks are computed in the idle time after a sub-step's hand-over (this wave is on
-                // wave 0's path from the first sub-step on: before the loop they delayed it, measured)
-                const bool want_noise = P.add_noise && !noise_in;
-                const int noise_seq = P.decimation >= 2 ? P.decimation - 2 : 0;
-                auto noise_out = [&](const int seq) {
-                    if (want_noise && seq == noise_seq) {
-                        U4 nzb[NZB];
-                        noise_blocks(P, genv, step, side, nzb);
-                        uint32_t* z = s_nz + lane;
-#pragma unroll
-                        for (int b = 0; b < NZB; ++b) { z[(b * 4 + 0) * 64] = nzb[b].x; z[(b * 4 + 1) * 64] = nzb[b].y; z[(b * 4 + 2) * 64] = nzb[b].z; z[(b * 4 + 3) * 64] = nzb[b].w; }
-                    }
-                };
-                if (DBG) noise_out(noise_seq);   // (no sub-steps: the blocks all the same)
-                else self_loop<HF, HF && W != 8, W == 8>(P, s_tab, GRX_HC(1), RB, s_footfr, self_carve(s_self), P.friction[e], L, lane, el, side, noise_out);
-            } else if (wv == 2) {
-                // (LPE == 4: this lane owns the foot spheres 2 half, 2 half + 1 -- slots 0, 1 here -- and parks them at the leg's first lane)
-                constexpr int NA = 4 / LPL;
-#pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    const int gi = NA * half + i;
-                    hs.ax[i] = P.anchors[(size_t)((side * 4 + gi) * 3 + 0) * N + e];
-                    hs.ay[i] = P.anchors[(size_t)((side * 4 + gi) * 3 + 1) * N + e];
-                    hs.vimp[i] = P.anchors[(size_t)((side * 4 + gi) * 3 + 2) * N + e];   // 0: no contact; else the contact's approach speed
-                    if (hs.vimp[i] != 0.0f) hs.anchor_on |= (1u << i);
-                }
-                V3 rpy_acc = v3(0.f, 0.f, 0.f);
-                if (!DBG) chain_contact_loop<HF, W == 8 ? 0 : (HF ? 2 : 5)>(P, GRX_HC(2), C, RB, s_footfr, mu, hmax, 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]), hs, L, lane, el, side, rpy_acc);
-                float* a_ = s_anch + (lane - half);
-                if (half == 0) { a_[13 * 64] = rpy_acc.x; a_[14 * 64] = rpy_acc.y; a_[15 * 64] = rpy_acc.z; }   // (both halves of a leg walk the whole chain)
-#pragma unroll
-                for (int i = 0; i < NA; ++i) { const int gi = NA * half + i; a_[gi * 64] = hs.ax[i]; a_[(4 + gi) * 64] = hs.ay[i]; a_[(9 + gi) * 64] = hs.vimp[i]; }
-                {
-                    const uint32_t mine = hs.anchor_on << (NA * half);
-                    a_[8 * 64] = __uint_as_float(LPL == 1 ? mine : (mine | __float_as_uint(half_swap(__uint_as_float(mine)))));
-                }
-            } else if (wv == 3) {
-                if (DBG) { s_tp[lane] = dbg[(size_t)DBG_TERM_CONTACT * N + e]; s_tp[64 + lane] = 0.f; }   // the injected termination contact takes the product's way to wave 0
-                else base_contact_loop<HF, W == 8>(P, s_tab, GRX_HC(3), RB, mu, hmax, bm, bc, bI, L, lane, el, side, s_tp, w3_lp, w3_rows, s_footfr, P.friction[e]);
-            } else if (DBG) {   // (waves 4..7 of the eight-wave pipeline have sub-step work only)
-            } else if (wv == 7) {
-                RareBuf RB7 = rare_carve(s_arena + RC_BYTES);
-                RB7.fchain = RB.fchain;   // (where wave 2 publishes the thigh / shank frames)
-                chain_rare_loop<HF>(P, s_tab, GRX_HC(7), RB7, mu, hmax, L, lane, el, side);
-            } else if (wv == 4) {
-                chain_bias_loop<3, 4>(P, GRX_HC(4), C, L, lane, el);
-            } else if (wv == 6) {
-                if (LPL == 1) chain_bias_loop<0, 2, true>(P, GRX_HC(6), C, L, lane, el, &s_tab, &RB, s_footfr, side, P.friction[e]);
-                else chain_bias_loop<0, 2>(P, GRX_HC(6), C, L, lane, el);
-            } else if (wv == 5) {
-                base_service_loop(P, GRX_HC(5), C, bm, bc, bI, L, lane, el);
-            }
-            float es_w1[NT], es_w3[NT];   // running episode sums of this wave's reward terms: HBM latency hidden behind the scan
-            if (wv == 1) load_episode_sums<1>(P, e, N, es_w1);
-#ifdef GRX_PROFILE_SECTIONS
-            if (lane == 0) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 80 + wv] = clock64();
-#endif
-            lds_barrier();   // final friction anchors + height-scan pose published (the last sub-step's row stores stay in flight)
-            if (wv == 3) {   // (this wave is the last to arrive: its HBM traffic goes out behind the barrier)
-                load_episode_sums<2>(P, e, N, es_w3);
-                if (!DBG) store_link_rows(LinkForceOut{true, act0 ? P.contact_forces + e : nullptr, (size_t)N}, w3_lp, w3_rows);
-            }
-            if (HF && P.measure_heights) {   // this wave's quarter of the height scan (legged_robot.py:1235-1274)
-                const float* hp = s_hp + el;
-                // (eight waves: seven shares -- wave 3, the last to finish its sub-steps, has the link rows to store instead)
-                // Eight waves: SIX shares -- wave 3, the last to finish its sub-steps, has the link rows to store instead, and WAVE 0 TAKES NO PART (round 5): the scan's
-                // gathers are a memory round trip it used to sit out at the barrier below (2.6 k cycles per step on the heightfield, tools/gpu_sections.py).  The scan's
-                // consumers -- the reward waves for feet_height, waves 4..7 for the observation height block, wave 0 when it writes feet_height -- wait for the COUNTER
-                // FL_SCAN instead of a block barrier.
-                if (W == 8) { if (wv != 3) { s_hsum[wv * 64 + lane] = height_scan_share<6, (LPE == 4 ? 6 : 11)>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
-                                                                                           LPE * (wv < 3 ? wv - 1 : wv - 2) + (lane & (LPE - 1)), nh, s_pri + el * PRS);
-                                             flag_add(s_flag + FL_SCAN, lane); } }
-                else {
-                s_hsum[wv * 64 + lane] = height_scan_share<4>(P, s_tab, hp[2 * EPB], hp[3 * EPB], v3(hp[0 * EPB], hp[1 * EPB], 0.f),
-                                                              LPE * wv + (lane & (LPE - 1)), nh, s_pri + el * PRS);
-                lds_barrier();   // height scan complete (raw heights and partial sums are in LDS: this wave's row stores of the last sub-step stay in flight)
-                }
-            }
-            if (wv == 2) {   // reset_idx's uniform draws, ready before wave 0 knows who resets
-                const ResetRand rr = reset_rand(P, genv, step, side);
-                float4* z = s_rr + lane;
-                z[0 * 64] = f4(rr.dof[0], rr.dof[1], rr.dof[2], rr.dof[3]);
-                z[1 * 64] = f4(rr.dof[4], rr.root[0], rr.root[1], rr.root[2]);
-                z[2 * 64] = f4(rr.root[3], rr.root[4], rr.root[5], rr.root[6]);
-                z[3 * 64] = f4(rr.root[7], rr.root[8], rr.cmd[0], rr.cmd[1]);
-                z[4 * 64] = f4(rr.cmd[2], 0.f, 0.f, 0.f);
-                flag_set(s_flag + FL_RR, 1, lane);
-            }
-            if (wv == 3) {   // the base / feet half of the reward terms, then half of the observation height block
-                flag_wait(s_flag + FL_REW, 1);
-                RewIn rin;
-                int i = 0;
-                rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
-                if (W == 8 && HF) rin.feet_height = scan_feet_height(P, s_flag, s_hsum, rin.feet_height, nh, lane);
-                reward_and_sums<2>(P, C, rin, lane, side, e, N, act, s_stat, es_w3, s_rwp, s_flag + FL_RWB, nullptr,
-                                   DBG && dbg[(size_t)DBG_APPLY_RESET * N + e] == 0.f);
-            }
-            if (wv == 1) {   // rewards + episode sums while wave 0 runs reset / observations / stores
-                flag_wait(s_flag + FL_REW, 1);
-                GRX_TICKW(14);
-                RewIn rin;
-                int i = 0;
-                rewin_fields(rin, [&](float& x) { x = s_rw[(i++) * 64 + lane]; });
-                if (W == 8 && HF) rin.feet_height = scan_feet_height(P, s_flag, s_hsum, rin.feet_height, nh, lane);
-                float a_ll1[LEG];   // DBG: the injected last_last_actions (action_diff_diff is one of this wave's terms)
-                if (DBG) {
-#pragma unroll
-                    for (int k = 0; k < LEG; ++k) a_ll1[k] = dbg[(size_t)(DBG_LAST_LAST_ACTIONS + j0 + k) * N + e];
-                }
-                reward_and_sums<1>(P, C, rin, lane, side, e, N, act, s_stat, es_w1, s_rwp, s_flag + FL_RWB, DBG ? a_ll1 : nullptr,
-                                   DBG && dbg[(size_t)DBG_APPLY_RESET * N + e] == 0.f);
-                GRX_TICKW(15);
-            }
-            if (W == 8) {   // eight waves: the observation height block on the four waves that have no reward terms, a quarter each
-                if (wv >= 4) {
-                    flag_wait(s_flag + FL_HZ, 1);
-                    const bool have_raw = HF && P.measure_heights;
-                    if (have_raw) flag_wait(s_flag + FL_SCAN, 6);   // every wave's raw heights are in the staging rows
-                    const float part = obs_heights_share<4 * LPE>(P, s_hp[el], (wv - 4) * LPE + (lane & (LPE - 1)), nh, s_pri + el * PRS, have_raw, act, e, N);
-                    if (HF) s_bho[(wv - 4) * 64 + lane] = env_sum(part);
-                    else s_hsum[wv * 64 + lane] = env_sum(part);   // (plane: no scan, the rows of waves 4..7 in s_hsum as before)
-                    flag_set(s_flag + (wv == 7 ? FL_BHO4 : FL_BHO1 + (wv - 4)), 1, lane);
-                }
-            } else if (wv < 4) {   // the observation height block, once wave 0 has published the (post-reset) base height: wave 2 takes
-                // the points k = 0, 1 (mod 4), waves 1 and 3 (busy with the rewards until now) k = 2, 3 and 6, 7 (mod 8)
-                flag_wait(s_flag + FL_HZ, 1);
-                if (wv == 2) GRX_TICKW(30);
-                const bool have_raw = HF && P.measure_heights;
-                float* hrow = s_pri + el * PRS;
-                const int li = lane & (LPE - 1);   // of every 4 LPE consecutive points: wave 2 takes the first 2 LPE, waves 1 and 3 LPE each
-                const float part = wv == 2 ? obs_heights_share<2 * LPE>(P, s_hp[el], li, nh, hrow, have_raw, act, e, N)
-                                           : obs_heights_share<4 * LPE>(P, s_hp[el], (wv == 1 ? LPE : 3 * LPE) + li, nh, hrow, have_raw, act, e, N);
-                s_hsum[wv * 64 + lane] = env_sum(part);
-                flag_set(s_flag + FL_BHO1 + (wv - 1), 1, lane);
-                if (wv == 2) GRX_TICKW(31);
-            }
-            if (P.publish_rbs && (W == 8 || wv < 4)) {   // every URDF link frame of the state wave 0 published after the last sub-step: a third (eight waves: a seventh) on each helper wave
-                float b_[13]; pipe_base_load(s_bq, el, b_);
-                const float* b = b_;
-                const float4 q0_ = s_q[lane], q1_ = s_q[64 + lane], q2_ = s_q[128 + lane];
-                const float fq[LEG] = {q0_.x, q0_.y, q0_.z, q0_.w, q1_.x}, fqd[LEG] = {q1_.y, q1_.z, q1_.w, q2_.x, q2_.y};
-                const float rq[4] = {b[3], b[4], b[5], b[6]};
-                publish_rigid_body_states(P, C, side, v3(b[0], b[1], b[2]), rq, v3(b[7], b[8], b[9]),
-                                          v3(b[10], b[11], b[12]), fq, fqd, e, N, act0, wv - 1, W == 8 ? 7 : 3);
-            }
-        } else {
-            for (int deci = 0; deci < P.decimation; ++deci) {
-                __syncthreads();   // #1: base state published
-                const float* b = s_base + el;
-                const V3 O = v3(b[0 * EPB], b[1 * EPB], b[2 * EPB]);
-                const R3 R0 = quat_to_R(b[3 * EPB], b[4 * EPB], b[5 * EPB], b[6 * EPB]);
-                const V3 vel = v3(b[7 * EPB], b[8 * EPB], b[9 * EPB]), ang = v3(b[10 * EPB], b[11 * EPB], b[12 * EPB]);
-                RareOut ro;
-                const ChainKin nok = {R0, v3(0.f, 0.f, 0.f), ang, vel};   // no chain shapes on this wave
-                rare_contacts<HF, 0, 8>(P, s_tab, C, RB, lane, el, side, R0, O, ang, vel, nok, nok, mu, hmax, ro, nullptr, RareNoWait(), deci == P.decimation - 1);
-                float* w_ = s_wr + lane;
-                if (deci == P.decimation - 1) {   // GRX_T_CONTACT_FORCES rows are written by the dynamics wave (it adds the self-collision forces)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { w_[(8 + 3 * i) * 64] = ro.lf[i].x; w_[(9 + 3 * i) * 64] = ro.lf[i].y; w_[(10 + 3 * i) * 64] = ro.lf[i].z; }
-                }
-                w_[0 * 64] = ro.f0a.x; w_[1 * 64] = ro.f0a.y; w_[2 * 64] = ro.f0a.z;
-                w_[3 * 64] = ro.f0l.x; w_[4 * 64] = ro.f0l.y; w_[5 * 64] = ro.f0l.z;
-                w_[6 * 64] = ro.term ? 1.f : 0.f; w_[7 * 64] = ro.pen_count;
-                __syncthreads();   // #3: wrench published
-            }
-        }
-    } else {
-
-#ifdef GRX_PROFILE_SECTIONS
-    long long tacc[22] = {};
-#else
-    long long* tacc = nullptr;
-#endif
-    GRX_TICK(0);
-    // ---- load state (SoA, coalesced)
-    LaneState st;
-    LaneConst LC;
-    float a_cur[LEG], a_last[LEG], qd_last[LEG];
-#pragma unroll
-    for (int k = 0; k < LEG; ++k) {
-        size_t o = (size_t)(j0 + k) * N + e;
-        st.q[k] = GCOL(P.q, o); st.qd[k] = GCOL(P.qd, o);
-        a_last[k] = GCOL(P.last_actions, o);
-        LC.strength[k] = GCOL(P.motor_strength, o);
-        float a = actions_in ? actions_in[(size_t)e * GRX_ND + j0 + k] : 0.0f;
-        a_cur[k] = fminf(fmaxf(a, C.body[k].amin), C.body[k].amax);  // clip_actions legged_robot_fftai.py:171-177
-    }
-    st.pos = v3(GCOL(P.root, 0 * (size_t)N + e), GCOL(P.root, 1 * (size_t)N + e), GCOL(P.root, 2 * (size_t)N + e));
-    st.qx = GCOL(P.root, 3 * (size_t)N + e); st.qy = GCOL(P.root, 4 * (size_t)N + e); st.qz = GCOL(P.root, 5 * (size_t)N + e); st.qw = GCOL(P.root, 6 * (size_t)N + e);
-    st.vel = v3(GCOL(P.root, 7 * (size_t)N + e), GCOL(P.root, 8 * (size_t)N + e), GCOL(P.root, 9 * (size_t)N + e));
-    st.ang = v3(GCOL(P.root, 10 * (size_t)N + e), GCOL(P.root, 11 * (size_t)N + e), GCOL(P.root, 12 * (size_t)N + e));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        st.ax[i] = GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 0) * N + e);
-        st.ay[i] = GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 1) * N + e);
-    }
-    st.anchor_on = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        st.vimp[i] = GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 2) * N + e);   // 0: no contact; else the contact's approach speed
-        if (st.vimp[i] != 0.0f) st.anchor_on |= (1u << i);
-    }
-    LC.base_m = GCOL(P.base_m, e);
-    LC.base_c = v3(GCOL(P.base_c, e), GCOL(P.base_c, (size_t)N + e), GCOL(P.base_c, 2 * (size_t)N + e));
-    LC.base_I.xx = P.base_I[e]; LC.base_I.xy = P.base_I[(size_t)N + e]; LC.base_I.xz = P.base_I[2 * (size_t)N + e];
-    LC.base_I.yy = P.base_I[3 * (size_t)N + e]; LC.base_I.yz = P.base_I[4 * (size_t)N + e]; LC.base_I.zz = P.base_I[5 * (size_t)N + e];
-    LC.mu = 0.5f * (P.terrain_friction + GCOL(P.friction, e));
-    LC.om_e = 1.0f - 0.5f * (P.terrain_restitution + GCOL(P.restitution, e));
-    LC.hmax = 0.0f;
-    if (HF) {
-        int ci = min(max((int)((st.pos.x + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_rows - 1);
-        int cj = min(max((int)((st.pos.y + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
-        LC.hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
-    }
-    // What only post_physics_step reads.  One-wave layouts: loaded here, so that the HBM latency overlaps the sub-steps.  The pipelines:
-    // loaded BEHIND the sub-steps, in front of the barrier that ends them -- this wave waits there ~1 k cycles for the last helper
-    // anyway, and ~20 values fewer live across its sub-step loop is what keeps the eight-wave kernels (256 registers per wave)
-    // free of scratch (round 3: 5-9 dwords spilled around the loop).
-    EnvAux ea;
-    float air_time, land_time, bho_stale;
-    bool contact_last;
-    long long ep_len;
-    auto load_post_state = [&]() {
-#pragma unroll
-        for (int k = 0; k < LEG; ++k) qd_last[k] = GCOL(P.last_dof_vel, (size_t)(j0 + k) * N + e);
-        ea.cmd[0] = GCOL(P.commands, e); ea.cmd[1] = GCOL(P.commands, (size_t)N + e); ea.cmd[2] = GCOL(P.commands, 2 * (size_t)N + e);
-        ea.origin[0] = GCOL(P.origins, e); ea.origin[1] = GCOL(P.origins, (size_t)N + e); ea.origin[2] = GCOL(P.origins, 2 * (size_t)N + e);
-        ea.level = GCOL(P.levels, e); ea.type = GCOL(P.types, e);
-        air_time = GCOL(P.air_time, (size_t)side * N + e); land_time = GCOL(P.land_time, (size_t)side * N + e);
-        contact_last = GCOL(P.feet_contact, (size_t)side * N + e) != 0;
-        bho_stale = GCOL(P.base_heights_offset, e);
-        ep_len = GCOL(P.ep_len, e);
-    };
-#ifndef GRX_LATE_POST
-#define GRX_LATE_POST 2   // 1: every pipeline, 2: the lane-quad pipelines only (measured: with lane pairs, whose wave 0 does not idle at that barrier, the late loads cost 1-2 %)
-#endif
-    constexpr bool kLatePost = PIPE && (GRX_LATE_POST == 1 || (GRX_LATE_POST == 2 && LPL == 2));
-    if (!kLatePost) load_post_state();
-
-    GRX_TICK(1);
-    // ---- during_physics_step (legged_robot_fftai.py:51-88), fused decimation loop
-    float avg_force = 0.f;
-    V3 avg_speed = v3(0.f, 0.f, 0.f);
-    V3 avg_rpy = v3(0.f, 0.f, 0.f);   // (the pipelines: summed on the foot wave, picked up behind the sub-steps' barrier)
-    float torque[LEG];
-    SubstepOut so;
-    FootKin fk;
-    SelfNear self_near; self_near.m = 0;   // self-collision broad phase of this policy step (!PIPE; with four waves it lives on wave 2)
-#ifdef GRX_REG_CONSTS
-    // PIPE: wave 0 has a SIMD's whole register file to itself; its chain's constants live in registers during the
-    // sub-steps (every LDS read of a constant is ~64 exposed cycles on a wave that runs alone)
-#ifndef GRX_W8_PAIR_LDS_CONSTS
-#define GRX_W8_PAIR_LDS_CONSTS 1   // (round 6: the eight-wave lane-pair kernel -- 256 registers per wave, a second wave on the SIMD to cover the LDS latency -- reads them from LDS: 51 -> 18 spilled registers, -1.1 % at 8192 envs)
-#endif
-#ifndef GRX_W8_QUAD_LDS_CONSTS
-#define GRX_W8_QUAD_LDS_CONSTS 1   // (the lane-quad kernel too: -0.5 % at 4096 envs, two runs each, profiles/r06_experiments.md)
-#endif
-    typename std::conditional<W == 8 && ((GRX_W8_PAIR_LDS_CONSTS && LPL == 1) || (GRX_W8_QUAD_LDS_CONSTS && LPL == 2)), const SideConst&, const SideConst>::type Cr = C;
-#else
-    const SideConst& Cr = C;
-#endif
-    // Round 6: the eight-wave lane-pair kernel -- 256 registers per wave -- kept BOTH action vectors live across the sub-step loop
-    // for `use_last ? a_last : a_cur`; the allocator sent them to scratch and every sub-step reloaded eight of them (80 scratch loads per policy
-    // step in wave 0's loop, the kernel's only in-loop scratch traffic).  There the loop holds the five actions IN FORCE and swaps them once, at the
-    // sub-step the delayed action arrives; a_last / a_cur are then cold until the rewards.
-#ifndef GRX_SEL_ACT
-#define GRX_SEL_ACT 1
-#endif
-#ifndef GRX_SEL_ACT_QUAD
-#define GRX_SEL_ACT_QUAD 0
-#endif
-    constexpr bool kSelAct = GRX_SEL_ACT && PIPE && W == 8 && (LPL == 1 || GRX_SEL_ACT_QUAD);
-    float a_sel[LEG];
-    bool sel_last = 0.f < delay;
-#pragma unroll
-    for (int k = 0; k < LEG; ++k) a_sel[k] = sel_last ? a_last[k] : a_cur[k];
-    for (int deci = 0; deci < (DBG ? 0 : P.decimation); ++deci) {
-        // keep the LDS-resident robot tables in LDS: without this barrier LICM hoists ~240 loop-invariant
-        // ds_reads into VGPRs and the kernel spills to scratch (measured: 604 B/lane -> 0)
-#ifndef GRX_NO_LICM_BARRIER
-        asm volatile("" ::: "memory");
-#endif
-        if (PIPE && side == 0 && half == 0) pipe_base_store(s_bq, el, st.pos, st.qx, st.qy, st.qz, st.qw, st.vel, st.ang);
-        if (W == 2 && side == 0) {   // publish the base state of this sub-step for the helper wave
-            float* b = s_base + el;
-            b[0 * EPB] = st.pos.x; b[1 * EPB] = st.pos.y; b[2 * EPB] = st.pos.z;
-            b[3 * EPB] = st.qx; b[4 * EPB] = st.qy; b[5 * EPB] = st.qz; b[6 * EPB] = st.qw;
-            b[7 * EPB] = st.vel.x; b[8 * EPB] = st.vel.y; b[9 * EPB] = st.vel.z;
-            b[10 * EPB] = st.ang.x; b[11 * EPB] = st.ang.y; b[12 * EPB] = st.ang.z;
-        }
-        if (PIPE) {
-            s_q[lane] = f4(st.q[0], st.q[1], st.q[2], st.q[3]);
-            s_q[64 + lane] = f4(st.q[4], st.qd[0], st.qd[1], st.qd[2]);
-            s_q[128 + lane] = f4(st.qd[3], st.qd[4], 0.f, 0.f);
-        }
-        if (PIPE) flag_set(s_flag + FL_STATE, deci + 1, lane);
-        else if (W == 2) __syncthreads();   // #1
-        const bool use_last = (float)deci < delay;
-        if (kSelAct && sel_last && !use_last) {   // (uniform: the sub-step the delayed action arrives at)
-#pragma unroll
-            for (int k = 0; k < LEG; ++k) a_sel[k] = a_cur[k];
-            sel_last = false;
-        }
-#pragma unroll
-        for (int k = 0; k < LEG; ++k) {  // _compute_torques legged_robot.py:679-715
-            float a = kSelAct ? a_sel[k] : (use_last ? a_last[k] : a_cur[k]);
-            float t = C.body[k].kp * (a * P.action_scale + C.body[k].q0 - st.q[k]) - C.body[k].kd * st.qd[k];
-            if (!PIPE && P.control_type != GRX_CONTROL_P)   // 'V' / 'T' (legged_robot.py:699-704): the one-wave layout only (grx_capi.cpp)
-                t = P.control_type == GRX_CONTROL_T ? a * P.action_scale
-                                                    : C.body[k].kp * (a * P.action_scale - st.qd[k]) - C.body[k].kd * (st.qd[k] - qd_last[k]) / P.sim_dt;
-            t *= LC.strength[k];
-            torque[k] = fminf(fmaxf(t, -C.body[k].effort), C.body[k].effort);
-        }
-        if (PIPE && LPL == 2) substep_q<HF, W == 8>(P, Cr, LC, st, torque, so, fk, L, lane, deci, tacc, C);
-        else if (PIPE) substep_p<HF, W == 8>(P, Cr, LC, st, torque, so, fk, L, RB, lane, deci, tacc, C);
-#ifdef GRX_W1_LEAN
-        else if (W == 1) substep_lean<HF>(P, s_tab, C, LC, st, torque, so, fk,
-                                          LinkForceOut{deci == P.decimation - 1, act0 ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side, self_near, deci == 0);
-#endif
-        else substep<HF, W>(P, s_tab, C, LC, st, torque, so, fk, s_wr + lane, tacc,
-                            LinkForceOut{deci == P.decimation - 1, act0 ? P.contact_forces + e : nullptr, (size_t)N}, RB, lane, el, side, self_near, deci == 0);
-        if (deci > 0) {  // fk = foot frame after the PREVIOUS sub-step
-            avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
-            if (!PIPE) avg_rpy = v3(avg_rpy.x + fabsf(fk.ang.x), avg_rpy.y + fabsf(fk.ang.y), avg_rpy.z + fabsf(fk.ang.z));
-        }
-        avg_force += grx_sqrt(dot(so.foot_force, so.foot_force));
-    }
-#ifndef GRX_NO_ADDR_LAUNDER
-    // The column addresses of this lane (64-bit: base + (row * N + e) * 4) are the same for the loads above and the stores below, and
-    // the compiler kept them across the sub-steps rather than form them twice -- 31 register pairs of the 92 dwords the lane-pair
-    // eight-wave kernel had in scratch.  Behind this the env index is a new value to it, and the addresses are formed again: 60 dwords
-    // of scratch instead of 92 there (+1.5 % at 8192 envs), none and 484 registers instead of 512 in the one-wave kernel (+1 % at
-    // 32768 and 131072 envs).  Not in the lane-quad pipelines, which load that state behind the sub-steps and kept nothing (-1 %).
-    if (!kLatePost) asm volatile("" : "+v"(e));   // (the lane's side / joint offset / LDS row laundered as well: 442 registers and 41 dwords, and the same rates)
-#endif
-    if (kLatePost) load_post_state();
-    const float yaw_n = fmaxf(sqrtf(st.qz * st.qz + st.qw * st.qw), 1e-9f);   // normalize(): torch_utils.py:43-45
-    const float yaw_z = st.qz / yaw_n, yaw_w = st.qw / yaw_n;
-    if (!PIPE && !DBG && P.publish_rbs) {
-        const float rq[4] = {st.qx, st.qy, st.qz, st.qw};
-        publish_rigid_body_states(P, C, side, st.pos, rq, st.vel, st.ang, st.q, st.qd, e, N, act0);
-    }
-    if (PIPE) {   // the foot wave owned the friction anchors during the sub-steps
-        if (side == 0) { float* hp = s_hp + el; hp[0 * EPB] = st.pos.x; hp[1 * EPB] = st.pos.y; hp[2 * EPB] = yaw_z; hp[3 * EPB] = yaw_w; }
-        if (P.publish_rbs) {   // the final state for the wave that publishes GRX_T_RIGID_BODY_STATES (wave 2, at the end of its work)
-            if (side == 0 && half == 0) pipe_base_store(s_bq, el, st.pos, st.qx, st.qy, st.qz, st.qw, st.vel, st.ang);
-            s_q[lane] = f4(st.q[0], st.q[1], st.q[2], st.q[3]);
-            s_q[64 + lane] = f4(st.q[4], st.qd[0], st.qd[1], st.qd[2]);
-            s_q[128 + lane] = f4(st.qd[3], st.qd[4], 0.f, 0.f);
-        }
-#ifdef GRX_PROFILE_SECTIONS
-        const long long tb0_ = clock64();
-        if (lane == 0) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 80] = tb0_;
-#endif
-        lds_barrier();   // final friction anchors + height-scan pose published (the last sub-step's row stores stay in flight)
-#ifdef GRX_PROFILE_SECTIONS
-        tacc[1] += clock64() - tb0_;
-#endif
-        const float* a_ = s_anch + (lane - half);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { st.ax[i] = a_[i * 64]; st.ay[i] = a_[(4 + i) * 64]; st.vimp[i] = a_[(9 + i) * 64]; }
-        st.anchor_on = __float_as_uint(a_[8 * 64]);
-        avg_rpy = v3(a_[13 * 64], a_[14 * 64], a_[15 * 64]);
-        so.term = s_tp[lane] != 0.f; so.pen_count = s_tp[64 + lane];   // from the net link forces (terrain + self-collision), wave 3
-    }
-    GRX_TICK(2);
-#ifdef GRX_PROFILE_SECTIONS
-    if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 16 + i] = tacc[i];
-    if (!PIPE && W == 1 && threadIdx.x == 0) for (int i = 0; i < 16; ++i) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 32 + i] = tacc[6 + i];
-#endif
-    fk = foot_kinematics(C, st);  // refresh_rigid_body_state_tensor after the last sub-step
-    avg_speed = v3(avg_speed.x + fabsf(fk.vel.x), avg_speed.y + fabsf(fk.vel.y), avg_speed.z + fabsf(fk.vel.z));
-    avg_force = avg_force / (float)P.decimation;  // legged_robot_fftai.py:86-88
-    avg_speed = v3(avg_speed.x / (float)P.decimation, avg_speed.y / (float)P.decimation, avg_speed.z / (float)P.decimation);
-    if (!DBG && act0) {   // avg_feet_speed_rpy (legged_robot_fftai.py:81, 88): no reward term reads it -- stored at once, nothing kept live
-        const float id = 1.0f / (float)P.decimation;
-        GCOL(P.avg_speed_rpy, (size_t)(side * 3 + 0) * N + e) = (avg_rpy.x + fabsf(fk.ang.x)) * id;
-        GCOL(P.avg_speed_rpy, (size_t)(side * 3 + 1) * N + e) = (avg_rpy.y + fabsf(fk.ang.y)) * id;
-        GCOL(P.avg_speed_rpy, (size_t)(side * 3 + 2) * N + e) = (avg_rpy.z + fabsf(fk.ang.z)) * id;
-    }
-    float a_ll[LEG];
-    bool dbg_apply_reset = true;
-    if (DBG) {   // injected "physics results" (grx_debug_post_physics)
-        const float* d = dbg + e;
-        const size_t n_ = (size_t)N;
-        so.foot_force = v3(d[(DBG_FEET_FORCE + side * 3 + 0) * n_], d[(DBG_FEET_FORCE + side * 3 + 1) * n_], d[(DBG_FEET_FORCE + side * 3 + 2) * n_]);
-        fk.pos = v3(d[(DBG_FEET_POS + side * 3 + 0) * n_], d[(DBG_FEET_POS + side * 3 + 1) * n_], d[(DBG_FEET_POS + side * 3 + 2) * n_]);
-        avg_force = d[(DBG_AVG_FORCE + side) * n_];
-        avg_speed = v3(d[(DBG_AVG_SPEED + side * 3 + 0) * n_], d[(DBG_AVG_SPEED + side * 3 + 1) * n_], d[(DBG_AVG_SPEED + side * 3 + 2) * n_]);
-#pragma unroll
-        for (int k = 0; k < LEG; ++k) { torque[k] = d[(DBG_TORQUES + j0 + k) * n_]; a_ll[k] = d[(DBG_LAST_LAST_ACTIONS + j0 + k) * n_]; }
-        if (!PIPE) { so.term = d[DBG_TERM_CONTACT * n_] != 0.f; so.pen_count = 0.f; }   // (the pipelines: through s_tp from wave 3, as in the product kernel)
-        dbg_apply_reset = d[DBG_APPLY_RESET * n_] != 0.f;
-    }
-    const bool term_contact = __builtin_bit_cast(int, pair_swap(__builtin_bit_cast(float, (int)so.term))) | (int)so.term;
-    const float pen_count = pair_sum(so.pen_count);
-
-    GRX_TICK(3);
-    // ---- post_physics_step (legged_robot.py:269-305)
-    float es_early[NT];   // running episode sums: loads issued here so their HBM latency overlaps the state update
-    if (!PIPE) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) es_early[t] = (P.reward_scale_dt[t] != 0.f) ? GCOL(P.episode_sums, (size_t)t * N + e) : 0.f;
-    }
-    ep_len += 1;
-    V3 qv = v3(st.qx, st.qy, st.qz);
-    V3 blv = quat_rotate_inverse(qv, st.qw, st.vel);
-    V3 bav = quat_rotate_inverse(qv, st.qw, st.ang);
-    V3 pg = quat_rotate_inverse(qv, st.qw, v3(0.f, 0.f, -1.f));
-    if (P.resample_command_interval > 0 && ((uint32_t)ep_len % (uint32_t)P.resample_command_interval) == 0)   // ep_len <= max_episode_length + 1
-        resample_commands(P, genv, step, GRX_RNG_CMD_TIME, ea.cmd);
-    if (!PIPE && P.heading_command) ea.cmd[2] = heading_yaw_command(P, v3(st.qx, st.qy, st.qz), st.qw);
-    // measured heights: this lane samples points k = 2*i + side; raw heights parked in the pri_obs staging row
-    float* prow = s_pri + el * PRS;
-    float hsum = 0.f;
-    if (HF && P.measure_heights) {
-        if (PIPE) {   // quarter of the scan here, the other three quarters on the helper waves
-            if (W != 8) {   // (eight waves: the scan runs on six helper waves and this wave picks its sum up when it writes feet_height -- see FL_SCAN)
-            hsum = height_scan_share<4>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
-            lds_barrier();   // height scan complete
-            hsum += s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane];
-            }
-        } else hsum = height_scan_share<1, GRX_W1_SCAN_BATCH>(P, s_tab, yaw_z, yaw_w, st.pos, lane & (LPE - 1), nh, prow);
-        hsum = env_sum(hsum);
-    }
-    if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {  // legged_robot.py:786-797
-        if (P.stash_pre_reset && act0 && side == 0) { P.pre_push_vel[e] = st.vel.x; P.pre_push_vel[(size_t)N + e] = st.vel.y; }   // (grx_refresh: the link frames of the state BEFORE the push, as the reference's un-refreshed tensor shows them)
-        st.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
-        st.vel.y = urand(P, genv, step, GRX_RNG_PUSH, 1, -P.max_push_vel_xy, P.max_push_vel_xy);
-    }
-    GRX_TICK(4);
-    // feet timers (legged_robot_fftai.py:108-133) -- this lane's foot
-    const bool contact = so.foot_force.z > 1.0f;
-    const bool contact_filt = contact || contact_last;
-    contact_last = contact;
-    const bool first_contact = (air_time > 0.f) && contact_filt;
-    air_time += dtp;
-    constexpr bool kLateScan = PIPE && W == 8 && HF;   // the height scan's sum arrives later (FL_SCAN): the reward waves and this wave's observation code form feet_height themselves
-    const bool late_scan = kLateScan && P.measure_heights;
-    float feet_height = late_scan ? fk.pos.z : (nh > 0 ? (fk.pos.z * (float)nh - hsum) / (float)nh : fk.pos.z);   // (late: the foot's z for now, scan_feet_height finishes it)
-    land_time = (land_time + dtp) * (contact ? 1.0f : 0.0f);
-    // check_termination (legged_robot.py:336-353)
-    bool reset = term_contact || (fabsf(pg.z) < P.termination_gravity_z);
-    const bool time_out = (float)ep_len > P.max_episode_length;
-    reset = reset || time_out;
-
-    GRX_TICK(5);
-    // ---- compute_reward + episode sums (reward_and_sums): here, or on wave 1 when the block has four waves
-    {
-        RewIn rin;
-#pragma unroll
-        for (int k = 0; k < LEG; ++k) {
-            rin.a_last[k] = a_last[k]; rin.a_cur[k] = a_cur[k]; rin.q[k] = st.q[k]; rin.qd[k] = st.qd[k];
-            rin.qd_last[k] = qd_last[k]; rin.torque[k] = torque[k];
-        }
-        rin.feet_height = feet_height; rin.air_time = air_time; rin.land_time = land_time; rin.avg_force = avg_force;
-        rin.avg_speed = avg_speed; rin.foot_force = so.foot_force;
-        rin.contact = contact ? 1.f : 0.f; rin.first_contact = first_contact ? 1.f : 0.f;
-        rin.cmd[0] = ea.cmd[0]; rin.cmd[1] = ea.cmd[1]; rin.cmd[2] = ea.cmd[2];
-        rin.blv = blv; rin.bav = bav; rin.pg = pg;
-        rin.bho_stale = bho_stale; rin.qx = st.qx; rin.qy = st.qy; rin.qz = st.qz; rin.qw = st.qw; rin.pen_count = pen_count;
-        rin.reset = reset ? 1.f : 0.f; rin.time_out = time_out ? 1.f : 0.f;
-        if (PIPE) {
-            int i = 0;
-            rewin_fields(rin, [&](float& x) { s_rw[(i++) * 64 + lane] = x; });
-            flag_set(s_flag + FL_REW, 1, lane);
-        } else reward_and_sums<0>(P, C, rin, lane, side, e, N, act, s_stat, es_early, nullptr, nullptr, DBG ? a_ll : nullptr, DBG && !dbg_apply_reset);
-    }
-    const bool writer = act0 && side == 0;
-    GRX_TICK(6);
-    // ---- reset_idx (masked, in-kernel)
-    const bool do_reset = DBG ? (reset && dbg_apply_reset) : reset;   // the debug entry may report a reset without applying it
-    if (P.stash_pre_reset && reset && act0) {   // (every REPORTED reset: the debug entry may report one without applying it -- GRX_T_RESET is what the refresh kernels go by)
-        // on-demand tensors (grx_refresh) show the state BEFORE reset_idx, as the step-written ones do
-        const size_t n_ = (size_t)N;
-#pragma unroll
-        for (int k = 0; k < LEG; ++k) { P.pre_q[(size_t)(side * LEG + k) * n_ + e] = st.q[k]; P.pre_qd[(size_t)(side * LEG + k) * n_ + e] = st.qd[k]; }
-        if (side == 0) {
-            float* r_ = P.pre_root + e;
-            r_[0] = st.pos.x; r_[n_] = st.pos.y; r_[2 * n_] = st.pos.z; r_[3 * n_] = st.qx; r_[4 * n_] = st.qy; r_[5 * n_] = st.qz; r_[6 * n_] = st.qw;
-            r_[7 * n_] = st.vel.x; r_[8 * n_] = st.vel.y; r_[9 * n_] = st.vel.z; r_[10 * n_] = st.ang.x; r_[11 * n_] = st.ang.y; r_[12 * n_] = st.ang.z;
-        }
-    }
-    if (PIPE ? __any(do_reset) : do_reset) {   // uniform test with four waves: the draws come from wave 2 through LDS
-        ResetRand rr;
-        if (PIPE) {
-            flag_wait(s_flag + FL_RR, 1);
-            const float4* z = s_rr + lane;
-            const float4 z0 = z[0 * 64], z1 = z[1 * 64], z2 = z[2 * 64], z3 = z[3 * 64], z4 = z[4 * 64];
-            rr.dof[0] = z0.x; rr.dof[1] = z0.y; rr.dof[2] = z0.z; rr.dof[3] = z0.w; rr.dof[4] = z1.x;
-            rr.root[0] = z1.y; rr.root[1] = z1.z; rr.root[2] = z1.w; rr.root[3] = z2.x; rr.root[4] = z2.y;
-            rr.root[5] = z2.z; rr.root[6] = z2.w; rr.root[7] = z3.x; rr.root[8] = z3.y;
-            rr.cmd[0] = z3.z; rr.cmd[1] = z3.w; rr.cmd[2] = z4.x;
-        } else rr = reset_rand(P, genv, step, side);
-      if (do_reset) {
-        reset_env(P, C, side, genv, step, true, st, ea, rr);
-#pragma unroll
-        for (int k = 0; k < LEG; ++k) { a_last[k] = 0.f; qd_last[k] = 0.f; }
-        air_time = 0.f; land_time = 0.f;
-        contact_last = false;
-        ep_len = 0;
-      }
-    }
-    const bool feet_contact_obs = do_reset ? false : contact;  // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
-    {   // statistics row NT + 1: terrain levels AFTER this step's curriculum moves (legged_robot.py:427-428)
-        const float ls = level_sum(ea.level, writer);
-        if (lane == 0) s_stat[NT + 1] = ls;
-    }
-
-    GRX_TICK(7);
-    // ---- compute_observations (legged_robot.py:442-452, legged_robot_fftai.py:148-167, gr1t1.py:281-336)
-    float bho = 0.f;
-    if (PIPE) {   // waves 2 and 3 do the height block (obs_heights_share) while this wave writes the other terms
-        if (side == 0) s_hp[el] = st.pos.z;
-        flag_set(s_flag + FL_HZ, 1, lane);
-    } else {
-        const float sum = env_sum(obs_heights_share<LPE>(P, st.pos.z, lane & (LPE - 1), nh, prow, HF && P.measure_heights, act, e, N));
-        bho = nh > 0 ? sum / (float)nh : 0.f;
-    }
-    GRX_TICK(11);
-    float* orow = s_obs + el * GRX_NUM_OBS;
-    const float clipo = P.clip_observations;
-    // observation noise (noise_blocks): with 4 waves per block wave 1 computed the blocks while wave 0 loaded state
-    U4 nzb[NZB];
-    if (P.add_noise && !noise_in) {
-        if (PIPE) {
-            const uint32_t* z = s_nz + lane;
-#pragma unroll
-            for (int b = 0; b < NZB; ++b) { nzb[b].x = z[(b * 4 + 0) * 64]; nzb[b].y = z[(b * 4 + 1) * 64]; nzb[b].z = z[(b * 4 + 2) * 64]; nzb[b].w = z[(b * 4 + 3) * 64]; }
-        } else noise_blocks(P, genv, step, side, nzb);
-    }
-    GRX_TICK(12);
-    // item: index within the lane's stream (compile-time); slot0: first block slot of that stream
-    auto put = [&](int idx, float val, float nscale, int item, int slot0) {
-        float pv = fminf(fmaxf(val, -clipo), clipo);
-        prow[idx] = pv;  // pri_obs copies obs BEFORE noise
-        float ov = val;
-        if (P.add_noise && nscale != 0.f) {
-            float u;
-            if (noise_in) u = noise_in[(size_t)e * GRX_NUM_OBS + idx];
-            else {
-                const U4 o = nzb[slot0 + (item >> 2)];
-                const int wsel = item & 3;
-                u = grx_u01(wsel == 0 ? o.x : (wsel == 1 ? o.y : (wsel == 2 ? o.z : o.w)));
-            }
-            ov += (2.f * u - 1.f) * nscale;
-        }
-        orow[idx] = fminf(fmaxf(ov, -clipo), clipo);
-    };
-    if (side == 0) {
-        put(0, ea.cmd[0], 0.f, 0, 4); put(1, ea.cmd[1], 0.f, 0, 4); put(2, ea.cmd[2], 0.f, 0, 4);
-        const float na = P.noise_ang_vel * P.noise_level * P.obs_scale_ang_vel;
-        put(3, bav.x * P.obs_scale_ang_vel, na, 0, 4); put(4, bav.y * P.obs_scale_ang_vel, na, 1, 4); put(5, bav.z * P.obs_scale_ang_vel, na, 2, 4);
-        const float ng = P.noise_gravity * P.noise_level * P.obs_scale_gravity;
-        put(6, pg.x * P.obs_scale_gravity, ng, 3, 4); put(7, pg.y * P.obs_scale_gravity, ng, 4, 4); put(8, pg.z * P.obs_scale_gravity, ng, 5, 4);
-        prow[GRX_NUM_OBS + 0] = fminf(fmaxf(blv.x * P.obs_scale_lin_vel, -clipo), clipo);
-        prow[GRX_NUM_OBS + 1] = fminf(fmaxf(blv.y * P.obs_scale_lin_vel, -clipo), clipo);
-        prow[GRX_NUM_OBS + 2] = fminf(fmaxf(blv.z * P.obs_scale_lin_vel, -clipo), clipo);
-    }
-    GRX_TICK(13);
-    {
-        const float np_ = P.noise_dof_pos * P.noise_level * P.obs_scale_dof_pos;
-        const float nv = P.noise_dof_vel * P.noise_level * P.obs_scale_dof_vel;
-        const float nac = P.noise_action * P.noise_level * P.obs_scale_action;
-#pragma unroll
-        for (int k = 0; k < LEG; ++k) {
-            put(9 + j0 + k, (st.q[k] - C.body[k].q0) * P.obs_scale_dof_pos, np_, k, 0);
-            put(9 + GRX_ND + j0 + k, st.qd[k] * P.obs_scale_dof_vel, nv, 5 + k, 0);
-            put(9 + 2 * GRX_ND + j0 + k, a_cur[k] * P.obs_scale_action, nac, 10 + k, 0);
-        }
-        if (late_scan) feet_height = scan_feet_height(P, s_flag, s_hsum, feet_height, nh, lane);
-        prow[GRX_NUM_OBS + 4 + side] = feet_contact_obs ? 1.f : 0.f;
-        prow[GRX_NUM_OBS + 6 + side] = fminf(fmaxf(feet_height * P.obs_scale_height, -clipo), clipo);
-    }
-    if (!PIPE && side == 0) prow[GRX_NUM_OBS + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
-
-    GRX_TICK(8);
-    // ---- store state (SoA) -- history: last_actions = actions, last_dof_vel = dof_vel (legged_robot.py:299-300)
-    if (act0) {
-#pragma unroll
-        for (int k = 0; k < LEG; ++k) {
-            size_t o = (size_t)(j0 + k) * N + e;
-            GCOL(P.q, o) = st.q[k]; GCOL(P.qd, o) = st.qd[k];
-            GCOL(P.last_actions, o) = a_cur[k]; GCOL(P.last_dof_vel, o) = st.qd[k];
-            GCOL(P.actions, o) = a_cur[k]; GCOL(P.torques, o) = torque[k];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 0) * N + e) = st.ax[i];
-            GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 1) * N + e) = st.ay[i];
-            GCOL(P.anchors, (size_t)((side * 4 + i) * 3 + 2) * N + e) = (st.anchor_on >> i) & 1u ? fmaxf(st.vimp[i], 1e-6f) : 0.f;
-        }
-        GCOL(P.air_time, (size_t)side * N + e) = air_time * (contact_filt ? 0.f : 1.f);  // legged_robot_fftai.py:97
-        GCOL(P.land_time, (size_t)side * N + e) = land_time;
-        GCOL(P.feet_contact, (size_t)side * N + e) = feet_contact_obs ? 1 : 0;
-        GCOL(P.feet_height, (size_t)side * N + e) = feet_height;
-        GCOL(P.avg_force, (size_t)side * N + e) = avg_force;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            float ff = i == 0 ? so.foot_force.x : (i == 1 ? so.foot_force.y : so.foot_force.z);
-            float fp = i == 0 ? fk.pos.x : (i == 1 ? fk.pos.y : fk.pos.z);
-            float as_ = i == 0 ? avg_speed.x : (i == 1 ? avg_speed.y : avg_speed.z);
-            GCOL(P.feet_force, (size_t)(side * 3 + i) * N + e) = ff;
-            GCOL(P.feet_pos, (size_t)(side * 3 + i) * N + e) = fp;
-            GCOL(P.avg_speed, (size_t)(side * 3 + i) * N + e) = as_;
-        }
-    }
-    GRX_TICK(93);
-    if (writer) {
-        float rs[13] = {st.pos.x, st.pos.y, st.pos.z, st.qx, st.qy, st.qz, st.qw, st.vel.x, st.vel.y, st.vel.z, st.ang.x, st.ang.y, st.ang.z};
-#pragma unroll
-        for (int i = 0; i < 13; ++i) GCOL(P.root, (size_t)i * N + e) = rs[i];
-        GCOL(P.commands, e) = ea.cmd[0]; GCOL(P.commands, (size_t)N + e) = ea.cmd[1]; GCOL(P.commands, 2 * (size_t)N + e) = ea.cmd[2];
-        GCOL(P.base_lin_vel, e) = blv.x; GCOL(P.base_lin_vel, (size_t)N + e) = blv.y; GCOL(P.base_lin_vel, 2 * (size_t)N + e) = blv.z;
-        GCOL(P.base_ang_vel, e) = bav.x; GCOL(P.base_ang_vel, (size_t)N + e) = bav.y; GCOL(P.base_ang_vel, 2 * (size_t)N + e) = bav.z;
-        GCOL(P.proj_grav, e) = pg.x; GCOL(P.proj_grav, (size_t)N + e) = pg.y; GCOL(P.proj_grav, 2 * (size_t)N + e) = pg.z;
-        GCOL(P.origins, e) = ea.origin[0]; GCOL(P.origins, (size_t)N + e) = ea.origin[1]; GCOL(P.origins, 2 * (size_t)N + e) = ea.origin[2];
-        GCOL(P.levels, e) = ea.level;
-        if (!PIPE) GCOL(P.base_heights_offset, e) = bho;
-        GCOL(P.ep_len, e) = ep_len;
-        GCOL(P.reset, e) = reset ? 1 : 0;
-        GCOL(P.time_out, e) = time_out ? 1 : 0;
-        GCOL(P.term_contact, e) = term_contact ? 1 : 0;
-    }
-    GRX_TICK(94);
-    if (PIPE) {   // base_heights_offset: the helper waves' partial sums of the observation height block
-        if (W == 8) {
-            flag_wait_all(s_flag, flag_want(lane, FL_BHO1, 1, FL_BHO1 + 1, 1, FL_BHO1 + 2, 1, FL_BHO4, 1), lane);
-            if (HF) bho = nh > 0 ? ((s_bho[0 * 64 + lane] + s_bho[1 * 64 + lane]) + (s_bho[2 * 64 + lane] + s_bho[3 * 64 + lane])) / (float)nh : 0.f;
-            else bho = nh > 0 ? ((s_hsum[4 * 64 + lane] + s_hsum[5 * 64 + lane]) + (s_hsum[6 * 64 + lane] + s_hsum[7 * 64 + lane])) / (float)nh : 0.f;
-        } else {
-        flag_wait(s_flag + FL_BHO1, 1);
-        flag_wait(s_flag + FL_BHO1 + 1, 1);
-        flag_wait(s_flag + FL_BHO1 + 2, 1);
-        bho = nh > 0 ? (s_hsum[1 * 64 + lane] + s_hsum[2 * 64 + lane] + s_hsum[3 * 64 + lane]) / (float)nh : 0.f;
-        }
-        if (side == 0) prow[GRX_NUM_OBS + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
-        if (writer) GCOL(P.base_heights_offset, e) = bho;
-    }
-    GRX_TICK(9);
-    }   // dynamics wave
-    // ---- coalesced AoS output rows (all waves): the block's 32 obs / pri_obs rows are contiguous in HBM
-    // (the rows and the statistics are staged in LDS: an LDS-only barrier -- a full one would drain every wave's state stores first,
-    //  measured 14 k cycles here)
-    lds_barrier();
-    {
-        const int e0 = grp * EPB;
-        const int nenv = min(EPB, N - e0);
-        float* gobs = (obs_out ? obs_out : P.obs) + (size_t)e0 * GRX_NUM_OBS;   // grx_step_args.obs_out: the caller's buffer (no copy per step)
-        const int tot = nenv * GRX_NUM_OBS;
-        if (nenv == EPB) {
-            const float4* s4 = reinterpret_cast<const float4*>(s_obs);
-            float4* g4 = reinterpret_cast<float4*>(gobs);
-            for (int i = tid; i < EPB * GRX_NUM_OBS / 4; i += NTHR) g4[i] = s4[i];
-        } else
-            for (int i = tid; i < tot; i += NTHR) gobs[i] = s_obs[i];
-        float* gpri = (pri_out ? pri_out : P.pri_obs) + (size_t)e0 * npri;
-        if (npri == GRX_MAX_PRI && nenv == EPB) {
-            const float2* s2 = reinterpret_cast<const float2*>(s_pri);
-            float2* g2 = reinterpret_cast<float2*>(gpri);
-            for (int i = tid; i < EPB * GRX_MAX_PRI / 2; i += NTHR) {
-                const int row = i / (GRX_MAX_PRI / 2);
-                g2[i] = s2[i + row * ((PRS - GRX_MAX_PRI) / 2)];
-            }
-        } else
-            for (int i = tid; i < nenv * npri; i += NTHR) gpri[i] = s_pri[(i / npri) * PRS + (i % npri)];
-        if (tid < NSTAT) stat_row(P, sq.seq, tid)[grp] = s_stat[tid];   // row-major: the reduction reads rows of one term
-        if (blockIdx.x == 0 && tid == 0) P.stat_nblocks[sq.seq & 1] = (int)gridDim.x;
-    }
-    // (The rows are reduced by the NEXT launch of the handle -- stats_fold_previous: the kernel boundary orders them for free.
-    //  Reducing them here, in the last block to finish, was tried twice in round 1: an agent-scope __threadfence per block is a
-    //  whole-L2 write-back on this 8-XCD part, +10 us per launch; agent-scope atomics without a fence wait +9 us for the
-    //  acknowledgements.  Round 2 paid a 4.5 us kernel of its own per step instead.)
-    GRX_TICK(10);
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 2 : GRX_WPE, W > 4 ? 2 : GRX_WPE))) void grx_step_kernel(GRX_STEP_KERNEL_ARGS) {
+#include "grx_step_kernel_body.inc"
+}
+// mesh_type 'trimesh': the same step against the reference's slope-corrected triangle mesh (terrain_eval's planes per triangle half, wall_contact)
+template <int W, bool DBG = false>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(W > 4 ? 2 : GRX_WPE, W > 4 ? 2 : GRX_WPE))) void grx_step_kernel_trimesh(GRX_STEP_KERNEL_ARGS) {
+    constexpr int HF = GRX_HF_TRIMESH;
+#include "grx_step_kernel_body.inc"
 }
 
 // -DGRX_SPIN_LIMIT builds (grx_flags.h): where an expired spin reports before it traps -- one pointer per translation unit
@@ -2338,9 +1570,12 @@ extern "C" void grx_launch_step_quad(const KParams* dP, int N, int heightfield, 
                                      const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {
     const int nblocks = (N + EPB - 1) / EPB;
 #define GRX_LAUNCH_QUAD(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out, *sq)
-    if (heightfield) { if (waves == 8) GRX_LAUNCH_QUAD(true, 8); else GRX_LAUNCH_QUAD(true, 4); }
-    else { if (waves == 8) GRX_LAUNCH_QUAD(false, 8); else GRX_LAUNCH_QUAD(false, 4); }
+#define GRX_LAUNCH_QUAD_TM(W_) hipLaunchKernelGGL((grx_step_kernel_trimesh<W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out, *sq)
+    if (heightfield == 1) { if (waves == 8) GRX_LAUNCH_QUAD(true, 8); else GRX_LAUNCH_QUAD(true, 4); }   // (heightfield: 0 plane, 1 raster, 2 trimesh)
+    else if (heightfield == 0) { if (waves == 8) GRX_LAUNCH_QUAD(false, 8); else GRX_LAUNCH_QUAD(false, 4); }
+    else { if (waves == 8) GRX_LAUNCH_QUAD_TM(8); else GRX_LAUNCH_QUAD_TM(4); }
 #undef GRX_LAUNCH_QUAD
+#undef GRX_LAUNCH_QUAD_TM
 }
 extern "C" int grx_envs_per_block_quad(void) { return EPB; }
 // TEST-ONLY (grx_debug_post_physics): the post-physics half of the lane-quad kernels on injected state
@@ -2348,9 +1583,12 @@ extern "C" void grx_launch_step_debug_quad(const KParams* dP, int N, int heightf
                                            const float* dbg, const StepSeq* sq, hipStream_t stream) {
     const int nblocks = (N + EPB - 1) / EPB;
 #define GRX_LAUNCH_DBGQ(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_, true>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr, *sq)
-    if (heightfield) { if (waves == 8) GRX_LAUNCH_DBGQ(true, 8); else GRX_LAUNCH_DBGQ(true, 4); }
-    else { if (waves == 8) GRX_LAUNCH_DBGQ(false, 8); else GRX_LAUNCH_DBGQ(false, 4); }
+#define GRX_LAUNCH_DBGQ_TM(W_) hipLaunchKernelGGL((grx_step_kernel_trimesh<W_, true>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr, *sq)
+    if (heightfield == 1) { if (waves == 8) GRX_LAUNCH_DBGQ(true, 8); else GRX_LAUNCH_DBGQ(true, 4); }
+    else if (heightfield == 0) { if (waves == 8) GRX_LAUNCH_DBGQ(false, 8); else GRX_LAUNCH_DBGQ(false, 4); }
+    else { if (waves == 8) GRX_LAUNCH_DBGQ_TM(8); else GRX_LAUNCH_DBGQ_TM(4); }
 #undef GRX_LAUNCH_DBGQ
+#undef GRX_LAUNCH_DBGQ_TM
 }
 #else
 #ifndef GRX_TREE16_TU   // (grx_tree16.hip: only the tree kernel's launchers below)
@@ -2580,7 +1818,7 @@ __global__ void grx_debug_terrain_kernel(const KParams* __restrict__ Pg, const f
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float gx = 0.f, gy = 0.f, h = 0.f;
-    if (P.terrain_type != GRX_TERRAIN_PLANE) h = terrain_height<true>(P, xy[2 * i], xy[2 * i + 1], gx, gy);
+    if (P.terrain_type != GRX_TERRAIN_PLANE) h = P.vertical_faces ? terrain_height<GRX_HF_TRIMESH>(P, xy[2 * i], xy[2 * i + 1], gx, gy) : terrain_height<GRX_HF_RASTER>(P, xy[2 * i], xy[2 * i + 1], gx, gy);
     out[3 * i] = h; out[3 * i + 1] = gx; out[3 * i + 2] = gy;
 }
 extern "C" void grx_launch_debug_terrain(const KParams* dP, const float* xy, int n, float* out, hipStream_t stream) {
@@ -2618,9 +1856,12 @@ extern "C" void grx_launch_step(const KParams* dP, int N, int heightfield, int w
                                 const float* noise, float* obs_out, float* pri_out, const StepSeq* sq, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
 #define GRX_LAUNCH_STEP(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out, *sq)
-    if (heightfield) { if (waves == 8) GRX_LAUNCH_STEP(true, 8); else if (waves == 4) GRX_LAUNCH_STEP(true, 4); else if (waves == 2) GRX_LAUNCH_STEP(true, 2); else GRX_LAUNCH_STEP(true, 1); }
-    else { if (waves == 8) GRX_LAUNCH_STEP(false, 8); else if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
+#define GRX_LAUNCH_STEP_TM(W_) hipLaunchKernelGGL((grx_step_kernel_trimesh<W_>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, delay, common_step, noise, (const float*)nullptr, obs_out, pri_out, *sq)
+    if (heightfield == 1) { if (waves == 8) GRX_LAUNCH_STEP(true, 8); else if (waves == 4) GRX_LAUNCH_STEP(true, 4); else if (waves == 2) GRX_LAUNCH_STEP(true, 2); else GRX_LAUNCH_STEP(true, 1); }   // (heightfield: 0 plane, 1 raster, 2 trimesh)
+    else if (heightfield == 0) { if (waves == 8) GRX_LAUNCH_STEP(false, 8); else if (waves == 4) GRX_LAUNCH_STEP(false, 4); else if (waves == 2) GRX_LAUNCH_STEP(false, 2); else GRX_LAUNCH_STEP(false, 1); }
+    else { if (waves == 8) GRX_LAUNCH_STEP_TM(8); else if (waves == 4) GRX_LAUNCH_STEP_TM(4); else if (waves == 2) GRX_LAUNCH_STEP_TM(2); else GRX_LAUNCH_STEP_TM(1); }
 #undef GRX_LAUNCH_STEP
+#undef GRX_LAUNCH_STEP_TM
 }
 // TEST-ONLY (grx_debug_post_physics): the post-physics half of the step on injected state, in the layout the handle steps with
 // (waves = 1, 4, 8; the two-wave layout shares the one-wave kernel's post-physics code and is served by it)
@@ -2628,9 +1869,12 @@ extern "C" void grx_launch_step_debug(const KParams* dP, int N, int heightfield,
                                       const float* dbg, const StepSeq* sq, hipStream_t stream) {
     int nblocks = (N + EPB - 1) / EPB;
 #define GRX_LAUNCH_DBG(HF_, W_) hipLaunchKernelGGL((grx_step_kernel<HF_, W_, true>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr, *sq)
-    if (heightfield) { if (waves == 8) GRX_LAUNCH_DBG(true, 8); else if (waves == 4) GRX_LAUNCH_DBG(true, 4); else GRX_LAUNCH_DBG(true, 1); }
-    else { if (waves == 8) GRX_LAUNCH_DBG(false, 8); else if (waves == 4) GRX_LAUNCH_DBG(false, 4); else GRX_LAUNCH_DBG(false, 1); }
+#define GRX_LAUNCH_DBG_TM(W_) hipLaunchKernelGGL((grx_step_kernel_trimesh<W_, true>), dim3(nblocks), dim3(64 * W_), 0, stream, dP, actions, 0.f, common_step, noise, dbg, (float*)nullptr, (float*)nullptr, *sq)
+    if (heightfield == 1) { if (waves == 8) GRX_LAUNCH_DBG(true, 8); else if (waves == 4) GRX_LAUNCH_DBG(true, 4); else GRX_LAUNCH_DBG(true, 1); }
+    else if (heightfield == 0) { if (waves == 8) GRX_LAUNCH_DBG(false, 8); else if (waves == 4) GRX_LAUNCH_DBG(false, 4); else GRX_LAUNCH_DBG(false, 1); }
+    else { if (waves == 8) GRX_LAUNCH_DBG_TM(8); else if (waves == 4) GRX_LAUNCH_DBG_TM(4); else GRX_LAUNCH_DBG_TM(1); }
 #undef GRX_LAUNCH_DBG
+#undef GRX_LAUNCH_DBG_TM
 }
 extern "C" int grx_debug_rows(void) { return DBG_ROWS; }
 extern "C" int grx_debug_row_of(int what) { return what == 0 ? (int)DBG_TORQUES : what == 1 ? (int)DBG_LAST_LAST_ACTIONS : what == 2 ? (int)DBG_TERM_CONTACT : (int)DBG_APPLY_RESET; }
@@ -2645,11 +1889,13 @@ extern "C" int grx_launch_step_generic(const KParams* dP, const void* tables, fl
         if (!raised) {   // > 64 KB of dynamic LDS needs the opt-in
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_generic<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_generic<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_generic_trimesh), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
             raised = true;
         }
         ws = nullptr;
     }
-    if (heightfield) hipLaunchKernelGGL(grx_step_generic<true>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise, obs_out, pri_out, seq);
+    if (heightfield == 2) hipLaunchKernelGGL(grx_step_generic_trimesh, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise, obs_out, pri_out, seq);
+    else if (heightfield) hipLaunchKernelGGL(grx_step_generic<true>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise, obs_out, pri_out, seq);
     else hipLaunchKernelGGL(grx_step_generic<false>, dim3(nblocks), dim3(epb), lds_bytes, stream, dP, T, ws, actions, delay, common_step, noise, obs_out, pri_out, seq);
     return 0;
 }
@@ -2671,12 +1917,14 @@ extern "C" int GRX_TREE_FN(grx_launch_step_tree)(const KParams* dP, const void* 
     if (!raised) {   // > 64 KB of dynamic LDS needs the opt-in
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree_trimesh<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
         raised = true;
     }
     const int nblocks = (N + TEPW * waves - 1) / (TEPW * waves);
     const TreeTab* Tt = static_cast<const TreeTab*>(tree_tab);
     const GenTables* Tg = static_cast<const GenTables*>(gen_tab);
-    if (heightfield) hipLaunchKernelGGL((grx_step_tree<true, false>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq, (const float*)nullptr);
+    if (heightfield == 2) hipLaunchKernelGGL((grx_step_tree_trimesh<false>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq, (const float*)nullptr);
+    else if (heightfield) hipLaunchKernelGGL((grx_step_tree<true, false>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq, (const float*)nullptr);
     else hipLaunchKernelGGL((grx_step_tree<false, false>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, delay, common_step, noise, obs_out, pri_out, *sq, (const float*)nullptr);
     return 0;
 }
@@ -2687,12 +1935,14 @@ extern "C" int GRX_TREE_FN(grx_launch_step_tree_debug)(const KParams* dP, const 
     if (!raised) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&grx_step_tree_trimesh<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess) return -1;
         raised = true;
     }
     const int nblocks = (N + TEPW * waves - 1) / (TEPW * waves);
     const TreeTab* Tt = static_cast<const TreeTab*>(tree_tab);
     const GenTables* Tg = static_cast<const GenTables*>(gen_tab);
-    if (heightfield) hipLaunchKernelGGL((grx_step_tree<true, true>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, 0.f, common_step, noise, (float*)nullptr, (float*)nullptr, *sq, dbg);
+    if (heightfield == 2) hipLaunchKernelGGL((grx_step_tree_trimesh<true>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, 0.f, common_step, noise, (float*)nullptr, (float*)nullptr, *sq, dbg);
+    else if (heightfield) hipLaunchKernelGGL((grx_step_tree<true, true>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, 0.f, common_step, noise, (float*)nullptr, (float*)nullptr, *sq, dbg);
     else hipLaunchKernelGGL((grx_step_tree<false, true>), dim3(nblocks), dim3(64 * waves), lds_bytes, stream, dP, Tt, Tg, actions, 0.f, common_step, noise, (float*)nullptr, (float*)nullptr, *sq, dbg);
     return 0;
 }

@@ -4,4 +4,5 @@
 #define GRX_LPE 4
 #define GRX_QUAD_TU
 #define grx_step_kernel grx_step_kernel_quad   // (a kernel of its own: the template's name is the symbol the HIP runtime registers)
+#define grx_step_kernel_trimesh grx_step_kernel_quad_trimesh
 #include "grx_kernels.hip"

@@ -79,7 +79,7 @@ struct RareNoWait { GRX_DEV void operator()() const {} };
 // Must be called by all 64 lanes in wave-uniform control flow.
 // OWN_POS (with FRAMES_IN_LDS): the caller walked the chain itself for R, rho of K2in / K3in (the reach tests need no velocities), so
 // the tests start before the other wave's frames are out; wait_frames() is then called right before the evaluation reads them.
-template <bool HF, int S0, int S1, bool FRAMES_IN_LDS = false, bool OWN_POS = false, class WaitFrames = RareNoWait>
+template <int HF, int S0, int S1, bool FRAMES_IN_LDS = false, bool OWN_POS = false, class WaitFrames = RareNoWait>
 GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const RareBuf& B, int lane, int el, int side, const R3& R0, V3 O, V3 ang, V3 vel,
                            const ChainKin& K2in, const ChainKin& K3in, float mu, float hmax, RareOut& out,
                            long long* rare_acc = nullptr, WaitFrames wait_frames = WaitFrames(), const bool want_links = true) {
@@ -215,7 +215,7 @@ GRX_DEV void rare_contacts(KP P, const KTables& T, const SideConst& C, const Rar
                 LaneState dummy;
                 dummy.anchor_on = 0;
                 V3 F = sphere_contact<HF, -1>(P, S, Fr.w, Fr.v, Ow, om.w, hmax_, dummy, xr, th);
-                if (HF && P.vertical_faces) {   // mesh_type 'trimesh': the vertical faces next to the shape
+                if (HF == GRX_HF_TRIMESH) {   // mesh_type 'trimesh': the vertical faces next to the shape
                     float wtx, wty;
                     const uint4 ww = wall_gather(P, Ow.x + xr.x, Ow.y + xr.y, wtx, wty);
                     F = F + wall_contact(P, ww, wtx, wty, Ow.z + xr.z, S.r, S.dmax, Fr.v + cross(Fr.w, xr), om.w);

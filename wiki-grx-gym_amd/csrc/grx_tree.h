@@ -151,7 +151,7 @@ GRX_DEV void tree_joint_phase(KP P, const TreeTab& T, float* wsw, int ei, int c,
 }
 
 // one sphere against the terrain (gen_sphere with the anchors and the link-force accumulators in the LDS workspace)
-template <bool HF, bool LF = true>   // LF: add the force to the link's accumulator here (false: the caller does, in its turn)
+template <int HF, bool LF = true>   // LF: add the force to the link's accumulator here (false: the caller does, in its turn)
 GRX_DEV V3 tree_sphere(KP P, const TreeSph& S, V3 w, V3 v, V3 O, float mu, float om_e, float hmax, float* wsw, int ei,
                        const TreeOff& o, V3 xr, const TerrainAt& th) {   // xr: the centre relative to O; th: the terrain under it (looked up by the caller, in batches)
     V3 F = v3(0.f, 0.f, 0.f);
@@ -329,7 +329,7 @@ GRX_DEV void tree_bias_all(const TreeTab& T, float* wsw, int ei, int c) {
 // phase) and ISSUES the terrain gathers -- ~1.2 us of memory latency on this part, which a wave alone on its SIMD cannot hide --;
 // tree_contacts evaluates them.  The kernel puts the bias forces of all bodies (tree_bias_all) between the two halves of round 0.
 struct TreeContactPre { V3 xr[2]; uint2 cc[2]; float tx[2], ty[2]; };   // cc: the raster cell's four corners as gathered (unpacked where they are used: a conversion next to the load would wait for it there)
-template <bool HF>
+template <int HF>
 GRX_DEV TreeContactPre tree_contact_probe(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0, int r) {
     TreeContactPre pr;
     const int b = T.cw[r][c].body, s0 = T.cw[r][c].s0, s1 = T.cw[r][c].s1;
@@ -351,12 +351,12 @@ GRX_DEV TreeContactPre tree_contact_probe(KP P, const TreeTab& T, float* wsw, in
         pr.cc[u] = make_uint2(0u, 0u); pr.tx[u] = 0.f; pr.ty[u] = 0.f;
         if (HF) {
             const int cell = terrain_locate(P, E.B.pos.x + pr.xr[u].x, E.B.pos.y + pr.xr[u].y, pr.tx[u], pr.ty[u]);
-            pr.cc[u] = P.hf_cells[terrain_record(P, cell, pr.tx[u], pr.ty[u])];
+            pr.cc[u] = P.hf_cells[terrain_record<HF>(P, cell, pr.tx[u], pr.ty[u])];
         }
     }
     return pr;
 }
-template <bool HF>
+template <int HF>
 GRX_DEV void tree_contacts(KP P, const TreeTab& T, float* wsw, int ei, int c, const TreeOff& o, const TreeEnv& E, const R3& R0, const TreeContactPre& pre0) {
     for (int r = 0; r < T.ncs; ++r) {
         const int b = T.cw[r][c].body, s0 = T.cw[r][c].s0, s1 = T.cw[r][c].s1, turn = T.cw[r][c].turn;
@@ -383,7 +383,7 @@ GRX_DEV void tree_contacts(KP P, const TreeTab& T, float* wsw, int ei, int c, co
                         th.h = terrain_eval<HF>(P, raw, th.gx, th.gy);
                     }
                     Fs[u] = tree_sphere<HF, false>(P, T.sph[s0 + u], w, v, E.B.pos, E.mu, E.om_e, E.hmax, wsw, ei, o, pr.xr[u], th);
-                    if (HF && P.vertical_faces && E.B.pos.z + pr.xr[u].z - T.sph[s0 + u].r <= E.hmax) {   // mesh_type 'trimesh': the vertical faces next to the shape
+                    if (HF == GRX_HF_TRIMESH && E.B.pos.z + pr.xr[u].z - T.sph[s0 + u].r <= E.hmax) {   // mesh_type 'trimesh': the vertical faces next to the shape
                         float wtx, wty;
                         const uint4 ww = wall_gather(P, E.B.pos.x + pr.xr[u].x, E.B.pos.y + pr.xr[u].y, wtx, wty);
                         Fs[u] = Fs[u] + wall_contact(P, ww, wtx, wty, E.B.pos.z + pr.xr[u].z, T.sph[s0 + u].r, T.sph[s0 + u].dmax, v + cross(w, pr.xr[u]), E.mu);
@@ -640,728 +640,16 @@ GRX_DEV void tree_self_collision(KP P, const TreeTab& T, float* wsw, int ei, int
 // DBG (TEST-ONLY, grx_debug_post_physics; the lower-limb model forced through this kernel, i.e. nd = 10 like the debug rows): no
 // sub-steps; foot forces / positions, sub-step averages, torques, termination contact and last_last_actions come from `dbg`
 // (grx_kernels.hip DbgRow) -- the reference's golden fixtures reach the post-physics code config 5 runs.
+#define GRX_STEP_TREE_ARGS const KParams* __restrict__ Pg, const TreeTab* __restrict__ Tt, const GenTables* __restrict__ Tg, const float* __restrict__ actions_in, float delay, long long common_step, \
+                           const float* __restrict__ noise_in, float* __restrict__ obs_out, float* __restrict__ pri_out, const StepSeq sq, const float* __restrict__ dbg
 template <bool HF, bool DBG = false>
-__global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_tree(const KParams* __restrict__ Pg, const TreeTab* __restrict__ Tt, const GenTables* __restrict__ Tg,
-                                                             const float* __restrict__ actions_in, float delay, long long common_step,
-                                                             const float* __restrict__ noise_in, float* __restrict__ obs_out, float* __restrict__ pri_out,
-                                                             const StepSeq sq, const float* __restrict__ dbg = nullptr) {
-    KP P = GRX_PARAMS(Pg);
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-    __shared__ float s_stat[TWAVES_MAX][NSTAT];   // a row per wave, added in wave order at the end: the same sums on every run (float atomics of four waves
-                                                  // would add in arrival order)
-    TreeTab& Tm = *reinterpret_cast<TreeTab*>(s_dyn);
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(Tt);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(s_dyn);
-        for (int i = threadIdx.x; i < (int)(sizeof(TreeTab) / 4); i += blockDim.x) dst[i] = src[i];
-        for (int i = threadIdx.x; i < TWAVES_MAX * NSTAT; i += blockDim.x) (&s_stat[0][0])[i] = 0.f;
-    }
-    __syncthreads();
-    const TreeTab& T = Tm;
-    const int nwaves = blockDim.x >> 6, tepb = TEPW * nwaves;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ew = lane / TG, c = lane & (TG - 1);   // ew: the env of the wave
-    if (wave == nwaves - 1) stats_fold_previous(P, sq, lane);   // the previous launch's episode statistics (and its ticket)
-    const TreeOff o = tree_offsets(T.nb, T.nlc, T.nchain, T.nsph);
-    const int thalf = tree_half_words(o.total);
-    float* const wsw = s_dyn + sizeof(TreeTab) / 4 + (size_t)wave * 2 * thalf;
-    const int ei = (ew / TEH) * thalf + (ew % TEH);   // (TW: the lane's offset into its half's block)
-    const size_t N = (size_t)P.N;
-    const int grp = step_group();   // (XCD-aware: grx_kernels.hip)
-    const int e_raw = grp * tepb + wave * TEPW + ew;
-    const bool act = e_raw < P.N;
-    const int e = act ? e_raw : P.N - 1;
-    const bool lead = c == 0, actl = act && lead;
-    const int nd = T.nd;
-    const uint32_t genv = (uint32_t)(P.env_offset + e), step = (uint32_t)common_step;
-    const int nh = P.nh, nobs = 9 + 3 * nd, npri = P.num_pri_obs;
-    const float dtp = P.sim_dt * (float)P.decimation;
-    // ---- load the state: the base in every lane of the group, a chain's joints by its lane
-    TreeEnv E;
-    E.B.pos = v3(P.root[e], P.root[N + e], P.root[2 * N + e]);
-    E.B.qx = P.root[3 * N + e]; E.B.qy = P.root[4 * N + e]; E.B.qz = P.root[5 * N + e]; E.B.qw = P.root[6 * N + e];
-    E.B.vel = v3(P.root[7 * N + e], P.root[8 * N + e], P.root[9 * N + e]);
-    E.B.ang = v3(P.root[10 * N + e], P.root[11 * N + e], P.root[12 * N + e]);
-    E.base_m = P.base_m[e];
-    E.base_c = v3(P.base_c[e], P.base_c[N + e], P.base_c[2 * N + e]);
-    E.base_I = S3{P.base_I[e], P.base_I[N + e], P.base_I[2 * N + e], P.base_I[3 * N + e], P.base_I[4 * N + e], P.base_I[5 * N + e]};
-    E.mu = 0.5f * (P.terrain_friction + P.friction[e]);
-    E.om_e = 1.0f - 0.5f * (P.terrain_restitution + P.restitution[e]);
-    E.hmax = 0.f;
-    if (HF) {
-        int ci = min(max((int)((E.B.pos.x + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_rows - 1);
-        int cj = min(max((int)((E.B.pos.y + P.border_size) / (P.horizontal_scale * (float)GRX_COARSE)), 0), P.coarse_cols - 1);
-        E.hmax = P.coarse_max[(size_t)ci * P.coarse_cols + cj];
-    }
-    TreeRegs G;
-    const float *const qcol = P.q + e, *const qdcol = P.qd + e, *const lacol = P.last_actions + e, *const mscol = P.motor_strength + e;   // (per-lane column bases: the ten unrolled levels below each re-fetched the four pointers from the parameter block)
-    TreeChain CH;
-    CH.first = T.first[c]; CH.last = T.last[c]; CH.hangp = 0; CH.hcmask = 0u;
-    const int nstep = __builtin_amdgcn_readfirstlane(T.nstep);
-#pragma unroll
-    for (int g = 0; g < TNG; ++g) {
-        const int b = g < nstep ? (int)T.sched[c][g] : -1;
-        G.sb[g] = b;
-        G.q[g] = 0.f; G.qd[g] = 0.f; G.Sa[g] = v3(0.f, 0.f, 0.f);
-        if (b >= 0) {
-            const int j = b - 1;
-            G.q[g] = qcol[(size_t)j * N]; G.qd[g] = qdcol[(size_t)j * N];
-            TW(TBO(b) + T_Q) = G.q[g]; TW(TBO(b) + T_QD) = G.qd[g];   // (the joint-local phase reads them from the row)
-            if (g == CH.first) CH.hangp = T.body[b].parent;
-            if (T.body[b].nhc > 0) CH.hcmask |= 1u << g;
-            const float a = actions_in ? actions_in[(size_t)e * nd + j] : 0.f;
-            TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j) = fminf(fmaxf(a, T.dof[j].amin), T.dof[j].amax);   // clip_actions (legged_robot_fftai.py:171-177)
-            TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j) = lacol[(size_t)j * N];
-            TW(o.dof + TD_STR * GRX_MAX_DOFS + j) = mscol[(size_t)j * N];
-        }
-    }
-    if (c < 8) {   // 8 anchor slots x (x, y, approach speed): one slot per lane (of the group's first eight)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) TW(o.an + c * 3 + k) = P.anchors[(size_t)(c * 3 + k) * N + e];
-    }
-    tree_fence();
-    // ---- during_physics_step (legged_robot_fftai.py:51-88)
-    float avg_force[2] = {0.f, 0.f};
-    V3 avg_speed[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};
-    V3 avg_rpy[2] = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};   // avg_feet_speed_rpy (legged_robot_fftai.py:81, 88)
-#ifdef GRX_PROFILE_SECTIONS
-    long long tt_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tt_prev = clock64();   // (8..: finer stamps inside the passes, slots 20.. of the block's row)
-    const long long tt_begin = tt_prev;
-#define TT(i) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = clock64(); tt_acc[i] += t_ - tt_prev; tt_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define TT(i) do {} while (0)
-#endif
-    if (DBG) {
-        for (int i = c; i < T.nlc * 3; i += TG) TW(o.lf + i) = 0.f;
-        tree_fence();
-    }
-    for (int deci = 0; deci < (DBG ? 0 : P.decimation); ++deci) {
-        TT(7);
-        asm volatile("" ::: "memory");   // (keeps the loop-invariant table reads of the unrolled passes in LDS: hoisted, they would spill)
-        for (int i = c; i < T.nlc * 3; i += TG) TW(o.lf + i) = 0.f;
-        if (c < 6) TW(o.misc + 8 + c) = 0.f;
-        tree_fence();
-        const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
-        tree_joint_phase<false>(P, T, wsw, ei, c, o, (float)deci < delay, P.last_dof_vel + e);
-        TT(8);
-        tree_outward<false>(P, T, wsw, ei, c, o, E, R0, CH, nstep, G);
-        TT(9);
-        {
-            const TreeContactPre pre0 = tree_contact_probe<HF>(P, T, wsw, ei, c, o, E, R0, 0);   // (the terrain gathers fly behind the bias forces)
-            TT(10);
-            tree_bias_all(T, wsw, ei, c);
-            TT(0);
-            tree_contacts<HF>(P, T, wsw, ei, c, o, E, R0, pre0);
-        }
-        TT(1);
-        // base: rigid lump (randomised per env); the terrain wrench on its own shapes was left in o.misc by the contact pass
-        S3 Ab; V3 h0;
-        rigid_inertia(R0, rot(R0, E.base_c), E.base_m, E.base_I, Ab, h0);
-        V3 pa0, pl0;
-        rigid_bias(R0, rot(R0, E.base_c), E.base_m, E.base_I, E.B.ang, E.B.vel, pa0, pl0);
-        pa0 = pa0 + tw_v3(wsw, ei, o.misc + 8); pl0 = pl0 + tw_v3(wsw, ei, o.misc + 11);
-        tree_fence();
-        TT(2);
-        if (P.self_collisions) tree_self_collision(P, T, wsw, ei, c, o, E, R0, pa0, pl0);
-        TT(3);
-        tree_rigid_inertias(T, wsw, ei, c);
-        TT(11);
-        tree_inward(P, T, wsw, ei, c, o, CH, nstep, G);
-        TT(4);
-        // ---- base: the chains that hang from it, in table order; [A B; B^T D][alpha; acc] = -[pa; pl]
-        S3 Db = {E.base_m, 0.f, 0.f, E.base_m, 0.f, E.base_m};
-        M3 Bb = {0.f, -h0.z, h0.y, h0.z, 0.f, -h0.x, -h0.y, h0.x, 0.f};
-        for (int k = 0; k < T.nh0; ++k) tree_add_up(wsw, ei, o.up + T.heads0[k] * T_UPW, Ab, Bb, Db, pa0, pl0);
-        const S3 Di = inv(Db);
-        const V3 b0 = v3(Bb.a00, Bb.a01, Bb.a02), b1 = v3(Bb.a10, Bb.a11, Bb.a12), b2 = v3(Bb.a20, Bb.a21, Bb.a22);
-        const V3 d0 = mul(Di, b0), d1 = mul(Di, b1), d2 = mul(Di, b2);
-        const S3 Sc = {Ab.xx - dot(b0, d0), Ab.xy - dot(b0, d1), Ab.xz - dot(b0, d2), Ab.yy - dot(b1, d1), Ab.yz - dot(b1, d2), Ab.zz - dot(b2, d2)};
-        const V3 alpha = mul(inv(Sc), mul(Bb, mul(Di, pl0)) - pa0);
-        const V3 acc = neg(mul(Di, pl0 + mulT(Bb, alpha)));
-        TT(5);
-        tree_accel(P, T, wsw, ei, c, alpha, acc, CH, nstep, G);
-        TT(6);
-        {   // integrate the base (semi-implicit Euler), every lane of the group alike
-            const float dt = P.sim_dt;
-            GenBase& B = E.B;
-            const V3 lin = acc + cross(B.ang, B.vel);
-            B.vel = v3(B.vel.x + (lin.x + P.gravity[0]) * dt, B.vel.y + (lin.y + P.gravity[1]) * dt, B.vel.z + (lin.z + P.gravity[2]) * dt);
-            B.ang = fma3(alpha, dt, B.ang);
-            B.pos = fma3(B.vel, dt, B.pos);
-            const float hx = 0.5f * dt * B.ang.x, hy = 0.5f * dt * B.ang.y, hz = 0.5f * dt * B.ang.z;
-            const float x = B.qx, y = B.qy, z = B.qz, ww = B.qw;
-            const float nx = x + hx * ww + hy * z - hz * y, ny = y - hx * z + hy * ww + hz * x;
-            const float nz = z + hx * y - hy * x + hz * ww, nw = ww - hx * x - hy * y - hz * z;
-            const float n = grx_rsq(nx * nx + ny * ny + nz * nz + nw * nw);
-            B.qx = nx * n; B.qy = ny * n; B.qz = nz * n; B.qw = nw * n;
-        }
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            if (deci > 0) {
-                const V3 fv = tw_v3(wsw, ei, o.misc + f * 3);
-                avg_speed[f] = v3(avg_speed[f].x + fabsf(fv.x), avg_speed[f].y + fabsf(fv.y), avg_speed[f].z + fabsf(fv.z));
-                const V3 fw = tw_v3(wsw, ei, TBO(T.foot_body[f]) + T_W);   // (the walk's: BEFORE this sub-step's integration, like fv)
-                avg_rpy[f] = v3(avg_rpy[f].x + fabsf(fw.x), avg_rpy[f].y + fabsf(fw.y), avg_rpy[f].z + fabsf(fw.z));
-            }
-            const V3 F = tw_v3(wsw, ei, o.lf + T.foot_link[f] * 3);
-            avg_force[f] += grx_sqrt(dot(F, F));
-        }
-    }
-#ifdef GRX_PROFILE_SECTIONS
-    const long long tt_phys = clock64() - tt_begin;
-    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 8] = tt_phys;
-#endif
-    // ---- what only the env pipeline behind the sub-steps reads is requested HERE (round 6: loaded at the kernel's start, these ~17 values sat in
-    // registers through all ten sub-steps of a kernel that needs every one of its 512); the final-frames walk below hides the latency
-    EnvAux ea;
-    ea.cmd[0] = P.commands[e]; ea.cmd[1] = P.commands[N + e]; ea.cmd[2] = P.commands[2 * N + e];
-    ea.origin[0] = P.origins[e]; ea.origin[1] = P.origins[N + e]; ea.origin[2] = P.origins[2 * N + e];
-    ea.level = P.levels[e]; ea.type = P.types[e];
-    float air_time[2] = {P.air_time[e], P.air_time[N + e]}, land_time[2] = {P.land_time[e], P.land_time[N + e]};
-    bool contact_last[2] = {P.feet_contact[e] != 0, P.feet_contact[N + e] != 0};
-    const float bho_stale = P.base_heights_offset[e];
-    long long ep_len = P.ep_len[e];
-    // (the running episode sums too, AHEAD of the kernel's first global stores: vmcnt counts loads and stores in one order, so a load requested
-    //  behind the contact_forces / height rows waits for those stores to be acknowledged by memory -- 12 k cycles of this section, measured)
-    // The reward scales, ONE per lane (lane t holds term t's), and the set of active terms as one scalar mask: the three loops over the terms
-    // below asked the parameter block for scale[t] -- and for the episode_sums pointer again -- behind a branch per term: ~100 dependent
-    // scalar-load round trips, 12 k cycles of this kernel's tail (from the ISA: s_load_dword / s_waitcnt lgkmcnt(0) / branch / s_load_dwordx2 ...).
-    static_assert(NT <= 64, "a reward term per lane");
-    const float scale_v = P.reward_scale_dt[lane < NT ? lane : 0];
-    const unsigned long long term_on = __ballot(lane < NT && scale_v != 0.f);
-    auto scale_of = [&](int t) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scale_v), t)); };
-    float* const es_col = P.episode_sums + e;
-    float es_old[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) es_old[t] = ((term_on >> t) & 1ull) ? es_col[(size_t)t * N] : 0.f;
-    // ---- refresh_rigid_body_state_tensor after the last sub-step: frames of the final state
-    {
-        const R3 R0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
-        tree_joint_phase<true>(P, T, wsw, ei, c, o, false, nullptr);
-        tree_outward<true>(P, T, wsw, ei, c, o, E, R0, CH, nstep, G);
-    }
-    if (P.publish_rbs) {   // GRX_T_RIGID_BODY_STATES (legged_robot.py:113,134): every URDF link frame of that state, the links go round the lanes
-        const LinkTab& LT = *P.link_tab;
-        const R3 Rb0 = quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw);
-        for (int l = c; l < LT.n; l += TG) {
-            const int b = LT.body[l];
-            const R3 Rb = b == 0 ? Rb0 : tw_R(wsw, ei, TBO(b) + T_R);
-            const V3 rho_b = b == 0 ? v3(0.f, 0.f, 0.f) : tw_v3(wsw, ei, TBO(b) + T_RHO);
-            const V3 w_b = b == 0 ? E.B.ang : tw_v3(wsw, ei, TBO(b) + T_W), v_b = b == 0 ? E.B.vel : tw_v3(wsw, ei, TBO(b) + T_V);
-            const V3 r_ = rho_b + rot(Rb, v3(LT.pos[l][0], LT.pos[l][1], LT.pos[l][2]));
-            const V3 vl = v_b + cross(w_b, r_);
-            // R_link = R_body * (link -> body), row-major entries m[i][k]
-            float m[9];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const V3 col = rot(Rb, v3(LT.rot[l][k], LT.rot[l][3 + k], LT.rot[l][6 + k]));   // column k of the link rotation, in world axes
-                m[k] = col.x; m[3 + k] = col.y; m[6 + k] = col.z;
-            }
-            float qx, qy, qz, qw;   // largest-component form (the oracle's m3_to_quat)
-            const float t0 = 1 + m[0] - m[4] - m[8], t1 = 1 - m[0] + m[4] - m[8], t2 = 1 - m[0] - m[4] + m[8], t3 = 1 + m[0] + m[4] + m[8];
-            if (t3 >= t0 && t3 >= t1 && t3 >= t2) { qx = m[7] - m[5]; qy = m[2] - m[6]; qz = m[3] - m[1]; qw = t3; }
-            else if (t0 >= t1 && t0 >= t2) { qx = t0; qy = m[1] + m[3]; qz = m[2] + m[6]; qw = m[7] - m[5]; }
-            else if (t1 >= t2) { qx = m[1] + m[3]; qy = t1; qz = m[5] + m[7]; qw = m[2] - m[6]; }
-            else { qx = m[2] + m[6]; qy = m[5] + m[7]; qz = t2; qw = m[3] - m[1]; }
-            const float qn = grx_rsq(qx * qx + qy * qy + qz * qz + qw * qw);
-            if (act) {
-                float* o_ = P.rbs + (size_t)(l * 13) * N + e;
-                o_[0] = E.B.pos.x + r_.x; o_[N] = E.B.pos.y + r_.y; o_[2 * N] = E.B.pos.z + r_.z;
-                o_[3 * N] = qx * qn; o_[4 * N] = qy * qn; o_[5 * N] = qz * qn; o_[6 * N] = qw * qn;
-                o_[7 * N] = vl.x; o_[8 * N] = vl.y; o_[9 * N] = vl.z;
-                o_[10 * N] = w_b.x; o_[11 * N] = w_b.y; o_[12 * N] = w_b.z;
-            }
-        }
-    }
-    V3 fpos[2], fvel[2], foot_force[2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int b = T.foot_body[f];
-        const R3 R = tw_R(wsw, ei, TBO(b) + T_R);
-        const V3 fr = tw_v3(wsw, ei, TBO(b) + T_RHO) + rot(R, v3(T.foot_pos[f][0], T.foot_pos[f][1], T.foot_pos[f][2]));
-        fpos[f] = E.B.pos + fr;
-        fvel[f] = tw_v3(wsw, ei, TBO(b) + T_V) + cross(tw_v3(wsw, ei, TBO(b) + T_W), fr);
-        avg_speed[f] = v3((avg_speed[f].x + fabsf(fvel[f].x)) / (float)P.decimation, (avg_speed[f].y + fabsf(fvel[f].y)) / (float)P.decimation,
-                          (avg_speed[f].z + fabsf(fvel[f].z)) / (float)P.decimation);
-        avg_force[f] /= (float)P.decimation;
-        {
-            const V3 fw = tw_v3(wsw, ei, TBO(b) + T_W);
-            avg_rpy[f] = v3((avg_rpy[f].x + fabsf(fw.x)) / (float)P.decimation, (avg_rpy[f].y + fabsf(fw.y)) / (float)P.decimation, (avg_rpy[f].z + fabsf(fw.z)) / (float)P.decimation);
-        }
-        foot_force[f] = tw_v3(wsw, ei, o.lf + T.foot_link[f] * 3);
-    }
-    bool dbg_apply_reset = true;
-    if (DBG) {   // injected "physics results" (rows of DbgRow, [row][N])
-        const float* d = dbg + e;
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            foot_force[f] = v3(d[(size_t)(DBG_FEET_FORCE + f * 3) * N], d[(size_t)(DBG_FEET_FORCE + f * 3 + 1) * N], d[(size_t)(DBG_FEET_FORCE + f * 3 + 2) * N]);
-            fpos[f] = v3(d[(size_t)(DBG_FEET_POS + f * 3) * N], d[(size_t)(DBG_FEET_POS + f * 3 + 1) * N], d[(size_t)(DBG_FEET_POS + f * 3 + 2) * N]);
-            avg_force[f] = d[(size_t)(DBG_AVG_FORCE + f) * N];
-            avg_speed[f] = v3(d[(size_t)(DBG_AVG_SPEED + f * 3) * N], d[(size_t)(DBG_AVG_SPEED + f * 3 + 1) * N], d[(size_t)(DBG_AVG_SPEED + f * 3 + 2) * N]);
-        }
-#pragma unroll
-        for (int g = 0; g < TNG; ++g)
-            if (G.sb[g] >= 0) TW(TBO(G.sb[g]) + T_TAU) = d[(size_t)(DBG_TORQUES + G.sb[g] - 1) * N];
-        dbg_apply_reset = d[(size_t)DBG_APPLY_RESET * N] != 0.f;
-        tree_fence();
-    }
-    // termination / collision from the per-link net forces of the LAST sub-step (legged_robot.py:336-353); contact_forces rows
-    bool term_contact = false;
-    float pen_count = 0.f;
-    for (int L = 0; L < T.nlc; ++L) {
-        const V3 F = tw_v3(wsw, ei, o.lf + L * 3);
-        const float n2 = dot(F, F);
-        if ((T.link_flags[L] & GRX_SPH_TERMINATE) && n2 > P.termination_force * P.termination_force) term_contact = true;
-        if ((T.link_flags[L] & GRX_SPH_PENALISE) && n2 > 0.01f) pen_count += 1.f;
-        if (act && (L & (TG - 1)) == c) {
-            float* cf = P.contact_forces + (size_t)(T.link_urdf[L] * 3) * N + e;
-            cf[0] = F.x; cf[N] = F.y; cf[2 * N] = F.z;
-        }
-    }
-    if (DBG) { term_contact = dbg[(size_t)DBG_TERM_CONTACT * N + e] != 0.f; pen_count = 0.f; }
-    float torso_g[2] = {0.f, 0.f}, fore_g[2] = {0.f, 0.f};
-    if (T.torso_body >= 0) {
-        const R3 R = T.torso_body == 0 ? quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw) : tw_R(wsw, ei, TBO(T.torso_body) + T_R);
-        torso_g[0] = -(R.cx.z * T.torso_rot[0] + R.cy.z * T.torso_rot[3] + R.cz.z * T.torso_rot[6]);
-        torso_g[1] = -(R.cx.z * T.torso_rot[1] + R.cy.z * T.torso_rot[4] + R.cz.z * T.torso_rot[7]);
-    }
-    if (T.forehead_body >= 0) {
-        const R3 R = T.forehead_body == 0 ? quat_to_R(E.B.qx, E.B.qy, E.B.qz, E.B.qw) : tw_R(wsw, ei, TBO(T.forehead_body) + T_R);
-        fore_g[0] = -(R.cx.z * T.forehead_rot[0] + R.cy.z * T.forehead_rot[3] + R.cz.z * T.forehead_rot[6]);
-        fore_g[1] = -(R.cx.z * T.forehead_rot[1] + R.cy.z * T.forehead_rot[4] + R.cz.z * T.forehead_rot[7]);
-    }
-#ifdef GRX_PROFILE_SECTIONS
-    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 10] = clock64() - tt_begin;
-#endif
-    // ---- post_physics_step (legged_robot.py:269-334)
-    GenBase& B = E.B;
-    ep_len += 1;
-    const V3 qv = v3(B.qx, B.qy, B.qz);
-    const V3 blv = quat_rotate_inverse(qv, B.qw, B.vel), bav = quat_rotate_inverse(qv, B.qw, B.ang);
-    const V3 pg = quat_rotate_inverse(qv, B.qw, v3(0.f, 0.f, -1.f));
-    if (P.resample_command_interval > 0 && ((uint32_t)ep_len % (uint32_t)P.resample_command_interval) == 0)
-        resample_commands(P, genv, step, GRX_RNG_CMD_TIME, ea.cmd);
-    if (P.heading_command) ea.cmd[2] = heading_yaw_command(P, qv, B.qw);   // legged_robot.py:320-326
-    float* heights = P.heights + e;   // raw measured heights: the scan's points go round the group's lanes
-    float hsum = 0.f;
-    // the lane's points of the scan (k = c, c + TG, ...): unrolled over the most a lane can hold, so that the points' table reads and raster
-    // gathers are in flight together (a rolled loop made every point two exposed memory round trips), and kept in registers for the
-    // observation block below (it used to read them back from memory)
-    constexpr int HPL = (GRX_MAX_HEIGHT_POINTS + TG - 1) / TG;
-    float hraw[HPL];
-#pragma unroll
-    for (int i = 0; i < HPL; ++i) hraw[i] = 0.f;
-    if (HF && P.measure_heights) {
-        const float yaw_n = fmaxf(sqrtf(B.qz * B.qz + B.qw * B.qw), 1e-9f);
-        const float yz = B.qz / yaw_n, yw = B.qw / yaw_n;
-        // (a lane's points are sampled WITHOUT a branch, the index clamped -- as the fused kernels' height_scan_share does: under `if (k < nh)`
-        //  every point re-fetched the raster's parameters from the parameter block behind its own branch, eight dependent scalar round trips)
-        const bool pub_h = act && P.publish_heights;
-#pragma unroll
-        for (int i = 0; i < HPL; ++i) hraw[i] = height_sample(P, *P.tables, yz, yw, B.pos, min(c + i * TG, nh - 1));
-#pragma unroll
-        for (int i = 0; i < HPL; ++i) {   // (summed in the order of the rolled loop)
-            const int k = c + i * TG;
-            if (k < nh) { if (pub_h) heights[(size_t)k * N] = hraw[i]; hsum += hraw[i]; } else hraw[i] = 0.f;
-        }
-        hsum = grp_sum(hsum);
-    } else {
-        const bool pub_h = act && P.publish_heights;
-#pragma unroll
-        for (int i = 0; i < HPL; ++i) { const int k = c + i * TG; if (k < nh && pub_h) heights[(size_t)k * N] = 0.f; }
-    }
-    if (P.push_robots && P.push_interval > 0 && (step % (uint32_t)P.push_interval) == 0) {
-        if (P.stash_pre_reset && actl) { P.pre_push_vel[e] = B.vel.x; P.pre_push_vel[(size_t)N + e] = B.vel.y; }   // (grx_refresh: link frames of the state BEFORE the push)
-        B.vel.x = urand(P, genv, step, GRX_RNG_PUSH, 0, -P.max_push_vel_xy, P.max_push_vel_xy);
-        B.vel.y = urand(P, genv, step, GRX_RNG_PUSH, 1, -P.max_push_vel_xy, P.max_push_vel_xy);
-    }
-    // feet timers (legged_robot_fftai.py:108-133)
-    bool contact[2], contact_filt[2], first_contact[2];
-    float feet_height[2];
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        contact[f] = foot_force[f].z > 1.0f;
-        contact_filt[f] = contact[f] || contact_last[f];
-        contact_last[f] = contact[f];
-        first_contact[f] = (air_time[f] > 0.f) && contact_filt[f];
-        air_time[f] += dtp;
-        feet_height[f] = nh > 0 ? (fpos[f].z * (float)nh - hsum) / (float)nh : fpos[f].z;
-        land_time[f] = (land_time[f] + dtp) * (contact[f] ? 1.f : 0.f);
-    }
-    bool reset = term_contact || (fabsf(pg.z) < P.termination_gravity_z);
-    const bool time_out = (float)ep_len > P.max_episode_length;
-    reset = reset || time_out;
-#ifdef GRX_PROFILE_SECTIONS
-    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 11] = clock64() - tt_begin;
-#endif
-    // ---- compute_reward (legged_robot.py:355-375; terms legged_robot_fftai.py:180-352, gr1t1.py:338-589): a lane sums over
-    // its chain's joints, the group adds up
-    float r[NT];
-    // (the running episode sums were requested in one batch behind the sub-steps: read inside the loop that folds them, behind its wave-uniform
-    //  branches, each of the 36 loads was an exposed round trip: 27 k cycles, gpu_tree_sections.py)
-    // The joint terms go round the group's lanes BY JOINT (two rounds of 16 lanes, four of 8) instead of riding on the ten depth levels of
-    // the lane's chain (a wave executes all ten whatever its lanes hold): the chains' owners publish q, qd in two slots of the body's row
-    // that are dead behind the sub-steps.
-    enum { T_QPUB = T_PL + 1, T_QDPUB = T_PL + 2 };
-#pragma unroll
-    for (int g = 0; g < TNG; ++g)
-        if (G.sb[g] >= 0) { TW(TBO(G.sb[g]) + T_QPUB) = G.q[g]; TW(TBO(G.sb[g]) + T_QDPUB) = G.qd[g]; }
-    tree_fence();
-    {
-        const float as = P.action_scale, H = P.swing_feet_height_target, Tt_ = P.feet_air_time_target;
-        const GRX_AS4 float* sg = P.reward_sigma;
-        float s2 = 0.f;   // DBG: the injected last_last_actions (otherwise last_last_actions == last_actions, legged_robot_fftai.py:94)
-        float s1 = 0.f, s3 = 0.f, sacc = 0.f, stor = 0.f, svel = 0.f, spose = 0.f, sla = 0.f, slp = 0.f, slt = 0.f, slv = 0.f, shy = 0.f;
-        float tor_hr = 0.f, vel_kn = 0.f, ank[2] = {0.f, 0.f};
-        for (int j = c; j < nd; j += TG) {
-            const TreeDof& td = T.dof[j];
-            const float ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j), al = TW(o.dof + TD_ALAST * GRX_MAX_DOFS + j), tj = TW(TBO(j + 1) + T_TAU);
-            const float qj = TW(TBO(j + 1) + T_QPUB), qdj = TW(TBO(j + 1) + T_QDPUB);
-            const uint32_t bit = 1u << j;
-            s1 += fabsf((al - ac) * as);
-            if (DBG) s2 += fabsf((al - ac) * as - (dbg[(size_t)(DBG_LAST_LAST_ACTIONS + j) * N + e] - al) * as);
-            if (P.knee_mask & bit) { s3 += fabsf((ac - al) * as); vel_kn += fabsf(qdj); }
-            sacc += fabsf((qdj - P.last_dof_vel[(size_t)j * N + e]) / dtp);
-            stor += fabsf(tj);
-            svel += fabsf(qdj);
-            const float po = fabsf(qj - td.q0);
-            spose += po;
-            if (P.hip_yaw_mask & bit) shy += po;
-            if (P.hip_roll_mask & bit) tor_hr += fabsf(tj);
-            if (P.ankle_left_mask & bit) ank[0] += fabsf(tj);
-            if (P.ankle_right_mask & bit) ank[1] += fabsf(tj);
-            const float a = ac * as;
-            float oa = 0.f, op = 0.f;
-            if (a - td.slo < 0.f) oa += -(a - td.slo);
-            if (a - td.shi > 0.f) oa += (a - td.shi);
-            sla += oa * oa;
-            if (qj - td.slo < 0.f) op += -(qj - td.slo);
-            if (qj - td.shi > 0.f) op += (qj - td.shi);
-            slp += fabsf(op);
-            slv += fminf(fmaxf(fabsf(qdj) - td.vlim * P.soft_dof_vel_limit, 0.f), 1.f);
-            slt += fmaxf(fabsf(tj) - td.effort * P.soft_torque_limit, 0.f);
-        }
-#ifdef GRX_PROFILE_SECTIONS
-        if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 14] = clock64() - tt_begin;
-#endif
-        s2 = DBG ? grp_sum(s2) : 0.f;
-        s1 = grp_sum(s1); s3 = grp_sum(s3); sacc = grp_sum(sacc); stor = grp_sum(stor); svel = grp_sum(svel); spose = grp_sum(spose);
-        sla = grp_sum(sla); slp = grp_sum(slp); slt = grp_sum(slt); slv = grp_sum(slv); shy = grp_sum(shy);
-        tor_hr = grp_sum(tor_hr); vel_kn = grp_sum(vel_kn); ank[0] = grp_sum(ank[0]); ank[1] = grp_sum(ank[1]);
-#ifdef GRX_PROFILE_SECTIONS
-        if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 15] = clock64() - tt_begin;
-#endif
-        const float hmin = fminf(feet_height[0], feet_height[1]);
-        float lift = 0.f, af = 0.f, ah = 0.f, at = 0.f, lt = 0.f, exy = 0.f, ez = 0.f, stum = 0.f, ncontact = 0.f;
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const float h = feet_height[f];
-            lift += ank[f] * fabsf(h) * (h > H * 0.5f ? 1.f : 0.f);
-            const float mid = fabsf(air_time[f] - Tt_ * 0.5f);
-            af += mid * avg_force[f];
-            ah += mid * fabsf(h - hmin - H);
-            at += expf(sg[GRX_REW_FEET_AIR_TIME] * fabsf(air_time[f] - Tt_)) * (first_contact[f] ? 1.f : 0.f);
-            const float le = (land_time[f] - P.feet_land_time_max) * (land_time[f] > P.feet_land_time_max ? 1.f : 0.f);
-            lt += 1.f - expf(sg[GRX_REW_FEET_LAND_TIME] * le);
-            const float close = fabsf(h - H * 0.25f) * (h < H * 0.25f ? 1.f : 0.f) / (H * 0.25f);
-            exy += sqrtf(avg_speed[f].x * avg_speed[f].x + avg_speed[f].y * avg_speed[f].y) * close;
-            const float far = fabsf(h - H * 3.f / 4.f) * (h > H * 3.f / 4.f ? 1.f : 0.f) / (H * 1.f / 4.f);
-            ez += fabsf(avg_speed[f].z) * far;
-            const V3 F = foot_force[f];
-            float serr = sqrtf(F.x * F.x + F.y * F.y) - P.feet_stumble_ratio * fabsf(F.z);
-            serr = serr * (serr > 0.f ? 1.f : 0.f);
-            stum += 1.f - expf(sg[GRX_REW_FEET_STUMBLE] * serr);
-            ncontact += contact[f] ? 1.f : 0.f;
-        }
-        const float cmd_n = sqrtf(ea.cmd[0] * ea.cmd[0] + ea.cmd[1] * ea.cmd[1]);
-        const float moving = cmd_n > 0.1f ? 1.f : 0.f;
-        r[GRX_REW_ACTION_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF] * s1);
-        r[GRX_REW_ACTION_DIFF_DIFF] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_DIFF] * (DBG ? s2 : s1));   // last_last_actions == last_actions
-        r[GRX_REW_ACTION_DIFF_KNEE] = 1.f - expf(sg[GRX_REW_ACTION_DIFF_KNEE] * s3);
-        r[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_PITCH] * fabsf(0.f - bav.y));
-        r[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_ROLL] * fabsf(0.f - bav.x));
-        r[GRX_REW_CMD_DIFF_ANG_VEL_YAW] = expf(sg[GRX_REW_CMD_DIFF_ANG_VEL_YAW] * fabsf(ea.cmd[2] - bav.z));
-        r[GRX_REW_CMD_DIFF_BASE_HEIGHT] = expf(sg[GRX_REW_CMD_DIFF_BASE_HEIGHT] * (fabsf(bho_stale) * (bho_stale < 0.f ? 1.f : 0.f)));
-        r[GRX_REW_CMD_DIFF_BASE_ORIENT] = expf(sg[GRX_REW_CMD_DIFF_BASE_ORIENT] * (fabsf(pg.x) + fabsf(pg.y)));
-        r[GRX_REW_CMD_DIFF_TORSO_ORIENT] = T.torso_body >= 0 ? expf(sg[GRX_REW_CMD_DIFF_TORSO_ORIENT] * (fabsf(torso_g[0]) + fabsf(torso_g[1]))) : 0.f;
-        r[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] = T.forehead_body >= 0 ? expf(sg[GRX_REW_CMD_DIFF_FOREHEAD_ORIENT] * (fabsf(fore_g[0]) + fabsf(fore_g[1]))) : 0.f;
-        r[GRX_REW_CMD_DIFF_LIN_VEL_X] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_X] * fabsf(ea.cmd[0] - blv.x));
-        r[GRX_REW_CMD_DIFF_LIN_VEL_Y] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Y] * fabsf(ea.cmd[1] - blv.y));
-        r[GRX_REW_CMD_DIFF_LIN_VEL_Z] = expf(sg[GRX_REW_CMD_DIFF_LIN_VEL_Z] * fabsf(0.f - blv.z));
-        r[GRX_REW_COLLISION] = 1.f - expf(sg[GRX_REW_COLLISION] * pen_count);
-        r[GRX_REW_DOF_ACC_NEW] = 1.f - expf(sg[GRX_REW_DOF_ACC_NEW] * sacc);
-        r[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] = 1.f - expf(sg[GRX_REW_DOF_TOR_ANKLE_FEET_LIFT_UP] * lift);
-        r[GRX_REW_DOF_TOR_NEW] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW] * stor);
-        r[GRX_REW_DOF_TOR_NEW_HIP_ROLL] = 1.f - expf(sg[GRX_REW_DOF_TOR_NEW_HIP_ROLL] * tor_hr);
-        r[GRX_REW_DOF_VEL_NEW] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW] * svel);
-        r[GRX_REW_DOF_VEL_NEW_KNEE] = 1.f - expf(sg[GRX_REW_DOF_VEL_NEW_KNEE] * vel_kn);
-        r[GRX_REW_FEET_AIR_FORCE] = expf(sg[GRX_REW_FEET_AIR_FORCE] * af) * moving;
-        r[GRX_REW_FEET_AIR_HEIGHT] = expf(sg[GRX_REW_FEET_AIR_HEIGHT] * ah) * moving;
-        r[GRX_REW_FEET_AIR_TIME] = at * moving;
-        r[GRX_REW_FEET_LAND_TIME] = lt * moving;
-        r[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] = expf(sg[GRX_REW_FEET_SPEED_XY_CLOSE_TO_GROUND] * exy);
-        r[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] = expf(sg[GRX_REW_FEET_SPEED_Z_CLOSE_TO_HEIGHT_TARGET] * ez);
-        r[GRX_REW_FEET_STUMBLE] = stum;
-        r[GRX_REW_LIMITS_ACTIONS] = 1.f - expf(sg[GRX_REW_LIMITS_ACTIONS] * sla);
-        r[GRX_REW_LIMITS_DOF_POS] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_POS] * slp);
-        r[GRX_REW_LIMITS_DOF_TOR] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_TOR] * slt);
-        r[GRX_REW_LIMITS_DOF_VEL] = 1.f - expf(sg[GRX_REW_LIMITS_DOF_VEL] * slv);
-        r[GRX_REW_ON_THE_AIR] = ncontact == 0.f ? 1.f : 0.f;
-        r[GRX_REW_POSE_OFFSET] = expf(sg[GRX_REW_POSE_OFFSET] * spose);
-        r[GRX_REW_POSE_OFFSET_HIP_YAW] = 1.f - expf(sg[GRX_REW_POSE_OFFSET_HIP_YAW] * shy);
-        r[GRX_REW_STAND_STILL] = expf(sg[GRX_REW_STAND_STILL] * spose) * (cmd_n < 0.1f ? 1.f : 0.f);
-        r[GRX_REW_TERMINATION] = (reset && !time_out) ? 1.f : 0.f;
-    }
-#ifdef GRX_PROFILE_SECTIONS
-    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 16] = clock64() - tt_begin;
-#endif
-    float rew = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float sc_t = scale_of(t);
-        float rt = 0.f;
-        if (t != GRX_REW_TERMINATION && ((term_on >> t) & 1ull)) { rt = r[t] * sc_t; rew += rt; }
-        r[t] = rt;
-    }
-    if (P.only_positive_rewards) rew = fmaxf(rew, 0.f);
-    if ((term_on >> GRX_REW_TERMINATION) & 1ull) {
-        const float rt = r[GRX_REW_TERMINATION] = ((reset && !time_out) ? 1.f : 0.f) * scale_of(GRX_REW_TERMINATION);
-        rew += rt;
-    }
-    // episode sums (the group's first lane); finished episodes -> the block's statistics row (deterministic lane order)
-#ifdef GRX_PROFILE_SECTIONS
-    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 17] = clock64() - tt_begin;
-#endif
-    const unsigned long long reset_mask = __ballot(reset && actl);
-    const bool publish_debug = P.publish_debug != 0;
-    float* const rt_col = P.reward_terms + e;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float es = es_old[t] + r[t];
-        if (reset_mask) {   // the finished episodes' sums, added in lane order: the groups' first lanes through v_readlane (an LDS shuffle per
-            // finished env and term -- 36 dependent round trips per env -- was most of this section)
-            const int esm = __float_as_int((reset && actl) ? es : 0.f);
-            float acc_ = 0.f;
-#pragma unroll
-            for (int k = 0; k < TEPW; ++k) acc_ += __int_as_float(__builtin_amdgcn_readlane(esm, k * TG));
-            if (lane == 0) s_stat[wave][t] = acc_;   // (the wave's row was zeroed at the kernel's start and this is its only writer: no read-modify-write)
-        }
-        if (actl && ((term_on >> t) & 1ull)) {
-            es_col[(size_t)t * N] = (reset && dbg_apply_reset) ? 0.f : es;
-            if (publish_debug) rt_col[(size_t)t * N] = r[t];
-        }
-    }
-    if (lane == 0) s_stat[wave][NT] = (float)__popcll(reset_mask);
-#ifdef GRX_PROFILE_SECTIONS
-    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 12] = clock64() - tt_begin;
-#endif
-    // ---- reset_idx (masked, in-kernel): a chain's joints by its lane, the base in every lane (same counters, same values)
-    if (P.stash_pre_reset && reset && act) {   // on-demand tensors (grx_refresh) show the state BEFORE reset_idx: a chain's joints by its lane, the base by lane 0 of the group
-        const size_t n_ = (size_t)N;
-#pragma unroll
-        for (int g = 0; g < TNG; ++g)
-            if (G.sb[g] >= 0) { const int j = G.sb[g] - 1; P.pre_q[(size_t)j * n_ + e] = G.q[g]; P.pre_qd[(size_t)j * n_ + e] = G.qd[g]; }
-        if (c == 0) {
-            float* r_ = P.pre_root + e;
-            r_[0] = B.pos.x; r_[n_] = B.pos.y; r_[2 * n_] = B.pos.z; r_[3 * n_] = B.qx; r_[4 * n_] = B.qy; r_[5 * n_] = B.qz; r_[6 * n_] = B.qw;
-            r_[7 * n_] = B.vel.x; r_[8 * n_] = B.vel.y; r_[9 * n_] = B.vel.z; r_[10 * n_] = B.ang.x; r_[11 * n_] = B.ang.y; r_[12 * n_] = B.ang.z;
-        }
-    }
-    const bool reported_reset = reset;   // (the debug entry may report a reset without applying it)
-    if (DBG && !dbg_apply_reset) reset = false;
-    if (reset) {
-        if (P.curriculum && P.terrain_type != GRX_TERRAIN_PLANE) {
-            const float dx = B.pos.x - ea.origin[0], dy = B.pos.y - ea.origin[1];
-            const float dist = sqrtf(dx * dx + dy * dy);
-            const int up = dist > P.terrain_length * 0.5f;
-            const float cn = sqrtf(ea.cmd[0] * ea.cmd[0] + ea.cmd[1] * ea.cmd[1]);
-            const int down = (dist < cn * P.max_episode_length_s * 0.5f) && !up;
-            ea.level += up - down;
-            if (ea.level >= P.num_terrain_rows) {
-                const float u = grx_rand(P.seed, genv, step, GRX_RNG_CURRICULUM, 0);
-                ea.level = min((int)(u * (float)P.num_terrain_rows), P.num_terrain_rows - 1);
-            } else if (ea.level < 0)
-                ea.level = 0;
-            const float* og = P.terrain_origins + ((size_t)ea.level * P.num_terrain_cols + ea.type) * 3;
-            ea.origin[0] = og[0]; ea.origin[1] = og[1]; ea.origin[2] = og[2];
-        }
-#pragma unroll
-        for (int g = 0; g < TNG; ++g) {
-            if (G.sb[g] < 0) continue;
-            const int j = G.sb[g] - 1;
-            const float f_ = P.randomize_init_dof_pos ? urand(P, genv, step, GRX_RNG_RESET_DOF, (uint32_t)j, 0.5f, 1.5f) : 1.0f;
-            G.q[g] = f_ * T.dof[j].q0;
-            G.qd[g] = 0.f;
-        }
-        B.pos = v3(P.init_pos[0] + ea.origin[0], P.init_pos[1] + ea.origin[1], P.init_pos[2] + ea.origin[2]);
-        if (P.terrain_type != GRX_TERRAIN_PLANE) {
-            B.pos.x += urand(P, genv, step, GRX_RNG_RESET_ROOT, 0, -1.0f, 1.0f);
-            B.pos.y += urand(P, genv, step, GRX_RNG_RESET_ROOT, 1, -1.0f, 1.0f);
-        }
-        const float yaw = urand(P, genv, step, GRX_RNG_RESET_ROOT, 2, -6.283185307179586f, 6.283185307179586f);
-        float sy, cy;
-        sincosf(yaw * 0.5f, &sy, &cy);
-        B.qx = 0.f; B.qy = 0.f; B.qz = sy; B.qw = cy;
-        if (P.randomize_init_base_velocity) {
-            B.vel = v3(urand(P, genv, step, GRX_RNG_RESET_ROOT, 3, -0.5f, 0.5f), urand(P, genv, step, GRX_RNG_RESET_ROOT, 4, -0.5f, 0.5f),
-                       urand(P, genv, step, GRX_RNG_RESET_ROOT, 5, -0.5f, 0.5f));
-            B.ang = v3(urand(P, genv, step, GRX_RNG_RESET_ROOT, 6, -0.5f, 0.5f), urand(P, genv, step, GRX_RNG_RESET_ROOT, 7, -0.5f, 0.5f),
-                       urand(P, genv, step, GRX_RNG_RESET_ROOT, 8, -0.5f, 0.5f));
-        } else {
-            B.vel = v3(0.f, 0.f, 0.f);
-            B.ang = v3(0.f, 0.f, 0.f);
-        }
-        resample_commands(P, genv, step, GRX_RNG_CMD_RESET, ea.cmd);
-        if (c < 8) TW(o.an + c * 3 + 2) = 0.f;   // the lane's anchor slot
-        for (int f = 0; f < 2; ++f) { air_time[f] = 0.f; land_time[f] = 0.f; contact_last[f] = false; }
-        ep_len = 0;
-    }
-    {   // statistics row NT + 1: terrain levels after this step's curriculum moves (legged_robot.py:427-428)
-        const float ls = level_sum(ea.level, actl);
-        if (lane == 0) s_stat[wave][NT + 1] = ls;
-    }
-#ifdef GRX_PROFILE_SECTIONS
-    if (threadIdx.x == 0 && blockIdx.x < 64) P.prof[(size_t)blockIdx.x * GRX_PROF_SLOTS + 13] = clock64() - tt_begin;
-#endif
-    // ---- compute_observations (legged_robot_fftai.py:148-167, gr1t1.py:281-336)
-    float* obs = (obs_out ? obs_out : P.obs) + (size_t)e * nobs;
-    float* pri = (pri_out ? pri_out : P.pri_obs) + (size_t)e * npri;
-    const float clipo = P.clip_observations;
-    float bho = 0.f;
-    {
-        float sum = 0.f;
-        const float bht = P.base_height_target, osh = P.obs_scale_height;   // (fetched once, not behind every point's branch)
-        float* const prih = pri + nobs + 8;
-#pragma unroll
-        for (int i = 0; i < HPL; ++i) {
-            const int k = c + i * TG;
-            if (k < nh) {
-                float d = B.pos.z - bht - hraw[i];
-                d = fminf(fmaxf(d, -1.f), 1.f) * osh;
-                if (act) prih[k] = fminf(fmaxf(d * osh, -clipo), clipo);
-                sum += d;
-            }
-        }
-        sum = grp_sum(sum);
-        bho = nh > 0 ? sum / (float)nh : 0.f;
-    }
-    // observation noise: the env's Philox blocks -- 2 of the base stream, ceil(3 (nd / 2) / 4) per half of the dof range (the oracle's scheme:
-    // item i of a stream is word i & 3 of block i >> 2) -- computed ONCE, the blocks going round the group's lanes, and parked in the
-    // bias-force slots of bodies 1.. (dead behind the sub-steps).  (Round 4, from the section profile: one whole Philox block per
-    // observation ELEMENT, 30 per lane with the level loop unrolled, and an integer division to find the element's stream made this
-    // section 40 k cycles of a 650 k step.)
-#pragma unroll
-    for (int g = 0; g < TNG; ++g)   // q, qd after reset_idx, for the joint-parallel loop below
-        if (G.sb[g] >= 0) { TW(TBO(G.sb[g]) + T_QPUB) = G.q[g]; TW(TBO(G.sb[g]) + T_QDPUB) = G.qd[g]; }
-    tree_fence();
-    const int half_ = nd / 2, nblk_dof = (3 * half_ + 3) / 4, nblk = 2 + 2 * nblk_dof;
-    const bool own_noise = P.add_noise && !noise_in, noise_lds = own_noise && nblk <= T.nb - 1;
-    if (noise_lds) {
-        for (int k = c; k < nblk; k += TG) {
-            const uint32_t stream = k < 2 ? (uint32_t)GRX_RNG_NOISE : (k < 2 + nblk_dof ? (uint32_t)GRX_RNG_NOISE_DOF_L : (uint32_t)GRX_RNG_NOISE_DOF_R);
-            const uint32_t blk = k < 2 ? (uint32_t)k : (uint32_t)(k < 2 + nblk_dof ? k - 2 : k - 2 - nblk_dof);
-            const U4 o4 = grx_philox4x32_10(genv, step, stream, blk, (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
-            const int wa = TBO(k + 1) + T_PA;
-            TW(wa) = __uint_as_float(o4.x); TW(wa + 1) = __uint_as_float(o4.y); TW(wa + 2) = __uint_as_float(o4.z); TW(wa + 3) = __uint_as_float(o4.w);
-        }
-        tree_fence();
-    }
-    if (act) {
-        // slot: block of the env's noise table (0, 1: base stream; 2..: left dofs; 2 + nblk_dof..: right dofs), item: index within the stream
-        auto noise_u = [&](uint32_t stream, int slot0, int item) -> float {
-            if (noise_lds) return grx_u01(__float_as_uint(TW(TBO(slot0 + (item >> 2) + 1) + T_PA + (item & 3))));
-            return grx_rand(P.seed, genv, step, stream, (uint32_t)item);
-        };
-        // idx: column of the observation; (stream, slot0, item): where its noise uniform comes from
-        auto put = [&](int idx, float val, float nscale, uint32_t stream, int slot0, int item) {
-            pri[idx] = fminf(fmaxf(val, -clipo), clipo);   // pri_obs copies obs BEFORE noise
-            float ov = val;
-            if (P.add_noise && nscale != 0.f) {
-                const float u = noise_in ? noise_in[(size_t)e * nobs + idx] : noise_u(stream, slot0, item);
-                ov += (2.f * u - 1.f) * nscale;
-            }
-            obs[idx] = fminf(fmaxf(ov, -clipo), clipo);
-        };
-        const float np_ = P.noise_dof_pos * P.noise_level * P.obs_scale_dof_pos, nv = P.noise_dof_vel * P.noise_level * P.obs_scale_dof_vel;
-        const float nac = P.noise_action * P.noise_level * P.obs_scale_action;
-        for (int j = c; j < nd; j += TG) {   // the joints go round the group's lanes (as in the reward terms): observations, history, state
-            const size_t oj = (size_t)j * N + e;
-            const float qj = TW(TBO(j + 1) + T_QPUB), qdj = TW(TBO(j + 1) + T_QDPUB), ac = TW(o.dof + TD_ACUR * GRX_MAX_DOFS + j);
-            // dof terms: one stream per half of the dof range, item = group * (nd / 2) + joint within the half (group 0 pos, 1 vel, 2 action)
-            const bool right = j >= half_;
-            const uint32_t ds_ = right ? (uint32_t)GRX_RNG_NOISE_DOF_R : (uint32_t)GRX_RNG_NOISE_DOF_L;
-            const int s0_ = right ? 2 + nblk_dof : 2, jj = right ? j - half_ : j;
-            put(9 + j, (qj - T.dof[j].q0) * P.obs_scale_dof_pos, np_, ds_, s0_, jj);
-            put(9 + nd + j, qdj * P.obs_scale_dof_vel, nv, ds_, s0_, half_ + jj);
-            put(9 + 2 * nd + j, ac * P.obs_scale_action, nac, ds_, s0_, 2 * half_ + jj);
-            P.q[oj] = qj; P.qd[oj] = qdj; P.actions[oj] = ac; P.torques[oj] = TW(TBO(j + 1) + T_TAU);
-            P.last_actions[oj] = ac; P.last_dof_vel[oj] = qdj;   // history (legged_robot.py:299-300, after reset_idx)
-        }
-        if (c < 8) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) P.anchors[(size_t)(c * 3 + k) * N + e] = TW(o.an + c * 3 + k);
-        }
-        if (lead) {
-            put(0, ea.cmd[0], 0.f, 0u, 0, 0); put(1, ea.cmd[1], 0.f, 0u, 0, 0); put(2, ea.cmd[2], 0.f, 0u, 0, 0);
-            const float na = P.noise_ang_vel * P.noise_level * P.obs_scale_ang_vel, ng = P.noise_gravity * P.noise_level * P.obs_scale_gravity;
-            const float bo[6] = {bav.x * P.obs_scale_ang_vel, bav.y * P.obs_scale_ang_vel, bav.z * P.obs_scale_ang_vel,
-                                 pg.x * P.obs_scale_gravity, pg.y * P.obs_scale_gravity, pg.z * P.obs_scale_gravity};
-#pragma unroll
-            for (int i = 0; i < 6; ++i) put(3 + i, bo[i], i < 3 ? na : ng, (uint32_t)GRX_RNG_NOISE, 0, i);   // base stream: item = column - 3
-            pri[nobs + 0] = fminf(fmaxf(blv.x * P.obs_scale_lin_vel, -clipo), clipo);
-            pri[nobs + 1] = fminf(fmaxf(blv.y * P.obs_scale_lin_vel, -clipo), clipo);
-            pri[nobs + 2] = fminf(fmaxf(blv.z * P.obs_scale_lin_vel, -clipo), clipo);
-            pri[nobs + 3] = fminf(fmaxf(bho * P.obs_scale_height, -clipo), clipo);
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                pri[nobs + 4 + f] = (reset ? false : contact[f]) ? 1.f : 0.f;   // feet_contact[env_ids] = 0 (legged_robot_fftai.py:141)
-                pri[nobs + 6 + f] = fminf(fmaxf(feet_height[f] * P.obs_scale_height, -clipo), clipo);
-            }
-            // ---- store the env's state
-            const float rs[13] = {B.pos.x, B.pos.y, B.pos.z, B.qx, B.qy, B.qz, B.qw, B.vel.x, B.vel.y, B.vel.z, B.ang.x, B.ang.y, B.ang.z};
-#pragma unroll
-            for (int i = 0; i < 13; ++i) P.root[(size_t)i * N + e] = rs[i];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                P.air_time[(size_t)f * N + e] = air_time[f] * (contact_filt[f] ? 0.f : 1.f);   // legged_robot_fftai.py:97
-                P.land_time[(size_t)f * N + e] = land_time[f];
-                P.feet_contact[(size_t)f * N + e] = (reset ? false : contact[f]) ? 1 : 0;
-                P.feet_height[(size_t)f * N + e] = feet_height[f];
-                P.avg_force[(size_t)f * N + e] = avg_force[f];
-                const float ff[3] = {foot_force[f].x, foot_force[f].y, foot_force[f].z}, fp[3] = {fpos[f].x, fpos[f].y, fpos[f].z};
-                const float as_[3] = {avg_speed[f].x, avg_speed[f].y, avg_speed[f].z}, ar_[3] = {avg_rpy[f].x, avg_rpy[f].y, avg_rpy[f].z};
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    P.avg_speed_rpy[(size_t)(f * 3 + i) * N + e] = ar_[i];
-                    P.feet_force[(size_t)(f * 3 + i) * N + e] = ff[i];
-                    P.feet_pos[(size_t)(f * 3 + i) * N + e] = fp[i];
-                    P.avg_speed[(size_t)(f * 3 + i) * N + e] = as_[i];
-                }
-            }
-            P.commands[e] = ea.cmd[0]; P.commands[N + e] = ea.cmd[1]; P.commands[2 * N + e] = ea.cmd[2];
-            P.base_lin_vel[e] = blv.x; P.base_lin_vel[N + e] = blv.y; P.base_lin_vel[2 * N + e] = blv.z;
-            P.base_ang_vel[e] = bav.x; P.base_ang_vel[N + e] = bav.y; P.base_ang_vel[2 * N + e] = bav.z;
-            P.proj_grav[e] = pg.x; P.proj_grav[N + e] = pg.y; P.proj_grav[2 * N + e] = pg.z;
-            P.origins[e] = ea.origin[0]; P.origins[N + e] = ea.origin[1]; P.origins[2 * N + e] = ea.origin[2];
-            P.levels[e] = ea.level;
-            P.base_heights_offset[e] = bho;
-            P.ep_len[e] = ep_len;
-            P.rew[e] = rew;
-            P.reset[e] = reported_reset ? 1 : 0;
-            P.time_out[e] = time_out ? 1 : 0;
-            P.term_contact[e] = term_contact ? 1 : 0;
-        }
-    }
-#ifdef GRX_PROFILE_SECTIONS
-    if (threadIdx.x == 0 && blockIdx.x < 64) {   // sections summed over the sub-steps: outward, contacts, base, self-collision, inward, base solve, accel, rest; [8] physics, [9] whole kernel
-        long long* pr = P.prof + (size_t)blockIdx.x * GRX_PROF_SLOTS;
-        for (int i = 0; i < 8; ++i) { pr[i] = tt_acc[i]; pr[20 + i] = tt_acc[8 + i]; }
-        pr[9] = clock64() - tt_begin;
-    }
-#endif
-    __syncthreads();
-    if (threadIdx.x < NSTAT) stat_row(P, sq.seq, threadIdx.x)[grp] = (s_stat[0][threadIdx.x] + s_stat[1][threadIdx.x]) + (s_stat[2][threadIdx.x] + s_stat[3][threadIdx.x]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) P.stat_nblocks[sq.seq & 1] = (int)gridDim.x;
+__global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_tree(GRX_STEP_TREE_ARGS) {
+#include "grx_step_tree_body.inc"
+}
+template <bool DBG = false>   // mesh_type 'trimesh' (grx_kernels.hip terrain_eval / wall_contact)
+__global__ __launch_bounds__(64 * TWAVES_MAX) __attribute__((amdgpu_waves_per_eu(1, 1))) void grx_step_tree_trimesh(GRX_STEP_TREE_ARGS) {
+    constexpr int HF = GRX_HF_TRIMESH;
+#include "grx_step_tree_body.inc"
 }
 #undef TW
 #undef TBO

@@ -7,4 +7,5 @@
 #define GRX_TREE16_TU
 #define GRX_TREE_GDEV 16
 #define grx_step_tree grx_step_tree16   // (a name of its own in the profiles)
+#define grx_step_tree_trimesh grx_step_tree16_trimesh
 #include "grx_kernels.hip"

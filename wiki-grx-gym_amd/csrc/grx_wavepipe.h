@@ -144,7 +144,7 @@ GRX_DEV void add_rigid(S3& A, M3& B, S3& D, const S3& Ak, V3 h, float m) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // wave 0: one sub-step of the state owner
-template <bool HF, bool W8>   // W8: eight waves per block (see the second half of this file): no velocity-product terms, the rigid inertias of
+template <int HF, bool W8>   // W8: eight waves per block (see the second half of this file): no velocity-product terms, the rigid inertias of
                               // bodies 2, 1, 0 and all bias forces from other waves, one poll per group of hand-overs
 GRX_DEV void substep_p(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                        SubstepOut& out, FootKin& fk_before, const PipeLds& L, const RareBuf& RB, int lane, int seq, long long* tacc,
@@ -474,7 +474,7 @@ GRX_DEV V3 sel3(bool c, V3 a, V3 b) { return v3(c ? a.x : b.x, c ? a.y : b.y, c 
 GRX_DEV V3 row0(const M3& B) { return v3(B.a00, B.a01, B.a02); }
 GRX_DEV V3 row1(const M3& B) { return v3(B.a10, B.a11, B.a12); }
 GRX_DEV V3 row2(const M3& B) { return v3(B.a20, B.a21, B.a22); }
-template <bool HF, bool W8>
+template <int HF, bool W8>
 GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState& st, const float tau_m[LEG],
                        SubstepOut& out, FootKin& fk_before, const PipeLds& L, int lane, int seq, long long* tacc, const SideConst& Clds) {
     const float dt = P.sim_dt;
@@ -770,7 +770,7 @@ GRX_DEV void substep_q(KP P, const SideConst& C, const LaneConst& LC, LaneState&
 // `idle(seq)` runs after the hand-over of every sub-step, in the ~2 k cycles this wave then waits for wave 0's next state.
 // OWNPOS (eight waves): positions-only walk of its own for the sphere centres and pair tests; the bodies' velocities (contact damping only)
 // are picked up from wave 2's frames, which are out by the time the centres are staged
-template <bool HF, bool WALK, bool OWNPOS, class Idle>   // WALK: four waves on a heightfield (see above); else the frames come from wave 2
+template <int HF, bool WALK, bool OWNPOS, class Idle>   // WALK: four waves on a heightfield (see above); else the frames come from wave 2
 GRX_DEV void self_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, const float4* footfr, const SelfBuf& SB, float mu_self,
                        const PipeLds& L, int lane, int el, int side, Idle idle) {
     GRX_HELPER_PROF_BEGIN;
@@ -988,7 +988,7 @@ GRX_DEV void chain_bias_loop(KP P, const SideConst& C, const SideConst& Clds, co
 
 // wave 7: the thigh / shank shapes of the seldom-touching set (grx_rare.h), on the frames wave 2 publishes, with a compaction
 // buffer of its own; wave 3 keeps the base-lump shapes, which need the base state only
-template <bool HF>
+template <int HF>
 GRX_DEV void chain_rare_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, float mu, float hmax, const PipeLds& L, int lane, int el, int side) {
     for (int seq = 0; seq < P.decimation; ++seq) {
         flag_wait(L.flag + FL_STATE, seq + 1);
@@ -1136,7 +1136,7 @@ GRX_DEV void base_service_loop(KP P, const SideConst& C, const SideConst& Clds, 
 
 // ---------------------------------------------------------------------------------------------------------------
 // wave 2: own walk with velocities; thigh / shank frames for wave 3; the anchored foot spheres
-template <bool HF, int NBIAS>   // NBIAS: this wave computes the bias forces of the last NBIAS chain bodies (5, 2, or 0: eight waves)
+template <int HF, int NBIAS>   // NBIAS: this wave computes the bias forces of the last NBIAS chain bodies (5, 2, or 0: eight waves)
 GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const SideConst& Clds, const RareBuf& RB, float4* footfr, float mu, float hmax, float om_e, LaneState& hs, const PipeLds& L,
                                 int lane, int el, int side, V3& rpy_acc) {   // rpy_acc: sum of the foot body's |angular velocity| at the START of sub-steps 1.. (avg_feet_speed_rpy)
     const int half = lane_half(lane);
@@ -1215,7 +1215,7 @@ GRX_DEV void chain_contact_loop(KP P, const SideConst& C, const SideConst& Clds,
 }
 
 // wave 3: the seldom-touching shapes -- base lump (torso, head, arms), thigh, shank -- lane-compacted (grx_rare.h)
-template <bool HF, bool W8, bool SPLIT = W8 && GRX_W8_RARESPLIT>   // W8 (eight waves): base-lump shapes only -- thigh / shank shapes on wave 7 (chain_rare_loop), base bias force on wave 5
+template <int HF, bool W8, bool SPLIT = W8 && GRX_W8_RARESPLIT>   // W8 (eight waves): base-lump shapes only -- thigh / shank shapes on wave 7 (chain_rare_loop), base bias force on wave 5
 GRX_DEV void base_contact_loop(KP P, const KTables& T, const SideConst& C, const RareBuf& RB, float mu, float hmax, float base_m, V3 base_c,
                                const S3& base_I, const PipeLds& L, int lane, int el, int side, float* s_tp, LinkPrep& lp, V3 link_rows[11],
                                const float4* footfr, float mu_self) {
