@@ -264,8 +264,9 @@ typedef struct grx_config {
     const int16_t* height_samples; /* HOST pointer, (hf_rows, hf_cols) row-major; copied at create */
     int32_t hf_rows, hf_cols;
     float horizontal_scale, vertical_scale, border_size;
-    int32_t vertical_faces;      /* mesh_type 'trimesh': raster steps steeper than slope_threshold are vertical faces at the HIGH
-                                    vertex (isaacgym terrain_utils.py:286-350 convert_heightfield_to_trimesh, legged_robot.py:903-921) */
+    int32_t vertical_faces;      /* mesh_type 'trimesh': the contact surface is the reference's slope-corrected triangle mesh of the raster (isaacgym
+                                    terrain_utils.py:286-350 convert_heightfield_to_trimesh with slope_threshold, the call of legged_robot.py:903-921) -- a ground
+                                    plane per triangle half of every cell and the mesh's vertical faces as contacts of their own */
     float slope_threshold;       /* legged_robot_config.py:99 (0.75) */
     int32_t curriculum;
     int32_t num_terrain_rows, num_terrain_cols; /* levels, types */
