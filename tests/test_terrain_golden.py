@@ -270,6 +270,37 @@ def test_trimesh_surface_against_the_reference_mesh(name):
         check_trimesh_surface(lambda pts: [ora.terrain(x, y)[0] for x, y in pts], name, tol)
 
 
+def test_trimesh_surface_of_every_tile_family():
+    """The same ray cast over a 3 x 10 curriculum grid that holds EVERY tile family (the grid of test_all_tile_families_and_trimesh_match_reference, which
+    pins this build's mesh conversion to the reference's vertices and triangles): smooth and rough slopes, stairs up and down, discrete obstacles, gap and
+    pit -- the oracle's ground IS the mesh; stepping stones (not in the reference's default terrain_proportions) -- stones one or two cells apart over a
+    5 m drop, where the reference's correction leaves needles and overlapping sheets inside the gaps: the stones' tops are exact, the gaps are not."""
+    from oracle.binding import OracleSim
+    from wiki_grx_gym_amd.envs import build_config
+    tcfg = config.LeggedRobotCfg.terrain()
+    tcfg.mesh_type = "trimesh"
+    tcfg.num_rows, tcfg.num_cols, tcfg.border_size = 3, 10, 5
+    tcfg.terrain_proportions = [0.1, 0.1, 0.2, 0.2, 0.1, 0.1, 0.1, 0.1]
+    ter = Terrain(tcfg, 30, seed=5)
+    v, t = np.asarray(ter.vertices, dtype=np.float64), np.asarray(ter.triangles)
+    cfg = make_cfg(terrain="trimesh")
+    cfg.terrain = tcfg
+    c, keep, _ = build_config.build(cfg, cfg.sim.dt, 30, terrain=ter)
+    ora = OracleSim(c, "f64", keep)
+    hs, b, px = tcfg.horizontal_scale, tcfg.border_size, ter.tile_pixels
+    rng = np.random.default_rng(0)
+    family = ["smooth slope", "rough slope", "stairs", "stairs", "stairs down", "stairs down", "obstacles", "stepping stones", "gap", "pit"]
+    allowed = {"rough slope": (5e-3, 5e-3), "obstacles": (8e-3, 8e-3), "stepping stones": (0.25, 0.06)}       # (fraction off by > 2e-5 m, by > 1 mm); observed 0.0013 / 0.0027 / 0.154, 0.030
+    for col in range(10):
+        pts = np.column_stack([rng.uniform(ter.border + 1, ter.border + 3 * px - 1, 600) * hs, rng.uniform(ter.border + col * px + 1, ter.border + (col + 1) * px - 1, 600) * hs])
+        f = pts / hs - np.floor(pts / hs)
+        pts = pts[(np.minimum(f, 1 - f).min(1) > 1e-4) & (np.abs(f[:, 0] - f[:, 1]) > 1e-4)]
+        near = (v[t[:, 0], 1] > pts[:, 1].min() - 0.5) & (v[t[:, 0], 1] < pts[:, 1].max() + 0.5)
+        dev = np.abs(_mesh_height(v, t[near], pts) - np.array([ora.terrain(x - b, y - b)[0] for x, y in pts]))
+        lim = allowed.get(family[col], (0.0, 0.0))
+        assert (dev > 2e-5).mean() <= lim[0] and (dev > 1e-3).mean() <= lim[1], (col, family[col], (dev > 2e-5).mean(), (dev > 1e-3).mean())
+
+
 @pytest.mark.parametrize("name", ["stairs", "obstacles"])
 def test_trimesh_vertical_faces_against_the_reference_mesh(name):
     """The second half of the corrected mesh: its vertical faces as contacts (VERDICT r5 missing #2).  A sphere against the oracle's per-cell

@@ -10,7 +10,9 @@ bash tools/collect_pmc.sh $tag rough16384 --envs-per-gpu 16384 --steps 200 --war
 bash tools/collect_pmc.sh $tag rough32768 --envs-per-gpu 32768 --steps 150 --warmup 20
 bash tools/collect_pmc.sh $tag full_body_rough4096 --robot full_body --envs-per-gpu 4096 --steps 150 --warmup 20
 bash tools/collect_pmc.sh $tag full_body_rough16384 --robot full_body --envs-per-gpu 16384 --steps 80 --warmup 10
-for w in rough4096:10141696 rough8192:20283392 rough16384:40566784 rough32768:81133568 full_body_rough4096:16990208 full_body_rough16384:67960832; do
+bash tools/collect_pmc.sh $tag trimesh4096 --terrain trimesh --steps 400 --warmup 50      # the same raster as the reference's corrected triangle mesh
+bash tools/collect_pmc.sh $tag trimesh8192 --terrain trimesh --envs-per-gpu 8192 --steps 300 --warmup 40
+for w in rough4096:10141696 rough8192:20283392 rough16384:40566784 rough32768:81133568 full_body_rough4096:16990208 full_body_rough16384:67960832 trimesh4096:10141696 trimesh8192:20283392; do
     python tools/summarise_pmc.py $tag ${w%%:*} ${w##*:} > /dev/null   # profiles/r05_pmc_{hbm,sq}_<workload>.json: what the bench lines below read
 done
 mkdir -p $out/pmc_json; cp profiles/${tag}_pmc_*.json $out/pmc_json/
@@ -28,6 +30,8 @@ done
 for n in 4096 16384; do
     timeout 600 python bench.py --robot full_body --envs-per-gpu $n --no-cpu-baseline --train-iters 0 2>> $out/full_body.err | tail -1 > $out/bench_full_body_rough$n.json
 done
+timeout 300 python bench.py --terrain trimesh --no-cpu-baseline --train-iters 0 2>/dev/null | tail -1 > $out/bench_trimesh.json
+timeout 300 python bench.py --terrain trimesh --envs-per-gpu 8192 --steps 4000 --warmup 400 --no-cpu-baseline --train-iters 0 2>/dev/null | tail -1 > $out/bench_trimesh8192.json
 # kernel stats (rocprofv3 --kernel-trace --stats) of the same commands as the bench lines
 stats() {   # name, bench args
     local d=$out/stats_$1; shift
@@ -40,9 +44,11 @@ stats rough16384 --envs-per-gpu 16384 --steps 2000 --warmup 200
 stats rough32768 --envs-per-gpu 32768 --steps 1500 --warmup 150
 stats full_body_rough4096 --robot full_body --envs-per-gpu 4096 --steps 600 --warmup 60
 stats full_body_rough16384 --robot full_body --envs-per-gpu 16384 --steps 300 --warmup 30
+stats trimesh4096 --terrain trimesh
+stats trimesh8192 --terrain trimesh --envs-per-gpu 8192 --steps 4000 --warmup 400
 python -c "
 import json
-for f in ('bench_rough','bench_flat','bench_driver_window','bench_rough_every_step','bench_full_body_rough4096','bench_full_body_rough16384'):
+for f in ('bench_rough','bench_flat','bench_driver_window','bench_rough_every_step','bench_full_body_rough4096','bench_full_body_rough16384','bench_trimesh','bench_trimesh8192'):
     try:
         j=json.load(open('$out/'+f+'.json')); print(f, round(j['value']/1e6,2), 'M', round(j['roofline']['kernel_ms']*1e3,2), 'us', j['config']['layout']['kernel'], (j.get('full_iteration') or {}).get('env_steps_per_s'))
     except Exception as e: print(f, 'bad', e)

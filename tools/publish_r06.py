@@ -5,7 +5,8 @@ pairs = {"bench_rough.json": "r06_bench_n1_rough4096.json", "bench_rough_runs.js
          "bench_driver_window.json": "r06_bench_n1_rough4096_driver_window.json", "bench_flat.json": "r06_bench_n1_flat4096.json",
          "bench_rough_every_step.json": "r06_bench_n1_rough4096_every_step.json", "sweep.jsonl": "r06_bench_n1_rough_sweep.jsonl",
          "bench_full_body_rough4096.json": "r06_bench_n1_full_body_rough4096.json", "bench_full_body_rough16384.json": "r06_bench_n1_full_body_rough16384.json",
-         "bench_gr1t2_rough4096.json": "r06_bench_n1_gr1t2_rough4096.json"}
+         "bench_gr1t2_rough4096.json": "r06_bench_n1_gr1t2_rough4096.json",
+         "bench_trimesh.json": "r06_bench_n1_trimesh4096.json", "bench_trimesh8192.json": "r06_bench_n1_trimesh8192.json"}
 for a, b in pairs.items():
     shutil.copy(os.path.join(src, a), os.path.join(dst, b))
 for d in glob.glob(src + "/stats_*/"):
