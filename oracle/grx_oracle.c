@@ -388,6 +388,11 @@ static void trimesh_build(struct grx_sim* s) {
             int16_t* e = s->tm_cells + 6 * ((size_t)i * C + j);
             e[0] = e[3] = H[(size_t)i * C + j]; e[1] = H[(size_t)i * C + j1]; e[4] = H[(size_t)i1 * C + j]; e[2] = e[5] = H[(size_t)i1 * C + j1];
             if (i > R - 2 || j > C - 2) continue;
+            int touched = 0;   /* a vertex of the 3 x 3 cells around this one was moved: else the cell is its own two triangles */
+            for (int a = (i > 0 ? i - 1 : 0); a <= (i + 2 < R ? i + 2 : R - 1) && !touched; ++a)
+                for (int b = (j > 0 ? j - 1 : 0); b <= (j + 2 < C ? j + 2 : C - 1); ++b)
+                    if (mv[2 * ((size_t)a * C + b)] | mv[2 * ((size_t)a * C + b) + 1]) { touched = 1; break; }
+            if (!touched) continue;
             double p[3];
             const double x1 = i + 1.0 / 3, y1 = j + 2.0 / 3, x2 = i + 2.0 / 3, y2 = j + 1.0 / 3;   /* centroids of the halves ty >= tx, tx > ty */
 #define TM_AT(px, py, cx, cy) tm_round(p[0] + p[1] * ((cx) - (px)) + p[2] * ((cy) - (py)))
@@ -407,7 +412,7 @@ static void trimesh_build(struct grx_sim* s) {
                 tmv_t t[3];
                 tm_triangle(H, mv, C, a, b, k, t);
                 const double den = (t[1].x - t[0].x) * (t[2].y - t[0].y) - (t[2].x - t[0].x) * (t[1].y - t[0].y);
-                if (fabs(den) > 1e-9) continue;
+                if (fabs(den) > 1e-9) continue;   /* (an undeformed triangle: den = -1) */
                 if (fmax(t[0].z, fmax(t[1].z, t[2].z)) <= fmin(t[0].z, fmin(t[1].z, t[2].z))) continue;
                 const int along_y = t[0].x == t[1].x && t[0].x == t[2].x, along_x = t[0].y == t[1].y && t[0].y == t[2].y;
                 if (along_y == along_x) continue;   /* a needle, or a face across the grid (not produced by axis-aligned steps) */

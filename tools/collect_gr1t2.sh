@@ -6,6 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 tag=r06; wl=gr1t2_rough4096; out=gpurun_out/$tag; mkdir -p $out
 bash tools/collect_pmc.sh $tag $wl --robot gr1t2 --steps 400 --warmup 50
 python tools/summarise_pmc.py $tag $wl 10141696
+find $out/pmc/$wl -name '*counter_collection.csv' -delete
 d=$out/stats_$wl
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$d -o b -- bash -c "cd $OLDPWD && python bench.py --robot gr1t2 --no-cpu-baseline --train-iters 0 > /dev/null" > $OLDPWD/$d.log 2>&1)
 find $d -name "*kernel_trace.csv" -delete

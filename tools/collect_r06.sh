@@ -16,6 +16,7 @@ for w in rough4096:10141696 rough8192:20283392 rough16384:40566784 rough32768:81
     python tools/summarise_pmc.py $tag ${w%%:*} ${w##*:} > /dev/null   # profiles/r05_pmc_{hbm,sq}_<workload>.json: what the bench lines below read
 done
 mkdir -p $out/pmc_json; cp profiles/${tag}_pmc_*.json $out/pmc_json/
+find $out/pmc -name '*counter_collection.csv' -delete   # (the raw per-dispatch rows: summarised above; gpurun merges at most 64 MiB back)
 # headline: three runs of the driver's default command, flat, the layouts, the sweep
 timeout 600 python bench.py 2> $out/bench_rough.err | tail -1 > $out/bench_rough.json
 cp $out/bench_rough.json $out/bench_rough_runs.jsonl

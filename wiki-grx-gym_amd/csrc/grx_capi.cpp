@@ -493,6 +493,10 @@ TrimeshTables build_trimesh_tables(const grx_config& c) {
             int16_t* e = &out.ground[6 * ((size_t)i * C + j)];
             e[0] = e[3] = (int16_t)at(i, j); e[1] = (int16_t)at(i, j1); e[4] = (int16_t)at(i1, j); e[2] = e[5] = (int16_t)at(i1, j1);
             if (i > R - 2 || j > C - 2) continue;
+            bool touched = false;   // only a moved vertex within the 3 x 3 cells around this one can change what lies over it
+            for (int a = std::max(i - 1, 0); a <= std::min(i + 2, R - 1) && !touched; ++a)
+                for (int b = std::max(j - 1, 0); b <= std::min(j + 2, C - 1) && !touched; ++b) touched = mx[(size_t)a * C + b] != 0 || my[(size_t)a * C + b] != 0;
+            if (!touched) continue;
             for (int half = 0; half < 2; ++half) {
                 const double px = i + (half ? 2.0 : 1.0) / 3, py = j + (half ? 1.0 : 2.0) / 3;   // the half's centroid
                 double pl[3];
