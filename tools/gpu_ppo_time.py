@@ -1,6 +1,8 @@
 """Time PPO.update() (4096 envs x 64 steps, the GR1T1 train config) eager-device path vs HIP-graph path."""
 import sys, os, time; sys.path.insert(0, ".")
 import torch
+if os.environ.get("GRX_PPO_BLAS"):   # 'hipblaslt' / 'hipblas' (tools/r06_ppo_blas.sh)
+    torch.backends.cuda.preferred_blas_library(os.environ["GRX_PPO_BLAS"])
 from wiki_grx_gym_amd.rl.modules import ActorCriticMLP
 from wiki_grx_gym_amd.rl.ppo import PPO
 if os.environ.get("GRX_PPO_FORCE_BUCKET") == "1":   # the multi-rank update on a one-rank RCCL group
