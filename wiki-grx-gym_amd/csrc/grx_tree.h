@@ -236,6 +236,9 @@ struct TreeChain {
     int first, last;   // the chain's run of levels (first > last: no chain)
     int hangp;         // the body the chain hangs from (0: the base)
     uint32_t hcmask;   // bit g: the chain's body of level g carries hanging chains
+    uint32_t hlev, hlane;   // ... which ones: up to eight (level + 1, lane of the hanging chain) pairs, a nibble each, in the order the inward pass adds them up
+                            // (level order, then the body's table order); nibble 0 of hlev: no more.  The inward pass used to ask the body table for them: two
+                            // dependent LDS round trips per hanging chain at the torso's level
 };
 
 // pass 1 (root -> leaves) over the depth levels: frames and velocities into LDS; KIN: nothing else (the state after the last sub-step).
@@ -481,15 +484,17 @@ GRX_DEV void tree_inward(KP P, const TreeTab& T, float* wsw, int ei, int c, cons
         if (g > 0) nx = tree_in_fetch(T, wsw, ei, max(G.sb[g > 0 ? g - 1 : 0], 1));
         if (G.sb[g] >= 0) {
             const int b = G.sb[g];
-            const TreeBody& tb = T.body[b];
             const int wb = TBO(b);
             const V3 rho = in.rho;
             float t = in.t;
             const float arm = in.arm, qlo = in.qlo, qhi = in.qhi, Klim = in.Klim, Clim = in.Clim;
             pa = pa + in.pab; pl = pl + in.plb;
             add_rigid(A, Bm, D, in.Ar, in.hk, in.mass);
-            if (CH.hcmask & (1u << g))   // chains that hang from this body, fixed order
-                for (int k = 0; k < tb.nhc; ++k) tree_add_up(wsw, ei, o.up + tb.hc[k] * T_UPW, A, Bm, D, pa, pl);
+            if (CH.hcmask & (1u << g)) {   // chains that hang from this body, fixed order
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((int)((CH.hlev >> (4 * k)) & 15u) == g + 1) tree_add_up(wsw, ei, o.up + (int)((CH.hlane >> (4 * k)) & 15u) * T_UPW, A, Bm, D, pa, pl);
+            }
             const V3 a = G.Sa[g], s = cross(rho, a);
             const V3 ua = mul(A, a) + mul(Bm, s);
             const V3 ul = mulT(Bm, a) + mul(D, s);
