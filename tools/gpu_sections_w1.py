@@ -28,7 +28,9 @@ for terrain in ("plane", "heightfield"):
     full = np.array(buf[:], dtype=np.int64).reshape(nbmax, 96)[:nb]
     a = full[:, :11]
     d = np.diff(a, axis=1)
-    print(terrain, "blocks", nb, "total cycles median", np.median(a[:, 10] - a[:, 0]))
+    tot = a[:, 10] - a[:, 0]
+    print(terrain, "blocks", nb, "total cycles median", np.median(tot), "| 5 / 95 / 99 % and max of the blocks:", [int(x) for x in np.percentile(tot, [5, 95, 99, 100])],
+          "| first start to last end over the launch:", int(a[:, 10].max() - a[:, 0].min()), "| spread of the starts:", int(a[:, 0].max() - a[:, 0].min()))
     for n, v in zip(names, np.median(d, axis=0)): print(f"   {n:16s} {v:9.0f} ticks")
     print("   sub-step sections, sum over the 10 sub-steps:")
     for n, v in zip(sub, np.median(full[:, 16:22], axis=0)): print(f"      {n:34s} {v:9.0f} ticks")
