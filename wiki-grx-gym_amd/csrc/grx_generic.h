@@ -401,10 +401,12 @@ template <bool HF>
 __global__ __launch_bounds__(64) void grx_step_generic(GRX_STEP_GENERIC_ARGS) {
 #include "grx_step_generic_body.inc"
 }
+#ifndef GRX_TREE16_TU   // (not a template: it would be emitted in grx_tree16.hip's object too, which launches none of the generic kernels)
 __global__ __launch_bounds__(64) void grx_step_generic_trimesh(GRX_STEP_GENERIC_ARGS) {   // mesh_type 'trimesh'
     constexpr int HF = GRX_HF_TRIMESH;
 #include "grx_step_generic_body.inc"
 }
+#endif
 
 // BaseTask.reset() first half for the generic path
 // mask: as in grx_reset_all_kernel (nullptr = every env, else reset_idx of the flagged ones)
