@@ -496,6 +496,12 @@ int grx_debug_terrain(grx_handle h, const float* xy, int32_t n, float* out, void
  * vertical triangles. */
 int grx_debug_wall(grx_handle h, const float* xyzr, int32_t n, float* out, void* stream);
 
+/* TEST-ONLY, host only (needs no device): the two per-cell tables grx_create derives from the raster for mesh_type 'trimesh' -- the reference's slope-corrected
+ * mesh as ground corner heights per triangle half (ground: int16[hf_rows * hf_cols][6] = (e00, e01, e11) where ty >= tx, (e00, e10, e11) where tx > ty) and
+ * the tops of its vertical faces on a cell's sides x-, x+, y-, y+ and at its corners 00, 10, 01, 11 (walls: int16[hf_rows * hf_cols][8], INT16_MIN = none);
+ * DESIGN.md 3.  The oracle's twin is gro_debug_trimesh_tables. */
+int grx_debug_trimesh_tables(const grx_config* cfg, int16_t* ground, int16_t* walls);
+
 /* TEST-ONLY: the wave pipelines of the step kernels hand over through LDS flags and spin on them.  A library built
  * with -DGRX_SPIN_LIMIT (csrc/variants/libgrx_spinlimit.so) bounds every spin; an expired one stores 'SP' << 48 | block << 32 | LDS
  * address of the flag << 16 | value waited for in a host-pinned word and traps.  *code = that word (0: none expired; readable after

@@ -46,6 +46,7 @@ def load(precision="f32"):
         lib.gro_debug_link_forces.argtypes = [H, C.c_int, dp, C.c_int]
         lib.gro_debug_terrain.argtypes = [H, C.c_double, C.c_double, dp]
         lib.gro_debug_wall.argtypes = [H, C.c_double, C.c_double, C.c_double, C.c_double, dp]
+        lib.gro_debug_trimesh_tables.argtypes = [H, C.POINTER(C.c_int16), C.POINTER(C.c_int16)]
         lib.gro_debug_import_state.argtypes = [H]
         _libs[precision] = (lib, api)
     return _libs[precision]
@@ -110,6 +111,12 @@ class OracleSim(SimHandle):
         o, op = self._d(np.zeros(4))
         self._check(self.lib.gro_debug_wall(self._h, float(x), float(y), float(z), float(r), op), "wall")
         return o.copy()
+
+    def trimesh_tables(self, rows, cols):
+        """mesh_type 'trimesh': (ground int16 [rows * cols, 6], walls int16 [rows * cols, 8]) as trimesh_build made them"""
+        g, w = np.zeros((rows * cols, 6), np.int16), np.zeros((rows * cols, 8), np.int16)
+        self._check(self.lib.gro_debug_trimesh_tables(self._h, g.ctypes.data_as(C.POINTER(C.c_int16)), w.ctypes.data_as(C.POINTER(C.c_int16))), "trimesh_tables")
+        return g, w
 
     def import_state(self):
         """Continue from the state written into the published views (tests.helpers.STATE_TENSORS): gro_debug_import_state."""

@@ -1945,6 +1945,15 @@ int gro_debug_terrain(grx_handle s, double x, double y, double* out) {
     return GRX_OK;
 }
 
+/* mesh_type 'trimesh': the per-cell tables of trimesh_build -- ground int16[rows * cols][6], walls int16[rows * cols][8] */
+int gro_debug_trimesh_tables(grx_handle s, int16_t* ground, int16_t* walls) {
+    if (!s || !s->tm_cells || !s->tm_walls) return fail(GRX_ERR_INVALID_ARGUMENT, "gro_debug_trimesh_tables: not a trimesh handle");
+    const size_t n = (size_t)s->cfg.hf_rows * s->cfg.hf_cols;
+    memcpy(ground, s->tm_cells, 6 * n * sizeof(int16_t));
+    memcpy(walls, s->tm_walls, 8 * n * sizeof(int16_t));
+    return GRX_OK;
+}
+
 /* mesh_type 'trimesh': overlap of a sphere (centre x y z, radius r) with the vertical faces next to it: out = {overlap, nx, ny, nz} (0 0 0 0: none) */
 int gro_debug_wall(grx_handle s, double x, double y, double z, double r, double* out) {
     real n[3] = {0, 0, 0}, c[3] = {(real)x, (real)y, (real)z};

@@ -218,6 +218,8 @@ def bind(lib, prefix="grx_"):
         api["debug_terrain"] = fn("debug_terrain", C.c_int, H, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.c_void_p)
     if hasattr(lib, prefix + "debug_wall") and prefix == "grx_":
         api["debug_wall"] = fn("debug_wall", C.c_int, H, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_float), C.c_void_p)
+    if hasattr(lib, prefix + "debug_trimesh_tables") and prefix == "grx_":
+        api["debug_trimesh_tables"] = fn("debug_trimesh_tables", C.c_int, C.POINTER(Config), C.POINTER(C.c_int16), C.POINTER(C.c_int16))
     if hasattr(lib, prefix + "sizeof"):
         api["sizeof"] = fn("sizeof", C.c_int, C.c_int)
     if hasattr(lib, prefix + "kernel_time_ms"):
@@ -228,7 +230,7 @@ def bind(lib, prefix="grx_"):
 EXPORTED_SYMBOLS = (
     "grx_create", "grx_destroy", "grx_reset_all", "grx_step", "grx_tensor", "grx_set_state",
     "grx_episode_stats", "grx_flush_stats", "grx_reset_idx", "grx_set_state_indexed", "grx_kernel_time_ms", "grx_wait_idle", "grx_last_error", "grx_abi_version",
-    "grx_reward_term_name", "grx_debug_post_physics", "grx_layout", "grx_stats_seq", "grx_debug_spin_report", "grx_sizeof", "grx_refresh", "grx_debug_terrain", "grx_debug_wall",
+    "grx_reward_term_name", "grx_debug_post_physics", "grx_layout", "grx_stats_seq", "grx_debug_spin_report", "grx_sizeof", "grx_refresh", "grx_debug_terrain", "grx_debug_wall", "grx_debug_trimesh_tables",
 )
 # grx_struct_id (include/grx.h): grx_sizeof(id) must equal ctypes.sizeof of the mirror -- checked once per process by sim.load_hip_library
 STRUCT_IDS = {"CONFIG": (0, Config), "STEP_ARGS": (1, StepArgs), "TENSOR_DESC": (2, TensorDesc), "PIPELINE_STATE": (3, PipelineState),

@@ -1700,6 +1700,18 @@ int grx_debug_terrain(grx_handle s, const float* xy, int32_t n, float* out, void
     return GRX_OK;
 }
 
+// TEST-ONLY, host only (no device needed): the per-cell tables grx_create builds for mesh_type 'trimesh' (build_trimesh_tables) -- ground int16[rows * cols][6],
+// walls int16[rows * cols][8] (include/grx.h); the CPU test tier compares them with the oracle's own (gro_debug_trimesh_tables)
+int grx_debug_trimesh_tables(const grx_config* cfg, int16_t* ground, int16_t* walls) {
+    if (!cfg || !ground || !walls) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_trimesh_tables: null argument");
+    if (cfg->terrain_type != GRX_TERRAIN_HEIGHTFIELD || !cfg->height_samples || cfg->hf_rows < 2 || cfg->hf_cols < 2)
+        return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_trimesh_tables: a heightfield raster is needed");
+    const TrimeshTables tm = build_trimesh_tables(*cfg);
+    memcpy(ground, tm.ground.data(), tm.ground.size() * sizeof(int16_t));
+    memcpy(walls, tm.walls.data(), tm.walls.size() * sizeof(int16_t));
+    return GRX_OK;
+}
+
 // TEST-ONLY: mesh_type 'trimesh', spheres at rest (x, y, z, r) against the vertical faces next to them -> host (overlap * unit direction) each (include/grx.h)
 int grx_debug_wall(grx_handle s, const float* xyzr, int32_t n, float* out, void* stream) {
     if (!s || (n > 0 && (!xyzr || !out))) return fail(GRX_ERR_INVALID_ARGUMENT, "grx_debug_wall: null argument");
